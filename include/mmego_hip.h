@@ -1,0 +1,148 @@
+/* mmego_hip.h -- C ABI of libmmego_hip.so: the MI355X (gfx950) kernels behind the mmEgo hot path.
+ *
+ * The reference (yenanjing/mmEgo) has no FFI of its own: its boundary is the Python nn.Module
+ * interface (Net/IMU_Net.py, Net/Upper_Net.py, Net/Lower_Net.py, Net/GCN.py) and the train_once bodies
+ * of Processor/Train/Train_*.py.  This library sits one level below that boundary; each entry point
+ * names the chain of aten ops of the reference it replaces.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (the library never allocates or frees);
+ *  - `stream` is a hipStream_t (pass the stream the caller's tensors are ordered on); all calls are
+ *    asynchronous and capturable into a HIP graph (no allocation, no synchronisation inside);
+ *  - tensors are fp32, row-major "rows x channels" (channels-last); `ld*` / `s*` are ELEMENT strides;
+ *  - return value: 0 = ok, -1 = bad argument, >0 = hipError_t of the failed launch;
+ *  - re-entrant per stream; workspaces are passed in by the caller.
+ */
+#ifndef MMEGO_HIP_H
+#define MMEGO_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- dense products (gemm.hip) ---------------------------------------------------------------
+ * C[b](m,n) (+)= sum_k A[b](m,k) * B[b](k,n) (+ bias[n]) (relu).  A(m,k) = A[m*sam + k*sak + b*sAb],
+ * B(k,n) = B[k*sbk + n*sbn + b*sBb], C(m,n) = C[m*scm + n*scn + b*sCb].  nsplit > 1 splits K into slabs
+ * in `splitk_ws` (nsplit*nbatch*M*N floats) that are then summed in a fixed order (deterministic).
+ * Replaces: nn.Linear / Conv1d(k=1) / Conv2d(1x1, 9x1) / Conv3d forward and their weight/input
+ * gradients -- Net/Upper_Net.py:242-301,343-364, Net/Lower_Net.py:40-72,95-123, Net/GCN.py:46-60,
+ * and the LSTM input projections of Net/IMU_Net.py:58-62. */
+int mmego_gemm(void* stream, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
+               long scm, long scn, const float* bias, int M, int N, int K, int nbatch, long sAb, long sBb, long sCb,
+               int relu, int accumulate, float* splitk_ws, int nsplit);
+
+/* ---- BatchNorm and row-wise helpers (bn.hip) ----------------------------------------------------
+ * Train-mode statistics of X[rows, C] (+ running-stat update with torch semantics: momentum, unbiased
+ * running var) -> mean, invstd, a = gamma*invstd, b = beta, so that y = (x-mean)*a + b.
+ * partial_ws: 3*C*mmego_colstats_nblk(rows) floats.   Replaces native_batch_norm (train) of
+ * Upper_Net.py:253-255,282-284, Lower_Net.py:51-53, GCN.py:106,117,136,310. */
+int mmego_colstats_nblk(long rows);
+int mmego_bn_train_stats(void* stream, const float* X, long ldx, long rows, int C, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         float* partial_ws, float* mean, float* invstd, float* a, float* b);
+/* Eval mode: the same four vectors from the running statistics. */
+int mmego_bn_eval_affine(void* stream, int C, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, float* mean, float* invstd, float* a, float* b);
+/* Y = act((X1-m1)*a1+b1 [+ (X2-m2)*a2+b2]) -- BN apply + ReLU, and the st_gcn "tcn(x)+residual" join
+ * (GCN.py:140-147). */
+int mmego_affine_act(void* stream, const float* X1, long ld1, const float* m1, const float* a1, const float* b1,
+                     const float* X2, long ld2, const float* m2, const float* a2, const float* b2, float* Y, long ldy,
+                     long rows, int C, int relu);
+/* Y[:, :C] (+)= X[:, :C] with row strides: the torch.cat pieces of Upper_Net.py:266, Lower_Net.py:70,111,119. */
+int mmego_copy2d(void* stream, const float* X, long ldx, float* Y, long ldy, long rows, int C, int accumulate);
+/* BatchNorm (train) backward through an optional ReLU mask (Ymask > 0): dgamma, dbeta, dX.
+ * partial_ws: 2*C*nblk floats, c12_ws: 2*C floats. */
+int mmego_bn_backward(void* stream, const float* dY, long lddy, const float* Ymask, long ldm, const float* X, long ldx,
+                      const float* mean, const float* invstd, const float* a, long rows, int C, float* partial_ws,
+                      float* c12_ws, float* dgamma, float* dbeta, float* dX, long lddx);
+/* out[c] (+)= sum_r X[r,c]: bias gradients.  partial_ws: C*nblk floats. */
+int mmego_colsum(void* stream, const float* X, long ldx, long rows, int C, float* partial_ws, float* out, int accumulate);
+/* G = 0 where H <= 0 (ReLU backward for Linear+ReLU pairs, Upper_Net.py:350-351). */
+int mmego_relu_mask(void* stream, float* G, long ldg, const float* H, long ldh, long rows, int C);
+int mmego_fill(void* stream, float* X, long n, float v);
+
+/* ---- LSTM (lstm.hip) ------------------------------------------------------------------------------
+ * One timestep of a (bi)LSTM, any H % 32 == 0: gates = xproj + hprev . W_hh^T, fused cell update, c in
+ * place.  Replaces the recurrent half of nn.LSTM for IMU_Net (Net/IMU_Net.py:58-62,77,82); xproj is the
+ * input projection (incl. b_ih + b_hh) produced by mmego_gemm.  Row strides: hps, xs, hos. */
+int mmego_lstm_step(void* stream, int ndir, int Bn, int H, const float* hprev0, const float* hprev1, long hps,
+                    const float* whh0, const float* whh1, const float* xproj0, const float* xproj1, long xs,
+                    float* hout0, float* hout1, long hos, float* c0, float* c1);
+/* Whole-sequence H=64 bidirectional LSTM layer (Upper_Net.py:333, Lower_Net.py:91, Upper_Net.py:210).
+ * xproj_d rows are (b*T+t) with row stride xs; out rows (b*T+t) with row stride os, direction d in
+ * columns [64d, 64d+64).  Optional stashes for backward: gates_d [T][B][256], cst_d [T][B][64],
+ * hprev_d [(b*T+t)][64]. */
+int mmego_lstm64_forward(void* stream, int B, int T, const float* xproj0, const float* xproj1, long xs,
+                         const float* whh0, const float* whh1, const float* h0_0, const float* h0_1, const float* c0_0,
+                         const float* c0_1, float* out, long os, float* hn0, float* hn1, float* cn0, float* cn1,
+                         float* gates0, float* gates1, float* cst0, float* cst1, float* hprev0, float* hprev1);
+/* Backward through time of the same layer: dgates_d rows (b*T+t), row stride dgs (pre-activation
+ * gradients; weight/input gradients follow as mmego_gemm products). */
+int mmego_lstm64_backward(void* stream, int B, int T, const float* dout, long dos, const float* gates0,
+                          const float* gates1, const float* cst0, const float* cst1, const float* c0_0,
+                          const float* c0_1, const float* whh0, const float* whh1, float* dgates0, float* dgates1,
+                          long dgs);
+
+/* ---- geometry, heads, loss, selection (geom.hip) --------------------------------------------------
+ * In-place xyz <- R (xyz - t) per frame (Utils.py:284-292, quirk Q1: the caller's buffer is mutated). */
+int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t);
+/* out = R^T in + t (transpose=1, add_t=1: Utils.py:274-281) or out = R in (its backward). */
+int mmego_rotate_points(void* stream, const float* in, float* out, long F, int P, const float* R, const float* t,
+                        int transpose, int add_t);
+/* which=0: y[F,87] -> q[F,14,3,3], joints[F,15,3] (Upper_Net.py:122-144,354-364);
+ * which=1: y[F,42] -> q[F,6,3,3], joints[F,8,3] (Lower_Net.py:12-37,125-136).  body [B,20,3]; frame n
+ * uses body row n % B (quirk Q2).  Joints are in the head frame. */
+int mmego_head_fk_forward(void* stream, int which, const float* y, const float* body, int B, long F, float* q,
+                          float* joints);
+int mmego_head_fk_backward(void* stream, int which, const float* y, const float* body, int B, long F, const float* dj,
+                           float* dy);
+/* y[F,9] -> R[F,3,3] (eps rule of IMU_Net.py:7-18), t[F,3]. */
+int mmego_imu_head(void* stream, const float* y, long F, float* R, float* t);
+/* loss = sum |pred - target[:, map]|, grad = scale*sign(.) (L1Loss(reduction='sum'), Train_Upper.py:53,179). */
+int mmego_l1_loss(void* stream, const float* pred, const float* target, const int* map, int nsel, int ntgt, long F,
+                  float scale, float* loss, float* grad);
+/* Keep the `keep` rows with the largest column-0 key, descending, ties lowest index first; idx is int64
+ * (Lower_Net.py:216-227). */
+int mmego_topk_rows(void* stream, const float* pts, long F, int N, int C, int keep, float* out, long long* idx);
+
+/* ---- pooling / attention / graph (pool.hip) -------------------------------------------------------
+ * Softmax-attention pooling over the P points of each of G groups (Upper_Net.py:285-301,163-177,
+ * IMU_Net.py:79-80). */
+int mmego_attn_pool_forward(void* stream, const float* X, const float* w, const float* b, long G, int P, int C,
+                            float* vec, float* attn);
+int mmego_attn_pool_backward(void* stream, const float* X, const float* w, const float* attn, const float* dvec, long G,
+                             int P, int C, float* dX, float* pdw, float* pdb);
+/* Y[g,:] = scale * sum_p X[g,p,:] and its broadcast backward (Lower_Net.py:112-115). */
+int mmego_group_sum(void* stream, const float* X, long G, int P, int C, float scale, float* Y, long ldy);
+int mmego_group_bcast(void* stream, const float* dY, long lddy, long G, int P, int C, float scale, float* dX,
+                      int accumulate);
+/* softmax(Q K^T * scale) V, 64 queries x 15 keys x 64 channels per frame (Lower_Net.py:105-109). */
+int mmego_cross_attn_forward(void* stream, const float* Q, const float* K, const float* V, long F, float scale, float* O,
+                             long ldo, float* P);
+int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, const float* V, const float* P,
+                              const float* dO, long lddo, long F, float scale, float* dQ, float* dK, float* dV);
+/* Gradient of einsum('nkctv,kvw->nctw') wrt A (GCN.py:62); the forward and dZ are mmego_gemm batches. */
+int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* dA);
+/* Temporal 9x1 unfold / fold of a channels-last (B,T,V,C) tensor (GCN.py:109-116). */
+int mmego_im2col_t(void* stream, const float* X, int B, int T, int V, int C, int taps, float* col);
+int mmego_col2im_t(void* stream, const float* dcol, int B, int T, int V, int C, int taps, float* dX);
+/* out[b][c][r] = in[b][r][c]: the (B,64,T,V)->(B,T,V,64) re-view of GCN.py:351-353 (quirk Q8). */
+int mmego_transpose_batched(void* stream, const float* in, float* out, long Bn, int R, int C);
+int mmego_mul(void* stream, const float* a, const float* b, float* out, long n);
+int mmego_add(void* stream, const float* a, const float* b, float* out, long n);
+/* x[i] += 1 for the BatchNorm num_batches_tracked counters (one launch for all layers of a net). */
+int mmego_inc_i64(void* stream, long long* x, long n);
+
+/* ---- optimiser (optim.hip) -------------------------------------------------------------------------
+ * torch.optim.Adam step (coupled L2 weight decay) over one flat buffer; state = 3 doubles on the device
+ * {step, lr/(1-b1^t), sqrt(1-b2^t)}, advanced by the call itself so a captured graph replays correctly
+ * (Train_Upper.py:60,182; Train_IMU.py:71-72). */
+int mmego_adam_step(void* stream, float* p, const float* g, float* m, float* v, long n, double* state, double lr,
+                    double beta1, double beta2, double eps, double weight_decay);
+/* Inverted dropout with a device-side seed counter (nn.LSTM(dropout=0.1) inter-layer dropout). */
+int mmego_dropout(void* stream, const float* X, float* Y, float* mask, long n, float p, unsigned long long* seed_ctr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

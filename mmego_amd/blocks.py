@@ -1,0 +1,219 @@
+"""Forward/backward building blocks of the nets, as sequences of HIP kernel launches.
+
+Each block keeps what its backward needs in the per-net Arena under a string key.  `G(p)` maps a
+parameter to its slot in the flat gradient buffer.  No torch compute ops are used here.
+"""
+import torch
+import torch.nn as nn
+
+from . import hip, ops
+
+
+class LstmParams(nn.Module):
+    """Parameter container with nn.LSTM's names, shapes, registration order and init (uniform +-1/sqrt(H)),
+    so state_dicts and seeded initial weights are interchangeable with torch's nn.LSTM
+    (reference Net/Upper_Net.py:333, Net/Lower_Net.py:91, Net/IMU_Net.py:58-62).  Gate order i,f,g,o."""
+
+    def __init__(self, input_size, hidden_size, num_layers, dropout=0.0, bidirectional=True):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.dropout = float(dropout)
+        self.num_directions = 2 if bidirectional else 1
+        H = hidden_size
+        for layer in range(num_layers):
+            for d in range(self.num_directions):
+                sfx = "_reverse" if d == 1 else ""
+                In = input_size if layer == 0 else H * self.num_directions
+                self.register_parameter("weight_ih_l%d%s" % (layer, sfx), nn.Parameter(torch.empty(4 * H, In)))
+                self.register_parameter("weight_hh_l%d%s" % (layer, sfx), nn.Parameter(torch.empty(4 * H, H)))
+                self.register_parameter("bias_ih_l%d%s" % (layer, sfx), nn.Parameter(torch.empty(4 * H)))
+                self.register_parameter("bias_hh_l%d%s" % (layer, sfx), nn.Parameter(torch.empty(4 * H)))
+        stdv = 1.0 / (H ** 0.5) if H > 0 else 0.0
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+    def w(self, kind, layer, d):
+        return getattr(self, "%s_l%d%s" % (kind, layer, "_reverse" if d == 1 else ""))
+
+
+# ---------------------------------------------------------------------------------------------------
+# three (k=1 conv, BatchNorm, ReLU) stages over rows
+# ---------------------------------------------------------------------------------------------------
+def _mlp3_layers(mod):
+    return ((mod.conv1, mod.cb1), (mod.conv2, mod.cb2), (mod.conv3, mod.cb3))
+
+
+def mlp3_forward(ar, key, mod, x, out_last, training):
+    rows = x.shape[0]
+    cur = x
+    for i, (conv, bn) in enumerate(_mlp3_layers(mod), 1):
+        C = conv.weight.shape[0]
+        z = ar.get("%s.z%d" % (key, i), (rows, C))
+        ops.linear(cur, conv.weight, conv.bias, z)
+        st = ops.bn_stats(ar, "%s.bn%d" % (key, i), z, bn, training)
+        y = out_last if i == 3 else ar.get("%s.y%d" % (key, i), (rows, C))
+        ops.affine_act(z, st, y, relu=True)
+        cur = y
+    return cur
+
+
+def mlp3_backward(ar, key, mod, x, y3, dy3, G, need_dx):
+    rows = x.shape[0]
+    layers = _mlp3_layers(mod)
+    dy = dy3
+    for i in (3, 2, 1):
+        conv, bn = layers[i - 1]
+        C = conv.weight.shape[0]
+        z = ar.get("%s.z%d" % (key, i), (rows, C))
+        y = y3 if i == 3 else ar.get("%s.y%d" % (key, i), (rows, C))
+        st = ops.BnState(ar, "%s.bn%d" % (key, i), C)
+        dz = ar.get("%s.dz%d" % (key, i), (rows, C))
+        ops.bn_backward(dy, y, z, st, G(bn.weight), G(bn.bias), dz)
+        inp = x if i == 1 else ar.get("%s.y%d" % (key, i - 1), (rows, layers[i - 2][0].weight.shape[0]))
+        ops.grad_weight(dz, inp, G(conv.weight))
+        ops.colsum(dz, G(conv.bias))
+        if i > 1 or need_dx:
+            dprev = ar.get("%s.dy%d" % (key, i - 1), (rows, inp.shape[1]))
+            ops.grad_input(dz, conv.weight, dprev)
+            dy = dprev
+    return dy if need_dx else None
+
+
+# ---------------------------------------------------------------------------------------------------
+# Linear (+ReLU) with backward
+# ---------------------------------------------------------------------------------------------------
+def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False):
+    """Gradients of y = x W^T + b: writes G(W), G(b); fills dx if given."""
+    ops.grad_weight(dy, x, G(lin.weight))
+    if lin.bias is not None:
+        ops.colsum(dy, G(lin.bias))
+    if dx is not None:
+        ops.grad_input(dy, lin.weight, dx, accumulate=accumulate_dx)
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------------
+# 3-layer bidirectional LSTM, H = 64 (persistent sequence kernels)
+# ---------------------------------------------------------------------------------------------------
+def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr):
+    """x [B*T, In] rows (b*T+t) -> out [B*T,128] (arena), hn, cn [2L,B,64] (fresh tensors)."""
+    L = lstm.num_layers
+    dev = x.device
+    hn = torch.empty((2 * L, B, 64), dtype=torch.float32, device=dev)
+    cn = torch.empty((2 * L, B, 64), dtype=torch.float32, device=dev)
+    cur = x
+    out = None
+    for l in range(L):
+        xp = ar.get("%s.xp%d" % (key, l), (B * T, 512))
+        for d in range(2):
+            bsum = ar.get("%s.bs%d%d" % (key, l, d), (256,))
+            hip.call("add", lstm.w("bias_ih", l, d), lstm.w("bias_hh", l, d), bsum, 256)
+            ops.linear(cur, lstm.w("weight_ih", l, d), bsum, xp[:, d * 256:(d + 1) * 256])
+        out = ar.get("%s.out%d" % (key, l), (B * T, 128))
+        if stash:
+            gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
+            cst = ar.get("%s.c%d" % (key, l), (2, T, B, 64))
+            hprev = ar.get("%s.hp%d" % (key, l), (2, B * T, 64))
+            st = (gates[0], gates[1], cst[0], cst[1], hprev[0], hprev[1])
+        else:
+            st = (None,) * 6
+        h00 = h0[2 * l] if h0 is not None else None
+        h01 = h0[2 * l + 1] if h0 is not None else None
+        c00 = c0[2 * l] if c0 is not None else None
+        c01 = c0[2 * l + 1] if c0 is not None else None
+        hip.call("lstm64_forward", B, T, xp, xp[:, 256:], 512, lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1),
+                 h00, h01, c00, c01, out, 128, hn[2 * l], hn[2 * l + 1], cn[2 * l], cn[2 * l + 1], *st)
+        cur = out
+        if stash and p_drop > 0.0 and l < L - 1:
+            dropped = ar.get("%s.do%d" % (key, l), (B * T, 128))
+            mask = ar.get("%s.mk%d" % (key, l), (B * T, 128))
+            hip.call("dropout", out, dropped, mask, out.numel(), float(p_drop), seed_ctr)
+            cur = dropped
+    return out, hn, cn
+
+
+def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
+    L = lstm.num_layers
+    d_cur = dout
+    for l in range(L - 1, -1, -1):
+        if l == 0:
+            inp = x
+        elif p_drop > 0.0:
+            inp = ar.get("%s.do%d" % (key, l - 1), (B * T, 128))
+        else:
+            inp = ar.get("%s.out%d" % (key, l - 1), (B * T, 128))
+        gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
+        cst = ar.get("%s.c%d" % (key, l), (2, T, B, 64))
+        hprev = ar.get("%s.hp%d" % (key, l), (2, B * T, 64))
+        dg = ar.get("%s.dg" % key, (B * T, 512))
+        c00 = c0[2 * l] if c0 is not None else None
+        c01 = c0[2 * l + 1] if c0 is not None else None
+        hip.call("lstm64_backward", B, T, d_cur, d_cur.stride(0), gates[0], gates[1], cst[0], cst[1], c00, c01,
+                 lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1), dg, dg[:, 256:], 512)
+        for d in range(2):
+            dgd = dg[:, d * 256:(d + 1) * 256]
+            ops.grad_weight(dgd, inp, G(lstm.w("weight_ih", l, d)))
+            ops.grad_weight(dgd, hprev[d], G(lstm.w("weight_hh", l, d)))
+            gb = G(lstm.w("bias_ih", l, d))
+            ops.colsum(dgd, gb)
+            ops.copy2d(gb.view(1, 256), G(lstm.w("bias_hh", l, d)).view(1, 256))
+        if l > 0 or need_dx:
+            dinp = ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))
+            ops.grad_input(dg[:, :256], lstm.w("weight_ih", l, 0), dinp)
+            ops.grad_input(dg[:, 256:], lstm.w("weight_ih", l, 1), dinp, accumulate=True)
+            if l > 0 and p_drop > 0.0:
+                mask = ar.get("%s.mk%d" % (key, l - 1), (B * T, 128))
+                hip.call("mul", dinp, mask, dinp, dinp.numel())
+            d_cur = dinp
+    return d_cur if need_dx else None
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention pooling over the points of each group
+# ---------------------------------------------------------------------------------------------------
+def attn_pool_forward(X, lin, G_, P, C, vec, attn):
+    hip.call("attn_pool_forward", X, lin.weight, lin.bias, G_, P, C, vec, attn)
+
+
+def attn_pool_backward(ar, key, X, lin, attn, dvec, G_, P, C, dX, G):
+    pdw = ar.get("%s.pdw" % key, (G_, C))
+    pdb = ar.get("%s.pdb" % key, (G_, 1))
+    hip.call("attn_pool_backward", X, lin.weight, attn, dvec, G_, P, C, dX, pdw, pdb)
+    ops.colsum(pdw, G(lin.weight).view(-1))
+    ops.colsum(pdb, G(lin.bias))
+
+
+# ---------------------------------------------------------------------------------------------------
+# generic-H step-kernel LSTM stack (forward only): IMU_Net's rnn_fast / rnn_slow
+# ---------------------------------------------------------------------------------------------------
+def lstm_steps_forward(ar, key, lstm, x, Bn, T):
+    """x [Bn*T, In] rows (b*T+t) -> out [Bn*T, 2H] of the last layer (eval mode: no dropout)."""
+    H = lstm.hidden_size
+    L = lstm.num_layers
+    cur = x
+    zeros = ar.get("%s.zero" % key, (Bn, H), zero=True)
+    out = None
+    for l in range(L):
+        xp = ar.get("%s.xp%d" % (key, l), (Bn * T, 8 * H))
+        for d in range(2):
+            bsum = ar.get("%s.bs%d%d" % (key, l, d), (4 * H,))
+            hip.call("add", lstm.w("bias_ih", l, d), lstm.w("bias_hh", l, d), bsum, 4 * H)
+            ops.linear(cur, lstm.w("weight_ih", l, d), bsum, xp[:, d * 4 * H:(d + 1) * 4 * H])
+        out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
+        c = ar.get("%s.c" % key, (2, Bn, H), zero=True)
+        w0, w1 = lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1)
+        xp_p, out_p, z_p = xp.data_ptr(), out.data_ptr(), zeros.data_ptr()
+        xs, os_ = T * 8 * H, T * 2 * H       # row strides between consecutive batch rows b
+        for s in range(T):
+            t0, t1 = s, T - 1 - s
+            if s == 0:
+                hp0, hp1, hps = z_p, z_p, H
+            else:
+                hp0 = out_p + 4 * ((t0 - 1) * 2 * H)
+                hp1 = out_p + 4 * ((t1 + 1) * 2 * H + H)
+                hps = os_
+            hip.call("lstm_step", 2, Bn, H, hp0, hp1, hps, w0, w1,
+                     xp_p + 4 * (t0 * 8 * H), xp_p + 4 * (t1 * 8 * H + 4 * H), xs,
+                     out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_, c[0], c[1])
+        cur = out
+    return out

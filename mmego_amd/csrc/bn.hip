@@ -1,0 +1,310 @@
+// BatchNorm (batch statistics, channels-last rows x C), its backward, and the small row-wise helpers
+// around it.  Replaces the native_batch_norm / relu / cat chains of reference Net/Upper_Net.py:242-301,
+// Net/Lower_Net.py:40-72 and Net/GCN.py:106-147.  All HBM-bound: one coalesced pass per kernel, threads
+// run along the channel axis (64 consecutive floats per wave row), partial statistics are combined with
+// Chan's formula in fp64 so that train-mode statistics are at least as accurate as a two-pass CPU BN.
+#include "common.h"
+
+#define RPB 128  // rows per block in the column-reduction kernels
+
+// partial[blk][c] = (n, mean, M2) over this block's rows of column c
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ X, long ldx, long rows, int C,
+                                                       float* __restrict__ partial) {
+  __shared__ float sh[4][64][3];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cx;
+  const long r0 = (long)blockIdx.x * RPB;
+  const long r1 = min(rows, r0 + RPB);
+  float n = 0.f, s = 0.f, ss = 0.f, shift = 0.f;
+  if (c < C) {
+    shift = X[r0 * ldx + c];  // block-local shift keeps the sum of squares well conditioned
+    for (long r = r0 + ry; r < r1; r += 4) {
+      float d = X[r * ldx + c] - shift;
+      s += d;
+      ss += d * d;
+      n += 1.f;
+    }
+  }
+  sh[ry][cx][0] = n; sh[ry][cx][1] = s; sh[ry][cx][2] = ss;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    float N = 0.f, S = 0.f, SS = 0.f;
+    for (int j = 0; j < 4; ++j) { N += sh[j][cx][0]; S += sh[j][cx][1]; SS += sh[j][cx][2]; }
+    float mean_d = S / N;
+    float* out = partial + ((long)blockIdx.x * C + c) * 3;
+    out[0] = N;
+    out[1] = shift + mean_d;
+    out[2] = fmaxf(SS - S * mean_d, 0.f);
+  }
+}
+
+// Combine partials (Chan, fp64); update running stats exactly like torch (momentum, unbiased running var).
+// outputs: mean[C], invstd[C], a[C] = gamma*invstd, b[C] = beta     so that y = (x-mean)*a + b
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var, float momentum,
+                                   float eps, float* mean_out, float* invstd_out, float* a_out, float* b_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double N = 0.0, mean = 0.0, M2 = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    const float* p = partial + ((long)k * C + c) * 3;
+    double nb = p[0], mb = p[1], m2b = p[2];
+    double tot = N + nb;
+    double delta = mb - mean;
+    mean += delta * nb / tot;
+    M2 += m2b + delta * delta * N * nb / tot;
+    N = tot;
+  }
+  double var = M2 / N;
+  float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  a_out[c] = gamma[c] * invstd;
+  b_out[c] = beta[c];
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    double unbiased = N > 1.0 ? M2 / (N - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// eval mode: y = (x - running_mean) * gamma/sqrt(running_var+eps) + beta
+__global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* running_mean,
+                                      const float* running_var, float eps, float* mean_out, float* invstd_out,
+                                      float* a_out, float* b_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float invstd = 1.0f / sqrtf(running_var[c] + eps);
+  mean_out[c] = running_mean[c];
+  invstd_out[c] = invstd;
+  a_out[c] = gamma[c] * invstd;
+  b_out[c] = beta[c];
+}
+
+// Y[r, c] = act( (X1-m1)*a1+b1 [+ (X2-m2)*a2+b2] )
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ X1, long ld1, const float* m1,
+                                                         const float* a1, const float* b1,
+                                                         const float* __restrict__ X2, long ld2, const float* m2,
+                                                         const float* a2, const float* b2, float* __restrict__ Y,
+                                                         long ldy, long rows, int C, int relu) {
+  long total = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / C;
+    int c = (int)(i - r * C);
+    float v = (X1[r * ld1 + c] - m1[c]) * a1[c] + b1[c];
+    if (X2) v += (X2[r * ld2 + c] - m2[c]) * a2[c] + b2[c];
+    if (relu) v = fmaxf(v, 0.f);
+    Y[r * ldy + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ X, long ldx, float* __restrict__ Y,
+                                                     long ldy, long rows, int C, int accumulate) {
+  long total = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / C;
+    int c = (int)(i - r * C);
+    float v = X[r * ldx + c];
+    if (accumulate) v += Y[r * ldy + c];
+    Y[r * ldy + c] = v;
+  }
+}
+
+// dZ = dY * [Ymask > 0];  partial[blk][c] = (sum dZ, sum dZ*xhat)   with xhat = (X-mean)*invstd
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dY, long lddy,
+                                                            const float* __restrict__ Ymask, long ldm,
+                                                            const float* __restrict__ X, long ldx, const float* mean,
+                                                            const float* invstd, long rows, int C,
+                                                            float* __restrict__ partial) {
+  __shared__ float sh[4][64][2];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cx;
+  const long r0 = (long)blockIdx.x * RPB;
+  const long r1 = min(rows, r0 + RPB);
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float mu = mean[c], is = invstd[c];
+    for (long r = r0 + ry; r < r1; r += 4) {
+      float g = dY[r * lddy + c];
+      if (Ymask && !(Ymask[r * ldm + c] > 0.f)) g = 0.f;
+      s1 += g;
+      s2 += g * ((X[r * ldx + c] - mu) * is);
+    }
+  }
+  sh[ry][cx][0] = s1; sh[ry][cx][1] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < 4; ++j) { a += sh[j][cx][0]; b += sh[j][cx][1]; }
+    partial[((long)blockIdx.x * C + c) * 2 + 0] = a;
+    partial[((long)blockIdx.x * C + c) * 2 + 1] = b;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long rows, float* dgamma,
+                                       float* dbeta, float* c1, float* c2) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    s1 += partial[((long)k * C + c) * 2 + 0];
+    s2 += partial[((long)k * C + c) * 2 + 1];
+  }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  c1[c] = (float)(s1 / (double)rows);
+  c2[c] = (float)(s2 / (double)rows);
+}
+
+// dX = a * (dZ - c1 - xhat*c2)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dY, long lddy,
+                                                           const float* __restrict__ Ymask, long ldm,
+                                                           const float* __restrict__ X, long ldx, const float* mean,
+                                                           const float* invstd, const float* a, const float* c1,
+                                                           const float* c2, float* __restrict__ dX, long lddx,
+                                                           long rows, int C) {
+  long total = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / C;
+    int c = (int)(i - r * C);
+    float g = dY[r * lddy + c];
+    if (Ymask && !(Ymask[r * ldm + c] > 0.f)) g = 0.f;
+    float xh = (X[r * ldx + c] - mean[c]) * invstd[c];
+    dX[r * lddx + c] = a[c] * (g - c1[c] - xh * c2[c]);
+  }
+}
+
+// partial[blk][c] = sum over the block's rows of X[r,c]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, long rows, int C,
+                                                             float* __restrict__ partial) {
+  __shared__ float sh[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cx;
+  const long r0 = (long)blockIdx.x * RPB;
+  const long r1 = min(rows, r0 + RPB);
+  float s = 0.f;
+  if (c < C)
+    for (long r = r0 + ry; r < r1; r += 4) s += X[r * ldx + c];
+  sh[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) partial[(long)blockIdx.x * C + c] = sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx];
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* out, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += partial[(long)k * C + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// G[r,c] = 0 where H[r,c] <= 0
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ G, long ldg, const float* __restrict__ H,
+                                                        long ldh, long rows, int C) {
+  long total = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / C;
+    int c = (int)(i - r * C);
+    if (!(H[r * ldh + c] > 0.f)) G[r * ldg + c] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ X, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) X[i] = v;
+}
+
+static inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+extern "C" int mmego_colstats_nblk(long rows) { return cdiv(rows, RPB); }
+
+extern "C" int mmego_bn_train_stats(void* stream, const float* X, long ldx, long rows, int C, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var, float momentum,
+                                    float eps, float* partial_ws, float* mean, float* invstd, float* a, float* b) {
+  MMEGO_REQUIRE(X && rows > 0 && C > 0 && partial_ws && mean && invstd && a && b);
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = cdiv(rows, RPB);
+  hipLaunchKernelGGL(colstats_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, X, ldx, rows, C, partial_ws);
+  MMEGO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial_ws, nblk, C, gamma, beta,
+                     running_mean, running_var, momentum, eps, mean, invstd, a, b);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_bn_eval_affine(void* stream, int C, const float* gamma, const float* beta,
+                                    const float* running_mean, const float* running_var, float eps, float* mean,
+                                    float* invstd, float* a, float* b) {
+  MMEGO_REQUIRE(C > 0 && gamma && beta && running_mean && running_var);
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, C, gamma, beta,
+                     running_mean, running_var, eps, mean, invstd, a, b);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_affine_act(void* stream, const float* X1, long ld1, const float* m1, const float* a1,
+                                const float* b1, const float* X2, long ld2, const float* m2, const float* a2,
+                                const float* b2, float* Y, long ldy, long rows, int C, int relu) {
+  MMEGO_REQUIRE(X1 && Y && rows > 0 && C > 0);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, (hipStream_t)stream, X1, ld1, m1, a1,
+                     b1, X2, ld2, m2, a2, b2, Y, ldy, rows, C, relu);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_copy2d(void* stream, const float* X, long ldx, float* Y, long ldy, long rows, int C,
+                            int accumulate) {
+  MMEGO_REQUIRE(X && Y && rows > 0 && C > 0);
+  hipLaunchKernelGGL(copy2d_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, (hipStream_t)stream, X, ldx, Y, ldy, rows,
+                     C, accumulate);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_bn_backward(void* stream, const float* dY, long lddy, const float* Ymask, long ldm,
+                                 const float* X, long ldx, const float* mean, const float* invstd, const float* a,
+                                 long rows, int C, float* partial_ws, float* c12_ws, float* dgamma, float* dbeta,
+                                 float* dX, long lddx) {
+  MMEGO_REQUIRE(dY && X && mean && invstd && a && rows > 0 && C > 0 && partial_ws && c12_ws && dgamma && dbeta && dX);
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = cdiv(rows, RPB);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
+                     mean, invstd, rows, C, partial_ws);
+  MMEGO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial_ws, nblk, C, rows, dgamma,
+                     dbeta, c12_ws, c12_ws + C);
+  MMEGO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
+                     mean, invstd, a, c12_ws, c12_ws + C, dX, lddx, rows, C);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, int C, float* partial_ws, float* out,
+                            int accumulate) {
+  MMEGO_REQUIRE(X && rows > 0 && C > 0 && partial_ws && out);
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = cdiv(rows, RPB);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, X, ldx, rows, C, partial_ws);
+  MMEGO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial_ws, nblk, C, out, accumulate);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_relu_mask(void* stream, float* G, long ldg, const float* H, long ldh, long rows, int C) {
+  MMEGO_REQUIRE(G && H && rows > 0 && C > 0);
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, (hipStream_t)stream, G, ldg, H, ldh,
+                     rows, C);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_fill(void* stream, float* X, long n, float v) {
+  MMEGO_REQUIRE(X && n > 0);
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, X, n, v);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

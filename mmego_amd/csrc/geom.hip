@@ -1,0 +1,340 @@
+// Geometry of the path: head-frame transforms, 6-D -> rotation, forward kinematics, L1 loss, and the
+// top-k point selection of Lower_Net.  One thread per frame (or per point); these are latency-sized
+// kernels (a few hundred frames), their job is to replace ~60 tiny aten launches per step.
+//
+// References: Util/Universal_Util/Utils.py:274-292 (Transform2H/2R), Net/Upper_Net.py:122-144,343-364,
+// Net/Lower_Net.py:12-37,125-136,216-227, Net/IMU_Net.py:7-47, Processor/Train/Train_Upper.py:53,179.
+#include "common.h"
+
+// r = (a0*b0 + a1*b1) + a2*b2 with every product and sum rounded separately (no fma contraction): this
+// is the operation order of the CPU bmm the reference runs for its 3x3 . 3x1 products, so transformed
+// coordinates -- which become sort keys downstream -- are bit-identical to the CPU path.
+__device__ __forceinline__ float dot3_nofma(float a0, float a1, float a2, float b0, float b1, float b2) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b1)), __fmul_rn(a2, b2));
+}
+
+// pts[f, p, 0:3] <- R[f] . (pts[f, p, 0:3] - t[f])   IN PLACE (reference quirk Q1)
+__global__ __launch_bounds__(256) void transform2h_kernel(float* __restrict__ pts, int P, int C, const float* __restrict__ R,
+                                                          const float* __restrict__ t, long npts) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npts) return;
+  long f = i / P;
+  const float* Rf = R + f * 9;
+  const float* tf = t + f * 3;
+  float* x = pts + i * C;
+  float d0 = __fsub_rn(x[0], tf[0]), d1 = __fsub_rn(x[1], tf[1]), d2 = __fsub_rn(x[2], tf[2]);
+  x[0] = dot3_nofma(Rf[0], Rf[1], Rf[2], d0, d1, d2);
+  x[1] = dot3_nofma(Rf[3], Rf[4], Rf[5], d0, d1, d2);
+  x[2] = dot3_nofma(Rf[6], Rf[7], Rf[8], d0, d1, d2);
+}
+
+// out[f, p, :] = R[f]^T . in[f, p, :] + t[f]     (transpose=1, Transform2R)
+// out[f, p, :] = R[f] . in[f, p, :]              (transpose=0, add_t=0: its backward)
+__global__ __launch_bounds__(256) void rotate_points_kernel(const float* __restrict__ in, float* __restrict__ out, int P,
+                                                            const float* __restrict__ R, const float* __restrict__ t,
+                                                            long npts, int transpose, int add_t) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npts) return;
+  long f = i / P;
+  const float* Rf = R + f * 9;
+  float v0 = in[i * 3], v1 = in[i * 3 + 1], v2 = in[i * 3 + 2];
+  float o0, o1, o2;
+  if (transpose) {
+    o0 = dot3_nofma(Rf[0], Rf[3], Rf[6], v0, v1, v2);
+    o1 = dot3_nofma(Rf[1], Rf[4], Rf[7], v0, v1, v2);
+    o2 = dot3_nofma(Rf[2], Rf[5], Rf[8], v0, v1, v2);
+  } else {
+    o0 = dot3_nofma(Rf[0], Rf[1], Rf[2], v0, v1, v2);
+    o1 = dot3_nofma(Rf[3], Rf[4], Rf[5], v0, v1, v2);
+    o2 = dot3_nofma(Rf[6], Rf[7], Rf[8], v0, v1, v2);
+  }
+  if (add_t) { o0 += t[f * 3]; o1 += t[f * 3 + 1]; o2 += t[f * 3 + 2]; }
+  out[i * 3] = o0; out[i * 3 + 1] = o1; out[i * 3 + 2] = o2;
+}
+
+// ---- 6-D -> rotation (Gram-Schmidt), two eps rules -------------------------------------------------
+// mode 0: F.normalize, v / max(|v|, 1e-12)  (Upper/Lower heads);  mode 1: v / max(|v|, 1e-8) (IMU_Net)
+struct Rot6 {
+  float x[3], y[3], z[3];
+  float na, nw;  // clamped norms of a and of w = x cross b
+};
+
+__device__ __forceinline__ void cross3(const float* u, const float* v, float* o) {
+  o[0] = u[1] * v[2] - u[2] * v[1];
+  o[1] = u[2] * v[0] - u[0] * v[2];
+  o[2] = u[0] * v[1] - u[1] * v[0];
+}
+
+__device__ __forceinline__ Rot6 rot6d_fwd(const float* six, float eps) {
+  Rot6 r;
+  const float* a = six;
+  const float* b = six + 3;
+  r.na = fmaxf(sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), eps);
+  for (int i = 0; i < 3; ++i) r.x[i] = a[i] / r.na;
+  float w[3];
+  cross3(r.x, b, w);
+  r.nw = fmaxf(sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), eps);
+  for (int i = 0; i < 3; ++i) r.z[i] = w[i] / r.nw;
+  cross3(r.z, r.x, r.y);
+  return r;
+}
+
+// gR: gradient wrt the 3x3 matrix whose COLUMNS are x,y,z (row-major 9 floats) -> gradient wrt the 6 inputs
+__device__ __forceinline__ void rot6d_bwd(const float* six, float eps, const float* gR, float* gsix) {
+  Rot6 r = rot6d_fwd(six, eps);
+  const float* b = six + 3;
+  float gx[3] = {gR[0], gR[3], gR[6]}, gy[3] = {gR[1], gR[4], gR[7]}, gz[3] = {gR[2], gR[5], gR[8]};
+  float tmp[3];
+  // y = z cross x
+  cross3(r.x, gy, tmp);
+  for (int i = 0; i < 3; ++i) gz[i] += tmp[i];
+  cross3(gy, r.z, tmp);
+  for (int i = 0; i < 3; ++i) gx[i] += tmp[i];
+  // z = w / max(|w|, eps)
+  float w2 = 0.f;
+  {
+    float w[3];
+    cross3(r.x, b, w);
+    w2 = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  }
+  float gw[3];
+  if (w2 > eps) {
+    float dz = r.z[0] * gz[0] + r.z[1] * gz[1] + r.z[2] * gz[2];
+    for (int i = 0; i < 3; ++i) gw[i] = (gz[i] - r.z[i] * dz) / r.nw;
+  } else {
+    for (int i = 0; i < 3; ++i) gw[i] = gz[i] / r.nw;
+  }
+  // w = x cross b
+  cross3(b, gw, tmp);
+  for (int i = 0; i < 3; ++i) gx[i] += tmp[i];
+  cross3(gw, r.x, gsix + 3);
+  // x = a / max(|a|, eps)
+  float a2 = sqrtf(six[0] * six[0] + six[1] * six[1] + six[2] * six[2]);
+  if (a2 > eps) {
+    float dx = r.x[0] * gx[0] + r.x[1] * gx[1] + r.x[2] * gx[2];
+    for (int i = 0; i < 3; ++i) gsix[i] = (gx[i] - r.x[i] * dx) / r.na;
+  } else {
+    for (int i = 0; i < 3; ++i) gsix[i] = gx[i] / r.na;
+  }
+}
+
+// Forward-kinematics plan: bone k writes slot child[k] = slot parent[k] + Rot[rot[k]] . body[row[k]]
+struct FkPlan {
+  int nbones, nslots, nrot;
+  int parent[16], child[16], rot[16], row[16];
+  int seed_slot[2], seed_off[2], nseed;  // slots seeded from the head output (offset into y)
+};
+
+// y: [F, ny] head output (6*nrot rotation params, then positions);  body: [B, 20, 3];  frame n uses body n % B (Q2)
+// outputs: q [F, nrot, 3, 3], joints_h [F, nslots, 3] (head frame)
+__global__ __launch_bounds__(128) void head_fk_fwd_kernel(const float* __restrict__ y, int ny, const float* __restrict__ body,
+                                                          int B, long F, FkPlan plan, float* __restrict__ q,
+                                                          float* __restrict__ joints) {
+  long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const float* yf = y + f * ny;
+  const float* bf = body + (f % B) * 60;
+  float* qf = q + f * plan.nrot * 9;
+  float l[16][3];
+  for (int s = 0; s < plan.nseed; ++s)
+    for (int i = 0; i < 3; ++i) l[plan.seed_slot[s]][i] = yf[plan.seed_off[s] + i];
+  for (int k = 0; k < plan.nrot; ++k) {
+    Rot6 r = rot6d_fwd(yf + 6 * k, 1e-12f);
+    for (int i = 0; i < 3; ++i) { qf[k * 9 + i * 3 + 0] = r.x[i]; qf[k * 9 + i * 3 + 1] = r.y[i]; qf[k * 9 + i * 3 + 2] = r.z[i]; }
+  }
+  for (int k = 0; k < plan.nbones; ++k) {
+    const float* Rm = qf + plan.rot[k] * 9;
+    const float* bv = bf + plan.row[k] * 3;
+    for (int i = 0; i < 3; ++i)
+      l[plan.child[k]][i] = l[plan.parent[k]][i] + (Rm[i * 3] * bv[0] + Rm[i * 3 + 1] * bv[1] + Rm[i * 3 + 2] * bv[2]);
+  }
+  for (int s = 0; s < plan.nslots; ++s)
+    for (int i = 0; i < 3; ++i) joints[(f * plan.nslots + s) * 3 + i] = l[s][i];
+}
+
+// dj: [F, nslots, 3] gradient wrt head-frame joints  ->  dy [F, ny]
+__global__ __launch_bounds__(128) void head_fk_bwd_kernel(const float* __restrict__ y, int ny, const float* __restrict__ body,
+                                                          int B, long F, FkPlan plan, const float* __restrict__ dj,
+                                                          float* __restrict__ dy) {
+  long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const float* yf = y + f * ny;
+  const float* bf = body + (f % B) * 60;
+  float g[16][3];
+  for (int s = 0; s < plan.nslots; ++s)
+    for (int i = 0; i < 3; ++i) g[s][i] = dj[(f * plan.nslots + s) * 3 + i];
+  float gq[14][9];
+  for (int k = 0; k < plan.nrot; ++k)
+    for (int i = 0; i < 9; ++i) gq[k][i] = 0.f;
+  for (int k = plan.nbones - 1; k >= 0; --k) {
+    const float* bv = bf + plan.row[k] * 3;
+    const int c = plan.child[k], pa = plan.parent[k], rr = plan.rot[k];
+    for (int i = 0; i < 3; ++i) {
+      g[pa][i] += g[c][i];
+      gq[rr][i * 3 + 0] += g[c][i] * bv[0];
+      gq[rr][i * 3 + 1] += g[c][i] * bv[1];
+      gq[rr][i * 3 + 2] += g[c][i] * bv[2];
+    }
+  }
+  float* dyf = dy + f * ny;
+  for (int k = 0; k < plan.nrot; ++k) rot6d_bwd(yf + 6 * k, 1e-12f, gq[k], dyf + 6 * k);
+  for (int i = 6 * plan.nrot; i < ny; ++i) dyf[i] = 0.f;
+  for (int s = 0; s < plan.nseed; ++s)
+    for (int i = 0; i < 3; ++i) dyf[plan.seed_off[s] + i] = g[plan.seed_slot[s]][i];
+}
+
+// IMU head: out[f, 0:9] -> R [f,3,3] (eps rule 1e-8), t [f,3]
+__global__ __launch_bounds__(128) void imu_head_kernel(const float* __restrict__ y, long F, float* __restrict__ R,
+                                                       float* __restrict__ t) {
+  long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  Rot6 r = rot6d_fwd(y + f * 9, 1e-8f);
+  for (int i = 0; i < 3; ++i) {
+    R[f * 9 + i * 3 + 0] = r.x[i]; R[f * 9 + i * 3 + 1] = r.y[i]; R[f * 9 + i * 3 + 2] = r.z[i];
+    t[f * 3 + i] = y[f * 9 + 6 + i];
+  }
+}
+
+// loss = sum |pred - target[:, map]| ; grad = scale * sign(pred - target)
+//   pred [F, nsel, 3]; target [F, ntgt, 3]; map[nsel] selects target joints.  Single block: deterministic sum.
+__global__ __launch_bounds__(1024) void l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                       const int* __restrict__ map, int nsel, int ntgt, long F,
+                                                       float scale, float* __restrict__ loss, float* __restrict__ grad) {
+  __shared__ double sh[16];
+  long total = F * nsel * 3;
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < total; i += blockDim.x) {
+    long f = i / (nsel * 3);
+    int r = (int)(i - f * nsel * 3);
+    int s = r / 3, c = r - s * 3;
+    float d = pred[i] - target[(f * ntgt + map[s]) * 3 + c];
+    acc += (double)fabsf(d);
+    if (grad) grad[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+    *loss = (float)s;
+  }
+}
+
+// Keep the `keep` rows with the largest key (column 0), descending, ties lowest-index-first (stable);
+// out [F, keep, C], idx int64 [F, keep].  Reference Lower_Net.py:216-227 (torch.sort, tie order unspecified).
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ pts, int N, int C, int keep,
+                                                        float* __restrict__ out, long long* __restrict__ idx) {
+  extern __shared__ float keys[];
+  const long f = blockIdx.x;
+  const float* pf = pts + f * N * C;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) keys[i] = pf[i * C];
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const float k = keys[i];
+    int rank = 0;
+    for (int j = 0; j < N; ++j) {
+      float kj = keys[j];
+      rank += (kj > k) || (kj == k && j < i);
+    }
+    if (rank < keep) {
+      idx[f * keep + rank] = i;
+      float* o = out + (f * keep + rank) * C;
+      for (int c = 0; c < C; ++c) o[c] = pf[i * C + c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static FkPlan make_plan(int which) {
+  FkPlan p;
+  if (which == 0) {  // upper: Config.skeleton_upper_body walked in order, head at slot 14 (quirk Q4)
+    static const int bones[14][2] = {{20, 3}, {3, 2}, {2, 1}, {2, 4}, {2, 8}, {4, 5}, {5, 6}, {6, 7},
+                                     {8, 9}, {9, 10}, {10, 11}, {1, 0}, {0, 12}, {0, 16}};
+    static const int umap[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 20};
+    auto slot = [&](int j) { for (int i = 0; i < 15; ++i) if (umap[i] == j) return i; return -1; };
+    p.nbones = 14; p.nslots = 15; p.nrot = 14;
+    for (int k = 0; k < 14; ++k) {
+      p.parent[k] = slot(bones[k][0]); p.child[k] = slot(bones[k][1]);
+      p.rot[k] = p.child[k]; p.row[k] = k;
+    }
+    p.nseed = 1; p.seed_slot[0] = 14; p.seed_off[0] = 84; p.seed_slot[1] = 0; p.seed_off[1] = 0;
+  } else {  // lower: hips at slots 0 and 4, body rows 14..19, rotation row from [13,14,15,17,18,19]
+    static const int bones[6][2] = {{12, 13}, {13, 14}, {14, 15}, {16, 17}, {17, 18}, {18, 19}};
+    static const int lmap[8] = {12, 13, 14, 15, 16, 17, 18, 19};
+    static const int rmap[6] = {13, 14, 15, 17, 18, 19};
+    auto slot = [&](int j) { for (int i = 0; i < 8; ++i) if (lmap[i] == j) return i; return -1; };
+    auto rslot = [&](int j) { for (int i = 0; i < 6; ++i) if (rmap[i] == j) return i; return -1; };
+    p.nbones = 6; p.nslots = 8; p.nrot = 6;
+    for (int k = 0; k < 6; ++k) {
+      p.parent[k] = slot(bones[k][0]); p.child[k] = slot(bones[k][1]);
+      p.rot[k] = rslot(bones[k][1]); p.row[k] = k + 14;
+    }
+    p.nseed = 2; p.seed_slot[0] = 0; p.seed_off[0] = 36; p.seed_slot[1] = 4; p.seed_off[1] = 39;
+  }
+  return p;
+}
+
+extern "C" int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t) {
+  MMEGO_REQUIRE(pts && R && t && F > 0 && P > 0 && C >= 3);
+  long n = F * P;
+  hipLaunchKernelGGL(transform2h_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, P, C, R, t, n);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_rotate_points(void* stream, const float* in, float* out, long F, int P, const float* R,
+                                   const float* t, int transpose, int add_t) {
+  MMEGO_REQUIRE(in && out && R && F > 0 && P > 0 && (!add_t || t));
+  long n = F * P;
+  hipLaunchKernelGGL(rotate_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, P, R, t, n,
+                     transpose, add_t);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// which: 0 = upper head (ny = 87 -> 14 rotations + head), 1 = lower head (ny = 42 -> 6 rotations + 2 hips)
+extern "C" int mmego_head_fk_forward(void* stream, int which, const float* y, const float* body, int B, long F, float* q,
+                                     float* joints) {
+  MMEGO_REQUIRE((which == 0 || which == 1) && y && body && q && joints && B > 0 && F > 0);
+  FkPlan plan = make_plan(which);
+  hipLaunchKernelGGL(head_fk_fwd_kernel, dim3(cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, y, which == 0 ? 87 : 42,
+                     body, B, F, plan, q, joints);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_head_fk_backward(void* stream, int which, const float* y, const float* body, int B, long F,
+                                      const float* dj, float* dy) {
+  MMEGO_REQUIRE((which == 0 || which == 1) && y && body && dj && dy && B > 0 && F > 0);
+  FkPlan plan = make_plan(which);
+  hipLaunchKernelGGL(head_fk_bwd_kernel, dim3(cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, y, which == 0 ? 87 : 42,
+                     body, B, F, plan, dj, dy);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_imu_head(void* stream, const float* y, long F, float* R, float* t) {
+  MMEGO_REQUIRE(y && R && t && F > 0);
+  hipLaunchKernelGGL(imu_head_kernel, dim3(cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, y, F, R, t);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_l1_loss(void* stream, const float* pred, const float* target, const int* map, int nsel, int ntgt,
+                             long F, float scale, float* loss, float* grad) {
+  MMEGO_REQUIRE(pred && target && map && loss && nsel > 0 && ntgt > 0 && F > 0);
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, target, map, nsel, ntgt, F,
+                     scale, loss, grad);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_topk_rows(void* stream, const float* pts, long F, int N, int C, int keep, float* out,
+                               long long* idx) {
+  MMEGO_REQUIRE(pts && out && idx && F > 0 && N > 0 && C > 0 && keep > 0 && keep <= N && N <= 4096);
+  hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)F), dim3(N < 256 ? ((N + 63) / 64) * 64 : 256),
+                     (size_t)N * sizeof(float), (hipStream_t)stream, pts, N, C, keep, out, idx);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

@@ -1,0 +1,391 @@
+// LSTM recurrences on the matrix cores (fp32, v_mfma_f32_16x16x4_f32), PyTorch gate order i,f,g,o.
+//
+//  lstm_step_kernel   one timestep of a (bi)LSTM of any hidden size H (H % 32 == 0): gates = xproj_t +
+//                     h_{t-1}.W_hh^T, fused cell update.  Used for IMU_Net's 2x(2-layer, H=512) BiLSTMs
+//                     (reference Net/IMU_Net.py:58-62,77,82), 94 % of the path's FLOPs.  Both directions
+//                     in one launch; a workgroup owns 64 batch rows x 32 hidden units x 4 gates so the
+//                     cell update is register-local; workgroups that share a W_hh slice are placed on
+//                     one XCD (its L2 then holds 1/8 of W_hh).
+//  lstm64_fwd/bwd     whole-sequence persistent kernels for the three H=64 BiLSTMs of Upper_Net /
+//                     Lower_Net (Upper_Net.py:333, Lower_Net.py:91): batch rows are independent through
+//                     the recurrence, so a workgroup keeps W_hh (64 KB) in LDS, 16 rows of h in LDS and c
+//                     in registers and walks all T steps with no inter-workgroup traffic.
+#include "common.h"
+
+struct LstmStepP {
+  const float* hprev[2]; long hps;
+  const float* whh[2];
+  const float* xproj[2]; long xs;
+  float* hout[2]; long hos;
+  float* c[2];
+  int Bn, H, ndir;
+};
+
+#define SLD 36  // LDS row stride (floats) of the [row][k] staging tiles: 32 k + 4 pad
+
+__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
+  __shared__ __attribute__((aligned(16))) float As[2][64][SLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][128][SLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H;
+  const int nrb = (p.Bn + 63) / 64, nht = H / 32, npairs = p.ndir * nht;
+  int pair, rb;
+  {
+    const int wg = blockIdx.x;
+    if ((npairs & 7) == 0) {  // XCD-aware: blocks b and b+8 share an XCD; give each XCD whole (dir, hidden-tile) pairs
+      const int xcd = wg & 7, q = wg >> 3;
+      pair = xcd + 8 * (q / nrb);
+      rb = q % nrb;
+    } else {
+      pair = wg / nrb;
+      rb = wg % nrb;
+    }
+  }
+  const int d = pair / nht, ht = pair % nht;
+  const int j0 = ht * 32, r0 = rb * 64;
+  const float* hp = p.hprev[d];
+  const float* W = p.whh[d];
+
+  const int lk = (tid & 7) * 4, lr = tid >> 3;  // staging: 8 lanes cover one 128-B row segment
+  const bool a0_ok = (r0 + lr) < p.Bn, a1_ok = (r0 + lr + 32) < p.Bn;
+  const float* ap0 = hp + (long)(r0 + lr) * p.hps + lk;
+  const float* ap1 = hp + (long)(r0 + lr + 32) * p.hps + lk;
+  const float* wp0 = W + ((long)0 * H + j0 + lr) * H + lk;  // Bs row = gate*32 + jl  <->  W row gate*H + j0 + jl
+  const float* wp1 = W + ((long)1 * H + j0 + lr) * H + lk;
+  const float* wp2 = W + ((long)2 * H + j0 + lr) * H + lk;
+  const float* wp3 = W + ((long)3 * H + j0 + lr) * H + lk;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ra0, ra1, rb0, rb1, rb2, rb3;
+#define STEP_GLOAD(k0)                                                   \
+  do {                                                                   \
+    ra0 = a0_ok ? *reinterpret_cast<const float4*>(ap0 + (k0)) : zero4;  \
+    ra1 = a1_ok ? *reinterpret_cast<const float4*>(ap1 + (k0)) : zero4;  \
+    rb0 = *reinterpret_cast<const float4*>(wp0 + (k0));                  \
+    rb1 = *reinterpret_cast<const float4*>(wp1 + (k0));                  \
+    rb2 = *reinterpret_cast<const float4*>(wp2 + (k0));                  \
+    rb3 = *reinterpret_cast<const float4*>(wp3 + (k0));                  \
+  } while (0)
+#define STEP_SSTORE(buf)                                                 \
+  do {                                                                   \
+    *reinterpret_cast<float4*>(&As[buf][lr][lk]) = ra0;                  \
+    *reinterpret_cast<float4*>(&As[buf][lr + 32][lk]) = ra1;             \
+    *reinterpret_cast<float4*>(&Bs[buf][lr][lk]) = rb0;                  \
+    *reinterpret_cast<float4*>(&Bs[buf][lr + 32][lk]) = rb1;             \
+    *reinterpret_cast<float4*>(&Bs[buf][lr + 64][lk]) = rb2;             \
+    *reinterpret_cast<float4*>(&Bs[buf][lr + 96][lk]) = rb3;             \
+  } while (0)
+
+  const int rowbase = (wave & 1) * 32, hb = (wave >> 1) * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = H / 32;
+  STEP_GLOAD(0);
+  STEP_SSTORE(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) STEP_GLOAD((kt + 1) * 32);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      // k-permuted operands: lane group fq supplies k = 16*kb + 4*fq + s at MFMA step s (same map for A and B)
+      float4 a[2], b[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&As[buf][rowbase + i * 16 + fr][kb * 16 + 4 * fq]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const float4*>(&Bs[buf][g * 32 + hb + fr][kb * 16 + 4 * fq]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[g].x, acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[g].y, acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[g].z, acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[g].w, acc[i][g], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) STEP_SSTORE(buf ^ 1);
+    __syncthreads();
+  }
+
+  // fused cell update; C layout: col = lane&15 (hidden), row = (lane>>4)*4 + reg
+  const int j = j0 + hb + fr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = r0 + rowbase + i * 16 + fq * 4 + reg;
+      if (row < p.Bn) {
+        const float* xp = p.xproj[d] + (long)row * p.xs + j;
+        float gi = sigmoidf_(acc[i][0][reg] + xp[0]);
+        float gf = sigmoidf_(acc[i][1][reg] + xp[H]);
+        float gg = tanhf(acc[i][2][reg] + xp[2 * H]);
+        float go = sigmoidf_(acc[i][3][reg] + xp[3 * H]);
+        float* cp = p.c[d] + (long)row * H + j;
+        float cn = gf * (*cp) + gi * gg;
+        *cp = cn;
+        p.hout[d][(long)row * p.hos + j] = go * tanhf(cn);
+      }
+    }
+  }
+}
+
+extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, const float* hprev0, const float* hprev1,
+                               long hps, const float* whh0, const float* whh1, const float* xproj0,
+                               const float* xproj1, long xs, float* hout0, float* hout1, long hos, float* c0,
+                               float* c1) {
+  MMEGO_REQUIRE((ndir == 1 || ndir == 2) && Bn > 0 && H > 0 && (H % 32) == 0 && (hps % 4) == 0);
+  MMEGO_REQUIRE(hprev0 && whh0 && xproj0 && hout0 && c0);
+  MMEGO_REQUIRE((((uintptr_t)hprev0 | (uintptr_t)whh0) & 15) == 0);
+  if (ndir == 2) {
+    MMEGO_REQUIRE(hprev1 && whh1 && xproj1 && hout1 && c1);
+    MMEGO_REQUIRE((((uintptr_t)hprev1 | (uintptr_t)whh1) & 15) == 0);
+  }
+  LstmStepP p;
+  p.hprev[0] = hprev0; p.hprev[1] = hprev1; p.hps = hps;
+  p.whh[0] = whh0; p.whh[1] = whh1;
+  p.xproj[0] = xproj0; p.xproj[1] = xproj1; p.xs = xs;
+  p.hout[0] = hout0; p.hout[1] = hout1; p.hos = hos;
+  p.c[0] = c0; p.c[1] = c1;
+  p.Bn = Bn; p.H = H; p.ndir = ndir;
+  int grid = ndir * (H / 32) * cdiv(Bn, 64);
+  hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// H = 64 persistent sequence kernels
+// ---------------------------------------------------------------------------------------------
+struct Lstm64P {
+  const float* xproj[2]; long xs;
+  const float* whh[2];
+  const float* h0[2]; const float* c0[2];
+  float* out; long os;
+  float* hn[2]; float* cn[2];
+  float* gates[2]; float* cst[2]; float* hprev[2];
+  int B, T;
+};
+
+#define WLD 272  // 256 gate columns + 16: consecutive k rows land on disjoint bank halves
+
+__global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;              // [64 k][WLD]   Ws[k][n] = W_hh[n][k]
+  float* hs = smem + 64 * WLD;   // [64 k][16 rows]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = blockIdx.y, r0 = blockIdx.x * 16;
+  const int B = p.B, T = p.T;
+  const float* W = p.whh[d];
+  for (int i = tid; i < 256 * 16; i += 256) {  // 256 rows x 16 float4
+    int n = i >> 4, k4 = (i & 15) * 4;
+    float4 v = *reinterpret_cast<const float4*>(W + n * 64 + k4);
+    Ws[(k4 + 0) * WLD + n] = v.x; Ws[(k4 + 1) * WLD + n] = v.y;
+    Ws[(k4 + 2) * WLD + n] = v.z; Ws[(k4 + 3) * WLD + n] = v.w;
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  const int j = wave * 16 + fr;  // hidden unit of this lane
+  float creg[4], hreg[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    int row = r0 + fq * 4 + reg;
+    bool ok = row < B;
+    creg[reg] = (ok && p.c0[d]) ? p.c0[d][row * 64 + j] : 0.f;
+    hreg[reg] = (ok && p.h0[d]) ? p.h0[d][row * 64 + j] : 0.f;
+    hs[j * 16 + fq * 4 + reg] = hreg[reg];
+  }
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int tt = d == 0 ? s : T - 1 - s;
+    float xp[4][4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      int row = r0 + fq * 4 + reg;
+      if (row < B) {
+        const float* x = p.xproj[d] + ((long)row * T + tt) * p.xs + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xp[g][reg] = x[g * 64];
+        if (p.hprev[d]) p.hprev[d][((long)row * T + tt) * 64 + j] = hreg[reg];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xp[g][reg] = 0.f;
+      }
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      const int k = k4 * 4 + fq;
+      float a = hs[k * 16 + fr];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float b = Ws[k * WLD + g * 64 + wave * 16 + fr];
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[g], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // everyone has finished reading hs for this step
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      int row = r0 + fq * 4 + reg;
+      float gi = sigmoidf_(acc[0][reg] + xp[0][reg]);
+      float gf = sigmoidf_(acc[1][reg] + xp[1][reg]);
+      float gg = tanhf(acc[2][reg] + xp[2][reg]);
+      float go = sigmoidf_(acc[3][reg] + xp[3][reg]);
+      float cn = gf * creg[reg] + gi * gg;
+      float hn = go * tanhf(cn);
+      creg[reg] = cn;
+      hreg[reg] = hn;
+      hs[j * 16 + fq * 4 + reg] = hn;
+      if (row < B) {
+        p.out[((long)row * T + tt) * p.os + d * 64 + j] = hn;
+        if (p.gates[d]) {
+          float* gs = p.gates[d] + ((long)tt * B + row) * 256 + j;
+          gs[0] = gi; gs[64] = gf; gs[128] = gg; gs[192] = go;
+          p.cst[d][((long)tt * B + row) * 64 + j] = cn;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    int row = r0 + fq * 4 + reg;
+    if (row < B) {
+      if (p.hn[d]) p.hn[d][row * 64 + j] = hreg[reg];
+      if (p.cn[d]) p.cn[d][row * 64 + j] = creg[reg];
+    }
+  }
+}
+
+extern "C" int mmego_lstm64_forward(void* stream, int B, int T, const float* xproj0, const float* xproj1, long xs,
+                                    const float* whh0, const float* whh1, const float* h0_0, const float* h0_1,
+                                    const float* c0_0, const float* c0_1, float* out, long os, float* hn0, float* hn1,
+                                    float* cn0, float* cn1, float* gates0, float* gates1, float* cst0, float* cst1,
+                                    float* hprev0, float* hprev1) {
+  MMEGO_REQUIRE(B > 0 && T > 0 && xproj0 && xproj1 && whh0 && whh1 && out);
+  MMEGO_REQUIRE((((uintptr_t)whh0 | (uintptr_t)whh1) & 15) == 0);
+  MMEGO_REQUIRE((gates0 == nullptr) == (cst0 == nullptr) && (gates1 == nullptr) == (cst1 == nullptr));
+  Lstm64P p;
+  p.xproj[0] = xproj0; p.xproj[1] = xproj1; p.xs = xs;
+  p.whh[0] = whh0; p.whh[1] = whh1;
+  p.h0[0] = h0_0; p.h0[1] = h0_1; p.c0[0] = c0_0; p.c0[1] = c0_1;
+  p.out = out; p.os = os;
+  p.hn[0] = hn0; p.hn[1] = hn1; p.cn[0] = cn0; p.cn[1] = cn1;
+  p.gates[0] = gates0; p.gates[1] = gates1; p.cst[0] = cst0; p.cst[1] = cst1;
+  p.hprev[0] = hprev0; p.hprev[1] = hprev1;
+  p.B = B; p.T = T;
+  size_t lds = (size_t)(64 * WLD + 64 * 16) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm64_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lstm64_fwd_kernel, dim3(cdiv(B, 16), 2), dim3(256), lds, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+struct Lstm64BwdP {
+  const float* dout; long dos;
+  const float* gates[2]; const float* cst[2]; const float* c0[2];
+  const float* whh[2];
+  float* dgates[2]; long dgs;
+  int B, T;
+};
+
+#define NLD 80  // W_hh natural rows [n][64 k] + 16 pad
+
+__global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wn = smem;               // [256 n][NLD]  natural W_hh rows
+  float* dgs = smem + 256 * NLD;  // [256 n][16 rows]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = blockIdx.y, r0 = blockIdx.x * 16;
+  const int B = p.B, T = p.T;
+  const float* W = p.whh[d];
+  for (int i = tid; i < 256 * 16; i += 256) {
+    int n = i >> 4, k4 = (i & 15) * 4;
+    *reinterpret_cast<float4*>(&Wn[n * NLD + k4]) = *reinterpret_cast<const float4*>(W + n * 64 + k4);
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  const int j = wave * 16 + fr;
+  float dcreg[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dhrec = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int s = T - 1; s >= 0; --s) {
+    const int tt = d == 0 ? s : T - 1 - s;
+    const int tprev = d == 0 ? tt - 1 : tt + 1;  // time index whose cell state fed this step
+    float dg4[4][4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      int row = r0 + fq * 4 + reg;
+      if (row < B) {
+        float dh = p.dout[((long)row * T + tt) * p.dos + d * 64 + j] + dhrec[reg];
+        const float* gs = p.gates[d] + ((long)tt * B + row) * 256 + j;
+        float gi = gs[0], gf = gs[64], gg = gs[128], go = gs[192];
+        float c = p.cst[d][((long)tt * B + row) * 64 + j];
+        float cprev = (s > 0) ? p.cst[d][((long)tprev * B + row) * 64 + j] : (p.c0[d] ? p.c0[d][row * 64 + j] : 0.f);
+        float tc = tanhf(c);
+        float dc = dcreg[reg] + dh * go * (1.f - tc * tc);
+        dg4[0][reg] = dc * gg * gi * (1.f - gi);
+        dg4[1][reg] = dc * cprev * gf * (1.f - gf);
+        dg4[2][reg] = dc * gi * (1.f - gg * gg);
+        dg4[3][reg] = dh * tc * go * (1.f - go);
+        dcreg[reg] = dc * gf;
+        float* dst = p.dgates[d] + ((long)row * T + tt) * p.dgs + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g * 64] = dg4[g][reg];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dg4[g][reg] = 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dgs[(g * 64 + j) * 16 + fq * 4 + reg] = dg4[g][reg];
+    }
+    __syncthreads();
+    // dh_rec[row][k] = sum_n dgates[row][n] * W_hh[n][k]; this wave owns k in [16*wave, 16*wave+16)
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int n4 = 0; n4 < 64; n4 += 2) {
+      int n = n4 * 4 + fq;
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dgs[n * 16 + fr], Wn[n * NLD + wave * 16 + fr], a0, 0, 0, 0);
+      n += 4;
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dgs[n * 16 + fr], Wn[n * NLD + wave * 16 + fr], a1, 0, 0, 0);
+    }
+    dhrec = a0 + a1;
+    __syncthreads();
+  }
+}
+
+extern "C" int mmego_lstm64_backward(void* stream, int B, int T, const float* dout, long dos, const float* gates0,
+                                     const float* gates1, const float* cst0, const float* cst1, const float* c0_0,
+                                     const float* c0_1, const float* whh0, const float* whh1, float* dgates0,
+                                     float* dgates1, long dgs) {
+  MMEGO_REQUIRE(B > 0 && T > 0 && dout && gates0 && gates1 && cst0 && cst1 && whh0 && whh1 && dgates0 && dgates1);
+  MMEGO_REQUIRE((((uintptr_t)whh0 | (uintptr_t)whh1) & 15) == 0);
+  Lstm64BwdP p;
+  p.dout = dout; p.dos = dos;
+  p.gates[0] = gates0; p.gates[1] = gates1; p.cst[0] = cst0; p.cst[1] = cst1;
+  p.c0[0] = c0_0; p.c0[1] = c0_1;
+  p.whh[0] = whh0; p.whh[1] = whh1;
+  p.dgates[0] = dgates0; p.dgates[1] = dgates1; p.dgs = dgs;
+  p.B = B; p.T = T;
+  size_t lds = (size_t)(256 * NLD + 256 * 16) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm64_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lstm64_bwd_kernel, dim3(cdiv(B, 16), 2), dim3(256), lds, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

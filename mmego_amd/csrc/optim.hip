@@ -1,0 +1,99 @@
+// Fused multi-tensor Adam over one flat parameter buffer (replaces torch.optim.Adam's foreach chain,
+// reference Processor/Train/Train_Upper.py:60,182), plus the dropout mask of the LSTM inter-layer dropout.
+// Pure HBM streaming: 16 B/param read (p,g,m,v) + 12 B/param written (p,m,v) = 28 B/param, float4 accesses,
+// grid-stride over <= 2048 workgroups.
+#include "common.h"
+
+// state[0] = step count (as double), state[1] = step_size = lr / (1 - b1^t), state[2] = sqrt(1 - b2^t)
+// Kept in device memory so that a captured HIP graph replays with the right bias corrections.
+__global__ void adam_tick_kernel(double* state, double lr, double beta1, double beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = state[0] + 1.0;
+    state[0] = t;
+    state[1] = lr / (1.0 - pow(beta1, t));
+    state[2] = sqrt(1.0 - pow(beta2, t));
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n4,
+                                                   const double* __restrict__ state, float beta2, float omb1,
+                                                   float omb2, float eps, float weight_decay) {
+  const float step_size = (float)state[1];
+  const float bc2_sqrt = (float)state[2];
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    float* pa = reinterpret_cast<float*>(&pp);
+    float* ga = reinterpret_cast<float*>(&gg);
+    float* ma = reinterpret_cast<float*>(&mm);
+    float* va = reinterpret_cast<float*>(&vv);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gr = ga[k];
+      if (weight_decay != 0.f) gr = gr + weight_decay * pa[k];
+      // torch: exp_avg.lerp_(grad, 1-beta1) == m + (g - m) * (1 - beta1)
+      ma[k] = ma[k] + (gr - ma[k]) * omb1;
+      va[k] = va[k] * beta2 + omb2 * gr * gr;
+      float denom = sqrtf(va[k]) / bc2_sqrt + eps;
+      pa[k] = pa[k] - step_size * (ma[k] / denom);
+    }
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+}
+
+// counter-based hash RNG (per element, per call seed): keep with probability 1-p, scale by 1/(1-p)
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ X, float* __restrict__ Y,
+                                                      float* __restrict__ mask, long n, float p,
+                                                      const unsigned long long* __restrict__ seed_ctr) {
+  const unsigned long long seed = seed_ctr[0];
+  const float keep_scale = 1.0f / (1.0f - p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned h = hash32((unsigned)i ^ hash32((unsigned)(seed & 0xffffffffU) + 0x9e3779b9U * (unsigned)(seed >> 32)));
+    float u = (h >> 8) * (1.0f / 16777216.0f);
+    float mk = u >= p ? keep_scale : 0.f;
+    mask[i] = mk;
+    Y[i] = X[i] * mk;
+  }
+}
+
+__global__ void seed_tick_kernel(unsigned long long* seed_ctr) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) seed_ctr[0] = seed_ctr[0] * 6364136223846793005ULL + 1442695040888963407ULL;
+}
+
+static inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+extern "C" int mmego_adam_step(void* stream, float* p, const float* g, float* m, float* v, long n, double* state,
+                               double lr, double beta1, double beta2, double eps, double weight_decay) {
+  MMEGO_REQUIRE(p && g && m && v && state && n > 0 && (n % 4) == 0);
+  MMEGO_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, state, lr, beta1, beta2);
+  MMEGO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, p, g, m, v, n / 4, state, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_dropout(void* stream, const float* X, float* Y, float* mask, long n, float p,
+                             unsigned long long* seed_ctr) {
+  MMEGO_REQUIRE(X && Y && mask && seed_ctr && n > 0 && p >= 0.f && p < 1.f);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(seed_tick_kernel, dim3(1), dim3(64), 0, st, seed_ctr);
+  MMEGO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, X, Y, mask, n, p, seed_ctr);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

@@ -1,0 +1,428 @@
+// Per-frame pooling / attention / graph kernels of Upper_Net and Lower_Net (fp32).
+//   attn_pool   : Linear(C,1) score, softmax over the group's points, weighted sum (Upper_Net.py:285-301,
+//                 163-177; IMU_Net.py:79-80)                      -- one workgroup per group, tile in LDS-free
+//                 two-pass form (scores by wave reductions, then a coalesced weighted column sum)
+//   group_sum   : sum / mean over the points of a group (Lower_Net.py:112-115: the degenerate Q6 gate, avg-pool)
+//   cross_attn  : softmax(Q K^T / 8) V with 64 query points and 15 joint keys per frame (Lower_Net.py:105-109);
+//                 K, V (and for backward Q, dO) staged in LDS, 4 lanes per query row
+//   graph_dA    : gradient of einsum('nkctv,kvw->nctw') wrt the (K,15,15) adjacency (GCN.py:62)
+//   im2col_t / col2im_t : 9-tap temporal unfold for the ST-GCN temporal conv (GCN.py:109-116)
+#include "common.h"
+
+// X [G, P, C]; w [C]; b scalar ptr -> vec [G, C], attn [G, P]
+__global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                            const float* __restrict__ bptr, int P, int C,
+                                                            float* __restrict__ vec, float* __restrict__ attn) {
+  extern __shared__ float sc[];  // [P] scores -> weights
+  __shared__ float red[8];
+  const long g = blockIdx.x;
+  const float* Xg = X + g * (long)P * C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const float b = bptr ? bptr[0] : 0.f;
+  for (int p = wave; p < P; p += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += Xg[(long)p * C + c] * w[c];
+    s = wave_sum(s);
+    if (lane == 0) sc[p] = s + b;
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) m = fmaxf(m, sc[p]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = red[0];
+  for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float e = expf(sc[p] - m);
+    sc[p] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = 0.f;
+  for (int i = 0; i < nw; ++i) sum += red[i];
+  const float inv = 1.0f / sum;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float a = sc[p] * inv;
+    attn[g * P + p] = a;
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int p = 0; p < P; ++p) acc += Xg[(long)p * C + c] * (sc[p] * inv);
+    vec[g * C + c] = acc;
+  }
+}
+
+// dvec [G, C] -> dX [G, P, C], partial_dw [G, C], partial_db [G]
+__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                            const float* __restrict__ attn,
+                                                            const float* __restrict__ dvec, int P, int C,
+                                                            float* __restrict__ dX, float* __restrict__ pdw,
+                                                            float* __restrict__ pdb) {
+  extern __shared__ float sh[];  // [P] da -> ds
+  __shared__ float red[8];
+  const long g = blockIdx.x;
+  const float* Xg = X + g * (long)P * C;
+  const float* dv = dvec + g * C;
+  const float* ag = attn + g * P;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int p = wave; p < P; p += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += Xg[(long)p * C + c] * dv[c];
+    s = wave_sum(s);
+    if (lane == 0) sh[p] = s;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) dot += ag[p] * sh[p];
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  dot = 0.f;
+  for (int i = 0; i < nw; ++i) dot += red[i];
+  __syncthreads();
+  float dbs = 0.f;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float ds = ag[p] * (sh[p] - dot);
+    sh[p] = ds;
+    dbs += ds;
+  }
+  dbs = wave_sum(dbs);
+  if (lane == 0) red[wave] = dbs;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    pdb[g] = s;
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float wc = w[c], dvc = dv[c];
+    float acc = 0.f;
+    for (int p = 0; p < P; ++p) {
+      float x = Xg[(long)p * C + c];
+      acc += sh[p] * x;
+      dX[(g * P + p) * (long)C + c] = ag[p] * dvc + sh[p] * wc;
+    }
+    pdw[g * C + c] = acc;
+  }
+}
+
+// Y[g, c] = scale * sum_p X[g, p, c]
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ X, int P, int C, float scale,
+                                                        float* __restrict__ Y, long ldy, long G) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  long g = i / C;
+  int c = (int)(i - g * C);
+  const float* x = X + g * (long)P * C + c;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += x[(long)p * C];
+  Y[g * ldy + c] = s * scale;
+}
+
+// dX[g, p, c] (+)= scale * dY[g, c]
+__global__ __launch_bounds__(256) void group_bcast_kernel(const float* __restrict__ dY, long lddy, int P, int C,
+                                                          float scale, float* __restrict__ dX, long G,
+                                                          int accumulate) {
+  long total = G * P * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long g = i / ((long)P * C);
+    float v = scale * dY[g * lddy + c];
+    dX[i] = accumulate ? dX[i] + v : v;
+  }
+}
+
+// ---- cross attention: Q [F,64,64]; K,V [F,15,64] -> O [F,64,64] written at ldo, P [F,64,15] -------------
+#define NQ 64
+#define NK 15
+#define DH 64
+
+__global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                             const float* __restrict__ V, float scale,
+                                                             float* __restrict__ O, long ldo, float* __restrict__ Pout) {
+  __shared__ float Ks[NK][DH + 1], Vs[NK][DH + 1];
+  const long f = blockIdx.x;
+  for (int i = threadIdx.x; i < NK * DH; i += 256) {
+    Ks[i / DH][i % DH] = K[f * NK * DH + i];
+    Vs[i / DH][i % DH] = V[f * NK * DH + i];
+  }
+  __syncthreads();
+  const int p = threadIdx.x >> 2, sub = threadIdx.x & 3;  // 4 lanes per query row, 16 channels each
+  const float* q = Q + (f * NQ + p) * DH + sub * 16;
+  float qr[16];
+  for (int c = 0; c < 16; ++c) qr[c] = q[c];
+  float s[NK];
+  float m = -INFINITY;
+  for (int j = 0; j < NK; ++j) {
+    float d = 0.f;
+    for (int c = 0; c < 16; ++c) d += qr[c] * Ks[j][sub * 16 + c];
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    s[j] = d * scale;
+    m = fmaxf(m, s[j]);
+  }
+  float sum = 0.f;
+  for (int j = 0; j < NK; ++j) { s[j] = expf(s[j] - m); sum += s[j]; }
+  const float inv = 1.0f / sum;
+  for (int j = 0; j < NK; ++j) s[j] *= inv;
+  if (sub == 0)
+    for (int j = 0; j < NK; ++j) Pout[(f * NQ + p) * NK + j] = s[j];
+  float* o = O + (f * NQ + p) * ldo + sub * 16;
+  for (int c = 0; c < 16; ++c) {
+    float acc = 0.f;
+    for (int j = 0; j < NK; ++j) acc += s[j] * Vs[j][sub * 16 + c];
+    o[c] = acc;
+  }
+}
+
+// dO read at lddo; -> dQ [F,64,64], dK, dV [F,15,64]
+__global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                             const float* __restrict__ V, const float* __restrict__ Pm,
+                                                             const float* __restrict__ dO, long lddo, float scale,
+                                                             float* __restrict__ dQ, float* __restrict__ dK,
+                                                             float* __restrict__ dV) {
+  __shared__ float Ks[NK][DH + 1], Vs[NK][DH + 1];
+  __shared__ float Qs[NQ][DH + 1], dOs[NQ][DH + 1];
+  __shared__ float Ps[NQ][NK + 1], dSs[NQ][NK + 1];
+  const long f = blockIdx.x;
+  for (int i = threadIdx.x; i < NK * DH; i += 256) {
+    Ks[i / DH][i % DH] = K[f * NK * DH + i];
+    Vs[i / DH][i % DH] = V[f * NK * DH + i];
+  }
+  for (int i = threadIdx.x; i < NQ * DH; i += 256) {
+    Qs[i / DH][i % DH] = Q[f * NQ * DH + i];
+    dOs[i / DH][i % DH] = dO[(f * NQ + i / DH) * lddo + (i % DH)];
+  }
+  for (int i = threadIdx.x; i < NQ * NK; i += 256) Ps[i / NK][i % NK] = Pm[f * NQ * NK + i];
+  __syncthreads();
+  const int p = threadIdx.x >> 2, sub = threadIdx.x & 3;
+  float dP[NK];
+  float dot = 0.f;
+  for (int j = 0; j < NK; ++j) {
+    float d = 0.f;
+    for (int c = 0; c < 16; ++c) d += dOs[p][sub * 16 + c] * Vs[j][sub * 16 + c];
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    dP[j] = d;
+    dot += Ps[p][j] * d;
+  }
+  for (int j = 0; j < NK; ++j) {
+    dP[j] = Ps[p][j] * (dP[j] - dot) * scale;  // dS
+    if (sub == 0) dSs[p][j] = dP[j];
+  }
+  float* dq = dQ + (f * NQ + p) * DH + sub * 16;
+  for (int c = 0; c < 16; ++c) {
+    float acc = 0.f;
+    for (int j = 0; j < NK; ++j) acc += dP[j] * Ks[j][sub * 16 + c];
+    dq[c] = acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NK * DH; i += 256) {
+    const int j = i / DH, c = i % DH;
+    float av = 0.f, ak = 0.f;
+    for (int pp = 0; pp < NQ; ++pp) {
+      av += Ps[pp][j] * dOs[pp][c];
+      ak += dSs[pp][j] * Qs[pp][c];
+    }
+    dV[f * NK * DH + i] = av;
+    dK[f * NK * DH + i] = ak;
+  }
+}
+
+// dA[k, v, w] = sum_{g, c} Z[g, v, k*C + c] * dY[g, w, c]     Z [G, V, K*C], dY [G, V, C]
+__global__ __launch_bounds__(256) void graph_dA_kernel(const float* __restrict__ Z, const float* __restrict__ dY, long G,
+                                                       int V, int Kk, int C, float* __restrict__ dA) {
+  __shared__ double red[4];
+  const int w = blockIdx.x % V, v = (blockIdx.x / V) % V, k = blockIdx.x / (V * V);
+  double acc = 0.0;
+  const long total = G * C;
+  for (long i = threadIdx.x; i < total; i += blockDim.x) {
+    long g = i / C;
+    int c = (int)(i - g * C);
+    acc += (double)(Z[(g * V + v) * (long)(Kk * C) + k * C + c] * dY[(g * V + w) * (long)C + c]);
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dA[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+// col[(b,t,v), ci*taps + tap] = X[b, t+tap-half, v, ci]  (zero outside)      X [B,T,V,C]
+__global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__ X, int B, int T, int V, int C, int taps,
+                                                       float* __restrict__ col) {
+  const long total = (long)B * T * V * C * taps;
+  const int half = taps / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int tap = (int)(i % taps);
+    long r = i / taps;
+    int ci = (int)(r % C);
+    long row = r / C;
+    int v = (int)(row % V);
+    long bt = row / V;
+    int t = (int)(bt % T);
+    long b = bt / T;
+    int ts = t + tap - half;
+    col[i] = (ts >= 0 && ts < T) ? X[((b * T + ts) * V + v) * (long)C + ci] : 0.f;
+  }
+}
+
+// dX[b,t,v,ci] = sum_tap dcol[(b, t-tap+half, v), ci*taps + tap]
+__global__ __launch_bounds__(256) void col2im_t_kernel(const float* __restrict__ dcol, int B, int T, int V, int C,
+                                                       int taps, float* __restrict__ dX) {
+  const long total = (long)B * T * V * C;
+  const int half = taps / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int ci = (int)(i % C);
+    long row = i / C;
+    int v = (int)(row % V);
+    long bt = row / V;
+    int t = (int)(bt % T);
+    long b = bt / T;
+    float acc = 0.f;
+    for (int tap = 0; tap < taps; ++tap) {
+      int to = t - tap + half;
+      if (to >= 0 && to < T) acc += dcol[(((b * T + to) * V + v) * (long)C + ci) * taps + tap];
+    }
+    dX[i] = acc;
+  }
+}
+
+// out[b][c][r] = in[b][r][c]
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                long Bn, int R, int C) {
+  const long total = Bn * R * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i % R);
+    long q = i / R;
+    int c = (int)(q % C);
+    long b = q / C;
+    out[i] = in[(b * R + r) * (long)C + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const float* a, const float* b, float* out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+
+__global__ void inc_i64_kernel(long long* x, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += 1;
+}
+
+static inline int ew_blocks(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+extern "C" int mmego_attn_pool_forward(void* stream, const float* X, const float* w, const float* b, long G, int P, int C,
+                                       float* vec, float* attn) {
+  MMEGO_REQUIRE(X && w && vec && attn && G > 0 && P > 0 && C > 0 && P <= 8192);
+  hipLaunchKernelGGL(attn_pool_fwd_kernel, dim3((unsigned)G), dim3(256), (size_t)P * sizeof(float), (hipStream_t)stream,
+                     X, w, b, P, C, vec, attn);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_attn_pool_backward(void* stream, const float* X, const float* w, const float* attn,
+                                        const float* dvec, long G, int P, int C, float* dX, float* pdw, float* pdb) {
+  MMEGO_REQUIRE(X && w && attn && dvec && dX && pdw && pdb && G > 0 && P > 0 && C > 0 && P <= 8192);
+  hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3((unsigned)G), dim3(256), (size_t)P * sizeof(float), (hipStream_t)stream,
+                     X, w, attn, dvec, P, C, dX, pdw, pdb);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_group_sum(void* stream, const float* X, long G, int P, int C, float scale, float* Y, long ldy) {
+  MMEGO_REQUIRE(X && Y && G > 0 && P > 0 && C > 0);
+  hipLaunchKernelGGL(group_sum_kernel, dim3(cdiv(G * C, 256)), dim3(256), 0, (hipStream_t)stream, X, P, C, scale, Y, ldy, G);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_group_bcast(void* stream, const float* dY, long lddy, long G, int P, int C, float scale, float* dX,
+                                 int accumulate) {
+  MMEGO_REQUIRE(dY && dX && G > 0 && P > 0 && C > 0);
+  hipLaunchKernelGGL(group_bcast_kernel, dim3(ew_blocks(G * P * C)), dim3(256), 0, (hipStream_t)stream, dY, lddy, P, C,
+                     scale, dX, G, accumulate);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_cross_attn_forward(void* stream, const float* Q, const float* K, const float* V, long F, float scale,
+                                        float* O, long ldo, float* P) {
+  MMEGO_REQUIRE(Q && K && V && O && P && F > 0);
+  hipLaunchKernelGGL(cross_attn_fwd_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, const float* V, const float* P,
+                                         const float* dO, long lddo, long F, float scale, float* dQ, float* dK,
+                                         float* dV) {
+  MMEGO_REQUIRE(Q && K && V && P && dO && dQ && dK && dV && F > 0);
+  hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, P, dO, lddo,
+                     scale, dQ, dK, dV);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* dA) {
+  MMEGO_REQUIRE(Z && dY && dA && G > 0 && V > 0 && K > 0 && C > 0);
+  hipLaunchKernelGGL(graph_dA_kernel, dim3(K * V * V), dim3(256), 0, (hipStream_t)stream, Z, dY, G, V, K, C, dA);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_im2col_t(void* stream, const float* X, int B, int T, int V, int C, int taps, float* col) {
+  MMEGO_REQUIRE(X && col && B > 0 && T > 0 && V > 0 && C > 0 && taps > 0 && (taps & 1));
+  hipLaunchKernelGGL(im2col_t_kernel, dim3(ew_blocks((long)B * T * V * C * taps)), dim3(256), 0, (hipStream_t)stream, X, B,
+                     T, V, C, taps, col);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_col2im_t(void* stream, const float* dcol, int B, int T, int V, int C, int taps, float* dX) {
+  MMEGO_REQUIRE(dcol && dX && B > 0 && T > 0 && V > 0 && C > 0 && taps > 0 && (taps & 1));
+  hipLaunchKernelGGL(col2im_t_kernel, dim3(ew_blocks((long)B * T * V * C)), dim3(256), 0, (hipStream_t)stream, dcol, B, T,
+                     V, C, taps, dX);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_transpose_batched(void* stream, const float* in, float* out, long Bn, int R, int C) {
+  MMEGO_REQUIRE(in && out && Bn > 0 && R > 0 && C > 0);
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(ew_blocks(Bn * R * C)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     Bn, R, C);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_mul(void* stream, const float* a, const float* b, float* out, long n) {
+  MMEGO_REQUIRE(a && b && out && n > 0);
+  hipLaunchKernelGGL(mul_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_add(void* stream, const float* a, const float* b, float* out, long n) {
+  MMEGO_REQUIRE(a && b && out && n > 0);
+  hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_inc_i64(void* stream, long long* x, long n) {
+  MMEGO_REQUIRE(x && n > 0);
+  hipLaunchKernelGGL(inc_i64_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, x, n);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

@@ -1,0 +1,556 @@
+"""IMUNet / UpperNet / LowerNet on the MI355X HIP path.
+
+Drop-in surface: class names, constructor and forward signatures, return tuples and state_dict
+keys/shapes of the reference's Net/IMU_Net.py:50-94, Net/Upper_Net.py:367-388 and
+Net/Lower_Net.py:170-239 (checked against the shipped checkpoints in tests/).  The sub-modules are
+parameter containers only (their initialisation order matches the reference, so torch.manual_seed gives
+the same weights); every forward/backward below is a hand-written sequence of HIP kernels from
+libmmego_hip.so.  There is no CPU path: calling a net on a CPU tensor raises.
+
+Reference quirks reproduced: Q1 in-place head transform of the caller's `x`,
+Q2 body row n % B, Q4 FK walk order, Q6 degenerate fusion gate, Q7 unused fc3 / ignored h0 arguments,
+Q8 re-view (not permute) of the ST-GCN output.
+"""
+import time
+
+import torch
+import torch.nn as nn
+
+from . import blocks, hip, ops
+from .blocks import LstmParams
+from .params import FlatParams
+from .skeleton import JOINTS_UPPER, LOWER_POINTS, gcn_adjacency
+
+
+def _require_gpu(t, who):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError("%s runs on the MI355X HIP path only (got a %s tensor); there is no CPU fallback"
+                           % (who, getattr(t, "device", type(t))))
+    hip.lib()
+
+
+def _f32c(t):
+    return t.contiguous() if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+
+class _NetBase(nn.Module):
+    """Shared plumbing: flat parameters, arenas, autograd bridge, save/load."""
+
+    def __init__(self):
+        super().__init__()
+        self._flat = None
+        self._arenas = {}
+        self._seed = None
+        self.lstm_dropout = None      # None -> use the LstmParams.dropout value in training mode
+
+    # -- storage -------------------------------------------------------------------------------
+    def flat(self):
+        if self._flat is None:
+            self._flat = FlatParams(self)
+        return self._flat.ensure()
+
+    def arena(self, name):
+        dev = next(self.parameters()).device
+        ar = self._arenas.get(name)
+        if ar is None or ar.device != dev:
+            ar = ops.Arena(dev)
+            self._arenas[name] = ar
+        return ar
+
+    def seed_counter(self):
+        dev = next(self.parameters()).device
+        if self._seed is None or self._seed.device != dev:
+            self._seed = torch.tensor([0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=dev)
+        return self._seed
+
+    def _drop_p(self, lstm):
+        if not self.training:
+            return 0.0
+        return float(lstm.dropout if self.lstm_dropout is None else self.lstm_dropout)
+
+    # -- checkpoint I/O (reference Net/*.py save/load; map_location handled correctly) ----------
+    def save(self, name=None):
+        if name is None:
+            name = time.strftime("checkpoints/%m%d_%H_%M_%S.pth")
+        torch.save(self.state_dict(), name)
+        return name
+
+    def load(self, pathname):
+        dev = next(self.parameters()).device
+        self.load_state_dict(torch.load(pathname, map_location=dev))
+
+
+class _Bridge(torch.autograd.Function):
+    """One autograd node per net: forward/backward are the hand-written kernel pipelines."""
+
+    @staticmethod
+    def forward(ctx, net, nout, args, *params):
+        ctx.net = net
+        outs = net._forward_impl(*args)
+        ctx.mark_non_differentiable(*outs[nout:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if not ctx.net.training:
+            raise NotImplementedError("backward through an eval-mode net (running-stat BatchNorm) is not supported; "
+                                      "the reference detaches frozen nets (Train_Lower.py:195-196)")
+        ctx.net._backward_impl(grads[0])
+        ctx.net.flat().bind_grads()
+        return (None, None, None) + (None,) * len(ctx.net._flat.params)
+
+
+# =====================================================================================================
+# Upper_Net
+# =====================================================================================================
+class _Mlp3(nn.Module):
+    def __init__(self, dims):
+        super().__init__()
+        self.conv1 = nn.Conv1d(dims[0], dims[1], 1)
+        self.cb1 = nn.BatchNorm1d(dims[1])
+        self.conv2 = nn.Conv1d(dims[1], dims[2], 1)
+        self.cb2 = nn.BatchNorm1d(dims[2])
+        self.conv3 = nn.Conv1d(dims[2], dims[3], 1)
+        self.cb3 = nn.BatchNorm1d(dims[3])
+
+
+class PointNet(_Mlp3):
+    def __init__(self):
+        super().__init__((6, 8, 16, 24))
+
+
+class GlobalPointNet(_Mlp3):
+    def __init__(self):
+        super().__init__((28, 32, 48, 64))
+        self.attn = nn.Linear(64, 1)
+
+
+class GlobalModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.gpointnet = GlobalPointNet()
+        self.grnn = LstmParams(64, 64, 3, dropout=0.1, bidirectional=True)
+
+
+class MLPHead(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(128, 128)
+        self.fc2 = nn.Linear(128, 14 * 6 + 3)
+
+
+class UpperNet(_NetBase):
+    """forward(x[B,T,N,6], h0_g[6,B,64], c0_g[6,B,64], initial_body[B,20,3], R[B,T,3,3], t[B,T,3])
+    -> (l[B,T,15,3], q[B,T,14,3,3], global_weights[B*T,N,1], hn_g, cn_g).  MUTATES x (Q1)."""
+
+    def __init__(self):
+        super().__init__()
+        self.module0 = PointNet()
+        self.module1 = GlobalModule()
+        self.mlpHead = MLPHead()
+
+    def forward(self, x, h0_g, c0_g, initial_body, R, t):
+        _require_gpu(x, "UpperNet")
+        args = (x, h0_g, c0_g, initial_body, R, t)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            self.flat()
+            return _Bridge.apply(self, 1, args, *self._flat.params)
+        return self._forward_impl(*args, stash=False)
+
+    # -- pipelines ---------------------------------------------------------------------------------
+    def _forward_impl(self, x, h0, c0, body, R, t, stash=True):
+        self.flat()
+        training = self.training
+        ar = self.arena("train" if stash else "eval")
+        if not (x.dtype == torch.float32 and x.is_contiguous()):
+            raise ValueError("UpperNet: x must be a contiguous fp32 tensor (it is transformed in place)")
+        B, T, N, Cx = x.shape
+        F, rows = B * T, B * T * N
+        R, t, body = _f32c(R), _f32c(t), _f32c(body)
+        h0 = _f32c(h0) if h0 is not None else None
+        c0 = _f32c(c0) if c0 is not None else None
+        ops.transform2h_(x, R, t)                                   # Q1: in place on the caller's tensor
+        pts = x.view(rows, Cx)
+        if stash:
+            keep = ar.get("pts", (rows, Cx))
+            ops.copy2d(pts, keep)
+            pts = keep
+        feats = ar.get("feats", (rows, 28))
+        ops.copy2d(pts[:, :4], feats[:, :4])
+        blocks.mlp3_forward(ar, "m0", self.module0, pts, feats[:, 4:28], training)
+        g3 = ar.get("g3", (rows, 64))
+        blocks.mlp3_forward(ar, "gp", self.module1.gpointnet, feats, g3, training)
+        vec = ar.get("vec", (F, 64))
+        attn = torch.empty((F, N, 1), dtype=torch.float32, device=x.device)
+        blocks.attn_pool_forward(g3, self.module1.gpointnet.attn, F, N, 64, vec, attn)
+        lstm = self.module1.grnn
+        seq, hn, cn = blocks.lstm64_forward(ar, "grnn", lstm, vec, B, T, h0, c0, stash, self._drop_p(lstm) if stash else 0.0,
+                                            self.seed_counter())
+        h1 = ar.get("h1", (F, 128))
+        ops.linear(seq, self.mlpHead.fc1.weight, self.mlpHead.fc1.bias, h1, relu=True)
+        y = ar.get("y", (F, 87))
+        ops.linear(h1, self.mlpHead.fc2.weight, self.mlpHead.fc2.bias, y)
+        q = torch.empty((B, T, 14, 3, 3), dtype=torch.float32, device=x.device)
+        jh = ar.get("jh", (F, 15, 3))
+        hip.call("head_fk_forward", 0, y, body, B, F, q, jh)
+        l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=x.device)
+        ops.rotate_points(jh, l, R, t, transpose=True)
+        if training:
+            self._flat.bump_bn_counters()
+        if stash:
+            self._saved = (B, T, N, R, body, c0, attn)
+        return l, q, attn, hn, cn
+
+    def _backward_impl(self, dl):
+        ar = self.arena("train")
+        B, T, N, R, body, c0, attn = self._saved
+        F, rows = B * T, B * T * N
+        G = self._flat.grad
+        dl = _f32c(dl)
+        djh = ar.get("djh", (F, 15, 3))
+        ops.rotate_points(dl, djh, R, None, transpose=False)
+        y, h1 = ar.get("y", (F, 87)), ar.get("h1", (F, 128))
+        dy = ar.get("dy", (F, 87))
+        hip.call("head_fk_backward", 0, y, body, B, F, djh, dy)
+        dh1 = ar.get("dh1", (F, 128))
+        blocks.linear_backward(dy, h1, self.mlpHead.fc2, G, dh1)
+        ops.relu_mask_(dh1, h1)
+        seq = ar.get("grnn.out2", (F, 128))
+        dseq = ar.get("dseq", (F, 128))
+        blocks.linear_backward(dh1, seq, self.mlpHead.fc1, G, dseq)
+        lstm = self.module1.grnn
+        vec = ar.get("vec", (F, 64))
+        dvec = blocks.lstm64_backward(ar, "grnn", lstm, vec, B, T, c0, dseq, G, self._drop_p(lstm), True)
+        g3 = ar.get("g3", (rows, 64))
+        dg3 = ar.get("dg3", (rows, 64))
+        blocks.attn_pool_backward(ar, "gpool", g3, self.module1.gpointnet.attn, attn, dvec, F, N, 64, dg3, G)
+        feats = ar.get("feats", (rows, 28))
+        dfeats = blocks.mlp3_backward(ar, "gp", self.module1.gpointnet, feats, g3, dg3, G, True)
+        pts = ar.get("pts", (rows, 6))
+        blocks.mlp3_backward(ar, "m0", self.module0, pts, feats[:, 4:28], dfeats[:, 4:28], G, False)
+
+
+# =====================================================================================================
+# Lower_Net
+# =====================================================================================================
+class BasePointNet(_Mlp3):
+    def __init__(self, hidden_dim=64):
+        super().__init__((6, 16, 32, hidden_dim - 3))
+
+
+class PointEncoder(nn.Module):
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.module0 = BasePointNet(hidden_dim)
+
+
+class _GraphConv(nn.Module):
+    def __init__(self, cin, cout, K):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout * K, kernel_size=(1, 1))
+
+
+class StGcnBlock(nn.Module):
+    """Parameter container of one st_gcn block (reference Net/GCN.py:67-147)."""
+
+    def __init__(self, cin, cout, K, taps=9):
+        super().__init__()
+        self.cin, self.cout, self.K, self.taps = cin, cout, K, taps
+        self.gcn = _GraphConv(cin, cout, K)
+        self.tcn = nn.ModuleDict({"0": nn.BatchNorm2d(cout),
+                                  "2": nn.Conv2d(cout, cout, (taps, 1), (1, 1), (taps // 2, 0)),
+                                  "3": nn.BatchNorm2d(cout)})
+        self.residual = nn.ModuleDict({"0": nn.Conv2d(cin, cout, kernel_size=1, stride=(1, 1)),
+                                       "1": nn.BatchNorm2d(cout)})
+
+
+class Model(nn.Module):
+    """ST-GCN container (reference Net/GCN.py:281-355); `extract_feature` runs inside LowerNet's pipeline."""
+
+    def __init__(self, in_channels, hidden_dim, graph_args={}, edge_importance_weighting=True, **kwargs):
+        super().__init__()
+        A = torch.tensor(gcn_adjacency(graph_args.get("strategy", "uniform")), dtype=torch.float32)
+        self.register_buffer("A", A)
+        K = A.size(0)
+        self.data_bn = nn.BatchNorm1d(in_channels * A.size(1))
+        self.gcn_networks = nn.ModuleList((StGcnBlock(in_channels, 32, K), StGcnBlock(32, 64, K),
+                                           StGcnBlock(64, 128, K)))
+        if edge_importance_weighting:
+            self.edge_importance = nn.ParameterList([nn.Parameter(torch.ones(A.size())) for _ in self.gcn_networks])
+        else:
+            raise NotImplementedError("edge_importance_weighting=False is not used by the reference nets")
+        self.fcn = nn.Conv2d(128, hidden_dim, kernel_size=1)
+
+
+class KeyEncoder(nn.Module):
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.gcn = Model(in_channels=3, hidden_dim=hidden_dim, graph_args={"strategy": "distance"})
+
+
+class FusionModule(nn.Module):
+    def __init__(self, hidden_dim=64):
+        super().__init__()
+        self.fc0 = nn.Linear(hidden_dim * 2 + JOINTS_UPPER * 3, 128)
+        self.fc1 = nn.Linear(128, 64)
+        self.to_q = nn.Linear(hidden_dim, hidden_dim, bias=True)
+        self.to_k = nn.Linear(hidden_dim, hidden_dim, bias=True)
+        self.to_v = nn.Linear(hidden_dim, hidden_dim, bias=True)
+        self.scale = hidden_dim ** -0.5
+        self.fc2 = nn.Linear(64, 6 * 6 + 2 * 3)
+        self.attn = nn.Linear(hidden_dim * 2, 1)       # Q6: its softmax runs over a size-1 axis -> no effect
+        self.rnn_pk = LstmParams(hidden_dim * 3, hidden_dim, 3, dropout=0.1, bidirectional=True)
+
+
+class LowerNet(_NetBase):
+    """forward(upper_l[B,T,15,3], x[B,T,N,6], h0_p, c0_p, h0_k, c0_k, initial_body, R, t) -> (l[B,T,8,3], q[B,T,6,3,3]).
+    The four state arguments are ignored, as in the reference (Q7).  MUTATES x (Q1)."""
+
+    def __init__(self, hidden_dim):
+        super().__init__()
+        if hidden_dim != 64:
+            raise ValueError("LowerNet: hidden_dim must be 64 (the reference hard-codes BatchNorm1d(61))")
+        self.pointEncoder = PointEncoder(hidden_dim)
+        self.keyEncoder = KeyEncoder(hidden_dim)
+        self.fusion = FusionModule(hidden_dim)
+
+    def forward(self, upper_l, x, h0_p, c0_p, h0_k, c0_k, initial_body, R, t):
+        _require_gpu(x, "LowerNet")
+        args = (upper_l, x, initial_body, R, t)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            self.flat()
+            return _Bridge.apply(self, 1, args, *self._flat.params)
+        return self._forward_impl(*args, stash=False)
+
+    def _forward_impl(self, upper_l, x, body, R, t, stash=True):
+        self.flat()
+        training = self.training
+        ar = self.arena("train" if stash else "eval")
+        if not (x.dtype == torch.float32 and x.is_contiguous()):
+            raise ValueError("LowerNet: x must be a contiguous fp32 tensor (it is transformed in place)")
+        B, T, N, Cx = x.shape
+        F = B * T
+        V = JOINTS_UPPER
+        dev = x.device
+        R, t, body = _f32c(R), _f32c(t), _f32c(body)
+        ops.transform2h_(x, R, t)                                     # Q1 (second transform after UpperNet)
+        up = ar.get("up", (F, V * 3))
+        ops.copy2d(_f32c(upper_l).view(F, V * 3), up)
+        ops.transform2h_(up.view(F, V, 3), R, t)
+        sel = ar.get("sel", (F * LOWER_POINTS, Cx))
+        idx = ar.get("sel_idx", (F, LOWER_POINTS), dtype=torch.int64)
+        hip.call("topk_rows", x, F, N, Cx, LOWER_POINTS, sel, idx)
+        self.last_select_idx = idx
+        prow = F * LOWER_POINTS
+        p_vec = ar.get("p_vec", (prow, 64))
+        ops.copy2d(sel[:, :3], p_vec[:, :3])
+        blocks.mlp3_forward(ar, "base", self.pointEncoder.module0, sel, p_vec[:, 3:64], training)
+
+        k_vec = self._gcn_forward(ar, up, B, T, training)            # [F*15, 64] in the re-viewed layout (Q8)
+
+        fu = self.fusion
+        Qm, Km, Vm = ar.get("Qm", (prow, 64)), ar.get("Km", (F * V, 64)), ar.get("Vm", (F * V, 64))
+        ops.linear(p_vec, fu.to_q.weight, fu.to_q.bias, Qm)
+        ops.linear(k_vec, fu.to_k.weight, fu.to_k.bias, Km)
+        ops.linear(k_vec, fu.to_v.weight, fu.to_v.bias, Vm)
+        both = ar.get("both", (prow, 128))
+        ops.copy2d(p_vec, both[:, :64])
+        Pm = ar.get("Pm", (F, LOWER_POINTS, V))
+        hip.call("cross_attn_forward", Qm, Km, Vm, F, float(fu.scale), both[:, 64:], 128, Pm)
+        ak = ar.get("ak", (F, 192))
+        hip.call("group_sum", both, F, LOWER_POINTS, 128, 1.0, ak, 192)            # Q6: gate == 1 -> plain sum
+        hip.call("group_sum", k_vec, F, V, 64, 1.0 / V, ak[:, 128:], 192)
+        lstm = fu.rnn_pk
+        seq, _, _ = blocks.lstm64_forward(ar, "rnn", lstm, ak, B, T, None, None, stash, self._drop_p(lstm) if stash else 0.0,
+                                          self.seed_counter())
+        cat = ar.get("cat", (F, 173))
+        ops.copy2d(seq, cat[:, :128])
+        ops.copy2d(up, cat[:, 128:173])
+        f0, f1, y = ar.get("f0", (F, 128)), ar.get("f1", (F, 64)), ar.get("y", (F, 42))
+        ops.linear(cat, fu.fc0.weight, fu.fc0.bias, f0, relu=True)
+        ops.linear(f0, fu.fc1.weight, fu.fc1.bias, f1, relu=True)
+        ops.linear(f1, fu.fc2.weight, fu.fc2.bias, y)
+        q = torch.empty((B, T, 6, 3, 3), dtype=torch.float32, device=dev)
+        jh = ar.get("jh", (F, 8, 3))
+        hip.call("head_fk_forward", 1, y, body, B, F, q, jh)
+        l = torch.empty((B, T, 8, 3), dtype=torch.float32, device=dev)
+        ops.rotate_points(jh, l, R, t, transpose=True)
+        if training:
+            self._flat.bump_bn_counters()
+        if stash:
+            self._saved = (B, T, N, R, body)
+        return l, q
+
+    # -- ST-GCN (Net/GCN.py:332-355) on channels-last rows (b,t,v) ------------------------------------
+    def _gcn_forward(self, ar, up, B, T, training):
+        gcn = self.keyEncoder.gcn
+        V = JOINTS_UPPER
+        F, rows = B * T, B * T * V
+        st = ops.bn_stats(ar, "gcn.dbn", up, gcn.data_bn, training)
+        x0 = ar.get("gcn.x0", (F, V * 3))
+        ops.affine_act(up, st, x0, relu=False)
+        cur = x0.view(rows, 3)
+        for i, blk in enumerate(gcn.gcn_networks):
+            cin, cout, K = blk.cin, blk.cout, blk.K
+            key = "gcn.b%d" % i
+            Aeff = ar.get(key + ".A", (K, V, V))
+            hip.call("mul", gcn.A, gcn.edge_importance[i], Aeff, Aeff.numel())
+            res_z = ar.get(key + ".rz", (rows, cout))
+            ops.linear(cur, blk.residual["0"].weight, blk.residual["0"].bias, res_z)
+            st_r = ops.bn_stats(ar, key + ".bnr", res_z, blk.residual["1"], training)
+            z = ar.get(key + ".z", (rows, K * cout))
+            ops.linear(cur, blk.gcn.conv.weight, blk.gcn.conv.bias, z)
+            ymix = ar.get(key + ".ymix", (rows, cout))
+            z3, y3 = z.view(F, V, K * cout), ymix.view(F, V, cout)
+            for k in range(K):                               # einsum('nkctv,kvw->nctw'): y[w,c] = sum_v A[k,v,w] z_k[v,c]
+                ops.bmm(Aeff[k].t().unsqueeze(0).expand(F, V, V), z3[:, :, k * cout:(k + 1) * cout], y3, accumulate=k > 0)
+            st0 = ops.bn_stats(ar, key + ".bn0", ymix, blk.tcn["0"], training)
+            y0 = ar.get(key + ".y0", (rows, cout))
+            ops.affine_act(ymix, st0, y0, relu=True)
+            col = ar.get(key + ".col", (rows, cout * blk.taps))
+            hip.call("im2col_t", y0, B, T, V, cout, blk.taps, col)
+            tz = ar.get(key + ".tz", (rows, cout))
+            ops.linear(col, blk.tcn["2"].weight, blk.tcn["2"].bias, tz)
+            st3 = ops.bn_stats(ar, key + ".bn3", tz, blk.tcn["3"], training)
+            out = ar.get(key + ".out", (rows, cout))
+            ops.affine_act(tz, st3, out, relu=True, X2=res_z, st2=st_r)
+            cur = out
+        fz = ar.get("gcn.fz", (rows, 64))
+        ops.linear(cur, gcn.fcn.weight, gcn.fcn.bias, fz)
+        kv = ar.get("gcn.kv", (B, 64, T * V))
+        hip.call("transpose_batched", fz, kv, B, T * V, 64)       # (B,T*V,64) -> (B,64,T*V), then re-viewed (Q8)
+        return kv.view(F * V, 64)
+
+    def _backward_impl(self, dl):
+        ar = self.arena("train")
+        B, T, N, R, body = self._saved
+        F, V = B * T, JOINTS_UPPER
+        prow = F * LOWER_POINTS
+        G = self._flat.grad
+        fu = self.fusion
+        dl = _f32c(dl)
+        djh = ar.get("djh", (F, 8, 3))
+        ops.rotate_points(dl, djh, R, None, transpose=False)
+        y, f1, f0, cat = ar.get("y", (F, 42)), ar.get("f1", (F, 64)), ar.get("f0", (F, 128)), ar.get("cat", (F, 173))
+        dy = ar.get("dy", (F, 42))
+        hip.call("head_fk_backward", 1, y, body, B, F, djh, dy)
+        df1, df0, dcat = ar.get("df1", (F, 64)), ar.get("df0", (F, 128)), ar.get("dcat", (F, 173))
+        blocks.linear_backward(dy, f1, fu.fc2, G, df1)
+        ops.relu_mask_(df1, f1)
+        blocks.linear_backward(df1, f0, fu.fc1, G, df0)
+        ops.relu_mask_(df0, f0)
+        blocks.linear_backward(df0, cat, fu.fc0, G, dcat)
+        lstm = fu.rnn_pk
+        ak = ar.get("ak", (F, 192))
+        dak = blocks.lstm64_backward(ar, "rnn", lstm, ak, B, T, None, dcat[:, :128], G, self._drop_p(lstm), True)
+        dboth = ar.get("dboth", (prow, 128))
+        hip.call("group_bcast", dak, 192, F, LOWER_POINTS, 128, 1.0, dboth, 0)
+        dk = ar.get("dk", (F * V, 64))
+        hip.call("group_bcast", dak[:, 128:], 192, F, V, 64, 1.0 / V, dk, 0)
+        dp = ar.get("dp", (prow, 64))
+        ops.copy2d(dboth[:, :64], dp)
+        Qm, Km, Vm = ar.get("Qm", (prow, 64)), ar.get("Km", (F * V, 64)), ar.get("Vm", (F * V, 64))
+        Pm = ar.get("Pm", (F, LOWER_POINTS, V))
+        dQ, dK, dV = ar.get("dQ", (prow, 64)), ar.get("dK", (F * V, 64)), ar.get("dV", (F * V, 64))
+        hip.call("cross_attn_backward", Qm, Km, Vm, Pm, dboth[:, 64:], 128, F, float(fu.scale), dQ, dK, dV)
+        p_vec = ar.get("p_vec", (prow, 64))
+        k_vec = ar.get("gcn.kv", (B, 64, T * V)).view(F * V, 64)
+        blocks.linear_backward(dQ, p_vec, fu.to_q, G, dp, accumulate_dx=True)
+        blocks.linear_backward(dK, k_vec, fu.to_k, G, dk, accumulate_dx=True)
+        blocks.linear_backward(dV, k_vec, fu.to_v, G, dk, accumulate_dx=True)
+        sel = ar.get("sel", (prow, 6))
+        blocks.mlp3_backward(ar, "base", self.pointEncoder.module0, sel, p_vec[:, 3:64], dp[:, 3:64], G, False)
+        self._gcn_backward(ar, dk, B, T, G)
+
+    def _gcn_backward(self, ar, dk, B, T, G):
+        gcn = self.keyEncoder.gcn
+        V = JOINTS_UPPER
+        F, rows = B * T, B * T * V
+        dfz = ar.get("gcn.dfz", (rows, 64))
+        hip.call("transpose_batched", dk, dfz, B, 64, T * V)      # (B,64,T*V) -> (B,T*V,64)
+        cur = ar.get("gcn.b2.out", (rows, 128))
+        dcur = ar.get("gcn.d3", (rows, 128))
+        blocks.linear_backward(dfz, cur, gcn.fcn, G, dcur)
+        for i in (2, 1, 0):
+            blk = gcn.gcn_networks[i]
+            cin, cout, K = blk.cin, blk.cout, blk.K
+            key = "gcn.b%d" % i
+            inp = ar.get("gcn.b%d.out" % (i - 1), (rows, cin)) if i > 0 else ar.get("gcn.x0", (F, V * 3)).view(rows, 3)
+            out, tz, res_z = ar.get(key + ".out", (rows, cout)), ar.get(key + ".tz", (rows, cout)), ar.get(key + ".rz", (rows, cout))
+            st3, st_r, st0 = ops.BnState(ar, key + ".bn3", cout), ops.BnState(ar, key + ".bnr", cout), ops.BnState(ar, key + ".bn0", cout)
+            dtz, drz = ar.get(key + ".dtz", (rows, cout)), ar.get(key + ".drz", (rows, cout))
+            ops.bn_backward(dcur, out, tz, st3, G(blk.tcn["3"].weight), G(blk.tcn["3"].bias), dtz)
+            ops.bn_backward(dcur, out, res_z, st_r, G(blk.residual["1"].weight), G(blk.residual["1"].bias), drz)
+            col = ar.get(key + ".col", (rows, cout * blk.taps))
+            dcol = ar.get(key + ".dcol", (rows, cout * blk.taps))
+            blocks.linear_backward(dtz, col, blk.tcn["2"], G, dcol)
+            dy0 = ar.get(key + ".dy0", (rows, cout))
+            hip.call("col2im_t", dcol, B, T, V, cout, blk.taps, dy0)
+            y0, ymix = ar.get(key + ".y0", (rows, cout)), ar.get(key + ".ymix", (rows, cout))
+            dymix = ar.get(key + ".dymix", (rows, cout))
+            ops.bn_backward(dy0, y0, ymix, st0, G(blk.tcn["0"].weight), G(blk.tcn["0"].bias), dymix)
+            z = ar.get(key + ".z", (rows, K * cout))
+            Aeff = ar.get(key + ".A", (K, V, V))
+            dA = ar.get(key + ".dA", (K, V, V))
+            hip.call("graph_dA", z, dymix, F, V, K, cout, dA)
+            hip.call("mul", dA, gcn.A, G(gcn.edge_importance[i]), dA.numel())
+            dz = ar.get(key + ".dz", (rows, K * cout))
+            dz3, dy3 = dz.view(F, V, K * cout), dymix.view(F, V, cout)
+            for k in range(K):                                   # dz_k[v,c] = sum_w A[k,v,w] dy[w,c]
+                ops.bmm(Aeff[k].unsqueeze(0).expand(F, V, V), dy3, dz3[:, :, k * cout:(k + 1) * cout])
+            dinp = ar.get(key + ".dinp", (rows, cin))
+            blocks.linear_backward(dz, inp, blk.gcn.conv, G, dinp)
+            blocks.linear_backward(drz, inp, blk.residual["0"], G, dinp, accumulate_dx=True)
+            dcur = dinp
+        up = ar.get("up", (F, V * 3))
+        st = ops.BnState(ar, "gcn.dbn", V * 3)
+        scratch = ar.get("gcn.dup", (F, V * 3))
+        ops.bn_backward(dcur.view(F, V * 3), None, up, st, G(gcn.data_bn.weight), G(gcn.data_bn.bias), scratch)
+
+
+# =====================================================================================================
+# IMU_Net (forward; it is frozen in stages 2/3 -- reference Train_Upper.py:57,136; Train_Lower.py:67,157)
+# =====================================================================================================
+class IMUNet(_NetBase):
+    """IMUNet(input_n, output_n, hidden_n, n_rnn_layer, bidirectional=True, dropout=0);
+    forward(imu[B,T,S,input_n], h0_i=None) -> (R[B,T,3,3], t[B,T,3])."""
+
+    def __init__(self, input_n, output_n, hidden_n, n_rnn_layer, bidirectional=True, dropout=0):
+        super().__init__()
+        if not bidirectional or output_n != 9 or hidden_n % 32 != 0:
+            raise ValueError("IMUNet HIP path supports bidirectional nets with output_n == 9 and hidden_n % 32 == 0")
+        d = 2
+        self.hidden_n = hidden_n
+        self.fc1 = nn.Linear(input_n, hidden_n)
+        self.fc2 = nn.Linear(hidden_n * d, output_n)
+        self.fc3 = nn.Linear(output_n, 3)                # Q7: present in checkpoints, unused
+        self.rnn_fast = LstmParams(hidden_n, hidden_n, n_rnn_layer, dropout=dropout, bidirectional=True)
+        self.rnn_slow = LstmParams(2 * hidden_n, hidden_n, n_rnn_layer, dropout=dropout, bidirectional=True)
+        self.attn = nn.Linear(hidden_n * d, 1)
+
+    def forward(self, imu, h0_i=None):
+        _require_gpu(imu, "IMUNet")
+        if h0_i is not None:
+            raise NotImplementedError("IMUNet: the reference never passes h0_i; only None is supported")
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("IMUNet training (stage 1) backward is not on the HIP path yet; call .eval()")
+        self.flat()
+        ar = self.arena("eval")
+        imu = _f32c(imu)
+        B, T, S, Cin = imu.shape
+        H = self.hidden_n
+        Bn = B * T
+        dev = imu.device
+        h = ar.get("fc1", (Bn * S, H))
+        ops.linear(imu.view(Bn * S, Cin), self.fc1.weight, self.fc1.bias, h, relu=True)
+        fast = blocks.lstm_steps_forward(ar, "fast", self.rnn_fast, h, Bn, S)          # [Bn*S, 2H]
+        pooled = ar.get("pooled", (Bn, 2 * H))
+        attn = ar.get("attn", (Bn, S))
+        blocks.attn_pool_forward(fast, self.attn, Bn, S, 2 * H, pooled, attn)
+        slow = blocks.lstm_steps_forward(ar, "slow", self.rnn_slow, pooled, B, T)       # [B*T, 2H]
+        y = ar.get("y", (Bn, 9))
+        ops.linear(slow, self.fc2.weight, self.fc2.bias, y)
+        R = torch.empty((B, T, 3, 3), dtype=torch.float32, device=dev)
+        t = torch.empty((B, T, 3), dtype=torch.float32, device=dev)
+        hip.call("imu_head", y, Bn, R, t)
+        return R, t

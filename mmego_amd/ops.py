@@ -1,0 +1,215 @@
+"""Typed host wrappers over the C ABI: shape/stride/dtype checks on the host, then one kernel launch.
+
+Every function here runs on the GPU through libmmego_hip.so; nothing computes with torch ops.  Tensors
+are fp32 CUDA(HIP) tensors; 2-D arguments may be strided views (e.g. a column slice of a wider buffer,
+or ``W.t()``) -- the element strides go straight to the kernel.
+"""
+import torch
+
+from . import hip
+
+
+def _chk(t, nd=None):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise TypeError("expected an fp32 device tensor, got %r" % (type(t),))
+    if nd is not None and t.dim() != nd:
+        raise ValueError("expected %d-D tensor, got shape %s" % (nd, tuple(t.shape)))
+    return t
+
+
+def _rows(t):
+    """2-D row view [rows, C] with unit column stride of a contiguous-by-rows tensor."""
+    _chk(t, 2)
+    if t.stride(1) != 1:
+        raise ValueError("row tensor needs unit column stride")
+    return t
+
+
+class Arena:
+    """Named scratch buffers that persist across calls (static addresses: HIP-graph friendly)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+
+    def get(self, key, shape, dtype=torch.float32, zero=False):
+        shape = tuple(int(s) for s in shape)
+        t = self.bufs.get(key)
+        if t is None or t.shape != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        if zero:
+            fill(t, 0.0) if dtype == torch.float32 else t.zero_()
+        return t
+
+    def has(self, key):
+        return key in self.bufs
+
+
+_scratch = {}
+
+
+def scratch(device, n):
+    """Grow-only fp32 scratch (split-K slabs, reduction partials).  Stream-ordered reuse is safe."""
+    key = str(device)
+    t = _scratch.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(int(n), 1 << 20), dtype=torch.float32, device=device)
+        _scratch[key] = t
+    return t
+
+
+def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1):
+    """C[M,N] (+)= A[M,K] @ B[K,N] (+bias)(relu); A, B, C are 2-D views with arbitrary strides."""
+    _chk(A, 2), _chk(B, 2), _chk(C, 2)
+    M, K = A.shape
+    K2, N = B.shape
+    if K2 != K or tuple(C.shape) != (M, N):
+        raise ValueError("mm shape mismatch %s @ %s -> %s" % (tuple(A.shape), tuple(B.shape), tuple(C.shape)))
+    if bias is not None and (bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous with N elements")
+    ws = None
+    if nsplit > 1:
+        ws = scratch(A.device, nsplit * M * N)
+    hip.call("gemm", A, A.stride(0), A.stride(1), B, B.stride(0), B.stride(1), C, C.stride(0), C.stride(1), bias,
+             M, N, K, 1, 0, 0, 0, int(relu), int(accumulate), ws, nsplit)
+    return C
+
+
+def bmm(A, B, C, accumulate=False):
+    """Batched C[b] (+)= A[b] @ B[b]; 3-D views, batch stride may be 0 (broadcast operand)."""
+    _chk(A, 3), _chk(B, 3), _chk(C, 3)
+    nb, M, K = A.shape
+    if B.shape[0] != nb or C.shape[0] != nb or B.shape[1] != K or tuple(C.shape[1:]) != (M, B.shape[2]):
+        raise ValueError("bmm shape mismatch")
+    hip.call("gemm", A, A.stride(1), A.stride(2), B, B.stride(1), B.stride(2), C, C.stride(1), C.stride(2), None,
+             M, B.shape[2], K, nb, A.stride(0), B.stride(0), C.stride(0), 0, int(accumulate), None, 1)
+    return C
+
+
+def linear(x, W, b, out, relu=False):
+    """out[rows,N] = x[rows,K] @ W[N,K]^T + b"""
+    return mm(x, W.view(W.shape[0], -1).t(), out, bias=b, relu=relu)
+
+
+def pick_split(M, N, K):
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    want = max(1, 512 // tiles)
+    return int(max(1, min(want, K // 256)))
+
+
+def grad_weight(dY, X, dW):
+    """dW[N,K] = dY[rows,N]^T @ X[rows,K]  (fixed-order split over rows)."""
+    W2 = dW.view(dW.shape[0], -1)
+    return mm(dY.t(), X, W2, nsplit=pick_split(W2.shape[0], W2.shape[1], X.shape[0]))
+
+
+def grad_input(dY, W, dX, accumulate=False):
+    """dX[rows,K] (+)= dY[rows,N] @ W[N,K]"""
+    return mm(dY, W.view(W.shape[0], -1), dX, accumulate=accumulate)
+
+
+def colsum(X, out, accumulate=False):
+    X = _rows(X)
+    rows, C = X.shape
+    ws = scratch(X.device, C * hip.colstats_nblk(rows))
+    hip.call("colsum", X, X.stride(0), rows, C, ws, out, int(accumulate))
+    return out
+
+
+def fill(t, v):
+    if not t.is_contiguous():
+        raise ValueError("fill needs a contiguous tensor")
+    hip.call("fill", t, t.numel(), float(v))
+    return t
+
+
+def copy2d(X, Y, accumulate=False):
+    X, Y = _rows(X), _rows(Y)
+    if X.shape != Y.shape:
+        raise ValueError("copy2d shape mismatch")
+    hip.call("copy2d", X, X.stride(0), Y, Y.stride(0), X.shape[0], X.shape[1], int(accumulate))
+    return Y
+
+
+def relu_mask_(G, H):
+    G, H = _rows(G), _rows(H)
+    hip.call("relu_mask", G, G.stride(0), H, H.stride(0), G.shape[0], G.shape[1])
+    return G
+
+
+class BnState:
+    """mean / invstd / a / b vectors of one BatchNorm application (kept for backward)."""
+
+    def __init__(self, arena, key, C):
+        v = arena.get(key, (4, C))
+        self.mean, self.invstd, self.a, self.b = v[0], v[1], v[2], v[3]
+        self.C = C
+
+
+def bn_stats(arena, key, X, bn, training):
+    """Compute the affine of a BatchNorm over the rows of X (train: batch stats + running update)."""
+    X = _rows(X)
+    rows, C = X.shape
+    st = BnState(arena, key, C)
+    if training:
+        ws = scratch(X.device, 3 * C * hip.colstats_nblk(rows))
+        hip.call("bn_train_stats", X, X.stride(0), rows, C, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                 float(bn.momentum), float(bn.eps), ws, st.mean, st.invstd, st.a, st.b)
+        bn.num_batches_tracked += 1
+    else:
+        hip.call("bn_eval_affine", C, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                 st.mean, st.invstd, st.a, st.b)
+    return st
+
+
+def affine_act(X, st, Y, relu=True, X2=None, st2=None):
+    X, Y = _rows(X), _rows(Y)
+    rows, C = X.shape
+    if X2 is not None:
+        X2 = _rows(X2)
+        hip.call("affine_act", X, X.stride(0), st.mean, st.a, st.b, X2, X2.stride(0), st2.mean, st2.a, st2.b, Y,
+                 Y.stride(0), rows, C, int(relu))
+    else:
+        hip.call("affine_act", X, X.stride(0), st.mean, st.a, st.b, None, 0, None, None, None, Y, Y.stride(0), rows, C,
+                 int(relu))
+    return Y
+
+
+def bn_backward(dY, Ymask, X, st, dgamma, dbeta, dX):
+    """BatchNorm(train) backward through an optional ReLU (mask = Ymask > 0)."""
+    dY, X, dX = _rows(dY), _rows(X), _rows(dX)
+    rows, C = X.shape
+    ws = scratch(X.device, 2 * C * hip.colstats_nblk(rows) + 2 * C)
+    c12 = ws[2 * C * hip.colstats_nblk(rows):]
+    if Ymask is not None:
+        Ymask = _rows(Ymask)
+        hip.call("bn_backward", dY, dY.stride(0), Ymask, Ymask.stride(0), X, X.stride(0), st.mean, st.invstd, st.a, rows,
+                 C, ws, c12, dgamma, dbeta, dX, dX.stride(0))
+    else:
+        hip.call("bn_backward", dY, dY.stride(0), None, 0, X, X.stride(0), st.mean, st.invstd, st.a, rows, C, ws, c12,
+                 dgamma, dbeta, dX, dX.stride(0))
+    return dX
+
+
+def transform2h_(pts, R, t):
+    """In place on pts [F, P, C] (or any contiguous view of it)."""
+    _chk(pts)
+    if not pts.is_contiguous():
+        raise ValueError("transform2h_ needs a contiguous point tensor")
+    F = R.numel() // 9
+    C = pts.shape[-1]
+    P = pts.numel() // (F * C)
+    if not (R.is_contiguous() and t.is_contiguous() and t.numel() == 3 * F):
+        raise ValueError("R/t must be contiguous [F,3,3]/[F,3]")
+    hip.call("transform2h", pts, F, P, C, R, t)
+    return pts
+
+
+def rotate_points(inp, out, R, t=None, transpose=True):
+    F = R.numel() // 9
+    P = inp.numel() // (3 * F)
+    if not (inp.is_contiguous() and out.is_contiguous() and R.is_contiguous()):
+        raise ValueError("rotate_points needs contiguous tensors")
+    hip.call("rotate_points", inp, out, F, P, R, t, int(transpose), int(t is not None))
+    return out

@@ -1,0 +1,86 @@
+"""CPU (no GPU): the C-ABI library loads and exports what include/mmego_hip.h declares; host-side logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+
+
+def test_library_exports_every_declared_symbol():
+    from mmego_amd import build, hip
+    lib_path = build.build_library()
+    assert os.path.exists(lib_path)
+    protos = hip.parse_header()
+    assert len(protos) >= 30
+    lib = ctypes.CDLL(lib_path)
+    for name in protos:
+        assert hasattr(lib, name), "header declares %s but the library does not export it" % name
+    # and nothing exported is missing from the header
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (mmego_\w+)", out))
+    assert exported == set(protos), exported ^ set(protos)
+    assert lib.mmego_colstats_nblk(ctypes.c_long(1000)) == 8      # pure host helper: safe without a GPU
+
+
+def test_no_torch_types_in_abi():
+    text = open(os.path.join(ROOT, "include", "mmego_hip.h")).read()
+    assert "at::" not in text and "torch" not in text.lower().replace("torch.optim", "").replace("torch semantics", "") \
+        .replace("torch.cat", "").replace("like torch", "").replace("torch (", "")
+
+
+def test_state_dict_surface_matches_shipped_checkpoints():
+    from mmego_amd import nets
+    up, lo = golden("w_upper_pretrained.npz"), golden("w_lower_pretrained.npz")
+    u, l = nets.UpperNet(), nets.LowerNet(64)
+    assert set(u.state_dict()) == set(up.files) and len(up.files) == 72
+    assert set(l.state_dict()) == set(lo.files)
+    for k, v in list(u.state_dict().items()) + list(l.state_dict().items()):
+        ref = up[k] if k in up.files else lo[k]
+        assert tuple(v.shape) == ref.shape, k
+    u.load_state_dict({k: torch.tensor(up[k]) for k in up.files})
+    l.load_state_dict({k: torch.tensor(lo[k]) for k in lo.files})
+    im = nets.IMUNet(15, 9, 512, 2, True, 0.1)
+    assert sum(p.numel() for p in im.parameters()) == 23119912
+    assert sum(p.numel() for p in u.parameters()) == 299656 and sum(p.numel() for p in l.parameters()) == 615986
+
+
+def test_seeded_init_equals_oracle_and_reference_order():
+    from mmego_amd import nets
+    from oracle import nets as on
+    for seed, a, b in ((1, nets.UpperNet, on.UpperNet), (2, lambda: nets.LowerNet(64), lambda: on.LowerNet(64)),
+                       (3, lambda: nets.IMUNet(15, 9, 32, 2, True, 0.1), lambda: on.IMUNet(15, 9, 32, 2, True, 0.1))):
+        torch.manual_seed(seed)
+        x = a()
+        torch.manual_seed(seed)
+        y = b()
+        for (kx, vx), (ky, vy) in zip(x.state_dict().items(), y.state_dict().items()):
+            assert kx == ky and torch.equal(vx, vy), kx
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from mmego_amd import nets
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nets.UpperNet()(torch.zeros(1, 2, 128, 6), None, None, torch.zeros(1, 20, 3), torch.zeros(1, 2, 3, 3), torch.zeros(1, 2, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nets.IMUNet(15, 9, 32, 2, True, 0).eval()(torch.zeros(1, 2, 20, 15))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "mmego_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_adjacency_matches_reference_golden():
+    from mmego_amd.skeleton import gcn_adjacency
+    g = golden("g3_adjacency.npz")
+    assert np.array_equal(gcn_adjacency("distance"), g["distance"])
+    assert np.array_equal(gcn_adjacency("uniform"), g["uniform"])
