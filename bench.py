@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training frames/s of the metric unit "U+L step" (SURVEY.md section 8-d).
+
+One step = one Train_Upper.train_once body + one Train_Lower.train_once body on the same synthetic
+minibatch (per GPU: B=64 sequences x T=8 frames x N=128 points, 21 joints), each as in the reference:
+frozen IMU_Net forward inside both, frozen Upper_Net forward inside the Lower body, L1(sum) loss,
+backward, Adam.  fp32 end to end.  Inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL gradient all-reduce)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, timed
+live with events on the launch stream) and, at N=1, `cpu_baseline` (the CPU oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+B, T, N = 64, 8, 128
+
+
+def synth_batch(seed, device):
+    """Synthetic minibatch with Sample_data's column statistics."""
+    g = torch.Generator().manual_seed(seed)
+    mu, sd = torch.tensor([0.84, 0.05, 0.18]), torch.tensor([0.41, 0.30, 0.38])
+    xyz = torch.randn(B, T, N, 3, generator=g) * sd + mu
+    x = torch.zeros(B, T, N, 6)
+    x[..., :3] = xyz
+    x[..., 3] = xyz.norm(dim=-1)
+    x[..., 4] = torch.randn(B, T, N, generator=g) * 0.41
+    x[..., 5] = torch.rand(B, T, N, generator=g) * 36 + 10
+    dead = torch.rand(B, T, N, generator=g) < 0.40
+    dead[:, :, :16] = False                                   # keep >= 16 live points per frame
+    x[dead] = 0.0
+    imu = torch.zeros(B, T, 20, 15)
+    q = torch.linalg.qr(torch.randn(B, T, 20, 3, 3, generator=g))[0]
+    imu[..., :9] = q.reshape(B, T, 20, 9)
+    imu[..., 9:12] = torch.randn(B, T, 20, 3, generator=g)
+    imu[..., 12:] = 0.3 * torch.randn(B, T, 20, 3, generator=g)
+    bones = torch.tensor([[0.0, 0.0, 0.18], [0.0, 0.0, 0.2], [0.0, 0.0, 0.15], [0.17, 0.0, 0.03], [-0.17, 0.0, 0.03],
+                          [0.27, 0.0, 0.0], [0.25, 0.0, 0.0], [0.08, 0.0, 0.0], [-0.27, 0.0, 0.0], [-0.25, 0.0, 0.0],
+                          [-0.08, 0.0, 0.0], [0.0, 0.0, 0.2], [0.09, 0.0, 0.0], [-0.09, 0.0, 0.0], [0.0, 0.0, 0.4],
+                          [0.0, 0.0, 0.4], [0.0, 0.12, 0.05], [0.0, 0.0, 0.4], [0.0, 0.0, 0.4], [0.0, 0.12, 0.05]])
+    body = bones.unsqueeze(0).repeat(B, 1, 1)                  # identical across the batch, as in the reference
+    skel = torch.cumsum(torch.cat((torch.tensor([[0.8, 0.0, 0.9]]), bones)), 0)
+    target = skel.view(1, 1, 21, 3) + 0.05 * torch.randn(B, T, 21, 3, generator=g)
+    return [v.contiguous().to(device) for v in (x, imu, body, target)]
+
+
+def build_hip_models(device):
+    from mmego_amd import nets
+    torch.manual_seed(1234)
+    imu = nets.IMUNet(15, 9, 512, 2, True, 0.1)
+    upper = nets.UpperNet()
+    lower = nets.LowerNet(64)
+    upper_frozen = nets.UpperNet()
+    upper_frozen.load_state_dict(upper.state_dict())
+    return imu.to(device).eval(), upper.to(device).train(), lower.to(device).train(), upper_frozen.to(device).eval()
+
+
+def profile_kernels(steps_fn, names, iters=3):
+    """Average launch duration (ms) and launch count per step of the named C-ABI entry points, measured with
+    event pairs on the launch stream while `steps_fn` runs eagerly (no graph)."""
+    from mmego_amd import hip
+    rec = {n: [] for n in names}
+    orig = hip.call
+
+    def timed_call(name, *args):
+        if name in rec:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(name, *args)
+            e1.record()
+            rec[name].append((e0, e1, args))
+        else:
+            orig(name, *args)
+    hip.call = timed_call
+    try:
+        for _ in range(iters):
+            steps_fn()
+        torch.cuda.synchronize()
+    finally:
+        hip.call = orig
+    return {n: [(a.elapsed_time(b), args) for a, b, args in v] for n, v in rec.items()}, iters
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity, capped by the cgroup CPU quota and by the 16-core
+    share a one-GPU box grants (oversubscribing a quota'd cgroup makes the baseline pathologically slow)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, int(os.environ.get("MMEGO_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(steps, warmup):
+    """The CPU oracle (a port of the reference path, pinned to it by tests/golden) on the host cores."""
+    from oracle import nets as on
+    from oracle import train as ot
+    ncores = host_cores()
+    torch.set_num_threads(ncores)
+    torch.manual_seed(1234)
+    imu = on.IMUNet(15, 9, 512, 2, True, 0.1)
+    upper, lower = on.UpperNet(), on.LowerNet(64)
+    x, imu_in, body, target = synth_batch(1234, "cpu")
+    tu, tl = ot.time_ul_step(upper, lower, imu, x, imu_in, body, target, steps=steps, warmup=warmup)
+    return {"value": B * T / (tu + tl), "unit": "frames/s", "cores": ncores, "kind": "port",
+            "sample": "%d U+L steps (after %d warm-up) of the same B=64,T=8,N=128 batch; t_upper %.1f ms, t_lower %.1f ms"
+                      % (steps, warmup, tu * 1e3, tl * 1e3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+        pg = torch.distributed.group.WORLD
+
+    from mmego_amd import hip
+    from mmego_amd.train_step import StageStep
+    hip.lib()
+    imu, upper, lower, upper_frozen = build_hip_models(device)
+    x, imu_in, body, target = synth_batch(1234 + rank, device)      # weak scaling: every rank its own B=64 shard
+    su = StageStep("upper", upper, imu, lr=3e-5, process_group=pg, use_graph=not args.no_graph)
+    sl = StageStep("lower", lower, imu, upper_frozen=upper_frozen, lr=3e-5, process_group=pg, use_graph=not args.no_graph)
+    su.bind(x, imu_in, body, target)
+    sl.bind(x, imu_in, body, target)
+
+    def ul_step():
+        su.step()
+        sl.step()
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ul_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ul_step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    loss_u, loss_l = su.loss.item(), sl.loss.item()
+
+    # per-stage split (device time, events on the launch stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record(); su.step(); ev[1].record(); sl.step(); ev[2].record()
+    torch.cuda.synchronize()
+    t_u, t_l = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {"metric": "train frames/sec (Upper+Lower U+L step, B=64/GPU, T=8, 128 pts)", "value": world * B * T / (dt / args.steps),
+               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "U+L step = Train_Upper.train_once body + Train_Lower.train_once body "
+                                      "(IMU_Net fwd in both, frozen Upper fwd in the Lower body), per-GPU B=64 T=8 N=128, "
+                                      "21 joints, Adam lr 3e-5, LSTM dropout 0.1 active",
+                          "global_batch": world * B, "seq_len": T, "points": N, "parallelism": "dp%d" % world,
+                          "hip_graph": not args.no_graph},
+               "t_upper_ms": t_u, "t_lower_ms": t_l, "loss_upper": loss_u, "loss_lower": loss_l}
+
+    # ---- roofline of the dominant kernel: eager replay with event pairs around every launch ----------------
+    if rank == 0:
+        su_e = StageStep("upper", upper, imu, lr=3e-5, use_graph=False)
+        sl_e = StageStep("lower", lower, imu, upper_frozen=upper_frozen, lr=3e-5, use_graph=False)
+        su_e.bind(x, imu_in, body, target)
+        sl_e.bind(x, imu_in, body, target)
+
+        def eager():
+            su_e._body()
+            sl_e._body()
+        eager()
+        torch.cuda.synchronize()
+        rec, iters = profile_kernels(eager, ("lstm_step", "gemm"))
+        # lstm_step: args = (ndir, Bn, H, ...): flops = ndir * 2 * Bn * 4H * H
+        steps_big = [(ms_, 2.0 * a[0] * a[1] * 4 * a[2] * a[2]) for ms_, a in rec["lstm_step"] if a[1] >= 512 and a[2] == 512]
+        gemm_big = [(ms_, 2.0 * a[10] * a[11] * a[12]) for ms_, a in rec["gemm"] if a[10] * a[11] * a[12] >= 2 ** 32]
+        cands = {}
+        if steps_big:
+            cands["lstm_step_kernel (IMU_Net rnn_fast recurrent step, 2 dirs x 512 rows x 2048 gates x K=512)"] = steps_big
+        if gemm_big:
+            cands["gemm128_nt_kernel (IMU_Net LSTM input projections, 10240 x 2048 x K)"] = gemm_big
+        best = max(cands.items(), key=lambda kv: sum(m for m, _ in kv[1]))
+        tot_ms = sum(m for m, _ in best[1])
+        tot_fl = sum(f for _, f in best[1])
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": best[0],
+                           "avg_launch_us": tot_ms / len(best[1]) * 1e3, "launches_per_step": len(best[1]) // iters,
+                           "flop_per_launch": tot_fl / len(best[1]),
+                           "share_of_step": (tot_ms / iters) / (t_u + t_l)}
+        out["kernels"] = {k: {"avg_us": sum(m for m, _ in v) / len(v) * 1e3, "launches_per_step": len(v) // iters,
+                              "tflops": sum(f for _, f in v) / (sum(m for m, _ in v) * 1e-3) / 1e12} for k, v in cands.items()}
+        sys.stderr.write("[bench] gpu part done: %.1f frames/s; timing the CPU oracle on %d threads\n" % (out["value"], host_cores()))
+        sys.stderr.flush()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_steps, 1)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,11 +5,17 @@
 // Chan's formula in fp64 so that train-mode statistics are at least as accurate as a two-pass CPU BN.
 #include "common.h"
 
-#define RPB 128  // rows per block in the column-reduction kernels
+// rows per block of the column-reduction kernels: at most 256 partial blocks, so the one-wave-per-channel
+// finalize kernels combine <= 4 partials per lane
+static inline long rows_per_block(long rows) {
+  long r = (rows + 255) / 256;
+  if (r < 64) r = 64;
+  return (r + 3) / 4 * 4;
+}
 
 // partial[blk][c] = (n, mean, M2) over this block's rows of column c
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ X, long ldx, long rows, int C,
-                                                       float* __restrict__ partial) {
+                                                       float* __restrict__ partial, long RPB) {
   __shared__ float sh[4][64][3];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cx;
@@ -40,13 +46,12 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
 
 // Combine partials (Chan, fp64); update running stats exactly like torch (momentum, unbiased running var).
 // outputs: mean[C], invstd[C], a[C] = gamma*invstd, b[C] = beta     so that y = (x-mean)*a + b
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, const float* gamma,
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum,
                                    float eps, float* mean_out, float* invstd_out, float* a_out, float* b_out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x, lane = threadIdx.x;
   double N = 0.0, mean = 0.0, M2 = 0.0;
-  for (int k = 0; k < nblk; ++k) {
+  for (int k = lane; k < nblk; k += 64) {
     const float* p = partial + ((long)k * C + c) * 3;
     double nb = p[0], mb = p[1], m2b = p[2];
     double tot = N + nb;
@@ -55,6 +60,20 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, 
     M2 += m2b + delta * delta * N * nb / tot;
     N = tot;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {  // butterfly Chan combine: every lane ends with the full statistics
+    double nb = __shfl_xor(N, o, 64), mb = __shfl_xor(mean, o, 64), m2b = __shfl_xor(M2, o, 64);
+    double tot = N + nb;
+    if (tot > 0.0) {
+      double delta = mb - mean;
+      // symmetric form so that both partners compute bit-identical results
+      double mnew = (mean * N + mb * nb) / tot;
+      M2 = M2 + m2b + delta * delta * N * nb / tot;
+      mean = mnew;
+      N = tot;
+    }
+  }
+  if (lane != 0) return;
   double var = M2 / N;
   float invstd = (float)(1.0 / sqrt(var + (double)eps));
   mean_out[c] = (float)mean;
@@ -115,7 +134,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ Ymask, long ldm,
                                                             const float* __restrict__ X, long ldx, const float* mean,
                                                             const float* invstd, long rows, int C,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial, long RPB) {
   __shared__ float sh[4][64][2];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cx;
@@ -141,15 +160,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long rows, float* dgamma,
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long rows, float* dgamma,
                                        float* dbeta, float* c1, float* c2) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x, lane = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nblk; ++k) {
+  for (int k = lane; k < nblk; k += 64) {
     s1 += partial[((long)k * C + c) * 2 + 0];
     s2 += partial[((long)k * C + c) * 2 + 1];
   }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane != 0) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   c1[c] = (float)(s1 / (double)rows);
@@ -176,7 +197,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // partial[blk][c] = sum over the block's rows of X[r,c]
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, long rows, int C,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, long RPB) {
   __shared__ float sh[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cx;
@@ -190,12 +211,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (ry == 0 && c < C) partial[(long)blockIdx.x * C + c] = sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx];
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* out, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* out, int accumulate) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0;
-  for (int k = 0; k < nblk; ++k) s += partial[(long)k * C + c];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+  for (int k = lane; k < nblk; k += 64) s += partial[(long)k * C + c];
+  s = wave_sum_d(s);
+  if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 // G[r,c] = 0 where H[r,c] <= 0
@@ -218,17 +239,18 @@ static inline int ew_blocks(long total) {
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
 }
 
-extern "C" int mmego_colstats_nblk(long rows) { return cdiv(rows, RPB); }
+extern "C" int mmego_colstats_nblk(long rows) { return cdiv(rows, rows_per_block(rows)); }
 
 extern "C" int mmego_bn_train_stats(void* stream, const float* X, long ldx, long rows, int C, const float* gamma,
                                     const float* beta, float* running_mean, float* running_var, float momentum,
                                     float eps, float* partial_ws, float* mean, float* invstd, float* a, float* b) {
   MMEGO_REQUIRE(X && rows > 0 && C > 0 && partial_ws && mean && invstd && a && b);
   hipStream_t st = (hipStream_t)stream;
+  const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
-  hipLaunchKernelGGL(colstats_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, X, ldx, rows, C, partial_ws);
+  hipLaunchKernelGGL(colstats_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB);
   MMEGO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial_ws, nblk, C, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, a, b);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
@@ -269,11 +291,12 @@ extern "C" int mmego_bn_backward(void* stream, const float* dY, long lddy, const
                                  float* dX, long lddx) {
   MMEGO_REQUIRE(dY && X && mean && invstd && a && rows > 0 && C > 0 && partial_ws && c12_ws && dgamma && dbeta && dX);
   hipStream_t st = (hipStream_t)stream;
+  const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
-                     mean, invstd, rows, C, partial_ws);
+                     mean, invstd, rows, C, partial_ws, RPB);
   MMEGO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial_ws, nblk, C, rows, dgamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, rows, dgamma,
                      dbeta, c12_ws, c12_ws + C);
   MMEGO_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
@@ -286,10 +309,11 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
                             int accumulate) {
   MMEGO_REQUIRE(X && rows > 0 && C > 0 && partial_ws && out);
   hipStream_t st = (hipStream_t)stream;
+  const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, X, ldx, rows, C, partial_ws);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB);
   MMEGO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial_ws, nblk, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, out, accumulate);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -1,0 +1,76 @@
+"""Fused train_once bodies of stage 2 (Upper_Net) and stage 3 (Lower_Net) on the HIP path.
+
+Mirrors reference Processor/Train/Train_Upper.py:134-187 and Train_Lower.py:155-230 per minibatch:
+frozen IMU_Net forward (eval) -> [frozen Upper_Net forward (eval)] -> trained net forward -> L1(sum) loss
+-> backward -> Adam.  Differences, all host-side: no DataLoader/numpy round trip, the loss stays on the
+device (no .item() sync per step), gradients live in one flat buffer (one all-reduce for data parallel,
+one fused Adam launch).  Each body is capturable into a HIP graph.
+"""
+import torch
+
+from . import hip, ops
+from .params import FusedAdam
+from .skeleton import LOWER_MAP, UPPER_MAP
+
+
+class StageStep:
+    """One training stage's per-minibatch body with static buffers (graph friendly)."""
+
+    def __init__(self, stage, net, imu_net, upper_frozen=None, lr=3e-5, weight_decay=0.0, process_group=None,
+                 use_graph=True):
+        assert stage in ("upper", "lower")
+        self.stage, self.net, self.imu, self.upper_frozen = stage, net, imu_net, upper_frozen
+        self.opt = FusedAdam(net.flat(), lr=lr, weight_decay=weight_decay)
+        self.pg = process_group
+        self.use_graph = use_graph
+        self.graph = None
+        self.static = None
+        dev = next(net.parameters()).device
+        self.jmap = torch.tensor(UPPER_MAP if stage == "upper" else LOWER_MAP, dtype=torch.int32, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def _body(self):
+        s = self.static
+        B, T = s["x"].shape[0], s["x"].shape[1]
+        ops.copy2d(s["x_src"].view(B * T, -1), s["x"].view(B * T, -1))        # fresh batch (x is transformed in place)
+        with torch.no_grad():
+            R, t = self.imu(s["imu"])
+            if self.stage == "upper":
+                l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["body"], R, t, stash=True)[0]
+                nsel = 15
+            else:
+                up = self.upper_frozen(s["x"], s["h0"], s["c0"], s["body"], R, t)[0]
+                l = self.net._forward_impl(up, s["x"], s["body"], R, t, stash=True)[0]
+                nsel = 8
+            dl = s["dl"]
+            hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss, dl)
+            self.net._backward_impl(dl)
+        self.last_pred = l
+
+    def bind(self, x, imu, body, target):
+        """Register the (device-resident) minibatch buffers; contents may be overwritten between steps."""
+        dev = x.device
+        B = x.shape[0]
+        nsel = 15 if self.stage == "upper" else 8
+        self.static = dict(x_src=x, x=torch.empty_like(x), imu=imu, body=body, target=target,
+                           h0=torch.zeros(6, B, 64, device=dev), c0=torch.zeros(6, B, 64, device=dev),
+                           dl=torch.empty(B, x.shape[1], nsel, 3, device=dev))
+        self.graph = None
+
+    def step(self):
+        if self.use_graph:
+            if self.graph is None:
+                self._body()                                   # warm-up: sizes arenas, sets kernel attributes
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body()
+                self.graph = g
+            self.graph.replay()
+        else:
+            self._body()
+        if self.pg is not None and torch.distributed.get_world_size(self.pg) > 1:
+            # loss is a SUM over the batch, so the global-batch gradient is the SUM of shard gradients
+            torch.distributed.all_reduce(self.net._flat.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        self.opt.step()
+        return self.loss

@@ -20,7 +20,7 @@ from oracle import skeleton as sk
 # parameters whose true gradient is exactly zero in train mode (bias before a batch-stat BN, bias of a
 # softmax-pooled score, the Q6 gate): their measured gradient is rounding noise, so Adam turns it into
 # +-lr steps that no two implementations agree on.  They cannot change any output.
-NOISE_GRAD = re.compile(r"(conv[123]\.bias|tcn\.2\.bias|residual\.0\.bias|attn\.bias|fusion\.attn\.weight)$")
+NOISE_GRAD = re.compile(r"(conv[123]\.bias|tcn\.2\.bias|residual\.0\.bias|attn\.bias|to_k\.bias|fusion\.attn\.weight)$")
 
 
 def T(a):
