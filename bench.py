@@ -146,12 +146,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    local_rank %= torch.cuda.device_count()         # (rehearsals on a one-GPU box put every rank on cuda:0)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("MMEGO_DIST_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
 
     from mmego_amd import hip

@@ -104,6 +104,21 @@ int mmego_l1_loss(void* stream, const float* pred, const float* target, const in
 /* Keep the `keep` rows with the largest column-0 key, descending, ties lowest index first; idx is int64
  * (Lower_Net.py:216-227). */
 int mmego_topk_rows(void* stream, const float* pts, long F, int N, int C, int keep, float* out, long long* idx);
+/* Per-frame evaluation figures of `--infer` (Processor/Test/Demo_test.py:64-69,121-123,150-163):
+ * E[f,0:21] joint errors (m) of the assembled 21-joint skeleton, E[f,21:41] bone angles (deg),
+ * E[f,41] mean upper-joint error, E[f,42] mean lower-joint error.  Means over frames via mmego_colsum. */
+int mmego_pose_errors(void* stream, const float* upper, const float* lower, const float* target, long F, float* E);
+
+/* ---- anchor ("voxel") grouping of UpperNetwlocal (group.hip) -----------------------------------------
+ * Per frame and per anchor of the 3x3x3 grid: indices (int64, exact, stable ties) of the 8 nearest points and
+ * the gathered rows cat(anchor, xyz-anchor, features) -- square_distance / point_ball_set / AnchorGrouping of
+ * Net/Upper_Net.py:10-32,54-72,100-119 (quirk Q5: points with xyz == 0 are at distance +inf).
+ * xf rows hold xyz in columns 0:3 and D features after them; grouped is [F*27*8, 6+D]; dist_out may be NULL. */
+int mmego_anchor_group(void* stream, const float* xf, long ldx, long F, int N, int D, const float* anchors,
+                       long long* idx, float* grouped, float* dist_out);
+/* Scatter the gradient of the gathered rows back to the points (accumulates into dxf, fixed order). */
+int mmego_anchor_group_backward(void* stream, const float* dgrouped, const long long* idx, long F, int N, int D,
+                                float* dxf, long lddx);
 
 /* ---- pooling / attention / graph (pool.hip) -------------------------------------------------------
  * Softmax-attention pooling over the P points of each of G groups (Upper_Net.py:285-301,163-177,

@@ -338,3 +338,67 @@ extern "C" int mmego_topk_rows(void* stream, const float* pts, long F, int N, in
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
+
+// ---- evaluation metric (Processor/Test/Demo_test.py:64-69,121-123,150-163) ------------------------------------
+// Per frame: assemble the 21-joint skeleton (lower overwrites the shared hips), per-joint Euclidean error,
+// per-bone angle (deg) between predicted and true bone vectors, mean upper / lower joint error.
+// E[f, 0:21] joint errors, E[f, 21:41] bone angles, E[f, 41] upper mean, E[f, 42] lower mean.
+__global__ __launch_bounds__(128) void pose_errors_kernel(const float* __restrict__ upper, const float* __restrict__ lower,
+                                                          const float* __restrict__ target, long F, float* __restrict__ E) {
+  const int umap[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 20};
+  const int lmap[8] = {12, 13, 14, 15, 16, 17, 18, 19};
+  const int bones[20][2] = {{20, 3}, {3, 2}, {2, 1}, {2, 4}, {2, 8}, {4, 5}, {5, 6}, {6, 7}, {8, 9}, {9, 10},
+                            {10, 11}, {1, 0}, {0, 12}, {0, 16}, {12, 13}, {13, 14}, {14, 15}, {16, 17}, {17, 18}, {18, 19}};
+  long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  float p[21][3];
+  const float* tg = target + f * 63;
+  float up_sum = 0.f, lo_sum = 0.f;
+  for (int s = 0; s < 15; ++s) {
+    float d2 = 0.f;
+    for (int i = 0; i < 3; ++i) {
+      float v = upper[(f * 15 + s) * 3 + i];
+      p[umap[s]][i] = v;
+      float d = v - tg[umap[s] * 3 + i];
+      d2 += d * d;
+    }
+    up_sum += sqrtf(d2);
+  }
+  for (int s = 0; s < 8; ++s) {
+    float d2 = 0.f;
+    for (int i = 0; i < 3; ++i) {
+      float v = lower[(f * 8 + s) * 3 + i];
+      p[lmap[s]][i] = v;
+      float d = v - tg[lmap[s] * 3 + i];
+      d2 += d * d;
+    }
+    lo_sum += sqrtf(d2);
+  }
+  float* e = E + f * 43;
+  for (int j = 0; j < 21; ++j) {
+    float d2 = 0.f;
+    for (int i = 0; i < 3; ++i) { float d = p[j][i] - tg[j * 3 + i]; d2 += d * d; }
+    e[j] = sqrtf(d2);
+  }
+  for (int b = 0; b < 20; ++b) {
+    const int r = bones[b][0], l = bones[b][1];
+    float dot = 0.f, n1 = 0.f, n2 = 0.f;
+    for (int i = 0; i < 3; ++i) {
+      float a = p[l][i] - p[r][i], c = tg[l * 3 + i] - tg[r * 3 + i];
+      dot += a * c; n1 += a * a; n2 += c * c;
+    }
+    float cs = dot / (fmaxf(sqrtf(n1), 1e-8f) * fmaxf(sqrtf(n2), 1e-8f));
+    cs = fminf(fmaxf(cs, -1.0f), 1.0f);
+    e[21 + b] = fabsf(acosf(cs) / 3.14159265358f * 180.0f);
+  }
+  e[41] = up_sum / 15.f;
+  e[42] = lo_sum / 8.f;
+}
+
+extern "C" int mmego_pose_errors(void* stream, const float* upper, const float* lower, const float* target, long F,
+                                 float* E) {
+  MMEGO_REQUIRE(upper && lower && target && E && F > 0);
+  hipLaunchKernelGGL(pose_errors_kernel, dim3(cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, upper, lower, target, F, E);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

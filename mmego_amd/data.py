@@ -1,0 +1,150 @@
+"""Sample_data loader: per-frame .mat files -> fixed-size windows of radar points, skeletons, IMU and head pose.
+
+Counterpart of the reference's Util/Universal_Util/Dataset_sample.py:12-277 (class PosePC) -- same constructor,
+same per-item tuples, same array attributes.  The numpy global RNG is consumed in the same order as the
+reference (one choice() per frame for the slot layout, plus the reference's unused second draw), so
+``np.random.seed(k)`` before construction reproduces the reference's padded point clouds bit for bit
+(checked in tests/test_data_cpu.py against tests/golden/real16.npz).
+"""
+import glob
+import os
+import re
+
+import numpy as np
+import scipy.io as scio
+
+from .config import Config
+
+R_RI = np.array([[0, 0, 1], [0, -1, 0], [1, 0, 0]])
+R_TTB = np.array([[0, -1, 0], [-1, 0, 0], [0, 0, -1]])
+R_CTW = np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]])
+
+
+def _numeric_key(path):
+    return [int(tok) for tok in re.findall(r"\d+", os.path.basename(path))]
+
+
+def list_snippets(root):
+    """[(action_index, snippet_index, [frame files...])] in the reference's traversal order."""
+    out = []
+    actions = sorted(os.listdir(root), key=lambda name: int(name))
+    for a, action in enumerate(actions):
+        adir = os.path.join(root, action)
+        for j, snip in enumerate(sorted(os.listdir(adir))):
+            sdir = os.path.join(adir, snip)
+            if not os.path.isdir(sdir):
+                continue
+            frames = sorted(glob.glob(os.path.join(sdir, "*.mat")), key=_numeric_key)
+            if frames and not (a == 0 and j == 0):           # the reference skips the very first snippet
+                out.append((a, j, frames))
+    return out
+
+
+def pack_points(raw, pc_no):
+    """(n,5) x,y,z,intensity,velocity -> (pc_no,6) x,y,z,range,velocity,intensity, zero-padded at random slots
+    or randomly subsampled (Dataset_sample.py:203-224)."""
+    n = raw.shape[0]
+    pts = np.zeros((n, 6), dtype=np.float32)
+    pts[:, 0:3] = raw[:, :3]
+    pts[:, 3] = np.linalg.norm(raw[:, 0:3], axis=1)
+    pts[:, 4] = raw[:, 4]
+    pts[:, 5] = raw[:, 3]
+    if n < pc_no:
+        slots = np.random.choice(pc_no, size=n, replace=False)
+        np.random.choice(n, size=pc_no - n, replace=True)      # drawn and discarded by the reference; keeps RNG in step
+        frame = np.zeros((pc_no, 6), dtype=np.float32)
+        frame[slots] = pts
+        return frame
+    return pts[np.random.choice(n, size=pc_no, replace=False)]
+
+
+def imu_to_radar_frame(imu, orientation_ref):
+    """Rotate the 20x(9+3+3) IMU samples into the radar frame and fix signs/gravity (Dataset_sample.py:183-192).
+    Mutates and returns ``imu``."""
+    R_ni = np.stack([imu[:, :3], imu[:, 3:6], imu[:, 6:9]], axis=2)
+    rot = R_RI @ (orientation_ref.T @ R_ni) @ R_RI.T
+    imu[:, :3], imu[:, 3:6], imu[:, 6:9] = rot[:, 0, :], rot[:, 1, :], rot[:, 2, :]
+    imu[:, 11] = imu[:, 11] + 9.8
+    imu[:, 10:12] = -1 * imu[:, 10:12]
+    imu[:, 13:] = -1 * imu[:, 13:]
+    return imu
+
+
+class PosePC:
+    """Dataset of non-overlapping ``frame_no``-frame windows (taken from the tail of each recording)."""
+
+    def __init__(self, train=True, vis=False, batch_length=None, root=None):
+        self.vis, self.train = vis, train
+        self.pc_no = Config.pc_no
+        self.frame_no = batch_length if batch_length is not None else Config.frame_no
+        self.joint_selection = Config.kinect_joint_selection
+        self.skeleton = Config.skeleton_all.tolist()
+        self.root = root or Config.data_root
+        (self.data_ti_, self.data_key_, self.imu_, self.skl_, self.ground_, self.foot_contact_, self.R_R0R_,
+         self.t_R0R_, self.R_RtW_) = self._read()
+        n = len(self.data_ti_)
+        if not vis:
+            order = np.arange(n)
+            np.random.RandomState(Config.dataset_random_seed).shuffle(order)    # same permutation as shuffling each array
+            for name in ("data_ti_", "data_key_", "skl_", "ground_", "foot_contact_", "imu_", "R_R0R_", "t_R0R_"):
+                setattr(self, name, getattr(self, name)[order])
+        cut = int(n * 0.8)
+        sl = slice(0, n) if vis else (slice(0, cut) if train else slice(cut, n))
+        self._items = [getattr(self, k)[sl] for k in ("data_ti_", "data_key_", "skl_", "imu_", "ground_",
+                                                      "foot_contact_", "R_R0R_", "t_R0R_")]
+        if vis:
+            self._items.append(self.R_RtW_)
+
+    def __len__(self):
+        return len(self._items[0])
+
+    def __getitem__(self, i):
+        return tuple(a[i] for a in self._items)
+
+    # -----------------------------------------------------------------------------------------
+    def _read(self):
+        if not os.path.isdir(self.root):
+            raise FileNotFoundError("Sample_data not found at %s (set MMEGO_DATA_ROOT or Config.data_root)" % self.root)
+        win = {k: [] for k in ("ti", "key", "imu", "skl", "ground", "foot", "R", "t", "RtW")}
+        ref = None          # (R_btc, imu orientation, bone vectors) of the first frame ever read
+        for _, _, files in list_snippets(self.root):
+            rec = {k: [] for k in ("ti", "key", "imu", "ground", "foot", "R", "t", "RtW")}
+            for path in files:
+                m = scio.loadmat(path)
+                raw = np.asarray(m["pc_xyziv_ti2"][:, 0:5].tolist())
+                if len(raw) == 0:
+                    continue
+                joints = np.asarray([m["pc_xyz_key_2"][:, 0:3][i] for i in self.joint_selection])
+                imu = m["imu_save_l"]
+                if ref is None:
+                    bones = [joints[p] - joints[c] for p, c in self.skeleton]
+                    ref = (m["R_btc"], np.asarray(m["orientation_imu_img"]), bones)
+                R_btc = m["R_btc"]
+                rec["R"].append(R_TTB @ ref[0] @ R_btc.T @ R_TTB.T)
+                rec["RtW"].append(R_TTB @ R_btc @ R_CTW)
+                rec["imu"].append(imu_to_radar_frame(imu, ref[1]))
+                fc = m["foot_contact"]
+                rec["foot"].append([[0, 1] if fc[0, 0] else [1, 0], [0, 1] if fc[0, 1] else [1, 0]])
+                ground = m["abcd_ground_2"]
+                rec["ground"].append(-1 * ground if ground[0, 0] > 0 else ground)
+                rec["ti"].append(pack_points(raw, self.pc_no))
+                rec["key"].append(joints)
+                rec["t"].append(m["t_R0R"])
+            L = self.frame_no
+            while len(rec["ti"]) >= L:
+                for k in rec:
+                    win[k].append(rec[k][-L:])
+                    rec[k] = rec[k][:-L]
+                win["skl"].append(ref[2])
+        print("data load end")
+        return tuple(np.asarray(win[k]) for k in ("ti", "key", "imu", "skl", "ground", "foot", "R", "t", "RtW"))
+
+
+def batches(dataset, batch_size, shuffle, rng=None):
+    """Minibatch iterator (the reference uses torch DataLoader(num_workers=0, drop_last=False)): yields tuples of
+    stacked numpy arrays."""
+    n = len(dataset)
+    order = (rng or np.random).permutation(n) if shuffle else np.arange(n)
+    for s in range(0, n, batch_size):
+        idx = order[s:s + batch_size]
+        yield tuple(a[idx] for a in dataset._items)

@@ -1,0 +1,192 @@
+"""UpperNetwlocal on the HIP path: UpperNet plus the anchor ("voxel") branch.
+
+Reference Net/Upper_Net.py:406-432 (defined there but constructed by no trainer; part of the drop-in surface):
+PointNet -> {GlobalModule, LocalModule (anchor grouping -> LocalPointNet -> LocalVoxelNet -> BiLSTM)} ->
+CombineModule -> FK -> Transform2R.  forward returns the reference's 8-tuple.
+"""
+import torch
+import torch.nn as nn
+
+from . import blocks, hip, ops
+from .blocks import LstmParams
+from .nets import GlobalModule, PointNet, _Bridge, _Mlp3, _NetBase, _f32c, _require_gpu
+
+N_ANCHOR, N_GROUP = 27, 8
+
+
+def anchor_grid():
+    """(27,3) fp32 anchors in [z][y][x] order: x in {0,.3,.6}, y,z in {-.3,0,.3} (Upper_Net.py:75-97)."""
+    pts = [(0 + xi * 0.3, -0.3 + yi * 0.3, -0.3 + zi * 0.3) for zi in range(3) for yi in range(3) for xi in range(3)]
+    return torch.tensor(pts, dtype=torch.float32)
+
+
+class LocalPointNet(_Mlp3):
+    def __init__(self):
+        super().__init__((24 + 4 + 3, 32, 48, 64))
+        self.attn = nn.Linear(64, 1)
+
+
+class LocalVoxelNet(nn.Module):
+    """Conv3d(64,96,k=3) over the whole 3x3x3 grid (= one 1728->96 map) and two 1x1x1 convs (Upper_Net.py:180-205)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv3d(64, 96, kernel_size=(3, 3, 3), padding=(0, 0, 0))
+        self.cb1 = nn.BatchNorm3d(96)
+        self.conv2 = nn.Conv3d(96, 128, kernel_size=(1, 1, 1))
+        self.cb2 = nn.BatchNorm3d(128)
+        self.conv3 = nn.Conv3d(128, 64, kernel_size=(1, 1, 1))
+        self.cb3 = nn.BatchNorm3d(64)
+
+
+class LocalRNN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.rnn = LstmParams(64, 64, 3, dropout=0.1, bidirectional=True)
+
+
+class LocalModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.template_point = anchor_grid().view(3, 3, 3, 3)      # plain tensor attribute, as in the reference
+        self.apointnet = LocalPointNet()
+        self.avoxel = LocalVoxelNet()
+        self.arnn = LocalRNN()
+
+
+class CombineModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(256, 128)
+        self.fc2 = nn.Linear(128, 14 * 6 + 3)
+
+
+class UpperNetwlocal(_NetBase):
+    """forward(x, h0_g, c0_g, h0_a, c0_a, initial_body, R, t) ->
+    (l, q, global_weights, anchor_weights, hn_g, cn_g, hn_a, cn_a).  MUTATES x (Q1)."""
+
+    def __init__(self):
+        super().__init__()
+        self.module0 = PointNet()
+        self.module1 = GlobalModule()
+        self.module2 = LocalModule()
+        self.module3 = CombineModule()
+        self._anchors = None
+
+    def anchors(self, dev):
+        if self._anchors is None or self._anchors.device != dev:
+            self._anchors = self.module2.template_point.reshape(N_ANCHOR, 3).to(dev).contiguous()
+        return self._anchors
+
+    def forward(self, x, h0_g, c0_g, h0_a, c0_a, initial_body, R, t):
+        _require_gpu(x, "UpperNetwlocal")
+        args = (x, h0_g, c0_g, h0_a, c0_a, initial_body, R, t)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            self.flat()
+            return _Bridge.apply(self, 1, args, *self._flat.params)
+        return self._forward_impl(*args, stash=False)
+
+    def _forward_impl(self, x, h0g, c0g, h0a, c0a, body, R, t, stash=True):
+        self.flat()
+        training = self.training
+        ar = self.arena("train" if stash else "eval")
+        if not (x.dtype == torch.float32 and x.is_contiguous()):
+            raise ValueError("UpperNetwlocal: x must be a contiguous fp32 tensor (it is transformed in place)")
+        B, T, N, Cx = x.shape
+        F, rows = B * T, B * T * N
+        dev = x.device
+        R, t, body = _f32c(R), _f32c(t), _f32c(body)
+        h0g, c0g, h0a, c0a = [_f32c(v) if v is not None else None for v in (h0g, c0g, h0a, c0a)]
+        ops.transform2h_(x, R, t)
+        pts = x.view(rows, Cx)
+        if stash:
+            keep = ar.get("pts", (rows, Cx))
+            ops.copy2d(pts, keep)
+            pts = keep
+        feats = ar.get("feats", (rows, 28))
+        ops.copy2d(pts[:, :4], feats[:, :4])
+        blocks.mlp3_forward(ar, "m0", self.module0, pts, feats[:, 4:28], training)
+        # global branch
+        g3 = ar.get("g3", (rows, 64))
+        blocks.mlp3_forward(ar, "gp", self.module1.gpointnet, feats, g3, training)
+        vec = ar.get("vec", (F, 64))
+        gw = torch.empty((F, N, 1), dtype=torch.float32, device=dev)
+        blocks.attn_pool_forward(g3, self.module1.gpointnet.attn, F, N, 64, vec, gw)
+        p_g = self._drop_p(self.module1.grnn) if stash else 0.0
+        cat = ar.get("cat", (F, 256))
+        seq_g, hn_g, cn_g = blocks.lstm64_forward(ar, "grnn", self.module1.grnn, vec, B, T, h0g, c0g, stash, p_g, self.seed_counter())
+        ops.copy2d(seq_g, cat[:, :128])
+        # local branch: grouping -> LocalPointNet (+attention pool over the 8 members) -> voxel net -> BiLSTM
+        grows = F * N_ANCHOR * N_GROUP
+        grouped = ar.get("grouped", (grows, 31))
+        gidx = ar.get("gidx", (F, N_ANCHOR, N_GROUP), dtype=torch.int64)
+        hip.call("anchor_group", feats, 28, F, N, 25, self.anchors(dev), gidx, grouped, None)
+        self.last_group_idx = gidx
+        l3 = ar.get("l3", (grows, 64))
+        blocks.mlp3_forward(ar, "lp", self.module2.apointnet, grouped, l3, training)
+        vox = ar.get("vox", (F * N_ANCHOR, 64))
+        aw = torch.empty((F * N_ANCHOR, N_GROUP, 1), dtype=torch.float32, device=dev)
+        blocks.attn_pool_forward(l3, self.module2.apointnet.attn, F * N_ANCHOR, N_GROUP, 64, vox, aw)
+        voxT = ar.get("voxT", (F, 64 * N_ANCHOR))
+        hip.call("transpose_batched", vox, voxT, F, N_ANCHOR, 64)         # (F,27,64) -> (F,64,27): conv input order (cin,z,y,x)
+        vvec = ar.get("vvec", (F, 64))
+        blocks.mlp3_forward(ar, "vx", self.module2.avoxel, voxT, vvec, training)
+        p_a = self._drop_p(self.module2.arnn.rnn) if stash else 0.0
+        seq_a, hn_a, cn_a = blocks.lstm64_forward(ar, "arnn", self.module2.arnn.rnn, vvec, B, T, h0a, c0a, stash, p_a, self.seed_counter())
+        ops.copy2d(seq_a, cat[:, 128:])
+        # combine head
+        h1 = ar.get("h1", (F, 128))
+        ops.linear(cat, self.module3.fc1.weight, self.module3.fc1.bias, h1, relu=True)
+        y = ar.get("y", (F, 87))
+        ops.linear(h1, self.module3.fc2.weight, self.module3.fc2.bias, y)
+        q = torch.empty((B, T, 14, 3, 3), dtype=torch.float32, device=dev)
+        jh = ar.get("jh", (F, 15, 3))
+        hip.call("head_fk_forward", 0, y, body, B, F, q, jh)
+        l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=dev)
+        ops.rotate_points(jh, l, R, t, transpose=True)
+        if training:
+            self._flat.bump_bn_counters()
+        if stash:
+            self._saved = (B, T, N, R, body, c0g, c0a, gw, aw)
+        return l, q, gw, aw, hn_g, cn_g, hn_a, cn_a
+
+    def _backward_impl(self, dl):
+        ar = self.arena("train")
+        B, T, N, R, body, c0g, c0a, gw, aw = self._saved
+        F, rows = B * T, B * T * N
+        grows = F * N_ANCHOR * N_GROUP
+        G = self._flat.grad
+        dl = _f32c(dl)
+        djh = ar.get("djh", (F, 15, 3))
+        ops.rotate_points(dl, djh, R, None, transpose=False)
+        y, h1, cat = ar.get("y", (F, 87)), ar.get("h1", (F, 128)), ar.get("cat", (F, 256))
+        dy = ar.get("dy", (F, 87))
+        hip.call("head_fk_backward", 0, y, body, B, F, djh, dy)
+        dh1 = ar.get("dh1", (F, 128))
+        blocks.linear_backward(dy, h1, self.module3.fc2, G, dh1)
+        ops.relu_mask_(dh1, h1)
+        dcat = ar.get("dcat", (F, 256))
+        blocks.linear_backward(dh1, cat, self.module3.fc1, G, dcat)
+        # global branch
+        vec = ar.get("vec", (F, 64))
+        dvec = blocks.lstm64_backward(ar, "grnn", self.module1.grnn, vec, B, T, c0g, dcat[:, :128], G, self._drop_p(self.module1.grnn), True)
+        g3, dg3 = ar.get("g3", (rows, 64)), ar.get("dg3", (rows, 64))
+        blocks.attn_pool_backward(ar, "gpool", g3, self.module1.gpointnet.attn, gw, dvec, F, N, 64, dg3, G)
+        feats = ar.get("feats", (rows, 28))
+        dfeats = blocks.mlp3_backward(ar, "gp", self.module1.gpointnet, feats, g3, dg3, G, True)
+        # local branch
+        vvec = ar.get("vvec", (F, 64))
+        dvvec = blocks.lstm64_backward(ar, "arnn", self.module2.arnn.rnn, vvec, B, T, c0a, dcat[:, 128:], G,
+                                       self._drop_p(self.module2.arnn.rnn), True)
+        voxT = ar.get("voxT", (F, 64 * N_ANCHOR))
+        dvoxT = blocks.mlp3_backward(ar, "vx", self.module2.avoxel, voxT, vvec, dvvec, G, True)
+        dvox = ar.get("dvox", (F * N_ANCHOR, 64))
+        hip.call("transpose_batched", dvoxT, dvox, F, 64, N_ANCHOR)       # (F,64,27) -> (F,27,64)
+        l3, dl3 = ar.get("l3", (grows, 64)), ar.get("dl3", (grows, 64))
+        blocks.attn_pool_backward(ar, "lpool", l3, self.module2.apointnet.attn, aw, dvox, F * N_ANCHOR, N_GROUP, 64, dl3, G)
+        grouped = ar.get("grouped", (grows, 31))
+        dgrouped = blocks.mlp3_backward(ar, "lp", self.module2.apointnet, grouped, l3, dl3, G, True)
+        gidx = ar.get("gidx", (F, N_ANCHOR, N_GROUP), dtype=torch.int64)
+        hip.call("anchor_group_backward", dgrouped, gidx, F, N, 25, dfeats, 28)
+        pts = ar.get("pts", (rows, 6))
+        blocks.mlp3_backward(ar, "m0", self.module0, pts, feats[:, 4:28], dfeats[:, 4:28], G, False)

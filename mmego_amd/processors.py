@@ -1,0 +1,309 @@
+"""Stage trainers and the `--infer` evaluator on the HIP path.
+
+Counterparts of the reference's Processor/Train/Train_Upper.py:20-251, Train_Lower.py:23-332,
+Train_IMU.py:38-185 and Processor/Test/Demo_test.py:23-184: same class shape (``MMEgo`` with
+train_upper / train_lower / train_once / eval_model), same directory side effects
+(Processor/Train/{report,model,lossAndacc}/<Idx>/, log-loss.txt, log-eval.txt, epoch*_batch*frame*lr*.pth),
+same stdout lines for `--infer`.  Plotting (matplotlib/seaborn) is out of scope.
+
+Data parallel (not in the reference): when launched under torch.distributed.run each rank trains on its
+own shard of every epoch's shuffled order; gradients are summed with one RCCL all-reduce per step.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import hip, ops
+from .config import Config, ConfigDemo
+from .data import PosePC, batches
+from .nets import IMUNet, LowerNet, UpperNet
+from .train_step import StageStep, shard_of
+from .utils import EarlyStopping
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_TRAIN_DIR = os.path.join(os.path.dirname(_HERE), "Processor", "Train")
+
+
+def _dev_tensor(a, device):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(device)
+
+
+class _Base:
+    """Shared set-up: directories, frozen IMU_Net (or ground-truth head pose), datasets."""
+
+    def __init__(self, cfg, make_dirs=True):
+        self.cfg = cfg
+        self.device = torch.device(cfg.device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the mmego_amd processors run on the MI355X HIP path only (device=%s)" % cfg.device)
+        hip.lib()
+        self.frame_no, self.batchsize = cfg.frame_no, getattr(cfg, "batch_size", 20)
+        self.Idx = cfg.Idx
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        if make_dirs and self.rank == 0:
+            for sub in ("report", "model", "lossAndacc"):
+                path = os.path.join(_TRAIN_DIR, sub, str(self.Idx))
+                os.makedirs(path, exist_ok=True)
+                print("%s saved in %s" % ({"report": "report", "model": "model", "lossAndacc": "Loss and accuracy"}[sub], path))
+
+    def _load_imu(self):
+        imu = IMUNet(15, 6 + 3, 512, 2, True, 0.1).to(self.device).eval()
+        if self.cfg.gt_head_pose:
+            print("[mmego_amd] head pose from the recording (R_R0R, ground-truth head joint); IMU_Net not used")
+            return None
+        if not os.path.exists(self.cfg.model_IMU_path):
+            raise FileNotFoundError("IMU_Net checkpoint %s not found (it is absent from the reference snapshot); pass "
+                                    "--load_IMU_path or --gt_head_pose" % self.cfg.model_IMU_path)
+        imu.load(self.cfg.model_IMU_path)
+        return imu
+
+    def head_pose(self, imu_net, imu, R_R0R, target):
+        """(R, t) fed to Upper/Lower: frozen IMU_Net output, or the recorded pose when --gt_head_pose."""
+        if imu_net is None:
+            return R_R0R.contiguous(), target[:, :, 20].contiguous()
+        with torch.no_grad():
+            return imu_net(imu)
+
+    def save_models(self, epoch, model):
+        if self.rank == 0:
+            torch.save(model.state_dict(), os.path.join(_TRAIN_DIR, "model", str(self.Idx), "epoch{}_batch{}frame{}lr{}.pth".format(
+                epoch, self.batchsize, self.frame_no, self.learning_rate)))
+
+    def pose_metrics(self, upper_l, lower_l, target):
+        """Demo_test per-batch figures on the device -> (all, upper, lower, per_joint[21], angle[20])."""
+        F = upper_l.shape[0] * upper_l.shape[1]
+        E = torch.empty((F, 43), dtype=torch.float32, device=self.device)
+        hip.call("pose_errors", upper_l.contiguous(), lower_l.contiguous(), target.contiguous(), F, E)
+        s = torch.empty(43, dtype=torch.float32, device=self.device)
+        ops.colsum(E, s)
+        m = (s / F).cpu().numpy().astype(np.float64)
+        return float(m[:21].mean()), float(m[41]), float(m[42]), m[:21], m[21:41]
+
+
+class _StageTrainer(_Base):
+    stage = None
+
+    def __init__(self):
+        super().__init__(Config)
+        cfg = self.cfg
+        self.num_epochs, self.save_slot, self.learning_rate = cfg.epochs, 50, cfg.lr
+        self.model_IMU = self._load_imu()
+        self.train_data = PosePC(batch_length=self.frame_no)
+        self.test_data = PosePC(train=False, batch_length=self.frame_no)
+        rep = os.path.join(_TRAIN_DIR, "report", str(self.Idx))
+        self.lossfile = open(os.path.join(rep, "log-loss.txt"), "w") if self.rank == 0 else None
+        self.evalfile = open(os.path.join(rep, "log-eval.txt"), "w") if self.rank == 0 else None
+        self._steps = {}
+        self._rng = np.random.RandomState(1234)
+
+    def _step_for(self, B):
+        """One StageStep (static buffers, optional HIP graph) per minibatch size."""
+        st = self._steps.get(B)
+        if st is None:
+            pg = torch.distributed.group.WORLD if self.world > 1 else None
+            st = StageStep(self.stage, self.model, self.model_IMU, upper_frozen=getattr(self, "Upper_net", None),
+                           lr=self.learning_rate, process_group=pg, use_graph=True)
+            if self._steps:
+                st.opt = next(iter(self._steps.values())).opt           # one optimiser state for all batch sizes
+            self._steps[B] = st
+        return st
+
+    def train_once(self):
+        self.model.train()
+        losses, accs = [], []
+        nsel = self.model_out_joints
+        jmap = self.cfg.upper_joint_map if self.stage == "upper" else self.cfg.lower_joint_map
+        for bi, (data, target, skl, imu, _, _, R_R0R, _) in enumerate(batches(self.train_data, self.batchsize * self.world, True, self._rng)):
+            sl = shard_of(self.rank, self.world)                        # this rank's shard of the global minibatch
+            data, target, skl, imu, R_R0R = data[sl], target[sl], skl[sl], imu[sl], R_R0R[sl]
+            if len(data) == 0:
+                continue
+            B = len(data)
+            st = self._step_for(B)
+            dev = self.device
+            x, tgt = _dev_tensor(data, dev), _dev_tensor(target, dev)
+            if st.static is None or st.static["x_src"].shape != x.shape:
+                st.bind(x, _dev_tensor(imu, dev), _dev_tensor(skl, dev), tgt, R_gt=_dev_tensor(R_R0R, dev))
+            else:                                                       # refill the static buffers (graph inputs)
+                st.static["x_src"].copy_(x); st.static["target"].copy_(tgt)
+                st.static["imu"].copy_(_dev_tensor(imu, dev)); st.static["body"].copy_(_dev_tensor(skl, dev))
+                st.static["R_gt"].copy_(_dev_tensor(R_R0R, dev))
+            loss = st.step()
+            pred = st.last_pred
+            acc = torch.mean(torch.sqrt(torch.sum(torch.square(pred - tgt[:, :, jmap, :]), dim=-1)))
+            losses.append(loss.item())
+            accs.append(acc.item())
+        assert nsel in (15, 8)
+        return accs, losses
+
+    def _train_loop(self, extra_print):
+        early = EarlyStopping(patience=30)
+        out = None
+        for epoch in range(self.num_epochs):
+            print("epoch: {}".format(epoch + 1))
+            self.train_once()
+            if (epoch + 1) % self.save_slot == 0:
+                self.save_models(epoch, self.model)
+            out = self.eval_model()
+            eval_loss, eval_loss_l, eval_accu, second, accu_ll, angle_ll = out
+            if self.rank == 0:
+                self.lossfile.write("%d %f\n" % (epoch + 1, eval_loss))
+                self.lossfile.write(str(eval_loss_l) + "\n")
+                self.lossfile.flush()
+                extra_print(epoch, out)
+            if early(eval_loss):
+                print("Early stopping")
+                self.save_models(epoch, self.model)
+                break
+        return out
+
+
+class UpperTrainer(_StageTrainer):
+    """`python main.py --train --network Upper_Net` (reference Train_Upper.MMEgo)."""
+    stage = "upper"
+    model_out_joints = 15
+
+    def __init__(self):
+        super().__init__()
+        self.model = UpperNet().to(self.device)
+        if self.cfg.Upper_pretrained:
+            self.model.load(self.cfg.model_upper_path)
+
+    def train_upper(self):
+        def report(epoch, out):
+            eval_loss, eval_loss_l, eval_accu, dis_l, accu_ll, angle_ll = out
+            self.evalfile.write("%d %f %f\n" % (epoch + 1, eval_accu, sum(angle_ll) / len(angle_ll)))
+            self.evalfile.write(str(accu_ll) + "\n" + str(angle_ll) + "\n" + str(accu_ll[self.cfg.hand_joint_map]) + "\n")
+            self.evalfile.flush()
+            print("\n wrist elbow(l, r): {}".format(accu_ll[self.cfg.hand_joint_map]))
+            print("Average Joint Localization Error: {}".format(eval_accu))
+            print("Average Joint Rotation Error: {}".format(sum(angle_ll) / len(angle_ll)))
+            print(accu_ll)
+            print("Eval_loss: {} Eval_loss_l (l, g): {} \n Angle_loss: {} \n".format(eval_loss, eval_loss_l, angle_ll))
+        return self._train_loop(report)
+
+    def eval_model(self):
+        self.model.eval()
+        dev = self.device
+        umap = self.cfg.upper_joint_map
+        loss_l, accu_l, per_joint, angles, dis = [], [], [], [], []
+        bones = [(umap.index(p), umap.index(c)) for p, c in self.cfg.skeleton_upper_body.tolist()]
+        with torch.no_grad():
+            for data, target, skl, imu, _, _, R_R0R, _ in batches(self.test_data, self.batchsize, True, self._rng):
+                B, T = data.shape[0], data.shape[1]
+                x, tgt = _dev_tensor(data, dev), _dev_tensor(target, dev)
+                R, t = self.head_pose(self.model_IMU, _dev_tensor(imu, dev), _dev_tensor(R_R0R, dev), tgt)
+                h0 = torch.zeros((6, B, 64), device=dev)
+                up = self.model(x, h0, h0.clone(), _dev_tensor(skl, dev), R, t)[0]
+                tu = tgt[:, :, umap, :]
+                loss_l.append((up - tu).abs().sum().item() / B / T)
+                d = torch.sqrt(torch.sum(torch.square(up - tu), dim=-1))
+                accu_l.append(d.mean().item())
+                per_joint.append(d.mean(0).mean(0).cpu().numpy())
+                dis.append((up - tu).abs().mean().item())
+                pv = torch.stack([up[:, :, c] - up[:, :, p] for p, c in bones], 2)
+                tv = torch.stack([tu[:, :, c] - tu[:, :, p] for p, c in bones], 2)
+                cs = torch.nn.functional.cosine_similarity(pv, tv, dim=-1)
+                angles.append((torch.acos(cs.clamp(-1.0, 1.0)) / 3.14159265358 * 180.0).abs().mean(0).mean(0).cpu().numpy())
+        eval_loss = float(np.mean(loss_l))
+        return (eval_loss, np.asarray([eval_loss / self.cfg.joint_num_upper]), float(np.mean(accu_l)), float(np.mean(dis)),
+                np.mean(per_joint, axis=0), np.mean(angles, axis=0))
+
+
+class LowerTrainer(_StageTrainer):
+    """`python main.py --train --network Lower_Net` (reference Train_Lower.MMEgo)."""
+    stage = "lower"
+    model_out_joints = 8
+
+    def __init__(self):
+        super().__init__()
+        self.model = LowerNet(hidden_dim=64).to(self.device)
+        if self.cfg.Lower_pretrained:
+            self.model.load(self.cfg.model_lower_path)
+        self.Upper_net = UpperNet().to(self.device).eval()
+        self.Upper_net.load(self.cfg.model_upper_path)
+
+    def train_lower(self):
+        def report(epoch, out):
+            eval_loss, eval_loss_l, eval_accu, accu_lower, accu_ll, angle_ll = out
+            self.evalfile.write("%d %f %f %f\n" % (epoch + 1, eval_accu, accu_lower, sum(angle_ll) / len(angle_ll)))
+            self.evalfile.write(str(accu_ll) + "\n" + str(angle_ll) + "\n" + str(accu_ll[self.cfg.hand_joint_map]) + "\n")
+            self.evalfile.flush()
+            print("\n wrist elbow(l, r): {}".format(accu_ll[self.cfg.hand_joint_map]))
+            print("Average Joint Localization Error: {}".format(eval_accu))
+            print("Average LowerBody Joint Localization Error: {}".format(accu_lower))
+            print("Average Joint Rotation Error: {}".format(sum(angle_ll) / len(angle_ll)))
+            print(accu_ll)
+            print("Eval_loss: {} Eval_loss_l (l, g): {} \n Angle_loss: {}".format(eval_loss, eval_loss_l, angle_ll))
+        return self._train_loop(report)
+
+    def eval_model(self):
+        self.model.eval()
+        return evaluate_full(self, self.model_IMU, self.Upper_net, self.model, batches(self.test_data, self.batchsize, True, self._rng))[0]
+
+
+def evaluate_full(base, imu_net, upper_net, lower_net, batch_iter):
+    """IMU -> Upper -> Lower over an iterator of minibatches; returns (reference-style tuple, summary dict)."""
+    dev = base.device
+    cfg = base.cfg
+    loss_l, accu_l, accu_up, accu_lo, per_joint, angles = [], [], [], [], [], []
+    lmap = cfg.lower_joint_map
+    with torch.no_grad():
+        for batch in batch_iter:
+            data, target, skl, imu, R_R0R = batch[0], batch[1], batch[2], batch[3], batch[6]
+            B, T = data.shape[0], data.shape[1]
+            x, tgt = _dev_tensor(data, dev), _dev_tensor(target, dev)
+            R, t = base.head_pose(imu_net, _dev_tensor(imu, dev), _dev_tensor(R_R0R, dev), tgt)
+            h0 = torch.zeros((6, B, 64), device=dev)
+            body = _dev_tensor(skl, dev)
+            up = upper_net(x, h0, h0.clone(), body, R, t)[0]
+            lo, _ = lower_net(up.clone(), x, h0, h0, h0, h0, body, R, t)        # x already transformed once (Q1)
+            loss_l.append((lo - tgt[:, :, lmap, :]).abs().sum().item() / B / T)
+            a, u, l, pj, ang = base.pose_metrics(up, lo, tgt)
+            accu_l.append(a); accu_up.append(u); accu_lo.append(l); per_joint.append(pj); angles.append(ang)
+    eval_loss = float(np.mean(loss_l))
+    accu_ll, angle_ll = np.mean(per_joint, axis=0), np.mean(angles, axis=0)
+    summary = dict(all_cm=float(np.mean(accu_l)) * 100, upper_cm=float(np.mean(accu_up)) * 100, lower_cm=float(np.mean(accu_lo)) * 100,
+                   rot_deg=float(sum(angle_ll) / len(angle_ll)), per_joint_cm=accu_ll * 100)
+    return (eval_loss, np.asarray([eval_loss / cfg.joint_num_lower]), float(np.mean(accu_l)), float(np.mean(accu_lo)), accu_ll, angle_ll), summary
+
+
+class Evaluator(_Base):
+    """`python main.py --infer` (reference Processor/Test/Demo_test.MMEgo.eval_model)."""
+
+    def __init__(self):
+        super().__init__(ConfigDemo, make_dirs=False)
+        cfg = self.cfg
+        self.model = LowerNet(hidden_dim=64).to(self.device).eval()
+        self.model_IMU = self._load_imu()
+        self.Upper_net = UpperNet().to(self.device).eval()
+        self.Upper_net.load(cfg.model_upper_path)
+        self.vis_data = PosePC(train=False, vis=True, batch_length=self.frame_no)
+
+    def eval_model(self):
+        self.model.load(self.cfg.model_lower_path)
+        self.model.eval()
+        out, s = evaluate_full(self, self.model_IMU, self.Upper_net, self.model, batches(self.vis_data, 1, False))
+        print("Average Joint Localization Error(cm): {}".format(s["all_cm"]))
+        print("Average UpperBody Joint Localization Error(cm): {}".format(s["upper_cm"]))
+        print("Average LowerBody Joint Localization Error(cm): {}".format(s["lower_cm"]))
+        print("Average Joint Rotation Error(°): {}".format(s["rot_deg"]))
+        print("Per Joint Localization Error(cm): {}".format(s["per_joint_cm"]))
+        return out
+
+    def eval_all_skeleton(self):
+        raise NotImplementedError("--vis (matplotlib animation) is outside the hot path and not provided")
+
+
+class ImuTrainer(_Base):
+    """`python main.py --train --network IMU_Net` (reference Train_IMU.MMEgo): stage 1 needs the BiLSTM-512 backward,
+    which is the next hot-path row and not on the HIP path yet."""
+
+    def __init__(self):
+        super().__init__(Config)
+
+    def train_imu(self):
+        raise NotImplementedError("IMU_Net stage-1 training is not on the HIP path yet (forward only); "
+                                  "train Upper/Lower with --load_IMU_path or --gt_head_pose")

@@ -13,8 +13,24 @@ from .params import FusedAdam
 from .skeleton import LOWER_MAP, UPPER_MAP
 
 
+def allreduce_grads(flat, process_group):
+    """SUM the flat gradient buffer over the ranks with ONE collective (RCCL over xGMI on the GPUs, gloo in the
+    CPU tests).  The loss is a SUM over the batch, so the global-batch gradient is the SUM of the shard
+    gradients -- not the mean."""
+    if process_group is not None and torch.distributed.get_world_size(process_group) > 1:
+        torch.distributed.all_reduce(flat.flat_g, op=torch.distributed.ReduceOp.SUM, group=process_group)
+
+
+def shard_of(rank, world):
+    """Slice of a global minibatch owned by ``rank`` (interleaved: balances a short last batch)."""
+    return slice(rank, None, world)
+
+
 class StageStep:
-    """One training stage's per-minibatch body with static buffers (graph friendly)."""
+    """One training stage's per-minibatch body with static buffers (graph friendly).
+
+    ``imu_net=None`` takes the head pose from the recording (R_gt, ground-truth head joint) instead of the
+    frozen IMU_Net -- the shipped reference snapshot has no IMU_Net checkpoint."""
 
     def __init__(self, stage, net, imu_net, upper_frozen=None, lr=3e-5, weight_decay=0.0, process_group=None,
                  use_graph=True):
@@ -28,13 +44,18 @@ class StageStep:
         dev = next(net.parameters()).device
         self.jmap = torch.tensor(UPPER_MAP if stage == "upper" else LOWER_MAP, dtype=torch.int32, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.last_pred = None
 
     def _body(self):
         s = self.static
         B, T = s["x"].shape[0], s["x"].shape[1]
         ops.copy2d(s["x_src"].view(B * T, -1), s["x"].view(B * T, -1))        # fresh batch (x is transformed in place)
         with torch.no_grad():
-            R, t = self.imu(s["imu"])
+            if self.imu is not None:
+                R, t = self.imu(s["imu"])
+            else:
+                R, t = s["R_gt"], s["t_gt"]
+                ops.copy2d(s["target"].view(B * T, 63)[:, 60:63], t.view(B * T, 3))
             if self.stage == "upper":
                 l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["body"], R, t, stash=True)[0]
                 nsel = 15
@@ -42,19 +63,21 @@ class StageStep:
                 up = self.upper_frozen(s["x"], s["h0"], s["c0"], s["body"], R, t)[0]
                 l = self.net._forward_impl(up, s["x"], s["body"], R, t, stash=True)[0]
                 nsel = 8
-            dl = s["dl"]
-            hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss, dl)
-            self.net._backward_impl(dl)
+            hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss, s["dl"])
+            self.net._backward_impl(s["dl"])
         self.last_pred = l
 
-    def bind(self, x, imu, body, target):
+    def bind(self, x, imu, body, target, R_gt=None):
         """Register the (device-resident) minibatch buffers; contents may be overwritten between steps."""
         dev = x.device
-        B = x.shape[0]
+        B, T = x.shape[0], x.shape[1]
         nsel = 15 if self.stage == "upper" else 8
+        if self.imu is None and R_gt is None:
+            raise ValueError("StageStep without an IMU_Net needs the recorded head rotations (R_gt)")
         self.static = dict(x_src=x, x=torch.empty_like(x), imu=imu, body=body, target=target,
                            h0=torch.zeros(6, B, 64, device=dev), c0=torch.zeros(6, B, 64, device=dev),
-                           dl=torch.empty(B, x.shape[1], nsel, 3, device=dev))
+                           dl=torch.empty(B, T, nsel, 3, device=dev), R_gt=R_gt,
+                           t_gt=torch.empty(B, T, 3, device=dev))
         self.graph = None
 
     def step(self):
@@ -69,8 +92,6 @@ class StageStep:
             self.graph.replay()
         else:
             self._body()
-        if self.pg is not None and torch.distributed.get_world_size(self.pg) > 1:
-            # loss is a SUM over the batch, so the global-batch gradient is the SUM of shard gradients
-            torch.distributed.all_reduce(self.net._flat.flat_g, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        allreduce_grads(self.net._flat, self.pg)
         self.opt.step()
         return self.loss
