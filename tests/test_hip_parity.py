@@ -165,7 +165,7 @@ def _train_pair(tag, seed, octor, hctor, dev):
     return o.train(), h.to(dev).train()
 
 
-def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev):
+def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev, later_grad_tol=2e-4):
     from mmego_amd.params import FusedAdam
     opt_o = torch.optim.Adam(o.parameters(), lr=3e-5)
     opt_h = FusedAdam(h.flat(), lr=3e-5)
@@ -187,7 +187,9 @@ def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev):
             go = po[k].grad if po[k].grad is not None else torch.zeros_like(po[k])
             gh = ph[k].grad.cpu()
             err = (gh - go).abs().max().item()
-            assert err < 2e-4 * scale, (tag, step, k, err, scale)
+            # after the first Adam step the two runs no longer hold bit-equal weights (sign-of-noise updates), so
+            # later steps compare two slightly different points of an ill-conditioned BatchNorm chain
+            assert err < (2e-4 if step == 1 else later_grad_tol) * scale, (tag, step, k, err, scale)
         if step == 1:
             grads = [(k, p.grad) for k, p in ph.items()]
             check_pinned(g, "%s.grad." % tag, grads, rtol=5e-3, atol=5e-3 * scale)     # vs the real reference
