@@ -224,14 +224,25 @@ def main():
         eager()
         torch.cuda.synchronize()
         rec, iters = profile_kernels(eager, ("lstm_step", "gemm"))
-        # lstm_step: args = (ndir, Bn, H, ...): flops = ndir * 2 * Bn * 4H * H
-        steps_big = [(ms_, 2.0 * a[0] * a[1] * 4 * a[2] * a[2]) for ms_, a in rec["lstm_step"] if a[1] >= 512 and a[2] == 512]
-        gemm_big = [(ms_, 2.0 * a[10] * a[11] * a[12]) for ms_, a in rec["gemm"] if a[10] * a[11] * a[12] >= 2 ** 32]
+        # lstm_step: args = (ndir, Bn, H, first, ...).  Algorithmic flops per launch = 2 * ndir * Bn * 4H * H (0 for the
+        # first timestep of a sequence, whose h_{t-1} = 0 product is skipped).  ALL launches of the kernel family are
+        # averaged, so avg_launch_us is directly comparable with rocprofv3's per-kernel AverageNs.
+        def step_flops(a):
+            return 0.0 if a[3] else 2.0 * a[0] * a[1] * 4 * a[2] * a[2]
+        big = [(ms_, step_flops(a)) for ms_, a in rec["lstm_step"] if a[1] >= 128]
+        small = [(ms_, step_flops(a)) for ms_, a in rec["lstm_step"] if a[1] < 128]
+
+        def is_gemm128(a):   # the dispatch rule of mmego_gemm (gemm.hip)
+            return (a[13] == 1 and a[20] == 1 and not a[18] and a[2] == 1 and a[4] == 1 and a[8] == 1 and a[10] % 128 == 0
+                    and a[11] % 128 == 0 and a[12] % 16 == 0)
+        g128 = [(ms_, 2.0 * a[10] * a[11] * a[12]) for ms_, a in rec["gemm"] if is_gemm128(a)]
         cands = {}
-        if steps_big:
-            cands["lstm_step_kernel (IMU_Net rnn_fast recurrent step, 2 dirs x 512 rows x 2048 gates x K=512)"] = steps_big
-        if gemm_big:
-            cands["gemm128_nt_kernel (IMU_Net LSTM input projections, 10240 x 2048 x K)"] = gemm_big
+        if big:
+            cands["lstm_step_kernel (IMU_Net rnn_fast recurrent steps: 2 dirs x 512 rows x 2048 gates x K=512 per launch)"] = big
+        if small:
+            cands["lstm_step_small_kernel (IMU_Net rnn_slow recurrent steps: 2 dirs x 64 rows x 2048 gates x K=512)"] = small
+        if g128:
+            cands["gemm128_nt_kernel (LSTM input projections and other 128-aligned products)"] = g128
         best = max(cands.items(), key=lambda kv: sum(m for m, _ in kv[1]))
         tot_ms = sum(m for m, _ in best[1])
         tot_fl = sum(f for _, f in best[1])
@@ -239,10 +250,11 @@ def main():
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": best[0],
                            "avg_launch_us": tot_ms / len(best[1]) * 1e3, "launches_per_step": len(best[1]) // iters,
-                           "flop_per_launch": tot_fl / len(best[1]),
+                           "flop_per_launch_avg": tot_fl / len(best[1]),
                            "share_of_step": (tot_ms / iters) / (t_u + t_l)}
         out["kernels"] = {k: {"avg_us": sum(m for m, _ in v) / len(v) * 1e3, "launches_per_step": len(v) // iters,
-                              "tflops": sum(f for _, f in v) / (sum(m for m, _ in v) * 1e-3) / 1e12} for k, v in cands.items()}
+                              "tflops": sum(f for _, f in v) / (sum(m for m, _ in v) * 1e-3) / 1e12,
+                              "ms_per_step": sum(m for m, _ in v) / iters} for k, v in cands.items()}
         sys.stderr.write("[bench] gpu part done: %.1f frames/s; timing the CPU oracle on %d threads\n" % (out["value"], host_cores()))
         sys.stderr.flush()
         if world == 1 and not args.no_cpu_baseline:

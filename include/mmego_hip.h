@@ -64,17 +64,20 @@ int mmego_fill(void* stream, float* X, long n, float v);
 /* ---- LSTM (lstm.hip) ------------------------------------------------------------------------------
  * One timestep of a (bi)LSTM, any H % 32 == 0: gates = xproj + hprev . W_hh^T, fused cell update, c in
  * place.  Replaces the recurrent half of nn.LSTM for IMU_Net (Net/IMU_Net.py:58-62,77,82); xproj is the
- * input projection (incl. b_ih + b_hh) produced by mmego_gemm.  Row strides: hps, xs, hos. */
-int mmego_lstm_step(void* stream, int ndir, int Bn, int H, const float* hprev0, const float* hprev1, long hps,
-                    const float* whh0, const float* whh1, const float* xproj0, const float* xproj1, long xs,
-                    float* hout0, float* hout1, long hos, float* c0, float* c1);
+ * input projection (incl. b_ih) produced by mmego_gemm, b_hh is added here.  first != 0: h_{t-1} = c_{t-1} = 0
+ * (hprev may be NULL, the product is skipped).  Row strides: hps, xs, hos. */
+int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first, const float* hprev0, const float* hprev1,
+                    long hps, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
+                    const float* xproj0, const float* xproj1, long xs, float* hout0, float* hout1, long hos, float* c0,
+                    float* c1);
 /* Whole-sequence H=64 bidirectional LSTM layer (Upper_Net.py:333, Lower_Net.py:91, Upper_Net.py:210).
  * xproj_d rows are (b*T+t) with row stride xs; out rows (b*T+t) with row stride os, direction d in
  * columns [64d, 64d+64).  Optional stashes for backward: gates_d [T][B][256], cst_d [T][B][64],
  * hprev_d [(b*T+t)][64]. */
 int mmego_lstm64_forward(void* stream, int B, int T, const float* xproj0, const float* xproj1, long xs,
-                         const float* whh0, const float* whh1, const float* h0_0, const float* h0_1, const float* c0_0,
-                         const float* c0_1, float* out, long os, float* hn0, float* hn1, float* cn0, float* cn1,
+                         const float* whh0, const float* whh1, const float* bhh0, const float* bhh1, const float* h0_0,
+                         const float* h0_1, const float* c0_0, const float* c0_1, float* out, long os, float* hn0,
+                         float* hn1, float* cn0, float* cn1,
                          float* gates0, float* gates1, float* cst0, float* cst1, float* hprev0, float* hprev1);
 /* Backward through time of the same layer: dgates_d rows (b*T+t), row stride dgs (pre-activation
  * gradients; weight/input gradients follow as mmego_gemm products). */

@@ -106,9 +106,7 @@ def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr):
     for l in range(L):
         xp = ar.get("%s.xp%d" % (key, l), (B * T, 512))
         for d in range(2):
-            bsum = ar.get("%s.bs%d%d" % (key, l, d), (256,))
-            hip.call("add", lstm.w("bias_ih", l, d), lstm.w("bias_hh", l, d), bsum, 256)
-            ops.linear(cur, lstm.w("weight_ih", l, d), bsum, xp[:, d * 256:(d + 1) * 256])
+            ops.linear(cur, lstm.w("weight_ih", l, d), lstm.w("bias_ih", l, d), xp[:, d * 256:(d + 1) * 256])
         out = ar.get("%s.out%d" % (key, l), (B * T, 128))
         if stash:
             gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
@@ -122,7 +120,7 @@ def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr):
         c00 = c0[2 * l] if c0 is not None else None
         c01 = c0[2 * l + 1] if c0 is not None else None
         hip.call("lstm64_forward", B, T, xp, xp[:, 256:], 512, lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1),
-                 h00, h01, c00, c01, out, 128, hn[2 * l], hn[2 * l + 1], cn[2 * l], cn[2 * l + 1], *st)
+                 lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1), h00, h01, c00, c01, out, 128, hn[2 * l], hn[2 * l + 1], cn[2 * l], cn[2 * l + 1], *st)
         cur = out
         if stash and p_drop > 0.0 and l < L - 1:
             dropped = ar.get("%s.do%d" % (key, l), (B * T, 128))
@@ -191,28 +189,22 @@ def lstm_steps_forward(ar, key, lstm, x, Bn, T):
     H = lstm.hidden_size
     L = lstm.num_layers
     cur = x
-    zeros = ar.get("%s.zero" % key, (Bn, H), zero=True)
     out = None
     for l in range(L):
         xp = ar.get("%s.xp%d" % (key, l), (Bn * T, 8 * H))
         for d in range(2):
-            bsum = ar.get("%s.bs%d%d" % (key, l, d), (4 * H,))
-            hip.call("add", lstm.w("bias_ih", l, d), lstm.w("bias_hh", l, d), bsum, 4 * H)
-            ops.linear(cur, lstm.w("weight_ih", l, d), bsum, xp[:, d * 4 * H:(d + 1) * 4 * H])
+            ops.linear(cur, lstm.w("weight_ih", l, d), lstm.w("bias_ih", l, d), xp[:, d * 4 * H:(d + 1) * 4 * H])
         out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
-        c = ar.get("%s.c" % key, (2, Bn, H), zero=True)
+        c = ar.get("%s.c" % key, (2, Bn, H))
         w0, w1 = lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1)
-        xp_p, out_p, z_p = xp.data_ptr(), out.data_ptr(), zeros.data_ptr()
+        b0, b1 = lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1)
+        xp_p, out_p = xp.data_ptr(), out.data_ptr()
         xs, os_ = T * 8 * H, T * 2 * H       # row strides between consecutive batch rows b
         for s in range(T):
             t0, t1 = s, T - 1 - s
-            if s == 0:
-                hp0, hp1, hps = z_p, z_p, H
-            else:
-                hp0 = out_p + 4 * ((t0 - 1) * 2 * H)
-                hp1 = out_p + 4 * ((t1 + 1) * 2 * H + H)
-                hps = os_
-            hip.call("lstm_step", 2, Bn, H, hp0, hp1, hps, w0, w1,
+            hp0 = out_p + 4 * ((t0 - 1) * 2 * H) if s > 0 else None          # h_{t-1} of each direction
+            hp1 = out_p + 4 * ((t1 + 1) * 2 * H + H) if s > 0 else None
+            hip.call("lstm_step", 2, Bn, H, int(s == 0), hp0, hp1, os_, w0, w1, b0, b1,
                      xp_p + 4 * (t0 * 8 * H), xp_p + 4 * (t1 * 8 * H + 4 * H), xs,
                      out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_, c[0], c[1])
         cur = out

@@ -1,5 +1,6 @@
 // LSTM recurrences on the matrix cores (fp32, v_mfma_f32_16x16x4_f32), PyTorch gate order i,f,g,o.
 //
+//  (lstm_step kernels live in lstm_step.hip)
 //  lstm_step_kernel   one timestep of a (bi)LSTM of any hidden size H (H % 32 == 0): gates = xproj_t +
 //                     h_{t-1}.W_hh^T, fused cell update.  Used for IMU_Net's 2x(2-layer, H=512) BiLSTMs
 //                     (reference Net/IMU_Net.py:58-62,77,82), 94 % of the path's FLOPs.  Both directions
@@ -12,158 +13,13 @@
 //                     in registers and walks all T steps with no inter-workgroup traffic.
 #include "common.h"
 
-struct LstmStepP {
-  const float* hprev[2]; long hps;
-  const float* whh[2];
-  const float* xproj[2]; long xs;
-  float* hout[2]; long hos;
-  float* c[2];
-  int Bn, H, ndir;
-};
-
-#define SLD 36  // LDS row stride (floats) of the [row][k] staging tiles: 32 k + 4 pad
-
-__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
-  __shared__ __attribute__((aligned(16))) float As[2][64][SLD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][128][SLD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = p.H;
-  const int nrb = (p.Bn + 63) / 64, nht = H / 32, npairs = p.ndir * nht;
-  int pair, rb;
-  {
-    const int wg = blockIdx.x;
-    if ((npairs & 7) == 0) {  // XCD-aware: blocks b and b+8 share an XCD; give each XCD whole (dir, hidden-tile) pairs
-      const int xcd = wg & 7, q = wg >> 3;
-      pair = xcd + 8 * (q / nrb);
-      rb = q % nrb;
-    } else {
-      pair = wg / nrb;
-      rb = wg % nrb;
-    }
-  }
-  const int d = pair / nht, ht = pair % nht;
-  const int j0 = ht * 32, r0 = rb * 64;
-  const float* hp = p.hprev[d];
-  const float* W = p.whh[d];
-
-  const int lk = (tid & 7) * 4, lr = tid >> 3;  // staging: 8 lanes cover one 128-B row segment
-  const bool a0_ok = (r0 + lr) < p.Bn, a1_ok = (r0 + lr + 32) < p.Bn;
-  const float* ap0 = hp + (long)(r0 + lr) * p.hps + lk;
-  const float* ap1 = hp + (long)(r0 + lr + 32) * p.hps + lk;
-  const float* wp0 = W + ((long)0 * H + j0 + lr) * H + lk;  // Bs row = gate*32 + jl  <->  W row gate*H + j0 + jl
-  const float* wp1 = W + ((long)1 * H + j0 + lr) * H + lk;
-  const float* wp2 = W + ((long)2 * H + j0 + lr) * H + lk;
-  const float* wp3 = W + ((long)3 * H + j0 + lr) * H + lk;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 ra0, ra1, rb0, rb1, rb2, rb3;
-#define STEP_GLOAD(k0)                                                   \
-  do {                                                                   \
-    ra0 = a0_ok ? *reinterpret_cast<const float4*>(ap0 + (k0)) : zero4;  \
-    ra1 = a1_ok ? *reinterpret_cast<const float4*>(ap1 + (k0)) : zero4;  \
-    rb0 = *reinterpret_cast<const float4*>(wp0 + (k0));                  \
-    rb1 = *reinterpret_cast<const float4*>(wp1 + (k0));                  \
-    rb2 = *reinterpret_cast<const float4*>(wp2 + (k0));                  \
-    rb3 = *reinterpret_cast<const float4*>(wp3 + (k0));                  \
-  } while (0)
-#define STEP_SSTORE(buf)                                                 \
-  do {                                                                   \
-    *reinterpret_cast<float4*>(&As[buf][lr][lk]) = ra0;                  \
-    *reinterpret_cast<float4*>(&As[buf][lr + 32][lk]) = ra1;             \
-    *reinterpret_cast<float4*>(&Bs[buf][lr][lk]) = rb0;                  \
-    *reinterpret_cast<float4*>(&Bs[buf][lr + 32][lk]) = rb1;             \
-    *reinterpret_cast<float4*>(&Bs[buf][lr + 64][lk]) = rb2;             \
-    *reinterpret_cast<float4*>(&Bs[buf][lr + 96][lk]) = rb3;             \
-  } while (0)
-
-  const int rowbase = (wave & 1) * 32, hb = (wave >> 1) * 16;
-  const int fr = lane & 15, fq = lane >> 4;
-  f32x4 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = H / 32;
-  STEP_GLOAD(0);
-  STEP_SSTORE(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) STEP_GLOAD((kt + 1) * 32);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      // k-permuted operands: lane group fq supplies k = 16*kb + 4*fq + s at MFMA step s (same map for A and B)
-      float4 a[2], b[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&As[buf][rowbase + i * 16 + fr][kb * 16 + 4 * fq]);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const float4*>(&Bs[buf][g * 32 + hb + fr][kb * 16 + 4 * fq]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[g].x, acc[i][g], 0, 0, 0);
-          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[g].y, acc[i][g], 0, 0, 0);
-          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[g].z, acc[i][g], 0, 0, 0);
-          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[g].w, acc[i][g], 0, 0, 0);
-        }
-    }
-    if (kt + 1 < nk) STEP_SSTORE(buf ^ 1);
-    __syncthreads();
-  }
-
-  // fused cell update; C layout: col = lane&15 (hidden), row = (lane>>4)*4 + reg
-  const int j = j0 + hb + fr;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = r0 + rowbase + i * 16 + fq * 4 + reg;
-      if (row < p.Bn) {
-        const float* xp = p.xproj[d] + (long)row * p.xs + j;
-        float gi = sigmoidf_(acc[i][0][reg] + xp[0]);
-        float gf = sigmoidf_(acc[i][1][reg] + xp[H]);
-        float gg = tanhf(acc[i][2][reg] + xp[2 * H]);
-        float go = sigmoidf_(acc[i][3][reg] + xp[3 * H]);
-        float* cp = p.c[d] + (long)row * H + j;
-        float cn = gf * (*cp) + gi * gg;
-        *cp = cn;
-        p.hout[d][(long)row * p.hos + j] = go * tanhf(cn);
-      }
-    }
-  }
-}
-
-extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, const float* hprev0, const float* hprev1,
-                               long hps, const float* whh0, const float* whh1, const float* xproj0,
-                               const float* xproj1, long xs, float* hout0, float* hout1, long hos, float* c0,
-                               float* c1) {
-  MMEGO_REQUIRE((ndir == 1 || ndir == 2) && Bn > 0 && H > 0 && (H % 32) == 0 && (hps % 4) == 0);
-  MMEGO_REQUIRE(hprev0 && whh0 && xproj0 && hout0 && c0);
-  MMEGO_REQUIRE((((uintptr_t)hprev0 | (uintptr_t)whh0) & 15) == 0);
-  if (ndir == 2) {
-    MMEGO_REQUIRE(hprev1 && whh1 && xproj1 && hout1 && c1);
-    MMEGO_REQUIRE((((uintptr_t)hprev1 | (uintptr_t)whh1) & 15) == 0);
-  }
-  LstmStepP p;
-  p.hprev[0] = hprev0; p.hprev[1] = hprev1; p.hps = hps;
-  p.whh[0] = whh0; p.whh[1] = whh1;
-  p.xproj[0] = xproj0; p.xproj[1] = xproj1; p.xs = xs;
-  p.hout[0] = hout0; p.hout[1] = hout1; p.hos = hos;
-  p.c[0] = c0; p.c[1] = c1;
-  p.Bn = Bn; p.H = H; p.ndir = ndir;
-  int grid = ndir * (H / 32) * cdiv(Bn, 64);
-  hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  MMEGO_LAUNCH_CHECK();
-  return MMEGO_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
 // H = 64 persistent sequence kernels
 // ---------------------------------------------------------------------------------------------
 struct Lstm64P {
   const float* xproj[2]; long xs;
   const float* whh[2];
+  const float* bhh[2];
   const float* h0[2]; const float* c0[2];
   float* out; long os;
   float* hn[2]; float* cn[2];
@@ -189,7 +45,9 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
   }
   const int fr = lane & 15, fq = lane >> 4;
   const int j = wave * 16 + fr;  // hidden unit of this lane
-  float creg[4], hreg[4];
+  float creg[4], hreg[4], bh[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bh[g] = p.bhh[d] ? p.bhh[d][g * 64 + j] : 0.f;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     int row = r0 + fq * 4 + reg;
@@ -209,7 +67,7 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
       if (row < B) {
         const float* x = p.xproj[d] + ((long)row * T + tt) * p.xs + j;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) xp[g][reg] = x[g * 64];
+        for (int g = 0; g < 4; ++g) xp[g][reg] = x[g * 64] + bh[g];
         if (p.hprev[d]) p.hprev[d][((long)row * T + tt) * 64 + j] = hreg[reg];
       } else {
 #pragma unroll
@@ -264,8 +122,9 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
 }
 
 extern "C" int mmego_lstm64_forward(void* stream, int B, int T, const float* xproj0, const float* xproj1, long xs,
-                                    const float* whh0, const float* whh1, const float* h0_0, const float* h0_1,
-                                    const float* c0_0, const float* c0_1, float* out, long os, float* hn0, float* hn1,
+                                    const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
+                                    const float* h0_0, const float* h0_1, const float* c0_0, const float* c0_1, float* out,
+                                    long os, float* hn0, float* hn1,
                                     float* cn0, float* cn1, float* gates0, float* gates1, float* cst0, float* cst1,
                                     float* hprev0, float* hprev1) {
   MMEGO_REQUIRE(B > 0 && T > 0 && xproj0 && xproj1 && whh0 && whh1 && out);
@@ -274,6 +133,7 @@ extern "C" int mmego_lstm64_forward(void* stream, int B, int T, const float* xpr
   Lstm64P p;
   p.xproj[0] = xproj0; p.xproj[1] = xproj1; p.xs = xs;
   p.whh[0] = whh0; p.whh[1] = whh1;
+  p.bhh[0] = bhh0; p.bhh[1] = bhh1;
   p.h0[0] = h0_0; p.h0[1] = h0_1; p.c0[0] = c0_0; p.c0[1] = c0_1;
   p.out = out; p.os = os;
   p.hn[0] = hn0; p.hn[1] = hn1; p.cn[0] = cn0; p.cn[1] = cn1;

@@ -1,0 +1,356 @@
+// One timestep of a (bi)LSTM of hidden size H (H % 32 == 0) on the fp32 matrix cores: the recurrent half of
+// IMU_Net's 2 x (2-layer, H=512) BiLSTMs (reference Net/IMU_Net.py:58-62,77,82) -- 94 % of the path's FLOPs.
+//   gates = xproj_t (+ b_hh) + h_{t-1} . W_hh^T ;  i,f,o = sigmoid, g = tanh ;  c = f c + i g ;  h = o tanh(c)
+// Both directions run in one launch.  Two kernels, chosen by the number of batch rows:
+//   lstm_step_kernel        Bn >= 128: WG = 64 rows x 32 hidden x 4 gates (v_mfma_f32_16x16x4_f32), [row][k] LDS
+//                           tiles read with ds_read_b128 + a k-permutation (one 16-B read feeds 4 MFMA steps),
+//                           double-buffered; the cell update is register-local.  WGs sharing a W_hh slice are
+//                           placed on one XCD, so each XCD's L2 holds 1/8 of W_hh.
+//   lstm_step_small_kernel  Bn < 128 (rnn_slow: 64 rows): the step is W_hh-streaming bound, so the hidden axis is
+//                           cut finely (4 hidden x 4 gates per WG -> 256 WGs for H=512, every CU streams 1/256 of
+//                           W_hh); gates of one hidden unit sit in 4 lanes and are exchanged with __shfl.
+// `first` != 0 means h_{t-1} = 0 and c_{t-1} = 0: the product is skipped altogether.
+#include <stdlib.h>
+
+#include "common.h"
+
+struct LstmStepP {
+  const float* hprev[2]; long hps;
+  const float* whh[2];
+  const float* bhh[2];
+  const float* xproj[2]; long xs;
+  float* hout[2]; long hos;
+  float* c[2];
+  int Bn, H, ndir, first;
+};
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + expf(2.0f * x)); }
+
+#define KC 64     // k per staged chunk
+#define SLD 68    // LDS row stride (floats) of the [row][k] staging tiles: 64 k + 4 pad (ds_read_b128 ~conflict-free)
+#define XLD 132   // xproj tile: 4 gates x 32 hidden + 4 pad (rows 4 apart land 16 banks apart: conflict-free C-layout reads)
+#define CLD 36    // c / h tiles: 32 hidden + 4 pad
+
+// WG = 64 batch rows x 32 hidden x 4 gates, 4 waves (32 rows x 16 hidden x 4 gates each), one WG per CU at Bn=512,H=512.
+// LDS: 2 x (64 + 128) x 68 floats of operand tiles (102 KB) + c tile (9 KB); the xproj tile and the h tile alias the
+// second operand buffer (they are live only before / after the product).
+__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float (*As)[64][SLD] = reinterpret_cast<float (*)[64][SLD]>(smem);                       // [2][64][SLD]
+  float (*Bs)[128][SLD] = reinterpret_cast<float (*)[128][SLD]>(smem + 2 * 64 * SLD);      // [2][128][SLD]
+  float (*CP)[CLD] = reinterpret_cast<float (*)[CLD]>(smem + 2 * 64 * SLD + 2 * 128 * SLD); // [64][CLD]
+  float (*XP)[XLD] = reinterpret_cast<float (*)[XLD]>(&Bs[1][0][0]);                       // [64][XLD] aliases Bs[1]
+  float (*HP)[CLD] = reinterpret_cast<float (*)[CLD]>(&Bs[1][0][0]);                       // [64][CLD] aliases Bs[1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H;
+  const int nrb = (p.Bn + 63) / 64, nht = H / 32, npairs = p.ndir * nht;
+  int pair, rb;
+  {
+    const int wg = blockIdx.x;
+    if ((npairs & 7) == 0) {  // XCD-aware: blocks b and b+8 share an XCD; give each XCD whole (dir, hidden-tile) pairs
+      const int xcd = wg & 7, q = wg >> 3;
+      pair = xcd + 8 * (q / nrb);
+      rb = q % nrb;
+    } else {
+      pair = wg / nrb;
+      rb = wg % nrb;
+    }
+  }
+  const int d = pair / nht, ht = pair % nht;
+  const int j0 = ht * 32, r0 = rb * 64;
+  const int rowbase = (wave & 1) * 32, hb = (wave >> 1) * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool first = p.first != 0;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // ---- operand tile staging (h_{t-1} rows and the W_hh slice): 16 lanes per 256-B row segment, rows lr + 16*i ----
+  const int lk = (tid & 15) * 4, lr = tid >> 4;
+  const int nk = H / KC;
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+  const float* ap = nullptr;
+  const float* wp = nullptr;
+  long rs16 = 0;
+  bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
+#define STEP_GLOAD(k0)                                                          \
+  do {                                                                          \
+    ra0 = ok0 ? *reinterpret_cast<const float4*>(ap + (k0)) : zero4;            \
+    ra1 = ok1 ? *reinterpret_cast<const float4*>(ap + rs16 + (k0)) : zero4;     \
+    ra2 = ok2 ? *reinterpret_cast<const float4*>(ap + 2 * rs16 + (k0)) : zero4; \
+    ra3 = ok3 ? *reinterpret_cast<const float4*>(ap + 3 * rs16 + (k0)) : zero4; \
+    rb0 = *reinterpret_cast<const float4*>(wp + (k0));                          \
+    rb1 = *reinterpret_cast<const float4*>(wp + 16 * H + (k0));                 \
+    rb2 = *reinterpret_cast<const float4*>(wp + (long)H * H + (k0));            \
+    rb3 = *reinterpret_cast<const float4*>(wp + (long)H * H + 16 * H + (k0));   \
+    rb4 = *reinterpret_cast<const float4*>(wp + 2L * H * H + (k0));             \
+    rb5 = *reinterpret_cast<const float4*>(wp + 2L * H * H + 16 * H + (k0));    \
+    rb6 = *reinterpret_cast<const float4*>(wp + 3L * H * H + (k0));             \
+    rb7 = *reinterpret_cast<const float4*>(wp + 3L * H * H + 16 * H + (k0));    \
+  } while (0)
+#define STEP_SSTORE(buf)                                                        \
+  do {                                                                          \
+    *reinterpret_cast<float4*>(&As[buf][lr][lk]) = ra0;                         \
+    *reinterpret_cast<float4*>(&As[buf][lr + 16][lk]) = ra1;                    \
+    *reinterpret_cast<float4*>(&As[buf][lr + 32][lk]) = ra2;                    \
+    *reinterpret_cast<float4*>(&As[buf][lr + 48][lk]) = ra3;                    \
+    *reinterpret_cast<float4*>(&Bs[buf][lr][lk]) = rb0;                         \
+    *reinterpret_cast<float4*>(&Bs[buf][lr + 16][lk]) = rb1;                    \
+    *reinterpret_cast<float4*>(&Bs[buf][lr + 32][lk]) = rb2;                    \
+    *reinterpret_cast<float4*>(&Bs[buf][lr + 48][lk]) = rb3;                    \
+    *reinterpret_cast<float4*>(&Bs[buf][lr + 64][lk]) = rb4;                    \
+    *reinterpret_cast<float4*>(&Bs[buf][lr + 80][lk]) = rb5;                    \
+    *reinterpret_cast<float4*>(&Bs[buf][lr + 96][lk]) = rb6;                    \
+    *reinterpret_cast<float4*>(&Bs[buf][lr + 112][lk]) = rb7;                   \
+  } while (0)
+  if (!first) {
+    ok0 = (r0 + lr) < p.Bn; ok1 = (r0 + lr + 16) < p.Bn; ok2 = (r0 + lr + 32) < p.Bn; ok3 = (r0 + lr + 48) < p.Bn;
+    ap = p.hprev[d] + (long)(r0 + lr) * p.hps + lk;
+    rs16 = 16 * p.hps;
+    wp = p.whh[d] + ((long)j0 + lr) * H + lk;   // Bs row = gate*32 + jl  <->  W row gate*H + j0 + jl  (jl = lr, lr+16)
+    STEP_GLOAD(0);                              // issued before the xproj stream so both are in flight together
+  }
+
+  // ---- stream in this step's xproj tile (64 rows x 4 gates x 32 hidden) and c tile with full 128-B row segments ----
+  {
+    const int xr = tid >> 2, xq = (tid & 3) * 8;
+    const bool ok = (r0 + xr) < p.Bn;
+    const float* xrow = p.xproj[d] + (long)(r0 + xr) * p.xs + j0 + xq;
+    float4 xv[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      xv[2 * g] = ok ? *reinterpret_cast<const float4*>(xrow + g * H) : zero4;
+      xv[2 * g + 1] = ok ? *reinterpret_cast<const float4*>(xrow + g * H + 4) : zero4;
+    }
+    float4 cv0 = zero4, cv1 = zero4;
+    if (ok && !first) {
+      const float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
+      cv0 = *reinterpret_cast<const float4*>(crow);
+      cv1 = *reinterpret_cast<const float4*>(crow + 4);
+    }
+    if (!first) STEP_SSTORE(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<float4*>(&XP[xr][g * 32 + xq]) = xv[2 * g];
+      *reinterpret_cast<float4*>(&XP[xr][g * 32 + xq + 4]) = xv[2 * g + 1];
+    }
+    *reinterpret_cast<float4*>(&CP[xr][xq]) = cv0;
+    *reinterpret_cast<float4*>(&CP[xr][xq + 4]) = cv1;
+  }
+  __syncthreads();
+
+  // accumulators start from xproj + b_hh (C layout: col = lane&15 (hidden), row = (lane>>4)*4 + reg)
+  f32x4 acc[2][4];
+  {
+    const int jj = hb + fr;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float bh = p.bhh[d] ? p.bhh[d][g * H + j0 + jj] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[i][g][reg] = XP[rowbase + i * 16 + fq * 4 + reg][g * 32 + jj] + bh;
+    }
+  }
+  __syncthreads();   // XP (aliasing operand buffer 1) has been consumed by every wave
+
+  if (!first) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) STEP_GLOAD((kt + 1) * KC);
+#pragma unroll
+      for (int kb = 0; kb < KC / 16; ++kb) {
+        // k-permuted operands: lane group fq supplies k = 16*kb + 4*fq + s at MFMA step s (same map for A and B)
+        float4 a[2], b[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&As[buf][rowbase + i * 16 + fr][kb * 16 + 4 * fq]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const float4*>(&Bs[buf][g * 32 + hb + fr][kb * 16 + 4 * fq]);
+        // step-major order: 8 independent accumulators between two MFMAs on the same one (dependent latency 40 > issue 32)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[g].x, acc[i][g], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[g].y, acc[i][g], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[g].z, acc[i][g], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[g].w, acc[i][g], 0, 0, 0);
+      }
+      if (kt + 1 < nk) STEP_SSTORE(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // fused cell update in registers, results staged in LDS for full-line stores (HP aliases operand buffer 1: idle now)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int lrow = rowbase + i * 16 + fq * 4 + reg;
+      float gi = fast_sigmoid(acc[i][0][reg]);
+      float gf = fast_sigmoid(acc[i][1][reg]);
+      float gg = fast_tanh(acc[i][2][reg]);
+      float go = fast_sigmoid(acc[i][3][reg]);
+      float cn = gf * CP[lrow][hb + fr] + gi * gg;
+      CP[lrow][hb + fr] = cn;
+      HP[lrow][hb + fr] = go * fast_tanh(cn);
+    }
+  }
+  __syncthreads();
+  {
+    const int xr = tid >> 2, xq = (tid & 3) * 8;
+    if ((r0 + xr) < p.Bn) {
+      float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
+      *reinterpret_cast<float4*>(crow) = *reinterpret_cast<const float4*>(&CP[xr][xq]);
+      *reinterpret_cast<float4*>(crow + 4) = *reinterpret_cast<const float4*>(&CP[xr][xq + 4]);
+      float* hrow = p.hout[d] + (long)(r0 + xr) * p.hos + j0 + xq;
+      *reinterpret_cast<float4*>(hrow) = *reinterpret_cast<const float4*>(&HP[xr][xq]);
+      *reinterpret_cast<float4*>(hrow + 4) = *reinterpret_cast<const float4*>(&HP[xr][xq + 4]);
+    }
+  }
+}
+
+#define STEP_LDS_BYTES ((2 * 64 * SLD + 2 * 128 * SLD + 64 * CLD) * sizeof(float))
+
+// ---- small-batch variant: WG = 64 rows x (4 hidden x 4 gates), K split over nothing, 4 waves = 4 row tiles ----------
+template <int SK>  // k per staged chunk (64, or 32 when H is not a multiple of 64)
+__global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
+  __shared__ __attribute__((aligned(16))) float As[2][64][SK + 4];
+  __shared__ __attribute__((aligned(16))) float Bs[2][16][SK + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H;
+  const int nrb = (p.Bn + 63) / 64, nht = H / 4;
+  const int wg = blockIdx.x;
+  const int rb = wg % nrb, pair = wg / nrb;
+  const int d = pair / nht, ht = pair % nht;
+  const int j0 = ht * 4, r0 = rb * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int gate = fr >> 2, jl = fr & 3;       // tile column fr = gate*4 + jl  <->  W row gate*H + j0 + jl
+  const int j = j0 + jl;
+  const int rowt = r0 + wave * 16;              // this wave's 16 rows
+
+  float xpv[4], cprev[4];
+  const float bh = p.bhh[d] ? p.bhh[d][gate * H + j] : 0.f;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = rowt + fq * 4 + reg;
+    const bool ok = row < p.Bn;
+    xpv[reg] = ok ? p.xproj[d][(long)row * p.xs + gate * H + j] + bh : 0.f;
+    cprev[reg] = (ok && !p.first && gate == 0) ? p.c[d][(long)row * H + j] : 0.f;
+  }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if (!p.first) {
+    const float* hp = p.hprev[d];
+    const float* W = p.whh[d];
+    // staging per chunk of 64 k: A 64 rows x 16 float4 = 1024 float4 (4 per thread), B 16 rows x 16 float4 = 256 (1 per thread)
+    constexpr int LPR = SK / 4;                     // lanes per row segment
+    constexpr int RPP = 256 / LPR;                  // rows staged per pass (16 or 32)
+    const int lk = (tid % LPR) * 4, lr = tid / LPR;
+    const float* wp = W + ((long)((lr & 15) >> 2) * H + j0 + (lr & 3)) * H + lk;   // (lr & 15) = gate*4 + jl
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nk = H / SK;
+    const bool ok0 = (r0 + lr) < p.Bn, ok1 = (r0 + lr + RPP) < p.Bn, ok2 = (r0 + lr + 2 * RPP) < p.Bn, ok3 = (r0 + lr + 3 * RPP) < p.Bn;
+    const float* ap = hp + (long)(r0 + lr) * p.hps + lk;
+    const long rs16 = RPP * p.hps;
+    float4 ra0, ra1, ra2 = zero4, ra3 = zero4, rbv = zero4;
+#define SM_GLOAD(k0)                                                          \
+  do {                                                                        \
+    ra0 = ok0 ? *reinterpret_cast<const float4*>(ap + (k0)) : zero4;            \
+    ra1 = ok1 ? *reinterpret_cast<const float4*>(ap + rs16 + (k0)) : zero4;     \
+    if (RPP == 16) {                                                          \
+      ra2 = ok2 ? *reinterpret_cast<const float4*>(ap + 2 * rs16 + (k0)) : zero4; \
+      ra3 = ok3 ? *reinterpret_cast<const float4*>(ap + 3 * rs16 + (k0)) : zero4; \
+    }                                                                         \
+    if (lr < 16) rbv = *reinterpret_cast<const float4*>(wp + (k0));           \
+  } while (0)
+#define SM_SSTORE(buf)                                                        \
+  do {                                                                        \
+    *reinterpret_cast<float4*>(&As[buf][lr][lk]) = ra0;                       \
+    *reinterpret_cast<float4*>(&As[buf][lr + RPP][lk]) = ra1;                 \
+    if (RPP == 16) {                                                          \
+      *reinterpret_cast<float4*>(&As[buf][lr + 32][lk]) = ra2;                \
+      *reinterpret_cast<float4*>(&As[buf][lr + 48][lk]) = ra3;                \
+    }                                                                         \
+    if (lr < 16) *reinterpret_cast<float4*>(&Bs[buf][lr][lk]) = rbv;          \
+  } while (0)
+    SM_GLOAD(0);
+    SM_SSTORE(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) SM_GLOAD((kt + 1) * SK);
+#pragma unroll
+      for (int kb = 0; kb < SK / 16; ++kb) {
+        float4 a = *reinterpret_cast<const float4*>(&As[buf][wave * 16 + fr][kb * 16 + 4 * fq]);
+        float4 b = *reinterpret_cast<const float4*>(&Bs[buf][fr][kb * 16 + 4 * fq]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
+      }
+      if (kt + 1 < nk) SM_SSTORE(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // lane holds gate `gate` of hidden j for rows fq*4+reg; fetch f,g,o from lanes fr+4, fr+8, fr+12 of the same group
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    float pre = acc0[reg] + acc1[reg] + xpv[reg];
+    float act = (gate == 2) ? fast_tanh(pre) : fast_sigmoid(pre);
+    const int base = (lane & 48) + jl;          // lane of gate 0 for this (group, jl)
+    float gi = __shfl(act, base, 64), gf = __shfl(act, base + 4, 64), gg = __shfl(act, base + 8, 64),
+          go = __shfl(act, base + 12, 64);
+    const int row = rowt + fq * 4 + reg;
+    if (gate == 0 && row < p.Bn) {
+      float cn = gf * cprev[reg] + gi * gg;
+      p.c[d][(long)row * H + j] = cn;
+      p.hout[d][(long)row * p.hos + j] = go * fast_tanh(cn);
+    }
+  }
+}
+
+extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first, const float* hprev0, const float* hprev1,
+                               long hps, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
+                               const float* xproj0, const float* xproj1, long xs, float* hout0, float* hout1, long hos,
+                               float* c0, float* c1) {
+  MMEGO_REQUIRE((ndir == 1 || ndir == 2) && Bn > 0 && H > 0 && (H % 32) == 0);
+  MMEGO_REQUIRE(whh0 && xproj0 && hout0 && c0 && (((uintptr_t)whh0) & 15) == 0);
+  MMEGO_REQUIRE((xs % 4) == 0 && (hos % 4) == 0 && ((((uintptr_t)xproj0) | ((uintptr_t)hout0) | ((uintptr_t)c0)) & 15) == 0);
+  if (!first) MMEGO_REQUIRE(hprev0 && (hps % 4) == 0 && (((uintptr_t)hprev0) & 15) == 0);
+  if (ndir == 2) {
+    MMEGO_REQUIRE(whh1 && xproj1 && hout1 && c1 && (((uintptr_t)whh1) & 15) == 0);
+    MMEGO_REQUIRE(((((uintptr_t)xproj1) | ((uintptr_t)hout1) | ((uintptr_t)c1)) & 15) == 0);
+    if (!first) MMEGO_REQUIRE(hprev1 && (((uintptr_t)hprev1) & 15) == 0);
+  }
+  LstmStepP p;
+  p.hprev[0] = hprev0; p.hprev[1] = hprev1; p.hps = hps;
+  p.whh[0] = whh0; p.whh[1] = whh1;
+  p.bhh[0] = bhh0; p.bhh[1] = bhh1;
+  p.xproj[0] = xproj0; p.xproj[1] = xproj1; p.xs = xs;
+  p.hout[0] = hout0; p.hout[1] = hout1; p.hos = hos;
+  p.c[0] = c0; p.c[1] = c1;
+  p.Bn = Bn; p.H = H; p.ndir = ndir; p.first = first;
+  if (Bn >= 128 && (H % KC) == 0) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)lstm_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_BYTES);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    int grid = ndir * (H / 32) * cdiv(Bn, 64);
+    hipLaunchKernelGGL(lstm_step_kernel, dim3(grid), dim3(256), STEP_LDS_BYTES, (hipStream_t)stream, p);
+  } else {
+    int grid = ndir * (H / 4) * cdiv(Bn, 64);
+    if ((H % 64) == 0) hipLaunchKernelGGL(lstm_step_small_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(lstm_step_small_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  }
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

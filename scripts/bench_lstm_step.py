@@ -1,0 +1,42 @@
+"""Micro-benchmark of mmego_lstm_step (Bn x H, both directions): us per launch and TFLOP/s.
+`first` carries diagnostic bits in this script only: 2 = no cell update math, 4 = no global tile loads, 8 = no MFMA."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmego_amd import hip  # noqa: E402
+
+dev = torch.device("cuda:0")
+Bn, H, T = int(sys.argv[1]) if len(sys.argv) > 1 else 512, 512, 20
+modes = [int(a) for a in sys.argv[2:]] or [0]
+torch.manual_seed(0)
+out = torch.randn(Bn, T, 2 * H, device=dev) * 0.1
+xp = torch.randn(Bn, T, 8 * H, device=dev) * 0.1
+w = [torch.randn(4 * H, H, device=dev) * 0.04 for _ in range(2)]
+b = [torch.randn(4 * H, device=dev) * 0.04 for _ in range(2)]
+c = torch.zeros(2, Bn, H, device=dev)
+xs, os_ = T * 8 * H, T * 2 * H
+
+
+def launch(mode, s=1):
+    t0, t1 = s, T - 1 - s
+    hip.call("lstm_step", 2, Bn, H, mode, out.data_ptr() + 4 * ((t0 - 1) * 2 * H), out.data_ptr() + 4 * ((t1 + 1) * 2 * H + H), os_,
+             w[0], w[1], b[0], b[1], xp.data_ptr() + 4 * (t0 * 8 * H), xp.data_ptr() + 4 * (t1 * 8 * H + 4 * H), xs,
+             out.data_ptr() + 4 * (t0 * 2 * H), out.data_ptr() + 4 * (t1 * 2 * H + H), os_, c[0], c[1])
+
+
+for mode in modes:
+    for _ in range(5):
+        launch(mode)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 200
+    e0.record()
+    for i in range(n):
+        launch(mode, 1 + (i % (T - 2)))
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    print("Bn=%d mode=%d: %.1f us/launch, %.1f TFLOP/s" % (Bn, mode, us, 2 * 2 * Bn * 4 * H * H / us / 1e6))

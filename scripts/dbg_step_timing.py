@@ -1,5 +1,5 @@
 import sys, time, torch, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mmego_amd.train_step import StageStep
 dev = torch.device("cuda:0")

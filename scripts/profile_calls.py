@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from mmego_amd import hip  # noqa: E402
 from mmego_amd.train_step import StageStep  # noqa: E402
