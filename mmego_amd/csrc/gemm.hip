@@ -12,6 +12,11 @@
 // conflict-free ds_read_b32 per operand; the transposed ds_write_b32 is at most 2-way (free).
 #include "common.h"
 
+namespace mmego_detail {
+int gemm_tile_launch(hipStream_t st, const float* A, const float* W, float* C, const float* bias, int M, int N, int K,
+                     long lda, long ldw, long ldc, int relu);
+}
+
 struct GemmP {
   const float* A;
   const float* B;
@@ -204,6 +209,12 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
                           long sBb, long sCb, int relu, int accumulate, float* splitk_ws, int nsplit) {
   MMEGO_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && nsplit >= 1);
   hipStream_t st = (hipStream_t)stream;
+  const bool nt_aligned = nbatch == 1 && nsplit == 1 && !accumulate && sak == 1 && sbk == 1 && scn == 1 && (sam % 4) == 0 &&
+                          (sbn % 4) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+  if (nt_aligned) {   // large-tile kernel (gemm_tile.hip) when the shape allows
+    int rc = mmego_detail::gemm_tile_launch(st, A, B, C, bias, M, N, K, sam, sbn, scm, relu);
+    if (rc != -2) return rc;
+  }
   const bool fast = nbatch == 1 && nsplit == 1 && !accumulate && sak == 1 && sbk == 1 && scn == 1 && (M % 128) == 0 &&
                     (N % 128) == 0 && (K % 16) == 0 && (sam % 4) == 0 && (sbn % 4) == 0 &&
                     (((uintptr_t)A | (uintptr_t)B) & 15) == 0;

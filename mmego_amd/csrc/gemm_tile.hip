@@ -1,0 +1,136 @@
+// fp32 NT GEMM, large-tile kernel: C[M,N] = A[M,K] . W[N,K]^T (+bias)(relu), K % 64 == 0.
+//
+// The dominant dense products of the path run here: the LSTM input projections of IMU_Net
+// (reference Net/IMU_Net.py:58-62: 10240 x 2048 x {512,1024}, 512 x 2048 x 1024) and the 128-aligned Linear layers.
+//
+//  * v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), BM x BN block tile (128x128 or 64x64), 4 waves as 2x2, each
+//    wave (BM/2) x (BN/2) = TM x TN tiles of 32x32.
+//  * Operand tiles live in LDS as [row][k] with a 68-float row stride (64 k + 4 pad): the global->LDS copy is a plain
+//    f32x4 -> ds_write_b128 (no transpose), and the operand fetch is ONE ds_read_b128 per 4 MFMA steps using a
+//    k-permutation (lane half h supplies k = 8*kb + 4*h + s at step s, identically for A and B).  With this stride
+//    every 16-lane group of the b128 read hits 16 distinct 16-B slots (conflict-free).
+//  * One LDS buffer + register prefetch of the next 64-k chunk (global loads are issued before the MFMA block and
+//    land under it), so 2 workgroups fit a CU (69.6 KB each at 128x128) and overlap each other's barriers.
+//  * XCD-aware tile order: consecutive tiles along N (sharing the A row panel) stay on one XCD's L2.
+#include "common.h"
+
+#define TLD 68
+// NOTE: staging registers are ext_vector f32x4 (not HIP's float4 struct): arrays of the struct type are left in
+// scratch memory by hipcc (ROCm 7.2), which serialises the prefetch.
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                        float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                                        int K, long lda, long ldw, long ldc, int relu) {
+  constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 tiles per wave
+  constexpr int AV = BM / 16, BV = BN / 16;          // f32x4 per thread per 64-k chunk (rows lr + 16*i)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float (*As)[TLD] = reinterpret_cast<float (*)[TLD]>(smem);
+  float (*Bs)[TLD] = reinterpret_cast<float (*)[TLD]>(smem + BM * TLD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int ntn = N / BN, ntm = M / BM, nwg = ntn * ntm;
+  int id = blockIdx.x;
+  if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
+  const int m0 = (id / ntn) * BM, n0 = (id % ntn) * BN;
+
+  const int lk = (tid & 15) * 4, lr = tid >> 4;      // 16 lanes cover one 256-B row segment
+  const float* Ap = A + (long)(m0 + lr) * lda + lk;
+  const float* Wp = W + (long)(n0 + lr) * ldw + lk;
+  f32x4 ra[AV], rb[BV];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
+
+  const int nk = K / 64;
+#pragma unroll
+  for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(Ap + (long)(16 * i) * lda);
+#pragma unroll
+  for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wp + (long)(16 * i) * ldw);
+  const int r = lane & 31, h = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                                  // previous chunk's operand reads are done
+#pragma unroll
+    for (int i = 0; i < AV; ++i) *reinterpret_cast<f32x4*>(&As[lr + 16 * i][lk]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BV; ++i) *reinterpret_cast<f32x4*>(&Bs[lr + 16 * i][lk]) = rb[i];
+    __syncthreads();
+    if (kt + 1 < nk) {
+      const int k0 = (kt + 1) * 64;
+#pragma unroll
+      for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(Ap + (long)(16 * i) * lda + k0);
+#pragma unroll
+      for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wp + (long)(16 * i) * ldw + k0);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[wm * (BM / 2) + i * 32 + r][kb * 8 + 4 * h]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[wn * (BN / 2) + j * 32 + r][kb * 8 + 4 * h]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+    const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        int row = m0 + wm * (BM / 2) + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        float v = acc[i][j][reg] + bv;
+        if (relu) v = fmaxf(v, 0.0f);
+        C[(long)row * ldc + col] = v;
+      }
+    }
+  }
+}
+
+namespace mmego_detail {
+
+// returns 0 on launch, -2 if the shape does not fit this kernel (caller falls back), >0 on a HIP error
+int gemm_tile_launch(hipStream_t st, const float* A, const float* W, float* C, const float* bias, int M, int N, int K,
+                     long lda, long ldw, long ldc, int relu) {
+  if ((K % 64) != 0 || (M % 64) != 0 || (N % 64) != 0) return -2;
+  const bool big_ok = (M % 128) == 0 && (N % 128) == 0;
+  const long tiles_big = big_ok ? (long)(M / 128) * (N / 128) : 0;
+  static bool attr_set = false;
+  const size_t lds_big = (size_t)(2 * 128 * TLD) * sizeof(float), lds_small = (size_t)(2 * 64 * TLD) * sizeof(float);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  if (tiles_big >= 192) {          // enough 128x128 tiles to fill 256 CUs
+    hipLaunchKernelGGL((gemm_tile_kernel<128, 128>), dim3((unsigned)tiles_big), dim3(256), lds_big, st, A, W, C, bias, M, N, K, lda,
+                       ldw, ldc, relu);
+  } else {
+    hipLaunchKernelGGL((gemm_tile_kernel<64, 64>), dim3((unsigned)((M / 64) * (N / 64))), dim3(256), lds_small, st, A, W, C, bias, M,
+                       N, K, lda, ldw, ldc, relu);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace mmego_detail

@@ -62,45 +62,45 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
   const int rowbase = (wave & 1) * 32, hb = (wave >> 1) * 16;
   const int fr = lane & 15, fq = lane >> 4;
   const bool first = p.first != 0;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- operand tile staging (h_{t-1} rows and the W_hh slice): 16 lanes per 256-B row segment, rows lr + 16*i ----
   const int lk = (tid & 15) * 4, lr = tid >> 4;
   const int nk = H / KC;
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
+  f32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
   const float* ap = nullptr;
   const float* wp = nullptr;
   long rs16 = 0;
   bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
 #define STEP_GLOAD(k0)                                                          \
   do {                                                                          \
-    ra0 = ok0 ? *reinterpret_cast<const float4*>(ap + (k0)) : zero4;            \
-    ra1 = ok1 ? *reinterpret_cast<const float4*>(ap + rs16 + (k0)) : zero4;     \
-    ra2 = ok2 ? *reinterpret_cast<const float4*>(ap + 2 * rs16 + (k0)) : zero4; \
-    ra3 = ok3 ? *reinterpret_cast<const float4*>(ap + 3 * rs16 + (k0)) : zero4; \
-    rb0 = *reinterpret_cast<const float4*>(wp + (k0));                          \
-    rb1 = *reinterpret_cast<const float4*>(wp + 16 * H + (k0));                 \
-    rb2 = *reinterpret_cast<const float4*>(wp + (long)H * H + (k0));            \
-    rb3 = *reinterpret_cast<const float4*>(wp + (long)H * H + 16 * H + (k0));   \
-    rb4 = *reinterpret_cast<const float4*>(wp + 2L * H * H + (k0));             \
-    rb5 = *reinterpret_cast<const float4*>(wp + 2L * H * H + 16 * H + (k0));    \
-    rb6 = *reinterpret_cast<const float4*>(wp + 3L * H * H + (k0));             \
-    rb7 = *reinterpret_cast<const float4*>(wp + 3L * H * H + 16 * H + (k0));    \
+    ra0 = ok0 ? *reinterpret_cast<const f32x4*>(ap + (k0)) : zero4;            \
+    ra1 = ok1 ? *reinterpret_cast<const f32x4*>(ap + rs16 + (k0)) : zero4;     \
+    ra2 = ok2 ? *reinterpret_cast<const f32x4*>(ap + 2 * rs16 + (k0)) : zero4; \
+    ra3 = ok3 ? *reinterpret_cast<const f32x4*>(ap + 3 * rs16 + (k0)) : zero4; \
+    rb0 = *reinterpret_cast<const f32x4*>(wp + (k0));                          \
+    rb1 = *reinterpret_cast<const f32x4*>(wp + 16 * H + (k0));                 \
+    rb2 = *reinterpret_cast<const f32x4*>(wp + (long)H * H + (k0));            \
+    rb3 = *reinterpret_cast<const f32x4*>(wp + (long)H * H + 16 * H + (k0));   \
+    rb4 = *reinterpret_cast<const f32x4*>(wp + 2L * H * H + (k0));             \
+    rb5 = *reinterpret_cast<const f32x4*>(wp + 2L * H * H + 16 * H + (k0));    \
+    rb6 = *reinterpret_cast<const f32x4*>(wp + 3L * H * H + (k0));             \
+    rb7 = *reinterpret_cast<const f32x4*>(wp + 3L * H * H + 16 * H + (k0));    \
   } while (0)
 #define STEP_SSTORE(buf)                                                        \
   do {                                                                          \
-    *reinterpret_cast<float4*>(&As[buf][lr][lk]) = ra0;                         \
-    *reinterpret_cast<float4*>(&As[buf][lr + 16][lk]) = ra1;                    \
-    *reinterpret_cast<float4*>(&As[buf][lr + 32][lk]) = ra2;                    \
-    *reinterpret_cast<float4*>(&As[buf][lr + 48][lk]) = ra3;                    \
-    *reinterpret_cast<float4*>(&Bs[buf][lr][lk]) = rb0;                         \
-    *reinterpret_cast<float4*>(&Bs[buf][lr + 16][lk]) = rb1;                    \
-    *reinterpret_cast<float4*>(&Bs[buf][lr + 32][lk]) = rb2;                    \
-    *reinterpret_cast<float4*>(&Bs[buf][lr + 48][lk]) = rb3;                    \
-    *reinterpret_cast<float4*>(&Bs[buf][lr + 64][lk]) = rb4;                    \
-    *reinterpret_cast<float4*>(&Bs[buf][lr + 80][lk]) = rb5;                    \
-    *reinterpret_cast<float4*>(&Bs[buf][lr + 96][lk]) = rb6;                    \
-    *reinterpret_cast<float4*>(&Bs[buf][lr + 112][lk]) = rb7;                   \
+    *reinterpret_cast<f32x4*>(&As[buf][lr][lk]) = ra0;                         \
+    *reinterpret_cast<f32x4*>(&As[buf][lr + 16][lk]) = ra1;                    \
+    *reinterpret_cast<f32x4*>(&As[buf][lr + 32][lk]) = ra2;                    \
+    *reinterpret_cast<f32x4*>(&As[buf][lr + 48][lk]) = ra3;                    \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr][lk]) = rb0;                         \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 16][lk]) = rb1;                    \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 32][lk]) = rb2;                    \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 48][lk]) = rb3;                    \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 64][lk]) = rb4;                    \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 80][lk]) = rb5;                    \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 96][lk]) = rb6;                    \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 112][lk]) = rb7;                   \
   } while (0)
   if (!first) {
     ok0 = (r0 + lr) < p.Bn; ok1 = (r0 + lr + 16) < p.Bn; ok2 = (r0 + lr + 32) < p.Bn; ok3 = (r0 + lr + 48) < p.Bn;
@@ -115,26 +115,26 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
     const int xr = tid >> 2, xq = (tid & 3) * 8;
     const bool ok = (r0 + xr) < p.Bn;
     const float* xrow = p.xproj[d] + (long)(r0 + xr) * p.xs + j0 + xq;
-    float4 xv[8];
+    f32x4 xv[8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      xv[2 * g] = ok ? *reinterpret_cast<const float4*>(xrow + g * H) : zero4;
-      xv[2 * g + 1] = ok ? *reinterpret_cast<const float4*>(xrow + g * H + 4) : zero4;
+      xv[2 * g] = ok ? *reinterpret_cast<const f32x4*>(xrow + g * H) : zero4;
+      xv[2 * g + 1] = ok ? *reinterpret_cast<const f32x4*>(xrow + g * H + 4) : zero4;
     }
-    float4 cv0 = zero4, cv1 = zero4;
+    f32x4 cv0 = zero4, cv1 = zero4;
     if (ok && !first) {
       const float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
-      cv0 = *reinterpret_cast<const float4*>(crow);
-      cv1 = *reinterpret_cast<const float4*>(crow + 4);
+      cv0 = *reinterpret_cast<const f32x4*>(crow);
+      cv1 = *reinterpret_cast<const f32x4*>(crow + 4);
     }
     if (!first) STEP_SSTORE(0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      *reinterpret_cast<float4*>(&XP[xr][g * 32 + xq]) = xv[2 * g];
-      *reinterpret_cast<float4*>(&XP[xr][g * 32 + xq + 4]) = xv[2 * g + 1];
+      *reinterpret_cast<f32x4*>(&XP[xr][g * 32 + xq]) = xv[2 * g];
+      *reinterpret_cast<f32x4*>(&XP[xr][g * 32 + xq + 4]) = xv[2 * g + 1];
     }
-    *reinterpret_cast<float4*>(&CP[xr][xq]) = cv0;
-    *reinterpret_cast<float4*>(&CP[xr][xq + 4]) = cv1;
+    *reinterpret_cast<f32x4*>(&CP[xr][xq]) = cv0;
+    *reinterpret_cast<f32x4*>(&CP[xr][xq + 4]) = cv1;
   }
   __syncthreads();
 
@@ -160,11 +160,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
 #pragma unroll
       for (int kb = 0; kb < KC / 16; ++kb) {
         // k-permuted operands: lane group fq supplies k = 16*kb + 4*fq + s at MFMA step s (same map for A and B)
-        float4 a[2], b[4];
+        f32x4 a[2], b[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&As[buf][rowbase + i * 16 + fr][kb * 16 + 4 * fq]);
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][rowbase + i * 16 + fr][kb * 16 + 4 * fq]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const float4*>(&Bs[buf][g * 32 + hb + fr][kb * 16 + 4 * fq]);
+        for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(&Bs[buf][g * 32 + hb + fr][kb * 16 + 4 * fq]);
         // step-major order: 8 independent accumulators between two MFMAs on the same one (dependent latency 40 > issue 32)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -208,11 +208,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
     const int xr = tid >> 2, xq = (tid & 3) * 8;
     if ((r0 + xr) < p.Bn) {
       float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
-      *reinterpret_cast<float4*>(crow) = *reinterpret_cast<const float4*>(&CP[xr][xq]);
-      *reinterpret_cast<float4*>(crow + 4) = *reinterpret_cast<const float4*>(&CP[xr][xq + 4]);
+      *reinterpret_cast<f32x4*>(crow) = *reinterpret_cast<const f32x4*>(&CP[xr][xq]);
+      *reinterpret_cast<f32x4*>(crow + 4) = *reinterpret_cast<const f32x4*>(&CP[xr][xq + 4]);
       float* hrow = p.hout[d] + (long)(r0 + xr) * p.hos + j0 + xq;
-      *reinterpret_cast<float4*>(hrow) = *reinterpret_cast<const float4*>(&HP[xr][xq]);
-      *reinterpret_cast<float4*>(hrow + 4) = *reinterpret_cast<const float4*>(&HP[xr][xq + 4]);
+      *reinterpret_cast<f32x4*>(hrow) = *reinterpret_cast<const f32x4*>(&HP[xr][xq]);
+      *reinterpret_cast<f32x4*>(hrow + 4) = *reinterpret_cast<const f32x4*>(&HP[xr][xq + 4]);
     }
   }
 }
@@ -249,36 +249,36 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
   if (!p.first) {
     const float* hp = p.hprev[d];
     const float* W = p.whh[d];
-    // staging per chunk of 64 k: A 64 rows x 16 float4 = 1024 float4 (4 per thread), B 16 rows x 16 float4 = 256 (1 per thread)
+    // staging per chunk of 64 k: A 64 rows x 16 f32x4 = 1024 f32x4 (4 per thread), B 16 rows x 16 f32x4 = 256 (1 per thread)
     constexpr int LPR = SK / 4;                     // lanes per row segment
     constexpr int RPP = 256 / LPR;                  // rows staged per pass (16 or 32)
     const int lk = (tid % LPR) * 4, lr = tid / LPR;
     const float* wp = W + ((long)((lr & 15) >> 2) * H + j0 + (lr & 3)) * H + lk;   // (lr & 15) = gate*4 + jl
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = H / SK;
     const bool ok0 = (r0 + lr) < p.Bn, ok1 = (r0 + lr + RPP) < p.Bn, ok2 = (r0 + lr + 2 * RPP) < p.Bn, ok3 = (r0 + lr + 3 * RPP) < p.Bn;
     const float* ap = hp + (long)(r0 + lr) * p.hps + lk;
     const long rs16 = RPP * p.hps;
-    float4 ra0, ra1, ra2 = zero4, ra3 = zero4, rbv = zero4;
+    f32x4 ra0, ra1, ra2 = zero4, ra3 = zero4, rbv = zero4;
 #define SM_GLOAD(k0)                                                          \
   do {                                                                        \
-    ra0 = ok0 ? *reinterpret_cast<const float4*>(ap + (k0)) : zero4;            \
-    ra1 = ok1 ? *reinterpret_cast<const float4*>(ap + rs16 + (k0)) : zero4;     \
+    ra0 = ok0 ? *reinterpret_cast<const f32x4*>(ap + (k0)) : zero4;            \
+    ra1 = ok1 ? *reinterpret_cast<const f32x4*>(ap + rs16 + (k0)) : zero4;     \
     if (RPP == 16) {                                                          \
-      ra2 = ok2 ? *reinterpret_cast<const float4*>(ap + 2 * rs16 + (k0)) : zero4; \
-      ra3 = ok3 ? *reinterpret_cast<const float4*>(ap + 3 * rs16 + (k0)) : zero4; \
+      ra2 = ok2 ? *reinterpret_cast<const f32x4*>(ap + 2 * rs16 + (k0)) : zero4; \
+      ra3 = ok3 ? *reinterpret_cast<const f32x4*>(ap + 3 * rs16 + (k0)) : zero4; \
     }                                                                         \
-    if (lr < 16) rbv = *reinterpret_cast<const float4*>(wp + (k0));           \
+    if (lr < 16) rbv = *reinterpret_cast<const f32x4*>(wp + (k0));           \
   } while (0)
 #define SM_SSTORE(buf)                                                        \
   do {                                                                        \
-    *reinterpret_cast<float4*>(&As[buf][lr][lk]) = ra0;                       \
-    *reinterpret_cast<float4*>(&As[buf][lr + RPP][lk]) = ra1;                 \
+    *reinterpret_cast<f32x4*>(&As[buf][lr][lk]) = ra0;                       \
+    *reinterpret_cast<f32x4*>(&As[buf][lr + RPP][lk]) = ra1;                 \
     if (RPP == 16) {                                                          \
-      *reinterpret_cast<float4*>(&As[buf][lr + 32][lk]) = ra2;                \
-      *reinterpret_cast<float4*>(&As[buf][lr + 48][lk]) = ra3;                \
+      *reinterpret_cast<f32x4*>(&As[buf][lr + 32][lk]) = ra2;                \
+      *reinterpret_cast<f32x4*>(&As[buf][lr + 48][lk]) = ra3;                \
     }                                                                         \
-    if (lr < 16) *reinterpret_cast<float4*>(&Bs[buf][lr][lk]) = rbv;          \
+    if (lr < 16) *reinterpret_cast<f32x4*>(&Bs[buf][lr][lk]) = rbv;          \
   } while (0)
     SM_GLOAD(0);
     SM_SSTORE(0);
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
       if (kt + 1 < nk) SM_GLOAD((kt + 1) * SK);
 #pragma unroll
       for (int kb = 0; kb < SK / 16; ++kb) {
-        float4 a = *reinterpret_cast<const float4*>(&As[buf][wave * 16 + fr][kb * 16 + 4 * fq]);
-        float4 b = *reinterpret_cast<const float4*>(&Bs[buf][fr][kb * 16 + 4 * fq]);
+        f32x4 a = *reinterpret_cast<const f32x4*>(&As[buf][wave * 16 + fr][kb * 16 + 4 * fq]);
+        f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[buf][fr][kb * 16 + 4 * fq]);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);

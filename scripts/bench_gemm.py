@@ -1,0 +1,30 @@
+"""Micro-benchmark of mmego_gemm (NT, contiguous): us per launch and TFLOP/s for the IMU projection shapes."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmego_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+shapes = [(10240, 2048, 512), (10240, 2048, 1024), (512, 2048, 1024), (512, 256, 128), (512, 128, 128), (7680, 128, 1152)]
+for M, N, K in shapes:
+    A = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev) * 0.05
+    b = torch.randn(N, device=dev)
+    C = torch.empty(M, N, device=dev)
+    for _ in range(3):
+        ops.linear(A, W, b, C)
+    ref = A[:256].double() @ W.double().t() + b.double()
+    err = (C[:256].double() - ref).abs().max().item()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 50
+    e0.record()
+    for _ in range(n):
+        ops.linear(A, W, b, C)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    print("M%d N%d K%d: %.1f us, %.1f TFLOP/s, max err %.2e" % (M, N, K, us, 2.0 * M * N * K / us / 1e6, err))
