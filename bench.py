@@ -112,6 +112,20 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MMEGO_CPU_THREADS", "16"))))
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in
+    separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950); None if no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
+    if not os.path.exists(path):
+        return None
+    pmc = json.load(open(path))
+    if kernel_label.startswith("lstm_step_kernel"):
+        return pmc.get("lstm_step_kernel", {}).get("hbm_bytes_per_launch")
+    if kernel_label.startswith("gemm_tile_kernel<128,128>"):
+        return pmc.get("gemm_tile_kernel<128,128>", {}).get("hbm_bytes_per_launch_bench_mix")
+    return None
+
+
 def cpu_baseline(steps, warmup):
     """The CPU oracle (a port of the reference path, pinned to it by tests/golden) on the host cores."""
     from oracle import nets as on
@@ -232,23 +246,29 @@ def main():
         big = [(ms_, step_flops(a)) for ms_, a in rec["lstm_step"] if a[1] >= 128]
         small = [(ms_, step_flops(a)) for ms_, a in rec["lstm_step"] if a[1] < 128]
 
-        def is_gemm128(a):   # the dispatch rule of mmego_gemm (gemm.hip)
-            return (a[13] == 1 and a[20] == 1 and not a[18] and a[2] == 1 and a[4] == 1 and a[8] == 1 and a[10] % 128 == 0
-                    and a[11] % 128 == 0 and a[12] % 16 == 0)
-        g128 = [(ms_, 2.0 * a[10] * a[11] * a[12]) for ms_, a in rec["gemm"] if is_gemm128(a)]
+        def is_nt_aligned(a):   # the dispatch rule of mmego_gemm (gemm.hip / gemm_tile.hip)
+            return (a[13] == 1 and a[20] == 1 and not a[18] and a[2] == 1 and a[4] == 1 and a[8] == 1 and a[10] % 64 == 0
+                    and a[11] % 64 == 0 and a[12] % 64 == 0)
+
+        def is_tile128(a):
+            return is_nt_aligned(a) and a[10] % 128 == 0 and a[11] % 128 == 0 and (a[10] // 128) * (a[11] // 128) >= 192
+        g128 = [(ms_, 2.0 * a[10] * a[11] * a[12]) for ms_, a in rec["gemm"] if is_tile128(a)]
+        g64 = [(ms_, 2.0 * a[10] * a[11] * a[12]) for ms_, a in rec["gemm"] if is_nt_aligned(a) and not is_tile128(a)]
         cands = {}
         if big:
             cands["lstm_step_kernel (IMU_Net rnn_fast recurrent steps: 2 dirs x 512 rows x 2048 gates x K=512 per launch)"] = big
         if small:
             cands["lstm_step_small_kernel (IMU_Net rnn_slow recurrent steps: 2 dirs x 64 rows x 2048 gates x K=512)"] = small
         if g128:
-            cands["gemm128_nt_kernel (LSTM input projections and other 128-aligned products)"] = g128
+            cands["gemm_tile_kernel<128,128> (IMU_Net LSTM input projections 10240 x 2048 x {512,1024})"] = g128
+        if g64:
+            cands["gemm_tile_kernel<64,64> (smaller 64-aligned products)"] = g64
         best = max(cands.items(), key=lambda kv: sum(m for m, _ in kv[1]))
         tot_ms = sum(m for m, _ in best[1])
         tot_fl = sum(f for _, f in best[1])
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": best[0],
+                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(best[0]), "kernel": best[0],
                            "avg_launch_us": tot_ms / len(best[1]) * 1e3, "launches_per_step": len(best[1]) // iters,
                            "flop_per_launch_avg": tot_fl / len(best[1]),
                            "share_of_step": (tot_ms / iters) / (t_u + t_l)}
