@@ -65,11 +65,12 @@ int mmego_fill(void* stream, float* X, long n, float v);
  * One timestep of a (bi)LSTM, any H % 32 == 0: gates = xproj + hprev . W_hh^T, fused cell update, c in
  * place.  Replaces the recurrent half of nn.LSTM for IMU_Net (Net/IMU_Net.py:58-62,77,82); xproj is the
  * input projection (incl. b_ih) produced by mmego_gemm, b_hh is added here.  first != 0: h_{t-1} = c_{t-1} = 0
- * (hprev may be NULL, the product is skipped).  Row strides: hps, xs, hos. */
+ * (hprev may be NULL, the product is skipped).  Row strides: hps, xs, hos.  gst_d [Bn][4H] / cst_d [Bn][H]: optional
+ * stash of this step's gate activations and cell state for mmego_lstm_cell_backward (training). */
 int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first, const float* hprev0, const float* hprev1,
                     long hps, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
                     const float* xproj0, const float* xproj1, long xs, float* hout0, float* hout1, long hos, float* c0,
-                    float* c1);
+                    float* c1, float* gst0, float* gst1, float* cst0, float* cst1);
 /* Whole-sequence H=64 bidirectional LSTM layer (Upper_Net.py:333, Lower_Net.py:91, Upper_Net.py:210).
  * xproj_d rows are (b*T+t) with row stride xs; out rows (b*T+t) with row stride os, direction d in
  * columns [64d, 64d+64).  Optional stashes for backward: gates_d [T][B][256], cst_d [T][B][64],
@@ -85,6 +86,21 @@ int mmego_lstm64_backward(void* stream, int B, int T, const float* dout, long do
                           const float* gates1, const float* cst0, const float* cst1, const float* c0_0,
                           const float* c0_1, const float* whh0, const float* whh1, float* dgates0, float* dgates1,
                           long dgs);
+
+/* ---- IMU_Net stage-1 training pieces (imu_train.hip): reference Processor/Train/Train_IMU.py:21-34,114-149 -------
+ * Pointwise LSTM cell backward of one timestep, both directions: dh = dout + dh_rec (dh_rec may be NULL), reads the
+ * stashed gates / cell states, writes the pre-activation gate gradients dgates_d [Bn][4H] (row stride dgs) and updates
+ * dc_d [Bn][H] in place (zero it before the last timestep).  cprev_d NULL means c_{t-1} = 0. */
+int mmego_lstm_cell_backward(void* stream, int ndir, int Bn, int H, const float* dout0, const float* dout1, long dos,
+                             const float* dhrec0, const float* dhrec1, const float* gst0, const float* gst1,
+                             const float* cst0, const float* cst1, const float* cprev0, const float* cprev1, float* dc0,
+                             float* dc1, float* dgates0, float* dgates1, long dgs);
+/* Stage-1 loss: sum acos(clamp((tr(R Rgt^T)-1)/2, +-(1-1e-7))) * 180/3.14159265358 + 100 * sum |t - head|_2 and its
+ * gradients wrt R [F,3,3] and t [F,3] (scaled by `scale`). */
+int mmego_imu_loss(void* stream, const float* R, const float* t, const float* R_gt, const float* head_gt, long F,
+                   float scale, float* loss, float* dR, float* dt);
+/* Backward of mmego_imu_head: (dR [F,3,3], dt [F,3]) -> dy [F,9]. */
+int mmego_imu_head_backward(void* stream, const float* y, const float* dR, const float* dt, long F, float* dy);
 
 /* ---- geometry, heads, loss, selection (geom.hip) --------------------------------------------------
  * In-place xyz <- R (xyz - t) per frame (Utils.py:284-292, quirk Q1: the caller's buffer is mutated). */

@@ -206,6 +206,6 @@ def lstm_steps_forward(ar, key, lstm, x, Bn, T):
             hp1 = out_p + 4 * ((t1 + 1) * 2 * H + H) if s > 0 else None
             hip.call("lstm_step", 2, Bn, H, int(s == 0), hp0, hp1, os_, w0, w1, b0, b1,
                      xp_p + 4 * (t0 * 8 * H), xp_p + 4 * (t1 * 8 * H + 4 * H), xs,
-                     out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_, c[0], c[1])
+                     out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_, c[0], c[1], None, None, None, None)
         cur = out
     return out

@@ -21,6 +21,8 @@ struct LstmStepP {
   const float* xproj[2]; long xs;
   float* hout[2]; long hos;
   float* c[2];
+  float* gst[2];   // optional stash for backward: post-activation gates [Bn][4H] and new cell state [Bn][H] of this step
+  float* cst[2];
   int Bn, H, ndir, first;
 };
 
@@ -201,6 +203,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
       float cn = gf * CP[lrow][hb + fr] + gi * gg;
       CP[lrow][hb + fr] = cn;
       HP[lrow][hb + fr] = go * fast_tanh(cn);
+      if (p.gst[d] && (r0 + lrow) < p.Bn) {     // training only: stash for the backward pass
+        float* gs = p.gst[d] + (long)(r0 + lrow) * 4 * H + j0 + hb + fr;
+        gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;
+        p.cst[d][(long)(r0 + lrow) * H + j0 + hb + fr] = cn;
+      }
     }
   }
   __syncthreads();
@@ -312,6 +319,11 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
       float cn = gf * cprev[reg] + gi * gg;
       p.c[d][(long)row * H + j] = cn;
       p.hout[d][(long)row * p.hos + j] = go * fast_tanh(cn);
+      if (p.gst[d]) {
+        float* gs = p.gst[d] + (long)row * 4 * H + j;
+        gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;
+        p.cst[d][(long)row * H + j] = cn;
+      }
     }
   }
 }
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
 extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first, const float* hprev0, const float* hprev1,
                                long hps, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
                                const float* xproj0, const float* xproj1, long xs, float* hout0, float* hout1, long hos,
-                               float* c0, float* c1) {
+                               float* c0, float* c1, float* gst0, float* gst1, float* cst0, float* cst1) {
   MMEGO_REQUIRE((ndir == 1 || ndir == 2) && Bn > 0 && H > 0 && (H % 32) == 0);
   MMEGO_REQUIRE(whh0 && xproj0 && hout0 && c0 && (((uintptr_t)whh0) & 15) == 0);
   MMEGO_REQUIRE((xs % 4) == 0 && (hos % 4) == 0 && ((((uintptr_t)xproj0) | ((uintptr_t)hout0) | ((uintptr_t)c0)) & 15) == 0);
@@ -336,6 +348,8 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
   p.xproj[0] = xproj0; p.xproj[1] = xproj1; p.xs = xs;
   p.hout[0] = hout0; p.hout[1] = hout1; p.hos = hos;
   p.c[0] = c0; p.c[1] = c1;
+  p.gst[0] = gst0; p.gst[1] = gst1; p.cst[0] = cst0; p.cst[1] = cst1;
+  MMEGO_REQUIRE((gst0 == nullptr) == (cst0 == nullptr) && (gst1 == nullptr) == (cst1 == nullptr));
   p.Bn = Bn; p.H = H; p.ndir = ndir; p.first = first;
   if (Bn >= 128 && (H % KC) == 0) {
     static bool attr_set = false;

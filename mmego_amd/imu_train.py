@@ -1,0 +1,158 @@
+"""IMU_Net stage-1 training on the HIP path: stashing forward, backward through the two BiLSTM(512) stacks,
+geodesic + position loss.  Reference: Net/IMU_Net.py:67-94, Processor/Train/Train_IMU.py:21-34,114-149.
+
+Correctness-first round-1 version: the recurrent products of the backward pass run as mmego_gemm calls (one per
+timestep and direction against a per-step transposed W_hh), weight gradients as split-K GEMMs.
+"""
+import torch
+
+from . import blocks, hip, ops
+
+
+def lstm_steps_forward_stash(ar, key, lstm, x, Bn, T):
+    """Like blocks.lstm_steps_forward but keeps gate activations / cell states of every step for backward."""
+    H, L = lstm.hidden_size, lstm.num_layers
+    cur = x
+    out = None
+    for l in range(L):
+        xp = ar.get("%s.xp%d" % (key, l), (Bn * T, 8 * H))
+        for d in range(2):
+            ops.linear(cur, lstm.w("weight_ih", l, d), lstm.w("bias_ih", l, d), xp[:, d * 4 * H:(d + 1) * 4 * H])
+        out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
+        c = ar.get("%s.c" % key, (2, Bn, H))
+        gst = ar.get("%s.gst%d" % (key, l), (2, T, Bn, 4 * H))
+        cst = ar.get("%s.cst%d" % (key, l), (2, T, Bn, H))
+        w0, w1 = lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1)
+        b0, b1 = lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1)
+        xp_p, out_p = xp.data_ptr(), out.data_ptr()
+        xs, os_ = T * 8 * H, T * 2 * H
+        for s in range(T):
+            t0, t1 = s, T - 1 - s
+            hp0 = out_p + 4 * ((t0 - 1) * 2 * H) if s > 0 else None
+            hp1 = out_p + 4 * ((t1 + 1) * 2 * H + H) if s > 0 else None
+            hip.call("lstm_step", 2, Bn, H, int(s == 0), hp0, hp1, os_, w0, w1, b0, b1,
+                     xp_p + 4 * (t0 * 8 * H), xp_p + 4 * (t1 * 8 * H + 4 * H), xs,
+                     out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_, c[0], c[1],
+                     gst[0, t0], gst[1, t1], cst[0, t0], cst[1, t1])
+        cur = out
+    return out
+
+
+def lstm_steps_backward(ar, key, lstm, x, Bn, T, dout, G, need_dx):
+    """dout [Bn*T, 2H] (rows b*T+t) -> gradients of every LSTM weight; returns d(x) if need_dx."""
+    H, L = lstm.hidden_size, lstm.num_layers
+    dev = x.device
+    d_cur = dout
+    zeros = ar.get("%s.zrow" % key, (Bn, H), zero=True)
+    for l in range(L - 1, -1, -1):
+        inp = x if l == 0 else ar.get("%s.out%d" % (key, l - 1), (Bn * T, 2 * H))
+        out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
+        gst = ar.get("%s.gst%d" % (key, l), (2, T, Bn, 4 * H))
+        cst = ar.get("%s.cst%d" % (key, l), (2, T, Bn, H))
+        dg = ar.get("%s.dg" % key, (Bn * T, 8 * H))
+        dc = ar.get("%s.dc" % key, (2, Bn, H), zero=True)
+        dhrec = ar.get("%s.dhrec" % key, (2, Bn, H))
+        wT = ar.get("%s.wT" % key, (2, H, 4 * H))
+        for d in range(2):
+            hip.call("transpose_batched", lstm.w("weight_hh", l, d), wT[d], 1, 4 * H, H)      # [4H,H] -> [H,4H]
+        dg3 = dg.view(Bn, T, 8 * H)
+        dcur3 = d_cur.view(Bn, T, 2 * H)
+        for s in range(T - 1, -1, -1):
+            t0, t1 = s, T - 1 - s
+            last = s == T - 1
+            hip.call("lstm_cell_backward", 2, Bn, H, dcur3[:, t0, :H], dcur3[:, t1, H:], T * 2 * H,
+                     None if last else dhrec[0], None if last else dhrec[1], gst[0, t0], gst[1, t1], cst[0, t0], cst[1, t1],
+                     cst[0, t0 - 1] if s > 0 else None, cst[1, t1 + 1] if s > 0 else None, dc[0], dc[1],
+                     dg3[:, t0, :4 * H], dg3[:, t1, 4 * H:], T * 8 * H)
+            if s > 0:                                               # dh_{t-1} = dgates_t . W_hh
+                ops.linear(dg3[:, t0, :4 * H], wT[0], None, dhrec[0])
+                ops.linear(dg3[:, t1, 4 * H:], wT[1], None, dhrec[1])
+        hp = ar.get("%s.hp" % key, (Bn * T, H))
+        for d in range(2):
+            dgd = dg[:, d * 4 * H:(d + 1) * 4 * H]
+            ops.grad_weight(dgd, inp, G(lstm.w("weight_ih", l, d)))
+            if d == 0:      # h_{t-1}: previous row of the same sequence; zero at t = 0
+                ops.copy2d(out[:Bn * T - 1, :H], hp[1:])
+                ops.copy2d(zeros, hp.view(Bn, T * H)[:, :H])
+            else:           # reverse direction: h fed into time t came from time t+1; zero at t = T-1
+                ops.copy2d(out[1:, H:], hp[:Bn * T - 1])
+                ops.copy2d(zeros, hp.view(Bn, T * H)[:, (T - 1) * H:])
+            ops.grad_weight(dgd, hp, G(lstm.w("weight_hh", l, d)))
+            gb = G(lstm.w("bias_ih", l, d))
+            ops.colsum(dgd, gb)
+            ops.copy2d(gb.view(1, 4 * H), G(lstm.w("bias_hh", l, d)).view(1, 4 * H))
+        if l > 0 or need_dx:
+            dinp = ar.get("%s.dx%d" % (key, l), (Bn * T, inp.shape[1]))
+            ops.grad_input(dg[:, :4 * H], lstm.w("weight_ih", l, 0), dinp)
+            ops.grad_input(dg[:, 4 * H:], lstm.w("weight_ih", l, 1), dinp, accumulate=True)
+            d_cur = dinp
+    return d_cur if need_dx else None
+
+
+def forward_train(net, imu):
+    """IMUNet forward keeping what backward needs.  Returns (R, t)."""
+    net.flat()
+    ar = net.arena("train")
+    B, T, S, Cin = imu.shape
+    H, Bn, dev = net.hidden_n, B * T, imu.device
+    x = ar.get("x", (Bn * S, Cin))
+    ops.copy2d(imu.view(Bn * S, Cin), x)
+    h = ar.get("fc1", (Bn * S, H))
+    ops.linear(x, net.fc1.weight, net.fc1.bias, h, relu=True)
+    fast = lstm_steps_forward_stash(ar, "fast", net.rnn_fast, h, Bn, S)
+    pooled = ar.get("pooled", (Bn, 2 * H))
+    attn = ar.get("attn", (Bn, S))
+    blocks.attn_pool_forward(fast, net.attn, Bn, S, 2 * H, pooled, attn)
+    slow = lstm_steps_forward_stash(ar, "slow", net.rnn_slow, pooled, B, T)
+    y = ar.get("y", (Bn, 9))
+    ops.linear(slow, net.fc2.weight, net.fc2.bias, y)
+    R = torch.empty((B, T, 3, 3), dtype=torch.float32, device=dev)
+    t = torch.empty((B, T, 3), dtype=torch.float32, device=dev)
+    hip.call("imu_head", y, Bn, R, t)
+    net._saved = (B, T, S, Cin)
+    return R, t
+
+
+def backward(net, dR, dt):
+    ar = net.arena("train")
+    B, T, S, Cin = net._saved
+    H, Bn = net.hidden_n, B * T
+    G = net._flat.grad
+    y = ar.get("y", (Bn, 9))
+    dy = ar.get("dy", (Bn, 9))
+    hip.call("imu_head_backward", y, dR.contiguous(), dt.contiguous(), Bn, dy)
+    slow = ar.get("slow.out%d" % (net.rnn_slow.num_layers - 1), (Bn, 2 * H))
+    dslow = ar.get("dslow", (Bn, 2 * H))
+    blocks.linear_backward(dy, slow, net.fc2, G, dslow)
+    pooled = ar.get("pooled", (Bn, 2 * H))
+    dpooled = lstm_steps_backward(ar, "slow", net.rnn_slow, pooled, B, T, dslow, G, True)
+    fast = ar.get("fast.out%d" % (net.rnn_fast.num_layers - 1), (Bn * S, 2 * H))
+    attn = ar.get("attn", (Bn, S))
+    dfast = ar.get("dfast", (Bn * S, 2 * H))
+    blocks.attn_pool_backward(ar, "pool", fast, net.attn, attn, dpooled, Bn, S, 2 * H, dfast, G)
+    h = ar.get("fc1", (Bn * S, H))
+    dh = lstm_steps_backward(ar, "fast", net.rnn_fast, h, Bn, S, dfast, G, True)
+    ops.relu_mask_(dh, h)
+    x = ar.get("x", (Bn * S, Cin))
+    blocks.linear_backward(dh, x, net.fc1, G)
+    # fc3 is never used in forward (Q7): its gradient stays zero
+
+
+class ImuBridge(torch.autograd.Function):
+    """One autograd node for the whole IMU_Net: forward/backward are the kernel pipelines above."""
+
+    @staticmethod
+    def forward(ctx, net, imu, *params):
+        ctx.net = net
+        return forward_train(net, imu)
+
+    @staticmethod
+    def backward(ctx, dR, dt):
+        net = ctx.net
+        dev = next(net.parameters()).device
+        B, T = net._saved[0], net._saved[1]
+        dR = dR if dR is not None else torch.zeros((B, T, 3, 3), device=dev)
+        dt = dt if dt is not None else torch.zeros((B, T, 3), device=dev)
+        backward(net, dR.to(torch.float32), dt.to(torch.float32))
+        net.flat().bind_grads()
+        return (None, None) + (None,) * len(net._flat.params)

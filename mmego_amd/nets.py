@@ -532,8 +532,13 @@ class IMUNet(_NetBase):
         _require_gpu(imu, "IMUNet")
         if h0_i is not None:
             raise NotImplementedError("IMUNet: the reference never passes h0_i; only None is supported")
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("IMUNet training (stage 1) backward is not on the HIP path yet; call .eval()")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self.rnn_fast.dropout > 0.0 or self.rnn_slow.dropout > 0.0:
+                raise NotImplementedError("IMUNet training with LSTM dropout > 0 is not supported (the reference trains "
+                                          "stage 1 with dropout=0, Train_IMU.py:50); construct it with dropout=0 or call .eval()")
+            from .imu_train import ImuBridge
+            self.flat()
+            return ImuBridge.apply(self, _f32c(imu), *self._flat.params)
         self.flat()
         ar = self.arena("eval")
         imu = _f32c(imu)

@@ -298,12 +298,86 @@ class Evaluator(_Base):
 
 
 class ImuTrainer(_Base):
-    """`python main.py --train --network IMU_Net` (reference Train_IMU.MMEgo): stage 1 needs the BiLSTM-512 backward,
-    which is the next hot-path row and not on the HIP path yet."""
+    """`python main.py --train --network IMU_Net` (reference Train_IMU.MMEgo): stage 1, geodesic + 100 x position loss,
+    Adam with coupled weight decay 1e-3."""
 
     def __init__(self):
         super().__init__(Config)
+        cfg = self.cfg
+        self.num_epochs, self.save_slot, self.learning_rate = cfg.epochs, 50, cfg.lr
+        self.model_IMU = IMUNet(15, 6 + 3, 512, 2, True, 0).to(self.device)
+        if cfg.IMU_pretrained:
+            self.model_IMU.load(cfg.model_IMU_path)
+        from .params import FusedAdam
+        self.optimizer_IMU = FusedAdam(self.model_IMU.flat(), lr=self.learning_rate, weight_decay=0.001)
+        self.train_data = PosePC(batch_length=self.frame_no)
+        self.test_data = PosePC(train=False, batch_length=self.frame_no)
+        rep = os.path.join(_TRAIN_DIR, "report", str(self.Idx))
+        self.lossfile = open(os.path.join(rep, "log-loss.txt"), "w") if self.rank == 0 else None
+        self._rng = np.random.RandomState(1234)
+        self._loss = torch.zeros(1, device=self.device)
+
+    def _loss_and_grads(self, R, t, R_gt, head, want_grad):
+        F = R.shape[0] * R.shape[1]
+        dR = torch.empty_like(R) if want_grad else None
+        dt = torch.empty_like(t) if want_grad else None
+        hip.call("imu_loss", R.contiguous(), t.contiguous(), R_gt.contiguous(), head.contiguous(), F, 1.0, self._loss, dR, dt)
+        return dR, dt
+
+    def train_imu_once(self):
+        from . import imu_train
+        from .train_step import allreduce_grads
+        self.model_IMU.train()
+        losses = []
+        pg = torch.distributed.group.WORLD if self.world > 1 else None
+        for data, target, skl, imu, _, _, R_R0R, _ in batches(self.train_data, self.batchsize * self.world, True, self._rng):
+            sl = shard_of(self.rank, self.world)
+            target, imu, R_R0R = target[sl], imu[sl], R_R0R[sl]
+            if len(imu) == 0:
+                continue
+            dev = self.device
+            B, T = imu.shape[0], imu.shape[1]
+            imu_d, tgt, Rg = _dev_tensor(imu, dev), _dev_tensor(target, dev), _dev_tensor(R_R0R, dev)
+            with torch.no_grad():
+                R, t = imu_train.forward_train(self.model_IMU, imu_d)
+                dR, dt = self._loss_and_grads(R, t, Rg, tgt[:, :, 20], True)
+                imu_train.backward(self.model_IMU, dR, dt)
+            allreduce_grads(self.model_IMU._flat, pg)
+            self.optimizer_IMU.step()
+            losses.append(self._loss.item() / B / T)
+        return float(np.mean(losses))
+
+    def eval_imu(self):
+        self.model_IMU.eval()
+        tot, parts = [], []
+        with torch.no_grad():
+            for data, target, skl, imu, _, _, R_R0R, _ in batches(self.test_data, self.batchsize, True, self._rng):
+                dev = self.device
+                B, T = imu.shape[0], imu.shape[1]
+                tgt, Rg = _dev_tensor(target, dev), _dev_tensor(R_R0R, dev)
+                R, t = self.model_IMU(_dev_tensor(imu, dev))
+                self._loss_and_grads(R, t, Rg, tgt[:, :, 20], False)
+                loss = self._loss.item()
+                pos = torch.sqrt(((t - tgt[:, :, 20]) ** 2).sum(-1)).sum().item()
+                tot.append(loss / B / T)
+                parts.append([(loss - 100 * pos) / B / T, pos / B / T])
+        return float(np.mean(tot)), np.mean(parts, axis=0)
 
     def train_imu(self):
-        raise NotImplementedError("IMU_Net stage-1 training is not on the HIP path yet (forward only); "
-                                  "train Upper/Lower with --load_IMU_path or --gt_head_pose")
+        early = EarlyStopping(patience=30)
+        for epoch in range(self.num_epochs):
+            print("epoch: {}".format(epoch + 1))
+            train_loss = self.train_imu_once()
+            if (epoch + 1) % self.save_slot == 0:
+                self.save_models(epoch, self.model_IMU)
+            eval_loss, eval_loss_l = self.eval_imu()
+            if self.rank == 0:
+                self.lossfile.write("%d %f\n" % (epoch + 1, eval_loss))
+                self.lossfile.write(str(eval_loss_l) + "\n")
+                self.lossfile.flush()
+            print("Train_loss: {}".format(train_loss))
+            print("Eval_loss: {}  Eval_loss_l (angle, H_pos): {}".format(eval_loss, eval_loss_l))
+            if early(eval_loss):
+                print("Early stopping")
+                self.save_models(epoch, self.model_IMU)
+                break

@@ -129,3 +129,39 @@ def test_infer_pipeline_on_real_sequences(dev, real16):
     for k in ("all_cm", "upper_cm", "lower_cm"):
         assert abs(s[k] - so[k]) < 1e-3, (k, s[k], so[k])
     assert abs(s["rot_deg"] - so["rot_deg"]) < 1e-2
+
+
+def test_imu_stage1_training(dev):
+    """IMU_Net forward + backward (BiLSTM backward through time, attention pool, geodesic + position loss) vs the
+    reference's gradients (golden g7, hidden 32) and vs the oracle at hidden 64 with the benchmark's T/S."""
+    from mmego_amd import hip, nets
+    g = golden("g7_imu.npz")
+    imu = T(g["imu"])
+    h = load_weights(nets.IMUNet(15, 9, 32, 2, True, 0), g, "train.w.").to(dev).train()
+    R, t = h(imu.to(dev))
+    Rg, hg = T(g["train.R_gt"]).to(dev), T(g["train.head_gt"]).to(dev)
+    loss = torch.zeros(1, device=dev)
+    dR, dt = torch.empty_like(R), torch.empty_like(t)
+    hip.call("imu_loss", R.detach().contiguous(), t.detach().contiguous(), Rg.contiguous(), hg.contiguous(), 6, 1.0, loss, dR, dt)
+    assert abs(loss.item() - float(g["train.loss"])) < 1e-4 * abs(float(g["train.loss"]))
+    torch.autograd.backward((R, t), (dR, dt))
+    grads = [(k, p.grad) for k, p in h.named_parameters()]
+    scale = max(x.abs().max().item() for _, x in grads)
+    check_pinned(g, "train.grad.", grads, rtol=2e-3, atol=2e-4 * scale)
+    # bigger instance against the oracle, through torch's autograd of an arbitrary scalar of (R, t)
+    torch.manual_seed(21)
+    o = on.IMUNet(15, 9, 64, 2, True, 0).train()
+    torch.manual_seed(21)
+    hb = nets.IMUNet(15, 9, 64, 2, True, 0).to(dev).train()
+    imu2 = torch.randn(3, 4, 20, 15)
+    wR, wt = torch.randn(3, 4, 3, 3), torch.randn(3, 4, 3)
+    Ro, to_ = o(imu2)
+    ((Ro * wR).sum() + (to_ * wt).sum()).backward()
+    Rh, th = hb(imu2.to(dev))
+    ((Rh * wR.to(dev)).sum() + (th * wt.to(dev)).sum()).backward()
+    assert torch.allclose(Rh.detach().cpu(), Ro.detach(), atol=1e-5) and torch.allclose(th.detach().cpu(), to_.detach(), atol=1e-5)
+    po = dict(o.named_parameters())
+    scale = max(p.grad.abs().max().item() for p in po.values() if p.grad is not None)
+    for k, ph in hb.named_parameters():
+        go = po[k].grad if po[k].grad is not None else torch.zeros_like(po[k])
+        assert (ph.grad.cpu() - go).abs().max().item() < 2e-4 * scale, k
