@@ -1,0 +1,66 @@
+"""GPU: the reference's command line end to end on a tiny synthetic Sample_data tree (same .mat keys and layout):
+stage-2, stage-3 and stage-1 training for one epoch each, then --infer with the checkpoints just written."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.io as scio
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_dataset(root, rng):
+    for a in (1, 2):
+        for s in (1, 2, 3):
+            d = os.path.join(root, "%02d" % a, "s%d" % s)
+            os.makedirs(d)
+            skel = rng.normal(0, 0.4, (32, 3)) + np.array([0.8, 0.0, 0.2])
+            for f in range(23):
+                n = int(rng.integers(20, 150))
+                pc = np.concatenate([rng.normal([0.8, 0.0, 0.2], 0.4, (n, 3)), rng.uniform(10, 46, (n, 1)), rng.normal(0, 0.4, (n, 1))], 1)
+                q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+                imu = np.concatenate([np.tile(q.reshape(1, 9), (20, 1)), rng.normal(size=(20, 6))], 1)
+                scio.savemat(os.path.join(d, "frame_%d.mat" % f), {
+                    "pc_xyziv_ti2": pc.astype(np.float32), "pc_xyz_key_2": skel + rng.normal(0, 0.01, (32, 3)),
+                    "imu_save_l": imu, "R_btc": q, "orientation_imu_img": np.eye(3), "t_R0R": rng.normal(size=(1, 3)),
+                    "abcd_ground_2": np.array([[0.0, 0.0, -1.0, 1.0]]), "foot_contact": np.array([[1, 0]])})
+
+
+def _run(args, env):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_main_train_and_infer_on_synthetic_tree(tmp_path):
+    data = str(tmp_path / "Sample_data")
+    _make_dataset(data, np.random.default_rng(0))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    model_dir = os.path.join(ROOT, "Processor", "Train", "model")
+    common = ["--data_root", data, "--epochs", "1", "--batch_size", "4", "--device", "cuda:0"]
+    out = _run(["--train", "--network", "Upper_Net", "--gt_head_pose", "--log_dir", "9101"] + common, env)
+    assert "epoch: 1" in out and "Average Joint Localization Error" in out
+    # the trainers save on (epoch+1) % 50 == 0 or early stop; write checkpoints for the next stages from fresh nets
+    import torch
+    from mmego_amd import nets
+    ck = tmp_path / "ck"
+    ck.mkdir()
+    torch.manual_seed(0)
+    torch.save(nets.UpperNet().state_dict(), ck / "upper.pth")
+    torch.save(nets.LowerNet(64).state_dict(), ck / "lower.pth")
+    out = _run(["--train", "--network", "Lower_Net", "--gt_head_pose", "--log_dir", "9102", "--load_Upper_path", str(ck / "upper.pth")] + common, env)
+    assert "Average LowerBody Joint Localization Error" in out
+    out = _run(["--train", "--network", "IMU_Net", "--log_dir", "9103"] + common, env)
+    assert "Train_loss:" in out and "Eval_loss:" in out
+    out = _run(["--infer", "--gt_head_pose", "--data_root", data, "--device", "cuda:0", "--load_Upper_path", str(ck / "upper.pth"),
+                "--load_Lower_path", str(ck / "lower.pth")], env)
+    for line in ("Average Joint Localization Error(cm):", "Average UpperBody Joint Localization Error(cm):",
+                 "Average LowerBody Joint Localization Error(cm):", "Average Joint Rotation Error", "Per Joint Localization Error(cm):"):
+        assert line in out
+    assert os.path.exists(os.path.join(ROOT, "Processor", "Train", "report", "9101", "log-loss.txt"))
+    assert os.path.isdir(model_dir)
