@@ -47,11 +47,41 @@ class Arena:
 
 
 _scratch = {}
+_side = {"stream": None, "active": False}
+
+
+class wgrad_overlap:
+    """Run weight-gradient work (dW = dY^T X, bias sums) on a second HIP stream while the main stream continues with
+    the input-gradient chain.  Weight gradients are leaves of the backward graph: nothing but the optimiser reads
+    them, so they only have to be finished at the join.  Works eagerly and under HIP-graph capture (fork/join become
+    graph edges)."""
+
+    def __enter__(self):
+        if _side["stream"] is None:
+            _side["stream"] = torch.cuda.Stream()
+        _side["stream"].wait_stream(torch.cuda.current_stream())
+        _side["active"] = True
+        return self
+
+    def __exit__(self, *exc):
+        _side["active"] = False
+        torch.cuda.current_stream().wait_stream(_side["stream"])
+        return False
+
+
+def on_side(fn):
+    """Run ``fn`` (kernel launches) on the weight-gradient stream, ordered after everything enqueued so far."""
+    if not _side["active"]:
+        return fn()
+    side = _side["stream"]
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        return fn()
 
 
 def scratch(device, n):
-    """Grow-only fp32 scratch (split-K slabs, reduction partials).  Stream-ordered reuse is safe."""
-    key = str(device)
+    """Grow-only fp32 scratch per (device, stream) (split-K slabs, reduction partials).  Stream-ordered reuse is safe."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
     t = _scratch.get(key)
     if t is None or t.numel() < n:
         t = torch.empty(max(int(n), 1 << 20), dtype=torch.float32, device=device)

@@ -64,7 +64,8 @@ class StageStep:
                 l = self.net._forward_impl(up, s["x"], s["body"], R, t, stash=True)[0]
                 nsel = 8
             hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss, s["dl"])
-            self.net._backward_impl(s["dl"])
+            with ops.wgrad_overlap():
+                self.net._backward_impl(s["dl"])
         self.last_pred = l
 
     def bind(self, x, imu, body, target, R_gt=None):
