@@ -155,8 +155,10 @@ int mmego_cross_attn_forward(void* stream, const float* Q, const float* K, const
                              long ldo, float* P);
 int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, const float* V, const float* P,
                               const float* dO, long lddo, long F, float scale, float* dQ, float* dK, float* dV);
-/* Gradient of einsum('nkctv,kvw->nctw') wrt A (GCN.py:62); the forward and dZ are mmego_gemm batches. */
-int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* dA);
+/* Gradient of einsum('nkctv,kvw->nctw') wrt A (GCN.py:62); the forward and dZ are mmego_gemm batches.  Writes
+ * per-block partial sums partial_ws[mmego_graph_dA_nblk(G)][K*V*V]; reduce them with mmego_colsum. */
+int mmego_graph_dA_nblk(long G);
+int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* partial_ws);
 /* Temporal 9x1 unfold / fold of a channels-last (B,T,V,C) tensor (GCN.py:109-116). */
 int mmego_im2col_t(void* stream, const float* X, int B, int T, int V, int C, int taps, float* col);
 int mmego_col2im_t(void* stream, const float* dcol, int B, int T, int V, int C, int taps, float* dX);

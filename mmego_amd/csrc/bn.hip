@@ -13,29 +13,38 @@ static inline long rows_per_block(long rows) {
   return (r + 3) / 4 * 4;
 }
 
+// Column-reduction thread tile: TC = min(64, next pow2 >= C) lanes across the channels (coalesced), TR = 256 / TC lanes
+// down the rows, so that narrow tensors (C = 8..32 in the PointNets) still keep every lane busy.
+static inline int col_tile(int C) {
+  int tc = 8;
+  while (tc < C && tc < 64) tc <<= 1;
+  return tc;
+}
+
 // partial[blk][c] = (n, mean, M2) over this block's rows of column c
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ X, long ldx, long rows, int C,
-                                                       float* __restrict__ partial, long RPB) {
-  __shared__ float sh[4][64][3];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cx;
+                                                       float* __restrict__ partial, long RPB, int TC) {
+  __shared__ float sh[256][3];
+  const int TR = 256 / TC;
+  const int cx = threadIdx.x % TC, ry = threadIdx.x / TC;
+  const int c = blockIdx.y * TC + cx;
   const long r0 = (long)blockIdx.x * RPB;
   const long r1 = min(rows, r0 + RPB);
   float n = 0.f, s = 0.f, ss = 0.f, shift = 0.f;
   if (c < C) {
     shift = X[r0 * ldx + c];  // block-local shift keeps the sum of squares well conditioned
-    for (long r = r0 + ry; r < r1; r += 4) {
+    for (long r = r0 + ry; r < r1; r += TR) {
       float d = X[r * ldx + c] - shift;
       s += d;
       ss += d * d;
       n += 1.f;
     }
   }
-  sh[ry][cx][0] = n; sh[ry][cx][1] = s; sh[ry][cx][2] = ss;
+  sh[threadIdx.x][0] = n; sh[threadIdx.x][1] = s; sh[threadIdx.x][2] = ss;
   __syncthreads();
   if (ry == 0 && c < C) {
     float N = 0.f, S = 0.f, SS = 0.f;
-    for (int j = 0; j < 4; ++j) { N += sh[j][cx][0]; S += sh[j][cx][1]; SS += sh[j][cx][2]; }
+    for (int j = 0; j < TR; ++j) { N += sh[j * TC + cx][0]; S += sh[j * TC + cx][1]; SS += sh[j * TC + cx][2]; }
     float mean_d = S / N;
     float* out = partial + ((long)blockIdx.x * C + c) * 3;
     out[0] = N;
@@ -134,27 +143,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ Ymask, long ldm,
                                                             const float* __restrict__ X, long ldx, const float* mean,
                                                             const float* invstd, long rows, int C,
-                                                            float* __restrict__ partial, long RPB) {
-  __shared__ float sh[4][64][2];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cx;
+                                                            float* __restrict__ partial, long RPB, int TC) {
+  __shared__ float sh[256][2];
+  const int TR = 256 / TC;
+  const int cx = threadIdx.x % TC, ry = threadIdx.x / TC;
+  const int c = blockIdx.y * TC + cx;
   const long r0 = (long)blockIdx.x * RPB;
   const long r1 = min(rows, r0 + RPB);
   float s1 = 0.f, s2 = 0.f;
   if (c < C) {
     const float mu = mean[c], is = invstd[c];
-    for (long r = r0 + ry; r < r1; r += 4) {
+    for (long r = r0 + ry; r < r1; r += TR) {
       float g = dY[r * lddy + c];
       if (Ymask && !(Ymask[r * ldm + c] > 0.f)) g = 0.f;
       s1 += g;
       s2 += g * ((X[r * ldx + c] - mu) * is);
     }
   }
-  sh[ry][cx][0] = s1; sh[ry][cx][1] = s2;
+  sh[threadIdx.x][0] = s1; sh[threadIdx.x][1] = s2;
   __syncthreads();
   if (ry == 0 && c < C) {
     float a = 0.f, b = 0.f;
-    for (int j = 0; j < 4; ++j) { a += sh[j][cx][0]; b += sh[j][cx][1]; }
+    for (int j = 0; j < TR; ++j) { a += sh[j * TC + cx][0]; b += sh[j * TC + cx][1]; }
     partial[((long)blockIdx.x * C + c) * 2 + 0] = a;
     partial[((long)blockIdx.x * C + c) * 2 + 1] = b;
   }
@@ -197,18 +207,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // partial[blk][c] = sum over the block's rows of X[r,c]
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, long rows, int C,
-                                                             float* __restrict__ partial, long RPB) {
-  __shared__ float sh[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cx;
+                                                             float* __restrict__ partial, long RPB, int TC) {
+  __shared__ float sh[256];
+  const int TR = 256 / TC;
+  const int cx = threadIdx.x % TC, ry = threadIdx.x / TC;
+  const int c = blockIdx.y * TC + cx;
   const long r0 = (long)blockIdx.x * RPB;
   const long r1 = min(rows, r0 + RPB);
   float s = 0.f;
   if (c < C)
-    for (long r = r0 + ry; r < r1; r += 4) s += X[r * ldx + c];
-  sh[ry][cx] = s;
+    for (long r = r0 + ry; r < r1; r += TR) s += X[r * ldx + c];
+  sh[threadIdx.x] = s;
   __syncthreads();
-  if (ry == 0 && c < C) partial[(long)blockIdx.x * C + c] = sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx];
+  if (ry == 0 && c < C) {
+    float a = 0.f;
+    for (int j = 0; j < TR; ++j) a += sh[j * TC + cx];
+    partial[(long)blockIdx.x * C + c] = a;
+  }
 }
 
 __global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* out, int accumulate) {
@@ -248,7 +263,8 @@ extern "C" int mmego_bn_train_stats(void* stream, const float* X, long ldx, long
   hipStream_t st = (hipStream_t)stream;
   const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
-  hipLaunchKernelGGL(colstats_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB);
+  const int TC = col_tile(C);
+  hipLaunchKernelGGL(colstats_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC);
   MMEGO_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, a, b);
@@ -293,8 +309,9 @@ extern "C" int mmego_bn_backward(void* stream, const float* dY, long lddy, const
   hipStream_t st = (hipStream_t)stream;
   const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
-                     mean, invstd, rows, C, partial_ws, RPB);
+  const int TC = col_tile(C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
+                     mean, invstd, rows, C, partial_ws, RPB, TC);
   MMEGO_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, rows, dgamma,
                      dbeta, c12_ws, c12_ws + C);
@@ -311,7 +328,8 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
   hipStream_t st = (hipStream_t)stream;
   const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB);
+  const int TC = col_tile(C);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC);
   MMEGO_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, out, accumulate);
   MMEGO_LAUNCH_CHECK();

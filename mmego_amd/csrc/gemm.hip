@@ -104,18 +104,26 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
   }
 }
 
-// ws: [nsplit][nbatch][M][N] contiguous partial products -> C (strided), + bias, relu, accumulate
+// ws: [nsplit][nbatch][M][N] contiguous partial products -> C (strided), + bias, relu, accumulate.
+// 64 outputs x 4 split-lanes per block; the 4 partial sums are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* C, const float* bias, int nsplit,
                                                             int nbatch, int M, int N, long scm, long scn, long sCb,
                                                             int relu, int accumulate) {
-  long total = (long)nbatch * M * N;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  __shared__ float sh[4][64];
+  const long total = (long)nbatch * M * N;
+  const int o = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + o;
+  float s = 0.0f;
+  if (i < total)
+    for (int k = kg; k < nsplit; k += 4) s += ws[(long)k * total + i];
+  sh[kg][o] = s;
+  __syncthreads();
+  if (kg == 0 && i < total) {
+    s = ((sh[0][o] + sh[1][o]) + sh[2][o]) + sh[3][o];
     int n = (int)(i % N);
     long r = i / N;
     int m = (int)(r % M);
     int b = (int)(r / M);
-    float s = 0.0f;
-    for (int k = 0; k < nsplit; ++k) s += ws[(long)k * total + i];
     if (bias) s += bias[n];
     if (relu) s = fmaxf(s, 0.0f);
     float* dst = C + (long)b * sCb + (long)m * scm + (long)n * scn;
@@ -249,8 +257,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   MMEGO_LAUNCH_CHECK();
   if (nsplit > 1) {
     long total = (long)nbatch * M * N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (int)((total + 63) / 64);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, C, bias, nsplit, nbatch, M, N,
                        scm, scn, sCb, relu, accumulate);
     MMEGO_LAUNCH_CHECK();

@@ -235,21 +235,34 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
 }
 
 // dA[k, v, w] = sum_{g, c} Z[g, v, k*C + c] * dY[g, w, c]     Z [G, V, K*C], dY [G, V, C]
-__global__ __launch_bounds__(256) void graph_dA_kernel(const float* __restrict__ Z, const float* __restrict__ dY, long G,
-                                                       int V, int Kk, int C, float* __restrict__ dA) {
-  __shared__ double red[4];
-  const int w = blockIdx.x % V, v = (blockIdx.x / V) % V, k = blockIdx.x / (V * V);
-  double acc = 0.0;
-  const long total = G * C;
-  for (long i = threadIdx.x; i < total; i += blockDim.x) {
-    long g = i / C;
-    int c = (int)(i - g * C);
-    acc += (double)(Z[(g * V + v) * (long)(Kk * C) + k * C + c] * dY[(g * V + w) * (long)C + c]);
+// Each block stages FPB frames' Z and dY rows in LDS once and every thread owns one (k,v,w) entry;
+// partial[blk][k*V*V + v*V + w] is then column-summed in fixed order by the caller (mmego_colsum kernels).
+#define GDA_FPB 8
+__global__ __launch_bounds__(512) void graph_dA_partial_kernel(const float* __restrict__ Z, const float* __restrict__ dY, long G,
+                                                               int V, int Kk, int C, float* __restrict__ partial) {
+  extern __shared__ float sm[];
+  const int KC = Kk * C;
+  float* zs = sm;                       // [V][KC + 1]
+  float* ys = sm + V * (KC + 1);        // [V][C + 1]
+  const int nout = Kk * V * V;
+  const int e = threadIdx.x;
+  const int w = e % V, v = (e / V) % V, k = e / (V * V);
+  float acc = 0.f;
+  const long g0 = (long)blockIdx.x * GDA_FPB;
+  for (long g = g0; g < g0 + GDA_FPB && g < G; ++g) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < V * KC; i += blockDim.x) zs[(i / KC) * (KC + 1) + (i % KC)] = Z[g * V * KC + i];
+    for (int i = threadIdx.x; i < V * C; i += blockDim.x) ys[(i / C) * (C + 1) + (i % C)] = dY[g * V * C + i];
+    __syncthreads();
+    if (e < nout) {
+      const float* zr = zs + v * (KC + 1) + k * C;
+      const float* yr = ys + w * (C + 1);
+      float a = 0.f;
+      for (int c = 0; c < C; ++c) a += zr[c] * yr[c];
+      acc += a;
+    }
   }
-  acc = wave_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) dA[blockIdx.x] = (float)(red[0] + red[1] + red[2] + red[3]);
+  if (e < nout) partial[(long)blockIdx.x * nout + e] = acc;
 }
 
 // col[(b,t,v), ci*taps + tap] = X[b, t+tap-half, v, ci]  (zero outside)      X [B,T,V,C]
@@ -375,9 +388,14 @@ extern "C" int mmego_cross_attn_backward(void* stream, const float* Q, const flo
   return MMEGO_OK;
 }
 
-extern "C" int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* dA) {
-  MMEGO_REQUIRE(Z && dY && dA && G > 0 && V > 0 && K > 0 && C > 0);
-  hipLaunchKernelGGL(graph_dA_kernel, dim3(K * V * V), dim3(256), 0, (hipStream_t)stream, Z, dY, G, V, K, C, dA);
+extern "C" int mmego_graph_dA_nblk(long G) { return cdiv(G, GDA_FPB); }
+
+extern "C" int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* partial_ws) {
+  MMEGO_REQUIRE(Z && dY && partial_ws && G > 0 && V > 0 && K > 0 && C > 0 && K * V * V <= 512);
+  size_t lds = (size_t)(V * (K * C + 1) + V * (C + 1)) * sizeof(float);
+  MMEGO_REQUIRE(lds <= 64 * 1024);
+  hipLaunchKernelGGL(graph_dA_partial_kernel, dim3(cdiv(G, GDA_FPB)), dim3(512), lds, (hipStream_t)stream, Z, dY, G, V, K, C,
+                     partial_ws);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

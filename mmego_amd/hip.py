@@ -71,5 +71,9 @@ def call(name, *args):
         raise RuntimeError("mmego_%s failed: %s" % (name, "bad argument" if rc < 0 else "hipError %d" % rc))
 
 
+def graph_dA_nblk(G):
+    return lib().mmego_graph_dA_nblk(G)
+
+
 def colstats_nblk(rows):
     return lib().mmego_colstats_nblk(rows)

@@ -492,8 +492,10 @@ class LowerNet(_NetBase):
             z = ar.get(key + ".z", (rows, K * cout))
             Aeff = ar.get(key + ".A", (K, V, V))
             dA = ar.get(key + ".dA", (K, V, V))
-            ops.on_side(lambda z=z, dymix=dymix, dA=dA, i=i, cout=cout, K=K: (
-                hip.call("graph_dA", z, dymix, F, V, K, cout, dA),
+            dAp = ar.get(key + ".dAp", (hip.lib().mmego_graph_dA_nblk(F), K * V * V))
+            ops.on_side(lambda z=z, dymix=dymix, dA=dA, dAp=dAp, i=i, cout=cout, K=K: (
+                hip.call("graph_dA", z, dymix, F, V, K, cout, dAp),
+                ops.colsum(dAp, dA.view(-1)),
                 hip.call("mul", dA, gcn.A, G(gcn.edge_importance[i]), dA.numel())))
             dz = ar.get(key + ".dz", (rows, K * cout))
             dz3, dy3 = dz.view(F, V, K * cout), dymix.view(F, V, cout)
