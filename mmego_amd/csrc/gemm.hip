@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int batch = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;   // M tiles on grid.x (no 65535 limit: rows can be millions)
   const float* A = p.A + (long)batch * p.sAb;
   const float* B = p.B + (long)batch * p.sBb;
   const int kbeg = split * p.kchunk;
@@ -248,7 +248,8 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
     p.kchunk = cdiv(K, 16) * 16;
     p.C = C; p.scm = scm; p.scn = scn; p.sCb = sCb; p.sCs = 0;
   }
-  dim3 grid(cdiv(N, 64), cdiv(M, 64), nbatch * nsplit);
+  MMEGO_REQUIRE(cdiv(N, 64) <= 65535 && (long)nbatch * nsplit <= 65535);
+  dim3 grid(cdiv(M, 64), cdiv(N, 64), nbatch * nsplit);
   const bool akc = (sak == 1), bkc = (sbk == 1);
   if (akc && bkc) hipLaunchKernelGGL((gemm64_kernel<true, true>), grid, dim3(256), 0, st, p);
   else if (akc) hipLaunchKernelGGL((gemm64_kernel<true, false>), grid, dim3(256), 0, st, p);

@@ -18,17 +18,19 @@
 // NOTE: staging registers are ext_vector f32x4 (not HIP's float4 struct): arrays of the struct type are left in
 // scratch memory by hipcc (ROCm 7.2), which serialises the prefetch.
 
-template <int BM, int BN>
+template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                         float* __restrict__ C, const float* __restrict__ bias, int M, int N,
                                                         int K, long lda, long ldw, long ldc, int relu) {
-  constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 tiles per wave
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
+  constexpr int TM = WM / 32, TN = WN / 32;           // 32x32 MFMA tiles per wave
   constexpr int AV = BM / 16, BV = BN / 16;          // f32x4 per thread per 64-k chunk (rows lr + 16*i)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float (*As)[TLD] = reinterpret_cast<float (*)[TLD]>(smem);
   float (*Bs)[TLD] = reinterpret_cast<float (*)[TLD]>(smem + BM * TLD);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
   const int ntn = N / BN, ntm = M / BM, nwg = ntn * ntm;
   int id = blockIdx.x;
   if ((nwg & 7) == 0) id = (id & 7) * (nwg >> 3) + (id >> 3);
@@ -68,9 +70,9 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const float* __restrict_
     for (int kb = 0; kb < 8; ++kb) {
       f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[wm * (BM / 2) + i * 32 + r][kb * 8 + 4 * h]);
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[wm * WM + i * 32 + r][kb * 8 + 4 * h]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[wn * (BN / 2) + j * 32 + r][kb * 8 + 4 * h]);
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[wn * WN + j * 32 + r][kb * 8 + 4 * h]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -92,13 +94,13 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const float* __restrict_
 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+    const int col = n0 + wn * WN + j * 32 + (lane & 31);
     const float bv = bias ? bias[col] : 0.0f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        int row = m0 + wm * (BM / 2) + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        int row = m0 + wm * WM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         float v = acc[i][j][reg] + bv;
         if (relu) v = fmaxf(v, 0.0f);
         C[(long)row * ldc + col] = v;
@@ -109,28 +111,44 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(const float* __restrict_
 
 namespace mmego_detail {
 
-// returns 0 on launch, -2 if the shape does not fit this kernel (caller falls back), >0 on a HIP error
-int gemm_tile_launch(hipStream_t st, const float* A, const float* W, float* C, const float* bias, int M, int N, int K,
-                     long lda, long ldw, long ldc, int relu) {
-  if ((K % 64) != 0 || (M % 64) != 0 || (N % 64) != 0) return -2;
-  const bool big_ok = (M % 128) == 0 && (N % 128) == 0;
-  const long tiles_big = big_ok ? (long)(M / 128) * (N / 128) : 0;
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_cfg(hipStream_t st, const float* A, const float* W, float* C, const float* bias, int M, int N, int K, long lda,
+                      long ldw, long ldc, int relu) {
   static bool attr_set = false;
-  const size_t lds_big = (size_t)(2 * 128 * TLD) * sizeof(float), lds_small = (size_t)(2 * 64 * TLD) * sizeof(float);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big);
+  const size_t lds = (size_t)((BM + BN) * TLD) * sizeof(float);
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  if (tiles_big >= 192) {          // enough 128x128 tiles to fill 256 CUs
-    hipLaunchKernelGGL((gemm_tile_kernel<128, 128>), dim3((unsigned)tiles_big), dim3(256), lds_big, st, A, W, C, bias, M, N, K, lda,
-                       ldw, ldc, relu);
-  } else {
-    hipLaunchKernelGGL((gemm_tile_kernel<64, 64>), dim3((unsigned)((M / 64) * (N / 64))), dim3(256), lds_small, st, A, W, C, bias, M,
-                       N, K, lda, ldw, ldc, relu);
-  }
+  hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N>), dim3((unsigned)((M / BM) * (N / BN))), dim3(256), lds, st, A, W, C,
+                     bias, M, N, K, lda, ldw, ldc, relu);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+// returns 0 on launch, -2 if the shape does not fit this kernel (caller falls back), >0 on a HIP error.
+// Tile choice: the configuration with the fewest (waves of co-resident workgroups) x (tile area).  A 160x128 tile
+// (1024 tiles = exactly 2 waves of 512 for the 10240 x 2048 LSTM projections, vs 2.5 -> 3 waves of 128x128) was measured
+// 3-4 % SLOWER (1x4 wave layout: 6 operand reads per 5 MFMAs), so it is not in the list.
+int gemm_tile_launch(hipStream_t st, const float* A, const float* W, float* C, const float* bias, int M, int N, int K,
+                     long lda, long ldw, long ldc, int relu) {
+  if ((K % 64) != 0 || (M % 64) != 0 || (N % 64) != 0) return -2;
+  struct Cfg { int bm, bn; };
+  const Cfg cfgs[3] = {{0, 0}, {128, 128}, {64, 64}};
+  long best_cost = -1;
+  int best = -1;
+  for (int i = 0; i < 3; ++i) {
+    if (cfgs[i].bm == 0 || (M % cfgs[i].bm) || (N % cfgs[i].bn)) continue;
+    const long tiles = (long)(M / cfgs[i].bm) * (N / cfgs[i].bn);
+    const long slots = cfgs[i].bm == 64 ? 1024 : 512;
+    long cost = ((tiles + slots - 1) / slots) * cfgs[i].bm * cfgs[i].bn;
+    if (cfgs[i].bm == 64) cost = cost * 5 / 4;             // small tiles re-read operands more: mild penalty
+    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+  }
+  if (best == 1) return launch_cfg<128, 128, 2, 2>(st, A, W, C, bias, M, N, K, lda, ldw, ldc, relu);
+  return launch_cfg<64, 64, 2, 2>(st, A, W, C, bias, M, N, K, lda, ldw, ldc, relu);
 }
 
 }  // namespace mmego_detail

@@ -210,3 +210,33 @@ def test_fused_stage_step_equals_autograd_path(dev):
             assert torch.allclose(b.flat().flat_g, ga, rtol=0, atol=1e-5 * scale), (stage, use_graph, (b.flat().flat_g - ga).abs().max().item(), scale)
             if not use_graph:      # (the graph path runs one warm-up body before capture; parameters see one Adam step either way)
                 assert torch.allclose(b.flat().flat_p, a.flat().flat_p, rtol=0, atol=1e-7), stage
+
+
+def test_large_batch_stress_forward_property(dev):
+    """BASELINE config 5 shape (B=2048, T=16, N=256; fp32 here): Upper_Net + Lower_Net eval forward on 8.4 M points.
+    Size-independent property: in eval mode every sequence is independent, so the first 4 sequences of the big
+    batch must equal the same 4 sequences run alone (bit for bit), and all outputs must be finite."""
+    from mmego_amd import nets
+    torch.manual_seed(5)
+    up, lo = nets.UpperNet().to(dev).eval(), nets.LowerNet(64).to(dev).eval()
+    B, Tn, N = 2048, 16, 256
+    g = torch.Generator(device="cpu").manual_seed(6)
+    x = torch.randn(B, Tn, N, 6, generator=g)
+    x[torch.rand(B, Tn, N, generator=g) < 0.4] = 0.0
+    body = 0.2 * torch.randn(1, 20, 3, generator=g).repeat(B, 1, 1)       # identical bodies (Q2 pairs frame n with body n % B)
+    ang = torch.rand(B, Tn, generator=g)
+    R = torch.zeros(B, Tn, 3, 3)
+    R[..., 0, 0], R[..., 0, 1], R[..., 1, 0], R[..., 1, 1], R[..., 2, 2] = ang.cos(), -ang.sin(), ang.sin(), ang.cos(), 1.0
+    t = 0.1 * torch.randn(B, Tn, 3, generator=g)
+    with torch.no_grad():
+        xd = x.to(dev)
+        h0 = torch.zeros(6, B, 64, device=dev)
+        lu = up(xd, h0, h0.clone(), body.to(dev), R.to(dev), t.to(dev))[0]
+        ll = lo(lu.clone(), xd, None, None, None, None, body.to(dev), R.to(dev), t.to(dev))[0]
+        assert torch.isfinite(lu).all() and torch.isfinite(ll).all()
+        xs = x[:4].clone().to(dev)
+        h0s = torch.zeros(6, 4, 64, device=dev)
+        lus = up(xs, h0s, h0s.clone(), body[:4].to(dev), R[:4].to(dev), t[:4].to(dev))[0]
+        lls = lo(lus.clone(), xs, None, None, None, None, body[:4].to(dev), R[:4].to(dev), t[:4].to(dev))[0]
+    assert torch.equal(xd[:4], xs), "in-place transform identical"
+    assert torch.allclose(lu[:4], lus, rtol=0, atol=1e-6) and torch.allclose(ll[:4], lls, rtol=0, atol=1e-6)
