@@ -187,6 +187,10 @@ def main():
         su.step()
         sl.step()
 
+    if world > 1:       # bring the RCCL communicator up outside the timed region even when --warmup 0
+        torch.distributed.all_reduce(torch.zeros(1, device=device))
+        torch.cuda.synchronize()
+
     def sync():
         if world > 1:
             torch.distributed.barrier()
