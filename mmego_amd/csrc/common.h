@@ -41,3 +41,28 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// In-kernel clock stamps: compiled ONLY into the diagnostic probe (scripts/clock_probe.hip defines MMEGO_STAMP); the
+// product library contains no stamp.  Slot s of workgroup b holds {s_memtime, s_memrealtime} taken by one lane.
+#ifdef MMEGO_STAMP
+#define MMEGO_STAMP_SLOTS 4
+__device__ unsigned long long mmego_stamp_buf[8192 * MMEGO_STAMP_SLOTS * 2];
+__device__ unsigned int mmego_stamp_hw[8192 * 2];   // {HW_ID, XCC_ID} of the stamping wave (where the workgroup ran)
+#define MMEGO_STAMP_AT(id, slot, cond)                                                                 \
+  do {                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    if (cond) {                                                                                      \
+      unsigned long long t_ = __builtin_amdgcn_s_memtime(), r_ = __builtin_amdgcn_s_memrealtime();   \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                                            \
+      mmego_stamp_buf[(((id) & 8191) * MMEGO_STAMP_SLOTS + (slot)) * 2] = t_;                  \
+      mmego_stamp_buf[(((id) & 8191) * MMEGO_STAMP_SLOTS + (slot)) * 2 + 1] = r_;              \
+      if ((slot) == 0) {                                                                             \
+        mmego_stamp_hw[((id) & 8191) * 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);         \
+        mmego_stamp_hw[((id) & 8191) * 2 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    \
+      }                                                                                              \
+    }                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  } while (0)
+#else
+#define MMEGO_STAMP_AT(id, slot, cond) do { } while (0)
+#endif

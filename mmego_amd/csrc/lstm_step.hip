@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
     *reinterpret_cast<f32x4*>(&Bs[buf][lr + 96][lk]) = rb6;                    \
     *reinterpret_cast<f32x4*>(&Bs[buf][lr + 112][lk]) = rb7;                   \
   } while (0)
+  MMEGO_STAMP_AT(blockIdx.x, 0, tid == 0);
   if (!first) {
     ok0 = (r0 + lr) < p.Bn; ok1 = (r0 + lr + 16) < p.Bn; ok2 = (r0 + lr + 32) < p.Bn; ok3 = (r0 + lr + 48) < p.Bn;
     ap = p.hprev[d] + (long)(r0 + lr) * p.hps + lk;
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
   }
   __syncthreads();   // XP (aliasing operand buffer 1) has been consumed by every wave
 
+  MMEGO_STAMP_AT(blockIdx.x, 1, tid == 0);
   if (!first) {
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
       __syncthreads();
     }
   }
+  MMEGO_STAMP_AT(blockIdx.x, 2, tid == 0);
 
   // fused cell update in registers, results staged in LDS for full-line stores (HP aliases operand buffer 1: idle now)
 #pragma unroll
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
     }
   }
   __syncthreads();
+  MMEGO_STAMP_AT(blockIdx.x, 3, tid == 0);
   {
     const int xr = tid >> 2, xq = (tid & 3) * 8;
     if ((r0 + xr) < p.Bn) {
@@ -225,6 +229,218 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
 }
 
 #define STEP_LDS_BYTES ((2 * 64 * SLD + 2 * 128 * SLD + 64 * CLD) * sizeof(float))
+
+// ---- warp-specialised variant: 4 compute waves (MFMA + cell update) + 4 loader waves (global -> LDS staging) -----------
+// Same tile as lstm_step_kernel.  The loader waves stream the xproj / c tiles and keep two operand chunks in flight
+// (registers) ahead of the LDS double buffer, so the compute waves' instruction stream is only ds_read_b128 + MFMA
+// between barriers: on each SIMD one compute wave owns the matrix pipe while its loader partner issues VMEM / ds_write.
+#define WS_LDS_FLOATS (2 * 64 * SLD + 2 * 128 * SLD + 64 * CLD + 64 * XLD)
+__global__ __launch_bounds__(512) void lstm_step_ws_kernel(LstmStepP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float (*As)[64][SLD] = reinterpret_cast<float (*)[64][SLD]>(smem);
+  float (*Bs)[128][SLD] = reinterpret_cast<float (*)[128][SLD]>(smem + 2 * 64 * SLD);
+  float (*CP)[CLD] = reinterpret_cast<float (*)[CLD]>(smem + 2 * 64 * SLD + 2 * 128 * SLD);
+  float (*XP)[XLD] = reinterpret_cast<float (*)[XLD]>(smem + 2 * 64 * SLD + 2 * 128 * SLD + 64 * CLD);
+  float (*HP)[CLD] = reinterpret_cast<float (*)[CLD]>(&XP[0][0]);     // h tile reuses the xproj tile after the seed
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loader = wave >= 4;
+  const int H = p.H;
+  const int nrb = (p.Bn + 63) / 64, nht = H / 32, npairs = p.ndir * nht;
+  int pair, rb;
+  {
+    const int wg = blockIdx.x;
+    if ((npairs & 7) == 0) {
+      const int xcd = wg & 7, q = wg >> 3;
+      pair = xcd + 8 * (q / nrb);
+      rb = q % nrb;
+    } else {
+      pair = wg / nrb;
+      rb = wg % nrb;
+    }
+  }
+  const int d = pair / nht, ht = pair % nht;
+  const int j0 = ht * 32, r0 = rb * 64;
+  const bool first = p.first != 0;
+  const int nk = H / KC;
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  MMEGO_STAMP_AT(blockIdx.x, 0, tid == 0);
+
+  if (loader) {
+    const int lt = tid - 256;
+    const int lk = (lt & 15) * 4, lr = lt >> 4;
+    // xproj / c tiles (full 128-B row segments)
+    {
+      const int xr = lt >> 2, xq = (lt & 3) * 8;
+      const bool ok = (r0 + xr) < p.Bn;
+      const float* xrow = p.xproj[d] + (long)(r0 + xr) * p.xs + j0 + xq;
+      f32x4 xv[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        xv[2 * g] = ok ? *reinterpret_cast<const f32x4*>(xrow + g * H) : zero4;
+        xv[2 * g + 1] = ok ? *reinterpret_cast<const f32x4*>(xrow + g * H + 4) : zero4;
+      }
+      f32x4 cv0 = zero4, cv1 = zero4;
+      if (ok && !first) {
+        const float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
+        cv0 = *reinterpret_cast<const f32x4*>(crow);
+        cv1 = *reinterpret_cast<const f32x4*>(crow + 4);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<f32x4*>(&XP[xr][g * 32 + xq]) = xv[2 * g];
+        *reinterpret_cast<f32x4*>(&XP[xr][g * 32 + xq + 4]) = xv[2 * g + 1];
+      }
+      *reinterpret_cast<f32x4*>(&CP[xr][xq]) = cv0;
+      *reinterpret_cast<f32x4*>(&CP[xr][xq + 4]) = cv1;
+    }
+    if (!first) {
+      const bool ok0 = (r0 + lr) < p.Bn, ok1 = (r0 + lr + 16) < p.Bn, ok2 = (r0 + lr + 32) < p.Bn, ok3 = (r0 + lr + 48) < p.Bn;
+      const float* ap = p.hprev[d] + (long)(r0 + lr) * p.hps + lk;
+      const long rs16 = 16 * p.hps;
+      const float* wp = p.whh[d] + ((long)j0 + lr) * H + lk;
+      f32x4 a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7;       // chunk being written
+      f32x4 c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7;       // chunk in flight
+#define WS_LOAD(A0, A1, A2, A3, B0, B1, B2, B3, B4, B5, B6, B7, k0)             \
+  do {                                                                          \
+    A0 = ok0 ? *reinterpret_cast<const f32x4*>(ap + (k0)) : zero4;              \
+    A1 = ok1 ? *reinterpret_cast<const f32x4*>(ap + rs16 + (k0)) : zero4;       \
+    A2 = ok2 ? *reinterpret_cast<const f32x4*>(ap + 2 * rs16 + (k0)) : zero4;   \
+    A3 = ok3 ? *reinterpret_cast<const f32x4*>(ap + 3 * rs16 + (k0)) : zero4;   \
+    B0 = *reinterpret_cast<const f32x4*>(wp + (k0));                            \
+    B1 = *reinterpret_cast<const f32x4*>(wp + 16 * H + (k0));                   \
+    B2 = *reinterpret_cast<const f32x4*>(wp + (long)H * H + (k0));              \
+    B3 = *reinterpret_cast<const f32x4*>(wp + (long)H * H + 16 * H + (k0));     \
+    B4 = *reinterpret_cast<const f32x4*>(wp + 2L * H * H + (k0));               \
+    B5 = *reinterpret_cast<const f32x4*>(wp + 2L * H * H + 16 * H + (k0));      \
+    B6 = *reinterpret_cast<const f32x4*>(wp + 3L * H * H + (k0));               \
+    B7 = *reinterpret_cast<const f32x4*>(wp + 3L * H * H + 16 * H + (k0));      \
+  } while (0)
+#define WS_STORE(buf, A0, A1, A2, A3, B0, B1, B2, B3, B4, B5, B6, B7)           \
+  do {                                                                          \
+    *reinterpret_cast<f32x4*>(&As[buf][lr][lk]) = A0;                           \
+    *reinterpret_cast<f32x4*>(&As[buf][lr + 16][lk]) = A1;                      \
+    *reinterpret_cast<f32x4*>(&As[buf][lr + 32][lk]) = A2;                      \
+    *reinterpret_cast<f32x4*>(&As[buf][lr + 48][lk]) = A3;                      \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr][lk]) = B0;                           \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 16][lk]) = B1;                      \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 32][lk]) = B2;                      \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 48][lk]) = B3;                      \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 64][lk]) = B4;                      \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 80][lk]) = B5;                      \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 96][lk]) = B6;                      \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lr + 112][lk]) = B7;                     \
+  } while (0)
+      WS_LOAD(a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7, 0);
+      if (nk > 1) WS_LOAD(c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7, KC);
+      WS_STORE(0, a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7);
+      __syncthreads();                                   // (1) chunk 0 + xproj + c tiles are in LDS
+      // iteration kt: compute waves consume buffer kt&1; we write chunk kt+1 into the other buffer and fetch chunk kt+2
+      for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 1 < nk) {
+          if (kt + 2 < nk) WS_LOAD(a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7, (kt + 2) * KC);
+          WS_STORE(1, c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+          if (kt + 2 < nk) {
+            if (kt + 3 < nk) WS_LOAD(c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7, (kt + 3) * KC);
+            WS_STORE(0, a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7);
+          }
+          __syncthreads();
+        }
+      }
+    } else {
+      __syncthreads();                                   // (1)
+    }
+    __syncthreads();                                     // (E) cell update done: CP / HP hold the new c / h tiles
+    {
+      const int xr = lt >> 2, xq = (lt & 3) * 8;
+      if ((r0 + xr) < p.Bn) {
+        float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
+        *reinterpret_cast<f32x4*>(crow) = *reinterpret_cast<const f32x4*>(&CP[xr][xq]);
+        *reinterpret_cast<f32x4*>(crow + 4) = *reinterpret_cast<const f32x4*>(&CP[xr][xq + 4]);
+        float* hrow = p.hout[d] + (long)(r0 + xr) * p.hos + j0 + xq;
+        *reinterpret_cast<f32x4*>(hrow) = *reinterpret_cast<const f32x4*>(&HP[xr][xq]);
+        *reinterpret_cast<f32x4*>(hrow + 4) = *reinterpret_cast<const f32x4*>(&HP[xr][xq + 4]);
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------- compute waves ----------------------------------------------
+  const int rowbase = (wave & 1) * 32, hb = (wave >> 1) * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[2][4];
+  float bh[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bh[g] = p.bhh[d] ? p.bhh[d][g * H + j0 + hb + fr] : 0.f;
+  __syncthreads();                                       // (1)
+  float cprev[2][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) acc[i][g][reg] = XP[rowbase + i * 16 + fq * 4 + reg][g * 32 + hb + fr] + bh[g];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) cprev[i][reg] = CP[rowbase + i * 16 + fq * 4 + reg][hb + fr];
+  MMEGO_STAMP_AT(blockIdx.x, 1, tid == 0);
+  if (!first) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+#pragma unroll
+      for (int kb = 0; kb < KC / 16; ++kb) {
+        f32x4 a[2], b[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][rowbase + i * 16 + fr][kb * 16 + 4 * fq]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(&Bs[buf][g * 32 + hb + fr][kb * 16 + 4 * fq]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[g].x, acc[i][g], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[g].y, acc[i][g], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[g].z, acc[i][g], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[g].w, acc[i][g], 0, 0, 0);
+      }
+      if (kt + 1 < nk) __syncthreads();                  // chunk kt+1 is in the other buffer; buffer kt&1 may be refilled
+    }
+  }
+  MMEGO_STAMP_AT(blockIdx.x, 2, tid == 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int lrow = rowbase + i * 16 + fq * 4 + reg;
+      float gi = fast_sigmoid(acc[i][0][reg]);
+      float gf = fast_sigmoid(acc[i][1][reg]);
+      float gg = fast_tanh(acc[i][2][reg]);
+      float go = fast_sigmoid(acc[i][3][reg]);
+      float cn = gf * cprev[i][reg] + gi * gg;
+      CP[lrow][hb + fr] = cn;
+      HP[lrow][hb + fr] = go * fast_tanh(cn);
+      if (p.gst[d] && (r0 + lrow) < p.Bn) {
+        float* gs = p.gst[d] + (long)(r0 + lrow) * 4 * H + j0 + hb + fr;
+        gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;
+        p.cst[d][(long)(r0 + lrow) * H + j0 + hb + fr] = cn;
+      }
+    }
+  }
+  __syncthreads();                                       // (E)
+  MMEGO_STAMP_AT(blockIdx.x, 3, tid == 0);
+}
+
 
 // ---- small-batch variant: WG = 64 rows x (4 hidden x 4 gates), K split over nothing, 4 waves = 4 row tiles ----------
 template <int SK>  // k per staged chunk (64, or 32 when H is not a multiple of 64)
@@ -351,7 +567,18 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
   p.gst[0] = gst0; p.gst[1] = gst1; p.cst[0] = cst0; p.cst[1] = cst1;
   MMEGO_REQUIRE((gst0 == nullptr) == (cst0 == nullptr) && (gst1 == nullptr) == (cst1 == nullptr));
   p.Bn = Bn; p.H = H; p.ndir = ndir; p.first = first;
-  if (Bn >= 128 && (H % KC) == 0) {
+  static const int ws_mode = getenv("MMEGO_STEP_WS") ? atoi(getenv("MMEGO_STEP_WS")) : 1;
+  if (Bn >= 128 && (H % KC) == 0 && ws_mode) {
+    static bool ws_attr = false;
+    const size_t lds = (size_t)WS_LDS_FLOATS * sizeof(float);
+    if (!ws_attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)lstm_step_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      ws_attr = true;
+    }
+    int grid = ndir * (H / 32) * cdiv(Bn, 64);
+    hipLaunchKernelGGL(lstm_step_ws_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+  } else if (Bn >= 128 && (H % KC) == 0) {
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute((const void*)lstm_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEP_LDS_BYTES);

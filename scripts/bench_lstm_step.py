@@ -24,7 +24,7 @@ def launch(mode, s=1):
     t0, t1 = s, T - 1 - s
     hip.call("lstm_step", 2, Bn, H, mode, out.data_ptr() + 4 * ((t0 - 1) * 2 * H), out.data_ptr() + 4 * ((t1 + 1) * 2 * H + H), os_,
              w[0], w[1], b[0], b[1], xp.data_ptr() + 4 * (t0 * 8 * H), xp.data_ptr() + 4 * (t1 * 8 * H + 4 * H), xs,
-             out.data_ptr() + 4 * (t0 * 2 * H), out.data_ptr() + 4 * (t1 * 2 * H + H), os_, c[0], c[1])
+             out.data_ptr() + 4 * (t0 * 2 * H), out.data_ptr() + 4 * (t1 * 2 * H + H), os_, c[0], c[1], None, None, None, None)
 
 
 for mode in modes:
