@@ -24,6 +24,7 @@ struct LstmStepP {
   float* gst[2];   // optional stash for backward: post-activation gates [Bn][4H] and new cell state [Bn][H] of this step
   float* cst[2];
   int Bn, H, ndir, first;
+  int packed;      // W_hh is in the chunk-packed layout (see lstm_step_ws_kernel)
 };
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
@@ -234,6 +235,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepP p) {
 // Same tile as lstm_step_kernel.  The loader waves stream the xproj / c tiles and keep two operand chunks in flight
 // (registers) ahead of the LDS double buffer, so the compute waves' instruction stream is only ds_read_b128 + MFMA
 // between barriers: on each SIMD one compute wave owns the matrix pipe while its loader partner issues VMEM / ds_write.
+// The compute waves double-buffer their operand fragments in registers: the ds_reads of k-block kb+1 are issued before
+// the 32 MFMAs of k-block kb, and the chunk barrier sits before the MFMAs of a chunk's LAST k-block (whose fragments
+// are already in registers), so the first reads of the next chunk also land under MFMAs.
+// (in-kernel stamps, scripts/clock_probe.hip: product loop 45.8k cycles in lstm_step_kernel, 42.2k with the wave split,
+//  MFMA-only bound 32.8k)
 #define WS_LDS_FLOATS (2 * 64 * SLD + 2 * 128 * SLD + 64 * CLD + 64 * XLD)
 __global__ __launch_bounds__(512) void lstm_step_ws_kernel(LstmStepP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -260,60 +266,47 @@ __global__ __launch_bounds__(512) void lstm_step_ws_kernel(LstmStepP p) {
   }
   const int d = pair / nht, ht = pair % nht;
   const int j0 = ht * 32, r0 = rb * 64;
+#ifdef MMEGO_STAMP
+  const bool first = (p.first & 1) != 0;      // diagnostic build only: bit 1 = no operand loads in the loop, bit 2 = no
+  const int dbg = p.first >> 1;               // operand ds_writes in the loop
+#else
   const bool first = p.first != 0;
-  const int nk = H / KC;
+  const int dbg = 0;
+#endif
+  const int nk = first ? 0 : H / KC;
   const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
   MMEGO_STAMP_AT(blockIdx.x, 0, tid == 0);
 
   if (loader) {
     const int lt = tid - 256;
     const int lk = (lt & 15) * 4, lr = lt >> 4;
-    // xproj / c tiles (full 128-B row segments)
-    {
-      const int xr = lt >> 2, xq = (lt & 3) * 8;
-      const bool ok = (r0 + xr) < p.Bn;
-      const float* xrow = p.xproj[d] + (long)(r0 + xr) * p.xs + j0 + xq;
-      f32x4 xv[8];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        xv[2 * g] = ok ? *reinterpret_cast<const f32x4*>(xrow + g * H) : zero4;
-        xv[2 * g + 1] = ok ? *reinterpret_cast<const f32x4*>(xrow + g * H + 4) : zero4;
-      }
-      f32x4 cv0 = zero4, cv1 = zero4;
-      if (ok && !first) {
-        const float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
-        cv0 = *reinterpret_cast<const f32x4*>(crow);
-        cv1 = *reinterpret_cast<const f32x4*>(crow + 4);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<f32x4*>(&XP[xr][g * 32 + xq]) = xv[2 * g];
-        *reinterpret_cast<f32x4*>(&XP[xr][g * 32 + xq + 4]) = xv[2 * g + 1];
-      }
-      *reinterpret_cast<f32x4*>(&CP[xr][xq]) = cv0;
-      *reinterpret_cast<f32x4*>(&CP[xr][xq + 4]) = cv1;
-    }
-    if (!first) {
-      const bool ok0 = (r0 + lr) < p.Bn, ok1 = (r0 + lr + 16) < p.Bn, ok2 = (r0 + lr + 32) < p.Bn, ok3 = (r0 + lr + 48) < p.Bn;
-      const float* ap = p.hprev[d] + (long)(r0 + lr) * p.hps + lk;
-      const long rs16 = 16 * p.hps;
-      const float* wp = p.whh[d] + ((long)j0 + lr) * H + lk;
-      f32x4 a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7;       // chunk being written
-      f32x4 c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7;       // chunk in flight
+    const int xr = lt >> 2, xq = (lt & 3) * 8;
+    const bool okx = (r0 + xr) < p.Bn;
+    const bool ok0 = (r0 + lr) < p.Bn, ok1 = (r0 + lr + 16) < p.Bn, ok2 = (r0 + lr + 32) < p.Bn, ok3 = (r0 + lr + 48) < p.Bn;
+    const float* ap = first ? nullptr : p.hprev[d] + (long)(r0 + lr) * p.hps + lk;
+    const long rs16 = 16 * p.hps;
+    // W_hh addressing: row stride wrs, gate stride wgs, chunk stride factor wks (floats per k).  Natural [4H][H] layout:
+    // (H, H*H, 1); chunk-packed layout [dir][hidden tile][chunk][gate*32 + j][64 k]: (64, 32*64, 128) -- every 64-k
+    // chunk of a workgroup's slice is one contiguous 32 KB block.
+    const bool packed = p.packed != 0;
+    const long wrs = packed ? 64 : H, wgs = packed ? 32 * 64 : (long)H * H, wks = packed ? 128 : 1;
+    const float* wp = packed ? p.whh[d] + (long)ht * 128 * H + lr * 64 + lk : p.whh[d] + ((long)j0 + lr) * H + lk;
+    f32x4 a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7;       // chunk being written
+    f32x4 c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7;       // chunk in flight
 #define WS_LOAD(A0, A1, A2, A3, B0, B1, B2, B3, B4, B5, B6, B7, k0)             \
   do {                                                                          \
     A0 = ok0 ? *reinterpret_cast<const f32x4*>(ap + (k0)) : zero4;              \
     A1 = ok1 ? *reinterpret_cast<const f32x4*>(ap + rs16 + (k0)) : zero4;       \
     A2 = ok2 ? *reinterpret_cast<const f32x4*>(ap + 2 * rs16 + (k0)) : zero4;   \
     A3 = ok3 ? *reinterpret_cast<const f32x4*>(ap + 3 * rs16 + (k0)) : zero4;   \
-    B0 = *reinterpret_cast<const f32x4*>(wp + (k0));                            \
-    B1 = *reinterpret_cast<const f32x4*>(wp + 16 * H + (k0));                   \
-    B2 = *reinterpret_cast<const f32x4*>(wp + (long)H * H + (k0));              \
-    B3 = *reinterpret_cast<const f32x4*>(wp + (long)H * H + 16 * H + (k0));     \
-    B4 = *reinterpret_cast<const f32x4*>(wp + 2L * H * H + (k0));               \
-    B5 = *reinterpret_cast<const f32x4*>(wp + 2L * H * H + 16 * H + (k0));      \
-    B6 = *reinterpret_cast<const f32x4*>(wp + 3L * H * H + (k0));               \
-    B7 = *reinterpret_cast<const f32x4*>(wp + 3L * H * H + 16 * H + (k0));      \
+    B0 = *reinterpret_cast<const f32x4*>(wp + (k0) * wks);                      \
+    B1 = *reinterpret_cast<const f32x4*>(wp + 16 * wrs + (k0) * wks);           \
+    B2 = *reinterpret_cast<const f32x4*>(wp + wgs + (k0) * wks);                \
+    B3 = *reinterpret_cast<const f32x4*>(wp + wgs + 16 * wrs + (k0) * wks);     \
+    B4 = *reinterpret_cast<const f32x4*>(wp + 2 * wgs + (k0) * wks);            \
+    B5 = *reinterpret_cast<const f32x4*>(wp + 2 * wgs + 16 * wrs + (k0) * wks); \
+    B6 = *reinterpret_cast<const f32x4*>(wp + 3 * wgs + (k0) * wks);            \
+    B7 = *reinterpret_cast<const f32x4*>(wp + 3 * wgs + 16 * wrs + (k0) * wks); \
   } while (0)
 #define WS_STORE(buf, A0, A1, A2, A3, B0, B1, B2, B3, B4, B5, B6, B7)           \
   do {                                                                          \
@@ -330,38 +323,289 @@ __global__ __launch_bounds__(512) void lstm_step_ws_kernel(LstmStepP p) {
     *reinterpret_cast<f32x4*>(&Bs[buf][lr + 96][lk]) = B6;                      \
     *reinterpret_cast<f32x4*>(&Bs[buf][lr + 112][lk]) = B7;                     \
   } while (0)
+    // every global load of the prologue is issued before the first wait: xproj tile (HBM), c tile, operand chunks 0, 1
+    const float* xrow = p.xproj[d] + (long)(r0 + xr) * p.xs + j0 + xq;
+    f32x4 x0, x1, x2, x3, x4, x5, x6, x7, cv0 = zero4, cv1 = zero4;
+    x0 = okx ? *reinterpret_cast<const f32x4*>(xrow) : zero4;
+    x1 = okx ? *reinterpret_cast<const f32x4*>(xrow + 4) : zero4;
+    x2 = okx ? *reinterpret_cast<const f32x4*>(xrow + H) : zero4;
+    x3 = okx ? *reinterpret_cast<const f32x4*>(xrow + H + 4) : zero4;
+    x4 = okx ? *reinterpret_cast<const f32x4*>(xrow + 2 * H) : zero4;
+    x5 = okx ? *reinterpret_cast<const f32x4*>(xrow + 2 * H + 4) : zero4;
+    x6 = okx ? *reinterpret_cast<const f32x4*>(xrow + 3 * H) : zero4;
+    x7 = okx ? *reinterpret_cast<const f32x4*>(xrow + 3 * H + 4) : zero4;
+    if (nk > 0) {
+      if (okx) {
+        const float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
+        cv0 = *reinterpret_cast<const f32x4*>(crow);
+        cv1 = *reinterpret_cast<const f32x4*>(crow + 4);
+      }
       WS_LOAD(a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7, 0);
       if (nk > 1) WS_LOAD(c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7, KC);
-      WS_STORE(0, a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7);
-      __syncthreads();                                   // (1) chunk 0 + xproj + c tiles are in LDS
-      // iteration kt: compute waves consume buffer kt&1; we write chunk kt+1 into the other buffer and fetch chunk kt+2
-      for (int kt = 0; kt < nk; kt += 2) {
-        if (kt + 1 < nk) {
-          if (kt + 2 < nk) WS_LOAD(a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7, (kt + 2) * KC);
-          WS_STORE(1, c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7);
-        }
+    }
+    *reinterpret_cast<f32x4*>(&XP[xr][xq]) = x0;
+    *reinterpret_cast<f32x4*>(&XP[xr][xq + 4]) = x1;
+    *reinterpret_cast<f32x4*>(&XP[xr][32 + xq]) = x2;
+    *reinterpret_cast<f32x4*>(&XP[xr][32 + xq + 4]) = x3;
+    *reinterpret_cast<f32x4*>(&XP[xr][64 + xq]) = x4;
+    *reinterpret_cast<f32x4*>(&XP[xr][64 + xq + 4]) = x5;
+    *reinterpret_cast<f32x4*>(&XP[xr][96 + xq]) = x6;
+    *reinterpret_cast<f32x4*>(&XP[xr][96 + xq + 4]) = x7;
+    *reinterpret_cast<f32x4*>(&CP[xr][xq]) = cv0;
+    *reinterpret_cast<f32x4*>(&CP[xr][xq + 4]) = cv1;
+    if (nk > 0) WS_STORE(0, a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7);
+    __syncthreads();                                     // (1) chunk 0 + xproj + c tiles are in LDS
+    if (nk < 2) __syncthreads();                         // (S) see the compute waves
+    // barrier kt -> kt+1: the compute waves hold chunk kt's last fragments in registers (buffer kt&1 is free again) and
+    // chunk kt+1 is complete in the other buffer.  Before it we write chunk kt+1 and fetch chunk kt+2.
+    for (int kt = 0; kt + 1 < nk; kt += 2) {
+      if (kt + 2 < nk && !(dbg & 1)) WS_LOAD(a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7, (kt + 2) * KC);
+      if (!(dbg & 2)) WS_STORE(1, c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7);
+      __syncthreads();
+      if (kt + 2 < nk) {
+        if (kt + 3 < nk && !(dbg & 1)) WS_LOAD(c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7, (kt + 3) * KC);
+        if (!(dbg & 2)) WS_STORE(0, a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7);
         __syncthreads();
-        if (kt + 1 < nk) {
-          if (kt + 2 < nk) {
-            if (kt + 3 < nk) WS_LOAD(c0, c1, c2, c3, e0, e1, e2, e3, e4, e5, e6, e7, (kt + 3) * KC);
-            WS_STORE(0, a0, a1, a2, a3, b0, b1, b2, b3, b4, b5, b6, b7);
-          }
-          __syncthreads();
-        }
       }
-    } else {
-      __syncthreads();                                   // (1)
     }
     __syncthreads();                                     // (E) cell update done: CP / HP hold the new c / h tiles
+    if (okx) {
+      float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
+      *reinterpret_cast<f32x4*>(crow) = *reinterpret_cast<const f32x4*>(&CP[xr][xq]);
+      *reinterpret_cast<f32x4*>(crow + 4) = *reinterpret_cast<const f32x4*>(&CP[xr][xq + 4]);
+      float* hrow = p.hout[d] + (long)(r0 + xr) * p.hos + j0 + xq;
+      *reinterpret_cast<f32x4*>(hrow) = *reinterpret_cast<const f32x4*>(&HP[xr][xq]);
+      *reinterpret_cast<f32x4*>(hrow + 4) = *reinterpret_cast<const f32x4*>(&HP[xr][xq + 4]);
+    }
+    return;
+  }
+
+  // ---------------------------------------------- compute waves ----------------------------------------------
+  const int rowbase = (wave & 1) * 32, hb = (wave >> 1) * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc00, acc01, acc02, acc03, acc10, acc11, acc12, acc13;   // acc<row half><gate>
+  float bh[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bh[g] = p.bhh[d] ? p.bhh[d][g * H + j0 + hb + fr] : 0.f;
+  __syncthreads();                                       // (1)
+  float cprev[2][4];
+#define WS_SEED(ACC, i, g)                                                                                   \
+  do {                                                                                                       \
+    ACC[0] = XP[rowbase + (i) * 16 + fq * 4 + 0][(g) * 32 + hb + fr] + bh[g];                                \
+    ACC[1] = XP[rowbase + (i) * 16 + fq * 4 + 1][(g) * 32 + hb + fr] + bh[g];                                \
+    ACC[2] = XP[rowbase + (i) * 16 + fq * 4 + 2][(g) * 32 + hb + fr] + bh[g];                                \
+    ACC[3] = XP[rowbase + (i) * 16 + fq * 4 + 3][(g) * 32 + hb + fr] + bh[g];                                \
+  } while (0)
+  WS_SEED(acc00, 0, 0); WS_SEED(acc01, 0, 1); WS_SEED(acc02, 0, 2); WS_SEED(acc03, 0, 3);
+  WS_SEED(acc10, 1, 0); WS_SEED(acc11, 1, 1); WS_SEED(acc12, 1, 2); WS_SEED(acc13, 1, 3);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) cprev[i][reg] = CP[rowbase + i * 16 + fq * 4 + reg][hb + fr];
+  // The h tile (HP) aliases the xproj tile: nobody may write h before every wave has seeded its accumulators.  With
+  // nk >= 2 a chunk barrier lies in between; otherwise (first step, H = 64) an explicit one is needed.
+  if (nk < 2) __syncthreads();                           // (S)
+  MMEGO_STAMP_AT(blockIdx.x, 1, tid == 0);
+  if (nk > 0) {
+    const float* arow = &As[0][rowbase + fr][4 * fq];
+    const float* brow = &Bs[0][hb + fr][4 * fq];
+    f32x4 pa0, pa1, pb0, pb1, pb2, pb3;                  // fragment set P
+    f32x4 qa0, qa1, qb0, qb1, qb2, qb3;                  // fragment set Q
+#define WS_RD(S, buf, kb)                                                                                    \
+  do {                                                                                                       \
+    S##a0 = *reinterpret_cast<const f32x4*>(arow + (buf) * 64 * SLD + (kb) * 16);                            \
+    S##a1 = *reinterpret_cast<const f32x4*>(arow + (buf) * 64 * SLD + 16 * SLD + (kb) * 16);                 \
+    S##b0 = *reinterpret_cast<const f32x4*>(brow + (buf) * 128 * SLD + (kb) * 16);                           \
+    S##b1 = *reinterpret_cast<const f32x4*>(brow + (buf) * 128 * SLD + 32 * SLD + (kb) * 16);                \
+    S##b2 = *reinterpret_cast<const f32x4*>(brow + (buf) * 128 * SLD + 64 * SLD + (kb) * 16);                \
+    S##b3 = *reinterpret_cast<const f32x4*>(brow + (buf) * 128 * SLD + 96 * SLD + (kb) * 16);                \
+  } while (0)
+#define WS_MM4(S, c)                                                                                         \
+  do {                                                                                                       \
+    acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a0.c, S##b0.c, acc00, 0, 0, 0);                          \
+    acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a0.c, S##b1.c, acc01, 0, 0, 0);                          \
+    acc02 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a0.c, S##b2.c, acc02, 0, 0, 0);                          \
+    acc03 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a0.c, S##b3.c, acc03, 0, 0, 0);                          \
+    acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a1.c, S##b0.c, acc10, 0, 0, 0);                          \
+    acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a1.c, S##b1.c, acc11, 0, 0, 0);                          \
+    acc12 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a1.c, S##b2.c, acc12, 0, 0, 0);                          \
+    acc13 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a1.c, S##b3.c, acc13, 0, 0, 0);                          \
+  } while (0)
+#define WS_MM(S) do { WS_MM4(S, x); WS_MM4(S, y); WS_MM4(S, z); WS_MM4(S, w); } while (0)
+    WS_RD(p, 0, 0);
+    const int last = nk - 1;
+    for (int kt = 0; kt < last; ++kt) {
+      const int buf = kt & 1;
+      WS_RD(q, buf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(p);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_RD(p, buf, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(q);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_RD(q, buf, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(p);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                   // chunk kt+1 is in the other buffer; buffer kt&1 may be refilled
+      WS_RD(p, buf ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {   // last chunk (peeled: its waits must not be merged with the loop's, where six younger reads are in flight)
+      const int buf = last & 1;
+      WS_RD(q, buf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(p);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_RD(p, buf, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(q);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_RD(q, buf, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(p);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(q);
+    }
+  }
+  MMEGO_STAMP_AT(blockIdx.x, 2, tid == 0);
+#define WS_CELL(A0, A1, A2, A3, i)                                                                           \
+  _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                      \
+    const int lrow = rowbase + (i) * 16 + fq * 4 + reg;                                                      \
+    float gi = fast_sigmoid(A0[reg]);                                                                        \
+    float gf = fast_sigmoid(A1[reg]);                                                                        \
+    float gg = fast_tanh(A2[reg]);                                                                           \
+    float go = fast_sigmoid(A3[reg]);                                                                        \
+    float cn = gf * cprev[i][reg] + gi * gg;                                                                 \
+    CP[lrow][hb + fr] = cn;                                                                                  \
+    HP[lrow][hb + fr] = go * fast_tanh(cn);                                                                  \
+    if (p.gst[d] && (r0 + lrow) < p.Bn) {                                                                    \
+      float* gs = p.gst[d] + (long)(r0 + lrow) * 4 * H + j0 + hb + fr;                                       \
+      gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;                                                \
+      p.cst[d][(long)(r0 + lrow) * H + j0 + hb + fr] = cn;                                                   \
+    }                                                                                                        \
+  }
+  WS_CELL(acc00, acc01, acc02, acc03, 0)
+  WS_CELL(acc10, acc11, acc12, acc13, 1)
+  MMEGO_STAMP_AT(blockIdx.x, 3, tid == 0);
+  __syncthreads();                                       // (E)
+}
+
+// ---- LDS-DMA variant: operands go global -> LDS directly (global_load_lds_dwordx4), never through VGPRs -------------
+// Why: with in-kernel stamps (scripts/clock_probe.hip) the register-staged kernels' product loop takes 45k cycles
+// against a 32.8k MFMA bound; removing only the loader waves' global loads gives 35.7k.  The data returning into the
+// loader waves' VGPRs (and leaving again through ds_write) competes with the MFMA waves on the same SIMDs.  LDS-DMA
+// takes the staging off the register file altogether.
+//   * Stage image (3 stages): A = 64 rows x 64 k, W = 128 rows x 64 k, UNPADDED rows of 16 16-B slots.  A DMA
+//     wave-instruction writes 1 KB lane-linearly (4 rows), so padding is impossible; bank conflicts are avoided by an
+//     XOR swizzle applied on BOTH sides: slot s of row r is stored at slot s ^ (r & 15) (the loader permutes its SOURCE
+//     address, the reader its LDS address; the 16 lanes of a ds_read_b128 phase hit 16 distinct slots).
+//   * 4 loader waves issue 12 DMAs each per chunk and wait with counted vmcnt; barriers are raw s_barrier so that a
+//     chunk stays in flight across them.  Chunk kt+3 is issued right after the barrier that retires chunk kt's stage,
+//     i.e. two chunk times of latency tolerance.
+//   * The xproj tile (seed of the accumulators) is DMA'd into stage 2 (free until chunk 2 is issued after barrier B0);
+//     the c tile has its own 8 KB; the new c / h tiles leave through a free stage as full 128-B lines.
+#define DMA_STAGE_FLOATS (192 * 64)
+#define DMA_LDS_FLOATS (3 * DMA_STAGE_FLOATS + 64 * 32)
+#define GLDS16(gptr, lptr)                                                                                  \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+__global__ __launch_bounds__(512) void lstm_step_dma_kernel(LstmStepP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const XP = smem + 2 * DMA_STAGE_FLOATS;          // [64][128] xproj tile, linear (aliases stage 2)
+  float* const CPI = smem + 3 * DMA_STAGE_FLOATS;         // [64][32] c_{t-1} tile, linear
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loader = wave >= 4;
+  const int H = p.H;
+  const int nrb = (p.Bn + 63) / 64, nht = H / 32, npairs = p.ndir * nht;
+  int pair, rb;
+  {
+    const int wg = blockIdx.x;
+    if ((npairs & 7) == 0) {
+      const int xcd = wg & 7, q = wg >> 3;
+      pair = xcd + 8 * (q / nrb);
+      rb = q % nrb;
+    } else {
+      pair = wg / nrb;
+      rb = wg % nrb;
+    }
+  }
+  const int d = pair / nht, ht = pair % nht;
+  const int j0 = ht * 32, r0 = rb * 64;
+  const bool first = p.first != 0;
+  const int nk = first ? 0 : H / KC;
+  float* const OUT = smem + (nk % 3) * DMA_STAGE_FLOATS;  // new c tile [64][CLD], then new h tile [64][CLD]
+  MMEGO_STAMP_AT(blockIdx.x, 0, tid == 0);
+
+  if (loader) {
+    const int lw = wave - 4, q4 = lane >> 4, sl = lane & 15;
+    const int rmax = p.Bn - 1 - r0;                       // rows past the batch read a valid row (their results are dropped)
+    // per-lane source pointers of the 4 A and 8 W DMAs of a chunk (k0 = 0), swizzled slot included
+    const float* ag[4];
+    const float* wg_[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ra = 4 * (lw + 4 * i) + q4;
+      ag[i] = first ? nullptr : p.hprev[d] + (long)(r0 + min(ra, rmax)) * p.hps + 4 * (sl ^ (ra & 15));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int rw = 4 * (lw + 4 * j) + q4;
+      wg_[j] = p.whh[d] + ((long)(rw >> 5) * H + j0 + (rw & 31)) * H + 4 * (sl ^ (rw & 15));
+    }
+#define DMA_CHUNK(kt)                                                                                       \
+  do {                                                                                                      \
+    float* st_ = smem + ((kt) % 3) * DMA_STAGE_FLOATS;                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) GLDS16(ag[i] + (kt) * KC, st_ + 4 * (lw + 4 * i) * 64);   \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) GLDS16(wg_[j] + (kt) * KC, st_ + 4096 + 4 * (lw + 4 * j) * 64); \
+  } while (0)
+    // prologue: xproj tile, c tile, chunks 0 and 1 -- all in flight before the first wait
     {
-      const int xr = lt >> 2, xq = (lt & 3) * 8;
+      const int piece = lane & 31;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ii = lw + 4 * j, xr = 2 * ii + (lane >> 5);
+        GLDS16(p.xproj[d] + (long)(r0 + min(xr, rmax)) * p.xs + (long)(piece >> 3) * H + j0 + (piece & 7) * 4, XP + 2 * ii * 128);
+      }
+    }
+    if (nk > 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ii = lw + 4 * j, cr = 8 * ii + (lane >> 3);
+        GLDS16(p.c[d] + (long)(r0 + min(cr, rmax)) * H + j0 + (lane & 7) * 4, CPI + 8 * ii * 32);
+      }
+      DMA_CHUNK(0);
+      if (nk > 1) {
+        DMA_CHUNK(1);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                         // (1) xproj, c, chunk 0 are in LDS
+    // barrier B_kt (kt = 0 .. nk-2): chunk kt+1 has landed; the compute waves hold chunk kt's last fragments in registers
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      if (kt >= 1 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt == 0 && 2 < nk) DMA_CHUNK(2);               // stage 2 held the xproj tile until every wave had seeded
+      if (kt + 3 < nk) DMA_CHUNK(kt + 3);
+    }
+    __builtin_amdgcn_s_barrier();                         // (E) new c / h tiles are in OUT
+    {
+      const int lt = tid - 256, xr = lt >> 2, xq = (lt & 3) * 8;
       if ((r0 + xr) < p.Bn) {
         float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
-        *reinterpret_cast<f32x4*>(crow) = *reinterpret_cast<const f32x4*>(&CP[xr][xq]);
-        *reinterpret_cast<f32x4*>(crow + 4) = *reinterpret_cast<const f32x4*>(&CP[xr][xq + 4]);
+        *reinterpret_cast<f32x4*>(crow) = *reinterpret_cast<const f32x4*>(OUT + xr * CLD + xq);
+        *reinterpret_cast<f32x4*>(crow + 4) = *reinterpret_cast<const f32x4*>(OUT + xr * CLD + xq + 4);
         float* hrow = p.hout[d] + (long)(r0 + xr) * p.hos + j0 + xq;
-        *reinterpret_cast<f32x4*>(hrow) = *reinterpret_cast<const f32x4*>(&HP[xr][xq]);
-        *reinterpret_cast<f32x4*>(hrow + 4) = *reinterpret_cast<const f32x4*>(&HP[xr][xq + 4]);
+        *reinterpret_cast<f32x4*>(hrow) = *reinterpret_cast<const f32x4*>(OUT + 64 * CLD + xr * CLD + xq);
+        *reinterpret_cast<f32x4*>(hrow + 4) = *reinterpret_cast<const f32x4*>(OUT + 64 * CLD + xr * CLD + xq + 4);
       }
     }
     return;
@@ -370,77 +614,103 @@ __global__ __launch_bounds__(512) void lstm_step_ws_kernel(LstmStepP p) {
   // ---------------------------------------------- compute waves ----------------------------------------------
   const int rowbase = (wave & 1) * 32, hb = (wave >> 1) * 16;
   const int fr = lane & 15, fq = lane >> 4;
-  f32x4 acc[2][4];
+  f32x4 acc00, acc01, acc02, acc03, acc10, acc11, acc12, acc13;   // acc<row half><gate>
   float bh[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) bh[g] = p.bhh[d] ? p.bhh[d][g * H + j0 + hb + fr] : 0.f;
   __syncthreads();                                       // (1)
   float cprev[2][4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) acc[i][g][reg] = XP[rowbase + i * 16 + fq * 4 + reg][g * 32 + hb + fr] + bh[g];
+#define DMA_SEED(ACC, i, g)                                                                                 \
+  do {                                                                                                      \
+    ACC[0] = XP[(rowbase + (i) * 16 + fq * 4 + 0) * 128 + (g) * 32 + hb + fr] + bh[g];                      \
+    ACC[1] = XP[(rowbase + (i) * 16 + fq * 4 + 1) * 128 + (g) * 32 + hb + fr] + bh[g];                      \
+    ACC[2] = XP[(rowbase + (i) * 16 + fq * 4 + 2) * 128 + (g) * 32 + hb + fr] + bh[g];                      \
+    ACC[3] = XP[(rowbase + (i) * 16 + fq * 4 + 3) * 128 + (g) * 32 + hb + fr] + bh[g];                      \
+  } while (0)
+  DMA_SEED(acc00, 0, 0); DMA_SEED(acc01, 0, 1); DMA_SEED(acc02, 0, 2); DMA_SEED(acc03, 0, 3);
+  DMA_SEED(acc10, 1, 0); DMA_SEED(acc11, 1, 1); DMA_SEED(acc12, 1, 2); DMA_SEED(acc13, 1, 3);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) cprev[i][reg] = CP[rowbase + i * 16 + fq * 4 + reg][hb + fr];
+    for (int reg = 0; reg < 4; ++reg) cprev[i][reg] = nk > 0 ? CPI[(rowbase + i * 16 + fq * 4 + reg) * 32 + hb + fr] : 0.f;
   MMEGO_STAMP_AT(blockIdx.x, 1, tid == 0);
-  if (!first) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-#pragma unroll
-      for (int kb = 0; kb < KC / 16; ++kb) {
-        f32x4 a[2], b[4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf][rowbase + i * 16 + fr][kb * 16 + 4 * fq]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(&Bs[buf][g * 32 + hb + fr][kb * 16 + 4 * fq]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[g].x, acc[i][g], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[g].y, acc[i][g], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[g].z, acc[i][g], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[g].w, acc[i][g], 0, 0, 0);
-      }
-      if (kt + 1 < nk) __syncthreads();                  // chunk kt+1 is in the other buffer; buffer kt&1 may be refilled
+  if (nk > 0) {
+    // fragment addresses: row * 64 floats + swizzled slot; sw<kb> = ((4 kb + fq) ^ fr) * 4 floats
+    const int sw0 = ((0 | fq) ^ fr) << 2, sw1 = ((4 | fq) ^ fr) << 2, sw2 = ((8 | fq) ^ fr) << 2, sw3 = ((12 | fq) ^ fr) << 2;
+    const float* arow = smem + (rowbase + fr) * 64;
+    const float* brow = smem + 4096 + (hb + fr) * 64;
+    f32x4 pa0, pa1, pb0, pb1, pb2, pb3;                  // fragment set P
+    f32x4 qa0, qa1, qb0, qb1, qb2, qb3;                  // fragment set Q
+#define DMA_RD(S, so, sw)                                                                                   \
+  do {                                                                                                      \
+    S##a0 = *reinterpret_cast<const f32x4*>(arow + (so) + (sw));                                            \
+    S##a1 = *reinterpret_cast<const f32x4*>(arow + (so) + 16 * 64 + (sw));                                  \
+    S##b0 = *reinterpret_cast<const f32x4*>(brow + (so) + (sw));                                            \
+    S##b1 = *reinterpret_cast<const f32x4*>(brow + (so) + 32 * 64 + (sw));                                  \
+    S##b2 = *reinterpret_cast<const f32x4*>(brow + (so) + 64 * 64 + (sw));                                  \
+    S##b3 = *reinterpret_cast<const f32x4*>(brow + (so) + 96 * 64 + (sw));                                  \
+  } while (0)
+    int so = 0;                                          // float offset of the stage being read
+    DMA_RD(p, so, sw0);
+    const int last = nk - 1;
+    for (int kt = 0; kt < last; ++kt) {
+      DMA_RD(q, so, sw1);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(p);
+      __builtin_amdgcn_sched_barrier(0);
+      DMA_RD(p, so, sw2);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(q);
+      __builtin_amdgcn_sched_barrier(0);
+      DMA_RD(q, so, sw3);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(p);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                   // B_kt: chunk kt+1 has landed; this stage may be refilled
+      so = (so == 2 * DMA_STAGE_FLOATS) ? 0 : so + DMA_STAGE_FLOATS;
+      DMA_RD(p, so, sw0);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {   // last chunk (peeled: its waits must not be merged with the loop's, where six younger reads are in flight)
+      DMA_RD(q, so, sw1);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(p);
+      __builtin_amdgcn_sched_barrier(0);
+      DMA_RD(p, so, sw2);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(q);
+      __builtin_amdgcn_sched_barrier(0);
+      DMA_RD(q, so, sw3);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(p);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(q);
     }
   }
   MMEGO_STAMP_AT(blockIdx.x, 2, tid == 0);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int lrow = rowbase + i * 16 + fq * 4 + reg;
-      float gi = fast_sigmoid(acc[i][0][reg]);
-      float gf = fast_sigmoid(acc[i][1][reg]);
-      float gg = fast_tanh(acc[i][2][reg]);
-      float go = fast_sigmoid(acc[i][3][reg]);
-      float cn = gf * cprev[i][reg] + gi * gg;
-      CP[lrow][hb + fr] = cn;
-      HP[lrow][hb + fr] = go * fast_tanh(cn);
-      if (p.gst[d] && (r0 + lrow) < p.Bn) {
-        float* gs = p.gst[d] + (long)(r0 + lrow) * 4 * H + j0 + hb + fr;
-        gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;
-        p.cst[d][(long)(r0 + lrow) * H + j0 + hb + fr] = cn;
-      }
-    }
+#define DMA_CELL(A0, A1, A2, A3, i)                                                                         \
+  _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                     \
+    const int lrow = rowbase + (i) * 16 + fq * 4 + reg;                                                     \
+    float gi = fast_sigmoid(A0[reg]);                                                                       \
+    float gf = fast_sigmoid(A1[reg]);                                                                       \
+    float gg = fast_tanh(A2[reg]);                                                                          \
+    float go = fast_sigmoid(A3[reg]);                                                                       \
+    float cn = gf * cprev[i][reg] + gi * gg;                                                                \
+    OUT[lrow * CLD + hb + fr] = cn;                                                                         \
+    OUT[64 * CLD + lrow * CLD + hb + fr] = go * fast_tanh(cn);                                              \
+    if (p.gst[d] && (r0 + lrow) < p.Bn) {                                                                   \
+      float* gs = p.gst[d] + (long)(r0 + lrow) * 4 * H + j0 + hb + fr;                                      \
+      gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;                                               \
+      p.cst[d][(long)(r0 + lrow) * H + j0 + hb + fr] = cn;                                                  \
+    }                                                                                                       \
   }
-  __syncthreads();                                       // (E)
+  DMA_CELL(acc00, acc01, acc02, acc03, 0)
+  DMA_CELL(acc10, acc11, acc12, acc13, 1)
   MMEGO_STAMP_AT(blockIdx.x, 3, tid == 0);
+  __syncthreads();                                       // (E)
 }
-
 
 // ---- small-batch variant: WG = 64 rows x (4 hidden x 4 gates), K split over nothing, 4 waves = 4 row tiles ----------
 template <int SK>  // k per staged chunk (64, or 32 when H is not a multiple of 64)
@@ -567,8 +837,22 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
   p.gst[0] = gst0; p.gst[1] = gst1; p.cst[0] = cst0; p.cst[1] = cst1;
   MMEGO_REQUIRE((gst0 == nullptr) == (cst0 == nullptr) && (gst1 == nullptr) == (cst1 == nullptr));
   p.Bn = Bn; p.H = H; p.ndir = ndir; p.first = first;
-  static const int ws_mode = getenv("MMEGO_STEP_WS") ? atoi(getenv("MMEGO_STEP_WS")) : 1;
-  if (Bn >= 128 && (H % KC) == 0 && ws_mode) {
+  p.packed = 0;
+#ifdef MMEGO_STAMP
+  p.packed = getenv("PROBE_PACKED") != nullptr;   // diagnostic build: address W_hh as if chunk-packed (traffic pattern only)
+#endif
+  static const int ws_mode = getenv("MMEGO_STEP_WS") ? atoi(getenv("MMEGO_STEP_WS")) : 2;
+  if (Bn >= 128 && (H % KC) == 0 && ws_mode == 2) {
+    static bool dma_attr = false;
+    const size_t lds = (size_t)DMA_LDS_FLOATS * sizeof(float);
+    if (!dma_attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)lstm_step_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      dma_attr = true;
+    }
+    int grid = ndir * (H / 32) * cdiv(Bn, 64);
+    hipLaunchKernelGGL(lstm_step_dma_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+  } else if (Bn >= 128 && (H % KC) == 0 && ws_mode) {
     static bool ws_attr = false;
     const size_t lds = (size_t)WS_LDS_FLOATS * sizeof(float);
     if (!ws_attr) {

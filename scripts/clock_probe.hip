@@ -64,7 +64,7 @@ static void report(const char* name, int nwg, double ideal_loop_cycles) {
 int main(int argc, char** argv) {
   const double secs = argc > 1 ? atof(argv[1]) : 2.5;
   hipStream_t st = 0;
-  {  // LSTM input projection shape of IMU_Net: 10240 x 2048 x 1024
+  if (!getenv("PROBE_SKIP_GEMM")) {  // LSTM input projection shape of IMU_Net: 10240 x 2048 x 1024
     const int M = 10240, N = 2048, K = 1024;
     float *A = dev_random((size_t)M * K, 1.0f, 1), *W = dev_random((size_t)N * K, 0.05f, 2), *C, *bias = dev_random(N, 0.1f, 3);
     hipMalloc(&C, (size_t)M * N * 4);
@@ -84,18 +84,19 @@ int main(int argc, char** argv) {
   {  // recurrent step of rnn_fast: Bn=512, H=512, both directions; the variant is chosen by MMEGO_STEP_WS (read once)
     const int ws = getenv("MMEGO_STEP_WS") ? atoi(getenv("MMEGO_STEP_WS")) : 1;
     const int Bn = 512, H = 512, T = 20;
+    const int dbg = getenv("PROBE_STEP_DBG") ? atoi(getenv("PROBE_STEP_DBG")) : 0;   // see lstm_step_ws_kernel
     float* out = dev_random((size_t)Bn * T * 2 * H, 0.5f, 4);
     float* xp = dev_random((size_t)Bn * T * 8 * H, 0.5f, 5);
     float *w0 = dev_random((size_t)4 * H * H, 0.04f, 6), *w1 = dev_random((size_t)4 * H * H, 0.04f, 7);
     float *b0 = dev_random(4 * H, 0.04f, 8), *b1 = dev_random(4 * H, 0.04f, 9);
     float* c = dev_random((size_t)2 * Bn * H, 0.5f, 10);
-    const long xs = (long)T * 8 * H, os = (long)T * 2 * H;
+    const long xs = (long)T * 8 * H, os = getenv("PROBE_DENSE_H") ? (long)2 * H : (long)T * 2 * H;   // dense: h rows 4 KB apart
     auto t0 = std::chrono::steady_clock::now();
     long n = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
       for (int i = 0; i < 200; ++i) {
         int s = 1 + (i % (T - 2)), t1 = T - 1 - s;
-        mmego_lstm_step(st, 2, Bn, H, 0, out + (long)(s - 1) * 2 * H, out + (long)(t1 + 1) * 2 * H + H, os, w0, w1, b0, b1,
+        mmego_lstm_step(st, 2, Bn, H, dbg << 1, out + (long)(s - 1) * 2 * H, out + (long)(t1 + 1) * 2 * H + H, os, w0, w1, b0, b1,
                         xp + (long)s * 8 * H, xp + (long)t1 * 8 * H + 4 * H, xs, out + (long)s * 2 * H, out + (long)t1 * 2 * H + H, os,
                         c, c + (long)Bn * H, nullptr, nullptr, nullptr, nullptr);
       }
@@ -103,7 +104,7 @@ int main(int argc, char** argv) {
       n += 200;
     }
     double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("lstm_step Bn=512 ws=%d: %ld launches, %.1f us each (stamped build)\n", ws, n, el / n * 1e6);
+    printf("lstm_step Bn=512 ws=%d dbg=%d: %ld launches, %.1f us each (stamped build)\n", ws, dbg, n, el / n * 1e6);
     report(ws ? "lstm_step_ws_kernel" : "lstm_step_kernel", 2 * (H / 32) * (Bn / 64), 8.0 * 4 * 32 * 32);
     hipFree(out); hipFree(xp); hipFree(w0); hipFree(w1); hipFree(b0); hipFree(b1); hipFree(c);
   }
