@@ -55,8 +55,10 @@ int mmego_copy2d(void* stream, const float* X, long ldx, float* Y, long ldy, lon
 int mmego_bn_backward(void* stream, const float* dY, long lddy, const float* Ymask, long ldm, const float* X, long ldx,
                       const float* mean, const float* invstd, const float* a, long rows, int C, float* partial_ws,
                       float* c12_ws, float* dgamma, float* dbeta, float* dX, long lddx);
-/* out[c] (+)= sum_r X[r,c]: bias gradients.  partial_ws: C*nblk floats. */
-int mmego_colsum(void* stream, const float* X, long ldx, long rows, int C, float* partial_ws, float* out, int accumulate);
+/* out[c] (+)= sum_r X[r,c]: bias gradients; out2 (may be NULL) receives a copy (nn.LSTM's bias_ih / bias_hh share
+ * one gradient).  partial_ws: C*nblk floats. */
+int mmego_colsum(void* stream, const float* X, long ldx, long rows, int C, float* partial_ws, float* out, float* out2,
+                 int accumulate);
 /* G = 0 where H <= 0 (ReLU backward for Linear+ReLU pairs, Upper_Net.py:350-351). */
 int mmego_relu_mask(void* stream, float* G, long ldg, const float* H, long ldh, long rows, int C);
 int mmego_fill(void* stream, float* X, long n, float v);

@@ -154,9 +154,7 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
                 dgd = dg[:, d * 256:(d + 1) * 256]
                 ops.grad_weight(dgd, inp, G(lstm.w("weight_ih", l, d)))
                 ops.grad_weight(dgd, hprev[d], G(lstm.w("weight_hh", l, d)))
-                gb = G(lstm.w("bias_ih", l, d))
-                ops.colsum(dgd, gb)
-                ops.copy2d(gb.view(1, 256), G(lstm.w("bias_hh", l, d)).view(1, 256))
+                ops.colsum(dgd, G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
         ops.on_side(wgrad)
         if l > 0 or need_dx:
             dinp = ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))

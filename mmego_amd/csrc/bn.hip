@@ -226,12 +226,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* out, int accumulate) {
+// out2 (optional) receives a copy of the result (nn.LSTM's bias_ih / bias_hh share one gradient)
+__global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* out, float* out2,
+                                                          int accumulate) {
   const int c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0;
   for (int k = lane; k < nblk; k += 64) s += partial[(long)k * C + c];
   s = wave_sum_d(s);
-  if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
+  if (lane == 0) {
+    const float v = accumulate ? out[c] + (float)s : (float)s;
+    out[c] = v;
+    if (out2) out2[c] = v;
+  }
 }
 
 // G[r,c] = 0 where H[r,c] <= 0
@@ -323,7 +329,7 @@ extern "C" int mmego_bn_backward(void* stream, const float* dY, long lddy, const
 }
 
 extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, int C, float* partial_ws, float* out,
-                            int accumulate) {
+                            float* out2, int accumulate) {
   MMEGO_REQUIRE(X && rows > 0 && C > 0 && partial_ws && out);
   hipStream_t st = (hipStream_t)stream;
   const long RPB = rows_per_block(rows);
@@ -331,7 +337,7 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
   const int TC = col_tile(C);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC);
   MMEGO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, out, out2, accumulate);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -27,14 +27,20 @@ struct GemmP {
   int M, N, K;
   int nsplit, kchunk;
   int relu, accumulate;
+  int avec, bvec;     // operand is k-contiguous with 16-B aligned rows: float4 loads allowed
 };
 
 #define LD64 68
 
-template <bool A_KC, bool B_KC>
+// 64x64xBK tiles, BK = 64 (16 when the K range of a workgroup is shorter than 64).  These products are small
+// (<= 1 GFLOP) and their k-loop is bound by the global-load latency of each step, not by the matrix cores (BK = 16:
+// 0.4-0.5 us per step, 32 steps for K = 512), so the step is made as deep as LDS allows: 4x fewer latency-bound steps,
+// 16 elements per operand per thread in flight, float4 loads where the operand is k-contiguous and 16-B aligned.
+template <bool A_KC, bool B_KC, int BK>
 __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
-  __shared__ float As[16][LD64];
-  __shared__ float Bs[16][LD64];
+  constexpr int EL = BK / 4;                          // elements per thread per operand per step
+  __shared__ float As[BK][LD64];
+  __shared__ float Bs[BK][LD64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int batch = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
@@ -44,45 +50,74 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
   const int kbeg = split * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
 
-  // staging coordinates: 4 elements per thread per operand
-  int am, ak[4], bn, bk[4];
-  if (A_KC) { am = tid >> 2; for (int j = 0; j < 4; ++j) ak[j] = (tid & 3) * 4 + j; }
-  else      { am = tid & 63; for (int j = 0; j < 4; ++j) ak[j] = (tid >> 6) + 4 * j; }
-  if (B_KC) { bn = tid >> 2; for (int j = 0; j < 4; ++j) bk[j] = (tid & 3) * 4 + j; }
-  else      { bn = tid & 63; for (int j = 0; j < 4; ++j) bk[j] = (tid >> 6) + 4 * j; }
+  // staging coordinates.  k-contiguous operand: row tid>>2, k = 4 (tid&3) + 16 g + c (g < EL/4, c < 4): four lanes cover
+  // 64 contiguous bytes; m-contiguous operand: m = tid&63, k = (tid>>6) + 4 j: a wave covers 256 contiguous bytes.
+  const int am = A_KC ? (tid >> 2) : (tid & 63), bn = B_KC ? (tid >> 2) : (tid & 63);
+  const int akb = A_KC ? (tid & 3) * 4 : (tid >> 6), bkb = B_KC ? (tid & 3) * 4 : (tid >> 6);
   const bool am_ok = (m0 + am) < p.M, bn_ok = (n0 + bn) < p.N;
   const float* Arow = A + (long)(m0 + am) * p.sam;
   const float* Bcol = B + (long)(n0 + bn) * p.sbn;
+  const bool avec = A_KC && p.avec, bvec = B_KC && p.bvec;
 
-  float ra[4], rb[4];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int ka = k0 + ak[j], kb = k0 + bk[j];
-      ra[j] = (am_ok && ka < kend) ? Arow[(long)ka * p.sak] : 0.0f;
-      rb[j] = (bn_ok && kb < kend) ? Bcol[(long)kb * p.sbk] : 0.0f;
-    }
-  };
+  float ra[EL], rb[EL];
+#define G64_LOAD(k0)                                                                                          \
+  do {                                                                                                        \
+    if (A_KC) {                                                                                               \
+      _Pragma("unroll") for (int g = 0; g < EL / 4; ++g) {                                                    \
+        const int ka = (k0) + akb + 16 * g;                                                                   \
+        if (avec && am_ok && ka + 3 < kend) {                                                                 \
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Arow + ka);                                         \
+          ra[4 * g] = v.x; ra[4 * g + 1] = v.y; ra[4 * g + 2] = v.z; ra[4 * g + 3] = v.w;                     \
+        } else {                                                                                              \
+          _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                       \
+            ra[4 * g + c] = (am_ok && ka + c < kend) ? Arow[(long)(ka + c) * p.sak] : 0.0f;                   \
+        }                                                                                                     \
+      }                                                                                                       \
+    } else {                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < EL; ++j) {                                                        \
+        const int ka = (k0) + akb + 4 * j;                                                                    \
+        ra[j] = (am_ok && ka < kend) ? Arow[(long)ka * p.sak] : 0.0f;                                         \
+      }                                                                                                       \
+    }                                                                                                         \
+    if (B_KC) {                                                                                               \
+      _Pragma("unroll") for (int g = 0; g < EL / 4; ++g) {                                                    \
+        const int kb = (k0) + bkb + 16 * g;                                                                   \
+        if (bvec && bn_ok && kb + 3 < kend) {                                                                 \
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Bcol + kb);                                         \
+          rb[4 * g] = v.x; rb[4 * g + 1] = v.y; rb[4 * g + 2] = v.z; rb[4 * g + 3] = v.w;                     \
+        } else {                                                                                              \
+          _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                       \
+            rb[4 * g + c] = (bn_ok && kb + c < kend) ? Bcol[(long)(kb + c) * p.sbk] : 0.0f;                   \
+        }                                                                                                     \
+      }                                                                                                       \
+    } else {                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < EL; ++j) {                                                        \
+        const int kb = (k0) + bkb + 4 * j;                                                                    \
+        rb[j] = (bn_ok && kb < kend) ? Bcol[(long)kb * p.sbk] : 0.0f;                                         \
+      }                                                                                                       \
+    }                                                                                                         \
+  } while (0)
 
   f32x16 acc = {0};
-  if (kbeg < kend) gload(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+  if (kbeg < kend) G64_LOAD(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      As[ak[j]][am] = ra[j];
-      Bs[bk[j]][bn] = rb[j];
+    for (int j = 0; j < EL; ++j) {
+      As[A_KC ? akb + 16 * (j >> 2) + (j & 3) : akb + 4 * j][am] = ra[j];
+      Bs[B_KC ? bkb + 16 * (j >> 2) + (j & 3) : bkb + 4 * j][bn] = rb[j];
     }
     __syncthreads();
-    if (k0 + 16 < kend) gload(k0 + 16);
+    if (k0 + BK < kend) G64_LOAD(k0 + BK);
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int kk = 0; kk < 16; kk += 2) {
+    for (int kk = 0; kk < BK; kk += 2) {
       float a = As[kk + h][wm * 32 + r];
       float b = Bs[kk + h][wn * 32 + r];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
   }
+#undef G64_LOAD
 
   // epilogue: lane holds column (lane&31), rows (reg&3)+8*(reg>>2)+4*(lane>>5)
   const int col = n0 + wn * 32 + (lane & 31);
@@ -105,21 +140,37 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
 }
 
 // ws: [nsplit][nbatch][M][N] contiguous partial products -> C (strided), + bias, relu, accumulate.
-// 64 outputs x 4 split-lanes per block; the 4 partial sums are combined in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, float* C, const float* bias, int nsplit,
+// 16 outputs x 16 split-lanes per block: lane group kg sums slabs kg, kg+16, ... (loads unrolled 8 deep: the loop is
+// load-latency bound), then the 16 partial sums are combined through LDS in a fixed order (deterministic).
+#define SKR_OUT 16
+#define SKR_LANES 16
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* C, const float* bias, int nsplit,
                                                             int nbatch, int M, int N, long scm, long scn, long sCb,
                                                             int relu, int accumulate) {
-  __shared__ float sh[4][64];
+  __shared__ float sh[SKR_LANES][SKR_OUT + 1];
   const long total = (long)nbatch * M * N;
-  const int o = threadIdx.x & 63, kg = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + o;
+  const int o = threadIdx.x & (SKR_OUT - 1), kg = threadIdx.x / SKR_OUT;
+  const long i = (long)blockIdx.x * SKR_OUT + o;
   float s = 0.0f;
-  if (i < total)
-    for (int k = kg; k < nsplit; k += 4) s += ws[(long)k * total + i];
+  if (i < total) {
+    const float* src = ws + i;
+    int k = kg;
+#pragma unroll 1
+    for (; k + 7 * SKR_LANES < nsplit; k += 8 * SKR_LANES) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u * SKR_LANES) * total];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nsplit; k += SKR_LANES) s += src[(long)k * total];
+  }
   sh[kg][o] = s;
   __syncthreads();
   if (kg == 0 && i < total) {
-    s = ((sh[0][o] + sh[1][o]) + sh[2][o]) + sh[3][o];
+    s = sh[0][o];
+#pragma unroll
+    for (int g = 1; g < SKR_LANES; ++g) s += sh[g][o];
     int n = (int)(i % N);
     long r = i / N;
     int m = (int)(r % M);
@@ -251,14 +302,23 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   MMEGO_REQUIRE(cdiv(N, 64) <= 65535 && (long)nbatch * nsplit <= 65535);
   dim3 grid(cdiv(M, 64), cdiv(N, 64), nbatch * nsplit);
   const bool akc = (sak == 1), bkc = (sbk == 1);
-  if (akc && bkc) hipLaunchKernelGGL((gemm64_kernel<true, true>), grid, dim3(256), 0, st, p);
-  else if (akc) hipLaunchKernelGGL((gemm64_kernel<true, false>), grid, dim3(256), 0, st, p);
-  else if (bkc) hipLaunchKernelGGL((gemm64_kernel<false, true>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((gemm64_kernel<false, false>), grid, dim3(256), 0, st, p);
+  p.avec = akc && (sam % 4) == 0 && (sAb % 4) == 0 && ((uintptr_t)A & 15) == 0;
+  p.bvec = bkc && (sbn % 4) == 0 && (sBb % 4) == 0 && ((uintptr_t)B & 15) == 0;
+  const bool deep = p.kchunk >= 64;                  // K range per workgroup
+#define G64_LAUNCH(AK, BKC)                                                                        \
+  do {                                                                                             \
+    if (deep) hipLaunchKernelGGL((gemm64_kernel<AK, BKC, 64>), grid, dim3(256), 0, st, p);         \
+    else hipLaunchKernelGGL((gemm64_kernel<AK, BKC, 16>), grid, dim3(256), 0, st, p);              \
+  } while (0)
+  if (akc && bkc) G64_LAUNCH(true, true);
+  else if (akc) G64_LAUNCH(true, false);
+  else if (bkc) G64_LAUNCH(false, true);
+  else G64_LAUNCH(false, false);
+#undef G64_LAUNCH
   MMEGO_LAUNCH_CHECK();
   if (nsplit > 1) {
     long total = (long)nbatch * M * N;
-    int blocks = (int)((total + 63) / 64);
+    int blocks = (int)((total + SKR_OUT - 1) / SKR_OUT);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, C, bias, nsplit, nbatch, M, N,
                        scm, scn, sCb, relu, accumulate);
     MMEGO_LAUNCH_CHECK();

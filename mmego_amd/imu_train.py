@@ -78,9 +78,7 @@ def lstm_steps_backward(ar, key, lstm, x, Bn, T, dout, G, need_dx):
                 ops.copy2d(out[1:, H:], hp[:Bn * T - 1])
                 ops.copy2d(zeros, hp.view(Bn, T * H)[:, (T - 1) * H:])
             ops.grad_weight(dgd, hp, G(lstm.w("weight_hh", l, d)))
-            gb = G(lstm.w("bias_ih", l, d))
-            ops.colsum(dgd, gb)
-            ops.copy2d(gb.view(1, 4 * H), G(lstm.w("bias_hh", l, d)).view(1, 4 * H))
+            ops.colsum(dgd, G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
         if l > 0 or need_dx:
             dinp = ar.get("%s.dx%d" % (key, l), (Bn * T, inp.shape[1]))
             ops.grad_input(dg[:, :4 * H], lstm.w("weight_ih", l, 0), dinp)

@@ -122,10 +122,17 @@ def linear(x, W, b, out, relu=False):
     return mm(x, W.view(W.shape[0], -1).t(), out, bias=b, relu=relu)
 
 
+import os as _os
+_SPLIT_K_MIN = int(_os.environ.get("MMEGO_SPLIT_K_MIN", "128"))
+
+
 def pick_split(M, N, K):
+    """Split-K factor of a weight-gradient product: these have few output tiles and a long K (the batch rows), and a
+    workgroup's k-loop is latency-bound per 64-k step, so K is cut down to one or two steps per workgroup as long as the
+    grid stays within ~2 workgroups per CU."""
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     want = max(1, 512 // tiles)
-    return int(max(1, min(want, K // 256)))
+    return int(max(1, min(want, K // _SPLIT_K_MIN)))
 
 
 def grad_weight(dY, X, dW):
@@ -139,11 +146,12 @@ def grad_input(dY, W, dX, accumulate=False):
     return mm(dY, W.view(W.shape[0], -1), dX, accumulate=accumulate)
 
 
-def colsum(X, out, accumulate=False):
+def colsum(X, out, accumulate=False, out2=None):
+    """out[c] (+)= sum_r X[r, c]; out2 (optional) gets a copy of the result."""
     X = _rows(X)
     rows, C = X.shape
     ws = scratch(X.device, C * hip.colstats_nblk(rows))
-    hip.call("colsum", X, X.stride(0), rows, C, ws, out, int(accumulate))
+    hip.call("colsum", X, X.stride(0), rows, C, ws, out, out2, int(accumulate))
     return out
 
 
