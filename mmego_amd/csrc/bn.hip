@@ -5,11 +5,12 @@
 // Chan's formula in fp64 so that train-mode statistics are at least as accurate as a two-pass CPU BN.
 #include "common.h"
 
-// rows per block of the column-reduction kernels: at most 256 partial blocks, so the one-wave-per-channel
-// finalize kernels combine <= 4 partials per lane
+// rows per block of the column-reduction kernels: about 1024 partial blocks for long tensors (the reductions are
+// streaming kernels: with one 256-thread block per CU they were load-latency bound at ~2 TB/s, a third of what the
+// elementwise kernels reach on the same bytes), never fewer than 16 rows per block.
 static inline long rows_per_block(long rows) {
-  long r = (rows + 255) / 256;
-  if (r < 64) r = 64;
+  long r = (rows + 1023) / 1024;
+  if (r < 16) r = 16;
   return (r + 3) / 4 * 4;
 }
 

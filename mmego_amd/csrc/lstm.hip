@@ -58,20 +58,31 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
   }
   __syncthreads();
 
+  // The input projections do not depend on the recurrence: step s+1's values are fetched while step s computes, so
+  // their latency (the longest thing in a step otherwise) is off the critical path.
+  float xp[4][4], xpn[4][4];
+#define L64_LOAD_XP(DST, step)                                                                      \
+  do {                                                                                              \
+    const int tq_ = d == 0 ? (step) : T - 1 - (step);                                               \
+    _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                           \
+      const int row_ = r0 + fq * 4 + reg;                                                           \
+      if (row_ < B) {                                                                               \
+        const float* x_ = p.xproj[d] + ((long)row_ * T + tq_) * p.xs + j;                           \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) DST[g][reg] = x_[g * 64];                     \
+      } else {                                                                                      \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) DST[g][reg] = 0.f;                            \
+      }                                                                                             \
+    }                                                                                               \
+  } while (0)
+  L64_LOAD_XP(xp, 0);
   for (int s = 0; s < T; ++s) {
     const int tt = d == 0 ? s : T - 1 - s;
-    float xp[4][4];
+    if (s + 1 < T) L64_LOAD_XP(xpn, s + 1);
+    if (p.hprev[d]) {
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      int row = r0 + fq * 4 + reg;
-      if (row < B) {
-        const float* x = p.xproj[d] + ((long)row * T + tt) * p.xs + j;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xp[g][reg] = x[g * 64] + bh[g];
-        if (p.hprev[d]) p.hprev[d][((long)row * T + tt) * 64 + j] = hreg[reg];
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xp[g][reg] = 0.f;
+      for (int reg = 0; reg < 4; ++reg) {
+        int row = r0 + fq * 4 + reg;
+        if (row < B) p.hprev[d][((long)row * T + tt) * 64 + j] = hreg[reg];
       }
     }
     f32x4 acc[4];
@@ -91,10 +102,10 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       int row = r0 + fq * 4 + reg;
-      float gi = sigmoidf_(acc[0][reg] + xp[0][reg]);
-      float gf = sigmoidf_(acc[1][reg] + xp[1][reg]);
-      float gg = tanhf(acc[2][reg] + xp[2][reg]);
-      float go = sigmoidf_(acc[3][reg] + xp[3][reg]);
+      float gi = sigmoidf_(acc[0][reg] + (xp[0][reg] + bh[0]));
+      float gf = sigmoidf_(acc[1][reg] + (xp[1][reg] + bh[1]));
+      float gg = tanhf(acc[2][reg] + (xp[2][reg] + bh[2]));
+      float go = sigmoidf_(acc[3][reg] + (xp[3][reg] + bh[3]));
       float cn = gf * creg[reg] + gi * gg;
       float hn = go * tanhf(cn);
       creg[reg] = cn;
@@ -109,8 +120,13 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
         }
       }
     }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) xp[g][reg] = xpn[g][reg];
     __syncthreads();
   }
+#undef L64_LOAD_XP
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     int row = r0 + fq * 4 + reg;
@@ -180,19 +196,47 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
   f32x4 dhrec = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
+  // Everything a step reads from memory (incoming dh, saved gates, cell states) is independent of the recurrence: the
+  // next step's values are fetched while this step computes.  c_{t-1} of this step is c_t of the next one.
+  float gin[4][6], gnx[4][6];        // per row: dh_in, i, f, g, o, c_prev
+  float ccur[4];
+#define L64_LOAD_BWD(DST, step)                                                                                \
+  do {                                                                                                         \
+    const int tq_ = d == 0 ? (step) : T - 1 - (step);                                                          \
+    const int tp_ = d == 0 ? tq_ - 1 : tq_ + 1;                                                                \
+    _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                      \
+      const int row_ = r0 + fq * 4 + reg;                                                                      \
+      if (row_ < B) {                                                                                          \
+        const float* gs_ = p.gates[d] + ((long)tq_ * B + row_) * 256 + j;                                      \
+        DST[reg][0] = p.dout[((long)row_ * T + tq_) * p.dos + d * 64 + j];                                     \
+        DST[reg][1] = gs_[0]; DST[reg][2] = gs_[64]; DST[reg][3] = gs_[128]; DST[reg][4] = gs_[192];           \
+        DST[reg][5] = ((step) > 0) ? p.cst[d][((long)tp_ * B + row_) * 64 + j] : (p.c0[d] ? p.c0[d][row_ * 64 + j] : 0.f); \
+      } else {                                                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 6; ++q) DST[reg][q] = 0.f;                                       \
+      }                                                                                                        \
+    }                                                                                                          \
+  } while (0)
+  L64_LOAD_BWD(gin, T - 1);
+  {
+    const int tl = d == 0 ? T - 1 : 0;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      int row = r0 + fq * 4 + reg;
+      ccur[reg] = row < B ? p.cst[d][((long)tl * B + row) * 64 + j] : 0.f;
+    }
+  }
   for (int s = T - 1; s >= 0; --s) {
     const int tt = d == 0 ? s : T - 1 - s;
-    const int tprev = d == 0 ? tt - 1 : tt + 1;  // time index whose cell state fed this step
+    if (s > 0) L64_LOAD_BWD(gnx, s - 1);
     float dg4[4][4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       int row = r0 + fq * 4 + reg;
       if (row < B) {
-        float dh = p.dout[((long)row * T + tt) * p.dos + d * 64 + j] + dhrec[reg];
-        const float* gs = p.gates[d] + ((long)tt * B + row) * 256 + j;
-        float gi = gs[0], gf = gs[64], gg = gs[128], go = gs[192];
-        float c = p.cst[d][((long)tt * B + row) * 64 + j];
-        float cprev = (s > 0) ? p.cst[d][((long)tprev * B + row) * 64 + j] : (p.c0[d] ? p.c0[d][row * 64 + j] : 0.f);
+        float dh = gin[reg][0] + dhrec[reg];
+        float gi = gin[reg][1], gf = gin[reg][2], gg = gin[reg][3], go = gin[reg][4];
+        float c = ccur[reg];
+        float cprev = gin[reg][5];
         float tc = tanhf(c);
         float dc = dcreg[reg] + dh * go * (1.f - tc * tc);
         dg4[0][reg] = dc * gg * gi * (1.f - gi);
@@ -209,6 +253,7 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) dgs[(g * 64 + j) * 16 + fq * 4 + reg] = dg4[g][reg];
+      ccur[reg] = gin[reg][5];
     }
     __syncthreads();
     // dh_rec[row][k] = sum_n dgates[row][n] * W_hh[n][k]; this wave owns k in [16*wave, 16*wave+16)
@@ -221,8 +266,13 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
       a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dgs[n * 16 + fr], Wn[n * NLD + wave * 16 + fr], a1, 0, 0, 0);
     }
     dhrec = a0 + a1;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) gin[reg][q] = gnx[reg][q];
     __syncthreads();
   }
+#undef L64_LOAD_BWD
 }
 
 extern "C" int mmego_lstm64_backward(void* stream, int B, int T, const float* dout, long dos, const float* gates0,

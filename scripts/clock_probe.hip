@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
   const double secs = argc > 1 ? atof(argv[1]) : 2.5;
   hipStream_t st = 0;
   if (!getenv("PROBE_SKIP_GEMM")) {  // LSTM input projection shape of IMU_Net: 10240 x 2048 x 1024
-    const int M = 10240, N = 2048, K = 1024;
+    const int M = 10240, N = 2048, K = getenv("PROBE_K") ? atoi(getenv("PROBE_K")) : 1024;
     float *A = dev_random((size_t)M * K, 1.0f, 1), *W = dev_random((size_t)N * K, 0.05f, 2), *C, *bias = dev_random(N, 0.1f, 3);
     hipMalloc(&C, (size_t)M * N * 4);
     auto t0 = std::chrono::steady_clock::now();
@@ -76,9 +76,9 @@ int main(int argc, char** argv) {
       n += 50;
     }
     double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("gemm_tile 10240x2048x1024: %ld launches, %.1f us each (stamped build)\n", n, el / n * 1e6);
+    printf("gemm_tile 10240x2048x%d: %ld launches, %.1f us each (stamped build)\n", K, n, el / n * 1e6);
     // 2 workgroups share a CU: a wave owns its SIMD's matrix pipe half of the time at best -> ideal = 2 x MFMA cycles
-    report("gemm_tile K=1024", getenv("MMEGO_GEMM_NO_PERSIST") ? 1280 : 1536, 2.0 * (K / 64) * 8 * 16 * 64);
+    report("gemm_tile", getenv("MMEGO_GEMM_NO_PERSIST") ? 1280 : 1536, 2.0 * (K / 64) * 8 * 16 * 64);
     hipFree(A); hipFree(W); hipFree(C); hipFree(bias);
   }
   {  // recurrent step of rnn_fast: Bn=512, H=512, both directions; the variant is chosen by MMEGO_STEP_WS (read once)

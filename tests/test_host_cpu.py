@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", lib_path], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (mmego_\w+)", out))
     assert exported == set(protos), exported ^ set(protos)
-    assert lib.mmego_colstats_nblk(ctypes.c_long(1000)) == 16     # pure host helper: safe without a GPU
+    assert lib.mmego_colstats_nblk(ctypes.c_long(1000)) == 63     # pure host helper: safe without a GPU
 
 
 def test_no_torch_types_in_abi():
