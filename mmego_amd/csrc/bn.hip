@@ -60,29 +60,24 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
                                    const float* beta, float* running_mean, float* running_var, float momentum,
                                    float eps, float* mean_out, float* invstd_out, float* a_out, float* b_out) {
   const int c = blockIdx.x, lane = threadIdx.x;
-  double N = 0.0, mean = 0.0, M2 = 0.0;
+  // Exact pooled statistics in two passes over the (<= 1024) block partials, fp64, no division inside the loops:
+  //   N = sum n_b,  mean = sum n_b mean_b / N,  M2 = sum [M2_b + n_b (mean_b - mean)^2]
+  double N = 0.0, S = 0.0;
   for (int k = lane; k < nblk; k += 64) {
     const float* p = partial + ((long)k * C + c) * 3;
-    double nb = p[0], mb = p[1], m2b = p[2];
-    double tot = N + nb;
-    double delta = mb - mean;
-    mean += delta * nb / tot;
-    M2 += m2b + delta * delta * N * nb / tot;
-    N = tot;
+    N += (double)p[0];
+    S += (double)p[0] * (double)p[1];
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {  // butterfly Chan combine: every lane ends with the full statistics
-    double nb = __shfl_xor(N, o, 64), mb = __shfl_xor(mean, o, 64), m2b = __shfl_xor(M2, o, 64);
-    double tot = N + nb;
-    if (tot > 0.0) {
-      double delta = mb - mean;
-      // symmetric form so that both partners compute bit-identical results
-      double mnew = (mean * N + mb * nb) / tot;
-      M2 = M2 + m2b + delta * delta * N * nb / tot;
-      mean = mnew;
-      N = tot;
-    }
+  N = wave_sum_d(N);
+  S = wave_sum_d(S);
+  const double mean = S / N;
+  double M2 = 0.0;
+  for (int k = lane; k < nblk; k += 64) {
+    const float* p = partial + ((long)k * C + c) * 3;
+    const double dm = (double)p[1] - mean;
+    M2 += (double)p[2] + (double)p[0] * dm * dm;
   }
+  M2 = wave_sum_d(M2);
   if (lane != 0) return;
   double var = M2 / N;
   float invstd = (float)(1.0 / sqrt(var + (double)eps));

@@ -10,6 +10,8 @@
 //
 // LDS tiles are k-major ([k][m]) so the MFMA operand read (lane l: row l&31, k l>>5) is one
 // conflict-free ds_read_b32 per operand; the transposed ds_write_b32 is at most 2-way (free).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mmego_detail {
@@ -131,6 +133,92 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
       float v = acc[reg] + bv;
       float* dst = C + (long)row * p.scm + (long)col * p.scn;
       if (p.nsplit == 1) {
+        if (p.relu) v = fmaxf(v, 0.0f);
+        if (p.accumulate) v += *dst;
+      }
+      *dst = v;
+    }
+  }
+}
+
+// ---- K-quartered 32x32 tiles for products with few output tiles ------------------------------------------------------
+// With at most a few hundred 64x64 tiles the chip is mostly idle and a workgroup's run time is its serial chain of k-steps, each
+// bound by a global-load round trip.  Here a workgroup owns a 32x32 output tile (4x more workgroups) and its four waves
+// each take a QUARTER of the K range (4x shorter chain); the four partial tiles are summed through LDS in a fixed order.
+// Operands go straight from global memory into the MFMA operand layout, no LDS staging: in a 32-k chunk lane (r, h) takes
+// k = k0 + 16 h + s at MFMA step s for BOTH operands (any k order is valid as long as A and B agree), which makes a
+// k-contiguous operand four 16-B loads per lane and an m-contiguous operand 16 loads that are contiguous across lanes.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
+  __shared__ float red[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int batch = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const float* A = p.A + (long)batch * p.sAb;
+  const float* B = p.B + (long)batch * p.sBb;
+  const int kbeg0 = split * p.kchunk;
+  const int kend0 = min(p.K, kbeg0 + p.kchunk);
+  const int kq = (((kend0 - kbeg0) + 3) / 4 + 31) / 32 * 32;      // k per wave, a multiple of the 32-k chunk
+  const int kbeg = kbeg0 + wave * kq;
+  const int kend = min(kend0, kbeg + kq);
+  const bool am_ok = (m0 + r) < p.M, bn_ok = (n0 + r) < p.N;
+  const float* Arow = A + (long)(m0 + r) * p.sam;
+  const float* Bcol = B + (long)(n0 + r) * p.sbn;
+  const bool avec = A_KC && p.avec, bvec = B_KC && p.bvec;
+
+  float ra[16], rb[16], na[16], nb[16];
+#define KQ_LOAD(RA, RB, k0)                                                                                   \
+  do {                                                                                                        \
+    const int kl = (k0) + 16 * h;                                                                             \
+    if (A_KC && avec && am_ok && kl + 15 < kend) {                                                            \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                         \
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Arow + kl + 4 * g);                                   \
+        RA[4 * g] = v.x; RA[4 * g + 1] = v.y; RA[4 * g + 2] = v.z; RA[4 * g + 3] = v.w;                       \
+      }                                                                                                       \
+    } else {                                                                                                  \
+      _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_)                                                       \
+        RA[s_] = (am_ok && kl + s_ < kend) ? Arow[(long)(kl + s_) * p.sak] : 0.0f;                            \
+    }                                                                                                         \
+    if (B_KC && bvec && bn_ok && kl + 15 < kend) {                                                            \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                         \
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Bcol + kl + 4 * g);                                   \
+        RB[4 * g] = v.x; RB[4 * g + 1] = v.y; RB[4 * g + 2] = v.z; RB[4 * g + 3] = v.w;                       \
+      }                                                                                                       \
+    } else {                                                                                                  \
+      _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_)                                                       \
+        RB[s_] = (bn_ok && kl + s_ < kend) ? Bcol[(long)(kl + s_) * p.sbk] : 0.0f;                            \
+    }                                                                                                         \
+  } while (0)
+
+  f32x16 acc = {0};
+  if (kbeg < kend) {
+    KQ_LOAD(ra, rb, kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+      const bool more = k0 + 32 < kend;
+      if (more) KQ_LOAD(na, nb, k0 + 32);
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s_], rb[s_], acc, 0, 0, 0);
+      if (more) {
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) { ra[s_] = na[s_]; rb[s_] = nb[s_]; }
+      }
+    }
+  }
+#undef KQ_LOAD
+  // partial tiles -> LDS; C layout of the 32x32 MFMA: lane holds column (lane&31), rows (reg&3) + 8 (reg>>2) + 4 (lane>>5)
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) red[wave][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] = acc[reg];
+  __syncthreads();
+  float* C = p.C + (long)batch * p.sCb + (long)split * p.sCs;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + 256 * e, row = idx >> 5, col = idx & 31;
+    if (m0 + row < p.M && n0 + col < p.N) {
+      float v = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+      float* dst = C + (long)(m0 + row) * p.scm + (long)(n0 + col) * p.scn;
+      if (p.nsplit == 1) {
+        if (p.bias) v += p.bias[n0 + col];
         if (p.relu) v = fmaxf(v, 0.0f);
         if (p.accumulate) v += *dst;
       }
@@ -299,15 +387,19 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
     p.kchunk = cdiv(K, 16) * 16;
     p.C = C; p.scm = scm; p.scn = scn; p.sCb = sCb; p.sCs = 0;
   }
-  MMEGO_REQUIRE(cdiv(N, 64) <= 65535 && (long)nbatch * nsplit <= 65535);
-  dim3 grid(cdiv(M, 64), cdiv(N, 64), nbatch * nsplit);
+  MMEGO_REQUIRE(cdiv(N, 32) <= 65535 && (long)nbatch * nsplit <= 65535);
+  const long wgs64 = (long)cdiv(M, 64) * cdiv(N, 64) * nbatch * nsplit;
+  static const int kq_max = getenv("MMEGO_GEMM_KQ_MAX") ? atoi(getenv("MMEGO_GEMM_KQ_MAX")) : 512;
+  const bool kq = wgs64 <= kq_max && p.kchunk >= 64;     // few tiles and a k-chain worth cutting: K-quartered 32x32 tiles
+  dim3 grid(cdiv(M, kq ? 32 : 64), cdiv(N, kq ? 32 : 64), nbatch * nsplit);
   const bool akc = (sak == 1), bkc = (sbk == 1);
   p.avec = akc && (sam % 4) == 0 && (sAb % 4) == 0 && ((uintptr_t)A & 15) == 0;
   p.bvec = bkc && (sbn % 4) == 0 && (sBb % 4) == 0 && ((uintptr_t)B & 15) == 0;
   const bool deep = p.kchunk >= 64;                  // K range per workgroup
 #define G64_LAUNCH(AK, BKC)                                                                        \
   do {                                                                                             \
-    if (deep) hipLaunchKernelGGL((gemm64_kernel<AK, BKC, 64>), grid, dim3(256), 0, st, p);         \
+    if (kq) hipLaunchKernelGGL((gemm32kq_kernel<AK, BKC>), grid, dim3(256), 0, st, p);             \
+    else if (deep) hipLaunchKernelGGL((gemm64_kernel<AK, BKC, 64>), grid, dim3(256), 0, st, p);    \
     else hipLaunchKernelGGL((gemm64_kernel<AK, BKC, 16>), grid, dim3(256), 0, st, p);              \
   } while (0)
   if (akc && bkc) G64_LAUNCH(true, true);
