@@ -60,22 +60,33 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
                                    const float* beta, float* running_mean, float* running_var, float momentum,
                                    float eps, float* mean_out, float* invstd_out, float* a_out, float* b_out) {
   const int c = blockIdx.x, lane = threadIdx.x;
-  // Exact pooled statistics in two passes over the (<= 1024) block partials, fp64, no division inside the loops:
+  // Exact pooled statistics of the (<= 1024) block partials, fp64, no division inside the loops:
   //   N = sum n_b,  mean = sum n_b mean_b / N,  M2 = sum [M2_b + n_b (mean_b - mean)^2]
+  // All of a lane's partials (<= 16) are fetched in ONE round of loads; the kernel is pure load latency otherwise.
+  float pn[16], pm[16], p2[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int k = lane + 64 * u;
+    const bool ok = k < nblk;
+    const float* p = partial + ((long)(ok ? k : 0) * C + c) * 3;
+    pn[u] = ok ? p[0] : 0.f;
+    pm[u] = ok ? p[1] : 0.f;
+    p2[u] = ok ? p[2] : 0.f;
+  }
   double N = 0.0, S = 0.0;
-  for (int k = lane; k < nblk; k += 64) {
-    const float* p = partial + ((long)k * C + c) * 3;
-    N += (double)p[0];
-    S += (double)p[0] * (double)p[1];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    N += (double)pn[u];
+    S += (double)pn[u] * (double)pm[u];
   }
   N = wave_sum_d(N);
   S = wave_sum_d(S);
   const double mean = S / N;
   double M2 = 0.0;
-  for (int k = lane; k < nblk; k += 64) {
-    const float* p = partial + ((long)k * C + c) * 3;
-    const double dm = (double)p[1] - mean;
-    M2 += (double)p[2] + (double)p[0] * dm * dm;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const double dm = (double)pm[u] - mean;
+    M2 += (double)p2[u] + (double)pn[u] * dm * dm;
   }
   M2 = wave_sum_d(M2);
   if (lane != 0) return;
@@ -169,10 +180,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long rows, float* dgamma,
                                        float* dbeta, float* c1, float* c2) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  float q1[16], q2[16];                 // one round of loads (<= 1024 partial blocks)
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int k = lane + 64 * u;
+    const bool ok = k < nblk;
+    const float* p = partial + ((long)(ok ? k : 0) * C + c) * 2;
+    q1[u] = ok ? p[0] : 0.f;
+    q2[u] = ok ? p[1] : 0.f;
+  }
   double s1 = 0.0, s2 = 0.0;
-  for (int k = lane; k < nblk; k += 64) {
-    s1 += partial[((long)k * C + c) * 2 + 0];
-    s2 += partial[((long)k * C + c) * 2 + 1];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    s1 += (double)q1[u];
+    s2 += (double)q2[u];
   }
   s1 = wave_sum_d(s1);
   s2 = wave_sum_d(s2);
@@ -226,8 +247,15 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 __global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float* out, float* out2,
                                                           int accumulate) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  float q[16];                          // one round of loads (<= 1024 partial blocks)
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int k = lane + 64 * u;
+    q[u] = k < nblk ? partial[(long)k * C + c] : 0.f;
+  }
   double s = 0.0;
-  for (int k = lane; k < nblk; k += 64) s += partial[(long)k * C + c];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) s += (double)q[u];
   s = wave_sum_d(s);
   if (lane == 0) {
     const float v = accumulate ? out[c] + (float)s : (float)s;
@@ -265,6 +293,7 @@ extern "C" int mmego_bn_train_stats(void* stream, const float* X, long ldx, long
   hipStream_t st = (hipStream_t)stream;
   const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
+  MMEGO_REQUIRE(nblk <= 1024);
   const int TC = col_tile(C);
   hipLaunchKernelGGL(colstats_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC);
   MMEGO_LAUNCH_CHECK();
@@ -311,6 +340,7 @@ extern "C" int mmego_bn_backward(void* stream, const float* dY, long lddy, const
   hipStream_t st = (hipStream_t)stream;
   const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
+  MMEGO_REQUIRE(nblk <= 1024);
   const int TC = col_tile(C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
                      mean, invstd, rows, C, partial_ws, RPB, TC);
@@ -330,6 +360,7 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
   hipStream_t st = (hipStream_t)stream;
   const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
+  MMEGO_REQUIRE(nblk <= 1024);
   const int TC = col_tile(C);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC);
   MMEGO_LAUNCH_CHECK();

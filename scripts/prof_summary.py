@@ -9,7 +9,8 @@ db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, grid_x, grid_y, grid_z, workgroup_x, end-start from kernels order by start"))
 short = lambda n: re.sub(r"\(.*", "", n).replace("void ", "")
 nper = sum(1 for r in rows if "gemm_tile_persistent" in r[0]) / 8.0
-steps = float(sys.argv[2]) if len(sys.argv) > 2 else (nper or 1.0)
+pos = [a for a in sys.argv[2:] if not a.startswith("--")]
+steps = float(pos[0]) if pos else (nper or 1.0)
 tot = sum(r[5] for r in rows)
 print("steps %.1f  kernel time %.3f ms/step  launches/step %.0f" % (steps, tot / steps / 1e6, len(rows) / steps))
 agg = collections.defaultdict(lambda: [0, 0])
