@@ -131,11 +131,7 @@ def pmc_traffic(kernel_label):
     if not os.path.exists(path):
         return None
     pmc = json.load(open(path))
-    if kernel_label.startswith("lstm_step_kernel"):
-        return pmc.get("lstm_step_kernel", {}).get("hbm_bytes_per_launch")
-    if kernel_label.startswith("gemm_tile_kernel<128,128>"):
-        return pmc.get("gemm_tile_kernel<128,128>", {}).get("hbm_bytes_per_launch_bench_mix")
-    return None
+    return pmc.get(kernel_label.split(" ")[0], {}).get("hbm_bytes_per_launch")
 
 
 def cpu_baseline(steps, warmup):
@@ -285,11 +281,11 @@ def main():
         g64 = [(ms_, 2.0 * a[10] * a[11] * a[12]) for ms_, a in rec["gemm"] if is_nt_aligned(a) and not is_tile128(a)]
         cands = {}
         if big:
-            cands["lstm_step_kernel (IMU_Net rnn_fast recurrent steps: 2 dirs x 512 rows x 2048 gates x K=512 per launch)"] = big
+            cands["lstm_step_dma_kernel (IMU_Net rnn_fast recurrent steps: 2 dirs x 512 rows x 2048 gates x K=512 per launch)"] = big
         if small:
             cands["lstm_step_small_kernel (IMU_Net rnn_slow recurrent steps: 2 dirs x 64 rows x 2048 gates x K=512)"] = small
         if g128:
-            cands["gemm_tile_kernel<128,128> (IMU_Net LSTM input projections 10240 x 2048 x {512,1024})"] = g128
+            cands["gemm_tile_persistent_kernel (128x128 tiles; IMU_Net LSTM input projections 10240 x 2048 x {512,1024})"] = g128
         if g64:
             cands["gemm_tile_kernel<64,64> (smaller 64-aligned products)"] = g64
         best = max(cands.items(), key=lambda kv: sum(m for m, _ in kv[1]))
