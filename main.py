@@ -6,7 +6,7 @@
   python main.py --infer [--vis]
 
 Added flags (not in the reference): --gt_head_pose (use the recorded head pose when no IMU_Net checkpoint is
-available), --data_root.  Under `python -m torch.distributed.run --nproc-per-node N main.py --train ...` training is
+available), --data_root, --seed, --resume (bit-exact continuation: weights, Adam moments/step, epoch, RNG states).  Under `python -m torch.distributed.run --nproc-per-node N main.py --train ...` training is
 data parallel (one rank per GPU, RCCL gradient all-reduce).
 """
 import argparse
@@ -35,6 +35,9 @@ def build_parser():
     p.add_argument("--load_Lower_path", type=str, help="Path to load Lower_Net")
     p.add_argument("--gt_head_pose", action="store_true", help="head pose from the recording instead of IMU_Net")
     p.add_argument("--data_root", type=str, help="Sample_data directory")
+    p.add_argument("--seed", type=int, help="seed torch (net initialisation) and numpy (point-cloud padding) -- the reference does not seed")
+    p.add_argument("--resume", type=str, help="continue --train from a checkpoint written by this framework (the model .pth "
+                                               "or its .train_state.pth: weights, Adam state, epoch, RNGs)")
     return p
 
 
@@ -59,11 +62,16 @@ def apply_overrides(args):
     if args.gt_head_pose:
         for c in both:
             c.gt_head_pose = True
+    Config.resume_path = args.resume
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
     apply_overrides(args)
+    if args.seed is not None:
+        import numpy as np
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed)          # PosePC pads / subsamples the point clouds with numpy's global generator
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and args.train:
         local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -96,3 +96,16 @@ class FusedAdam:
 
     def zero_grad(self):
         pass  # every backward overwrites the flat gradient buffer
+
+    def state_dict(self):
+        """Moments and step counters (host copies) + hyper-parameters: everything a bit-exact resume needs."""
+        self._ensure()
+        return {"m": self.m.cpu(), "v": self.v.cpu(), "state": self.state.cpu(), "lr": self.lr, "betas": tuple(self.betas),
+                "eps": self.eps, "weight_decay": self.weight_decay}
+
+    def load_state_dict(self, sd):
+        f = self._ensure()
+        if sd["m"].numel() != f.flat_p.numel():
+            raise ValueError("optimizer state has %d elements, the net's flat parameter buffer %d" % (sd["m"].numel(), f.flat_p.numel()))
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.state.copy_(sd["state"])
+        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]

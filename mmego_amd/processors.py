@@ -66,10 +66,34 @@ class _Base:
         with torch.no_grad():
             return imu_net(imu)
 
-    def save_models(self, epoch, model):
-        if self.rank == 0:
-            torch.save(model.state_dict(), os.path.join(_TRAIN_DIR, "model", str(self.Idx), "epoch{}_batch{}frame{}lr{}.pth".format(
-                epoch, self.batchsize, self.frame_no, self.learning_rate)))
+    def save_models(self, epoch, model, optimizer=None, early=None):
+        """The reference's checkpoint (state_dict only, same file name: Train_Upper.py:69-74) plus, beside it, a
+        `.train_state.pth` with what a bit-exact `--resume` needs and the reference never saved: Adam moments and step
+        count, the epoch, the minibatch-order RNG, the dropout counter and the early-stopping state."""
+        if self.rank != 0:
+            return None
+        path = os.path.join(_TRAIN_DIR, "model", str(self.Idx), "epoch{}_batch{}frame{}lr{}.pth".format(
+            epoch, self.batchsize, self.frame_no, self.learning_rate))
+        torch.save(model.state_dict(), path)
+        if optimizer is not None:
+            torch.save({"epoch": epoch + 1, "model": model.state_dict(), "optimizer": optimizer.state_dict(),
+                        "rng": self._rng.get_state(), "dropout_counter": model.seed_counter().cpu(),
+                        "early": None if early is None else (early.counter, early.best_score)},
+                       path[:-4] + ".train_state.pth")
+        return path
+
+    def load_train_state(self, path, model):
+        """Restore a `.train_state.pth` written by save_models (or the one beside a given model `.pth`)."""
+        if not path.endswith(".train_state.pth"):
+            path = path[:-4] + ".train_state.pth"
+        ts = torch.load(path, map_location="cpu", weights_only=False)
+        model.load_state_dict(ts["model"])
+        model.seed_counter().copy_(ts["dropout_counter"])
+        self._rng.set_state(ts["rng"])
+        self.start_epoch = int(ts["epoch"])
+        self._resume = ts
+        print("[mmego_amd] resumed from %s at epoch %d" % (path, self.start_epoch))
+        return ts
 
     def pose_metrics(self, upper_l, lower_l, target):
         """Demo_test per-batch figures on the device -> (all, upper, lower, per_joint[21], angle[20])."""
@@ -97,6 +121,10 @@ class _StageTrainer(_Base):
         self.evalfile = open(os.path.join(rep, "log-eval.txt"), "w") if self.rank == 0 else None
         self._steps = {}
         self._rng = np.random.RandomState(1234)
+        self.start_epoch, self._resume = 0, None
+
+    def _optimizer(self):
+        return next(iter(self._steps.values())).opt if self._steps else None
 
     def _step_for(self, B):
         """One StageStep (static buffers, optional HIP graph) per minibatch size."""
@@ -107,6 +135,8 @@ class _StageTrainer(_Base):
                            lr=self.learning_rate, process_group=pg, use_graph=True)
             if self._steps:
                 st.opt = next(iter(self._steps.values())).opt           # one optimiser state for all batch sizes
+            elif self._resume is not None:
+                st.opt.load_state_dict(self._resume["optimizer"])
             self._steps[B] = st
         return st
 
@@ -140,12 +170,14 @@ class _StageTrainer(_Base):
 
     def _train_loop(self, extra_print):
         early = EarlyStopping(patience=30)
+        if getattr(self.cfg, "resume_path", None):
+            ts = self.load_train_state(self.cfg.resume_path, self.model)
+            if ts["early"] is not None:
+                early.counter, early.best_score = ts["early"]
         out = None
-        for epoch in range(self.num_epochs):
+        for epoch in range(self.start_epoch, self.num_epochs):
             print("epoch: {}".format(epoch + 1))
             self.train_once()
-            if (epoch + 1) % self.save_slot == 0:
-                self.save_models(epoch, self.model)
             out = self.eval_model()
             eval_loss, eval_loss_l, eval_accu, second, accu_ll, angle_ll = out
             if self.rank == 0:
@@ -153,9 +185,13 @@ class _StageTrainer(_Base):
                 self.lossfile.write(str(eval_loss_l) + "\n")
                 self.lossfile.flush()
                 extra_print(epoch, out)
-            if early(eval_loss):
+            stop = early(eval_loss)
+            # (the reference saves before the evaluation pass; saving after it keeps the RNG / early-stopping state in the
+            #  checkpoint consistent with "epoch finished", which is what --resume continues from)
+            if (epoch + 1) % self.save_slot == 0 or epoch + 1 == self.num_epochs or stop:
+                self.save_models(epoch, self.model, self._optimizer(), early)
+            if stop:
                 print("Early stopping")
-                self.save_models(epoch, self.model)
                 break
         return out
 
@@ -316,6 +352,7 @@ class ImuTrainer(_Base):
         self.lossfile = open(os.path.join(rep, "log-loss.txt"), "w") if self.rank == 0 else None
         self._rng = np.random.RandomState(1234)
         self._loss = torch.zeros(1, device=self.device)
+        self.start_epoch, self._resume = 0, None
 
     def _loss_and_grads(self, R, t, R_gt, head, want_grad):
         F = R.shape[0] * R.shape[1]
@@ -365,11 +402,14 @@ class ImuTrainer(_Base):
 
     def train_imu(self):
         early = EarlyStopping(patience=30)
-        for epoch in range(self.num_epochs):
+        if getattr(self.cfg, "resume_path", None):
+            ts = self.load_train_state(self.cfg.resume_path, self.model_IMU)
+            self.optimizer_IMU.load_state_dict(ts["optimizer"])
+            if ts["early"] is not None:
+                early.counter, early.best_score = ts["early"]
+        for epoch in range(self.start_epoch, self.num_epochs):
             print("epoch: {}".format(epoch + 1))
             train_loss = self.train_imu_once()
-            if (epoch + 1) % self.save_slot == 0:
-                self.save_models(epoch, self.model_IMU)
             eval_loss, eval_loss_l = self.eval_imu()
             if self.rank == 0:
                 self.lossfile.write("%d %f\n" % (epoch + 1, eval_loss))
@@ -377,7 +417,9 @@ class ImuTrainer(_Base):
                 self.lossfile.flush()
             print("Train_loss: {}".format(train_loss))
             print("Eval_loss: {}  Eval_loss_l (angle, H_pos): {}".format(eval_loss, eval_loss_l))
-            if early(eval_loss):
+            stop = early(eval_loss)
+            if (epoch + 1) % self.save_slot == 0 or epoch + 1 == self.num_epochs or stop:
+                self.save_models(epoch, self.model_IMU, self.optimizer_IMU, early)
+            if stop:
                 print("Early stopping")
-                self.save_models(epoch, self.model_IMU)
                 break

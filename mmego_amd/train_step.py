@@ -81,11 +81,25 @@ class StageStep:
                            t_gt=torch.empty(B, T, 3, device=dev))
         self.graph = None
 
+    def _mutable_state(self):
+        """What a body changes besides gradients/activations: BatchNorm running statistics + step counters and the dropout
+        counter of the trained net (the frozen nets run in eval mode)."""
+        return list(self.net.buffers()) + [self.net.seed_counter()]
+
+    def warm_up(self):
+        """Run the body once WITHOUT side effects (sizes the arenas, sets kernel attributes before graph capture): the
+        mutable state is put back afterwards, so graph and eager runs -- and a resumed run -- see identical states."""
+        keep = [t.clone() for t in self._mutable_state()]
+        self._body()
+        torch.cuda.synchronize()
+        for t, k in zip(self._mutable_state(), keep):
+            t.copy_(k)
+        torch.cuda.synchronize()
+
     def step(self):
         if self.use_graph:
             if self.graph is None:
-                self._body()                                   # warm-up: sizes arenas, sets kernel attributes
-                torch.cuda.synchronize()
+                self.warm_up()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._body()
@@ -133,9 +147,13 @@ class ConcurrentStages:
         if self.use_graph:
             if self.graph is None:
                 for st in self.stages:                          # warm-up one by one: sizes arenas, sets kernel attributes
-                    st._body()
-                torch.cuda.synchronize()
+                    st.warm_up()
+                keep = [[t.clone() for t in st._mutable_state()] for st in self.stages]
                 self._bodies()                                  # per-stream scratch buffers of the side streams
+                torch.cuda.synchronize()
+                for st, ks in zip(self.stages, keep):
+                    for t, k in zip(st._mutable_state(), ks):
+                        t.copy_(k)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):

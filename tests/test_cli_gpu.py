@@ -64,3 +64,36 @@ def test_main_train_and_infer_on_synthetic_tree(tmp_path):
         assert line in out
     assert os.path.exists(os.path.join(ROOT, "Processor", "Train", "report", "9101", "log-loss.txt"))
     assert os.path.isdir(model_dir)
+
+
+def test_resume_continues_bit_exactly(tmp_path):
+    """`--resume`: 1 epoch + resume for the 2nd == 2 epochs in one go, bit for bit (weights, BN buffers):
+    the checkpoint carries Adam moments and step count, the minibatch-order RNG, the dropout counter, early-stopping state."""
+    import glob
+    import torch
+    data = str(tmp_path / "Sample_data")
+    _make_dataset(data, np.random.default_rng(1))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    mdir = os.path.join(ROOT, "Processor", "Train", "model")
+    base = ["--train", "--network", "Upper_Net", "--gt_head_pose", "--data_root", data, "--batch_size", "4", "--device", "cuda:0",
+            "--seed", "5"]
+    for idx in ("9111", "9112", "9113"):
+        for f in glob.glob(os.path.join(mdir, idx, "*")):
+            os.remove(f)
+    _run(base + ["--epochs", "2", "--log_dir", "9111"], env)
+    _run(base + ["--epochs", "1", "--log_dir", "9112"], env)
+    first = glob.glob(os.path.join(mdir, "9112", "epoch0_*lr*.pth"))
+    first = [f for f in first if not f.endswith(".train_state.pth")]
+    assert len(first) == 1 and os.path.exists(first[0][:-4] + ".train_state.pth")
+    out = _run(base + ["--epochs", "2", "--log_dir", "9113", "--resume", first[0]], env)
+    assert "resumed from" in out and "epoch: 2" in out and "epoch: 1\n" not in out
+    a = [f for f in glob.glob(os.path.join(mdir, "9111", "epoch1_*.pth")) if not f.endswith(".train_state.pth")]
+    b = [f for f in glob.glob(os.path.join(mdir, "9113", "epoch1_*.pth")) if not f.endswith(".train_state.pth")]
+    assert len(a) == 1 and len(b) == 1
+    sa, sb = torch.load(a[0], map_location="cpu"), torch.load(b[0], map_location="cpu")
+    assert sa.keys() == sb.keys()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    ta = torch.load(a[0][:-4] + ".train_state.pth", map_location="cpu", weights_only=False)
+    tb = torch.load(b[0][:-4] + ".train_state.pth", map_location="cpu", weights_only=False)
+    assert torch.equal(ta["optimizer"]["m"], tb["optimizer"]["m"]) and torch.equal(ta["optimizer"]["state"], tb["optimizer"]["state"])
