@@ -50,6 +50,9 @@ int mmego_affine_act(void* stream, const float* X1, long ld1, const float* m1, c
                      long rows, int C, int relu);
 /* Y[:, :C] (+)= X[:, :C] with row strides: the torch.cat pieces of Upper_Net.py:266, Lower_Net.py:70,111,119. */
 int mmego_copy2d(void* stream, const float* X, long ldx, float* Y, long ldy, long rows, int C, int accumulate);
+/* Y[i,:] = X[idx[i],:] (rows of W floats, idx int64; indices outside [0,nsrc) give zero rows): minibatch assembly from
+ * the HBM-resident dataset -- replaces the DataLoader collate + per-batch host->device copies of Train_Upper.py:140-150. */
+int mmego_gather_rows(void* stream, const float* X, long nsrc, long W, const long long* idx, long nout, float* Y);
 /* BatchNorm (train) backward through an optional ReLU mask (Ymask > 0): dgamma, dbeta, dX.
  * partial_ws: 2*C*nblk floats, c12_ws: 2*C floats. */
 int mmego_bn_backward(void* stream, const float* dY, long lddy, const float* Ymask, long ldm, const float* X, long ldx,

@@ -264,6 +264,17 @@ __global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restric
   }
 }
 
+// Y[i, :] = X[idx[i], :]   (rows of W floats; minibatch assembly from the HBM-resident dataset)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ X, const long long* __restrict__ idx,
+                                                          float* __restrict__ Y, long nout, long W, long nsrc) {
+  const long total = nout * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / W, c = i - r * W;
+    const long long s = idx[r];
+    Y[i] = (s >= 0 && s < nsrc) ? X[s * W + c] : 0.f;      // out-of-range indices give zero rows instead of a fault
+  }
+}
+
 // G[r,c] = 0 where H[r,c] <= 0
 __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ G, long ldg, const float* __restrict__ H,
                                                         long ldh, long rows, int C) {
@@ -365,6 +376,13 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC);
   MMEGO_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, out, out2, accumulate);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_gather_rows(void* stream, const float* X, long nsrc, long W, const long long* idx, long nout, float* Y) {
+  MMEGO_REQUIRE(X && idx && Y && nsrc > 0 && W > 0 && nout > 0);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_blocks(nout * W)), dim3(256), 0, (hipStream_t)stream, X, idx, Y, nout, W, nsrc);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -7,6 +7,7 @@ reference (one choice() per frame for the slot layout, plus the reference's unus
 (checked in tests/test_data_cpu.py against tests/golden/real16.npz).
 """
 import glob
+import hashlib
 import os
 import re
 
@@ -14,6 +15,8 @@ import numpy as np
 import scipy.io as scio
 
 from .config import Config
+
+CACHE_VERSION = 1
 
 R_RI = np.array([[0, 0, 1], [0, -1, 0], [1, 0, 0]])
 R_TTB = np.array([[0, -1, 0], [-1, 0, 0], [0, 0, -1]])
@@ -102,13 +105,24 @@ class PosePC:
         return tuple(a[i] for a in self._items)
 
     # -----------------------------------------------------------------------------------------
-    def _read(self):
-        if not os.path.isdir(self.root):
-            raise FileNotFoundError("Sample_data not found at %s (set MMEGO_DATA_ROOT or Config.data_root)" % self.root)
-        win = {k: [] for k in ("ti", "key", "imu", "skl", "ground", "foot", "R", "t", "RtW")}
+    def _decode(self):
+        """Everything that comes out of the .mat files and does NOT depend on numpy's RNG: per snippet, per non-empty
+        frame the raw points and the derived small arrays.  This is the slow part of the reference's start-up (one
+        scipy.loadmat per frame, 19 208 files = 14 s, done twice: train and test set) and it is deterministic, so it is
+        kept in a packed binary cache: one .npz per (file list, sizes, mtimes)."""
+        snippets = list_snippets(self.root)
+        cache = _cache_path(self.root, snippets, self.joint_selection, self.skeleton)
+        if cache and os.path.exists(cache):
+            try:
+                z = np.load(cache, allow_pickle=False)
+                return {k: z[k] for k in z.files}
+            except (OSError, ValueError, KeyError):
+                pass
+        fr = {k: [] for k in ("pts", "npts", "key", "imu", "ground", "foot", "R", "t", "RtW")}
+        snip_len = []
         ref = None          # (R_btc, imu orientation, bone vectors) of the first frame ever read
-        for _, _, files in list_snippets(self.root):
-            rec = {k: [] for k in ("ti", "key", "imu", "ground", "foot", "R", "t", "RtW")}
+        for _, _, files in snippets:
+            count = 0
             for path in files:
                 m = scio.loadmat(path)
                 raw = np.asarray(m["pc_xyziv_ti2"][:, 0:5].tolist())
@@ -120,24 +134,118 @@ class PosePC:
                     bones = [joints[p] - joints[c] for p, c in self.skeleton]
                     ref = (m["R_btc"], np.asarray(m["orientation_imu_img"]), bones)
                 R_btc = m["R_btc"]
-                rec["R"].append(R_TTB @ ref[0] @ R_btc.T @ R_TTB.T)
-                rec["RtW"].append(R_TTB @ R_btc @ R_CTW)
-                rec["imu"].append(imu_to_radar_frame(imu, ref[1]))
+                fr["R"].append(R_TTB @ ref[0] @ R_btc.T @ R_TTB.T)
+                fr["RtW"].append(R_TTB @ R_btc @ R_CTW)
+                fr["imu"].append(imu_to_radar_frame(imu, ref[1]))
                 fc = m["foot_contact"]
-                rec["foot"].append([[0, 1] if fc[0, 0] else [1, 0], [0, 1] if fc[0, 1] else [1, 0]])
+                fr["foot"].append([[0, 1] if fc[0, 0] else [1, 0], [0, 1] if fc[0, 1] else [1, 0]])
                 ground = m["abcd_ground_2"]
-                rec["ground"].append(-1 * ground if ground[0, 0] > 0 else ground)
-                rec["ti"].append(pack_points(raw, self.pc_no))
-                rec["key"].append(joints)
-                rec["t"].append(m["t_R0R"])
+                fr["ground"].append(-1 * ground if ground[0, 0] > 0 else ground)
+                fr["pts"].append(raw)
+                fr["npts"].append(len(raw))
+                fr["key"].append(joints)
+                fr["t"].append(m["t_R0R"])
+                count += 1
+            snip_len.append(count)
+        dec = {"pts": np.concatenate(fr["pts"], 0) if fr["pts"] else np.zeros((0, 5)), "npts": np.asarray(fr["npts"], dtype=np.int64),
+               "snip_len": np.asarray(snip_len, dtype=np.int64),
+               "bones": np.asarray(ref[2]) if ref is not None else np.zeros((0, 3))}
+        for k in ("key", "imu", "ground", "foot", "R", "t", "RtW"):
+            dec[k] = np.asarray(fr[k])
+        if cache:
+            try:
+                os.makedirs(os.path.dirname(cache), exist_ok=True)
+                tmp = cache + ".tmp%d.npz" % os.getpid()
+                np.savez(tmp, **dec)
+                os.replace(tmp, cache)
+            except OSError:
+                pass                                    # read-only location: work without a cache
+        return dec
+
+    def _read(self):
+        if not os.path.isdir(self.root):
+            raise FileNotFoundError("Sample_data not found at %s (set MMEGO_DATA_ROOT or Config.data_root)" % self.root)
+        dec = self._decode()
+        win = {k: [] for k in ("ti", "key", "imu", "skl", "ground", "foot", "R", "t", "RtW")}
+        bones = [b for b in dec["bones"]]
+        f0 = 0                                           # first frame of the snippet in the packed arrays
+        p0 = 0                                           # first point of that frame in dec["pts"]
+        for count in dec["snip_len"]:
+            rec = {k: [] for k in ("ti", "key", "imu", "ground", "foot", "R", "t", "RtW")}
+            for f in range(f0, f0 + int(count)):
+                n = int(dec["npts"][f])
+                rec["ti"].append(pack_points(dec["pts"][p0:p0 + n], self.pc_no))     # consumes numpy's RNG like the reference
+                p0 += n
+                for k in ("key", "imu", "ground", "foot", "R", "t", "RtW"):
+                    rec[k].append(dec[k][f])
+            f0 += int(count)
             L = self.frame_no
             while len(rec["ti"]) >= L:
                 for k in rec:
                     win[k].append(rec[k][-L:])
                     rec[k] = rec[k][:-L]
-                win["skl"].append(ref[2])
+                win["skl"].append(bones)
         print("data load end")
         return tuple(np.asarray(win[k]) for k in ("ti", "key", "imu", "skl", "ground", "foot", "R", "t", "RtW"))
+
+
+def _cache_path(root, snippets, joint_selection, skeleton):
+    """Cache file of the decoded frames of ``root``: keyed by every frame file's path, size and mtime (and by the joint
+    selection).  MMEGO_CACHE_DIR overrides the location (default ~/.cache/mmego_amd); MMEGO_CACHE_DIR=off disables it."""
+    base = os.environ.get("MMEGO_CACHE_DIR", os.path.join(os.path.expanduser("~"), ".cache", "mmego_amd"))
+    if base == "off":
+        return None
+    h = hashlib.sha256()
+    h.update(("v%d|%s|%s|%s" % (CACHE_VERSION, os.path.abspath(root), list(joint_selection), skeleton)).encode())
+    for _, _, files in snippets:
+        for path in files:
+            st = os.stat(path)
+            h.update(("%s|%d|%d" % (path, st.st_size, st.st_mtime_ns)).encode())
+    return os.path.join(base, "frames_%s.npz" % h.hexdigest()[:24])
+
+
+class DeviceArrays:
+    """The training arrays of a PosePC resident in HBM as fp32 (uploaded once: 835 x 20 x 128 x 6 floats = 51 MB for
+    Sample_data), with minibatches gathered ON the device by index (mmego_gather_rows).  Replaces the reference's
+    per-batch numpy stacking + float64->float32 `torch.tensor(...)` + host->device copies (Train_Upper.py:140-150);
+    the values are the same (the one rounding to fp32 happens at upload instead of per batch)."""
+
+    FIELDS = (("data", 0), ("target", 1), ("skl", 2), ("imu", 3), ("R_R0R", 6))
+
+    def __init__(self, dataset, device):
+        import torch
+        self.n = len(dataset)
+        self.device = device
+        self.src, self.shape = {}, {}
+        for name, i in self.FIELDS:
+            a = np.ascontiguousarray(dataset._items[i])
+            self.shape[name] = tuple(a.shape[1:])
+            self.src[name] = torch.as_tensor(a.reshape(self.n, -1), dtype=torch.float32).to(device)
+        self._out = {}
+
+    def gather(self, index):
+        """index: int array of item numbers -> dict of device tensors [len(index), ...] (buffers reused per batch size)."""
+        import torch
+        from . import ops
+        idx = torch.as_tensor(np.ascontiguousarray(index), dtype=torch.int64).to(self.device)
+        B = idx.numel()
+        out = {}
+        for name, _ in self.FIELDS:
+            key = (name, B)
+            dst = self._out.get(key)
+            if dst is None:
+                dst = torch.empty((B, self.src[name].shape[1]), dtype=torch.float32, device=self.device)
+                self._out[key] = dst
+            ops.gather_rows(self.src[name], idx, dst)
+            out[name] = dst.view((B,) + self.shape[name])
+        return out
+
+
+def batch_indices(n, batch_size, shuffle, rng=None):
+    """The index sets `batches` iterates over (same RNG consumption), for on-device gathering."""
+    order = (rng or np.random).permutation(n) if shuffle else np.arange(n)
+    for s in range(0, n, batch_size):
+        yield order[s:s + batch_size]
 
 
 def batches(dataset, batch_size, shuffle, rng=None):

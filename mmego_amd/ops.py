@@ -177,6 +177,17 @@ def copy2d(X, Y, accumulate=False):
     return Y
 
 
+def gather_rows(X, idx, Y):
+    """Y[i, :] = X[idx[i], :] for contiguous fp32 X [n, W], int64 idx [m], Y [m, W]."""
+    _chk(X, 2), _chk(Y, 2)
+    if not (X.is_contiguous() and Y.is_contiguous() and idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()):
+        raise ValueError("gather_rows needs contiguous fp32 X/Y and a contiguous int64 device index")
+    if Y.shape != (idx.numel(), X.shape[1]):
+        raise ValueError("gather_rows shape mismatch")
+    hip.call("gather_rows", X, X.shape[0], X.shape[1], idx, idx.numel(), Y)
+    return Y
+
+
 def relu_mask_(G, H):
     G, H = _rows(G), _rows(H)
     hip.call("relu_mask", G, G.stride(0), H, H.stride(0), G.shape[0], G.shape[1])

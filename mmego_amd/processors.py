@@ -16,7 +16,7 @@ import torch
 
 from . import hip, ops
 from .config import Config, ConfigDemo
-from .data import PosePC, batches
+from .data import DeviceArrays, PosePC, batch_indices, batches
 from .nets import IMUNet, LowerNet, UpperNet
 from .train_step import StageStep, shard_of
 from .utils import EarlyStopping
@@ -122,6 +122,7 @@ class _StageTrainer(_Base):
         self._steps = {}
         self._rng = np.random.RandomState(1234)
         self.start_epoch, self._resume = 0, None
+        self._train_dev = None
 
     def _optimizer(self):
         return next(iter(self._steps.values())).opt if self._steps else None
@@ -145,21 +146,18 @@ class _StageTrainer(_Base):
         losses, accs = [], []
         nsel = self.model_out_joints
         jmap = self.cfg.upper_joint_map if self.stage == "upper" else self.cfg.lower_joint_map
-        for bi, (data, target, skl, imu, _, _, R_R0R, _) in enumerate(batches(self.train_data, self.batchsize * self.world, True, self._rng)):
-            sl = shard_of(self.rank, self.world)                        # this rank's shard of the global minibatch
-            data, target, skl, imu, R_R0R = data[sl], target[sl], skl[sl], imu[sl], R_R0R[sl]
-            if len(data) == 0:
+        if self._train_dev is None:                                     # the training set lives in HBM (51 MB for Sample_data)
+            self._train_dev = DeviceArrays(self.train_data, self.device)
+        for idx in batch_indices(len(self.train_data), self.batchsize * self.world, True, self._rng):
+            idx = idx[shard_of(self.rank, self.world)]                  # this rank's shard of the global minibatch
+            if len(idx) == 0:
                 continue
-            B = len(data)
+            B = len(idx)
             st = self._step_for(B)
-            dev = self.device
-            x, tgt = _dev_tensor(data, dev), _dev_tensor(target, dev)
-            if st.static is None or st.static["x_src"].shape != x.shape:
-                st.bind(x, _dev_tensor(imu, dev), _dev_tensor(skl, dev), tgt, R_gt=_dev_tensor(R_R0R, dev))
-            else:                                                       # refill the static buffers (graph inputs)
-                st.static["x_src"].copy_(x); st.static["target"].copy_(tgt)
-                st.static["imu"].copy_(_dev_tensor(imu, dev)); st.static["body"].copy_(_dev_tensor(skl, dev))
-                st.static["R_gt"].copy_(_dev_tensor(R_R0R, dev))
+            b = self._train_dev.gather(idx)                             # on-device gather into per-batch-size static buffers
+            tgt = b["target"]
+            if st.static is None or st.static["x_src"].data_ptr() != b["data"].data_ptr():
+                st.bind(b["data"], b["imu"], b["skl"], tgt, R_gt=b["R_R0R"])
             loss = st.step()
             pred = st.last_pred
             acc = torch.mean(torch.sqrt(torch.sum(torch.square(pred - tgt[:, :, jmap, :]), dim=-1)))
@@ -353,6 +351,7 @@ class ImuTrainer(_Base):
         self._rng = np.random.RandomState(1234)
         self._loss = torch.zeros(1, device=self.device)
         self.start_epoch, self._resume = 0, None
+        self._train_dev = None
 
     def _loss_and_grads(self, R, t, R_gt, head, want_grad):
         F = R.shape[0] * R.shape[1]
@@ -367,14 +366,15 @@ class ImuTrainer(_Base):
         self.model_IMU.train()
         losses = []
         pg = torch.distributed.group.WORLD if self.world > 1 else None
-        for data, target, skl, imu, _, _, R_R0R, _ in batches(self.train_data, self.batchsize * self.world, True, self._rng):
-            sl = shard_of(self.rank, self.world)
-            target, imu, R_R0R = target[sl], imu[sl], R_R0R[sl]
-            if len(imu) == 0:
+        if self._train_dev is None:
+            self._train_dev = DeviceArrays(self.train_data, self.device)
+        for idx in batch_indices(len(self.train_data), self.batchsize * self.world, True, self._rng):
+            idx = idx[shard_of(self.rank, self.world)]
+            if len(idx) == 0:
                 continue
-            dev = self.device
-            B, T = imu.shape[0], imu.shape[1]
-            imu_d, tgt, Rg = _dev_tensor(imu, dev), _dev_tensor(target, dev), _dev_tensor(R_R0R, dev)
+            b = self._train_dev.gather(idx)
+            imu_d, tgt, Rg = b["imu"], b["target"], b["R_R0R"]
+            B, T = imu_d.shape[0], imu_d.shape[1]
             with torch.no_grad():
                 R, t = imu_train.forward_train(self.model_IMU, imu_d)
                 dR, dt = self._loss_and_grads(R, t, Rg, tgt[:, :, 20], True)

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the loader's decoded-frame cache defaults to ~/.cache/mmego_amd: keep test runs inside a throw-away directory
+if "MMEGO_CACHE_DIR" not in os.environ:
+    import tempfile
+    os.environ["MMEGO_CACHE_DIR"] = tempfile.mkdtemp(prefix="mmego_cache_")
 
 
 def pytest_configure(config):

@@ -254,6 +254,34 @@ def test_concurrent_stages_equal_sequential(dev):
         ConcurrentStages([su, sl])
 
 
+def test_device_resident_minibatches(dev):
+    """mmego_gather_rows / data.DeviceArrays: minibatches gathered on the device equal numpy fancy indexing followed by the
+    reference's float64 -> float32 conversion (bit-exact), repeated and out-of-range indices included."""
+    from mmego_amd import ops
+    from mmego_amd.data import DeviceArrays
+    rng = np.random.RandomState(0)
+    X = torch.randn(50, 37, device=dev)
+    idx = torch.tensor([3, 49, 3, 0, 17, 50, -1], dtype=torch.int64, device=dev)
+    Y = torch.full((7, 37), 9.0, device=dev)
+    ops.gather_rows(X, idx, Y)
+    assert torch.equal(Y[:5], X[idx[:5]]) and (Y[5:] == 0).all()
+
+    class FakeSet:
+        _items = [rng.randn(31, 4, 16, 6).astype(np.float32), rng.randn(31, 4, 21, 3), rng.randn(31, 20, 3), rng.randn(31, 4, 20, 15),
+                  None, None, rng.randn(31, 4, 3, 3), None]
+
+        def __len__(self):
+            return 31
+    ds = FakeSet()
+    da = DeviceArrays(ds, dev)
+    for pick in (rng.permutation(31)[:8], rng.permutation(31)[:8], rng.permutation(31)[:5]):
+        b = da.gather(pick)
+        for name, i in DeviceArrays.FIELDS:
+            ref = torch.tensor(ds._items[i][pick], dtype=torch.float32)
+            assert b[name].shape == ref.shape and torch.equal(b[name].cpu(), ref), name
+    assert da.gather(np.arange(8))["data"].data_ptr() == da.gather(np.arange(8, 16))["data"].data_ptr()   # static per batch size
+
+
 def test_large_batch_stress_forward_property(dev):
     """BASELINE config 5 shape (B=2048, T=16, N=256; fp32 here): Upper_Net + Lower_Net eval forward on 8.4 M points.
     Size-independent property: in eval mode every sequence is independent, so the first 4 sequences of the big
