@@ -14,10 +14,7 @@
 
 #include "common.h"
 
-namespace mmego_detail {
-int gemm_tile_launch(hipStream_t st, const float* A, const float* W, float* C, const float* bias, int M, int N, int K,
-                     long lda, long ldw, long ldc, int relu);
-}
+#include "gemm_tile.h"
 
 struct GemmP {
   const float* A;
@@ -356,11 +353,39 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
                           long sBb, long sCb, int relu, int accumulate, float* splitk_ws, int nsplit) {
   MMEGO_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && nsplit >= 1);
   hipStream_t st = (hipStream_t)stream;
-  const bool nt_aligned = nbatch == 1 && nsplit == 1 && !accumulate && sak == 1 && sbk == 1 && scn == 1 && (sam % 4) == 0 &&
-                          (sbn % 4) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
-  if (nt_aligned) {   // large-tile kernel (gemm_tile.hip) when the shape allows
-    int rc = mmego_detail::gemm_tile_launch(st, A, B, C, bias, M, N, K, sam, sbn, scm, relu);
-    if (rc != -2) return rc;
+  // Large-tile kernels (gemm_tile.hip): 64-aligned shapes with enough work units to be worth a 64x64+ tile, any operand
+  // orientation whose contiguous index has unit stride and 16-B aligned rows.
+  {
+    const bool a_kc = sak == 1, a_mc = sam == 1 && !a_kc;
+    const bool b_kc = sbk == 1, b_mc = sbn == 1 && !b_kc;
+    const long lda = a_kc ? sam : sak, ldw = b_kc ? sbn : sbk;
+    const int kchunk_t = nsplit > 1 ? cdiv(cdiv(K, nsplit), 64) * 64 : K;
+    // k-contiguous x k-contiguous products take the tile kernels at any size (measured better than the K-quartered kernel
+    // even for 32 tiles); the other orientations only when there are enough 64x64 work units to fill the chip.
+    static const long tile_min_other = getenv("MMEGO_GEMM_TILE_MIN") ? atol(getenv("MMEGO_GEMM_TILE_MIN")) : 256;
+    const long tile_min_units = (a_kc && b_kc && nsplit == 1) ? 1 : tile_min_other;
+    const long units64 = (long)(M / 64) * (N / 64) * nsplit;
+    static const bool nt_only = getenv("MMEGO_GEMM_TILE_NT_ONLY") != nullptr;
+    const bool ok = !(nt_only && !(a_kc && b_kc && nsplit == 1 && !accumulate)) && nbatch == 1 && scn == 1 && (a_kc || a_mc) && (b_kc || b_mc) && (lda % 4) == 0 && (ldw % 4) == 0 &&
+                    (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (M % 64) == 0 && (N % 64) == 0 &&
+                    (K % 64) == 0 && units64 >= tile_min_units && (nsplit == 1 || (long)(nsplit - 1) * kchunk_t < K);
+    if (ok) {
+      TileP tp;
+      tp.A = A; tp.W = B; tp.C = C; tp.bias = bias;
+      tp.M = M; tp.N = N; tp.K = K;
+      tp.lda = lda; tp.ldw = ldw; tp.ldc = scm;
+      tp.relu = relu; tp.accumulate = accumulate;
+      tp.nsplit = nsplit; tp.kchunk = kchunk_t; tp.ws = splitk_ws;
+      int rc = mmego_detail::gemm_tile_launch(st, tp, a_kc, b_kc);
+      if (rc == 0 && nsplit > 1) {
+        long total = (long)M * N;
+        int blocks = (int)((total + SKR_OUT - 1) / SKR_OUT);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, C, bias, nsplit, 1, M, N, scm, scn, 0L,
+                           relu, accumulate);
+        MMEGO_LAUNCH_CHECK();
+      }
+      if (rc != -2) return rc;
+    }
   }
   const bool fast = nbatch == 1 && nsplit == 1 && !accumulate && sak == 1 && sbk == 1 && scn == 1 && (M % 128) == 0 &&
                     (N % 128) == 0 && (K % 16) == 0 && (sam % 4) == 0 && (sbn % 4) == 0 &&

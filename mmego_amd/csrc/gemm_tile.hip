@@ -1,41 +1,54 @@
-// fp32 NT GEMM, large-tile kernel: C[M,N] = A[M,K] . W[N,K]^T (+bias)(relu), K % 64 == 0.
+// fp32 GEMM, large-tile kernels: C[M,N] (+)= A . B (+bias)(relu) for 64-aligned shapes, any operand orientation.
 //
-// The dominant dense products of the path run here: the LSTM input projections of IMU_Net
-// (reference Net/IMU_Net.py:58-62: 10240 x 2048 x {512,1024}, 512 x 2048 x 1024) and the 128-aligned Linear layers.
+// The dense products of the path run here: the LSTM input projections of IMU_Net (reference Net/IMU_Net.py:58-62:
+// 10240 x 2048 x {512,1024}, 512 x 2048 x 1024), the 64-aligned Linear layers, and -- for stage-1 training
+// (Processor/Train/Train_IMU.py:114-149) -- the input-gradient (dX = dY . W) and weight-gradient (dW = dY^T . X) products
+// of those layers, which differ only in which index of an operand is contiguous in memory.
 //
-//  * v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), BM x BN block tile (128x128 or 64x64), 4 waves as 2x2, each
+//  * v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), BM x BN block tile (128x128, 128x64 or 64x64), 4 waves as 2x2, each
 //    wave (BM/2) x (BN/2) = TM x TN tiles of 32x32.
-//  * Operand tiles live in LDS as [row][k] with a 68-float row stride (64 k + 4 pad): the global->LDS copy is a plain
-//    f32x4 -> ds_write_b128 (no transpose), and the operand fetch is ONE ds_read_b128 per 4 MFMA steps using a
-//    k-permutation (lane half h supplies k = 8*kb + 4*h + s at step s, identically for A and B).  With this stride
-//    every 16-lane group of the b128 read hits 16 distinct 16-B slots (conflict-free).
-//  * One LDS buffer + register prefetch of the next 64-k chunk (global loads are issued before the MFMA block and
-//    land under it), so 2 workgroups fit a CU (69.6 KB each at 128x128) and overlap each other's barriers.
+//  * Operand staging, 64 k per chunk, one LDS buffer + register prefetch of the next chunk (global loads are issued before
+//    the MFMA block and land under it); 2 workgroups fit a CU (69.6 KB each at 128x128) and overlap each other's barriers.
+//      - k-contiguous operand (X[row][k]): LDS tile [row][k] with a 68-float row stride; global->LDS is a plain
+//        f32x4 -> ds_write_b128 and the operand fetch is ONE conflict-free ds_read_b128 per 4 MFMA steps through a
+//        k-permutation (lane half h supplies k = 8 kb + 4 h + s at step s -- identically for both operands).
+//      - row-contiguous operand (X[k][row], e.g. dY^T and X in dW = dY^T . X): LDS tile [k][row] with a (rows+4)-float
+//        stride, f32x4 loads/stores along the rows, four conflict-free ds_read_b32 per 4 MFMA steps in the same k order.
+//  * Split-K (weight gradients: few tiles, K = batch rows): the K range is cut into `nsplit` slabs whose partial tiles go
+//    to a workspace [nsplit][M][N]; the caller reduces them in a fixed order (deterministic).
 //  * XCD-aware tile order: consecutive tiles along N (sharing the A row panel) stay on one XCD's L2.
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_tile.h"
 
 #define TLD 68
 // NOTE: staging registers are ext_vector f32x4 (not HIP's float4 struct): arrays of the struct type are left in
 // scratch memory by hipcc (ROCm 7.2), which serialises the prefetch.
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__device__ __forceinline__ void gemm_tile_body(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ C,
-                                               const float* __restrict__ bias, int K, long lda, long ldw, long ldc, int relu,
-                                               int m0, int n0, float* smem, int sid) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
+__device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, int split, float* smem, int sid) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;           // 32x32 MFMA tiles per wave
-  constexpr int AV = BM / 16, BV = BN / 16;          // f32x4 per thread per 64-k chunk (rows lr + 16*i)
-  float (*As)[TLD] = reinterpret_cast<float (*)[TLD]>(smem);
-  float (*Bs)[TLD] = reinterpret_cast<float (*)[TLD]>(smem + BM * TLD);
+  constexpr int AV = BM / 16, BV = BN / 16;          // f32x4 per thread per 64-k chunk
+  constexpr int ALD = BM + 4, BLD = BN + 4;          // row strides of the [k][row] tiles
+  constexpr int ARP = 1024 / BM, BRP = 1024 / BN;    // k rows covered per pass of the 256 threads ([k][row] staging)
+  float* As = smem;
+  float* Bs = smem + BM * TLD;                        // (BM * TLD >= 64 * ALD for BM in {64, 128})
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+  const int kbeg = split * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+  const int nk = (kend - kbeg) / 64;
 
-  const int lk = (tid & 15) * 4, lr = tid >> 4;      // 16 lanes cover one 256-B row segment
-  const float* Ap = A + (long)(m0 + lr) * lda + lk;
-  const float* Wp = W + (long)(n0 + lr) * ldw + lk;
+  // staging coordinates
+  const int lk = (tid & 15) * 4, lr = tid >> 4;      // [row][k]: 16 lanes cover one 256-B row segment, rows lr + 16 i
+  const int amk = tid / (BM / 4), am4 = (tid % (BM / 4)) * 4;   // [k][row]: k rows amk + ARP i, 4 rows at am4
+  const int bnk = tid / (BN / 4), bn4 = (tid % (BN / 4)) * 4;
+  const float* Ap = A_KC ? p.A + (long)(m0 + lr) * p.lda + kbeg + lk : p.A + (long)(kbeg + amk) * p.lda + m0 + am4;
+  const float* Wp = B_KC ? p.W + (long)(n0 + lr) * p.ldw + kbeg + lk : p.W + (long)(kbeg + bnk) * p.ldw + n0 + bn4;
+  const long astep = A_KC ? 16 * p.lda : (long)ARP * p.lda, akstep = A_KC ? 64 : 64 * p.lda;
+  const long bstep = B_KC ? 16 * p.ldw : (long)BRP * p.ldw, bkstep = B_KC ? 64 : 64 * p.ldw;
   f32x4 ra[AV], rb[BV];
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -43,35 +56,57 @@ __device__ __forceinline__ void gemm_tile_body(const float* __restrict__ A, cons
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
 
-  const int nk = K / 64;
   MMEGO_STAMP_AT(sid, 0, tid == 0);
+  if (nk > 0) {
 #pragma unroll
-  for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(Ap + (long)(16 * i) * lda);
+    for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(Ap + i * astep);
 #pragma unroll
-  for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wp + (long)(16 * i) * ldw);
+    for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wp + i * bstep);
+  }
   const int r = lane & 31, h = lane >> 5;
   MMEGO_STAMP_AT(sid, 1, tid == 0);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();                                  // previous chunk's operand reads are done
 #pragma unroll
-    for (int i = 0; i < AV; ++i) *reinterpret_cast<f32x4*>(&As[lr + 16 * i][lk]) = ra[i];
+    for (int i = 0; i < AV; ++i) {
+      if (A_KC) *reinterpret_cast<f32x4*>(&As[(lr + 16 * i) * TLD + lk]) = ra[i];
+      else *reinterpret_cast<f32x4*>(&As[(amk + ARP * i) * ALD + am4]) = ra[i];
+    }
 #pragma unroll
-    for (int i = 0; i < BV; ++i) *reinterpret_cast<f32x4*>(&Bs[lr + 16 * i][lk]) = rb[i];
+    for (int i = 0; i < BV; ++i) {
+      if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(lr + 16 * i) * TLD + lk]) = rb[i];
+      else *reinterpret_cast<f32x4*>(&Bs[(bnk + BRP * i) * BLD + bn4]) = rb[i];
+    }
     __syncthreads();
     if (kt + 1 < nk) {
-      const int k0 = (kt + 1) * 64;
+      const float* An = Ap + (kt + 1) * akstep;
+      const float* Wn = Wp + (kt + 1) * bkstep;
 #pragma unroll
-      for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(Ap + (long)(16 * i) * lda + k0);
+      for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(An + i * astep);
 #pragma unroll
-      for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wp + (long)(16 * i) * ldw + k0);
+      for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wn + i * bstep);
     }
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
       f32x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[wm * WM + i * 32 + r][kb * 8 + 4 * h]);
+      for (int i = 0; i < TM; ++i) {
+        if (A_KC) {
+          a[i] = *reinterpret_cast<const f32x4*>(&As[(wm * WM + i * 32 + r) * TLD + kb * 8 + 4 * h]);
+        } else {
+          const float* q = &As[(kb * 8 + 4 * h) * ALD + wm * WM + i * 32 + r];
+          a[i] = (f32x4){q[0], q[ALD], q[2 * ALD], q[3 * ALD]};
+        }
+      }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bs[wn * WN + j * 32 + r][kb * 8 + 4 * h]);
+      for (int j = 0; j < TN; ++j) {
+        if (B_KC) {
+          b[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn * WN + j * 32 + r) * TLD + kb * 8 + 4 * h]);
+        } else {
+          const float* q = &Bs[(kb * 8 + 4 * h) * BLD + wn * WN + j * 32 + r];
+          b[j] = (f32x4){q[0], q[BLD], q[2 * BLD], q[3 * BLD]};
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -92,10 +127,14 @@ __device__ __forceinline__ void gemm_tile_body(const float* __restrict__ A, cons
   }
   MMEGO_STAMP_AT(sid, 2, tid == 0);
 
+  const bool slab = p.nsplit > 1;
+  float* C = slab ? p.ws + (long)split * p.M * p.N : p.C;
+  const long ldc = slab ? (long)p.N : p.ldc;
+  const bool relu = !slab && p.relu, accumulate = !slab && p.accumulate;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WN + j * 32 + (lane & 31);
-    const float bv = bias ? bias[col] : 0.0f;
+    const float bv = (!slab && p.bias) ? p.bias[col] : 0.0f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -103,7 +142,9 @@ __device__ __forceinline__ void gemm_tile_body(const float* __restrict__ A, cons
         int row = m0 + wm * WM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         float v = acc[i][j][reg] + bv;
         if (relu) v = fmaxf(v, 0.0f);
-        C[(long)row * ldc + col] = v;
+        float* dst = C + (long)row * ldc + col;
+        if (accumulate) v += *dst;
+        *dst = v;
       }
     }
   }
@@ -113,99 +154,106 @@ __device__ __forceinline__ void gemm_tile_body(const float* __restrict__ A, cons
 // XCD-aware tile order: blocks b and b+8 share an XCD; hand each XCD a contiguous run of tile ids
 __device__ __forceinline__ int xcd_order(int id, int n) { return (n & 7) == 0 ? (id & 7) * (n >> 3) + (id >> 3) : id; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                        float* __restrict__ C, const float* __restrict__ bias, int M, int N,
-                                                        int K, long lda, long ldw, long ldc, int relu) {
+// work unit u = split * tiles + tile
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(TileP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int ntn = N / BN, nwg = ntn * (M / BM);
-  const int id = xcd_order(blockIdx.x, nwg);
-  gemm_tile_body<BM, BN, WAVES_M, WAVES_N>(A, W, C, bias, K, lda, ldw, ldc, relu, (id / ntn) * BM, (id % ntn) * BN, smem, id);
+  const int ntn = p.N / BN, tiles = ntn * (p.M / BM);
+  const int u = xcd_order(blockIdx.x, (int)gridDim.x);
+  const int split = u / tiles, id = u % tiles;
+  gemm_tile_body<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC>(p, (id / ntn) * BM, (id % ntn) * BN, split, smem, u);
 }
 
 // Persistent, tail-balanced launch for outputs of more than one wave of co-resident workgroups.  The grid is exactly the
-// 512 co-resident workgroups (2 per CU); workgroup w walks a STATIC tile list, so no CU can end up with an extra tile
-// (measured with per-workgroup stamps: the hardware dispatcher hands freed slots out greedily and 1-3 CUs regularly
-// received 6 of the 1280 tiles of the 10240 x 2048 projections instead of 5: 383 us instead of 330).  When the tile
-// count leaves at most half a wave of workgroups over, those tiles are cut into two 128x64 halves, one per workgroup:
-// the tail costs half a tile time (2.5 tile times per workgroup for 1280 tiles, not 3).  Per output element the
-// arithmetic is the plain kernel's (bit-identical result).
-__global__ __launch_bounds__(256) void gemm_tile_persistent_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                                   float* __restrict__ C, const float* __restrict__ bias, int M,
-                                                                   int N, int K, long lda, long ldw, long ldc, int relu, int nfull,
-                                                                   int nhalf, int stagger) {
+// 512 co-resident workgroups (2 per CU); workgroup w walks a STATIC list of work units, so no CU can end up with an
+// extra tile (measured with per-workgroup stamps: the hardware dispatcher hands freed slots out greedily and 1-3 CUs
+// regularly received 6 of the 1280 tiles of the 10240 x 2048 projections instead of 5: 383 us instead of 330).  When the
+// unit count leaves at most half a wave of workgroups over, those units are cut into two 128x64 halves, one per
+// workgroup: the tail costs half a tile time (2.5 tile times per workgroup for 1280 tiles, not 3).  Per output element
+// the arithmetic is the plain kernel's (bit-identical result).
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_tile_persistent_kernel(TileP p, int nfull, int nhalf, int stagger) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int ntn = N / 128, G = (int)gridDim.x;
-  const int w = xcd_order(blockIdx.x, G);                  // each XCD walks a contiguous run of tile ids per round
+  const int ntn = p.N / 128, tiles = ntn * (p.M / 128), G = (int)gridDim.x;
+  const int w = xcd_order(blockIdx.x, G);                  // each XCD walks a contiguous run of unit ids per round
   // The two workgroups of a CU (blocks b and b + G/2) start together and would reach their store epilogues together,
   // leaving the matrix pipe idle; the second one therefore runs its half tile FIRST, which keeps the pair out of phase.
   const bool halves_first = (int)blockIdx.x >= G / 2 && stagger;
   if (halves_first)
     for (int q = w; q < nhalf; q += G) {
-      const int id = nfull + (q >> 1);
-      gemm_tile_body<128, 64, 2, 2>(A, W, C, bias, K, lda, ldw, ldc, relu, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, smem, nfull + q);
+      const int u = nfull + (q >> 1), id = u % tiles;
+      gemm_tile_body<128, 64, 2, 2, A_KC, B_KC>(p, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, u / tiles, smem, nfull + q);
     }
-  for (int id = w; id < nfull; id += G)
-    gemm_tile_body<128, 128, 2, 2>(A, W, C, bias, K, lda, ldw, ldc, relu, (id / ntn) * 128, (id % ntn) * 128, smem, id);
+  for (int u = w; u < nfull; u += G) {
+    const int id = u % tiles;
+    gemm_tile_body<128, 128, 2, 2, A_KC, B_KC>(p, (id / ntn) * 128, (id % ntn) * 128, u / tiles, smem, u);
+  }
   if (!halves_first)
     for (int q = w; q < nhalf; q += G) {
-      const int id = nfull + (q >> 1);
-      gemm_tile_body<128, 64, 2, 2>(A, W, C, bias, K, lda, ldw, ldc, relu, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, smem, nfull + q);
+      const int u = nfull + (q >> 1), id = u % tiles;
+      gemm_tile_body<128, 64, 2, 2, A_KC, B_KC>(p, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, u / tiles, smem, nfull + q);
     }
 }
 
 namespace mmego_detail {
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-static int launch_cfg(hipStream_t st, const float* A, const float* W, float* C, const float* bias, int M, int N, int K, long lda,
-                      long ldw, long ldc, int relu) {
+template <int BM, int BN, bool A_KC, bool B_KC>
+static int launch_plain(hipStream_t st, const TileP& p) {
   static bool attr_set = false;
   const size_t lds = (size_t)((BM + BN) * TLD) * sizeof(float);
   if (!attr_set && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<BM, BN, 2, 2, A_KC, B_KC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, WAVES_M, WAVES_N>), dim3((unsigned)((M / BM) * (N / BN))), dim3(256), lds, st, A, W, C,
-                     bias, M, N, K, lda, ldw, ldc, relu);
+  const unsigned units = (unsigned)((p.M / BM) * (p.N / BN) * p.nsplit);
+  hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, 2, 2, A_KC, B_KC>), dim3(units), dim3(256), lds, st, p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
 
-// returns 0 on launch, -2 if the shape does not fit this kernel (caller falls back), >0 on a HIP error.
-// Tile choice: the configuration with the fewest (waves of co-resident workgroups) x (tile area).  A 160x128 tile
-// (1024 tiles = exactly 2 waves of 512 for the 10240 x 2048 LSTM projections, vs 2.5 -> 3 waves of 128x128) was measured
-// 3-4 % SLOWER (1x4 wave layout: 6 operand reads per 5 MFMAs), so it is not in the list.
-int gemm_tile_launch(hipStream_t st, const float* A, const float* W, float* C, const float* bias, int M, int N, int K,
-                     long lda, long ldw, long ldc, int relu) {
-  if ((K % 64) != 0 || (M % 64) != 0 || (N % 64) != 0) return -2;
-  // 128x128 whenever it yields enough tiles to occupy the 256 CUs (measured: 128x128 runs the 10240 x 2048 projections
-  // at 93-109 TFLOP/s, 64x64 at 88-97), else 64x64 (e.g. M = 512: 23.6 us vs 84 us with 64 big tiles).
-  const bool big_ok = (M % 128) == 0 && (N % 128) == 0 && (long)(M / 128) * (N / 128) >= 192;
+template <bool A_KC, bool B_KC>
+static int launch_layout(hipStream_t st, const TileP& p) {
+  // 128x128 whenever it yields enough work units to occupy the 256 CUs (measured: 128x128 runs the 10240 x 2048
+  // projections at 93-109 TFLOP/s, 64x64 at 88-97), else 64x64 (e.g. M = 512: 23.6 us vs 84 us with 64 big tiles).
+  // A 160x128 tile (1024 tiles = exactly 2 waves of 512 for those projections) was measured 3-4 % SLOWER (1x4 wave
+  // layout: 6 operand reads per 5 MFMAs), so it is not in the list.
+  const long units128 = (long)(p.M / 128) * (p.N / 128) * p.nsplit;
+  const bool big_ok = (p.M % 128) == 0 && (p.N % 128) == 0 && units128 >= 192;
   if (big_ok) {
-    const int tiles = (M / 128) * (N / 128), slots = 512;      // 2 workgroups per CU x 256 CUs
+    const int units = (int)units128, slots = 512;               // 2 workgroups per CU x 256 CUs
     static const bool no_persist = getenv("MMEGO_GEMM_NO_PERSIST") != nullptr;
     static const int stagger = getenv("MMEGO_GEMM_NO_STAGGER") == nullptr;
-    if (tiles > slots && !no_persist) {
-      const int rest = tiles % slots;
+    if (units > slots && !no_persist) {
+      const int rest = units % slots;
       const bool halves = rest > 0 && rest <= slots / 2;
-      const int nfull = halves ? tiles - rest : tiles, nhalf = halves ? 2 * rest : 0;
+      const int nfull = halves ? units - rest : units, nhalf = halves ? 2 * rest : 0;
       static bool attr_set = false;
       const size_t lds = (size_t)(256 * TLD) * sizeof(float);
       if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_persistent_kernel<A_KC, B_KC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
       }
-      hipLaunchKernelGGL(gemm_tile_persistent_kernel, dim3(slots), dim3(256), lds, st, A, W, C, bias, M, N, K, lda, ldw, ldc, relu,
-                         nfull, nhalf, stagger);
+      hipLaunchKernelGGL((gemm_tile_persistent_kernel<A_KC, B_KC>), dim3(slots), dim3(256), lds, st, p, nfull, nhalf, stagger);
       hipError_t e = hipGetLastError();
       return e == hipSuccess ? 0 : (int)e;
     }
-    return launch_cfg<128, 128, 2, 2>(st, A, W, C, bias, M, N, K, lda, ldw, ldc, relu);
+    return launch_plain<128, 128, A_KC, B_KC>(st, p);
   }
-  return launch_cfg<64, 64, 2, 2>(st, A, W, C, bias, M, N, K, lda, ldw, ldc, relu);
+  return launch_plain<64, 64, A_KC, B_KC>(st, p);
+}
+
+// returns 0 on launch, -2 if the shape does not fit these kernels (caller falls back), >0 on a HIP error.
+int gemm_tile_launch(hipStream_t st, const TileP& p, bool a_kc, bool b_kc) {
+  if ((p.K % 64) != 0 || (p.M % 64) != 0 || (p.N % 64) != 0 || p.nsplit < 1) return -2;
+  if (p.nsplit > 1 && ((p.kchunk % 64) != 0 || p.ws == nullptr)) return -2;
+  if (a_kc && b_kc) return launch_layout<true, true>(st, p);
+  if (a_kc) return launch_layout<true, false>(st, p);
+  if (b_kc) return launch_layout<false, true>(st, p);
+  return launch_layout<false, false>(st, p);
 }
 
 }  // namespace mmego_detail

@@ -1,8 +1,9 @@
 """IMU_Net stage-1 training on the HIP path: stashing forward, backward through the two BiLSTM(512) stacks,
 geodesic + position loss.  Reference: Net/IMU_Net.py:67-94, Processor/Train/Train_IMU.py:21-34,114-149.
 
-Correctness-first round-1 version: the recurrent products of the backward pass run as mmego_gemm calls (one per
-timestep and direction against a per-step transposed W_hh), weight gradients as split-K GEMMs.
+The recurrent products of the backward pass run as split-K mmego_gemm calls (one per timestep and direction against a
+per-layer transposed W_hh); input and weight gradients of the projections run on the large-tile kernels in their
+natural operand orientation (dX = dY . W: NN, dW = dY^T . X: TN).
 """
 import torch
 
@@ -64,9 +65,10 @@ def lstm_steps_backward(ar, key, lstm, x, Bn, T, dout, G, need_dx):
                      None if last else dhrec[0], None if last else dhrec[1], gst[0, t0], gst[1, t1], cst[0, t0], cst[1, t1],
                      cst[0, t0 - 1] if s > 0 else None, cst[1, t1 + 1] if s > 0 else None, dc[0], dc[1],
                      dg3[:, t0, :4 * H], dg3[:, t1, 4 * H:], T * 8 * H)
-            if s > 0:                                               # dh_{t-1} = dgates_t . W_hh
-                ops.linear(dg3[:, t0, :4 * H], wT[0], None, dhrec[0])
-                ops.linear(dg3[:, t1, 4 * H:], wT[1], None, dhrec[1])
+            if s > 0:                                               # dh_{t-1} = dgates_t . W_hh  (on the serial chain: split-K)
+                ns = ops.chain_split(Bn, H, 4 * H)
+                ops.mm(dg3[:, t0, :4 * H], wT[0].t(), dhrec[0], nsplit=ns)
+                ops.mm(dg3[:, t1, 4 * H:], wT[1].t(), dhrec[1], nsplit=ns)
         hp = ar.get("%s.hp" % key, (Bn * T, H))
         for d in range(2):
             dgd = dg[:, d * 4 * H:(d + 1) * 4 * H]

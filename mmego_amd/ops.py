@@ -142,6 +142,13 @@ def pick_split(M, N, K):
     return int(max(1, min(want, K // _SPLIT_K_MIN)))
 
 
+def chain_split(M, N, K):
+    """Split-K factor for a product on a serial critical path (the recurrent dh = dgates . W_hh of the LSTM backward): few
+    output tiles and a long K, so the K range is cut until about one workgroup per CU is busy (>= 512 k per slab)."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    return int(max(1, min(256 // max(tiles, 1), K // 512)))
+
+
 def grad_weight(dY, X, dW):
     """dW[N,K] = dY[rows,N]^T @ X[rows,K]  (fixed-order split over rows)."""
     W2 = dW.view(dW.shape[0], -1)

@@ -352,6 +352,7 @@ class ImuTrainer(_Base):
         self._loss = torch.zeros(1, device=self.device)
         self.start_epoch, self._resume = 0, None
         self._train_dev = None
+        self._steps = {}
 
     def _loss_and_grads(self, R, t, R_gt, head, want_grad):
         F = R.shape[0] * R.shape[1]
@@ -361,8 +362,7 @@ class ImuTrainer(_Base):
         return dR, dt
 
     def train_imu_once(self):
-        from . import imu_train
-        from .train_step import allreduce_grads
+        from .train_step import ImuStep
         self.model_IMU.train()
         losses = []
         pg = torch.distributed.group.WORLD if self.world > 1 else None
@@ -373,15 +373,16 @@ class ImuTrainer(_Base):
             if len(idx) == 0:
                 continue
             b = self._train_dev.gather(idx)
-            imu_d, tgt, Rg = b["imu"], b["target"], b["R_R0R"]
-            B, T = imu_d.shape[0], imu_d.shape[1]
-            with torch.no_grad():
-                R, t = imu_train.forward_train(self.model_IMU, imu_d)
-                dR, dt = self._loss_and_grads(R, t, Rg, tgt[:, :, 20], True)
-                imu_train.backward(self.model_IMU, dR, dt)
-            allreduce_grads(self.model_IMU._flat, pg)
-            self.optimizer_IMU.step()
-            losses.append(self._loss.item() / B / T)
+            B, T = b["imu"].shape[0], b["imu"].shape[1]
+            st = self._steps.get(B)
+            if st is None:                                              # one graph per minibatch size, one optimiser
+                st = ImuStep(self.model_IMU, lr=self.learning_rate, weight_decay=0.001, process_group=pg, use_graph=True)
+                st.opt = self.optimizer_IMU
+                self._steps[B] = st
+            if st.static is None or st.static["imu"].data_ptr() != b["imu"].data_ptr():
+                st.bind(b["imu"], b["R_R0R"], b["target"])
+            st.step()
+            losses.append(st.loss.item() / B / T)
         return float(np.mean(losses))
 
     def eval_imu(self):

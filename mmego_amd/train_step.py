@@ -112,6 +112,57 @@ class StageStep:
         return self.loss
 
 
+class ImuStep:
+    """Stage-1 per-minibatch body (reference Processor/Train/Train_IMU.py:114-149): IMU_Net forward, geodesic + 100 x
+    position loss (sum), backward through the two BiLSTM(512) stacks, Adam with coupled weight decay -- with static
+    buffers, capturable into one HIP graph (the eager body is ~650 launches and CPU-launch bound)."""
+
+    def __init__(self, net, lr=1e-4, weight_decay=0.001, process_group=None, use_graph=True):
+        self.net = net
+        self.opt = FusedAdam(net.flat(), lr=lr, weight_decay=weight_decay)
+        self.pg = process_group
+        self.use_graph = use_graph
+        self.graph = None
+        self.static = None
+        dev = next(net.parameters()).device
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def bind(self, imu, R_gt, target):
+        dev = imu.device
+        B, T = imu.shape[0], imu.shape[1]
+        self.static = dict(imu=imu, R_gt=R_gt, target=target, head=torch.empty(B, T, 3, device=dev),
+                           dR=torch.empty(B, T, 3, 3, device=dev), dt=torch.empty(B, T, 3, device=dev))
+        self.graph = None
+
+    def _body(self):
+        from . import imu_train
+        s = self.static
+        B, T = s["imu"].shape[0], s["imu"].shape[1]
+        with torch.no_grad():
+            ops.copy2d(s["target"].view(B * T, 63)[:, 60:63], s["head"].view(B * T, 3))     # head joint = joint 20
+            R, t = imu_train.forward_train(self.net, s["imu"])
+            hip.call("imu_loss", R, t, s["R_gt"], s["head"], B * T, 1.0, self.loss, s["dR"], s["dt"])
+            imu_train.backward(self.net, s["dR"], s["dt"])
+
+    def step(self):
+        if self.use_graph:
+            if self.graph is None:
+                keep = self.net.seed_counter().clone()
+                self._body()                                   # warm-up (side-effect free: IMU_Net has no BatchNorm)
+                torch.cuda.synchronize()
+                self.net.seed_counter().copy_(keep)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body()
+                self.graph = g
+            self.graph.replay()
+        else:
+            self._body()
+        allreduce_grads(self.net._flat, self.pg)
+        self.opt.step()
+        return self.loss
+
+
 class ConcurrentStages:
     """Several INDEPENDENT stage bodies per minibatch as concurrent branches of one HIP graph.
 

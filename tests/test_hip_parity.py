@@ -52,6 +52,28 @@ def test_gemm_variants(dev):
         dW = torch.empty(N, K, device=dev)
         ops.grad_weight(dY.to(dev), A.to(dev), dW)
         assert torch.allclose(dW.cpu().double(), dY.double().t() @ A.double(), rtol=1e-5, atol=1e-4 * M ** 0.5)
+    # large-tile kernels in every operand orientation (NT / NN / TN / TT), column-slice operands, accumulate, relu + bias,
+    # split-K slabs, 128x128 persistent + 128x64 half tiles (M x N = 2304 x 2048 -> 288 tiles ... 10240 x 1024 -> 640 units)
+    for M, N, K, nsplit in ((512, 256, 192, 1), (1024, 640, 128, 1), (256, 128, 1536, 4), (2048, 1024, 256, 3), (5120, 2048, 128, 1)):
+        Ad, Bd = torch.randn(M, K + 8, generator=g).to(dev), torch.randn(K, N + 4, generator=g).to(dev)
+        At, Bt = Ad[:, 4:K + 4].t().contiguous(), Bd[:, :N].t().contiguous()        # [K, M], [N, K]
+        bias = torch.randn(N, generator=g).to(dev)
+        ref = Ad[:, 4:K + 4].double() @ Bd[:, :N].double()
+        tol = dict(rtol=1e-5, atol=2e-5 * K ** 0.5)
+        for a_kc in (True, False):
+            for b_kc in (True, False):
+                Aop = Ad[:, 4:K + 4] if a_kc else At.t()            # [M, K] view: k- or m-contiguous
+                Bop = Bt.t() if b_kc else Bd[:, :N]                 # [K, N] view: k- or n-contiguous
+                C = torch.zeros(M, N + 64, device=dev)
+                ops.mm(Aop, Bop, C[:, 64:], nsplit=nsplit)
+                assert torch.allclose(C[:, 64:].double(), ref, **tol), (M, N, K, nsplit, a_kc, b_kc)
+                assert (C[:, :64] == 0).all()
+        C0 = torch.randn(M, N, generator=g).to(dev)
+        C = C0.clone()
+        ops.mm(Ad[:, 4:K + 4], Bd[:, :N], C, accumulate=True)
+        assert torch.allclose(C.double(), C0.double() + ref, **tol), (M, N, K, "accumulate")
+        ops.mm(At.t(), Bt.t(), C, bias=bias, relu=True, nsplit=nsplit)
+        assert torch.allclose(C.double(), torch.relu(ref + bias.double()), **tol), (M, N, K, "bias+relu")
     # relu + accumulate + batched broadcast
     A, B = torch.randn(7, 15, 15, generator=g), torch.randn(7, 15, 40, generator=g)
     C = torch.randn(7, 15, 40, generator=g)
