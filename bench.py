@@ -234,6 +234,26 @@ def main():
             tu_s.append(ev[0].elapsed_time(ev[1])); tl_s.append(ev[1].elapsed_time(ev[2]))
     t_u, t_l = sorted(tu_s)[len(tu_s) // 2], sorted(tl_s)[len(tl_s) // 2]
 
+    # "IMU-shared" variant: one IMU_Net forward per minibatch feeds both bodies.  Extra figure, not `value`.
+    from mmego_amd.train_step import SharedImuStages
+    su_s = StageStep("upper", upper, None, lr=3e-5, process_group=pg, use_graph=False)
+    sl_s = StageStep("lower", lower, None, upper_frozen=upper_frozen, lr=3e-5, process_group=pg, use_graph=False)
+    shared = SharedImuStages(imu, [su_s, sl_s], imu_in, use_graph=not args.no_graph)
+    su_s.bind(x, imu_in, body, target)
+    sl_s.bind(x, imu_in, body, target)
+    for _ in range(3):
+        shared.step()
+    sync()
+    t0s = time.perf_counter()
+    for _ in range(args.steps):
+        shared.step()
+    sync()
+    dt_shared = time.perf_counter() - t0s
+    if world > 1:
+        tt = torch.tensor([dt_shared], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt_shared = tt.item()
+
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -247,6 +267,8 @@ def main():
                                                                   "as concurrent branches of one HIP graph"),
                           "global_batch": world * B, "seq_len": T, "points": N, "parallelism": "dp%d" % world,
                           "hip_graph": not args.no_graph, "stages_concurrent": not args.sequential},
+               "ms_per_step_imu_shared": dt_shared / args.steps * 1e3,
+               "frames_per_s_imu_shared": world * B * T / (dt_shared / args.steps),
                "ms_per_step_sequential": t_u + t_l, "frames_per_s_sequential": world * B * T / ((t_u + t_l) * 1e-3),
                "t_upper_ms": t_u, "t_lower_ms": t_l, "loss_upper": loss_u, "loss_lower": loss_l}
 

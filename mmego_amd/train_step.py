@@ -33,9 +33,10 @@ class StageStep:
     frozen IMU_Net -- the shipped reference snapshot has no IMU_Net checkpoint."""
 
     def __init__(self, stage, net, imu_net, upper_frozen=None, lr=3e-5, weight_decay=0.0, process_group=None,
-                 use_graph=True):
+                 use_graph=True, pose=None):
         assert stage in ("upper", "lower")
         self.stage, self.net, self.imu, self.upper_frozen = stage, net, imu_net, upper_frozen
+        self.pose = pose              # (R, t) device buffers filled by somebody else (the "IMU-shared" arrangement)
         self.opt = FusedAdam(net.flat(), lr=lr, weight_decay=weight_decay)
         self.pg = process_group
         self.use_graph = use_graph
@@ -51,7 +52,9 @@ class StageStep:
         B, T = s["x"].shape[0], s["x"].shape[1]
         ops.copy2d(s["x_src"].view(B * T, -1), s["x"].view(B * T, -1))        # fresh batch (x is transformed in place)
         with torch.no_grad():
-            if self.imu is not None:
+            if self.pose is not None:
+                R, t = self.pose
+            elif self.imu is not None:
                 R, t = self.imu(s["imu"])
             else:
                 R, t = s["R_gt"], s["t_gt"]
@@ -73,7 +76,7 @@ class StageStep:
         dev = x.device
         B, T = x.shape[0], x.shape[1]
         nsel = 15 if self.stage == "upper" else 8
-        if self.imu is None and R_gt is None:
+        if self.imu is None and R_gt is None and self.pose is None:
             raise ValueError("StageStep without an IMU_Net needs the recorded head rotations (R_gt)")
         self.static = dict(x_src=x, x=torch.empty_like(x), imu=imu, body=body, target=target,
                            h0=torch.zeros(6, B, 64, device=dev), c0=torch.zeros(6, B, 64, device=dev),
@@ -161,6 +164,52 @@ class ImuStep:
         allreduce_grads(self.net._flat, self.pg)
         self.opt.step()
         return self.loss
+
+
+class SharedImuStages:
+    """The "IMU-shared" arrangement of SURVEY 8-d: ONE frozen IMU_Net forward per minibatch feeds both stage bodies (they
+    run as two concurrent branches after it).  Not what the reference does (each stage program runs its own IMU_Net
+    forward); reported beside the literal U+L step."""
+
+    def __init__(self, imu_net, stages, imu_in, use_graph=True):
+        self.imu, self.stages, self.imu_in = imu_net, list(stages), imu_in
+        B, T = imu_in.shape[0], imu_in.shape[1]
+        dev = imu_in.device
+        self.R, self.t = torch.empty(B, T, 3, 3, device=dev), torch.empty(B, T, 3, device=dev)
+        for st in self.stages:
+            st.pose = (self.R, self.t)
+        self.pair = ConcurrentStages(self.stages, use_graph=False)
+        self.use_graph, self.graph = use_graph, None
+
+    def _body(self):
+        with torch.no_grad():
+            R, t = self.imu(self.imu_in)
+            ops.copy2d(R.view(-1, 9), self.R.view(-1, 9))
+            ops.copy2d(t.view(-1, 3), self.t.view(-1, 3))
+        self.pair._bodies()
+
+    def step(self):
+        if self.use_graph:
+            if self.graph is None:
+                keep = [[t.clone() for t in st._mutable_state()] for st in self.stages]
+                for _ in range(2):
+                    self._body()
+                    torch.cuda.synchronize()
+                for st, ks in zip(self.stages, keep):
+                    for t, k in zip(st._mutable_state(), ks):
+                        t.copy_(k)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body()
+                self.graph = g
+            self.graph.replay()
+        else:
+            self._body()
+        for st in self.stages:
+            allreduce_grads(st.net._flat, st.pg)
+        for st in self.stages:
+            st.opt.step()
 
 
 class ConcurrentStages:

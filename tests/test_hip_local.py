@@ -254,6 +254,39 @@ def test_concurrent_stages_equal_sequential(dev):
         ConcurrentStages([su, sl])
 
 
+def test_shared_imu_stages_equal_separate_forwards(dev):
+    """train_step.SharedImuStages (one IMU_Net forward feeding both stage bodies) == each stage running its own IMU_Net
+    forward with the same weights: identical losses, gradients and parameters after two steps."""
+    from mmego_amd import nets
+    from mmego_amd.train_step import SharedImuStages, StageStep
+    g = golden("g6_train.npz")
+    x0, body, target = [T(g[k]).to(dev) for k in ("x", "body", "target")]
+    torch.manual_seed(5)
+    imu_in = torch.randn(4, 8, 20, 15, device=dev)
+
+    def build(own_imu):
+        torch.manual_seed(92)
+        imu = nets.IMUNet(15, 9, 64, 2, True, 0.1).to(dev).eval()
+        imu2 = nets.IMUNet(15, 9, 64, 2, True, 0.1).to(dev).eval()
+        imu2.load_state_dict(imu.state_dict())
+        up, lo, fr = nets.UpperNet().to(dev).train(), nets.LowerNet(64).to(dev).train(), nets.UpperNet().to(dev).eval()
+        su = StageStep("upper", up, imu if own_imu else None, lr=3e-5, use_graph=False)
+        sl = StageStep("lower", lo, imu2 if own_imu else None, upper_frozen=fr, lr=3e-5, use_graph=False)
+        shared = None if own_imu else SharedImuStages(imu, [su, sl], imu_in, use_graph=False)
+        for st in (su, sl):
+            st.bind(x0.clone(), imu_in, body, target)
+        return su, sl, shared
+    ru, rl, _ = build(True)
+    su, sl, shared = build(False)
+    for _ in range(2):
+        ru.step(); rl.step()
+        shared.step()
+    torch.cuda.synchronize()
+    for a, b in ((su, ru), (sl, rl)):
+        assert a.loss.item() == b.loss.item(), a.stage
+        assert torch.equal(a.net.flat().flat_g, b.net.flat().flat_g) and torch.equal(a.net.flat().flat_p, b.net.flat().flat_p), a.stage
+
+
 def test_device_resident_minibatches(dev):
     """mmego_gather_rows / data.DeviceArrays: minibatches gathered on the device equal numpy fancy indexing followed by the
     reference's float64 -> float32 conversion (bit-exact), repeated and out-of-range indices included."""
