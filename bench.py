@@ -303,7 +303,7 @@ def main():
         g64 = [(ms_, 2.0 * a[10] * a[11] * a[12]) for ms_, a in rec["gemm"] if is_nt_aligned(a) and not is_tile128(a)]
         cands = {}
         if big:
-            cands["lstm_step_dma_kernel (IMU_Net rnn_fast recurrent steps: 2 dirs x 512 rows x 2048 gates x K=512 per launch)"] = big
+            cands["lstm_step_dma2_kernel (IMU_Net rnn_fast recurrent steps: 2 dirs x 512 rows x 2048 gates x K=512 per launch)"] = big
         if small:
             cands["lstm_step_small_kernel (IMU_Net rnn_slow recurrent steps: 2 dirs x 64 rows x 2048 gates x K=512)"] = small
         if g128:

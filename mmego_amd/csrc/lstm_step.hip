@@ -712,6 +712,171 @@ __global__ __launch_bounds__(512) void lstm_step_dma_kernel(LstmStepP p) {
   __syncthreads();                                       // (E)
 }
 
+// ---- LDS-DMA variant with a 72 KB footprint: TWO workgroups per CU -----------------------------------------------------
+// Same tile and DMA scheme as lstm_step_dma_kernel, but 32-k chunks (three 24-KB stages) and no xproj / c tiles in LDS:
+// the compute waves fetch their own xproj / c_{t-1} elements straight into registers at kernel start and consume them
+// AFTER the product (gates = h.W^T + xproj + b).  With 72 KB and <= 128 VGPRs two workgroups share a CU.  That matters
+// when independent step kernels exist (the two concurrent stage programs each run an IMU_Net forward): while one waits for
+// its first operands, its barriers or its stores, the other owns the matrix pipe -- and kernels of other branches with
+// modest LDS needs can co-reside as well.
+//   stage image: A 64 rows x 32 k, W 128 rows x 32 k, unpadded 128-B rows of 8 16-B pieces; piece p of row r is stored at
+//   piece p ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 phase (rows fr = 0..15, same piece) hit 16 distinct 4-bank groups.
+#define D2_KC 32
+#define D2_STAGE_FLOATS (192 * D2_KC)
+#define D2_LDS_FLOATS (3 * D2_STAGE_FLOATS)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void lstm_step_dma2_kernel(LstmStepP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loader = wave >= 4;
+  const int H = p.H;
+  const int nrb = (p.Bn + 63) / 64, nht = H / 32, npairs = p.ndir * nht;
+  int pair, rb;
+  {
+    const int wg = blockIdx.x;
+    if ((npairs & 7) == 0) {
+      const int xcd = wg & 7, q = wg >> 3;
+      pair = xcd + 8 * (q / nrb);
+      rb = q % nrb;
+    } else {
+      pair = wg / nrb;
+      rb = wg % nrb;
+    }
+  }
+  const int d = pair / nht, ht = pair % nht;
+  const int j0 = ht * 32, r0 = rb * 64;
+  const bool first = p.first != 0;
+  const int nk = first ? 0 : H / D2_KC;
+  float* const OUT = smem + (nk % 3) * D2_STAGE_FLOATS;   // new c tile [64][CLD], then new h tile [64][CLD] (4608 floats)
+  MMEGO_STAMP_AT(blockIdx.x, 0, tid == 0);
+
+  if (loader) {
+    const int lw = wave - 4, q8 = lane >> 3, sl = lane & 7;
+    const int rmax = p.Bn - 1 - r0;                       // rows past the batch read a valid row (their results are dropped)
+    const float* ag[2];
+    const float* wg_[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ra = 8 * (lw + 4 * i) + q8;
+      ag[i] = first ? nullptr : p.hprev[d] + (long)(r0 + min(ra, rmax)) * p.hps + 4 * (sl ^ ((ra >> 1) & 7));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rw = 8 * (lw + 4 * j) + q8;
+      wg_[j] = p.whh[d] + ((long)(rw >> 5) * H + j0 + (rw & 31)) * H + 4 * (sl ^ ((rw >> 1) & 7));
+    }
+#define D2_CHUNK(kt)                                                                                        \
+  do {                                                                                                      \
+    float* st_ = smem + ((kt) % 3) * D2_STAGE_FLOATS;                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) GLDS16(ag[i] + (kt) * D2_KC, st_ + 8 * (lw + 4 * i) * 32); \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) GLDS16(wg_[j] + (kt) * D2_KC, st_ + 2048 + 8 * (lw + 4 * j) * 32); \
+  } while (0)
+    if (nk > 0) {
+      D2_CHUNK(0);
+      if (nk > 1) D2_CHUNK(1);
+      if (nk > 2) D2_CHUNK(2);
+      if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                         // (1) chunk 0 is in LDS
+    for (int kt = 0; kt + 1 < nk; ++kt) {                 // B_kt: chunk kt+1 has landed; stage kt % 3 may be refilled
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 3 < nk) D2_CHUNK(kt + 3);
+    }
+    __builtin_amdgcn_s_barrier();                         // (E) new c / h tiles are in OUT
+    {
+      const int lt = tid - 256, xr = lt >> 2, xq = (lt & 3) * 8;
+      if ((r0 + xr) < p.Bn) {
+        float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
+        *reinterpret_cast<f32x4*>(crow) = *reinterpret_cast<const f32x4*>(OUT + xr * CLD + xq);
+        *reinterpret_cast<f32x4*>(crow + 4) = *reinterpret_cast<const f32x4*>(OUT + xr * CLD + xq + 4);
+        float* hrow = p.hout[d] + (long)(r0 + xr) * p.hos + j0 + xq;
+        *reinterpret_cast<f32x4*>(hrow) = *reinterpret_cast<const f32x4*>(OUT + 64 * CLD + xr * CLD + xq);
+        *reinterpret_cast<f32x4*>(hrow + 4) = *reinterpret_cast<const f32x4*>(OUT + 64 * CLD + xr * CLD + xq + 4);
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------- compute waves ----------------------------------------------
+  const int rowbase = (wave & 1) * 32, hb = (wave >> 1) * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rmax = p.Bn - 1 - r0;
+  // xproj (+ b_hh) and c_{t-1} of this lane's 8 rows x 4 gates, fetched now, consumed after the product
+  float xg[2][4][4], cprev[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int lrow = min(rowbase + i * 16 + fq * 4 + reg, rmax);
+      const float* xrow = p.xproj[d] + (long)(r0 + lrow) * p.xs + j0 + hb + fr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xg[i][g][reg] = xrow[(long)g * H];
+      cprev[i][reg] = nk > 0 ? p.c[d][(long)(r0 + lrow) * H + j0 + hb + fr] : 0.f;
+    }
+  float bh[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bh[g] = p.bhh[d] ? p.bhh[d][g * H + j0 + hb + fr] : 0.f;
+  f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc02 = acc00, acc03 = acc00, acc10 = acc00, acc11 = acc00, acc12 = acc00,
+        acc13 = acc00;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // (1)  (raw barrier: the xproj loads stay in flight)
+  MMEGO_STAMP_AT(blockIdx.x, 1, tid == 0);
+  if (nk > 0) {
+    const int key = (fr >> 1) & 7;
+    const int sw0 = ((0 | fq) ^ key) << 2, sw1 = ((4 | fq) ^ key) << 2;       // k-block 0 / 1 of a 32-k chunk
+    const float* arow = smem + (rowbase + fr) * 32;
+    const float* brow = smem + 2048 + (hb + fr) * 32;
+    f32x4 pa0, pa1, pb0, pb1, pb2, pb3;
+#define D2_RD(S, so, sw)                                                                                    \
+  do {                                                                                                      \
+    S##a0 = *reinterpret_cast<const f32x4*>(arow + (so) + (sw));                                            \
+    S##a1 = *reinterpret_cast<const f32x4*>(arow + (so) + 16 * 32 + (sw));                                  \
+    S##b0 = *reinterpret_cast<const f32x4*>(brow + (so) + (sw));                                            \
+    S##b1 = *reinterpret_cast<const f32x4*>(brow + (so) + 32 * 32 + (sw));                                  \
+    S##b2 = *reinterpret_cast<const f32x4*>(brow + (so) + 64 * 32 + (sw));                                  \
+    S##b3 = *reinterpret_cast<const f32x4*>(brow + (so) + 96 * 32 + (sw));                                  \
+  } while (0)
+    // One fragment set only (<= 128 VGPRs so that two workgroups fit a CU): the other workgroup on the CU covers this
+    // wave's ds_read latency and barrier waits.
+    int so = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      D2_RD(p, so, sw0);
+      WS_MM(p);
+      D2_RD(p, so, sw1);
+      if (kt + 1 < nk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the stage are done (fragments in registers)
+        __builtin_amdgcn_s_barrier();                       // B_kt
+        so = (so == 2 * D2_STAGE_FLOATS) ? 0 : so + D2_STAGE_FLOATS;
+      }
+      WS_MM(p);
+    }
+  }
+  MMEGO_STAMP_AT(blockIdx.x, 2, tid == 0);
+#define D2_CELL(A0, A1, A2, A3, i)                                                                          \
+  _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                     \
+    const int lrow = rowbase + (i) * 16 + fq * 4 + reg;                                                     \
+    float gi = fast_sigmoid(A0[reg] + (xg[i][0][reg] + bh[0]));                                             \
+    float gf = fast_sigmoid(A1[reg] + (xg[i][1][reg] + bh[1]));                                             \
+    float gg = fast_tanh(A2[reg] + (xg[i][2][reg] + bh[2]));                                                \
+    float go = fast_sigmoid(A3[reg] + (xg[i][3][reg] + bh[3]));                                             \
+    float cn = gf * cprev[i][reg] + gi * gg;                                                                \
+    OUT[lrow * CLD + hb + fr] = cn;                                                                         \
+    OUT[64 * CLD + lrow * CLD + hb + fr] = go * fast_tanh(cn);                                              \
+    if (p.gst[d] && (r0 + lrow) < p.Bn) {                                                                   \
+      float* gs = p.gst[d] + (long)(r0 + lrow) * 4 * H + j0 + hb + fr;                                      \
+      gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;                                               \
+      p.cst[d][(long)(r0 + lrow) * H + j0 + hb + fr] = cn;                                                  \
+    }                                                                                                       \
+  }
+  D2_CELL(acc00, acc01, acc02, acc03, 0)
+  D2_CELL(acc10, acc11, acc12, acc13, 1)
+  MMEGO_STAMP_AT(blockIdx.x, 3, tid == 0);
+  __syncthreads();                                       // (E)
+}
+
 // ---- small-batch variant: WG = 64 rows x (4 hidden x 4 gates), K split over nothing, 4 waves = 4 row tiles ----------
 template <int SK>  // k per staged chunk (64, or 32 when H is not a multiple of 64)
 __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
@@ -841,8 +1006,18 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
 #ifdef MMEGO_STAMP
   p.packed = getenv("PROBE_PACKED") != nullptr;   // diagnostic build: address W_hh as if chunk-packed (traffic pattern only)
 #endif
-  static const int ws_mode = getenv("MMEGO_STEP_WS") ? atoi(getenv("MMEGO_STEP_WS")) : 2;
-  if (Bn >= 128 && (H % KC) == 0 && ws_mode == 2) {
+  static const int ws_mode = getenv("MMEGO_STEP_WS") ? atoi(getenv("MMEGO_STEP_WS")) : 3;   // 3: 72-KB DMA, 2: 156-KB DMA, 1: wave-split, 0: plain
+  if (Bn >= 128 && (H % 32) == 0 && ws_mode == 3) {
+    static bool d2_attr = false;
+    const size_t lds = (size_t)D2_LDS_FLOATS * sizeof(float);
+    if (!d2_attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)lstm_step_dma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      d2_attr = true;
+    }
+    int grid = ndir * (H / 32) * cdiv(Bn, 64);
+    hipLaunchKernelGGL(lstm_step_dma2_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+  } else if (Bn >= 128 && (H % KC) == 0 && ws_mode == 2) {
     static bool dma_attr = false;
     const size_t lds = (size_t)DMA_LDS_FLOATS * sizeof(float);
     if (!dma_attr) {
