@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying HIP graphs")
     ap.add_argument("--sequential", action="store_true", help="run the Upper and Lower bodies one after the other")
+    ap.add_argument("--trace-only", action="store_true", help="warm-up + timed loop only, then exit (clean input for rocprofv3 summaries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
     args = ap.parse_args()
@@ -223,6 +224,12 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
     loss_u, loss_l = su.loss.item(), sl.loss.item()
+    if args.trace_only:
+        if rank == 0:
+            print(json.dumps({"trace_only": True, "ms_per_step": dt / args.steps * 1e3, "stages_concurrent": not args.sequential}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     # per-stage split, stages one after the other (device time, events on the launch stream; median of 5)
     tu_s, tl_s = [], []

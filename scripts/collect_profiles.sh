@@ -10,8 +10,8 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$out/trace_concurrent" -o bench -- python3 "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$out/trace_concurrent.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$out/trace_sequential" -o bench -- python3 "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --sequential > "$out/trace_sequential.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/trace_concurrent" -o bench -- python3 "$root/bench.py" --steps 20 --warmup 3 --trace-only > "$out/trace_concurrent.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/trace_sequential" -o bench -- python3 "$root/bench.py" --steps 20 --warmup 3 --trace-only --sequential > "$out/trace_sequential.log" 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
   name=$(echo "$grp" | cut -d' ' -f1)
   rocprofv3 --pmc $grp --output-format csv -d "$out/pmc_step_$name" -o pmc -- python3 "$root/scripts/bench_lstm_step.py" 512 0 > "$out/pmc_step_$name.log" 2>&1

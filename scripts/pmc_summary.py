@@ -8,7 +8,7 @@ import os
 import sys
 
 root = sys.argv[1]
-KERNELS = {"lstm_step_dma_kernel": "step", "gemm_tile_persistent_kernel": "gemm"}
+KERNELS = {"lstm_step_dma2_kernel": "step", "gemm_tile_persistent_kernel": "gemm"}
 res = {}
 for kname, which in KERNELS.items():
     by_grid = collections.defaultdict(lambda: collections.defaultdict(list))
