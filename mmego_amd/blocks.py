@@ -184,6 +184,11 @@ def attn_pool_backward(ar, key, X, lin, attn, dvec, G_, P, C, dX, G):
 # ---------------------------------------------------------------------------------------------------
 # generic-H step-kernel LSTM stack (forward only): IMU_Net's rnn_fast / rnn_slow
 # ---------------------------------------------------------------------------------------------------
+# Scheduling hook of train_step.ConcurrentStages: called (key, layer) right after a layer's input projections have been
+# enqueued, i.e. at the boundary between the throughput-bound GEMMs and the latency-bound recurrent chain.
+milestone = None
+
+
 def lstm_steps_forward(ar, key, lstm, x, Bn, T):
     """x [Bn*T, In] rows (b*T+t) -> out [Bn*T, 2H] of the last layer (eval mode: no dropout)."""
     H = lstm.hidden_size
@@ -194,6 +199,8 @@ def lstm_steps_forward(ar, key, lstm, x, Bn, T):
         xp = ar.get("%s.xp%d" % (key, l), (Bn * T, 8 * H))
         for d in range(2):
             ops.linear(cur, lstm.w("weight_ih", l, d), lstm.w("bias_ih", l, d), xp[:, d * 4 * H:(d + 1) * 4 * H])
+        if milestone is not None:
+            milestone(key, l)
         out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
         c = ar.get("%s.c" % key, (2, Bn, H))
         w0, w1 = lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1)

@@ -7,9 +7,10 @@
 //
 //  * v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), BM x BN block tile (128x128, 128x64 or 64x64), 4 waves as 2x2, each
 //    wave (BM/2) x (BN/2) = TM x TN tiles of 32x32.
-//  * Operand staging, 64 k per chunk, one LDS buffer + register prefetch of the next chunk (global loads are issued before
-//    the MFMA block and land under it); 2 workgroups fit a CU (69.6 KB each at 128x128) and overlap each other's barriers.
-//      - k-contiguous operand (X[row][k]): LDS tile [row][k] with a 68-float row stride; global->LDS is a plain
+//  * Operand staging, 32 k per chunk (64 optional), one LDS buffer + register prefetch of the next chunk (global loads are
+//    issued before the MFMA block and land under it); 2 workgroups per CU (36.9 KB each at 128x128) overlap each other's
+//    barriers.
+//      - k-contiguous operand (X[row][k]): LDS tile [row][k] with a (chunk+4)-float row stride; global->LDS is a plain
 //        f32x4 -> ds_write_b128 and the operand fetch is ONE conflict-free ds_read_b128 per 4 MFMA steps through a
 //        k-permutation (lane half h supplies k = 8 kb + 4 h + s at step s -- identically for both operands).
 //      - row-contiguous operand (X[k][row], e.g. dY^T and X in dW = dY^T . X): LDS tile [k][row] with a (rows+4)-float
@@ -22,33 +23,36 @@
 #include "common.h"
 #include "gemm_tile.h"
 
-#define TLD 68
+#define TLD_MAX 68
 // NOTE: staging registers are ext_vector f32x4 (not HIP's float4 struct): arrays of the struct type are left in
 // scratch memory by hipcc (ROCm 7.2), which serialises the prefetch.
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int KCH>
 __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, int split, float* smem, int sid) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(KCH == 64 || KCH == 32, "k per staged chunk");
+  constexpr int TLD = KCH + 4;                        // [row][k] row stride: 68 / 36 floats, conflict-free ds_read_b128
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;   // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;           // 32x32 MFMA tiles per wave
-  constexpr int AV = BM / 16, BV = BN / 16;          // f32x4 per thread per 64-k chunk
+  constexpr int AV = BM * KCH / 1024, BV = BN * KCH / 1024;   // f32x4 per thread per chunk
+  constexpr int LPR = KCH / 4, RPP = 256 / LPR;      // [row][k] staging: lanes per row segment, rows per pass
   constexpr int ALD = BM + 4, BLD = BN + 4;          // row strides of the [k][row] tiles
   constexpr int ARP = 1024 / BM, BRP = 1024 / BN;    // k rows covered per pass of the 256 threads ([k][row] staging)
   float* As = smem;
-  float* Bs = smem + BM * TLD;                        // (BM * TLD >= 64 * ALD for BM in {64, 128})
+  float* Bs = smem + BM * TLD;                        // (BM * TLD >= KCH * ALD for BM in {64, 128})
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
   const int kbeg = split * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
-  const int nk = (kend - kbeg) / 64;
+  const int nk = (kend - kbeg) / KCH;
 
   // staging coordinates
-  const int lk = (tid & 15) * 4, lr = tid >> 4;      // [row][k]: 16 lanes cover one 256-B row segment, rows lr + 16 i
+  const int lk = (tid % LPR) * 4, lr = tid / LPR;    // [row][k]: LPR lanes cover one row segment of the chunk, rows lr + RPP i
   const int amk = tid / (BM / 4), am4 = (tid % (BM / 4)) * 4;   // [k][row]: k rows amk + ARP i, 4 rows at am4
   const int bnk = tid / (BN / 4), bn4 = (tid % (BN / 4)) * 4;
   const float* Ap = A_KC ? p.A + (long)(m0 + lr) * p.lda + kbeg + lk : p.A + (long)(kbeg + amk) * p.lda + m0 + am4;
   const float* Wp = B_KC ? p.W + (long)(n0 + lr) * p.ldw + kbeg + lk : p.W + (long)(kbeg + bnk) * p.ldw + n0 + bn4;
-  const long astep = A_KC ? 16 * p.lda : (long)ARP * p.lda, akstep = A_KC ? 64 : 64 * p.lda;
-  const long bstep = B_KC ? 16 * p.ldw : (long)BRP * p.ldw, bkstep = B_KC ? 64 : 64 * p.ldw;
+  const long astep = A_KC ? RPP * p.lda : (long)ARP * p.lda, akstep = A_KC ? KCH : KCH * p.lda;
+  const long bstep = B_KC ? RPP * p.ldw : (long)BRP * p.ldw, bkstep = B_KC ? KCH : KCH * p.ldw;
   f32x4 ra[AV], rb[BV];
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -69,12 +73,12 @@ __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, i
     __syncthreads();                                  // previous chunk's operand reads are done
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
-      if (A_KC) *reinterpret_cast<f32x4*>(&As[(lr + 16 * i) * TLD + lk]) = ra[i];
+      if (A_KC) *reinterpret_cast<f32x4*>(&As[(lr + RPP * i) * TLD + lk]) = ra[i];
       else *reinterpret_cast<f32x4*>(&As[(amk + ARP * i) * ALD + am4]) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < BV; ++i) {
-      if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(lr + 16 * i) * TLD + lk]) = rb[i];
+      if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(lr + RPP * i) * TLD + lk]) = rb[i];
       else *reinterpret_cast<f32x4*>(&Bs[(bnk + BRP * i) * BLD + bn4]) = rb[i];
     }
     __syncthreads();
@@ -87,7 +91,7 @@ __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, i
       for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wn + i * bstep);
     }
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
+    for (int kb = 0; kb < KCH / 8; ++kb) {
       f32x4 a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -155,13 +159,13 @@ __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, i
 __device__ __forceinline__ int xcd_order(int id, int n) { return (n & 7) == 0 ? (id & 7) * (n >> 3) + (id >> 3) : id; }
 
 // work unit u = split * tiles + tile
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int KCH>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(TileP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ntn = p.N / BN, tiles = ntn * (p.M / BM);
   const int u = xcd_order(blockIdx.x, (int)gridDim.x);
   const int split = u / tiles, id = u % tiles;
-  gemm_tile_body<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC>(p, (id / ntn) * BM, (id % ntn) * BN, split, smem, u);
+  gemm_tile_body<BM, BN, WAVES_M, WAVES_N, A_KC, B_KC, KCH>(p, (id / ntn) * BM, (id % ntn) * BN, split, smem, u);
 }
 
 // Persistent, tail-balanced launch for outputs of more than one wave of co-resident workgroups.  The grid is exactly the
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(TileP p) {
 // unit count leaves at most half a wave of workgroups over, those units are cut into two 128x64 halves, one per
 // workgroup: the tail costs half a tile time (2.5 tile times per workgroup for 1280 tiles, not 3).  Per output element
 // the arithmetic is the plain kernel's (bit-identical result).
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int KCH>
 __global__ __launch_bounds__(256) void gemm_tile_persistent_kernel(TileP p, int nfull, int nhalf, int stagger) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ntn = p.N / 128, tiles = ntn * (p.M / 128), G = (int)gridDim.x;
@@ -182,35 +186,50 @@ __global__ __launch_bounds__(256) void gemm_tile_persistent_kernel(TileP p, int 
   if (halves_first)
     for (int q = w; q < nhalf; q += G) {
       const int u = nfull + (q >> 1), id = u % tiles;
-      gemm_tile_body<128, 64, 2, 2, A_KC, B_KC>(p, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, u / tiles, smem, nfull + q);
+      gemm_tile_body<128, 64, 2, 2, A_KC, B_KC, KCH>(p, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, u / tiles, smem, nfull + q);
     }
   for (int u = w; u < nfull; u += G) {
     const int id = u % tiles;
-    gemm_tile_body<128, 128, 2, 2, A_KC, B_KC>(p, (id / ntn) * 128, (id % ntn) * 128, u / tiles, smem, u);
+    gemm_tile_body<128, 128, 2, 2, A_KC, B_KC, KCH>(p, (id / ntn) * 128, (id % ntn) * 128, u / tiles, smem, u);
   }
   if (!halves_first)
     for (int q = w; q < nhalf; q += G) {
       const int u = nfull + (q >> 1), id = u % tiles;
-      gemm_tile_body<128, 64, 2, 2, A_KC, B_KC>(p, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, u / tiles, smem, nfull + q);
+      gemm_tile_body<128, 64, 2, 2, A_KC, B_KC, KCH>(p, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, u / tiles, smem, nfull + q);
     }
 }
 
 namespace mmego_detail {
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-static int launch_plain(hipStream_t st, const TileP& p) {
+// k per staged chunk: 32 by default (measured at least as fast as 64 for the persistent kernel -- 207.8 / 348.9 us against
+// 210.5 / 353.1 us on the 10240 x 2048 x {512, 1024} projections -- and it halves the LDS footprint: 36.9 KB per 128x128
+// workgroup, so a 72-KB recurrent-step workgroup of another branch fits beside the two GEMM workgroups of a CU).
+static int chunk_k() {
+  static const int kch = getenv("MMEGO_GEMM_KC") ? atoi(getenv("MMEGO_GEMM_KC")) : 32;
+  return kch == 64 ? 64 : 32;
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int KCH>
+static int launch_plain_k(hipStream_t st, const TileP& p) {
   static bool attr_set = false;
-  const size_t lds = (size_t)((BM + BN) * TLD) * sizeof(float);
+  const size_t lds = (size_t)((BM + BN) * (KCH + 4)) * sizeof(float);
   if (!attr_set && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<BM, BN, 2, 2, A_KC, B_KC>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_kernel<BM, BN, 2, 2, A_KC, B_KC, KCH>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const unsigned units = (unsigned)((p.M / BM) * (p.N / BN) * p.nsplit);
-  hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, 2, 2, A_KC, B_KC>), dim3(units), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, 2, 2, A_KC, B_KC, KCH>), dim3(units), dim3(256), lds, st, p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+static int launch_plain(hipStream_t st, const TileP& p) {
+  static const int plain_kc = getenv("MMEGO_GEMM_PLAIN_KC") ? atoi(getenv("MMEGO_GEMM_PLAIN_KC")) : chunk_k();
+  if (plain_kc == 32 && (p.kchunk % 32) == 0) return launch_plain_k<BM, BN, A_KC, B_KC, 32>(st, p);
+  return launch_plain_k<BM, BN, A_KC, B_KC, 64>(st, p);
 }
 
 template <bool A_KC, bool B_KC>
@@ -229,15 +248,20 @@ static int launch_layout(hipStream_t st, const TileP& p) {
       const int rest = units % slots;
       const bool halves = rest > 0 && rest <= slots / 2;
       const int nfull = halves ? units - rest : units, nhalf = halves ? 2 * rest : 0;
-      static bool attr_set = false;
-      const size_t lds = (size_t)(256 * TLD) * sizeof(float);
-      if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_persistent_kernel<A_KC, B_KC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+      if (chunk_k() == 32 && (p.kchunk % 32) == 0) {
+        const size_t lds = (size_t)(256 * 36) * sizeof(float);
+        hipLaunchKernelGGL((gemm_tile_persistent_kernel<A_KC, B_KC, 32>), dim3(slots), dim3(256), lds, st, p, nfull, nhalf, stagger);
+      } else {
+        static bool attr_set = false;
+        const size_t lds = (size_t)(256 * TLD_MAX) * sizeof(float);
+        if (!attr_set) {
+          hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_persistent_kernel<A_KC, B_KC, 64>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          if (e != hipSuccess) return (int)e;
+          attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_tile_persistent_kernel<A_KC, B_KC, 64>), dim3(slots), dim3(256), lds, st, p, nfull, nhalf, stagger);
       }
-      hipLaunchKernelGGL((gemm_tile_persistent_kernel<A_KC, B_KC>), dim3(slots), dim3(256), lds, st, p, nfull, nhalf, stagger);
       hipError_t e = hipGetLastError();
       return e == hipSuccess ? 0 : (int)e;
     }

@@ -39,7 +39,7 @@ class StageStep:
         assert stage in ("upper", "lower")
         self.stage, self.net, self.imu, self.upper_frozen = stage, net, imu_net, upper_frozen
         self.pose = pose              # (R, t) device buffers filled by somebody else (the "IMU-shared" arrangement)
-        self.before_imu = self.after_imu = None     # scheduling hooks of ConcurrentStages (stream waits / event records)
+        self.before_imu = self.after_imu = self.imu_milestone = None   # scheduling hooks of ConcurrentStages
         self.opt = FusedAdam(net.flat(), lr=lr, weight_decay=weight_decay)
         self.pg = process_group
         self.use_graph = use_graph
@@ -60,7 +60,12 @@ class StageStep:
             if self.pose is not None:
                 R, t = self.pose
             elif self.imu is not None:
-                R, t = self.imu(s["imu"])
+                from . import blocks
+                blocks.milestone = self.imu_milestone
+                try:
+                    R, t = self.imu(s["imu"])
+                finally:
+                    blocks.milestone = None
             else:
                 R, t = s["R_gt"], s["t_gt"]
                 ops.copy2d(s["target"].view(B * T, 63)[:, 60:63], t.view(B * T, 3))
@@ -239,7 +244,7 @@ class ConcurrentStages:
         self.use_graph = use_graph
         self.graph = None
         self.side = [torch.cuda.Stream() for _ in self.stages[1:]]
-        self.chain_imu = os.environ.get("MMEGO_CHAIN_IMU", "1") != "0"
+        self.chain_imu = int(os.environ.get("MMEGO_CHAIN_IMU", "1"))
 
     def _bodies(self):
         """Branch order: the LAST stage (longest tail: the Lower body also runs the frozen Upper_Net) runs its IMU_Net
@@ -251,10 +256,15 @@ class ConcurrentStages:
         stages, streams = self.stages, [main] + self.side
         events = [torch.cuda.Event() for _ in stages]
         for i, st in enumerate(stages):
-            st.after_imu = (lambda ev=events[i], sm=streams[i]: ev.record(sm)) if self.chain_imu else None
-            st.before_imu = None
+            st.before_imu = st.after_imu = st.imu_milestone = None
+            if self.chain_imu == 1:                          # release the next branch when the whole IMU_Net forward is done
+                st.after_imu = lambda ev=events[i], sm=streams[i]: ev.record(sm)
+            elif self.chain_imu == 2:                        # ... when rnn_fast's first input projections are done
+                st.imu_milestone = lambda key, l, ev=events[i], sm=streams[i]: ev.record(sm) if (key, l) == ("fast", 0) else None
+                if st.imu is None:
+                    st.after_imu = lambda ev=events[i], sm=streams[i]: ev.record(sm)
         if self.chain_imu:
-            for i in range(len(stages) - 1):                 # stage i waits for stage i+1's IMU forward
+            for i in range(len(stages) - 1):                 # stage i waits for stage i+1
                 stages[i].before_imu = (lambda ev=events[i + 1], sm=streams[i]: sm.wait_event(ev))
         for side in self.side:
             side.wait_stream(main)
@@ -265,7 +275,7 @@ class ConcurrentStages:
         for side in self.side:
             main.wait_stream(side)
         for st in stages:
-            st.before_imu = st.after_imu = None
+            st.before_imu = st.after_imu = st.imu_milestone = None
 
     def step(self):
         if self.use_graph:
