@@ -22,7 +22,7 @@ static inline int col_tile(int C) {
   return tc;
 }
 
-// partial[blk][c] = (n, mean, M2) over this block's rows of column c
+// partial[c][blk] = (n, mean, M2) over this block's rows of column c
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ X, long ldx, long rows, int C,
                                                        float* __restrict__ partial, long RPB, int TC) {
   __shared__ float sh[256][3];
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
     float N = 0.f, S = 0.f, SS = 0.f;
     for (int j = 0; j < TR; ++j) { N += sh[j * TC + cx][0]; S += sh[j * TC + cx][1]; SS += sh[j * TC + cx][2]; }
     float mean_d = S / N;
-    float* out = partial + ((long)blockIdx.x * C + c) * 3;
+    float* out = partial + ((long)c * gridDim.x + blockIdx.x) * 3;     // [channel][block]: the finalize lanes read consecutive records
     out[0] = N;
     out[1] = shift + mean_d;
     out[2] = fmaxf(SS - S * mean_d, 0.f);
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
   for (int u = 0; u < 16; ++u) {
     const int k = lane + 64 * u;
     const bool ok = k < nblk;
-    const float* p = partial + ((long)(ok ? k : 0) * C + c) * 3;
+    const float* p = partial + ((long)c * nblk + (ok ? k : 0)) * 3;
     pn[u] = ok ? p[0] : 0.f;
     pm[u] = ok ? p[1] : 0.f;
     p2[u] = ok ? p[2] : 0.f;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ X
   }
 }
 
-// dZ = dY * [Ymask > 0];  partial[blk][c] = (sum dZ, sum dZ*xhat)   with xhat = (X-mean)*invstd
+// dZ = dY * [Ymask > 0];  partial[c][blk] = (sum dZ, sum dZ*xhat)   with xhat = (X-mean)*invstd
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dY, long lddy,
                                                             const float* __restrict__ Ymask, long ldm,
                                                             const float* __restrict__ X, long ldx, const float* mean,
@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   if (ry == 0 && c < C) {
     float a = 0.f, b = 0.f;
     for (int j = 0; j < TR; ++j) { a += sh[j * TC + cx][0]; b += sh[j * TC + cx][1]; }
-    partial[((long)blockIdx.x * C + c) * 2 + 0] = a;
-    partial[((long)blockIdx.x * C + c) * 2 + 1] = b;
+    partial[((long)c * gridDim.x + blockIdx.x) * 2 + 0] = a;           // [channel][block]
+    partial[((long)c * gridDim.x + blockIdx.x) * 2 + 1] = b;
   }
 }
 
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
   for (int u = 0; u < 16; ++u) {
     const int k = lane + 64 * u;
     const bool ok = k < nblk;
-    const float* p = partial + ((long)(ok ? k : 0) * C + c) * 2;
+    const float* p = partial + ((long)c * nblk + (ok ? k : 0)) * 2;
     q1[u] = ok ? p[0] : 0.f;
     q2[u] = ok ? p[1] : 0.f;
   }
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
-// partial[blk][c] = sum over the block's rows of X[r,c]
+// partial[c][blk] = sum over the block's rows of X[r,c]
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long ldx, long rows, int C,
                                                              float* __restrict__ partial, long RPB, int TC) {
   __shared__ float sh[256];
@@ -239,7 +239,35 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   if (ry == 0 && c < C) {
     float a = 0.f;
     for (int j = 0; j < TR; ++j) a += sh[j * TC + cx];
-    partial[(long)blockIdx.x * C + c] = a;
+    partial[(long)c * gridDim.x + blockIdx.x] = a;                     // [channel][block]
+  }
+}
+
+// Short tensors (<= 1024 rows): one block per column tile sums all rows -- one launch instead of two (a kernel boundary
+// costs more than these reductions themselves).  Same fixed summation structure on every run (deterministic).
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ X, long ldx, long rows, int C, float* out,
+                                                           float* out2, int accumulate, int TC) {
+  __shared__ double sh[256];
+  const int TR = 256 / TC;
+  const int cx = threadIdx.x % TC, ry = threadIdx.x / TC;
+  const int c = blockIdx.x * TC + cx;
+  double s = 0.0;
+  if (c < C) {
+    long r = ry;
+    for (; r + 3L * TR < rows; r += 4L * TR) {           // four loads in flight per thread
+      float v0 = X[r * ldx + c], v1 = X[(r + TR) * ldx + c], v2 = X[(r + 2L * TR) * ldx + c], v3 = X[(r + 3L * TR) * ldx + c];
+      s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; r < rows; r += TR) s += (double)X[r * ldx + c];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    double a = 0.0;
+    for (int j = 0; j < TR; ++j) a += sh[j * TC + cx];
+    const float v = accumulate ? out[c] + (float)a : (float)a;
+    out[c] = v;
+    if (out2) out2[c] = v;
   }
 }
 
@@ -251,7 +279,7 @@ __global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restric
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int k = lane + 64 * u;
-    q[u] = k < nblk ? partial[(long)k * C + c] : 0.f;
+    q[u] = k < nblk ? partial[(long)c * nblk + k] : 0.f;
   }
   double s = 0.0;
 #pragma unroll
@@ -369,6 +397,12 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
                             float* out2, int accumulate) {
   MMEGO_REQUIRE(X && rows > 0 && C > 0 && partial_ws && out);
   hipStream_t st = (hipStream_t)stream;
+  if (rows <= 1024) {
+    const int TCs = col_tile(C);
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(C, TCs)), dim3(256), 0, st, X, ldx, rows, C, out, out2, accumulate, TCs);
+    MMEGO_LAUNCH_CHECK();
+    return MMEGO_OK;
+  }
   const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
   MMEGO_REQUIRE(nblk <= 1024);
