@@ -164,7 +164,7 @@ def test_imu_forward(dev):
     with torch.no_grad():
         R, t = big(imu.to(dev))
     assert torch.allclose(R.cpu(), T(g["big.R"]), atol=2e-5) and torch.allclose(t.cpu(), T(g["big.t"]), atol=2e-5)
-    # a batch shaped like the benchmark (B*T = 512 rows in the fast LSTM) against the oracle
+    # 64 rows in the fast LSTM (the small-batch step kernel) against the oracle
     torch.manual_seed(9)
     imu2 = torch.randn(8, 8, 20, 15)
     ob = on.IMUNet(15, 9, 512, 2, True, 0.1).eval()
@@ -173,6 +173,55 @@ def test_imu_forward(dev):
         Ro, to_ = ob(imu2)
         Rh, th = big(imu2.to(dev))
     assert torch.allclose(Rh.cpu(), Ro, atol=2e-5) and torch.allclose(th.cpu(), to_, atol=2e-5)
+    # >= 128 rows: the LDS-DMA step kernel, the persistent / tile GEMMs; 200 rows = 3 full 64-row blocks + a ragged one of 8
+    for Bq, Tq in ((25, 8), (16, 8)):
+        imu3 = torch.randn(Bq, Tq, 20, 15)
+        with torch.no_grad():
+            Ro, to_ = ob(imu3)
+            Rh, th = big(imu3.to(dev))
+        assert torch.allclose(Rh.cpu(), Ro, atol=2e-5) and torch.allclose(th.cpu(), to_, atol=2e-5), (Bq, Tq)
+
+
+def test_lstm_step_kernel_variants(dev):
+    """Every recurrent-step kernel variant (MMEGO_STEP_WS = 3 default / 2 / 1 / 0) gives the same h and c as a plain torch
+    LSTM cell step on 200 rows (ragged last block), including the first step (h = c = 0) and the stashing mode."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from mmego_amd import hip
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+Bn, H = 200, 512
+w = [torch.randn(4 * H, H, device=dev) * 0.04 for _ in range(2)]
+b = [torch.randn(4 * H, device=dev) * 0.1 for _ in range(2)]
+xp = torch.randn(2, Bn, 4 * H, device=dev)
+h0 = torch.randn(2, Bn, H, device=dev) * 0.5
+c0 = torch.randn(2, Bn, H, device=dev) * 0.5
+for first in (0, 1):
+    c = c0.clone() if not first else torch.zeros_like(c0)
+    hout = torch.zeros(2, Bn, H, device=dev)
+    gst = torch.zeros(2, Bn, 4 * H, device=dev); cst = torch.zeros(2, Bn, H, device=dev)
+    hip.call("lstm_step", 2, Bn, H, first, None if first else h0[0], None if first else h0[1], H, w[0], w[1], b[0], b[1],
+             xp[0], xp[1], 4 * H, hout[0], hout[1], H, c[0], c[1], gst[0], gst[1], cst[0], cst[1])
+    torch.cuda.synchronize()
+    for d in range(2):
+        hp = torch.zeros(Bn, H, device=dev, dtype=torch.float64) if first else h0[d].double()
+        cp = torch.zeros(Bn, H, device=dev, dtype=torch.float64) if first else c0[d].double()
+        g = xp[d].double() + b[d].double() + hp @ w[d].double().t()
+        i, f, gg, o = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2*H]), torch.tanh(g[:, 2*H:3*H]), torch.sigmoid(g[:, 3*H:])
+        cn = f * cp + i * gg
+        hn = o * torch.tanh(cn)
+        assert (c[d].double() - cn).abs().max().item() < 2e-5, ("c", first, d)
+        assert (hout[d].double() - hn).abs().max().item() < 2e-5, ("h", first, d)
+        assert (cst[d].double() - cn).abs().max().item() < 2e-5 and (gst[d][:, :H].double() - i).abs().max().item() < 2e-5
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("3", "2", "1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MMEGO_STEP_WS=mode), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout[-500:], r.stderr[-1500:])
 
 
 def _train_pair(tag, seed, octor, hctor, dev):
