@@ -122,7 +122,9 @@ int mmego_head_fk_backward(void* stream, int which, const float* y, const float*
                            float* dy);
 /* y[F,9] -> R[F,3,3] (eps rule of IMU_Net.py:7-18), t[F,3]. */
 int mmego_imu_head(void* stream, const float* y, long F, float* R, float* t);
-/* loss = sum |pred - target[:, map]|, grad = scale*sign(.) (L1Loss(reduction='sum'), Train_Upper.py:53,179). */
+/* loss[0] = sum |pred - target[:, map]|, grad = scale*sign(.) (L1Loss(reduction='sum'), Train_Upper.py:53,179);
+ * loss[1] = sum of the per-joint Euclidean distances (the per-minibatch accuracy log, Train_Upper.py:183-185).
+ * `loss` holds TWO floats. */
 int mmego_l1_loss(void* stream, const float* pred, const float* target, const int* map, int nsel, int ntgt, long F,
                   float scale, float* loss, float* grad);
 /* Keep the `keep` rows with the largest column-0 key, descending, ties lowest index first; idx is int64

@@ -195,29 +195,39 @@ __global__ __launch_bounds__(128) void imu_head_kernel(const float* __restrict__
   }
 }
 
-// loss = sum |pred - target[:, map]| ; grad = scale * sign(pred - target)
-//   pred [F, nsel, 3]; target [F, ntgt, 3]; map[nsel] selects target joints.  Single block: deterministic sum.
+// loss[0] = sum |pred - target[:, map]| ; grad = scale * sign(pred - target) ; loss[1] = sum of the per-joint Euclidean
+// distances (the "accuracy" the reference logs per minibatch, Train_Upper.py:183-185: mean = loss[1] / (F * nsel)).
+//   pred [F, nsel, 3]; target [F, ntgt, 3]; map[nsel] selects target joints.  One thread per joint; single block with a
+//   fixed summation structure: deterministic.
 __global__ __launch_bounds__(1024) void l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                        const int* __restrict__ map, int nsel, int ntgt, long F,
                                                        float scale, float* __restrict__ loss, float* __restrict__ grad) {
-  __shared__ double sh[16];
-  long total = F * nsel * 3;
-  double acc = 0.0;
-  for (long i = threadIdx.x; i < total; i += blockDim.x) {
-    long f = i / (nsel * 3);
-    int r = (int)(i - f * nsel * 3);
-    int s = r / 3, c = r - s * 3;
-    float d = pred[i] - target[(f * ntgt + map[s]) * 3 + c];
-    acc += (double)fabsf(d);
-    if (grad) grad[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+  __shared__ double sh[2][16];
+  const long joints = F * nsel;
+  double acc = 0.0, dist = 0.0;
+  for (long i = threadIdx.x; i < joints; i += blockDim.x) {
+    const long f = i / nsel;
+    const int s = (int)(i - f * nsel);
+    const float* pp = pred + i * 3;
+    const float* tp = target + (f * ntgt + map[s]) * 3;
+    const float dx = pp[0] - tp[0], dy = pp[1] - tp[1], dz = pp[2] - tp[2];
+    acc += ((double)fabsf(dx) + (double)fabsf(dy)) + (double)fabsf(dz);
+    dist += (double)sqrtf(dx * dx + dy * dy + dz * dz);
+    if (grad) {
+      grad[i * 3 + 0] = dx > 0.f ? scale : (dx < 0.f ? -scale : 0.f);
+      grad[i * 3 + 1] = dy > 0.f ? scale : (dy < 0.f ? -scale : 0.f);
+      grad[i * 3 + 2] = dz > 0.f ? scale : (dz < 0.f ? -scale : 0.f);
+    }
   }
   acc = wave_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  dist = wave_sum_d(dist);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = acc; sh[1][threadIdx.x >> 6] = dist; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
-    *loss = (float)s;
+    double s0 = 0.0, s1 = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { s0 += sh[0][w]; s1 += sh[1][w]; }
+    loss[0] = (float)s0;
+    loss[1] = (float)s1;
   }
 }
 

@@ -123,6 +123,7 @@ class _StageTrainer(_Base):
         self._rng = np.random.RandomState(1234)
         self.start_epoch, self._resume = 0, None
         self._train_dev = None
+        self._log = None
 
     def _optimizer(self):
         return next(iter(self._steps.values())).opt if self._steps else None
@@ -143,9 +144,10 @@ class _StageTrainer(_Base):
 
     def train_once(self):
         self.model.train()
-        losses, accs = [], []
         nsel = self.model_out_joints
-        jmap = self.cfg.upper_joint_map if self.stage == "upper" else self.cfg.lower_joint_map
+        if self._log is None:
+            self._log = torch.zeros((64, 2), dtype=torch.float32, device=self.device)
+        nlog, scales = 0, []
         if self._train_dev is None:                                     # the training set lives in HBM (51 MB for Sample_data)
             self._train_dev = DeviceArrays(self.train_data, self.device)
         for idx in batch_indices(len(self.train_data), self.batchsize * self.world, True, self._rng):
@@ -158,11 +160,17 @@ class _StageTrainer(_Base):
             tgt = b["target"]
             if st.static is None or st.static["x_src"].data_ptr() != b["data"].data_ptr():
                 st.bind(b["data"], b["imu"], b["skl"], tgt, R_gt=b["R_R0R"])
-            loss = st.step()
-            pred = st.last_pred
-            acc = torch.mean(torch.sqrt(torch.sum(torch.square(pred - tgt[:, :, jmap, :]), dim=-1)))
-            losses.append(loss.item())
-            accs.append(acc.item())
+            st.step()
+            # per-minibatch log (L1 sum, mean joint distance): kept on the device, read once per epoch (the reference
+            # calls loss.item() every step: Train_Upper.py:183-186)
+            if nlog == self._log.shape[0]:
+                self._log = torch.cat((self._log, torch.zeros_like(self._log)))
+            ops.copy2d(st.loss2.view(1, 2), self._log[nlog:nlog + 1])
+            scales.append(1.0 / (B * self.frame_no * nsel))
+            nlog += 1
+        log = self._log[:nlog].cpu().numpy()
+        losses = [float(v) for v in log[:, 0]]
+        accs = [float(v * sc) for v, sc in zip(log[:, 1], scales)]
         assert nsel in (15, 8)
         return accs, losses
 

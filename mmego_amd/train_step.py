@@ -47,7 +47,8 @@ class StageStep:
         self.static = None
         dev = next(net.parameters()).device
         self.jmap = torch.tensor(UPPER_MAP if stage == "upper" else LOWER_MAP, dtype=torch.int32, device=dev)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss2 = torch.zeros(2, dtype=torch.float32, device=dev)   # [L1 sum, sum of per-joint Euclidean distances]
+        self.loss = self.loss2[:1]
         self.last_pred = None
 
     def _body(self):
@@ -78,7 +79,7 @@ class StageStep:
                 up = self.upper_frozen(s["x"], s["h0"], s["c0"], s["body"], R, t)[0]
                 l = self.net._forward_impl(up, s["x"], s["body"], R, t, stash=True)[0]
                 nsel = 8
-            hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss, s["dl"])
+            hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss2, s["dl"])
             with ops.wgrad_overlap():
                 self.net._backward_impl(s["dl"])
         self.last_pred = l
