@@ -363,10 +363,11 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
     // k-contiguous x k-contiguous products take the tile kernels at any size (measured better than the K-quartered kernel
     // even for 32 tiles); the other orientations only when there are enough 64x64 work units to fill the chip.
     static const long tile_min_other = getenv("MMEGO_GEMM_TILE_MIN") ? atol(getenv("MMEGO_GEMM_TILE_MIN")) : 256;
-    const long tile_min_units = (a_kc && b_kc && nsplit == 1) ? 1 : tile_min_other;
-    const long units64 = (long)(M / 64) * (N / 64) * nsplit;
+    // (a long-K product with few tiles is a serial chain of load-latency-bound chunks: the K-quartered kernel is better)
+    const long tile_min_units = (a_kc && b_kc && nsplit == 1) ? (K <= 1024 ? 1 : 200) : tile_min_other;
+    const long units64 = (long)(M / 64) * (N / 64) * nsplit * nbatch;
     static const bool nt_only = getenv("MMEGO_GEMM_TILE_NT_ONLY") != nullptr;
-    const bool ok = !(nt_only && !(a_kc && b_kc && nsplit == 1 && !accumulate)) && nbatch == 1 && scn == 1 && (a_kc || a_mc) && (b_kc || b_mc) && (lda % 4) == 0 && (ldw % 4) == 0 &&
+    const bool ok = !(nt_only && !(a_kc && b_kc && nsplit == 1 && !accumulate)) && scn == 1 && (nbatch == 1 || ((sAb % 4) == 0 && (sBb % 4) == 0)) && (a_kc || a_mc) && (b_kc || b_mc) && (lda % 4) == 0 && (ldw % 4) == 0 &&
                     (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (M % 64) == 0 && (N % 64) == 0 &&
                     (K % 64) == 0 && units64 >= tile_min_units && (nsplit == 1 || (long)(nsplit - 1) * kchunk_t < K);
     if (ok) {
@@ -376,12 +377,13 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
       tp.lda = lda; tp.ldw = ldw; tp.ldc = scm;
       tp.relu = relu; tp.accumulate = accumulate;
       tp.nsplit = nsplit; tp.kchunk = kchunk_t; tp.ws = splitk_ws;
+      tp.nbatch = nbatch; tp.sAb = sAb; tp.sWb = sBb; tp.sCb = sCb;
       int rc = mmego_detail::gemm_tile_launch(st, tp, a_kc, b_kc);
       if (rc == 0 && nsplit > 1) {
-        long total = (long)M * N;
+        long total = (long)nbatch * M * N;
         int blocks = (int)((total + SKR_OUT - 1) / SKR_OUT);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, C, bias, nsplit, 1, M, N, scm, scn, 0L,
-                           relu, accumulate);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, C, bias, nsplit, nbatch, M, N, scm, scn,
+                           sCb, relu, accumulate);
         MMEGO_LAUNCH_CHECK();
       }
       if (rc != -2) return rc;

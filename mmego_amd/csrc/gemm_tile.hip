@@ -28,7 +28,8 @@
 // scratch memory by hipcc (ROCm 7.2), which serialises the prefetch.
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int KCH>
-__device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, int split, float* smem, int sid) {
+__device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, int sb, float* smem, int sid) {
+  const int split = sb % p.nsplit, batch = sb / p.nsplit;      // sb = batch * nsplit + split
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(KCH == 64 || KCH == 32, "k per staged chunk");
   constexpr int TLD = KCH + 4;                        // [row][k] row stride: 68 / 36 floats, conflict-free ds_read_b128
@@ -49,8 +50,10 @@ __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, i
   const int lk = (tid % LPR) * 4, lr = tid / LPR;    // [row][k]: LPR lanes cover one row segment of the chunk, rows lr + RPP i
   const int amk = tid / (BM / 4), am4 = (tid % (BM / 4)) * 4;   // [k][row]: k rows amk + ARP i, 4 rows at am4
   const int bnk = tid / (BN / 4), bn4 = (tid % (BN / 4)) * 4;
-  const float* Ap = A_KC ? p.A + (long)(m0 + lr) * p.lda + kbeg + lk : p.A + (long)(kbeg + amk) * p.lda + m0 + am4;
-  const float* Wp = B_KC ? p.W + (long)(n0 + lr) * p.ldw + kbeg + lk : p.W + (long)(kbeg + bnk) * p.ldw + n0 + bn4;
+  const float* Ab = p.A + (long)batch * p.sAb;
+  const float* Wb = p.W + (long)batch * p.sWb;
+  const float* Ap = A_KC ? Ab + (long)(m0 + lr) * p.lda + kbeg + lk : Ab + (long)(kbeg + amk) * p.lda + m0 + am4;
+  const float* Wp = B_KC ? Wb + (long)(n0 + lr) * p.ldw + kbeg + lk : Wb + (long)(kbeg + bnk) * p.ldw + n0 + bn4;
   const long astep = A_KC ? RPP * p.lda : (long)ARP * p.lda, akstep = A_KC ? KCH : KCH * p.lda;
   const long bstep = B_KC ? RPP * p.ldw : (long)BRP * p.ldw, bkstep = B_KC ? KCH : KCH * p.ldw;
   f32x4 ra[AV], rb[BV];
@@ -132,7 +135,7 @@ __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, i
   MMEGO_STAMP_AT(sid, 2, tid == 0);
 
   const bool slab = p.nsplit > 1;
-  float* C = slab ? p.ws + (long)split * p.M * p.N : p.C;
+  float* C = slab ? p.ws + ((long)split * p.nbatch + batch) * p.M * p.N : p.C + (long)batch * p.sCb;
   const long ldc = slab ? (long)p.N : p.ldc;
   const bool relu = !slab && p.relu, accumulate = !slab && p.accumulate;
 #pragma unroll
@@ -158,7 +161,7 @@ __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, i
 // XCD-aware tile order: blocks b and b+8 share an XCD; hand each XCD a contiguous run of tile ids
 __device__ __forceinline__ int xcd_order(int id, int n) { return (n & 7) == 0 ? (id & 7) * (n >> 3) + (id >> 3) : id; }
 
-// work unit u = split * tiles + tile
+// work unit u = (batch * nsplit + split) * tiles + tile
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int KCH>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(TileP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -219,7 +222,7 @@ static int launch_plain_k(hipStream_t st, const TileP& p) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const unsigned units = (unsigned)((p.M / BM) * (p.N / BN) * p.nsplit);
+  const unsigned units = (unsigned)((p.M / BM) * (p.N / BN) * p.nsplit * p.nbatch);
   hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, 2, 2, A_KC, B_KC, KCH>), dim3(units), dim3(256), lds, st, p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -238,7 +241,7 @@ static int launch_layout(hipStream_t st, const TileP& p) {
   // projections at 93-109 TFLOP/s, 64x64 at 88-97), else 64x64 (e.g. M = 512: 23.6 us vs 84 us with 64 big tiles).
   // A 160x128 tile (1024 tiles = exactly 2 waves of 512 for those projections) was measured 3-4 % SLOWER (1x4 wave
   // layout: 6 operand reads per 5 MFMAs), so it is not in the list.
-  const long units128 = (long)(p.M / 128) * (p.N / 128) * p.nsplit;
+  const long units128 = (long)(p.M / 128) * (p.N / 128) * p.nsplit * p.nbatch;
   const bool big_ok = (p.M % 128) == 0 && (p.N % 128) == 0 && units128 >= 192;
   if (big_ok) {
     const int units = (int)units128, slots = 512;               // 2 workgroups per CU x 256 CUs
@@ -272,7 +275,7 @@ static int launch_layout(hipStream_t st, const TileP& p) {
 
 // returns 0 on launch, -2 if the shape does not fit these kernels (caller falls back), >0 on a HIP error.
 int gemm_tile_launch(hipStream_t st, const TileP& p, bool a_kc, bool b_kc) {
-  if ((p.K % 64) != 0 || (p.M % 64) != 0 || (p.N % 64) != 0 || p.nsplit < 1) return -2;
+  if ((p.K % 64) != 0 || (p.M % 64) != 0 || (p.N % 64) != 0 || p.nsplit < 1 || p.nbatch < 1) return -2;
   if (p.nsplit > 1 && ((p.kchunk % 64) != 0 || p.ws == nullptr)) return -2;
   if (a_kc && b_kc) return launch_layout<true, true>(st, p);
   if (a_kc) return launch_layout<true, false>(st, p);

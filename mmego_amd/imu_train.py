@@ -65,10 +65,13 @@ def lstm_steps_backward(ar, key, lstm, x, Bn, T, dout, G, need_dx):
                      None if last else dhrec[0], None if last else dhrec[1], gst[0, t0], gst[1, t1], cst[0, t0], cst[1, t1],
                      cst[0, t0 - 1] if s > 0 else None, cst[1, t1 + 1] if s > 0 else None, dc[0], dc[1],
                      dg3[:, t0, :4 * H], dg3[:, t1, 4 * H:], T * 8 * H)
-            if s > 0:                                               # dh_{t-1} = dgates_t . W_hh  (on the serial chain: split-K)
-                ns = ops.chain_split(Bn, H, 4 * H)
-                ops.mm(dg3[:, t0, :4 * H], wT[0].t(), dhrec[0], nsplit=ns)
-                ops.mm(dg3[:, t1, 4 * H:], wT[1].t(), dhrec[1], nsplit=ns)
+            if s > 0:
+                # dh_{t-1} = dgates_t . W_hh for BOTH directions in one batched launch (few tiles, K = 4H: the K-quartered
+                # small-GEMM kernel, in-workgroup K split, no separate reduce; measured 35 us against 42 us as a batched split-K
+                # tile product and 2 x 27 us as two split-K calls): this product sits on the serial backward chain.
+                # A batch = direction: rows of dg at time t0 (cols 0:4H) / t1 (cols 4H:8H); the batch stride may be negative.
+                hip.call("gemm", dg.data_ptr() + 4 * (t0 * 8 * H), T * 8 * H, 1, wT, 1, 4 * H, dhrec, H, 1, None,
+                         Bn, H, 4 * H, 2, (t1 - t0) * 8 * H + 4 * H, H * 4 * H, Bn * H, 0, 0, None, 1)
         hp = ar.get("%s.hp" % key, (Bn * T, H))
         for d in range(2):
             dgd = dg[:, d * 4 * H:(d + 1) * 4 * H]

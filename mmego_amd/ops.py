@@ -144,9 +144,9 @@ def pick_split(M, N, K):
 
 def chain_split(M, N, K):
     """Split-K factor for a product on a serial critical path (the recurrent dh = dgates . W_hh of the LSTM backward): few
-    output tiles and a long K, so the K range is cut until about one workgroup per CU is busy (>= 512 k per slab)."""
+    output tiles and a long K, so the K range is cut until about two workgroups per CU are busy (>= 512 k per slab)."""
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    return int(max(1, min(256 // max(tiles, 1), K // 512)))
+    return int(max(1, min(512 // max(tiles, 1), K // 512)))
 
 
 def grad_weight(dY, X, dW):

@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
     const int M = 10240, N = 2048, K = getenv("PROBE_K") ? atoi(getenv("PROBE_K")) : 1024;
     float *A = dev_random((size_t)M * K, 1.0f, 1), *W = dev_random((size_t)N * K, 0.05f, 2), *C, *bias = dev_random(N, 0.1f, 3);
     hipMalloc(&C, (size_t)M * N * 4);
-    TileP tp = {A, W, C, bias, M, N, K, K, K, N, 0, 0, 1, K, nullptr};
+    TileP tp = {A, W, C, bias, M, N, K, K, K, N, 0, 0, 1, K, nullptr, 1, 0, 0, 0};
     auto t0 = std::chrono::steady_clock::now();
     long n = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
