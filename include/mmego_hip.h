@@ -43,6 +43,10 @@ int mmego_bn_train_stats(void* stream, const float* X, long ldx, long rows, int 
 /* Eval mode: the same four vectors from the running statistics. */
 int mmego_bn_eval_affine(void* stream, int C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* mean, float* invstd, float* a, float* b);
+/* Eval mode: fold BatchNorm(running statistics) into the preceding k=1 conv / Linear: Wf = s W, bf = (b - mean) s + beta with
+ * s = gamma / sqrt(var + eps); the product then applies bias + ReLU in its epilogue (Upper_Net.py:253-255 etc. in eval). */
+int mmego_bn_fold_linear(void* stream, const float* W, const float* b, int N, int K, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, float eps, float* Wf, float* bf);
 /* Y = act((X1-m1)*a1+b1 [+ (X2-m2)*a2+b2]) -- BN apply + ReLU, and the st_gcn "tcn(x)+residual" join
  * (GCN.py:140-147). */
 int mmego_affine_act(void* stream, const float* X1, long ld1, const float* m1, const float* a1, const float* b1,

@@ -48,6 +48,15 @@ def mlp3_forward(ar, key, mod, x, out_last, training):
     cur = x
     for i, (conv, bn) in enumerate(_mlp3_layers(mod), 1):
         C = conv.weight.shape[0]
+        if not training:        # eval: BatchNorm folded into the conv, ReLU in the product's epilogue (no pre-BN tensor)
+            K = conv.weight.numel() // C
+            wf, bf = ar.get("%s.wf%d" % (key, i), (C, K)), ar.get("%s.bf%d" % (key, i), (C,))
+            hip.call("bn_fold_linear", conv.weight, conv.bias, C, K, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                     float(bn.eps), wf, bf)
+            y = out_last if i == 3 else ar.get("%s.y%d" % (key, i), (rows, C))
+            ops.linear(cur, wf, bf, y, relu=True)
+            cur = y
+            continue
         z = ar.get("%s.z%d" % (key, i), (rows, C))
         ops.linear(cur, conv.weight, conv.bias, z)
         st = ops.bn_stats(ar, "%s.bn%d" % (key, i), z, bn, training)

@@ -116,6 +116,23 @@ __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* be
   b_out[c] = beta[c];
 }
 
+// Eval mode: fold BatchNorm(running stats) into the preceding k=1 conv / Linear:
+//   y = ((W x + b) - mean) * s + beta,  s = gamma / sqrt(var + eps)   ==   (s W) x + ((b - mean) * s + beta)
+// Wf [N, K] = s[n] * W[n, k],  bf[n] = (b[n] - mean[n]) * s[n] + beta[n].  One launch instead of the affine pass over the
+// activations (and no pre-BN tensor in memory): the product then runs with bias + ReLU in its epilogue.
+__global__ __launch_bounds__(256) void bn_fold_linear_kernel(const float* __restrict__ W, const float* __restrict__ b, int N, int K,
+                                                             const float* gamma, const float* beta, const float* rmean,
+                                                             const float* rvar, float eps, float* __restrict__ Wf,
+                                                             float* __restrict__ bf) {
+  const long total = (long)N * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / K);
+    const float s = gamma[n] / sqrtf(rvar[n] + eps);
+    Wf[i] = s * W[i];
+    if (i - (long)n * K == 0) bf[n] = ((b ? b[n] : 0.f) - rmean[n]) * s + beta[n];
+  }
+}
+
 // Y[r, c] = act( (X1-m1)*a1+b1 [+ (X2-m2)*a2+b2] )
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ X1, long ld1, const float* m1,
                                                          const float* a1, const float* b1,
@@ -348,6 +365,16 @@ extern "C" int mmego_bn_eval_affine(void* stream, int C, const float* gamma, con
   MMEGO_REQUIRE(C > 0 && gamma && beta && running_mean && running_var);
   hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, C, gamma, beta,
                      running_mean, running_var, eps, mean, invstd, a, b);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_bn_fold_linear(void* stream, const float* W, const float* b, int N, int K, const float* gamma,
+                                    const float* beta, const float* running_mean, const float* running_var, float eps,
+                                    float* Wf, float* bf) {
+  MMEGO_REQUIRE(W && N > 0 && K > 0 && gamma && beta && running_mean && running_var && Wf && bf);
+  hipLaunchKernelGGL(bn_fold_linear_kernel, dim3(ew_blocks((long)N * K)), dim3(256), 0, (hipStream_t)stream, W, b, N, K, gamma, beta,
+                     running_mean, running_var, eps, Wf, bf);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
