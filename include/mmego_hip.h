@@ -47,6 +47,11 @@ int mmego_bn_eval_affine(void* stream, int C, const float* gamma, const float* b
  * s = gamma / sqrt(var + eps); the product then applies bias + ReLU in its epilogue (Upper_Net.py:253-255 etc. in eval). */
 int mmego_bn_fold_linear(void* stream, const float* W, const float* b, int N, int K, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var, float eps, float* Wf, float* bf);
+/* Eval-mode pointwise MLP: Y = relu(W3 relu(W2 relu(W1 x + b1) + b2) + b3) per row with BN-folded weights, one kernel,
+ * intermediates in LDS (BasePointNet / GlobalPointNet of Upper_Net.py:242-301, Lower_Net.py:40-72 in eval mode).
+ * Cin, C1 <= 32; C2, C3 <= 64.  X, Y may be column slices (row strides ldx, ldy). */
+int mmego_mlp3_eval(void* stream, const float* X, long ldx, long rows, int Cin, const float* W1, const float* b1, int C1,
+                    const float* W2, const float* b2, int C2, const float* W3, const float* b3, int C3, float* Y, long ldy);
 /* Y = act((X1-m1)*a1+b1 [+ (X2-m2)*a2+b2]) -- BN apply + ReLU, and the st_gcn "tcn(x)+residual" join
  * (GCN.py:140-147). */
 int mmego_affine_act(void* stream, const float* X1, long ld1, const float* m1, const float* a1, const float* b1,

@@ -3,6 +3,8 @@
 Each block keeps what its backward needs in the per-net Arena under a string key.  `G(p)` maps a
 parameter to its slot in the flat gradient buffer.  No torch compute ops are used here.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -39,6 +41,9 @@ class LstmParams(nn.Module):
 # ---------------------------------------------------------------------------------------------------
 # three (k=1 conv, BatchNorm, ReLU) stages over rows
 # ---------------------------------------------------------------------------------------------------
+_FUSED_EVAL_MLP = os.environ.get("MMEGO_FUSED_EVAL_MLP", "1") != "0"
+
+
 def _mlp3_layers(mod):
     return ((mod.conv1, mod.cb1), (mod.conv2, mod.cb2), (mod.conv3, mod.cb3))
 
@@ -46,17 +51,31 @@ def _mlp3_layers(mod):
 def mlp3_forward(ar, key, mod, x, out_last, training):
     rows = x.shape[0]
     cur = x
-    for i, (conv, bn) in enumerate(_mlp3_layers(mod), 1):
-        C = conv.weight.shape[0]
-        if not training:        # eval: BatchNorm folded into the conv, ReLU in the product's epilogue (no pre-BN tensor)
+    if not training:
+        # eval: BatchNorm folded into the convs (bn_fold_linear), then the three stages in ONE kernel whose intermediates
+        # stay in LDS (mlp3.hip) -- no pre-BN tensors, no per-point 32/48/64-channel activations in HBM
+        layers = _mlp3_layers(mod)
+        folded = []
+        for i, (conv, bn) in enumerate(layers, 1):
+            C = conv.weight.shape[0]
             K = conv.weight.numel() // C
             wf, bf = ar.get("%s.wf%d" % (key, i), (C, K)), ar.get("%s.bf%d" % (key, i), (C,))
             hip.call("bn_fold_linear", conv.weight, conv.bias, C, K, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                      float(bn.eps), wf, bf)
-            y = out_last if i == 3 else ar.get("%s.y%d" % (key, i), (rows, C))
+            folded += [wf, bf, C]
+        Cin = layers[0][0].weight.numel() // layers[0][0].weight.shape[0]
+        if (_FUSED_EVAL_MLP and Cin <= 32 and folded[2] <= 32 and folded[5] <= 64 and folded[8] <= 64 and x.stride(1) == 1
+                and out_last.stride(1) == 1):
+            hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *folded, out_last, out_last.stride(0))
+            return out_last
+        for i in range(3):                                  # wider layers: one product per stage, bias + ReLU in its epilogue
+            wf, bf, C = folded[3 * i:3 * i + 3]
+            y = out_last if i == 2 else ar.get("%s.y%d" % (key, i + 1), (rows, C))
             ops.linear(cur, wf, bf, y, relu=True)
             cur = y
-            continue
+        return cur
+    for i, (conv, bn) in enumerate(_mlp3_layers(mod), 1):
+        C = conv.weight.shape[0]
         z = ar.get("%s.z%d" % (key, i), (rows, C))
         ops.linear(cur, conv.weight, conv.bias, z)
         st = ops.bn_stats(ar, "%s.bn%d" % (key, i), z, bn, training)
