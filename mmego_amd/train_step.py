@@ -255,6 +255,8 @@ class ConcurrentStages:
         branches start together."""
         main = torch.cuda.current_stream()
         stages, streams = self.stages, [main] + self.side
+        wgrad_was, ops._side["enabled"] = ops._side["enabled"], False    # (the opt-in weight-gradient side stream makes the
+        #                                                                  multi-branch graph crash at instantiation: keep it off here)
         events = [torch.cuda.Event() for _ in stages]
         for i, st in enumerate(stages):
             st.before_imu = st.after_imu = st.imu_milestone = None
@@ -277,6 +279,7 @@ class ConcurrentStages:
             main.wait_stream(side)
         for st in stages:
             st.before_imu = st.after_imu = st.imu_milestone = None
+        ops._side["enabled"] = wgrad_was
 
     def step(self):
         if self.use_graph:
