@@ -27,6 +27,14 @@ struct Lstm64P {
   int B, T;
 };
 
+// rcp-based activations (as in lstm_step.hip): ~1 ulp from the libm forms, a fraction of their instruction count
+__device__ __forceinline__ float l64_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
+__device__ __forceinline__ float l64_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + expf(2.0f * x)); }
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load / store
+// (vmcnt(0)), which would put the prefetch of the next step's inputs and this step's stash stores back on the critical path.
+#define L64_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 #define WLD 272  // 256 gate columns + 16: consecutive k rows land on disjoint bank halves
 
 __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
@@ -57,6 +65,13 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
     hs[j * 16 + fq * 4 + reg] = hreg[reg];
   }
   __syncthreads();
+  // this lane's W_hh operand fragments (its hidden unit's 4 gate columns x the 16 k-quads it feeds) stay in registers for the
+  // whole sequence: the per-step inner loop is then 16 LDS reads of h + 64 MFMAs
+  float wreg[16][4];
+#pragma unroll
+  for (int k4 = 0; k4 < 16; ++k4)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wreg[k4][g] = Ws[(k4 * 4 + fq) * WLD + g * 64 + wave * 16 + fr];
 
   // The input projections do not depend on the recurrence: step s+1's values are fetched while step s computes, so
   // their latency (the longest thing in a step otherwise) is off the critical path.
@@ -90,24 +105,20 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k4 = 0; k4 < 16; ++k4) {
-      const int k = k4 * 4 + fq;
-      float a = hs[k * 16 + fr];
+      float a = hs[(k4 * 4 + fq) * 16 + fr];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float b = Ws[k * WLD + g * 64 + wave * 16 + fr];
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[g], 0, 0, 0);
-      }
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[k4][g], acc[g], 0, 0, 0);
     }
-    __syncthreads();  // everyone has finished reading hs for this step
+    L64_LDS_BARRIER();  // everyone has finished reading hs for this step
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       int row = r0 + fq * 4 + reg;
-      float gi = sigmoidf_(acc[0][reg] + (xp[0][reg] + bh[0]));
-      float gf = sigmoidf_(acc[1][reg] + (xp[1][reg] + bh[1]));
-      float gg = tanhf(acc[2][reg] + (xp[2][reg] + bh[2]));
-      float go = sigmoidf_(acc[3][reg] + (xp[3][reg] + bh[3]));
+      float gi = l64_sigmoid(acc[0][reg] + (xp[0][reg] + bh[0]));
+      float gf = l64_sigmoid(acc[1][reg] + (xp[1][reg] + bh[1]));
+      float gg = l64_tanh(acc[2][reg] + (xp[2][reg] + bh[2]));
+      float go = l64_sigmoid(acc[3][reg] + (xp[3][reg] + bh[3]));
       float cn = gf * creg[reg] + gi * gg;
-      float hn = go * tanhf(cn);
+      float hn = go * l64_tanh(cn);
       creg[reg] = cn;
       hreg[reg] = hn;
       hs[j * 16 + fq * 4 + reg] = hn;
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) xp[g][reg] = xpn[g][reg];
-    __syncthreads();
+    L64_LDS_BARRIER();
   }
 #undef L64_LOAD_XP
 #pragma unroll
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
       for (int g = 0; g < 4; ++g) dgs[(g * 64 + j) * 16 + fq * 4 + reg] = dg4[g][reg];
       ccur[reg] = gin[reg][5];
     }
-    __syncthreads();
+    L64_LDS_BARRIER();
     // dh_rec[row][k] = sum_n dgates[row][n] * W_hh[n][k]; this wave owns k in [16*wave, 16*wave+16)
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
     for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
       for (int q = 0; q < 6; ++q) gin[reg][q] = gnx[reg][q];
-    __syncthreads();
+    L64_LDS_BARRIER();
   }
 #undef L64_LOAD_BWD
 }
