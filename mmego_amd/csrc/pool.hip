@@ -57,6 +57,99 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restr
   }
 }
 
+// Same, with the group's [P, C] tile staged once in LDS (16-B loads, every byte read from HBM exactly once): used when the tile
+// fits (P * C * 4 <= 96 KB; IMU_Net's pooling: 20 x 1024 = 80 KB, the PointNets': 128 x 64 = 32 KB).  C % 4 == 0.
+__global__ __launch_bounds__(256) void attn_pool_fwd_lds_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                                const float* __restrict__ bptr, int P, int C,
+                                                                float* __restrict__ vec, float* __restrict__ attn) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Xs = lds;                       // [P][C]
+  float* sc = lds + (long)P * C;         // [P]
+  __shared__ float red[8];
+  const long g = blockIdx.x;
+  const float* Xg = X + g * (long)P * C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int n4 = P * C / 4;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x)
+    reinterpret_cast<f32x4*>(Xs)[i] = reinterpret_cast<const f32x4*>(Xg)[i];
+  const float b = bptr ? bptr[0] : 0.f;
+  __syncthreads();
+  for (int p = wave; p < P; p += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += Xs[p * C + c] * w[c];
+    s = wave_sum(s);
+    if (lane == 0) sc[p] = s + b;
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) m = fmaxf(m, sc[p]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = red[0];
+  for (int i = 1; i < nw; ++i) m = fmaxf(m, red[i]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float e = expf(sc[p] - m);
+    sc[p] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = 0.f;
+  for (int i = 0; i < nw; ++i) sum += red[i];
+  const float inv = 1.0f / sum;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) attn[g * P + p] = sc[p] * inv;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int p = 0; p < P; ++p) acc += Xs[p * C + c] * (sc[p] * inv);
+    vec[g * C + c] = acc;
+  }
+}
+
+// Few rows x many channels (IMU_Net's pooling over the 20 samples of a frame, C = 1024): the whole [P, C] tile of a group lives
+// in REGISTERS -- thread t holds channels 4t..4t+3 of every row (P <= 32 f32x4) -- so HBM is read exactly once with all loads
+// in flight together, and no large LDS tile limits the workgroups per CU.  C % 4 == 0, C <= 4 * blockDim.
+template <int PMAX>
+__global__ __launch_bounds__(256) void attn_pool_fwd_reg_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                                const float* __restrict__ bptr, int P, int C,
+                                                                float* __restrict__ vec, float* __restrict__ attn) {
+  __shared__ float part[4][PMAX];
+  __shared__ float sc[PMAX];
+  const long g = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool act = 4 * tid < C;
+  const float* Xg = X + g * (long)P * C + 4 * tid;
+  f32x4 xr[PMAX];
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) xr[p] = (act && p < P) ? *reinterpret_cast<const f32x4*>(Xg + (long)p * C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x4 w4 = act ? *reinterpret_cast<const f32x4*>(w + 4 * tid) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float b = bptr ? bptr[0] : 0.f;
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) {
+    float s = (xr[p].x * w4.x + xr[p].y * w4.y) + (xr[p].z * w4.z + xr[p].w * w4.w);
+    s = wave_sum(s);
+    if (lane == 0) part[wave][p] = s;
+  }
+  __syncthreads();
+  if (tid < PMAX) sc[tid] = tid < P ? ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + b : -INFINITY;
+  __syncthreads();
+  float m = -INFINITY;
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) m = fmaxf(m, sc[p]);
+  float e[PMAX], sum = 0.f;
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) { e[p] = p < P ? expf(sc[p] - m) : 0.f; sum += e[p]; }
+  const float inv = 1.0f / sum;
+  if (tid < P) attn[g * P + tid] = e[tid < PMAX ? tid : 0] * inv;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) acc += xr[p] * (e[p] * inv);
+  if (act) *reinterpret_cast<f32x4*>(vec + g * C + 4 * tid) = acc;
+}
+
 // dvec [G, C] -> dX [G, P, C], partial_dw [G, C], partial_db [G]
 __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restrict__ X, const float* __restrict__ w,
                                                             const float* __restrict__ attn,
@@ -339,6 +432,25 @@ static inline int ew_blocks(long total) {
 extern "C" int mmego_attn_pool_forward(void* stream, const float* X, const float* w, const float* b, long G, int P, int C,
                                        float* vec, float* attn) {
   MMEGO_REQUIRE(X && w && vec && attn && G > 0 && P > 0 && C > 0 && P <= 8192);
+  const size_t tile = ((size_t)P * C + P) * sizeof(float);
+  const bool vec_ok = (C % 4) == 0 && ((((uintptr_t)X) | ((uintptr_t)w) | ((uintptr_t)vec)) & 15) == 0;
+  if (vec_ok && P <= 32 && C <= 1024) {            // the tile fits the register file of one workgroup
+    if (P <= 20) hipLaunchKernelGGL((attn_pool_fwd_reg_kernel<20>), dim3((unsigned)G), dim3(256), 0, (hipStream_t)stream, X, w, b, P, C, vec, attn);
+    else hipLaunchKernelGGL((attn_pool_fwd_reg_kernel<32>), dim3((unsigned)G), dim3(256), 0, (hipStream_t)stream, X, w, b, P, C, vec, attn);
+    MMEGO_LAUNCH_CHECK();
+    return MMEGO_OK;
+  }
+  if (vec_ok && tile <= 96 * 1024) {
+    static size_t attr_bytes = 0;
+    if (tile > 64 * 1024 && tile > attr_bytes) {
+      hipError_t e = hipFuncSetAttribute((const void*)attn_pool_fwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_bytes = 96 * 1024;
+    }
+    hipLaunchKernelGGL(attn_pool_fwd_lds_kernel, dim3((unsigned)G), dim3(256), tile, (hipStream_t)stream, X, w, b, P, C, vec, attn);
+    MMEGO_LAUNCH_CHECK();
+    return MMEGO_OK;
+  }
   hipLaunchKernelGGL(attn_pool_fwd_kernel, dim3((unsigned)G), dim3(256), (size_t)P * sizeof(float), (hipStream_t)stream,
                      X, w, b, P, C, vec, attn);
   MMEGO_LAUNCH_CHECK();
