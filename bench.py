@@ -91,7 +91,7 @@ def profile_kernels(steps_fn, names, iters=3):
             # The big projections are launched twice back to back between the event pair (the product is idempotent), so the
             # event / launch latency of an eager launch (5-10 us) is amortised and the figure is the kernel's own duration,
             # comparable with rocprofv3's AverageNs.  The recurrent step updates c in place: launched once.
-            rep = 2 if (name == "gemm" and 2.0 * args[10] * args[11] * args[12] > 1e10 and not args[18]) else 1
+            rep = 2 if (name == "gemm" and 2.0 * args[10] * args[11] * args[12] * args[13] > 1e10 and not args[18]) else 1
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(rep):
@@ -305,21 +305,21 @@ def main():
         big = [(ms_, step_flops(a)) for ms_, a in rec["lstm_step"] if a[1] >= 128]
         small = [(ms_, step_flops(a)) for ms_, a in rec["lstm_step"] if a[1] < 128]
 
-        def is_nt_aligned(a):   # the dispatch rule of mmego_gemm (gemm.hip / gemm_tile.hip)
-            return (a[13] == 1 and a[20] == 1 and not a[18] and a[2] == 1 and a[4] == 1 and a[8] == 1 and a[10] % 64 == 0
+        def is_nt_aligned(a):   # the dispatch rule of mmego_gemm (gemm.hip / gemm_tile.hip); a[13] = nbatch
+            return (a[20] == 1 and not a[18] and a[2] == 1 and a[4] == 1 and a[8] == 1 and a[10] % 64 == 0
                     and a[11] % 64 == 0 and a[12] % 64 == 0)
 
         def is_tile128(a):
-            return is_nt_aligned(a) and a[10] % 128 == 0 and a[11] % 128 == 0 and (a[10] // 128) * (a[11] // 128) >= 192
-        g128 = [(ms_, 2.0 * a[10] * a[11] * a[12]) for ms_, a in rec["gemm"] if is_tile128(a)]
-        g64 = [(ms_, 2.0 * a[10] * a[11] * a[12]) for ms_, a in rec["gemm"] if is_nt_aligned(a) and not is_tile128(a)]
+            return is_nt_aligned(a) and a[10] % 128 == 0 and a[11] % 128 == 0 and (a[10] // 128) * (a[11] // 128) * a[13] >= 192
+        g128 = [(ms_, 2.0 * a[10] * a[11] * a[12] * a[13]) for ms_, a in rec["gemm"] if is_tile128(a)]
+        g64 = [(ms_, 2.0 * a[10] * a[11] * a[12] * a[13]) for ms_, a in rec["gemm"] if is_nt_aligned(a) and not is_tile128(a)]
         cands = {}
         if big:
             cands["lstm_step_dma2_kernel (IMU_Net rnn_fast recurrent steps: 2 dirs x 512 rows x 2048 gates x K=512 per launch)"] = big
         if small:
             cands["lstm_step_small_kernel (IMU_Net rnn_slow recurrent steps: 2 dirs x 64 rows x 2048 gates x K=512)"] = small
         if g128:
-            cands["gemm_tile_persistent_kernel (128x128 tiles; IMU_Net LSTM input projections 10240 x 2048 x {512,1024})"] = g128
+            cands["gemm_tile_persistent_kernel (128x128 tiles; IMU_Net LSTM input projections, both directions per launch: 2 x 10240 x 2048 x {512,1024})"] = g128
         if g64:
             cands["gemm_tile_kernel<64,64> (smaller 64-aligned products)"] = g64
         best = max(cands.items(), key=lambda kv: sum(m for m, _ in kv[1]))

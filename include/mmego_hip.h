@@ -27,9 +27,11 @@ extern "C" {
  * Replaces: nn.Linear / Conv1d(k=1) / Conv2d(1x1, 9x1) / Conv3d forward and their weight/input
  * gradients -- Net/Upper_Net.py:242-301,343-364, Net/Lower_Net.py:40-72,95-123, Net/GCN.py:46-60,
  * and the LSTM input projections of Net/IMU_Net.py:58-62. */
+/* (sBiasb: element stride of `bias` between batches, 0 = one bias for all -- lets the two directions' input projections of a
+ * BiLSTM layer run as ONE batched product: same A, two weight / bias / output-column blocks.) */
 int mmego_gemm(void* stream, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
                long scm, long scn, const float* bias, int M, int N, int K, int nbatch, long sAb, long sBb, long sCb,
-               int relu, int accumulate, float* splitk_ws, int nsplit);
+               int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb);
 
 /* ---- BatchNorm and row-wise helpers (bn.hip) ----------------------------------------------------
  * Train-mode statistics of X[rows, C] (+ running-stat update with torch semantics: momentum, unbiased

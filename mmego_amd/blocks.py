@@ -225,8 +225,7 @@ def lstm_steps_forward(ar, key, lstm, x, Bn, T):
     out = None
     for l in range(L):
         xp = ar.get("%s.xp%d" % (key, l), (Bn * T, 8 * H))
-        for d in range(2):
-            ops.linear(cur, lstm.w("weight_ih", l, d), lstm.w("bias_ih", l, d), xp[:, d * 4 * H:(d + 1) * 4 * H])
+        ops.linear_pair(cur, lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1), lstm.w("bias_ih", l, 0), lstm.w("bias_ih", l, 1), xp, 4 * H)
         if milestone is not None:
             milestone(key, l)
         out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))

@@ -22,7 +22,7 @@ struct GemmP {
   float* C;
   const float* bias;
   long sam, sak, sbk, sbn, scm, scn;
-  long sAb, sBb, sCb, sCs;
+  long sAb, sBb, sCb, sCs, sBiasb;
   int M, N, K;
   int nsplit, kchunk;
   int relu, accumulate;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
   const int col = n0 + wn * 32 + (lane & 31);
   if (col >= p.N) return;
   float* C = p.C + (long)batch * p.sCb + (long)split * p.sCs;
-  const float bv = (p.bias && p.nsplit == 1) ? p.bias[col] : 0.0f;
+  const float bv = (p.bias && p.nsplit == 1) ? p.bias[(long)batch * p.sBiasb + col] : 0.0f;
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     int row = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
       float v = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
       float* dst = C + (long)(m0 + row) * p.scm + (long)(n0 + col) * p.scn;
       if (p.nsplit == 1) {
-        if (p.bias) v += p.bias[n0 + col];
+        if (p.bias) v += p.bias[(long)batch * p.sBiasb + n0 + col];
         if (p.relu) v = fmaxf(v, 0.0f);
         if (p.accumulate) v += *dst;
       }
@@ -350,8 +350,9 @@ __global__ __launch_bounds__(256) void gemm128_nt_kernel(const float* __restrict
 
 extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                           float* C, long scm, long scn, const float* bias, int M, int N, int K, int nbatch, long sAb,
-                          long sBb, long sCb, int relu, int accumulate, float* splitk_ws, int nsplit) {
+                          long sBb, long sCb, int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb) {
   MMEGO_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && nsplit >= 1);
+  MMEGO_REQUIRE(sBiasb == 0 || nsplit == 1);          // (the split-K reducer applies one shared bias)
   hipStream_t st = (hipStream_t)stream;
   // Large-tile kernels (gemm_tile.hip): 64-aligned shapes with enough work units to be worth a 64x64+ tile, any operand
   // orientation whose contiguous index has unit stride and 16-B aligned rows.
@@ -377,7 +378,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
       tp.lda = lda; tp.ldw = ldw; tp.ldc = scm;
       tp.relu = relu; tp.accumulate = accumulate;
       tp.nsplit = nsplit; tp.kchunk = kchunk_t; tp.ws = splitk_ws;
-      tp.nbatch = nbatch; tp.sAb = sAb; tp.sWb = sBb; tp.sCb = sCb;
+      tp.nbatch = nbatch; tp.sAb = sAb; tp.sWb = sBb; tp.sCb = sCb; tp.sBiasb = sBiasb;
       int rc = mmego_detail::gemm_tile_launch(st, tp, a_kc, b_kc);
       if (rc == 0 && nsplit > 1) {
         long total = (long)nbatch * M * N;
@@ -401,7 +402,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   GemmP p;
   p.A = A; p.B = B; p.bias = bias;
   p.sam = sam; p.sak = sak; p.sbk = sbk; p.sbn = sbn;
-  p.sAb = sAb; p.sBb = sBb;
+  p.sAb = sAb; p.sBb = sBb; p.sBiasb = sBiasb;
   p.M = M; p.N = N; p.K = K;
   p.nsplit = nsplit;
   p.relu = relu; p.accumulate = accumulate;

@@ -13,7 +13,7 @@ struct TileP {
   int nsplit, kchunk; // split-K: slab s covers k in [s * kchunk, min(K, (s+1) * kchunk)), kchunk % 64 == 0
   float* ws;          // [nsplit][nbatch][M][N] partial products when nsplit > 1 (bias / relu / accumulate: the reducer's job)
   int nbatch;         // independent products sharing the shapes; element strides between them (may be negative):
-  long sAb, sWb, sCb;
+  long sAb, sWb, sCb, sBiasb;
 };
 
 namespace mmego_detail {

@@ -141,7 +141,7 @@ __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, i
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WN + j * 32 + (lane & 31);
-    const float bv = (!slab && p.bias) ? p.bias[col] : 0.0f;
+    const float bv = (!slab && p.bias) ? p.bias[(long)batch * p.sBiasb + col] : 0.0f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll

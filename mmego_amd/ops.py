@@ -110,7 +110,7 @@ def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1):
     if nsplit > 1:
         ws = scratch(A.device, nsplit * M * N)
     hip.call("gemm", A, A.stride(0), A.stride(1), B, B.stride(0), B.stride(1), C, C.stride(0), C.stride(1), bias,
-             M, N, K, 1, 0, 0, 0, int(relu), int(accumulate), ws, nsplit)
+             M, N, K, 1, 0, 0, 0, int(relu), int(accumulate), ws, nsplit, 0)
     return C
 
 
@@ -121,8 +121,24 @@ def bmm(A, B, C, accumulate=False):
     if B.shape[0] != nb or C.shape[0] != nb or B.shape[1] != K or tuple(C.shape[1:]) != (M, B.shape[2]):
         raise ValueError("bmm shape mismatch")
     hip.call("gemm", A, A.stride(1), A.stride(2), B, B.stride(1), B.stride(2), C, C.stride(1), C.stride(2), None,
-             M, B.shape[2], K, nb, A.stride(0), B.stride(0), C.stride(0), 0, int(accumulate), None, 1)
+             M, B.shape[2], K, nb, A.stride(0), B.stride(0), C.stride(0), 0, int(accumulate), None, 1, 0)
     return C
+
+
+def linear_pair(x, W0, W1, b0, b1, out, ncol):
+    """out[:, :ncol] = x W0^T + b0 and out[:, ncol:2 ncol] = x W1^T + b1 as ONE batched product (the two directions' input
+    projections of a BiLSTM layer: 2 x 1280 tiles = exactly five rounds of the persistent GEMM grid instead of 2 x 2.5)."""
+    _chk(x, 2), _chk(out, 2)
+    rows, K = x.shape
+    ok = (W0.shape == W1.shape == (ncol, K) and W0.is_contiguous() and W1.is_contiguous() and b0.is_contiguous() and b1.is_contiguous()
+          and x.stride(1) == 1 and out.stride(1) == 1 and out.shape[1] >= 2 * ncol)
+    dW, dB = (W1.data_ptr() - W0.data_ptr()) // 4, (b1.data_ptr() - b0.data_ptr()) // 4
+    if not ok or (W1.data_ptr() - W0.data_ptr()) % 16 or (b1.data_ptr() - b0.data_ptr()) % 4:
+        linear(x, W0, b0, out[:, :ncol])
+        linear(x, W1, b1, out[:, ncol:2 * ncol])
+        return out
+    hip.call("gemm", x, x.stride(0), 1, W0, 1, K, out, out.stride(0), 1, b0, rows, ncol, K, 2, 0, dW, ncol, 0, 0, None, 1, dB)
+    return out
 
 
 def linear(x, W, b, out, relu=False):

@@ -75,7 +75,7 @@ def test_train_upper_wlocal(dev):
         out = m(x0.clone(), h0, c0, h0, c0, body, R, t)
         holder.setdefault("oidx", m.module2.last_group_idx.clone())
         return out[0]
-    _compare_training("wlocal", o, h, fwd_o, fwd_h, target[:, :, list(sk.UPPER_MAP)], g, dev, later_grad_tol=2e-2)  # steps 2-3 start from weights that already differ by sign-of-noise Adam updates; the LocalPointNet BN chain over 8-point groups amplifies that (2.4e-3..6e-3 observed run to run)
+    _compare_training("wlocal", o, h, fwd_o, fwd_h, target[:, :, list(sk.UPPER_MAP)], g, dev, later_grad_tol=2e-2, later_out_atol=1e-3)  # steps 2-3 start from weights that already differ by sign-of-noise Adam updates; the LocalPointNet BN chain over 8-point groups amplifies that (2.4e-3..6e-3 observed run to run)
     assert holder["n"] == 8, "UpperNetwlocal returns the reference's 8-tuple"
     assert torch.equal(holder["idx"], holder["oidx"]), "voxel (group) indices bit-exact vs the oracle"
     with torch.no_grad():

@@ -236,7 +236,7 @@ def _train_pair(tag, seed, octor, hctor, dev):
     return o.train(), h.to(dev).train()
 
 
-def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev, later_grad_tol=2e-4):
+def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev, later_grad_tol=2e-4, later_out_atol=2e-5):
     from mmego_amd.params import FusedAdam
     opt_o = torch.optim.Adam(o.parameters(), lr=3e-5)
     opt_h = FusedAdam(h.flat(), lr=3e-5)
@@ -251,7 +251,9 @@ def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev, later_grad_tol=2e
         loss_h.backward()
         assert abs(loss_h.item() - loss_o.item()) < 2e-5 * abs(loss_o.item()), (step, loss_h.item(), loss_o.item())
         assert abs(loss_h.item() - float(g["%s.loss%d" % (tag, step)])) < 2e-4 * abs(loss_o.item()), "vs the real reference"
-        assert torch.allclose(lh.detach().cpu(), lo_.detach(), rtol=1e-4, atol=2e-5), (step, (lh.detach().cpu() - lo_.detach()).abs().max())
+        # (from step 2 on the two runs start from weights that differ by sign-of-noise Adam updates: see later_grad_tol)
+        assert torch.allclose(lh.detach().cpu(), lo_.detach(), rtol=1e-4, atol=2e-5 if step == 1 else later_out_atol), \
+            (step, (lh.detach().cpu() - lo_.detach()).abs().max())
         po, ph = dict(o.named_parameters()), dict(h.named_parameters())
         scale = max(p.grad.abs().max().item() for p in po.values() if p.grad is not None)
         for k in po:
