@@ -30,3 +30,19 @@ for M, N, K in shapes:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
     print("M%d N%d K%d: %.1f us, %.1f TFLOP/s, max err %.2e" % (M, N, K, us, 2.0 * M * N * K / us / 1e6, err))
+    if M == 10240:      # both directions of a BiLSTM layer as one batched product (what IMU_Net's forward launches)
+        W2 = torch.cat((W, torch.randn(N, K, device=dev) * 0.05))
+        b2 = torch.cat((b, torch.randn(N, device=dev)))
+        C2 = torch.empty(M, 2 * N, device=dev)
+        for _ in range(3):
+            ops.linear_pair(A, W2[:N], W2[N:], b2[:N], b2[N:], C2, N)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            ops.linear_pair(A, W2[:N], W2[N:], b2[:N], b2[N:], C2, N)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        ref2 = A[:128].double() @ W2.double().t() + b2.double()
+        print("   pair 2 x (M%d N%d K%d): %.1f us, %.1f TFLOP/s, max err %.2e" % (M, N, K, us, 4.0 * M * N * K / us / 1e6,
+                                                                               (C2[:128].double() - ref2).abs().max().item()))

@@ -2,7 +2,7 @@
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
 #   1. kernel trace + stats of the default bench run (concurrent stage graphs) and of --sequential
 #   2. PMC passes (one counter group per run, never combined with tracing) for the two dominant kernels,
-#      driven by the micro-benchmarks scripts/bench_lstm_step.py and scripts/bench_gemm.py
+#      driven by the micro-benchmarks scripts/bench_lstm_step.py and scripts/bench_gemm_pair.py
 # Everything lands in gpurun_out/prof_<tag>/ ; scripts/prof_summary.py and scripts/pmc_summary.py condense it.
 set -e -o pipefail
 tag=${1:-r01}
@@ -15,6 +15,6 @@ rocprofv3 --kernel-trace --stats -d "$out/trace_sequential" -o bench -- python3 
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
   name=$(echo "$grp" | cut -d' ' -f1)
   rocprofv3 --pmc $grp --output-format csv -d "$out/pmc_step_$name" -o pmc -- python3 "$root/scripts/bench_lstm_step.py" 512 0 > "$out/pmc_step_$name.log" 2>&1
-  rocprofv3 --pmc $grp --output-format csv -d "$out/pmc_gemm_$name" -o pmc -- python3 "$root/scripts/bench_gemm.py" > "$out/pmc_gemm_$name.log" 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d "$out/pmc_gemm_$name" -o pmc -- python3 "$root/scripts/bench_gemm_pair.py" > "$out/pmc_gemm_$name.log" 2>&1
 done
 echo "profiles collected in $out"

@@ -36,6 +36,6 @@ for kname, which in KERNELS.items():
         entry["hbm_fraction_of_8TBps"] = entry["hbm_GBps"] / 8000.0
     res[kname] = entry
 res["note"] = ("separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group); FETCH doubled per MI355X_MICROARCH.md; "
-               "lstm_step: Bn=512,H=512,ndir=2 (scripts/bench_lstm_step.py 512 0); gemm: averages over the launches of "
-               "scripts/bench_gemm.py that take the persistent kernel (10240 x 2048 x {512,1024})")
+               "lstm_step: Bn=512,H=512,ndir=2 (scripts/bench_lstm_step.py 512 0); gemm: scripts/bench_gemm_pair.py, both "
+               "directions per launch, 2 x (10240 x 2048 x {512,1024}) averaged as in the U+L step")
 print(json.dumps(res, indent=1))
