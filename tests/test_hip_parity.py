@@ -82,6 +82,36 @@ def test_gemm_variants(dev):
     assert torch.allclose(Cd.cpu(), C + A[0].t() @ B, atol=1e-4)
 
 
+def test_fused_eval_mlp_and_bn_fold(dev):
+    """mmego_bn_fold_linear + mmego_mlp3_eval (eval-mode PointNet stages in one kernel) against conv -> BatchNorm(eval) -> ReLU
+    in fp64, for the three channel plans of the path, ragged row counts and column-slice inputs / outputs."""
+    from mmego_amd import hip
+    g = torch.Generator().manual_seed(11)
+    for rows, dims in ((1000, (28, 32, 48, 64)), (77, (6, 8, 16, 24)), (4099, (6, 16, 32, 61))):
+        Cin = dims[0]
+        xbuf = torch.randn(rows, Cin + 5, generator=g).to(dev)
+        x = xbuf[:, 3:3 + Cin]                                            # column slice (row stride Cin + 5)
+        ybuf = torch.full((rows, dims[3] + 7), 7.0, device=dev)
+        y = ybuf[:, 2:2 + dims[3]]
+        cur = x.double().cpu()
+        folded = []
+        for i in range(3):
+            K, C = dims[i], dims[i + 1]
+            W, b = torch.randn(C, K, generator=g) * 0.4, torch.randn(C, generator=g) * 0.2
+            gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+            mean, var = torch.randn(C, generator=g) * 0.3, torch.rand(C, generator=g) + 0.2
+            z = cur @ W.double().t() + b.double()
+            cur = torch.relu((z - mean.double()) / torch.sqrt(var.double() + 1e-5) * gamma.double() + beta.double())
+            wf, bf = torch.empty(C, K, device=dev), torch.empty(C, device=dev)
+            hip.call("bn_fold_linear", W.to(dev), b.to(dev), C, K, gamma.to(dev), beta.to(dev), mean.to(dev), var.to(dev), 1e-5, wf, bf)
+            folded += [wf, bf, C]
+        hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *folded, y, y.stride(0))
+        torch.cuda.synchronize()
+        err = (y.double().cpu() - cur).abs().max().item()
+        assert err < 2e-5 * max(1.0, cur.abs().max().item()), (rows, dims, err)
+        assert (ybuf[:, :2] == 7.0).all() and (ybuf[:, 2 + dims[3]:] == 7.0).all(), "writes stay inside the output slice"
+
+
 def _seq(real16, i, device=None):
     x = T(real16["x"][i:i + 1]).clone()
     tgt = T(real16["target"][i:i + 1])
