@@ -255,8 +255,8 @@ class ConcurrentStages:
         branches start together."""
         main = torch.cuda.current_stream()
         stages, streams = self.stages, [main] + self.side
-        wgrad_was, ops._side["enabled"] = ops._side["enabled"], False    # (the opt-in weight-gradient side stream makes the
-        #                                                                  multi-branch graph crash at instantiation: keep it off here)
+        wgrad_was, ops._side["enabled"] = ops._side["enabled"], False    # (the opt-in weight-gradient side streams make the
+        #                                                                  multi-branch graph crash at instantiation: off here)
         events = [torch.cuda.Event() for _ in stages]
         for i, st in enumerate(stages):
             st.before_imu = st.after_imu = st.imu_milestone = None
