@@ -216,6 +216,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.sequential:                 # graph capture happens here, outside the timed region, whatever --warmup is
+        su.prepare(); sl.prepare()
+    else:
+        both.prepare()
     for _ in range(args.warmup):
         ul_step()
     sync()

@@ -112,14 +112,19 @@ class StageStep:
             t.copy_(k)
         torch.cuda.synchronize()
 
+    def prepare(self):
+        """Size the arenas and capture the HIP graph without changing any state (so that the first step() costs what
+        every step costs)."""
+        if self.use_graph and self.graph is None:
+            self.warm_up()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body()
+            self.graph = g
+
     def step(self):
         if self.use_graph:
-            if self.graph is None:
-                self.warm_up()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._body()
-                self.graph = g
+            self.prepare()
             self.graph.replay()
         else:
             self._body()
@@ -281,22 +286,26 @@ class ConcurrentStages:
             st.before_imu = st.after_imu = st.imu_milestone = None
         ops._side["enabled"] = wgrad_was
 
+    def prepare(self):
+        """Warm-up (side-effect free) and graph capture, so that the first step() costs what every step costs."""
+        if self.use_graph and self.graph is None:
+            for st in self.stages:                          # warm-up one by one: sizes arenas, sets kernel attributes
+                st.warm_up()
+            keep = [[t.clone() for t in st._mutable_state()] for st in self.stages]
+            self._bodies()                                  # per-stream scratch buffers of the side streams
+            torch.cuda.synchronize()
+            for st, ks in zip(self.stages, keep):
+                for t, k in zip(st._mutable_state(), ks):
+                    t.copy_(k)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._bodies()
+            self.graph = g
+
     def step(self):
         if self.use_graph:
-            if self.graph is None:
-                for st in self.stages:                          # warm-up one by one: sizes arenas, sets kernel attributes
-                    st.warm_up()
-                keep = [[t.clone() for t in st._mutable_state()] for st in self.stages]
-                self._bodies()                                  # per-stream scratch buffers of the side streams
-                torch.cuda.synchronize()
-                for st, ks in zip(self.stages, keep):
-                    for t, k in zip(st._mutable_state(), ks):
-                        t.copy_(k)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._bodies()
-                self.graph = g
+            self.prepare()
             self.graph.replay()
         else:
             self._bodies()
