@@ -207,8 +207,10 @@ def main():
         else:
             both.step()
 
-    if world > 1:       # bring the RCCL communicator up outside the timed region even when --warmup 0
+    if world > 1:       # bring the RCCL communicator (and its channels for these message sizes) up outside the timed region
         torch.distributed.all_reduce(torch.zeros(1, device=device))
+        for net in (upper, lower):      # the gradient buffers are overwritten by every backward: reducing them here is harmless
+            torch.distributed.all_reduce(net.flat().flat_g)
         torch.cuda.synchronize()
 
     def sync():
