@@ -337,6 +337,12 @@ def main():
                            "avg_launch_us": tot_ms / len(best[1]) * 1e3, "launches_per_step": len(best[1]) // iters,
                            "flop_per_launch_avg": tot_fl / len(best[1]),
                            "share_of_step": (tot_ms / iters) / (t_u + t_l)}
+        # The step against the HBM roofline (SURVEY 8-d figures): 129.1 MB of parameter / gradient / optimiser traffic per
+        # U+L step + 4 830 B of streaming I/O per frame.  The path is matrix-pipe and latency bound, not HBM bound.
+        alg_bytes = 129.1e6 + 4830.0 * B * T
+        out["hbm_roofline"] = {"algorithmic_bytes_per_step": alg_bytes, "peak_GBps": 8000.0,
+                               "achieved_GBps": alg_bytes / (out["ms_per_step"] * 1e-3) / 1e9,
+                               "frac": alg_bytes / (out["ms_per_step"] * 1e-3) / 8e12}
         out["kernels"] = {k: {"avg_us": sum(m for m, _ in v) / len(v) * 1e3, "launches_per_step": len(v) // iters,
                               "tflops": sum(f for _, f in v) / (sum(m for m, _ in v) * 1e-3) / 1e12,
                               "ms_per_step": sum(m for m, _ in v) / iters} for k, v in cands.items()}
