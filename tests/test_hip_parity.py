@@ -82,6 +82,35 @@ def test_gemm_variants(dev):
     assert torch.allclose(Cd.cpu(), C + A[0].t() @ B, atol=1e-4)
 
 
+def test_linear_pair_and_batched_bias(dev):
+    """ops.linear_pair (both directions' input projections as one batched product with a bias batch stride) equals two separate
+    ops.linear calls bit for bit on every dispatch path: persistent tiles (10240 rows), plain tiles (512 rows), the K-quartered
+    small kernel (ragged 200 x 96) and the non-contiguous fallback."""
+    from mmego_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for rows, ncol, K in ((10240, 256, 128), (512, 2048, 256), (200, 96, 160), (64, 32, 24)):
+        x = torch.randn(rows, K, generator=g).to(dev)
+        Wb = (torch.randn(2 * ncol + 8, K, generator=g) * 0.1).to(dev)
+        bb = torch.randn(2 * ncol + 8, generator=g).to(dev)
+        W0, W1, b0, b1 = Wb[:ncol], Wb[ncol + 8:], bb[:ncol], bb[ncol + 8:]        # a gap between the two blocks
+        ref = torch.empty(rows, 2 * ncol, device=dev)
+        ops.linear(x, W0, b0, ref[:, :ncol])
+        ops.linear(x, W1, b1, ref[:, ncol:])
+        out = torch.full((rows, 2 * ncol + 4), 3.0, device=dev)
+        ops.linear_pair(x, W0, W1, b0, b1, out, ncol)
+        assert torch.equal(out[:, :2 * ncol], ref), (rows, ncol, K)
+        assert (out[:, 2 * ncol:] == 3.0).all()
+        dbl = x.double() @ W1.double().t() + b1.double()
+        assert torch.allclose(out[:, ncol:2 * ncol].double(), dbl, rtol=1e-5, atol=2e-5 * K ** 0.5)
+    # non-contiguous weight view -> falls back to two products
+    Wt = (torch.randn(64, 2 * 48, generator=g) * 0.1).to(dev)
+    x = torch.randn(100, 64, generator=g).to(dev)
+    out = torch.empty(100, 96, device=dev)
+    b = torch.zeros(96, device=dev)
+    ops.linear_pair(x, Wt[:, :48].t(), Wt[:, 48:].t(), b[:48], b[48:], out, 48)
+    assert torch.allclose(out.double(), x.double() @ Wt.double(), rtol=1e-5, atol=1e-4)
+
+
 def test_fused_eval_mlp_and_bn_fold(dev):
     """mmego_bn_fold_linear + mmego_mlp3_eval (eval-mode PointNet stages in one kernel) against conv -> BatchNorm(eval) -> ReLU
     in fp64, for the three channel plans of the path, ragged row counts and column-slice inputs / outputs."""
