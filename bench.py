@@ -139,8 +139,11 @@ def pmc_traffic(kernel_label):
     return pmc.get(kernel_label.split(" ")[0], {}).get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(steps, warmup):
-    """The CPU oracle (a port of the reference path, pinned to it by tests/golden) on the host cores."""
+def cpu_baseline(steps, warmup, device=None):
+    """The CPU oracle (a port of the reference path, pinned to it by tests/golden) on the host cores.  While it is at hand it
+    also serves as the checker of the metric's "joint-err parity": freshly seeded nets on both sides (identical weights),
+    train-mode forward of IMU_Net -> Upper_Net -> Lower_Net on the first 8 sequences of the synthetic batch, largest joint
+    distance between the HIP path and the oracle."""
     from oracle import nets as on
     from oracle import train as ot
     ncores = host_cores()
@@ -149,10 +152,41 @@ def cpu_baseline(steps, warmup):
     imu = on.IMUNet(15, 9, 512, 2, True, 0.1)
     upper, lower = on.UpperNet(), on.LowerNet(64)
     x, imu_in, body, target = synth_batch(1234, "cpu")
+    parity = None
+    if device is not None:
+        himu, hupper, hlower, _ = build_hip_models(device)                 # same seed -> the same initial weights
+        nb = 8
+        for m in (upper, lower, hupper, hlower):
+            for mod in m.modules():
+                if hasattr(mod, "dropout") and isinstance(getattr(mod, "dropout"), float):
+                    mod.dropout = 0.0                                      # LSTM dropout off on both sides (different RNGs)
+            if hasattr(m, "lstm_dropout"):
+                m.lstm_dropout = 0.0
+        imu.eval(); upper.train(); lower.train()
+        with torch.no_grad():
+            h0, c0 = ot.zeros_state(nb)
+            xo = x[:nb].clone()
+            Ro, to_ = imu(imu_in[:nb])
+            upo = upper(xo, h0, c0, body[:nb], Ro, to_)[0]
+            loo = lower(upo.clone(), xo, h0, c0, h0, c0, body[:nb], Ro, to_)[0]
+            xh = x[:nb].clone().to(device)
+            hz = torch.zeros(6, nb, 64, device=device)
+            Rh, th = himu(imu_in[:nb].to(device))
+            uph = hupper(xh, hz, hz.clone(), body[:nb].to(device), Rh, th)[0]
+            loh = hlower(uph.clone(), xh, hz, hz, hz, hz, body[:nb].to(device), Rh, th)[0]
+        du = (uph.cpu() - upo).norm(dim=-1).max().item() * 100.0
+        dl = (loh.cpu() - loo).norm(dim=-1).max().item() * 100.0
+        parity = {"max_joint_distance_cm": max(du, dl), "upper_cm": du, "lower_cm": dl, "tolerance_cm": 1e-3,
+                  "what": "HIP vs CPU oracle, same seeded weights, train-mode forward (batch-stat BatchNorm, LSTM dropout off) of "
+                          "IMU_Net -> Upper_Net -> Lower_Net on 8 sequences of the synthetic batch"}
+        torch.manual_seed(1234)                                            # fresh oracle nets for the timed steps
+        imu = on.IMUNet(15, 9, 512, 2, True, 0.1)
+        upper, lower = on.UpperNet(), on.LowerNet(64)
     tu, tl = ot.time_ul_step(upper, lower, imu, x, imu_in, body, target, steps=steps, warmup=warmup)
-    return {"value": B * T / (tu + tl), "unit": "frames/s", "cores": ncores, "kind": "port",
-            "sample": "%d U+L steps (after %d warm-up) of the same B=64,T=8,N=128 batch; t_upper %.1f ms, t_lower %.1f ms"
-                      % (steps, warmup, tu * 1e3, tl * 1e3)}
+    out = {"value": B * T / (tu + tl), "unit": "frames/s", "cores": ncores, "kind": "port",
+           "sample": "%d U+L steps (after %d warm-up) of the same B=64,T=8,N=128 batch; t_upper %.1f ms, t_lower %.1f ms"
+                     % (steps, warmup, tu * 1e3, tl * 1e3)}
+    return out, parity
 
 
 def main():
@@ -349,7 +383,7 @@ def main():
         sys.stderr.write("[bench] gpu part done: %.1f frames/s; timing the CPU oracle on %d threads\n" % (out["value"], host_cores()))
         sys.stderr.flush()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_steps, 1)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_steps, 1, device)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
