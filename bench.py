@@ -362,7 +362,15 @@ def main():
             cands["gemm_tile_persistent_kernel (128x128 tiles; IMU_Net LSTM input projections, both directions per launch: 2 x 10240 x 2048 x {512,1024})"] = g128
         if g64:
             cands["gemm_tile_kernel<64,64> (smaller 64-aligned products)"] = g64
-        best = max(cands.items(), key=lambda kv: sum(m for m, _ in kv[1]))
+        # dominant kernel = largest total time.  The eager event pairs around the recurrent steps include a launch gap that the
+        # graph replay does not have, which can put the step kernel a few % ahead of the projection GEMM although the GEMM leads
+        # in the rocprofv3 trace of the real (graph) step: a near tie goes to the GEMM.
+        totals = {k: sum(m for m, _ in v) for k, v in cands.items()}
+        best_k = max(totals, key=totals.get)
+        gk = [k for k in totals if k.startswith("gemm_tile_persistent_kernel")]
+        if gk and totals[gk[0]] >= 0.9 * totals[best_k]:
+            best_k = gk[0]
+        best = (best_k, cands[best_k])
         tot_ms = sum(m for m, _ in best[1])
         tot_fl = sum(f for _, f in best[1])
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
