@@ -134,8 +134,7 @@ def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr):
     out = None
     for l in range(L):
         xp = ar.get("%s.xp%d" % (key, l), (B * T, 512))
-        for d in range(2):
-            ops.linear(cur, lstm.w("weight_ih", l, d), lstm.w("bias_ih", l, d), xp[:, d * 256:(d + 1) * 256])
+        ops.linear_pair(cur, lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1), lstm.w("bias_ih", l, 0), lstm.w("bias_ih", l, 1), xp, 256)
         out = ar.get("%s.out%d" % (key, l), (B * T, 128))
         if stash:
             gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
