@@ -118,69 +118,111 @@ __device__ __forceinline__ void rot6d_bwd(const float* six, float eps, const flo
   }
 }
 
-// Forward-kinematics plan: bone k writes slot child[k] = slot parent[k] + Rot[rot[k]] . body[row[k]]
-struct FkPlan {
-  int nbones, nslots, nrot;
-  int parent[16], child[16], rot[16], row[16];
-  int seed_slot[2], seed_off[2], nseed;  // slots seeded from the head output (offset into y)
+// Forward-kinematics plans, compile-time: bone k writes slot child[k] = slot parent[k] + Rot[rot[k]] . body[row[k]].
+// (With the plan as a kernel argument the per-frame joint / gradient arrays were indexed at run time and lived in scratch
+//  memory: 25-29 us per launch on 4 workgroups.  Constant indices keep them in registers.)
+//   WHICH = 0, upper head (Upper_Net.py:122-144, quirk Q4): Config.skeleton_upper_body walked in order
+//     (20,3)(3,2)(2,1)(2,4)(2,8)(4,5)(5,6)(6,7)(8,9)(9,10)(10,11)(1,0)(0,12)(0,16), slots = index in
+//     upper_joint_map [0..12,16,20] (head = slot 14, seeded from y[84:87]); rotation row = child slot, body row = k.
+//   WHICH = 1, lower head (Lower_Net.py:12-37): (12,13)(13,14)(14,15)(16,17)(17,18)(18,19), slots = joint - 12, hips at slots
+//     0 / 4 seeded from y[36:39] / y[39:42]; rotation row = index of the child in [13,14,15,17,18,19]; body rows 14..19.
+template <int WHICH> struct FkC;
+template <> struct FkC<0> {
+  static constexpr int nbones = 14, nslots = 15, nrot = 14, ny = 87, nseed = 1;
+  static constexpr int parent[14] = {14, 3, 2, 2, 2, 4, 5, 6, 8, 9, 10, 1, 0, 0};
+  static constexpr int child[14] = {3, 2, 1, 4, 8, 5, 6, 7, 9, 10, 11, 0, 12, 13};
+  static constexpr int rot[14] = {3, 2, 1, 4, 8, 5, 6, 7, 9, 10, 11, 0, 12, 13};
+  static constexpr int row[14] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13};
+  static constexpr int seed_slot[2] = {14, 0}, seed_off[2] = {84, 0};
+};
+template <> struct FkC<1> {
+  static constexpr int nbones = 6, nslots = 8, nrot = 6, ny = 42, nseed = 2;
+  static constexpr int parent[6] = {0, 1, 2, 4, 5, 6};
+  static constexpr int child[6] = {1, 2, 3, 5, 6, 7};
+  static constexpr int rot[6] = {0, 1, 2, 3, 4, 5};
+  static constexpr int row[6] = {14, 15, 16, 17, 18, 19};
+  static constexpr int seed_slot[2] = {0, 4}, seed_off[2] = {36, 39};
 };
 
 // y: [F, ny] head output (6*nrot rotation params, then positions);  body: [B, 20, 3];  frame n uses body n % B (Q2)
 // outputs: q [F, nrot, 3, 3], joints_h [F, nslots, 3] (head frame)
-__global__ __launch_bounds__(128) void head_fk_fwd_kernel(const float* __restrict__ y, int ny, const float* __restrict__ body,
-                                                          int B, long F, FkPlan plan, float* __restrict__ q,
-                                                          float* __restrict__ joints) {
+template <int WHICH>
+__global__ __launch_bounds__(64) void head_fk_fwd_kernel(const float* __restrict__ y, const float* __restrict__ body, int B, long F,
+                                                         float* __restrict__ q, float* __restrict__ joints) {
+  using P = FkC<WHICH>;
   long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
-  const float* yf = y + f * ny;
+  const float* yf = y + f * P::ny;
   const float* bf = body + (f % B) * 60;
-  float* qf = q + f * plan.nrot * 9;
-  float l[16][3];
-  for (int s = 0; s < plan.nseed; ++s)
-    for (int i = 0; i < 3; ++i) l[plan.seed_slot[s]][i] = yf[plan.seed_off[s] + i];
-  for (int k = 0; k < plan.nrot; ++k) {
+  float* qf = q + f * P::nrot * 9;
+  float l[P::nslots][3];
+  float R[P::nrot][9];
+#pragma unroll
+  for (int s = 0; s < P::nseed; ++s)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) l[P::seed_slot[s]][i] = yf[P::seed_off[s] + i];
+#pragma unroll
+  for (int k = 0; k < P::nrot; ++k) {
     Rot6 r = rot6d_fwd(yf + 6 * k, 1e-12f);
-    for (int i = 0; i < 3; ++i) { qf[k * 9 + i * 3 + 0] = r.x[i]; qf[k * 9 + i * 3 + 1] = r.y[i]; qf[k * 9 + i * 3 + 2] = r.z[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { R[k][i * 3 + 0] = r.x[i]; R[k][i * 3 + 1] = r.y[i]; R[k][i * 3 + 2] = r.z[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) qf[k * 9 + i] = R[k][i];
   }
-  for (int k = 0; k < plan.nbones; ++k) {
-    const float* Rm = qf + plan.rot[k] * 9;
-    const float* bv = bf + plan.row[k] * 3;
+#pragma unroll
+  for (int k = 0; k < P::nbones; ++k) {
+    const float* bv = bf + P::row[k] * 3;
+    const float b0 = bv[0], b1 = bv[1], b2 = bv[2];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
-      l[plan.child[k]][i] = l[plan.parent[k]][i] + (Rm[i * 3] * bv[0] + Rm[i * 3 + 1] * bv[1] + Rm[i * 3 + 2] * bv[2]);
+      l[P::child[k]][i] = l[P::parent[k]][i] + (R[P::rot[k]][i * 3] * b0 + R[P::rot[k]][i * 3 + 1] * b1 + R[P::rot[k]][i * 3 + 2] * b2);
   }
-  for (int s = 0; s < plan.nslots; ++s)
-    for (int i = 0; i < 3; ++i) joints[(f * plan.nslots + s) * 3 + i] = l[s][i];
+#pragma unroll
+  for (int s = 0; s < P::nslots; ++s)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) joints[(f * P::nslots + s) * 3 + i] = l[s][i];
 }
 
 // dj: [F, nslots, 3] gradient wrt head-frame joints  ->  dy [F, ny]
-__global__ __launch_bounds__(128) void head_fk_bwd_kernel(const float* __restrict__ y, int ny, const float* __restrict__ body,
-                                                          int B, long F, FkPlan plan, const float* __restrict__ dj,
-                                                          float* __restrict__ dy) {
+template <int WHICH>
+__global__ __launch_bounds__(64) void head_fk_bwd_kernel(const float* __restrict__ y, const float* __restrict__ body, int B, long F,
+                                                         const float* __restrict__ dj, float* __restrict__ dy) {
+  using P = FkC<WHICH>;
   long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
-  const float* yf = y + f * ny;
+  const float* yf = y + f * P::ny;
   const float* bf = body + (f % B) * 60;
-  float g[16][3];
-  for (int s = 0; s < plan.nslots; ++s)
-    for (int i = 0; i < 3; ++i) g[s][i] = dj[(f * plan.nslots + s) * 3 + i];
-  float gq[14][9];
-  for (int k = 0; k < plan.nrot; ++k)
+  float g[P::nslots][3];
+#pragma unroll
+  for (int s = 0; s < P::nslots; ++s)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[s][i] = dj[(f * P::nslots + s) * 3 + i];
+  float gq[P::nrot][9];
+#pragma unroll
+  for (int k = 0; k < P::nrot; ++k)
+#pragma unroll
     for (int i = 0; i < 9; ++i) gq[k][i] = 0.f;
-  for (int k = plan.nbones - 1; k >= 0; --k) {
-    const float* bv = bf + plan.row[k] * 3;
-    const int c = plan.child[k], pa = plan.parent[k], rr = plan.rot[k];
+#pragma unroll
+  for (int k = P::nbones - 1; k >= 0; --k) {
+    const float* bv = bf + P::row[k] * 3;
+    const float b0 = bv[0], b1 = bv[1], b2 = bv[2];
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
-      g[pa][i] += g[c][i];
-      gq[rr][i * 3 + 0] += g[c][i] * bv[0];
-      gq[rr][i * 3 + 1] += g[c][i] * bv[1];
-      gq[rr][i * 3 + 2] += g[c][i] * bv[2];
+      g[P::parent[k]][i] += g[P::child[k]][i];
+      gq[P::rot[k]][i * 3 + 0] += g[P::child[k]][i] * b0;
+      gq[P::rot[k]][i * 3 + 1] += g[P::child[k]][i] * b1;
+      gq[P::rot[k]][i * 3 + 2] += g[P::child[k]][i] * b2;
     }
   }
-  float* dyf = dy + f * ny;
-  for (int k = 0; k < plan.nrot; ++k) rot6d_bwd(yf + 6 * k, 1e-12f, gq[k], dyf + 6 * k);
-  for (int i = 6 * plan.nrot; i < ny; ++i) dyf[i] = 0.f;
-  for (int s = 0; s < plan.nseed; ++s)
-    for (int i = 0; i < 3; ++i) dyf[plan.seed_off[s] + i] = g[plan.seed_slot[s]][i];
+  float* dyf = dy + f * P::ny;
+#pragma unroll
+  for (int k = 0; k < P::nrot; ++k) rot6d_bwd(yf + 6 * k, 1e-12f, gq[k], dyf + 6 * k);
+#pragma unroll
+  for (int i = 6 * P::nrot; i < P::ny; ++i) dyf[i] = 0.f;
+#pragma unroll
+  for (int s = 0; s < P::nseed; ++s)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dyf[P::seed_off[s] + i] = g[P::seed_slot[s]][i];
 }
 
 // IMU head: out[f, 0:9] -> R [f,3,3] (eps rule 1e-8), t [f,3]
@@ -256,35 +298,6 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-static FkPlan make_plan(int which) {
-  FkPlan p;
-  if (which == 0) {  // upper: Config.skeleton_upper_body walked in order, head at slot 14 (quirk Q4)
-    static const int bones[14][2] = {{20, 3}, {3, 2}, {2, 1}, {2, 4}, {2, 8}, {4, 5}, {5, 6}, {6, 7},
-                                     {8, 9}, {9, 10}, {10, 11}, {1, 0}, {0, 12}, {0, 16}};
-    static const int umap[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 20};
-    auto slot = [&](int j) { for (int i = 0; i < 15; ++i) if (umap[i] == j) return i; return -1; };
-    p.nbones = 14; p.nslots = 15; p.nrot = 14;
-    for (int k = 0; k < 14; ++k) {
-      p.parent[k] = slot(bones[k][0]); p.child[k] = slot(bones[k][1]);
-      p.rot[k] = p.child[k]; p.row[k] = k;
-    }
-    p.nseed = 1; p.seed_slot[0] = 14; p.seed_off[0] = 84; p.seed_slot[1] = 0; p.seed_off[1] = 0;
-  } else {  // lower: hips at slots 0 and 4, body rows 14..19, rotation row from [13,14,15,17,18,19]
-    static const int bones[6][2] = {{12, 13}, {13, 14}, {14, 15}, {16, 17}, {17, 18}, {18, 19}};
-    static const int lmap[8] = {12, 13, 14, 15, 16, 17, 18, 19};
-    static const int rmap[6] = {13, 14, 15, 17, 18, 19};
-    auto slot = [&](int j) { for (int i = 0; i < 8; ++i) if (lmap[i] == j) return i; return -1; };
-    auto rslot = [&](int j) { for (int i = 0; i < 6; ++i) if (rmap[i] == j) return i; return -1; };
-    p.nbones = 6; p.nslots = 8; p.nrot = 6;
-    for (int k = 0; k < 6; ++k) {
-      p.parent[k] = slot(bones[k][0]); p.child[k] = slot(bones[k][1]);
-      p.rot[k] = rslot(bones[k][1]); p.row[k] = k + 14;
-    }
-    p.nseed = 2; p.seed_slot[0] = 0; p.seed_off[0] = 36; p.seed_slot[1] = 4; p.seed_off[1] = 39;
-  }
-  return p;
-}
-
 extern "C" int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t) {
   MMEGO_REQUIRE(pts && R && t && F > 0 && P > 0 && C >= 3);
   long n = F * P;
@@ -307,9 +320,8 @@ extern "C" int mmego_rotate_points(void* stream, const float* in, float* out, lo
 extern "C" int mmego_head_fk_forward(void* stream, int which, const float* y, const float* body, int B, long F, float* q,
                                      float* joints) {
   MMEGO_REQUIRE((which == 0 || which == 1) && y && body && q && joints && B > 0 && F > 0);
-  FkPlan plan = make_plan(which);
-  hipLaunchKernelGGL(head_fk_fwd_kernel, dim3(cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, y, which == 0 ? 87 : 42,
-                     body, B, F, plan, q, joints);
+  if (which == 0) hipLaunchKernelGGL(head_fk_fwd_kernel<0>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints);
+  else hipLaunchKernelGGL(head_fk_fwd_kernel<1>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
@@ -317,9 +329,8 @@ extern "C" int mmego_head_fk_forward(void* stream, int which, const float* y, co
 extern "C" int mmego_head_fk_backward(void* stream, int which, const float* y, const float* body, int B, long F,
                                       const float* dj, float* dy) {
   MMEGO_REQUIRE((which == 0 || which == 1) && y && body && dj && dy && B > 0 && F > 0);
-  FkPlan plan = make_plan(which);
-  hipLaunchKernelGGL(head_fk_bwd_kernel, dim3(cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, y, which == 0 ? 87 : 42,
-                     body, B, F, plan, dj, dy);
+  if (which == 0) hipLaunchKernelGGL(head_fk_bwd_kernel<0>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, dj, dy);
+  else hipLaunchKernelGGL(head_fk_bwd_kernel<1>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, dj, dy);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
