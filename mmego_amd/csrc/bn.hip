@@ -425,7 +425,9 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
   MMEGO_REQUIRE(X && rows > 0 && C > 0 && partial_ws && out);
   hipStream_t st = (hipStream_t)stream;
   if (rows <= 1024) {
-    const int TCs = col_tile(C);
+    // narrow column tiles (16 lanes across, 16 down the rows): more blocks and 4x shorter per-thread row loops than the
+    // 64-wide tile of the long-tensor path -- this kernel's time is the depth of its dependent load rounds
+    const int TCs = C >= 16 ? 16 : col_tile(C);
     hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(C, TCs)), dim3(256), 0, st, X, ldx, rows, C, out, out2, accumulate, TCs);
     MMEGO_LAUNCH_CHECK();
     return MMEGO_OK;
