@@ -204,6 +204,77 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const float* __restr
   }
 }
 
+// Same with the group's [P, C] tile staged once in LDS (tile <= 64 KB, C % 4 == 0: the PointNets' pooling, 128 x 64): every
+// thread works in every phase (the plain kernel's last loop runs on C of its 256 threads and walks the P rows serially).
+__global__ __launch_bounds__(256) void attn_pool_bwd_lds_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                                const float* __restrict__ attn, const float* __restrict__ dvec,
+                                                                int P, int C, float* __restrict__ dX, float* __restrict__ pdw,
+                                                                float* __restrict__ pdb) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Xs = lds;                        // [P][C]
+  float* sh = lds + (long)P * C;          // [P]  da -> ds
+  float* ags = sh + P;                    // [P]
+  float* part = ags + P;                  // [PG][C] partial dw
+  __shared__ float red[8];
+  const long g = blockIdx.x;
+  const float* Xg = X + g * (long)P * C;
+  const float* dv = dvec + g * C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int n4 = P * C / 4;
+  for (int i = tid; i < n4; i += blockDim.x) reinterpret_cast<f32x4*>(Xs)[i] = reinterpret_cast<const f32x4*>(Xg)[i];
+  for (int p = tid; p < P; p += blockDim.x) ags[p] = attn[g * P + p];
+  __syncthreads();
+  for (int p = wave; p < P; p += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += Xs[p * C + c] * dv[c];
+    s = wave_sum(s);
+    if (lane == 0) sh[p] = s;
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int p = tid; p < P; p += blockDim.x) dot += ags[p] * sh[p];
+  dot = wave_sum(dot);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  dot = 0.f;
+  for (int i = 0; i < nw; ++i) dot += red[i];
+  __syncthreads();
+  float dbs = 0.f;
+  for (int p = tid; p < P; p += blockDim.x) {
+    float ds = ags[p] * (sh[p] - dot);
+    sh[p] = ds;
+    dbs += ds;
+  }
+  dbs = wave_sum(dbs);
+  if (lane == 0) red[wave] = dbs;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    pdb[g] = s;
+  }
+  // dX and the per-group dw: thread (cx, pg) walks rows pg, pg + PG, ... of columns cx, cx + TCc, ...
+  const int TCc = C < 256 ? C : 256, PG = 256 / TCc;
+  const int cx = tid % TCc, pg = tid / TCc;
+  if (pg < PG) {
+    for (int c = cx; c < C; c += TCc) {
+      const float wc = w[c], dvc = dv[c];
+      float acc = 0.f;
+      for (int p = pg; p < P; p += PG) {
+        acc += sh[p] * Xs[p * C + c];
+        dX[(g * P + p) * (long)C + c] = ags[p] * dvc + sh[p] * wc;
+      }
+      part[pg * C + c] = acc;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float a = 0.f;
+    for (int q = 0; q < PG; ++q) a += part[q * C + c];
+    pdw[g * C + c] = a;
+  }
+}
+
 // Y[g, c] = scale * sum_p X[g, p, c]
 __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ X, int P, int C, float scale,
                                                         float* __restrict__ Y, long ldy, long G) {
@@ -460,6 +531,16 @@ extern "C" int mmego_attn_pool_forward(void* stream, const float* X, const float
 extern "C" int mmego_attn_pool_backward(void* stream, const float* X, const float* w, const float* attn,
                                         const float* dvec, long G, int P, int C, float* dX, float* pdw, float* pdb) {
   MMEGO_REQUIRE(X && w && attn && dvec && dX && pdw && pdb && G > 0 && P > 0 && C > 0 && P <= 8192);
+  {
+    const int TCc = C < 256 ? C : 256, PG = 256 / TCc;
+    const size_t tile = ((size_t)P * C + 2 * P + (size_t)PG * C) * sizeof(float);
+    if ((C % 4) == 0 && (256 % TCc) == 0 && tile <= 64 * 1024 && (((uintptr_t)X) & 15) == 0) {
+      hipLaunchKernelGGL(attn_pool_bwd_lds_kernel, dim3((unsigned)G), dim3(256), tile, (hipStream_t)stream, X, w, attn, dvec, P, C, dX,
+                         pdw, pdb);
+      MMEGO_LAUNCH_CHECK();
+      return MMEGO_OK;
+    }
+  }
   hipLaunchKernelGGL(attn_pool_bwd_kernel, dim3((unsigned)G), dim3(256), (size_t)P * sizeof(float), (hipStream_t)stream,
                      X, w, attn, dvec, P, C, dX, pdw, pdb);
   MMEGO_LAUNCH_CHECK();
