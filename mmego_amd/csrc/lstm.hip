@@ -27,9 +27,10 @@ struct Lstm64P {
   int B, T;
 };
 
-// rcp-based activations (as in lstm_step.hip): ~1 ulp from the libm forms, a fraction of their instruction count
-__device__ __forceinline__ float l64_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
-__device__ __forceinline__ float l64_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + expf(2.0f * x)); }
+// rcp / v_exp_f32-based activations: a few ulp from the libm forms at a fraction of their instruction count (the step loop
+// of this kernel issued ~490 VALU instructions per 64 MFMAs, most of them libm expf and 64-bit address arithmetic)
+__device__ __forceinline__ float l64_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float l64_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load / store
 // (vmcnt(0)), which would put the prefetch of the next step's inputs and this step's stash stores back on the critical path.
@@ -39,18 +40,11 @@ __device__ __forceinline__ float l64_tanh(float x) { return 1.0f - 2.0f * __buil
 
 __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ws = smem;              // [64 k][WLD]   Ws[k][n] = W_hh[n][k]
-  float* hs = smem + 64 * WLD;   // [64 k][16 rows]
+  float* hs = smem;              // [64 k][16 rows]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = blockIdx.y, r0 = blockIdx.x * 16;
   const int B = p.B, T = p.T;
   const float* W = p.whh[d];
-  for (int i = tid; i < 256 * 16; i += 256) {  // 256 rows x 16 float4
-    int n = i >> 4, k4 = (i & 15) * 4;
-    float4 v = *reinterpret_cast<const float4*>(W + n * 64 + k4);
-    Ws[(k4 + 0) * WLD + n] = v.x; Ws[(k4 + 1) * WLD + n] = v.y;
-    Ws[(k4 + 2) * WLD + n] = v.z; Ws[(k4 + 3) * WLD + n] = v.w;
-  }
   const int fr = lane & 15, fq = lane >> 4;
   const int j = wave * 16 + fr;  // hidden unit of this lane
   float creg[4], hreg[4], bh[4];
@@ -65,13 +59,19 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
     hs[j * 16 + fq * 4 + reg] = hreg[reg];
   }
   __syncthreads();
-  // this lane's W_hh operand fragments (its hidden unit's 4 gate columns x the 16 k-quads it feeds) stay in registers for the
-  // whole sequence: the per-step inner loop is then 16 LDS reads of h + 64 MFMAs
+  // This lane's W_hh operand fragments stay in registers for the whole sequence, loaded straight from global memory: at
+  // MFMA step s lane quad fq takes k = 16 fq + s (for h and W_hh alike: any k order is valid as long as both operands agree),
+  // so the 16 values of a gate are 4 contiguous 16-B loads.  No W_hh tile in LDS, no staging pass.
   float wreg[16][4];
 #pragma unroll
-  for (int k4 = 0; k4 < 16; ++k4)
+  for (int g = 0; g < 4; ++g) {
+    const float* wrow = W + (g * 64 + j) * 64 + 16 * fq;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) wreg[k4][g] = Ws[(k4 * 4 + fq) * WLD + g * 64 + wave * 16 + fr];
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
+      wreg[4 * q + 0][g] = v.x; wreg[4 * q + 1][g] = v.y; wreg[4 * q + 2][g] = v.z; wreg[4 * q + 3][g] = v.w;
+    }
+  }
 
   // The input projections do not depend on the recurrence: step s+1's values are fetched while step s computes, so
   // their latency (the longest thing in a step otherwise) is off the critical path.
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
     for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k4 = 0; k4 < 16; ++k4) {
-      float a = hs[(k4 * 4 + fq) * 16 + fr];
+      float a = hs[(16 * fq + k4) * 16 + fr];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[k4][g], acc[g], 0, 0, 0);
     }
@@ -167,7 +167,7 @@ extern "C" int mmego_lstm64_forward(void* stream, int B, int T, const float* xpr
   p.gates[0] = gates0; p.gates[1] = gates1; p.cst[0] = cst0; p.cst[1] = cst1;
   p.hprev[0] = hprev0; p.hprev[1] = hprev1;
   p.B = B; p.T = T;
-  size_t lds = (size_t)(64 * WLD + 64 * 16) * sizeof(float);
+  size_t lds = (size_t)(64 * 16) * sizeof(float);            // h tile only: W_hh lives in registers
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm64_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
