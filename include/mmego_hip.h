@@ -103,6 +103,29 @@ int mmego_lstm64_backward(void* stream, int B, int T, const float* dout, long do
                           const float* c0_1, const float* whh0, const float* whh1, float* dgates0, float* dgates1,
                           long dgs);
 
+/* ---- bf16-operand / fp32-accumulate forward of the frozen IMU_Net (bf16.hip; BASELINE config 5) -------------------
+ * Opt-in precision mode, never the parity path.  bf16 values cross the ABI as raw bits in unsigned short.
+ * Y[r, 0:cols] = bf16(X[r, 0:cols]) (round to nearest even); cols, ldx, ldy multiples of 4. */
+int mmego_cvt_bf16(void* stream, const float* X, long ldx, long rows, long cols, unsigned short* Y, long ldy);
+/* C[M,N] = A[M,K] . W[N,K]^T + bias[N] (relu), operands bf16, products and sums fp32; C (fp32) and/or Cb (bf16 copy)
+ * are written.  K % 64 == 0.  Replaces the BiLSTM input projections of Net/IMU_Net.py:58-62 in bf16 mode. */
+int mmego_gemm_bf16(void* stream, const unsigned short* A, long lda, const unsigned short* W, long ldw, float* C,
+                    long ldc, unsigned short* Cb, long ldcb, const float* bias, int M, int N, int K, int relu);
+/* One (bi)LSTM timestep as mmego_lstm_step, with h_{t-1} and W_hh in bf16: gates = xproj + h_{t-1} . W_hh^T (xproj
+ * already holds b_ih + b_hh), cell update in fp32, c in place.  H % 64 == 0.
+ * The recurrent operands are FRAGMENT-MAJOR (the order the MFMA lanes read them, so a wave's operand load is one
+ * coalesced 1-KB read): element (r, k) of an [R, H] matrix sits at
+ *     (((r/32)*(H/16) + k/16)*64 + ((k/8)&1)*32 + r%32)*8 + k%8        (R padded to a multiple of 32 rows).
+ * hprev_d: h_{t-1} in that layout (R = Bn); whh_d: W_hh in that layout with its rows reordered to
+ * [hidden block jb][gate n][32 units] (row 128*jb + 32*n + jj = W_hh[n*H + 32*jb + jj]).
+ * h_t is written three times: hout (fp32, row stride hos), houtb (bf16 row-major, row stride hbs, may be NULL: the next
+ * layer's projection operand) and hfrag_d (bf16 fragment-major: the next step's hprev_d; must not alias hprev_d). */
+int mmego_lstm_step_bf16(void* stream, int ndir, int Bn, int H, int first, const unsigned short* hprev0,
+                         const unsigned short* hprev1, const unsigned short* whh0, const unsigned short* whh1,
+                         const float* xproj0, const float* xproj1, long xs, float* hout0, float* hout1,
+                         long hos, unsigned short* houtb0, unsigned short* houtb1, long hbs,
+                         unsigned short* hfrag0, unsigned short* hfrag1, float* c0, float* c1);
+
 /* ---- IMU_Net stage-1 training pieces (imu_train.hip): reference Processor/Train/Train_IMU.py:21-34,114-149 -------
  * Pointwise LSTM cell backward of one timestep, both directions: dh = dout + dh_rec (dh_rec may be NULL), reads the
  * stashed gates / cell states, writes the pre-activation gate gradients dgates_d [Bn][4H] (row stride dgs) and updates

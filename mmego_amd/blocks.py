@@ -242,3 +242,72 @@ def lstm_steps_forward(ar, key, lstm, x, Bn, T):
                      out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_, c[0], c[1], None, None, None, None)
         cur = out
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16-operand / fp32-accumulate BiLSTM forward (opt-in precision mode of the frozen IMU_Net, bf16.hip)
+# ---------------------------------------------------------------------------------------------------
+def cvt_bf16(x, out):
+    """out (torch.bfloat16 storage) = round-to-nearest-even(x); 2-D row-strided views."""
+    if x.dim() != 2 or out.shape != x.shape or x.stride(1) != 1 or out.stride(1) != 1 or out.dtype != torch.bfloat16:
+        raise ValueError("cvt_bf16 needs 2-D unit-column-stride fp32 input and a bf16 output of the same shape")
+    hip.call("cvt_bf16", x, x.stride(0), x.shape[0], x.shape[1], out, out.stride(0))
+    return out
+
+
+def lstm_bf16_weights(lstm):
+    """Per layer: (W_ih of both directions stacked [8H, In] bf16, b_ih + b_hh stacked [8H] fp32, W_hh bf16 per direction).
+    Built once per parameter version (the IMU_Net of stages 2/3 is frozen)."""
+    ver = tuple(p._version for p in lstm.parameters()) + tuple(p.data_ptr() for p in lstm.parameters())
+    cache = getattr(lstm, "_bf16_cache", None)
+    if cache is not None and cache[0] == ver:
+        return cache[1]
+    H = lstm.hidden_size
+    layers = []
+    for l in range(lstm.num_layers):
+        In = lstm.w("weight_ih", l, 0).shape[1]
+        dev = lstm.w("weight_ih", l, 0).device
+        wih = torch.empty((8 * H, In), dtype=torch.bfloat16, device=dev)
+        bias = torch.empty((8 * H,), dtype=torch.float32, device=dev)
+        whh = []
+        for d in range(2):
+            cvt_bf16(lstm.w("weight_ih", l, d).detach(), wih[4 * H * d:4 * H * (d + 1)])
+            hip.call("add", lstm.w("bias_ih", l, d).detach(), lstm.w("bias_hh", l, d).detach(), bias[4 * H * d:], 4 * H)
+            wb = cvt_bf16(lstm.w("weight_hh", l, d).detach(), torch.empty((4 * H, H), dtype=torch.bfloat16, device=dev))
+            # fragment-major [hidden block][gate][16-k step][k half][unit][8 k] (include/mmego_hip.h, mmego_lstm_step_bf16):
+            # a one-time re-layout of frozen weights
+            whh.append(wb.view(4, H // 32, 32, H // 16, 2, 8).permute(1, 0, 3, 4, 2, 5).contiguous())
+        layers.append((wih, bias, whh[0], whh[1]))
+    lstm._bf16_cache = (ver, layers)
+    return layers
+
+
+def lstm_steps_forward_bf16(ar, key, lstm, x_bf, Bn, T):
+    """As lstm_steps_forward with bf16 product operands: x_bf [Bn*T, In] bf16 rows (b*T+t) -> (out fp32, out bf16)
+    [Bn*T, 2H] of the last layer.  Gate pre-activations, cell state and outputs are fp32."""
+    H = lstm.hidden_size
+    W = lstm_bf16_weights(lstm)
+    cur = x_bf
+    out = outb = None
+    for l in range(lstm.num_layers):
+        wih, bias, whh0, whh1 = W[l]
+        xp = ar.get("%s.xp%d" % (key, l), (Bn * T, 8 * H))
+        hip.call("gemm_bf16", cur, cur.stride(0), wih, wih.stride(0), xp, xp.stride(0), None, 0, bias,
+                 Bn * T, 8 * H, cur.shape[1], 0)
+        if milestone is not None:
+            milestone(key, l)
+        out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
+        outb = ar.get("%s.outb%d" % (key, l), (Bn * T, 2 * H), dtype=torch.bfloat16)
+        c = ar.get("%s.c" % key, (2, Bn, H))
+        hf = ar.get("%s.hfrag" % key, (2, 2, (Bn + 31) // 32 * 32, H), dtype=torch.bfloat16)   # [ping-pong][direction]
+        xp_p, out_p, outb_p = xp.data_ptr(), out.data_ptr(), outb.data_ptr()
+        xs, os_ = T * 8 * H, T * 2 * H       # row strides between consecutive batch rows b
+        for s in range(T):
+            t0, t1 = s, T - 1 - s
+            prev, nxt = hf[(s + 1) & 1], hf[s & 1]
+            hip.call("lstm_step_bf16", 2, Bn, H, int(s == 0), prev[0] if s > 0 else None, prev[1] if s > 0 else None,
+                     whh0, whh1, xp_p + 4 * (t0 * 8 * H), xp_p + 4 * (t1 * 8 * H + 4 * H), xs,
+                     out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_,
+                     outb_p + 2 * (t0 * 2 * H), outb_p + 2 * (t1 * 2 * H + H), os_, nxt[0], nxt[1], c[0], c[1])
+        cur = outb
+    return out, outb

@@ -1,0 +1,471 @@
+// bf16-input / fp32-accumulate contractions for the frozen IMU_Net forward (BASELINE config 5: "bf16 forward / fp32
+// accumulate").  Opt-in: the fp32 kernels (gemm_tile.hip, lstm_step.hip) stay the default and the parity path.
+//
+// What is bf16 and what is not: the two OPERANDS of every dense product (activations and weights of the BiLSTM input
+// projections, h_{t-1} and W_hh of the recurrence -- Net/IMU_Net.py:58-62,77,82) are rounded to bf16 (round to nearest
+// even); products are exact in fp32 and accumulate in fp32 on v_mfma_f32_32x32x16_bf16; gate pre-activations, the
+// cell state, the cell non-linearities and every output are fp32.
+//
+//   cvt_bf16_kernel          fp32 -> bf16 (RNE), 2-D with row strides.
+//   gemm_bf16_nt_kernel      C[M,N] = A[M,K] . W[N,K]^T + bias  (128x128 tile, 64-k chunks, 4 waves x (64x64)).
+//   lstm_step_bf16_*kernel   one BiLSTM timestep: gates = xproj + h_{t-1} . W_hh^T, fused cell update; writes h_t as fp32
+//                            (consumers: pooling, heads) and as bf16 (next step's / next layer's product operand).
+//                            The recurrent operands live in a fragment-major layout (see below).
+#include "common.h"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef unsigned short bf16_t;   // raw bf16 bits (the C ABI carries them as unsigned short)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned int f2bf_bits(float x) {
+  unsigned int u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;                     // round to nearest even
+}
+
+// ---- fp32 -> bf16 ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ X, long ldx, long rows, long cols4,
+                                                        bf16_t* __restrict__ Y, long ldy) {
+  const long total = rows * cols4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cols4, c = (i - r * cols4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(X + r * ldx + c);
+    uint2 o;
+    o.x = f2bf_bits(v[0]) | (f2bf_bits(v[1]) << 16);
+    o.y = f2bf_bits(v[2]) | (f2bf_bits(v[3]) << 16);
+    *reinterpret_cast<uint2*>(Y + r * ldy + c) = o;
+  }
+}
+
+extern "C" int mmego_cvt_bf16(void* stream, const float* X, long ldx, long rows, long cols, unsigned short* Y, long ldy) {
+  MMEGO_REQUIRE(rows >= 0 && cols >= 0 && cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0);
+  MMEGO_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Y) & 7) == 0);
+  if (rows == 0 || cols == 0) return MMEGO_OK;
+  const long total = rows * (cols / 4);
+  const int grid = (int)(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+  cvt_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(X, ldx, rows, cols / 4, Y, ldy);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// ---- shared tile machinery -----------------------------------------------------------------------------------------
+// Operand tiles sit in LDS as [row][64 k + 8 pad] bf16 (144-B rows): a lane's MFMA operand is the 16 B at
+// (row = lane%32, k = 8*(lane/32) .. +8) of a 16-k step, one ds_read_b128; 144-B rows put 16 consecutive rows' 16-B
+// reads on 16 distinct bank quads (conflict-free).
+#define BK 64
+#define BLD 72
+
+// XCD-aware tile order: blocks b and b+8 share an XCD; hand each XCD a contiguous run of tile ids.
+__device__ __forceinline__ int bf_xcd_order(int id, int n) { return (n & 7) == 0 ? (id & 7) * (n >> 3) + (id >> 3) : id; }
+
+__device__ __forceinline__ bf16x8 lds_frag(const bf16_t* tile, int row, int k) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * BLD + k);
+}
+
+struct GemmBfP {
+  const bf16_t* A; long lda;
+  const bf16_t* W; long ldw;
+  float* C; long ldc;
+  bf16_t* Cb; long ldcb;        // optional bf16 copy of the output
+  const float* bias;
+  int M, N, K, relu, tiles_m, tiles_n;
+};
+
+// 256 threads, tile 128 (M) x 128 (N); wave w owns the 64x64 block (w/2, w%2): 2x2 MFMA 32x32 tiles, 64 accumulators.
+// One LDS buffer; the next chunk travels global -> registers while the current one is multiplied.
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBfP p) {
+  __shared__ __attribute__((aligned(16))) bf16_t As[128 * BLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[128 * BLD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  // tile order: runs of 16 row-panels sweep the N tiles, so a W tile is shared by 16 consecutive blocks and the 16 A
+  // panels stay in L2 for the whole sweep.
+  const int id = bf_xcd_order(blockIdx.x, (int)gridDim.x);
+  const int GM = 16;
+  const int per_group = GM * p.tiles_n;
+  const int group = id / per_group, in_group = id - group * per_group;
+  const int gm = min(GM, p.tiles_m - group * GM);
+  const int tm = group * GM + in_group % gm, tn = in_group / gm;
+  const int m0 = tm * 128, n0 = tn * 128;
+
+  const int lrow = tid >> 3, lseg = (tid & 7) * 8;
+  const bf16_t* ag[4];
+  const bf16_t* wg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ag[i] = p.A + (long)min(m0 + lrow + 32 * i, p.M - 1) * p.lda + lseg;
+    wg[i] = p.W + (long)min(n0 + lrow + 32 * i, p.N - 1) * p.ldw + lseg;
+  }
+  u32x4 ra[4], rb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ra[i] = *reinterpret_cast<const u32x4*>(ag[i]);
+    rb[i] = *reinterpret_cast<const u32x4*>(wg[i]);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+  const int fr = lane & 31, fk = (lane >> 5) * 8;
+  for (int k0 = 0; k0 < p.K; k0 += BK) {
+    __syncthreads();   // the previous chunk's fragments have been read
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(As + (lrow + 32 * i) * BLD + lseg) = ra[i];
+      *reinterpret_cast<u32x4*>(Bs + (lrow + 32 * i) * BLD + lseg) = rb[i];
+    }
+    __syncthreads();
+    if (k0 + BK < p.K) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const u32x4*>(ag[i] + k0 + BK);
+        rb[i] = *reinterpret_cast<const u32x4*>(wg[i] + k0 + BK);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = lds_frag(As, wm * 64 + mi * 32 + fr, kk + fk);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) b[ni] = lds_frag(Bs, wn * 64 + ni * 32 + fr, kk + fk);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+  // C layout of the 32x32 MFMA: register i of lane l is (row = 8*(i/4) + 4*(l/32) + i%4, col = l%32)
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = n0 + wn * 64 + ni * 32 + fr;
+    if (col >= p.N) continue;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + wm * 64 + mi * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+        if (row < p.M) {
+          float v = acc[mi][ni][i] + bv;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.C) p.C[(long)row * p.ldc + col] = v;
+          if (p.Cb) p.Cb[(long)row * p.ldcb + col] = (bf16_t)f2bf_bits(v);
+        }
+      }
+    }
+  }
+}
+
+extern "C" int mmego_gemm_bf16(void* stream, const unsigned short* A, long lda, const unsigned short* W, long ldw, float* C,
+                               long ldc, unsigned short* Cb, long ldcb, const float* bias, int M, int N, int K, int relu) {
+  MMEGO_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
+  MMEGO_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (C || Cb));
+  GemmBfP p;
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.Cb = Cb; p.ldcb = ldcb; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.relu = relu;
+  p.tiles_m = cdiv(M, 128); p.tiles_n = cdiv(N, 128);
+  const long tiles = (long)p.tiles_m * p.tiles_n;
+  MMEGO_REQUIRE(tiles < (1L << 30));
+  gemm_bf16_nt_kernel<<<(int)tiles, 256, 0, (hipStream_t)stream>>>(p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// ---- one BiLSTM timestep ---------------------------------------------------------------------------------------------
+// FRAGMENT-MAJOR operand layout.  The MFMA wants, per 16-k step s and 32-row block rb, 16 B per lane: lane l holds
+// row 32*rb + l%32, k = 16*s + 8*(l/32) .. +8.  Row-major storage makes that 32 different cache lines per wave
+// instruction; so both recurrent operands -- W_hh (frozen, laid out once on the host) and h_{t-1} (written by the previous
+// step's epilogue) -- are stored as the lanes will read them:
+//     frag(X, rb, s)[l][e] = X[32*rb + l%32][16*s + 8*(l/32) + e],   blocks ordered [rb][s], 1 KB each,
+// i.e. element (r, k) sits at (((r/32)*(H/16) + k/16)*64 + ((k/8)&1)*32 + r%32)*8 + k%8.  For W_hh the "rows" are
+// ordered [hidden block jb][gate n][32 hidden units] (row 128*jb + 32*n + jj = W_hh[n*H + 32*jb + jj]), so one WG's four
+// gate tiles are adjacent.  A wave's fragment load is then one fully coalesced 1-KB read and needs no LDS transpose.
+struct StepBfP {
+  const bf16_t* hprev[2];               // h_{t-1}, fragment-major, ceil(Bn/32) row blocks
+  const bf16_t* whh[2];                 // W_hh, fragment-major as above
+  const float* xproj[2]; long xs;       // x.W_ih^T + b_ih + b_hh (fp32)
+  float* hout[2]; long hos;             // h_t fp32, row-major
+  bf16_t* houtb[2]; long hbs;           // h_t bf16, row-major (next layer's projection operand); may be null
+  bf16_t* hfrag[2];                     // h_t bf16, fragment-major (next step's operand)
+  float* c[2];
+  int Bn, H, first;
+};
+
+__device__ __forceinline__ float bf_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float bf_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+__device__ __forceinline__ long frag_off(int r, int k, int H) {
+  return ((((long)(r >> 5) * (H >> 4) + (k >> 4)) * 64) + ((k >> 3) & 1) * 32 + (r & 31)) * 8 + (k & 7);
+}
+
+// cell update of one (row, j) and the three stores of h_t
+__device__ __forceinline__ void bf_cell(const StepBfP& p, int d, int row, int j, float pi, float pf, float pg, float po,
+                                        float cprev) {
+  const float gi = bf_sigmoid(pi), gf = bf_sigmoid(pf), gg = bf_tanh(pg), go = bf_sigmoid(po);
+  const float cn = gf * cprev + gi * gg;
+  const float hn = go * bf_tanh(cn);
+  p.c[d][(long)row * p.H + j] = cn;
+  p.hout[d][(long)row * p.hos + j] = hn;
+  const bf16_t hb = (bf16_t)f2bf_bits(hn);
+  if (p.houtb[d]) p.houtb[d][(long)row * p.hbs + j] = hb;
+  p.hfrag[d][frag_off(row, j, p.H)] = hb;
+}
+
+// Large batches (Bn > 2048) or H % 256 != 0.  WG = (32*WR*(4/KS)) batch rows x 32 hidden units x 4 gates; 4 waves.
+// Wave w: row group w % (4/KS), k-slice w / (4/KS) (KS = 2: the 16-k steps {0,1} or {2,3} of every 64-k chunk; the
+// slices are summed through LDS at the end).  64-k chunks are staged in LDS, themselves fragment-major (a straight
+// 4-KB copy per row block; lane-linear ds_read_b128, conflict-free without padding); the next chunk travels
+// global -> registers while the current one is multiplied.
+//   <WR=2, KS=1>: 256 rows / WG -- a W_hh tile is read once per 256 batch rows.
+//   <WR=1, KS=2>:  64 rows / WG -- small batches with H % 256 != 0.
+// The accumulator tile n (of 4) is gate n for hidden units j0..j0+31, so one lane holds i, f, g, o of its (row, j).
+template <int WR, int KS>
+__global__ __launch_bounds__(256) void lstm_step_bf16_kernel(StepBfP p) {
+  constexpr int RG = 4 / KS;            // row groups (waves along rows)
+  constexpr int ROWS = 32 * WR * RG;    // batch rows per WG
+  constexpr int RB = ROWS / 32;         // row blocks per WG = 16-B loads per thread and chunk for the h tile
+  constexpr int TILE_B = (RB + 4) * 4096;
+  constexpr int RED_B = KS == 2 ? RG * WR * 4 * 16 * 64 * 4 : 0;
+  constexpr int SMEM_B = TILE_B > RED_B ? TILE_B : RED_B;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_B];
+  u32x4* As = reinterpret_cast<u32x4*>(smem_raw);       // [RB][4 steps][64 lanes] 16-B fragments
+  u32x4* Bs = As + RB * 256;                            // [4 gates][4 steps][64 lanes]
+  float* red = reinterpret_cast<float*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wr = w % RG, wk = w / RG;
+  const int d = blockIdx.z, H = p.H, S = H >> 4;
+  // blocks sharing a W_hh slice (same j0, different rows) are consecutive ids on one XCD
+  const int nrb = gridDim.y, nb = gridDim.x * nrb;
+  const int id = bf_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, nb);
+  const int jb = id / nrb, j0 = jb * 32, r0 = (id % nrb) * ROWS;
+  const int fr = lane & 31, fh = lane >> 5;
+
+  f32x16 acc[WR][4];
+#pragma unroll
+  for (int mi = 0; mi < WR; ++mi)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][n][i] = 0.f;
+
+  if (!p.first) {
+    const int last_rb = (p.Bn - 1) >> 5;
+    const u32x4* ag[RB];
+    const u32x4* wg[4];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      ag[i] = reinterpret_cast<const u32x4*>(p.hprev[d]) + (long)min((r0 >> 5) + i, last_rb) * S * 64 + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wg[i] = reinterpret_cast<const u32x4*>(p.whh[d]) + (long)(jb * 4 + i) * S * 64 + tid;
+    u32x4 ra[RB], rb[4];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) ra[i] = ag[i][0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[i] = wg[i][0];
+    for (int s0 = 0; s0 < S; s0 += 4) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < RB; ++i) As[i * 256 + tid] = ra[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Bs[i * 256 + tid] = rb[i];
+      __syncthreads();
+      if (s0 + 4 < S) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) ra[i] = ag[i][(s0 + 4) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = wg[i][(s0 + 4) * 64];
+      }
+#pragma unroll
+      for (int s = 0; s < 4 / KS; ++s) {
+        const int sl = wk * (4 / KS) + s;
+        u32x4 a[WR], b[4];
+#pragma unroll
+        for (int mi = 0; mi < WR; ++mi) a[mi] = As[((wr * WR + mi) * 4 + sl) * 64 + lane];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b[n] = Bs[(n * 4 + sl) * 64 + lane];
+#pragma unroll
+        for (int mi = 0; mi < WR; ++mi)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi]),
+                                                                 __builtin_bit_cast(bf16x8, b[n]), acc[mi][n], 0, 0, 0);
+      }
+    }
+    if (KS == 2) {
+      __syncthreads();   // operand tiles are dead: their LDS becomes the reduction buffer
+      if (wk == 1) {
+#pragma unroll
+        for (int mi = 0; mi < WR; ++mi)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(((wr * WR + mi) * 4 + n) * 16 + i) * 64 + lane] = acc[mi][n][i];
+      }
+      __syncthreads();
+      if (wk == 0) {
+#pragma unroll
+        for (int mi = 0; mi < WR; ++mi)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][n][i] += red[(((wr * WR + mi) * 4 + n) * 16 + i) * 64 + lane];
+      }
+    }
+  }
+  if (wk != 0) return;
+  const int j = j0 + fr;
+#pragma unroll
+  for (int mi = 0; mi < WR; ++mi) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = r0 + (wr * WR + mi) * 32 + 8 * (i >> 2) + 4 * fh + (i & 3);
+      if (row < p.Bn) {
+        const float* xp = p.xproj[d] + (long)row * p.xs + j;
+        const float cprev = p.first ? 0.f : p.c[d][(long)row * H + j];
+        bf_cell(p, d, row, j, acc[mi][0][i] + xp[0], acc[mi][1][i] + xp[H], acc[mi][2][i] + xp[2 * H],
+                acc[mi][3][i] + xp[3 * H], cprev);
+      }
+    }
+  }
+}
+
+// Small batches (Bn <= 2048, H % 256 == 0; the config-3 shape Bn = 512, H = 512 gives 8 x 16 x 2 = 256 WGs, one per CU):
+// the step is a chain of latencies (launch, operand fetch, product, cell), not a throughput problem, so the kernel is
+// built to pay ONE memory latency.  No LDS staging: wave w takes k quarter w of the WG's whole 64 rows x 128 W rows, so no
+// fragment is fetched twice, and requests all its fragments (GS 16-k steps x 6 coalesced 1-KB reads) before the first
+// MFMA, together with the xproj / c values of the cells it will finish.  The four k-quarter partial tiles meet in LDS
+// (each wave writes its 128 accumulators, then sums the 32 of the 16 rows x 32 units it owns, in fixed order), and all
+// four waves run the cell update.
+template <int GS>
+__global__ __launch_bounds__(256) void lstm_step_bf16_direct_kernel(StepBfP p) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [4 waves][2 mi][4 n][16 i][64 lanes] = 128 KB
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int d = blockIdx.z, H = p.H, S = H >> 4, SQ = S >> 2;
+  const int nrb = gridDim.y, nb = gridDim.x * nrb;
+  const int id = bf_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, nb);
+  const int jb = id / nrb, j0 = jb * 32, r0 = (id % nrb) * 64;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int j = j0 + fr;
+  const int own_mi = w >> 1, own_i0 = 8 * (w & 1);     // this wave finishes rows 32*own_mi + 16*(w&1) .. +16:
+  const int own_r0 = own_mi * 32 + 16 * (w & 1);       // accumulator registers own_i0 .. own_i0+8 of row block own_mi
+
+  float xp[4][8], cprev[8];
+#pragma unroll
+  for (int ii = 0; ii < 8; ++ii) {
+    const int row = min(r0 + own_r0 + 8 * (ii >> 2) + 4 * fh + (ii & 3), p.Bn - 1);
+    const float* x = p.xproj[d] + (long)row * p.xs + j;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) xp[n][ii] = x[n * H];
+    cprev[ii] = p.first ? 0.f : p.c[d][(long)row * H + j];
+  }
+  float pre[4][8];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) pre[n][ii] = 0.f;
+
+  if (!p.first) {
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mi][n][i] = 0.f;
+    const int last_rb = (p.Bn - 1) >> 5;
+    const u32x4* ap[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+      ap[mi] = reinterpret_cast<const u32x4*>(p.hprev[d]) + ((long)min((r0 >> 5) + mi, last_rb) * S + w * SQ) * 64 + lane;
+    const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh[d]) + ((long)jb * 4 * S + w * SQ) * 64 + lane;
+    const int gstride = S * 64;             // between the gates' fragment runs
+    for (int s0 = 0; s0 < SQ; s0 += GS) {
+      u32x4 a[GS][2], b[GS][4];
+#pragma unroll
+      for (int s = 0; s < GS; ++s) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[s][mi] = ap[mi][(s0 + s) * 64];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b[s][n] = wp[n * gstride + (s0 + s) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // every request is out before the first MFMA (the scheduler would interleave them)
+#pragma unroll
+      for (int s = 0; s < GS; ++s)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s][mi]),
+                                                                 __builtin_bit_cast(bf16x8, b[s][n]), acc[mi][n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[(((w * 2 + mi) * 4 + n) * 16 + i) * 64 + lane] = acc[mi][n][i];
+    __syncthreads();
+#pragma unroll
+    for (int src = 0; src < 4; ++src)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) pre[n][ii] += red[(((src * 2 + own_mi) * 4 + n) * 16 + own_i0 + ii) * 64 + lane];
+  }
+#pragma unroll
+  for (int ii = 0; ii < 8; ++ii) {
+    const int row = r0 + own_r0 + 8 * (ii >> 2) + 4 * fh + (ii & 3);
+    if (row < p.Bn)
+      bf_cell(p, d, row, j, pre[0][ii] + xp[0][ii], pre[1][ii] + xp[1][ii], pre[2][ii] + xp[2][ii], pre[3][ii] + xp[3][ii], cprev[ii]);
+  }
+}
+
+extern "C" int mmego_lstm_step_bf16(void* stream, int ndir, int Bn, int H, int first, const unsigned short* hprev0,
+                                    const unsigned short* hprev1, const unsigned short* whh0, const unsigned short* whh1,
+                                    const float* xproj0, const float* xproj1, long xs, float* hout0, float* hout1,
+                                    long hos, unsigned short* houtb0, unsigned short* houtb1, long hbs,
+                                    unsigned short* hfrag0, unsigned short* hfrag1, float* c0, float* c1) {
+  MMEGO_REQUIRE((ndir == 1 || ndir == 2) && Bn > 0 && H > 0 && H % 64 == 0);
+  MMEGO_REQUIRE(first || (hprev0 && (ndir == 1 || hprev1) && (((uintptr_t)hprev0) & 15) == 0 &&
+                          (ndir == 1 || (((uintptr_t)hprev1) & 15) == 0)));
+  MMEGO_REQUIRE((((uintptr_t)whh0) & 15) == 0 && (ndir == 1 || (((uintptr_t)whh1) & 15) == 0));
+  MMEGO_REQUIRE(hfrag0 && (ndir == 1 || hfrag1) && hfrag0 != hprev0 && (ndir == 1 || hfrag1 != hprev1));
+  StepBfP p;
+  p.hprev[0] = hprev0; p.hprev[1] = hprev1;
+  p.whh[0] = whh0; p.whh[1] = whh1;
+  p.xproj[0] = xproj0; p.xproj[1] = xproj1; p.xs = xs;
+  p.hout[0] = hout0; p.hout[1] = hout1; p.hos = hos;
+  p.houtb[0] = houtb0; p.houtb[1] = houtb1; p.hbs = hbs;
+  p.hfrag[0] = hfrag0; p.hfrag[1] = hfrag1;
+  p.c[0] = c0; p.c[1] = c1;
+  p.Bn = Bn; p.H = H; p.first = first;
+  hipStream_t st = (hipStream_t)stream;
+  if (Bn <= 2048 && H % 256 == 0) {
+    const int lds = 4 * 2 * 4 * 16 * 64 * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)lstm_step_bf16_direct_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lstm_step_bf16_direct_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    dim3 grid(H / 32, cdiv(Bn, 64), ndir);
+    if (H % 512 == 0) lstm_step_bf16_direct_kernel<8><<<grid, 256, lds, st>>>(p);
+    else lstm_step_bf16_direct_kernel<4><<<grid, 256, lds, st>>>(p);
+  } else if (Bn <= 2048) {
+    dim3 grid(H / 32, cdiv(Bn, 64), ndir);
+    lstm_step_bf16_kernel<1, 2><<<grid, 256, 0, st>>>(p);
+  } else {
+    dim3 grid(H / 32, cdiv(Bn, 256), ndir);
+    lstm_step_bf16_kernel<2, 1><<<grid, 256, 0, st>>>(p);
+  }
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

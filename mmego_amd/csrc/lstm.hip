@@ -74,30 +74,47 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
   }
 
   // The input projections do not depend on the recurrence: step s+1's values are fetched while step s computes, so
-  // their latency (the longest thing in a step otherwise) is off the critical path.
+  // their latency (the longest thing in a step otherwise) is off the critical path.  All addresses advance by a
+  // per-step stride from bases computed once (the address arithmetic used to outweigh the MFMAs).
   float xp[4][4], xpn[4][4];
-#define L64_LOAD_XP(DST, step)                                                                      \
+  const bool stash = p.gates[d] != nullptr, keep_h = p.hprev[d] != nullptr;
+  const int t_first = d == 0 ? 0 : T - 1;
+  const long dir = d == 0 ? 1 : -1;
+  const float* xq[4];
+  float* oq[4];
+  float* hq[4];
+  float* gq[4];
+  float* cq[4];
+  bool live[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = r0 + fq * 4 + reg;
+    live[reg] = row < B;
+    const long rt = (long)(live[reg] ? row : 0) * T + t_first;
+    xq[reg] = p.xproj[d] + rt * p.xs + j;
+    oq[reg] = p.out + rt * p.os + d * 64 + j;
+    hq[reg] = keep_h ? p.hprev[d] + rt * 64 + j : nullptr;
+    const long tr = (long)t_first * B + (live[reg] ? row : 0);
+    gq[reg] = stash ? p.gates[d] + tr * 256 + j : nullptr;
+    cq[reg] = stash ? p.cst[d] + tr * 64 + j : nullptr;
+  }
+  const long xstep = dir * p.xs, ostep = dir * p.os, hstep = dir * 64, gstep = dir * (long)B * 256,
+             cstep = dir * (long)B * 64;
+#define L64_LOAD_XP(DST)                                                                            \
   do {                                                                                              \
-    const int tq_ = d == 0 ? (step) : T - 1 - (step);                                               \
     _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                           \
-      const int row_ = r0 + fq * 4 + reg;                                                           \
-      if (row_ < B) {                                                                               \
-        const float* x_ = p.xproj[d] + ((long)row_ * T + tq_) * p.xs + j;                           \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) DST[g][reg] = x_[g * 64];                     \
-      } else {                                                                                      \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) DST[g][reg] = 0.f;                            \
-      }                                                                                             \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) DST[g][reg] = live[reg] ? xq[reg][g * 64] : 0.f; \
+      xq[reg] += xstep;                                                                             \
     }                                                                                               \
   } while (0)
-  L64_LOAD_XP(xp, 0);
+  L64_LOAD_XP(xp);
   for (int s = 0; s < T; ++s) {
-    const int tt = d == 0 ? s : T - 1 - s;
-    if (s + 1 < T) L64_LOAD_XP(xpn, s + 1);
-    if (p.hprev[d]) {
+    if (s + 1 < T) L64_LOAD_XP(xpn);
+    if (keep_h) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        int row = r0 + fq * 4 + reg;
-        if (row < B) p.hprev[d][((long)row * T + tt) * 64 + j] = hreg[reg];
+        if (live[reg]) *hq[reg] = hreg[reg];
+        hq[reg] += hstep;
       }
     }
     f32x4 acc[4];
@@ -112,7 +129,6 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
     L64_LDS_BARRIER();  // everyone has finished reading hs for this step
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      int row = r0 + fq * 4 + reg;
       float gi = l64_sigmoid(acc[0][reg] + (xp[0][reg] + bh[0]));
       float gf = l64_sigmoid(acc[1][reg] + (xp[1][reg] + bh[1]));
       float gg = l64_tanh(acc[2][reg] + (xp[2][reg] + bh[2]));
@@ -122,14 +138,16 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
       creg[reg] = cn;
       hreg[reg] = hn;
       hs[j * 16 + fq * 4 + reg] = hn;
-      if (row < B) {
-        p.out[((long)row * T + tt) * p.os + d * 64 + j] = hn;
-        if (p.gates[d]) {
-          float* gs = p.gates[d] + ((long)tt * B + row) * 256 + j;
+      if (live[reg]) {
+        *oq[reg] = hn;
+        if (stash) {
+          float* gs = gq[reg];
           gs[0] = gi; gs[64] = gf; gs[128] = gg; gs[192] = go;
-          p.cst[d][((long)tt * B + row) * 64 + j] = cn;
+          *cq[reg] = cn;
         }
       }
+      oq[reg] += ostep;
+      if (stash) { gq[reg] += gstep; cq[reg] += cstep; }
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g)

@@ -11,6 +11,7 @@ Reference quirks reproduced: Q1 in-place head transform 
 Q2 body row n % B, Q4 FK walk order, Q6 degenerate fusion gate, Q7 unused fc3 / ignored h0 arguments,
 Q8 re-view (not permute) of the ST-GCN output.
 """
+import os
 import time
 
 import torch
@@ -530,6 +531,15 @@ class IMUNet(_NetBase):
         self.rnn_fast = LstmParams(hidden_n, hidden_n, n_rnn_layer, dropout=dropout, bidirectional=True)
         self.rnn_slow = LstmParams(2 * hidden_n, hidden_n, n_rnn_layer, dropout=dropout, bidirectional=True)
         self.attn = nn.Linear(hidden_n * d, 1)
+        # "fp32" (default, the parity path) or "bf16": eval-mode BiLSTM products with bf16 operands and fp32 accumulation
+        # (BASELINE config 5); everything else -- gates, cell state, pooling, heads -- stays fp32 in both modes.
+        self.precision = os.environ.get("MMEGO_IMU_PRECISION", "fp32")
+
+    def train(self, mode=True):
+        if mode:                                   # weights may change: drop the bf16 copies of the LSTM weights
+            for m in (self.rnn_fast, self.rnn_slow):
+                m._bf16_cache = None
+        return super().train(mode)
 
     def forward(self, imu, h0_i=None):
         _require_gpu(imu, "IMUNet")
@@ -551,11 +561,22 @@ class IMUNet(_NetBase):
         dev = imu.device
         h = ar.get("fc1", (Bn * S, H))
         ops.linear(imu.view(Bn * S, Cin), self.fc1.weight, self.fc1.bias, h, relu=True)
-        fast = blocks.lstm_steps_forward(ar, "fast", self.rnn_fast, h, Bn, S)          # [Bn*S, 2H]
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError("IMUNet.precision must be 'fp32' or 'bf16', got %r" % (self.precision,))
+        bf16 = self.precision == "bf16"
+        if bf16:
+            hb = blocks.cvt_bf16(h, ar.get("fc1b", (Bn * S, H), dtype=torch.bfloat16))
+            fast, _ = blocks.lstm_steps_forward_bf16(ar, "fast", self.rnn_fast, hb, Bn, S)
+        else:
+            fast = blocks.lstm_steps_forward(ar, "fast", self.rnn_fast, h, Bn, S)          # [Bn*S, 2H]
         pooled = ar.get("pooled", (Bn, 2 * H))
         attn = ar.get("attn", (Bn, S))
         blocks.attn_pool_forward(fast, self.attn, Bn, S, 2 * H, pooled, attn)
-        slow = blocks.lstm_steps_forward(ar, "slow", self.rnn_slow, pooled, B, T)       # [B*T, 2H]
+        if bf16:
+            pb = blocks.cvt_bf16(pooled, ar.get("pooledb", (Bn, 2 * H), dtype=torch.bfloat16))
+            slow, _ = blocks.lstm_steps_forward_bf16(ar, "slow", self.rnn_slow, pb, B, T)
+        else:
+            slow = blocks.lstm_steps_forward(ar, "slow", self.rnn_slow, pooled, B, T)       # [B*T, 2H]
         y = ar.get("y", (Bn, 9))
         ops.linear(slow, self.fc2.weight, self.fc2.bias, y)
         R = torch.empty((B, T, 3, 3), dtype=torch.float32, device=dev)

@@ -1,0 +1,130 @@
+"""bf16-operand / fp32-accumulate mode of the frozen IMU_Net forward (mmego_amd/csrc/bf16.hip; BASELINE config 5).
+
+The checker is an emulation of the same arithmetic on the CPU: operands rounded to bf16 with torch's
+round-to-nearest-even cast, products and sums in float64.  Tolerances (stated per test): the conversion is bit-exact;
+a product differs from the emulation only by fp32 summation order; the recurrence re-rounds h_t to bf16 every step,
+so a 1e-7 difference can flip one bf16 ulp (2^-8 relative) of an operand of the next step.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+def test_cvt_bf16_is_round_to_nearest_even_bit_exact():
+    from mmego_amd import blocks
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 64, generator=g) * torch.logspace(-30, 30, 64)
+    x[0, :8] = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), 1.00390625, 1.01171875, 3.3895e38])
+    x[1, :4] = torch.tensor([1e-40, -1e-40, 1.0 + 2 ** -9, 1.0 + 2 ** -8 + 2 ** -9])      # denormals, ties
+    xd = x.to(_dev())
+    out = torch.empty((37, 64), dtype=torch.bfloat16, device=_dev())
+    blocks.cvt_bf16(xd, out)
+    want = x.to(torch.bfloat16)
+    got = out.cpu()
+    nan = torch.isnan(want.float())
+    assert torch.equal(torch.isnan(got.float()), nan)
+    assert torch.equal(got.view(torch.int16)[~nan], want.view(torch.int16)[~nan])
+    # row-strided views on both sides
+    big = torch.zeros((37, 96), dtype=torch.bfloat16, device=_dev())
+    blocks.cvt_bf16(xd[:, 16:48], big[:, 32:64])
+    assert torch.equal(big[:, 32:64].cpu().view(torch.int16)[~nan[:, 16:48]], want[:, 16:48].view(torch.int16)[~nan[:, 16:48]])
+    assert float(big[:, :32].float().abs().sum()) == 0.0 and float(big[:, 64:].float().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(200, 192, 128, 0), (512, 4096, 512, 0), (1, 1, 64, 1), (300, 130, 1024, 1)])
+def test_gemm_bf16_matches_fp64_product_of_rounded_operands(M, N, K, relu):
+    from mmego_amd import blocks, hip
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    dev = _dev()
+    Ab = blocks.cvt_bf16(A.to(dev), torch.empty((M, K), dtype=torch.bfloat16, device=dev))
+    Wb = blocks.cvt_bf16(W.to(dev), torch.empty((N, K), dtype=torch.bfloat16, device=dev))
+    C = torch.full((M, N + 3), 7.0, device=dev)            # padded leading dimension: the pad must stay untouched
+    Cb = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
+    hip.call("gemm_bf16", Ab, K, Wb, K, C, C.stride(0), Cb, Cb.stride(0), b.to(dev), M, N, K, relu)
+    want = _bf(A) @ _bf(W).T + b.double()
+    if relu:
+        want = want.clamp_min(0)
+    got = C[:, :N].cpu().double()
+    # fp32 accumulation of K exact products of O(1/sqrt(K)) magnitude: error ~ K * 2^-24 * |partial sums| << 1e-4
+    assert float((got - want).abs().max()) < 1e-4
+    assert float(C[:, N:].min()) == 7.0
+    assert torch.equal(Cb.cpu().view(torch.int16), C[:, :N].cpu().to(torch.bfloat16).view(torch.int16))
+
+
+def _emulate_bilstm(x, W, H, Bn, T):
+    """x [Bn*T, In] (rows b*T+t) float64 already bf16-rounded; W = per layer per direction (w_ih, w_hh, b_ih, b_hh)."""
+    cur = x
+    for layer in W:
+        out = torch.zeros(Bn, T, 2 * H, dtype=torch.float64)
+        xin = cur.view(Bn, T, -1)
+        for d, (w_ih, w_hh, b_ih, b_hh) in enumerate(layer):
+            xp = (xin @ _bf(w_ih).T).float() + (b_ih + b_hh)           # fp32 projection output, as on the device
+            h = torch.zeros(Bn, H, dtype=torch.float64)
+            c = torch.zeros(Bn, H, dtype=torch.float64)
+            for s in range(T):
+                t = s if d == 0 else T - 1 - s
+                gates = xp[:, t].double() + _bf(h.float()) @ _bf(w_hh).T
+                i, f, gg, o = gates.split(H, dim=1)
+                c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+                h = torch.sigmoid(o) * torch.tanh(c)
+                out[:, t, d * H:(d + 1) * H] = h
+        cur = _bf(out.view(Bn * T, 2 * H).float())
+    return out.view(Bn * T, 2 * H)
+
+
+@pytest.mark.parametrize("Bn,T,H,In", [(200, 5, 128, 64), (2100, 3, 64, 128), (64, 4, 512, 1024), (200, 3, 256, 64)])
+def test_bilstm_bf16_forward_matches_emulation(Bn, T, H, In):
+    from mmego_amd import blocks, ops
+    torch.manual_seed(Bn)
+    lstm = blocks.LstmParams(In, H, 2).to(_dev())
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(Bn * T, In, generator=g)
+    xb = blocks.cvt_bf16(x.to(_dev()), torch.empty((Bn * T, In), dtype=torch.bfloat16, device=_dev()))
+    out, outb = blocks.lstm_steps_forward_bf16(ops.Arena(_dev()), "t", lstm, xb, Bn, T)
+    W = [[tuple(lstm.w(k, l, d).detach().cpu() for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")) for d in range(2)]
+         for l in range(2)]
+    want = _emulate_bilstm(_bf(x), W, H, Bn, T)
+    got = out.cpu().double()
+    err = (got - want).abs()
+    # |h| < 1; a flipped bf16 ulp of one operand moves a gate by <= 2^-8 * |w| ~ 4e-4: allow 2e-3 at worst, 2e-5 typical
+    assert float(err.max()) < 2e-3, float(err.max())
+    assert float(err.mean()) < 2e-5, float(err.mean())
+    assert torch.equal(outb.cpu().view(torch.int16), out.cpu().to(torch.bfloat16).view(torch.int16))
+
+
+def test_imu_forward_bf16_mode_is_close_to_fp32_and_is_opt_in():
+    from mmego_amd import nets
+    torch.manual_seed(3)
+    net = nets.IMUNet(15, 9, 512, 2).to(_dev()).eval()
+    assert net.precision == "fp32"
+    g = torch.Generator().manual_seed(2)
+    imu = torch.randn(16, 8, 20, 15, generator=g).to(_dev())
+    with torch.no_grad():
+        R32, t32 = [v.clone() for v in net(imu)]
+        net.precision = "bf16"
+        Rb, tb = [v.clone() for v in net(imu)]
+        Rb2, tb2 = net(imu)
+        assert torch.equal(Rb, Rb2) and torch.equal(tb, tb2)          # deterministic
+        net.precision = "fp32"
+        R32b, _ = net(imu)
+    assert torch.equal(R32, R32b)                                     # switching back restores the fp32 path bit for bit
+    assert not torch.equal(R32, Rb)
+    # bf16 operands (2^-9 relative rounding) through two BiLSTM stacks: head rotation entries move by ~1e-3
+    assert float((R32 - Rb).abs().max()) < 2e-2
+    assert float((t32 - tb).abs().max()) < 2e-2
+    net.precision = "fp16"
+    with pytest.raises(ValueError):
+        net(imu)
