@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="run the Upper and Lower bodies one after the other")
     ap.add_argument("--trace-only", action="store_true", help="warm-up + timed loop only, then exit (clean input for rocprofv3 summaries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16-variant", action="store_true", help="skip the extra bf16-IMU figure")
     ap.add_argument("--cpu-steps", type=int, default=5)
     args = ap.parse_args()
 
@@ -306,6 +307,35 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt_shared = tt.item()
 
+    # bf16-operand variant of the two frozen IMU_Net forwards (IMUNet.precision = "bf16": BiLSTM products with bf16 operands
+    # and fp32 accumulation, everything else fp32).  Extra figure, never `value`: it is outside the 1e-3 cm parity bound.
+    bf16_extra = {}
+    if not args.no_bf16_variant:
+        try:
+            imu.precision = imu_l.precision = "bf16"
+            su_b = StageStep("upper", upper, imu, lr=3e-5, process_group=pg, use_graph=not args.no_graph)
+            sl_b = StageStep("lower", lower, imu_l, upper_frozen=upper_frozen, lr=3e-5, process_group=pg, use_graph=not args.no_graph)
+            su_b.bind(x, imu_in, body, target)
+            sl_b.bind(x, imu_in, body, target)
+            both_b = ConcurrentStages([su_b, sl_b], use_graph=not args.no_graph)
+            both_b.prepare()
+            for _ in range(3):
+                both_b.step()
+            sync()
+            t0b = time.perf_counter()
+            for _ in range(args.steps):
+                both_b.step()
+            sync()
+            dt_b = time.perf_counter() - t0b
+            if world > 1:
+                tt = torch.tensor([dt_b], dtype=torch.float64, device=device)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                dt_b = tt.item()
+            bf16_extra = {"ms_per_step_bf16_imu": dt_b / args.steps * 1e3,
+                          "frames_per_s_bf16_imu": world * B * T / (dt_b / args.steps)}
+        finally:
+            imu.precision = imu_l.precision = "fp32"
+
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -323,6 +353,7 @@ def main():
                "frames_per_s_imu_shared": world * B * T / (dt_shared / args.steps),
                "ms_per_step_sequential": t_u + t_l, "frames_per_s_sequential": world * B * T / ((t_u + t_l) * 1e-3),
                "t_upper_ms": t_u, "t_lower_ms": t_l, "loss_upper": loss_u, "loss_lower": loss_l}
+        out.update(bf16_extra)
 
     # ---- roofline of the dominant kernel: eager replay with event pairs around every launch ----------------
     if rank == 0:

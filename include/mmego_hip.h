@@ -107,10 +107,16 @@ int mmego_lstm64_backward(void* stream, int B, int T, const float* dout, long do
  * Opt-in precision mode, never the parity path.  bf16 values cross the ABI as raw bits in unsigned short.
  * Y[r, 0:cols] = bf16(X[r, 0:cols]) (round to nearest even); cols, ldx, ldy multiples of 4. */
 int mmego_cvt_bf16(void* stream, const float* X, long ldx, long rows, long cols, unsigned short* Y, long ldy);
-/* C[M,N] = A[M,K] . W[N,K]^T + bias[N] (relu), operands bf16, products and sums fp32; C (fp32) and/or Cb (bf16 copy)
- * are written.  K % 64 == 0.  Replaces the BiLSTM input projections of Net/IMU_Net.py:58-62 in bf16 mode. */
+/* Same with a row permutation: rows (b*T + t) of X -> rows (t*Bp + b) of Y (Bp >= Bn, pad rows untouched): the time-major
+ * operand of a BiLSTM layer's input projection. */
+int mmego_cvt_bf16_tm(void* stream, const float* X, long ldx, int Bn, int T, long cols, unsigned short* Y, int Bp);
+/* C[M,N] = A[M,K] . W[N,K]^T + bias[N] (relu), operands bf16, products and sums fp32.  Any of three outputs (NULL = skip):
+ * C (fp32 row-major), Cb (bf16 row-major), Cf (fp32 TILE-MAJOR, M % 32 == 0 and N % 32 == 0): element (m, n) at
+ *     ((m/32)*(N/32) + n/32)*1024 + ((m%32)/8)*256 + (n%32 + 32*(((m%32)/4)&1))*4 + m%4,
+ * i.e. every 32x32 tile stored as the MFMA accumulator holds it (coalesced 16 B per lane for producer and consumer).
+ * K % 64 == 0.  Replaces the BiLSTM input projections of Net/IMU_Net.py:58-62 in bf16 mode. */
 int mmego_gemm_bf16(void* stream, const unsigned short* A, long lda, const unsigned short* W, long ldw, float* C,
-                    long ldc, unsigned short* Cb, long ldcb, const float* bias, int M, int N, int K, int relu);
+                    long ldc, unsigned short* Cb, long ldcb, float* Cf, const float* bias, int M, int N, int K, int relu);
 /* One (bi)LSTM timestep as mmego_lstm_step, with h_{t-1} and W_hh in bf16: gates = xproj + h_{t-1} . W_hh^T (xproj
  * already holds b_ih + b_hh), cell update in fp32, c in place.  H % 64 == 0.
  * The recurrent operands are FRAGMENT-MAJOR (the order the MFMA lanes read them, so a wave's operand load is one
@@ -118,11 +124,14 @@ int mmego_gemm_bf16(void* stream, const unsigned short* A, long lda, const unsig
  *     (((r/32)*(H/16) + k/16)*64 + ((k/8)&1)*32 + r%32)*8 + k%8        (R padded to a multiple of 32 rows).
  * hprev_d: h_{t-1} in that layout (R = Bn); whh_d: W_hh in that layout with its rows reordered to
  * [hidden block jb][gate n][32 units] (row 128*jb + 32*n + jj = W_hh[n*H + 32*jb + jj]).
+ * xpf: the layer's input projection, the tile-major Cf of mmego_gemm_bf16 with M = T*Bp rows ordered t*Bp + b
+ * (Bp = Bn rounded up to 32) and N = 8H columns ordered d*4H + gate*H + j; mt0_d = t_d * Bp/32 selects direction d's
+ * timestep.
  * h_t is written three times: hout (fp32, row stride hos), houtb (bf16 row-major, row stride hbs, may be NULL: the next
  * layer's projection operand) and hfrag_d (bf16 fragment-major: the next step's hprev_d; must not alias hprev_d). */
 int mmego_lstm_step_bf16(void* stream, int ndir, int Bn, int H, int first, const unsigned short* hprev0,
                          const unsigned short* hprev1, const unsigned short* whh0, const unsigned short* whh1,
-                         const float* xproj0, const float* xproj1, long xs, float* hout0, float* hout1,
+                         const float* xpf, long mt0_0, long mt0_1, float* hout0, float* hout1,
                          long hos, unsigned short* houtb0, unsigned short* houtb1, long hbs,
                          unsigned short* hfrag0, unsigned short* hfrag1, float* c0, float* c1);
 

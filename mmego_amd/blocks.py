@@ -282,32 +282,38 @@ def lstm_bf16_weights(lstm):
     return layers
 
 
-def lstm_steps_forward_bf16(ar, key, lstm, x_bf, Bn, T):
-    """As lstm_steps_forward with bf16 product operands: x_bf [Bn*T, In] bf16 rows (b*T+t) -> (out fp32, out bf16)
-    [Bn*T, 2H] of the last layer.  Gate pre-activations, cell state and outputs are fp32."""
+def lstm_steps_forward_bf16(ar, key, lstm, x, Bn, T):
+    """As lstm_steps_forward with bf16 product operands: x [Bn*T, In] fp32 rows (b*T+t) -> out [Bn*T, 2H] fp32 of the last
+    layer (same row order).  Gate pre-activations, cell state and outputs are fp32.  Internal layouts (include/mmego_hip.h):
+    projection operands time-major bf16 [T][Bp][In], projections tile-major fp32, recurrent operands fragment-major."""
     H = lstm.hidden_size
     W = lstm_bf16_weights(lstm)
-    cur = x_bf
-    out = outb = None
+    Bp = (Bn + 31) // 32 * 32
+    In = x.shape[1]
+    cur = ar.get("%s.xtm" % key, (T * Bp, In), dtype=torch.bfloat16)
+    hip.call("cvt_bf16_tm", x, x.stride(0), Bn, T, In, cur, Bp)
+    out = None
     for l in range(lstm.num_layers):
         wih, bias, whh0, whh1 = W[l]
-        xp = ar.get("%s.xp%d" % (key, l), (Bn * T, 8 * H))
-        hip.call("gemm_bf16", cur, cur.stride(0), wih, wih.stride(0), xp, xp.stride(0), None, 0, bias,
-                 Bn * T, 8 * H, cur.shape[1], 0)
+        xpf = ar.get("%s.xpf%d" % (key, l), (T * Bp * 8 * H,))
+        hip.call("gemm_bf16", cur, cur.stride(0), wih, wih.stride(0), None, 0, None, 0, xpf, bias, T * Bp, 8 * H, cur.shape[1], 0)
         if milestone is not None:
             milestone(key, l)
         out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
-        outb = ar.get("%s.outb%d" % (key, l), (Bn * T, 2 * H), dtype=torch.bfloat16)
+        last = l == lstm.num_layers - 1
+        outb = None if last else ar.get("%s.outb%d" % (key, l), (T * Bp, 2 * H), dtype=torch.bfloat16)   # time-major
         c = ar.get("%s.c" % key, (2, Bn, H))
-        hf = ar.get("%s.hfrag" % key, (2, 2, (Bn + 31) // 32 * 32, H), dtype=torch.bfloat16)   # [ping-pong][direction]
-        xp_p, out_p, outb_p = xp.data_ptr(), out.data_ptr(), outb.data_ptr()
-        xs, os_ = T * 8 * H, T * 2 * H       # row strides between consecutive batch rows b
+        hf = ar.get("%s.hfrag" % key, (2, 2, Bp, H), dtype=torch.bfloat16)   # [ping-pong][direction]
+        out_p = out.data_ptr()
+        outb_p = 0 if last else outb.data_ptr()
+        os_ = T * 2 * H                      # fp32 output: row stride between consecutive batch rows b
         for s in range(T):
             t0, t1 = s, T - 1 - s
             prev, nxt = hf[(s + 1) & 1], hf[s & 1]
             hip.call("lstm_step_bf16", 2, Bn, H, int(s == 0), prev[0] if s > 0 else None, prev[1] if s > 0 else None,
-                     whh0, whh1, xp_p + 4 * (t0 * 8 * H), xp_p + 4 * (t1 * 8 * H + 4 * H), xs,
+                     whh0, whh1, xpf, t0 * (Bp // 32), t1 * (Bp // 32),
                      out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_,
-                     outb_p + 2 * (t0 * 2 * H), outb_p + 2 * (t1 * 2 * H + H), os_, nxt[0], nxt[1], c[0], c[1])
+                     None if last else outb_p + 2 * (t0 * Bp * 2 * H), None if last else outb_p + 2 * (t1 * Bp * 2 * H + H), 2 * H,
+                     nxt[0], nxt[1], c[0], c[1])
         cur = outb
-    return out, outb
+    return out

@@ -48,6 +48,32 @@ extern "C" int mmego_cvt_bf16(void* stream, const float* X, long ldx, long rows,
   return MMEGO_OK;
 }
 
+// rows (b*T + t) of X -> rows (t*Bp + b) of Y: the time-major operand of a layer's input projection, so that 32 consecutive
+// rows of the product belong to ONE timestep (see the tile-major xproj layout below)
+__global__ __launch_bounds__(256) void cvt_bf16_tm_kernel(const float* __restrict__ X, long ldx, int Bn, int T, long cols4,
+                                                           bf16_t* __restrict__ Y, int Bp) {
+  const long total = (long)Bn * T * cols4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / cols4, c = (i - r * cols4) * 4;
+    const long b = r / T, t = r - b * T;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(X + r * ldx + c);
+    uint2 o;
+    o.x = f2bf_bits(v[0]) | (f2bf_bits(v[1]) << 16);
+    o.y = f2bf_bits(v[2]) | (f2bf_bits(v[3]) << 16);
+    *reinterpret_cast<uint2*>(Y + (t * Bp + b) * (cols4 * 4) + c) = o;
+  }
+}
+
+extern "C" int mmego_cvt_bf16_tm(void* stream, const float* X, long ldx, int Bn, int T, long cols, unsigned short* Y, int Bp) {
+  MMEGO_REQUIRE(Bn > 0 && T > 0 && cols > 0 && cols % 4 == 0 && ldx % 4 == 0 && Bp >= Bn);
+  MMEGO_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Y) & 7) == 0);
+  const long total = (long)Bn * T * (cols / 4);
+  const int grid = (int)(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+  cvt_bf16_tm_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(X, ldx, Bn, T, cols / 4, Y, Bp);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
 // ---- shared tile machinery -----------------------------------------------------------------------------------------
 // Operand tiles sit in LDS as [row][64 k + 8 pad] bf16 (144-B rows): a lane's MFMA operand is the 16 B at
 // (row = lane%32, k = 8*(lane/32) .. +8) of a 16-k step, one ds_read_b128; 144-B rows put 16 consecutive rows' 16-B
@@ -67,6 +93,7 @@ struct GemmBfP {
   const bf16_t* W; long ldw;
   float* C; long ldc;
   bf16_t* Cb; long ldcb;        // optional bf16 copy of the output
+  float* Cf;                    // optional tile-major fp32 output (see "TILE-MAJOR xproj" below)
   const float* bias;
   int M, N, K, relu, tiles_m, tiles_n;
 };
@@ -160,14 +187,41 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmBfP p) {
       }
     }
   }
+  if (p.Cf) {   // an MFMA accumulator tile IS a tile of the tile-major layout: four coalesced 1-KB stores per 32x32 tile
+    const int ntn = p.N >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int c0 = n0 + wn * 64 + ni * 32;
+      if (c0 >= p.N) continue;
+      const float bv = p.bias ? p.bias[c0 + fr] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int rr0 = m0 + wm * 64 + mi * 32;
+        if (rr0 >= p.M) continue;
+        float* t = p.Cf + ((long)(rr0 >> 5) * ntn + (c0 >> 5)) * 1024 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[mi][ni][4 * q + r] + bv;
+            if (p.relu) v[r] = fmaxf(v[r], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(t + q * 256) = v;
+        }
+      }
+    }
+  }
 }
 
 extern "C" int mmego_gemm_bf16(void* stream, const unsigned short* A, long lda, const unsigned short* W, long ldw, float* C,
-                               long ldc, unsigned short* Cb, long ldcb, const float* bias, int M, int N, int K, int relu) {
+                               long ldc, unsigned short* Cb, long ldcb, float* Cf, const float* bias, int M, int N, int K,
+                               int relu) {
   MMEGO_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && lda % 8 == 0 && ldw % 8 == 0);
-  MMEGO_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (C || Cb));
+  MMEGO_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (C || Cb || Cf));
+  MMEGO_REQUIRE(!Cf || (M % 32 == 0 && N % 32 == 0 && (((uintptr_t)Cf) & 15) == 0));
   GemmBfP p;
-  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.Cb = Cb; p.ldcb = ldcb; p.bias = bias;
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.Cb = Cb; p.ldcb = ldcb; p.Cf = Cf; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.relu = relu;
   p.tiles_m = cdiv(M, 128); p.tiles_n = cdiv(N, 128);
   const long tiles = (long)p.tiles_m * p.tiles_n;
@@ -186,10 +240,18 @@ extern "C" int mmego_gemm_bf16(void* stream, const unsigned short* A, long lda, 
 // i.e. element (r, k) sits at (((r/32)*(H/16) + k/16)*64 + ((k/8)&1)*32 + r%32)*8 + k%8.  For W_hh the "rows" are
 // ordered [hidden block jb][gate n][32 hidden units] (row 128*jb + 32*n + jj = W_hh[n*H + 32*jb + jj]), so one WG's four
 // gate tiles are adjacent.  A wave's fragment load is then one fully coalesced 1-KB read and needs no LDS transpose.
+//
+// TILE-MAJOR xproj.  The projection's result is consumed exactly once, by the cell update, which holds gate pre-activations
+// in the MFMA accumulator layout.  So the projection GEMM stores every 32x32 accumulator tile as it sits in registers and
+// the step kernel loads it back the same way (coalesced 16 B per lane both times, no transposition anywhere): element
+// (m, n) of the [M, N] product lives at
+//     ((m/32)*(N/32) + n/32)*1024 + ((m%32)/8)*256 + (n%32 + 32*(((m%32)/4)&1))*4 + m%4.
+// Rows are TIME-MAJOR, m = t*Bp + b with Bp = Bn rounded up to 32, so a tile's 32 rows are 32 sequences at one timestep;
+// columns are n = d*4H + gate*H + j.
 struct StepBfP {
   const bf16_t* hprev[2];               // h_{t-1}, fragment-major, ceil(Bn/32) row blocks
   const bf16_t* whh[2];                 // W_hh, fragment-major as above
-  const float* xproj[2]; long xs;       // x.W_ih^T + b_ih + b_hh (fp32)
+  const float* xpf; long mt0[2];        // x.W_ih^T + b_ih + b_hh, tile-major; mt0[d] = first row tile of direction d's timestep
   float* hout[2]; long hos;             // h_t fp32, row-major
   bf16_t* houtb[2]; long hbs;           // h_t bf16, row-major (next layer's projection operand); may be null
   bf16_t* hfrag[2];                     // h_t bf16, fragment-major (next step's operand)
@@ -202,6 +264,12 @@ __device__ __forceinline__ float bf_tanh(float x) { return 1.0f - 2.0f * __built
 
 __device__ __forceinline__ long frag_off(int r, int k, int H) {
   return ((((long)(r >> 5) * (H >> 4) + (k >> 4)) * 64) + ((k >> 3) & 1) * 32 + (r & 31)) * 8 + (k & 7);
+}
+
+// this lane's 16 B (registers 4q .. 4q+3) of the xproj tile (row block rb, direction d, gate n, hidden block jb)
+__device__ __forceinline__ const f32x4* xp_tile(const StepBfP& p, int d, int rb, int n, int jb, int lane) {
+  const int hb = p.H >> 5;
+  return reinterpret_cast<const f32x4*>(p.xpf + ((p.mt0[d] + rb) * (long)(8 * hb) + (d * 4 + n) * hb + jb) * 1024) + lane;
 }
 
 // cell update of one (row, j) and the three stores of h_t
@@ -323,14 +391,22 @@ __global__ __launch_bounds__(256) void lstm_step_bf16_kernel(StepBfP p) {
   const int j = j0 + fr;
 #pragma unroll
   for (int mi = 0; mi < WR; ++mi) {
+    const int rb = (r0 >> 5) + wr * WR + mi;
+    if (rb * 32 >= p.Bn) continue;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = r0 + (wr * WR + mi) * 32 + 8 * (i >> 2) + 4 * fh + (i & 3);
-      if (row < p.Bn) {
-        const float* xp = p.xproj[d] + (long)row * p.xs + j;
-        const float cprev = p.first ? 0.f : p.c[d][(long)row * H + j];
-        bf_cell(p, d, row, j, acc[mi][0][i] + xp[0], acc[mi][1][i] + xp[H], acc[mi][2][i] + xp[2 * H],
-                acc[mi][3][i] + xp[3 * H], cprev);
+    for (int q = 0; q < 4; ++q) {
+      f32x4 x[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) x[n] = xp_tile(p, d, rb, n, jb, lane)[q * 64];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * q + r;
+        const int row = rb * 32 + 8 * q + 4 * fh + r;
+        if (row < p.Bn) {
+          const float cprev = p.first ? 0.f : p.c[d][(long)row * H + j];
+          bf_cell(p, d, row, j, acc[mi][0][i] + x[0][r], acc[mi][1][i] + x[1][r], acc[mi][2][i] + x[2][r],
+                  acc[mi][3][i] + x[3][r], cprev);
+        }
       }
     }
   }
@@ -356,13 +432,18 @@ __global__ __launch_bounds__(256) void lstm_step_bf16_direct_kernel(StepBfP p) {
   const int own_mi = w >> 1, own_i0 = 8 * (w & 1);     // this wave finishes rows 32*own_mi + 16*(w&1) .. +16:
   const int own_r0 = own_mi * 32 + 16 * (w & 1);       // accumulator registers own_i0 .. own_i0+8 of row block own_mi
 
-  float xp[4][8], cprev[8];
+  f32x4 xp[4][2];
+  float cprev[8];
+  {
+    const int rb = min((r0 >> 5) + own_mi, (p.Bn - 1) >> 5);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) xp[n][qq] = xp_tile(p, d, rb, n, jb, lane)[(2 * (w & 1) + qq) * 64];
+  }
 #pragma unroll
   for (int ii = 0; ii < 8; ++ii) {
     const int row = min(r0 + own_r0 + 8 * (ii >> 2) + 4 * fh + (ii & 3), p.Bn - 1);
-    const float* x = p.xproj[d] + (long)row * p.xs + j;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) xp[n][ii] = x[n * H];
     cprev[ii] = p.first ? 0.f : p.c[d][(long)row * H + j];
   }
   float pre[4][8];
@@ -423,13 +504,14 @@ __global__ __launch_bounds__(256) void lstm_step_bf16_direct_kernel(StepBfP p) {
   for (int ii = 0; ii < 8; ++ii) {
     const int row = r0 + own_r0 + 8 * (ii >> 2) + 4 * fh + (ii & 3);
     if (row < p.Bn)
-      bf_cell(p, d, row, j, pre[0][ii] + xp[0][ii], pre[1][ii] + xp[1][ii], pre[2][ii] + xp[2][ii], pre[3][ii] + xp[3][ii], cprev[ii]);
+      bf_cell(p, d, row, j, pre[0][ii] + xp[0][ii >> 2][ii & 3], pre[1][ii] + xp[1][ii >> 2][ii & 3],
+              pre[2][ii] + xp[2][ii >> 2][ii & 3], pre[3][ii] + xp[3][ii >> 2][ii & 3], cprev[ii]);
   }
 }
 
 extern "C" int mmego_lstm_step_bf16(void* stream, int ndir, int Bn, int H, int first, const unsigned short* hprev0,
                                     const unsigned short* hprev1, const unsigned short* whh0, const unsigned short* whh1,
-                                    const float* xproj0, const float* xproj1, long xs, float* hout0, float* hout1,
+                                    const float* xpf, long mt0_0, long mt0_1, float* hout0, float* hout1,
                                     long hos, unsigned short* houtb0, unsigned short* houtb1, long hbs,
                                     unsigned short* hfrag0, unsigned short* hfrag1, float* c0, float* c1) {
   MMEGO_REQUIRE((ndir == 1 || ndir == 2) && Bn > 0 && H > 0 && H % 64 == 0);
@@ -437,10 +519,11 @@ extern "C" int mmego_lstm_step_bf16(void* stream, int ndir, int Bn, int H, int f
                           (ndir == 1 || (((uintptr_t)hprev1) & 15) == 0)));
   MMEGO_REQUIRE((((uintptr_t)whh0) & 15) == 0 && (ndir == 1 || (((uintptr_t)whh1) & 15) == 0));
   MMEGO_REQUIRE(hfrag0 && (ndir == 1 || hfrag1) && hfrag0 != hprev0 && (ndir == 1 || hfrag1 != hprev1));
+  MMEGO_REQUIRE(xpf && (((uintptr_t)xpf) & 15) == 0 && mt0_0 >= 0 && mt0_1 >= 0);
   StepBfP p;
   p.hprev[0] = hprev0; p.hprev[1] = hprev1;
   p.whh[0] = whh0; p.whh[1] = whh1;
-  p.xproj[0] = xproj0; p.xproj[1] = xproj1; p.xs = xs;
+  p.xpf = xpf; p.mt0[0] = mt0_0; p.mt0[1] = mt0_1;
   p.hout[0] = hout0; p.hout[1] = hout1; p.hos = hos;
   p.houtb[0] = houtb0; p.houtb[1] = houtb1; p.hbs = hbs;
   p.hfrag[0] = hfrag0; p.hfrag[1] = hfrag1;

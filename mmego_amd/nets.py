@@ -565,16 +565,14 @@ class IMUNet(_NetBase):
             raise ValueError("IMUNet.precision must be 'fp32' or 'bf16', got %r" % (self.precision,))
         bf16 = self.precision == "bf16"
         if bf16:
-            hb = blocks.cvt_bf16(h, ar.get("fc1b", (Bn * S, H), dtype=torch.bfloat16))
-            fast, _ = blocks.lstm_steps_forward_bf16(ar, "fast", self.rnn_fast, hb, Bn, S)
+            fast = blocks.lstm_steps_forward_bf16(ar, "fast", self.rnn_fast, h, Bn, S)
         else:
             fast = blocks.lstm_steps_forward(ar, "fast", self.rnn_fast, h, Bn, S)          # [Bn*S, 2H]
         pooled = ar.get("pooled", (Bn, 2 * H))
         attn = ar.get("attn", (Bn, S))
         blocks.attn_pool_forward(fast, self.attn, Bn, S, 2 * H, pooled, attn)
         if bf16:
-            pb = blocks.cvt_bf16(pooled, ar.get("pooledb", (Bn, 2 * H), dtype=torch.bfloat16))
-            slow, _ = blocks.lstm_steps_forward_bf16(ar, "slow", self.rnn_slow, pb, B, T)
+            slow = blocks.lstm_steps_forward_bf16(ar, "slow", self.rnn_slow, pooled, B, T)
         else:
             slow = blocks.lstm_steps_forward(ar, "slow", self.rnn_slow, pooled, B, T)       # [B*T, 2H]
         y = ar.get("y", (Bn, 9))

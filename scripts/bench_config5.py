@@ -57,7 +57,7 @@ for M, N, K in (() if "--steps-only" in sys.argv else ((10240, 8192, 512), (1024
     Ab = blocks.cvt_bf16(A, torch.empty((M, K), dtype=torch.bfloat16, device=dev))
     Wb = blocks.cvt_bf16(W, torch.empty((N, K), dtype=torch.bfloat16, device=dev))
     C = torch.empty((M, N), device=dev)
-    ms = timeit(lambda: hip.call("gemm_bf16", Ab, K, Wb, K, C, N, None, 0, b, M, N, K, 0), n=10)
+    ms = timeit(lambda: hip.call("gemm_bf16", Ab, K, Wb, K, None, 0, None, 0, C, b, M, N, K, 0), n=10)     # tile-major output
     tf = 2.0 * M * N * K / ms / 1e9
     ms32 = timeit(lambda: ops.linear_pair(A, W[:N // 2], W[N // 2:], b[:N // 2], b[N // 2:], C, N // 2), n=5)
     tf32 = 2.0 * M * N * K / ms32 / 1e9
@@ -65,11 +65,13 @@ for M, N, K in (() if "--steps-only" in sys.argv else ((10240, 8192, 512), (1024
           % (M, N, K, ms, tf, tf / PEAK_BF16, ms32, tf32, tf32 / PEAK_F32))
     del A, W, Ab, Wb, C
 
+if "--gemm-only" in sys.argv:
+    sys.exit(0)
 for Bn, H in ((512, 512),) + (() if quick else ((32768, 512),)):
     T = 4
     lstm = blocks.LstmParams(H, H, 1).to(dev)
     Wc = blocks.lstm_bf16_weights(lstm)[0]
-    xp = torch.randn(Bn * T, 8 * H, device=dev)
+    xp = torch.randn(Bn * T, 8 * H, device=dev)             # (the bf16 step reads it as T tile-major [Bn, 8H] slabs)
     out = torch.zeros(Bn * T, 2 * H, device=dev)
     outb = torch.zeros(Bn * T, 2 * H, dtype=torch.bfloat16, device=dev)
     c = torch.zeros(2, Bn, H, device=dev)
@@ -78,8 +80,8 @@ for Bn, H in ((512, 512),) + (() if quick else ((32768, 512),)):
     hf = torch.zeros(2, 2, Bn, H, dtype=torch.bfloat16, device=dev)
 
     def step_bf(first=0):
-        hip.call("lstm_step_bf16", 2, Bn, H, first, hf[0, 0], hf[0, 1], Wc[2], Wc[3],
-                 xp.data_ptr(), xp.data_ptr() + 16 * H, xs, out.data_ptr() + 4 * 2 * H, out.data_ptr() + 4 * 3 * H, os_,
+        hip.call("lstm_step_bf16", 2, Bn, H, first, hf[0, 0], hf[0, 1], Wc[2], Wc[3], xp, 1 * (Bn // 32), 2 * (Bn // 32),
+                 out.data_ptr() + 4 * 2 * H, out.data_ptr() + 4 * 3 * H, os_,
                  outb.data_ptr() + 2 * 2 * H, outb.data_ptr() + 2 * 3 * H, os_, hf[1, 0], hf[1, 1], c[0], c[1])
 
     w0, w1 = lstm.w("weight_hh", 0, 0), lstm.w("weight_hh", 0, 1)

@@ -41,7 +41,8 @@ def test_cvt_bf16_is_round_to_nearest_even_bit_exact():
     assert float(big[:, :32].float().abs().sum()) == 0.0 and float(big[:, 64:].float().abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K,relu", [(200, 192, 128, 0), (512, 4096, 512, 0), (1, 1, 64, 1), (300, 130, 1024, 1)])
+@pytest.mark.parametrize("M,N,K,relu", [(200, 192, 128, 0), (512, 4096, 512, 0), (1, 1, 64, 1), (300, 130, 1024, 1),
+                                         (1120, 1024, 128, 0), (96, 160, 320, 1)])
 def test_gemm_bf16_matches_fp64_product_of_rounded_operands(M, N, K, relu):
     from mmego_amd import blocks, hip
     g = torch.Generator().manual_seed(M + N + K)
@@ -53,7 +54,9 @@ def test_gemm_bf16_matches_fp64_product_of_rounded_operands(M, N, K, relu):
     Wb = blocks.cvt_bf16(W.to(dev), torch.empty((N, K), dtype=torch.bfloat16, device=dev))
     C = torch.full((M, N + 3), 7.0, device=dev)            # padded leading dimension: the pad must stay untouched
     Cb = torch.zeros((M, N), dtype=torch.bfloat16, device=dev)
-    hip.call("gemm_bf16", Ab, K, Wb, K, C, C.stride(0), Cb, Cb.stride(0), b.to(dev), M, N, K, relu)
+    tile_major = M % 32 == 0 and N % 32 == 0
+    Cf = torch.zeros(M * N, device=dev) if tile_major else None
+    hip.call("gemm_bf16", Ab, K, Wb, K, C, C.stride(0), Cb, Cb.stride(0), Cf, b.to(dev), M, N, K, relu)
     want = _bf(A) @ _bf(W).T + b.double()
     if relu:
         want = want.clamp_min(0)
@@ -62,6 +65,12 @@ def test_gemm_bf16_matches_fp64_product_of_rounded_operands(M, N, K, relu):
     assert float((got - want).abs().max()) < 1e-4
     assert float(C[:, N:].min()) == 7.0
     assert torch.equal(Cb.cpu().view(torch.int16), C[:, :N].cpu().to(torch.bfloat16).view(torch.int16))
+    if tile_major:
+        # element (m, n) at ((m/32)*(N/32) + n/32)*1024 + ((m%32)/8)*256 + (n%32 + 32*(((m%32)/4)&1))*4 + m%4
+        m = torch.arange(M).view(M, 1)
+        n = torch.arange(N).view(1, N)
+        off = ((m // 32) * (N // 32) + n // 32) * 1024 + ((m % 32) // 8) * 256 + (n % 32 + 32 * (((m % 32) // 4) & 1)) * 4 + m % 4
+        assert torch.equal(Cf.cpu()[off], C[:, :N].cpu())
 
 
 def _emulate_bilstm(x, W, H, Bn, T):
@@ -92,8 +101,7 @@ def test_bilstm_bf16_forward_matches_emulation(Bn, T, H, In):
     lstm = blocks.LstmParams(In, H, 2).to(_dev())
     g = torch.Generator().manual_seed(1)
     x = torch.randn(Bn * T, In, generator=g)
-    xb = blocks.cvt_bf16(x.to(_dev()), torch.empty((Bn * T, In), dtype=torch.bfloat16, device=_dev()))
-    out, outb = blocks.lstm_steps_forward_bf16(ops.Arena(_dev()), "t", lstm, xb, Bn, T)
+    out = blocks.lstm_steps_forward_bf16(ops.Arena(_dev()), "t", lstm, x.to(_dev()), Bn, T)
     W = [[tuple(lstm.w(k, l, d).detach().cpu() for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")) for d in range(2)]
          for l in range(2)]
     want = _emulate_bilstm(_bf(x), W, H, Bn, T)
@@ -102,7 +110,6 @@ def test_bilstm_bf16_forward_matches_emulation(Bn, T, H, In):
     # |h| < 1; a flipped bf16 ulp of one operand moves a gate by <= 2^-8 * |w| ~ 4e-4: allow 2e-3 at worst, 2e-5 typical
     assert float(err.max()) < 2e-3, float(err.max())
     assert float(err.mean()) < 2e-5, float(err.mean())
-    assert torch.equal(outb.cpu().view(torch.int16), out.cpu().to(torch.bfloat16).view(torch.int16))
 
 
 def test_imu_forward_bf16_mode_is_close_to_fp32_and_is_opt_in():
