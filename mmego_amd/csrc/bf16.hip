@@ -290,7 +290,9 @@ __device__ __forceinline__ void bf_cell(const StepBfP& p, int d, int row, int j,
 // slices are summed through LDS at the end).  64-k chunks are staged in LDS, themselves fragment-major (a straight
 // 4-KB copy per row block; lane-linear ds_read_b128, conflict-free without padding); the next chunk travels
 // global -> registers while the current one is multiplied.
-//   <WR=2, KS=1>: 256 rows / WG -- a W_hh tile is read once per 256 batch rows.
+//   <WR=1, KS=1>: 128 rows / WG, 64 accumulators per lane -- three WGs per CU, so one WG's HBM-bound epilogue (xproj, c,
+//                 h: ~1 GB per step at Bn = 32768) overlaps the others' products.  (256 rows / WG with 128 accumulators
+//                 re-reads W_hh half as often but runs one WG per CU: measured 695 us per step against 374 us.)
 //   <WR=1, KS=2>:  64 rows / WG -- small batches with H % 256 != 0.
 // The accumulator tile n (of 4) is gate n for hidden units j0..j0+31, so one lane holds i, f, g, o of its (row, j).
 template <int WR, int KS>
@@ -546,8 +548,8 @@ extern "C" int mmego_lstm_step_bf16(void* stream, int ndir, int Bn, int H, int f
     dim3 grid(H / 32, cdiv(Bn, 64), ndir);
     lstm_step_bf16_kernel<1, 2><<<grid, 256, 0, st>>>(p);
   } else {
-    dim3 grid(H / 32, cdiv(Bn, 256), ndir);
-    lstm_step_bf16_kernel<2, 1><<<grid, 256, 0, st>>>(p);
+    dim3 grid(H / 32, cdiv(Bn, 128), ndir);
+    lstm_step_bf16_kernel<1, 1><<<grid, 256, 0, st>>>(p);
   }
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;

@@ -94,7 +94,7 @@ def _emulate_bilstm(x, W, H, Bn, T):
     return out.view(Bn * T, 2 * H)
 
 
-@pytest.mark.parametrize("Bn,T,H,In", [(200, 5, 128, 64), (2100, 3, 64, 128), (64, 4, 512, 1024), (200, 3, 256, 64)])
+@pytest.mark.parametrize("Bn,T,H,In", [(200, 5, 128, 64), (2100, 3, 64, 128), (64, 4, 512, 1024), (200, 3, 256, 64), (2050, 2, 256, 64)])
 def test_bilstm_bf16_forward_matches_emulation(Bn, T, H, In):
     from mmego_amd import blocks, ops
     torch.manual_seed(Bn)
