@@ -248,12 +248,12 @@ def test_lstm_step_kernel_variants(dev):
     import subprocess
     import sys
     code = r"""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, %r)
 from mmego_amd import hip
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-Bn, H = 200, 512
+Bn, H = int(os.environ.get("T_BN", "200")), int(os.environ.get("T_H", "512"))
 w = [torch.randn(4 * H, H, device=dev) * 0.04 for _ in range(2)]
 b = [torch.randn(4 * H, device=dev) * 0.1 for _ in range(2)]
 xp = torch.randn(2, Bn, 4 * H, device=dev)
@@ -281,6 +281,10 @@ print("ok")
     for mode in ("3", "2", "1", "0"):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MMEGO_STEP_WS=mode), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout[-500:], r.stderr[-1500:])
+    # small batches (rnn_slow: Bn < 128 -> lstm_step_small_kernel), ragged rows, H a multiple of 64 and of 32 only
+    for bn, h in (("100", "512"), ("64", "256"), ("37", "96")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, T_BN=bn, T_H=h), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (bn, h, r.stdout[-500:], r.stderr[-1500:])
 
 
 def _train_pair(tag, seed, octor, hctor, dev):
