@@ -135,6 +135,24 @@ int mmego_lstm_step_bf16(void* stream, int ndir, int Bn, int H, int first, const
                          long hos, unsigned short* houtb0, unsigned short* houtb1, long hbs,
                          unsigned short* hfrag0, unsigned short* hfrag1, float* c0, float* c1);
 
+/* Large batches: the input projection folded into the step -- gates = [x_t | h_{t-1}] . [W_ih | W_hh]^T + bias in ONE fp32
+ * accumulation, no projection tensor in HBM.  Up to two input segments (layer 0: x_t, K0 = In; upper layers: the previous
+ * layer's forward and backward h_t, K0 = K1 = H) plus h_{t-1} (skipped when first != 0); every operand fragment-major as in
+ * mmego_lstm_step_bf16 (a*_d: [Bp x K] activations of direction d's timestep; w*_d: the matching column block of W_ih with rows
+ * reordered [hidden block][gate][32 units]); bias = [2][4H] b_ih + b_hh.  K0, K1, H multiples of 64.  hout_d (fp32, may be NULL
+ * for layers whose output only feeds the next layer) and hfrag_d (fragment-major bf16, always) receive h_t. */
+int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H, int first, int nseg,
+                               const unsigned short* a0_0, const unsigned short* a0_1, const unsigned short* w0_0,
+                               const unsigned short* w0_1, int K0, const unsigned short* a1_0,
+                               const unsigned short* a1_1, const unsigned short* w1_0, const unsigned short* w1_1,
+                               int K1, const unsigned short* hprev0, const unsigned short* hprev1,
+                               const unsigned short* whh0, const unsigned short* whh1, const float* bias,
+                               float* hout0, float* hout1, long hos, unsigned short* hfrag0, unsigned short* hfrag1,
+                               float* c0, float* c1);
+/* rows (b*T + t) of X[., C] -> T fragment-major [Bp x C] bf16 matrices (timestep t at offset t*Bp*C): a layer-0 input of
+ * mmego_lstm_step_bf16_fused.  C % 16 == 0, Bp % 32 == 0. */
+int mmego_cvt_bf16_frag_tm(void* stream, const float* X, long ldx, int Bn, int T, int C, unsigned short* Y, int Bp);
+
 /* ---- IMU_Net stage-1 training pieces (imu_train.hip): reference Processor/Train/Train_IMU.py:21-34,114-149 -------
  * Pointwise LSTM cell backward of one timestep, both directions: dh = dout + dh_rec (dh_rec may be NULL), reads the
  * stashed gates / cell states, writes the pre-activation gate gradients dgates_d [Bn][4H] (row stride dgs) and updates

@@ -282,14 +282,83 @@ def lstm_bf16_weights(lstm):
     return layers
 
 
+def _frag_major_w(wb, H):
+    """[4H, K] bf16 row-major -> fragment-major [hidden block][gate][16-k step][k half][unit][8 k] (include/mmego_hip.h)."""
+    K = wb.shape[1]
+    return wb.view(4, H // 32, 32, K // 16, 2, 8).permute(1, 0, 3, 4, 2, 5).contiguous()
+
+
+def lstm_bf16_weights_fused(lstm):
+    """Per layer: ([per direction: list of fragment-major W_ih column blocks], [W_hh fragment-major per direction], bias [2][4H])
+    for the fused projection + recurrence step (large batches)."""
+    ver = tuple(p._version for p in lstm.parameters()) + tuple(p.data_ptr() for p in lstm.parameters())
+    cache = getattr(lstm, "_bf16_fused_cache", None)
+    if cache is not None and cache[0] == ver:
+        return cache[1]
+    H = lstm.hidden_size
+    base = lstm_bf16_weights(lstm)
+    layers = []
+    for l in range(lstm.num_layers):
+        wih, bias, whh0, whh1 = base[l]
+        segs = []
+        for d in range(2):
+            wd = wih[4 * H * d:4 * H * (d + 1)]
+            cols = [wd] if l == 0 else [wd[:, :H], wd[:, H:]]
+            segs.append([_frag_major_w(c.contiguous(), H) for c in cols])
+        layers.append((segs, (whh0, whh1), bias))
+    lstm._bf16_fused_cache = (ver, layers)
+    return layers
+
+
+FUSED_MIN_ROWS = int(os.environ.get("MMEGO_BF16_FUSED_MIN", "2049"))
+
+
+def lstm_steps_forward_bf16_fused(ar, key, lstm, x, Bn, T):
+    """Large-batch form of lstm_steps_forward_bf16: no projection tensor; every step multiplies [x_t | h_{t-1}] by [W_ih | W_hh]
+    (bf16.hip, lstm_step_bf16_fused_kernel).  Layer inputs and all h_t live fragment-major, one [Bp x K] matrix per timestep."""
+    H = lstm.hidden_size
+    W = lstm_bf16_weights_fused(lstm)
+    Bp = (Bn + 31) // 32 * 32
+    In = x.shape[1]
+    xf = ar.get("%s.xfrag" % key, (T, Bp * In), dtype=torch.bfloat16)
+    hip.call("cvt_bf16_frag_tm", x, x.stride(0), Bn, T, In, xf, Bp)
+    out = None
+    prev = None
+    for l in range(lstm.num_layers):
+        segs, whh, bias = W[l]
+        last = l == lstm.num_layers - 1
+        hf = ar.get("%s.hfall%d" % (key, l), (T, 2, Bp * H), dtype=torch.bfloat16)      # h_t of every timestep, fragment-major
+        c = ar.get("%s.c" % key, (2, Bn, H))
+        if last:
+            out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
+        out_p = out.data_ptr() if last else 0
+        os_ = T * 2 * H
+        for s in range(T):
+            t0, t1 = s, T - 1 - s
+            if l == 0:
+                a = (xf[t0], xf[t1], segs[0][0], segs[1][0], In, None, None, None, None, 0)
+                nseg = 1
+            else:
+                a = (prev[t0, 0], prev[t1, 0], segs[0][0], segs[1][0], H, prev[t0, 1], prev[t1, 1], segs[0][1], segs[1][1], H)
+                nseg = 2
+            hip.call("lstm_step_bf16_fused", 2, Bn, H, int(s == 0), nseg, *a,
+                     hf[t0 - 1, 0] if s > 0 else None, hf[t1 + 1, 1] if s > 0 else None, whh[0], whh[1], bias,
+                     out_p + 4 * (t0 * 2 * H) if last else None, out_p + 4 * (t1 * 2 * H + H) if last else None, os_,
+                     hf[t0, 0], hf[t1, 1], c[0], c[1])
+        prev = hf
+    return out
+
+
 def lstm_steps_forward_bf16(ar, key, lstm, x, Bn, T):
     """As lstm_steps_forward with bf16 product operands: x [Bn*T, In] fp32 rows (b*T+t) -> out [Bn*T, 2H] fp32 of the last
     layer (same row order).  Gate pre-activations, cell state and outputs are fp32.  Internal layouts (include/mmego_hip.h):
     projection operands time-major bf16 [T][Bp][In], projections tile-major fp32, recurrent operands fragment-major."""
     H = lstm.hidden_size
+    In = x.shape[1]
+    if Bn >= FUSED_MIN_ROWS and In % 64 == 0:
+        return lstm_steps_forward_bf16_fused(ar, key, lstm, x, Bn, T)
     W = lstm_bf16_weights(lstm)
     Bp = (Bn + 31) // 32 * 32
-    In = x.shape[1]
     cur = ar.get("%s.xtm" % key, (T * Bp, In), dtype=torch.bfloat16)
     hip.call("cvt_bf16_tm", x, x.stride(0), Bn, T, In, cur, Bp)
     out = None

@@ -554,3 +554,181 @@ extern "C" int mmego_lstm_step_bf16(void* stream, int ndir, int Bn, int H, int f
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
+
+// ---- large batches: input projection folded into the recurrent step ------------------------------------------------------
+// At Bn = 32768 the separate projection is an HBM round trip of 16 B per gate pre-activation (21.5 GB written by the GEMM and
+// read back by the steps, per layer: 86 of the ~140 GB a config-5 forward moves).  Here the step computes
+//     gates = [x_t | h_{t-1}] . [W_ih | W_hh]^T + (b_ih + b_hh)
+// in one accumulation: the K loop walks up to three operand SEGMENTS (layer 0: x_t, h_{t-1}; upper layers: the previous
+// layer's forward and backward h_t, then h_{t-1}), every segment fragment-major for both operands, so the loop body is the
+// one of lstm_step_bf16_kernel<1,1> (128 rows x 32 units x 4 gates per WG, 64-k chunks through LDS, 3 WGs per CU).  No
+// projection tensor exists; per step the kernel streams x_t, h_{t-1}, c (read + write) and h_t.
+// frag-major time-major conversion of a layer-0 input: rows (b*T + t) of X -> fragment-major [T][Bp x C]
+__global__ __launch_bounds__(256) void cvt_bf16_frag_tm_kernel(const float* __restrict__ X, long ldx, int Bn, int T, int C,
+                                                                bf16_t* __restrict__ Y, int Bp) {
+  const long c8 = C >> 3, total = (long)Bn * T * c8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / c8;
+    const int k = (int)(i - r * c8) * 8;
+    const int b = (int)(r / T), t = (int)(r - (long)b * T);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(X + r * ldx + k);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(X + r * ldx + k + 4);
+    u32x4 o;
+    o[0] = f2bf_bits(v0[0]) | (f2bf_bits(v0[1]) << 16);
+    o[1] = f2bf_bits(v0[2]) | (f2bf_bits(v0[3]) << 16);
+    o[2] = f2bf_bits(v1[0]) | (f2bf_bits(v1[1]) << 16);
+    o[3] = f2bf_bits(v1[2]) | (f2bf_bits(v1[3]) << 16);
+    *reinterpret_cast<u32x4*>(Y + (long)t * Bp * C + frag_off(b, k, C)) = o;
+  }
+}
+
+extern "C" int mmego_cvt_bf16_frag_tm(void* stream, const float* X, long ldx, int Bn, int T, int C, unsigned short* Y, int Bp) {
+  MMEGO_REQUIRE(Bn > 0 && T > 0 && C > 0 && C % 16 == 0 && ldx % 4 == 0 && Bp >= Bn && Bp % 32 == 0);
+  MMEGO_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Y) & 15) == 0);
+  const long total = (long)Bn * T * (C / 8);
+  const int grid = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+  cvt_bf16_frag_tm_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(X, ldx, Bn, T, C, Y, Bp);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+struct FusedStepP {
+  const bf16_t* a[3][2];     // operand segments [segment][direction], fragment-major [Bp x 16*S]; the last one is h_{t-1}
+  const bf16_t* w[3][2];     // weight segments, fragment-major with rows [hidden block][gate][32 units]
+  int S[3];                  // 16-k steps per segment (multiples of 4)
+  int nseg;                  // segments in use, h_{t-1} last; at the first timestep the host passes nseg without it
+  const float* bias;         // [2][4H] b_ih + b_hh
+  StepBfP o;                 // outputs, c, Bn, H, first (hprev / whh / xpf unused)
+};
+
+// one operand segment through the chunk pipeline (the body of lstm_step_bf16_kernel<WR,1>): WG = 128*WR rows, wave wr owns
+// WR row blocks of 32 rows
+template <int WR>
+__device__ __forceinline__ void fused_segment(const bf16_t* A, const bf16_t* W, int S, int jb, const int (&rbi)[4 * WR], int tid,
+                                              int lane, int wr, u32x4* As, u32x4* Bs, f32x16 (&acc)[WR][4]) {
+  constexpr int RB = 4 * WR;
+  const u32x4* ab = reinterpret_cast<const u32x4*>(A) + tid;
+  const u32x4* wb = reinterpret_cast<const u32x4*>(W) + (long)jb * 4 * S * 64 + tid;
+  u32x4 ra[RB], rw[4];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) ra[i] = ab[(long)rbi[i] * S * 64];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rw[i] = wb[(long)i * S * 64];
+  for (int s0 = 0; s0 < S; s0 += 4) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RB; ++i) As[i * 256 + tid] = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Bs[i * 256 + tid] = rw[i];
+    __syncthreads();
+    if (s0 + 4 < S) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) ra[i] = ab[((long)rbi[i] * S + s0 + 4) * 64];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rw[i] = wb[((long)i * S + s0 + 4) * 64];
+    }
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      u32x4 a[WR], b[4];
+#pragma unroll
+      for (int mi = 0; mi < WR; ++mi) a[mi] = As[((wr * WR + mi) * 4 + sl) * 64 + lane];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = Bs[(n * 4 + sl) * 64 + lane];
+#pragma unroll
+      for (int mi = 0; mi < WR; ++mi)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[n]),
+                                                               acc[mi][n], 0, 0, 0);
+    }
+  }
+}
+
+template <int WR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void lstm_step_bf16_fused_kernel(FusedStepP p) {
+  __shared__ __attribute__((aligned(16))) u32x4 As[4 * WR * 256];  // [row block][4 steps][64 lanes]
+  __shared__ __attribute__((aligned(16))) u32x4 Bs[4 * 256];       // [gate][4 steps][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wr = tid >> 6;
+  const int d = blockIdx.z, H = p.o.H;
+  const int nrb = gridDim.y, nb = gridDim.x * nrb;
+  const int id = bf_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, nb);
+  const int jb = id / nrb, j0 = jb * 32, r0 = (id % nrb) * (128 * WR);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int last_rb = (p.o.Bn - 1) >> 5;
+  int rbi[4 * WR];
+#pragma unroll
+  for (int i = 0; i < 4 * WR; ++i) rbi[i] = min((r0 >> 5) + i, last_rb);
+
+  f32x16 acc[WR][4];
+#pragma unroll
+  for (int mi = 0; mi < WR; ++mi)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][n][i] = 0.f;
+#pragma unroll
+  for (int seg = 0; seg < 3; ++seg)
+    if (seg < p.nseg) fused_segment<WR>(p.a[seg][d], p.w[seg][d], p.S[seg], jb, rbi, tid, lane, wr, As, Bs, acc);
+
+  const int j = j0 + fr;
+  float bv[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) bv[n] = p.bias[(d * 4 + n) * H + j];
+#pragma unroll
+  for (int mi = 0; mi < WR; ++mi) {
+    const int rb = (r0 >> 5) + wr * WR + mi;
+    if (rb * 32 >= p.o.Bn) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = rb * 32 + 8 * (i >> 2) + 4 * fh + (i & 3);
+      if (row < p.o.Bn) {
+        const float cprev = p.o.first ? 0.f : p.o.c[d][(long)row * H + j];
+        const float gi = bf_sigmoid(acc[mi][0][i] + bv[0]), gf = bf_sigmoid(acc[mi][1][i] + bv[1]);
+        const float gg = bf_tanh(acc[mi][2][i] + bv[2]), go = bf_sigmoid(acc[mi][3][i] + bv[3]);
+        const float cn = gf * cprev + gi * gg;
+        const float hn = go * bf_tanh(cn);
+        p.o.c[d][(long)row * H + j] = cn;
+        if (p.o.hout[d]) p.o.hout[d][(long)row * p.o.hos + j] = hn;
+        p.o.hfrag[d][frag_off(row, j, H)] = (bf16_t)f2bf_bits(hn);
+      }
+    }
+  }
+}
+
+extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H, int first, int nseg,
+                                          const unsigned short* a0_0, const unsigned short* a0_1, const unsigned short* w0_0,
+                                          const unsigned short* w0_1, int K0, const unsigned short* a1_0,
+                                          const unsigned short* a1_1, const unsigned short* w1_0, const unsigned short* w1_1,
+                                          int K1, const unsigned short* hprev0, const unsigned short* hprev1,
+                                          const unsigned short* whh0, const unsigned short* whh1, const float* bias,
+                                          float* hout0, float* hout1, long hos, unsigned short* hfrag0, unsigned short* hfrag1,
+                                          float* c0, float* c1) {
+  MMEGO_REQUIRE((ndir == 1 || ndir == 2) && Bn > 0 && H > 0 && H % 64 == 0 && (nseg == 1 || nseg == 2));
+  MMEGO_REQUIRE(K0 > 0 && K0 % 64 == 0 && a0_0 && w0_0 && (ndir == 1 || (a0_1 && w0_1)));
+  MMEGO_REQUIRE(nseg == 1 || (K1 > 0 && K1 % 64 == 0 && a1_0 && w1_0 && (ndir == 1 || (a1_1 && w1_1))));
+  MMEGO_REQUIRE(first || (hprev0 && whh0 && (ndir == 1 || (hprev1 && whh1))));
+  MMEGO_REQUIRE(bias && hfrag0 && c0 && (ndir == 1 || (hfrag1 && c1)) && hfrag0 != hprev0);
+  FusedStepP p;
+  int s = 0;
+  p.a[s][0] = a0_0; p.a[s][1] = a0_1; p.w[s][0] = w0_0; p.w[s][1] = w0_1; p.S[s] = K0 / 16; ++s;
+  if (nseg == 2) { p.a[s][0] = a1_0; p.a[s][1] = a1_1; p.w[s][0] = w1_0; p.w[s][1] = w1_1; p.S[s] = K1 / 16; ++s; }
+  if (!first) { p.a[s][0] = hprev0; p.a[s][1] = hprev1; p.w[s][0] = whh0; p.w[s][1] = whh1; p.S[s] = H / 16; ++s; }
+  p.nseg = s;
+  for (; s < 3; ++s) { p.a[s][0] = p.a[s][1] = p.w[s][0] = p.w[s][1] = nullptr; p.S[s] = 0; }
+  for (int q = 0; q < p.nseg; ++q)
+    for (int dd = 0; dd < ndir; ++dd)
+      MMEGO_REQUIRE((((uintptr_t)p.a[q][dd]) & 15) == 0 && (((uintptr_t)p.w[q][dd]) & 15) == 0);
+  p.bias = bias;
+  p.o.hprev[0] = p.o.hprev[1] = nullptr; p.o.whh[0] = p.o.whh[1] = nullptr; p.o.xpf = nullptr; p.o.mt0[0] = p.o.mt0[1] = 0;
+  p.o.hout[0] = hout0; p.o.hout[1] = hout1; p.o.hos = hos;
+  p.o.houtb[0] = p.o.houtb[1] = nullptr; p.o.hbs = 0;
+  p.o.hfrag[0] = hfrag0; p.o.hfrag[1] = hfrag1;
+  p.o.c[0] = c0; p.o.c[1] = c1;
+  p.o.Bn = Bn; p.o.H = H; p.o.first = first;
+  // WR = 1 (128 rows per WG, 128 VGPRs, four WGs per CU): 22.8 ms per config-5 IMU_Net forward; WR = 2 (256 rows, two WGs
+  // per CU, fewer LDS reads per MFMA) measured 24.5 ms -- co-resident workgroups hide the barriers better than a leaner loop.
+  dim3 grid(H / 32, cdiv(Bn, 128), ndir);
+  lstm_step_bf16_fused_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

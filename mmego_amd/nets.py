@@ -538,7 +538,7 @@ class IMUNet(_NetBase):
     def train(self, mode=True):
         if mode:                                   # weights may change: drop the bf16 copies of the LSTM weights
             for m in (self.rnn_fast, self.rnn_slow):
-                m._bf16_cache = None
+                m._bf16_cache = m._bf16_fused_cache = None
         return super().train(mode)
 
     def forward(self, imu, h0_i=None):

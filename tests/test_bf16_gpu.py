@@ -94,9 +94,13 @@ def _emulate_bilstm(x, W, H, Bn, T):
     return out.view(Bn * T, 2 * H)
 
 
-@pytest.mark.parametrize("Bn,T,H,In", [(200, 5, 128, 64), (2100, 3, 64, 128), (64, 4, 512, 1024), (200, 3, 256, 64), (2050, 2, 256, 64)])
-def test_bilstm_bf16_forward_matches_emulation(Bn, T, H, In):
+@pytest.mark.parametrize("Bn,T,H,In,fused", [(200, 5, 128, 64, False), (2100, 3, 64, 128, False), (64, 4, 512, 1024, False),
+                                               (200, 3, 256, 64, False), (2050, 2, 256, 64, False),
+                                               (2100, 3, 64, 128, True), (2050, 2, 256, 64, True), (130, 4, 128, 192, True)])
+def test_bilstm_bf16_forward_matches_emulation(Bn, T, H, In, fused, monkeypatch):
+    """fused = the large-batch form (projection folded into the step kernel; default from 2049 rows), forced on or off here."""
     from mmego_amd import blocks, ops
+    monkeypatch.setattr(blocks, "FUSED_MIN_ROWS", 1 if fused else 10 ** 9)
     torch.manual_seed(Bn)
     lstm = blocks.LstmParams(In, H, 2).to(_dev())
     g = torch.Generator().manual_seed(1)
