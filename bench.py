@@ -310,7 +310,7 @@ def main():
     # bf16-operand variant of the two frozen IMU_Net forwards (IMUNet.precision = "bf16": BiLSTM products with bf16 operands
     # and fp32 accumulation, everything else fp32).  Extra figure, never `value`: it is outside the 1e-3 cm parity bound.
     bf16_extra = {}
-    if not args.no_bf16_variant:
+    if not args.no_bf16_variant and world == 1:      # single-GPU extra; the scaling runs keep to the fp32 path
         try:
             imu.precision = imu_l.precision = "bf16"
             su_b = StageStep("upper", upper, imu, lr=3e-5, process_group=pg, use_graph=not args.no_graph)
