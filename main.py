@@ -36,6 +36,9 @@ def build_parser():
     p.add_argument("--gt_head_pose", action="store_true", help="head pose from the recording instead of IMU_Net")
     p.add_argument("--data_root", type=str, help="Sample_data directory")
     p.add_argument("--seed", type=int, help="seed torch (net initialisation) and numpy (point-cloud padding) -- the reference does not seed")
+    p.add_argument("--imu_precision", type=str, choices=["fp32", "bf16"],
+                   help="eval-mode IMU_Net forwards (stages 2/3, --infer): fp32 (default, parity path) or bf16 product operands "
+                        "with fp32 accumulation (DESIGN.md 7a)")
     p.add_argument("--resume", type=str, help="continue --train from a checkpoint written by this framework (the model .pth "
                                                "or its .train_state.pth: weights, Adam state, epoch, RNGs)")
     return p
@@ -63,6 +66,8 @@ def apply_overrides(args):
         for c in both:
             c.gt_head_pose = True
     Config.resume_path = args.resume
+    if args.imu_precision is not None:
+        os.environ["MMEGO_IMU_PRECISION"] = args.imu_precision      # read by IMUNet.__init__
 
 
 def main(argv=None):

@@ -64,6 +64,16 @@ def test_main_train_and_infer_on_synthetic_tree(tmp_path):
         assert line in out
     assert os.path.exists(os.path.join(ROOT, "Processor", "Train", "report", "9101", "log-loss.txt"))
     assert os.path.isdir(model_dir)
+    # head pose from IMU_Net instead of the recording, fp32 and with --imu_precision bf16 (opt-in mode): the
+    # bf16 run moves the head rotation by ~2e-3, i.e. the average joint error by well under a centimetre
+    torch.save(nets.IMUNet(15, 9, 512, 2, True, 0.1).state_dict(), ck / "imu.pth")
+    import re
+    errs = {}
+    for prec in ("fp32", "bf16"):
+        out = _run(["--infer", "--data_root", data, "--device", "cuda:0", "--load_Upper_path", str(ck / "upper.pth"),
+                    "--load_Lower_path", str(ck / "lower.pth"), "--load_IMU_path", str(ck / "imu.pth"), "--imu_precision", prec], env)
+        errs[prec] = float(re.search(r"Average Joint Localization Error\(cm\):\s*([0-9.eE+-]+)", out).group(1))
+    assert errs["fp32"] != errs["bf16"] and abs(errs["fp32"] - errs["bf16"]) < 0.5, errs
 
 
 def test_resume_continues_bit_exactly(tmp_path):
