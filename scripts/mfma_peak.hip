@@ -1,9 +1,11 @@
-// Calibration: sustained fp32 MFMA rate of the chip with no memory traffic at all (register operands only).
+// Calibration: sustained fp32 (and bf16) MFMA rate of the chip with no memory traffic at all (register operands only).
 // Build: hipcc -O3 --offload-arch=gfx950 scripts/mfma_peak.hip -o /tmp/mfma_peak ; run: /tmp/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int KIND>
 __global__ __launch_bounds__(256) void spin(float* out, int iters) {
@@ -17,6 +19,25 @@ __global__ __launch_bounds__(256) void spin(float* out, int iters) {
         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c1, 0, 0, 0);
         c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c2, 0, 0, 0);
         c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c3, 0, 0, 0);
+      }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+  } else if (KIND == 2) {
+    // bf16 32x32x16 with realistic (non-constant) operand bits: the data pattern moves the power draw and with it the clock
+    u32x4 ua, ub;
+    for (int e = 0; e < 4; ++e) {
+      ua[e] = 0x3f803f80u + 0x01230007u * (threadIdx.x + 17 * e);
+      ub[e] = 0x3f003e80u + 0x00510003u * (threadIdx.x * 3 + e);
+    }
+    const bf16x8 xa = __builtin_bit_cast(bf16x8, ua), xb = __builtin_bit_cast(bf16x8, ub);
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xb, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, xa, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa, xa, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xb, xb, c3, 0, 0, 0);
       }
     }
     out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
@@ -67,5 +88,7 @@ int main() {
   run<0>("32x32x2 long ", 512, 100000, 2.0 * 32 * 32 * 2, 32);
   run<1>("16x16x4 short", 256, 2000, 2.0 * 16 * 16 * 4, 64);
   run<1>("16x16x4 long ", 512, 100000, 2.0 * 16 * 16 * 4, 64);
+  run<2>("bf16 32x32x16 short", 256, 2000, 2.0 * 32 * 32 * 16, 32);
+  run<2>("bf16 32x32x16 long ", 512, 100000, 2.0 * 32 * 32 * 16, 32);
   return 0;
 }
