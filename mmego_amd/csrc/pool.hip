@@ -66,19 +66,54 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_lds_kernel(const float* __r
   float* Xs = lds;                       // [P][C]
   float* sc = lds + (long)P * C;         // [P]
   __shared__ float red[8];
+  __shared__ __attribute__((aligned(16))) float part[1024];     // partial scores [TPP][P] / partial sums [PG][C]
   const long g = blockIdx.x;
   const float* Xg = X + g * (long)P * C;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int n4 = P * C / 4;
-  for (int i = threadIdx.x; i < n4; i += blockDim.x)
-    reinterpret_cast<f32x4*>(Xs)[i] = reinterpret_cast<const f32x4*>(Xg)[i];
+  {
+    // all of the tile's loads in flight at once (a rolled copy loop waits for every load before its LDS store: 16 latencies
+    // for a 64-KB tile), then the stores
+    f32x4 v[24];
+#pragma unroll
+    for (int q = 0; q < 24; ++q)
+      if (tid + 256 * q < n4) v[q] = reinterpret_cast<const f32x4*>(Xg)[tid + 256 * q];
+#pragma unroll
+    for (int q = 0; q < 24; ++q)
+      if (tid + 256 * q < n4) reinterpret_cast<f32x4*>(Xs)[tid + 256 * q] = v[q];
+  }
   const float b = bptr ? bptr[0] : 0.f;
   __syncthreads();
-  for (int p = wave; p < P; p += nw) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += Xs[p * C + c] * w[c];
-    s = wave_sum(s);
-    if (lane == 0) sc[p] = s + b;
+  // scores: TPP threads per point, each over a contiguous slice of the channels, started at a point-dependent offset so that
+  // neighbouring threads hit different LDS banks (the points' rows are C floats apart); partials summed in fixed order
+  int TPP = 1;
+  while (TPP * 2 * P <= 256 && TPP * 2 * P <= 1024 && (C % (TPP * 2)) == 0) TPP *= 2;
+  const bool wide = P * TPP <= 1024 && P <= 1024;
+  if (wide) {
+    const int len = C / TPP;
+    for (int q = tid; q < P * TPP; q += blockDim.x) {
+      const int p = q % P, pt = q / P, c0 = pt * len;
+      float s = 0.f;
+      for (int i = 0; i < len; ++i) {
+        int c = i + p;
+        c = c0 + (c >= len ? c % len : c);
+        s += Xs[p * C + c] * w[c];
+      }
+      part[pt * P + p] = s;
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += blockDim.x) {
+      float s = part[p];
+      for (int pt = 1; pt < TPP; ++pt) s += part[pt * P + p];
+      sc[p] = s + b;
+    }
+  } else {
+    for (int p = wave; p < P; p += nw) {
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) s += Xs[p * C + c] * w[c];
+      s = wave_sum(s);
+      if (lane == 0) sc[p] = s + b;
+    }
   }
   __syncthreads();
   float m = -INFINITY;
@@ -102,10 +137,25 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_lds_kernel(const float* __r
   for (int i = 0; i < nw; ++i) sum += red[i];
   const float inv = 1.0f / sum;
   for (int p = threadIdx.x; p < P; p += blockDim.x) attn[g * P + p] = sc[p] * inv;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  // weighted sum: with few channels, PG point groups share the work of a channel (256 / C threads per channel)
+  const int PG = (C <= 128 && (256 % C) == 0) ? 256 / C : 1;
+  if (PG > 1) {
+    const int c = tid % C, pg = tid / C;
     float acc = 0.f;
-    for (int p = 0; p < P; ++p) acc += Xs[p * C + c] * (sc[p] * inv);
-    vec[g * C + c] = acc;
+    for (int p = pg; p < P; p += PG) acc += Xs[p * C + c] * (sc[p] * inv);
+    part[pg * C + c] = acc;
+    __syncthreads();
+    if (tid < C) {
+      float a = part[tid];
+      for (int q = 1; q < PG; ++q) a += part[q * C + tid];
+      vec[g * C + tid] = a;
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float acc = 0.f;
+      for (int p = 0; p < P; ++p) acc += Xs[p * C + c] * (sc[p] * inv);
+      vec[g * C + c] = acc;
+    }
   }
 }
 
