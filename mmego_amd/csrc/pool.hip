@@ -271,14 +271,47 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_lds_kernel(const float* __r
   const float* dv = dvec + g * C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int n4 = P * C / 4;
-  for (int i = tid; i < n4; i += blockDim.x) reinterpret_cast<f32x4*>(Xs)[i] = reinterpret_cast<const f32x4*>(Xg)[i];
+  {
+    f32x4 v[16];                          // tile <= 64 KB: all of its loads in flight at once, then the LDS stores
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (tid + 256 * q < n4) v[q] = reinterpret_cast<const f32x4*>(Xg)[tid + 256 * q];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (tid + 256 * q < n4) reinterpret_cast<f32x4*>(Xs)[tid + 256 * q] = v[q];
+  }
   for (int p = tid; p < P; p += blockDim.x) ags[p] = attn[g * P + p];
   __syncthreads();
-  for (int p = wave; p < P; p += nw) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += Xs[p * C + c] * dv[c];
-    s = wave_sum(s);
-    if (lane == 0) sh[p] = s;
+  // da[p] = X[p, :] . dvec: TPP threads per row, each over a contiguous channel slice entered at a row-dependent offset
+  // (bank-conflict free), partials summed in fixed order -- as in attn_pool_fwd_lds_kernel
+  __shared__ float ps[1024];
+  int TPP = 1;
+  while (TPP * 2 * P <= 256 && (C % (TPP * 2)) == 0) TPP *= 2;
+  if (P * TPP <= 1024) {
+    const int len = C / TPP;
+    for (int q = tid; q < P * TPP; q += blockDim.x) {
+      const int p = q % P, pt = q / P, c0 = pt * len;
+      float s = 0.f;
+      for (int i = 0; i < len; ++i) {
+        int c = i + p;
+        c = c0 + (c >= len ? c % len : c);
+        s += Xs[p * C + c] * dv[c];
+      }
+      ps[pt * P + p] = s;
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += blockDim.x) {
+      float s = ps[p];
+      for (int pt = 1; pt < TPP; ++pt) s += ps[pt * P + p];
+      sh[p] = s;
+    }
+  } else {
+    for (int p = wave; p < P; p += nw) {
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) s += Xs[p * C + c] * dv[c];
+      s = wave_sum(s);
+      if (lane == 0) sh[p] = s;
+    }
   }
   __syncthreads();
   float dot = 0.f;
@@ -451,7 +484,7 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
 // dA[k, v, w] = sum_{g, c} Z[g, v, k*C + c] * dY[g, w, c]     Z [G, V, K*C], dY [G, V, C]
 // Each block stages FPB frames' Z and dY rows in LDS once and every thread owns one (k,v,w) entry;
 // partial[blk][k*V*V + v*V + w] is then column-summed in fixed order by the caller (mmego_colsum kernels).
-#define GDA_FPB 8
+#define GDA_FPB 2   // frames per block: 512 frames -> 256 blocks (8 per block left 3 of 4 CUs idle and chained 8 load latencies)
 __global__ __launch_bounds__(512) void graph_dA_partial_kernel(const float* __restrict__ Z, const float* __restrict__ dY, long G,
                                                                int V, int Kk, int C, float* __restrict__ partial) {
   extern __shared__ float sm[];
