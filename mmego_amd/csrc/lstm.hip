@@ -205,25 +205,25 @@ struct Lstm64BwdP {
   int B, T;
 };
 
-#define NLD 80  // W_hh natural rows [n][64 k] + 16 pad
 
 __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wn = smem;               // [256 n][NLD]  natural W_hh rows
-  float* dgs = smem + 256 * NLD;  // [256 n][16 rows]
+  float* dgs = smem;              // [256 n][16 rows]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = blockIdx.y, r0 = blockIdx.x * 16;
   const int B = p.B, T = p.T;
-  const float* W = p.whh[d];
-  for (int i = tid; i < 256 * 16; i += 256) {
-    int n = i >> 4, k4 = (i & 15) * 4;
-    *reinterpret_cast<float4*>(&Wn[n * NLD + k4]) = *reinterpret_cast<const float4*>(W + n * 64 + k4);
-  }
   const int fr = lane & 15, fq = lane >> 4;
   const int j = wave * 16 + fr;
+  // W_hh as this lane's 64 MFMA operands (row n = 4*i + fq, column 16*wave + fr), straight from global memory with all
+  // loads in flight (the LDS copy it replaces was a rolled loop of 16 dependent global -> LDS round trips per launch)
+  float wreg[64];
+  {
+    const float* W = p.whh[d] + fq * 64 + wave * 16 + fr;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) wreg[i] = W[i * 256];
+  }
   float dcreg[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 dhrec = {0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
 
   // Everything a step reads from memory (incoming dh, saved gates, cell states) is independent of the recurrence: the
   // next step's values are fetched while this step computes.  c_{t-1} of this step is c_t of the next one.
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
         float gi = gin[reg][1], gf = gin[reg][2], gg = gin[reg][3], go = gin[reg][4];
         float c = ccur[reg];
         float cprev = gin[reg][5];
-        float tc = tanhf(c);
+        float tc = l64_tanh(c);
         float dc = dcreg[reg] + dh * go * (1.f - tc * tc);
         dg4[0][reg] = dc * gg * gi * (1.f - gi);
         dg4[1][reg] = dc * cprev * gf * (1.f - gf);
@@ -287,12 +287,10 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
     L64_LDS_BARRIER();
     // dh_rec[row][k] = sum_n dgates[row][n] * W_hh[n][k]; this wave owns k in [16*wave, 16*wave+16)
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+#pragma unroll
     for (int n4 = 0; n4 < 64; n4 += 2) {
-      int n = n4 * 4 + fq;
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dgs[n * 16 + fr], Wn[n * NLD + wave * 16 + fr], a0, 0, 0, 0);
-      n += 4;
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dgs[n * 16 + fr], Wn[n * NLD + wave * 16 + fr], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dgs[(n4 * 4 + fq) * 16 + fr], wreg[n4], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dgs[(n4 * 4 + 4 + fq) * 16 + fr], wreg[n4 + 1], a1, 0, 0, 0);
     }
     dhrec = a0 + a1;
 #pragma unroll
@@ -317,13 +315,7 @@ extern "C" int mmego_lstm64_backward(void* stream, int B, int T, const float* do
   p.whh[0] = whh0; p.whh[1] = whh1;
   p.dgates[0] = dgates0; p.dgates[1] = dgates1; p.dgs = dgs;
   p.B = B; p.T = T;
-  size_t lds = (size_t)(256 * NLD + 256 * 16) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm64_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  const size_t lds = (size_t)(256 * 16) * sizeof(float);
   hipLaunchKernelGGL(lstm64_bwd_kernel, dim3(cdiv(B, 16), 2), dim3(256), lds, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
