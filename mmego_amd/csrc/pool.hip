@@ -367,7 +367,14 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict_
   int c = (int)(i - g * C);
   const float* x = X + g * (long)P * C + c;
   float s = 0.f;
-  for (int p = 0; p < P; ++p) s += x[(long)p * C];
+  for (int p0 = 0; p0 < P; p0 += 8) {          // eight rows' loads in flight, summed in row order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p0 + u < P ? x[(long)(p0 + u) * C] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p0 + u < P) s += v[u];
+  }
   Y[g * ldy + c] = s * scale;
 }
 
