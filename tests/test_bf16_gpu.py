@@ -139,3 +139,21 @@ def test_imu_forward_bf16_mode_is_close_to_fp32_and_is_opt_in():
     net.precision = "fp16"
     with pytest.raises(ValueError):
         net(imu)
+
+
+def test_large_batch_fused_and_unfused_forms_agree(monkeypatch):
+    """At a config-5-like size (4096 sequences, H = 512) the CPU emulation is too slow; instead the two device forms of the mode
+    -- separate tile-major projection + step kernels, and the projection folded into the step -- must agree: same bf16 operand
+    roundings, fp32 accumulation in a different order (plus the occasional flipped bf16 ulp of h_t that follows from it)."""
+    from mmego_amd import blocks, ops
+    Bn, T, H, In = 4096, 3, 512, 512
+    torch.manual_seed(11)
+    lstm = blocks.LstmParams(In, H, 2).to(_dev())
+    x = torch.randn(Bn * T, In, generator=torch.Generator().manual_seed(12)).to(_dev())
+    outs = {}
+    for fused in (False, True):
+        monkeypatch.setattr(blocks, "FUSED_MIN_ROWS", 1 if fused else 10 ** 9)
+        outs[fused] = blocks.lstm_steps_forward_bf16(ops.Arena(_dev()), "t", lstm, x, Bn, T).clone()
+    err = (outs[True] - outs[False]).abs()
+    assert float(err.max()) < 2e-3 and float(err.mean()) < 2e-5, (float(err.max()), float(err.mean()))
+    assert float(outs[True].abs().mean()) > 1e-2          # not trivially zero
