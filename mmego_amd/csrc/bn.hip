@@ -63,6 +63,9 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
   // Exact pooled statistics of the (<= 1024) block partials, fp64, no division inside the loops:
   //   N = sum n_b,  mean = sum n_b mean_b / N,  M2 = sum [M2_b + n_b (mean_b - mean)^2]
   // All of a lane's partials (<= 16) are fetched in ONE round of loads; the kernel is pure load latency otherwise.
+  // (the per-channel parameters the epilogue needs travel with the same round of loads)
+  const float g_c = gamma[c], be_c = beta[c];
+  const float rm_c = running_mean ? running_mean[c] : 0.f, rv_c = running_mean ? running_var[c] : 0.f;
   float pn[16], pm[16], p2[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
@@ -94,12 +97,12 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
   float invstd = (float)(1.0 / sqrt(var + (double)eps));
   mean_out[c] = (float)mean;
   invstd_out[c] = invstd;
-  a_out[c] = gamma[c] * invstd;
-  b_out[c] = beta[c];
+  a_out[c] = g_c * invstd;
+  b_out[c] = be_c;
   if (running_mean) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_mean[c] = (1.f - momentum) * rm_c + momentum * (float)mean;
     double unbiased = N > 1.0 ? M2 / (N - 1.0) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    running_var[c] = (1.f - momentum) * rv_c + momentum * (float)unbiased;
   }
 }
 
