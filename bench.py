@@ -199,6 +199,7 @@ def main():
     ap.add_argument("--trace-only", action="store_true", help="warm-up + timed loop only, then exit (clean input for rocprofv3 summaries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-variant", action="store_true", help="skip the extra bf16-IMU figure")
+    ap.add_argument("--no-pipelined-variant", action="store_true", help="skip the extra prefetch-pipelined figure")
     ap.add_argument("--cpu-steps", type=int, default=5)
     args = ap.parse_args()
 
@@ -336,6 +337,37 @@ def main():
         finally:
             imu.precision = imu_l.precision = "fp32"
 
+    # Prefetch-pipelined variant (train_step.PipelinedStages): the frozen IMU_Net forwards of minibatch i+1 overlap the trainable
+    # bodies of minibatch i; two DIFFERENT synthetic minibatches alternate and are copied into the static buffers inside the timed
+    # loop.  Same work per step, bit-identical results (tests/test_hip_local.py); extra figure, never `value`.
+    pipe_extra = {}
+    if not args.no_pipelined_variant and world == 1:
+        from mmego_amd.train_step import PipelinedStages
+        x2, imu2, _, target2 = synth_batch(4321 + rank, device)
+        sets = [(x, target, imu_in), (x2, target2, imu2)]
+        xb, tb, inext = x.clone(), target.clone(), imu_in.clone()
+        su_p = StageStep("upper", upper, None, lr=3e-5, process_group=pg, use_graph=False)
+        sl_p = StageStep("lower", lower, None, upper_frozen=upper_frozen, lr=3e-5, process_group=pg, use_graph=False)
+        pipe = PipelinedStages([su_p, sl_p], [imu, imu_l], inext, use_graph=not args.no_graph)
+        su_p.bind(xb, imu_in, body, tb)
+        sl_p.bind(xb, imu_in, body, tb)
+        pipe.prime()
+        pipe.prepare()
+
+        def pipe_step(i):
+            xs_, ts_, _ = sets[i % 2]
+            xb.copy_(xs_); tb.copy_(ts_); inext.copy_(sets[(i + 1) % 2][2])
+            pipe.step()
+        for i in range(4):
+            pipe_step(i)
+        sync()
+        t0p = time.perf_counter()
+        for i in range(args.steps):
+            pipe_step(i)
+        sync()
+        dt_p = time.perf_counter() - t0p
+        pipe_extra = {"ms_per_step_pipelined": dt_p / args.steps * 1e3, "frames_per_s_pipelined": world * B * T / (dt_p / args.steps)}
+
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -354,6 +386,7 @@ def main():
                "ms_per_step_sequential": t_u + t_l, "frames_per_s_sequential": world * B * T / ((t_u + t_l) * 1e-3),
                "t_upper_ms": t_u, "t_lower_ms": t_l, "loss_upper": loss_u, "loss_lower": loss_l}
         out.update(bf16_extra)
+        out.update(pipe_extra)
 
     # ---- roofline of the dominant kernel: eager replay with event pairs around every launch ----------------
     if rank == 0:

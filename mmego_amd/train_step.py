@@ -314,3 +314,85 @@ class ConcurrentStages:
         for st in self.stages:
             st.opt.step()
         return [st.loss for st in self.stages]
+
+
+class PipelinedStages:
+    """ConcurrentStages with the frozen IMU_Net forwards moved one minibatch ahead (a prefetch pipeline).
+
+    The IMU_Net forwards of a stage body depend on nothing the step changes (frozen weights, the minibatch's IMU samples), so
+    the forwards for minibatch i+1 can run while the trainable bodies work on minibatch i: the compute-bound half of a body
+    overlaps the latency-bound half of the previous one.  One replay = [head poses of minibatch i move from the "next" to the
+    "current" buffers] -> {Upper body(i) | Lower body(i) | IMU_Net_L(i+1), IMU_Net_U(i+1)} as three concurrent branches.
+    Every step still runs both IMU_Net forwards in full; results are bit-identical to ConcurrentStages on the same sequence of
+    minibatches (tests/test_hip_local.py).  `imu_next` is the static buffer the caller fills with minibatch i+1's IMU samples
+    before step i; `prime()` runs the forwards for the first minibatch."""
+
+    def __init__(self, stages, imu_nets, imu_next, use_graph=True):
+        self.stages, self.imus, self.imu_next = list(stages), list(imu_nets), imu_next
+        if len(self.stages) != len(self.imus) or any(st.imu is not None for st in self.stages):
+            raise ValueError("PipelinedStages: one IMU_Net per stage, and the stages themselves must be built with imu_net=None")
+        if len({id(m) for m in self.imus}) != len(self.imus):
+            raise ValueError("PipelinedStages: every stage needs its own IMU_Net instance")
+        B, T = imu_next.shape[0], imu_next.shape[1]
+        dev = imu_next.device
+        mk = lambda: (torch.empty(B, T, 3, 3, device=dev), torch.empty(B, T, 3, device=dev))
+        self.cur = [mk() for _ in self.stages]
+        self.nxt = [mk() for _ in self.stages]
+        for st, pose in zip(self.stages, self.cur):
+            st.pose = pose
+        self.pair = ConcurrentStages(self.stages, use_graph=False)
+        self.side = torch.cuda.Stream()
+        self.use_graph, self.graph = use_graph, None
+
+    def _imu_forwards(self):
+        with torch.no_grad():
+            for net, (Rn, tn) in zip(reversed(self.imus), reversed(self.nxt)):      # (Lower's first, as in ConcurrentStages)
+                R, t = net(self.imu_next)
+                ops.copy2d(R.view(-1, 9), Rn.view(-1, 9))
+                ops.copy2d(t.view(-1, 3), tn.view(-1, 3))
+
+    def prime(self):
+        """Head poses of the first minibatch (its IMU samples are in `imu_next`)."""
+        self._imu_forwards()
+        torch.cuda.synchronize()
+
+    def _body(self):
+        main = torch.cuda.current_stream()
+        for (Rc, tc), (Rn, tn) in zip(self.cur, self.nxt):
+            ops.copy2d(Rn.view(-1, 9), Rc.view(-1, 9))
+            ops.copy2d(tn.view(-1, 3), tc.view(-1, 3))
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self._imu_forwards()
+        self.pair._bodies()
+        main.wait_stream(self.side)
+
+    def prepare(self):
+        if self.use_graph and self.graph is None:
+            keep = [[t.clone() for t in st._mutable_state()] for st in self.stages]
+            keep_pose = [[t.clone() for pr in (self.cur, self.nxt) for pose in pr for t in pose]]
+            for _ in range(2):
+                self._body()
+                torch.cuda.synchronize()
+            for st, ks in zip(self.stages, keep):
+                for t, k in zip(st._mutable_state(), ks):
+                    t.copy_(k)
+            for t, k in zip([t for pr in (self.cur, self.nxt) for pose in pr for t in pose], keep_pose[0]):
+                t.copy_(k)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body()
+            self.graph = g
+
+    def step(self):
+        if self.use_graph:
+            self.prepare()
+            self.graph.replay()
+        else:
+            self._body()
+        for st in self.stages:
+            allreduce_grads(st.net._flat, st.pg)
+        for st in self.stages:
+            st.opt.step()
+        return [st.loss for st in self.stages]

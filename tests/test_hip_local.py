@@ -287,6 +287,62 @@ def test_shared_imu_stages_equal_separate_forwards(dev):
         assert torch.equal(a.net.flat().flat_g, b.net.flat().flat_g) and torch.equal(a.net.flat().flat_p, b.net.flat().flat_p), a.stage
 
 
+def test_pipelined_stages_equal_concurrent_stages(dev):
+    """train_step.PipelinedStages (the frozen IMU_Net forwards of minibatch i+1 overlap the stage bodies of minibatch i) gives,
+    on a sequence of DIFFERENT minibatches, bit-identical losses, gradients and parameters to ConcurrentStages, eagerly and as
+    a replayed HIP graph."""
+    from mmego_amd import nets
+    from mmego_amd.train_step import ConcurrentStages, PipelinedStages, StageStep
+    g = golden("g6_train.npz")
+    x0, body, target = [T(g[k]).to(dev) for k in ("x", "body", "target")]
+    gen = torch.Generator().manual_seed(7)
+    nb = 4
+    xs = [(x0.cpu() * (1.0 + 0.05 * i)).to(dev) for i in range(nb)]                      # four different minibatches
+    tg = [(target.cpu() + 0.01 * torch.randn(target.shape, generator=gen)).to(dev) for _ in range(nb)]
+    im = [torch.randn(4, 8, 20, 15, generator=gen).to(dev) for _ in range(nb + 1)]
+
+    def build(pipelined):
+        torch.manual_seed(93)
+        imu_u = nets.IMUNet(15, 9, 64, 2, True, 0.1).to(dev).eval()
+        imu_l = nets.IMUNet(15, 9, 64, 2, True, 0.1).to(dev).eval()
+        up, lo, fr = nets.UpperNet().to(dev).train(), nets.LowerNet(64).to(dev).train(), nets.UpperNet().to(dev).eval()
+        su = StageStep("upper", up, None if pipelined else imu_u, lr=3e-5, use_graph=False)
+        sl = StageStep("lower", lo, None if pipelined else imu_l, upper_frozen=fr, lr=3e-5, use_graph=False)
+        return su, sl, imu_u, imu_l
+
+    def run(pipelined, use_graph):
+        su, sl, imu_u, imu_l = build(pipelined)
+        xb, ib, tb = xs[0].clone(), im[0].clone(), tg[0].clone()                          # the static minibatch buffers
+        inext = im[0].clone()
+        if pipelined:
+            eng = PipelinedStages([su, sl], [imu_u, imu_l], inext, use_graph=use_graph)
+        else:
+            eng = ConcurrentStages([su, sl], use_graph=use_graph)
+        for st in (su, sl):
+            st.bind(xb, ib, body, tb)
+        if pipelined:
+            eng.prime()
+            eng.prepare()
+        losses = []
+        for i in range(nb):
+            xb.copy_(xs[i]); ib.copy_(im[i]); tb.copy_(tg[i]); inext.copy_(im[i + 1])
+            eng.step()
+            losses.append((su.loss.item(), sl.loss.item()))
+        torch.cuda.synchronize()
+        return losses, su, sl
+
+    ref_losses, ru, rl = run(False, False)
+    assert len(set(ref_losses)) == nb                                                    # the minibatches really differ
+    for use_graph in (False, True):
+        losses, su, sl = run(True, use_graph)
+        assert losses == ref_losses, (use_graph, losses, ref_losses)
+        for a, b in ((su, ru), (sl, rl)):
+            assert torch.equal(a.net.flat().flat_g, b.net.flat().flat_g), (use_graph, a.stage)
+            assert torch.equal(a.net.flat().flat_p, b.net.flat().flat_p), (use_graph, a.stage)
+            for ba, bb in zip(a.net.buffers(), b.net.buffers()):
+                assert torch.equal(ba, bb), (use_graph, a.stage)
+
+
 def test_device_resident_minibatches(dev):
     """mmego_gather_rows / data.DeviceArrays: minibatches gathered on the device equal numpy fancy indexing followed by the
     reference's float64 -> float32 conversion (bit-exact), repeated and out-of-range indices included."""
