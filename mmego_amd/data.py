@@ -241,6 +241,19 @@ class DeviceArrays:
         return out
 
 
+def _gather_field_into(self, name, index, out):
+    """One field of the items `index` into a caller-owned buffer `out` [len(index), ...] (the prefetch of the NEXT minibatch's
+    IMU samples for train_step.PipelinedStages, which must not disturb the current minibatch's buffers)."""
+    import torch
+    from . import ops
+    idx = torch.as_tensor(np.ascontiguousarray(index), dtype=torch.int64).to(self.device)
+    ops.gather_rows(self.src[name], idx, out.view(idx.numel(), -1))
+    return out
+
+
+DeviceArrays.gather_field_into = _gather_field_into
+
+
 def batch_indices(n, batch_size, shuffle, rng=None):
     """The index sets `batches` iterates over (same RNG consumption), for on-device gathering."""
     order = (rng or np.random).permutation(n) if shuffle else np.arange(n)

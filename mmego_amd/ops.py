@@ -28,7 +28,12 @@ def _rows(t):
 
 
 class Arena:
-    """Named scratch buffers that persist across calls (static addresses: HIP-graph friendly)."""
+    """Named scratch buffers that persist across calls (static addresses: HIP-graph friendly).
+
+    A buffer is never replaced: asking for a known name with another shape (a net used at a second minibatch size -- the short
+    last minibatch of an epoch, an evaluation pass) creates a second buffer beside the first.  Captured HIP graphs keep replaying
+    on the addresses they were captured with, so freeing or recycling a buffer they use would let them scribble over whatever
+    the allocator puts there next."""
 
     def __init__(self, device):
         self.device = device
@@ -36,19 +41,21 @@ class Arena:
 
     def get(self, key, shape, dtype=torch.float32, zero=False):
         shape = tuple(int(s) for s in shape)
-        t = self.bufs.get(key)
-        if t is None or t.shape != shape or t.dtype != dtype:
+        slot = (key, shape, dtype)
+        t = self.bufs.get(slot)
+        if t is None:
             t = torch.empty(shape, dtype=dtype, device=self.device)
-            self.bufs[key] = t
+            self.bufs[slot] = t
         if zero:
             fill(t, 0.0) if dtype == torch.float32 else t.zero_()
         return t
 
     def has(self, key):
-        return key in self.bufs
+        return any(k[0] == key for k in self.bufs)
 
 
 _scratch = {}
+_retired = []
 _side = {"streams": {}, "stack": [], "enabled": _os.environ.get("MMEGO_WGRAD_OVERLAP", "0") != "0"}
 
 
@@ -94,6 +101,8 @@ def scratch(device, n):
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     t = _scratch.get(key)
     if t is None or t.numel() < n:
+        if t is not None:
+            _retired.append(t)          # captured graphs may still replay on the smaller buffer: never hand its memory back
         t = torch.empty(max(int(n), 1 << 20), dtype=torch.float32, device=device)
         _scratch[key] = t
     return t

@@ -18,7 +18,7 @@ from . import hip, ops
 from .config import Config, ConfigDemo
 from .data import DeviceArrays, PosePC, batch_indices, batches
 from .nets import IMUNet, LowerNet, UpperNet
-from .train_step import StageStep, shard_of
+from .train_step import PipelinedStages, StageStep, shard_of
 from .utils import EarlyStopping
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -129,16 +129,25 @@ class _StageTrainer(_Base):
         return next(iter(self._steps.values())).opt if self._steps else None
 
     def _step_for(self, B):
-        """One StageStep (static buffers, optional HIP graph) per minibatch size."""
+        """One StageStep (static buffers, optional HIP graph) per minibatch size.  With a frozen IMU_Net in the loop its forward
+        runs one minibatch ahead of the trainable body (train_step.PipelinedStages: same results bit for bit, the compute-bound
+        IMU_Net forward of minibatch i+1 overlaps the latency-bound body of minibatch i); MMEGO_PIPELINE_IMU=0 turns that off."""
         st = self._steps.get(B)
         if st is None:
             pg = torch.distributed.group.WORLD if self.world > 1 else None
-            st = StageStep(self.stage, self.model, self.model_IMU, upper_frozen=getattr(self, "Upper_net", None),
-                           lr=self.learning_rate, process_group=pg, use_graph=True)
+            pipelined = self.model_IMU is not None and os.environ.get("MMEGO_PIPELINE_IMU", "1") != "0"
+            st = StageStep(self.stage, self.model, None if pipelined else self.model_IMU,
+                           upper_frozen=getattr(self, "Upper_net", None), lr=self.learning_rate, process_group=pg,
+                           use_graph=not pipelined)
             if self._steps:
                 st.opt = next(iter(self._steps.values())).opt           # one optimiser state for all batch sizes
             elif self._resume is not None:
                 st.opt.load_state_dict(self._resume["optimizer"])
+            st.engine = None
+            if pipelined:
+                st.imu_next = torch.empty((B, self.frame_no) + tuple(self._train_dev.shape["imu"][1:]), dtype=torch.float32,
+                                          device=self.device)
+                st.engine = PipelinedStages([st], [self.model_IMU], st.imu_next, use_graph=True)
             self._steps[B] = st
         return st
 
@@ -150,17 +159,29 @@ class _StageTrainer(_Base):
         nlog, scales = 0, []
         if self._train_dev is None:                                     # the training set lives in HBM (51 MB for Sample_data)
             self._train_dev = DeviceArrays(self.train_data, self.device)
-        for idx in batch_indices(len(self.train_data), self.batchsize * self.world, True, self._rng):
-            idx = idx[shard_of(self.rank, self.world)]                  # this rank's shard of the global minibatch
-            if len(idx) == 0:
-                continue
+        todo = [idx[shard_of(self.rank, self.world)]                    # this rank's shard of every global minibatch
+                for idx in batch_indices(len(self.train_data), self.batchsize * self.world, True, self._rng)]
+        todo = [idx for idx in todo if len(idx)]
+        primed = None                                                   # number of the minibatch whose head poses are ready
+        for i, idx in enumerate(todo):
             B = len(idx)
             st = self._step_for(B)
             b = self._train_dev.gather(idx)                             # on-device gather into per-batch-size static buffers
             tgt = b["target"]
             if st.static is None or st.static["x_src"].data_ptr() != b["data"].data_ptr():
                 st.bind(b["data"], b["imu"], b["skl"], tgt, R_gt=b["R_R0R"])
-            st.step()
+            if st.engine is None:
+                st.step()
+            else:
+                if primed != i:                                         # first minibatch, or the size changed: no forward ran ahead
+                    st.imu_next.copy_(b["imu"])
+                    st.engine.prime()
+                if i + 1 < len(todo) and len(todo[i + 1]) == B:         # IMU samples of the next minibatch for the forward that
+                    self._train_dev.gather_field_into("imu", todo[i + 1], st.imu_next)      # runs beside this body
+                    primed = i + 1
+                else:
+                    primed = None
+                st.engine.step()
             # per-minibatch log (L1 sum, mean joint distance): kept on the device, read once per epoch (the reference
             # calls loss.item() every step: Train_Upper.py:183-186)
             if nlog == self._log.shape[0]:

@@ -107,3 +107,31 @@ def test_resume_continues_bit_exactly(tmp_path):
     ta = torch.load(a[0][:-4] + ".train_state.pth", map_location="cpu", weights_only=False)
     tb = torch.load(b[0][:-4] + ".train_state.pth", map_location="cpu", weights_only=False)
     assert torch.equal(ta["optimizer"]["m"], tb["optimizer"]["m"]) and torch.equal(ta["optimizer"]["state"], tb["optimizer"]["state"])
+
+
+def test_training_with_imu_net_pipelined_equals_unpipelined(tmp_path):
+    """`--train --network Upper_Net` with the head pose from a frozen IMU_Net: by default the trainer runs the IMU_Net forward one
+    minibatch ahead of the trainable body (train_step.PipelinedStages); MMEGO_PIPELINE_IMU=0 runs it inside the body.  Two epochs
+    with minibatches of 3, 3 and 2 windows (a size change mid-epoch, where nothing runs ahead): identical checkpoints."""
+    import glob
+    import torch
+    from mmego_amd import nets
+    data = str(tmp_path / "Sample_data")
+    _make_dataset(data, np.random.default_rng(2))
+    torch.manual_seed(1)
+    imu_ck = str(tmp_path / "imu.pth")
+    torch.save(nets.IMUNet(15, 9, 512, 2, True, 0.1).state_dict(), imu_ck)
+    model_dir = os.path.join(ROOT, "Processor", "Train", "model")
+    sd = {}
+    for tag, idx, extra in (("pipelined", "9111", {}), ("plain", "9112", {"MMEGO_PIPELINE_IMU": "0"})):
+        env = dict(os.environ, PYTHONPATH=ROOT, **extra)
+        out = _run(["--train", "--network", "Upper_Net", "--load_IMU_path", imu_ck, "--data_root", data, "--epochs", "2",
+                    "--batch_size", "3", "--device", "cuda:0", "--seed", "3", "--log_dir", idx], env)
+        assert "epoch: 2" in out
+        files = sorted(glob.glob(os.path.join(model_dir, idx, "epoch*_batch3frame*.pth")))      # (saved once, after the last epoch)
+        files = [f for f in files if not f.endswith(".train_state.pth")]
+        assert files, os.listdir(os.path.join(model_dir, idx))
+        sd[tag] = torch.load(files[-1], map_location="cpu")
+    assert sd["pipelined"].keys() == sd["plain"].keys()
+    for k in sd["plain"]:
+        assert torch.equal(sd["pipelined"][k], sd["plain"][k]), k
