@@ -153,29 +153,6 @@ int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H, int first,
  * mmego_lstm_step_bf16_fused.  C % 16 == 0, Bp % 32 == 0. */
 int mmego_cvt_bf16_frag_tm(void* stream, const float* X, long ldx, int Bn, int T, int C, unsigned short* Y, int Bp);
 
-/* ---- fp32 products on the bf16 matrix pipe (x9.hip) -----------------------------------------------------------------------
- * "bf16x9": each fp32 operand is split exactly into three bf16 pieces (a = a_h + a_m + a_l) and a product is the fp32-
- * accumulated sum of the nine exact piece products.  Same accuracy class as v_mfma_f32_32x32x2_f32 (only the order of the
- * fp32 accumulation roundings differs), 16/9 of its peak rate.
- * mmego_x9_split: X fp32 [rows, K] -> split-interleaved [rows][K/8][h,m,l][8] bf16 (6 B per element).  K % 8 == 0. */
-int mmego_x9_split(void* stream, const float* X, long ldx, long rows, int K, unsigned short* Y);
-/* C[M,N] = A[M,K] . W[N,K]^T + bias[N] (relu) with A, W split-interleaved; C row-major and/or Cf tile-major (as in
- * mmego_gemm_bf16).  K % 32 == 0.  Replaces the BiLSTM input projections of Net/IMU_Net.py:58-62 for frozen nets. */
-int mmego_x9_gemm(void* stream, const unsigned short* A, const unsigned short* W, float* C, long ldc, float* Cf,
-                  const float* bias, int M, int N, int K, int relu);
-
-/* One (bi)LSTM timestep with split products (the recurrent half of nn.LSTM for frozen nets, fp32-accurate on the bf16 matrix
- * pipe): as mmego_lstm_step_bf16, with every recurrent operand carrying its three pieces -- fragment-major with a piece index,
- *     element (r, k), piece p at ((((r/32)*(H/16) + k/16)*3 + p)*64 + ((k/8)&1)*32 + r%32)*8 + k%8,
- * W_hh rows reordered [hidden block][gate][32 units].  xpf: tile-major projection (incl. b_ih + b_hh).  h_t is written as fp32
- * (hout, may be NULL), as split-interleaved rows of a [., hss] matrix (hsplit_d points at direction d's first column; may be
- * NULL: the next layer's mmego_x9_gemm operand) and as the next step's hprev (hfrag_d).  H % 128 == 0. */
-int mmego_lstm_step_x9(void* stream, int ndir, int Bn, int H, int first, const unsigned short* hprev0,
-                       const unsigned short* hprev1, const unsigned short* whh0, const unsigned short* whh1,
-                       const float* xpf, long mt0_0, long mt0_1, float* hout0, float* hout1, long hos,
-                       unsigned short* hsplit0, unsigned short* hsplit1, long hss, unsigned short* hfrag0,
-                       unsigned short* hfrag1, float* c0, float* c1);
-
 /* ---- IMU_Net stage-1 training pieces (imu_train.hip): reference Processor/Train/Train_IMU.py:21-34,114-149 -------
  * Pointwise LSTM cell backward of one timestep, both directions: dh = dout + dh_rec (dh_rec may be NULL), reads the
  * stashed gates / cell states, writes the pre-activation gate gradients dgates_d [Bn][4H] (row stride dgs) and updates
@@ -263,9 +240,11 @@ int mmego_inc_i64(void* stream, long long* x, long n);
 /* ---- optimiser (optim.hip) -------------------------------------------------------------------------
  * torch.optim.Adam step (coupled L2 weight decay) over one flat buffer; state = 3 doubles on the device
  * {step, lr/(1-b1^t), sqrt(1-b2^t)}, advanced by the call itself so a captured graph replays correctly
- * (Train_Upper.py:60,182; Train_IMU.py:71-72). */
+ * (Train_Upper.py:60,182; Train_IMU.py:71-72).  skip: HOST array of nskip (<= 4) [begin, end) element ranges (multiples of 4) that
+ * the update leaves untouched -- parameters that never receive a gradient (torch.optim.Adam skips grad=None: IMU_Net.fc3,
+ * Net/IMU_Net.py:55, which would otherwise decay under Train_IMU's weight_decay).  NULL / 0: update everything. */
 int mmego_adam_step(void* stream, float* p, const float* g, float* m, float* v, long n, double* state, double lr,
-                    double beta1, double beta2, double eps, double weight_decay);
+                    double beta1, double beta2, double eps, double weight_decay, const long* skip, int nskip);
 /* Inverted dropout with a device-side seed counter (nn.LSTM(dropout=0.1) inter-layer dropout). */
 int mmego_dropout(void* stream, const float* X, float* Y, float* mask, long n, float p, unsigned long long* seed_ctr);
 

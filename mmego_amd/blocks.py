@@ -98,7 +98,8 @@ def mlp3_backward(ar, key, mod, x, y3, dy3, G, need_dx):
         dz = ar.get("%s.dz%d" % (key, i), (rows, C))
         ops.bn_backward(dy, y, z, st, G(bn.weight), G(bn.bias), dz)
         inp = x if i == 1 else ar.get("%s.y%d" % (key, i - 1), (rows, layers[i - 2][0].weight.shape[0]))
-        ops.on_side(lambda: (ops.grad_weight(dz, inp, G(conv.weight)), ops.colsum(dz, G(conv.bias))))
+        ops.grad_weight(dz, inp, G(conv.weight))
+        ops.colsum(dz, G(conv.bias))
         if i > 1 or need_dx:
             dprev = ar.get("%s.dy%d" % (key, i - 1), (rows, inp.shape[1]))
             ops.grad_input(dz, conv.weight, dprev)
@@ -111,11 +112,9 @@ def mlp3_backward(ar, key, mod, x, y3, dy3, G, need_dx):
 # ---------------------------------------------------------------------------------------------------
 def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False):
     """Gradients of y = x W^T + b: writes G(W), G(b); fills dx if given."""
-    def wgrad():
-        ops.grad_weight(dy, x, G(lin.weight))
-        if lin.bias is not None:
-            ops.colsum(dy, G(lin.bias))
-    ops.on_side(wgrad)
+    ops.grad_weight(dy, x, G(lin.weight))
+    if lin.bias is not None:
+        ops.colsum(dy, G(lin.bias))
     if dx is not None:
         ops.grad_input(dy, lin.weight, dx, accumulate=accumulate_dx)
     return dx
@@ -171,18 +170,16 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
         gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
         cst = ar.get("%s.c%d" % (key, l), (2, T, B, 64))
         hprev = ar.get("%s.hp%d" % (key, l), (2, B * T, 64))
-        dg = ar.get("%s.dg%d" % (key, l), (B * T, 512))        # per layer: the side stream may still be reading it
+        dg = ar.get("%s.dg%d" % (key, l), (B * T, 512))
         c00 = c0[2 * l] if c0 is not None else None
         c01 = c0[2 * l + 1] if c0 is not None else None
         hip.call("lstm64_backward", B, T, d_cur, d_cur.stride(0), gates[0], gates[1], cst[0], cst[1], c00, c01,
                  lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1), dg, dg[:, 256:], 512)
-        def wgrad(l=l, dg=dg, inp=inp, hprev=hprev):
-            for d in range(2):
-                dgd = dg[:, d * 256:(d + 1) * 256]
-                ops.grad_weight(dgd, inp, G(lstm.w("weight_ih", l, d)))
-                ops.grad_weight(dgd, hprev[d], G(lstm.w("weight_hh", l, d)))
-                ops.colsum(dgd, G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
-        ops.on_side(wgrad)
+        for d in range(2):
+            dgd = dg[:, d * 256:(d + 1) * 256]
+            ops.grad_weight(dgd, inp, G(lstm.w("weight_ih", l, d)))
+            ops.grad_weight(dgd, hprev[d], G(lstm.w("weight_hh", l, d)))
+            ops.colsum(dgd, G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
         if l > 0 or need_dx:
             dinp = ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))
             ops.grad_input(dg[:, :256], lstm.w("weight_ih", l, 0), dinp)
@@ -205,7 +202,8 @@ def attn_pool_backward(ar, key, X, lin, attn, dvec, G_, P, C, dX, G):
     pdw = ar.get("%s.pdw" % key, (G_, C))
     pdb = ar.get("%s.pdb" % key, (G_, 1))
     hip.call("attn_pool_backward", X, lin.weight, attn, dvec, G_, P, C, dX, pdw, pdb)
-    ops.on_side(lambda: (ops.colsum(pdw, G(lin.weight).view(-1)), ops.colsum(pdb, G(lin.bias))))
+    ops.colsum(pdw, G(lin.weight).view(-1))
+    ops.colsum(pdb, G(lin.bias))
 
 
 # ---------------------------------------------------------------------------------------------------

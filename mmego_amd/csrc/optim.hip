@@ -4,6 +4,12 @@
 // grid-stride over <= 2048 workgroups.
 #include "common.h"
 
+// Ranges of the flat buffer (in float4 units) that the update leaves untouched: parameters that never receive a gradient.
+// torch.optim.Adam skips a parameter whose .grad is None (IMU_Net.fc3, never used in forward: Net/IMU_Net.py:55), so with
+// weight decay > 0 those tensors must not decay here either.
+#define ADAM_MAX_SKIP 4
+struct AdamSkip { long lo[ADAM_MAX_SKIP], hi[ADAM_MAX_SKIP]; int n; };
+
 // state[0] = step count (as double), state[1] = step_size = lr / (1 - b1^t), state[2] = sqrt(1 - b2^t)
 // Kept in device memory so that a captured HIP graph replays with the right bias corrections.
 __global__ void adam_tick_kernel(double* state, double lr, double beta1, double beta2) {
@@ -18,7 +24,7 @@ __global__ void adam_tick_kernel(double* state, double lr, double beta1, double 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n4,
                                                    const double* __restrict__ state, float beta2, float omb1,
-                                                   float omb2, float eps, float weight_decay) {
+                                                   float omb2, float eps, float weight_decay, AdamSkip skip) {
   const float step_size = (float)state[1];
   const float bc2_sqrt = (float)state[2];
   float4* p4 = reinterpret_cast<float4*>(p);
@@ -26,6 +32,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   float4* m4 = reinterpret_cast<float4*>(m);
   float4* v4 = reinterpret_cast<float4*>(v);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    bool skipped = false;
+#pragma unroll
+    for (int r = 0; r < ADAM_MAX_SKIP; ++r) skipped |= (r < skip.n && i >= skip.lo[r] && i < skip.hi[r]);
+    if (skipped) continue;                     // a tensor that never receives a gradient (torch.optim.Adam skips grad=None)
     float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
     float* pa = reinterpret_cast<float*>(&pp);
     float* ga = reinterpret_cast<float*>(&gg);
@@ -75,14 +85,27 @@ static inline int ew_blocks(long total) {
 }
 
 extern "C" int mmego_adam_step(void* stream, float* p, const float* g, float* m, float* v, long n, double* state,
-                               double lr, double beta1, double beta2, double eps, double weight_decay) {
+                               double lr, double beta1, double beta2, double eps, double weight_decay, const long* skip,
+                               int nskip) {
   MMEGO_REQUIRE(p && g && m && v && state && n > 0 && (n % 4) == 0);
+  MMEGO_REQUIRE(nskip >= 0 && nskip <= ADAM_MAX_SKIP && (nskip == 0 || skip));
+  AdamSkip sk;
+  sk.n = nskip;
+  for (int r = 0; r < ADAM_MAX_SKIP; ++r) {
+    sk.lo[r] = sk.hi[r] = 0;
+    if (r < nskip) {
+      MMEGO_REQUIRE(skip[2 * r] >= 0 && skip[2 * r] <= skip[2 * r + 1] && skip[2 * r + 1] <= n && (skip[2 * r] % 4) == 0 &&
+                    (skip[2 * r + 1] % 4) == 0);
+      sk.lo[r] = skip[2 * r] / 4;
+      sk.hi[r] = skip[2 * r + 1] / 4;
+    }
+  }
   MMEGO_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, state, lr, beta1, beta2);
   MMEGO_LAUNCH_CHECK();
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, p, g, m, v, n / 4, state, (float)beta2,
-                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay);
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, sk);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

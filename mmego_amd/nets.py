@@ -315,15 +315,19 @@ class LowerNet(_NetBase):
         self.keyEncoder = KeyEncoder(hidden_dim)
         self.fusion = FusionModule(hidden_dim)
 
-    def forward(self, upper_l, x, h0_p, c0_p, h0_k, c0_k, initial_body, R, t):
+    def forward(self, upper_l, x, h0_p, c0_p, h0_k, c0_k, initial_body, R, t, pin_select_idx=None):
+        """``pin_select_idx`` [B*T, 64] int64 (tests only; not in the reference's signature): use these point indices instead of
+        the kernel's own top-64-by-x selection.  torch.sort in the reference is unstable, so where equal x keys straddle the
+        cut its choice depends on the torch build; replaying the recorded choice lets the HIP path be compared with the
+        reference's outputs (goldens G5 / G9) at the 1e-3 cm bar instead of through the oracle alone."""
         _require_gpu(x, "LowerNet")
-        args = (upper_l, x, initial_body, R, t)
+        args = (upper_l, x, initial_body, R, t, pin_select_idx)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             self.flat()
             return _Bridge.apply(self, 1, args, *self._flat.params)
         return self._forward_impl(*args, stash=False)
 
-    def _forward_impl(self, upper_l, x, body, R, t, stash=True):
+    def _forward_impl(self, upper_l, x, body, R, t, pin_select_idx=None, stash=True):
         self.flat()
         training = self.training
         ar = self.arena("train" if stash else "eval")
@@ -340,7 +344,15 @@ class LowerNet(_NetBase):
         ops.transform2h_(up.view(F, V, 3), R, t)
         sel = ar.get("sel", (F * LOWER_POINTS, Cx))
         idx = ar.get("sel_idx", (F, LOWER_POINTS), dtype=torch.int64)
-        hip.call("topk_rows", x, F, N, Cx, LOWER_POINTS, sel, idx)
+        if pin_select_idx is None:
+            hip.call("topk_rows", x, F, N, Cx, LOWER_POINTS, sel, idx)
+        else:                                                         # replay a recorded selection (see forward)
+            pin = pin_select_idx.to(device=dev, dtype=torch.int64).reshape(F, LOWER_POINTS)
+            if int(pin.min()) < 0 or int(pin.max()) >= N:
+                raise ValueError("pin_select_idx out of range")
+            idx.copy_(pin)
+            flat_idx = (pin + torch.arange(F, device=dev, dtype=torch.int64).view(F, 1) * N).reshape(-1).contiguous()
+            ops.gather_rows(x.view(F * N, Cx), flat_idx, sel)
         self.last_select_idx = idx
         prow = F * LOWER_POINTS
         p_vec = ar.get("p_vec", (prow, 64))
@@ -494,10 +506,9 @@ class LowerNet(_NetBase):
             Aeff = ar.get(key + ".A", (K, V, V))
             dA = ar.get(key + ".dA", (K, V, V))
             dAp = ar.get(key + ".dAp", (hip.lib().mmego_graph_dA_nblk(F), K * V * V))
-            ops.on_side(lambda z=z, dymix=dymix, dA=dA, dAp=dAp, i=i, cout=cout, K=K: (
-                hip.call("graph_dA", z, dymix, F, V, K, cout, dAp),
-                ops.colsum(dAp, dA.view(-1)),
-                hip.call("mul", dA, gcn.A, G(gcn.edge_importance[i]), dA.numel())))
+            hip.call("graph_dA", z, dymix, F, V, K, cout, dAp)
+            ops.colsum(dAp, dA.view(-1))
+            hip.call("mul", dA, gcn.A, G(gcn.edge_importance[i]), dA.numel())
             dz = ar.get(key + ".dz", (rows, K * cout))
             dz3, dy3 = dz.view(F, V, K * cout), dymix.view(F, V, cout)
             for k in range(K):                                   # dz_k[v,c] = sum_w A[k,v,w] dy[w,c]
@@ -534,6 +545,11 @@ class IMUNet(_NetBase):
         # "fp32" (default, the parity path) or "bf16": eval-mode BiLSTM products with bf16 operands and fp32 accumulation
         # (BASELINE config 5); everything else -- gates, cell state, pooling, heads -- stays fp32 in both modes.
         self.precision = os.environ.get("MMEGO_IMU_PRECISION", "fp32")
+
+    def never_trained(self):
+        """Q7: fc3 is in the state_dict but not in forward, so its .grad stays None in the reference and torch's Adam never
+        touches it (params.FusedAdam leaves these ranges alone, weight decay included)."""
+        return (self.fc3.weight, self.fc3.bias)
 
     def train(self, mode=True):
         if mode:                                   # weights may change: drop the bf16 copies of the LSTM weights

@@ -56,45 +56,6 @@ class Arena:
 
 _scratch = {}
 _retired = []
-_side = {"streams": {}, "stack": [], "enabled": _os.environ.get("MMEGO_WGRAD_OVERLAP", "0") != "0"}
-
-
-class wgrad_overlap:
-    """OFF by default (MMEGO_WGRAD_OVERLAP=1 enables it): measured under HIP-graph replay it costs time (fork/join edges around
-    ~90 tiny kernels) instead of saving it.
-    Run weight-gradient work (dW = dY^T X, bias sums) on a second HIP stream while the main stream continues with
-    the input-gradient chain.  Weight gradients are leaves of the backward graph: nothing but the optimiser reads
-    them, so they only have to be finished at the join.  Works eagerly and under HIP-graph capture (fork/join become
-    graph edges).  Every launching stream gets its own side stream (two concurrent stage branches do not share one)."""
-
-    def __enter__(self):
-        if not _side["enabled"]:
-            return self
-        cur = torch.cuda.current_stream()
-        side = _side["streams"].get(cur.cuda_stream)
-        if side is None:
-            side = _side["streams"][cur.cuda_stream] = torch.cuda.Stream()
-        side.wait_stream(cur)
-        _side["stack"].append((cur, side))
-        return self
-
-    def __exit__(self, *exc):
-        if not _side["enabled"]:
-            return False
-        cur, side = _side["stack"].pop()
-        cur.wait_stream(side)
-        return False
-
-
-def on_side(fn):
-    """Run ``fn`` (kernel launches) on the weight-gradient stream, ordered after everything enqueued so far."""
-    if not _side["stack"]:
-        return fn()
-    cur, side = _side["stack"][-1]
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        return fn()
-
 
 def scratch(device, n):
     """Grow-only fp32 scratch per (device, stream) (split-K slabs, reduction partials).  Stream-ordered reuse is safe."""

@@ -62,6 +62,20 @@ class FlatParams:
     def grad(self, p):
         return self._gviews[id(p)]
 
+    def rebind_grad(self, buf):
+        """Move the flat gradient buffer into ``buf`` (1-D fp32, same length, 16-byte aligned): several nets' gradients can
+        then live back to back in ONE buffer and be summed over the ranks by ONE collective (train_step.GradBucket).  Must
+        happen before anything captures the old addresses (HIP graphs)."""
+        self.ensure()
+        if buf.numel() != self.flat_g.numel() or buf.dtype != torch.float32 or buf.device != self.flat_g.device or buf.data_ptr() % 16:
+            raise ValueError("rebind_grad: need an aligned fp32 buffer of %d elements on %s" % (self.flat_g.numel(), self.flat_g.device))
+        buf.copy_(self.flat_g)
+        self.flat_g = buf
+        for p, off in zip(self.params, self.offsets):
+            self._gviews[id(p)] = buf[off:off + p.numel()].view(p.shape)
+            if p.grad is not None:
+                p.grad = self._gviews[id(p)]
+
     def bump_bn_counters(self):
         if self._counters is not None:
             hip.call("inc_i64", self._counters, self._counters.numel())
@@ -80,6 +94,25 @@ class FusedAdam:
         self.flat = flat
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.m = self.v = self.state = None
+        self._skip = None
+
+    def _skip_ranges(self, f):
+        """Element ranges of parameters that never receive a gradient (`module.never_trained()`, e.g. IMU_Net.fc3):
+        torch.optim.Adam leaves a parameter with grad=None alone -- no moment update, no weight decay."""
+        if self._skip is None:
+            dead = {id(p) for p in getattr(f.module, "never_trained", lambda: ())()}
+            spans = []
+            for p, off in zip(f.params, f.offsets):
+                if id(p) in dead:
+                    end = off + (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+                    if spans and spans[-1][1] == off:
+                        spans[-1][1] = end
+                    else:
+                        spans.append([off, end])
+            if len(spans) > 4:
+                raise ValueError("FusedAdam supports at most 4 disjoint never-trained parameter ranges")
+            self._skip = torch.tensor([v for sp in spans for v in sp], dtype=torch.int64) if spans else False
+        return self._skip
 
     def _ensure(self):
         f = self.flat.ensure()
@@ -91,8 +124,10 @@ class FusedAdam:
 
     def step(self):
         f = self._ensure()
+        skip = self._skip_ranges(f)
         hip.call("adam_step", f.flat_p, f.flat_g, self.m, self.v, f.flat_p.numel(), self.state, float(self.lr),
-                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay))
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                 skip if skip is not False else None, skip.numel() // 2 if skip is not False else 0)
 
     def zero_grad(self):
         pass  # every backward overwrites the flat gradient buffer

@@ -18,11 +18,12 @@ from . import hip, ops
 from .config import Config, ConfigDemo
 from .data import DeviceArrays, PosePC, batch_indices, batches
 from .nets import IMUNet, LowerNet, UpperNet
-from .train_step import PipelinedStages, StageStep, shard_of
+from .train_step import PipelinedStages, StageStep, broadcast_flag, empty_step, shard_of, sync_replicas
 from .utils import EarlyStopping
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_TRAIN_DIR = os.path.join(os.path.dirname(_HERE), "Processor", "Train")
+# where report/, model/, lossAndacc/ go: the reference's Processor/Train (Train_Upper.py:22-50) unless MMEGO_TRAIN_DIR says otherwise
+_TRAIN_DIR = os.environ.get("MMEGO_TRAIN_DIR") or os.path.join(os.path.dirname(_HERE), "Processor", "Train")
 
 
 def _dev_tensor(a, device):
@@ -42,11 +43,22 @@ class _Base:
         self.Idx = cfg.Idx
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        self.pg = torch.distributed.group.WORLD if self.world > 1 else None
         if make_dirs and self.rank == 0:
             for sub in ("report", "model", "lossAndacc"):
                 path = os.path.join(_TRAIN_DIR, sub, str(self.Idx))
                 os.makedirs(path, exist_ok=True)
                 print("%s saved in %s" % ({"report": "report", "model": "model", "lossAndacc": "Loss and accuracy"}[sub], path))
+
+    def _dp_start(self, model):
+        """Data parallel: every replica starts from rank 0's weights and buffers (the nets are built from each rank's own
+        torch RNG unless --seed is given), and the dropout streams of the ranks are decorrelated (SURVEY 8-e ii)."""
+        if self.world > 1:
+            sync_replicas(model, self.pg)
+            model.seed_counter().bitwise_xor_((self.rank * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF)
+
+    def _log_mode(self):
+        return "a" if getattr(self.cfg, "resume_path", None) else "w"     # --resume continues the logs instead of truncating them
 
     def _load_imu(self):
         imu = IMUNet(15, 6 + 3, 512, 2, True, 0.1).to(self.device).eval()
@@ -117,16 +129,17 @@ class _StageTrainer(_Base):
         self.train_data = PosePC(batch_length=self.frame_no)
         self.test_data = PosePC(train=False, batch_length=self.frame_no)
         rep = os.path.join(_TRAIN_DIR, "report", str(self.Idx))
-        self.lossfile = open(os.path.join(rep, "log-loss.txt"), "w") if self.rank == 0 else None
-        self.evalfile = open(os.path.join(rep, "log-eval.txt"), "w") if self.rank == 0 else None
+        self.lossfile = open(os.path.join(rep, "log-loss.txt"), self._log_mode()) if self.rank == 0 else None
+        self.evalfile = open(os.path.join(rep, "log-eval.txt"), self._log_mode()) if self.rank == 0 else None
         self._steps = {}
         self._rng = np.random.RandomState(1234)
         self.start_epoch, self._resume = 0, None
         self._train_dev = None
         self._log = None
+        self._opt_shared = None
 
     def _optimizer(self):
-        return next(iter(self._steps.values())).opt if self._steps else None
+        return self._opt_shared
 
     def _step_for(self, B):
         """One StageStep (static buffers, optional HIP graph) per minibatch size.  With a frozen IMU_Net in the loop its forward
@@ -134,15 +147,17 @@ class _StageTrainer(_Base):
         IMU_Net forward of minibatch i+1 overlaps the latency-bound body of minibatch i); MMEGO_PIPELINE_IMU=0 turns that off."""
         st = self._steps.get(B)
         if st is None:
-            pg = torch.distributed.group.WORLD if self.world > 1 else None
+            pg = self.pg
             pipelined = self.model_IMU is not None and os.environ.get("MMEGO_PIPELINE_IMU", "1") != "0"
             st = StageStep(self.stage, self.model, None if pipelined else self.model_IMU,
                            upper_frozen=getattr(self, "Upper_net", None), lr=self.learning_rate, process_group=pg,
                            use_graph=not pipelined)
-            if self._steps:
-                st.opt = next(iter(self._steps.values())).opt           # one optimiser state for all batch sizes
-            elif self._resume is not None:
-                st.opt.load_state_dict(self._resume["optimizer"])
+            if self._opt_shared is not None:
+                st.opt = self._opt_shared                               # one optimiser state for all batch sizes
+            else:
+                self._opt_shared = st.opt
+                if self._resume is not None:
+                    st.opt.load_state_dict(self._resume["optimizer"])
             st.engine = None
             if pipelined:
                 st.imu_next = torch.empty((B, self.frame_no) + tuple(self._train_dev.shape["imu"][1:]), dtype=torch.float32,
@@ -161,10 +176,18 @@ class _StageTrainer(_Base):
             self._train_dev = DeviceArrays(self.train_data, self.device)
         todo = [idx[shard_of(self.rank, self.world)]                    # this rank's shard of every global minibatch
                 for idx in batch_indices(len(self.train_data), self.batchsize * self.world, True, self._rng)]
-        todo = [idx for idx in todo if len(idx)]
         primed = None                                                   # number of the minibatch whose head poses are ready
         for i, idx in enumerate(todo):
             B = len(idx)
+            if B == 0:              # short last global minibatch, nothing for this rank: zero gradient, same collective + update
+                if self._opt_shared is None:
+                    from .params import FusedAdam
+                    self._opt_shared = FusedAdam(self.model.flat(), lr=self.learning_rate)
+                    if self._resume is not None:
+                        self._opt_shared.load_state_dict(self._resume["optimizer"])
+                empty_step(self.model, self._opt_shared, self.pg)
+                primed = None
+                continue
             st = self._step_for(B)
             b = self._train_dev.gather(idx)                             # on-device gather into per-batch-size static buffers
             tgt = b["target"]
@@ -205,6 +228,7 @@ class _StageTrainer(_Base):
         for epoch in range(self.start_epoch, self.num_epochs):
             print("epoch: {}".format(epoch + 1))
             self.train_once()
+            sync_replicas(self.model, self.pg, params=False)       # BatchNorm running statistics: rank 0's, on every rank
             out = self.eval_model()
             eval_loss, eval_loss_l, eval_accu, second, accu_ll, angle_ll = out
             if self.rank == 0:
@@ -212,7 +236,9 @@ class _StageTrainer(_Base):
                 self.lossfile.write(str(eval_loss_l) + "\n")
                 self.lossfile.flush()
                 extra_print(epoch, out)
-            stop = early(eval_loss)
+            # every rank evaluates its own copy of the test split (the reference's unseeded padding makes them differ), so
+            # the ranks could disagree on when to stop and leave each other hanging in the next all-reduce: rank 0 decides
+            stop = broadcast_flag(early(eval_loss), self.device, self.pg)
             # (the reference saves before the evaluation pass; saving after it keeps the RNG / early-stopping state in the
             #  checkpoint consistent with "epoch finished", which is what --resume continues from)
             if (epoch + 1) % self.save_slot == 0 or epoch + 1 == self.num_epochs or stop:
@@ -233,6 +259,7 @@ class UpperTrainer(_StageTrainer):
         self.model = UpperNet().to(self.device)
         if self.cfg.Upper_pretrained:
             self.model.load(self.cfg.model_upper_path)
+        self._dp_start(self.model)
 
     def train_upper(self):
         def report(epoch, out):
@@ -287,6 +314,7 @@ class LowerTrainer(_StageTrainer):
             self.model.load(self.cfg.model_lower_path)
         self.Upper_net = UpperNet().to(self.device).eval()
         self.Upper_net.load(self.cfg.model_upper_path)
+        self._dp_start(self.model)
 
     def train_lower(self):
         def report(epoch, out):
@@ -372,11 +400,12 @@ class ImuTrainer(_Base):
         if cfg.IMU_pretrained:
             self.model_IMU.load(cfg.model_IMU_path)
         from .params import FusedAdam
+        self._dp_start(self.model_IMU)
         self.optimizer_IMU = FusedAdam(self.model_IMU.flat(), lr=self.learning_rate, weight_decay=0.001)
         self.train_data = PosePC(batch_length=self.frame_no)
         self.test_data = PosePC(train=False, batch_length=self.frame_no)
         rep = os.path.join(_TRAIN_DIR, "report", str(self.Idx))
-        self.lossfile = open(os.path.join(rep, "log-loss.txt"), "w") if self.rank == 0 else None
+        self.lossfile = open(os.path.join(rep, "log-loss.txt"), self._log_mode()) if self.rank == 0 else None
         self._rng = np.random.RandomState(1234)
         self._loss = torch.zeros(1, device=self.device)
         self.start_epoch, self._resume = 0, None
@@ -394,12 +423,13 @@ class ImuTrainer(_Base):
         from .train_step import ImuStep
         self.model_IMU.train()
         losses = []
-        pg = torch.distributed.group.WORLD if self.world > 1 else None
+        pg = self.pg
         if self._train_dev is None:
             self._train_dev = DeviceArrays(self.train_data, self.device)
         for idx in batch_indices(len(self.train_data), self.batchsize * self.world, True, self._rng):
             idx = idx[shard_of(self.rank, self.world)]
-            if len(idx) == 0:
+            if len(idx) == 0:       # nothing for this rank in a short last global minibatch: zero gradient, same update
+                empty_step(self.model_IMU, self.optimizer_IMU, pg)
                 continue
             b = self._train_dev.gather(idx)
             B, T = b["imu"].shape[0], b["imu"].shape[1]
@@ -447,7 +477,7 @@ class ImuTrainer(_Base):
                 self.lossfile.flush()
             print("Train_loss: {}".format(train_loss))
             print("Eval_loss: {}  Eval_loss_l (angle, H_pos): {}".format(eval_loss, eval_loss_l))
-            stop = early(eval_loss)
+            stop = broadcast_flag(early(eval_loss), self.device, self.pg)       # rank 0 decides for everybody
             if (epoch + 1) % self.save_slot == 0 or epoch + 1 == self.num_epochs or stop:
                 self.save_models(epoch, self.model_IMU, self.optimizer_IMU, early)
             if stop:

@@ -23,9 +23,78 @@ def allreduce_grads(flat, process_group):
         torch.distributed.all_reduce(flat.flat_g, op=torch.distributed.ReduceOp.SUM, group=process_group)
 
 
+class GradBucket:
+    """The flat gradient buffers of several nets back to back in ONE buffer: one all-reduce per step for all of them (the
+    Upper and Lower stage of a U+L step: 1.2 + 2.5 MB -- latency-bound messages, so one collective instead of two is one
+    launch + one ring latency saved per step)."""
+
+    def __init__(self, nets):
+        flats = [n.flat() for n in nets]
+        sizes = [f.flat_g.numel() for f in flats]
+        self.members = [id(f) for f in flats]
+        self.buf = torch.zeros(sum(sizes), dtype=torch.float32, device=flats[0].flat_g.device)
+        off = 0
+        for f, n in zip(flats, sizes):
+            f.rebind_grad(self.buf[off:off + n])
+            f._bucket = self
+            off += n
+
+    @staticmethod
+    def of(nets):
+        """The bucket these nets already share (same nets, same order), else a new one.  Re-bucketing moves the gradient
+        buffers, which would strand HIP graphs captured on the old addresses, so an existing bucket is always reused."""
+        flats = [n.flat() for n in nets]
+        b = getattr(flats[0], "_bucket", None)
+        if b is not None and b.members == [id(f) for f in flats] and all(getattr(f, "_bucket", None) is b for f in flats):
+            return b
+        return GradBucket(nets)
+
+    def allreduce(self, process_group):
+        if process_group is not None and torch.distributed.get_world_size(process_group) > 1:
+            torch.distributed.all_reduce(self.buf, op=torch.distributed.ReduceOp.SUM, group=process_group)
+
+
 def shard_of(rank, world):
     """Slice of a global minibatch owned by ``rank`` (interleaved: balances a short last batch)."""
     return slice(rank, None, world)
+
+
+def sync_replicas(net, process_group, src=0, params=True):
+    """Make every rank's replica of ``net`` identical to rank ``src``'s: ONE broadcast of the flat parameter buffer (when
+    ``params``) and one per registered buffer (BatchNorm running statistics, step counters, graph adjacency).  Called once when a
+    data-parallel trainer starts (the nets are initialised from each rank's own RNG unless --seed is given) and once per epoch
+    for the buffers alone (BatchNorm statistics are per shard, so the running averages drift apart; rank 0's are the ones
+    that get saved and evaluated)."""
+    if process_group is None or torch.distributed.get_world_size(process_group) < 2:
+        return
+    flat = net.flat()
+    if params:
+        torch.distributed.broadcast(flat.flat_p, src=src, group=process_group)
+    seen = set()
+    for b in net.buffers():
+        if b.data_ptr() in seen:
+            continue
+        seen.add(b.data_ptr())
+        torch.distributed.broadcast(b if b.dim() else b.view(1), src=src, group=process_group)
+
+
+def empty_step(net, opt, process_group):
+    """A rank whose shard of a short last global minibatch is empty still takes part in the step: it contributes a zero
+    gradient to the all-reduce and applies the same Adam update as everybody else (otherwise the other ranks would wait
+    for it forever and the replicas would part ways)."""
+    flat = net.flat()
+    ops.fill(flat.flat_g, 0.0)
+    allreduce_grads(flat, process_group)
+    opt.step()
+
+
+def broadcast_flag(value, device, process_group, src=0):
+    """Rank ``src``'s boolean decision (early stopping), agreed on by every rank."""
+    if process_group is None or torch.distributed.get_world_size(process_group) < 2:
+        return bool(value)
+    t = torch.tensor([1.0 if value else 0.0], device=device)
+    torch.distributed.broadcast(t, src=src, group=process_group)
+    return bool(t.item() != 0.0)
 
 
 class StageStep:
@@ -80,8 +149,7 @@ class StageStep:
                 l = self.net._forward_impl(up, s["x"], s["body"], R, t, stash=True)[0]
                 nsel = 8
             hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss2, s["dl"])
-            with ops.wgrad_overlap():
-                self.net._backward_impl(s["dl"])
+            self.net._backward_impl(s["dl"])
         self.last_pred = l
 
     def bind(self, x, imu, body, target, R_gt=None):
@@ -224,8 +292,7 @@ class SharedImuStages:
             self.graph.replay()
         else:
             self._body()
-        for st in self.stages:
-            allreduce_grads(st.net._flat, st.pg)
+        self.pair.allreduce()
         for st in self.stages:
             st.opt.step()
 
@@ -251,6 +318,19 @@ class ConcurrentStages:
         self.graph = None
         self.side = [torch.cuda.Stream() for _ in self.stages[1:]]
         self.chain_imu = int(os.environ.get("MMEGO_CHAIN_IMU", "1"))
+        # data parallel: the stages' gradients share one buffer, so one collective per step serves all of them
+        self.bucket = None
+        pgs = {id(st.pg) for st in self.stages}
+        pg = self.stages[0].pg
+        if len(pgs) == 1 and pg is not None and torch.distributed.get_world_size(pg) > 1 and len(self.stages) > 1:
+            self.bucket = GradBucket.of([st.net for st in self.stages])
+
+    def allreduce(self):
+        if self.bucket is not None:
+            self.bucket.allreduce(self.stages[0].pg)
+        else:
+            for st in self.stages:
+                allreduce_grads(st.net._flat, st.pg)
 
     def _bodies(self):
         """Branch order: the LAST stage (longest tail: the Lower body also runs the frozen Upper_Net) runs its IMU_Net
@@ -260,8 +340,6 @@ class ConcurrentStages:
         branches start together."""
         main = torch.cuda.current_stream()
         stages, streams = self.stages, [main] + self.side
-        wgrad_was, ops._side["enabled"] = ops._side["enabled"], False    # (the opt-in weight-gradient side streams make the
-        #                                                                  multi-branch graph crash at instantiation: off here)
         events = [torch.cuda.Event() for _ in stages]
         for i, st in enumerate(stages):
             st.before_imu = st.after_imu = st.imu_milestone = None
@@ -284,7 +362,6 @@ class ConcurrentStages:
             main.wait_stream(side)
         for st in stages:
             st.before_imu = st.after_imu = st.imu_milestone = None
-        ops._side["enabled"] = wgrad_was
 
     def prepare(self):
         """Warm-up (side-effect free) and graph capture, so that the first step() costs what every step costs."""
@@ -309,8 +386,7 @@ class ConcurrentStages:
             self.graph.replay()
         else:
             self._bodies()
-        for st in self.stages:
-            allreduce_grads(st.net._flat, st.pg)
+        self.allreduce()
         for st in self.stages:
             st.opt.step()
         return [st.loss for st in self.stages]
@@ -391,8 +467,7 @@ class PipelinedStages:
             self.graph.replay()
         else:
             self._body()
-        for st in self.stages:
-            allreduce_grads(st.net._flat, st.pg)
+        self.pair.allreduce()
         for st in self.stages:
             st.opt.step()
         return [st.loss for st in self.stages]

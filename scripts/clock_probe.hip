@@ -82,10 +82,8 @@ int main(int argc, char** argv) {
     report("gemm_tile", getenv("MMEGO_GEMM_NO_PERSIST") ? 1280 : 1536, 2.0 * (K / 64) * 8 * 16 * 64);
     hipFree(A); hipFree(W); hipFree(C); hipFree(bias);
   }
-  {  // recurrent step of rnn_fast: Bn=512, H=512, both directions; the variant is chosen by MMEGO_STEP_WS (read once)
-    const int ws = getenv("MMEGO_STEP_WS") ? atoi(getenv("MMEGO_STEP_WS")) : 1;
+  {  // recurrent step of rnn_fast: Bn=512, H=512, both directions; lstm_step_dma2_kernel
     const int Bn = 512, H = 512, T = 20;
-    const int dbg = getenv("PROBE_STEP_DBG") ? atoi(getenv("PROBE_STEP_DBG")) : 0;   // see lstm_step_ws_kernel
     float* out = dev_random((size_t)Bn * T * 2 * H, 0.5f, 4);
     float* xp = dev_random((size_t)Bn * T * 8 * H, 0.5f, 5);
     float *w0 = dev_random((size_t)4 * H * H, 0.04f, 6), *w1 = dev_random((size_t)4 * H * H, 0.04f, 7);
@@ -97,7 +95,7 @@ int main(int argc, char** argv) {
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
       for (int i = 0; i < 200; ++i) {
         int s = 1 + (i % (T - 2)), t1 = T - 1 - s;
-        mmego_lstm_step(st, 2, Bn, H, dbg << 1, out + (long)(s - 1) * 2 * H, out + (long)(t1 + 1) * 2 * H + H, os, w0, w1, b0, b1,
+        mmego_lstm_step(st, 2, Bn, H, 0, out + (long)(s - 1) * 2 * H, out + (long)(t1 + 1) * 2 * H + H, os, w0, w1, b0, b1,
                         xp + (long)s * 8 * H, xp + (long)t1 * 8 * H + 4 * H, xs, out + (long)s * 2 * H, out + (long)t1 * 2 * H + H, os,
                         c, c + (long)Bn * H, nullptr, nullptr, nullptr, nullptr);
       }
@@ -105,8 +103,8 @@ int main(int argc, char** argv) {
       n += 200;
     }
     double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("lstm_step Bn=512 ws=%d dbg=%d: %ld launches, %.1f us each (stamped build)\n", ws, dbg, n, el / n * 1e6);
-    report(ws ? "lstm_step_ws_kernel" : "lstm_step_kernel", 2 * (H / 32) * (Bn / 64), 8.0 * 4 * 32 * 32);
+    printf("lstm_step Bn=512: %ld launches, %.1f us each (stamped build)\n", n, el / n * 1e6);
+    report("lstm_step_dma2_kernel", 2 * (H / 32) * (Bn / 64), 8.0 * 4 * 32 * 32);
     hipFree(out); hipFree(xp); hipFree(w0); hipFree(w1); hipFree(b0); hipFree(b1); hipFree(c);
   }
   return 0;

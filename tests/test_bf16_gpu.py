@@ -157,3 +157,39 @@ def test_large_batch_fused_and_unfused_forms_agree(monkeypatch):
     err = (outs[True] - outs[False]).abs()
     assert float(err.max()) < 2e-3 and float(err.mean()) < 2e-5, (float(err.max()), float(err.mean()))
     assert float(outs[True].abs().mean()) > 1e-2          # not trivially zero
+
+
+def test_config5_full_size_bf16_forward():
+    """BASELINE config 5 at its FULL size (B = 2048 sequences, T = 16 frames -> 32 768 rows x 20 samples through rnn_fast, the
+    fused projection + recurrence step; 2048 x 16 through rnn_slow): IMUNet.precision = "bf16".  The CPU emulation cannot run
+    this size, so the check is through size-independent properties: (i) every output is finite and R is a rotation;
+    (ii) sequences are independent in eval mode, so the first 4 sequences of the big batch equal the same 4 run alone -- a
+    different kernel family (64 rows: the direct step kernel + tile-major projections), i.e. the same bf16 operand roundings
+    accumulated in another order, hence the mode's stated 2e-3 bound rather than equality; (iii) against the fp32 path on the
+    same inputs the head rotation moves by < 2e-2 (bf16 operands, 2^-9 relative rounding, two BiLSTM stacks)."""
+    from mmego_amd import nets
+    dev = _dev()
+    torch.manual_seed(17)
+    net = nets.IMUNet(15, 9, 512, 2, True, 0.1).to(dev).eval()
+    B, Tn = 2048, 16
+    g = torch.Generator().manual_seed(18)
+    imu = torch.zeros(B, Tn, 20, 15)
+    imu[..., :9] = torch.linalg.qr(torch.randn(B, Tn, 20, 3, 3, generator=g))[0].reshape(B, Tn, 20, 9)
+    imu[..., 9:12] = torch.randn(B, Tn, 20, 3, generator=g)
+    imu[..., 12:] = 0.3 * torch.randn(B, Tn, 20, 3, generator=g)
+    imu = imu.to(dev)
+    with torch.no_grad():
+        net.precision = "bf16"
+        Rb, tb = [v.clone() for v in net(imu)]
+        Rs, ts = [v.clone() for v in net(imu[:4].contiguous())]
+        net.precision = "fp32"
+        R32, t32 = [v.clone() for v in net(imu)]
+    assert Rb.shape == (B, Tn, 3, 3) and tb.shape == (B, Tn, 3)
+    assert bool(torch.isfinite(Rb).all()) and bool(torch.isfinite(tb).all())
+    eye = torch.eye(3, device=dev).expand(B, Tn, 3, 3)
+    assert float((Rb @ Rb.transpose(-1, -2) - eye).abs().max()) < 1e-4, "R is orthonormal (6-D -> rotation head)"
+    assert float((Rb[:4] - Rs).abs().max()) < 2e-3 and float((tb[:4] - ts).abs().max()) < 2e-3, \
+        (float((Rb[:4] - Rs).abs().max()), float((tb[:4] - ts).abs().max()))
+    assert float((Rb - R32).abs().max()) < 2e-2 and float((tb - t32).abs().max()) < 2e-2, \
+        (float((Rb - R32).abs().max()), float((tb - t32).abs().max()))
+    assert float((Rb - R32).abs().mean()) < 2e-3

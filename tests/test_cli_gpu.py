@@ -40,8 +40,9 @@ def _run(args, env):
 def test_main_train_and_infer_on_synthetic_tree(tmp_path):
     data = str(tmp_path / "Sample_data")
     _make_dataset(data, np.random.default_rng(0))
-    env = dict(os.environ, PYTHONPATH=ROOT)
-    model_dir = os.path.join(ROOT, "Processor", "Train", "model")
+    out_dir = str(tmp_path / "train_out")
+    env = dict(os.environ, PYTHONPATH=ROOT, MMEGO_TRAIN_DIR=out_dir)
+    model_dir = os.path.join(out_dir, "model")
     common = ["--data_root", data, "--epochs", "1", "--batch_size", "4", "--device", "cuda:0"]
     out = _run(["--train", "--network", "Upper_Net", "--gt_head_pose", "--log_dir", "9101"] + common, env)
     assert "epoch: 1" in out and "Average Joint Localization Error" in out
@@ -62,7 +63,7 @@ def test_main_train_and_infer_on_synthetic_tree(tmp_path):
     for line in ("Average Joint Localization Error(cm):", "Average UpperBody Joint Localization Error(cm):",
                  "Average LowerBody Joint Localization Error(cm):", "Average Joint Rotation Error", "Per Joint Localization Error(cm):"):
         assert line in out
-    assert os.path.exists(os.path.join(ROOT, "Processor", "Train", "report", "9101", "log-loss.txt"))
+    assert os.path.exists(os.path.join(out_dir, "report", "9101", "log-loss.txt"))
     assert os.path.isdir(model_dir)
     # head pose from IMU_Net instead of the recording, fp32 and with --imu_precision bf16 (opt-in mode): the
     # bf16 run moves the head rotation by ~2e-3, i.e. the average joint error by well under a centimetre
@@ -83,13 +84,11 @@ def test_resume_continues_bit_exactly(tmp_path):
     import torch
     data = str(tmp_path / "Sample_data")
     _make_dataset(data, np.random.default_rng(1))
-    env = dict(os.environ, PYTHONPATH=ROOT)
-    mdir = os.path.join(ROOT, "Processor", "Train", "model")
+    out_dir = str(tmp_path / "train_out")
+    env = dict(os.environ, PYTHONPATH=ROOT, MMEGO_TRAIN_DIR=out_dir)
+    mdir = os.path.join(out_dir, "model")
     base = ["--train", "--network", "Upper_Net", "--gt_head_pose", "--data_root", data, "--batch_size", "4", "--device", "cuda:0",
             "--seed", "5"]
-    for idx in ("9111", "9112", "9113"):
-        for f in glob.glob(os.path.join(mdir, idx, "*")):
-            os.remove(f)
     _run(base + ["--epochs", "2", "--log_dir", "9111"], env)
     _run(base + ["--epochs", "1", "--log_dir", "9112"], env)
     first = glob.glob(os.path.join(mdir, "9112", "epoch0_*lr*.pth"))
@@ -121,10 +120,11 @@ def test_training_with_imu_net_pipelined_equals_unpipelined(tmp_path):
     torch.manual_seed(1)
     imu_ck = str(tmp_path / "imu.pth")
     torch.save(nets.IMUNet(15, 9, 512, 2, True, 0.1).state_dict(), imu_ck)
-    model_dir = os.path.join(ROOT, "Processor", "Train", "model")
+    out_dir = str(tmp_path / "train_out")
+    model_dir = os.path.join(out_dir, "model")
     sd = {}
-    for tag, idx, extra in (("pipelined", "9111", {}), ("plain", "9112", {"MMEGO_PIPELINE_IMU": "0"})):
-        env = dict(os.environ, PYTHONPATH=ROOT, **extra)
+    for tag, idx, extra in (("pipelined", "9121", {}), ("plain", "9122", {"MMEGO_PIPELINE_IMU": "0"})):
+        env = dict(os.environ, PYTHONPATH=ROOT, MMEGO_TRAIN_DIR=out_dir, **extra)
         out = _run(["--train", "--network", "Upper_Net", "--load_IMU_path", imu_ck, "--data_root", data, "--epochs", "2",
                     "--batch_size", "3", "--device", "cuda:0", "--seed", "3", "--log_dir", idx], env)
         assert "epoch: 2" in out

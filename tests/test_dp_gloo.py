@@ -34,7 +34,29 @@ def _worker(rank, world, port, q):
     ok = all(torch.all(p.grad == 3.0).item() for p in net.parameters())      # 1 + 2: SUM, not mean
     alias = all(p.grad.data_ptr() == flat.grad(p).data_ptr() for p in net.parameters())
     idx = list(range(10))[shard_of(rank, world)]
-    q.put((rank, ok, alias, idx))
+    # replicas built from different seeds agree after sync_replicas (weights AND buffers); rank 0 decides early stopping;
+    # two nets' gradients in one bucket are summed by ONE collective
+    from mmego_amd.train_step import GradBucket, broadcast_flag, sync_replicas
+    torch.manual_seed(100 + rank)
+    a, b = nets.UpperNet(), nets.LowerNet(64)
+    for m in (a, b):
+        for buf in m.buffers():
+            if buf.dtype.is_floating_point:
+                buf.add_(float(rank))
+        sync_replicas(m, dist.group.WORLD)
+    torch.manual_seed(100)
+    a0, b0 = nets.UpperNet(), nets.LowerNet(64)
+    synced = all(torch.equal(v, w) for m, m0 in ((a, a0), (b, b0)) for v, w in zip(m.state_dict().values(), m0.state_dict().values()))
+    bucket = GradBucket([a, b])
+    same_bucket = GradBucket.of([a, b]) is bucket
+    a.flat().flat_g.fill_(float(rank + 1))
+    b.flat().flat_g.fill_(10.0 * (rank + 1))
+    bucket.allreduce(dist.group.WORLD)
+    a.flat().bind_grads(); b.flat().bind_grads()
+    bucket_ok = (all(torch.all(p.grad == 3.0).item() for p in a.parameters()) and all(torch.all(p.grad == 30.0).item() for p in b.parameters())
+                 and a.flat().flat_g.data_ptr() == bucket.buf.data_ptr() and same_bucket)
+    flag = broadcast_flag(rank == 0, torch.device("cpu"), dist.group.WORLD)       # rank 1 says False, rank 0's True wins
+    q.put((rank, ok, alias, idx, synced, bucket_ok, flag))
     dist.destroy_process_group()
 
 
@@ -50,4 +72,7 @@ def test_flat_gradient_allreduce_sum_and_sharding():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] and r[2] for r in res)
+    assert all(r[4] for r in res), "sync_replicas: every rank holds rank 0's parameters and buffers"
+    assert all(r[5] for r in res), "GradBucket: both nets' gradients summed by one collective"
+    assert all(r[6] is True for r in res), "broadcast_flag: rank 0's decision on every rank"
     assert res[0][3] == [0, 2, 4, 6, 8] and res[1][3] == [1, 3, 5, 7, 9]      # disjoint, exhaustive shards

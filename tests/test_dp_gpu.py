@@ -1,0 +1,132 @@
+"""GPU, two ranks on ONE MI355X (gloo between them): the data-parallel U+L step end to end through the real StageStep /
+ConcurrentStages bodies (reference Train_Upper.py:154-182, Train_Lower.py:186-224 per rank).
+
+Each rank owns a shard of the minibatch, builds its nets from its OWN seed (as an unseeded `main.py --train` would), takes rank
+0's weights through train_step.sync_replicas, runs the two stage bodies as one HIP graph, sums the gradients of BOTH stages
+with one all-reduce (GradBucket) and applies Adam.  Checked against a single process that runs the two shards one after the
+other: the all-reduced gradient must equal g(shard 0) + g(shard 1) bit for bit, the parameters after Adam must be bit-equal on
+both ranks and equal to the single-process result, and each rank's BatchNorm running statistics must be its own shard's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(dev):
+    g = golden("g6_train.npz")
+    x, body, target = [torch.tensor(np.asarray(g[k])).to(dev) for k in ("x", "body", "target")]
+    imu = torch.randn(4, 8, 20, 15, generator=torch.Generator().manual_seed(3)).to(dev)
+    return x, imu, body, target
+
+
+def _build(dev, seed):
+    from mmego_amd import nets
+    torch.manual_seed(seed)
+    up, lo = nets.UpperNet().to(dev).train(), nets.LowerNet(64).to(dev).train()
+    torch.manual_seed(50)                                        # frozen nets come from checkpoints: identical everywhere
+    imu_u = nets.IMUNet(15, 9, 64, 2, True, 0.1).to(dev).eval()
+    imu_l = nets.IMUNet(15, 9, 64, 2, True, 0.1).to(dev).eval()
+    imu_l.load_state_dict(imu_u.state_dict())
+    fr = nets.UpperNet().to(dev).eval()
+    return up, lo, imu_u, imu_l, fr
+
+
+def _stages(nets_, shard, pg, use_graph):
+    from mmego_amd.train_step import StageStep
+    up, lo, imu_u, imu_l, fr = nets_
+    x, imu, body, target = shard
+    su = StageStep("upper", up, imu_u, lr=3e-5, process_group=pg, use_graph=use_graph)
+    sl = StageStep("lower", lo, imu_l, upper_frozen=fr, lr=3e-5, process_group=pg, use_graph=use_graph)
+    for st in (su, sl):
+        st.bind(x.clone(), imu, body, target)
+    return su, sl
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mmego_amd.train_step import ConcurrentStages, shard_of, sync_replicas
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(0)
+        pg = dist.group.WORLD
+        nets_ = _build(dev, seed=1000 + rank)                    # DIFFERENT trainable weights per rank before the sync
+        for net in nets_[:2]:
+            sync_replicas(net, pg)
+        sh = shard_of(rank, world)
+        shard = tuple(v[sh].contiguous() for v in _batch(dev))
+        su, sl = _stages(nets_, shard, pg, use_graph=True)
+        both = ConcurrentStages([su, sl], use_graph=True)
+        assert both.bucket is not None, "one gradient bucket for both stages"
+        out = {}
+        for step in range(2):
+            both.step()
+            torch.cuda.synchronize()
+            out["g%d" % step] = [st.net.flat().flat_g.cpu().clone() for st in (su, sl)]
+            out["p%d" % step] = [st.net.flat().flat_p.cpu().clone() for st in (su, sl)]
+        out["buffers"] = [[b.cpu().clone() for b in st.net.buffers()] for st in (su, sl)]
+        out["loss"] = [st.loss.item() for st in (su, sl)]
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_ul_step_equals_sum_of_shard_gradients():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-process reference: rank 0's initial weights (seed 1000), the two shards one after the other, eager, no process group
+    from mmego_amd.train_step import shard_of
+    dev = torch.device("cuda:0")
+    full = _batch(dev)
+    reps = []
+    for r in range(2):
+        nets_ = _build(dev, seed=1000)
+        shard = tuple(v[shard_of(r, 2)].contiguous() for v in full)
+        reps.append(_stages(nets_, shard, None, use_graph=False))
+    for step in range(2):
+        for su, sl in reps:
+            su._body(); sl._body()
+        torch.cuda.synchronize()
+        for k in range(2):                                               # k = 0: Upper stage, 1: Lower stage
+            g0, g1 = reps[0][k].net.flat().flat_g, reps[1][k].net.flat().flat_g
+            gsum = g0 + g1
+            for r in range(2):
+                assert torch.equal(res[r]["g%d" % step][k], gsum.cpu()), ("all-reduced gradient == g0 + g1", step, k, r)
+            for rep in reps:                                             # every replica applies the same summed gradient
+                rep[k].net.flat().flat_g.copy_(gsum)
+                rep[k].opt.step()
+            torch.cuda.synchronize()
+            pref = reps[0][k].net.flat().flat_p.cpu()
+            assert torch.equal(reps[1][k].net.flat().flat_p.cpu(), pref)
+            assert torch.equal(res[0]["p%d" % step][k], res[1]["p%d" % step][k]), ("parameters bit-equal on both ranks", step, k)
+            assert torch.equal(res[0]["p%d" % step][k], pref), ("... and equal to the single-process result", step, k)
+    for r in range(2):                                                   # BatchNorm statistics are per shard (local BN)
+        for k in range(2):
+            for a, b in zip(res[r]["buffers"][k], reps[r][k].net.buffers()):
+                assert torch.equal(a, b.cpu()), ("rank's BatchNorm buffers are its own shard's", r, k)
+            assert res[r]["loss"][k] == reps[r][k].loss.item()
+    assert not torch.equal(res[0]["buffers"][0][0], res[1]["buffers"][0][0]), "the shards really differ"

@@ -75,13 +75,39 @@ def test_train_upper_wlocal(dev):
         out = m(x0.clone(), h0, c0, h0, c0, body, R, t)
         holder.setdefault("oidx", m.module2.last_group_idx.clone())
         return out[0]
-    _compare_training("wlocal", o, h, fwd_o, fwd_h, target[:, :, list(sk.UPPER_MAP)], g, dev, later_grad_tol=2e-2, later_out_atol=1e-3)  # steps 2-3 start from weights that already differ by sign-of-noise Adam updates; the LocalPointNet BN chain over 8-point groups amplifies that (2.4e-3..6e-3 observed run to run)
+    # Steps 2-3 of the free-running comparison start from weights that already differ by sign-of-noise Adam updates, and the
+    # LocalPointNet BatchNorm chain over 8-point groups amplifies that (2.4e-3..6e-3 of the largest gradient observed run to
+    # run): hence the wide later_* bounds HERE.  That this is drift and not a step-2 defect of the anchor-group / LocalPointNet
+    # backward is what test_train_upper_wlocal_from_synced_states shows: the same three steps, each started from the oracle's
+    # parameters and BatchNorm statistics, hold the step-1 bar (2e-4 of the largest gradient, outputs 2e-5).
+    _compare_training("wlocal", o, h, fwd_o, fwd_h, target[:, :, list(sk.UPPER_MAP)], g, dev, later_grad_tol=2e-2, later_out_atol=1e-3)
     assert holder["n"] == 8, "UpperNetwlocal returns the reference's 8-tuple"
     assert torch.equal(holder["idx"], holder["oidx"]), "voxel (group) indices bit-exact vs the oracle"
     with torch.no_grad():
         xh = geo.transform_to_head_(x0.clone(), R, t)[..., :3].contiguous()
         keys = geo.square_distance(geo.anchor_grid().unsqueeze(0).expand(32, -1, -1), xh)
     assert_indices_equal_modulo_ties(holder["idx"], T(g["wlocal.group_idx"]), keys)      # vs the real reference
+
+
+def test_train_upper_wlocal_from_synced_states(dev):
+    """UpperNetwlocal (U10-U12): steps 2 and 3 at the step-1 tolerances when every step starts from the oracle's parameters
+    and BatchNorm buffers, plus the eval-mode forward of the trained net against the oracle."""
+    from mmego_amd.nets_local import UpperNetwlocal
+    g = golden("g6_train.npz")
+    x0, body, R, t, target = [T(g[k]) for k in ("x", "body", "R", "t", "target")]
+    h0, c0 = ot.zeros_state(4)
+    o, h = _train_pair("wlocal", 602, on.UpperNetwlocal, UpperNetwlocal, dev)
+    d = lambda v: v.to(dev)
+    fwd_h = lambda m: m(d(x0.clone()), d(h0), d(c0), d(h0), d(c0), d(body), d(R), d(t))[0]
+    fwd_o = lambda m: m(x0.clone(), h0, c0, h0, c0, body, R, t)[0]
+    _compare_training("wlocal", o, h, fwd_o, fwd_h, target[:, :, list(sk.UPPER_MAP)], g, dev, resync=True)
+    o.eval(); h.eval()
+    with torch.no_grad():
+        out_o = o(x0.clone(), h0, c0, h0, c0, body, R, t)
+        out_h = h(d(x0.clone()), d(h0), d(c0), d(h0), d(c0), d(body), d(R), d(t))
+    assert len(out_h) == len(out_o) == 8
+    for i, (a, b) in enumerate(zip(out_h, out_o)):
+        assert torch.allclose(a.cpu().reshape(b.shape), b, rtol=1e-4, atol=2e-5), ("eval-mode 8-tuple element", i)
 
 
 def test_pose_metric_kernel(dev):
@@ -165,6 +191,53 @@ def test_imu_stage1_training(dev):
     for k, ph in hb.named_parameters():
         go = po[k].grad if po[k].grad is not None else torch.zeros_like(po[k])
         assert (ph.grad.cpu() - go).abs().max().item() < 2e-4 * scale, k
+
+
+def test_imu_stage1_gradients_at_full_size(dev):
+    """Stage-1 backward at the REAL size: IMUNet(15, 9, 512, 2) with 128 and 512 rnn_fast rows -- the
+    dispatch the 8.9 ms/step figure runs on (persistent 128x128 tile products in NN / TN orientation with split-K, the batched
+    K-quartered dh launch, lstm_step_dma2_kernel with gate and cell stashes) -- against the oracle's autograd: every gradient
+    element, 2e-4 of the largest gradient.  Then one Adam step with Train_IMU's weight decay: fc3 (never used in forward, Q7)
+    must stay untouched, as under torch.optim.Adam (its .grad is None there), everything else must match torch's update."""
+    from mmego_amd import nets
+    from mmego_amd.params import FusedAdam
+    torch.manual_seed(31)
+    o = on.IMUNet(15, 9, 512, 2, True, 0).train()
+    hb = nets.IMUNet(15, 9, 512, 2, True, 0)
+    hb.load_state_dict(o.state_dict())
+    hb = hb.to(dev).train()
+    for Bq, Tq in ((16, 8), (64, 8)):
+        gen = torch.Generator().manual_seed(100 + Bq)
+        imu = torch.randn(Bq, Tq, 20, 15, generator=gen)
+        wR, wt = torch.randn(Bq, Tq, 3, 3, generator=gen), torch.randn(Bq, Tq, 3, generator=gen)
+        for p_ in o.parameters():
+            p_.grad = None
+        Ro, to_ = o(imu)
+        ((Ro * wR).sum() + (to_ * wt).sum()).backward()
+        Rh, th = hb(imu.to(dev))
+        ((Rh * wR.to(dev)).sum() + (th * wt.to(dev)).sum()).backward()
+        assert torch.allclose(Rh.detach().cpu(), Ro.detach(), atol=2e-5) and torch.allclose(th.detach().cpu(), to_.detach(), atol=2e-5)
+        po = dict(o.named_parameters())
+        scale = max(p_.grad.abs().max().item() for p_ in po.values() if p_.grad is not None)
+        for k, ph in hb.named_parameters():
+            go = po[k].grad if po[k].grad is not None else torch.zeros_like(po[k])
+            err = (ph.grad.cpu() - go).abs().max().item()
+            assert err < 2e-4 * scale, (Bq, Tq, k, err, scale)
+    # one optimiser step as Train_IMU.py:71-72 configures it (lr 1e-4 is the CLI's; weight_decay 1e-3)
+    before = {k: v.clone() for k, v in o.state_dict().items()}
+    opt_o = torch.optim.Adam(o.parameters(), lr=1e-4, weight_decay=0.001)
+    opt_o.step()
+    FusedAdam(hb.flat(), lr=1e-4, weight_decay=0.001).step()
+    sd_h, sd_o = hb.state_dict(), o.state_dict()
+    for k in ("fc3.weight", "fc3.bias"):
+        assert torch.equal(sd_o[k], before[k]), "torch leaves a grad=None parameter alone"
+        assert torch.equal(sd_h[k].cpu(), before[k]), k + " must not decay: it never receives a gradient"
+    n_bad = n_all = 0
+    for k in sd_o:
+        dlt = (sd_h[k].cpu() - sd_o[k]).abs()
+        assert dlt.max().item() <= 2.1e-4, (k, dlt.max().item())                  # at most a +-lr flip of a ~0 gradient
+        n_bad += int((dlt > 2e-6).sum()); n_all += dlt.numel()
+    assert n_bad < 0.02 * n_all, (n_bad, n_all)
 
 
 def test_fused_stage_step_equals_autograd_path(dev):

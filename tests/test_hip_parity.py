@@ -173,10 +173,31 @@ def test_transform_bit_exact(dev, real16):
     assert torch.equal(p.cpu(), T(g1["mutated"]))
 
 
+def test_transforms_through_utils_surface(dev):
+    """mmego_amd.utils.Transform2H / Transform2R (the drop-in surface of Util/Universal_Util/Utils.py:274-292) against the
+    reference's own outputs (golden G1): the in-place quirk Q1, the returned view, and the head -> world transform."""
+    from mmego_amd import utils
+    g1 = golden("g1_transforms.npz")
+    Rg, tg = T(g1["R"]).to(dev), T(g1["t"]).to(dev)
+    B_, T_, P_ = g1["pts"].shape[:3]
+    pts = T(g1["pts"]).to(dev)
+    out_h = utils.Transform2H(pts, B_, T_, P_, Rg, tg)
+    assert out_h.shape == (B_ * T_, P_, 6) and out_h.data_ptr() == pts.data_ptr(), "Transform2H returns a view of its input"
+    assert torch.equal(out_h.cpu(), T(g1["out_h"])) and torch.equal(pts.cpu(), T(g1["mutated"]))
+    joints = T(g1["joints"]).to(dev)
+    keep = joints.clone()
+    out_r = utils.Transform2R(joints, B_, T_, joints.shape[2], Rg, tg)
+    assert out_r.shape == tuple(g1["out_r"].shape) and torch.equal(joints, keep), "Transform2R returns a new tensor"
+    assert torch.allclose(out_r.cpu(), T(g1["out_r"]), rtol=0, atol=1e-6), (out_r.cpu() - T(g1["out_r"])).abs().max()
+    assert torch.allclose(out_r.cpu(), geo.transform_to_world(T(g1["joints"]), T(g1["R"]), T(g1["t"])), rtol=0, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        utils.Transform2R(T(g1["joints"]), B_, T_, joints.shape[2], T(g1["R"]), T(g1["t"]))      # no CPU fallback
+
+
 def test_eval_forward_pretrained(dev, real16, pretrained):
     ou, ol, hu, hl = pretrained
     g4, g5 = golden("g4_upper_eval.npz"), golden("g5_lower_eval.npz")
-    rows_h, rows_o = [], []
+    rows_h, rows_o, rows_p = [], [], []
     with torch.no_grad():
         for i in range(16):
             x, skl, R, t, tgt = _seq(real16, i)
@@ -197,13 +218,29 @@ def test_eval_forward_pretrained(dev, real16, pretrained):
             assert torch.allclose(lqh.cpu(), lqo, rtol=1e-4, atol=5e-5), (i, (lqh.cpu() - lqo).abs().max())
             rows_h.append(om.batch_errors(lh.cpu(), llh.cpu(), tgt))
             rows_o.append(om.batch_errors(lo_, llo, tgt))
-    sh, so = om.summarize(rows_h), om.summarize(rows_o)
+            # the reference's own (unstable-sort) top-64 choice replayed on the HIP path: Lower_Net vs the REFERENCE's outputs
+            xp_ = xd.clone()
+            hu_x = T(real16["x"][i:i + 1]).clone().to(dev)
+            lh2 = hu(hu_x, h0.to(dev), c0.to(dev), skld, Rd, td)[0]
+            llp, lqp = hl(lh2.clone(), hu_x, None, None, None, None, skld, Rd, td, pin_select_idx=T(real16["ref_sel_idx"][i]))
+            assert torch.equal(hu_x, xp_), "pinned run sees the same doubly transformed points"
+            assert torch.equal(hl.last_select_idx.cpu(), T(real16["ref_sel_idx"][i]))
+            if i < 8:
+                assert torch.allclose(llp.cpu(), T(g5["l_%d" % i]), rtol=1e-4, atol=2e-5), ("pinned l vs reference", i)
+                assert torch.allclose(lqp.cpu(), T(g5["q_%d" % i]), rtol=1e-4, atol=5e-5), ("pinned q vs reference", i)
+            rows_p.append(om.batch_errors(lh.cpu(), llp.cpu(), tgt))
+    sh, so, sp = om.summarize(rows_h), om.summarize(rows_o), om.summarize(rows_p)
     for k in ("all_cm", "upper_cm", "lower_cm"):
         assert abs(sh[k] - so[k]) < 1e-3, (k, sh[k], so[k])          # north star: error equal within 1e-3 cm
     assert np.allclose(sh["per_joint_cm"], so["per_joint_cm"], atol=1e-3)
     g9 = golden("g9_end2end.npz")
     assert abs(sh["upper_cm"] - float(g9["upper_cm"])) < 1e-3                # vs the real reference (no tie dependence)
     assert abs(sh["lower_cm"] - float(g9["lower_cm"])) < 0.05               # reference tie order differs (see oracle tests)
+    # ... and with the reference's tie choices replayed, the HIP path meets the 1e-3 cm bar against the REFERENCE directly
+    for k in ("all_cm", "upper_cm", "lower_cm"):
+        assert abs(sp[k] - float(g9[k])) < 1e-3, (k, sp[k], float(g9[k]))
+    assert np.allclose(sp["per_joint_cm"], g9["per_joint_cm"], atol=1e-3)
+    assert abs(sp["rot_deg"] - float(g9["rot_deg"])) < 1e-2
 
 
 def test_imu_forward(dev):
@@ -242,8 +279,8 @@ def test_imu_forward(dev):
 
 
 def test_lstm_step_kernel_variants(dev):
-    """Every recurrent-step kernel variant (MMEGO_STEP_WS = 3 default / 2 / 1 / 0) gives the same h and c as a plain torch
-    LSTM cell step on 200 rows (ragged last block), including the first step (h = c = 0) and the stashing mode."""
+    """The recurrent-step kernels (LDS-DMA kernel for >= 128 rows, W_hh-streaming kernel below) give the same h and c as a plain
+    torch LSTM cell step in fp64: 200 rows (ragged last block), the first step (h = c = 0), the stashing mode, small batches."""
     import os
     import subprocess
     import sys
@@ -278,9 +315,8 @@ for first in (0, 1):
         assert (cst[d].double() - cn).abs().max().item() < 2e-5 and (gst[d][:, :H].double() - i).abs().max().item() < 2e-5
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for mode in ("3", "2", "1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MMEGO_STEP_WS=mode), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout[-500:], r.stderr[-1500:])
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
     # small batches (rnn_slow: Bn < 128 -> lstm_step_small_kernel), ragged rows, H a multiple of 64 and of 32 only
     for bn, h in (("100", "512"), ("64", "256"), ("37", "96")):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, T_BN=bn, T_H=h), capture_output=True, text=True, timeout=300)
@@ -299,7 +335,10 @@ def _train_pair(tag, seed, octor, hctor, dev):
     return o.train(), h.to(dev).train()
 
 
-def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev, later_grad_tol=2e-4, later_out_atol=2e-5):
+def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev, later_grad_tol=2e-4, later_out_atol=2e-5, resync=False):
+    """Three train steps on both sides.  ``resync``: after every optimiser step the oracle's parameters and BatchNorm buffers
+    are copied into the HIP net, so steps 2 and 3 start from bit-equal states and are held to the step-1 bar -- this separates
+    "the two runs drifted apart by sign-of-noise Adam updates" from "the backward is wrong from step 2 on"."""
     from mmego_amd.params import FusedAdam
     opt_o = torch.optim.Adam(o.parameters(), lr=3e-5)
     opt_h = FusedAdam(h.flat(), lr=3e-5)
@@ -331,6 +370,9 @@ def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev, later_grad_tol=2e
             check_pinned(g, "%s.grad." % tag, grads, rtol=5e-3, atol=5e-3 * scale)     # vs the real reference
         opt_o.step()
         opt_h.step()
+        if resync:
+            h.load_state_dict({k: v.to(dev) for k, v in o.state_dict().items()})
+            continue
         n_bad = n_all = 0
         for k in po:
             if NOISE_GRAD.search(k):
@@ -355,6 +397,25 @@ def test_train_upper(dev):
     d = lambda v: v.to(dev)
     _compare_training("upper", o, h, lambda m: m(x0.clone(), h0, c0, body, R, t)[0],
                       lambda m: m(d(x0.clone()), d(h0), d(c0), d(body), d(R), d(t))[0], target[:, :, list(sk.UPPER_MAP)], g, dev)
+
+
+def test_train_steps_from_synced_states(dev):
+    """Steps 2 and 3 of Upper_Net and Lower_Net training at the STEP-1 tolerances (outputs 2e-5, gradients 2e-4 of the largest
+    gradient), each step starting from the oracle's parameters and BatchNorm statistics."""
+    from mmego_amd import nets
+    g = golden("g6_train.npz")
+    x0, body, R, t, target = [T(g[k]) for k in ("x", "body", "R", "t", "target")]
+    up_l, x_l = T(g["lower.upper_in"]), T(g["lower.x_in"])
+    h0, c0 = ot.zeros_state(4)
+    d = lambda v: v.to(dev)
+    o, h = _train_pair("upper", 601, on.UpperNet, nets.UpperNet, dev)
+    _compare_training("upper", o, h, lambda m: m(x0.clone(), h0, c0, body, R, t)[0],
+                      lambda m: m(d(x0.clone()), d(h0), d(c0), d(body), d(R), d(t))[0], target[:, :, list(sk.UPPER_MAP)], g, dev,
+                      resync=True)
+    o, h = _train_pair("lower", 604, lambda: on.LowerNet(64), lambda: nets.LowerNet(64), dev)
+    _compare_training("lower", o, h, lambda m: m(up_l.clone(), x_l.clone(), h0, c0, h0, c0, body, R, t)[0],
+                      lambda m: m(d(up_l.clone()), d(x_l.clone()), None, None, None, None, d(body), d(R), d(t))[0],
+                      target[:, :, list(sk.LOWER_MAP)], g, dev, resync=True)
 
 
 def test_train_lower(dev):
@@ -384,6 +445,6 @@ def test_fused_adam_matches_torch(dev):
             grad = torch.randn(n) * (10.0 ** (step - 3))
             ref_p.grad = grad.clone()
             opt.step()
-            hip.call("adam_step", p, grad.to(dev), m, v, n, state, 3e-5, 0.9, 0.999, 1e-8, wd)
+            hip.call("adam_step", p, grad.to(dev), m, v, n, state, 3e-5, 0.9, 0.999, 1e-8, wd, None, 0)
             assert torch.allclose(p.cpu(), ref_p.detach(), rtol=0, atol=2e-7), (wd, step)
         assert state[0].item() == 5.0
