@@ -28,7 +28,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense bf16 MFMA peak (same guide)
+PEAK_HBM_GBPS = 8000.0
 B, T, N = 64, 8, 128
+# algorithmic FLOPs per frame of the literal U+L step (IMU_Net forward counted in BOTH bodies, as the reference
+# runs it): 2 x 444.96 (IMU) + 6.45 + 2.15 (Upper f/b + frozen forward) + 27.79 (Lower f/b) = 926.3 MFLOP
+STEP_MFLOP_PER_FRAME = 926.3
 
 
 def synth_batch(seed, device):
@@ -130,13 +135,16 @@ def host_cores():
 
 
 def pmc_traffic(kernel_label):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in
-    separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950); None if no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
-    if not os.path.exists(path):
-        return None
-    pmc = json.load(open(path))
-    return pmc.get(kernel_label.split(" ")[0], {}).get("hbm_bytes_per_launch")
+    """(HBM bytes per launch, source file) of a kernel from the COMMITTED rocprofv3 --pmc passes of this command (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950).  It is read from profiles/, not
+    measured in this run (counters need rocprofv3 around the process): the bench line says so in `traffic_source`."""
+    for name in ("r02_pmc_counters.json", "r01_pmc_counters.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            v = json.load(open(path)).get(kernel_label.split(" ")[0], {}).get("hbm_bytes_per_launch")
+            if v is not None:
+                return v, "profiles/" + name + " (rocprofv3 --pmc passes of `bench.py --trace-only`, committed; not measured in this run)"
+    return None, None
 
 
 def cpu_baseline(steps, warmup, device=None):
@@ -189,17 +197,149 @@ def cpu_baseline(steps, warmup, device=None):
     return out, parity
 
 
+def _synth_points(Bq, Tq, Nq, seed):
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.randn(Bq, Tq, Nq, 3, generator=g) * torch.tensor([0.41, 0.30, 0.38]) + torch.tensor([0.84, 0.05, 0.18])
+    x = torch.zeros(Bq, Tq, Nq, 6)
+    x[..., :3] = xyz
+    x[..., 3] = xyz.norm(dim=-1)
+    x[..., 4] = torch.randn(Bq, Tq, Nq, generator=g) * 0.41
+    x[..., 5] = torch.rand(Bq, Tq, Nq, generator=g) * 36 + 10
+    dead = torch.rand(Bq, Tq, Nq, generator=g) < 0.40
+    dead[:, :, :16] = False
+    x[dead] = 0.0
+    R = torch.linalg.qr(torch.randn(Bq, Tq, 3, 3, generator=g))[0].contiguous()
+    t = torch.randn(Bq, Tq, 3, generator=g) * 0.1 + torch.tensor([0.8, 0.0, 0.9])
+    body = torch.randn(Bq, 20, 3, generator=g) * 0.2
+    imu = torch.randn(Bq, Tq, 20, 15, generator=g)
+    return x, R, t, body, imu
+
+
+def _time_events(fn, n, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def config2_forward(device):
+    """BASELINE config 2: Upper_Net eval forward, synthetic B=64 T=8 N=128, fp32, one GPU.  20 forwards are captured into one
+    HIP graph (the trainers replay graphs too), so the figure holds no host launch cost.  SURVEY 8-d: 2.15 MFLOP and 3 330 B
+    per frame + 1.2 MB of weights per forward => t_roof ~ 7 us per 512-frame batch, BELOW the latency of one dependent kernel
+    launch: this configuration is bound by its chain of dependent launches, and the fractions below say so."""
+    from mmego_amd import nets
+    torch.manual_seed(2)
+    up = nets.UpperNet().to(device).eval()
+    x0, R, t, body, _ = [v.to(device) for v in _synth_points(B, T, N, 22)]
+    h0 = torch.zeros(6, B, 64, device=device)
+    x = torch.empty_like(x0)
+
+    def fwd():
+        with torch.no_grad():
+            x.copy_(x0)                                           # (Upper_Net transforms its input in place, Q1)
+            return up(x, h0, h0, body, R, t)[0]
+    fwd()
+    torch.cuda.synchronize()
+    inner = 20
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(inner):
+            fwd()
+    ms = _time_events(g.replay, 20, 3) / inner
+    flop, byts = 2.15e6 * B * T, 3330.0 * B * T + 1.2e6
+    t_roof_us = max(flop / (PEAK_FP32_MFMA_TFLOPS * 1e12), byts / (PEAK_HBM_GBPS * 1e9)) * 1e6
+    return {"workload": "Upper_Net eval forward, B=64 T=8 N=128, fp32, HIP-graph replay", "ms_per_forward": ms,
+            "frames_per_s": B * T / (ms * 1e-3), "t_roofline_us": t_roof_us, "roofline_frac": t_roof_us / (ms * 1e3),
+            "bound": "dependent-launch latency (t_roofline is below one kernel boundary)"}
+
+
+def config5_forward(device):
+    """BASELINE config 5: B=2048 T=16 N=256, IMU_Net -> Upper_Net -> Lower_Net eval forward with IMU_Net's BiLSTM products in
+    bf16-operand / fp32-accumulate mode (everything else fp32).  Reports ms per forward, frames/s, and for the dominant kernel
+    (the fused projection + recurrence step, lstm_step_bf16_fused_kernel) its MFMA and HBM fractions from live event pairs:
+      flop per launch   = 2 x ndir x Bn x 4H x (K_in + H)            (K_in + 0 on the first timestep)
+      bytes per launch  = ndir x Bn x [2 K_in (x_t bf16) + 2 H (h_t-1 bf16) + 8 H (c read + write) + 2 H (h_t bf16)
+                          + 4 H (h_t fp32, last layer only)] + the weights once (2 x 4H x (K_in + H) x 2 B)."""
+    from mmego_amd import hip, nets
+    Bq, Tq, Nq, H = 2048, 16, 256, 512
+    torch.manual_seed(5)
+    imu_net = nets.IMUNet(15, 9, H, 2, True, 0.1).to(device).eval()
+    imu_net.precision = "bf16"
+    up, lo = nets.UpperNet().to(device).eval(), nets.LowerNet(64).to(device).eval()
+    x0, _, _, body, imu_in = [v.to(device) for v in _synth_points(Bq, Tq, Nq, 55)]
+    h0 = torch.zeros(6, Bq, 64, device=device)
+
+    def fwd():
+        with torch.no_grad():
+            x = x0.clone()
+            R, t = imu_net(imu_in)
+            u = up(x, h0, h0, body, R, t)[0]
+            return lo(u, x, None, None, None, None, body, R, t)[0]
+    ms = _time_events(fwd, 3, 2)
+    out = fwd()
+    finite = bool(torch.isfinite(out).all())
+    rec = []
+    orig = hip.call
+
+    def timed(name, *a):
+        if name == "lstm_step_bf16_fused":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); orig(name, *a); e1.record()
+            rec.append((e0, e1, a))
+        else:
+            orig(name, *a)
+    hip.call = timed
+    try:
+        fwd()
+        torch.cuda.synchronize()
+    finally:
+        hip.call = orig
+    tot_ms = tot_fl = tot_by = 0.0
+    for e0, e1, a in rec:
+        ndir, Bn, Hh, first, kin = a[0], a[1], a[2], a[3], a[9] + a[14]
+        last = a[20] is not None                                  # fp32 output pointer: last layer of a stack only
+        tot_ms += e0.elapsed_time(e1)
+        tot_fl += 2.0 * ndir * Bn * 4 * Hh * (kin + (0 if first else Hh))
+        tot_by += ndir * Bn * (2.0 * kin + (0 if first else 2.0 * Hh) + 8.0 * Hh + 2.0 * Hh + (4.0 * Hh if last else 0.0)) \
+            + ndir * 4.0 * Hh * (kin + Hh) * 2.0
+    k = {}
+    if rec:
+        tf, gbps = tot_fl / (tot_ms * 1e-3) / 1e12, tot_by / (tot_ms * 1e-3) / 1e9
+        k = {"kernel": "lstm_step_bf16_fused_kernel (projection folded into the recurrent step)", "launches_per_forward": len(rec),
+             "avg_launch_us": tot_ms / len(rec) * 1e3, "share_of_forward": tot_ms / ms,
+             "mfma": {"achieved": tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_MFMA_TFLOPS},
+             "hbm": {"achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                     "algorithmic_bytes_per_launch_avg": tot_by / len(rec)}}
+    # algorithmic FLOPs of the forward (SURVEY 8-d per-frame figures: IMU 444.96, Upper 2.15, Lower 9.26 MFLOP at N=128; the
+    # per-point part of Upper/Lower doubles at N=256 and stays < 3 % of the total)
+    fl = (444.96e6 + 2.15e6 + 9.26e6) * Bq * Tq
+    res = {"workload": "IMU_Net -> Upper_Net -> Lower_Net eval forward, B=2048 T=16 N=256, IMU BiLSTM products bf16 operands / "
+                       "fp32 accumulation, everything else fp32", "ms_per_forward": ms, "frames_per_s": Bq * Tq / (ms * 1e-3),
+           "algorithmic_tflops": fl / (ms * 1e-3) / 1e12, "frac_of_bf16_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+           "outputs_finite": finite, "dominant_kernel": k}
+    del imu_net, up, lo, x0, imu_in
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed U+L steps (default: > 1 s of timed region)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying HIP graphs")
     ap.add_argument("--sequential", action="store_true", help="run the Upper and Lower bodies one after the other")
     ap.add_argument("--trace-only", action="store_true", help="warm-up + timed loop only, then exit (clean input for rocprofv3 summaries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-variant", action="store_true", help="skip the extra bf16-IMU figure")
     ap.add_argument("--no-pipelined-variant", action="store_true", help="skip the extra prefetch-pipelined figure")
+    ap.add_argument("--no-config-extras", action="store_true", help="skip the config-2 / config-5 forward figures")
     ap.add_argument("--cpu-steps", type=int, default=5)
     args = ap.parse_args()
 
@@ -426,34 +566,45 @@ def main():
             cands["gemm_tile_persistent_kernel (128x128 tiles; IMU_Net LSTM input projections, both directions per launch: 2 x 10240 x 2048 x {512,1024})"] = g128
         if g64:
             cands["gemm_tile_kernel<64,64> (smaller 64-aligned products)"] = g64
-        # dominant kernel = largest total time.  The eager event pairs around the recurrent steps include a launch gap that the
-        # graph replay does not have, which can put the step kernel a few % ahead of the projection GEMM although the GEMM leads
-        # in the rocprofv3 trace of the real (graph) step: a near tie goes to the GEMM.
+        # dominant kernel = largest total time over the eager replay; no tie rule.  Every candidate is reported with its own
+        # fraction in `roofline_kernels`, so a near tie between the projection GEMM and the recurrent step shows as such.
         totals = {k: sum(m for m, _ in v) for k, v in cands.items()}
         best_k = max(totals, key=totals.get)
-        gk = [k for k in totals if k.startswith("gemm_tile_persistent_kernel")]
-        if gk and totals[gk[0]] >= 0.9 * totals[best_k]:
-            best_k = gk[0]
         best = (best_k, cands[best_k])
         tot_ms = sum(m for m, _ in best[1])
         tot_fl = sum(f for _, f in best[1])
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(best[0])
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(best[0]), "kernel": best[0],
+                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                           "kernel": best[0],
                            "avg_launch_us": tot_ms / len(best[1]) * 1e3, "launches_per_step": len(best[1]) // iters,
                            "flop_per_launch_avg": tot_fl / len(best[1]),
                            "share_of_step": (tot_ms / iters) / (t_u + t_l)}
+        # the WHOLE step against the same roofline: algorithmic FLOPs of the literal U+L step / measured step time / peak
+        step_flop = STEP_MFLOP_PER_FRAME * 1e6 * B * T
+        out["roofline_step"] = {"bound": "mfma", "algorithmic_gflop_per_step": step_flop / 1e9,
+                                "achieved": step_flop / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": step_flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                "frac_sequential": step_flop / ((t_u + t_l) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                "what": "SURVEY 8-d: 926.3 MFLOP/frame (IMU_Net forward in both bodies) x %d frames / ms_per_step / "
+                                        "157.3 TFLOP/s; frac_sequential uses t_upper + t_lower" % (B * T)}
         # The step against the HBM roofline (SURVEY 8-d figures): 129.1 MB of parameter / gradient / optimiser traffic per
         # U+L step + 4 830 B of streaming I/O per frame.  The path is matrix-pipe and latency bound, not HBM bound.
         alg_bytes = 129.1e6 + 4830.0 * B * T
-        out["hbm_roofline"] = {"algorithmic_bytes_per_step": alg_bytes, "peak_GBps": 8000.0,
+        out["hbm_roofline"] = {"algorithmic_bytes_per_step": alg_bytes, "peak_GBps": PEAK_HBM_GBPS,
                                "achieved_GBps": alg_bytes / (out["ms_per_step"] * 1e-3) / 1e9,
                                "frac": alg_bytes / (out["ms_per_step"] * 1e-3) / 8e12}
-        out["kernels"] = {k: {"avg_us": sum(m for m, _ in v) / len(v) * 1e3, "launches_per_step": len(v) // iters,
-                              "tflops": sum(f for _, f in v) / (sum(m for m, _ in v) * 1e-3) / 1e12,
-                              "ms_per_step": sum(m for m, _ in v) / iters} for k, v in cands.items()}
+        out["roofline_kernels"] = {k: {"avg_us": sum(m for m, _ in v) / len(v) * 1e3, "launches_per_step": len(v) // iters,
+                                       "tflops": sum(f for _, f in v) / (sum(m for m, _ in v) * 1e-3) / 1e12,
+                                       "frac": sum(f for _, f in v) / (sum(m for m, _ in v) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                       "ms_per_step": sum(m for m, _ in v) / iters,
+                                       "share_of_step": (sum(m for m, _ in v) / iters) / (t_u + t_l)} for k, v in cands.items()}
         sys.stderr.write("[bench] gpu part done: %.1f frames/s; timing the CPU oracle on %d threads\n" % (out["value"], host_cores()))
         sys.stderr.flush()
+        if world == 1 and not args.no_config_extras:
+            out["config2"] = config2_forward(device)
+            out["config5"] = config5_forward(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_steps, 1, device)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

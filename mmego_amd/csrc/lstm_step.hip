@@ -28,8 +28,10 @@ struct LstmStepP {
   int Bn, H, ndir, first;
 };
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + expf(2.0f * x)); }
+// rcp / v_exp_f32 based activations (as in lstm.hip): a few ulp from the libm forms at a fraction of their instruction count
+// (libm expf is ~15 VALU instructions; the cell update evaluates 40 of them per lane)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 #define CLD 36    // LDS row stride of the c / h output tiles: 32 hidden + 4 pad
 
@@ -49,10 +51,10 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __bui
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-// ---- LDS-DMA variant with a 72 KB footprint: TWO workgroups per CU -----------------------------------------------------
-// Same tile and DMA scheme as lstm_step_dma_kernel, but 32-k chunks (three 24-KB stages) and no xproj / c tiles in LDS:
-// the compute waves fetch their own xproj / c_{t-1} elements straight into registers at kernel start and consume them
-// AFTER the product (gates = h.W^T + xproj + b).  With 72 KB and <= 128 VGPRs two workgroups share a CU.  That matters
+// ---- LDS-DMA step kernel, 72 KB footprint: TWO workgroups per CU -------------------------------------------------------
+// Operands go global -> LDS by LDS-DMA (4 loader waves, counted vmcnt, raw s_barriers), 32-k chunks in a ring of three 24-KB
+// stages; no xproj / c tiles in LDS: the compute waves fetch their own xproj elements straight into the accumulators
+// (gates = xproj + b + h.W^T) and c_{t-1} into registers at kernel start.  With 72 KB and <= 128 VGPRs two workgroups share a CU.  That matters
 // when independent step kernels exist (the two concurrent stage programs each run an IMU_Net forward): while one waits for
 // its first operands, its barriers or its stores, the other owns the matrix pipe -- and kernels of other branches with
 // modest LDS needs can co-reside as well.
@@ -141,32 +143,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int rowbase = (wave & 1) * 32, hb = (wave >> 1) * 16;
   const int fr = lane & 15, fq = lane >> 4;
   const int rmax = p.Bn - 1 - r0;
-  // xproj (+ b_hh) and c_{t-1} of this lane's 8 rows x 4 gates, fetched now, consumed after the product
-  float xg[2][4][4], cprev[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int lrow = min(rowbase + i * 16 + fq * 4 + reg, rmax);
-      const float* xrow = p.xproj[d] + (long)(r0 + lrow) * p.xs + j0 + hb + fr;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) xg[i][g][reg] = xrow[(long)g * H];
-      cprev[i][reg] = nk > 0 ? p.c[d][(long)(r0 + lrow) * H + j0 + hb + fr] : 0.f;
-    }
+  // The accumulators are SEEDED with xproj (+ b_hh) of this lane's 8 rows x 4 gates (gates = xproj + b + h.W^T), so the
+  // projection needs no registers of its own during the product -- they pay for a second fragment set (below).  The loads
+  // land while the loader waves' first operand chunk is in flight.  c_{t-1} is fetched now and consumed after the product.
   float bh[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) bh[g] = p.bhh[d] ? p.bhh[d][g * H + j0 + hb + fr] : 0.f;
-  f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc02 = acc00, acc03 = acc00, acc10 = acc00, acc11 = acc00, acc12 = acc00,
-        acc13 = acc00;
+  f32x4 acc00, acc01, acc02, acc03, acc10, acc11, acc12, acc13;
+  float cprev[2][4];
+#define D2_SEED(A0, A1, A2, A3, i)                                                                          \
+  _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                     \
+    const int lrow = min(rowbase + (i) * 16 + fq * 4 + reg, rmax);                                          \
+    const float* xrow = p.xproj[d] + (long)(r0 + lrow) * p.xs + j0 + hb + fr;                               \
+    A0[reg] = xrow[0] + bh[0];                                                                              \
+    A1[reg] = xrow[(long)H] + bh[1];                                                                        \
+    A2[reg] = xrow[2 * (long)H] + bh[2];                                                                    \
+    A3[reg] = xrow[3 * (long)H] + bh[3];                                                                    \
+    cprev[i][reg] = nk > 0 ? p.c[d][(long)(r0 + lrow) * H + j0 + hb + fr] : 0.f;                            \
+  }
+  D2_SEED(acc00, acc01, acc02, acc03, 0)
+  D2_SEED(acc10, acc11, acc12, acc13, 1)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                          // (1)  (raw barrier: the xproj loads stay in flight)
+  __builtin_amdgcn_s_barrier();                          // (1)  chunk 0 is in LDS
   MMEGO_STAMP_AT(blockIdx.x, 1, tid == 0);
   if (nk > 0) {
     const int key = (fr >> 1) & 7;
     const int sw0 = ((0 | fq) ^ key) << 2, sw1 = ((4 | fq) ^ key) << 2;       // k-block 0 / 1 of a 32-k chunk
     const float* arow = smem + (rowbase + fr) * 32;
     const float* brow = smem + 2048 + (hb + fr) * 32;
-    f32x4 pa0, pa1, pb0, pb1, pb2, pb3;
+    f32x4 pa0, pa1, pb0, pb1, pb2, pb3, qa0, qa1, qb0, qb1, qb2, qb3;
 #define D2_RD(S, so, sw)                                                                                    \
   do {                                                                                                      \
     S##a0 = *reinterpret_cast<const f32x4*>(arow + (so) + (sw));                                            \
@@ -176,29 +181,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     S##b2 = *reinterpret_cast<const f32x4*>(brow + (so) + 64 * 32 + (sw));                                  \
     S##b3 = *reinterpret_cast<const f32x4*>(brow + (so) + 96 * 32 + (sw));                                  \
   } while (0)
-    // One fragment set only (<= 128 VGPRs so that two workgroups fit a CU): the other workgroup on the CU covers this
-    // wave's ds_read latency and barrier waits.
+    // Two fragment sets: set p holds the first 16 k of a chunk, set q the second.  Each set's ds_reads are issued one
+    // half-chunk (32 MFMAs = 1024 matrix-pipe cycles) ahead of the MFMAs that consume them, so the LDS latency is never
+    // exposed; the barrier that hands a stage back to the loaders is waited for with a full set of MFMAs in the pipe.
     int so = 0;
+    D2_RD(p, 0, sw0);
     for (int kt = 0; kt < nk; ++kt) {
-      D2_RD(p, so, sw0);
-      WS_MM(p);
-      D2_RD(p, so, sw1);
+      D2_RD(q, so, sw1);                                    // last reads of stage kt
+      __builtin_amdgcn_sched_barrier(0);
+      WS_MM(p);                                             // (waits for set p only: the compiler counts lgkmcnt)
+      __builtin_amdgcn_sched_barrier(0);
       if (kt + 1 < nk) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the stage are done (fragments in registers)
-        __builtin_amdgcn_s_barrier();                       // B_kt
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stage kt are done (fragments in registers)
+        __builtin_amdgcn_s_barrier();                       // B_kt: chunk kt+1 has landed, stage kt may be refilled
         so = (so == 2 * D2_STAGE_FLOATS) ? 0 : so + D2_STAGE_FLOATS;
+        D2_RD(p, so, sw0);                                  // first reads of stage kt+1, under set q's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
       }
-      WS_MM(p);
+      WS_MM(q);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   MMEGO_STAMP_AT(blockIdx.x, 2, tid == 0);
 #define D2_CELL(A0, A1, A2, A3, i)                                                                          \
   _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                     \
     const int lrow = rowbase + (i) * 16 + fq * 4 + reg;                                                     \
-    float gi = fast_sigmoid(A0[reg] + (xg[i][0][reg] + bh[0]));                                             \
-    float gf = fast_sigmoid(A1[reg] + (xg[i][1][reg] + bh[1]));                                             \
-    float gg = fast_tanh(A2[reg] + (xg[i][2][reg] + bh[2]));                                                \
-    float go = fast_sigmoid(A3[reg] + (xg[i][3][reg] + bh[3]));                                             \
+    float gi = fast_sigmoid(A0[reg]);                                                                       \
+    float gf = fast_sigmoid(A1[reg]);                                                                       \
+    float gg = fast_tanh(A2[reg]);                                                                          \
+    float go = fast_sigmoid(A3[reg]);                                                                       \
     float cn = gf * cprev[i][reg] + gi * gg;                                                                \
     OUT[lrow * CLD + hb + fr] = cn;                                                                         \
     OUT[64 * CLD + lrow * CLD + hb + fr] = go * fast_tanh(cn);                                              \

@@ -78,9 +78,10 @@ def _worker(rank, world, port, q):
         for step in range(2):
             both.step()
             torch.cuda.synchronize()
-            out["g%d" % step] = [st.net.flat().flat_g.cpu().clone() for st in (su, sl)]
-            out["p%d" % step] = [st.net.flat().flat_p.cpu().clone() for st in (su, sl)]
-        out["buffers"] = [[b.cpu().clone() for b in st.net.buffers()] for st in (su, sl)]
+            # (numpy arrays: pickled by value -- torch tensors would travel as file descriptors of a process that is gone)
+            out["g%d" % step] = [st.net.flat().flat_g.cpu().numpy().copy() for st in (su, sl)]
+            out["p%d" % step] = [st.net.flat().flat_p.cpu().numpy().copy() for st in (su, sl)]
+        out["buffers"] = [[b.cpu().numpy().copy() for b in st.net.buffers()] for st in (su, sl)]
         out["loss"] = [st.loss.item() for st in (su, sl)]
         q.put((rank, out))
     finally:
@@ -98,6 +99,10 @@ def test_two_rank_ul_step_equals_sum_of_shard_gradients():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    for r in res:
+        for k, v in res[r].items():
+            if k != "loss":
+                res[r][k] = [[torch.from_numpy(a) for a in e] if isinstance(e, list) else torch.from_numpy(e) for e in v]
     # single-process reference: rank 0's initial weights (seed 1000), the two shards one after the other, eager, no process group
     from mmego_amd.train_step import shard_of
     dev = torch.device("cuda:0")
