@@ -214,6 +214,81 @@ def attn_pool_backward(ar, key, X, lin, attn, dvec, G_, P, C, dX, G):
 milestone = None
 
 
+_LSTM_TWO_CHAINS_DEFAULT = os.environ.get("MMEGO_LSTM_TWO_CHAINS", "1") != "0"
+_LSTM_TWO_CHAINS = _LSTM_TWO_CHAINS_DEFAULT
+_side_streams = {}
+
+
+class two_chains:
+    """Context: switch the two-chain recurrence (lstm_recurrence) on or off.  The engines that run OTHER work beside an IMU_Net
+    forward (train_step.ConcurrentStages / PipelinedStages: the other stage's small-kernel tail fills the recurrence's gaps
+    already, and competes for the CUs' second workgroup slot) switch it off: measured 6.11 ms (off) against 6.19 ms (on) per
+    U+L step, while a forward that runs alone gains (sequential U+L step 7.66 -> 7.51 ms, IMU-shared 4.70 -> 4.52 ms)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        global _LSTM_TWO_CHAINS
+        self.was, _LSTM_TWO_CHAINS = _LSTM_TWO_CHAINS, bool(self.on) and _LSTM_TWO_CHAINS_DEFAULT
+        return self
+
+    def __exit__(self, *exc):
+        global _LSTM_TWO_CHAINS
+        _LSTM_TWO_CHAINS = self.was
+        return False
+
+
+def _side_stream(cur):
+    """One extra stream per launching stream (the second direction's chain of a BiLSTM layer's recurrence)."""
+    st = _side_streams.get(cur.cuda_stream)
+    if st is None:
+        st = _side_streams[cur.cuda_stream] = torch.cuda.Stream()
+    return st
+
+
+def lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T, gst=None, cst=None):
+    """The recurrent half of BiLSTM layer ``l``: xp [Bn*T, 8H] (input projections of both directions, rows b*T+t) ->
+    out [Bn*T, 2H]; gst / cst [2, T, Bn, 4H / H]: stashes for backward.
+
+    With >= 128 rows the two directions run as TWO CHAINS of single-direction mmego_lstm_step launches on two streams (two
+    parallel branches under graph capture; only where a side stream may be forked: ops.capture_can_fork): they are independent dependency chains, each launch covers the chip once
+    (64 x 16 tiles, lstm_step.hip), so a CU holds one workgroup of each direction, and while one direction sits in its launch
+    gap / cold-L2 prologue / cell update the other one's product loop owns the matrix pipe: 21.7 us per timestep against
+    23.4 us with both directions in one launch (Bn = H = 512, scripts/bench_lstm_step.py --chains).  Same arithmetic in the
+    same order: results are bit-identical (tests/test_hip_parity.py)."""
+    H = lstm.hidden_size
+    c = ar.get("%s.c" % key, (2, Bn, H))
+    w0, w1 = lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1)
+    b0, b1 = lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1)
+    xp_p, out_p = xp.data_ptr(), out.data_ptr()
+    xs, os_ = T * 8 * H, T * 2 * H       # row strides between consecutive batch rows b
+    if _LSTM_TWO_CHAINS and T > 1 and Bn >= 128 and ops.capture_can_fork():
+        cur = torch.cuda.current_stream()
+        side = _side_stream(cur)
+        side.wait_stream(cur)
+        for s in range(T):
+            t0, t1 = s, T - 1 - s
+            hip.call("lstm_step", 1, Bn, H, int(s == 0), out_p + 4 * ((t0 - 1) * 2 * H) if s > 0 else None, None, os_, w0, None, b0, None,
+                     xp_p + 4 * (t0 * 8 * H), None, xs, out_p + 4 * (t0 * 2 * H), None, os_, c[0], None,
+                     None if gst is None else gst[0, t0], None, None if cst is None else cst[0, t0], None)
+            with torch.cuda.stream(side):
+                hip.call("lstm_step", 1, Bn, H, int(s == 0), out_p + 4 * ((t1 + 1) * 2 * H + H) if s > 0 else None, None, os_, w1, None,
+                         b1, None, xp_p + 4 * (t1 * 8 * H + 4 * H), None, xs, out_p + 4 * (t1 * 2 * H + H), None, os_, c[1], None,
+                         None if gst is None else gst[1, t1], None, None if cst is None else cst[1, t1], None)
+        cur.wait_stream(side)
+        return
+    for s in range(T):
+        t0, t1 = s, T - 1 - s
+        hp0 = out_p + 4 * ((t0 - 1) * 2 * H) if s > 0 else None          # h_{t-1} of each direction
+        hp1 = out_p + 4 * ((t1 + 1) * 2 * H + H) if s > 0 else None
+        hip.call("lstm_step", 2, Bn, H, int(s == 0), hp0, hp1, os_, w0, w1, b0, b1,
+                 xp_p + 4 * (t0 * 8 * H), xp_p + 4 * (t1 * 8 * H + 4 * H), xs,
+                 out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_, c[0], c[1],
+                 None if gst is None else gst[0, t0], None if gst is None else gst[1, t1],
+                 None if cst is None else cst[0, t0], None if cst is None else cst[1, t1])
+
+
 def lstm_steps_forward(ar, key, lstm, x, Bn, T):
     """x [Bn*T, In] rows (b*T+t) -> out [Bn*T, 2H] of the last layer (eval mode: no dropout)."""
     H = lstm.hidden_size
@@ -226,18 +301,7 @@ def lstm_steps_forward(ar, key, lstm, x, Bn, T):
         if milestone is not None:
             milestone(key, l)
         out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
-        c = ar.get("%s.c" % key, (2, Bn, H))
-        w0, w1 = lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1)
-        b0, b1 = lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1)
-        xp_p, out_p = xp.data_ptr(), out.data_ptr()
-        xs, os_ = T * 8 * H, T * 2 * H       # row strides between consecutive batch rows b
-        for s in range(T):
-            t0, t1 = s, T - 1 - s
-            hp0 = out_p + 4 * ((t0 - 1) * 2 * H) if s > 0 else None          # h_{t-1} of each direction
-            hp1 = out_p + 4 * ((t1 + 1) * 2 * H + H) if s > 0 else None
-            hip.call("lstm_step", 2, Bn, H, int(s == 0), hp0, hp1, os_, w0, w1, b0, b1,
-                     xp_p + 4 * (t0 * 8 * H), xp_p + 4 * (t1 * 8 * H + 4 * H), xs,
-                     out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_, c[0], c[1], None, None, None, None)
+        lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T)
         cur = out
     return out
 

@@ -2,10 +2,10 @@
 // IMU_Net's 2 x (2-layer, H=512) BiLSTMs (reference Net/IMU_Net.py:58-62,77,82) -- 94 % of the path's FLOPs.
 //   gates = xproj_t (+ b_hh) + h_{t-1} . W_hh^T ;  i,f,o = sigmoid, g = tanh ;  c = f c + i g ;  h = o tanh(c)
 // Both directions run in one launch.  Two kernels, chosen by the number of batch rows:
-//   lstm_step_dma2_kernel   Bn >= 128: WG = 64 rows x 32 hidden x 4 gates (v_mfma_f32_16x16x4_f32); operands go
-//                           global -> LDS by LDS-DMA into a 3-stage ring of 32-k chunks (72 KB: two WGs per CU), four
-//                           loader waves + four MFMA waves; the cell update is register-local.  WGs sharing a W_hh
-//                           slice are placed on one XCD, so each XCD's L2 holds 1/8 of W_hh.
+//   lstm_step_dma_kernel<HT>  Bn >= 128: WG = 64 rows x HT (16 | 32) hidden x 4 gates (v_mfma_f32_16x16x4_f32); operands
+//                           go global -> LDS by LDS-DMA into a 3-stage ring of 32-k chunks, four loader waves + four
+//                           MFMA waves; the cell update is register-local.  WGs sharing a W_hh slice are placed on one
+//                           XCD, so each XCD's L2 holds 1/8 of W_hh.
 //                           (Earlier variants -- plain double-buffered, register-staged loader waves, a 156-KB DMA
 //                           ring -- all measured slower and were removed)
 //   lstm_step_small_kernel  Bn < 128 (rnn_slow: 64 rows): the step is W_hh-streaming bound, so the hidden axis is
@@ -26,6 +26,9 @@ struct LstmStepP {
   float* gst[2];   // optional stash for backward: post-activation gates [Bn][4H] and new cell state [Bn][H] of this step
   float* cst[2];
   int Bn, H, ndir, first;
+#ifdef MMEGO_STAMP
+  int dbg;         // diagnostic probe only (scripts/clock_probe.hip): 1 = loaders do not wait for DMAs, 2 = no DMAs, 4 = no ds_reads
+#endif
 };
 
 // rcp / v_exp_f32 based activations (as in lstm.hip): a few ulp from the libm forms at a fraction of their instruction count
@@ -33,46 +36,47 @@ struct LstmStepP {
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
-#define CLD 36    // LDS row stride of the c / h output tiles: 32 hidden + 4 pad
-
-#define WS_MM4(S, c)                                                                                         \
-  do {                                                                                                       \
-    acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a0.c, S##b0.c, acc00, 0, 0, 0);                          \
-    acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a0.c, S##b1.c, acc01, 0, 0, 0);                          \
-    acc02 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a0.c, S##b2.c, acc02, 0, 0, 0);                          \
-    acc03 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a0.c, S##b3.c, acc03, 0, 0, 0);                          \
-    acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a1.c, S##b0.c, acc10, 0, 0, 0);                          \
-    acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a1.c, S##b1.c, acc11, 0, 0, 0);                          \
-    acc12 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a1.c, S##b2.c, acc12, 0, 0, 0);                          \
-    acc13 = __builtin_amdgcn_mfma_f32_16x16x4f32(S##a1.c, S##b3.c, acc13, 0, 0, 0);                          \
-  } while (0)
-#define WS_MM(S) do { WS_MM4(S, x); WS_MM4(S, y); WS_MM4(S, z); WS_MM4(S, w); } while (0)
 #define GLDS16(gptr, lptr)                                                                                  \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+#ifdef MMEGO_STAMP
+#define D2_DBG(bit) (p.dbg & (bit))
+#else
+#define D2_DBG(bit) 0
+#endif
 
-// ---- LDS-DMA step kernel, 72 KB footprint: TWO workgroups per CU -------------------------------------------------------
-// Operands go global -> LDS by LDS-DMA (4 loader waves, counted vmcnt, raw s_barriers), 32-k chunks in a ring of three 24-KB
-// stages; no xproj / c tiles in LDS: the compute waves fetch their own xproj elements straight into the accumulators
-// (gates = xproj + b + h.W^T) and c_{t-1} into registers at kernel start.  With 72 KB and <= 128 VGPRs two workgroups share a CU.  That matters
-// when independent step kernels exist (the two concurrent stage programs each run an IMU_Net forward): while one waits for
-// its first operands, its barriers or its stores, the other owns the matrix pipe -- and kernels of other branches with
-// modest LDS needs can co-reside as well.
-//   stage image: A 64 rows x 32 k, W 128 rows x 32 k, unpadded 128-B rows of 8 16-B pieces; piece p of row r is stored at
-//   piece p ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 phase (rows fr = 0..15, same piece) hit 16 distinct 4-bank groups.
-#define D2_KC 32
-#define D2_STAGE_FLOATS (192 * D2_KC)
-#define D2_LDS_FLOATS (3 * D2_STAGE_FLOATS)
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void lstm_step_dma2_kernel(LstmStepP p) {
+// ---- LDS-DMA step kernel -------------------------------------------------------------------------------------------------
+// WG = 64 batch rows x HT hidden units x 4 gates, 8 waves: four LOADER waves move the operands global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: never through VGPRs; counted vmcnt, raw s_barriers so that chunks stay in flight across them),
+// four COMPUTE waves (one per SIMD) run only ds_read_b128 + v_mfma_f32_16x16x4_f32.  32-k chunks in a ring of three stages.
+//   stage image: A 64 rows x 32 k, then W 4*HT rows x 32 k (row = gate*HT + unit), unpadded 128-B rows of 8 16-B pieces;
+//   piece p of row r sits at piece p ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 phase (rows fr = 0..15, same piece)
+//   hit 16 distinct 4-bank groups (PMC: no bank conflicts).
+// The accumulators are seeded with xproj + b_hh (gates = xproj + b + h.W^T), fetched straight from global memory while the
+// first chunk is in flight; c_{t-1} waits in registers for the cell update, which is register-local.
+// HT = 32: 72 KB of LDS, wave tile 32 rows x 16 units x 4 gates (8 accumulator tiles, 6 fragment reads per 32 MFMAs);
+// HT = 16: 48 KB, wave tile 16 x 16 x 4 (4 tiles, 5 reads per 16 MFMAs) and twice the workgroups.
+// Why two sizes (in-kernel stamps, scripts/clock_probe.hip, Bn = 512, H = 512): with ONE workgroup per CU (256 WGs at
+// HT = 32) the product loop takes 40.4 k cycles against 32.8 k of MFMA issue; with the DMAs and the LDS reads taken out it
+// still takes 35.7 k -- the matrix pipe drains at every chunk barrier (the in-order compute wave cannot issue past it).
+// With HT = 16 there are 512 WGs, two per CU with independent barriers: while one workgroup's compute wave sits at its
+// barrier the other one's owns the SIMD's matrix pipe.  HT = 32 remains for grids that fill the chip twice over anyway.
+template <int HT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void lstm_step_dma_kernel(LstmStepP p) {
+  constexpr int NA = HT / 16;                  // A fragments (16-row groups) per compute wave
+  constexpr int WROWS = 4 * HT;                // W rows per stage
+  constexpr int NWP = WROWS / 32;              // W DMA pieces-groups per loader wave and chunk (8 rows each)
+  constexpr int STAGE = (64 + WROWS) * 32;     // floats per stage
+  constexpr int CLD = HT + 4;                  // row stride of the c / h output tiles in LDS
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool loader = wave >= 4;
   const int H = p.H;
-  const int nrb = (p.Bn + 63) / 64, nht = H / 32, npairs = p.ndir * nht;
+  const int nrb = (p.Bn + 63) / 64, nht = H / HT, npairs = p.ndir * nht;
   int pair, rb;
   {
     const int wg = blockIdx.x;
-    if ((npairs & 7) == 0) {
+    if ((npairs & 7) == 0) {                   // workgroups sharing a W_hh slice on one XCD: each L2 holds 1/8 of W_hh
       const int xcd = wg & 7, q = wg >> 3;
       pair = xcd + 8 * (q / nrb);
       rb = q % nrb;
@@ -82,147 +86,160 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
   }
   const int d = pair / nht, ht = pair % nht;
-  const int j0 = ht * 32, r0 = rb * 64;
+  const int j0 = ht * HT, r0 = rb * 64;
   const bool first = p.first != 0;
-  const int nk = first ? 0 : H / D2_KC;
-  float* const OUT = smem + (nk % 3) * D2_STAGE_FLOATS;   // new c tile [64][CLD], then new h tile [64][CLD] (4608 floats)
+  const int nk = first ? 0 : H / 32;
+  float* const OUT = smem + (nk % 3) * STAGE;  // new c tile [64][CLD], then new h tile [64][CLD]
   MMEGO_STAMP_AT(blockIdx.x, 0, tid == 0);
 
   if (loader) {
     const int lw = wave - 4, q8 = lane >> 3, sl = lane & 7;
-    const int rmax = p.Bn - 1 - r0;                       // rows past the batch read a valid row (their results are dropped)
+    const int rmax = p.Bn - 1 - r0;            // rows past the batch read a valid row (their results are dropped)
     const float* ag[2];
-    const float* wg_[4];
+    const float* wg_[NWP];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ra = 8 * (lw + 4 * i) + q8;
       ag[i] = first ? nullptr : p.hprev[d] + (long)(r0 + min(ra, rmax)) * p.hps + 4 * (sl ^ ((ra >> 1) & 7));
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NWP; ++j) {
       const int rw = 8 * (lw + 4 * j) + q8;
-      wg_[j] = p.whh[d] + ((long)(rw >> 5) * H + j0 + (rw & 31)) * H + 4 * (sl ^ ((rw >> 1) & 7));
+      wg_[j] = p.whh[d] + ((long)(rw / HT) * H + j0 + (rw % HT)) * H + 4 * (sl ^ ((rw >> 1) & 7));
     }
 #define D2_CHUNK(kt)                                                                                        \
   do {                                                                                                      \
-    float* st_ = smem + ((kt) % 3) * D2_STAGE_FLOATS;                                                       \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) GLDS16(ag[i] + (kt) * D2_KC, st_ + 8 * (lw + 4 * i) * 32); \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) GLDS16(wg_[j] + (kt) * D2_KC, st_ + 2048 + 8 * (lw + 4 * j) * 32); \
+    if (D2_DBG(2)) break;                                                                                   \
+    float* st_ = smem + ((kt) % 3) * STAGE;                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) GLDS16(ag[i] + (kt) * 32, st_ + 8 * (lw + 4 * i) * 32);   \
+    _Pragma("unroll") for (int j = 0; j < NWP; ++j) GLDS16(wg_[j] + (kt) * 32, st_ + 2048 + 8 * (lw + 4 * j) * 32); \
   } while (0)
+    constexpr int PC = 2 + NWP;                // DMAs per loader wave and chunk
     if (nk > 0) {
       D2_CHUNK(0);
       if (nk > 1) D2_CHUNK(1);
       if (nk > 2) D2_CHUNK(2);
-      if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (D2_DBG(1)) { }
+      else if (nk > 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PC) & 15) | (((2 * PC) >> 4) << 14));
+      else if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (PC & 15) | ((PC >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
     }
-    __builtin_amdgcn_s_barrier();                         // (1) chunk 0 is in LDS
-    for (int kt = 0; kt + 1 < nk; ++kt) {                 // B_kt: chunk kt+1 has landed; stage kt % 3 may be refilled
-      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // (1) chunk 0 is in LDS
+    for (int kt = 0; kt + 1 < nk; ++kt) {      // B_kt: chunk kt+1 has landed; stage kt % 3 may be refilled
+      if (D2_DBG(1)) { }
+      else if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0F70 | (PC & 15) | ((PC >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (kt + 3 < nk) D2_CHUNK(kt + 3);
     }
-    __builtin_amdgcn_s_barrier();                         // (E) new c / h tiles are in OUT
+    __builtin_amdgcn_s_barrier();              // (E) new c / h tiles are in OUT
     {
-      const int lt = tid - 256, xr = lt >> 2, xq = (lt & 3) * 8;
-      if ((r0 + xr) < p.Bn) {
-        float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
-        *reinterpret_cast<f32x4*>(crow) = *reinterpret_cast<const f32x4*>(OUT + xr * CLD + xq);
-        *reinterpret_cast<f32x4*>(crow + 4) = *reinterpret_cast<const f32x4*>(OUT + xr * CLD + xq + 4);
-        float* hrow = p.hout[d] + (long)(r0 + xr) * p.hos + j0 + xq;
-        *reinterpret_cast<f32x4*>(hrow) = *reinterpret_cast<const f32x4*>(OUT + 64 * CLD + xr * CLD + xq);
-        *reinterpret_cast<f32x4*>(hrow + 4) = *reinterpret_cast<const f32x4*>(OUT + 64 * CLD + xr * CLD + xq + 4);
+      constexpr int TPR = HT / 8;              // threads per row (two 16-B stores each to c and to h)
+      const int lt = tid - 256;
+      for (int e = lt; e < 64 * TPR; e += 256) {
+        const int xr = e / TPR, xq = (e % TPR) * 8;
+        if ((r0 + xr) < p.Bn) {
+          float* crow = p.c[d] + (long)(r0 + xr) * H + j0 + xq;
+          *reinterpret_cast<f32x4*>(crow) = *reinterpret_cast<const f32x4*>(OUT + xr * CLD + xq);
+          *reinterpret_cast<f32x4*>(crow + 4) = *reinterpret_cast<const f32x4*>(OUT + xr * CLD + xq + 4);
+          float* hrow = p.hout[d] + (long)(r0 + xr) * p.hos + j0 + xq;
+          *reinterpret_cast<f32x4*>(hrow) = *reinterpret_cast<const f32x4*>(OUT + 64 * CLD + xr * CLD + xq);
+          *reinterpret_cast<f32x4*>(hrow + 4) = *reinterpret_cast<const f32x4*>(OUT + 64 * CLD + xr * CLD + xq + 4);
+        }
       }
     }
     return;
   }
 
   // ---------------------------------------------- compute waves ----------------------------------------------
-  const int rowbase = (wave & 1) * 32, hb = (wave >> 1) * 16;
+  const int rowbase = HT == 32 ? (wave & 1) * 32 : wave * 16;
+  const int hb = HT == 32 ? (wave >> 1) * 16 : 0;
   const int fr = lane & 15, fq = lane >> 4;
   const int rmax = p.Bn - 1 - r0;
-  // The accumulators are SEEDED with xproj (+ b_hh) of this lane's 8 rows x 4 gates (gates = xproj + b + h.W^T), so the
-  // projection needs no registers of its own during the product -- they pay for a second fragment set (below).  The loads
-  // land while the loader waves' first operand chunk is in flight.  c_{t-1} is fetched now and consumed after the product.
   float bh[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) bh[g] = p.bhh[d] ? p.bhh[d][g * H + j0 + hb + fr] : 0.f;
-  f32x4 acc00, acc01, acc02, acc03, acc10, acc11, acc12, acc13;
-  float cprev[2][4];
-#define D2_SEED(A0, A1, A2, A3, i)                                                                          \
-  _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                     \
-    const int lrow = min(rowbase + (i) * 16 + fq * 4 + reg, rmax);                                          \
-    const float* xrow = p.xproj[d] + (long)(r0 + lrow) * p.xs + j0 + hb + fr;                               \
-    A0[reg] = xrow[0] + bh[0];                                                                              \
-    A1[reg] = xrow[(long)H] + bh[1];                                                                        \
-    A2[reg] = xrow[2 * (long)H] + bh[2];                                                                    \
-    A3[reg] = xrow[3 * (long)H] + bh[3];                                                                    \
-    cprev[i][reg] = nk > 0 ? p.c[d][(long)(r0 + lrow) * H + j0 + hb + fr] : 0.f;                            \
-  }
-  D2_SEED(acc00, acc01, acc02, acc03, 0)
-  D2_SEED(acc10, acc11, acc12, acc13, 1)
+  f32x4 acc[NA][4];
+  float cprev[NA][4];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int lrow = min(rowbase + i * 16 + fq * 4 + reg, rmax);
+      const float* xrow = p.xproj[d] + (long)(r0 + lrow) * p.xs + j0 + hb + fr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[i][g][reg] = xrow[(long)g * H] + bh[g];
+      cprev[i][reg] = nk > 0 ? p.c[d][(long)(r0 + lrow) * H + j0 + hb + fr] : 0.f;
+    }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                          // (1)  chunk 0 is in LDS
+  __builtin_amdgcn_s_barrier();                // (1) chunk 0 is in LDS
   MMEGO_STAMP_AT(blockIdx.x, 1, tid == 0);
   if (nk > 0) {
     const int key = (fr >> 1) & 7;
     const int sw0 = ((0 | fq) ^ key) << 2, sw1 = ((4 | fq) ^ key) << 2;       // k-block 0 / 1 of a 32-k chunk
     const float* arow = smem + (rowbase + fr) * 32;
     const float* brow = smem + 2048 + (hb + fr) * 32;
-    f32x4 pa0, pa1, pb0, pb1, pb2, pb3, qa0, qa1, qb0, qb1, qb2, qb3;
-#define D2_RD(S, so, sw)                                                                                    \
+    f32x4 pa[NA], pb[4], qa[NA], qb[4];
+#define D2_RD(A_, B_, so, sw)                                                                               \
   do {                                                                                                      \
-    S##a0 = *reinterpret_cast<const f32x4*>(arow + (so) + (sw));                                            \
-    S##a1 = *reinterpret_cast<const f32x4*>(arow + (so) + 16 * 32 + (sw));                                  \
-    S##b0 = *reinterpret_cast<const f32x4*>(brow + (so) + (sw));                                            \
-    S##b1 = *reinterpret_cast<const f32x4*>(brow + (so) + 32 * 32 + (sw));                                  \
-    S##b2 = *reinterpret_cast<const f32x4*>(brow + (so) + 64 * 32 + (sw));                                  \
-    S##b3 = *reinterpret_cast<const f32x4*>(brow + (so) + 96 * 32 + (sw));                                  \
+    if (D2_DBG(4)) break;                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < NA; ++i) A_[i] = *reinterpret_cast<const f32x4*>(arow + (so) + i * 16 * 32 + (sw)); \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) B_[g] = *reinterpret_cast<const f32x4*>(brow + (so) + g * HT * 32 + (sw));  \
   } while (0)
-    // Two fragment sets: set p holds the first 16 k of a chunk, set q the second.  Each set's ds_reads are issued one
-    // half-chunk (32 MFMAs = 1024 matrix-pipe cycles) ahead of the MFMAs that consume them, so the LDS latency is never
-    // exposed; the barrier that hands a stage back to the loaders is waited for with a full set of MFMAs in the pipe.
+#define D2_MM(A_, B_)                                                                                       \
+  do {                                                                                                      \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                           \
+      _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                        \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                       \
+          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[i][c], B_[g][c], acc[i][g], 0, 0, 0);         \
+  } while (0)
+    // Two fragment sets: set p holds the first 16 k of a chunk, set q the second; each set's ds_reads are issued one
+    // half-chunk ahead of the MFMAs that consume them, and the barrier that hands a stage back to the loaders is waited
+    // for with a full set of MFMAs queued.
     int so = 0;
-    D2_RD(p, 0, sw0);
+    D2_RD(pa, pb, 0, sw0);
     for (int kt = 0; kt < nk; ++kt) {
-      D2_RD(q, so, sw1);                                    // last reads of stage kt
+      D2_RD(qa, qb, so, sw1);                  // last reads of stage kt
       __builtin_amdgcn_sched_barrier(0);
-      WS_MM(p);                                             // (waits for set p only: the compiler counts lgkmcnt)
+      D2_MM(pa, pb);                           // (waits for set p only: the compiler counts lgkmcnt)
       __builtin_amdgcn_sched_barrier(0);
       if (kt + 1 < nk) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stage kt are done (fragments in registers)
-        __builtin_amdgcn_s_barrier();                       // B_kt: chunk kt+1 has landed, stage kt may be refilled
-        so = (so == 2 * D2_STAGE_FLOATS) ? 0 : so + D2_STAGE_FLOATS;
-        D2_RD(p, so, sw0);                                  // first reads of stage kt+1, under set q's MFMAs
+        // this wave's reads of stage kt are done (fragments in registers).  The BUILTIN, not inline asm: the compiler's
+        // wait-count pass must know that set q has landed, or it makes q's MFMAs wait for the p reads issued just before them.
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // B_kt: chunk kt+1 has landed, stage kt may be refilled
+        so = (so == 2 * STAGE) ? 0 : so + STAGE;
+        D2_RD(pa, pb, so, sw0);                // first reads of stage kt+1, under set q's MFMAs
         __builtin_amdgcn_sched_barrier(0);
       }
-      WS_MM(q);
+      D2_MM(qa, qb);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   MMEGO_STAMP_AT(blockIdx.x, 2, tid == 0);
-#define D2_CELL(A0, A1, A2, A3, i)                                                                          \
-  _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                     \
-    const int lrow = rowbase + (i) * 16 + fq * 4 + reg;                                                     \
-    float gi = fast_sigmoid(A0[reg]);                                                                       \
-    float gf = fast_sigmoid(A1[reg]);                                                                       \
-    float gg = fast_tanh(A2[reg]);                                                                          \
-    float go = fast_sigmoid(A3[reg]);                                                                       \
-    float cn = gf * cprev[i][reg] + gi * gg;                                                                \
-    OUT[lrow * CLD + hb + fr] = cn;                                                                         \
-    OUT[64 * CLD + lrow * CLD + hb + fr] = go * fast_tanh(cn);                                              \
-    if (p.gst[d] && (r0 + lrow) < p.Bn) {                                                                   \
-      float* gs = p.gst[d] + (long)(r0 + lrow) * 4 * H + j0 + hb + fr;                                      \
-      gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;                                               \
-      p.cst[d][(long)(r0 + lrow) * H + j0 + hb + fr] = cn;                                                  \
-    }                                                                                                       \
-  }
-  D2_CELL(acc00, acc01, acc02, acc03, 0)
-  D2_CELL(acc10, acc11, acc12, acc13, 1)
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int lrow = rowbase + i * 16 + fq * 4 + reg;
+      const float gi = fast_sigmoid(acc[i][0][reg]);
+      const float gf = fast_sigmoid(acc[i][1][reg]);
+      const float gg = fast_tanh(acc[i][2][reg]);
+      const float go = fast_sigmoid(acc[i][3][reg]);
+      const float cn = gf * cprev[i][reg] + gi * gg;
+      OUT[lrow * CLD + hb + fr] = cn;
+      OUT[64 * CLD + lrow * CLD + hb + fr] = go * fast_tanh(cn);
+      if (p.gst[d] && (r0 + lrow) < p.Bn) {
+        float* gs = p.gst[d] + (long)(r0 + lrow) * 4 * H + j0 + hb + fr;
+        gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;
+        p.cst[d][(long)(r0 + lrow) * H + j0 + hb + fr] = cn;
+      }
+    }
   MMEGO_STAMP_AT(blockIdx.x, 3, tid == 0);
-  __syncthreads();                                       // (E)
+  __syncthreads();                             // (E)
 }
 
 // ---- small-batch variant: WG = 64 rows x (4 hidden x 4 gates), K split over nothing, 4 waves = 4 row tiles ----------
@@ -327,6 +344,9 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
   }
 }
 
+#ifdef MMEGO_STAMP
+static int mmego_step_dbg = 0;
+#endif
 extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first, const float* hprev0, const float* hprev1,
                                long hps, const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
                                const float* xproj0, const float* xproj1, long xs, float* hout0, float* hout1, long hos,
@@ -350,16 +370,42 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
   p.gst[0] = gst0; p.gst[1] = gst1; p.cst[0] = cst0; p.cst[1] = cst1;
   MMEGO_REQUIRE((gst0 == nullptr) == (cst0 == nullptr) && (gst1 == nullptr) == (cst1 == nullptr));
   p.Bn = Bn; p.H = H; p.ndir = ndir; p.first = first;
+#ifdef MMEGO_STAMP
+  p.dbg = mmego_step_dbg;
+#endif
   if (Bn >= 128) {
-    static bool d2_attr = false;
-    const size_t lds = (size_t)D2_LDS_FLOATS * sizeof(float);
-    if (!d2_attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)lstm_step_dma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      d2_attr = true;
+    // HT = 32 by default; MMEGO_STEP_HT=16 selects the two-workgroups-per-CU variant for A/B runs (its product loop is
+    // shorter, 37.9 k against 41.1 k cycles, but its prologue -- twice the workgroups fetching first chunks -- costs more)
+    static const int force_ht = getenv("MMEGO_STEP_HT") ? atoi(getenv("MMEGO_STEP_HT")) : 0;
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     }
-    int grid = ndir * (H / 32) * cdiv(Bn, 64);
-    hipLaunchKernelGGL(lstm_step_dma2_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+    const int grid32 = ndir * (H / 32) * cdiv(Bn, 64);
+    // (both directions in one launch, Bn = H = 512: 26.7 us with HT 16 against 24.3 us with HT 32 per step.)  A launch that
+    // would fill at most HALF the chip with HT = 32 -- one direction of the pair, launched on its own stream -- takes HT = 16:
+    // then each direction's grid covers every CU once and the two directions' workgroups share the CUs out of phase
+    const bool ht16 = force_ht ? force_ht == 16 : 2 * grid32 <= ncu;
+    static bool attr32 = false, attr16 = false;
+    if (ht16) {
+      const size_t lds = (size_t)3 * (64 + 64) * 32 * sizeof(float);
+      if (!attr16) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_step_dma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr16 = true;
+      }
+      hipLaunchKernelGGL(lstm_step_dma_kernel<16>, dim3(2 * grid32), dim3(512), lds, (hipStream_t)stream, p);
+    } else {
+      const size_t lds = (size_t)3 * (64 + 128) * 32 * sizeof(float);
+      if (!attr32) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_step_dma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr32 = true;
+      }
+      hipLaunchKernelGGL(lstm_step_dma_kernel<32>, dim3(grid32), dim3(512), lds, (hipStream_t)stream, p);
+    }
   } else {
     int grid = ndir * (H / 4) * cdiv(Bn, 64);
     if ((H % 64) == 0) hipLaunchKernelGGL(lstm_step_small_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);

@@ -19,21 +19,9 @@ def lstm_steps_forward_stash(ar, key, lstm, x, Bn, T):
         xp = ar.get("%s.xp%d" % (key, l), (Bn * T, 8 * H))
         ops.linear_pair(cur, lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1), lstm.w("bias_ih", l, 0), lstm.w("bias_ih", l, 1), xp, 4 * H)
         out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
-        c = ar.get("%s.c" % key, (2, Bn, H))
         gst = ar.get("%s.gst%d" % (key, l), (2, T, Bn, 4 * H))
         cst = ar.get("%s.cst%d" % (key, l), (2, T, Bn, H))
-        w0, w1 = lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1)
-        b0, b1 = lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1)
-        xp_p, out_p = xp.data_ptr(), out.data_ptr()
-        xs, os_ = T * 8 * H, T * 2 * H
-        for s in range(T):
-            t0, t1 = s, T - 1 - s
-            hp0 = out_p + 4 * ((t0 - 1) * 2 * H) if s > 0 else None
-            hp1 = out_p + 4 * ((t1 + 1) * 2 * H + H) if s > 0 else None
-            hip.call("lstm_step", 2, Bn, H, int(s == 0), hp0, hp1, os_, w0, w1, b0, b1,
-                     xp_p + 4 * (t0 * 8 * H), xp_p + 4 * (t1 * 8 * H + 4 * H), xs,
-                     out_p + 4 * (t0 * 2 * H), out_p + 4 * (t1 * 2 * H + H), os_, c[0], c[1],
-                     gst[0, t0], gst[1, t1], cst[0, t0], cst[1, t1])
+        blocks.lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T, gst=gst, cst=cst)
         cur = out
     return out
 

@@ -57,6 +57,24 @@ class Arena:
 _scratch = {}
 _retired = []
 
+_capture_origin = {"stream": None}
+
+
+def mark_capture_origin():
+    """Called by whoever starts enqueuing a captured body: remembers the capture's ORIGIN stream.  On this ROCm a stream forked
+    from an already-forked capture stream crashes graph capture (minimal reproduction: scripts/repro_nested_capture_fork.py), so
+    code that wants a side stream under capture may only fork from the origin: see capture_can_fork()."""
+    _capture_origin["stream"] = torch.cuda.current_stream().cuda_stream if torch.cuda.is_current_stream_capturing() else None
+
+
+def capture_can_fork():
+    """True when a side stream may be forked from the current stream: always when running eagerly; under graph capture only on
+    the capture's origin stream."""
+    if not torch.cuda.is_current_stream_capturing():
+        return True
+    return _capture_origin["stream"] is not None and torch.cuda.current_stream().cuda_stream == _capture_origin["stream"]
+
+
 def scratch(device, n):
     """Grow-only fp32 scratch per (device, stream) (split-K slabs, reduction partials).  Stream-ordered reuse is safe."""
     key = (str(device), torch.cuda.current_stream().cuda_stream)

@@ -120,7 +120,9 @@ class StageStep:
         self.loss = self.loss2[:1]
         self.last_pred = None
 
-    def _body(self):
+    def _body(self, nested=False):
+        if not nested:
+            ops.mark_capture_origin()
         s = self.static
         B, T = s["x"].shape[0], s["x"].shape[1]
         ops.copy2d(s["x_src"].view(B * T, -1), s["x"].view(B * T, -1))        # fresh batch (x is transformed in place)
@@ -225,6 +227,7 @@ class ImuStep:
 
     def _body(self):
         from . import imu_train
+        ops.mark_capture_origin()
         s = self.static
         B, T = s["imu"].shape[0], s["imu"].shape[1]
         with torch.no_grad():
@@ -268,11 +271,12 @@ class SharedImuStages:
         self.use_graph, self.graph = use_graph, None
 
     def _body(self):
+        ops.mark_capture_origin()
         with torch.no_grad():
             R, t = self.imu(self.imu_in)
             ops.copy2d(R.view(-1, 9), self.R.view(-1, 9))
             ops.copy2d(t.view(-1, 3), self.t.view(-1, 3))
-        self.pair._bodies()
+        self.pair._bodies(nested=True)
 
     def step(self):
         if self.use_graph:
@@ -318,6 +322,7 @@ class ConcurrentStages:
         self.graph = None
         self.side = [torch.cuda.Stream() for _ in self.stages[1:]]
         self.chain_imu = int(os.environ.get("MMEGO_CHAIN_IMU", "1"))
+        self._poses = {}
         # data parallel: the stages' gradients share one buffer, so one collective per step serves all of them
         self.bucket = None
         pgs = {id(st.pg) for st in self.stages}
@@ -332,20 +337,48 @@ class ConcurrentStages:
             for st in self.stages:
                 allreduce_grads(st.net._flat, st.pg)
 
-    def _bodies(self):
-        """Branch order: the LAST stage (longest tail: the Lower body also runs the frozen Upper_Net) runs its IMU_Net
-        forward first; each earlier stage starts its own IMU_Net forward when the next one's has finished.  The IMU_Net
-        forwards are compute-bound and gain nothing from running side by side, whereas the small-kernel tail of one stage
-        overlaps well with the IMU_Net forward of another (measured: 6.88 -> 6.54 ms per U+L step).  MMEGO_CHAIN_IMU=0 lets the
-        branches start together."""
+    def _bodies(self, nested=False):
+        """Branch order: the LAST stage (longest tail: the Lower body also runs the frozen Upper_Net) gets its IMU_Net forward
+        first; each earlier stage's IMU_Net forward follows when that one has finished.  The IMU_Net forwards are compute-bound
+        and gain nothing from running side by side, whereas the small-kernel tail of one stage overlaps well with the IMU_Net
+        forward of another (measured: 6.88 -> 6.54 ms per U+L step).
+
+        MMEGO_CHAIN_IMU=1 (default): the IMU_Net forwards run one after the other on the launching stream and hand their head
+        poses to the stage bodies through per-stage buffers; each stage's remaining body forks off right after its own forward.
+        MMEGO_CHAIN_IMU=0 lets the branches (IMU_Net forwards included) start together; 2 offsets them by the first projections."""
+        if not nested:
+            ops.mark_capture_origin()
         main = torch.cuda.current_stream()
         stages, streams = self.stages, [main] + self.side
+        if self.chain_imu == 1:
+            keep = [(st.imu, st.pose) for st in stages]
+            try:
+                for i in range(len(stages) - 1, -1, -1):
+                    st = stages[i]
+                    if st.imu is not None and st.pose is None:
+                        from . import blocks
+                        with torch.no_grad(), blocks.two_chains(False):   # another stage's tail runs beside it: blocks.two_chains
+                            R, t = st.imu(st.static["imu"])
+                            pose = self._pose_buf(i, R, t)
+                            ops.copy2d(R.view(-1, 9), pose[0].view(-1, 9))
+                            ops.copy2d(t.view(-1, 3), pose[1].view(-1, 3))
+                        st.pose = pose
+                    if i > 0:
+                        streams[i].wait_stream(main)
+                        with torch.cuda.stream(streams[i]):
+                            st._body(nested=True)
+                    else:
+                        st._body(nested=True)
+            finally:
+                for st, (imu, pose) in zip(stages, keep):
+                    st.imu, st.pose = imu, pose
+            for side in self.side:
+                main.wait_stream(side)
+            return
         events = [torch.cuda.Event() for _ in stages]
         for i, st in enumerate(stages):
             st.before_imu = st.after_imu = st.imu_milestone = None
-            if self.chain_imu == 1:                          # release the next branch when the whole IMU_Net forward is done
-                st.after_imu = lambda ev=events[i], sm=streams[i]: ev.record(sm)
-            elif self.chain_imu == 2:                        # ... when rnn_fast's first input projections are done
+            if self.chain_imu == 2:                          # release the next branch when rnn_fast's first input projections are done
                 st.imu_milestone = lambda key, l, ev=events[i], sm=streams[i]: ev.record(sm) if (key, l) == ("fast", 0) else None
                 if st.imu is None:
                     st.after_imu = lambda ev=events[i], sm=streams[i]: ev.record(sm)
@@ -356,12 +389,18 @@ class ConcurrentStages:
             side.wait_stream(main)
         for i in range(len(stages) - 1, 0, -1):              # enqueue the later stages first: their events must exist
             with torch.cuda.stream(streams[i]):
-                stages[i]._body()
-        stages[0]._body()
+                stages[i]._body(nested=True)
+        stages[0]._body(nested=True)
         for side in self.side:
             main.wait_stream(side)
         for st in stages:
             st.before_imu = st.after_imu = st.imu_milestone = None
+
+    def _pose_buf(self, i, R, t):
+        buf = self._poses.get(i)
+        if buf is None or buf[0].shape != R.shape:
+            buf = self._poses[i] = (torch.empty_like(R), torch.empty_like(t))
+        return buf
 
     def prepare(self):
         """Warm-up (side-effect free) and graph capture, so that the first step() costs what every step costs."""
@@ -421,7 +460,8 @@ class PipelinedStages:
         self.use_graph, self.graph = use_graph, None
 
     def _imu_forwards(self):
-        with torch.no_grad():
+        from . import blocks
+        with torch.no_grad(), blocks.two_chains(False):       # (the stage bodies run beside these forwards: see blocks.two_chains)
             for net, (Rn, tn) in zip(reversed(self.imus), reversed(self.nxt)):      # (Lower's first, as in ConcurrentStages)
                 R, t = net(self.imu_next)
                 ops.copy2d(R.view(-1, 9), Rn.view(-1, 9))
@@ -433,6 +473,7 @@ class PipelinedStages:
         torch.cuda.synchronize()
 
     def _body(self):
+        ops.mark_capture_origin()
         main = torch.cuda.current_stream()
         for (Rc, tc), (Rn, tn) in zip(self.cur, self.nxt):
             ops.copy2d(Rn.view(-1, 9), Rc.view(-1, 9))
@@ -440,7 +481,7 @@ class PipelinedStages:
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             self._imu_forwards()
-        self.pair._bodies()
+        self.pair._bodies(nested=True)
         main.wait_stream(self.side)
 
     def prepare(self):

@@ -62,3 +62,38 @@ for mode in modes:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
     print("Bn=%d mode=%d: %.1f us/launch, %.1f TFLOP/s" % (Bn, mode, us, 2 * 2 * Bn * 4 * H * H / us / 1e6))
+
+
+if "--chains" in sys.argv:
+    # the whole T-step recurrence of one BiLSTM layer: both directions per launch against two chains of single-direction launches
+    from mmego_amd import blocks, ops
+    lstm = blocks.LstmParams(H, H, 1).to(dev)
+    xp2 = torch.randn(Bn * T, 8 * H, device=dev) * 0.1
+    for two in (False, True):
+        blocks._LSTM_TWO_CHAINS = two
+        ar = ops.Arena(dev)
+        o2 = ar.get("out", (Bn * T, 2 * H))
+        run = lambda: blocks.lstm_recurrence(ar, "k", lstm, 0, xp2, o2, Bn, T)
+        run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            run()
+            with torch.cuda.graph(g, stream=st):
+                run()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        fl = 2.0 * 2 * Bn * 4 * H * H * (T - 1)
+        print("layer recurrence Bn=%d T=%d, %s: %.1f us per layer = %.2f us per timestep, %.1f TFLOP/s"
+              % (Bn, T, "2 chains x %d single-direction launches" % T if two else "%d launches (both directions each)" % T, us, us / T,
+                 fl / us / 1e6))

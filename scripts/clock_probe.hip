@@ -82,8 +82,9 @@ int main(int argc, char** argv) {
     report("gemm_tile", getenv("MMEGO_GEMM_NO_PERSIST") ? 1280 : 1536, 2.0 * (K / 64) * 8 * 16 * 64);
     hipFree(A); hipFree(W); hipFree(C); hipFree(bias);
   }
-  {  // recurrent step of rnn_fast: Bn=512, H=512, both directions; lstm_step_dma2_kernel
+  {  // recurrent step of rnn_fast: Bn=512, H=512, both directions; lstm_step_dma_kernel<HT> (MMEGO_STEP_HT=16|32)
     const int Bn = 512, H = 512, T = 20;
+    mmego_step_dbg = getenv("PROBE_STEP_DBG") ? atoi(getenv("PROBE_STEP_DBG")) : 0;
     float* out = dev_random((size_t)Bn * T * 2 * H, 0.5f, 4);
     float* xp = dev_random((size_t)Bn * T * 8 * H, 0.5f, 5);
     float *w0 = dev_random((size_t)4 * H * H, 0.04f, 6), *w1 = dev_random((size_t)4 * H * H, 0.04f, 7);
@@ -104,7 +105,11 @@ int main(int argc, char** argv) {
     }
     double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("lstm_step Bn=512: %ld launches, %.1f us each (stamped build)\n", n, el / n * 1e6);
-    report("lstm_step_dma2_kernel", 2 * (H / 32) * (Bn / 64), 8.0 * 4 * 32 * 32);
+    {
+      const int ht = getenv("MMEGO_STEP_HT") ? atoi(getenv("MMEGO_STEP_HT")) : 16;
+      // ideal = MFMA issue cycles of the work that shares one SIMD's matrix pipe (two workgroups per CU at HT = 16)
+      report(ht == 16 ? "lstm_step_dma_kernel<16>" : "lstm_step_dma_kernel<32>", 2 * (H / ht) * (Bn / 64), 8.0 * 4 * 32 * 32);
+    }
     hipFree(out); hipFree(xp); hipFree(w0); hipFree(w1); hipFree(b0); hipFree(b1); hipFree(c);
   }
   return 0;

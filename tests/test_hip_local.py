@@ -327,6 +327,71 @@ def test_concurrent_stages_equal_sequential(dev):
         ConcurrentStages([su, sl])
 
 
+def test_stage_engines_with_two_chain_recurrence_in_graphs(dev):
+    """From 128 rows the BiLSTM recurrences of IMU_Net run as two chains on two streams (blocks.lstm_recurrence).  Under graph
+    capture a side stream may only be forked from the capture's origin stream (ROCm defect, scripts/repro_nested_capture_fork.py),
+    and the engines that overlap an IMU_Net forward with other work switch the two-chain form off (blocks.two_chains).  Here:
+    B = 16, T = 8 (128 rows through rnn_fast); per-stage HIP graphs (two captured chains), ConcurrentStages and PipelinedStages
+    graphs, against plain eager StageSteps run one after the other with the one-launch-per-timestep recurrence -- bit-identical
+    losses, gradients, parameters and BatchNorm buffers."""
+    from mmego_amd import blocks, nets
+    from mmego_amd.train_step import ConcurrentStages, PipelinedStages, StageStep
+    gen = torch.Generator().manual_seed(11)
+    Bq, Tq = 16, 8
+    x0 = torch.randn(Bq, Tq, 128, 6, generator=gen)
+    x0[torch.rand(Bq, Tq, 128, generator=gen) < 0.4] = 0.0
+    x0 = x0.to(dev)
+    body = (0.2 * torch.randn(Bq, 20, 3, generator=gen)).to(dev)
+    target = torch.randn(Bq, Tq, 21, 3, generator=gen).to(dev)
+    imus = [torch.randn(Bq, Tq, 20, 15, generator=gen).to(dev) for _ in range(3)]
+
+    def build(own_imu, use_graph=False):
+        torch.manual_seed(95)
+        imu_u = nets.IMUNet(15, 9, 64, 2, True, 0.1).to(dev).eval()
+        imu_l = nets.IMUNet(15, 9, 64, 2, True, 0.1).to(dev).eval()
+        up, lo, fr = nets.UpperNet().to(dev).train(), nets.LowerNet(64).to(dev).train(), nets.UpperNet().to(dev).eval()
+        su = StageStep("upper", up, imu_u if own_imu else None, lr=3e-5, use_graph=use_graph)
+        sl = StageStep("lower", lo, imu_l if own_imu else None, upper_frozen=fr, lr=3e-5, use_graph=use_graph)
+        return su, sl, imu_u, imu_l
+
+    def run(kind):
+        blocks._LSTM_TWO_CHAINS = kind != "reference"
+        try:
+            su, sl, imu_u, imu_l = build(kind != "pipelined", use_graph=kind == "stage_graphs")
+            ib, inext = imus[0].clone(), imus[0].clone()
+            if kind in ("reference", "stage_graphs"):
+                eng = None                   # (stage_graphs: each StageStep its own HIP graph, recurrences as two captured chains)
+            elif kind == "concurrent":
+                eng = ConcurrentStages([su, sl], use_graph=True)
+            else:
+                eng = PipelinedStages([su, sl], [imu_u, imu_l], inext, use_graph=True)
+            for st in (su, sl):
+                st.bind(x0.clone(), ib, body, target)
+            if kind == "pipelined":
+                eng.prime()
+            losses = []
+            for i in range(2):
+                ib.copy_(imus[i]); inext.copy_(imus[i + 1])
+                if eng is None:
+                    su.step(); sl.step()
+                else:
+                    eng.step()
+                losses.append((su.loss.item(), sl.loss.item()))
+            torch.cuda.synchronize()
+            return losses, su, sl
+        finally:
+            blocks._LSTM_TWO_CHAINS = True
+    ref_losses, ru, rl = run("reference")
+    for kind in ("stage_graphs", "concurrent", "pipelined"):
+        losses, su, sl = run(kind)
+        assert losses == ref_losses, (kind, losses, ref_losses)
+        for a, b in ((su, ru), (sl, rl)):
+            assert torch.equal(a.net.flat().flat_g, b.net.flat().flat_g), (kind, a.stage)
+            assert torch.equal(a.net.flat().flat_p, b.net.flat().flat_p), (kind, a.stage)
+            for ba, bb in zip(a.net.buffers(), b.net.buffers()):
+                assert torch.equal(ba, bb), (kind, a.stage)
+
+
 def test_shared_imu_stages_equal_separate_forwards(dev):
     """train_step.SharedImuStages (one IMU_Net forward feeding both stage bodies) == each stage running its own IMU_Net
     forward with the same weights: identical losses, gradients and parameters after two steps."""

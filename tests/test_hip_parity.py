@@ -323,6 +323,63 @@ print("ok")
         assert r.returncode == 0 and "ok" in r.stdout, (bn, h, r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_lstm_recurrence_two_chains_equal_one_launch_per_step(dev, monkeypatch):
+    """blocks.lstm_recurrence: the two directions as two chains of single-direction launches on two streams (64 x 16 tiles, the
+    default from 128 rows) give bit-identical h_t, final c and backward stashes to both directions in one launch per timestep
+    (64 x 32 tiles) -- full and ragged row blocks, eagerly and as a replayed HIP graph -- and match fp64 arithmetic."""
+    from mmego_amd import blocks, ops
+    H = 512
+    torch.manual_seed(41)
+    lstm = blocks.LstmParams(H, H, 1).to(dev)
+    for Bn, Tn, stash in ((512, 20, False), (200, 7, True), (130, 3, False)):
+        xp = torch.randn(Bn * Tn, 8 * H, generator=torch.Generator().manual_seed(100 * Bn)).to(dev)
+        res = []
+        for two, graph in ((True, False), (False, False), (True, True)):
+            monkeypatch.setattr(blocks, "_LSTM_TWO_CHAINS", two)
+            ar = ops.Arena(dev)
+            out = ar.get("out", (Bn * Tn, 2 * H), zero=True)
+            gst = ar.get("gst", (2, Tn, Bn, 4 * H)) if stash else None
+            cst = ar.get("cst", (2, Tn, Bn, H)) if stash else None
+            run = lambda: blocks.lstm_recurrence(ar, "k", lstm, 0, xp, out, Bn, Tn, gst=gst, cst=cst)
+            if graph:
+                run()
+                torch.cuda.synchronize()
+                ops.fill(out, 0.0)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run()
+                g.replay()
+            else:
+                run()
+            torch.cuda.synchronize()
+            res.append((out.clone(), ar.get("k.c", (2, Bn, H)).clone(), None if gst is None else gst.clone(),
+                        None if cst is None else cst.clone()))
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                if a is not None:
+                    assert torch.equal(a, b), (Bn, Tn, stash, (a - b).abs().max().item())
+    Bn, Tn = 256, 5
+    xp = (torch.randn(Bn * Tn, 8 * H, generator=torch.Generator().manual_seed(7)) * 0.5).to(dev)
+    ar = ops.Arena(dev)
+    monkeypatch.setattr(blocks, "_LSTM_TWO_CHAINS", True)
+    out = ar.get("out", (Bn * Tn, 2 * H))
+    blocks.lstm_recurrence(ar, "k", lstm, 0, xp, out, Bn, Tn)
+    x3 = xp.double().view(Bn, Tn, 2, 4 * H).cpu()
+    want = torch.zeros(Bn, Tn, 2, H, dtype=torch.float64)
+    for d in range(2):
+        W, b = lstm.w("weight_hh", 0, d).detach().double().cpu(), lstm.w("bias_hh", 0, d).detach().double().cpu()
+        h = torch.zeros(Bn, H, dtype=torch.float64)
+        c = torch.zeros(Bn, H, dtype=torch.float64)
+        for s_ in range(Tn):
+            t_ = s_ if d == 0 else Tn - 1 - s_
+            g_ = x3[:, t_, d] + b + h @ W.t()
+            i_, f_, gg, o_ = g_.split(H, dim=1)
+            c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(gg)
+            h = torch.sigmoid(o_) * torch.tanh(c)
+            want[:, t_, d] = h
+    assert (out.double().cpu().view(Bn, Tn, 2, H) - want).abs().max().item() < 2e-5
+
+
 def _train_pair(tag, seed, octor, hctor, dev):
     torch.manual_seed(seed)
     o = octor()
