@@ -99,7 +99,9 @@ def mlp3_backward(ar, key, mod, x, y3, dy3, G, need_dx):
         ops.bn_backward(dy, y, z, st, G(bn.weight), G(bn.bias), dz)
         inp = x if i == 1 else ar.get("%s.y%d" % (key, i - 1), (rows, layers[i - 2][0].weight.shape[0]))
         ops.grad_weight(dz, inp, G(conv.weight))
-        ops.colsum(dz, G(conv.bias))
+        # (no bias gradient: a bias in front of a batch-statistics BatchNorm has EXACTLY zero gradient -- the column sums of
+        #  dz vanish identically -- so its slot in the flat gradient buffer simply stays 0; the reference's autograd produces
+        #  rounding noise there, which cannot change any output)
         if i > 1 or need_dx:
             dprev = ar.get("%s.dy%d" % (key, i - 1), (rows, inp.shape[1]))
             ops.grad_input(dz, conv.weight, dprev)
@@ -110,10 +112,11 @@ def mlp3_backward(ar, key, mod, x, y3, dy3, G, need_dx):
 # ---------------------------------------------------------------------------------------------------
 # Linear (+ReLU) with backward
 # ---------------------------------------------------------------------------------------------------
-def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False):
-    """Gradients of y = x W^T + b: writes G(W), G(b); fills dx if given."""
+def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False, bias_grad=True):
+    """Gradients of y = x W^T + b: writes G(W), G(b); fills dx if given.  bias_grad=False: the layer feeds a batch-statistics
+    BatchNorm directly, so the bias gradient is identically zero and its slot in the gradient buffer stays 0."""
     ops.grad_weight(dy, x, G(lin.weight))
-    if lin.bias is not None:
+    if lin.bias is not None and bias_grad:
         ops.colsum(dy, G(lin.bias))
     if dx is not None:
         ops.grad_input(dy, lin.weight, dx, accumulate=accumulate_dx)
@@ -175,11 +178,11 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
         c01 = c0[2 * l + 1] if c0 is not None else None
         hip.call("lstm64_backward", B, T, d_cur, d_cur.stride(0), gates[0], gates[1], cst[0], cst[1], c00, c01,
                  lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1), dg, dg[:, 256:], 512)
+        # weight gradients of both directions per launch (batch dimension = direction)
+        ops.grad_weight_pair(dg, 256, inp, G(lstm.w("weight_ih", l, 0)), G(lstm.w("weight_ih", l, 1)))
+        ops.grad_weight_pair(dg, 256, hprev[0], G(lstm.w("weight_hh", l, 0)), G(lstm.w("weight_hh", l, 1)), X1=hprev[1])
         for d in range(2):
-            dgd = dg[:, d * 256:(d + 1) * 256]
-            ops.grad_weight(dgd, inp, G(lstm.w("weight_ih", l, d)))
-            ops.grad_weight(dgd, hprev[d], G(lstm.w("weight_hh", l, d)))
-            ops.colsum(dgd, G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
+            ops.colsum(dg[:, d * 256:(d + 1) * 256], G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
         if l > 0 or need_dx:
             dinp = ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))
             ops.grad_input(dg[:, :256], lstm.w("weight_ih", l, 0), dinp)

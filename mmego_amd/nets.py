@@ -496,7 +496,7 @@ class LowerNet(_NetBase):
             ops.bn_backward(dcur, out, res_z, st_r, G(blk.residual["1"].weight), G(blk.residual["1"].bias), drz)
             col = ar.get(key + ".col", (rows, cout * blk.taps))
             dcol = ar.get(key + ".dcol", (rows, cout * blk.taps))
-            blocks.linear_backward(dtz, col, blk.tcn["2"], G, dcol)
+            blocks.linear_backward(dtz, col, blk.tcn["2"], G, dcol, bias_grad=False)       # (BatchNorm follows)
             dy0 = ar.get(key + ".dy0", (rows, cout))
             hip.call("col2im_t", dcol, B, T, V, cout, blk.taps, dy0)
             y0, ymix = ar.get(key + ".y0", (rows, cout)), ar.get(key + ".ymix", (rows, cout))
@@ -515,7 +515,7 @@ class LowerNet(_NetBase):
                 ops.bmm(Aeff[k].unsqueeze(0).expand(F, V, V), dy3, dz3[:, :, k * cout:(k + 1) * cout])
             dinp = ar.get(key + ".dinp", (rows, cin))
             blocks.linear_backward(dz, inp, blk.gcn.conv, G, dinp)
-            blocks.linear_backward(drz, inp, blk.residual["0"], G, dinp, accumulate_dx=True)
+            blocks.linear_backward(drz, inp, blk.residual["0"], G, dinp, accumulate_dx=True, bias_grad=False)
             dcur = dinp
         up = ar.get("up", (F, V * 3))
         st = ops.BnState(ar, "gcn.dbn", V * 3)

@@ -137,12 +137,15 @@ def linear(x, W, b, out, relu=False):
 
 
 _SPLIT_K_MIN = int(_os.environ.get("MMEGO_SPLIT_K_MIN", "128"))
+_SPLIT_K_FROM = int(_os.environ.get("MMEGO_SPLIT_K_FROM", "1024"))
 
 
 def pick_split(M, N, K):
     """Split-K factor of a weight-gradient product: these have few output tiles and a long K (the batch rows), and a
     workgroup's k-loop is latency-bound per 64-k step, so K is cut down to one or two steps per workgroup as long as the
     grid stays within ~2 workgroups per CU."""
+    if K <= _SPLIT_K_FROM:
+        return 1        # short K: the K-quartered small-product kernel does it in one launch (no slab-reduce launch behind it)
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     want = max(1, 512 // tiles)
     return int(max(1, min(want, K // _SPLIT_K_MIN)))
@@ -159,6 +162,24 @@ def grad_weight(dY, X, dW):
     """dW[N,K] = dY[rows,N]^T @ X[rows,K]  (fixed-order split over rows)."""
     W2 = dW.view(dW.shape[0], -1)
     return mm(dY.t(), X, W2, nsplit=pick_split(W2.shape[0], W2.shape[1], X.shape[0]))
+
+
+def grad_weight_pair(dY, ncol, X, dW0, dW1, X1=None):
+    """dW0 = dY[:, :ncol]^T @ X and dW1 = dY[:, ncol:2 ncol]^T @ (X1 or X) as ONE batched product (the two directions' weight
+    gradients of a BiLSTM layer; their slots in the flat gradient buffer are a fixed distance apart).  Falls back to two
+    products when the layout does not allow it."""
+    rows, K = X.shape
+    Xb = X if X1 is None else X1
+    W0, W1 = dW0.view(dW0.shape[0], -1), dW1.view(dW1.shape[0], -1)
+    dist, xdist = W1.data_ptr() - W0.data_ptr(), Xb.data_ptr() - X.data_ptr()
+    ok = (W0.shape == W1.shape == (ncol, K) and W0.is_contiguous() and W1.is_contiguous() and dY.stride(1) == 1 and X.stride(1) == 1
+          and Xb.shape == X.shape and Xb.stride() == X.stride() and dist % 16 == 0 and xdist % 16 == 0
+          and pick_split(ncol, K, rows) == 1)
+    if not ok:
+        grad_weight(dY[:, :ncol], X, dW0)
+        grad_weight(dY[:, ncol:2 * ncol], Xb, dW1)
+        return
+    hip.call("gemm", dY, 1, dY.stride(0), X, X.stride(0), 1, W0, K, 1, None, ncol, K, rows, 2, ncol, xdist // 4, dist // 4, 0, 0, None, 1, 0)
 
 
 def grad_input(dY, W, dX, accumulate=False):
