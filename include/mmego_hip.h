@@ -237,6 +237,35 @@ int mmego_add(void* stream, const float* a, const float* b, float* out, long n);
 /* x[i] += 1 for the BatchNorm num_batches_tracked counters (one launch for all layers of a net). */
 int mmego_inc_i64(void* stream, long long* x, long n);
 
+/* ---- train-mode pointwise MLP layers, fused per layer (mlp_train.hip) -------------------------------------------------
+ * k=1 conv -> BatchNorm (batch statistics) -> ReLU stages of Net/Upper_Net.py:242-301,147-177 and Net/Lower_Net.py:40-72 in
+ * training.  Channel widths <= 64.  nblk = mmego_mlp_train_nblk(rows) workgroups per layer launch; statistics partials are
+ * nblk x 2 x 64 doubles, dW partials nblk x 4096 floats.  A BatchNorm "state" is [4][C] floats: mean, invstd, gamma*invstd, beta.
+ *   mmego_mlp_fwd_layer     Z = act(X) W^T + bias, act = ReLU(BatchNorm) of the layer below finalized from in_part (NULL: identity;
+ *                           workgroup 0 stores in_state and updates in_rmean / in_rvar with in_momentum); out_part receives this
+ *                           layer's (sum z, sum z^2).
+ *   mmego_mlp_bn_act        Y = ReLU(BatchNorm(Z)) for the last stage, statistics finalized from part (state, running stats as above).
+ *   mmego_mlp_bn_bwd_reduce part = (sum g, sum g xhat), g = dY . [BatchNorm(Z) > 0]: first reduction of a block's backward chain.
+ *   mmego_mlp_bwd_layer     dz from (dY, Z, state, g_part); dgamma, dbeta; dX = dz W (NULL: skipped); gprev_part = the same
+ *                           two sums for the layer below (Xin = its pre-BN z, in_state its BatchNorm; NULL in_state: Xin is the
+ *                           plain layer input); dW_part = per-workgroup dz^T act(Xin).
+ *   mmego_mlp_dw_reduce     dW_l = fixed-order sum of the nblk partials, up to three layers per launch. */
+int mmego_mlp_train_nblk(long rows);
+int mmego_mlp_fwd_layer(void* stream, const float* X, long ldx, long rows, int Cin, const double* in_part, const float* in_gamma,
+                        const float* in_beta, double in_eps, float* in_rmean, float* in_rvar, double in_momentum,
+                        float* in_state, const float* W, const float* bias, int Cout, float* Z, long ldz, double* out_part);
+int mmego_mlp_bn_act(void* stream, const float* Z, long ldz, long rows, int C, const double* part, const float* gamma,
+                     const float* beta, double eps, float* rmean, float* rvar, double momentum, float* state, float* Y,
+                     long ldy);
+int mmego_mlp_bn_bwd_reduce(void* stream, const float* dY, long lddy, const float* Z, long ldz, long rows, int C,
+                            const float* state, double* part);
+int mmego_mlp_bwd_layer(void* stream, const float* dY, long lddy, const float* Z, long ldz, long rows, int Cout,
+                        const float* state, const double* g_part, float* dgamma, float* dbeta, const float* Xin, long ldxin,
+                        int Cin, const float* in_state, const float* W, float* dX, long lddx, double* gprev_part,
+                        float* dW_part);
+int mmego_mlp_dw_reduce(void* stream, long rows, int nlayers, const float* part0, float* dW0, int Cout0, int Cin0,
+                        const float* part1, float* dW1, int Cout1, int Cin1, const float* part2, float* dW2, int Cout2, int Cin2);
+
 /* ---- optimiser (optim.hip) -------------------------------------------------------------------------
  * torch.optim.Adam step (coupled L2 weight decay) over one flat buffer; state = 3 doubles on the device
  * {step, lr/(1-b1^t), sqrt(1-b2^t)}, advanced by the call itself so a captured graph replays correctly

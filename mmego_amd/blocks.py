@@ -48,9 +48,71 @@ def _mlp3_layers(mod):
     return ((mod.conv1, mod.cb1), (mod.conv2, mod.cb2), (mod.conv3, mod.cb3))
 
 
+_FUSED_TRAIN_MLP = os.environ.get("MMEGO_FUSED_TRAIN_MLP", "1") != "0"
+
+
+def _mlp3_fused_train(mod, x):
+    dims = [mod.conv1.weight.numel() // mod.conv1.weight.shape[0]] + [c.weight.shape[0] for c in (mod.conv1, mod.conv2, mod.conv3)]
+    return _FUSED_TRAIN_MLP and max(dims) <= 64 and x.stride(1) == 1
+
+
+def _mlp3_forward_fused(ar, key, mod, x, out_last):
+    """Training forward of the three stages as 3 + 1 launches (mlp_train.hip): each product applies the PREVIOUS stage's
+    BatchNorm + ReLU while loading its operand and leaves its own column statistics as per-workgroup partials; only the
+    pre-BN tensors z1, z2, z3 and the last stage's output exist in memory."""
+    rows = x.shape[0]
+    nblk = hip.lib().mmego_mlp_train_nblk(rows)
+    cur, part, bn_prev, st_prev = x, None, None, None
+    for i, (conv, bn) in enumerate(_mlp3_layers(mod), 1):
+        C = conv.weight.shape[0]
+        K = conv.weight.numel() // C
+        z = ar.get("%s.z%d" % (key, i), (rows, C))
+        part_i = ar.get("%s.sp%d" % (key, i), (nblk * 2 * 64,), dtype=torch.float64)
+        if part is None:
+            hip.call("mlp_fwd_layer", cur, cur.stride(0), rows, K, None, None, None, 0.0, None, None, 0.0, None,
+                     conv.weight, conv.bias, C, z, z.stride(0), part_i)
+        else:
+            hip.call("mlp_fwd_layer", cur, cur.stride(0), rows, K, part, bn_prev.weight, bn_prev.bias, float(bn_prev.eps),
+                     bn_prev.running_mean, bn_prev.running_var, float(bn_prev.momentum), st_prev.all,
+                     conv.weight, conv.bias, C, z, z.stride(0), part_i)
+        cur, part, bn_prev, st_prev = z, part_i, bn, ops.BnState(ar, "%s.bn%d" % (key, i), C)
+    hip.call("mlp_bn_act", cur, cur.stride(0), rows, cur.shape[1], part, bn_prev.weight, bn_prev.bias, float(bn_prev.eps),
+             bn_prev.running_mean, bn_prev.running_var, float(bn_prev.momentum), st_prev.all, out_last, out_last.stride(0))
+    return out_last
+
+
+def _mlp3_backward_fused(ar, key, mod, x, dy3, G, need_dx):
+    """Backward of the three stages as 1 + 3 + 1 launches: per stage ONE pass computes dz, dX (the next stage's dy), the
+    per-workgroup dW partial and the BatchNorm sums of the stage below; a last launch sums the dW partials of all three."""
+    rows = x.shape[0]
+    nblk = hip.lib().mmego_mlp_train_nblk(rows)
+    layers = _mlp3_layers(mod)
+    dims = [layers[0][0].weight.numel() // layers[0][0].weight.shape[0]] + [c.weight.shape[0] for c, _ in layers]
+    zs = [None] + [ar.get("%s.z%d" % (key, i), (rows, dims[i])) for i in (1, 2, 3)]
+    sts = [None] + [ops.BnState(ar, "%s.bn%d" % (key, i), dims[i]) for i in (1, 2, 3)]
+    gp = [None] + [ar.get("%s.gp%d" % (key, i), (nblk * 2 * 64,), dtype=torch.float64) for i in (1, 2, 3)]
+    dwp = [None] + [ar.get("%s.dwp%d" % (key, i), (nblk * 4096,)) for i in (1, 2, 3)]
+    hip.call("mlp_bn_bwd_reduce", dy3, dy3.stride(0), zs[3], zs[3].stride(0), rows, dims[3], sts[3].all, gp[3])
+    dy = dy3
+    for i in (3, 2, 1):
+        conv, bn = layers[i - 1]
+        xin = zs[i - 1] if i > 1 else x
+        want_dx = i > 1 or need_dx
+        dprev = ar.get("%s.dy%d" % (key, i - 1), (rows, dims[i - 1])) if want_dx else None
+        hip.call("mlp_bwd_layer", dy, dy.stride(0), zs[i], zs[i].stride(0), rows, dims[i], sts[i].all, gp[i], G(bn.weight), G(bn.bias),
+                 xin, xin.stride(0), dims[i - 1], sts[i - 1].all if i > 1 else None, conv.weight, dprev,
+                 dprev.stride(0) if want_dx else 0, gp[i - 1] if i > 1 else None, dwp[i])
+        dy = dprev
+    hip.call("mlp_dw_reduce", rows, 3, dwp[1], G(layers[0][0].weight), dims[1], dims[0], dwp[2], G(layers[1][0].weight), dims[2],
+             dims[1], dwp[3], G(layers[2][0].weight), dims[3], dims[2])
+    return dy if need_dx else None
+
+
 def mlp3_forward(ar, key, mod, x, out_last, training):
     rows = x.shape[0]
     cur = x
+    if training and _mlp3_fused_train(mod, x) and out_last.stride(1) == 1:
+        return _mlp3_forward_fused(ar, key, mod, x, out_last)
     if not training:
         # eval: BatchNorm folded into the convs (bn_fold_linear), then the three stages in ONE kernel whose intermediates
         # stay in LDS (mlp3.hip) -- no pre-BN tensors, no per-point 32/48/64-channel activations in HBM
@@ -86,6 +148,8 @@ def mlp3_forward(ar, key, mod, x, out_last, training):
 
 
 def mlp3_backward(ar, key, mod, x, y3, dy3, G, need_dx):
+    if _mlp3_fused_train(mod, x) and dy3.stride(1) == 1:
+        return _mlp3_backward_fused(ar, key, mod, x, dy3, G, need_dx)
     rows = x.shape[0]
     layers = _mlp3_layers(mod)
     dy = dy3

@@ -233,6 +233,7 @@ class BnState:
 
     def __init__(self, arena, key, C):
         v = arena.get(key, (4, C))
+        self.all = v
         self.mean, self.invstd, self.a, self.b = v[0], v[1], v[2], v[3]
         self.C = C
 

@@ -8,7 +8,7 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, grid_x, grid_y, grid_z, workgroup_x, end-start from kernels order by start"))
 short = lambda n: re.sub(r"\(.*", "", n).replace("void ", "")
-nper = sum(1 for r in rows if "lstm_step_dma2_kernel" in r[0]) / 80.0   # 80 rnn_fast recurrent steps per U+L step
+nper = sum(1 for r in rows if "gemm_tile_persistent_kernel<true, true" in r[0]) / 4.0   # 4 batched input projections per U+L step
 pos = [a for a in sys.argv[2:] if not a.startswith("--")]
 steps = float(pos[0]) if pos else (nper or 1.0)
 tot = sum(r[5] for r in rows)
