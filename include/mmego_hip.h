@@ -228,6 +228,19 @@ int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, cons
 int mmego_graph_dA_nblk(long G);
 int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* partial_ws);
 /* Temporal 9x1 unfold / fold of a channels-last (B,T,V,C) tensor (GCN.py:109-116). */
+/* ---- ST-GCN layer pieces (gcn.hip): Net/GCN.py:55-64 (graph convolution einsum), :108-122 (9x1 temporal convolution) --------
+ * mmego_graph_mix: Y[f][w][c] = sum_k sum_v (A . importance)[k][v][w] X[f][v][k*C + c]  (backward = 0; X is z [F][V][K*C]), or the
+ * input gradient Y[f][v][k*C + c] = sum_w (A . importance)[k][v][w] X[f][w][c] (backward = 1; X is dy [F][V][C]).
+ * mmego_tconv: temporal convolution over rows (b, t, v) as an implicit GEMM, out[r][n] = bias[n] + sum_tap sum_k
+ * act(X[r + (tap - taps/2) V][k]) W[tap*wts + n*wns + k*wks], taps leaving the sequence contribute zero; act = ReLU(BatchNorm)
+ * given by in_state [4][Cin] (mean, invstd, gamma*invstd, beta) or identity (NULL).  Conv weight [Cout][Cin][taps] as it is:
+ * (wts, wns, wks) = (1, Cin*taps, taps); its input gradient: X = dY, W pointing at the last tap, (-1, taps, Cin*taps).
+ * mmego_tconv_pack: W[co][ci][tap] -> [tap][co][ci] (mode 0) / [taps-1-tap][ci][co] (mode 1) for frozen nets (k-contiguous reads). */
+int mmego_graph_mix(void* stream, const float* X, const float* A, const float* importance, float* Y, long F, int V, int K, int C,
+                    int backward);
+int mmego_tconv_pack(void* stream, const float* W, int Co, int Ci, int taps, int mode, float* Wp);
+int mmego_tconv(void* stream, const float* X, long ldx, const float* in_state, const float* W, long wts, long wns, long wks,
+                const float* bias, float* Y, long ldy, int B, int T, int V, int Cin, int Cout, int taps);
 int mmego_im2col_t(void* stream, const float* X, int B, int T, int V, int C, int taps, float* col);
 int mmego_col2im_t(void* stream, const float* dcol, int B, int T, int V, int C, int taps, float* dX);
 /* out[b][c][r] = in[b][r][c]: the (B,64,T,V)->(B,T,V,64) re-view of GCN.py:351-353 (quirk Q8). */

@@ -1,0 +1,190 @@
+// ST-GCN layer pieces of Lower_Net's KeyEncoder (reference Net/GCN.py:55-64 ConvTemporalGraphical, :108-122 the 9x1 temporal
+// convolution of st_gcn.tcn) on channels-last rows (b, t, v):
+//   graph_mix    einsum('nkctv,kvw->nctw', x, A * edge_importance): y[f][w][c] = sum_k sum_v (A.imp)[k][v][w] z[f][v][k*C + c],
+//                and its input gradient dz[f][v][k*C + c] = sum_w (A.imp)[k][v][w] dy[f][w][c].  A . edge_importance is formed
+//                in LDS by the kernel itself (no `mul` launch, no K batched-product launches with a broadcast 15 x 15 operand),
+//                a frame's z tile is staged in LDS once and every output is a 15-term dot product from there.
+//   tconv        the 9x1 temporal convolution (padding 4) as an IMPLICIT GEMM: out[r][co] = b[co] + sum_tap sum_ci
+//                act(in[r + (tap-4) V][ci]) W[co][ci][tap], rows (b, t, v), taps that leave the sequence contribute zero.  The
+//                unfolded operand (im2col_t: 9x the activation, 9.4 GB per config-5 forward) never exists: per tap the A tile is
+//                the SAME 64 rows shifted by (tap-4) V rows.  The preceding BatchNorm + ReLU (st_gcn.tcn[0..1]) is applied while
+//                the tile is loaded.  The input gradient of the convolution is the same kernel on flipped, transposed weights
+//                (tconv_pack mode 1), so col2im_t disappears as well.
+//                The weight element (tap, n, k) is addressed through three strides, so the conv weight [co][ci][tap] serves as it
+//                is (training: the weights change every step) -- forward (tap, co, ci) -> (1, Ci*taps, taps), input gradient on
+//                a pointer to the LAST tap with (-1, taps, Ci*taps) -- or re-packed k-contiguous for frozen nets:
+//   tconv_pack   W[co][ci][tap] -> Wp[tap][co][ci] (mode 0) or Wp[tap][ci][co] with the taps reversed (mode 1).
+// 64 x 64 output tiles, v_mfma_f32_32x32x2_f32, operands in LDS with a 65-float row stride, next chunk prefetched in registers.
+#include "common.h"
+
+#define GC_S 66          // even row stride: fragments are read as aligned float2 (lanes r = 0..31 hit 64 distinct banks)
+
+__global__ __launch_bounds__(256) void graph_mix_kernel(const float* __restrict__ X, const float* __restrict__ A,
+                                                        const float* __restrict__ imp, float* __restrict__ Y, long F, int V,
+                                                        int Kk, int C, int backward) {
+  extern __shared__ float sm[];
+  // forward : X = z [F][V][Kk*C] -> Y = y [F][V][C];   backward: X = dy [F][V][C] -> Y = dz [F][V][Kk*C]
+  const int Cin = backward ? C : Kk * C, Cout = backward ? Kk * C : C;
+  float* As = sm;                          // [Kk][V][V]  A . importance
+  float* Xs = sm + Kk * V * V;             // [V][Cin + 1]
+  for (int i = threadIdx.x; i < Kk * V * V; i += blockDim.x) As[i] = A[i] * imp[i];
+  for (long f = blockIdx.x; f < F; f += gridDim.x) {
+    __syncthreads();
+    const float* xf = X + f * V * Cin;
+    for (int i = threadIdx.x; i < V * Cin; i += blockDim.x) Xs[(i / Cin) * (Cin + 1) + (i % Cin)] = xf[i];
+    __syncthreads();
+    float* yf = Y + f * V * Cout;
+    for (int i = threadIdx.x; i < V * Cout; i += blockDim.x) {
+      const int row = i / Cout, col = i - row * Cout;
+      float acc = 0.f;
+      if (!backward) {                     // row = w, col = c
+        for (int k = 0; k < Kk; ++k)
+          for (int v = 0; v < V; ++v) acc += As[(k * V + v) * V + row] * Xs[v * (Cin + 1) + k * C + col];
+      } else {                             // row = v, col = k*C + c
+        const int k = col / C, c = col - k * C;
+        for (int w = 0; w < V; ++w) acc += As[(k * V + row) * V + w] * Xs[w * (Cin + 1) + c];
+      }
+      yf[i] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tconv_pack_kernel(const float* __restrict__ W, int Co, int Ci, int taps, int mode,
+                                                         float* __restrict__ Wp) {
+  const long total = (long)Co * Ci * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const long q = i / taps;
+    const int ci = (int)(q % Ci), co = (int)(q / Ci);
+    if (mode == 0) Wp[((long)tap * Co + co) * Ci + ci] = W[i];
+    else Wp[((long)(taps - 1 - tap) * Ci + ci) * Co + co] = W[i];
+  }
+}
+
+struct TconvP {
+  const float* X; long ldx;          // input rows (b, t, v) x Cin
+  const float* in_state;             // [4][Cin] mean, invstd, a, b of the BatchNorm in front (+ ReLU); null: plain input
+  const float* W; long wts, wns, wks; // weight element (tap, n = output channel, k = input channel) at W[tap*wts + n*wns + k*wks]
+  const float* bias;                 // [Cout] or null
+  float* Y; long ldy;
+  long rows; int T, V, Cin, Cout, taps;
+};
+
+// acc[32x32] += A[32 rows][K] . B[32 rows][K]^T (row-major LDS tiles, stride GC_S), K a multiple of 4 (zero padded).
+// One ds_read_b64 per operand feeds two MFMA steps: lane (r, h) holds k = 4j + 2h, 4j + 2h + 1 -- the same k-permutation on
+// both operands, so the sum over k is unchanged.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// workgroup tile: (64 RT) rows x 64 output channels; every wave owns RT row tiles of 32 sharing one B fragment, so the weight
+// tile -- re-fetched for every tap and channel chunk -- is amortised over RT x more rows (RT = 1 is what runs: see mmego_tconv)
+template <int RT>
+__global__ __launch_bounds__(256) void tconv_kernel(TconvP p) {
+  __shared__ float As[RT * 64 * GC_S], Bs[64 * GC_S];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rt = wave & 1, ct = wave >> 1;
+  const long r0 = (long)blockIdx.x * 64 * RT;
+  const int n0 = blockIdx.y * 64;
+  const int half = p.taps / 2;
+  const int xk = tid & 63, xr = tid >> 6;
+  const int nkc = (p.Cin + 63) / 64;                       // 64-channel chunks per tap
+  const int nchunks = p.taps * nkc;
+  // this thread's 16 RT rows of the tile: their frame index t (taps that leave [0, T) are masked)
+  int tt[16 * RT];
+#pragma unroll
+  for (int j = 0; j < 16 * RT; ++j) {
+    const long row = r0 + xr + 4 * j;
+    tt[j] = row < p.rows ? (int)((row / p.V) % p.T) : -1000000;
+  }
+  float av[16 * RT], bv[16];
+#define TC_FETCH(ch)                                                                                \
+  do {                                                                                              \
+    const int tap_ = (ch) / nkc, k0_ = ((ch) % nkc) * 64;                                           \
+    const int d_ = tap_ - half;                                                                     \
+    const int kc_ = k0_ + xk;                                                                       \
+    const bool kok_ = kc_ < p.Cin;                                                                  \
+    float mu_ = 0.f, a_ = 1.f, b_ = 0.f;                                                            \
+    if (p.in_state && kok_) { mu_ = p.in_state[kc_]; a_ = p.in_state[2 * p.Cin + kc_]; b_ = p.in_state[3 * p.Cin + kc_]; } \
+    _Pragma("unroll") for (int j = 0; j < 16 * RT; ++j) {                                           \
+      const int ts_ = tt[j] + d_;                                                                   \
+      const bool ok_ = kok_ && ts_ >= 0 && ts_ < p.T;                                               \
+      float v_ = ok_ ? p.X[(r0 + xr + 4 * j + (long)d_ * p.V) * p.ldx + kc_] : 0.f;                 \
+      if (p.in_state) v_ = ok_ ? fmaxf(__builtin_fmaf(v_ - mu_, a_, b_), 0.f) : 0.f;                \
+      av[j] = v_;                                                                                   \
+    }                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                \
+      const int n_ = n0 + xr + 4 * j;                                                               \
+      bv[j] = (n_ < p.Cout && kok_) ? p.W[tap_ * p.wts + n_ * p.wns + kc_ * p.wks] : 0.f;           \
+    }                                                                                               \
+  } while (0)
+  TC_FETCH(0);
+  f32x16 acc[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) acc[i] = (f32x16){0};
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16 * RT; ++j) As[(xr + 4 * j) * GC_S + xk] = av[j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Bs[(xr + 4 * j) * GC_S + xk] = bv[j];
+    __syncthreads();
+    if (ch + 1 < nchunks) TC_FETCH(ch + 1);
+    const int kleft = p.Cin - (ch % nkc) * 64;
+    const int K = kleft >= 64 ? 64 : ((kleft + 3) & ~3);
+    {
+      const int r = lane & 31, h = lane >> 5;
+      const f32x2* bp = reinterpret_cast<const f32x2*>(Bs + (ct * 32 + r) * GC_S + 2 * h);
+      const f32x2* ap = reinterpret_cast<const f32x2*>(As + (rt * 32 + r) * GC_S + 2 * h);
+#pragma unroll 4
+      for (int k = 0; k < K; k += 4) {
+        const f32x2 b = bp[k >> 1];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const f32x2 a = ap[(i * 64 * GC_S + k) >> 1];
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int col = n0 + ct * 32 + (lane & 31);
+  if (col < p.Cout) {
+    const float bb = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const long row = r0 + i * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (row < p.rows) p.Y[row * p.ldy + col] = acc[i][reg] + bb;
+      }
+  }
+}
+
+extern "C" int mmego_graph_mix(void* stream, const float* X, const float* A, const float* importance, float* Y, long F, int V, int K,
+                               int C, int backward) {
+  MMEGO_REQUIRE(X && A && importance && Y && F > 0 && V >= 1 && V <= 32 && K >= 1 && K <= 4 && C >= 1);
+  const int Cin = backward ? C : K * C;
+  const size_t lds = (size_t)(K * V * V + V * (Cin + 1)) * sizeof(float);
+  MMEGO_REQUIRE(lds <= 64 * 1024);
+  const int grid = (int)(F < 2048 ? F : 2048);
+  hipLaunchKernelGGL(graph_mix_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, A, importance, Y, F, V, K, C, backward);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_tconv_pack(void* stream, const float* W, int Co, int Ci, int taps, int mode, float* Wp) {
+  MMEGO_REQUIRE(W && Wp && Co >= 1 && Ci >= 1 && taps >= 1 && (mode == 0 || mode == 1));
+  long b = ((long)Co * Ci * taps + 255) / 256;
+  hipLaunchKernelGGL(tconv_pack_kernel, dim3((int)(b > 1024 ? 1024 : b)), dim3(256), 0, (hipStream_t)stream, W, Co, Ci, taps, mode, Wp);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_tconv(void* stream, const float* X, long ldx, const float* in_state, const float* W, long wts, long wns, long wks,
+                           const float* bias, float* Y, long ldy, int B, int T, int V, int Cin, int Cout, int taps) {
+  MMEGO_REQUIRE(X && W && Y && B > 0 && T > 0 && V > 0 && Cin >= 1 && Cout >= 1 && taps >= 1 && (taps & 1) && ldx >= Cin && ldy >= Cout);
+  TconvP p = {X, ldx, in_state, W, wts, wns, wks, bias, Y, ldy, (long)B * T * V, T, V, Cin, Cout, taps};
+  // (128-row tiles, RT = 2, measured slower at every size: 3.19 ms against 2.98 ms for the three config-5 launches)
+  dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((Cout + 63) / 64));
+  hipLaunchKernelGGL(tconv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

@@ -355,7 +355,8 @@ class LowerNet(_NetBase):
             ops.gather_rows(x.view(F * N, Cx), flat_idx, sel)
         self.last_select_idx = idx
         prow = F * LOWER_POINTS
-        p_vec = ar.get("p_vec", (prow, 64))
+        both = ar.get("both", (prow, 128))                      # [p_vec | cross-attention output]: p_vec is written in place
+        p_vec = both[:, :64]
         ops.copy2d(sel[:, :3], p_vec[:, :3])
         blocks.mlp3_forward(ar, "base", self.pointEncoder.module0, sel, p_vec[:, 3:64], training)
 
@@ -366,8 +367,6 @@ class LowerNet(_NetBase):
         ops.linear(p_vec, fu.to_q.weight, fu.to_q.bias, Qm)
         ops.linear(k_vec, fu.to_k.weight, fu.to_k.bias, Km)
         ops.linear(k_vec, fu.to_v.weight, fu.to_v.bias, Vm)
-        both = ar.get("both", (prow, 128))
-        ops.copy2d(p_vec, both[:, :64])
         Pm = ar.get("Pm", (F, LOWER_POINTS, V))
         hip.call("cross_attn_forward", Qm, Km, Vm, F, float(fu.scale), both[:, 64:], 128, Pm)
         ak = ar.get("ak", (F, 192))
@@ -394,6 +393,18 @@ class LowerNet(_NetBase):
             self._saved = (B, T, N, R, body)
         return l, q
 
+    def _packed_tconv(self, i, wt, taps):
+        """Temporal-conv weight of block i re-packed [tap][co][ci] (k-contiguous tile loads) for eval-mode forwards; rebuilt
+        only when the weight tensor changed."""
+        cache = self.__dict__.setdefault("_tconv_packed", {})
+        ver = (wt._version, wt.data_ptr())
+        ent = cache.get(i)
+        if ent is None or ent[0] != ver:
+            wp = torch.empty(wt.numel(), dtype=torch.float32, device=wt.device)
+            hip.call("tconv_pack", wt, wt.shape[0], wt.shape[1], taps, 0, wp)
+            ent = cache[i] = (ver, wp)
+        return ent[1]
+
     # -- ST-GCN (Net/GCN.py:332-355) on channels-last rows (b,t,v) ------------------------------------
     def _gcn_forward(self, ar, up, B, T, training):
         gcn = self.keyEncoder.gcn
@@ -406,24 +417,25 @@ class LowerNet(_NetBase):
         for i, blk in enumerate(gcn.gcn_networks):
             cin, cout, K = blk.cin, blk.cout, blk.K
             key = "gcn.b%d" % i
-            Aeff = ar.get(key + ".A", (K, V, V))
-            hip.call("mul", gcn.A, gcn.edge_importance[i], Aeff, Aeff.numel())
             res_z = ar.get(key + ".rz", (rows, cout))
             ops.linear(cur, blk.residual["0"].weight, blk.residual["0"].bias, res_z)
             st_r = ops.bn_stats(ar, key + ".bnr", res_z, blk.residual["1"], training)
             z = ar.get(key + ".z", (rows, K * cout))
             ops.linear(cur, blk.gcn.conv.weight, blk.gcn.conv.bias, z)
             ymix = ar.get(key + ".ymix", (rows, cout))
-            z3, y3 = z.view(F, V, K * cout), ymix.view(F, V, cout)
-            for k in range(K):                               # einsum('nkctv,kvw->nctw'): y[w,c] = sum_v A[k,v,w] z_k[v,c]
-                ops.bmm(Aeff[k].t().unsqueeze(0).expand(F, V, V), z3[:, :, k * cout:(k + 1) * cout], y3, accumulate=k > 0)
+            # einsum('nkctv,kvw->nctw', z, A * edge_importance): one launch, A . importance formed in LDS (gcn.hip)
+            hip.call("graph_mix", z, gcn.A, gcn.edge_importance[i], ymix, F, V, K, cout, 0)
             st0 = ops.bn_stats(ar, key + ".bn0", ymix, blk.tcn["0"], training)
-            y0 = ar.get(key + ".y0", (rows, cout))
-            ops.affine_act(ymix, st0, y0, relu=True)
-            col = ar.get(key + ".col", (rows, cout * blk.taps))
-            hip.call("im2col_t", y0, B, T, V, cout, blk.taps, col)
             tz = ar.get(key + ".tz", (rows, cout))
-            ops.linear(col, blk.tcn["2"].weight, blk.tcn["2"].bias, tz)
+            wt = blk.tcn["2"].weight                          # [cout, cout, taps, 1]
+            if training:
+                y0 = ar.get(key + ".y0", (rows, cout))         # (kept: the backward pass needs it)
+                ops.affine_act(ymix, st0, y0, relu=True)
+                hip.call("tconv", y0, cout, None, wt, 1, cout * blk.taps, blk.taps, blk.tcn["2"].bias, tz, cout, B, T, V, cout, cout, blk.taps)
+            else:
+                # frozen net: BatchNorm + ReLU applied while the convolution loads its tiles, weights re-packed k-contiguous once
+                hip.call("tconv", ymix, cout, st0.all, self._packed_tconv(i, wt, blk.taps), cout * cout, cout, 1, blk.tcn["2"].bias, tz,
+                         cout, B, T, V, cout, cout, blk.taps)
             st3 = ops.bn_stats(ar, key + ".bn3", tz, blk.tcn["3"], training)
             out = ar.get(key + ".out", (rows, cout))
             ops.affine_act(tz, st3, out, relu=True, X2=res_z, st2=st_r)
@@ -466,7 +478,7 @@ class LowerNet(_NetBase):
         Pm = ar.get("Pm", (F, LOWER_POINTS, V))
         dQ, dK, dV = ar.get("dQ", (prow, 64)), ar.get("dK", (F * V, 64)), ar.get("dV", (F * V, 64))
         hip.call("cross_attn_backward", Qm, Km, Vm, Pm, dboth[:, 64:], 128, F, float(fu.scale), dQ, dK, dV)
-        p_vec = ar.get("p_vec", (prow, 64))
+        p_vec = ar.get("both", (prow, 128))[:, :64]
         k_vec = ar.get("gcn.kv", (B, 64, T * V)).view(F * V, 64)
         blocks.linear_backward(dQ, p_vec, fu.to_q, G, dp, accumulate_dx=True)
         blocks.linear_backward(dK, k_vec, fu.to_k, G, dk, accumulate_dx=True)
@@ -494,25 +506,27 @@ class LowerNet(_NetBase):
             dtz, drz = ar.get(key + ".dtz", (rows, cout)), ar.get(key + ".drz", (rows, cout))
             ops.bn_backward(dcur, out, tz, st3, G(blk.tcn["3"].weight), G(blk.tcn["3"].bias), dtz)
             ops.bn_backward(dcur, out, res_z, st_r, G(blk.residual["1"].weight), G(blk.residual["1"].bias), drz)
-            col = ar.get(key + ".col", (rows, cout * blk.taps))
-            dcol = ar.get(key + ".dcol", (rows, cout * blk.taps))
-            blocks.linear_backward(dtz, col, blk.tcn["2"], G, dcol, bias_grad=False)       # (BatchNorm follows)
-            dy0 = ar.get(key + ".dy0", (rows, cout))
-            hip.call("col2im_t", dcol, B, T, V, cout, blk.taps, dy0)
             y0, ymix = ar.get(key + ".y0", (rows, cout)), ar.get(key + ".ymix", (rows, cout))
+            # weight gradient of the temporal convolution from the unfolded y0 (built here, in the backward pass only);
+            # no bias gradient: a batch-statistics BatchNorm follows
+            col = ar.get(key + ".col", (rows, cout * blk.taps))
+            hip.call("im2col_t", y0, B, T, V, cout, blk.taps, col)
+            blocks.linear_backward(dtz, col, blk.tcn["2"], G, None, bias_grad=False)
+            # input gradient = the same implicit-GEMM convolution of dtz with the taps reversed and (co, ci) swapped
+            dy0 = ar.get(key + ".dy0", (rows, cout))
+            wt = blk.tcn["2"].weight
+            hip.call("tconv", dtz, cout, None, wt.data_ptr() + 4 * (blk.taps - 1), -1, blk.taps, cout * blk.taps, None, dy0, cout,
+                     B, T, V, cout, cout, blk.taps)
             dymix = ar.get(key + ".dymix", (rows, cout))
             ops.bn_backward(dy0, y0, ymix, st0, G(blk.tcn["0"].weight), G(blk.tcn["0"].bias), dymix)
             z = ar.get(key + ".z", (rows, K * cout))
-            Aeff = ar.get(key + ".A", (K, V, V))
             dA = ar.get(key + ".dA", (K, V, V))
             dAp = ar.get(key + ".dAp", (hip.lib().mmego_graph_dA_nblk(F), K * V * V))
             hip.call("graph_dA", z, dymix, F, V, K, cout, dAp)
             ops.colsum(dAp, dA.view(-1))
             hip.call("mul", dA, gcn.A, G(gcn.edge_importance[i]), dA.numel())
             dz = ar.get(key + ".dz", (rows, K * cout))
-            dz3, dy3 = dz.view(F, V, K * cout), dymix.view(F, V, cout)
-            for k in range(K):                                   # dz_k[v,c] = sum_w A[k,v,w] dy[w,c]
-                ops.bmm(Aeff[k].unsqueeze(0).expand(F, V, V), dy3, dz3[:, :, k * cout:(k + 1) * cout])
+            hip.call("graph_mix", dymix, gcn.A, gcn.edge_importance[i], dz, F, V, K, cout, 1)    # dz_k[v] = sum_w (A.imp)[k,v,w] dy[w]
             dinp = ar.get(key + ".dinp", (rows, cin))
             blocks.linear_backward(dz, inp, blk.gcn.conv, G, dinp)
             blocks.linear_backward(drz, inp, blk.residual["0"], G, dinp, accumulate_dx=True, bias_grad=False)
