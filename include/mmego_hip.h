@@ -235,7 +235,8 @@ int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V,
  * act(X[r + (tap - taps/2) V][k]) W[tap*wts + n*wns + k*wks], taps leaving the sequence contribute zero; act = ReLU(BatchNorm)
  * given by in_state [4][Cin] (mean, invstd, gamma*invstd, beta) or identity (NULL).  Conv weight [Cout][Cin][taps] as it is:
  * (wts, wns, wks) = (1, Cin*taps, taps); its input gradient: X = dY, W pointing at the last tap, (-1, taps, Cin*taps).
- * mmego_tconv_pack: W[co][ci][tap] -> [tap][co][ci] (mode 0) / [taps-1-tap][ci][co] (mode 1) for frozen nets (k-contiguous reads). */
+ * mmego_tconv_pack: W[co][ci][tap] -> [tap][co][ci] (mode 0) / [taps-1-tap][ci][co] (mode 1) / both, one behind the other (mode 2):
+ * k-contiguous tile loads for mmego_tconv, strides (Cout*Cin, Cin, 1). */
 int mmego_graph_mix(void* stream, const float* X, const float* A, const float* importance, float* Y, long F, int V, int K, int C,
                     int backward);
 int mmego_tconv_pack(void* stream, const float* W, int Co, int Ci, int taps, int mode, float* Wp);

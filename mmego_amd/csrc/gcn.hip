@@ -10,10 +10,12 @@
 //                the SAME 64 rows shifted by (tap-4) V rows.  The preceding BatchNorm + ReLU (st_gcn.tcn[0..1]) is applied while
 //                the tile is loaded.  The input gradient of the convolution is the same kernel on flipped, transposed weights
 //                (tconv_pack mode 1), so col2im_t disappears as well.
-//                The weight element (tap, n, k) is addressed through three strides, so the conv weight [co][ci][tap] serves as it
-//                is (training: the weights change every step) -- forward (tap, co, ci) -> (1, Ci*taps, taps), input gradient on
-//                a pointer to the LAST tap with (-1, taps, Ci*taps) -- or re-packed k-contiguous for frozen nets:
-//   tconv_pack   W[co][ci][tap] -> Wp[tap][co][ci] (mode 0) or Wp[tap][ci][co] with the taps reversed (mode 1).
+//                The weight element (tap, n, k) is addressed through three strides; the conv weight [co][ci][tap] as it is would
+//                work (forward (1, Ci*taps, taps), input gradient from the LAST tap with (-1, taps, Ci*taps)) but puts the 64 lanes
+//                of a tile load 36 B / 4.6 KB apart (measured: 61 us per launch at the training shape), so the weights are
+//                re-packed k-contiguous first:
+//   tconv_pack   W[co][ci][tap] -> Wp[tap][co][ci] (mode 0) or Wp[tap][ci][co] with the taps reversed (mode 1); mode 2 writes both,
+//                one behind the other (a training step packs once in its forward pass and uses the second half in backward).
 // 64 x 64 output tiles, v_mfma_f32_32x32x2_f32, operands in LDS with a 65-float row stride, next chunk prefetched in registers.
 #include "common.h"
 
@@ -56,8 +58,9 @@ __global__ __launch_bounds__(256) void tconv_pack_kernel(const float* __restrict
     const int tap = (int)(i % taps);
     const long q = i / taps;
     const int ci = (int)(q % Ci), co = (int)(q / Ci);
-    if (mode == 0) Wp[((long)tap * Co + co) * Ci + ci] = W[i];
-    else Wp[((long)(taps - 1 - tap) * Ci + ci) * Co + co] = W[i];
+    const float w = W[i];
+    if (mode != 1) Wp[((long)tap * Co + co) * Ci + ci] = w;                                      // mode 0 / 2: forward pack
+    if (mode != 0) Wp[(mode == 2 ? total : 0) + ((long)(taps - 1 - tap) * Ci + ci) * Co + co] = w;   // mode 1 / 2: gradient pack
   }
 }
 
@@ -74,87 +77,113 @@ struct TconvP {
 // One ds_read_b64 per operand feeds two MFMA steps: lane (r, h) holds k = 4j + 2h, 4j + 2h + 1 -- the same k-permutation on
 // both operands, so the sum over k is unchanged.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// workgroup tile: (64 RT) rows x 64 output channels; every wave owns RT row tiles of 32 sharing one B fragment, so the weight
-// tile -- re-fetched for every tap and channel chunk -- is amortised over RT x more rows (RT = 1 is what runs: see mmego_tconv)
-template <int RT>
-__global__ __launch_bounds__(256) void tconv_kernel(TconvP p) {
-  __shared__ float As[RT * 64 * GC_S], Bs[64 * GC_S];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Workgroup = NG groups of 4 waves on ONE 64 x 64 output tile; group g takes the (tap, channel-chunk) steps g, g + NG, ... with
+// operand tiles of its own, so NG steps' loads are in flight at once, and the groups' partial tiles are added through LDS in a
+// fixed order at the end.  NG = 4 for small row counts (the training shape: 120 row tiles, where one step at a time left the
+// kernel waiting on 9-18 dependent memory round trips), NG = 1 when the grid alone fills the chip.
+template <int NG>
+__global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = t >> 6;
+  float* As = smem + grp * 2 * 64 * GC_S;
+  float* Bs = As + 64 * GC_S;
   const int rt = wave & 1, ct = wave >> 1;
-  const long r0 = (long)blockIdx.x * 64 * RT;
+  const long r0 = (long)blockIdx.x * 64;
   const int n0 = blockIdx.y * 64;
   const int half = p.taps / 2;
-  const int xk = tid & 63, xr = tid >> 6;
+  const int xk = t & 63, xr = t >> 6;
   const int nkc = (p.Cin + 63) / 64;                       // 64-channel chunks per tap
   const int nchunks = p.taps * nkc;
-  // this thread's 16 RT rows of the tile: their frame index t (taps that leave [0, T) are masked)
-  int tt[16 * RT];
+  // this thread's 16 rows of the tile (rows xr + 4 j): their frame index t, four per register as signed bytes (taps that leave
+  // [0, T) are masked; rows past the end count as t = -128).  Addresses are kept as uniform row pointers (scalar registers)
+  // plus ONE 32-bit lane offset per operand: spelled out per element, the 32 loads of a step cost 64 address registers and the
+  // kernel spilled.
+  int tpk[4];
 #pragma unroll
-  for (int j = 0; j < 16 * RT; ++j) {
-    const long row = r0 + xr + 4 * j;
-    tt[j] = row < p.rows ? (int)((row / p.V) % p.T) : -1000000;
+  for (int q = 0; q < 4; ++q) {
+    int w = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long row = r0 + xr + 4 * (4 * q + u);
+      const int tv = row < p.rows ? (int)((row / p.V) % p.T) : -128;
+      w |= (tv & 255) << (8 * u);
+    }
+    tpk[q] = w;
   }
-  float av[16 * RT], bv[16];
+  const int xoff = xr * (int)p.ldx + xk;                   // lane part of an input address
+  const int woff = xr * (int)p.wns + xk * (int)p.wks;      // lane part of a weight address
+  float av[16], bv[16];
 #define TC_FETCH(ch)                                                                                \
   do {                                                                                              \
     const int tap_ = (ch) / nkc, k0_ = ((ch) % nkc) * 64;                                           \
     const int d_ = tap_ - half;                                                                     \
-    const int kc_ = k0_ + xk;                                                                       \
-    const bool kok_ = kc_ < p.Cin;                                                                  \
+    const bool kok_ = k0_ + xk < p.Cin;                                                             \
     float mu_ = 0.f, a_ = 1.f, b_ = 0.f;                                                            \
-    if (p.in_state && kok_) { mu_ = p.in_state[kc_]; a_ = p.in_state[2 * p.Cin + kc_]; b_ = p.in_state[3 * p.Cin + kc_]; } \
-    _Pragma("unroll") for (int j = 0; j < 16 * RT; ++j) {                                           \
-      const int ts_ = tt[j] + d_;                                                                   \
+    if (p.in_state && kok_) { mu_ = p.in_state[k0_ + xk]; a_ = p.in_state[2 * p.Cin + k0_ + xk]; b_ = p.in_state[3 * p.Cin + k0_ + xk]; } \
+    const float* xrow_ = p.X + (r0 + (long)d_ * p.V) * p.ldx + k0_;               /* uniform */     \
+    const float* wrow_ = p.W + (long)tap_ * p.wts + (long)n0 * p.wns + (long)k0_ * p.wks;           \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                \
+      const int ts_ = (int)(signed char)(tpk[j >> 2] >> (8 * (j & 3))) + d_;                        \
       const bool ok_ = kok_ && ts_ >= 0 && ts_ < p.T;                                               \
-      float v_ = ok_ ? p.X[(r0 + xr + 4 * j + (long)d_ * p.V) * p.ldx + kc_] : 0.f;                 \
+      float v_ = ok_ ? (xrow_ + (long)(4 * j) * p.ldx)[xoff] : 0.f;                                 \
       if (p.in_state) v_ = ok_ ? fmaxf(__builtin_fmaf(v_ - mu_, a_, b_), 0.f) : 0.f;                \
       av[j] = v_;                                                                                   \
-    }                                                                                               \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                \
-      const int n_ = n0 + xr + 4 * j;                                                               \
-      bv[j] = (n_ < p.Cout && kok_) ? p.W[tap_ * p.wts + n_ * p.wns + kc_ * p.wks] : 0.f;           \
+      bv[j] = (n0 + xr + 4 * j < p.Cout && kok_) ? (wrow_ + (long)(4 * j) * p.wns)[woff] : 0.f;     \
     }                                                                                               \
   } while (0)
-  TC_FETCH(0);
-  f32x16 acc[RT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i) acc[i] = (f32x16){0};
-  for (int ch = 0; ch < nchunks; ++ch) {
+  if (grp < nchunks) TC_FETCH(grp);
+  f32x16 acc = {0};
+  for (int ch0 = 0; ch0 < nchunks; ch0 += NG) {
+    const int ch = ch0 + grp;
     __syncthreads();
+    if (ch < nchunks) {
 #pragma unroll
-    for (int j = 0; j < 16 * RT; ++j) As[(xr + 4 * j) * GC_S + xk] = av[j];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) Bs[(xr + 4 * j) * GC_S + xk] = bv[j];
+      for (int j = 0; j < 16; ++j) {
+        As[(xr + 4 * j) * GC_S + xk] = av[j];
+        Bs[(xr + 4 * j) * GC_S + xk] = bv[j];
+      }
+    }
     __syncthreads();
-    if (ch + 1 < nchunks) TC_FETCH(ch + 1);
-    const int kleft = p.Cin - (ch % nkc) * 64;
-    const int K = kleft >= 64 ? 64 : ((kleft + 3) & ~3);
-    {
+    if (ch + NG < nchunks) TC_FETCH(ch + NG);
+    if (ch < nchunks) {
+      const int kleft = p.Cin - (ch % nkc) * 64;
+      const int K = kleft >= 64 ? 64 : ((kleft + 3) & ~3);
       const int r = lane & 31, h = lane >> 5;
       const f32x2* bp = reinterpret_cast<const f32x2*>(Bs + (ct * 32 + r) * GC_S + 2 * h);
       const f32x2* ap = reinterpret_cast<const f32x2*>(As + (rt * 32 + r) * GC_S + 2 * h);
 #pragma unroll 4
       for (int k = 0; k < K; k += 4) {
-        const f32x2 b = bp[k >> 1];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          const f32x2 a = ap[(i * 64 * GC_S + k) >> 1];
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[i], 0, 0, 0);
-        }
+        const f32x2 a = ap[k >> 1], b = bp[k >> 1];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
       }
     }
   }
-  const int col = n0 + ct * 32 + (lane & 31);
+  const int lcol = ct * 32 + (lane & 31);
+  if (NG > 1) {                                            // groups 1 .. NG-1 hand their partial tiles to group 0 (fixed order)
+    __syncthreads();
+    float* xch = smem;                                     // [NG-1][64][64]
+    if (grp > 0) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        xch[((grp - 1) * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 64 + lcol] = acc[reg];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < NG; ++g)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        acc[reg] += xch[((g - 1) * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 64 + lcol];
+  }
+  const int col = n0 + lcol;
   if (col < p.Cout) {
     const float bb = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const long row = r0 + i * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (row < p.rows) p.Y[row * p.ldy + col] = acc[i][reg] + bb;
-      }
+    for (int reg = 0; reg < 16; ++reg) {
+      const long row = r0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      if (row < p.rows) p.Y[row * p.ldy + col] = acc[reg] + bb;
+    }
   }
 }
 
@@ -171,7 +200,7 @@ extern "C" int mmego_graph_mix(void* stream, const float* X, const float* A, con
 }
 
 extern "C" int mmego_tconv_pack(void* stream, const float* W, int Co, int Ci, int taps, int mode, float* Wp) {
-  MMEGO_REQUIRE(W && Wp && Co >= 1 && Ci >= 1 && taps >= 1 && (mode == 0 || mode == 1));
+  MMEGO_REQUIRE(W && Wp && Co >= 1 && Ci >= 1 && taps >= 1 && mode >= 0 && mode <= 2);
   long b = ((long)Co * Ci * taps + 255) / 256;
   hipLaunchKernelGGL(tconv_pack_kernel, dim3((int)(b > 1024 ? 1024 : b)), dim3(256), 0, (hipStream_t)stream, W, Co, Ci, taps, mode, Wp);
   MMEGO_LAUNCH_CHECK();
@@ -182,9 +211,19 @@ extern "C" int mmego_tconv(void* stream, const float* X, long ldx, const float* 
                            const float* bias, float* Y, long ldy, int B, int T, int V, int Cin, int Cout, int taps) {
   MMEGO_REQUIRE(X && W && Y && B > 0 && T > 0 && V > 0 && Cin >= 1 && Cout >= 1 && taps >= 1 && (taps & 1) && ldx >= Cin && ldy >= Cout);
   TconvP p = {X, ldx, in_state, W, wts, wns, wks, bias, Y, ldy, (long)B * T * V, T, V, Cin, Cout, taps};
-  // (128-row tiles, RT = 2, measured slower at every size: 3.19 ms against 2.98 ms for the three config-5 launches)
   dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((Cout + 63) / 64));
-  hipLaunchKernelGGL(tconv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  if ((long)grid.x * grid.y <= 512) {                      // small grid: four steps in flight per workgroup
+    const size_t lds = (size_t)4 * 2 * 64 * GC_S * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)tconv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      attr = true;
+    }
+    hipLaunchKernelGGL(tconv_kernel<4>, grid, dim3(1024), lds, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(tconv_kernel<1>, grid, dim3(256), (size_t)2 * 64 * GC_S * sizeof(float), (hipStream_t)stream, p);
+  }
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

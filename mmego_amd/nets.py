@@ -23,6 +23,13 @@ from .params import FlatParams
 from .skeleton import JOINTS_UPPER, LOWER_POINTS, gcn_adjacency
 
 
+# Training-mode temporal convolution of the ST-GCN blocks: implicit GEMM (gcn.hip, no unfolded operand) from this many rows
+# (b, t, v) on; below it the unfold + large-tile product is faster (B=64, T=8: 7680 rows -> 120 row tiles, the implicit kernel
+# is bound by its 9-18 dependent steps per tile: 5.99 ms against 6.10 ms per U+L step).  Eval-mode forwards always use the
+# implicit kernel.  MMEGO_TCONV_TRAIN_MIN_ROWS overrides the threshold (0: always implicit).
+_TCONV_TRAIN_MIN_ROWS = int(os.environ.get("MMEGO_TCONV_TRAIN_MIN_ROWS", "16384"))
+
+
 def _require_gpu(t, who):
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise RuntimeError("%s runs on the MI355X HIP path only (got a %s tensor); there is no CPU fallback"
@@ -428,10 +435,18 @@ class LowerNet(_NetBase):
             st0 = ops.bn_stats(ar, key + ".bn0", ymix, blk.tcn["0"], training)
             tz = ar.get(key + ".tz", (rows, cout))
             wt = blk.tcn["2"].weight                          # [cout, cout, taps, 1]
-            if training:
+            if training and rows < _TCONV_TRAIN_MIN_ROWS:
+                y0 = ar.get(key + ".y0", (rows, cout))
+                ops.affine_act(ymix, st0, y0, relu=True)
+                col = ar.get(key + ".col", (rows, cout * blk.taps))
+                hip.call("im2col_t", y0, B, T, V, cout, blk.taps, col)
+                ops.linear(col, blk.tcn["2"].weight, blk.tcn["2"].bias, tz)
+            elif training:
                 y0 = ar.get(key + ".y0", (rows, cout))         # (kept: the backward pass needs it)
                 ops.affine_act(ymix, st0, y0, relu=True)
-                hip.call("tconv", y0, cout, None, wt, 1, cout * blk.taps, blk.taps, blk.tcn["2"].bias, tz, cout, B, T, V, cout, cout, blk.taps)
+                wp = ar.get(key + ".wp", (2, wt.numel()))          # packed for the forward product and for its input gradient
+                hip.call("tconv_pack", wt, cout, cout, blk.taps, 2, wp)
+                hip.call("tconv", y0, cout, None, wp[0], cout * cout, cout, 1, blk.tcn["2"].bias, tz, cout, B, T, V, cout, cout, blk.taps)
             else:
                 # frozen net: BatchNorm + ReLU applied while the convolution loads its tiles, weights re-packed k-contiguous once
                 hip.call("tconv", ymix, cout, st0.all, self._packed_tconv(i, wt, blk.taps), cout * cout, cout, 1, blk.tcn["2"].bias, tz,
@@ -510,13 +525,17 @@ class LowerNet(_NetBase):
             # weight gradient of the temporal convolution from the unfolded y0 (built here, in the backward pass only);
             # no bias gradient: a batch-statistics BatchNorm follows
             col = ar.get(key + ".col", (rows, cout * blk.taps))
-            hip.call("im2col_t", y0, B, T, V, cout, blk.taps, col)
-            blocks.linear_backward(dtz, col, blk.tcn["2"], G, None, bias_grad=False)
-            # input gradient = the same implicit-GEMM convolution of dtz with the taps reversed and (co, ci) swapped
             dy0 = ar.get(key + ".dy0", (rows, cout))
-            wt = blk.tcn["2"].weight
-            hip.call("tconv", dtz, cout, None, wt.data_ptr() + 4 * (blk.taps - 1), -1, blk.taps, cout * blk.taps, None, dy0, cout,
-                     B, T, V, cout, cout, blk.taps)
+            if rows >= _TCONV_TRAIN_MIN_ROWS:
+                hip.call("im2col_t", y0, B, T, V, cout, blk.taps, col)
+                blocks.linear_backward(dtz, col, blk.tcn["2"], G, None, bias_grad=False)
+                # input gradient = the same implicit-GEMM convolution of dtz with the taps reversed and (co, ci) swapped
+                wp = ar.get(key + ".wp", (2, blk.tcn["2"].weight.numel()))
+                hip.call("tconv", dtz, cout, None, wp[1], cout * cout, cout, 1, None, dy0, cout, B, T, V, cout, cout, blk.taps)
+            else:
+                dcol = ar.get(key + ".dcol", (rows, cout * blk.taps))
+                blocks.linear_backward(dtz, col, blk.tcn["2"], G, dcol, bias_grad=False)
+                hip.call("col2im_t", dcol, B, T, V, cout, blk.taps, dy0)
             dymix = ar.get(key + ".dymix", (rows, cout))
             ops.bn_backward(dy0, y0, ymix, st0, G(blk.tcn["0"].weight), G(blk.tcn["0"].bias), dymix)
             z = ar.get(key + ".z", (rows, K * cout))

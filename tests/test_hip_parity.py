@@ -488,6 +488,67 @@ def test_train_lower(dev):
                       target[:, :, list(sk.LOWER_MAP)], g, dev)
 
 
+def test_train_lower_implicit_temporal_conv(dev, monkeypatch):
+    """The same three training steps with the ST-GCN temporal convolution forced onto the implicit-GEMM kernel (gcn.hip; by
+    default only from 16384 rows on) -- forward product, input gradient on the reversed taps, weight gradient from the
+    unfold built in the backward pass."""
+    from mmego_amd import nets
+    monkeypatch.setattr(nets, "_TCONV_TRAIN_MIN_ROWS", 0)
+    test_train_lower(dev)
+
+
+def test_gcn_kernels_against_torch(dev):
+    """mmego_graph_mix (einsum 'nkctv,kvw->nctw' with A * edge_importance, and its input gradient) and mmego_tconv (9x1 temporal
+    convolution as an implicit GEMM: plain / with BatchNorm+ReLU applied on load / input gradient on reversed taps; packed
+    and unpacked weight strides; ragged row and channel counts) against torch in fp64."""
+    from mmego_amd import hip
+    g = torch.Generator().manual_seed(23)
+    Fn, V, K, C = 37, 15, 2, 24
+    z = torch.randn(Fn, V, K * C, generator=g)
+    A, imp = torch.rand(K, V, V, generator=g), torch.randn(K, V, V, generator=g)
+    Ae = (A * imp).double()
+    want = torch.einsum("fvkc,kvw->fwc", z.double().view(Fn, V, K, C), Ae)
+    y = torch.empty(Fn, V, C, device=dev)
+    hip.call("graph_mix", z.to(dev), A.to(dev), imp.to(dev), y, Fn, V, K, C, 0)
+    assert (y.cpu().double() - want).abs().max().item() < 1e-4
+    dy = torch.randn(Fn, V, C, generator=g)
+    want_dz = torch.einsum("fwc,kvw->fvkc", dy.double(), Ae).reshape(Fn, V, K * C)
+    dz = torch.empty(Fn, V, K * C, device=dev)
+    hip.call("graph_mix", dy.to(dev), A.to(dev), imp.to(dev), dz, Fn, V, K, C, 1)
+    assert (dz.cpu().double() - want_dz).abs().max().item() < 1e-4
+    for Bq, Tq, Ci, Co in ((3, 8, 32, 32), (2, 5, 20, 70), (70, 16, 128, 128)):
+        taps = 9
+        x = torch.randn(Bq, Tq, V, Ci, generator=g)
+        W = torch.randn(Co, Ci, taps, 1, generator=g) / (Ci * taps) ** 0.5
+        b = torch.randn(Co, generator=g)
+        conv = lambda inp, w, bias: torch.nn.functional.conv2d(inp.permute(0, 3, 1, 2), w, bias, padding=(taps // 2, 0)).permute(0, 2, 3, 1)
+        want = conv(x.double(), W.double(), b.double())
+        rows = Bq * Tq * V
+        xd, Wd, bd = x.to(dev).view(rows, Ci), W.to(dev), b.to(dev)
+        out = torch.empty(rows, Co, device=dev)
+        hip.call("tconv", xd, Ci, None, Wd, 1, Ci * taps, taps, bd, out, Co, Bq, Tq, V, Ci, Co, taps)          # conv weight as it is
+        assert (out.cpu().double().view_as(want) - want).abs().max().item() < 2e-4, (Bq, Tq, Ci, Co)
+        wp = torch.empty(2, W.numel(), device=dev)
+        hip.call("tconv_pack", Wd, Co, Ci, taps, 2, wp)
+        out2 = torch.empty(rows, Co, device=dev)
+        hip.call("tconv", xd, Ci, None, wp[0], Co * Ci, Ci, 1, bd, out2, Co, Bq, Tq, V, Ci, Co, taps)
+        assert (out2.cpu().double().view_as(want) - want).abs().max().item() < 2e-4
+        # BatchNorm + ReLU applied on load: state = mean, invstd, a, b
+        st = torch.stack((torch.randn(Ci, generator=g) * 0.2, torch.ones(Ci), torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.1))
+        act = torch.relu((x.double() - st[0].double()) * st[2].double() + st[3].double())
+        want3 = conv(act, W.double(), b.double())
+        out3 = torch.empty(rows, Co, device=dev)
+        hip.call("tconv", xd, Ci, st.to(dev).contiguous(), wp[0], Co * Ci, Ci, 1, bd, out3, Co, Bq, Tq, V, Ci, Co, taps)
+        assert (out3.cpu().double().view_as(want3) - want3).abs().max().item() < 2e-4
+        # input gradient: autograd of the convolution against the same kernel on the gradient pack
+        xg = x.double().clone().requires_grad_(True)
+        dyc = torch.randn(Bq, Tq, V, Co, generator=g)
+        (conv(xg, W.double(), None) * dyc.double()).sum().backward()
+        dx = torch.empty(rows, Ci, device=dev)
+        hip.call("tconv", dyc.to(dev).view(rows, Co), Co, None, wp[1], Ci * Co, Co, 1, None, dx, Ci, Bq, Tq, V, Co, Ci, taps)
+        assert (dx.cpu().double().view_as(xg.grad) - xg.grad).abs().max().item() < 2e-4
+
+
 def test_fused_adam_matches_torch(dev):
     from mmego_amd import hip
     torch.manual_seed(5)
