@@ -157,7 +157,7 @@ def pmc_traffic(kernel_label):
     for name in ("r02_pmc_counters.json", "r01_pmc_counters.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
-            v = json.load(open(path)).get(kernel_label.split(" ")[0], {}).get("hbm_bytes_per_launch")
+            v = json.load(open(path)).get(kernel_label.split(" ")[0].split("<")[0], {}).get("hbm_bytes_per_launch")
             if v is not None:
                 return v, "profiles/" + name + " (rocprofv3 --pmc passes of `bench.py --trace-only`, committed; not measured in this run)"
     return None, None

@@ -5,7 +5,7 @@
 #   3. PMC passes of the same run (one counter group per run, never combined with tracing)
 # Everything lands in gpurun_out/prof_<tag>_c5/ ; scripts/config5_summary.py condenses it into profiles/<tag>_config5.json.
 set -e -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_${tag}_c5
 mkdir -p "$out"

@@ -5,7 +5,7 @@
 #      driven by the micro-benchmarks scripts/bench_lstm_step.py and scripts/bench_gemm_pair.py
 # Everything lands in gpurun_out/prof_<tag>/ ; scripts/prof_summary.py and scripts/pmc_summary.py condense it.
 set -e -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"

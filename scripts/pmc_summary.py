@@ -8,7 +8,7 @@ import os
 import sys
 
 root = sys.argv[1]
-KERNELS = {"lstm_step_dma2_kernel": "step", "gemm_tile_persistent_kernel": "gemm"}
+KERNELS = {"lstm_step_dma_kernel": "step", "gemm_tile_persistent_kernel": "gemm"}
 res = {}
 for kname, which in KERNELS.items():
     by_grid = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -36,6 +36,6 @@ for kname, which in KERNELS.items():
         entry["hbm_fraction_of_8TBps"] = entry["hbm_GBps"] / 8000.0
     res[kname] = entry
 res["note"] = ("separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group); FETCH doubled per MI355X_MICROARCH.md; "
-               "lstm_step: Bn=512,H=512,ndir=2 (scripts/bench_lstm_step.py 512 0); gemm: scripts/bench_gemm_pair.py, both "
+               "lstm_step: lstm_step_dma_kernel<32>, Bn=512,H=512,ndir=2 (scripts/bench_lstm_step.py 512 0); gemm: scripts/bench_gemm_pair.py, both "
                "directions per launch, 2 x (10240 x 2048 x {512,1024}) averaged as in the U+L step")
 print(json.dumps(res, indent=1))
