@@ -148,14 +148,10 @@ __global__ __launch_bounds__(1024) void mlp_fwd_layer_kernel(MlpFwdP p) {
   }
   if (tid < 64) Bs[tid] = (tid < p.Cout && p.bias) ? p.bias[tid] : 0.f;
   const bool act = p.in_part != nullptr;
-  if (act) mt_finalize_stats<16>(p.in_part, p.in_nblk, p.Cin, p.rows, p.in_gamma, p.in_beta, p.in_eps, p.in_rmean, p.in_rvar,
-                                 p.in_momentum, p.in_state, sm, red);
-  else __syncthreads();
   const int K = (p.Cin + 1) & ~1;
   const int rt = wave & 1, ct = wave >> 1, col = ct * 32 + (lane & 31);
   const long rbeg = (long)blockIdx.x * p.rows_per_wg, rend = min(p.rows, rbeg + p.rows_per_wg);
   const int xk = t & 63, xr = t >> 6;
-  const float mu = act && xk < p.Cin ? sm[0][xk] : 0.f, aa = act && xk < p.Cin ? sm[1][xk] : 1.f, bb = act && xk < p.Cin ? sm[2][xk] : 0.f;
   float* const Xg = Xs[grp];
   float xv[16];
 #define MTF_FETCH(r0_)                                                                              \
@@ -163,7 +159,11 @@ __global__ __launch_bounds__(1024) void mlp_fwd_layer_kernel(MlpFwdP p) {
     const long rr_ = (r0_) + xr + 4 * j;                                                            \
     xv[j] = (rr_ < rend && xk < p.Cin) ? p.X[rr_ * p.ldx + xk] : 0.f;                               \
   }
-  if (rbeg < rend) { MTF_FETCH(rbeg + 64 * grp) }
+  if (rbeg < rend) { MTF_FETCH(rbeg + 64 * grp) }          // the first tile's loads fly while the statistics are finalized
+  if (act) mt_finalize_stats<16>(p.in_part, p.in_nblk, p.Cin, p.rows, p.in_gamma, p.in_beta, p.in_eps, p.in_rmean, p.in_rvar,
+                                 p.in_momentum, p.in_state, sm, red);
+  else __syncthreads();
+  const float mu = act && xk < p.Cin ? sm[0][xk] : 0.f, aa = act && xk < p.Cin ? sm[1][xk] : 1.f, bb = act && xk < p.Cin ? sm[2][xk] : 0.f;
   double s1 = 0.0, s2 = 0.0;
   const float bv = Bs[col];
   for (long rr0 = rbeg; rr0 < rend; rr0 += 64 * MTF_NG) {
@@ -202,10 +202,10 @@ struct MlpActP {
   float* Y; long ldy;
 };
 
-__global__ __launch_bounds__(256) void mlp_bn_act_kernel(MlpActP p) {
+__global__ __launch_bounds__(1024) void mlp_bn_act_kernel(MlpActP p) {
   __shared__ float sm[4][64];
-  __shared__ double red[4][2][64];
-  mt_finalize_stats<4>(p.part, p.nblk, p.C, p.rows, p.gamma, p.beta, p.eps, p.rmean, p.rvar, p.momentum, p.state, sm, red);
+  __shared__ double red[16][2][64];
+  mt_finalize_stats<16>(p.part, p.nblk, p.C, p.rows, p.gamma, p.beta, p.eps, p.rmean, p.rvar, p.momentum, p.state, sm, red);
   const long total = p.rows * p.C, stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 8 * stride) {
     float zv[8];
@@ -229,18 +229,18 @@ struct MlpRedP {
   const float* dY; long lddy; const float* Z; long ldz; long rows; int C; const float* state; double* part; long rows_per_wg;
 };
 
-__global__ __launch_bounds__(256) void mlp_bn_bwd_reduce_kernel(MlpRedP p) {
-  __shared__ double red[4][2][64];
+__global__ __launch_bounds__(1024) void mlp_bn_bwd_reduce_kernel(MlpRedP p) {
+  __shared__ double red[16][2][64];
   const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
   const long rbeg = (long)blockIdx.x * p.rows_per_wg, rend = min(p.rows, rbeg + p.rows_per_wg);
   double s1 = 0.0, s2 = 0.0;
   if (c < p.C) {
     const float mu = p.state[c], is = p.state[p.C + c], a = p.state[2 * p.C + c], b = p.state[3 * p.C + c];
-    for (long r = rbeg + q; r < rend; r += 32) {          // 8 rows per round: 16 loads in flight per thread
+    for (long r = rbeg + q; r < rend; r += 128) {         // 8 rows per round: 16 loads in flight per thread
       float zz[8], gg[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const long rr = r + 4 * u;
+        const long rr = r + 16 * u;
         zz[u] = rr < rend ? p.Z[rr * p.ldz + c] : 0.f;
         gg[u] = rr < rend ? p.dY[rr * p.lddy + c] : 0.f;
       }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void mlp_bn_bwd_reduce_kernel(MlpRedP p) {
       }
     }
   }
-  mt_store_partials<4>(s1, s2, c, q, p.part, red);
+  mt_store_partials<16>(s1, s2, c, q, p.part, red);
 }
 
 struct MlpBwdP {
@@ -296,6 +296,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
     st[6][tid] = oki ? p.in_state[2 * p.Cin + tid] : 1.f;
     st[7][tid] = oki ? p.in_state[3 * p.Cin + tid] : 0.f;
   }
+  const long rbeg = (long)blockIdx.x * p.rows_per_wg, rend = min(p.rows, rbeg + p.rows_per_wg);
+  const int xk = t & 63, xr = t >> 6;
+  float gy[16], gz[16], gx[16];
+#define MTB_FETCH(r0_)                                                                              \
+  _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
+    const long rr_ = (r0_) + xr + 4 * j;                                                            \
+    const bool oko_ = rr_ < rend && xk < p.Cout;                                                    \
+    gy[j] = oko_ ? p.dY[rr_ * p.lddy + xk] : 0.f;                                                   \
+    gz[j] = oko_ ? p.Z[rr_ * p.ldz + xk] : 0.f;                                                     \
+    gx[j] = (rr_ < rend && xk < p.Cin) ? p.Xin[rr_ * p.ldxin + xk] : 0.f;                           \
+  }
+  if (rbeg < rend) { MTB_FETCH(rbeg + 64 * grp) }          // the first tile's loads fly while the partial sums are gathered
   {  // finalize this layer's (sum g, sum g xhat): c1, c2; d(gamma), d(beta) by workgroup 0
     mt_gather_partials<8>(p.g_part, p.g_nblk, p.Cout, red);
     const int c = tid & 63;
@@ -309,20 +321,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
   }
   const int Ko = (p.Cout + 1) & ~1;
   const int rt = wave & 1, ct = wave >> 1, col = ct * 32 + (lane & 31);
-  const long rbeg = (long)blockIdx.x * p.rows_per_wg, rend = min(p.rows, rbeg + p.rows_per_wg);
-  const int xk = t & 63, xr = t >> 6;
   const bool act = p.in_state != nullptr;
   const bool want_dx = p.dX != nullptr, want_prev = p.gprev_part != nullptr;
-  float gy[16], gz[16], gx[16];
-#define MTB_FETCH(r0_)                                                                              \
-  _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
-    const long rr_ = (r0_) + xr + 4 * j;                                                            \
-    const bool oko_ = rr_ < rend && xk < p.Cout;                                                    \
-    gy[j] = oko_ ? p.dY[rr_ * p.lddy + xk] : 0.f;                                                   \
-    gz[j] = oko_ ? p.Z[rr_ * p.ldz + xk] : 0.f;                                                     \
-    gx[j] = (rr_ < rend && xk < p.Cin) ? p.Xin[rr_ * p.ldxin + xk] : 0.f;                           \
-  }
-  if (rbeg < rend) { MTB_FETCH(rbeg + 64 * grp) }
   f32x16 accw = {0};
   double s1 = 0.0, s2 = 0.0;
   for (long rr0 = rbeg; rr0 < rend; rr0 += 64 * MTB_NG) {
@@ -469,9 +469,9 @@ extern "C" int mmego_mlp_bn_act(void* stream, const float* Z, long ldz, long row
   int nblk; long rpw;
   mt_grid(rows, &nblk, &rpw);
   MlpActP p = {Z, ldz, rows, C, part, nblk, gamma, beta, (float)eps, rmean, rvar, (float)momentum, state, Y, ldy};
-  long b = (rows * C + 2047) / 2048;
+  long b = (rows * C + 8191) / 8192;
   const int grid = (int)(b > MT_MAXBLK ? MT_MAXBLK : (b < 1 ? 1 : b));       // (every workgroup re-reads the partials: keep them few)
-  hipLaunchKernelGGL(mlp_bn_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(mlp_bn_act_kernel, dim3(grid), dim3(1024), 0, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
@@ -483,7 +483,7 @@ extern "C" int mmego_mlp_bn_bwd_reduce(void* stream, const float* dY, long lddy,
   int nblk;
   mt_grid(rows, &nblk, &p.rows_per_wg);
   p.dY = dY; p.lddy = lddy; p.Z = Z; p.ldz = ldz; p.rows = rows; p.C = C; p.state = state; p.part = part;
-  hipLaunchKernelGGL(mlp_bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(mlp_bn_bwd_reduce_kernel, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
