@@ -1,5 +1,5 @@
 """Per-call-site device time of one eager U+L step (event pairs around every C-ABI launch).
-Usage (GPU box): python scripts/profile_calls.py [iters]"""
+Usage (GPU box): python scripts/profile_calls.py [iters] [both|upper|lower]"""
 import collections
 import os
 import sys
@@ -12,6 +12,7 @@ from mmego_amd import hip  # noqa: E402
 from mmego_amd.train_step import StageStep  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+which = sys.argv[2] if len(sys.argv) > 2 else "both"      # "upper" / "lower": that stage's body alone
 dev = torch.device("cuda:0")
 imu, upper, lower, upper_frozen = bench.build_hip_models(dev)
 x, imu_in, body, target = bench.synth_batch(1234, dev)
@@ -22,8 +23,10 @@ sl.bind(x, imu_in, body, target)
 
 
 def step():
-    su.step()
-    sl.step()
+    if which in ("both", "upper"):
+        su.step()
+    if which in ("both", "lower"):
+        sl.step()
 
 
 step()
