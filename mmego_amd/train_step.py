@@ -357,7 +357,10 @@ class ConcurrentStages:
                     st = stages[i]
                     if st.imu is not None and st.pose is None:
                         from . import blocks
-                        with torch.no_grad(), blocks.two_chains(False):   # another stage's tail runs beside it: blocks.two_chains
+                        # the FIRST forward (the last stage's) has the GPU to itself: its recurrences run as two chains; the
+                        # later ones have another stage's tail beside them, which fills the same gaps (blocks.two_chains)
+                        alone = i == len(stages) - 1 and os.environ.get("MMEGO_FIRST_IMU_TWO_CHAINS", "1") != "0"
+                        with torch.no_grad(), blocks.two_chains(alone):
                             R, t = st.imu(st.static["imu"])
                             pose = self._pose_buf(i, R, t)
                             ops.copy2d(R.view(-1, 9), pose[0].view(-1, 9))
