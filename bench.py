@@ -116,7 +116,7 @@ def profile_kernels(steps_fn, names, iters=3):
         e0.record()
         orig_rec(ar, key, lstm, l, xp, out, Bn, T_, **kw)
         e1.record()
-        rec_layers.append((e0, e1, (Bn, lstm.hidden_size, T_)))
+        rec_layers.append((e0, e1, (Bn, lstm.hidden_size, T_, bool(blocks._LSTM_TWO_CHAINS and T_ > 1 and Bn >= 128))))
     hip.call = timed_call
     blocks.lstm_recurrence = timed_recurrence
     try:
@@ -554,10 +554,12 @@ def main():
         from mmego_amd import blocks as _blocks
 
         def eager():
-            # the same recurrence form as the timed arrangement: one launch per timestep for both directions inside the
-            # concurrent-stage graph (blocks.two_chains), two single-direction chains when the stages run one after the other
+            # the same recurrence forms as the timed arrangement (train_step.ConcurrentStages): the Lower stage's IMU_Net forward
+            # runs first and alone -> two single-direction chains; the Upper stage's has the Lower tail beside it -> one launch
+            # per timestep for both directions.  --sequential: two chains in both.
             with _blocks.two_chains(args.sequential):
                 su_e._body()
+            with _blocks.two_chains(True):
                 sl_e._body()
         eager()
         torch.cuda.synchronize()
@@ -567,7 +569,8 @@ def main():
         # averaged, so avg_launch_us is directly comparable with rocprofv3's per-kernel AverageNs.
         def step_flops(a):
             return 0.0 if a[3] else 2.0 * a[0] * a[1] * 4 * a[2] * a[2]
-        big = [(ms_, step_flops(a)) for ms_, a in rec["lstm_step"] if a[1] >= 128]
+        big = [(ms_, step_flops(a)) for ms_, a in rec["lstm_step"] if a[1] >= 128 and a[0] == 2]
+        big16 = [(ms_, step_flops(a)) for ms_, a in rec["lstm_step"] if a[1] >= 128 and a[0] == 1]
         small = [(ms_, step_flops(a)) for ms_, a in rec["lstm_step"] if a[1] < 128]
 
         def is_nt_aligned(a):   # the dispatch rule of mmego_gemm (gemm.hip / gemm_tile.hip); a[13] = nbatch
@@ -580,17 +583,18 @@ def main():
         g64 = [(ms_, 2.0 * a[10] * a[11] * a[12] * a[13]) for ms_, a in rec["gemm"] if is_nt_aligned(a) and not is_tile128(a)]
         cands = {}
         if big:
-            if big[0][1] and all(f == big[-1][1] or f == 0.0 for _, f in big) and big[-1][1] < 2e9:
-                cands["lstm_step_dma_kernel<16> (IMU_Net rnn_fast recurrent steps, ONE direction per launch: 512 rows x 2048 gates x K=512; "
-                      "the two directions' launches run concurrently as two chains, so a launch's duration is NOT its share of the "
-                      "step: see lstm_recurrence)"] = big
-            else:
-                cands["lstm_step_dma_kernel<32> (IMU_Net rnn_fast recurrent steps: 2 dirs x 512 rows x 2048 gates x K=512 per launch)"] = big
-        # a rnn_fast layer's whole recurrence (20 timesteps, both directions as two concurrent chains) timed as ONE region:
+            cands["lstm_step_dma_kernel<32> (IMU_Net rnn_fast recurrent steps, both directions per launch: 2 x 512 rows x 2048 gates x "
+                  "K=512)"] = big
+        if big16:
+            cands["lstm_step_dma_kernel<16> (IMU_Net rnn_fast recurrent steps, ONE direction per launch: 512 rows x 2048 gates x K=512; "
+                  "the two directions' launches run concurrently as two chains, so a launch's duration is NOT its share of the "
+                  "step: see lstm_recurrence)"] = big16
+        # a rnn_fast layer's whole recurrence run as two concurrent single-direction chains, timed as ONE region:
         # flops = 2 dirs x 2 x Bn x 4H x H per product-carrying timestep; reported per timestep
-        layers = [(ms_ / a[2], 2.0 * 2 * a[0] * 4 * a[1] * a[1] * (a[2] - 1) / a[2]) for ms_, a in rec["lstm_recurrence"] if a[0] >= 128]
-        if layers and args.sequential:
-            cands["lstm_recurrence (IMU_Net rnn_fast: per TIMESTEP of a layer's recurrence, both directions = two concurrent "
+        layers = [(ms_ / a[2], 2.0 * 2 * a[0] * 4 * a[1] * a[1] * (a[2] - 1) / a[2]) for ms_, a in rec["lstm_recurrence"]
+                  if a[0] >= 128 and a[3]]
+        if layers:
+            cands["lstm_recurrence (IMU_Net rnn_fast: per TIMESTEP of a layer's recurrence run as two concurrent "
                   "lstm_step_dma_kernel<16> chains; 2 x 512 rows x 2048 gates x K=512)"] = layers
         if small:
             cands["lstm_step_small_kernel (IMU_Net rnn_slow recurrent steps: 2 dirs x 64 rows x 2048 gates x K=512)"] = small

@@ -123,6 +123,11 @@ class StageStep:
     def _body(self, nested=False):
         if not nested:
             ops.mark_capture_origin()
+        self._body_forward()
+        self._body_backward()
+
+    def _body_forward(self):
+        """Fresh batch, head pose, forward of the trained net (and of the frozen Upper_Net in the Lower stage), loss."""
         s = self.static
         B, T = s["x"].shape[0], s["x"].shape[1]
         ops.copy2d(s["x_src"].view(B * T, -1), s["x"].view(B * T, -1))        # fresh batch (x is transformed in place)
@@ -151,8 +156,11 @@ class StageStep:
                 l = self.net._forward_impl(up, s["x"], s["body"], R, t, stash=True)[0]
                 nsel = 8
             hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss2, s["dl"])
-            self.net._backward_impl(s["dl"])
         self.last_pred = l
+
+    def _body_backward(self):
+        with torch.no_grad():
+            self.net._backward_impl(self.static["dl"])
 
     def bind(self, x, imu, body, target, R_gt=None):
         """Register the (device-resident) minibatch buffers; contents may be overwritten between steps."""
