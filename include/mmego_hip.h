@@ -28,10 +28,12 @@ extern "C" {
  * gradients -- Net/Upper_Net.py:242-301,343-364, Net/Lower_Net.py:40-72,95-123, Net/GCN.py:46-60,
  * and the LSTM input projections of Net/IMU_Net.py:58-62. */
 /* (sBiasb: element stride of `bias` between batches, 0 = one bias for all -- lets the two directions' input projections of a
- * BiLSTM layer run as ONE batched product: same A, two weight / bias / output-column blocks.) */
+ * BiLSTM layer run as ONE batched product: same A, two weight / bias / output-column blocks.)
+ * cmul (may be NULL; nsplit == 1 only): elementwise multiplier in C's layout applied after bias / relu / accumulate -- the
+ * inter-layer dropout mask on an LSTM layer's input gradient. */
 int mmego_gemm(void* stream, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
                long scm, long scn, const float* bias, int M, int N, int K, int nbatch, long sAb, long sBb, long sCb,
-               int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb);
+               int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb, const float* cmul);
 
 /* ---- BatchNorm and row-wise helpers (bn.hip) ----------------------------------------------------
  * Train-mode statistics of X[rows, C] (+ running-stat update with torch semantics: momentum, unbiased
@@ -49,11 +51,15 @@ int mmego_bn_eval_affine(void* stream, int C, const float* gamma, const float* b
  * s = gamma / sqrt(var + eps); the product then applies bias + ReLU in its epilogue (Upper_Net.py:253-255 etc. in eval). */
 int mmego_bn_fold_linear(void* stream, const float* W, const float* b, int N, int K, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var, float eps, float* Wf, float* bf);
-/* Eval-mode pointwise MLP: Y = relu(W3 relu(W2 relu(W1 x + b1) + b2) + b3) per row with BN-folded weights, one kernel,
- * intermediates in LDS (BasePointNet / GlobalPointNet of Upper_Net.py:242-301, Lower_Net.py:40-72 in eval mode).
+/* Eval-mode pointwise MLP: Y = relu(W3 relu(W2 relu(W1 x + b1) + b2) + b3) per row, one kernel, intermediates in LDS
+ * (BasePointNet / GlobalPointNet of Upper_Net.py:242-301, Lower_Net.py:40-72 in eval mode).
+ * bn == NULL: W, b are BN-folded already (mmego_bn_fold_linear).  Otherwise bn is a HOST array of 12 device pointers
+ * {gamma, beta, running_mean, running_var} x 3 layers and W, b are the raw conv parameters (b may be NULL): the kernel folds
+ * BatchNorm(eps) into them while staging the weights, with mmego_bn_fold_linear's arithmetic (same bits).
  * Cin, C1 <= 32; C2, C3 <= 64.  X, Y may be column slices (row strides ldx, ldy). */
 int mmego_mlp3_eval(void* stream, const float* X, long ldx, long rows, int Cin, const float* W1, const float* b1, int C1,
-                    const float* W2, const float* b2, int C2, const float* W3, const float* b3, int C3, float* Y, long ldy);
+                    const float* W2, const float* b2, int C2, const float* W3, const float* b3, int C3, float* Y, long ldy,
+                    const float* const* bn, float eps);
 /* Y = act((X1-m1)*a1+b1 [+ (X2-m2)*a2+b2]) -- BN apply + ReLU, and the st_gcn "tcn(x)+residual" join
  * (GCN.py:140-147). */
 int mmego_affine_act(void* stream, const float* X1, long ld1, const float* m1, const float* a1, const float* b1,
@@ -73,6 +79,10 @@ int mmego_bn_backward(void* stream, const float* dY, long lddy, const float* Yma
  * one gradient).  partial_ws: C*nblk floats. */
 int mmego_colsum(void* stream, const float* X, long ldx, long rows, int C, float* partial_ws, float* out, float* out2,
                  int accumulate);
+/* The same for X [rows <= 1024, 2C] in ONE launch: columns [0, C) -> outA (and outA2), columns [C, 2C) -> outB (and outB2): the
+ * four bias gradients of a BiLSTM layer (both directions x bias_ih / bias_hh) from its gate gradients.  C % 16 == 0. */
+int mmego_colsum_pair(void* stream, const float* X, long ldx, long rows, int C, float* outA, float* outA2, float* outB,
+                      float* outB2, int accumulate);
 /* G = 0 where H <= 0 (ReLU backward for Linear+ReLU pairs, Upper_Net.py:350-351). */
 int mmego_relu_mask(void* stream, float* G, long ldg, const float* H, long ldh, long rows, int C);
 int mmego_fill(void* stream, float* X, long n, float v);
@@ -90,12 +100,17 @@ int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first, const floa
 /* Whole-sequence H=64 bidirectional LSTM layer (Upper_Net.py:333, Lower_Net.py:91, Upper_Net.py:210).
  * xproj_d rows are (b*T+t) with row stride xs; out rows (b*T+t) with row stride os, direction d in
  * columns [64d, 64d+64).  Optional stashes for backward: gates_d [T][B][256], cst_d [T][B][64],
- * hprev_d [(b*T+t)][64]. */
+ * hprev_d [(b*T+t)][64].
+ * drop_y / drop_mask (both or neither; out's layout): nn.LSTM(dropout=drop_p)'s inverted inter-layer dropout applied while the
+ * outputs are stored -- drop_mask = 0 or 1/(1-p) per element from a counter-based hash of (element index, seed_ctr[0], salt),
+ * drop_y = out * drop_mask.  seed_ctr is only read; mmego_inc_i64 advances it once per training forward, salt tells the
+ * call sites of one forward apart. */
 int mmego_lstm64_forward(void* stream, int B, int T, const float* xproj0, const float* xproj1, long xs,
                          const float* whh0, const float* whh1, const float* bhh0, const float* bhh1, const float* h0_0,
                          const float* h0_1, const float* c0_0, const float* c0_1, float* out, long os, float* hn0,
                          float* hn1, float* cn0, float* cn1,
-                         float* gates0, float* gates1, float* cst0, float* cst1, float* hprev0, float* hprev1);
+                         float* gates0, float* gates1, float* cst0, float* cst1, float* hprev0, float* hprev1,
+                         float* drop_y, float* drop_mask, float drop_p, const unsigned long long* seed_ctr, int salt);
 /* Backward through time of the same layer: dgates_d rows (b*T+t), row stride dgs (pre-activation
  * gradients; weight/input gradients follow as mmego_gemm products). */
 int mmego_lstm64_backward(void* stream, int B, int T, const float* dout, long dos, const float* gates0,
@@ -248,8 +263,9 @@ int mmego_col2im_t(void* stream, const float* dcol, int B, int T, int V, int C, 
 int mmego_transpose_batched(void* stream, const float* in, float* out, long Bn, int R, int C);
 int mmego_mul(void* stream, const float* a, const float* b, float* out, long n);
 int mmego_add(void* stream, const float* a, const float* b, float* out, long n);
-/* x[i] += 1 for the BatchNorm num_batches_tracked counters (one launch for all layers of a net). */
-int mmego_inc_i64(void* stream, long long* x, long n);
+/* The once-per-training-forward tick of a net: x[i] += 1 for the BatchNorm num_batches_tracked counters (one launch for all
+ * layers; n may be 0) and, when seed_ctr is given, the next value of the dropout seed counter (mmego_lstm64_forward). */
+int mmego_inc_i64(void* stream, long long* x, long n, unsigned long long* seed_ctr);
 
 /* ---- train-mode pointwise MLP layers, fused per layer (mlp_train.hip) -------------------------------------------------
  * k=1 conv -> BatchNorm (batch statistics) -> ReLU stages of Net/Upper_Net.py:242-301,147-177 and Net/Lower_Net.py:40-72 in
@@ -288,8 +304,6 @@ int mmego_mlp_dw_reduce(void* stream, long rows, int nlayers, const float* part0
  * Net/IMU_Net.py:55, which would otherwise decay under Train_IMU's weight_decay).  NULL / 0: update everything. */
 int mmego_adam_step(void* stream, float* p, const float* g, float* m, float* v, long n, double* state, double lr,
                     double beta1, double beta2, double eps, double weight_decay, const long* skip, int nskip);
-/* Inverted dropout with a device-side seed counter (nn.LSTM(dropout=0.1) inter-layer dropout). */
-int mmego_dropout(void* stream, const float* X, float* Y, float* mask, long n, float p, unsigned long long* seed_ctr);
 
 #ifdef __cplusplus
 }

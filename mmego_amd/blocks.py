@@ -117,6 +117,16 @@ def mlp3_forward(ar, key, mod, x, out_last, training):
         # eval: BatchNorm folded into the convs (bn_fold_linear), then the three stages in ONE kernel whose intermediates
         # stay in LDS (mlp3.hip) -- no pre-BN tensors, no per-point 32/48/64-channel activations in HBM
         layers = _mlp3_layers(mod)
+        dims = [conv.weight.shape[0] for conv, _ in layers]
+        Cin = layers[0][0].weight.numel() // dims[0]
+        if (_FUSED_EVAL_MLP and Cin <= 32 and dims[0] <= 32 and dims[1] <= 64 and dims[2] <= 64 and x.stride(1) == 1
+                and out_last.stride(1) == 1 and len({bn.eps for _, bn in layers}) == 1):
+            # BatchNorm folded by the kernel itself while it stages the weights: no fold launches
+            bnp = torch.tensor([t.data_ptr() for _, bn in layers for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)],
+                               dtype=torch.int64)
+            wb = [v for (conv, _), C in zip(layers, dims) for v in (conv.weight, conv.bias, C)]
+            hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *wb, out_last, out_last.stride(0), bnp, float(layers[0][1].eps))
+            return out_last
         folded = []
         for i, (conv, bn) in enumerate(layers, 1):
             C = conv.weight.shape[0]
@@ -125,11 +135,6 @@ def mlp3_forward(ar, key, mod, x, out_last, training):
             hip.call("bn_fold_linear", conv.weight, conv.bias, C, K, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                      float(bn.eps), wf, bf)
             folded += [wf, bf, C]
-        Cin = layers[0][0].weight.numel() // layers[0][0].weight.shape[0]
-        if (_FUSED_EVAL_MLP and Cin <= 32 and folded[2] <= 32 and folded[5] <= 64 and folded[8] <= 64 and x.stride(1) == 1
-                and out_last.stride(1) == 1):
-            hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *folded, out_last, out_last.stride(0))
-            return out_last
         for i in range(3):                                  # wider layers: one product per stage, bias + ReLU in its epilogue
             wf, bf, C = folded[3 * i:3 * i + 3]
             y = out_last if i == 2 else ar.get("%s.y%d" % (key, i + 1), (rows, C))
@@ -190,8 +195,10 @@ def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False, bias_grad=True)
 # ---------------------------------------------------------------------------------------------------
 # 3-layer bidirectional LSTM, H = 64 (persistent sequence kernels)
 # ---------------------------------------------------------------------------------------------------
-def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr):
-    """x [B*T, In] rows (b*T+t) -> out [B*T,128] (arena), hn, cn [2L,B,64] (fresh tensors)."""
+def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr, salt=0):
+    """x [B*T, In] rows (b*T+t) -> out [B*T,128] (arena), hn, cn [2L,B,64] (fresh tensors).  With ``stash`` and p_drop > 0 the
+    inter-layer dropout is applied by the layer kernel itself while it stores its outputs (mask from seed_ctr, which the net's
+    once-per-forward tick advances: FlatParams.bump_bn_counters; ``salt`` separates the LSTM stacks of one net)."""
     L = lstm.num_layers
     dev = x.device
     hn = torch.empty((2 * L, B, 64), dtype=torch.float32, device=dev)
@@ -213,14 +220,14 @@ def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr):
         h01 = h0[2 * l + 1] if h0 is not None else None
         c00 = c0[2 * l] if c0 is not None else None
         c01 = c0[2 * l + 1] if c0 is not None else None
-        hip.call("lstm64_forward", B, T, xp, xp[:, 256:], 512, lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1),
-                 lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1), h00, h01, c00, c01, out, 128, hn[2 * l], hn[2 * l + 1], cn[2 * l], cn[2 * l + 1], *st)
         cur = out
+        drop = (None, None, 0.0, None, 0)
         if stash and p_drop > 0.0 and l < L - 1:
-            dropped = ar.get("%s.do%d" % (key, l), (B * T, 128))
-            mask = ar.get("%s.mk%d" % (key, l), (B * T, 128))
-            hip.call("dropout", out, dropped, mask, out.numel(), float(p_drop), seed_ctr)
-            cur = dropped
+            cur = ar.get("%s.do%d" % (key, l), (B * T, 128))
+            drop = (cur, ar.get("%s.mk%d" % (key, l), (B * T, 128)), float(p_drop), seed_ctr, 8 * salt + l)
+        hip.call("lstm64_forward", B, T, xp, xp[:, 256:], 512, lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1),
+                 lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1), h00, h01, c00, c01, out, 128, hn[2 * l], hn[2 * l + 1], cn[2 * l], cn[2 * l + 1],
+                 *st, *drop)
     return out, hn, cn
 
 
@@ -245,15 +252,18 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
         # weight gradients of both directions per launch (batch dimension = direction)
         ops.grad_weight_pair(dg, 256, inp, G(lstm.w("weight_ih", l, 0)), G(lstm.w("weight_ih", l, 1)))
         ops.grad_weight_pair(dg, 256, hprev[0], G(lstm.w("weight_hh", l, 0)), G(lstm.w("weight_hh", l, 1)), X1=hprev[1])
-        for d in range(2):
-            ops.colsum(dg[:, d * 256:(d + 1) * 256], G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
+        if B * T <= 1024:       # the four bias gradients (bias_ih = bias_hh per direction) in one launch
+            hip.call("colsum_pair", dg, dg.stride(0), B * T, 256, G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_hh", l, 0)),
+                     G(lstm.w("bias_ih", l, 1)), G(lstm.w("bias_hh", l, 1)), 0)
+        else:
+            for d in range(2):
+                ops.colsum(dg[:, d * 256:(d + 1) * 256], G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
         if l > 0 or need_dx:
             dinp = ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))
+            # (the inter-layer dropout mask is applied by the second product's epilogue)
+            mask = ar.get("%s.mk%d" % (key, l - 1), (B * T, 128)) if l > 0 and p_drop > 0.0 else None
             ops.grad_input(dg[:, :256], lstm.w("weight_ih", l, 0), dinp)
-            ops.grad_input(dg[:, 256:], lstm.w("weight_ih", l, 1), dinp, accumulate=True)
-            if l > 0 and p_drop > 0.0:
-                mask = ar.get("%s.mk%d" % (key, l - 1), (B * T, 128))
-                hip.call("mul", dinp, mask, dinp, dinp.numel())
+            ops.grad_input(dg[:, 256:], lstm.w("weight_ih", l, 1), dinp, accumulate=True, cmul=mask)
             d_cur = dinp
     return d_cur if need_dx else None
 
@@ -276,11 +286,6 @@ def attn_pool_backward(ar, key, X, lin, attn, dvec, G_, P, C, dX, G):
 # ---------------------------------------------------------------------------------------------------
 # generic-H step-kernel LSTM stack (forward only): IMU_Net's rnn_fast / rnn_slow
 # ---------------------------------------------------------------------------------------------------
-# Scheduling hook of train_step.ConcurrentStages: called (key, layer) right after a layer's input projections have been
-# enqueued, i.e. at the boundary between the throughput-bound GEMMs and the latency-bound recurrent chain.
-milestone = None
-
-
 _LSTM_TWO_CHAINS_DEFAULT = os.environ.get("MMEGO_LSTM_TWO_CHAINS", "1") != "0"
 _LSTM_TWO_CHAINS = _LSTM_TWO_CHAINS_DEFAULT
 _side_streams = {}
@@ -359,14 +364,11 @@ def lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T, gst=None, cst=None):
 def lstm_steps_forward(ar, key, lstm, x, Bn, T):
     """x [Bn*T, In] rows (b*T+t) -> out [Bn*T, 2H] of the last layer (eval mode: no dropout)."""
     H = lstm.hidden_size
-    L = lstm.num_layers
     cur = x
     out = None
-    for l in range(L):
+    for l in range(lstm.num_layers):
         xp = ar.get("%s.xp%d" % (key, l), (Bn * T, 8 * H))
         ops.linear_pair(cur, lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1), lstm.w("bias_ih", l, 0), lstm.w("bias_ih", l, 1), xp, 4 * H)
-        if milestone is not None:
-            milestone(key, l)
         out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
         lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T)
         cur = out
@@ -495,8 +497,6 @@ def lstm_steps_forward_bf16(ar, key, lstm, x, Bn, T):
         wih, bias, whh0, whh1 = W[l]
         xpf = ar.get("%s.xpf%d" % (key, l), (T * Bp * 8 * H,))
         hip.call("gemm_bf16", cur, cur.stride(0), wih, wih.stride(0), None, 0, None, 0, xpf, bias, T * Bp, 8 * H, cur.shape[1], 0)
-        if milestone is not None:
-            milestone(key, l)
         out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
         last = l == lstm.num_layers - 1
         outb = None if last else ar.get("%s.outb%d" % (key, l), (T * Bp, 2 * H), dtype=torch.bfloat16)   # time-major

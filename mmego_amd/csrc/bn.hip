@@ -265,8 +265,10 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 // Short tensors (<= 1024 rows): one block per column tile sums all rows -- one launch instead of two (a kernel boundary
 // costs more than these reductions themselves).  Same fixed summation structure on every run (deterministic).
+// seg > 0: columns [seg, C) go to outB / out2B (index c - seg): the gate gradients of both directions of a BiLSTM layer in one launch.
 __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ X, long ldx, long rows, int C, float* out,
-                                                           float* out2, int accumulate, int TC) {
+                                                           float* out2, int accumulate, int TC, int seg, float* outB,
+                                                           float* out2B) {
   __shared__ double sh[256];
   const int TR = 256 / TC;
   const int cx = threadIdx.x % TC, ry = threadIdx.x / TC;
@@ -285,9 +287,13 @@ __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restri
   if (ry == 0 && c < C) {
     double a = 0.0;
     for (int j = 0; j < TR; ++j) a += sh[j * TC + cx];
-    const float v = accumulate ? out[c] + (float)a : (float)a;
-    out[c] = v;
-    if (out2) out2[c] = v;
+    float* o = out;
+    float* o2 = out2;
+    int cc = c;
+    if (seg > 0 && c >= seg) { o = outB; o2 = out2B; cc = c - seg; }
+    const float v = accumulate ? o[cc] + (float)a : (float)a;
+    o[cc] = v;
+    if (o2) o2[cc] = v;
   }
 }
 
@@ -431,7 +437,8 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
     // narrow column tiles (16 lanes across, 16 down the rows): more blocks and 4x shorter per-thread row loops than the
     // 64-wide tile of the long-tensor path -- this kernel's time is the depth of its dependent load rounds
     const int TCs = C >= 16 ? 16 : col_tile(C);
-    hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(C, TCs)), dim3(256), 0, st, X, ldx, rows, C, out, out2, accumulate, TCs);
+    hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(C, TCs)), dim3(256), 0, st, X, ldx, rows, C, out, out2, accumulate, TCs, 0,
+                       (float*)nullptr, (float*)nullptr);
     MMEGO_LAUNCH_CHECK();
     return MMEGO_OK;
   }
@@ -442,6 +449,15 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC);
   MMEGO_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, out, out2, accumulate);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_colsum_pair(void* stream, const float* X, long ldx, long rows, int C, float* outA, float* outA2, float* outB,
+                                 float* outB2, int accumulate) {
+  MMEGO_REQUIRE(X && rows > 0 && rows <= 1024 && C >= 16 && (C % 16) == 0 && outA && outB);
+  hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(2 * C, 16)), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, 2 * C, outA, outA2,
+                     accumulate, 16, C, outB, outB2);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -42,6 +42,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// Counter-based dropout RNG: element i of a call keeps its value when a 24-bit hash of (i, call key) is >= p.  The call key
+// mixes the device-side seed counter (advanced once per training forward by mmego_inc_i64) with a per-call-site salt.
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned dropout_key(unsigned long long seed, unsigned salt) {
+  seed = (seed + (unsigned long long)salt * 0x9E3779B97F4A7C15ULL) * 6364136223846793005ULL + 1442695040888963407ULL;
+  return hash32((unsigned)(seed & 0xffffffffU) + 0x9e3779b9U * (unsigned)(seed >> 32));
+}
+__device__ __forceinline__ bool dropout_keep(unsigned key, unsigned i, float p) {
+  return (hash32(i ^ key) >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
 // In-kernel clock stamps: compiled ONLY into the diagnostic probe (scripts/clock_probe.hip defines MMEGO_STAMP); the
 // product library contains no stamp.  Slot s of workgroup b holds {s_memtime, s_memrealtime} taken by one lane.
 #ifdef MMEGO_STAMP

@@ -27,6 +27,7 @@ struct GemmP {
   int nsplit, kchunk;
   int relu, accumulate;
   int avec, bvec;     // operand is k-contiguous with 16-B aligned rows: float4 loads allowed
+  const float* cmul;  // optional elementwise multiplier in C's layout, applied last (a dropout mask on an input gradient)
 };
 
 #define LD64 68
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
       if (p.nsplit == 1) {
         if (p.relu) v = fmaxf(v, 0.0f);
         if (p.accumulate) v += *dst;
+        if (p.cmul) v *= p.cmul[dst - p.C];
       }
       *dst = v;
     }
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
         if (p.bias) v += p.bias[(long)batch * p.sBiasb + n0 + col];
         if (p.relu) v = fmaxf(v, 0.0f);
         if (p.accumulate) v += *dst;
+        if (p.cmul) v *= p.cmul[dst - p.C];
       }
       *dst = v;
     }
@@ -350,8 +353,10 @@ __global__ __launch_bounds__(256) void gemm128_nt_kernel(const float* __restrict
 
 extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                           float* C, long scm, long scn, const float* bias, int M, int N, int K, int nbatch, long sAb,
-                          long sBb, long sCb, int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb) {
+                          long sBb, long sCb, int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb,
+                          const float* cmul) {
   MMEGO_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && nsplit >= 1);
+  MMEGO_REQUIRE(!cmul || nsplit == 1);
   MMEGO_REQUIRE(sBiasb == 0 || nsplit == 1);          // (the split-K reducer applies one shared bias)
   hipStream_t st = (hipStream_t)stream;
   // Large-tile kernels (gemm_tile.hip): 64-aligned shapes with enough work units to be worth a 64x64+ tile, any operand
@@ -368,7 +373,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
     const long tile_min_units = (a_kc && b_kc && nsplit == 1) ? (K <= 1024 ? 1 : 200) : tile_min_other;
     const long units64 = (long)(M / 64) * (N / 64) * nsplit * nbatch;
     static const bool nt_only = getenv("MMEGO_GEMM_TILE_NT_ONLY") != nullptr;
-    const bool ok = !(nt_only && !(a_kc && b_kc && nsplit == 1 && !accumulate)) && scn == 1 && (nbatch == 1 || ((sAb % 4) == 0 && (sBb % 4) == 0)) && (a_kc || a_mc) && (b_kc || b_mc) && (lda % 4) == 0 && (ldw % 4) == 0 &&
+    const bool ok = !cmul && !(nt_only && !(a_kc && b_kc && nsplit == 1 && !accumulate)) && scn == 1 && (nbatch == 1 || ((sAb % 4) == 0 && (sBb % 4) == 0)) && (a_kc || a_mc) && (b_kc || b_mc) && (lda % 4) == 0 && (ldw % 4) == 0 &&
                     (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (M % 64) == 0 && (N % 64) == 0 &&
                     (K % 64) == 0 && units64 >= tile_min_units && (nsplit == 1 || (long)(nsplit - 1) * kchunk_t < K);
     if (ok) {
@@ -390,7 +395,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
       if (rc != -2) return rc;
     }
   }
-  const bool fast = nbatch == 1 && nsplit == 1 && !accumulate && sak == 1 && sbk == 1 && scn == 1 && (M % 128) == 0 &&
+  const bool fast = !cmul && nbatch == 1 && nsplit == 1 && !accumulate && sak == 1 && sbk == 1 && scn == 1 && (M % 128) == 0 &&
                     (N % 128) == 0 && (K % 16) == 0 && (sam % 4) == 0 && (sbn % 4) == 0 &&
                     (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
   if (fast) {
@@ -406,6 +411,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   p.M = M; p.N = N; p.K = K;
   p.nsplit = nsplit;
   p.relu = relu; p.accumulate = accumulate;
+  p.cmul = cmul;
   if (nsplit > 1) {
     MMEGO_REQUIRE(splitk_ws != nullptr);
     int kc = cdiv(K, nsplit);

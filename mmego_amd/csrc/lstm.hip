@@ -25,6 +25,9 @@ struct Lstm64P {
   float* hn[2]; float* cn[2];
   float* gates[2]; float* cst[2]; float* hprev[2];
   int B, T;
+  // inverted inter-layer dropout fused into the output store (nn.LSTM(dropout=p) between stacked layers): drop_y / drop_mask
+  // have out's layout; the mask of element i is a hash of (i, seed_ctr[0], salt)
+  float* drop_y; float* drop_mask; float drop_p; const unsigned long long* seed_ctr; unsigned salt;
 };
 
 // rcp / v_exp_f32-based activations: a few ulp from the libm forms at a fraction of their instruction count (the step loop
@@ -78,6 +81,9 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
   // per-step stride from bases computed once (the address arithmetic used to outweigh the MFMAs).
   float xp[4][4], xpn[4][4];
   const bool stash = p.gates[d] != nullptr, keep_h = p.hprev[d] != nullptr;
+  const bool drop = p.drop_mask != nullptr;
+  const unsigned dkey = drop ? dropout_key(p.seed_ctr[0], p.salt) : 0u;
+  const float keep_scale = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
   const int t_first = d == 0 ? 0 : T - 1;
   const long dir = d == 0 ? 1 : -1;
   const float* xq[4];
@@ -140,6 +146,12 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
       hs[j * 16 + fq * 4 + reg] = hn;
       if (live[reg]) {
         *oq[reg] = hn;
+        if (drop) {
+          const long off = oq[reg] - p.out;
+          const float mk = dropout_keep(dkey, (unsigned)off, p.drop_p) ? keep_scale : 0.f;
+          p.drop_mask[off] = mk;
+          p.drop_y[off] = hn * mk;
+        }
         if (stash) {
           float* gs = gq[reg];
           gs[0] = gi; gs[64] = gf; gs[128] = gg; gs[192] = go;
@@ -171,7 +183,10 @@ extern "C" int mmego_lstm64_forward(void* stream, int B, int T, const float* xpr
                                     const float* h0_0, const float* h0_1, const float* c0_0, const float* c0_1, float* out,
                                     long os, float* hn0, float* hn1,
                                     float* cn0, float* cn1, float* gates0, float* gates1, float* cst0, float* cst1,
-                                    float* hprev0, float* hprev1) {
+                                    float* hprev0, float* hprev1, float* drop_y, float* drop_mask, float drop_p,
+                                    const unsigned long long* seed_ctr, int salt) {
+  MMEGO_REQUIRE((drop_mask == nullptr) == (drop_y == nullptr));
+  MMEGO_REQUIRE(!drop_mask || (seed_ctr && drop_p > 0.f && drop_p < 1.f && (long)B * T * os < (1L << 32)));
   MMEGO_REQUIRE(B > 0 && T > 0 && xproj0 && xproj1 && whh0 && whh1 && out);
   MMEGO_REQUIRE((((uintptr_t)whh0 | (uintptr_t)whh1) & 15) == 0);
   MMEGO_REQUIRE((gates0 == nullptr) == (cst0 == nullptr) && (gates1 == nullptr) == (cst1 == nullptr));
@@ -185,6 +200,7 @@ extern "C" int mmego_lstm64_forward(void* stream, int B, int T, const float* xpr
   p.gates[0] = gates0; p.gates[1] = gates1; p.cst[0] = cst0; p.cst[1] = cst1;
   p.hprev[0] = hprev0; p.hprev[1] = hprev1;
   p.B = B; p.T = T;
+  p.drop_y = drop_y; p.drop_mask = drop_mask; p.drop_p = drop_p; p.seed_ctr = seed_ctr; p.salt = (unsigned)salt;
   size_t lds = (size_t)(64 * 16) * sizeof(float);            // h tile only: W_hh lives in registers
   static bool attr_set = false;
   if (!attr_set) {

@@ -55,30 +55,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
-// counter-based hash RNG (per element, per call seed): keep with probability 1-p, scale by 1/(1-p)
-__device__ __forceinline__ unsigned hash32(unsigned x) {
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-  return x;
-}
-
-__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ X, float* __restrict__ Y,
-                                                      float* __restrict__ mask, long n, float p,
-                                                      const unsigned long long* __restrict__ seed_ctr) {
-  const unsigned long long seed = seed_ctr[0];
-  const float keep_scale = 1.0f / (1.0f - p);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    unsigned h = hash32((unsigned)i ^ hash32((unsigned)(seed & 0xffffffffU) + 0x9e3779b9U * (unsigned)(seed >> 32)));
-    float u = (h >> 8) * (1.0f / 16777216.0f);
-    float mk = u >= p ? keep_scale : 0.f;
-    mask[i] = mk;
-    Y[i] = X[i] * mk;
-  }
-}
-
-__global__ void seed_tick_kernel(unsigned long long* seed_ctr) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) seed_ctr[0] = seed_ctr[0] * 6364136223846793005ULL + 1442695040888963407ULL;
-}
-
 static inline int ew_blocks(long total) {
   long b = (total + 255) / 256;
   return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -106,17 +82,6 @@ extern "C" int mmego_adam_step(void* stream, float* p, const float* g, float* m,
   MMEGO_LAUNCH_CHECK();
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, p, g, m, v, n / 4, state, (float)beta2,
                      (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, sk);
-  MMEGO_LAUNCH_CHECK();
-  return MMEGO_OK;
-}
-
-extern "C" int mmego_dropout(void* stream, const float* X, float* Y, float* mask, long n, float p,
-                             unsigned long long* seed_ctr) {
-  MMEGO_REQUIRE(X && Y && mask && seed_ctr && n > 0 && p >= 0.f && p < 1.f);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(seed_tick_kernel, dim3(1), dim3(64), 0, st, seed_ctr);
-  MMEGO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, X, Y, mask, n, p, seed_ctr);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -580,9 +580,10 @@ __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
 }
 
-__global__ void inc_i64_kernel(long long* x, long n) {
+__global__ void inc_i64_kernel(long long* x, long n, unsigned long long* seed_ctr) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] += 1;
+  if (i == 0 && seed_ctr) seed_ctr[0] = seed_ctr[0] * 6364136223846793005ULL + 1442695040888963407ULL;
 }
 
 static inline int ew_blocks(long total) {
@@ -721,9 +722,9 @@ extern "C" int mmego_add(void* stream, const float* a, const float* b, float* ou
   return MMEGO_OK;
 }
 
-extern "C" int mmego_inc_i64(void* stream, long long* x, long n) {
-  MMEGO_REQUIRE(x && n > 0);
-  hipLaunchKernelGGL(inc_i64_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, x, n);
+extern "C" int mmego_inc_i64(void* stream, long long* x, long n, unsigned long long* seed_ctr) {
+  MMEGO_REQUIRE(n >= 0 && (n == 0 || x) && (n > 0 || seed_ctr));
+  hipLaunchKernelGGL(inc_i64_kernel, dim3(n > 0 ? cdiv(n, 64) : 1), dim3(64), 0, (hipStream_t)stream, x, n, seed_ctr);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

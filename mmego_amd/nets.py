@@ -204,7 +204,7 @@ class UpperNet(_NetBase):
         l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=x.device)
         ops.rotate_points(jh, l, R, t, transpose=True)
         if training:
-            self._flat.bump_bn_counters()
+            self._flat.bump_bn_counters(self.seed_counter())
         if stash:
             self._saved = (B, T, N, R, body, c0, attn)
         return l, q, attn, hn, cn
@@ -395,7 +395,7 @@ class LowerNet(_NetBase):
         l = torch.empty((B, T, 8, 3), dtype=torch.float32, device=dev)
         ops.rotate_points(jh, l, R, t, transpose=True)
         if training:
-            self._flat.bump_bn_counters()
+            self._flat.bump_bn_counters(self.seed_counter())
         if stash:
             self._saved = (B, T, N, R, body)
         return l, q

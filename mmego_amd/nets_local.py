@@ -132,7 +132,7 @@ class UpperNetwlocal(_NetBase):
         vvec = ar.get("vvec", (F, 64))
         blocks.mlp3_forward(ar, "vx", self.module2.avoxel, voxT, vvec, training)
         p_a = self._drop_p(self.module2.arnn.rnn) if stash else 0.0
-        seq_a, hn_a, cn_a = blocks.lstm64_forward(ar, "arnn", self.module2.arnn.rnn, vvec, B, T, h0a, c0a, stash, p_a, self.seed_counter())
+        seq_a, hn_a, cn_a = blocks.lstm64_forward(ar, "arnn", self.module2.arnn.rnn, vvec, B, T, h0a, c0a, stash, p_a, self.seed_counter(), salt=1)
         ops.copy2d(seq_a, cat[:, 128:])
         # combine head
         h1 = ar.get("h1", (F, 128))
@@ -145,7 +145,7 @@ class UpperNetwlocal(_NetBase):
         l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=dev)
         ops.rotate_points(jh, l, R, t, transpose=True)
         if training:
-            self._flat.bump_bn_counters()
+            self._flat.bump_bn_counters(self.seed_counter())
         if stash:
             self._saved = (B, T, N, R, body, c0g, c0a, gw, aw)
         return l, q, gw, aw, hn_g, cn_g, hn_a, cn_a

@@ -87,8 +87,9 @@ def scratch(device, n):
     return t
 
 
-def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1):
-    """C[M,N] (+)= A[M,K] @ B[K,N] (+bias)(relu); A, B, C are 2-D views with arbitrary strides."""
+def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1, cmul=None):
+    """C[M,N] (+)= A[M,K] @ B[K,N] (+bias)(relu), then (*= cmul, a tensor with C's shape and strides);
+    A, B, C are 2-D views with arbitrary strides."""
     _chk(A, 2), _chk(B, 2), _chk(C, 2)
     M, K = A.shape
     K2, N = B.shape
@@ -99,8 +100,10 @@ def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1):
     ws = None
     if nsplit > 1:
         ws = scratch(A.device, nsplit * M * N)
+    if cmul is not None and (tuple(cmul.shape) != (M, N) or cmul.stride() != C.stride() or nsplit > 1):
+        raise ValueError("mm: cmul needs C's shape and strides, and an unsplit product")
     hip.call("gemm", A, A.stride(0), A.stride(1), B, B.stride(0), B.stride(1), C, C.stride(0), C.stride(1), bias,
-             M, N, K, 1, 0, 0, 0, int(relu), int(accumulate), ws, nsplit, 0)
+             M, N, K, 1, 0, 0, 0, int(relu), int(accumulate), ws, nsplit, 0, cmul)
     return C
 
 
@@ -111,7 +114,7 @@ def bmm(A, B, C, accumulate=False):
     if B.shape[0] != nb or C.shape[0] != nb or B.shape[1] != K or tuple(C.shape[1:]) != (M, B.shape[2]):
         raise ValueError("bmm shape mismatch")
     hip.call("gemm", A, A.stride(1), A.stride(2), B, B.stride(1), B.stride(2), C, C.stride(1), C.stride(2), None,
-             M, B.shape[2], K, nb, A.stride(0), B.stride(0), C.stride(0), 0, int(accumulate), None, 1, 0)
+             M, B.shape[2], K, nb, A.stride(0), B.stride(0), C.stride(0), 0, int(accumulate), None, 1, 0, None)
     return C
 
 
@@ -127,7 +130,7 @@ def linear_pair(x, W0, W1, b0, b1, out, ncol):
         linear(x, W0, b0, out[:, :ncol])
         linear(x, W1, b1, out[:, ncol:2 * ncol])
         return out
-    hip.call("gemm", x, x.stride(0), 1, W0, 1, K, out, out.stride(0), 1, b0, rows, ncol, K, 2, 0, dW, ncol, 0, 0, None, 1, dB)
+    hip.call("gemm", x, x.stride(0), 1, W0, 1, K, out, out.stride(0), 1, b0, rows, ncol, K, 2, 0, dW, ncol, 0, 0, None, 1, dB, None)
     return out
 
 
@@ -179,12 +182,12 @@ def grad_weight_pair(dY, ncol, X, dW0, dW1, X1=None):
         grad_weight(dY[:, :ncol], X, dW0)
         grad_weight(dY[:, ncol:2 * ncol], Xb, dW1)
         return
-    hip.call("gemm", dY, 1, dY.stride(0), X, X.stride(0), 1, W0, K, 1, None, ncol, K, rows, 2, ncol, xdist // 4, dist // 4, 0, 0, None, 1, 0)
+    hip.call("gemm", dY, 1, dY.stride(0), X, X.stride(0), 1, W0, K, 1, None, ncol, K, rows, 2, ncol, xdist // 4, dist // 4, 0, 0, None, 1, 0, None)
 
 
-def grad_input(dY, W, dX, accumulate=False):
-    """dX[rows,K] (+)= dY[rows,N] @ W[N,K]"""
-    return mm(dY, W.view(W.shape[0], -1), dX, accumulate=accumulate)
+def grad_input(dY, W, dX, accumulate=False, cmul=None):
+    """dX[rows,K] (+)= dY[rows,N] @ W[N,K], then (*= cmul)"""
+    return mm(dY, W.view(W.shape[0], -1), dX, accumulate=accumulate, cmul=cmul)
 
 
 def colsum(X, out, accumulate=False, out2=None):

@@ -76,9 +76,12 @@ class FlatParams:
             if p.grad is not None:
                 p.grad = self._gviews[id(p)]
 
-    def bump_bn_counters(self):
+    def bump_bn_counters(self, seed_ctr=None):
+        """The once-per-training-forward tick: BatchNorm num_batches_tracked += 1 and, with ``seed_ctr``, the next dropout seed."""
         if self._counters is not None:
-            hip.call("inc_i64", self._counters, self._counters.numel())
+            hip.call("inc_i64", self._counters, self._counters.numel(), seed_ctr)
+        elif seed_ctr is not None:
+            hip.call("inc_i64", None, 0, seed_ctr)
 
     def bind_grads(self):
         """Expose the flat gradient views as ``p.grad`` (for torch optimisers / inspection)."""

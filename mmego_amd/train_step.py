@@ -108,7 +108,6 @@ class StageStep:
         assert stage in ("upper", "lower")
         self.stage, self.net, self.imu, self.upper_frozen = stage, net, imu_net, upper_frozen
         self.pose = pose              # (R, t) device buffers filled by somebody else (the "IMU-shared" arrangement)
-        self.before_imu = self.after_imu = self.imu_milestone = None   # scheduling hooks of ConcurrentStages
         self.opt = FusedAdam(net.flat(), lr=lr, weight_decay=weight_decay)
         self.pg = process_group
         self.use_graph = use_graph
@@ -132,22 +131,13 @@ class StageStep:
         B, T = s["x"].shape[0], s["x"].shape[1]
         ops.copy2d(s["x_src"].view(B * T, -1), s["x"].view(B * T, -1))        # fresh batch (x is transformed in place)
         with torch.no_grad():
-            if self.before_imu is not None:
-                self.before_imu()
             if self.pose is not None:
                 R, t = self.pose
             elif self.imu is not None:
-                from . import blocks
-                blocks.milestone = self.imu_milestone
-                try:
-                    R, t = self.imu(s["imu"])
-                finally:
-                    blocks.milestone = None
+                R, t = self.imu(s["imu"])
             else:
                 R, t = s["R_gt"], s["t_gt"]
                 ops.copy2d(s["target"].view(B * T, 63)[:, 60:63], t.view(B * T, 3))
-            if self.after_imu is not None:
-                self.after_imu()
             if self.stage == "upper":
                 l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["body"], R, t, stash=True)[0]
                 nsel = 15
@@ -329,7 +319,6 @@ class ConcurrentStages:
         self.use_graph = use_graph
         self.graph = None
         self.side = [torch.cuda.Stream() for _ in self.stages[1:]]
-        self.chain_imu = int(os.environ.get("MMEGO_CHAIN_IMU", "1"))
         self._poses = {}
         # data parallel: the stages' gradients share one buffer, so one collective per step serves all of them
         self.bucket = None
@@ -347,65 +336,42 @@ class ConcurrentStages:
 
     def _bodies(self, nested=False):
         """Branch order: the LAST stage (longest tail: the Lower body also runs the frozen Upper_Net) gets its IMU_Net forward
-        first; each earlier stage's IMU_Net forward follows when that one has finished.  The IMU_Net forwards are compute-bound
-        and gain nothing from running side by side, whereas the small-kernel tail of one stage overlaps well with the IMU_Net
-        forward of another (measured: 6.88 -> 6.54 ms per U+L step).
-
-        MMEGO_CHAIN_IMU=1 (default): the IMU_Net forwards run one after the other on the launching stream and hand their head
-        poses to the stage bodies through per-stage buffers; each stage's remaining body forks off right after its own forward.
-        MMEGO_CHAIN_IMU=0 lets the branches (IMU_Net forwards included) start together; 2 offsets them by the first projections."""
+        first, alone on the GPU, with its recurrences as two single-direction chains (blocks.two_chains); each earlier stage's
+        IMU_Net forward follows on the launching stream when that one has finished, with the previous stage's small-kernel tail
+        beside it; each stage's remaining body forks off right after its own forward and takes the head pose from a per-stage
+        buffer.  The IMU_Net forwards are compute-bound and gain nothing from running side by side, whereas the small-kernel
+        tail of one stage overlaps with the IMU_Net forward of another (measured: 6.88 -> 6.54 ms per U+L step).  Other
+        arrangements that were measured and dropped: DESIGN.md section 9."""
         if not nested:
             ops.mark_capture_origin()
         main = torch.cuda.current_stream()
         stages, streams = self.stages, [main] + self.side
-        if self.chain_imu == 1:
-            keep = [(st.imu, st.pose) for st in stages]
-            try:
-                for i in range(len(stages) - 1, -1, -1):
-                    st = stages[i]
-                    if st.imu is not None and st.pose is None:
-                        from . import blocks
-                        # the FIRST forward (the last stage's) has the GPU to itself: its recurrences run as two chains; the
-                        # later ones have another stage's tail beside them, which fills the same gaps (blocks.two_chains)
-                        alone = i == len(stages) - 1 and os.environ.get("MMEGO_FIRST_IMU_TWO_CHAINS", "1") != "0"
-                        with torch.no_grad(), blocks.two_chains(alone):
-                            R, t = st.imu(st.static["imu"])
-                            pose = self._pose_buf(i, R, t)
-                            ops.copy2d(R.view(-1, 9), pose[0].view(-1, 9))
-                            ops.copy2d(t.view(-1, 3), pose[1].view(-1, 3))
-                        st.pose = pose
-                    if i > 0:
-                        streams[i].wait_stream(main)
-                        with torch.cuda.stream(streams[i]):
-                            st._body(nested=True)
-                    else:
+        keep = [(st.imu, st.pose) for st in stages]
+        try:
+            for i in range(len(stages) - 1, -1, -1):
+                st = stages[i]
+                if st.imu is not None and st.pose is None:
+                    from . import blocks
+                    # the FIRST forward (the last stage's) has the GPU to itself: its recurrences run as two chains; the
+                    # later ones have another stage's tail beside them, which fills the same gaps (blocks.two_chains)
+                    alone = i == len(stages) - 1 and os.environ.get("MMEGO_FIRST_IMU_TWO_CHAINS", "1") != "0"
+                    with torch.no_grad(), blocks.two_chains(alone):
+                        R, t = st.imu(st.static["imu"])
+                        pose = self._pose_buf(i, R, t)
+                        ops.copy2d(R.view(-1, 9), pose[0].view(-1, 9))
+                        ops.copy2d(t.view(-1, 3), pose[1].view(-1, 3))
+                    st.pose = pose
+                if i > 0:
+                    streams[i].wait_stream(main)
+                    with torch.cuda.stream(streams[i]):
                         st._body(nested=True)
-            finally:
-                for st, (imu, pose) in zip(stages, keep):
-                    st.imu, st.pose = imu, pose
-            for side in self.side:
-                main.wait_stream(side)
-            return
-        events = [torch.cuda.Event() for _ in stages]
-        for i, st in enumerate(stages):
-            st.before_imu = st.after_imu = st.imu_milestone = None
-            if self.chain_imu == 2:                          # release the next branch when rnn_fast's first input projections are done
-                st.imu_milestone = lambda key, l, ev=events[i], sm=streams[i]: ev.record(sm) if (key, l) == ("fast", 0) else None
-                if st.imu is None:
-                    st.after_imu = lambda ev=events[i], sm=streams[i]: ev.record(sm)
-        if self.chain_imu:
-            for i in range(len(stages) - 1):                 # stage i waits for stage i+1
-                stages[i].before_imu = (lambda ev=events[i + 1], sm=streams[i]: sm.wait_event(ev))
-        for side in self.side:
-            side.wait_stream(main)
-        for i in range(len(stages) - 1, 0, -1):              # enqueue the later stages first: their events must exist
-            with torch.cuda.stream(streams[i]):
-                stages[i]._body(nested=True)
-        stages[0]._body(nested=True)
+                else:
+                    st._body(nested=True)
+        finally:
+            for st, (imu, pose) in zip(stages, keep):
+                st.imu, st.pose = imu, pose
         for side in self.side:
             main.wait_stream(side)
-        for st in stages:
-            st.before_imu = st.after_imu = st.imu_milestone = None
 
     def _pose_buf(self, i, R, t):
         buf = self._poses.get(i)

@@ -13,7 +13,7 @@ for T in (8, 16):
         gates = torch.empty(2, T, B, 256, device=dev); cst = torch.empty(2, T, B, 64, device=dev); hp = torch.empty(2, B * T, 64, device=dev)
         st = (gates[0], gates[1], cst[0], cst[1], hp[0], hp[1]) if stash else (None,) * 6
         def call():
-            hip.call("lstm64_forward", B, T, xp, xp[:, 256:], 512, w[0], w[1], b[0], b[1], None, None, None, None, out, 128, hn[0], hn[1], cn[0], cn[1], *st)
+            hip.call("lstm64_forward", B, T, xp, xp[:, 256:], 512, w[0], w[1], b[0], b[1], None, None, None, None, out, 128, hn[0], hn[1], cn[0], cn[1], *st, None, None, 0.0, None, 0)
         for _ in range(5): call()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -97,3 +97,56 @@ if "--chains" in sys.argv:
         print("layer recurrence Bn=%d T=%d, %s: %.1f us per layer = %.2f us per timestep, %.1f TFLOP/s"
               % (Bn, T, "2 chains x %d single-direction launches" % T if two else "%d launches (both directions each)" % T, us, us / T,
                  fl / us / 1e6))
+
+
+if "--pair" in sys.argv:
+    # two INDEPENDENT BiLSTM layers (the two stages' frozen IMU_Net instances): one after the other against side by side on two
+    # streams, every launch carrying both directions of its instance (HT = 32, two workgroups of different launches per CU)
+    from mmego_amd import blocks, ops
+    inst = [blocks.LstmParams(H, H, 1).to(dev) for _ in range(2)]
+    xps = [torch.randn(Bn * T, 8 * H, device=dev) * 0.1 for _ in range(2)]
+    ars = [ops.Arena(dev) for _ in range(2)]
+    outs = [a.get("out", (Bn * T, 2 * H)) for a in ars]
+    side = torch.cuda.Stream()
+
+    def one(i):
+        blocks.lstm_recurrence(ars[i], "k", inst[i], 0, xps[i], outs[i], Bn, T)
+
+    def serial(two_first):
+        with blocks.two_chains(two_first):
+            one(0)
+        with blocks.two_chains(False):
+            one(1)
+
+    def beside():
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with blocks.two_chains(False):
+            with torch.cuda.stream(side):
+                one(1)
+            one(0)
+        cur.wait_stream(side)
+
+    for name, run in (("one after the other, both one launch per timestep", lambda: serial(False)),
+                      ("one after the other, the first as two chains", lambda: serial(True)),
+                      ("side by side on two streams, one launch per timestep each", beside)):
+        run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(g, stream=st):
+                ops.mark_capture_origin()
+                run()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        print("two instances' layer recurrence Bn=%d T=%d, %s: %.1f us = %.2f us per timestep of both" % (Bn, T, name, us, us / T))

@@ -123,7 +123,7 @@ def test_fused_eval_mlp_and_bn_fold(dev):
         ybuf = torch.full((rows, dims[3] + 7), 7.0, device=dev)
         y = ybuf[:, 2:2 + dims[3]]
         cur = x.double().cpu()
-        folded = []
+        folded, raw, bn = [], [], []
         for i in range(3):
             K, C = dims[i], dims[i + 1]
             W, b = torch.randn(C, K, generator=g) * 0.4, torch.randn(C, generator=g) * 0.2
@@ -132,13 +132,68 @@ def test_fused_eval_mlp_and_bn_fold(dev):
             z = cur @ W.double().t() + b.double()
             cur = torch.relu((z - mean.double()) / torch.sqrt(var.double() + 1e-5) * gamma.double() + beta.double())
             wf, bf = torch.empty(C, K, device=dev), torch.empty(C, device=dev)
-            hip.call("bn_fold_linear", W.to(dev), b.to(dev), C, K, gamma.to(dev), beta.to(dev), mean.to(dev), var.to(dev), 1e-5, wf, bf)
+            dv = [t.to(dev) for t in (W, b, gamma, beta, mean, var)]
+            hip.call("bn_fold_linear", dv[0], dv[1], C, K, dv[2], dv[3], dv[4], dv[5], 1e-5, wf, bf)
             folded += [wf, bf, C]
-        hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *folded, y, y.stride(0))
+            raw += [dv[0], dv[1], C]
+            bn += dv[2:]
+        hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *folded, y, y.stride(0), None, 0.0)
         torch.cuda.synchronize()
         err = (y.double().cpu() - cur).abs().max().item()
         assert err < 2e-5 * max(1.0, cur.abs().max().item()), (rows, dims, err)
         assert (ybuf[:, :2] == 7.0).all() and (ybuf[:, 2 + dims[3]:] == 7.0).all(), "writes stay inside the output slice"
+        # the kernel folding BatchNorm itself (raw conv parameters + a host array of the 12 BatchNorm vectors): same bits
+        y2 = torch.empty(rows, dims[3], device=dev)
+        hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *raw, y2, y2.stride(0),
+                 torch.tensor([t.data_ptr() for t in bn], dtype=torch.int64), 1e-5)
+        assert torch.equal(y2, y)
+
+
+def test_lstm64_fused_dropout_and_bias_pair(dev):
+    """nn.LSTM(dropout=0.1)'s inter-layer dropout as applied by the layer kernel while it stores its outputs: masks are 0 or
+    1/(1-p) with the right rate, differ per layer, are a function of the seed counter alone and change when the net's
+    once-per-forward tick advances it; the layer outputs themselves are those of the dropout-free pass on the same inputs.
+    Backward: the mask on the input gradient (product epilogue) and the four bias gradients of a layer in one launch."""
+    from mmego_amd import blocks, hip, ops
+    torch.manual_seed(3)
+    lstm = blocks.LstmParams(64, 64, 3, dropout=0.1).to(dev)
+    B, T, p = 64, 8, 0.1
+    x = torch.randn(B * T, 64, device=dev)
+    seed = torch.tensor([12345], dtype=torch.int64, device=dev)
+    ar = ops.Arena(dev)
+    blocks.lstm64_forward(ar, "k", lstm, x, B, T, None, None, True, p, seed)
+    masks = []
+    for l in (0, 1):
+        o, d, m = (ar.get("k.%s%d" % (n, l), (B * T, 128)) for n in ("out", "do", "mk"))
+        assert torch.equal(d, o * m)
+        keep = torch.tensor(1.0 / (1.0 - p), device=dev)
+        assert ((m == 0) | (m == keep)).all()
+        rate = (m == 0).float().mean().item()
+        assert abs(rate - p) < 0.01, rate                       # 65536 draws: sigma = 0.0012
+        masks.append(m.clone())
+    assert not torch.equal(masks[0], masks[1])
+    ar2 = ops.Arena(dev)
+    blocks.lstm64_forward(ar2, "k", lstm, x, B, T, None, None, True, p, seed)         # same counter: same masks
+    assert torch.equal(ar2.get("k.mk0", (B * T, 128)), masks[0])
+    hip.call("inc_i64", None, 0, seed)                                              # the tick of a training forward
+    blocks.lstm64_forward(ar2, "k", lstm, x, B, T, None, None, True, p, seed)
+    assert not torch.equal(ar2.get("k.mk0", (B * T, 128)), masks[0])
+    ar3 = ops.Arena(dev)
+    blocks.lstm64_forward(ar3, "k", lstm, x, B, T, None, None, True, 0.0, seed)      # layer 0 sees the same input either way
+    assert torch.equal(ar3.get("k.out0", (B * T, 128)), ar.get("k.out0", (B * T, 128)))
+    # backward pieces
+    dg = torch.randn(B * T, 512, device=dev)
+    outs = [torch.zeros(256, device=dev) for _ in range(4)]
+    hip.call("colsum_pair", dg, 512, B * T, 256, outs[0], outs[1], outs[2], outs[3], 0)
+    ref = dg.double().sum(0).float()
+    assert torch.allclose(outs[0], ref[:256], rtol=1e-6, atol=1e-5) and torch.equal(outs[0], outs[1])
+    assert torch.allclose(outs[2], ref[256:], rtol=1e-6, atol=1e-5) and torch.equal(outs[2], outs[3])
+    W = torch.randn(256, 128, device=dev) * 0.1
+    dx, dx2 = torch.randn(B * T, 128, device=dev), None
+    dx2 = dx.clone()
+    ops.grad_input(dg[:, 256:], W, dx, accumulate=True, cmul=masks[0])
+    ops.grad_input(dg[:, 256:], W, dx2, accumulate=True)
+    assert torch.equal(dx, dx2 * masks[0])
 
 
 def _seq(real16, i, device=None):
