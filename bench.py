@@ -105,30 +105,73 @@ def profile_kernels(steps_fn, names, iters=3):
             rec[name].append((e0, e1, args, rep))
         else:
             orig(name, *args)
-    from mmego_amd import blocks
-    rec_layers = []
-    orig_rec = blocks.lstm_recurrence
-
-    def timed_recurrence(ar, key, lstm, l, xp, out, Bn, T_, **kw):
-        # one BiLSTM layer's recurrence (T_ timesteps, both directions; from 128 rows: two concurrent chains of single-direction
-        # launches) between ONE event pair on the launching stream: fork and join are inside
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig_rec(ar, key, lstm, l, xp, out, Bn, T_, **kw)
-        e1.record()
-        rec_layers.append((e0, e1, (Bn, lstm.hidden_size, T_, bool(blocks._LSTM_TWO_CHAINS and T_ > 1 and Bn >= 128))))
     hip.call = timed_call
-    blocks.lstm_recurrence = timed_recurrence
     try:
         for _ in range(iters):
             steps_fn()
         torch.cuda.synchronize()
     finally:
         hip.call = orig
-        blocks.lstm_recurrence = orig_rec
     out = {n: [(a.elapsed_time(b) / rep, args) for a, b, args, rep in v] for n, v in rec.items()}
-    out["lstm_recurrence"] = [(a.elapsed_time(b), args) for a, b, args in rec_layers]
     return out, iters
+
+
+def recurrence_graph(device, Bn=512, H=512, T=20, replays=20):
+    """One rnn_fast layer's recurrence (T timesteps, Bn rows, both directions) as REPLAYED HIP GRAPHS, the way the step runs it
+    (an eager event pair around a launch includes 5-10 us of host launch latency): (a) one launch per timestep for both
+    directions, (b) two concurrent chains of single-direction launches (what the first IMU_Net forward of the U+L step uses),
+    (c) two independent nets' recurrences side by side on two streams (not what the step uses).  Per
+    timestep of ONE net: us and fraction of the fp32 MFMA peak over the T-1 product-carrying steps."""
+    from mmego_amd import blocks, ops
+    nets = [blocks.LstmParams(H, H, 1).to(device) for _ in range(2)]
+    xps = [torch.randn(Bn * T, 8 * H, device=device) * 0.1 for _ in range(2)]
+    ars = [ops.Arena(device) for _ in range(2)]
+    outs = [a.get("out", (Bn * T, 2 * H)) for a in ars]
+    side = torch.cuda.Stream()
+    one = lambda i: blocks.lstm_recurrence(ars[i], "k", nets[i], 0, xps[i], outs[i], Bn, T)
+
+    def single():
+        with blocks.two_chains(False):
+            one(0)
+
+    def chains():
+        with blocks.two_chains(True):
+            one(0)
+
+    def pair():
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with blocks.two_chains(False):
+            with torch.cuda.stream(side):
+                one(1)
+            one(0)
+        cur.wait_stream(side)
+    res = {}
+    flops = 2.0 * 2 * Bn * 4 * H * H * (T - 1)
+    for name, body, nets_in_body in (("one_launch_per_timestep", single, 1), ("two_chains", chains, 1), ("two_nets_side_by_side", pair, 2)):
+        body()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(g, stream=st):
+                ops.mark_capture_origin()
+                body()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(replays):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / replays * 1e3 / nets_in_body
+        res[name] = {"us_per_timestep": us / T, "tflops": flops / us / 1e6, "frac": flops / us / 1e6 / PEAK_FP32_MFMA_TFLOPS}
+    res["what"] = ("replayed graphs of one BiLSTM layer's recurrence, Bn=%d H=%d T=%d; per timestep of one net; 2 x 2 x Bn x 4H x H "
+                   "flop per product step" % (Bn, H, T))
+    return res
 
 
 def host_cores():
@@ -588,14 +631,7 @@ def main():
         if big16:
             cands["lstm_step_dma_kernel<16> (IMU_Net rnn_fast recurrent steps, ONE direction per launch: 512 rows x 2048 gates x K=512; "
                   "the two directions' launches run concurrently as two chains, so a launch's duration is NOT its share of the "
-                  "step: see lstm_recurrence)"] = big16
-        # a rnn_fast layer's whole recurrence run as two concurrent single-direction chains, timed as ONE region:
-        # flops = 2 dirs x 2 x Bn x 4H x H per product-carrying timestep; reported per timestep
-        layers = [(ms_ / a[2], 2.0 * 2 * a[0] * 4 * a[1] * a[1] * (a[2] - 1) / a[2]) for ms_, a in rec["lstm_recurrence"]
-                  if a[0] >= 128 and a[3]]
-        if layers:
-            cands["lstm_recurrence (IMU_Net rnn_fast: per TIMESTEP of a layer's recurrence run as two concurrent "
-                  "lstm_step_dma_kernel<16> chains; 2 x 512 rows x 2048 gates x K=512)"] = layers
+                  "step: see recurrence_graph)"] = big16
         if small:
             cands["lstm_step_small_kernel (IMU_Net rnn_slow recurrent steps: 2 dirs x 64 rows x 2048 gates x K=512)"] = small
         if g128:
@@ -605,8 +641,7 @@ def main():
         # dominant kernel = largest total time over the eager replay; no tie rule.  Every candidate is reported with its own
         # fraction in `roofline_kernels`, so a near tie between the projection GEMM and the recurrent step shows as such.
         # (per-launch entries of the recurrent step stay out of the contest when a whole-recurrence entry covers them)
-        totals = {k: sum(m for m, _ in v) for k, v in cands.items()
-                  if not (k.startswith("lstm_step_dma_kernel<16>") or k.startswith("lstm_recurrence"))}
+        totals = {k: sum(m for m, _ in v) for k, v in cands.items() if not k.startswith("lstm_step_dma_kernel<16>")}
         best_k = max(totals, key=totals.get)
         best = (best_k, cands[best_k])
         tot_ms = sum(m for m, _ in best[1])
@@ -638,6 +673,7 @@ def main():
                                        "frac": sum(f for _, f in v) / (sum(m for m, _ in v) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                        "ms_per_step": sum(m for m, _ in v) / iters,
                                        "share_of_step": (sum(m for m, _ in v) / iters) / (t_u + t_l)} for k, v in cands.items()}
+        out["recurrence_graph"] = recurrence_graph(device)
         sys.stderr.write("[bench] gpu part done: %.1f frames/s; timing the CPU oracle on %d threads\n" % (out["value"], host_cores()))
         sys.stderr.flush()
         if world == 1 and not args.no_config_extras:
