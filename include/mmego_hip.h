@@ -30,10 +30,13 @@ extern "C" {
 /* (sBiasb: element stride of `bias` between batches, 0 = one bias for all -- lets the two directions' input projections of a
  * BiLSTM layer run as ONE batched product: same A, two weight / bias / output-column blocks.)
  * cmul (may be NULL; nsplit == 1 only): elementwise multiplier in C's layout applied after bias / relu / accumulate -- the
- * inter-layer dropout mask on an LSTM layer's input gradient. */
+ * inter-layer dropout mask on an LSTM layer's input gradient.
+ * asum (may be NULL): asum[b*M + m] (+)= sum_k A[b](m,k), computed from the operand values the product loads anyway -- the bias
+ * gradient beside a weight gradient dW = dY^T X (A = dY^T).  Only for the small-product shapes (about M*N*nsplit*nbatch <=
+ * 2 M outputs, K slabs >= 64: bad argument otherwise); with nsplit > 1 splitk_ws needs nsplit*nbatch*M more floats. */
 int mmego_gemm(void* stream, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
                long scm, long scn, const float* bias, int M, int N, int K, int nbatch, long sAb, long sBb, long sCb,
-               int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb, const float* cmul);
+               int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb, const float* cmul, float* asum);
 
 /* ---- BatchNorm and row-wise helpers (bn.hip) ----------------------------------------------------
  * Train-mode statistics of X[rows, C] (+ running-stat update with torch semantics: momentum, unbiased

@@ -184,9 +184,7 @@ def mlp3_backward(ar, key, mod, x, y3, dy3, G, need_dx):
 def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False, bias_grad=True):
     """Gradients of y = x W^T + b: writes G(W), G(b); fills dx if given.  bias_grad=False: the layer feeds a batch-statistics
     BatchNorm directly, so the bias gradient is identically zero and its slot in the gradient buffer stays 0."""
-    ops.grad_weight(dy, x, G(lin.weight))
-    if lin.bias is not None and bias_grad:
-        ops.colsum(dy, G(lin.bias))
+    ops.grad_weight(dy, x, G(lin.weight), db=G(lin.bias) if lin.bias is not None and bias_grad else None)
     if dx is not None:
         ops.grad_input(dy, lin.weight, dx, accumulate=accumulate_dx)
     return dx

@@ -28,6 +28,8 @@ struct GemmP {
   int relu, accumulate;
   int avec, bvec;     // operand is k-contiguous with 16-B aligned rows: float4 loads allowed
   const float* cmul;  // optional elementwise multiplier in C's layout, applied last (a dropout mask on an input gradient)
+  float* asum;        // optional: asum[b][m] (+)= sum_k A[b](m,k) -- the bias gradient beside a weight gradient dW = dY^T X
+                      // (gemm32kq only; with split-K the slab sums go behind the product slabs and the reducer finishes them)
 };
 
 #define LD64 68
@@ -191,11 +193,17 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
   } while (0)
 
   f32x16 acc = {0};
+  const bool want_asum = p.asum != nullptr && blockIdx.y == 0;
+  float asum = 0.f;
   if (kbeg < kend) {
     KQ_LOAD(ra, rb, kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
       const bool more = k0 + 32 < kend;
       if (more) KQ_LOAD(na, nb, k0 + 32);
+      if (want_asum) {
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) asum += ra[s_];
+      }
 #pragma unroll
       for (int s_ = 0; s_ < 16; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s_], rb[s_], acc, 0, 0, 0);
       if (more) {
@@ -208,7 +216,20 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
   // partial tiles -> LDS; C layout of the 32x32 MFMA: lane holds column (lane&31), rows (reg&3) + 8 (reg>>2) + 4 (lane>>5)
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) red[wave][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] = acc[reg];
+  __shared__ float ared[4][2][32];
+  if (want_asum) ared[wave][h][r] = asum;
   __syncthreads();
+  if (want_asum && tid < 32 && m0 + tid < p.M) {          // the eight partial row sums in a fixed order
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += ared[w][0][tid] + ared[w][1][tid];
+    if (p.nsplit == 1) {
+      float* dst = p.asum + (long)batch * p.M + m0 + tid;
+      *dst = p.accumulate ? *dst + v : v;
+    } else {                                               // slab sums: [split][batch][M] behind the product slabs
+      p.asum[((long)split * (gridDim.z / p.nsplit) + batch) * p.M + m0 + tid] = v;
+    }
+  }
   float* C = p.C + (long)batch * p.sCb + (long)split * p.sCs;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -232,13 +253,23 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
 // load-latency bound), then the 16 partial sums are combined through LDS in a fixed order (deterministic).
 #define SKR_OUT 16
 #define SKR_LANES 16
+// asum_ws / asum_out (optional): [nsplit][nbatch*M] slab row sums of A (mmego_gemm's asum) -> asum_out[nbatch*M], reduced by the
+// blocks behind the product's own (the same lane structure, the same fixed order).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* C, const float* bias, int nsplit,
                                                             int nbatch, int M, int N, long scm, long scn, long sCb,
-                                                            int relu, int accumulate) {
+                                                            int relu, int accumulate, const float* __restrict__ asum_ws,
+                                                            float* asum_out) {
   __shared__ float sh[SKR_LANES][SKR_OUT + 1];
-  const long total = (long)nbatch * M * N;
+  long total = (long)nbatch * M * N;
   const int o = threadIdx.x & (SKR_OUT - 1), kg = threadIdx.x / SKR_OUT;
-  const long i = (long)blockIdx.x * SKR_OUT + o;
+  long i = (long)blockIdx.x * SKR_OUT + o;
+  const long cblocks = (total + SKR_OUT - 1) / SKR_OUT;
+  const bool is_asum = (long)blockIdx.x >= cblocks;        // (uniform per block)
+  if (is_asum) {
+    i = ((long)blockIdx.x - cblocks) * SKR_OUT + o;
+    total = (long)nbatch * M;
+    ws = asum_ws;
+  }
   float s = 0.0f;
   if (i < total) {
     const float* src = ws + i;
@@ -259,6 +290,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     s = sh[0][o];
 #pragma unroll
     for (int g = 1; g < SKR_LANES; ++g) s += sh[g][o];
+    if (is_asum) {
+      asum_out[i] = accumulate ? asum_out[i] + s : s;
+      return;
+    }
     int n = (int)(i % N);
     long r = i / N;
     int m = (int)(r % M);
@@ -354,7 +389,7 @@ __global__ __launch_bounds__(256) void gemm128_nt_kernel(const float* __restrict
 extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                           float* C, long scm, long scn, const float* bias, int M, int N, int K, int nbatch, long sAb,
                           long sBb, long sCb, int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb,
-                          const float* cmul) {
+                          const float* cmul, float* asum) {
   MMEGO_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && nsplit >= 1);
   MMEGO_REQUIRE(!cmul || nsplit == 1);
   MMEGO_REQUIRE(sBiasb == 0 || nsplit == 1);          // (the split-K reducer applies one shared bias)
@@ -373,7 +408,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
     const long tile_min_units = (a_kc && b_kc && nsplit == 1) ? (K <= 1024 ? 1 : 200) : tile_min_other;
     const long units64 = (long)(M / 64) * (N / 64) * nsplit * nbatch;
     static const bool nt_only = getenv("MMEGO_GEMM_TILE_NT_ONLY") != nullptr;
-    const bool ok = !cmul && !(nt_only && !(a_kc && b_kc && nsplit == 1 && !accumulate)) && scn == 1 && (nbatch == 1 || ((sAb % 4) == 0 && (sBb % 4) == 0)) && (a_kc || a_mc) && (b_kc || b_mc) && (lda % 4) == 0 && (ldw % 4) == 0 &&
+    const bool ok = !cmul && !asum && !(nt_only && !(a_kc && b_kc && nsplit == 1 && !accumulate)) && scn == 1 && (nbatch == 1 || ((sAb % 4) == 0 && (sBb % 4) == 0)) && (a_kc || a_mc) && (b_kc || b_mc) && (lda % 4) == 0 && (ldw % 4) == 0 &&
                     (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (M % 64) == 0 && (N % 64) == 0 &&
                     (K % 64) == 0 && units64 >= tile_min_units && (nsplit == 1 || (long)(nsplit - 1) * kchunk_t < K);
     if (ok) {
@@ -389,13 +424,13 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
         long total = (long)nbatch * M * N;
         int blocks = (int)((total + SKR_OUT - 1) / SKR_OUT);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, C, bias, nsplit, nbatch, M, N, scm, scn,
-                           sCb, relu, accumulate);
+                           sCb, relu, accumulate, (const float*)nullptr, (float*)nullptr);
         MMEGO_LAUNCH_CHECK();
       }
       if (rc != -2) return rc;
     }
   }
-  const bool fast = !cmul && nbatch == 1 && nsplit == 1 && !accumulate && sak == 1 && sbk == 1 && scn == 1 && (M % 128) == 0 &&
+  const bool fast = !cmul && !asum && nbatch == 1 && nsplit == 1 && !accumulate && sak == 1 && sbk == 1 && scn == 1 && (M % 128) == 0 &&
                     (N % 128) == 0 && (K % 16) == 0 && (sam % 4) == 0 && (sbn % 4) == 0 &&
                     (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
   if (fast) {
@@ -412,11 +447,13 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   p.nsplit = nsplit;
   p.relu = relu; p.accumulate = accumulate;
   p.cmul = cmul;
+  p.asum = asum;
   if (nsplit > 1) {
     MMEGO_REQUIRE(splitk_ws != nullptr);
     int kc = cdiv(K, nsplit);
     p.kchunk = cdiv(kc, 16) * 16;
     p.C = splitk_ws; p.scm = N; p.scn = 1; p.sCb = (long)M * N; p.sCs = (long)nbatch * M * N;
+    if (asum) p.asum = splitk_ws + (long)nsplit * nbatch * M * N;      // slab row sums behind the product slabs
   } else {
     p.kchunk = cdiv(K, 16) * 16;
     p.C = C; p.scm = scm; p.scn = scn; p.sCb = sCb; p.sCs = 0;
@@ -425,6 +462,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   const long wgs64 = (long)cdiv(M, 64) * cdiv(N, 64) * nbatch * nsplit;
   static const int kq_max = getenv("MMEGO_GEMM_KQ_MAX") ? atoi(getenv("MMEGO_GEMM_KQ_MAX")) : 512;
   const bool kq = wgs64 <= kq_max && p.kchunk >= 64;     // few tiles and a k-chain worth cutting: K-quartered 32x32 tiles
+  MMEGO_REQUIRE(!asum || kq);                            // (row sums of A: the K-quartered kernel only; callers check with ops)
   dim3 grid(cdiv(M, kq ? 32 : 64), cdiv(N, kq ? 32 : 64), nbatch * nsplit);
   const bool akc = (sak == 1), bkc = (sbk == 1);
   p.avec = akc && (sam % 4) == 0 && (sAb % 4) == 0 && ((uintptr_t)A & 15) == 0;
@@ -445,8 +483,9 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   if (nsplit > 1) {
     long total = (long)nbatch * M * N;
     int blocks = (int)((total + SKR_OUT - 1) / SKR_OUT);
+    if (asum) blocks += (int)(((long)nbatch * M + SKR_OUT - 1) / SKR_OUT);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, C, bias, nsplit, nbatch, M, N,
-                       scm, scn, sCb, relu, accumulate);
+                       scm, scn, sCb, relu, accumulate, (const float*)p.asum, asum);
     MMEGO_LAUNCH_CHECK();
   }
   return MMEGO_OK;

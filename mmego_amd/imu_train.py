@@ -58,7 +58,7 @@ def lstm_steps_backward(ar, key, lstm, x, Bn, T, dout, G, need_dx):
                 # tile product and 2 x 27 us as two split-K calls): this product sits on the serial backward chain.
                 # A batch = direction: rows of dg at time t0 (cols 0:4H) / t1 (cols 4H:8H); the batch stride may be negative.
                 hip.call("gemm", dg.data_ptr() + 4 * (t0 * 8 * H), T * 8 * H, 1, wT, 1, 4 * H, dhrec, H, 1, None,
-                         Bn, H, 4 * H, 2, (t1 - t0) * 8 * H + 4 * H, H * 4 * H, Bn * H, 0, 0, None, 1, 0, None)
+                         Bn, H, 4 * H, 2, (t1 - t0) * 8 * H + 4 * H, H * 4 * H, Bn * H, 0, 0, None, 1, 0, None, None)
         hp = ar.get("%s.hp" % key, (Bn * T, H))
         for d in range(2):
             dgd = dg[:, d * 4 * H:(d + 1) * 4 * H]

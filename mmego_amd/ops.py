@@ -87,9 +87,9 @@ def scratch(device, n):
     return t
 
 
-def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1, cmul=None):
+def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1, cmul=None, asum=None):
     """C[M,N] (+)= A[M,K] @ B[K,N] (+bias)(relu), then (*= cmul, a tensor with C's shape and strides);
-    A, B, C are 2-D views with arbitrary strides."""
+    A, B, C are 2-D views with arbitrary strides.  asum [M] (+)= row sums of A (see asum_ok)."""
     _chk(A, 2), _chk(B, 2), _chk(C, 2)
     M, K = A.shape
     K2, N = B.shape
@@ -99,11 +99,13 @@ def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1, cmul=None):
         raise ValueError("bias must be contiguous with N elements")
     ws = None
     if nsplit > 1:
-        ws = scratch(A.device, nsplit * M * N)
+        ws = scratch(A.device, nsplit * (M * N + (M if asum is not None else 0)))
+    if asum is not None and (asum.numel() != M or not asum.is_contiguous() or not asum_ok(M, N, K, nsplit)):
+        raise ValueError("mm: asum needs M contiguous elements and a small-product shape (ops.asum_ok)")
     if cmul is not None and (tuple(cmul.shape) != (M, N) or cmul.stride() != C.stride() or nsplit > 1):
         raise ValueError("mm: cmul needs C's shape and strides, and an unsplit product")
     hip.call("gemm", A, A.stride(0), A.stride(1), B, B.stride(0), B.stride(1), C, C.stride(0), C.stride(1), bias,
-             M, N, K, 1, 0, 0, 0, int(relu), int(accumulate), ws, nsplit, 0, cmul)
+             M, N, K, 1, 0, 0, 0, int(relu), int(accumulate), ws, nsplit, 0, cmul, asum)
     return C
 
 
@@ -114,7 +116,7 @@ def bmm(A, B, C, accumulate=False):
     if B.shape[0] != nb or C.shape[0] != nb or B.shape[1] != K or tuple(C.shape[1:]) != (M, B.shape[2]):
         raise ValueError("bmm shape mismatch")
     hip.call("gemm", A, A.stride(1), A.stride(2), B, B.stride(1), B.stride(2), C, C.stride(1), C.stride(2), None,
-             M, B.shape[2], K, nb, A.stride(0), B.stride(0), C.stride(0), 0, int(accumulate), None, 1, 0, None)
+             M, B.shape[2], K, nb, A.stride(0), B.stride(0), C.stride(0), 0, int(accumulate), None, 1, 0, None, None)
     return C
 
 
@@ -130,7 +132,7 @@ def linear_pair(x, W0, W1, b0, b1, out, ncol):
         linear(x, W0, b0, out[:, :ncol])
         linear(x, W1, b1, out[:, ncol:2 * ncol])
         return out
-    hip.call("gemm", x, x.stride(0), 1, W0, 1, K, out, out.stride(0), 1, b0, rows, ncol, K, 2, 0, dW, ncol, 0, 0, None, 1, dB, None)
+    hip.call("gemm", x, x.stride(0), 1, W0, 1, K, out, out.stride(0), 1, b0, rows, ncol, K, 2, 0, dW, ncol, 0, 0, None, 1, dB, None, None)
     return out
 
 
@@ -161,10 +163,28 @@ def chain_split(M, N, K):
     return int(max(1, min(512 // max(tiles, 1), K // 512)))
 
 
-def grad_weight(dY, X, dW):
-    """dW[N,K] = dY[rows,N]^T @ X[rows,K]  (fixed-order split over rows)."""
+_KQ_MAX = int(_os.environ.get("MMEGO_GEMM_KQ_MAX", "512"))
+
+
+def asum_ok(M, N, K, nsplit):
+    """Whether mmego_gemm takes the K-quartered small-product kernel for this shape (its dispatch rule, gemm.hip), the one that
+    can return the row sums of its A operand beside the product."""
+    kchunk = -(-(-(-K // nsplit)) // 16) * 16
+    wgs64 = ((M + 63) // 64) * ((N + 63) // 64) * nsplit
+    tile = M % 64 == 0 and N % 64 == 0 and K % 64 == 0 and (M // 64) * (N // 64) * nsplit >= 256
+    return wgs64 <= _KQ_MAX and kchunk >= 64 and not tile and M * N < (1 << 16)
+
+
+def grad_weight(dY, X, dW, db=None):
+    """dW[N,K] = dY[rows,N]^T @ X[rows,K]  (fixed-order split over rows); db[N] (optional) = column sums of dY, the bias
+    gradient: from the same launch where the product runs on the small-product kernel, a column-sum launch otherwise."""
     W2 = dW.view(dW.shape[0], -1)
-    return mm(dY.t(), X, W2, nsplit=pick_split(W2.shape[0], W2.shape[1], X.shape[0]))
+    nsplit = pick_split(W2.shape[0], W2.shape[1], X.shape[0])
+    fused = db is not None and db.is_contiguous() and asum_ok(W2.shape[0], W2.shape[1], X.shape[0], nsplit)
+    mm(dY.t(), X, W2, nsplit=nsplit, asum=db if fused else None)
+    if db is not None and not fused:
+        colsum(dY, db)
+    return dW
 
 
 def grad_weight_pair(dY, ncol, X, dW0, dW1, X1=None):
@@ -182,7 +202,7 @@ def grad_weight_pair(dY, ncol, X, dW0, dW1, X1=None):
         grad_weight(dY[:, :ncol], X, dW0)
         grad_weight(dY[:, ncol:2 * ncol], Xb, dW1)
         return
-    hip.call("gemm", dY, 1, dY.stride(0), X, X.stride(0), 1, W0, K, 1, None, ncol, K, rows, 2, ncol, xdist // 4, dist // 4, 0, 0, None, 1, 0, None)
+    hip.call("gemm", dY, 1, dY.stride(0), X, X.stride(0), 1, W0, K, 1, None, ncol, K, rows, 2, ncol, xdist // 4, dist // 4, 0, 0, None, 1, 0, None, None)
 
 
 def grad_input(dY, W, dX, accumulate=False, cmul=None):

@@ -149,6 +149,25 @@ def test_fused_eval_mlp_and_bn_fold(dev):
         assert torch.equal(y2, y)
 
 
+def test_weight_gradient_with_bias_gradient_in_one_launch(dev):
+    """ops.grad_weight(dY, X, dW, db): the bias gradient (column sums of dY) comes out of the weight-gradient product itself where
+    that runs on the K-quartered small-product kernel (unsplit and split-K), and from a column-sum launch otherwise."""
+    from mmego_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for rows, N, K in ((512, 87, 128), (7680, 64, 32), (7680, 128, 64), (7680, 64, 3), (1000, 42, 64), (32768, 64, 64)):
+        dY = torch.randn(rows, N + 3, generator=g).to(dev)[:, 1:N + 1]            # column slice: row stride N + 3
+        X = torch.randn(rows, K, generator=g).to(dev)
+        dW, db = torch.full((N, K), 7.0, device=dev), torch.full((N,), 7.0, device=dev)
+        ops.grad_weight(dY, X, dW, db=db)
+        ref_w = (dY.double().t() @ X.double())
+        ref_b = dY.double().sum(0)
+        assert torch.allclose(dW.double(), ref_w, rtol=1e-5, atol=2e-4 * max(1.0, ref_w.abs().max().item())), (rows, N, K)
+        assert torch.allclose(db.double(), ref_b, rtol=1e-5, atol=1e-5 * max(1.0, dY.abs().sum(0).max().item())), (rows, N, K)
+        dW2 = torch.empty_like(dW)
+        ops.grad_weight(dY, X, dW2)                                               # without db: the same product bits
+        assert torch.equal(dW2, dW)
+
+
 def test_lstm64_fused_dropout_and_bias_pair(dev):
     """nn.LSTM(dropout=0.1)'s inter-layer dropout as applied by the layer kernel while it stores its outputs: masks are 0 or
     1/(1-p) with the right rate, differ per layer, are a function of the seed counter alone and change when the net's
