@@ -79,9 +79,10 @@ int mmego_bn_backward(void* stream, const float* dY, long lddy, const float* Yma
                       const float* mean, const float* invstd, const float* a, long rows, int C, float* partial_ws,
                       float* c12_ws, float* dgamma, float* dbeta, float* dX, long lddx);
 /* out[c] (+)= sum_r X[r,c]: bias gradients; out2 (may be NULL) receives a copy (nn.LSTM's bias_ih / bias_hh share
- * one gradient).  partial_ws: C*nblk floats. */
+ * one gradient).  partial_ws: C*nblk floats.  scale (may be NULL; rows <= 1024): the sum is multiplied by scale[c] first (the
+ * edge-importance gradient = A . sum of the per-workgroup partials of mmego_graph_dA, GCN.py:62). */
 int mmego_colsum(void* stream, const float* X, long ldx, long rows, int C, float* partial_ws, float* out, float* out2,
-                 int accumulate);
+                 int accumulate, const float* scale);
 /* The same for X [rows <= 1024, 2C] in ONE launch: columns [0, C) -> outA (and outA2), columns [C, 2C) -> outB (and outB2): the
  * four bias gradients of a BiLSTM layer (both directions x bias_ih / bias_hh) from its gate gradients.  C % 16 == 0. */
 int mmego_colsum_pair(void* stream, const float* X, long ldx, long rows, int C, float* outA, float* outA2, float* outB,
@@ -304,9 +305,11 @@ int mmego_mlp_dw_reduce(void* stream, long rows, int nlayers, const float* part0
  * {step, lr/(1-b1^t), sqrt(1-b2^t)}, advanced by the call itself so a captured graph replays correctly
  * (Train_Upper.py:60,182; Train_IMU.py:71-72).  skip: HOST array of nskip (<= 4) [begin, end) element ranges (multiples of 4) that
  * the update leaves untouched -- parameters that never receive a gradient (torch.optim.Adam skips grad=None: IMU_Net.fc3,
- * Net/IMU_Net.py:55, which would otherwise decay under Train_IMU's weight_decay).  NULL / 0: update everything. */
+ * Net/IMU_Net.py:55, which would otherwise decay under Train_IMU's weight_decay).  NULL / 0: update everything.
+ * ticket: one device int, 0 before the first call and left 0 by every call (the step count in `state` advances inside the update
+ * launch: the workgroup that finishes last stores it). */
 int mmego_adam_step(void* stream, float* p, const float* g, float* m, float* v, long n, double* state, double lr,
-                    double beta1, double beta2, double eps, double weight_decay, const long* skip, int nskip);
+                    double beta1, double beta2, double eps, double weight_decay, const long* skip, int nskip, int* ticket);
 
 #ifdef __cplusplus
 }

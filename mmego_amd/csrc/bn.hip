@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // seg > 0: columns [seg, C) go to outB / out2B (index c - seg): the gate gradients of both directions of a BiLSTM layer in one launch.
 __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ X, long ldx, long rows, int C, float* out,
                                                            float* out2, int accumulate, int TC, int seg, float* outB,
-                                                           float* out2B) {
+                                                           float* out2B, const float* __restrict__ scale) {
   __shared__ double sh[256];
   const int TR = 256 / TC;
   const int cx = threadIdx.x % TC, ry = threadIdx.x / TC;
@@ -291,7 +291,9 @@ __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restri
     float* o2 = out2;
     int cc = c;
     if (seg > 0 && c >= seg) { o = outB; o2 = out2B; cc = c - seg; }
-    const float v = accumulate ? o[cc] + (float)a : (float)a;
+    float af = (float)a;
+    if (scale) af *= scale[c];
+    const float v = accumulate ? o[cc] + af : af;
     o[cc] = v;
     if (o2) o2[cc] = v;
   }
@@ -430,15 +432,16 @@ extern "C" int mmego_bn_backward(void* stream, const float* dY, long lddy, const
 }
 
 extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, int C, float* partial_ws, float* out,
-                            float* out2, int accumulate) {
+                            float* out2, int accumulate, const float* scale) {
   MMEGO_REQUIRE(X && rows > 0 && C > 0 && partial_ws && out);
+  MMEGO_REQUIRE(!scale || rows <= 1024);
   hipStream_t st = (hipStream_t)stream;
   if (rows <= 1024) {
     // narrow column tiles (16 lanes across, 16 down the rows): more blocks and 4x shorter per-thread row loops than the
     // 64-wide tile of the long-tensor path -- this kernel's time is the depth of its dependent load rounds
     const int TCs = C >= 16 ? 16 : col_tile(C);
     hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(C, TCs)), dim3(256), 0, st, X, ldx, rows, C, out, out2, accumulate, TCs, 0,
-                       (float*)nullptr, (float*)nullptr);
+                       (float*)nullptr, (float*)nullptr, scale);
     MMEGO_LAUNCH_CHECK();
     return MMEGO_OK;
   }
@@ -457,7 +460,7 @@ extern "C" int mmego_colsum_pair(void* stream, const float* X, long ldx, long ro
                                  float* outB2, int accumulate) {
   MMEGO_REQUIRE(X && rows > 0 && rows <= 1024 && C >= 16 && (C % 16) == 0 && outA && outB);
   hipLaunchKernelGGL(colsum_small_kernel, dim3(cdiv(2 * C, 16)), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, 2 * C, outA, outA2,
-                     accumulate, 16, C, outB, outB2);
+                     accumulate, 16, C, outB, outB2, (const float*)nullptr);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -11,22 +11,25 @@
 struct AdamSkip { long lo[ADAM_MAX_SKIP], hi[ADAM_MAX_SKIP]; int n; };
 
 // state[0] = step count (as double), state[1] = step_size = lr / (1 - b1^t), state[2] = sqrt(1 - b2^t)
-// Kept in device memory so that a captured HIP graph replays with the right bias corrections.
-__global__ void adam_tick_kernel(double* state, double lr, double beta1, double beta2) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double t = state[0] + 1.0;
-    state[0] = t;
-    state[1] = lr / (1.0 - pow(beta1, t));
-    state[2] = sqrt(1.0 - pow(beta2, t));
-  }
-}
-
+// Kept in device memory so that a captured HIP graph replays with the right bias corrections.  The step count advances
+// INSIDE the update launch: every workgroup reads state[0] = t-1 when it starts and works with t; the workgroup whose ticket
+// add comes last (all the others have read the state by then: their add follows their read) stores the new state and puts the
+// ticket back to 0.  No separate tick launch.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n4,
-                                                   const double* __restrict__ state, float beta2, float omb1,
-                                                   float omb2, float eps, float weight_decay, AdamSkip skip) {
-  const float step_size = (float)state[1];
-  const float bc2_sqrt = (float)state[2];
+                                                   double* state, double lr, double beta1, double beta2d, int* ticket,
+                                                   float beta2, float omb1, float omb2, float eps, float weight_decay,
+                                                   AdamSkip skip) {
+  __shared__ double bc[3];
+  if (threadIdx.x == 0) {
+    const double t = state[0] + 1.0;
+    bc[0] = t;
+    bc[1] = lr / (1.0 - pow(beta1, t));
+    bc[2] = sqrt(1.0 - pow(beta2d, t));
+  }
+  __syncthreads();
+  const float step_size = (float)bc[1];
+  const float bc2_sqrt = (float)bc[2];
   float4* p4 = reinterpret_cast<float4*>(p);
   const float4* g4 = reinterpret_cast<const float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m);
@@ -53,6 +56,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     p4[i] = pp; m4[i] = mm; v4[i] = vv;
   }
+  if (threadIdx.x == 0) {
+    if (atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+      state[0] = bc[0]; state[1] = bc[1]; state[2] = bc[2];
+      *ticket = 0;
+    }
+  }
 }
 
 static inline int ew_blocks(long total) {
@@ -62,8 +71,8 @@ static inline int ew_blocks(long total) {
 
 extern "C" int mmego_adam_step(void* stream, float* p, const float* g, float* m, float* v, long n, double* state,
                                double lr, double beta1, double beta2, double eps, double weight_decay, const long* skip,
-                               int nskip) {
-  MMEGO_REQUIRE(p && g && m && v && state && n > 0 && (n % 4) == 0);
+                               int nskip, int* ticket) {
+  MMEGO_REQUIRE(p && g && m && v && state && ticket && n > 0 && (n % 4) == 0);
   MMEGO_REQUIRE(nskip >= 0 && nskip <= ADAM_MAX_SKIP && (nskip == 0 || skip));
   AdamSkip sk;
   sk.n = nskip;
@@ -78,10 +87,8 @@ extern "C" int mmego_adam_step(void* stream, float* p, const float* g, float* m,
   }
   MMEGO_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, state, lr, beta1, beta2);
-  MMEGO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, p, g, m, v, n / 4, state, (float)beta2,
-                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, sk);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, p, g, m, v, n / 4, state, lr, beta1, beta2, ticket,
+                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, sk);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

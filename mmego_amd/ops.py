@@ -210,12 +210,12 @@ def grad_input(dY, W, dX, accumulate=False, cmul=None):
     return mm(dY, W.view(W.shape[0], -1), dX, accumulate=accumulate, cmul=cmul)
 
 
-def colsum(X, out, accumulate=False, out2=None):
-    """out[c] (+)= sum_r X[r, c]; out2 (optional) gets a copy of the result."""
+def colsum(X, out, accumulate=False, out2=None, scale=None):
+    """out[c] (+)= sum_r X[r, c] (* scale[c], for up to 1024 rows); out2 (optional) gets a copy of the result."""
     X = _rows(X)
     rows, C = X.shape
     ws = scratch(X.device, C * hip.colstats_nblk(rows))
-    hip.call("colsum", X, X.stride(0), rows, C, ws, out, out2, int(accumulate))
+    hip.call("colsum", X, X.stride(0), rows, C, ws, out, out2, int(accumulate), scale)
     return out
 
 

@@ -96,7 +96,7 @@ class FusedAdam:
     def __init__(self, flat, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.flat = flat
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.m = self.v = self.state = None
+        self.m = self.v = self.state = self._ticket = None
         self._skip = None
 
     def _skip_ranges(self, f):
@@ -123,6 +123,7 @@ class FusedAdam:
             self.m = torch.zeros_like(f.flat_p)
             self.v = torch.zeros_like(f.flat_p)
             self.state = torch.zeros(3, dtype=torch.float64, device=f.device)
+            self._ticket = torch.zeros(1, dtype=torch.int32, device=f.device)
         return f
 
     def step(self):
@@ -130,7 +131,7 @@ class FusedAdam:
         skip = self._skip_ranges(f)
         hip.call("adam_step", f.flat_p, f.flat_g, self.m, self.v, f.flat_p.numel(), self.state, float(self.lr),
                  float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                 skip if skip is not False else None, skip.numel() // 2 if skip is not False else 0)
+                 skip if skip is not False else None, skip.numel() // 2 if skip is not False else 0, self._ticket)
 
     def zero_grad(self):
         pass  # every backward overwrites the flat gradient buffer

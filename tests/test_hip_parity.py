@@ -633,10 +633,11 @@ def test_fused_adam_matches_torch(dev):
         opt = torch.optim.Adam([ref_p], lr=3e-5, weight_decay=wd)
         p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
         state = torch.zeros(3, dtype=torch.float64, device=dev)
+        ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         for step in range(1, 6):
             grad = torch.randn(n) * (10.0 ** (step - 3))
             ref_p.grad = grad.clone()
             opt.step()
-            hip.call("adam_step", p, grad.to(dev), m, v, n, state, 3e-5, 0.9, 0.999, 1e-8, wd, None, 0)
+            hip.call("adam_step", p, grad.to(dev), m, v, n, state, 3e-5, 0.9, 0.999, 1e-8, wd, None, 0, ticket)
             assert torch.allclose(p.cpu(), ref_p.detach(), rtol=0, atol=2e-7), (wd, step)
-        assert state[0].item() == 5.0
+        assert state[0].item() == 5.0 and ticket.item() == 0
