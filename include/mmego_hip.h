@@ -30,7 +30,8 @@ extern "C" {
 /* (sBiasb: element stride of `bias` between batches, 0 = one bias for all -- lets the two directions' input projections of a
  * BiLSTM layer run as ONE batched product: same A, two weight / bias / output-column blocks.)
  * cmul (may be NULL; nsplit == 1 only): elementwise multiplier in C's layout applied after bias / relu / accumulate -- the
- * inter-layer dropout mask on an LSTM layer's input gradient.
+ * inter-layer dropout mask on an LSTM layer's input gradient.  relu == 2 (with cmul): no ReLU on the result; instead the result is
+ * set to 0 where cmul <= 0 -- ReLU's backward on an input gradient, cmul = the layer's forward output (Upper_Net.py:350-351).
  * asum (may be NULL): asum[b*M + m] (+)= sum_k A[b](m,k), computed from the operand values the product loads anyway -- the bias
  * gradient beside a weight gradient dW = dY^T X (A = dY^T).  Only for the small-product shapes (about M*N*nsplit*nbatch <=
  * 2 M outputs, K slabs >= 64: bad argument otherwise); with nsplit > 1 splitk_ws needs nsplit*nbatch*M more floats. */

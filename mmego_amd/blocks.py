@@ -181,12 +181,17 @@ def mlp3_backward(ar, key, mod, x, y3, dy3, G, need_dx):
 # ---------------------------------------------------------------------------------------------------
 # Linear (+ReLU) with backward
 # ---------------------------------------------------------------------------------------------------
-def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False, bias_grad=True):
+def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False, bias_grad=True, relu_input=False):
     """Gradients of y = x W^T + b: writes G(W), G(b); fills dx if given.  bias_grad=False: the layer feeds a batch-statistics
-    BatchNorm directly, so the bias gradient is identically zero and its slot in the gradient buffer stays 0."""
+    BatchNorm directly, so the bias gradient is identically zero and its slot in the gradient buffer stays 0.
+    relu_input: x is the output of a ReLU whose backward is applied to dx right here (dx = 0 where x <= 0), in the epilogue of
+    the product that computes dx."""
     ops.grad_weight(dy, x, G(lin.weight), db=G(lin.bias) if lin.bias is not None and bias_grad else None)
     if dx is not None:
-        ops.grad_input(dy, lin.weight, dx, accumulate=accumulate_dx)
+        masked = relu_input and x.shape == dx.shape and x.stride() == dx.stride()
+        ops.grad_input(dy, lin.weight, dx, accumulate=accumulate_dx, cmask=x if masked else None)
+        if relu_input and not masked:
+            ops.relu_mask_(dx, x)
     return dx
 
 

@@ -133,9 +133,9 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
       float v = acc[reg] + bv;
       float* dst = C + (long)row * p.scm + (long)col * p.scn;
       if (p.nsplit == 1) {
-        if (p.relu) v = fmaxf(v, 0.0f);
+        if (p.relu == 1) v = fmaxf(v, 0.0f);
         if (p.accumulate) v += *dst;
-        if (p.cmul) v *= p.cmul[dst - p.C];
+        if (p.cmul) { const float cm = p.cmul[dst - p.C]; v = p.relu == 2 ? (cm > 0.f ? v : 0.f) : v * cm; }
       }
       *dst = v;
     }
@@ -239,9 +239,9 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
       float* dst = C + (long)(m0 + row) * p.scm + (long)(n0 + col) * p.scn;
       if (p.nsplit == 1) {
         if (p.bias) v += p.bias[(long)batch * p.sBiasb + n0 + col];
-        if (p.relu) v = fmaxf(v, 0.0f);
+        if (p.relu == 1) v = fmaxf(v, 0.0f);
         if (p.accumulate) v += *dst;
-        if (p.cmul) v *= p.cmul[dst - p.C];
+        if (p.cmul) { const float cm = p.cmul[dst - p.C]; v = p.relu == 2 ? (cm > 0.f ? v : 0.f) : v * cm; }
       }
       *dst = v;
     }
@@ -392,6 +392,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
                           const float* cmul, float* asum) {
   MMEGO_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && nsplit >= 1);
   MMEGO_REQUIRE(!cmul || nsplit == 1);
+  MMEGO_REQUIRE(relu == 0 || relu == 1 || (relu == 2 && cmul));
   MMEGO_REQUIRE(sBiasb == 0 || nsplit == 1);          // (the split-K reducer applies one shared bias)
   hipStream_t st = (hipStream_t)stream;
   // Large-tile kernels (gemm_tile.hip): 64-aligned shapes with enough work units to be worth a 64x64+ tile, any operand

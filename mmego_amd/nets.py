@@ -221,8 +221,7 @@ class UpperNet(_NetBase):
         dy = ar.get("dy", (F, 87))
         hip.call("head_fk_backward", 0, y, body, B, F, djh, dy)
         dh1 = ar.get("dh1", (F, 128))
-        blocks.linear_backward(dy, h1, self.mlpHead.fc2, G, dh1)
-        ops.relu_mask_(dh1, h1)
+        blocks.linear_backward(dy, h1, self.mlpHead.fc2, G, dh1, relu_input=True)
         seq = ar.get("grnn.out2", (F, 128))
         dseq = ar.get("dseq", (F, 128))
         blocks.linear_backward(dh1, seq, self.mlpHead.fc1, G, dseq)
@@ -455,10 +454,16 @@ class LowerNet(_NetBase):
             out = ar.get(key + ".out", (rows, cout))
             ops.affine_act(tz, st3, out, relu=True, X2=res_z, st2=st_r)
             cur = out
-        fz = ar.get("gcn.fz", (rows, 64))
-        ops.linear(cur, gcn.fcn.weight, gcn.fcn.bias, fz)
         kv = ar.get("gcn.kv", (B, 64, T * V))
-        hip.call("transpose_batched", fz, kv, B, T * V, 64)       # (B,T*V,64) -> (B,64,T*V), then re-viewed (Q8)
+        if rows <= 16384:
+            # fcn as one product per sequence b with a TRANSPOSED store: (B,T*V,128) -> (B,64,T*V), then re-viewed (Q8); no
+            # transpose launch (small shapes: the strided store is not coalesced)
+            ops.bmm(cur.view(B, T * V, cur.shape[1]), gcn.fcn.weight.view(64, -1).t().unsqueeze(0).expand(B, -1, -1),
+                    kv.transpose(1, 2), bias=gcn.fcn.bias)
+        else:
+            fz = ar.get("gcn.fz", (rows, 64))
+            ops.linear(cur, gcn.fcn.weight, gcn.fcn.bias, fz)
+            hip.call("transpose_batched", fz, kv, B, T * V, 64)       # (B,T*V,64) -> (B,64,T*V), then re-viewed (Q8)
         return kv.view(F * V, 64)
 
     def _backward_impl(self, dl):
@@ -475,10 +480,8 @@ class LowerNet(_NetBase):
         dy = ar.get("dy", (F, 42))
         hip.call("head_fk_backward", 1, y, body, B, F, djh, dy)
         df1, df0, dcat = ar.get("df1", (F, 64)), ar.get("df0", (F, 128)), ar.get("dcat", (F, 173))
-        blocks.linear_backward(dy, f1, fu.fc2, G, df1)
-        ops.relu_mask_(df1, f1)
-        blocks.linear_backward(df1, f0, fu.fc1, G, df0)
-        ops.relu_mask_(df0, f0)
+        blocks.linear_backward(dy, f1, fu.fc2, G, df1, relu_input=True)
+        blocks.linear_backward(df1, f0, fu.fc1, G, df0, relu_input=True)
         blocks.linear_backward(df0, cat, fu.fc0, G, dcat)
         lstm = fu.rnn_pk
         ak = ar.get("ak", (F, 192))
@@ -487,8 +490,7 @@ class LowerNet(_NetBase):
         hip.call("group_bcast", dak, 192, F, LOWER_POINTS, 128, 1.0, dboth, 0)
         dk = ar.get("dk", (F * V, 64))
         hip.call("group_bcast", dak[:, 128:], 192, F, V, 64, 1.0 / V, dk, 0)
-        dp = ar.get("dp", (prow, 64))
-        ops.copy2d(dboth[:, :64], dp)
+        dp = dboth[:, :64]           # (accumulated into in place: the attention's input gradient reads the other half)
         Qm, Km, Vm = ar.get("Qm", (prow, 64)), ar.get("Km", (F * V, 64)), ar.get("Vm", (F * V, 64))
         Pm = ar.get("Pm", (F, LOWER_POINTS, V))
         dQ, dK, dV = ar.get("dQ", (prow, 64)), ar.get("dK", (F * V, 64)), ar.get("dV", (F * V, 64))

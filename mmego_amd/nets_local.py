@@ -163,8 +163,7 @@ class UpperNetwlocal(_NetBase):
         dy = ar.get("dy", (F, 87))
         hip.call("head_fk_backward", 0, y, body, B, F, djh, dy)
         dh1 = ar.get("dh1", (F, 128))
-        blocks.linear_backward(dy, h1, self.module3.fc2, G, dh1)
-        ops.relu_mask_(dh1, h1)
+        blocks.linear_backward(dy, h1, self.module3.fc2, G, dh1, relu_input=True)
         dcat = ar.get("dcat", (F, 256))
         blocks.linear_backward(dh1, cat, self.module3.fc1, G, dcat)
         # global branch

@@ -87,9 +87,13 @@ def scratch(device, n):
     return t
 
 
-def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1, cmul=None, asum=None):
-    """C[M,N] (+)= A[M,K] @ B[K,N] (+bias)(relu), then (*= cmul, a tensor with C's shape and strides);
-    A, B, C are 2-D views with arbitrary strides.  asum [M] (+)= row sums of A (see asum_ok)."""
+def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1, cmul=None, asum=None, cmask=None):
+    """C[M,N] (+)= A[M,K] @ B[K,N] (+bias)(relu), then (*= cmul) or (= 0 where cmask <= 0) -- cmul / cmask: a tensor with C's
+    shape and strides; A, B, C are 2-D views with arbitrary strides.  asum [M] (+)= row sums of A (see asum_ok)."""
+    if cmask is not None:
+        if cmul is not None or relu:
+            raise ValueError("mm: cmask excludes cmul and relu")
+        cmul, relu = cmask, 2
     _chk(A, 2), _chk(B, 2), _chk(C, 2)
     M, K = A.shape
     K2, N = B.shape
@@ -109,13 +113,15 @@ def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1, cmul=None, as
     return C
 
 
-def bmm(A, B, C, accumulate=False):
-    """Batched C[b] (+)= A[b] @ B[b]; 3-D views, batch stride may be 0 (broadcast operand)."""
+def bmm(A, B, C, accumulate=False, bias=None):
+    """Batched C[b] (+)= A[b] @ B[b] (+ bias[n]); 3-D views, batch stride may be 0 (broadcast operand)."""
     _chk(A, 3), _chk(B, 3), _chk(C, 3)
     nb, M, K = A.shape
     if B.shape[0] != nb or C.shape[0] != nb or B.shape[1] != K or tuple(C.shape[1:]) != (M, B.shape[2]):
         raise ValueError("bmm shape mismatch")
-    hip.call("gemm", A, A.stride(1), A.stride(2), B, B.stride(1), B.stride(2), C, C.stride(1), C.stride(2), None,
+    if bias is not None and (bias.numel() != B.shape[2] or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous with N elements")
+    hip.call("gemm", A, A.stride(1), A.stride(2), B, B.stride(1), B.stride(2), C, C.stride(1), C.stride(2), bias,
              M, B.shape[2], K, nb, A.stride(0), B.stride(0), C.stride(0), 0, int(accumulate), None, 1, 0, None, None)
     return C
 
@@ -205,9 +211,9 @@ def grad_weight_pair(dY, ncol, X, dW0, dW1, X1=None):
     hip.call("gemm", dY, 1, dY.stride(0), X, X.stride(0), 1, W0, K, 1, None, ncol, K, rows, 2, ncol, xdist // 4, dist // 4, 0, 0, None, 1, 0, None, None)
 
 
-def grad_input(dY, W, dX, accumulate=False, cmul=None):
-    """dX[rows,K] (+)= dY[rows,N] @ W[N,K], then (*= cmul)"""
-    return mm(dY, W.view(W.shape[0], -1), dX, accumulate=accumulate, cmul=cmul)
+def grad_input(dY, W, dX, accumulate=False, cmul=None, cmask=None):
+    """dX[rows,K] (+)= dY[rows,N] @ W[N,K], then (*= cmul) or (= 0 where cmask <= 0: ReLU backward, cmask = the forward output)"""
+    return mm(dY, W.view(W.shape[0], -1), dX, accumulate=accumulate, cmul=cmul, cmask=cmask)
 
 
 def colsum(X, out, accumulate=False, out2=None, scale=None):
