@@ -28,6 +28,9 @@ from .skeleton import JOINTS_UPPER, LOWER_POINTS, gcn_adjacency
 # is bound by its 9-18 dependent steps per tile: 5.99 ms against 6.10 ms per U+L step).  Eval-mode forwards always use the
 # implicit kernel.  MMEGO_TCONV_TRAIN_MIN_ROWS overrides the threshold (0: always implicit).
 _TCONV_TRAIN_MIN_ROWS = int(os.environ.get("MMEGO_TCONV_TRAIN_MIN_ROWS", "16384"))
+# Below that row count: blocks with at least this many channels still take the implicit kernel for the INPUT gradient of the
+# temporal convolution (MMEGO_TCONV_BWD_MIN_CHANNELS; 1 << 30: never).
+_TCONV_BWD_MIN_CHANNELS = int(os.environ.get("MMEGO_TCONV_BWD_MIN_CHANNELS", "64"))
 
 
 def _require_gpu(t, who):
@@ -534,6 +537,13 @@ class LowerNet(_NetBase):
                 # input gradient = the same implicit-GEMM convolution of dtz with the taps reversed and (co, ci) swapped
                 wp = ar.get(key + ".wp", (2, blk.tcn["2"].weight.numel()))
                 hip.call("tconv", dtz, cout, None, wp[1], cout * cout, cout, 1, None, dy0, cout, B, T, V, cout, cout, blk.taps)
+            elif cout >= _TCONV_BWD_MIN_CHANNELS:
+                # wide block at a small row count: the unfolded operand of the forward pass serves the weight gradient, the
+                # input gradient is the implicit convolution (no [rows, 9 C] gradient written and folded back)
+                blocks.linear_backward(dtz, col, blk.tcn["2"], G, None, bias_grad=False)
+                wp1 = ar.get(key + ".wp1", (blk.tcn["2"].weight.numel(),))
+                hip.call("tconv_pack", blk.tcn["2"].weight, cout, cout, blk.taps, 1, wp1)
+                hip.call("tconv", dtz, cout, None, wp1, cout * cout, cout, 1, None, dy0, cout, B, T, V, cout, cout, blk.taps)
             else:
                 dcol = ar.get(key + ".dcol", (rows, cout * blk.taps))
                 blocks.linear_backward(dtz, col, blk.tcn["2"], G, dcol, bias_grad=False)
