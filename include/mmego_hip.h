@@ -79,6 +79,15 @@ int mmego_gather_rows(void* stream, const float* X, long nsrc, long W, const lon
 int mmego_bn_backward(void* stream, const float* dY, long lddy, const float* Ymask, long ldm, const float* X, long ldx,
                       const float* mean, const float* invstd, const float* a, long rows, int C, float* partial_ws,
                       float* c12_ws, float* dgamma, float* dbeta, float* dX, long lddx);
+/* Two BatchNorms that share dY and the mask -- st_gcn's relu(BN(tcn(x)) + BN(residual(x))), GCN.py:140-147 -- in the same three
+ * launches (the second one rides along as channels [C, 2C); results are those of two mmego_bn_backward calls, bit for bit).
+ * partial_ws: 4*C*nblk floats, c12_ws: 4*C floats; C a multiple of the 8..64-wide column tile (8, 16, 32, 64, 128, ...). */
+int mmego_bn_backward_pair(void* stream, const float* dY, long lddy, const float* Ymask, long ldm, long rows, int C,
+                           float* partial_ws, float* c12_ws,
+                           const float* X1, long ldx1, const float* mean1, const float* invstd1, const float* a1,
+                           float* dgamma1, float* dbeta1, float* dX1, long lddx1,
+                           const float* X2, long ldx2, const float* mean2, const float* invstd2, const float* a2,
+                           float* dgamma2, float* dbeta2, float* dX2, long lddx2);
 /* out[c] (+)= sum_r X[r,c]: bias gradients; out2 (may be NULL) receives a copy (nn.LSTM's bias_ih / bias_hh share
  * one gradient).  partial_ws: C*nblk floats.  scale (may be NULL; rows <= 1024): the sum is multiplied by scale[c] first (the
  * edge-importance gradient = A . sum of the per-workgroup partials of mmego_graph_dA, GCN.py:62). */

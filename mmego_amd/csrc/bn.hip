@@ -166,19 +166,27 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ X
 }
 
 // dZ = dY * [Ymask > 0];  partial[c][blk] = (sum dZ, sum dZ*xhat)   with xhat = (X-mean)*invstd
+// A second BatchNorm that shares dY and the mask (st_gcn: relu(BN(tcn) + BN(residual)), GCN.py:140-147) rides along as the
+// virtual channels [C, 2C): Bn2 holds its X / mean / invstd (pair.X == nullptr: single).
+struct BnSecond { const float* X; long ldx; const float* mean; const float* invstd; const float* a; float* dgamma; float* dbeta; float* dX; long lddx; };
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dY, long lddy,
                                                             const float* __restrict__ Ymask, long ldm,
                                                             const float* __restrict__ X, long ldx, const float* mean,
                                                             const float* invstd, long rows, int C,
-                                                            float* __restrict__ partial, long RPB, int TC) {
+                                                            float* __restrict__ partial, long RPB, int TC, BnSecond pair) {
   __shared__ float sh[256][2];
   const int TR = 256 / TC;
   const int cx = threadIdx.x % TC, ry = threadIdx.x / TC;
-  const int c = blockIdx.y * TC + cx;
+  const int cv = blockIdx.y * TC + cx;                     // virtual channel
+  const bool second = pair.X != nullptr && cv >= C;
+  const int c = second ? cv - C : cv;
+  const int Ctot = pair.X ? 2 * C : C;
+  if (second) { X = pair.X; ldx = pair.ldx; mean = pair.mean; invstd = pair.invstd; }
   const long r0 = (long)blockIdx.x * RPB;
   const long r1 = min(rows, r0 + RPB);
   float s1 = 0.f, s2 = 0.f;
-  if (c < C) {
+  if (cv < Ctot) {
     const float mu = mean[c], is = invstd[c];
     for (long r = r0 + ry; r < r1; r += TR) {
       float g = dY[r * lddy + c];
@@ -189,17 +197,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
   sh[threadIdx.x][0] = s1; sh[threadIdx.x][1] = s2;
   __syncthreads();
-  if (ry == 0 && c < C) {
+  if (ry == 0 && cv < Ctot) {
     float a = 0.f, b = 0.f;
     for (int j = 0; j < TR; ++j) { a += sh[j * TC + cx][0]; b += sh[j * TC + cx][1]; }
-    partial[((long)c * gridDim.x + blockIdx.x) * 2 + 0] = a;           // [channel][block]
-    partial[((long)c * gridDim.x + blockIdx.x) * 2 + 1] = b;
+    partial[((long)cv * gridDim.x + blockIdx.x) * 2 + 0] = a;           // [virtual channel][block]
+    partial[((long)cv * gridDim.x + blockIdx.x) * 2 + 1] = b;
   }
 }
 
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long rows, float* dgamma,
-                                       float* dbeta, float* c1, float* c2) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+                                       float* dbeta, float* c1, float* c2, BnSecond pair) {
+  const int c = blockIdx.x, lane = threadIdx.x;           // (virtual channel: [C, 2C) = the second BatchNorm of a pair)
   float q1[16], q2[16];                 // one round of loads (<= 1024 partial blocks)
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
@@ -218,9 +226,9 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
   s1 = wave_sum_d(s1);
   s2 = wave_sum_d(s2);
   if (lane != 0) return;
-  dbeta[c] = (float)s1;
-  dgamma[c] = (float)s2;
-  c1[c] = (float)(s1 / (double)rows);
+  if (c >= C) { pair.dbeta[c - C] = (float)s1; pair.dgamma[c - C] = (float)s2; }
+  else { dbeta[c] = (float)s1; dgamma[c] = (float)s2; }
+  c1[c] = (float)(s1 / (double)rows);                     // (c1 / c2: [Ctot] each)
   c2[c] = (float)(s2 / (double)rows);
 }
 
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ X, long ldx, const float* mean,
                                                            const float* invstd, const float* a, const float* c1,
                                                            const float* c2, float* __restrict__ dX, long lddx,
-                                                           long rows, int C) {
+                                                           long rows, int C, BnSecond pair) {
   long total = rows * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long r = i / C;
@@ -239,6 +247,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (Ymask && !(Ymask[r * ldm + c] > 0.f)) g = 0.f;
     float xh = (X[r * ldx + c] - mean[c]) * invstd[c];
     dX[r * lddx + c] = a[c] * (g - c1[c] - xh * c2[c]);
+    if (pair.X) {                                          // the second BatchNorm of a pair: same dY and mask
+      float xh2 = (pair.X[r * pair.ldx + c] - pair.mean[c]) * pair.invstd[c];
+      pair.dX[r * pair.lddx + c] = pair.a[c] * (g - c1[C + c] - xh2 * c2[C + c]);
+    }
   }
 }
 
@@ -409,26 +421,48 @@ extern "C" int mmego_copy2d(void* stream, const float* X, long ldx, float* Y, lo
   return MMEGO_OK;
 }
 
+static int bn_backward_launch(hipStream_t st, const float* dY, long lddy, const float* Ymask, long ldm, const float* X, long ldx,
+                              const float* mean, const float* invstd, const float* a, long rows, int C, float* partial_ws,
+                              float* c12_ws, float* dgamma, float* dbeta, float* dX, long lddx, BnSecond pair) {
+  const long RPB = rows_per_block(rows);
+  int nblk = cdiv(rows, RPB);
+  MMEGO_REQUIRE(nblk <= 1024);
+  const int TC = col_tile(C);
+  const int Ctot = pair.X ? 2 * C : C;
+  MMEGO_REQUIRE(!pair.X || (C % TC) == 0);               // (a column tile must not straddle the two BatchNorms)
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, cdiv(Ctot, TC)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
+                     mean, invstd, rows, C, partial_ws, RPB, TC, pair);
+  MMEGO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(Ctot), dim3(64), 0, st, partial_ws, nblk, C, rows, dgamma,
+                     dbeta, c12_ws, c12_ws + Ctot, pair);
+  MMEGO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
+                     mean, invstd, a, c12_ws, c12_ws + Ctot, dX, lddx, rows, C, pair);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
 extern "C" int mmego_bn_backward(void* stream, const float* dY, long lddy, const float* Ymask, long ldm,
                                  const float* X, long ldx, const float* mean, const float* invstd, const float* a,
                                  long rows, int C, float* partial_ws, float* c12_ws, float* dgamma, float* dbeta,
                                  float* dX, long lddx) {
   MMEGO_REQUIRE(dY && X && mean && invstd && a && rows > 0 && C > 0 && partial_ws && c12_ws && dgamma && dbeta && dX);
-  hipStream_t st = (hipStream_t)stream;
-  const long RPB = rows_per_block(rows);
-  int nblk = cdiv(rows, RPB);
-  MMEGO_REQUIRE(nblk <= 1024);
-  const int TC = col_tile(C);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
-                     mean, invstd, rows, C, partial_ws, RPB, TC);
-  MMEGO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, rows, dgamma,
-                     dbeta, c12_ws, c12_ws + C);
-  MMEGO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, st, dY, lddy, Ymask, ldm, X, ldx,
-                     mean, invstd, a, c12_ws, c12_ws + C, dX, lddx, rows, C);
-  MMEGO_LAUNCH_CHECK();
-  return MMEGO_OK;
+  BnSecond none = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  return bn_backward_launch((hipStream_t)stream, dY, lddy, Ymask, ldm, X, ldx, mean, invstd, a, rows, C, partial_ws, c12_ws, dgamma,
+                            dbeta, dX, lddx, none);
+}
+
+extern "C" int mmego_bn_backward_pair(void* stream, const float* dY, long lddy, const float* Ymask, long ldm, long rows, int C,
+                                      float* partial_ws, float* c12_ws,
+                                      const float* X1, long ldx1, const float* mean1, const float* invstd1, const float* a1,
+                                      float* dgamma1, float* dbeta1, float* dX1, long lddx1,
+                                      const float* X2, long ldx2, const float* mean2, const float* invstd2, const float* a2,
+                                      float* dgamma2, float* dbeta2, float* dX2, long lddx2) {
+  MMEGO_REQUIRE(dY && rows > 0 && C > 0 && partial_ws && c12_ws);
+  MMEGO_REQUIRE(X1 && mean1 && invstd1 && a1 && dgamma1 && dbeta1 && dX1 && X2 && mean2 && invstd2 && a2 && dgamma2 && dbeta2 && dX2);
+  BnSecond second = {X2, ldx2, mean2, invstd2, a2, dgamma2, dbeta2, dX2, lddx2};
+  return bn_backward_launch((hipStream_t)stream, dY, lddy, Ymask, ldm, X1, ldx1, mean1, invstd1, a1, rows, C, partial_ws, c12_ws,
+                            dgamma1, dbeta1, dX1, lddx1, second);
 }
 
 extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, int C, float* partial_ws, float* out,

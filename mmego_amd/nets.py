@@ -524,8 +524,9 @@ class LowerNet(_NetBase):
             out, tz, res_z = ar.get(key + ".out", (rows, cout)), ar.get(key + ".tz", (rows, cout)), ar.get(key + ".rz", (rows, cout))
             st3, st_r, st0 = ops.BnState(ar, key + ".bn3", cout), ops.BnState(ar, key + ".bnr", cout), ops.BnState(ar, key + ".bn0", cout)
             dtz, drz = ar.get(key + ".dtz", (rows, cout)), ar.get(key + ".drz", (rows, cout))
-            ops.bn_backward(dcur, out, tz, st3, G(blk.tcn["3"].weight), G(blk.tcn["3"].bias), dtz)
-            ops.bn_backward(dcur, out, res_z, st_r, G(blk.residual["1"].weight), G(blk.residual["1"].bias), drz)
+            # out = relu(BN3(tz) + BNr(res_z)): both BatchNorm backwards share dcur and the mask -- one set of launches
+            ops.bn_backward_pair(dcur, out, tz, st3, G(blk.tcn["3"].weight), G(blk.tcn["3"].bias), dtz,
+                                 res_z, st_r, G(blk.residual["1"].weight), G(blk.residual["1"].bias), drz)
             y0, ymix = ar.get(key + ".y0", (rows, cout)), ar.get(key + ".ymix", (rows, cout))
             # weight gradient of the temporal convolution from the unfolded y0 (built here, in the backward pass only);
             # no bias gradient: a batch-statistics BatchNorm follows

@@ -312,6 +312,24 @@ def bn_backward(dY, Ymask, X, st, dgamma, dbeta, dX):
     return dX
 
 
+def bn_backward_pair(dY, Ymask, X1, st1, dgamma1, dbeta1, dX1, X2, st2, dgamma2, dbeta2, dX2):
+    """Two BatchNorm(train) backwards that share dY and the ReLU mask, in the launches of one (same bits as two bn_backward calls)."""
+    dY, Ymask, X1, dX1, X2, dX2 = (_rows(t) for t in (dY, Ymask, X1, dX1, X2, dX2))
+    rows, C = X1.shape
+    tc = 8
+    while tc < C and tc < 64:
+        tc <<= 1
+    if X2.shape != X1.shape or C % tc:
+        bn_backward(dY, Ymask, X1, st1, dgamma1, dbeta1, dX1)
+        bn_backward(dY, Ymask, X2, st2, dgamma2, dbeta2, dX2)
+        return
+    nblk = hip.colstats_nblk(rows)
+    ws = scratch(X1.device, 4 * C * nblk + 4 * C)
+    hip.call("bn_backward_pair", dY, dY.stride(0), Ymask, Ymask.stride(0), rows, C, ws, ws[4 * C * nblk:],
+             X1, X1.stride(0), st1.mean, st1.invstd, st1.a, dgamma1, dbeta1, dX1, dX1.stride(0),
+             X2, X2.stride(0), st2.mean, st2.invstd, st2.a, dgamma2, dbeta2, dX2, dX2.stride(0))
+
+
 def transform2h_(pts, R, t):
     """In place on pts [F, P, C] (or any contiguous view of it)."""
     _chk(pts)

@@ -149,6 +149,29 @@ def test_fused_eval_mlp_and_bn_fold(dev):
         assert torch.equal(y2, y)
 
 
+def test_bn_backward_pair_equals_two_calls(dev):
+    """ops.bn_backward_pair (st_gcn's two BatchNorms behind one ReLU share dY and the mask) gives the bits of two bn_backward calls."""
+    from mmego_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for rows, C in ((7680, 128), (7680, 32), (1000, 64), (333, 24)):           # (C = 24: not a tile multiple -> falls back to two calls)
+        ar = ops.Arena(dev)
+        dY, Y = torch.randn(rows, C, generator=g).to(dev), torch.randn(rows, C, generator=g).to(dev)
+        Xs = [torch.randn(rows, C, generator=g).to(dev) for _ in range(2)]
+        sts = []
+        for i, X in enumerate(Xs):
+            bn = torch.nn.BatchNorm1d(C).to(dev)
+            bn.weight.data.uniform_(0.5, 1.5)
+            sts.append(ops.bn_stats(ar, "bn%d" % i, X, bn, True))
+        single = [[torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(rows, C, device=dev)] for _ in range(2)]
+        for X, st, (dg, db, dX) in zip(Xs, sts, single):
+            ops.bn_backward(dY, Y, X, st, dg, db, dX)
+        pair = [[torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(rows, C, device=dev)] for _ in range(2)]
+        ops.bn_backward_pair(dY, Y, Xs[0], sts[0], *pair[0], Xs[1], sts[1], *pair[1])
+        for a, b in zip(single, pair):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), (rows, C)
+
+
 def test_weight_gradient_with_bias_gradient_in_one_launch(dev):
     """ops.grad_weight(dY, X, dW, db): the bias gradient (column sums of dY) comes out of the weight-gradient product itself where
     that runs on the K-quartered small-product kernel (unsplit and split-K), and from a column-sum launch otherwise."""
