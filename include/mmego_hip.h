@@ -48,6 +48,14 @@ int mmego_colstats_nblk(long rows);
 int mmego_bn_train_stats(void* stream, const float* X, long ldx, long rows, int C, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          float* partial_ws, float* mean, float* invstd, float* a, float* b);
+/* The same for two tensors of one shape in the same two launches (st_gcn's BatchNorms of tcn(x) and residual(x), GCN.py:140-147;
+ * the second rides along as channels [C, 2C); same results as two calls).  partial_ws: 6*C*nblk floats; C a multiple of the
+ * 8..64-wide column tile. */
+int mmego_bn_train_stats_pair(void* stream, long rows, int C, float* partial_ws,
+                              const float* X1, long ldx1, const float* gamma1, const float* beta1, float* running_mean1,
+                              float* running_var1, float momentum1, float eps1, float* mean1, float* invstd1, float* a1, float* b1,
+                              const float* X2, long ldx2, const float* gamma2, const float* beta2, float* running_mean2,
+                              float* running_var2, float momentum2, float eps2, float* mean2, float* invstd2, float* a2, float* b2);
 /* Eval mode: the same four vectors from the running statistics. */
 int mmego_bn_eval_affine(void* stream, int C, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* mean, float* invstd, float* a, float* b);

@@ -23,16 +23,22 @@ static inline int col_tile(int C) {
 }
 
 // partial[c][blk] = (n, mean, M2) over this block's rows of column c
+// X2 (optional, same shape): a second tensor whose statistics ride along as the virtual channels [C, 2C) (two BatchNorms of
+// one st_gcn block in one launch; C a multiple of TC then).
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ X, long ldx, long rows, int C,
-                                                       float* __restrict__ partial, long RPB, int TC) {
+                                                       float* __restrict__ partial, long RPB, int TC,
+                                                       const float* __restrict__ X2, long ldx2) {
   __shared__ float sh[256][3];
   const int TR = 256 / TC;
   const int cx = threadIdx.x % TC, ry = threadIdx.x / TC;
-  const int c = blockIdx.y * TC + cx;
+  const int cv = blockIdx.y * TC + cx;
+  int c = cv;
+  if (X2 && cv >= C) { X = X2; ldx = ldx2; c = cv - C; }
+  const bool live = cv < (X2 ? 2 * C : C);
   const long r0 = (long)blockIdx.x * RPB;
   const long r1 = min(rows, r0 + RPB);
   float n = 0.f, s = 0.f, ss = 0.f, shift = 0.f;
-  if (c < C) {
+  if (live) {
     shift = X[r0 * ldx + c];  // block-local shift keeps the sum of squares well conditioned
     for (long r = r0 + ry; r < r1; r += TR) {
       float d = X[r * ldx + c] - shift;
@@ -43,11 +49,11 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
   }
   sh[threadIdx.x][0] = n; sh[threadIdx.x][1] = s; sh[threadIdx.x][2] = ss;
   __syncthreads();
-  if (ry == 0 && c < C) {
+  if (ry == 0 && live) {
     float N = 0.f, S = 0.f, SS = 0.f;
     for (int j = 0; j < TR; ++j) { N += sh[j * TC + cx][0]; S += sh[j * TC + cx][1]; SS += sh[j * TC + cx][2]; }
     float mean_d = S / N;
-    float* out = partial + ((long)c * gridDim.x + blockIdx.x) * 3;     // [channel][block]: the finalize lanes read consecutive records
+    float* out = partial + ((long)cv * gridDim.x + blockIdx.x) * 3;    // [channel][block]: the finalize lanes read consecutive records
     out[0] = N;
     out[1] = shift + mean_d;
     out[2] = fmaxf(SS - S * mean_d, 0.f);
@@ -56,10 +62,21 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
 
 // Combine partials (Chan, fp64); update running stats exactly like torch (momentum, unbiased running var).
 // outputs: mean[C], invstd[C], a[C] = gamma*invstd, b[C] = beta     so that y = (x-mean)*a + b
+struct BnStatsSecond { const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum; float eps;
+                       float* mean_out; float* invstd_out; float* a_out; float* b_out; };
+
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var, float momentum,
-                                   float eps, float* mean_out, float* invstd_out, float* a_out, float* b_out) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+                                   float eps, float* mean_out, float* invstd_out, float* a_out, float* b_out, BnStatsSecond second) {
+  int c = blockIdx.x;
+  const int lane = threadIdx.x;
+  partial += (long)c * nblk * 3;                          // this (virtual) channel's records
+  if (c >= C) {                                           // the second BatchNorm of a pair (colstats_kernel's X2)
+    c -= C;
+    gamma = second.gamma; beta = second.beta; running_mean = second.running_mean; running_var = second.running_var;
+    momentum = second.momentum; eps = second.eps;
+    mean_out = second.mean_out; invstd_out = second.invstd_out; a_out = second.a_out; b_out = second.b_out;
+  }
   // Exact pooled statistics of the (<= 1024) block partials, fp64, no division inside the loops:
   //   N = sum n_b,  mean = sum n_b mean_b / N,  M2 = sum [M2_b + n_b (mean_b - mean)^2]
   // All of a lane's partials (<= 16) are fetched in ONE round of loads; the kernel is pure load latency otherwise.
@@ -71,7 +88,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
   for (int u = 0; u < 16; ++u) {
     const int k = lane + 64 * u;
     const bool ok = k < nblk;
-    const float* p = partial + ((long)c * nblk + (ok ? k : 0)) * 3;
+    const float* p = partial + (long)(ok ? k : 0) * 3;
     pn[u] = ok ? p[0] : 0.f;
     pm[u] = ok ? p[1] : 0.f;
     p2[u] = ok ? p[2] : 0.f;
@@ -374,10 +391,37 @@ extern "C" int mmego_bn_train_stats(void* stream, const float* X, long ldx, long
   int nblk = cdiv(rows, RPB);
   MMEGO_REQUIRE(nblk <= 1024);
   const int TC = col_tile(C);
-  hipLaunchKernelGGL(colstats_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC);
+  BnStatsSecond none = {};
+  hipLaunchKernelGGL(colstats_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC,
+                     (const float*)nullptr, 0L);
   MMEGO_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, gamma, beta,
-                     running_mean, running_var, momentum, eps, mean, invstd, a, b);
+                     running_mean, running_var, momentum, eps, mean, invstd, a, b, none);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_bn_train_stats_pair(void* stream, long rows, int C, float* partial_ws,
+                                         const float* X1, long ldx1, const float* gamma1, const float* beta1, float* running_mean1,
+                                         float* running_var1, float momentum1, float eps1, float* mean1, float* invstd1, float* a1,
+                                         float* b1,
+                                         const float* X2, long ldx2, const float* gamma2, const float* beta2, float* running_mean2,
+                                         float* running_var2, float momentum2, float eps2, float* mean2, float* invstd2, float* a2,
+                                         float* b2) {
+  MMEGO_REQUIRE(rows > 0 && C > 0 && partial_ws && X1 && mean1 && invstd1 && a1 && b1 && X2 && mean2 && invstd2 && a2 && b2);
+  MMEGO_REQUIRE(gamma1 && beta1 && gamma2 && beta2 && (running_mean1 == nullptr) == (running_var1 == nullptr) &&
+                (running_mean2 == nullptr) == (running_var2 == nullptr));
+  hipStream_t st = (hipStream_t)stream;
+  const long RPB = rows_per_block(rows);
+  int nblk = cdiv(rows, RPB);
+  MMEGO_REQUIRE(nblk <= 1024);
+  const int TC = col_tile(C);
+  MMEGO_REQUIRE((C % TC) == 0);                          // (a column tile must not straddle the two tensors)
+  BnStatsSecond second = {gamma2, beta2, running_mean2, running_var2, momentum2, eps2, mean2, invstd2, a2, b2};
+  hipLaunchKernelGGL(colstats_kernel, dim3(nblk, cdiv(2 * C, TC)), dim3(256), 0, st, X1, ldx1, rows, C, partial_ws, RPB, TC, X2, ldx2);
+  MMEGO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(2 * C), dim3(64), 0, st, partial_ws, nblk, C, gamma1, beta1,
+                     running_mean1, running_var1, momentum1, eps1, mean1, invstd1, a1, b1, second);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -428,7 +428,6 @@ class LowerNet(_NetBase):
             key = "gcn.b%d" % i
             res_z = ar.get(key + ".rz", (rows, cout))
             ops.linear(cur, blk.residual["0"].weight, blk.residual["0"].bias, res_z)
-            st_r = ops.bn_stats(ar, key + ".bnr", res_z, blk.residual["1"], training)
             z = ar.get(key + ".z", (rows, K * cout))
             ops.linear(cur, blk.gcn.conv.weight, blk.gcn.conv.bias, z)
             ymix = ar.get(key + ".ymix", (rows, cout))
@@ -453,7 +452,8 @@ class LowerNet(_NetBase):
                 # frozen net: BatchNorm + ReLU applied while the convolution loads its tiles, weights re-packed k-contiguous once
                 hip.call("tconv", ymix, cout, st0.all, self._packed_tconv(i, wt, blk.taps), cout * cout, cout, 1, blk.tcn["2"].bias, tz,
                          cout, B, T, V, cout, cout, blk.taps)
-            st3 = ops.bn_stats(ar, key + ".bn3", tz, blk.tcn["3"], training)
+            # the block's two closing BatchNorms (temporal branch, residual branch) in one pair of launches
+            st3, st_r = ops.bn_stats_pair(ar, key + ".bn3", tz, blk.tcn["3"], key + ".bnr", res_z, blk.residual["1"], training)
             out = ar.get(key + ".out", (rows, cout))
             ops.affine_act(tz, st3, out, relu=True, X2=res_z, st2=st_r)
             cur = out

@@ -283,6 +283,25 @@ def bn_stats(arena, key, X, bn, training):
     return st
 
 
+def bn_stats_pair(arena, key1, X1, bn1, key2, X2, bn2, training):
+    """bn_stats of two same-shape tensors; in training one pair of launches instead of two (same results)."""
+    X1, X2 = _rows(X1), _rows(X2)
+    rows, C = X1.shape
+    tc = 8
+    while tc < C and tc < 64:
+        tc <<= 1
+    if not training or X2.shape != X1.shape or C % tc:
+        return bn_stats(arena, key1, X1, bn1, training), bn_stats(arena, key2, X2, bn2, training)
+    st1, st2 = BnState(arena, key1, C), BnState(arena, key2, C)
+    ws = scratch(X1.device, 6 * C * hip.colstats_nblk(rows))
+    hip.call("bn_train_stats_pair", rows, C, ws,
+             X1, X1.stride(0), bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, float(bn1.momentum), float(bn1.eps),
+             st1.mean, st1.invstd, st1.a, st1.b,
+             X2, X2.stride(0), bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, float(bn2.momentum), float(bn2.eps),
+             st2.mean, st2.invstd, st2.a, st2.b)
+    return st1, st2
+
+
 def affine_act(X, st, Y, relu=True, X2=None, st2=None):
     X, Y = _rows(X), _rows(Y)
     rows, C = X.shape

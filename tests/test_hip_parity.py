@@ -162,6 +162,17 @@ def test_bn_backward_pair_equals_two_calls(dev):
             bn = torch.nn.BatchNorm1d(C).to(dev)
             bn.weight.data.uniform_(0.5, 1.5)
             sts.append(ops.bn_stats(ar, "bn%d" % i, X, bn, True))
+        # the statistics pair gives the states (and running statistics) of two single calls
+        bns = [torch.nn.BatchNorm1d(C).to(dev) for _ in range(4)]
+        for b in bns:
+            b.weight.data.uniform_(0.5, 1.5)
+        for i in (0, 1):
+            bns[2 + i].load_state_dict(bns[i].state_dict())
+        sa = [ops.bn_stats(ar, "s%d" % i, Xs[i], bns[i], True) for i in (0, 1)]
+        sb = ops.bn_stats_pair(ar, "p0", Xs[0], bns[2], "p1", Xs[1], bns[3], True)
+        for i in (0, 1):
+            assert torch.equal(sa[i].all, sb[i].all), (rows, C)
+            assert torch.equal(bns[i].running_mean, bns[2 + i].running_mean) and torch.equal(bns[i].running_var, bns[2 + i].running_var)
         single = [[torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(rows, C, device=dev)] for _ in range(2)]
         for X, st, (dg, db, dX) in zip(Xs, sts, single):
             ops.bn_backward(dY, Y, X, st, dg, db, dX)
