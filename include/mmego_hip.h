@@ -279,7 +279,10 @@ int mmego_graph_mix(void* stream, const float* X, const float* A, const float* i
 int mmego_tconv_pack(void* stream, const float* W, int Co, int Ci, int taps, int mode, float* Wp);
 int mmego_tconv(void* stream, const float* X, long ldx, const float* in_state, const float* W, long wts, long wns, long wks,
                 const float* bias, float* Y, long ldy, int B, int T, int V, int Cin, int Cout, int taps);
-int mmego_im2col_t(void* stream, const float* X, int B, int T, int V, int C, int taps, float* col);
+/* (im2col_t: state (may be NULL) = [4][C] mean, invstd, a, b of the BatchNorm in front: BatchNorm + ReLU applied to the elements as
+ * they are gathered, mmego_affine_act's arithmetic; y_out (may be NULL, needs state) receives the activated tensor itself.) */
+int mmego_im2col_t(void* stream, const float* X, int B, int T, int V, int C, int taps, float* col, const float* state,
+                   float* y_out);
 int mmego_col2im_t(void* stream, const float* dcol, int B, int T, int V, int C, int taps, float* dX);
 /* out[b][c][r] = in[b][r][c]: the (B,64,T,V)->(B,T,V,64) re-view of GCN.py:351-353 (quirk Q8). */
 int mmego_transpose_batched(void* stream, const float* in, float* out, long Bn, int R, int C);

@@ -520,8 +520,11 @@ __global__ __launch_bounds__(512) void graph_dA_partial_kernel(const float* __re
 }
 
 // col[(b,t,v), ci*taps + tap] = X[b, t+tap-half, v, ci]  (zero outside)      X [B,T,V,C]
+// state (optional): [4][C] mean, invstd, a, b of a BatchNorm in front, applied with ReLU to every element as it is read (the
+// expression of affine_act_kernel, bn.hip: same bits); y_out (optional) then receives the activated tensor itself (the centre tap).
 __global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__ X, int B, int T, int V, int C, int taps,
-                                                       float* __restrict__ col) {
+                                                       float* __restrict__ col, const float* __restrict__ state,
+                                                       float* __restrict__ y_out) {
   const long total = (long)B * T * V * C * taps;
   const int half = taps / 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -534,7 +537,16 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__
     int t = (int)(bt % T);
     long b = bt / T;
     int ts = t + tap - half;
-    col[i] = (ts >= 0 && ts < T) ? X[((b * T + ts) * V + v) * (long)C + ci] : 0.f;
+    float val = 0.f;
+    if (ts >= 0 && ts < T) {
+      val = X[((b * T + ts) * V + v) * (long)C + ci];
+      if (state) {
+        val = (val - state[ci]) * state[2 * C + ci] + state[3 * C + ci];
+        val = fmaxf(val, 0.f);
+      }
+    }
+    col[i] = val;
+    if (y_out && tap == half) y_out[row * C + ci] = val;
   }
 }
 
@@ -684,10 +696,12 @@ extern "C" int mmego_graph_dA(void* stream, const float* Z, const float* dY, lon
   return MMEGO_OK;
 }
 
-extern "C" int mmego_im2col_t(void* stream, const float* X, int B, int T, int V, int C, int taps, float* col) {
+extern "C" int mmego_im2col_t(void* stream, const float* X, int B, int T, int V, int C, int taps, float* col, const float* state,
+                              float* y_out) {
   MMEGO_REQUIRE(X && col && B > 0 && T > 0 && V > 0 && C > 0 && taps > 0 && (taps & 1));
+  MMEGO_REQUIRE(!y_out || state);
   hipLaunchKernelGGL(im2col_t_kernel, dim3(ew_blocks((long)B * T * V * C * taps)), dim3(256), 0, (hipStream_t)stream, X, B,
-                     T, V, C, taps, col);
+                     T, V, C, taps, col, state, y_out);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

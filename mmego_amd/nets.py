@@ -437,10 +437,10 @@ class LowerNet(_NetBase):
             tz = ar.get(key + ".tz", (rows, cout))
             wt = blk.tcn["2"].weight                          # [cout, cout, taps, 1]
             if training and rows < _TCONV_TRAIN_MIN_ROWS:
+                # BatchNorm + ReLU applied while the rows are unfolded; y0 (kept for backward) leaves from the same launch
                 y0 = ar.get(key + ".y0", (rows, cout))
-                ops.affine_act(ymix, st0, y0, relu=True)
                 col = ar.get(key + ".col", (rows, cout * blk.taps))
-                hip.call("im2col_t", y0, B, T, V, cout, blk.taps, col)
+                hip.call("im2col_t", ymix, B, T, V, cout, blk.taps, col, st0.all, y0)
                 ops.linear(col, blk.tcn["2"].weight, blk.tcn["2"].bias, tz)
             elif training:
                 y0 = ar.get(key + ".y0", (rows, cout))         # (kept: the backward pass needs it)
@@ -533,7 +533,7 @@ class LowerNet(_NetBase):
             col = ar.get(key + ".col", (rows, cout * blk.taps))
             dy0 = ar.get(key + ".dy0", (rows, cout))
             if rows >= _TCONV_TRAIN_MIN_ROWS:
-                hip.call("im2col_t", y0, B, T, V, cout, blk.taps, col)
+                hip.call("im2col_t", y0, B, T, V, cout, blk.taps, col, None, None)
                 blocks.linear_backward(dtz, col, blk.tcn["2"], G, None, bias_grad=False)
                 # input gradient = the same implicit-GEMM convolution of dtz with the taps reversed and (co, ci) swapped
                 wp = ar.get(key + ".wp", (2, blk.tcn["2"].weight.numel()))
