@@ -213,11 +213,14 @@ int mmego_rotate_points(void* stream, const float* in, float* out, long F, int P
                         int transpose, int add_t);
 /* which=0: y[F,87] -> q[F,14,3,3], joints[F,15,3] (Upper_Net.py:122-144,354-364);
  * which=1: y[F,42] -> q[F,6,3,3], joints[F,8,3] (Lower_Net.py:12-37,125-136).  body [B,20,3]; frame n
- * uses body row n % B (quirk Q2).  Joints are in the head frame. */
+ * uses body row n % B (quirk Q2).  Joints are in the head frame.
+ * Rw [F,3,3], tw [F,3], world [F,nslots,3] (all three or none): world = Rw^T joint + tw, the head-to-world transform that follows
+ * the kinematics (Upper_Net.py:362-364, Lower_Net.py:225-227; mmego_rotate_points' arithmetic) from the same launch.
+ * backward: Rw given -> dj is the gradient wrt the WORLD-frame joints (the head-frame gradient Rw dj is formed first). */
 int mmego_head_fk_forward(void* stream, int which, const float* y, const float* body, int B, long F, float* q,
-                          float* joints);
+                          float* joints, const float* Rw, const float* tw, float* world);
 int mmego_head_fk_backward(void* stream, int which, const float* y, const float* body, int B, long F, const float* dj,
-                           float* dy);
+                           float* dy, const float* Rw);
 /* y[F,9] -> R[F,3,3] (eps rule of IMU_Net.py:7-18), t[F,3]. */
 int mmego_imu_head(void* stream, const float* y, long F, float* R, float* t);
 /* loss[0] = sum |pred - target[:, map]|, grad = scale*sign(.) (L1Loss(reduction='sum'), Train_Upper.py:53,179);

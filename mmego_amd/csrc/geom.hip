@@ -147,8 +147,12 @@ template <> struct FkC<1> {
 // y: [F, ny] head output (6*nrot rotation params, then positions);  body: [B, 20, 3];  frame n uses body n % B (Q2)
 // outputs: q [F, nrot, 3, 3], joints_h [F, nslots, 3] (head frame)
 template <int WHICH>
+// Rw / tw / world (optional): the frame's head pose; world [F, nslots, 3] = Rw^T joint + tw, the rotate_points(transpose) that
+// follows the kinematics in the nets (Upper_Net.py:362-364, Lower_Net.py:225-227), same arithmetic, no extra launch.
 __global__ __launch_bounds__(64) void head_fk_fwd_kernel(const float* __restrict__ y, const float* __restrict__ body, int B, long F,
-                                                         float* __restrict__ q, float* __restrict__ joints) {
+                                                         float* __restrict__ q, float* __restrict__ joints,
+                                                         const float* __restrict__ Rw, const float* __restrict__ tw,
+                                                         float* __restrict__ world) {
   using P = FkC<WHICH>;
   long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
@@ -181,12 +185,25 @@ __global__ __launch_bounds__(64) void head_fk_fwd_kernel(const float* __restrict
   for (int s = 0; s < P::nslots; ++s)
 #pragma unroll
     for (int i = 0; i < 3; ++i) joints[(f * P::nslots + s) * 3 + i] = l[s][i];
+  if (world) {
+    const float* Rf = Rw + f * 9;
+    const float t0 = tw[f * 3], t1 = tw[f * 3 + 1], t2 = tw[f * 3 + 2];
+#pragma unroll
+    for (int s = 0; s < P::nslots; ++s) {
+      float* w = world + (f * P::nslots + s) * 3;
+      w[0] = dot3_nofma(Rf[0], Rf[3], Rf[6], l[s][0], l[s][1], l[s][2]) + t0;
+      w[1] = dot3_nofma(Rf[1], Rf[4], Rf[7], l[s][0], l[s][1], l[s][2]) + t1;
+      w[2] = dot3_nofma(Rf[2], Rf[5], Rf[8], l[s][0], l[s][1], l[s][2]) + t2;
+    }
+  }
 }
 
 // dj: [F, nslots, 3] gradient wrt head-frame joints  ->  dy [F, ny]
+// Rw (optional): dj is the gradient wrt the WORLD-frame joints; the head-frame gradient Rw dj is formed first.
 template <int WHICH>
 __global__ __launch_bounds__(64) void head_fk_bwd_kernel(const float* __restrict__ y, const float* __restrict__ body, int B, long F,
-                                                         const float* __restrict__ dj, float* __restrict__ dy) {
+                                                         const float* __restrict__ dj, float* __restrict__ dy,
+                                                         const float* __restrict__ Rw) {
   using P = FkC<WHICH>;
   long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
@@ -197,6 +214,16 @@ __global__ __launch_bounds__(64) void head_fk_bwd_kernel(const float* __restrict
   for (int s = 0; s < P::nslots; ++s)
 #pragma unroll
     for (int i = 0; i < 3; ++i) g[s][i] = dj[(f * P::nslots + s) * 3 + i];
+  if (Rw) {
+    const float* Rf = Rw + f * 9;
+#pragma unroll
+    for (int s = 0; s < P::nslots; ++s) {
+      const float v0 = g[s][0], v1 = g[s][1], v2 = g[s][2];
+      g[s][0] = dot3_nofma(Rf[0], Rf[1], Rf[2], v0, v1, v2);
+      g[s][1] = dot3_nofma(Rf[3], Rf[4], Rf[5], v0, v1, v2);
+      g[s][2] = dot3_nofma(Rf[6], Rf[7], Rf[8], v0, v1, v2);
+    }
+  }
   float gq[P::nrot][9];
 #pragma unroll
   for (int k = 0; k < P::nrot; ++k)
@@ -338,19 +365,20 @@ extern "C" int mmego_rotate_points(void* stream, const float* in, float* out, lo
 
 // which: 0 = upper head (ny = 87 -> 14 rotations + head), 1 = lower head (ny = 42 -> 6 rotations + 2 hips)
 extern "C" int mmego_head_fk_forward(void* stream, int which, const float* y, const float* body, int B, long F, float* q,
-                                     float* joints) {
+                                     float* joints, const float* Rw, const float* tw, float* world) {
   MMEGO_REQUIRE((which == 0 || which == 1) && y && body && q && joints && B > 0 && F > 0);
-  if (which == 0) hipLaunchKernelGGL(head_fk_fwd_kernel<0>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints);
-  else hipLaunchKernelGGL(head_fk_fwd_kernel<1>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints);
+  MMEGO_REQUIRE(!world || (Rw && tw));
+  if (which == 0) hipLaunchKernelGGL(head_fk_fwd_kernel<0>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints, Rw, tw, world);
+  else hipLaunchKernelGGL(head_fk_fwd_kernel<1>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints, Rw, tw, world);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
 
 extern "C" int mmego_head_fk_backward(void* stream, int which, const float* y, const float* body, int B, long F,
-                                      const float* dj, float* dy) {
+                                      const float* dj, float* dy, const float* Rw) {
   MMEGO_REQUIRE((which == 0 || which == 1) && y && body && dj && dy && B > 0 && F > 0);
-  if (which == 0) hipLaunchKernelGGL(head_fk_bwd_kernel<0>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, dj, dy);
-  else hipLaunchKernelGGL(head_fk_bwd_kernel<1>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, dj, dy);
+  if (which == 0) hipLaunchKernelGGL(head_fk_bwd_kernel<0>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, dj, dy, Rw);
+  else hipLaunchKernelGGL(head_fk_bwd_kernel<1>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, dj, dy, Rw);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

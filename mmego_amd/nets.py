@@ -203,9 +203,8 @@ class UpperNet(_NetBase):
         ops.linear(h1, self.mlpHead.fc2.weight, self.mlpHead.fc2.bias, y)
         q = torch.empty((B, T, 14, 3, 3), dtype=torch.float32, device=x.device)
         jh = ar.get("jh", (F, 15, 3))
-        hip.call("head_fk_forward", 0, y, body, B, F, q, jh)
         l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=x.device)
-        ops.rotate_points(jh, l, R, t, transpose=True)
+        hip.call("head_fk_forward", 0, y, body, B, F, q, jh, R, t, l)       # kinematics + head-to-world transform, one launch
         if training:
             self._flat.bump_bn_counters(self.seed_counter())
         if stash:
@@ -218,11 +217,9 @@ class UpperNet(_NetBase):
         F, rows = B * T, B * T * N
         G = self._flat.grad
         dl = _f32c(dl)
-        djh = ar.get("djh", (F, 15, 3))
-        ops.rotate_points(dl, djh, R, None, transpose=False)
         y, h1 = ar.get("y", (F, 87)), ar.get("h1", (F, 128))
         dy = ar.get("dy", (F, 87))
-        hip.call("head_fk_backward", 0, y, body, B, F, djh, dy)
+        hip.call("head_fk_backward", 0, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
         dh1 = ar.get("dh1", (F, 128))
         blocks.linear_backward(dy, h1, self.mlpHead.fc2, G, dh1, relu_input=True)
         seq = ar.get("grnn.out2", (F, 128))
@@ -393,9 +390,8 @@ class LowerNet(_NetBase):
         ops.linear(f1, fu.fc2.weight, fu.fc2.bias, y)
         q = torch.empty((B, T, 6, 3, 3), dtype=torch.float32, device=dev)
         jh = ar.get("jh", (F, 8, 3))
-        hip.call("head_fk_forward", 1, y, body, B, F, q, jh)
         l = torch.empty((B, T, 8, 3), dtype=torch.float32, device=dev)
-        ops.rotate_points(jh, l, R, t, transpose=True)
+        hip.call("head_fk_forward", 1, y, body, B, F, q, jh, R, t, l)       # kinematics + head-to-world transform, one launch
         if training:
             self._flat.bump_bn_counters(self.seed_counter())
         if stash:
@@ -477,11 +473,9 @@ class LowerNet(_NetBase):
         G = self._flat.grad
         fu = self.fusion
         dl = _f32c(dl)
-        djh = ar.get("djh", (F, 8, 3))
-        ops.rotate_points(dl, djh, R, None, transpose=False)
         y, f1, f0, cat = ar.get("y", (F, 42)), ar.get("f1", (F, 64)), ar.get("f0", (F, 128)), ar.get("cat", (F, 173))
         dy = ar.get("dy", (F, 42))
-        hip.call("head_fk_backward", 1, y, body, B, F, djh, dy)
+        hip.call("head_fk_backward", 1, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
         df1, df0, dcat = ar.get("df1", (F, 64)), ar.get("df0", (F, 128)), ar.get("dcat", (F, 173))
         blocks.linear_backward(dy, f1, fu.fc2, G, df1, relu_input=True)
         blocks.linear_backward(df1, f0, fu.fc1, G, df0, relu_input=True)

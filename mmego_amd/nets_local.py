@@ -141,9 +141,8 @@ class UpperNetwlocal(_NetBase):
         ops.linear(h1, self.module3.fc2.weight, self.module3.fc2.bias, y)
         q = torch.empty((B, T, 14, 3, 3), dtype=torch.float32, device=dev)
         jh = ar.get("jh", (F, 15, 3))
-        hip.call("head_fk_forward", 0, y, body, B, F, q, jh)
         l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=dev)
-        ops.rotate_points(jh, l, R, t, transpose=True)
+        hip.call("head_fk_forward", 0, y, body, B, F, q, jh, R, t, l)       # kinematics + head-to-world transform, one launch
         if training:
             self._flat.bump_bn_counters(self.seed_counter())
         if stash:
@@ -157,11 +156,9 @@ class UpperNetwlocal(_NetBase):
         grows = F * N_ANCHOR * N_GROUP
         G = self._flat.grad
         dl = _f32c(dl)
-        djh = ar.get("djh", (F, 15, 3))
-        ops.rotate_points(dl, djh, R, None, transpose=False)
         y, h1, cat = ar.get("y", (F, 87)), ar.get("h1", (F, 128)), ar.get("cat", (F, 256))
         dy = ar.get("dy", (F, 87))
-        hip.call("head_fk_backward", 0, y, body, B, F, djh, dy)
+        hip.call("head_fk_backward", 0, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
         dh1 = ar.get("dh1", (F, 128))
         blocks.linear_backward(dy, h1, self.module3.fc2, G, dh1, relu_input=True)
         dcat = ar.get("dcat", (F, 256))
