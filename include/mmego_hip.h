@@ -263,10 +263,13 @@ int mmego_cross_attn_forward(void* stream, const float* Q, const float* K, const
                              long ldo, float* P);
 int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, const float* V, const float* P,
                               const float* dO, long lddo, long F, float scale, float* dQ, float* dK, float* dV);
-/* Gradient of einsum('nkctv,kvw->nctw') wrt A (GCN.py:62); the forward and dZ are mmego_gemm batches.  Writes
- * per-block partial sums partial_ws[mmego_graph_dA_nblk(G)][K*V*V]; reduce them with mmego_colsum. */
+/* Gradient of einsum('nkctv,kvw->nctw') wrt A (GCN.py:62).  Writes per-block partial sums
+ * partial_ws[mmego_graph_dA_nblk(G)][K*V*V]; reduce them with mmego_colsum (scale = A gives the edge-importance gradient).
+ * A, imp, dZ (all three or none): the einsum's input gradient dZ [G, V, K*C] from the same launch (what mmego_graph_mix
+ * with backward = 1 computes, same bits). */
 int mmego_graph_dA_nblk(long G);
-int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* partial_ws);
+int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* partial_ws,
+                   const float* A, const float* imp, float* dZ);
 /* Temporal 9x1 unfold / fold of a channels-last (B,T,V,C) tensor (GCN.py:109-116). */
 /* ---- ST-GCN layer pieces (gcn.hip): Net/GCN.py:55-64 (graph convolution einsum), :108-122 (9x1 temporal convolution) --------
  * mmego_graph_mix: Y[f][w][c] = sum_k sum_v (A . importance)[k][v][w] X[f][v][k*C + c]  (backward = 0; X is z [F][V][K*C]), or the

@@ -492,12 +492,20 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
 // Each block stages FPB frames' Z and dY rows in LDS once and every thread owns one (k,v,w) entry;
 // partial[blk][k*V*V + v*V + w] is then column-summed in fixed order by the caller (mmego_colsum kernels).
 #define GDA_FPB 2   // frames per block: 512 frames -> 256 blocks (8 per block left 3 of 4 CUs idle and chained 8 load latencies)
+// A / imp / dZ (optional, all three): the einsum's input gradient dZ[g, v, k*C + c] = sum_w (A . imp)[k, v, w] dY[g, w, c] from
+// the same staged dY rows (graph_mix_kernel's backward arithmetic, gcn.hip: same sums in the same order) -- one launch for
+// both gradients of the einsum.
 __global__ __launch_bounds__(512) void graph_dA_partial_kernel(const float* __restrict__ Z, const float* __restrict__ dY, long G,
-                                                               int V, int Kk, int C, float* __restrict__ partial) {
+                                                               int V, int Kk, int C, float* __restrict__ partial,
+                                                               const float* __restrict__ A, const float* __restrict__ imp,
+                                                               float* __restrict__ dZ) {
   extern __shared__ float sm[];
   const int KC = Kk * C;
   float* zs = sm;                       // [V][KC + 1]
   float* ys = sm + V * (KC + 1);        // [V][C + 1]
+  float* As = ys + V * (C + 1);         // [Kk][V][V]  A . importance (only with dZ)
+  if (dZ)
+    for (int i = threadIdx.x; i < Kk * V * V; i += blockDim.x) As[i] = A[i] * imp[i];
   const int nout = Kk * V * V;
   const int e = threadIdx.x;
   const int w = e % V, v = (e / V) % V, k = e / (V * V);
@@ -514,6 +522,16 @@ __global__ __launch_bounds__(512) void graph_dA_partial_kernel(const float* __re
       float a = 0.f;
       for (int c = 0; c < C; ++c) a += zr[c] * yr[c];
       acc += a;
+    }
+    if (dZ) {
+      float* zf = dZ + g * V * KC;
+      for (int i = threadIdx.x; i < V * KC; i += blockDim.x) {
+        const int row = i / KC, col = i - row * KC;
+        const int kk = col / C, c = col - kk * C;
+        float a = 0.f;
+        for (int w2 = 0; w2 < V; ++w2) a += As[(kk * V + row) * V + w2] * ys[w2 * (C + 1) + c];
+        zf[i] = a;
+      }
     }
   }
   if (e < nout) partial[(long)blockIdx.x * nout + e] = acc;
@@ -686,12 +704,14 @@ extern "C" int mmego_cross_attn_backward(void* stream, const float* Q, const flo
 
 extern "C" int mmego_graph_dA_nblk(long G) { return cdiv(G, GDA_FPB); }
 
-extern "C" int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* partial_ws) {
+extern "C" int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* partial_ws,
+                              const float* A, const float* imp, float* dZ) {
   MMEGO_REQUIRE(Z && dY && partial_ws && G > 0 && V > 0 && K > 0 && C > 0 && K * V * V <= 512);
-  size_t lds = (size_t)(V * (K * C + 1) + V * (C + 1)) * sizeof(float);
+  MMEGO_REQUIRE(!dZ || (A && imp));
+  size_t lds = (size_t)(V * (K * C + 1) + V * (C + 1) + K * V * V) * sizeof(float);
   MMEGO_REQUIRE(lds <= 64 * 1024);
   hipLaunchKernelGGL(graph_dA_partial_kernel, dim3(cdiv(G, GDA_FPB)), dim3(512), lds, (hipStream_t)stream, Z, dY, G, V, K, C,
-                     partial_ws);
+                     partial_ws, A, imp, dZ);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

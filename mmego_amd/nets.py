@@ -547,15 +547,15 @@ class LowerNet(_NetBase):
             ops.bn_backward(dy0, y0, ymix, st0, G(blk.tcn["0"].weight), G(blk.tcn["0"].bias), dymix)
             z = ar.get(key + ".z", (rows, K * cout))
             dAp = ar.get(key + ".dAp", (hip.lib().mmego_graph_dA_nblk(F), K * V * V))
-            hip.call("graph_dA", z, dymix, F, V, K, cout, dAp)
+            dz = ar.get(key + ".dz", (rows, K * cout))
+            # both gradients of the einsum from one launch: dA partials and dz_k[v] = sum_w (A.imp)[k,v,w] dy[w]
+            hip.call("graph_dA", z, dymix, F, V, K, cout, dAp, gcn.A, gcn.edge_importance[i], dz)
             if dAp.shape[0] <= 1024 and gcn.A.is_contiguous():      # d(importance) = A . sum of the partials, one launch
                 ops.colsum(dAp, G(gcn.edge_importance[i]).view(-1), scale=gcn.A.view(-1))
             else:
                 dA = ar.get(key + ".dA", (K, V, V))
                 ops.colsum(dAp, dA.view(-1))
                 hip.call("mul", dA, gcn.A, G(gcn.edge_importance[i]), dA.numel())
-            dz = ar.get(key + ".dz", (rows, K * cout))
-            hip.call("graph_mix", dymix, gcn.A, gcn.edge_importance[i], dz, F, V, K, cout, 1)    # dz_k[v] = sum_w (A.imp)[k,v,w] dy[w]
             dinp = ar.get(key + ".dinp", (rows, cin))
             blocks.linear_backward(dz, inp, blk.gcn.conv, G, dinp)
             blocks.linear_backward(drz, inp, blk.residual["0"], G, dinp, accumulate_dx=True, bias_grad=False)
