@@ -48,6 +48,11 @@ int mmego_colstats_nblk(long rows);
 int mmego_bn_train_stats(void* stream, const float* X, long ldx, long rows, int C, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          float* partial_ws, float* mean, float* invstd, float* a, float* b);
+/* The second half of mmego_bn_train_stats alone: partial = nblk records (n, mean, M2) per channel, [C][nblk][3], produced by a
+ * kernel that had the tensor in its hands anyway (mmego_graph_mix's `stats`).  nblk <= 1024. */
+int mmego_bn_finalize(void* stream, const float* partial, int nblk, int C, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* a,
+                      float* b);
 /* The same for two tensors of one shape in the same two launches (st_gcn's BatchNorms of tcn(x) and residual(x), GCN.py:140-147;
  * the second rides along as channels [C, 2C); same results as two calls).  partial_ws: 6*C*nblk floats; C a multiple of the
  * 8..64-wide column tile. */
@@ -274,6 +279,8 @@ int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V,
 /* ---- ST-GCN layer pieces (gcn.hip): Net/GCN.py:55-64 (graph convolution einsum), :108-122 (9x1 temporal convolution) --------
  * mmego_graph_mix: Y[f][w][c] = sum_k sum_v (A . importance)[k][v][w] X[f][v][k*C + c]  (backward = 0; X is z [F][V][K*C]), or the
  * input gradient Y[f][v][k*C + c] = sum_w (A . importance)[k][v][w] X[f][w][c] (backward = 1; X is dy [F][V][C]).
+ * stats (may be NULL; forward, F <= 1024): [C][F][3] BatchNorm partial records (V, mean, M2) of Y per frame and channel, for
+ * mmego_bn_finalize -- the batch statistics of st_gcn.tcn[0] without a pass of their own over Y.
  * mmego_tconv: temporal convolution over rows (b, t, v) as an implicit GEMM, out[r][n] = bias[n] + sum_tap sum_k
  * act(X[r + (tap - taps/2) V][k]) W[tap*wts + n*wns + k*wks], taps leaving the sequence contribute zero; act = ReLU(BatchNorm)
  * given by in_state [4][Cin] (mean, invstd, gamma*invstd, beta) or identity (NULL).  Conv weight [Cout][Cin][taps] as it is:
@@ -281,7 +288,7 @@ int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V,
  * mmego_tconv_pack: W[co][ci][tap] -> [tap][co][ci] (mode 0) / [taps-1-tap][ci][co] (mode 1) / both, one behind the other (mode 2):
  * k-contiguous tile loads for mmego_tconv, strides (Cout*Cin, Cin, 1). */
 int mmego_graph_mix(void* stream, const float* X, const float* A, const float* importance, float* Y, long F, int V, int K, int C,
-                    int backward);
+                    int backward, float* stats);
 int mmego_tconv_pack(void* stream, const float* W, int Co, int Ci, int taps, int mode, float* Wp);
 int mmego_tconv(void* stream, const float* X, long ldx, const float* in_state, const float* W, long wts, long wns, long wks,
                 const float* bias, float* Y, long ldy, int B, int T, int V, int Cin, int Cout, int taps);

@@ -401,6 +401,18 @@ extern "C" int mmego_bn_train_stats(void* stream, const float* X, long ldx, long
   return MMEGO_OK;
 }
 
+extern "C" int mmego_bn_finalize(void* stream, const float* partial, int nblk, int C, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                                 float* a, float* b) {
+  MMEGO_REQUIRE(partial && nblk >= 1 && nblk <= 1024 && C > 0 && gamma && beta && mean && invstd && a && b);
+  MMEGO_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  BnStatsSecond none = {};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, nblk, C, gamma, beta, running_mean,
+                     running_var, momentum, eps, mean, invstd, a, b, none);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
 extern "C" int mmego_bn_train_stats_pair(void* stream, long rows, int C, float* partial_ws,
                                          const float* X1, long ldx1, const float* gamma1, const float* beta1, float* running_mean1,
                                          float* running_var1, float momentum1, float eps1, float* mean1, float* invstd1, float* a1,

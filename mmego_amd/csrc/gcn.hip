@@ -21,14 +21,18 @@
 
 #define GC_S 66          // even row stride: fragments are read as aligned float2 (lanes r = 0..31 hit 64 distinct banks)
 
+// stats (optional, forward): per-frame BatchNorm partials of the output, stats[(c*F + f)*3 + {0,1,2}] = (V, mean, M2) of channel c
+// over the frame's V rows -- the record format of colstats_kernel (bn.hip) with one "block" per frame, so that the batch
+// statistics of the BatchNorm behind the einsum (st_gcn.tcn[0]) need no pass of their own over y.
 __global__ __launch_bounds__(256) void graph_mix_kernel(const float* __restrict__ X, const float* __restrict__ A,
                                                         const float* __restrict__ imp, float* __restrict__ Y, long F, int V,
-                                                        int Kk, int C, int backward) {
+                                                        int Kk, int C, int backward, float* __restrict__ stats) {
   extern __shared__ float sm[];
   // forward : X = z [F][V][Kk*C] -> Y = y [F][V][C];   backward: X = dy [F][V][C] -> Y = dz [F][V][Kk*C]
   const int Cin = backward ? C : Kk * C, Cout = backward ? Kk * C : C;
   float* As = sm;                          // [Kk][V][V]  A . importance
   float* Xs = sm + Kk * V * V;             // [V][Cin + 1]
+  float* Ys = Xs + V * (Cin + 1);          // [V][Cout + 1]  (only with stats)
   for (int i = threadIdx.x; i < Kk * V * V; i += blockDim.x) As[i] = A[i] * imp[i];
   for (long f = blockIdx.x; f < F; f += gridDim.x) {
     __syncthreads();
@@ -47,6 +51,19 @@ __global__ __launch_bounds__(256) void graph_mix_kernel(const float* __restrict_
         for (int w = 0; w < V; ++w) acc += As[(k * V + row) * V + w] * Xs[w * (Cin + 1) + c];
       }
       yf[i] = acc;
+      if (stats) Ys[row * (Cout + 1) + col] = acc;
+    }
+    if (stats) {
+      __syncthreads();
+      for (int c = threadIdx.x; c < Cout; c += blockDim.x) {
+        float sum = 0.f;
+        for (int r = 0; r < V; ++r) sum += Ys[r * (Cout + 1) + c];
+        const float mean = sum / (float)V;
+        float m2 = 0.f;
+        for (int r = 0; r < V; ++r) { const float d = Ys[r * (Cout + 1) + c] - mean; m2 += d * d; }
+        float* rec = stats + ((long)c * F + f) * 3;
+        rec[0] = (float)V; rec[1] = mean; rec[2] = m2;
+      }
     }
   }
 }
@@ -188,13 +205,15 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
 }
 
 extern "C" int mmego_graph_mix(void* stream, const float* X, const float* A, const float* importance, float* Y, long F, int V, int K,
-                               int C, int backward) {
+                               int C, int backward, float* stats) {
   MMEGO_REQUIRE(X && A && importance && Y && F > 0 && V >= 1 && V <= 32 && K >= 1 && K <= 4 && C >= 1);
-  const int Cin = backward ? C : K * C;
-  const size_t lds = (size_t)(K * V * V + V * (Cin + 1)) * sizeof(float);
+  MMEGO_REQUIRE(!stats || (!backward && F <= 1024));     // (one record per frame and channel: mmego_bn_finalize takes <= 1024)
+  const int Cin = backward ? C : K * C, Cout = backward ? K * C : C;
+  const size_t lds = (size_t)(K * V * V + V * (Cin + 1) + (stats ? V * (Cout + 1) : 0)) * sizeof(float);
   MMEGO_REQUIRE(lds <= 64 * 1024);
   const int grid = (int)(F < 2048 ? F : 2048);
-  hipLaunchKernelGGL(graph_mix_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, A, importance, Y, F, V, K, C, backward);
+  hipLaunchKernelGGL(graph_mix_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, A, importance, Y, F, V, K, C, backward,
+                     stats);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -428,8 +428,17 @@ class LowerNet(_NetBase):
             ops.linear(cur, blk.gcn.conv.weight, blk.gcn.conv.bias, z)
             ymix = ar.get(key + ".ymix", (rows, cout))
             # einsum('nkctv,kvw->nctw', z, A * edge_importance): one launch, A . importance formed in LDS (gcn.hip)
-            hip.call("graph_mix", z, gcn.A, gcn.edge_importance[i], ymix, F, V, K, cout, 0)
-            st0 = ops.bn_stats(ar, key + ".bn0", ymix, blk.tcn["0"], training)
+            if training and F <= 1024:
+                # the einsum leaves the BatchNorm partials of its output (one record per frame and channel) beside it
+                ws = ops.scratch(z.device, 3 * cout * F)
+                hip.call("graph_mix", z, gcn.A, gcn.edge_importance[i], ymix, F, V, K, cout, 0, ws)
+                st0 = ops.BnState(ar, key + ".bn0", cout)
+                bn0 = blk.tcn["0"]
+                hip.call("bn_finalize", ws, F, cout, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, float(bn0.momentum),
+                         float(bn0.eps), st0.mean, st0.invstd, st0.a, st0.b)
+            else:
+                hip.call("graph_mix", z, gcn.A, gcn.edge_importance[i], ymix, F, V, K, cout, 0, None)
+                st0 = ops.bn_stats(ar, key + ".bn0", ymix, blk.tcn["0"], training)
             tz = ar.get(key + ".tz", (rows, cout))
             wt = blk.tcn["2"].weight                          # [cout, cout, taps, 1]
             if training and rows < _TCONV_TRAIN_MIN_ROWS:

@@ -617,12 +617,18 @@ def test_gcn_kernels_against_torch(dev):
     Ae = (A * imp).double()
     want = torch.einsum("fvkc,kvw->fwc", z.double().view(Fn, V, K, C), Ae)
     y = torch.empty(Fn, V, C, device=dev)
-    hip.call("graph_mix", z.to(dev), A.to(dev), imp.to(dev), y, Fn, V, K, C, 0)
+    stats = torch.empty(C, Fn, 3, device=dev)
+    hip.call("graph_mix", z.to(dev), A.to(dev), imp.to(dev), y, Fn, V, K, C, 0, stats)
     assert (y.cpu().double() - want).abs().max().item() < 1e-4
+    # the BatchNorm partial records it leaves beside the output: (V, mean, M2) per channel and frame
+    yc = y.double().cpu()
+    assert (stats[:, :, 0] == V).all()
+    assert (stats[:, :, 1].double().cpu() - yc.mean(1).t()).abs().max().item() < 1e-5
+    assert (stats[:, :, 2].double().cpu() - ((yc - yc.mean(1, keepdim=True)) ** 2).sum(1).t()).abs().max().item() < 1e-3
     dy = torch.randn(Fn, V, C, generator=g)
     want_dz = torch.einsum("fwc,kvw->fvkc", dy.double(), Ae).reshape(Fn, V, K * C)
     dz = torch.empty(Fn, V, K * C, device=dev)
-    hip.call("graph_mix", dy.to(dev), A.to(dev), imp.to(dev), dz, Fn, V, K, C, 1)
+    hip.call("graph_mix", dy.to(dev), A.to(dev), imp.to(dev), dz, Fn, V, K, C, 1, None)
     assert (dz.cpu().double() - want_dz).abs().max().item() < 1e-4
     # both gradients of the einsum from mmego_graph_dA: dA (per-workgroup partials, summed here) and the same dz, bit for bit
     nblk = hip.graph_dA_nblk(Fn)
