@@ -211,8 +211,9 @@ int mmego_imu_loss(void* stream, const float* R, const float* t, const float* R_
 int mmego_imu_head_backward(void* stream, const float* y, const float* dR, const float* dt, long F, float* dy);
 
 /* ---- geometry, heads, loss, selection (geom.hip) --------------------------------------------------
- * In-place xyz <- R (xyz - t) per frame (Utils.py:284-292, quirk Q1: the caller's buffer is mutated). */
-int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t);
+ * In-place xyz <- R (xyz - t) per frame (Utils.py:284-292, quirk Q1: the caller's buffer is mutated).
+ * src (may be NULL): xyz is read from src [F*P, 3] instead of pts (copy + transform, one launch). */
+int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t, const float* src);
 /* out = R^T in + t (transpose=1, add_t=1: Utils.py:274-281) or out = R in (its backward). */
 int mmego_rotate_points(void* stream, const float* in, float* out, long F, int P, const float* R, const float* t,
                         int transpose, int add_t);
@@ -221,9 +222,12 @@ int mmego_rotate_points(void* stream, const float* in, float* out, long F, int P
  * uses body row n % B (quirk Q2).  Joints are in the head frame.
  * Rw [F,3,3], tw [F,3], world [F,nslots,3] (all three or none): world = Rw^T joint + tw, the head-to-world transform that follows
  * the kinematics (Upper_Net.py:362-364, Lower_Net.py:225-227; mmego_rotate_points' arithmetic) from the same launch.
+ * counters / ncount / seed_ctr (0 / NULL: none): the net's once-per-training-forward tick (mmego_inc_i64) on the same launch --
+ * this kernel runs once per forward, behind every reader of the dropout seed.
  * backward: Rw given -> dj is the gradient wrt the WORLD-frame joints (the head-frame gradient Rw dj is formed first). */
 int mmego_head_fk_forward(void* stream, int which, const float* y, const float* body, int B, long F, float* q,
-                          float* joints, const float* Rw, const float* tw, float* world);
+                          float* joints, const float* Rw, const float* tw, float* world, long long* counters, int ncount,
+                          unsigned long long* seed_ctr);
 int mmego_head_fk_backward(void* stream, int which, const float* y, const float* body, int B, long F, const float* dj,
                            float* dy, const float* Rw);
 /* y[F,9] -> R[F,3,3] (eps rule of IMU_Net.py:7-18), t[F,3]. */

@@ -14,15 +14,17 @@ __device__ __forceinline__ float dot3_nofma(float a0, float a1, float a2, float 
 }
 
 // pts[f, p, 0:3] <- R[f] . (pts[f, p, 0:3] - t[f])   IN PLACE (reference quirk Q1)
-__global__ __launch_bounds__(256) void transform2h_kernel(float* __restrict__ pts, int P, int C, const float* __restrict__ R,
-                                                          const float* __restrict__ t, long npts) {
+// src (optional): read the points from src [npts, 3] instead (out of place: a copy + transform in one launch)
+__global__ __launch_bounds__(256) void transform2h_kernel(float* pts, int P, int C, const float* __restrict__ R,
+                                                          const float* __restrict__ t, long npts, const float* src) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts) return;
   long f = i / P;
   const float* Rf = R + f * 9;
   const float* tf = t + f * 3;
   float* x = pts + i * C;
-  float d0 = __fsub_rn(x[0], tf[0]), d1 = __fsub_rn(x[1], tf[1]), d2 = __fsub_rn(x[2], tf[2]);
+  const float* xs = src ? src + i * 3 : x;
+  float d0 = __fsub_rn(xs[0], tf[0]), d1 = __fsub_rn(xs[1], tf[1]), d2 = __fsub_rn(xs[2], tf[2]);
   x[0] = dot3_nofma(Rf[0], Rf[1], Rf[2], d0, d1, d2);
   x[1] = dot3_nofma(Rf[3], Rf[4], Rf[5], d0, d1, d2);
   x[2] = dot3_nofma(Rf[6], Rf[7], Rf[8], d0, d1, d2);
@@ -152,9 +154,16 @@ template <int WHICH>
 __global__ __launch_bounds__(64) void head_fk_fwd_kernel(const float* __restrict__ y, const float* __restrict__ body, int B, long F,
                                                          float* __restrict__ q, float* __restrict__ joints,
                                                          const float* __restrict__ Rw, const float* __restrict__ tw,
-                                                         float* __restrict__ world) {
+                                                         float* __restrict__ world, long long* counters, int ncount,
+                                                         unsigned long long* seed_ctr) {
   using P = FkC<WHICH>;
   long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f == 0) {
+    // the net's once-per-training-forward tick (mmego_inc_i64's arithmetic) rides on this launch: BatchNorm
+    // num_batches_tracked += 1, next dropout seed (every reader of the seed in this forward has run: same stream, earlier)
+    for (int i = 0; i < ncount; ++i) counters[i] += 1;
+    if (seed_ctr) seed_ctr[0] = seed_ctr[0] * 6364136223846793005ULL + 1442695040888963407ULL;
+  }
   if (f >= F) return;
   const float* yf = y + f * P::ny;
   const float* bf = body + (f % B) * 60;
@@ -345,10 +354,10 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t) {
+extern "C" int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t, const float* src) {
   MMEGO_REQUIRE(pts && R && t && F > 0 && P > 0 && C >= 3);
   long n = F * P;
-  hipLaunchKernelGGL(transform2h_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, P, C, R, t, n);
+  hipLaunchKernelGGL(transform2h_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, P, C, R, t, n, src);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
@@ -365,11 +374,13 @@ extern "C" int mmego_rotate_points(void* stream, const float* in, float* out, lo
 
 // which: 0 = upper head (ny = 87 -> 14 rotations + head), 1 = lower head (ny = 42 -> 6 rotations + 2 hips)
 extern "C" int mmego_head_fk_forward(void* stream, int which, const float* y, const float* body, int B, long F, float* q,
-                                     float* joints, const float* Rw, const float* tw, float* world) {
+                                     float* joints, const float* Rw, const float* tw, float* world, long long* counters,
+                                     int ncount, unsigned long long* seed_ctr) {
   MMEGO_REQUIRE((which == 0 || which == 1) && y && body && q && joints && B > 0 && F > 0);
   MMEGO_REQUIRE(!world || (Rw && tw));
-  if (which == 0) hipLaunchKernelGGL(head_fk_fwd_kernel<0>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints, Rw, tw, world);
-  else hipLaunchKernelGGL(head_fk_fwd_kernel<1>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints, Rw, tw, world);
+  MMEGO_REQUIRE(ncount >= 0 && ncount <= 4096 && (ncount == 0 || counters));
+  if (which == 0) hipLaunchKernelGGL(head_fk_fwd_kernel<0>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints, Rw, tw, world, counters, ncount, seed_ctr);
+  else hipLaunchKernelGGL(head_fk_fwd_kernel<1>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints, Rw, tw, world, counters, ncount, seed_ctr);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

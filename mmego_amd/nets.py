@@ -204,9 +204,8 @@ class UpperNet(_NetBase):
         q = torch.empty((B, T, 14, 3, 3), dtype=torch.float32, device=x.device)
         jh = ar.get("jh", (F, 15, 3))
         l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=x.device)
-        hip.call("head_fk_forward", 0, y, body, B, F, q, jh, R, t, l)       # kinematics + head-to-world transform, one launch
-        if training:
-            self._flat.bump_bn_counters(self.seed_counter())
+        tick = self._flat.tick_args(self.seed_counter()) if training else (None, 0, None)   # BatchNorm counters + dropout seed
+        hip.call("head_fk_forward", 0, y, body, B, F, q, jh, R, t, l, *tick)       # kinematics + head-to-world transform, one launch
         if stash:
             self._saved = (B, T, N, R, body, c0, attn)
         return l, q, attn, hn, cn
@@ -346,8 +345,7 @@ class LowerNet(_NetBase):
         R, t, body = _f32c(R), _f32c(t), _f32c(body)
         ops.transform2h_(x, R, t)                                     # Q1 (second transform after UpperNet)
         up = ar.get("up", (F, V * 3))
-        ops.copy2d(_f32c(upper_l).view(F, V * 3), up)
-        ops.transform2h_(up.view(F, V, 3), R, t)
+        ops.transform2h_(up.view(F, V, 3), R, t, src=_f32c(upper_l).view(F, V, 3))     # (copy + transform, one launch)
         sel = ar.get("sel", (F * LOWER_POINTS, Cx))
         idx = ar.get("sel_idx", (F, LOWER_POINTS), dtype=torch.int64)
         if pin_select_idx is None:
@@ -391,9 +389,8 @@ class LowerNet(_NetBase):
         q = torch.empty((B, T, 6, 3, 3), dtype=torch.float32, device=dev)
         jh = ar.get("jh", (F, 8, 3))
         l = torch.empty((B, T, 8, 3), dtype=torch.float32, device=dev)
-        hip.call("head_fk_forward", 1, y, body, B, F, q, jh, R, t, l)       # kinematics + head-to-world transform, one launch
-        if training:
-            self._flat.bump_bn_counters(self.seed_counter())
+        tick = self._flat.tick_args(self.seed_counter()) if training else (None, 0, None)   # BatchNorm counters + dropout seed
+        hip.call("head_fk_forward", 1, y, body, B, F, q, jh, R, t, l, *tick)       # kinematics + head-to-world transform, one launch
         if stash:
             self._saved = (B, T, N, R, body)
         return l, q

@@ -142,9 +142,8 @@ class UpperNetwlocal(_NetBase):
         q = torch.empty((B, T, 14, 3, 3), dtype=torch.float32, device=dev)
         jh = ar.get("jh", (F, 15, 3))
         l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=dev)
-        hip.call("head_fk_forward", 0, y, body, B, F, q, jh, R, t, l)       # kinematics + head-to-world transform, one launch
-        if training:
-            self._flat.bump_bn_counters(self.seed_counter())
+        tick = self._flat.tick_args(self.seed_counter()) if training else (None, 0, None)   # BatchNorm counters + dropout seed
+        hip.call("head_fk_forward", 0, y, body, B, F, q, jh, R, t, l, *tick)       # kinematics + head-to-world transform, one launch
         if stash:
             self._saved = (B, T, N, R, body, c0g, c0a, gw, aw)
         return l, q, gw, aw, hn_g, cn_g, hn_a, cn_a

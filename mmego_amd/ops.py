@@ -349,17 +349,19 @@ def bn_backward_pair(dY, Ymask, X1, st1, dgamma1, dbeta1, dX1, X2, st2, dgamma2,
              X2, X2.stride(0), st2.mean, st2.invstd, st2.a, dgamma2, dbeta2, dX2, dX2.stride(0))
 
 
-def transform2h_(pts, R, t):
-    """In place on pts [F, P, C] (or any contiguous view of it)."""
+def transform2h_(pts, R, t, src=None):
+    """In place on pts [F, P, C] (or any contiguous view of it); src [F, P, 3] (optional): the xyz are read from there."""
     _chk(pts)
     if not pts.is_contiguous():
         raise ValueError("transform2h_ needs a contiguous point tensor")
+    if src is not None and not (src.is_contiguous() and src.dtype == torch.float32 and src.numel() * pts.shape[-1] == 3 * pts.numel()):
+        raise ValueError("transform2h_: src must be a contiguous fp32 [.., 3] tensor with one row per point")
     F = R.numel() // 9
     C = pts.shape[-1]
     P = pts.numel() // (F * C)
     if not (R.is_contiguous() and t.is_contiguous() and t.numel() == 3 * F):
         raise ValueError("R/t must be contiguous [F,3,3]/[F,3]")
-    hip.call("transform2h", pts, F, P, C, R, t)
+    hip.call("transform2h", pts, F, P, C, R, t, src)
     return pts
 
 

@@ -83,6 +83,12 @@ class FlatParams:
         elif seed_ctr is not None:
             hip.call("inc_i64", None, 0, seed_ctr)
 
+    def tick_args(self, seed_ctr=None):
+        """(counters, n, seed_ctr) for a kernel that carries the once-per-training-forward tick itself (mmego_head_fk_forward)."""
+        if self._counters is not None:
+            return (self._counters, self._counters.numel(), seed_ctr)
+        return (None, 0, seed_ctr)
+
     def bind_grads(self):
         """Expose the flat gradient views as ``p.grad`` (for torch optimisers / inspection)."""
         for p in self.params:

@@ -537,6 +537,8 @@ def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev, later_grad_tol=2e
         opt_h.step()
         if resync:
             h.load_state_dict({k: v.to(dev) for k, v in o.state_dict().items()})
+            for k, v in o.state_dict().items():      # the next step really starts from the oracle's state
+                assert torch.equal(h.state_dict()[k].cpu(), v), ("resync did not take", tag, step, k)
             continue
         n_bad = n_all = 0
         for k in po:
