@@ -201,7 +201,7 @@ def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False, bias_grad=True,
 def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr, salt=0):
     """x [B*T, In] rows (b*T+t) -> out [B*T,128] (arena), hn, cn [2L,B,64] (fresh tensors).  With ``stash`` and p_drop > 0 the
     inter-layer dropout is applied by the layer kernel itself while it stores its outputs (mask from seed_ctr, which the net's
-    once-per-forward tick advances: FlatParams.bump_bn_counters; ``salt`` separates the LSTM stacks of one net)."""
+    once-per-forward tick advances: FlatParams.tick_args; ``salt`` separates the LSTM stacks of one net)."""
     L = lstm.num_layers
     dev = x.device
     hn = torch.empty((2 * L, B, 64), dtype=torch.float32, device=dev)

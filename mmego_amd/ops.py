@@ -276,7 +276,7 @@ def bn_stats(arena, key, X, bn, training):
         ws = scratch(X.device, 3 * C * hip.colstats_nblk(rows))
         hip.call("bn_train_stats", X, X.stride(0), rows, C, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                  float(bn.momentum), float(bn.eps), ws, st.mean, st.invstd, st.a, st.b)
-        # num_batches_tracked is bumped once per forward for the whole net (FlatParams.bump_bn_counters)
+        # num_batches_tracked is bumped once per forward for the whole net (FlatParams.tick_args)
     else:
         hip.call("bn_eval_affine", C, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
                  st.mean, st.invstd, st.a, st.b)

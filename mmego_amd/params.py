@@ -76,15 +76,10 @@ class FlatParams:
             if p.grad is not None:
                 p.grad = self._gviews[id(p)]
 
-    def bump_bn_counters(self, seed_ctr=None):
-        """The once-per-training-forward tick: BatchNorm num_batches_tracked += 1 and, with ``seed_ctr``, the next dropout seed."""
-        if self._counters is not None:
-            hip.call("inc_i64", self._counters, self._counters.numel(), seed_ctr)
-        elif seed_ctr is not None:
-            hip.call("inc_i64", None, 0, seed_ctr)
-
     def tick_args(self, seed_ctr=None):
-        """(counters, n, seed_ctr) for a kernel that carries the once-per-training-forward tick itself (mmego_head_fk_forward)."""
+        """(counters, n, seed_ctr): the once-per-training-forward tick of a net -- BatchNorm num_batches_tracked += 1 for all
+        layers and the next dropout seed -- as the arguments of the kernel that carries it (mmego_head_fk_forward; mmego_inc_i64
+        is the same tick as a launch of its own)."""
         if self._counters is not None:
             return (self._counters, self._counters.numel(), seed_ctr)
         return (None, 0, seed_ctr)
