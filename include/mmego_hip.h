@@ -275,14 +275,15 @@ int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, cons
 /* Gradient of einsum('nkctv,kvw->nctw') wrt A (GCN.py:62).  Writes per-block partial sums
  * partial_ws[mmego_graph_dA_nblk(G)][K*V*V]; reduce them with mmego_colsum (scale = A gives the edge-importance gradient).
  * A, imp, dZ (all three or none): the einsum's input gradient dZ [G, V, K*C] from the same launch (what mmego_graph_mix
- * with backward = 1 computes, same bits). */
+ * with backward = 1 computes, same bits).  ldz / lddz: row strides of Z / dZ in floats (column slices of wider buffers). */
 int mmego_graph_dA_nblk(long G);
 int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* partial_ws,
-                   const float* A, const float* imp, float* dZ);
+                   const float* A, const float* imp, float* dZ, long ldz, long lddz);
 /* Temporal 9x1 unfold / fold of a channels-last (B,T,V,C) tensor (GCN.py:109-116). */
 /* ---- ST-GCN layer pieces (gcn.hip): Net/GCN.py:55-64 (graph convolution einsum), :108-122 (9x1 temporal convolution) --------
  * mmego_graph_mix: Y[f][w][c] = sum_k sum_v (A . importance)[k][v][w] X[f][v][k*C + c]  (backward = 0; X is z [F][V][K*C]), or the
  * input gradient Y[f][v][k*C + c] = sum_w (A . importance)[k][v][w] X[f][w][c] (backward = 1; X is dy [F][V][C]).
+ * ldx: row stride of X in floats (X may be a column slice of a wider buffer; Y is dense).
  * stats (may be NULL; forward, F <= 1024): [C][F][3] BatchNorm partial records (V, mean, M2) of Y per frame and channel, for
  * mmego_bn_finalize -- the batch statistics of st_gcn.tcn[0] without a pass of their own over Y.
  * mmego_tconv: temporal convolution over rows (b, t, v) as an implicit GEMM, out[r][n] = bias[n] + sum_tap sum_k
@@ -292,7 +293,7 @@ int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V,
  * mmego_tconv_pack: W[co][ci][tap] -> [tap][co][ci] (mode 0) / [taps-1-tap][ci][co] (mode 1) / both, one behind the other (mode 2):
  * k-contiguous tile loads for mmego_tconv, strides (Cout*Cin, Cin, 1). */
 int mmego_graph_mix(void* stream, const float* X, const float* A, const float* importance, float* Y, long F, int V, int K, int C,
-                    int backward, float* stats);
+                    int backward, float* stats, long ldx);
 int mmego_tconv_pack(void* stream, const float* W, int Co, int Ci, int taps, int mode, float* Wp);
 int mmego_tconv(void* stream, const float* X, long ldx, const float* in_state, const float* W, long wts, long wns, long wks,
                 const float* bias, float* Y, long ldy, int B, int T, int V, int Cin, int Cout, int taps);

@@ -26,7 +26,7 @@
 // statistics of the BatchNorm behind the einsum (st_gcn.tcn[0]) need no pass of their own over y.
 __global__ __launch_bounds__(256) void graph_mix_kernel(const float* __restrict__ X, const float* __restrict__ A,
                                                         const float* __restrict__ imp, float* __restrict__ Y, long F, int V,
-                                                        int Kk, int C, int backward, float* __restrict__ stats) {
+                                                        int Kk, int C, int backward, float* __restrict__ stats, long ldx) {
   extern __shared__ float sm[];
   // forward : X = z [F][V][Kk*C] -> Y = y [F][V][C];   backward: X = dy [F][V][C] -> Y = dz [F][V][Kk*C]
   const int Cin = backward ? C : Kk * C, Cout = backward ? Kk * C : C;
@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void graph_mix_kernel(const float* __restrict_
   for (int i = threadIdx.x; i < Kk * V * V; i += blockDim.x) As[i] = A[i] * imp[i];
   for (long f = blockIdx.x; f < F; f += gridDim.x) {
     __syncthreads();
-    const float* xf = X + f * V * Cin;
-    for (int i = threadIdx.x; i < V * Cin; i += blockDim.x) Xs[(i / Cin) * (Cin + 1) + (i % Cin)] = xf[i];
+    const float* xf = X + f * V * ldx;                     // (ldx: row stride of X, >= Cin -- X may be a column slice)
+    for (int i = threadIdx.x; i < V * Cin; i += blockDim.x) Xs[(i / Cin) * (Cin + 1) + (i % Cin)] = xf[(long)(i / Cin) * ldx + (i % Cin)];
     __syncthreads();
     float* yf = Y + f * V * Cout;
     for (int i = threadIdx.x; i < V * Cout; i += blockDim.x) {
@@ -205,15 +205,16 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
 }
 
 extern "C" int mmego_graph_mix(void* stream, const float* X, const float* A, const float* importance, float* Y, long F, int V, int K,
-                               int C, int backward, float* stats) {
+                               int C, int backward, float* stats, long ldx) {
   MMEGO_REQUIRE(X && A && importance && Y && F > 0 && V >= 1 && V <= 32 && K >= 1 && K <= 4 && C >= 1);
+  MMEGO_REQUIRE(ldx >= (backward ? C : K * C));
   MMEGO_REQUIRE(!stats || (!backward && F <= 1024));     // (one record per frame and channel: mmego_bn_finalize takes <= 1024)
   const int Cin = backward ? C : K * C, Cout = backward ? K * C : C;
   const size_t lds = (size_t)(K * V * V + V * (Cin + 1) + (stats ? V * (Cout + 1) : 0)) * sizeof(float);
   MMEGO_REQUIRE(lds <= 64 * 1024);
   const int grid = (int)(F < 2048 ? F : 2048);
   hipLaunchKernelGGL(graph_mix_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, X, A, importance, Y, F, V, K, C, backward,
-                     stats);
+                     stats, ldx);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

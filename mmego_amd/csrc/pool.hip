@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
 __global__ __launch_bounds__(512) void graph_dA_partial_kernel(const float* __restrict__ Z, const float* __restrict__ dY, long G,
                                                                int V, int Kk, int C, float* __restrict__ partial,
                                                                const float* __restrict__ A, const float* __restrict__ imp,
-                                                               float* __restrict__ dZ) {
+                                                               float* __restrict__ dZ, long ldz, long lddz) {
   extern __shared__ float sm[];
   const int KC = Kk * C;
   float* zs = sm;                       // [V][KC + 1]
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(512) void graph_dA_partial_kernel(const float* __re
   const long g0 = (long)blockIdx.x * GDA_FPB;
   for (long g = g0; g < g0 + GDA_FPB && g < G; ++g) {
     __syncthreads();
-    for (int i = threadIdx.x; i < V * KC; i += blockDim.x) zs[(i / KC) * (KC + 1) + (i % KC)] = Z[g * V * KC + i];
+    for (int i = threadIdx.x; i < V * KC; i += blockDim.x) zs[(i / KC) * (KC + 1) + (i % KC)] = Z[(g * V + i / KC) * ldz + (i % KC)];
     for (int i = threadIdx.x; i < V * C; i += blockDim.x) ys[(i / C) * (C + 1) + (i % C)] = dY[g * V * C + i];
     __syncthreads();
     if (e < nout) {
@@ -524,13 +524,13 @@ __global__ __launch_bounds__(512) void graph_dA_partial_kernel(const float* __re
       acc += a;
     }
     if (dZ) {
-      float* zf = dZ + g * V * KC;
+      float* zf = dZ + g * V * lddz;
       for (int i = threadIdx.x; i < V * KC; i += blockDim.x) {
         const int row = i / KC, col = i - row * KC;
         const int kk = col / C, c = col - kk * C;
         float a = 0.f;
         for (int w2 = 0; w2 < V; ++w2) a += As[(kk * V + row) * V + w2] * ys[w2 * (C + 1) + c];
-        zf[i] = a;
+        zf[(long)row * lddz + col] = a;
       }
     }
   }
@@ -705,13 +705,14 @@ extern "C" int mmego_cross_attn_backward(void* stream, const float* Q, const flo
 extern "C" int mmego_graph_dA_nblk(long G) { return cdiv(G, GDA_FPB); }
 
 extern "C" int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* partial_ws,
-                              const float* A, const float* imp, float* dZ) {
+                              const float* A, const float* imp, float* dZ, long ldz, long lddz) {
   MMEGO_REQUIRE(Z && dY && partial_ws && G > 0 && V > 0 && K > 0 && C > 0 && K * V * V <= 512);
   MMEGO_REQUIRE(!dZ || (A && imp));
+  MMEGO_REQUIRE(ldz >= (long)K * C && (!dZ || lddz >= (long)K * C));
   size_t lds = (size_t)(V * (K * C + 1) + V * (C + 1) + K * V * V) * sizeof(float);
   MMEGO_REQUIRE(lds <= 64 * 1024);
   hipLaunchKernelGGL(graph_dA_partial_kernel, dim3(cdiv(G, GDA_FPB)), dim3(512), lds, (hipStream_t)stream, Z, dY, G, V, K, C,
-                     partial_ws, A, imp, dZ);
+                     partial_ws, A, imp, dZ, ldz, lddz);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

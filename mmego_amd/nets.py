@@ -320,6 +320,28 @@ class LowerNet(_NetBase):
         self.keyEncoder = KeyEncoder(hidden_dim)
         self.fusion = FusionModule(hidden_dim)
 
+    def flat_param_order(self):
+        """Flat-buffer layout (params.FlatParams): registration order, except that tensors one product treats as a single matrix
+        follow each other -- per st_gcn block the graph convolution's and the residual branch's k=1 conv weights (both read the
+        block input: one stacked [3 cout, cin] product forward, one weight-gradient and one input-gradient product backward) and
+        their biases."""
+        named = list(self.named_parameters())
+        pulled = {}
+        for i in range(len(self.keyEncoder.gcn.gcn_networks)):
+            pre = "keyEncoder.gcn.gcn_networks.%d." % i
+            pulled[pre + "gcn.conv.weight"] = pre + "residual.0.weight"
+            pulled[pre + "gcn.conv.bias"] = pre + "residual.0.bias"
+        by_name = dict(named)
+        late = set(pulled.values())
+        out = []
+        for name, prm in named:
+            if name in late:
+                continue
+            out.append(prm)
+            if name in pulled:
+                out.append(by_name[pulled[name]])
+        return out
+
     def forward(self, upper_l, x, h0_p, c0_p, h0_k, c0_k, initial_body, R, t, pin_select_idx=None):
         """``pin_select_idx`` [B*T, 64] int64 (tests only; not in the reference's signature): use these point indices instead of
         the kernel's own top-64-by-x selection.  torch.sort in the reference is unstable, so where equal x keys straddle the
@@ -419,22 +441,30 @@ class LowerNet(_NetBase):
         for i, blk in enumerate(gcn.gcn_networks):
             cin, cout, K = blk.cin, blk.cout, blk.K
             key = "gcn.b%d" % i
-            res_z = ar.get(key + ".rz", (rows, cout))
-            ops.linear(cur, blk.residual["0"].weight, blk.residual["0"].bias, res_z)
-            z = ar.get(key + ".z", (rows, K * cout))
-            ops.linear(cur, blk.gcn.conv.weight, blk.gcn.conv.bias, z)
+            # the graph convolution's and the residual branch's k=1 convs read the same input: one product with the stacked
+            # weight [K cout + cout, cin] (the two tensors are neighbours in the flat buffer: flat_param_order), outputs side by
+            # side in one buffer
+            zr = ar.get(key + ".zr", (rows, (K + 1) * cout))
+            z, res_z = zr[:, :K * cout], zr[:, K * cout:]
+            Wc = ops.stacked(blk.gcn.conv.weight.view(K * cout, cin), blk.residual["0"].weight.view(cout, cin))
+            bc = ops.stacked(blk.gcn.conv.bias, blk.residual["0"].bias)
+            if Wc is not None and bc is not None:
+                ops.linear(cur, Wc, bc, zr)
+            else:
+                ops.linear(cur, blk.residual["0"].weight, blk.residual["0"].bias, res_z)
+                ops.linear(cur, blk.gcn.conv.weight, blk.gcn.conv.bias, z)
             ymix = ar.get(key + ".ymix", (rows, cout))
             # einsum('nkctv,kvw->nctw', z, A * edge_importance): one launch, A . importance formed in LDS (gcn.hip)
             if training and F <= 1024:
                 # the einsum leaves the BatchNorm partials of its output (one record per frame and channel) beside it
                 ws = ops.scratch(z.device, 3 * cout * F)
-                hip.call("graph_mix", z, gcn.A, gcn.edge_importance[i], ymix, F, V, K, cout, 0, ws)
+                hip.call("graph_mix", z, gcn.A, gcn.edge_importance[i], ymix, F, V, K, cout, 0, ws, z.stride(0))
                 st0 = ops.BnState(ar, key + ".bn0", cout)
                 bn0 = blk.tcn["0"]
                 hip.call("bn_finalize", ws, F, cout, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, float(bn0.momentum),
                          float(bn0.eps), st0.mean, st0.invstd, st0.a, st0.b)
             else:
-                hip.call("graph_mix", z, gcn.A, gcn.edge_importance[i], ymix, F, V, K, cout, 0, None)
+                hip.call("graph_mix", z, gcn.A, gcn.edge_importance[i], ymix, F, V, K, cout, 0, None, z.stride(0))
                 st0 = ops.bn_stats(ar, key + ".bn0", ymix, blk.tcn["0"], training)
             tz = ar.get(key + ".tz", (rows, cout))
             wt = blk.tcn["2"].weight                          # [cout, cout, taps, 1]
@@ -521,9 +551,13 @@ class LowerNet(_NetBase):
             cin, cout, K = blk.cin, blk.cout, blk.K
             key = "gcn.b%d" % i
             inp = ar.get("gcn.b%d.out" % (i - 1), (rows, cin)) if i > 0 else ar.get("gcn.x0", (F, V * 3)).view(rows, 3)
-            out, tz, res_z = ar.get(key + ".out", (rows, cout)), ar.get(key + ".tz", (rows, cout)), ar.get(key + ".rz", (rows, cout))
+            out, tz = ar.get(key + ".out", (rows, cout)), ar.get(key + ".tz", (rows, cout))
+            zr = ar.get(key + ".zr", (rows, (K + 1) * cout))
+            z, res_z = zr[:, :K * cout], zr[:, K * cout:]
             st3, st_r, st0 = ops.BnState(ar, key + ".bn3", cout), ops.BnState(ar, key + ".bnr", cout), ops.BnState(ar, key + ".bn0", cout)
-            dtz, drz = ar.get(key + ".dtz", (rows, cout)), ar.get(key + ".drz", (rows, cout))
+            dtz = ar.get(key + ".dtz", (rows, cout))
+            dzr = ar.get(key + ".dzr", (rows, (K + 1) * cout))           # [dz | drz]: gradients of the stacked product's output
+            dz, drz = dzr[:, :K * cout], dzr[:, K * cout:]
             # out = relu(BN3(tz) + BNr(res_z)): both BatchNorm backwards share dcur and the mask -- one set of launches
             ops.bn_backward_pair(dcur, out, tz, st3, G(blk.tcn["3"].weight), G(blk.tcn["3"].bias), dtz,
                                  res_z, st_r, G(blk.residual["1"].weight), G(blk.residual["1"].bias), drz)
@@ -551,11 +585,9 @@ class LowerNet(_NetBase):
                 hip.call("col2im_t", dcol, B, T, V, cout, blk.taps, dy0)
             dymix = ar.get(key + ".dymix", (rows, cout))
             ops.bn_backward(dy0, y0, ymix, st0, G(blk.tcn["0"].weight), G(blk.tcn["0"].bias), dymix)
-            z = ar.get(key + ".z", (rows, K * cout))
             dAp = ar.get(key + ".dAp", (hip.lib().mmego_graph_dA_nblk(F), K * V * V))
-            dz = ar.get(key + ".dz", (rows, K * cout))
             # both gradients of the einsum from one launch: dA partials and dz_k[v] = sum_w (A.imp)[k,v,w] dy[w]
-            hip.call("graph_dA", z, dymix, F, V, K, cout, dAp, gcn.A, gcn.edge_importance[i], dz)
+            hip.call("graph_dA", z, dymix, F, V, K, cout, dAp, gcn.A, gcn.edge_importance[i], dz, z.stride(0), dz.stride(0))
             if dAp.shape[0] <= 1024 and gcn.A.is_contiguous():      # d(importance) = A . sum of the partials, one launch
                 ops.colsum(dAp, G(gcn.edge_importance[i]).view(-1), scale=gcn.A.view(-1))
             else:
@@ -563,8 +595,18 @@ class LowerNet(_NetBase):
                 ops.colsum(dAp, dA.view(-1))
                 hip.call("mul", dA, gcn.A, G(gcn.edge_importance[i]), dA.numel())
             dinp = ar.get(key + ".dinp", (rows, cin))
-            blocks.linear_backward(dz, inp, blk.gcn.conv, G, dinp)
-            blocks.linear_backward(drz, inp, blk.residual["0"], G, dinp, accumulate_dx=True, bias_grad=False)
+            Wc = ops.stacked(blk.gcn.conv.weight.view(K * cout, cin), blk.residual["0"].weight.view(cout, cin))
+            gWc = ops.stacked(G(blk.gcn.conv.weight).view(K * cout, cin), G(blk.residual["0"].weight).view(cout, cin))
+            gbc = ops.stacked(G(blk.gcn.conv.bias), G(blk.residual["0"].bias))
+            if Wc is not None and gWc is not None and gbc is not None:
+                # the stacked product's gradients: one weight-gradient product (bias sums beside it) and one input-gradient
+                # product for both convolutions.  (The residual conv's bias feeds a batch-statistics BatchNorm: its true gradient
+                # is exactly zero and what lands in its slot is rounding noise, as in the reference's autograd.)
+                ops.grad_weight(dzr, inp, gWc, db=gbc)
+                ops.grad_input(dzr, Wc, dinp)
+            else:
+                blocks.linear_backward(dz, inp, blk.gcn.conv, G, dinp)
+                blocks.linear_backward(drz, inp, blk.residual["0"], G, dinp, accumulate_dx=True, bias_grad=False)
             dcur = dinp
         up = ar.get("up", (F, V * 3))
         st = ops.BnState(ar, "gcn.dbn", V * 3)

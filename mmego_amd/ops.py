@@ -142,6 +142,15 @@ def linear_pair(x, W0, W1, b0, b1, out, ncol):
     return out
 
 
+def stacked(a, b):
+    """One [na + nb, ...] view over ``a`` and ``b`` when ``b`` sits directly behind ``a`` in memory (two tensors laid out back to
+    back in a flat parameter / gradient buffer: params.FlatParams, a module's flat_param_order), else None."""
+    if (a.dtype != b.dtype or tuple(a.shape[1:]) != tuple(b.shape[1:]) or not a.is_contiguous() or not b.is_contiguous()
+            or b.data_ptr() != a.data_ptr() + a.numel() * a.element_size()):
+        return None
+    return torch.as_strided(a.detach(), (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride())
+
+
 def linear(x, W, b, out, relu=False):
     """out[rows,N] = x[rows,K] @ W[N,K]^T + b"""
     return mm(x, W.view(W.shape[0], -1).t(), out, bias=b, relu=relu)

@@ -17,6 +17,15 @@ class FlatParams:
     def __init__(self, module):
         self.module = module
         self.params = [p for p in module.parameters()]
+        # A module may ask for a layout of its own (``flat_param_order() -> list of its parameters``): tensors that one product
+        # wants to treat as ONE matrix (the weights of two convolutions over the same input, stacked) then sit back to back in
+        # the parameter AND gradient buffers.  state_dict keys and shapes are untouched; only the flat offsets move.
+        order = getattr(module, "flat_param_order", None)
+        if callable(order):
+            wanted = list(order())
+            if sorted(id(p) for p in wanted) != sorted(id(p) for p in self.params):
+                raise ValueError("flat_param_order() must return every parameter of the module exactly once")
+            self.params = wanted
         self.device = None
         self.flat_p = self.flat_g = None
         self.offsets = []

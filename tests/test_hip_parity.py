@@ -629,7 +629,7 @@ def test_gcn_kernels_against_torch(dev):
     want = torch.einsum("fvkc,kvw->fwc", z.double().view(Fn, V, K, C), Ae)
     y = torch.empty(Fn, V, C, device=dev)
     stats = torch.empty(C, Fn, 3, device=dev)
-    hip.call("graph_mix", z.to(dev), A.to(dev), imp.to(dev), y, Fn, V, K, C, 0, stats)
+    hip.call("graph_mix", z.to(dev), A.to(dev), imp.to(dev), y, Fn, V, K, C, 0, stats, K * C)
     assert (y.cpu().double() - want).abs().max().item() < 1e-4
     # the BatchNorm partial records it leaves beside the output: (V, mean, M2) per channel and frame
     yc = y.double().cpu()
@@ -639,17 +639,17 @@ def test_gcn_kernels_against_torch(dev):
     dy = torch.randn(Fn, V, C, generator=g)
     want_dz = torch.einsum("fwc,kvw->fvkc", dy.double(), Ae).reshape(Fn, V, K * C)
     dz = torch.empty(Fn, V, K * C, device=dev)
-    hip.call("graph_mix", dy.to(dev), A.to(dev), imp.to(dev), dz, Fn, V, K, C, 1, None)
+    hip.call("graph_mix", dy.to(dev), A.to(dev), imp.to(dev), dz, Fn, V, K, C, 1, None, C)
     assert (dz.cpu().double() - want_dz).abs().max().item() < 1e-4
     # both gradients of the einsum from mmego_graph_dA: dA (per-workgroup partials, summed here) and the same dz, bit for bit
     nblk = hip.graph_dA_nblk(Fn)
     part, dz2 = torch.empty(nblk, K * V * V, device=dev), torch.empty(Fn, V, K * C, device=dev)
-    hip.call("graph_dA", z.to(dev), dy.to(dev), Fn, V, K, C, part, A.to(dev), imp.to(dev), dz2)
+    hip.call("graph_dA", z.to(dev), dy.to(dev), Fn, V, K, C, part, A.to(dev), imp.to(dev), dz2, K * C, K * C)
     assert torch.equal(dz2, dz)
     want_dA = torch.einsum("fvkc,fwc->kvw", z.double().view(Fn, V, K, C), dy.double())
     assert (part.double().sum(0).cpu().view(K, V, V) - want_dA).abs().max().item() < 1e-3
     part2 = torch.empty_like(part)
-    hip.call("graph_dA", z.to(dev), dy.to(dev), Fn, V, K, C, part2, None, None, None)
+    hip.call("graph_dA", z.to(dev), dy.to(dev), Fn, V, K, C, part2, None, None, None, K * C, 0)
     assert torch.equal(part2, part)
     for Bq, Tq, Ci, Co in ((3, 8, 32, 32), (2, 5, 20, 70), (70, 16, 128, 128)):
         taps = 9
