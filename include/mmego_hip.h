@@ -267,11 +267,12 @@ int mmego_attn_pool_backward(void* stream, const float* X, const float* w, const
 int mmego_group_sum(void* stream, const float* X, long G, int P, int C, float scale, float* Y, long ldy);
 int mmego_group_bcast(void* stream, const float* dY, long lddy, long G, int P, int C, float scale, float* dX,
                       int accumulate);
-/* softmax(Q K^T * scale) V, 64 queries x 15 keys x 64 channels per frame (Lower_Net.py:105-109). */
+/* softmax(Q K^T * scale) V, 64 queries x 15 keys x 64 channels per frame (Lower_Net.py:105-109).  ldkv: row stride of K and V
+ * (and of dK, dV) in floats -- K and V may be the column halves of one [rows, 128] buffer (to_k and to_v as one stacked product). */
 int mmego_cross_attn_forward(void* stream, const float* Q, const float* K, const float* V, long F, float scale, float* O,
-                             long ldo, float* P);
+                             long ldo, float* P, long ldkv);
 int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, const float* V, const float* P,
-                              const float* dO, long lddo, long F, float scale, float* dQ, float* dK, float* dV);
+                              const float* dO, long lddo, long F, float scale, float* dQ, float* dK, float* dV, long ldkv);
 /* Gradient of einsum('nkctv,kvw->nctw') wrt A (GCN.py:62).  Writes per-block partial sums
  * partial_ws[mmego_graph_dA_nblk(G)][K*V*V]; reduce them with mmego_colsum (scale = A gives the edge-importance gradient).
  * A, imp, dZ (all three or none): the einsum's input gradient dZ [G, V, K*C] from the same launch (what mmego_graph_mix

@@ -263,10 +263,14 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
                 ops.colsum(dg[:, d * 256:(d + 1) * 256], G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
         if l > 0 or need_dx:
             dinp = ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))
-            # (the inter-layer dropout mask is applied by the second product's epilogue)
+            # (the inter-layer dropout mask is applied by the last product's epilogue)
             mask = ar.get("%s.mk%d" % (key, l - 1), (B * T, 128)) if l > 0 and p_drop > 0.0 else None
-            ops.grad_input(dg[:, :256], lstm.w("weight_ih", l, 0), dinp)
-            ops.grad_input(dg[:, 256:], lstm.w("weight_ih", l, 1), dinp, accumulate=True, cmul=mask)
+            Wc = ops.stacked(lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1))
+            if Wc is not None:      # both directions' input weights back to back (the net's flat_param_order): one product
+                ops.grad_input(dg, Wc, dinp, cmul=mask)
+            else:
+                ops.grad_input(dg[:, :256], lstm.w("weight_ih", l, 0), dinp)
+                ops.grad_input(dg[:, 256:], lstm.w("weight_ih", l, 1), dinp, accumulate=True, cmul=mask)
             d_cur = dinp
     return d_cur if need_dx else None
 

@@ -398,12 +398,13 @@ __global__ __launch_bounds__(256) void group_bcast_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                              const float* __restrict__ V, float scale,
-                                                             float* __restrict__ O, long ldo, float* __restrict__ Pout) {
+                                                             float* __restrict__ O, long ldo, float* __restrict__ Pout,
+                                                             long ldkv) {
   __shared__ float Ks[NK][DH + 1], Vs[NK][DH + 1];
   const long f = blockIdx.x;
-  for (int i = threadIdx.x; i < NK * DH; i += 256) {
-    Ks[i / DH][i % DH] = K[f * NK * DH + i];
-    Vs[i / DH][i % DH] = V[f * NK * DH + i];
+  for (int i = threadIdx.x; i < NK * DH; i += 256) {     // (ldkv: row stride of K and V -- column halves of one [.., 2 DH] buffer)
+    Ks[i / DH][i % DH] = K[(f * NK + i / DH) * ldkv + (i % DH)];
+    Vs[i / DH][i % DH] = V[(f * NK + i / DH) * ldkv + (i % DH)];
   }
   __syncthreads();
   const int p = threadIdx.x >> 2, sub = threadIdx.x & 3;  // 4 lanes per query row, 16 channels each
@@ -439,14 +440,14 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
                                                              const float* __restrict__ V, const float* __restrict__ Pm,
                                                              const float* __restrict__ dO, long lddo, float scale,
                                                              float* __restrict__ dQ, float* __restrict__ dK,
-                                                             float* __restrict__ dV) {
+                                                             float* __restrict__ dV, long ldkv) {
   __shared__ float Ks[NK][DH + 1], Vs[NK][DH + 1];
   __shared__ float Qs[NQ][DH + 1], dOs[NQ][DH + 1];
   __shared__ float Ps[NQ][NK + 1], dSs[NQ][NK + 1];
   const long f = blockIdx.x;
-  for (int i = threadIdx.x; i < NK * DH; i += 256) {
-    Ks[i / DH][i % DH] = K[f * NK * DH + i];
-    Vs[i / DH][i % DH] = V[f * NK * DH + i];
+  for (int i = threadIdx.x; i < NK * DH; i += 256) {     // (ldkv: row stride of K, V, dK and dV)
+    Ks[i / DH][i % DH] = K[(f * NK + i / DH) * ldkv + (i % DH)];
+    Vs[i / DH][i % DH] = V[(f * NK + i / DH) * ldkv + (i % DH)];
   }
   for (int i = threadIdx.x; i < NQ * DH; i += 256) {
     Qs[i / DH][i % DH] = Q[f * NQ * DH + i];
@@ -483,8 +484,8 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
       av += Ps[pp][j] * dOs[pp][c];
       ak += dSs[pp][j] * Qs[pp][c];
     }
-    dV[f * NK * DH + i] = av;
-    dK[f * NK * DH + i] = ak;
+    dV[(f * NK + j) * ldkv + c] = av;
+    dK[(f * NK + j) * ldkv + c] = ak;
   }
 }
 
@@ -685,19 +686,19 @@ extern "C" int mmego_group_bcast(void* stream, const float* dY, long lddy, long 
 }
 
 extern "C" int mmego_cross_attn_forward(void* stream, const float* Q, const float* K, const float* V, long F, float scale,
-                                        float* O, long ldo, float* P) {
-  MMEGO_REQUIRE(Q && K && V && O && P && F > 0);
-  hipLaunchKernelGGL(cross_attn_fwd_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P);
+                                        float* O, long ldo, float* P, long ldkv) {
+  MMEGO_REQUIRE(Q && K && V && O && P && F > 0 && ldkv >= DH);
+  hipLaunchKernelGGL(cross_attn_fwd_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P, ldkv);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
 
 extern "C" int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, const float* V, const float* P,
                                          const float* dO, long lddo, long F, float scale, float* dQ, float* dK,
-                                         float* dV) {
-  MMEGO_REQUIRE(Q && K && V && P && dO && dQ && dK && dV && F > 0);
+                                         float* dV, long ldkv) {
+  MMEGO_REQUIRE(Q && K && V && P && dO && dQ && dK && dV && F > 0 && ldkv >= DH);
   hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, P, dO, lddo,
-                     scale, dQ, dK, dV);
+                     scale, dQ, dK, dV, ldkv);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -68,6 +68,33 @@ class _NetBase(nn.Module):
             self._arenas[name] = ar
         return ar
 
+    def _pulled_pairs(self):
+        """{name: name of the parameter to lay out directly behind it} -- see flat_param_order."""
+        pulled = {}
+        for mname, m in self.named_modules():
+            if isinstance(m, LstmParams) and m.hidden_size == 64 and m.num_directions == 2:
+                # BiLSTM(64) stacks: the two directions' input weights of a layer back to back, so that the layer's input
+                # gradient is ONE product dgates[rows, 512] . [W_ih ; W_ih_reverse] (blocks.lstm64_backward)
+                for l in range(m.num_layers):
+                    pulled["%s.weight_ih_l%d" % (mname, l)] = "%s.weight_ih_l%d_reverse" % (mname, l)
+        return pulled
+
+    def flat_param_order(self):
+        """Flat-buffer layout (params.FlatParams): registration order, except that tensors which one product treats as a single
+        stacked matrix follow each other (`_pulled_pairs`; ops.stacked builds the view).  state_dict keys are untouched."""
+        named = list(self.named_parameters())
+        pulled = self._pulled_pairs()
+        by_name = dict(named)
+        late = set(pulled.values())
+        out = []
+        for name, prm in named:
+            if name in late:
+                continue
+            out.append(prm)
+            if name in pulled:
+                out.append(by_name[pulled[name]])
+        return out
+
     def seed_counter(self):
         dev = next(self.parameters()).device
         if self._seed is None or self._seed.device != dev:
@@ -320,27 +347,18 @@ class LowerNet(_NetBase):
         self.keyEncoder = KeyEncoder(hidden_dim)
         self.fusion = FusionModule(hidden_dim)
 
-    def flat_param_order(self):
-        """Flat-buffer layout (params.FlatParams): registration order, except that tensors one product treats as a single matrix
-        follow each other -- per st_gcn block the graph convolution's and the residual branch's k=1 conv weights (both read the
-        block input: one stacked [3 cout, cin] product forward, one weight-gradient and one input-gradient product backward) and
-        their biases."""
-        named = list(self.named_parameters())
-        pulled = {}
+    def _pulled_pairs(self):
+        """Besides the BiLSTM pairs: per st_gcn block the graph convolution's and the residual branch's k=1 conv weights (both
+        read the block input: one stacked [3 cout, cin] product forward, one weight-gradient and one input-gradient product
+        backward) and their biases; the fusion attention's key and value projections likewise."""
+        pulled = super()._pulled_pairs()
         for i in range(len(self.keyEncoder.gcn.gcn_networks)):
             pre = "keyEncoder.gcn.gcn_networks.%d." % i
             pulled[pre + "gcn.conv.weight"] = pre + "residual.0.weight"
             pulled[pre + "gcn.conv.bias"] = pre + "residual.0.bias"
-        by_name = dict(named)
-        late = set(pulled.values())
-        out = []
-        for name, prm in named:
-            if name in late:
-                continue
-            out.append(prm)
-            if name in pulled:
-                out.append(by_name[pulled[name]])
-        return out
+        pulled["fusion.to_k.weight"] = "fusion.to_v.weight"          # key / value projections of the same skeleton features
+        pulled["fusion.to_k.bias"] = "fusion.to_v.bias"
+        return pulled
 
     def forward(self, upper_l, x, h0_p, c0_p, h0_k, c0_k, initial_body, R, t, pin_select_idx=None):
         """``pin_select_idx`` [B*T, 64] int64 (tests only; not in the reference's signature): use these point indices instead of
@@ -389,12 +407,17 @@ class LowerNet(_NetBase):
         k_vec = self._gcn_forward(ar, up, B, T, training)            # [F*15, 64] in the re-viewed layout (Q8)
 
         fu = self.fusion
-        Qm, Km, Vm = ar.get("Qm", (prow, 64)), ar.get("Km", (F * V, 64)), ar.get("Vm", (F * V, 64))
+        Qm, KVm = ar.get("Qm", (prow, 64)), ar.get("KVm", (F * V, 128))
+        Km, Vm = KVm[:, :64], KVm[:, 64:]
         ops.linear(p_vec, fu.to_q.weight, fu.to_q.bias, Qm)
-        ops.linear(k_vec, fu.to_k.weight, fu.to_k.bias, Km)
-        ops.linear(k_vec, fu.to_v.weight, fu.to_v.bias, Vm)
+        Wkv, bkv = ops.stacked(fu.to_k.weight, fu.to_v.weight), ops.stacked(fu.to_k.bias, fu.to_v.bias)
+        if Wkv is not None and bkv is not None:                 # keys and values: one stacked product (flat_param_order)
+            ops.linear(k_vec, Wkv, bkv, KVm)
+        else:
+            ops.linear(k_vec, fu.to_k.weight, fu.to_k.bias, Km)
+            ops.linear(k_vec, fu.to_v.weight, fu.to_v.bias, Vm)
         Pm = ar.get("Pm", (F, LOWER_POINTS, V))
-        hip.call("cross_attn_forward", Qm, Km, Vm, F, float(fu.scale), both[:, 64:], 128, Pm)
+        hip.call("cross_attn_forward", Qm, Km, Vm, F, float(fu.scale), both[:, 64:], 128, Pm, 128)
         ak = ar.get("ak", (F, 192))
         hip.call("group_sum", both, F, LOWER_POINTS, 128, 1.0, ak, 192)            # Q6: gate == 1 -> plain sum
         hip.call("group_sum", k_vec, F, V, 64, 1.0 / V, ak[:, 128:], 192)
@@ -524,15 +547,23 @@ class LowerNet(_NetBase):
         dk = ar.get("dk", (F * V, 64))
         hip.call("group_bcast", dak[:, 128:], 192, F, V, 64, 1.0 / V, dk, 0)
         dp = dboth[:, :64]           # (accumulated into in place: the attention's input gradient reads the other half)
-        Qm, Km, Vm = ar.get("Qm", (prow, 64)), ar.get("Km", (F * V, 64)), ar.get("Vm", (F * V, 64))
+        Qm, KVm = ar.get("Qm", (prow, 64)), ar.get("KVm", (F * V, 128))
+        Km, Vm = KVm[:, :64], KVm[:, 64:]
         Pm = ar.get("Pm", (F, LOWER_POINTS, V))
-        dQ, dK, dV = ar.get("dQ", (prow, 64)), ar.get("dK", (F * V, 64)), ar.get("dV", (F * V, 64))
-        hip.call("cross_attn_backward", Qm, Km, Vm, Pm, dboth[:, 64:], 128, F, float(fu.scale), dQ, dK, dV)
+        dQ, dKV = ar.get("dQ", (prow, 64)), ar.get("dKV", (F * V, 128))
+        dK, dV = dKV[:, :64], dKV[:, 64:]
+        hip.call("cross_attn_backward", Qm, Km, Vm, Pm, dboth[:, 64:], 128, F, float(fu.scale), dQ, dK, dV, 128)
         p_vec = ar.get("both", (prow, 128))[:, :64]
         k_vec = ar.get("gcn.kv", (B, 64, T * V)).view(F * V, 64)
         blocks.linear_backward(dQ, p_vec, fu.to_q, G, dp, accumulate_dx=True)
-        blocks.linear_backward(dK, k_vec, fu.to_k, G, dk, accumulate_dx=True)
-        blocks.linear_backward(dV, k_vec, fu.to_v, G, dk, accumulate_dx=True)
+        Wkv = ops.stacked(fu.to_k.weight, fu.to_v.weight)
+        gWkv, gbkv = ops.stacked(G(fu.to_k.weight), G(fu.to_v.weight)), ops.stacked(G(fu.to_k.bias), G(fu.to_v.bias))
+        if Wkv is not None and gWkv is not None and gbkv is not None:
+            ops.grad_weight(dKV, k_vec, gWkv, db=gbkv)          # both projections' gradients from the stacked products
+            ops.grad_input(dKV, Wkv, dk, accumulate=True)
+        else:
+            blocks.linear_backward(dK, k_vec, fu.to_k, G, dk, accumulate_dx=True)
+            blocks.linear_backward(dV, k_vec, fu.to_v, G, dk, accumulate_dx=True)
         sel = ar.get("sel", (prow, 6))
         blocks.mlp3_backward(ar, "base", self.pointEncoder.module0, sel, p_vec[:, 3:64], dp[:, 3:64], G, False)
         self._gcn_backward(ar, dk, B, T, G)
