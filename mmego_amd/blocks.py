@@ -253,9 +253,15 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
         hip.call("lstm64_backward", B, T, d_cur, d_cur.stride(0), gates[0], gates[1], cst[0], cst[1], c00, c01,
                  lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1), dg, dg[:, 256:], 512)
         # weight gradients of both directions per launch (batch dimension = direction)
-        ops.grad_weight_pair(dg, 256, inp, G(lstm.w("weight_ih", l, 0)), G(lstm.w("weight_ih", l, 1)))
-        ops.grad_weight_pair(dg, 256, hprev[0], G(lstm.w("weight_hh", l, 0)), G(lstm.w("weight_hh", l, 1)), X1=hprev[1])
-        if B * T <= 1024:       # the four bias gradients (bias_ih = bias_hh per direction) in one launch
+        # the bias gradients (row sums of the gate gradients; bias_ih and bias_hh of a direction share them) ride on the two
+        # batched weight-gradient products where the directions' bias tensors are neighbours in the flat buffer
+        bi = ops.stacked(G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_ih", l, 1)))
+        bh = ops.stacked(G(lstm.w("bias_hh", l, 0)), G(lstm.w("bias_hh", l, 1)))
+        got_i = ops.grad_weight_pair(dg, 256, inp, G(lstm.w("weight_ih", l, 0)), G(lstm.w("weight_ih", l, 1)), db=bi)
+        got_h = ops.grad_weight_pair(dg, 256, hprev[0], G(lstm.w("weight_hh", l, 0)), G(lstm.w("weight_hh", l, 1)), X1=hprev[1], db=bh)
+        if got_i and got_h:
+            pass
+        elif B * T <= 1024:     # the four bias gradients (bias_ih = bias_hh per direction) in one launch
             hip.call("colsum_pair", dg, dg.stride(0), B * T, 256, G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_hh", l, 0)),
                      G(lstm.w("bias_ih", l, 1)), G(lstm.w("bias_hh", l, 1)), 0)
         else:

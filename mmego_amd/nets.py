@@ -75,8 +75,11 @@ class _NetBase(nn.Module):
             if isinstance(m, LstmParams) and m.hidden_size == 64 and m.num_directions == 2:
                 # BiLSTM(64) stacks: the two directions' input weights of a layer back to back, so that the layer's input
                 # gradient is ONE product dgates[rows, 512] . [W_ih ; W_ih_reverse] (blocks.lstm64_backward)
+                # ... and the directions' bias_ih / bias_hh pairs, so that the bias gradients (row sums of the gate gradients) come
+                # out of the two batched weight-gradient products as their `asum` (no column-sum launch)
                 for l in range(m.num_layers):
-                    pulled["%s.weight_ih_l%d" % (mname, l)] = "%s.weight_ih_l%d_reverse" % (mname, l)
+                    for kind in ("weight_ih", "bias_ih", "bias_hh"):
+                        pulled["%s.%s_l%d" % (mname, kind, l)] = "%s.%s_l%d_reverse" % (mname, kind, l)
         return pulled
 
     def flat_param_order(self):

@@ -181,12 +181,12 @@ def chain_split(M, N, K):
 _KQ_MAX = int(_os.environ.get("MMEGO_GEMM_KQ_MAX", "512"))
 
 
-def asum_ok(M, N, K, nsplit):
+def asum_ok(M, N, K, nsplit, nbatch=1):
     """Whether mmego_gemm takes the K-quartered small-product kernel for this shape (its dispatch rule, gemm.hip), the one that
     can return the row sums of its A operand beside the product."""
     kchunk = -(-(-(-K // nsplit)) // 16) * 16
-    wgs64 = ((M + 63) // 64) * ((N + 63) // 64) * nsplit
-    tile = M % 64 == 0 and N % 64 == 0 and K % 64 == 0 and (M // 64) * (N // 64) * nsplit >= 256
+    wgs64 = ((M + 63) // 64) * ((N + 63) // 64) * nsplit * nbatch
+    tile = M % 64 == 0 and N % 64 == 0 and K % 64 == 0 and (M // 64) * (N // 64) * nsplit * nbatch >= 256
     return wgs64 <= _KQ_MAX and kchunk >= 64 and not tile and M * N < (1 << 16)
 
 
@@ -202,10 +202,11 @@ def grad_weight(dY, X, dW, db=None):
     return dW
 
 
-def grad_weight_pair(dY, ncol, X, dW0, dW1, X1=None):
+def grad_weight_pair(dY, ncol, X, dW0, dW1, X1=None, db=None):
     """dW0 = dY[:, :ncol]^T @ X and dW1 = dY[:, ncol:2 ncol]^T @ (X1 or X) as ONE batched product (the two directions' weight
     gradients of a BiLSTM layer; their slots in the flat gradient buffer are a fixed distance apart).  Falls back to two
-    products when the layout does not allow it."""
+    products when the layout does not allow it.  db [2 ncol] (optional, contiguous): the column sums of dY (both directions'
+    bias gradients) from the same launch; -> True when db was written."""
     rows, K = X.shape
     Xb = X if X1 is None else X1
     W0, W1 = dW0.view(dW0.shape[0], -1), dW1.view(dW1.shape[0], -1)
@@ -216,8 +217,11 @@ def grad_weight_pair(dY, ncol, X, dW0, dW1, X1=None):
     if not ok:
         grad_weight(dY[:, :ncol], X, dW0)
         grad_weight(dY[:, ncol:2 * ncol], Xb, dW1)
-        return
-    hip.call("gemm", dY, 1, dY.stride(0), X, X.stride(0), 1, W0, K, 1, None, ncol, K, rows, 2, ncol, xdist // 4, dist // 4, 0, 0, None, 1, 0, None, None)
+        return False
+    fused = db is not None and db.is_contiguous() and db.numel() == 2 * ncol and asum_ok(ncol, K, rows, 1, nbatch=2)
+    hip.call("gemm", dY, 1, dY.stride(0), X, X.stride(0), 1, W0, K, 1, None, ncol, K, rows, 2, ncol, xdist // 4, dist // 4, 0, 0, None, 1, 0,
+             None, db if fused else None)
+    return fused
 
 
 def grad_input(dY, W, dX, accumulate=False, cmul=None, cmask=None):
