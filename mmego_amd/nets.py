@@ -29,8 +29,9 @@ from .skeleton import JOINTS_UPPER, LOWER_POINTS, gcn_adjacency
 # implicit kernel.  MMEGO_TCONV_TRAIN_MIN_ROWS overrides the threshold (0: always implicit).
 _TCONV_TRAIN_MIN_ROWS = int(os.environ.get("MMEGO_TCONV_TRAIN_MIN_ROWS", "16384"))
 # Below that row count: blocks with at least this many channels still take the implicit kernel for the INPUT gradient of the
-# temporal convolution (MMEGO_TCONV_BWD_MIN_CHANNELS; 1 << 30: never).
-_TCONV_BWD_MIN_CHANNELS = int(os.environ.get("MMEGO_TCONV_BWD_MIN_CHANNELS", "64"))
+# temporal convolution (MMEGO_TCONV_BWD_MIN_CHANNELS; 1 << 30: never).  Traced at 7680 rows: 128 channels 54.7 us (pack + implicit)
+# against 57 us (product + fold), 64 channels 33.8 against 25.4 us.
+_TCONV_BWD_MIN_CHANNELS = int(os.environ.get("MMEGO_TCONV_BWD_MIN_CHANNELS", "128"))
 
 
 def _require_gpu(t, who):
