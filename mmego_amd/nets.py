@@ -637,7 +637,7 @@ class LowerNet(_NetBase):
                 # the stacked product's gradients: one weight-gradient product (bias sums beside it) and one input-gradient
                 # product for both convolutions.  (The residual conv's bias feeds a batch-statistics BatchNorm: its true gradient
                 # is exactly zero and what lands in its slot is rounding noise, as in the reference's autograd.)
-                ops.grad_weight(dzr, inp, gWc, db=gbc)
+                ops.grad_weight(dzr, inp, gWc, db=gbc, prefer_fused=True)
                 ops.grad_input(dzr, Wc, dinp)
             else:
                 blocks.linear_backward(dz, inp, blk.gcn.conv, G, dinp)

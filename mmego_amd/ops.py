@@ -104,7 +104,7 @@ def mm(A, B, C, bias=None, relu=False, accumulate=False, nsplit=1, cmul=None, as
     ws = None
     if nsplit > 1:
         ws = scratch(A.device, nsplit * (M * N + (M if asum is not None else 0)))
-    if asum is not None and (asum.numel() != M or not asum.is_contiguous() or not asum_ok(M, N, K, nsplit)):
+    if asum is not None and (asum.numel() != M or not asum.is_contiguous() or not asum_ok(M, N, K, nsplit, over_tile=True)):
         raise ValueError("mm: asum needs M contiguous elements and a small-product shape (ops.asum_ok)")
     if cmul is not None and (tuple(cmul.shape) != (M, N) or cmul.stride() != C.stride() or nsplit > 1):
         raise ValueError("mm: cmul needs C's shape and strides, and an unsplit product")
@@ -181,21 +181,23 @@ def chain_split(M, N, K):
 _KQ_MAX = int(_os.environ.get("MMEGO_GEMM_KQ_MAX", "512"))
 
 
-def asum_ok(M, N, K, nsplit, nbatch=1):
+def asum_ok(M, N, K, nsplit, nbatch=1, over_tile=False):
     """Whether mmego_gemm takes the K-quartered small-product kernel for this shape (its dispatch rule, gemm.hip), the one that
     can return the row sums of its A operand beside the product."""
     kchunk = -(-(-(-K // nsplit)) // 16) * 16
     wgs64 = ((M + 63) // 64) * ((N + 63) // 64) * nsplit * nbatch
     tile = M % 64 == 0 and N % 64 == 0 and K % 64 == 0 and (M // 64) * (N // 64) * nsplit * nbatch >= 256
-    return wgs64 <= _KQ_MAX and kchunk >= 64 and not tile and M * N < (1 << 16)
+    return wgs64 <= _KQ_MAX and kchunk >= 64 and (over_tile or not tile) and M * N < (1 << 16)
 
 
-def grad_weight(dY, X, dW, db=None):
+def grad_weight(dY, X, dW, db=None, prefer_fused=False):
     """dW[N,K] = dY[rows,N]^T @ X[rows,K]  (fixed-order split over rows); db[N] (optional) = column sums of dY, the bias
     gradient: from the same launch where the product runs on the small-product kernel, a column-sum launch otherwise."""
     W2 = dW.view(dW.shape[0], -1)
     nsplit = pick_split(W2.shape[0], W2.shape[1], X.shape[0])
-    fused = db is not None and db.is_contiguous() and asum_ok(W2.shape[0], W2.shape[1], X.shape[0], nsplit)
+    # (prefer_fused: take the small-product kernel with the bias sums even where the tile kernel would be picked for the product
+    # alone -- product + slab reduce instead of product + slab reduce + two column-sum launches)
+    fused = db is not None and db.is_contiguous() and asum_ok(W2.shape[0], W2.shape[1], X.shape[0], nsplit, over_tile=prefer_fused)
     mm(dY.t(), X, W2, nsplit=nsplit, asum=db if fused else None)
     if db is not None and not fused:
         colsum(dY, db)
