@@ -257,6 +257,9 @@ struct Lstm64BwdP {
 };
 
 
+// FULL as in lstm64_fwd_kernel: straight-line step loop (no row predicates, the prefetch unconditional, loads from explicit
+// global pointers), so the compiler counts its waits instead of draining the memory pipe every step.
+template <bool FULL>
 __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dgs = smem;              // [256 n][16 rows]
@@ -280,17 +283,22 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
   // next step's values are fetched while this step computes.  c_{t-1} of this step is c_t of the next one.
   float gin[4][6], gnx[4][6];        // per row: dh_in, i, f, g, o, c_prev
   float ccur[4];
+  const l64_gcptr g_gates = (l64_gcptr)p.gates[d], g_dout = (l64_gcptr)p.dout, g_cst = (l64_gcptr)p.cst[d];
+  const bool has_c0 = p.c0[d] != nullptr;
+  const l64_gcptr g_c0 = has_c0 ? (l64_gcptr)p.c0[d] : g_cst;      // (a valid address either way: the value is masked below)
 #define L64_LOAD_BWD(DST, step)                                                                                \
   do {                                                                                                         \
     const int tq_ = d == 0 ? (step) : T - 1 - (step);                                                          \
     const int tp_ = d == 0 ? tq_ - 1 : tq_ + 1;                                                                \
     _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                      \
       const int row_ = r0 + fq * 4 + reg;                                                                      \
-      if (row_ < B) {                                                                                          \
-        const float* gs_ = p.gates[d] + ((long)tq_ * B + row_) * 256 + j;                                      \
-        DST[reg][0] = p.dout[((long)row_ * T + tq_) * p.dos + d * 64 + j];                                     \
+      if (FULL || row_ < B) {                                                                                  \
+        const l64_gcptr gs_ = g_gates + ((long)tq_ * B + row_) * 256 + j;                                      \
+        DST[reg][0] = g_dout[((long)row_ * T + tq_) * p.dos + d * 64 + j];                                     \
         DST[reg][1] = gs_[0]; DST[reg][2] = gs_[64]; DST[reg][3] = gs_[128]; DST[reg][4] = gs_[192];           \
-        DST[reg][5] = ((step) > 0) ? p.cst[d][((long)tp_ * B + row_) * 64 + j] : (p.c0[d] ? p.c0[d][row_ * 64 + j] : 0.f); \
+        const l64_gcptr cp_ = ((step) > 0) ? g_cst + ((long)tp_ * B + row_) * 64 + j : g_c0 + (long)row_ * 64 + j; \
+        const float cv_ = *cp_;                                                                                \
+        DST[reg][5] = ((step) > 0 || has_c0) ? cv_ : 0.f;                                                      \
       } else {                                                                                                 \
         _Pragma("unroll") for (int q = 0; q < 6; ++q) DST[reg][q] = 0.f;                                       \
       }                                                                                                        \
@@ -302,17 +310,18 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       int row = r0 + fq * 4 + reg;
-      ccur[reg] = row < B ? p.cst[d][((long)tl * B + row) * 64 + j] : 0.f;
+      ccur[reg] = (FULL || row < B) ? g_cst[((long)tl * B + row) * 64 + j] : 0.f;
     }
   }
   for (int s = T - 1; s >= 0; --s) {
     const int tt = d == 0 ? s : T - 1 - s;
-    if (s > 0) L64_LOAD_BWD(gnx, s - 1);
+    const int sn = s > 0 ? s - 1 : 0;          // (unconditional prefetch: the last step loads step 0's values again)
+    L64_LOAD_BWD(gnx, sn);
     float dg4[4][4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       int row = r0 + fq * 4 + reg;
-      if (row < B) {
+      if (FULL || row < B) {
         float dh = gin[reg][0] + dhrec[reg];
         float gi = gin[reg][1], gf = gin[reg][2], gg = gin[reg][3], go = gin[reg][4];
         float c = ccur[reg];
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
         dg4[2][reg] = dc * gi * (1.f - gg * gg);
         dg4[3][reg] = dh * tc * go * (1.f - go);
         dcreg[reg] = dc * gf;
-        float* dst = p.dgates[d] + ((long)row * T + tt) * p.dgs + j;
+        l64_gptr dst = (l64_gptr)p.dgates[d] + ((long)row * T + tt) * p.dgs + j;
 #pragma unroll
         for (int g = 0; g < 4; ++g) dst[g * 64] = dg4[g][reg];
       } else {
@@ -337,13 +346,24 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
     }
     L64_LDS_BARRIER();
     // dh_rec[row][k] = sum_n dgates[row][n] * W_hh[n][k]; this wave owns k in [16*wave, 16*wave+16)
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    // four accumulator chains (a dependent 16x16x4 MFMA can issue every 32 cycles, an independent one every 8) and the
+    // operand reads in groups of 16 ahead of their MFMAs (fixed summation order: (a0 + a1) + (a2 + a3))
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, a3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int n4 = 0; n4 < 64; n4 += 2) {
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dgs[(n4 * 4 + fq) * 16 + fr], wreg[n4], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dgs[(n4 * 4 + 4 + fq) * 16 + fr], wreg[n4 + 1], a1, 0, 0, 0);
+    for (int nb = 0; nb < 64; nb += 16) {
+      float dk[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) dk[u] = dgs[((nb + u) * 4 + fq) * 16 + fr];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dk[u], wreg[nb + u], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dk[u + 1], wreg[nb + u + 1], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(dk[u + 2], wreg[nb + u + 2], a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(dk[u + 3], wreg[nb + u + 3], a3, 0, 0, 0);
+      }
     }
-    dhrec = a0 + a1;
+    dhrec = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
@@ -367,7 +387,8 @@ extern "C" int mmego_lstm64_backward(void* stream, int B, int T, const float* do
   p.dgates[0] = dgates0; p.dgates[1] = dgates1; p.dgs = dgs;
   p.B = B; p.T = T;
   const size_t lds = (size_t)(256 * 16) * sizeof(float);
-  hipLaunchKernelGGL(lstm64_bwd_kernel, dim3(cdiv(B, 16), 2), dim3(256), lds, (hipStream_t)stream, p);
+  if (B % 16 == 0) hipLaunchKernelGGL(lstm64_bwd_kernel<true>, dim3(cdiv(B, 16), 2), dim3(256), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(lstm64_bwd_kernel<false>, dim3(cdiv(B, 16), 2), dim3(256), lds, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
