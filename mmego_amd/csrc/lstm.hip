@@ -178,6 +178,8 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
       oq[reg] += ostep;
       if (stash) { gq[reg] += gstep; cq[reg] += cstep; }
     }
+    // (the copy stays HERE: hoisted into the MFMA block by the scheduler, it made every step wait for the loads it had just issued)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -364,6 +366,7 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
       }
     }
     dhrec = (a0 + a1) + (a2 + a3);
+    __builtin_amdgcn_sched_barrier(0);       // (keep the copy of the prefetched values at the end of the step: see the forward kernel)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
