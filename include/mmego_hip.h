@@ -126,8 +126,9 @@ int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first, const floa
                     float* c1, float* gst0, float* gst1, float* cst0, float* cst1);
 /* Whole-sequence H=64 bidirectional LSTM layer (Upper_Net.py:333, Lower_Net.py:91, Upper_Net.py:210).
  * xproj_d rows are (b*T+t) with row stride xs; out rows (b*T+t) with row stride os, direction d in
- * columns [64d, 64d+64).  Optional stashes for backward: gates_d [T][B][256], cst_d [T][B][64],
- * hprev_d [(b*T+t)][64].
+ * columns [64d, 64d+64).  Optional stashes for backward (all or none): gates_d [T][B][64][4] (the four gate activations
+ * i, f, g, o of a hidden unit side by side: a private format between this call and mmego_lstm64_backward, 16-byte aligned),
+ * cst_d [T][B][64], hprev_d [(b*T+t)][64].
  * drop_y / drop_mask (both or neither; out's layout): nn.LSTM(dropout=drop_p)'s inverted inter-layer dropout applied while the
  * outputs are stored -- drop_mask = 0 or 1/(1-p) per element from a counter-based hash of (element index, seed_ctr[0], salt),
  * drop_y = out * drop_mask.  seed_ctr is only read; mmego_inc_i64 advances it once per training forward, salt tells the

@@ -46,6 +46,9 @@ __device__ __forceinline__ float l64_tanh(float x) { return 1.0f - 2.0f * __buil
 // loads and stores in flight.  Explicit global address space keeps them global_load / global_store (vmcnt only).
 typedef const float __attribute__((address_space(1)))* l64_gcptr;
 typedef float __attribute__((address_space(1)))* l64_gptr;
+typedef float l64_f4 __attribute__((ext_vector_type(4)));
+typedef l64_f4 __attribute__((address_space(1)))* l64_gptr4;
+typedef const l64_f4 __attribute__((address_space(1)))* l64_gcptr4;
 
 // FULL: B is a multiple of the 16 rows of a workgroup, so every `live` test is a compile-time true; STASH / DROP: the backward
 // stashes (gates, cell states, h_{t-1}: all or none) / the fused inter-layer dropout.  Template parameters so that the step loop is
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
     oq[reg] = (l64_gptr)(p.out + rt * p.os + d * 64 + j);
     hq[reg] = keep_h ? (l64_gptr)(p.hprev[d] + rt * 64 + j) : (l64_gptr)nullptr;
     const long tr = (long)t_first * B + (live[reg] ? row : 0);
-    gq[reg] = stash ? (l64_gptr)(p.gates[d] + tr * 256 + j) : (l64_gptr)nullptr;
+    gq[reg] = stash ? (l64_gptr)(p.gates[d] + tr * 256 + 4 * j) : (l64_gptr)nullptr;   // gate stash: [t][b][unit][i,f,g,o]
     cq[reg] = stash ? (l64_gptr)(p.cst[d] + tr * 64 + j) : (l64_gptr)nullptr;
   }
   const long xstep = dir * p.xs, ostep = dir * p.os, hstep = dir * 64, gstep = dir * (long)B * 256,
@@ -170,8 +173,7 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
           p.drop_y[off] = hn * mk;
         }
         if (stash) {
-          l64_gptr gs = gq[reg];
-          gs[0] = gi; gs[64] = gf; gs[128] = gg; gs[192] = go;
+          *(l64_gptr4)gq[reg] = (l64_f4){gi, gf, gg, go};       // one 16-B store (was four dword stores 256 B apart)
           *cq[reg] = cn;
         }
       }
@@ -295,9 +297,9 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
     _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                                                      \
       const int row_ = r0 + fq * 4 + reg;                                                                      \
       if (FULL || row_ < B) {                                                                                  \
-        const l64_gcptr gs_ = g_gates + ((long)tq_ * B + row_) * 256 + j;                                      \
+        const l64_f4 gv_ = *(l64_gcptr4)(g_gates + ((long)tq_ * B + row_) * 256 + 4 * j);                      \
         DST[reg][0] = g_dout[((long)row_ * T + tq_) * p.dos + d * 64 + j];                                     \
-        DST[reg][1] = gs_[0]; DST[reg][2] = gs_[64]; DST[reg][3] = gs_[128]; DST[reg][4] = gs_[192];           \
+        DST[reg][1] = gv_.x; DST[reg][2] = gv_.y; DST[reg][3] = gv_.z; DST[reg][4] = gv_.w;                    \
         const l64_gcptr cp_ = ((step) > 0) ? g_cst + ((long)tp_ * B + row_) * 64 + j : g_c0 + (long)row_ * 64 + j; \
         const float cv_ = *cp_;                                                                                \
         DST[reg][5] = ((step) > 0 || has_c0) ? cv_ : 0.f;                                                      \
