@@ -243,7 +243,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ---- small-batch variant: WG = 64 rows x (4 hidden x 4 gates), K split over nothing, 4 waves = 4 row tiles ----------
-template <int SK>  // k per staged chunk (64, or 32 when H is not a multiple of 64)
+// FULL: Bn is a multiple of the 64 rows of a workgroup -- no row predicates, so the prologue's loads (4 input projections, 4 cell
+// states per lane) and every chunk's operand loads are straight-line code.  Predicated row by row they were a chain of
+// "branch, load, wait for everything" blocks: four dependent memory round trips before the product even started.
+template <int SK, bool FULL>  // SK: k per staged chunk (64, or 32 when H is not a multiple of 64)
 __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
   __shared__ __attribute__((aligned(16))) float As[2][64][SK + 4];
   __shared__ __attribute__((aligned(16))) float Bs[2][16][SK + 4];
@@ -264,9 +267,10 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int row = rowt + fq * 4 + reg;
-    const bool ok = row < p.Bn;
+    const bool ok = FULL || row < p.Bn;
     xpv[reg] = ok ? p.xproj[d][(long)row * p.xs + gate * H + j] + bh : 0.f;
-    cprev[reg] = (ok && !p.first && gate == 0) ? p.c[d][(long)row * H + j] : 0.f;
+    // (every lane loads it -- only the gate-0 lanes use it: a lane-divergent predicate would put a branch around the load)
+    cprev[reg] = (ok && !p.first) ? p.c[d][(long)row * H + j] : 0.f;
   }
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   if (!p.first) {
@@ -279,7 +283,8 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
     const float* wp = W + ((long)((lr & 15) >> 2) * H + j0 + (lr & 3)) * H + lk;   // (lr & 15) = gate*4 + jl
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = H / SK;
-    const bool ok0 = (r0 + lr) < p.Bn, ok1 = (r0 + lr + RPP) < p.Bn, ok2 = (r0 + lr + 2 * RPP) < p.Bn, ok3 = (r0 + lr + 3 * RPP) < p.Bn;
+    const bool ok0 = FULL || (r0 + lr) < p.Bn, ok1 = FULL || (r0 + lr + RPP) < p.Bn, ok2 = FULL || (r0 + lr + 2 * RPP) < p.Bn,
+               ok3 = FULL || (r0 + lr + 3 * RPP) < p.Bn;
     const float* ap = hp + (long)(r0 + lr) * p.hps + lk;
     const long rs16 = RPP * p.hps;
     f32x4 ra0, ra1, ra2 = zero4, ra3 = zero4, rbv = zero4;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
       ra2 = ok2 ? *reinterpret_cast<const f32x4*>(ap + 2 * rs16 + (k0)) : zero4; \
       ra3 = ok3 ? *reinterpret_cast<const f32x4*>(ap + 3 * rs16 + (k0)) : zero4; \
     }                                                                         \
-    if (lr < 16) rbv = *reinterpret_cast<const f32x4*>(wp + (k0));           \
+    if (RPP == 16 || lr < 16) rbv = *reinterpret_cast<const f32x4*>(wp + (k0)); \
   } while (0)
 #define SM_SSTORE(buf)                                                        \
   do {                                                                        \
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
       *reinterpret_cast<f32x4*>(&As[buf][lr + 32][lk]) = ra2;                \
       *reinterpret_cast<f32x4*>(&As[buf][lr + 48][lk]) = ra3;                \
     }                                                                         \
-    if (lr < 16) *reinterpret_cast<f32x4*>(&Bs[buf][lr][lk]) = rbv;          \
+    if (RPP == 16 || lr < 16) *reinterpret_cast<f32x4*>(&Bs[buf][lr][lk]) = rbv; \
   } while (0)
     SM_GLOAD(0);
     SM_SSTORE(0);
@@ -408,8 +413,11 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
     }
   } else {
     int grid = ndir * (H / 4) * cdiv(Bn, 64);
-    if ((H % 64) == 0) hipLaunchKernelGGL(lstm_step_small_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(lstm_step_small_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    const bool full = (Bn % 64) == 0;
+    if ((H % 64) == 0 && full) hipLaunchKernelGGL((lstm_step_small_kernel<64, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if ((H % 64) == 0) hipLaunchKernelGGL((lstm_step_small_kernel<64, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (full) hipLaunchKernelGGL((lstm_step_small_kernel<32, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((lstm_step_small_kernel<32, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   }
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
