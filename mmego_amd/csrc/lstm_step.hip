@@ -246,10 +246,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // FULL: Bn is a multiple of the 64 rows of a workgroup -- no row predicates, so the prologue's loads (4 input projections, 4 cell
 // states per lane) and every chunk's operand loads are straight-line code.  Predicated row by row they were a chain of
 // "branch, load, wait for everything" blocks: four dependent memory round trips before the product even started.
-template <int SK, bool FULL>  // SK: k per staged chunk (64, or 32 when H is not a multiple of 64)
+template <int SK, bool FULL>  // SK: k per staged chunk (128 / 64, or 32 when H is not a multiple of 64)
 __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
-  __shared__ __attribute__((aligned(16))) float As[2][64][SK + 4];
-  __shared__ __attribute__((aligned(16))) float Bs[2][16][SK + 4];
+  // two stages of A [64 rows][SK + 4] and B [16 gate columns][SK + 4] (dynamic LDS: 84.5 KB at SK = 128)
+  extern __shared__ __attribute__((aligned(16))) float sm_small[];
+  constexpr int LDK = SK + 4;
+  float* const As = sm_small;                       // [2][64][LDK]
+  float* const Bs = sm_small + 2 * 64 * LDK;        // [2][16][LDK]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H;
   const int nrb = (p.Bn + 63) / 64, nht = H / 4;
@@ -276,37 +279,34 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
   if (!p.first) {
     const float* hp = p.hprev[d];
     const float* W = p.whh[d];
-    // staging per chunk of 64 k: A 64 rows x 16 f32x4 = 1024 f32x4 (4 per thread), B 16 rows x 16 f32x4 = 256 (1 per thread)
-    constexpr int LPR = SK / 4;                     // lanes per row segment
-    constexpr int RPP = 256 / LPR;                  // rows staged per pass (16 or 32)
+    // staging per chunk of SK k: a thread moves f32x4 pieces; LPR lanes cover a row's SK floats, RPP rows per pass of the
+    // 256 threads, NA passes for the 64 rows of A, NB passes (or a quarter of the threads) for the 16 rows of B
+    constexpr int LPR = SK / 4, RPP = 256 / LPR, NA = 64 / RPP, NB = RPP >= 16 ? 1 : 16 / RPP;
     const int lk = (tid % LPR) * 4, lr = tid / LPR;
-    const float* wp = W + ((long)((lr & 15) >> 2) * H + j0 + (lr & 3)) * H + lk;   // (lr & 15) = gate*4 + jl
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = H / SK;
-    const bool ok0 = FULL || (r0 + lr) < p.Bn, ok1 = FULL || (r0 + lr + RPP) < p.Bn, ok2 = FULL || (r0 + lr + 2 * RPP) < p.Bn,
-               ok3 = FULL || (r0 + lr + 3 * RPP) < p.Bn;
     const float* ap = hp + (long)(r0 + lr) * p.hps + lk;
-    const long rs16 = RPP * p.hps;
-    f32x4 ra0, ra1, ra2 = zero4, ra3 = zero4, rbv = zero4;
-#define SM_GLOAD(k0)                                                          \
-  do {                                                                        \
-    ra0 = ok0 ? *reinterpret_cast<const f32x4*>(ap + (k0)) : zero4;            \
-    ra1 = ok1 ? *reinterpret_cast<const f32x4*>(ap + rs16 + (k0)) : zero4;     \
-    if (RPP == 16) {                                                          \
-      ra2 = ok2 ? *reinterpret_cast<const f32x4*>(ap + 2 * rs16 + (k0)) : zero4; \
-      ra3 = ok3 ? *reinterpret_cast<const f32x4*>(ap + 3 * rs16 + (k0)) : zero4; \
-    }                                                                         \
-    if (RPP == 16 || lr < 16) rbv = *reinterpret_cast<const f32x4*>(wp + (k0)); \
+    const long rsp = (long)RPP * p.hps;
+    const float* wp[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int rowb = (lr + b * RPP) & 15;         // = gate*4 + jl of the staged W row
+      wp[b] = W + ((long)(rowb >> 2) * H + j0 + (rowb & 3)) * H + lk;
+    }
+    f32x4 ra[NA], rbv[NB];
+#define SM_GLOAD(k0)                                                                                          \
+  do {                                                                                                        \
+    _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                            \
+      ra[a] = (FULL || (r0 + lr + a * RPP) < p.Bn) ? *reinterpret_cast<const f32x4*>(ap + a * rsp + (k0)) : zero4; \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                            \
+      if (RPP <= 16 || lr < 16) rbv[b] = *reinterpret_cast<const f32x4*>(wp[b] + (k0));                      \
   } while (0)
-#define SM_SSTORE(buf)                                                        \
-  do {                                                                        \
-    *reinterpret_cast<f32x4*>(&As[buf][lr][lk]) = ra0;                       \
-    *reinterpret_cast<f32x4*>(&As[buf][lr + RPP][lk]) = ra1;                 \
-    if (RPP == 16) {                                                          \
-      *reinterpret_cast<f32x4*>(&As[buf][lr + 32][lk]) = ra2;                \
-      *reinterpret_cast<f32x4*>(&As[buf][lr + 48][lk]) = ra3;                \
-    }                                                                         \
-    if (RPP == 16 || lr < 16) *reinterpret_cast<f32x4*>(&Bs[buf][lr][lk]) = rbv; \
+#define SM_SSTORE(buf)                                                                                        \
+  do {                                                                                                        \
+    _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                            \
+      *reinterpret_cast<f32x4*>(&As[((buf) * 64 + lr + a * RPP) * LDK + lk]) = ra[a];                        \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                            \
+      if (RPP <= 16 || lr < 16) *reinterpret_cast<f32x4*>(&Bs[((buf) * 16 + lr + b * RPP) * LDK + lk]) = rbv[b]; \
   } while (0)
     SM_GLOAD(0);
     SM_SSTORE(0);
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
       if (kt + 1 < nk) SM_GLOAD((kt + 1) * SK);
 #pragma unroll
       for (int kb = 0; kb < SK / 16; ++kb) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(&As[buf][wave * 16 + fr][kb * 16 + 4 * fq]);
-        f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[buf][fr][kb * 16 + 4 * fq]);
+        f32x4 a = *reinterpret_cast<const f32x4*>(&As[(buf * 64 + wave * 16 + fr) * LDK + kb * 16 + 4 * fq]);
+        f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[(buf * 16 + fr) * LDK + kb * 16 + 4 * fq]);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
@@ -326,6 +326,8 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
       if (kt + 1 < nk) SM_SSTORE(buf ^ 1);
       __syncthreads();
     }
+#undef SM_GLOAD
+#undef SM_SSTORE
   }
   // lane holds gate `gate` of hidden j for rows fq*4+reg; fetch f,g,o from lanes fr+4, fr+8, fr+12 of the same group
 #pragma unroll
@@ -414,10 +416,24 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
   } else {
     int grid = ndir * (H / 4) * cdiv(Bn, 64);
     const bool full = (Bn % 64) == 0;
-    if ((H % 64) == 0 && full) hipLaunchKernelGGL((lstm_step_small_kernel<64, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else if ((H % 64) == 0) hipLaunchKernelGGL((lstm_step_small_kernel<64, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else if (full) hipLaunchKernelGGL((lstm_step_small_kernel<32, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((lstm_step_small_kernel<32, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    // (128-k chunks -- half as many dependent chunk round trips, 84.5 KB of LDS -- measured the same 9.9-10.0 us: kept for A/B runs)
+    static const int small_sk = getenv("MMEGO_STEP_SMALL_SK") ? atoi(getenv("MMEGO_STEP_SMALL_SK")) : 64;
+#define SMALL_LAUNCH(SK_, F_)                                                                                        \
+  do {                                                                                                               \
+    const size_t lds = (size_t)2 * (64 + 16) * (SK_ + 4) * sizeof(float);                                            \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      hipError_t e = hipFuncSetAttribute((const void*)lstm_step_small_kernel<SK_, F_>,                               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+      if (e != hipSuccess) return (int)e;                                                                            \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL((lstm_step_small_kernel<SK_, F_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);       \
+  } while (0)
+    if ((H % 128) == 0 && small_sk == 128) { if (full) SMALL_LAUNCH(128, true); else SMALL_LAUNCH(128, false); }
+    else if ((H % 64) == 0) { if (full) SMALL_LAUNCH(64, true); else SMALL_LAUNCH(64, false); }
+    else { if (full) SMALL_LAUNCH(32, true); else SMALL_LAUNCH(32, false); }
+#undef SMALL_LAUNCH
   }
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
