@@ -89,9 +89,13 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
     const int k = lane + 64 * u;
     const bool ok = k < nblk;
     const float* p = partial + (long)(ok ? k : 0) * 3;
-    pn[u] = ok ? p[0] : 0.f;
-    pm[u] = ok ? p[1] : 0.f;
-    p2[u] = ok ? p[2] : 0.f;
+    // (load first, select afterwards: the address is clamped, so the load is always legal -- written as `ok ? p[0] : 0` the
+    // compiler must not speculate it and puts a branch and an s_waitcnt vmcnt(0) around every single load: 48 dependent round
+    // trips instead of one)
+    const float v0 = p[0], v1 = p[1], v2 = p[2];
+    pn[u] = ok ? v0 : 0.f;
+    pm[u] = ok ? v1 : 0.f;
+    p2[u] = ok ? v2 : 0.f;
   }
   double N = 0.0, S = 0.0;
 #pragma unroll
@@ -231,8 +235,9 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
     const int k = lane + 64 * u;
     const bool ok = k < nblk;
     const float* p = partial + ((long)c * nblk + (ok ? k : 0)) * 2;
-    q1[u] = ok ? p[0] : 0.f;
-    q2[u] = ok ? p[1] : 0.f;
+    const float v0 = p[0], v1 = p[1];      // (load, then select: see bn_finalize_kernel)
+    q1[u] = ok ? v0 : 0.f;
+    q2[u] = ok ? v1 : 0.f;
   }
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -336,7 +341,8 @@ __global__ __launch_bounds__(64) void colsum_final_kernel(const float* __restric
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int k = lane + 64 * u;
-    q[u] = k < nblk ? partial[(long)c * nblk + k] : 0.f;
+    const float v = partial[(long)c * nblk + (k < nblk ? k : 0)];      // (clamped address: load, then select)
+    q[u] = k < nblk ? v : 0.f;
   }
   double s = 0.0;
 #pragma unroll

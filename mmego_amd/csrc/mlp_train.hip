@@ -66,8 +66,11 @@ __device__ __forceinline__ void mt_gather_partials(const double* __restrict__ pa
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int b = b0 + u * NQ;
-        v1[u] = b < nblk ? part[((long)b * 2 + 0) * 64 + c] : 0.0;
-        v2[u] = b < nblk ? part[((long)b * 2 + 1) * 64 + c] : 0.0;
+        // (clamped index, load, then select: a predicate around the load itself costs a branch and a full wait per load)
+        const int bc = b < nblk ? b : nblk - 1;
+        const double w1 = part[((long)bc * 2 + 0) * 64 + c], w2 = part[((long)bc * 2 + 1) * 64 + c];
+        v1[u] = b < nblk ? w1 : 0.0;
+        v2[u] = b < nblk ? w2 : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) { s1 += v1[u]; s2 += v2[u]; }
@@ -154,11 +157,21 @@ __global__ __launch_bounds__(1024) void mlp_fwd_layer_kernel(MlpFwdP p) {
   const int xk = t & 63, xr = t >> 6;
   float* const Xg = Xs[grp];
   float xv[16];
+// (clamped addresses, all 16 loads issued, THEN the selects: written as `ok ? X[..] : 0` -- or even as load + select, which the
+// compiler turns back into a branch around the load -- every load got its own s_cbranch_execz and s_waitcnt vmcnt(0), 16
+// dependent round trips per tile; MT_PIN keeps the loaded value live outside the select so the load stays unconditional)
+#define MT_PIN(v) asm volatile("" : "+v"(v))
 #define MTF_FETCH(r0_)                                                                              \
   _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
     const long rr_ = (r0_) + xr + 4 * j;                                                            \
-    xv[j] = (rr_ < rend && xk < p.Cin) ? p.X[rr_ * p.ldx + xk] : 0.f;                               \
+    xv[j] = p.X[(rr_ < rend ? rr_ : rend - 1) * p.ldx + xkc];                                       \
+  }                                                                                                 \
+  _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
+    const long rr_ = (r0_) + xr + 4 * j;                                                            \
+    MT_PIN(xv[j]);                                                                                  \
+    xv[j] = (rr_ < rend && xk < p.Cin) ? xv[j] : 0.f;                                               \
   }
+  const int xkc = xk < p.Cin ? xk : p.Cin - 1;
   if (rbeg < rend) { MTF_FETCH(rbeg + 64 * grp) }          // the first tile's loads fly while the statistics are finalized
   if (act) mt_finalize_stats<16>(p.in_part, p.in_nblk, p.Cin, p.rows, p.in_gamma, p.in_beta, p.in_eps, p.in_rmean, p.in_rvar,
                                  p.in_momentum, p.in_state, sm, red);
@@ -214,9 +227,10 @@ __global__ __launch_bounds__(1024) void mlp_bn_act_kernel(MlpActP p) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const long ii = i + u * stride;
-      rr[u] = ii / p.C;
-      cc_[u] = (int)(ii - rr[u] * p.C);
-      zv[u] = ii < total ? p.Z[rr[u] * p.ldz + cc_[u]] : 0.f;
+      const long iic = ii < total ? ii : total - 1;
+      rr[u] = iic / p.C;
+      cc_[u] = (int)(iic - rr[u] * p.C);
+      zv[u] = p.Z[rr[u] * p.ldz + cc_[u]];                 // (clamped index: unconditional load; the store below is predicated)
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -241,8 +255,10 @@ __global__ __launch_bounds__(1024) void mlp_bn_bwd_reduce_kernel(MlpRedP p) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const long rr = r + 16 * u;
-        zz[u] = rr < rend ? p.Z[rr * p.ldz + c] : 0.f;
-        gg[u] = rr < rend ? p.dY[rr * p.lddy + c] : 0.f;
+        const long rc = rr < rend ? rr : rend - 1;         // (clamped: unconditional loads, then select)
+        const float zl = p.Z[rc * p.ldz + c], gl = p.dY[rc * p.lddy + c];
+        zz[u] = rr < rend ? zl : 0.f;
+        gg[u] = rr < rend ? gl : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -302,11 +318,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
 #define MTB_FETCH(r0_)                                                                              \
   _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
     const long rr_ = (r0_) + xr + 4 * j;                                                            \
+    const long rc_ = rr_ < rend ? rr_ : rend - 1;      /* clamped row / columns: unconditional loads (see MTF_FETCH) */ \
+    gy[j] = p.dY[rc_ * p.lddy + xko]; gz[j] = p.Z[rc_ * p.ldz + xko]; gx[j] = p.Xin[rc_ * p.ldxin + xki]; \
+  }                                                                                                 \
+  _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
+    const long rr_ = (r0_) + xr + 4 * j;                                                            \
     const bool oko_ = rr_ < rend && xk < p.Cout;                                                    \
-    gy[j] = oko_ ? p.dY[rr_ * p.lddy + xk] : 0.f;                                                   \
-    gz[j] = oko_ ? p.Z[rr_ * p.ldz + xk] : 0.f;                                                     \
-    gx[j] = (rr_ < rend && xk < p.Cin) ? p.Xin[rr_ * p.ldxin + xk] : 0.f;                           \
+    MT_PIN(gy[j]); MT_PIN(gz[j]); MT_PIN(gx[j]);                                                    \
+    gy[j] = oko_ ? gy[j] : 0.f;                                                                     \
+    gz[j] = oko_ ? gz[j] : 0.f;                                                                     \
+    gx[j] = (rr_ < rend && xk < p.Cin) ? gx[j] : 0.f;                                               \
   }
+  const int xko = xk < p.Cout ? xk : p.Cout - 1, xki = xk < p.Cin ? xk : p.Cin - 1;
   if (rbeg < rend) { MTB_FETCH(rbeg + 64 * grp) }          // the first tile's loads fly while the partial sums are gathered
   {  // finalize this layer's (sum g, sum g xhat): c1, c2; d(gamma), d(beta) by workgroup 0
     mt_gather_partials<8>(p.g_part, p.g_nblk, p.Cout, red);
@@ -410,7 +433,8 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(MlpDwP p) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int b = s_ + 16 * u;
-        v[u] = b < nblk ? src[(long)b * 64 * 64] : 0.f;
+        const float vl = src[(long)(b < nblk ? b : nblk - 1) * 64 * 64];      // (clamped: load, then select)
+        v[u] = b < nblk ? vl : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u) s += (double)v[u];

@@ -57,6 +57,27 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const float* __restr
   }
 }
 
+// Copy a tile of n4 f32x4 pieces from global memory to LDS with 256 threads: ALL of the tile's loads in flight before the first
+// LDS store, and no branch in between.  NQ (pieces per thread) is a compile-time bound and the index is clamped, not predicated:
+// written as `if (i < n4) v[q] = src[i]` every load got its own branch and its own s_waitcnt vmcnt(0) -- NQ dependent round
+// trips instead of one (the clamped lanes re-read and re-write the tile's last piece: same value, harmless).
+template <int NQ>
+__device__ __forceinline__ void tile_to_lds(const float* __restrict__ src, float* dst, int n4, int tid) {
+  f32x4 v[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) v[q] = reinterpret_cast<const f32x4*>(src)[min(tid + 256 * q, n4 - 1)];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) reinterpret_cast<f32x4*>(dst)[min(tid + 256 * q, n4 - 1)] = v[q];
+}
+__device__ __forceinline__ void tile_to_lds_any(const float* __restrict__ src, float* dst, int n4, int tid) {
+  const int nq = (n4 + 255) / 256;                 // (uniform)
+  if (nq <= 2) tile_to_lds<2>(src, dst, n4, tid);
+  else if (nq <= 4) tile_to_lds<4>(src, dst, n4, tid);
+  else if (nq <= 8) tile_to_lds<8>(src, dst, n4, tid);
+  else if (nq <= 16) tile_to_lds<16>(src, dst, n4, tid);
+  else tile_to_lds<24>(src, dst, n4, tid);
+}
+
 // Same, with the group's [P, C] tile staged once in LDS (16-B loads, every byte read from HBM exactly once): used when the tile
 // fits (P * C * 4 <= 96 KB; IMU_Net's pooling: 20 x 1024 = 80 KB, the PointNets': 128 x 64 = 32 KB).  C % 4 == 0.
 __global__ __launch_bounds__(256) void attn_pool_fwd_lds_kernel(const float* __restrict__ X, const float* __restrict__ w,
@@ -71,17 +92,7 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_lds_kernel(const float* __r
   const float* Xg = X + g * (long)P * C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int n4 = P * C / 4;
-  {
-    // all of the tile's loads in flight at once (a rolled copy loop waits for every load before its LDS store: 16 latencies
-    // for a 64-KB tile), then the stores
-    f32x4 v[24];
-#pragma unroll
-    for (int q = 0; q < 24; ++q)
-      if (tid + 256 * q < n4) v[q] = reinterpret_cast<const f32x4*>(Xg)[tid + 256 * q];
-#pragma unroll
-    for (int q = 0; q < 24; ++q)
-      if (tid + 256 * q < n4) reinterpret_cast<f32x4*>(Xs)[tid + 256 * q] = v[q];
-  }
+  tile_to_lds_any(Xg, Xs, n4, tid);        // all of the tile's loads in flight at once, then the LDS stores
   const float b = bptr ? bptr[0] : 0.f;
   __syncthreads();
   // scores: TPP threads per point, each over a contiguous slice of the channels, started at a point-dependent offset so that
@@ -271,15 +282,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_lds_kernel(const float* __r
   const float* dv = dvec + g * C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int n4 = P * C / 4;
-  {
-    f32x4 v[16];                          // tile <= 64 KB: all of its loads in flight at once, then the LDS stores
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-      if (tid + 256 * q < n4) v[q] = reinterpret_cast<const f32x4*>(Xg)[tid + 256 * q];
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-      if (tid + 256 * q < n4) reinterpret_cast<f32x4*>(Xs)[tid + 256 * q] = v[q];
-  }
+  tile_to_lds_any(Xg, Xs, n4, tid);        // tile <= 64 KB: all of its loads in flight at once, then the LDS stores
   for (int p = tid; p < P; p += blockDim.x) ags[p] = attn[g * P + p];
   __syncthreads();
   // da[p] = X[p, :] . dvec: TPP threads per row, each over a contiguous channel slice entered at a row-dependent offset
