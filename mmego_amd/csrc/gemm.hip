@@ -163,33 +163,35 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
   const int kq = (((kend0 - kbeg0) + 3) / 4 + 31) / 32 * 32;      // k per wave, a multiple of the 32-k chunk
   const int kbeg = kbeg0 + wave * kq;
   const int kend = min(kend0, kbeg + kq);
-  const bool am_ok = (m0 + r) < p.M, bn_ok = (n0 + r) < p.N;
-  const float* Arow = A + (long)(m0 + r) * p.sam;
-  const float* Bcol = B + (long)(n0 + r) * p.sbn;
+  // Rows / columns past M / N are CLAMPED, not predicated: their products land in output elements that are never stored, and a
+  // predicate on the load itself costs a branch and a full s_waitcnt vmcnt(0) per load (the compiler will not speculate it).
+  // Only k has to be masked, and only in a wave's last partial chunk: the vector path is taken by whole chunks (a wave-uniform
+  // test), the scalar path loads from clamped k and zeroes the tail afterwards.
+  const float* Arow = A + (long)min(m0 + r, p.M - 1) * p.sam;
+  const float* Bcol = B + (long)min(n0 + r, p.N - 1) * p.sbn;
   const bool avec = A_KC && p.avec, bvec = B_KC && p.bvec;
 
   float ra[16], rb[16], na[16], nb[16];
-#define KQ_LOAD(RA, RB, k0)                                                                                   \
+#define KQ_PIN(v) asm volatile("" : "+v"(v))
+#define KQ_LOAD1(R, PTR, SK, VEC, k0)                                                                         \
   do {                                                                                                        \
     const int kl = (k0) + 16 * h;                                                                             \
-    if (A_KC && avec && am_ok && kl + 15 < kend) {                                                            \
+    if ((VEC) && (k0) + 32 <= kend) {                                                                         \
       _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                         \
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Arow + kl + 4 * g);                                   \
-        RA[4 * g] = v.x; RA[4 * g + 1] = v.y; RA[4 * g + 2] = v.z; RA[4 * g + 3] = v.w;                       \
+        const f32x4 v = *reinterpret_cast<const f32x4*>((PTR) + kl + 4 * g);                                  \
+        R[4 * g] = v.x; R[4 * g + 1] = v.y; R[4 * g + 2] = v.z; R[4 * g + 3] = v.w;                           \
       }                                                                                                       \
     } else {                                                                                                  \
-      _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_)                                                       \
-        RA[s_] = (am_ok && kl + s_ < kend) ? Arow[(long)(kl + s_) * p.sak] : 0.0f;                            \
-    }                                                                                                         \
-    if (B_KC && bvec && bn_ok && kl + 15 < kend) {                                                            \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                         \
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Bcol + kl + 4 * g);                                   \
-        RB[4 * g] = v.x; RB[4 * g + 1] = v.y; RB[4 * g + 2] = v.z; RB[4 * g + 3] = v.w;                       \
+      _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) R[s_] = (PTR)[(long)min(kl + s_, kend - 1) * (SK)];   \
+      if ((k0) + 32 > kend) {                                                                                 \
+        _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_) { KQ_PIN(R[s_]); R[s_] = (kl + s_ < kend) ? R[s_] : 0.0f; } \
       }                                                                                                       \
-    } else {                                                                                                  \
-      _Pragma("unroll") for (int s_ = 0; s_ < 16; ++s_)                                                       \
-        RB[s_] = (bn_ok && kl + s_ < kend) ? Bcol[(long)(kl + s_) * p.sbk] : 0.0f;                            \
     }                                                                                                         \
+  } while (0)
+#define KQ_LOAD(RA, RB, k0)                                                                                   \
+  do {                                                                                                        \
+    KQ_LOAD1(RA, Arow, p.sak, avec, k0);                                                                      \
+    KQ_LOAD1(RB, Bcol, p.sbk, bvec, k0);                                                                      \
   } while (0)
 
   f32x16 acc = {0};
@@ -213,6 +215,8 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
     }
   }
 #undef KQ_LOAD
+#undef KQ_LOAD1
+#undef KQ_PIN
   // partial tiles -> LDS; C layout of the 32x32 MFMA: lane holds column (lane&31), rows (reg&3) + 8 (reg>>2) + 4 (lane>>5)
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) red[wave][(reg & 3) + 8 * (reg >> 2) + 4 * h][r] = acc[reg];
