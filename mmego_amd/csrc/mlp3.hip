@@ -23,14 +23,8 @@ struct Mlp3P {
   Mlp3Bn bn[3]; float eps;
 };
 
-// s = gamma / sqrt(var + eps); Wf = s W; bf = (b - mean) s + beta: the expressions of bn_fold_linear_kernel (bn.hip), so
-// that folding here and folding beforehand give the same bits
-__device__ __forceinline__ float m3_scale(const Mlp3Bn& bn, float eps, int n) { return bn.gamma ? bn.gamma[n] / sqrtf(bn.rvar[n] + eps) : 1.f; }
-__device__ __forceinline__ float m3_w(const Mlp3Bn& bn, float eps, int n, float w) { return bn.gamma ? m3_scale(bn, eps, n) * w : w; }
-__device__ __forceinline__ float m3_b(const Mlp3Bn& bn, float eps, int n, const float* b) {
-  if (!bn.gamma) return b[n];
-  return ((b ? b[n] : 0.f) - bn.rmean[n]) * m3_scale(bn, eps, n) + bn.beta[n];
-}
+// BatchNorm folding: s = gamma / sqrt(var + eps); Wf = s W; bf = (b - mean) s + beta -- the expressions of bn_fold_linear_kernel
+// (bn.hip), so that folding here and folding beforehand give the same bits.
 
 // one 32x32 output tile: acc = A[rt*32.., 0:K] . W[ct*32.., 0:K]^T ; A row stride as, W row stride ws; K even
 __device__ __forceinline__ f32x16 m3_tile(const float* A, int as, const float* W, int ws, int K, int lane) {
@@ -47,12 +41,63 @@ __global__ __launch_bounds__(256) void mlp3_eval_kernel(Mlp3P p) {
   __shared__ float B1s[32], B2s[64], B3s[64];
   __shared__ float Xs[M3_ROWS * M3_S32], Y1s[M3_ROWS * M3_S32], Y2s[M3_ROWS * M3_S64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // weights (zero padded) -> LDS, once per workgroup
-  for (int i = tid; i < 32 * 32; i += 256) { int n = i >> 5, k = i & 31; W1s[n * M3_S32 + k] = (n < p.C1 && k < p.Cin) ? m3_w(p.bn[0], p.eps, n, p.W1[n * p.Cin + k]) : 0.f; }
-  for (int i = tid; i < 64 * 32; i += 256) { int n = i >> 5, k = i & 31; W2s[n * M3_S32 + k] = (n < p.C2 && k < p.C1) ? m3_w(p.bn[1], p.eps, n, p.W2[n * p.C1 + k]) : 0.f; }
-  for (int i = tid; i < 64 * 64; i += 256) { int n = i >> 6, k = i & 63; W3s[n * M3_S64 + k] = (n < p.C3 && k < p.C2) ? m3_w(p.bn[2], p.eps, n, p.W3[n * p.C2 + k]) : 0.f; }
-  if (tid < 32) B1s[tid] = tid < p.C1 ? m3_b(p.bn[0], p.eps, tid, p.b1) : 0.f;
-  if (tid < 64) { B2s[tid] = tid < p.C2 ? m3_b(p.bn[1], p.eps, tid, p.b2) : 0.f; B3s[tid] = tid < p.C3 ? m3_b(p.bn[2], p.eps, tid, p.b3) : 0.f; }
+  // Weights (zero padded, BatchNorm folded) -> LDS, once per workgroup.  Two phases, every load unconditional from a clamped index and
+  // all of a phase's loads in flight together: first the per-channel scales and folded biases (threads 0..63), then the 28 weight
+  // elements of each thread.  (Written as `(n < C && k < K) ? fold(W[..]) : 0` every element was a branch around three dependent
+  // loads -- W, gamma, running_var -- with a full wait each: 28 serial round trips before the first tile.)
+  __shared__ float S1s[32], S2s[64], S3s[64];
+#define M3_PIN(v) asm volatile("" : "+v"(v))
+  if (tid < 64) {
+    const int n1 = min(tid, p.C1 - 1), n2 = min(tid, p.C2 - 1), n3 = min(tid, p.C3 - 1);
+    const bool fold = p.bn[0].gamma != nullptr;       // (all three layers carry BatchNorm vectors, or none does)
+    float s1 = 1.f, s2 = 1.f, s3 = 1.f, b1, b2, b3;
+    if (fold) {
+      float g1 = p.bn[0].gamma[n1], v1 = p.bn[0].rvar[n1], m1 = p.bn[0].rmean[n1], e1 = p.bn[0].beta[n1];
+      float g2 = p.bn[1].gamma[n2], v2 = p.bn[1].rvar[n2], m2 = p.bn[1].rmean[n2], e2 = p.bn[1].beta[n2];
+      float g3 = p.bn[2].gamma[n3], v3 = p.bn[2].rvar[n3], m3 = p.bn[2].rmean[n3], e3 = p.bn[2].beta[n3];
+      float c1 = p.b1 ? p.b1[n1] : 0.f, c2 = p.b2 ? p.b2[n2] : 0.f, c3 = p.b3 ? p.b3[n3] : 0.f;
+      s1 = g1 / sqrtf(v1 + p.eps); s2 = g2 / sqrtf(v2 + p.eps); s3 = g3 / sqrtf(v3 + p.eps);
+      b1 = (c1 - m1) * s1 + e1; b2 = (c2 - m2) * s2 + e2; b3 = (c3 - m3) * s3 + e3;
+    } else {
+      b1 = p.b1[n1]; b2 = p.b2[n2]; b3 = p.b3[n3];
+    }
+    if (tid < 32) { S1s[tid] = s1; B1s[tid] = tid < p.C1 ? b1 : 0.f; }
+    S2s[tid] = s2; B2s[tid] = tid < p.C2 ? b2 : 0.f;
+    S3s[tid] = s3; B3s[tid] = tid < p.C3 ? b3 : 0.f;
+  }
+  __syncthreads();
+  {
+    const bool fold = p.bn[0].gamma != nullptr;
+    float w1[4], w2[8], w3[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = tid + 256 * u, n = i >> 5, k = i & 31; w1[u] = p.W1[min(n, p.C1 - 1) * p.Cin + min(k, p.Cin - 1)]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = tid + 256 * u, n = i >> 5, k = i & 31; w2[u] = p.W2[min(n, p.C2 - 1) * p.C1 + min(k, p.C1 - 1)]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int i = tid + 256 * u, n = i >> 6, k = i & 63; w3[u] = p.W3[min(n, p.C3 - 1) * p.C2 + min(k, p.C2 - 1)]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u, n = i >> 5, k = i & 31;
+      M3_PIN(w1[u]);
+      const float wf = fold ? S1s[n] * w1[u] : w1[u];
+      W1s[n * M3_S32 + k] = (n < p.C1 && k < p.Cin) ? wf : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + 256 * u, n = i >> 5, k = i & 31;
+      M3_PIN(w2[u]);
+      const float wf = fold ? S2s[n] * w2[u] : w2[u];
+      W2s[n * M3_S32 + k] = (n < p.C2 && k < p.C1) ? wf : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = tid + 256 * u, n = i >> 6, k = i & 63;
+      M3_PIN(w3[u]);
+      const float wf = fold ? S3s[n] * w3[u] : w3[u];
+      W3s[n * M3_S64 + k] = (n < p.C3 && k < p.C2) ? wf : 0.f;
+    }
+  }
+#undef M3_PIN
   const int K1 = (p.Cin + 1) & ~1, K2 = (p.C1 + 1) & ~1, K3 = (p.C2 + 1) & ~1;
   const int rt = wave & 1, ct = wave >> 1;               // 2 x 2 tiles of 32 x 32 over the 64 x 64 stage output
   const int col = ct * 32 + (lane & 31);
@@ -60,13 +105,21 @@ __global__ __launch_bounds__(256) void mlp3_eval_kernel(Mlp3P p) {
   // this thread's 8 elements of a 64 x 32 input tile: row (tid >> 5) + 8 j, column tid & 31; the NEXT tile's elements are
   // fetched while the current tile is computed (the loop is otherwise one exposed global-load round trip per tile)
   const int xk = tid & 31, xr = tid >> 5;
+  const int xkc = xk < p.Cin ? xk : p.Cin - 1;
   float xv[8];
+  // (clamped addresses, all eight loads issued, THEN the selects; the asm keeps each loaded value live outside its select so that
+  // the compiler cannot turn load + select back into a branch around the load -- which costs an s_waitcnt vmcnt(0) per load)
 #define M3_FETCH(tile)                                                                              \
   do {                                                                                              \
     const long rb_ = (tile) * M3_ROWS;                                                              \
     _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
       const long rr_ = rb_ + xr + 8 * j;                                                            \
-      xv[j] = (rr_ < p.rows && xk < p.Cin) ? p.X[rr_ * p.ldx + xk] : 0.f;                           \
+      xv[j] = p.X[(rr_ < p.rows ? rr_ : p.rows - 1) * p.ldx + xkc];                                 \
+    }                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
+      const long rr_ = rb_ + xr + 8 * j;                                                            \
+      asm volatile("" : "+v"(xv[j]));                                                               \
+      xv[j] = (rr_ < p.rows && xk < p.Cin) ? xv[j] : 0.f;                                           \
     }                                                                                               \
   } while (0)
   if ((long)blockIdx.x < ntiles) M3_FETCH((long)blockIdx.x);
