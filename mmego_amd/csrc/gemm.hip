@@ -56,48 +56,48 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
   // 64 contiguous bytes; m-contiguous operand: m = tid&63, k = (tid>>6) + 4 j: a wave covers 256 contiguous bytes.
   const int am = A_KC ? (tid >> 2) : (tid & 63), bn = B_KC ? (tid >> 2) : (tid & 63);
   const int akb = A_KC ? (tid & 3) * 4 : (tid >> 6), bkb = B_KC ? (tid & 3) * 4 : (tid >> 6);
-  const bool am_ok = (m0 + am) < p.M, bn_ok = (n0 + bn) < p.N;
-  const float* Arow = A + (long)(m0 + am) * p.sam;
-  const float* Bcol = B + (long)(n0 + bn) * p.sbn;
+  // rows / columns past M / N: CLAMPED (their products land in output elements that are never stored); k past the slab: loaded from
+  // a clamped k and zeroed afterwards -- only in a chunk that is not whole (a workgroup-uniform test).  A predicate on a load itself
+  // costs a branch and a full s_waitcnt vmcnt(0) per load (see gemm32kq_kernel).
+  const float* Arow = A + (long)min(m0 + am, p.M - 1) * p.sam;
+  const float* Bcol = B + (long)min(n0 + bn, p.N - 1) * p.sbn;
   const bool avec = A_KC && p.avec, bvec = B_KC && p.bvec;
 
   float ra[EL], rb[EL];
+#define G64_PIN(v) asm volatile("" : "+v"(v))
+#define G64_LOAD1(R, PTR, SK, KC, VEC, KB, k0)                                                                \
+  do {                                                                                                        \
+    const bool whole_ = (k0) + BK <= kend;                     /* uniform */                                  \
+    if (KC) {                                                                                                 \
+      if ((VEC) && whole_) {                                                                                  \
+        _Pragma("unroll") for (int g = 0; g < EL / 4; ++g) {                                                  \
+          const f32x4 v = *reinterpret_cast<const f32x4*>((PTR) + (k0) + (KB) + 16 * g);                      \
+          R[4 * g] = v.x; R[4 * g + 1] = v.y; R[4 * g + 2] = v.z; R[4 * g + 3] = v.w;                         \
+        }                                                                                                     \
+      } else {                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < EL; ++j)                                                        \
+          R[j] = (PTR)[(long)min((k0) + (KB) + 16 * (j >> 2) + (j & 3), kend - 1) * (SK)];                    \
+        if (!whole_) {                                                                                        \
+          _Pragma("unroll") for (int j = 0; j < EL; ++j) {                                                    \
+            G64_PIN(R[j]);                                                                                    \
+            R[j] = ((k0) + (KB) + 16 * (j >> 2) + (j & 3) < kend) ? R[j] : 0.0f;                              \
+          }                                                                                                   \
+        }                                                                                                     \
+      }                                                                                                       \
+    } else {                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < EL; ++j) R[j] = (PTR)[(long)min((k0) + (KB) + 4 * j, kend - 1) * (SK)]; \
+      if (!whole_) {                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < EL; ++j) {                                                      \
+          G64_PIN(R[j]);                                                                                      \
+          R[j] = ((k0) + (KB) + 4 * j < kend) ? R[j] : 0.0f;                                                  \
+        }                                                                                                     \
+      }                                                                                                       \
+    }                                                                                                         \
+  } while (0)
 #define G64_LOAD(k0)                                                                                          \
   do {                                                                                                        \
-    if (A_KC) {                                                                                               \
-      _Pragma("unroll") for (int g = 0; g < EL / 4; ++g) {                                                    \
-        const int ka = (k0) + akb + 16 * g;                                                                   \
-        if (avec && am_ok && ka + 3 < kend) {                                                                 \
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Arow + ka);                                         \
-          ra[4 * g] = v.x; ra[4 * g + 1] = v.y; ra[4 * g + 2] = v.z; ra[4 * g + 3] = v.w;                     \
-        } else {                                                                                              \
-          _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                       \
-            ra[4 * g + c] = (am_ok && ka + c < kend) ? Arow[(long)(ka + c) * p.sak] : 0.0f;                   \
-        }                                                                                                     \
-      }                                                                                                       \
-    } else {                                                                                                  \
-      _Pragma("unroll") for (int j = 0; j < EL; ++j) {                                                        \
-        const int ka = (k0) + akb + 4 * j;                                                                    \
-        ra[j] = (am_ok && ka < kend) ? Arow[(long)ka * p.sak] : 0.0f;                                         \
-      }                                                                                                       \
-    }                                                                                                         \
-    if (B_KC) {                                                                                               \
-      _Pragma("unroll") for (int g = 0; g < EL / 4; ++g) {                                                    \
-        const int kb = (k0) + bkb + 16 * g;                                                                   \
-        if (bvec && bn_ok && kb + 3 < kend) {                                                                 \
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Bcol + kb);                                         \
-          rb[4 * g] = v.x; rb[4 * g + 1] = v.y; rb[4 * g + 2] = v.z; rb[4 * g + 3] = v.w;                     \
-        } else {                                                                                              \
-          _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                       \
-            rb[4 * g + c] = (bn_ok && kb + c < kend) ? Bcol[(long)(kb + c) * p.sbk] : 0.0f;                   \
-        }                                                                                                     \
-      }                                                                                                       \
-    } else {                                                                                                  \
-      _Pragma("unroll") for (int j = 0; j < EL; ++j) {                                                        \
-        const int kb = (k0) + bkb + 4 * j;                                                                    \
-        rb[j] = (bn_ok && kb < kend) ? Bcol[(long)kb * p.sbk] : 0.0f;                                         \
-      }                                                                                                       \
-    }                                                                                                         \
+    G64_LOAD1(ra, Arow, p.sak, A_KC, avec, akb, k0);                                                          \
+    G64_LOAD1(rb, Bcol, p.sbk, B_KC, bvec, bkb, k0);                                                          \
   } while (0)
 
   f32x16 acc = {0};
@@ -120,6 +120,8 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
     }
   }
 #undef G64_LOAD
+#undef G64_LOAD1
+#undef G64_PIN
 
   // epilogue: lane holds column (lane&31), rows (reg&3)+8*(reg>>2)+4*(lane>>5)
   const int col = n0 + wn * 32 + (lane & 31);
