@@ -165,7 +165,12 @@ __global__ __launch_bounds__(64) void head_fk_fwd_kernel(const float* __restrict
     if (seed_ctr) seed_ctr[0] = seed_ctr[0] * 6364136223846793005ULL + 1442695040888963407ULL;
   }
   if (f >= F) return;
-  const float* yf = y + f * P::ny;
+  // the frame's head outputs into registers first: all loads in flight at once (read where they were used -- six floats per rotation
+  // -- they were 14 dependent round trips)
+  float yv[P::ny];
+#pragma unroll
+  for (int i = 0; i < P::ny; ++i) yv[i] = y[f * P::ny + i];
+  const float* yf = yv;
   const float* bf = body + (f % B) * 60;
   float* qf = q + f * P::nrot * 9;
   float l[P::nslots][3];
@@ -216,7 +221,10 @@ __global__ __launch_bounds__(64) void head_fk_bwd_kernel(const float* __restrict
   using P = FkC<WHICH>;
   long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= F) return;
-  const float* yf = y + f * P::ny;
+  float yv[P::ny];                       // (preloaded: see the forward kernel)
+#pragma unroll
+  for (int i = 0; i < P::ny; ++i) yv[i] = y[f * P::ny + i];
+  const float* yf = yv;
   const float* bf = body + (f % B) * 60;
   float g[P::nslots][3];
 #pragma unroll
@@ -292,16 +300,20 @@ __global__ __launch_bounds__(1024) void l1_loss_kernel(const float* __restrict__
     float pv[8][3], tv[8][3];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const long i = base + (long)u * blockDim.x + threadIdx.x;
-      if (i < joints) {
-        const long f = i / nsel;
-        const int s = (int)(i - f * nsel);
-        const float* pp = pred + i * 3;
-        const float* tp = target + (f * ntgt + (nsel <= 64 ? smap[s] : map[s])) * 3;
+      // (clamped joint index: the loads are unconditional -- an `if (i < joints)` around them made every load a branch plus a
+      // full wait, 48 dependent round trips per pass; the uses below are predicated)
+      const long i = min(base + (long)u * blockDim.x + threadIdx.x, joints - 1);
+      const long f = i / nsel;
+      const int s = (int)(i - f * nsel);
+      const float* pp = pred + i * 3;
+      const float* tp = target + (f * ntgt + (nsel <= 64 ? smap[s] : map[s])) * 3;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { pv[u][k] = pp[k]; tv[u][k] = tp[k]; }
-      }
+      for (int k = 0; k < 3; ++k) { pv[u][k] = pp[k]; tv[u][k] = tp[k]; }
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { asm volatile("" : "+v"(pv[u][k])); asm volatile("" : "+v"(tv[u][k])); }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const long i = base + (long)u * blockDim.x + threadIdx.x;
