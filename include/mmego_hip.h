@@ -281,7 +281,6 @@ int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, cons
 int mmego_graph_dA_nblk(long G);
 int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V, int K, int C, float* partial_ws,
                    const float* A, const float* imp, float* dZ, long ldz, long lddz);
-/* Temporal 9x1 unfold / fold of a channels-last (B,T,V,C) tensor (GCN.py:109-116). */
 /* ---- ST-GCN layer pieces (gcn.hip): Net/GCN.py:55-64 (graph convolution einsum), :108-122 (9x1 temporal convolution) --------
  * mmego_graph_mix: Y[f][w][c] = sum_k sum_v (A . importance)[k][v][w] X[f][v][k*C + c]  (backward = 0; X is z [F][V][K*C]), or the
  * input gradient Y[f][v][k*C + c] = sum_w (A . importance)[k][v][w] X[f][w][c] (backward = 1; X is dy [F][V][C]).
@@ -289,21 +288,21 @@ int mmego_graph_dA(void* stream, const float* Z, const float* dY, long G, int V,
  * stats (may be NULL; forward, F <= 1024): [C][F][3] BatchNorm partial records (V, mean, M2) of Y per frame and channel, for
  * mmego_bn_finalize -- the batch statistics of st_gcn.tcn[0] without a pass of their own over Y.
  * mmego_tconv: temporal convolution over rows (b, t, v) as an implicit GEMM, out[r][n] = bias[n] + sum_tap sum_k
- * act(X[r + (tap - taps/2) V][k]) W[tap*wts + n*wns + k*wks], taps leaving the sequence contribute zero; act = ReLU(BatchNorm)
- * given by in_state [4][Cin] (mean, invstd, gamma*invstd, beta) or identity (NULL).  Conv weight [Cout][Cin][taps] as it is:
- * (wts, wns, wks) = (1, Cin*taps, taps); its input gradient: X = dY, W pointing at the last tap, (-1, taps, Cin*taps).
- * mmego_tconv_pack: W[co][ci][tap] -> [tap][co][ci] (mode 0) / [taps-1-tap][ci][co] (mode 1) / both, one behind the other (mode 2):
- * k-contiguous tile loads for mmego_tconv, strides (Cout*Cin, Cin, 1). */
+ * act(X[r + (tap - taps/2) V][k]) Wp[(tap*Cout + n)*Cin + k], taps leaving the sequence contribute zero; act = ReLU(BatchNorm)
+ * given by in_state [4][Cin] (mean, invstd, gamma*invstd, beta) or identity (NULL).  Wp: the conv weight re-packed by
+ * mmego_tconv_pack (mode 0; the input gradient of the convolution is the same call with X = dY, Cin/Cout swapped, on the mode-1
+ * pack).  act_out (may be NULL, needs in_state): [rows][Cin], receives act(X) -- what the backward pass keeps.  Cin % 4 == 0.
+ * mmego_tconv_pack: W[co][ci][tap] -> [tap][co][ci] (mode 0) / [taps-1-tap][ci][co] (mode 1) / both, one behind the other (mode 2).
+ * mmego_tconv_wgrad: dW[co][ci][tap] (+)= sum_r dY[r][co] Xa[r + (tap - taps/2) V][ci] (the convolution's weight gradient, no
+ * unfolded operand); ws: mmego_tconv_wgrad_nsplit(...) * taps * Cout * Cin floats of partial tiles, added in a fixed order. */
 int mmego_graph_mix(void* stream, const float* X, const float* A, const float* importance, float* Y, long F, int V, int K, int C,
                     int backward, float* stats, long ldx);
 int mmego_tconv_pack(void* stream, const float* W, int Co, int Ci, int taps, int mode, float* Wp);
-int mmego_tconv(void* stream, const float* X, long ldx, const float* in_state, const float* W, long wts, long wns, long wks,
-                const float* bias, float* Y, long ldy, int B, int T, int V, int Cin, int Cout, int taps);
-/* (im2col_t: state (may be NULL) = [4][C] mean, invstd, a, b of the BatchNorm in front: BatchNorm + ReLU applied to the elements as
- * they are gathered, mmego_affine_act's arithmetic; y_out (may be NULL, needs state) receives the activated tensor itself.) */
-int mmego_im2col_t(void* stream, const float* X, int B, int T, int V, int C, int taps, float* col, const float* state,
-                   float* y_out);
-int mmego_col2im_t(void* stream, const float* dcol, int B, int T, int V, int C, int taps, float* dX);
+int mmego_tconv(void* stream, const float* X, long ldx, const float* in_state, const float* Wp, const float* bias, float* Y,
+                long ldy, float* act_out, int B, int T, int V, int Cin, int Cout, int taps);
+int mmego_tconv_wgrad_nsplit(int B, int T, int V, int Cin, int Cout, int taps);
+int mmego_tconv_wgrad(void* stream, const float* dY, long lddy, const float* Xa, long ldx, float* ws, float* dW, int accumulate,
+                      int B, int T, int V, int Cin, int Cout, int taps);
 /* out[b][c][r] = in[b][r][c]: the (B,64,T,V)->(B,T,V,64) re-view of GCN.py:351-353 (quirk Q8). */
 int mmego_transpose_batched(void* stream, const float* in, float* out, long Bn, int R, int C);
 int mmego_mul(void* stream, const float* a, const float* b, float* out, long n);

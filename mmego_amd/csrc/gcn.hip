@@ -6,17 +6,17 @@
 //                a frame's z tile is staged in LDS once and every output is a 15-term dot product from there.
 //   tconv        the 9x1 temporal convolution (padding 4) as an IMPLICIT GEMM: out[r][co] = b[co] + sum_tap sum_ci
 //                act(in[r + (tap-4) V][ci]) W[co][ci][tap], rows (b, t, v), taps that leave the sequence contribute zero.  The
-//                unfolded operand (im2col_t: 9x the activation, 9.4 GB per config-5 forward) never exists: per tap the A tile is
-//                the SAME 64 rows shifted by (tap-4) V rows.  The preceding BatchNorm + ReLU (st_gcn.tcn[0..1]) is applied while
-//                the tile is loaded.  The input gradient of the convolution is the same kernel on flipped, transposed weights
-//                (tconv_pack mode 1), so col2im_t disappears as well.
-//                The weight element (tap, n, k) is addressed through three strides; the conv weight [co][ci][tap] as it is would
-//                work (forward (1, Ci*taps, taps), input gradient from the LAST tap with (-1, taps, Ci*taps)) but puts the 64 lanes
-//                of a tile load 36 B / 4.6 KB apart (measured: 61 us per launch at the training shape), so the weights are
-//                re-packed k-contiguous first:
+//                unfolded operand (9x the activation, 9.4 GB per config-5 forward) never exists: per tap the A tile is the SAME
+//                64 rows shifted by (tap-4) V rows.  The preceding BatchNorm + ReLU (st_gcn.tcn[0..1]) is applied while the tile
+//                is loaded; a training step keeps the activated rows (they come out of the centre tap's loads).  The input
+//                gradient of the convolution is the same kernel on flipped, transposed weights (tconv_pack mode 1).
+//                The conv weight [co][ci][tap] as it lies would put the 64 lanes of a tile load 36 B apart (measured: 61 us per
+//                launch at the training shape), so the weights are re-packed k-contiguous first:
 //   tconv_pack   W[co][ci][tap] -> Wp[tap][co][ci] (mode 0) or Wp[tap][ci][co] with the taps reversed (mode 1); mode 2 writes both,
 //                one behind the other (a training step packs once in its forward pass and uses the second half in backward).
-// 64 x 64 output tiles, v_mfma_f32_32x32x2_f32, operands in LDS with a 65-float row stride, next chunk prefetched in registers.
+//   tconv_wgrad  the weight gradient, implicit too: per tap a product over the row axis of dY and the shifted activated rows,
+//                row axis split over workgroups, partial tiles added in a fixed order.
+// 64 x 64 output tiles, v_mfma_f32_32x32x2_f32, operands in LDS, next chunk prefetched in registers.
 #include "common.h"
 
 #define GC_S 66          // even row stride: fragments are read as aligned float2 (lanes r = 0..31 hit 64 distinct banks)
@@ -84,9 +84,11 @@ __global__ __launch_bounds__(256) void tconv_pack_kernel(const float* __restrict
 struct TconvP {
   const float* X; long ldx;          // input rows (b, t, v) x Cin
   const float* in_state;             // [4][Cin] mean, invstd, a, b of the BatchNorm in front (+ ReLU); null: plain input
-  const float* W; long wts, wns, wks; // weight element (tap, n = output channel, k = input channel) at W[tap*wts + n*wns + k*wks]
+  const float* W;                    // packed [taps][Cout][Cin] (tconv_pack)
   const float* bias;                 // [Cout] or null
   float* Y; long ldy;
+  float* act;                        // optional [rows][Cin]: the activated input (kept for the backward pass), written from the
+                                     // centre tap's tile loads by the workgroups of the first column tile
   long rows; int T, V, Cin, Cout, taps;
 };
 
@@ -94,11 +96,14 @@ struct TconvP {
 // One ds_read_b64 per operand feeds two MFMA steps: lane (r, h) holds k = 4j + 2h, 4j + 2h + 1 -- the same k-permutation on
 // both operands, so the sum over k is unchanged.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define TC_PIN4(v) asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w))
 // Workgroup = NG groups of 4 waves on ONE 64 x 64 output tile; group g takes the (tap, channel-chunk) steps g, g + NG, ... with
 // operand tiles of its own, so NG steps' loads are in flight at once, and the groups' partial tiles are added through LDS in a
 // fixed order at the end.  NG = 4 for small row counts (the training shape: 120 row tiles, where one step at a time left the
 // kernel waiting on 9-18 dependent memory round trips), NG = 1 when the grid alone fills the chip.
-template <int NG>
+// Tile loads: 16-byte loads from CLAMPED addresses, all eight of a step issued before the first is used, masks applied to the
+// values afterwards (a predicate on the load itself compiles to branch + load + wait: one memory round trip per load).
+template <int NG, bool ACT>
 __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = t >> 6;
@@ -108,61 +113,96 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
   const long r0 = (long)blockIdx.x * 64;
   const int n0 = blockIdx.y * 64;
   const int half = p.taps / 2;
-  const int xk = t & 63, xr = t >> 6;
+  const int c4 = t & 15, rr = t >> 4;                      // this thread's 16-byte column and its rows rr + 16 j of a tile
   const int nkc = (p.Cin + 63) / 64;                       // 64-channel chunks per tap
   const int nchunks = p.taps * nkc;
-  // this thread's 16 rows of the tile (rows xr + 4 j): their frame index t, four per register as signed bytes (taps that leave
-  // [0, T) are masked; rows past the end count as t = -128).  Addresses are kept as uniform row pointers (scalar registers)
-  // plus ONE 32-bit lane offset per operand: spelled out per element, the 32 loads of a step cost 64 address registers and the
-  // kernel spilled.
-  int tpk[4];
+  // per row of the tile: element offset of its (clamped) input row, its frame index t (rows past the end: far outside), the
+  // weight row's offset -- 32-bit (the launcher checks the extents), so that a step's addresses cost a few adds per load
+  unsigned xoff[4], woff[4];
+  int tv[4];
+  bool nok[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    int w = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long row = r0 + xr + 4 * (4 * q + u);
-      const int tv = row < p.rows ? (int)((row / p.V) % p.T) : -128;
-      w |= (tv & 255) << (8 * u);
-    }
-    tpk[q] = w;
+  for (int j = 0; j < 4; ++j) {
+    const long row = r0 + rr + 16 * j;
+    const bool in = row < p.rows;
+    xoff[j] = (unsigned)(in ? row : p.rows - 1) * (unsigned)p.ldx;
+    tv[j] = in ? (int)(((unsigned)row / (unsigned)p.V) % (unsigned)p.T) : -(1 << 20);
+    const int n = n0 + rr + 16 * j;
+    nok[j] = n < p.Cout;
+    woff[j] = (unsigned)(nok[j] ? n : p.Cout - 1) * (unsigned)p.Cin;
   }
-  const int xoff = xr * (int)p.ldx + xk;                   // lane part of an input address
-  const int woff = xr * (int)p.wns + xk * (int)p.wks;      // lane part of a weight address
-  float av[16], bv[16];
-#define TC_FETCH(ch)                                                                                \
+  const int vstep = p.V * (int)p.ldx;                      // one frame, in elements
+  f32x4 av[4], bv[4], mu = {0.f, 0.f, 0.f, 0.f}, sa = mu, sb = mu;
+  // TC_ISSUE: the loads of step ch (clamped addresses, nothing waits on them); TC_FINISH: masks and activation, run when the
+  // values are about to be stored to LDS -- the MFMAs of the step before sit between the two
+#define TC_ISSUE(ch)                                                                                \
   do {                                                                                              \
     const int tap_ = (ch) / nkc, k0_ = ((ch) % nkc) * 64;                                           \
     const int d_ = tap_ - half;                                                                     \
-    const bool kok_ = k0_ + xk < p.Cin;                                                             \
-    float mu_ = 0.f, a_ = 1.f, b_ = 0.f;                                                            \
-    if (p.in_state && kok_) { mu_ = p.in_state[k0_ + xk]; a_ = p.in_state[2 * p.Cin + k0_ + xk]; b_ = p.in_state[3 * p.Cin + k0_ + xk]; } \
-    const float* xrow_ = p.X + (r0 + (long)d_ * p.V) * p.ldx + k0_;               /* uniform */     \
-    const float* wrow_ = p.W + (long)tap_ * p.wts + (long)n0 * p.wns + (long)k0_ * p.wks;           \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                \
-      const int ts_ = (int)(signed char)(tpk[j >> 2] >> (8 * (j & 3))) + d_;                        \
-      const bool ok_ = kok_ && ts_ >= 0 && ts_ < p.T;                                               \
-      float v_ = ok_ ? (xrow_ + (long)(4 * j) * p.ldx)[xoff] : 0.f;                                 \
-      if (p.in_state) v_ = ok_ ? fmaxf(__builtin_fmaf(v_ - mu_, a_, b_), 0.f) : 0.f;                \
-      av[j] = v_;                                                                                   \
-      bv[j] = (n0 + xr + 4 * j < p.Cout && kok_) ? (wrow_ + (long)(4 * j) * p.wns)[woff] : 0.f;     \
+    const int kk_ = k0_ + 4 * c4;                                                                   \
+    const int kc_ = kk_ < p.Cin ? kk_ : 0;                                                          \
+    if (ACT) {                                                                                      \
+      mu = *reinterpret_cast<const f32x4*>(p.in_state + kc_);                                       \
+      sa = *reinterpret_cast<const f32x4*>(p.in_state + 2 * p.Cin + kc_);                           \
+      sb = *reinterpret_cast<const f32x4*>(p.in_state + 3 * p.Cin + kc_);                           \
+    }                                                                                               \
+    const float* wt_ = p.W + (long)tap_ * p.Cout * p.Cin;                         /* uniform */     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+      const unsigned ts_ = (unsigned)(tv[j] + d_);                                                  \
+      const unsigned o_ = xoff[j] + (unsigned)(ts_ < (unsigned)p.T ? d_ * vstep : 0) + (unsigned)kc_; \
+      av[j] = *reinterpret_cast<const f32x4*>(p.X + o_);                                            \
+    }                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
+      bv[j] = *reinterpret_cast<const f32x4*>(wt_ + (woff[j] + (unsigned)kc_));                     \
+  } while (0)
+#define TC_FINISH(ch)                                                                               \
+  do {                                                                                              \
+    const int d_ = (ch) / nkc - half;                                                               \
+    const bool kok_ = ((ch) % nkc) * 64 + 4 * c4 < p.Cin;                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) { TC_PIN4(av[j]); TC_PIN4(bv[j]); }               \
+    if (ACT) { TC_PIN4(mu); TC_PIN4(sa); TC_PIN4(sb); }                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+      const int ts_ = tv[j] + d_;                                                                   \
+      f32x4 v_ = av[j];                                                                             \
+      if (ACT) {                                                                                    \
+        v_.x = fmaxf(__builtin_fmaf(v_.x - mu.x, sa.x, sb.x), 0.f);                                 \
+        v_.y = fmaxf(__builtin_fmaf(v_.y - mu.y, sa.y, sb.y), 0.f);                                 \
+        v_.z = fmaxf(__builtin_fmaf(v_.z - mu.z, sa.z, sb.z), 0.f);                                 \
+        v_.w = fmaxf(__builtin_fmaf(v_.w - mu.w, sa.w, sb.w), 0.f);                                 \
+      }                                                                                             \
+      const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                        \
+      av[j] = (kok_ && ts_ >= 0 && ts_ < p.T) ? v_ : z_;                                            \
+      bv[j] = (nok[j] && kok_) ? bv[j] : z_;                                                        \
     }                                                                                               \
   } while (0)
-  if (grp < nchunks) TC_FETCH(grp);
+  // (issued unconditionally, past the last step on a clamped index: a load under a condition would have its values copied -- and
+  // waited for -- where the condition ends)
+  TC_ISSUE(grp < nchunks ? grp : nchunks - 1);
   f32x16 acc = {0};
+  const bool live = n0 + ct * 32 < p.Cout && r0 + rt * 32 < p.rows;      // (a wave whose whole 32 x 32 part is padding skips the MFMAs)
   for (int ch0 = 0; ch0 < nchunks; ch0 += NG) {
     const int ch = ch0 + grp;
     __syncthreads();
     if (ch < nchunks) {
+      TC_FINISH(ch);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        As[(xr + 4 * j) * GC_S + xk] = av[j];
-        Bs[(xr + 4 * j) * GC_S + xk] = bv[j];
+      for (int j = 0; j < 4; ++j) {
+        f32x2* ad = reinterpret_cast<f32x2*>(As + (rr + 16 * j) * GC_S + 4 * c4);
+        f32x2* bd = reinterpret_cast<f32x2*>(Bs + (rr + 16 * j) * GC_S + 4 * c4);
+        ad[0] = f32x2{av[j].x, av[j].y}; ad[1] = f32x2{av[j].z, av[j].w};
+        bd[0] = f32x2{bv[j].x, bv[j].y}; bd[1] = f32x2{bv[j].z, bv[j].w};
+      }
+      if (ACT && p.act && blockIdx.y == 0 && ch / nkc == half) {
+        const int kk = (ch % nkc) * 64 + 4 * c4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (kk < p.Cin && tv[j] >= 0) *reinterpret_cast<f32x4*>(p.act + (r0 + rr + 16 * j) * p.Cin + kk) = av[j];
       }
     }
     __syncthreads();
-    if (ch + NG < nchunks) TC_FETCH(ch + NG);
-    if (ch < nchunks) {
+    TC_ISSUE(ch + NG < nchunks ? ch + NG : nchunks - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ch < nchunks && live) {
       const int kleft = p.Cin - (ch % nkc) * 64;
       const int K = kleft >= 64 ? 64 : ((kleft + 3) & ~3);
       const int r = lane & 31, h = lane >> 5;
@@ -176,6 +216,8 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
       }
     }
   }
+#undef TC_ISSUE
+#undef TC_FINISH
   const int lcol = ct * 32 + (lane & 31);
   if (NG > 1) {                                            // groups 1 .. NG-1 hand their partial tiles to group 0 (fixed order)
     __syncthreads();
@@ -196,11 +238,191 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
   const int col = n0 + lcol;
   if (col < p.Cout) {
     const float bb = p.bias ? p.bias[col] : 0.f;
+    float* yp = p.Y + (r0 + rt * 32 + 4 * (lane >> 5)) * p.ldy + col;
+    if (r0 + 64 <= p.rows) {                               // whole tile: stores without a predicate each (one behind the other)
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const long row = r0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      if (row < p.rows) p.Y[row * p.ldy + col] = acc[reg] + bb;
+      for (int reg = 0; reg < 16; ++reg) yp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldy] = acc[reg] + bb;
+    } else {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const long row = r0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (row < p.rows) p.Y[row * p.ldy + col] = acc[reg] + bb;
+      }
     }
+  }
+}
+
+// Weight gradient of the temporal convolution, implicit as well: dW[co][ci][tap] = sum_r dY[r][co] act[r + (tap-4) V][ci] (rows
+// whose shifted frame leaves the sequence contribute nothing) -- per tap a product over the ROW axis of two tiles read as they
+// lie in memory (k-major: row r of both operands is one LDS row, a lane reads its output channel's column).  The row axis is
+// cut into nsplit slabs (grid.x), one 64 x 64 (co, ci) tile per tap and workgroup; the partial tiles go to ws[split][tap][co][ci]
+// and tconv_wgrad_reduce adds them in split order into the convolution's [co][ci][tap] layout.
+struct TconvWgP {
+  const float* dY; long lddy;
+  const float* Xa; long ldx;
+  float* ws;
+  long rows, rows_per_split;
+  int T, V, Cin, Cout, taps;
+};
+#define TW_S 72          // LDS row stride (floats): 16-byte aligned rows
+#define TW_K 64          // rows per chunk: 8 16-byte loads per thread in flight, 37 KB of LDS -- several workgroups per CU (one 128-row
+                         // chunk per CU left every load round trip exposed: 55 us for the 128-channel block at 7680 rows)
+// acc += sum over KN k-major LDS rows of a[k][m] b[k][n]: fragment reads of the next 16 rows are issued before the MFMAs of the
+// current 16 (one wave per SIMD: nothing else hides the LDS latency; reading right in front of each MFMA ran at 0.25 of the peak)
+template <int KN>
+__device__ __forceinline__ void tw_mfma(const float* ap, const float* bp, f32x16& acc) {
+  static_assert(KN % 16 == 0, "k range: whole groups of 16 rows");
+  float a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a0[i] = ap[2 * i * TW_S]; b0[i] = bp[2 * i * TW_S]; }
+#pragma unroll
+  for (int k = 0; k < KN; k += 32) {
+    if (k + 16 < KN) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { a1[i] = ap[(k + 16 + 2 * i) * TW_S]; b1[i] = bp[(k + 16 + 2 * i) * TW_S]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // (the scheduler would sink every read to its MFMA again)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k + 32 < KN) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { a0[i] = ap[(k + 32 + 2 * i) * TW_S]; b0[i] = bp[(k + 32 + 2 * i) * TW_S]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (k + 16 < KN) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// KSPLIT (both channel counts <= 32: one 32 x 32 tile): the four waves take a quarter of every chunk's rows each and add
+// their tiles through LDS at the end, in wave order.
+template <bool KSPLIT>
+__global__ __launch_bounds__(256) void tconv_wgrad_kernel(TconvWgP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ds = smem;
+  float* Xs = smem + TW_K * TW_S;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int rt = KSPLIT ? 0 : wave & 1, ct = KSPLIT ? 0 : wave >> 1;
+  const int ntn = (p.Cin + 63) / 64, ntm = (p.Cout + 63) / 64;
+  const int tap = blockIdx.y / (ntm * ntn), tile = blockIdx.y % (ntm * ntn);
+  const int m0 = (tile / ntn) * 64, n0 = (tile % ntn) * 64;
+  const int d = tap - p.taps / 2;
+  const long rbeg = (long)blockIdx.x * p.rows_per_split;
+  const long rend = rbeg + p.rows_per_split < p.rows ? rbeg + p.rows_per_split : p.rows;
+  const int c4 = t & 15, rr = t >> 4;                      // 16-byte column, rows rr + 16 j of a chunk
+  const int mm = m0 + 4 * c4, nn = n0 + 4 * c4;
+  const bool mok = mm < p.Cout, nok = nn < p.Cin;
+  const int mc = mok ? mm : 0, ncl = nok ? nn : 0;
+  constexpr int NJ = TW_K / 16;
+  f32x4 dv[NJ], xv[NJ];
+  // frame index t of every row of a chunk (rows past the split's end: far outside), one division per ROW and chunk instead of
+  // one per load (measured: the address arithmetic of 16 loads per thread took three times the chunk's MFMA time), for the
+  // chunk in flight and the next one
+  int* tab = reinterpret_cast<int*>(smem + 2 * TW_K * TW_S);   // [2][TW_K]
+#define TW_TAB(buf, rb)                                                                             \
+  if (t < TW_K) {                                                                                   \
+    const long row_ = (rb) + t;                                                                     \
+    tab[(buf) * TW_K + t] = row_ < rend ? (int)(((unsigned)row_ / (unsigned)p.V) % (unsigned)p.T) : -(1 << 20); \
+  }
+  const unsigned lastd = (unsigned)(p.rows - 1) * (unsigned)p.lddy, lastx = (unsigned)(p.rows - 1) * (unsigned)p.ldx;
+  const int vstep = d * p.V * (int)p.ldx;                  // this tap's shift, in elements
+#define TW_ISSUE(buf, rb)                                                                           \
+  do {                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                \
+      const int tq_ = tab[(buf) * TW_K + rr + 16 * j];                                              \
+      const unsigned row_ = (unsigned)((rb) + rr + 16 * j);                                         \
+      const unsigned od_ = tq_ >= 0 ? row_ * (unsigned)p.lddy : lastd;                              \
+      const unsigned ox_ = tq_ >= 0 ? row_ * (unsigned)p.ldx : lastx;                               \
+      dv[j] = *reinterpret_cast<const f32x4*>(p.dY + (od_ + (unsigned)mc));                        \
+      xv[j] = *reinterpret_cast<const f32x4*>(p.Xa + (ox_ + (unsigned)((unsigned)(tq_ + d) < (unsigned)p.T ? vstep : 0) + (unsigned)ncl)); \
+    }                                                                                               \
+  } while (0)
+#define TW_FINISH(buf)                                                                              \
+  do {                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) { TC_PIN4(dv[j]); TC_PIN4(xv[j]); }              \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                \
+      const int tq_ = tab[(buf) * TW_K + rr + 16 * j];                                              \
+      const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                        \
+      dv[j] = (tq_ >= 0 && mok) ? dv[j] : z_;                                                       \
+      xv[j] = ((unsigned)(tq_ + d) < (unsigned)p.T && nok) ? xv[j] : z_;                            \
+    }                                                                                               \
+  } while (0)
+  f32x16 acc = {0};
+  const bool live = m0 + rt * 32 < p.Cout && n0 + ct * 32 < p.Cin;
+  TW_TAB(0, rbeg)
+  __syncthreads();
+  TW_ISSUE(0, rbeg);                                       // (unconditional, rows past the end clamped: see tconv_kernel)
+  int buf = 0;
+  for (long rb = rbeg; rb < rend; rb += TW_K, buf ^= 1) {
+    TW_TAB(buf ^ 1, rb + TW_K)
+    __syncthreads();
+    TW_FINISH(buf);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      *reinterpret_cast<f32x4*>(Ds + (rr + 16 * j) * TW_S + 4 * c4) = dv[j];
+      *reinterpret_cast<f32x4*>(Xs + (rr + 16 * j) * TW_S + 4 * c4) = xv[j];
+    }
+    __syncthreads();
+    TW_ISSUE(buf ^ 1, rb + TW_K);
+    __builtin_amdgcn_sched_barrier(0);
+    if (live) {
+      const int r = lane & 31, h = lane >> 5;
+      const int kb = KSPLIT ? wave * (TW_K / 4) : 0;
+      const float* ap = Ds + (kb + h) * TW_S + rt * 32 + r;
+      const float* bp = Xs + (kb + h) * TW_S + ct * 32 + r;
+      tw_mfma<KSPLIT ? TW_K / 4 : TW_K>(ap, bp, acc);
+    }
+  }
+#undef TW_ISSUE
+#undef TW_FINISH
+#undef TW_TAB
+  if (KSPLIT) {                                            // waves 1..3 hand their tiles to wave 0
+    __syncthreads();
+    float* xch = smem;                                     // [3][16][64]
+    if (wave > 0) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) xch[((wave - 1) * 16 + reg) * 64 + lane] = acc[reg];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) acc[reg] += xch[(w * 16 + reg) * 64 + lane];
+  }
+  const int n = n0 + ct * 32 + (lane & 31);
+  if (n < p.Cin) {
+    float* out = p.ws + ((long)blockIdx.x * p.taps + tap) * p.Cout * p.Cin;
+    const int mw = m0 + rt * 32;
+    if (mw + 32 <= p.Cout) {                               // whole 32-row part: stores without a predicate each
+      float* op = out + (long)(mw + 4 * (lane >> 5)) * p.Cin + n;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) op[(long)((reg & 3) + 8 * (reg >> 2)) * p.Cin] = acc[reg];
+    } else {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = mw + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (m < p.Cout) out[(long)m * p.Cin + n] = acc[reg];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tconv_wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, int taps, int Co, int Ci,
+                                                                 float* __restrict__ dW, int accumulate) {
+  const long per = (long)taps * Co * Ci;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += ws[k * per + i];
+    const int ci = (int)(i % Ci);
+    const long q = i / Ci;
+    const int co = (int)(q % Co), tap = (int)(q / Co);
+    float* o = dW + ((long)co * Ci + ci) * taps + tap;
+    *o = accumulate ? *o + s : s;
   }
 }
 
@@ -227,23 +449,79 @@ extern "C" int mmego_tconv_pack(void* stream, const float* W, int Co, int Ci, in
   return MMEGO_OK;
 }
 
-extern "C" int mmego_tconv(void* stream, const float* X, long ldx, const float* in_state, const float* W, long wts, long wns, long wks,
-                           const float* bias, float* Y, long ldy, int B, int T, int V, int Cin, int Cout, int taps) {
-  MMEGO_REQUIRE(X && W && Y && B > 0 && T > 0 && V > 0 && Cin >= 1 && Cout >= 1 && taps >= 1 && (taps & 1) && ldx >= Cin && ldy >= Cout);
-  TconvP p = {X, ldx, in_state, W, wts, wns, wks, bias, Y, ldy, (long)B * T * V, T, V, Cin, Cout, taps};
+extern "C" int mmego_tconv(void* stream, const float* X, long ldx, const float* in_state, const float* Wp, const float* bias, float* Y,
+                           long ldy, float* act, int B, int T, int V, int Cin, int Cout, int taps) {
+  MMEGO_REQUIRE((long)B * T * V * ldx < (1L << 30) && (long)Cout * Cin < (1L << 30));   // (32-bit element offsets)
+  MMEGO_REQUIRE(X && Wp && Y && B > 0 && T > 0 && V > 0 && Cin >= 4 && Cout >= 1 && taps >= 1 && (taps & 1) && ldx >= Cin && ldy >= Cout);
+  MMEGO_REQUIRE((Cin % 4) == 0 && (ldx % 4) == 0 && (((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)in_state | (uintptr_t)act) & 15) == 0);
+  MMEGO_REQUIRE(!act || in_state);
+  TconvP p = {X, ldx, in_state, Wp, bias, Y, ldy, act, (long)B * T * V, T, V, Cin, Cout, taps};
   dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((Cout + 63) / 64));
+  hipStream_t st = (hipStream_t)stream;
   if ((long)grid.x * grid.y <= 512) {                      // small grid: four steps in flight per workgroup
     const size_t lds = (size_t)4 * 2 * 64 * GC_S * sizeof(float);
     static bool attr = false;
     if (!attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)tconv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute((const void*)tconv_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tconv_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
       attr = true;
     }
-    hipLaunchKernelGGL(tconv_kernel<4>, grid, dim3(1024), lds, (hipStream_t)stream, p);
+    if (in_state) hipLaunchKernelGGL((tconv_kernel<4, true>), grid, dim3(1024), lds, st, p);
+    else hipLaunchKernelGGL((tconv_kernel<4, false>), grid, dim3(1024), lds, st, p);
   } else {
-    hipLaunchKernelGGL(tconv_kernel<1>, grid, dim3(256), (size_t)2 * 64 * GC_S * sizeof(float), (hipStream_t)stream, p);
+    const size_t lds = (size_t)2 * 64 * GC_S * sizeof(float);
+    if (in_state) hipLaunchKernelGGL((tconv_kernel<1, true>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((tconv_kernel<1, false>), grid, dim3(256), lds, st, p);
   }
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// rows of one split of the weight-gradient product (a multiple of the chunk) and the number of splits: enough workgroups to cover the
+// chip about once, at least 256 rows each
+static void tconv_wgrad_split(long rows, int Cin, int Cout, int taps, long* rps, int* nsplit) {
+  const long tiles = (long)taps * ((Cin + 63) / 64) * ((Cout + 63) / 64);
+  long want = (576 + tiles - 1) / tiles;
+  if (want < 1) want = 1;
+  long per = (rows + want - 1) / want;
+  if (per < 256) per = 256;
+  per = (per + TW_K - 1) / TW_K * TW_K;
+  *rps = per;
+  *nsplit = (int)((rows + per - 1) / per);
+}
+
+extern "C" int mmego_tconv_wgrad_nsplit(int B, int T, int V, int Cin, int Cout, int taps) {
+  long rps;
+  int ns;
+  tconv_wgrad_split((long)B * T * V, Cin, Cout, taps, &rps, &ns);
+  return ns;
+}
+
+extern "C" int mmego_tconv_wgrad(void* stream, const float* dY, long lddy, const float* Xa, long ldx, float* ws, float* dW, int accumulate,
+                                 int B, int T, int V, int Cin, int Cout, int taps) {
+  MMEGO_REQUIRE((long)B * T * V * ldx < (1L << 30) && (long)B * T * V * lddy < (1L << 30));   // (32-bit element offsets)
+  MMEGO_REQUIRE(dY && Xa && ws && dW && B > 0 && T > 0 && V > 0 && Cin >= 4 && Cout >= 4 && taps >= 1 && (taps & 1));
+  MMEGO_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0 && (ldx % 4) == 0 && (lddy % 4) == 0 && ldx >= Cin && lddy >= Cout);
+  MMEGO_REQUIRE((((uintptr_t)dY | (uintptr_t)Xa | (uintptr_t)ws) & 15) == 0);
+  TconvWgP p = {dY, lddy, Xa, ldx, ws, (long)B * T * V, 0, T, V, Cin, Cout, taps};
+  int ns;
+  tconv_wgrad_split(p.rows, Cin, Cout, taps, &p.rows_per_split, &ns);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ns, (unsigned)(taps * ((Cin + 63) / 64) * ((Cout + 63) / 64)));
+  const size_t lds = (size_t)2 * TW_K * TW_S * sizeof(float) + 2 * TW_K * sizeof(int);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)tconv_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tconv_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  if (Cin <= 32 && Cout <= 32) hipLaunchKernelGGL(tconv_wgrad_kernel<true>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(tconv_wgrad_kernel<false>, grid, dim3(256), lds, st, p);
+  MMEGO_LAUNCH_CHECK();
+  long b = ((long)taps * Cin * Cout + 255) / 256;
+  hipLaunchKernelGGL(tconv_wgrad_reduce_kernel, dim3((int)(b > 1024 ? 1024 : b)), dim3(256), 0, st, ws, ns, taps, Cout, Cin, dW, accumulate);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

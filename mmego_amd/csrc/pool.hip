@@ -6,7 +6,6 @@
 //   cross_attn  : softmax(Q K^T / 8) V with 64 query points and 15 joint keys per frame (Lower_Net.py:105-109);
 //                 K, V (and for backward Q, dO) staged in LDS, 4 lanes per query row
 //   graph_dA    : gradient of einsum('nkctv,kvw->nctw') wrt the (K,15,15) adjacency (GCN.py:62)
-//   im2col_t / col2im_t : 9-tap temporal unfold for the ST-GCN temporal conv (GCN.py:109-116)
 #include "common.h"
 
 // X [G, P, C]; w [C]; b scalar ptr -> vec [G, C], attn [G, P]
@@ -541,58 +540,6 @@ __global__ __launch_bounds__(512) void graph_dA_partial_kernel(const float* __re
   if (e < nout) partial[(long)blockIdx.x * nout + e] = acc;
 }
 
-// col[(b,t,v), ci*taps + tap] = X[b, t+tap-half, v, ci]  (zero outside)      X [B,T,V,C]
-// state (optional): [4][C] mean, invstd, a, b of a BatchNorm in front, applied with ReLU to every element as it is read (the
-// expression of affine_act_kernel, bn.hip: same bits); y_out (optional) then receives the activated tensor itself (the centre tap).
-__global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__ X, int B, int T, int V, int C, int taps,
-                                                       float* __restrict__ col, const float* __restrict__ state,
-                                                       float* __restrict__ y_out) {
-  const long total = (long)B * T * V * C * taps;
-  const int half = taps / 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int tap = (int)(i % taps);
-    long r = i / taps;
-    int ci = (int)(r % C);
-    long row = r / C;
-    int v = (int)(row % V);
-    long bt = row / V;
-    int t = (int)(bt % T);
-    long b = bt / T;
-    int ts = t + tap - half;
-    float val = 0.f;
-    if (ts >= 0 && ts < T) {
-      val = X[((b * T + ts) * V + v) * (long)C + ci];
-      if (state) {
-        val = (val - state[ci]) * state[2 * C + ci] + state[3 * C + ci];
-        val = fmaxf(val, 0.f);
-      }
-    }
-    col[i] = val;
-    if (y_out && tap == half) y_out[row * C + ci] = val;
-  }
-}
-
-// dX[b,t,v,ci] = sum_tap dcol[(b, t-tap+half, v), ci*taps + tap]
-__global__ __launch_bounds__(256) void col2im_t_kernel(const float* __restrict__ dcol, int B, int T, int V, int C,
-                                                       int taps, float* __restrict__ dX) {
-  const long total = (long)B * T * V * C;
-  const int half = taps / 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int ci = (int)(i % C);
-    long row = i / C;
-    int v = (int)(row % V);
-    long bt = row / V;
-    int t = (int)(bt % T);
-    long b = bt / T;
-    float acc = 0.f;
-    for (int tap = 0; tap < taps; ++tap) {
-      int to = t - tap + half;
-      if (to >= 0 && to < T) acc += dcol[(((b * T + to) * V + v) * (long)C + ci) * taps + tap];
-    }
-    dX[i] = acc;
-  }
-}
-
 // out[b][c][r] = in[b][r][c]
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 long Bn, int R, int C) {
@@ -717,24 +664,6 @@ extern "C" int mmego_graph_dA(void* stream, const float* Z, const float* dY, lon
   MMEGO_REQUIRE(lds <= 64 * 1024);
   hipLaunchKernelGGL(graph_dA_partial_kernel, dim3(cdiv(G, GDA_FPB)), dim3(512), lds, (hipStream_t)stream, Z, dY, G, V, K, C,
                      partial_ws, A, imp, dZ, ldz, lddz);
-  MMEGO_LAUNCH_CHECK();
-  return MMEGO_OK;
-}
-
-extern "C" int mmego_im2col_t(void* stream, const float* X, int B, int T, int V, int C, int taps, float* col, const float* state,
-                              float* y_out) {
-  MMEGO_REQUIRE(X && col && B > 0 && T > 0 && V > 0 && C > 0 && taps > 0 && (taps & 1));
-  MMEGO_REQUIRE(!y_out || state);
-  hipLaunchKernelGGL(im2col_t_kernel, dim3(ew_blocks((long)B * T * V * C * taps)), dim3(256), 0, (hipStream_t)stream, X, B,
-                     T, V, C, taps, col, state, y_out);
-  MMEGO_LAUNCH_CHECK();
-  return MMEGO_OK;
-}
-
-extern "C" int mmego_col2im_t(void* stream, const float* dcol, int B, int T, int V, int C, int taps, float* dX) {
-  MMEGO_REQUIRE(dcol && dX && B > 0 && T > 0 && V > 0 && C > 0 && taps > 0 && (taps & 1));
-  hipLaunchKernelGGL(col2im_t_kernel, dim3(ew_blocks((long)B * T * V * C)), dim3(256), 0, (hipStream_t)stream, dcol, B, T,
-                     V, C, taps, dX);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -23,17 +23,6 @@ from .params import FlatParams
 from .skeleton import JOINTS_UPPER, LOWER_POINTS, gcn_adjacency
 
 
-# Training-mode temporal convolution of the ST-GCN blocks: implicit GEMM (gcn.hip, no unfolded operand) from this many rows
-# (b, t, v) on; below it the unfold + large-tile product is faster (B=64, T=8: 7680 rows -> 120 row tiles, the implicit kernel
-# is bound by its 9-18 dependent steps per tile: 5.99 ms against 6.10 ms per U+L step).  Eval-mode forwards always use the
-# implicit kernel.  MMEGO_TCONV_TRAIN_MIN_ROWS overrides the threshold (0: always implicit).
-_TCONV_TRAIN_MIN_ROWS = int(os.environ.get("MMEGO_TCONV_TRAIN_MIN_ROWS", "16384"))
-# Below that row count: blocks with at least this many channels still take the implicit kernel for the INPUT gradient of the
-# temporal convolution (MMEGO_TCONV_BWD_MIN_CHANNELS; 1 << 30: never).  Traced at 7680 rows: 128 channels 54.7 us (pack + implicit)
-# against 57 us (product + fold), 64 channels 33.8 against 25.4 us.
-_TCONV_BWD_MIN_CHANNELS = int(os.environ.get("MMEGO_TCONV_BWD_MIN_CHANNELS", "128"))
-
-
 def _require_gpu(t, who):
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise RuntimeError("%s runs on the MI355X HIP path only (got a %s tensor); there is no CPU fallback"
@@ -495,22 +484,16 @@ class LowerNet(_NetBase):
                 st0 = ops.bn_stats(ar, key + ".bn0", ymix, blk.tcn["0"], training)
             tz = ar.get(key + ".tz", (rows, cout))
             wt = blk.tcn["2"].weight                          # [cout, cout, taps, 1]
-            if training and rows < _TCONV_TRAIN_MIN_ROWS:
-                # BatchNorm + ReLU applied while the rows are unfolded; y0 (kept for backward) leaves from the same launch
+            # 9x1 temporal convolution, implicit (gcn.hip): BatchNorm + ReLU applied while the tiles are loaded; a training step
+            # keeps the activated rows y0 (they leave from the same launch) and packs the weights for both of its uses
+            if training:
                 y0 = ar.get(key + ".y0", (rows, cout))
-                col = ar.get(key + ".col", (rows, cout * blk.taps))
-                hip.call("im2col_t", ymix, B, T, V, cout, blk.taps, col, st0.all, y0)
-                ops.linear(col, blk.tcn["2"].weight, blk.tcn["2"].bias, tz)
-            elif training:
-                y0 = ar.get(key + ".y0", (rows, cout))         # (kept: the backward pass needs it)
-                ops.affine_act(ymix, st0, y0, relu=True)
-                wp = ar.get(key + ".wp", (2, wt.numel()))          # packed for the forward product and for its input gradient
+                wp = ar.get(key + ".wp", (2, wt.numel()))
                 hip.call("tconv_pack", wt, cout, cout, blk.taps, 2, wp)
-                hip.call("tconv", y0, cout, None, wp[0], cout * cout, cout, 1, blk.tcn["2"].bias, tz, cout, B, T, V, cout, cout, blk.taps)
+                hip.call("tconv", ymix, cout, st0.all, wp[0], blk.tcn["2"].bias, tz, cout, y0, B, T, V, cout, cout, blk.taps)
             else:
-                # frozen net: BatchNorm + ReLU applied while the convolution loads its tiles, weights re-packed k-contiguous once
-                hip.call("tconv", ymix, cout, st0.all, self._packed_tconv(i, wt, blk.taps), cout * cout, cout, 1, blk.tcn["2"].bias, tz,
-                         cout, B, T, V, cout, cout, blk.taps)
+                hip.call("tconv", ymix, cout, st0.all, self._packed_tconv(i, wt, blk.taps), blk.tcn["2"].bias, tz, cout, None,
+                         B, T, V, cout, cout, blk.taps)
             # the block's two closing BatchNorms (temporal branch, residual branch) in one pair of launches
             st3, st_r = ops.bn_stats_pair(ar, key + ".bn3", tz, blk.tcn["3"], key + ".bnr", res_z, blk.residual["1"], training)
             out = ar.get(key + ".out", (rows, cout))
@@ -597,27 +580,14 @@ class LowerNet(_NetBase):
             ops.bn_backward_pair(dcur, out, tz, st3, G(blk.tcn["3"].weight), G(blk.tcn["3"].bias), dtz,
                                  res_z, st_r, G(blk.residual["1"].weight), G(blk.residual["1"].bias), drz)
             y0, ymix = ar.get(key + ".y0", (rows, cout)), ar.get(key + ".ymix", (rows, cout))
-            # weight gradient of the temporal convolution from the unfolded y0 (built here, in the backward pass only);
-            # no bias gradient: a batch-statistics BatchNorm follows
-            col = ar.get(key + ".col", (rows, cout * blk.taps))
+            # temporal convolution: weight gradient from dtz and the shifted rows of y0 (no bias gradient: a batch-statistics
+            # BatchNorm follows), input gradient = the same implicit convolution of dtz on the reversed, transposed pack
             dy0 = ar.get(key + ".dy0", (rows, cout))
-            if rows >= _TCONV_TRAIN_MIN_ROWS:
-                hip.call("im2col_t", y0, B, T, V, cout, blk.taps, col, None, None)
-                blocks.linear_backward(dtz, col, blk.tcn["2"], G, None, bias_grad=False)
-                # input gradient = the same implicit-GEMM convolution of dtz with the taps reversed and (co, ci) swapped
-                wp = ar.get(key + ".wp", (2, blk.tcn["2"].weight.numel()))
-                hip.call("tconv", dtz, cout, None, wp[1], cout * cout, cout, 1, None, dy0, cout, B, T, V, cout, cout, blk.taps)
-            elif cout >= _TCONV_BWD_MIN_CHANNELS:
-                # wide block at a small row count: the unfolded operand of the forward pass serves the weight gradient, the
-                # input gradient is the implicit convolution (no [rows, 9 C] gradient written and folded back)
-                blocks.linear_backward(dtz, col, blk.tcn["2"], G, None, bias_grad=False)
-                wp1 = ar.get(key + ".wp1", (blk.tcn["2"].weight.numel(),))
-                hip.call("tconv_pack", blk.tcn["2"].weight, cout, cout, blk.taps, 1, wp1)
-                hip.call("tconv", dtz, cout, None, wp1, cout * cout, cout, 1, None, dy0, cout, B, T, V, cout, cout, blk.taps)
-            else:
-                dcol = ar.get(key + ".dcol", (rows, cout * blk.taps))
-                blocks.linear_backward(dtz, col, blk.tcn["2"], G, dcol, bias_grad=False)
-                hip.call("col2im_t", dcol, B, T, V, cout, blk.taps, dy0)
+            wp = ar.get(key + ".wp", (2, blk.tcn["2"].weight.numel()))
+            nsp = hip.lib().mmego_tconv_wgrad_nsplit(B, T, V, cout, cout, blk.taps)
+            hip.call("tconv_wgrad", dtz, cout, y0, cout, ops.scratch(dtz.device, nsp * blk.taps * cout * cout), G(blk.tcn["2"].weight), 0,
+                     B, T, V, cout, cout, blk.taps)
+            hip.call("tconv", dtz, cout, None, wp[1], None, dy0, cout, None, B, T, V, cout, cout, blk.taps)
             dymix = ar.get(key + ".dymix", (rows, cout))
             ops.bn_backward(dy0, y0, ymix, st0, G(blk.tcn["0"].weight), G(blk.tcn["0"].bias), dymix)
             dAp = ar.get(key + ".dAp", (hip.lib().mmego_graph_dA_nblk(F), K * V * V))

@@ -67,3 +67,9 @@ tot = sum(v[1] for v in agg.values())
 print("total %.2f ms/step over %d launches/step" % (tot / iters, len(rec) // iters))
 for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     print("%-70s n/step %4d  avg %8.1f us  %6.2f ms/step %5.1f%%" % (k, n // iters, ms / n * 1e3, ms / iters, 100 * ms / tot))
+if os.environ.get("MMEGO_PROFILE_ORDER"):
+    # the last step's calls in launch order (event-pair time of each)
+    n = len(rec) // iters
+    print("-- launch order of one step --")
+    for i, (k, a, b) in enumerate(rec[-n:]):
+        print("%4d %-70s %8.1f us" % (i, k, a.elapsed_time(b) * 1e3))

@@ -607,19 +607,10 @@ def test_train_lower(dev):
                       target[:, :, list(sk.LOWER_MAP)], g, dev)
 
 
-def test_train_lower_implicit_temporal_conv(dev, monkeypatch):
-    """The same three training steps with the ST-GCN temporal convolution forced onto the implicit-GEMM kernel (gcn.hip; by
-    default only from 16384 rows on) -- forward product, input gradient on the reversed taps, weight gradient from the
-    unfold built in the backward pass."""
-    from mmego_amd import nets
-    monkeypatch.setattr(nets, "_TCONV_TRAIN_MIN_ROWS", 0)
-    test_train_lower(dev)
-
-
 def test_gcn_kernels_against_torch(dev):
     """mmego_graph_mix (einsum 'nkctv,kvw->nctw' with A * edge_importance, and its input gradient) and mmego_tconv (9x1 temporal
-    convolution as an implicit GEMM: plain / with BatchNorm+ReLU applied on load / input gradient on reversed taps; packed
-    and unpacked weight strides; ragged row and channel counts) against torch in fp64."""
+    convolution as an implicit GEMM: plain / with BatchNorm+ReLU applied on load / input gradient on reversed taps / weight
+    gradient; ragged row and channel counts) against torch in fp64."""
     from mmego_amd import hip
     g = torch.Generator().manual_seed(23)
     Fn, V, K, C = 37, 15, 2, 24
@@ -651,7 +642,7 @@ def test_gcn_kernels_against_torch(dev):
     part2 = torch.empty_like(part)
     hip.call("graph_dA", z.to(dev), dy.to(dev), Fn, V, K, C, part2, None, None, None, K * C, 0)
     assert torch.equal(part2, part)
-    for Bq, Tq, Ci, Co in ((3, 8, 32, 32), (2, 5, 20, 70), (70, 16, 128, 128)):
+    for Bq, Tq, Ci, Co in ((3, 8, 32, 32), (2, 5, 20, 70), (5, 7, 36, 72), (70, 16, 128, 128)):
         taps = 9
         x = torch.randn(Bq, Tq, V, Ci, generator=g)
         W = torch.randn(Co, Ci, taps, 1, generator=g) / (Ci * taps) ** 0.5
@@ -660,28 +651,38 @@ def test_gcn_kernels_against_torch(dev):
         want = conv(x.double(), W.double(), b.double())
         rows = Bq * Tq * V
         xd, Wd, bd = x.to(dev).view(rows, Ci), W.to(dev), b.to(dev)
-        out = torch.empty(rows, Co, device=dev)
-        hip.call("tconv", xd, Ci, None, Wd, 1, Ci * taps, taps, bd, out, Co, Bq, Tq, V, Ci, Co, taps)          # conv weight as it is
-        assert (out.cpu().double().view_as(want) - want).abs().max().item() < 2e-4, (Bq, Tq, Ci, Co)
         wp = torch.empty(2, W.numel(), device=dev)
         hip.call("tconv_pack", Wd, Co, Ci, taps, 2, wp)
         out2 = torch.empty(rows, Co, device=dev)
-        hip.call("tconv", xd, Ci, None, wp[0], Co * Ci, Ci, 1, bd, out2, Co, Bq, Tq, V, Ci, Co, taps)
-        assert (out2.cpu().double().view_as(want) - want).abs().max().item() < 2e-4
-        # BatchNorm + ReLU applied on load: state = mean, invstd, a, b
+        hip.call("tconv", xd, Ci, None, wp[0], bd, out2, Co, None, Bq, Tq, V, Ci, Co, taps)
+        assert (out2.cpu().double().view_as(want) - want).abs().max().item() < 2e-4, (Bq, Tq, Ci, Co)
+        # BatchNorm + ReLU applied on load: state = mean, invstd, a, b; the activated rows come out beside the product
         st = torch.stack((torch.randn(Ci, generator=g) * 0.2, torch.ones(Ci), torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.1))
         act = torch.relu((x.double() - st[0].double()) * st[2].double() + st[3].double())
         want3 = conv(act, W.double(), b.double())
-        out3 = torch.empty(rows, Co, device=dev)
-        hip.call("tconv", xd, Ci, st.to(dev).contiguous(), wp[0], Co * Ci, Ci, 1, bd, out3, Co, Bq, Tq, V, Ci, Co, taps)
+        out3, act_out = torch.empty(rows, Co, device=dev), torch.full((rows, Ci), float("nan"), device=dev)
+        hip.call("tconv", xd, Ci, st.to(dev).contiguous(), wp[0], bd, out3, Co, act_out, Bq, Tq, V, Ci, Co, taps)
         assert (out3.cpu().double().view_as(want3) - want3).abs().max().item() < 2e-4
+        assert (act_out.cpu().double().view_as(act) - act).abs().max().item() < 1e-5
         # input gradient: autograd of the convolution against the same kernel on the gradient pack
         xg = x.double().clone().requires_grad_(True)
+        Wg = W.double().clone().requires_grad_(True)
         dyc = torch.randn(Bq, Tq, V, Co, generator=g)
-        (conv(xg, W.double(), None) * dyc.double()).sum().backward()
+        (conv(xg, Wg, None) * dyc.double()).sum().backward()
         dx = torch.empty(rows, Ci, device=dev)
-        hip.call("tconv", dyc.to(dev).view(rows, Co), Co, None, wp[1], Ci * Co, Co, 1, None, dx, Ci, Bq, Tq, V, Co, Ci, taps)
-        assert (dx.cpu().double().view_as(xg.grad) - xg.grad).abs().max().item() < 2e-4
+        dyd = dyc.to(dev).view(rows, Co)
+        if Co % 4 == 0:
+            hip.call("tconv", dyd, Co, None, wp[1], None, dx, Ci, None, Bq, Tq, V, Co, Ci, taps)
+            assert (dx.cpu().double().view_as(xg.grad) - xg.grad).abs().max().item() < 2e-4
+            # weight gradient, implicit too: dW[co][ci][tap] = sum_r dy[r][co] x[r + (tap-4) V][ci]; plain and accumulating
+            nsp = hip.lib().mmego_tconv_wgrad_nsplit(Bq, Tq, V, Ci, Co, taps)
+            ws = torch.empty(nsp * W.numel(), device=dev)
+            dW = torch.full((Co, Ci, taps, 1), float("nan"), device=dev)
+            hip.call("tconv_wgrad", dyd, Co, xd, Ci, ws, dW, 0, Bq, Tq, V, Ci, Co, taps)
+            scale = Wg.grad.abs().max().item()
+            assert (dW.cpu().double() - Wg.grad).abs().max().item() < 1e-5 * scale + 1e-4, (Bq, Tq, Ci, Co)
+            hip.call("tconv_wgrad", dyd, Co, xd, Ci, ws, dW, 1, Bq, Tq, V, Ci, Co, taps)
+            assert (dW.cpu().double() - 2 * Wg.grad).abs().max().item() < 2e-5 * scale + 2e-4
 
 
 def test_fused_adam_matches_torch(dev):
