@@ -123,24 +123,50 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
 #undef G64_LOAD1
 #undef G64_PIN
 
-  // epilogue: lane holds column (lane&31), rows (reg&3)+8*(reg>>2)+4*(lane>>5)
+  // epilogue: lane holds column (lane&31), rows (reg&3)+8*(reg>>2)+4*(lane>>5).  Whatever the options read (accumulate: C itself,
+  // cmul: the mask / factor tensor) is fetched for all 16 elements first, from clamped addresses, and only then do the stores
+  // begin: a load between two stores waits for the store in front of it as well (one counter for both on gfx9) -- the 16
+  // elements were 16 consecutive memory round trips.
   const int col = n0 + wn * 32 + (lane & 31);
   if (col >= p.N) return;
   float* C = p.C + (long)batch * p.sCb + (long)split * p.sCs;
   const float bv = (p.bias && p.nsplit == 1) ? p.bias[(long)batch * p.sBiasb + col] : 0.0f;
+  const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
+  const bool final_ = p.nsplit == 1;
+  float old[16], cm[16];
+  if (final_ && p.accumulate) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = rbase + (reg & 3) + 8 * (reg >> 2);
+      old[reg] = C[(long)(row < p.M ? row : p.M - 1) * p.scm + (long)col * p.scn];
+    }
+  }
+  if (final_ && p.cmul) {
+    const float* cmp = p.cmul + (C - p.C);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = rbase + (reg & 3) + 8 * (reg >> 2);
+      cm[reg] = cmp[(long)(row < p.M ? row : p.M - 1) * p.scm + (long)col * p.scn];
+    }
+  }
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
-    int row = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    if (row < p.M) {
-      float v = acc[reg] + bv;
-      float* dst = C + (long)row * p.scm + (long)col * p.scn;
-      if (p.nsplit == 1) {
-        if (p.relu == 1) v = fmaxf(v, 0.0f);
-        if (p.accumulate) v += *dst;
-        if (p.cmul) { const float cm = p.cmul[dst - p.C]; v = p.relu == 2 ? (cm > 0.f ? v : 0.f) : v * cm; }
-      }
-      *dst = v;
+    float v = acc[reg] + bv;
+    if (final_) {
+      if (p.relu == 1) v = fmaxf(v, 0.0f);
+      if (p.accumulate) { asm volatile("" : "+v"(old[reg])); v += old[reg]; }
+      if (p.cmul) { asm volatile("" : "+v"(cm[reg])); v = p.relu == 2 ? (cm[reg] > 0.f ? v : 0.f) : v * cm[reg]; }
     }
+    acc[reg] = v;
+  }
+  float* cp = C + (long)rbase * p.scm + (long)col * p.scn;
+  if (m0 + wm * 32 + 32 <= p.M) {                          // whole 32-row part: stores without a predicate each
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) cp[(long)((reg & 3) + 8 * (reg >> 2)) * p.scm] = acc[reg];
+  } else {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg)
+      if (rbase + (reg & 3) + 8 * (reg >> 2) < p.M) cp[(long)((reg & 3) + 8 * (reg >> 2)) * p.scm] = acc[reg];
   }
 }
 
@@ -236,21 +262,45 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
       p.asum[((long)split * (gridDim.z / p.nsplit) + batch) * p.M + m0 + tid] = v;
     }
   }
+  // (options' loads for all four elements first, from clamped addresses, then the stores: see gemm64_kernel's epilogue)
   float* C = p.C + (long)batch * p.sCb + (long)split * p.sCs;
+  const bool final_ = p.nsplit == 1;
+  const int col = tid & 31, colc = n0 + col < p.N ? n0 + col : p.N - 1;
+  long off[4];
+  float v[4], old[4], cm[4], bv = 0.f;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int idx = tid + 256 * e, row = idx >> 5, col = idx & 31;
-    if (m0 + row < p.M && n0 + col < p.N) {
-      float v = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
-      float* dst = C + (long)(m0 + row) * p.scm + (long)(n0 + col) * p.scn;
-      if (p.nsplit == 1) {
-        if (p.bias) v += p.bias[(long)batch * p.sBiasb + n0 + col];
-        if (p.relu == 1) v = fmaxf(v, 0.0f);
-        if (p.accumulate) v += *dst;
-        if (p.cmul) { const float cm = p.cmul[dst - p.C]; v = p.relu == 2 ? (cm > 0.f ? v : 0.f) : v * cm; }
-      }
-      *dst = v;
+    const int row = (tid >> 5) + 8 * e;
+    v[e] = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+    off[e] = (long)(m0 + row < p.M ? m0 + row : p.M - 1) * p.scm + (long)colc * p.scn;
+  }
+  if (final_ && p.bias) bv = p.bias[(long)batch * p.sBiasb + colc];
+  if (final_ && p.accumulate) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) old[e] = C[off[e]];
+  }
+  if (final_ && p.cmul) {
+    const float* cmp = p.cmul + (C - p.C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cm[e] = cmp[off[e]];
+  }
+  if (final_) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = v[e] + bv;
+      if (p.relu == 1) x = fmaxf(x, 0.0f);
+      if (p.accumulate) { asm volatile("" : "+v"(old[e])); x += old[e]; }
+      if (p.cmul) { asm volatile("" : "+v"(cm[e])); x = p.relu == 2 ? (cm[e] > 0.f ? x : 0.f) : x * cm[e]; }
+      v[e] = x;
     }
+  }
+  if (m0 + 32 <= p.M && n0 + 32 <= p.N) {                  // whole tile: stores without a predicate each
+#pragma unroll
+    for (int e = 0; e < 4; ++e) C[off[e]] = v[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (m0 + (tid >> 5) + 8 * e < p.M && n0 + col < p.N) C[off[e]] = v[e];
   }
 }
 

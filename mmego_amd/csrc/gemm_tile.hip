@@ -144,14 +144,20 @@ __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, i
     const float bv = (!slab && p.bias) ? p.bias[(long)batch * p.sBiasb + col] : 0.0f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float* cp = C + (long)(m0 + wm * WM + i * 32 + 4 * (lane >> 5)) * ldc + col;
+      float old[16];
+      if (accumulate) {                                    // all 16 reads before the first store (a load behind a store waits for it too)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) old[reg] = cp[(long)((reg & 3) + 8 * (reg >> 2)) * ldc];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) asm volatile("" : "+v"(old[reg]));
+      }
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        int row = m0 + wm * WM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         float v = acc[i][j][reg] + bv;
         if (relu) v = fmaxf(v, 0.0f);
-        float* dst = C + (long)row * ldc + col;
-        if (accumulate) v += *dst;
-        *dst = v;
+        if (accumulate) v += old[reg];
+        cp[(long)((reg & 3) + 8 * (reg >> 2)) * ldc] = v;
       }
     }
   }
