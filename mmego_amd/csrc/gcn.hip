@@ -239,14 +239,18 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
   if (col < p.Cout) {
     const float bb = p.bias ? p.bias[col] : 0.f;
     float* yp = p.Y + (r0 + rt * 32 + 4 * (lane >> 5)) * p.ldy + col;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) acc[reg] += bb;     // (final values in registers of their own before the first store: a value
+                                                           // computed under a store's predicate reuses one register, and overwriting a
+                                                           // store's data register waits for that store)
     if (r0 + 64 <= p.rows) {                               // whole tile: stores without a predicate each (one behind the other)
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) yp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldy] = acc[reg] + bb;
+      for (int reg = 0; reg < 16; ++reg) yp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldy] = acc[reg];
     } else {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const long row = r0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (row < p.rows) p.Y[row * p.ldy + col] = acc[reg] + bb;
+        if (row < p.rows) yp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldy] = acc[reg];
       }
     }
   }

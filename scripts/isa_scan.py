@@ -15,9 +15,12 @@ for src in sys.argv[1:]:
                         "-I" + os.path.join(root, "mmego_amd/csrc"), "-I" + os.path.join(root, "include"), src, "-o", out], check=True)
         txt = open(out).read()
     print(src)
-    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", txt, re.S | re.M):
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", txt, re.S | re.M):
         name, body = m.group(1), m.group(2)
         dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
-        print("  %-56s lines %5d  vmcnt(0) %3d  execz %3d  loads %3d  scratch %3d" % (
-            dem[:56], body.count("\n"), len(re.findall(r"vmcnt\(0\)", body)), body.count("s_cbranch_execz"),
-            len(re.findall(r"\b(global_load|buffer_load|flat_load)", body)), len(re.findall(r"scratch_", body))))
+        first_store = body.find("global_store")
+        after = body[first_store:] if first_store >= 0 else ""
+        print("  %-56s lines %5d  vmcnt(0) %3d (%3d behind the first store)  execz %3d  loads %3d  stores %3d  scratch %3d" % (
+            dem[:56], body.count("\n"), len(re.findall(r"vmcnt\(0\)", body)), len(re.findall(r"vmcnt\(0\)", after)),
+            body.count("s_cbranch_execz"), len(re.findall(r"\b(global_load|buffer_load|flat_load)", body)),
+            len(re.findall(r"\b(global_store|buffer_store|flat_store)", body)), len(re.findall(r"scratch_", body))))
