@@ -601,52 +601,64 @@ struct FusedStepP {
   StepBfP o;                 // outputs, c, Bn, H, first (hprev / whh / xpf unused)
 };
 
-// one operand segment through the chunk pipeline (the body of lstm_step_bf16_kernel<WR,1>): WG = 128*WR rows, wave wr owns
-// WR row blocks of 32 rows
+// one operand segment through the chunk pipeline: WG = 128 WR rows, wave wr owns WR row blocks of 32 rows.  The activation
+// fragments of a wave's OWN row block never touch LDS: they are fragment-major in memory (one coalesced 1-KB read per 16-k
+// step), no other wave needs them, so each wave fetches them straight into the registers the MFMAs read -- only the weight
+// tile, which all four waves share, is staged.  (Staging both, the LDS array's read + write cycles of a chunk, 576 per
+// workgroup, exceeded its 512 MFMA cycles: MFMA busy 0.38.)
 template <int WR>
 __device__ __forceinline__ void fused_segment(const bf16_t* A, const bf16_t* W, int S, int jb, const int (&rbi)[4 * WR], int tid,
-                                              int lane, int wr, u32x4* As, u32x4* Bs, f32x16 (&acc)[WR][4]) {
-  constexpr int RB = 4 * WR;
-  const u32x4* ab = reinterpret_cast<const u32x4*>(A) + tid;
-  const u32x4* wb = reinterpret_cast<const u32x4*>(W) + (long)jb * 4 * S * 64 + tid;
-  u32x4 ra[RB], rw[4];
+                                              int lane, int wr, u32x4* Bs, f32x16 (&acc)[WR][4]) {
+  const u32x4* aw[WR];
 #pragma unroll
-  for (int i = 0; i < RB; ++i) ra[i] = ab[(long)rbi[i] * S * 64];
+  for (int mi = 0; mi < WR; ++mi) aw[mi] = reinterpret_cast<const u32x4*>(A) + (long)rbi[wr * WR + mi] * S * 64 + lane;
+  const u32x4* wb = reinterpret_cast<const u32x4*>(W) + (long)jb * 4 * S * 64 + tid;
+  u32x4 ra[WR][4], rw[4];
+#pragma unroll
+  for (int mi = 0; mi < WR; ++mi)
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) ra[mi][sl] = aw[mi][sl * 64];
 #pragma unroll
   for (int i = 0; i < 4; ++i) rw[i] = wb[(long)i * S * 64];
   for (int s0 = 0; s0 < S; s0 += 4) {
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < RB; ++i) As[i * 256 + tid] = ra[i];
+    u32x4 ac[WR][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) Bs[i * 256 + tid] = rw[i];
+#pragma unroll
+    for (int mi = 0; mi < WR; ++mi)
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) ac[mi][sl] = ra[mi][sl];
     __syncthreads();
-    if (s0 + 4 < S) {
+    {
+      // (unconditional, past the last chunk on a clamped index: loads under a condition have their values copied -- and waited
+      // for -- where the condition ends, i.e. in front of this chunk's MFMAs)
+      const int sn = s0 + 4 < S ? s0 + 4 : s0;
 #pragma unroll
-      for (int i = 0; i < RB; ++i) ra[i] = ab[((long)rbi[i] * S + s0 + 4) * 64];
+      for (int mi = 0; mi < WR; ++mi)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rw[i] = wb[((long)i * S + s0 + 4) * 64];
+        for (int sl = 0; sl < 4; ++sl) ra[mi][sl] = aw[mi][(sn + sl) * 64];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rw[i] = wb[((long)i * S + sn) * 64];
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
-      u32x4 a[WR], b[4];
-#pragma unroll
-      for (int mi = 0; mi < WR; ++mi) a[mi] = As[((wr * WR + mi) * 4 + sl) * 64 + lane];
+      u32x4 b[4];
 #pragma unroll
       for (int n = 0; n < 4; ++n) b[n] = Bs[(n * 4 + sl) * 64 + lane];
 #pragma unroll
       for (int mi = 0; mi < WR; ++mi)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-          acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[n]),
+          acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[mi][sl]), __builtin_bit_cast(bf16x8, b[n]),
                                                                acc[mi][n], 0, 0, 0);
     }
   }
 }
 
 template <int WR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void lstm_step_bf16_fused_kernel(FusedStepP p) {
-  __shared__ __attribute__((aligned(16))) u32x4 As[4 * WR * 256];  // [row block][4 steps][64 lanes]
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 / WR, 4 / WR))) void lstm_step_bf16_fused_kernel(FusedStepP p) {
   __shared__ __attribute__((aligned(16))) u32x4 Bs[4 * 256];       // [gate][4 steps][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, wr = tid >> 6;
   const int d = blockIdx.z, H = p.o.H;
@@ -686,28 +698,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
       for (int i = 0; i < 16; ++i) acc[mi][n][i] = 0.f;
 #pragma unroll
   for (int seg = 0; seg < 3; ++seg)
-    if (seg < p.nseg) fused_segment<WR>(p.a[seg][d], p.w[seg][d], p.S[seg], jb, rbi, tid, lane, wr, As, Bs, acc);
+    if (seg < p.nseg) fused_segment<WR>(p.a[seg][d], p.w[seg][d], p.S[seg], jb, rbi, tid, lane, wr, Bs, acc);
 
   const int j = j0 + fr;
   float bv[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) bv[n] = p.bias[(d * 4 + n) * H + j];
+  // cell update: c_{t-1} of all 16 elements in one round of loads (clamped rows), every result in a register of its own, then
+  // the stores -- element by element (load, compute, three stores under the row predicate) each load waited for the stores in
+  // front of it: 16 consecutive memory round trips per workgroup
 #pragma unroll
   for (int mi = 0; mi < WR; ++mi) {
     const int rb = (r0 >> 5) + wr * WR + mi;
     if (rb * 32 >= p.o.Bn) continue;
+    float cn[16], hn[16];
+    if (!p.o.first) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = rb * 32 + 8 * (i >> 2) + 4 * fh + (i & 3);
+        cn[i] = p.o.c[d][(long)(row < p.o.Bn ? row : p.o.Bn - 1) * H + j];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(cn[i]));
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int row = rb * 32 + 8 * (i >> 2) + 4 * fh + (i & 3);
-      if (row < p.o.Bn) {
-        const float cprev = p.o.first ? 0.f : p.o.c[d][(long)row * H + j];
-        const float gi = bf_sigmoid(acc[mi][0][i] + bv[0]), gf = bf_sigmoid(acc[mi][1][i] + bv[1]);
-        const float gg = bf_tanh(acc[mi][2][i] + bv[2]), go = bf_sigmoid(acc[mi][3][i] + bv[3]);
-        const float cn = gf * cprev + gi * gg;
-        const float hn = go * bf_tanh(cn);
-        p.o.c[d][(long)row * H + j] = cn;
-        if (p.o.hout[d]) p.o.hout[d][(long)row * p.o.hos + j] = hn;
-        p.o.hfrag[d][frag_off(row, j, H)] = (bf16_t)f2bf_bits(hn);
+      const float cprev = p.o.first ? 0.f : cn[i];
+      const float gi = bf_sigmoid(acc[mi][0][i] + bv[0]), gf = bf_sigmoid(acc[mi][1][i] + bv[1]);
+      const float gg = bf_tanh(acc[mi][2][i] + bv[2]), go = bf_sigmoid(acc[mi][3][i] + bv[3]);
+      cn[i] = gf * cprev + gi * gg;
+      hn[i] = go * bf_tanh(cn[i]);
+    }
+    if (rb * 32 + 32 <= p.o.Bn) {                          // whole row block: no predicate per element
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = rb * 32 + 8 * (i >> 2) + 4 * fh + (i & 3);
+        p.o.c[d][(long)row * H + j] = cn[i];
+        if (p.o.hout[d]) p.o.hout[d][(long)row * p.o.hos + j] = hn[i];
+        p.o.hfrag[d][frag_off(row, j, H)] = (bf16_t)f2bf_bits(hn[i]);
+      }
+    } else {
+      unsigned short hb[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hb[i] = f2bf_bits(hn[i]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = rb * 32 + 8 * (i >> 2) + 4 * fh + (i & 3);
+        if (row < p.o.Bn) {
+          p.o.c[d][(long)row * H + j] = cn[i];
+          if (p.o.hout[d]) p.o.hout[d][(long)row * p.o.hos + j] = hn[i];
+          p.o.hfrag[d][frag_off(row, j, H)] = (bf16_t)hb[i];
+        }
       }
     }
   }
@@ -743,10 +784,18 @@ extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H,
   p.o.hfrag[0] = hfrag0; p.o.hfrag[1] = hfrag1;
   p.o.c[0] = c0; p.o.c[1] = c1;
   p.o.Bn = Bn; p.o.H = H; p.o.first = first;
-  // WR = 1 (128 rows per WG, 128 VGPRs, four WGs per CU): 22.8 ms per config-5 IMU_Net forward; WR = 2 (256 rows, two WGs
-  // per CU, fewer LDS reads per MFMA) measured 24.5 ms -- co-resident workgroups hide the barriers better than a leaner loop.
-  dim3 grid(H / 32, cdiv(Bn, 128), ndir);
-  lstm_step_bf16_fused_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+  // WR = 1 (128 rows per WG, 128 VGPRs, four WGs per CU) by default; MMEGO_BF16_FUSED_WR=2 (256 rows, two WGs per CU, half the
+  // weight-tile reads per MFMA) for A/B runs: 20.3 - 20.5 ms per config-5 IMU_Net forward either way.  Also measured without
+  // effect on that figure: the weight tile double-buffered in LDS (one barrier per chunk), L2 super-tiles of 8 x 2, 16 x 1, 2 x 8
+  // (hidden x row blocks) instead of 4 x 4.
+  static const int wr2 = getenv("MMEGO_BF16_FUSED_WR") ? atoi(getenv("MMEGO_BF16_FUSED_WR")) == 2 : 0;
+  if (wr2) {
+    dim3 grid(H / 32, cdiv(Bn, 256), ndir);
+    lstm_step_bf16_fused_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+  } else {
+    dim3 grid(H / 32, cdiv(Bn, 128), ndir);
+    lstm_step_bf16_fused_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+  }
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
