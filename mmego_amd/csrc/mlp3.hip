@@ -39,7 +39,10 @@ __device__ __forceinline__ f32x16 m3_tile(const float* A, int as, const float* W
 __global__ __launch_bounds__(256) void mlp3_eval_kernel(Mlp3P p) {
   __shared__ float W1s[32 * M3_S32], W2s[64 * M3_S32], W3s[64 * M3_S64];
   __shared__ float B1s[32], B2s[64], B3s[64];
-  __shared__ float Xs[M3_ROWS * M3_S32], Y1s[M3_ROWS * M3_S32], Y2s[M3_ROWS * M3_S64];
+  // (the input tile shares its LDS with the stage-2 output: Xs is last read in stage 1, Y2s first written behind the barrier that
+  // ends stage 1 -- 8.4 KB less, and at 75 KB two workgroups fit on a CU)
+  __shared__ float Y1s[M3_ROWS * M3_S32], Y2s[M3_ROWS * M3_S64];
+  float* const Xs = Y2s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // Weights (zero padded, BatchNorm folded) -> LDS, once per workgroup.  Two phases, every load unconditional from a clamped index and
   // all of a phase's loads in flight together: first the per-channel scales and folded biases (threads 0..63), then the 28 weight
@@ -122,14 +125,17 @@ __global__ __launch_bounds__(256) void mlp3_eval_kernel(Mlp3P p) {
       xv[j] = (rr_ < p.rows && xk < p.Cin) ? xv[j] : 0.f;                                           \
     }                                                                                               \
   } while (0)
-  if ((long)blockIdx.x < ntiles) M3_FETCH((long)blockIdx.x);
+  // (prefetches are unconditional, past the last tile on a clamped index: loads under a condition have their values copied -- and
+  // waited for -- where the condition ends, in front of the tile's MFMAs)
+  M3_FETCH((long)blockIdx.x < ntiles ? (long)blockIdx.x : ntiles - 1);
   for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const long r0 = t * M3_ROWS;
     __syncthreads();                                      // previous iteration's readers of Xs / Y1s / Y2s are done
 #pragma unroll
     for (int j = 0; j < 8; ++j) Xs[(xr + 8 * j) * M3_S32 + xk] = xv[j];
     __syncthreads();
-    if (t + gridDim.x < ntiles) M3_FETCH(t + gridDim.x);
+    M3_FETCH(t + gridDim.x < ntiles ? t + gridDim.x : t);
+    __builtin_amdgcn_sched_barrier(0);
     if (ct == 0) {                                        // stage 1: 64 x 32 outputs = 2 tiles (waves 0, 1)
       f32x16 acc = m3_tile(Xs + rt * 32 * M3_S32, M3_S32, W1s, M3_S32, K1, lane);
       const float bv = B1s[lane & 31];
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void mlp3_eval_kernel(Mlp3P p) {
       }
     }
     __syncthreads();
-    {                                                     // stage 2: 64 x 64 outputs = 4 tiles
+    if (ct * 32 < p.C2) {                                 // stage 2: 64 x 64 outputs = 4 tiles (column tiles that are all padding: skipped)
       f32x16 acc = m3_tile(Y1s + rt * 32 * M3_S32, M3_S32, W2s + ct * 32 * M3_S32, M3_S32, K2, lane);
       const float bv = B2s[col];
 #pragma unroll
@@ -150,14 +156,24 @@ __global__ __launch_bounds__(256) void mlp3_eval_kernel(Mlp3P p) {
       }
     }
     __syncthreads();
-    {                                                     // stage 3 -> global
+    if (ct * 32 < p.C3) {                                 // stage 3 -> global
       f32x16 acc = m3_tile(Y2s + rt * 32 * M3_S64, M3_S64, W3s + ct * 32 * M3_S64, M3_S64, K3, lane);
       const float bv = B3s[col];
-      if (col < p.C3) {
+      // (final values in registers of their own before the first store, whole tiles stored without a predicate per element: a
+      // value computed under a store's predicate shares one register, and overwriting a store's data register waits for the store)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const long row = r0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-          if (row < p.rows) p.Y[row * p.ldy + col] = fmaxf(acc[reg] + bv, 0.f);
+      for (int reg = 0; reg < 16; ++reg) acc[reg] = fmaxf(acc[reg] + bv, 0.f);
+      if (col < p.C3) {
+        float* yp = p.Y + (r0 + rt * 32 + 4 * (lane >> 5)) * p.ldy + col;
+        if (r0 + M3_ROWS <= p.rows) {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) yp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldy] = acc[reg];
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const long row = r0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (row < p.rows) yp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldy] = acc[reg];
+          }
         }
       }
     }
@@ -180,7 +196,7 @@ extern "C" int mmego_mlp3_eval(void* stream, const float* X, long ldx, long rows
     }
   }
   const long ntiles = (rows + M3_ROWS - 1) / M3_ROWS;
-  const unsigned grid = (unsigned)(ntiles < 1024 ? ntiles : 1024);    // 83.5 KB of LDS: one workgroup per CU, 4 tiles each at most
+  const unsigned grid = (unsigned)(ntiles < 2048 ? ntiles : 2048);    // 75 KB of LDS: two workgroups per CU
   hipLaunchKernelGGL(mlp3_eval_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;

@@ -414,7 +414,12 @@ class PipelinedStages:
     The IMU_Net forwards of a stage body depend on nothing the step changes (frozen weights, the minibatch's IMU samples), so
     the forwards for minibatch i+1 can run while the trainable bodies work on minibatch i: the compute-bound half of a body
     overlaps the latency-bound half of the previous one.  One replay = [head poses of minibatch i move from the "next" to the
-    "current" buffers] -> {Upper body(i) | Lower body(i) | IMU_Net_L(i+1), IMU_Net_U(i+1)} as three concurrent branches.
+    "current" buffers] -> {Upper body(i) | Lower body(i) | IMU_Net_L(i+1) | IMU_Net_U(i+1)} as four concurrent branches: the two
+    forwards run SIDE BY SIDE (each on a stream of its own, forked from the capture's origin), so that one net's recurrent step
+    fills the launch gap / prologue / cell update of the other's -- 19.3 us per timestep and net instead of 23.4 (bench.py
+    `recurrence_graph`), 5.18 ms per U+L step instead of 5.48 with the two forwards one after the other in ONE branch
+    (MMEGO_PIPE_IMU_SIDE_BY_SIDE=0).  Within one minibatch the same pairing loses (both tails then start together, DESIGN.md
+    section 9); across minibatches nothing waits for the forwards.
     Every step still runs both IMU_Net forwards in full; results are bit-identical to ConcurrentStages on the same sequence of
     minibatches (tests/test_hip_local.py).  `imu_next` is the static buffer the caller fills with minibatch i+1's IMU samples
     before step i; `prime()` runs the forwards for the first minibatch."""
@@ -434,15 +439,21 @@ class PipelinedStages:
             st.pose = pose
         self.pair = ConcurrentStages(self.stages, use_graph=False)
         self.side = torch.cuda.Stream()
+        self.sides = [self.side] + [torch.cuda.Stream() for _ in self.imus[1:]]
+        self.side_by_side = os.environ.get("MMEGO_PIPE_IMU_SIDE_BY_SIDE", "1") != "0"
         self.use_graph, self.graph = use_graph, None
 
-    def _imu_forwards(self):
+    def _imu_forward(self, k):
         from . import blocks
+        net, (Rn, tn) = self.imus[k], self.nxt[k]
         with torch.no_grad(), blocks.two_chains(False):       # (the stage bodies run beside these forwards: see blocks.two_chains)
-            for net, (Rn, tn) in zip(reversed(self.imus), reversed(self.nxt)):      # (Lower's first, as in ConcurrentStages)
-                R, t = net(self.imu_next)
-                ops.copy2d(R.view(-1, 9), Rn.view(-1, 9))
-                ops.copy2d(t.view(-1, 3), tn.view(-1, 3))
+            R, t = net(self.imu_next)
+            ops.copy2d(R.view(-1, 9), Rn.view(-1, 9))
+            ops.copy2d(t.view(-1, 3), tn.view(-1, 3))
+
+    def _imu_forwards(self):
+        for k in reversed(range(len(self.imus))):             # (Lower's first, as in ConcurrentStages)
+            self._imu_forward(k)
 
     def prime(self):
         """Head poses of the first minibatch (its IMU samples are in `imu_next`)."""
@@ -455,6 +466,15 @@ class PipelinedStages:
         for (Rc, tc), (Rn, tn) in zip(self.cur, self.nxt):
             ops.copy2d(Rn.view(-1, 9), Rc.view(-1, 9))
             ops.copy2d(tn.view(-1, 3), tc.view(-1, 3))
+        if self.side_by_side:
+            for k in reversed(range(len(self.imus))):
+                self.sides[k].wait_stream(main)
+                with torch.cuda.stream(self.sides[k]):
+                    self._imu_forward(k)
+            self.pair._bodies(nested=True)
+            for sd in self.sides:
+                main.wait_stream(sd)
+            return
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             self._imu_forwards()
