@@ -233,6 +233,10 @@ int mmego_head_fk_backward(void* stream, int which, const float* y, const float*
                            float* dy, const float* Rw);
 /* y[F,9] -> R[F,3,3] (eps rule of IMU_Net.py:7-18), t[F,3]. */
 int mmego_imu_head(void* stream, const float* y, long F, float* R, float* t);
+/* IMU_Net.fc2 (Net/IMU_Net.py:84) and mmego_imu_head in one launch: y = X [F][K] . W[9][K]^T + b (row-wise dot products, fixed
+ * summation structure), then R, t as mmego_imu_head; y_out [F][9] optional.  K % 256 == 0, ldx % 4 == 0. */
+int mmego_imu_fc2_head(void* stream, const float* X, long ldx, const float* W, const float* b, long F, int K, float* y_out,
+                       float* R, float* t);
 /* loss[0] = sum |pred - target[:, map]|, grad = scale*sign(.) (L1Loss(reduction='sum'), Train_Upper.py:53,179);
  * loss[1] = sum of the per-joint Euclidean distances (the per-minibatch accuracy log, Train_Upper.py:183-185).
  * `loss` holds TWO floats. */

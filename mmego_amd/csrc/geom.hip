@@ -281,6 +281,67 @@ __global__ __launch_bounds__(128) void imu_head_kernel(const float* __restrict__
   }
 }
 
+// IMU_Net's last Linear (2H -> 9, Net/IMU_Net.py:84) and the head in one launch: y[r][0:9] = b + x[r][:] . W[9][K] as row-wise
+// dot products, then 6-D -> R and t.  (As a product with 9 output columns it was 16 workgroups chaining 8 dependent k-steps:
+// 13.9 us plus the head launch; here every row is one coalesced read by half a workgroup.)  One wave per 2 rows, lane l takes
+// k = 4 l + 256 i; the 64 lane sums meet in a butterfly of fixed shape: deterministic.  K % 256 == 0.
+__global__ __launch_bounds__(256) void imu_fc2_head_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ W,
+                                                           const float* __restrict__ b, long F, int K, float* __restrict__ y_out,
+                                                           float* __restrict__ R, float* __restrict__ t) {
+  const int lane = threadIdx.x & 63;
+  const long r0 = 2 * ((long)blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (r0 >= F) return;
+  const long r1 = r0 + 1 < F ? r0 + 1 : r0;
+  const f32x4* x0 = reinterpret_cast<const f32x4*>(X + r0 * ldx) + lane;
+  const f32x4* x1 = reinterpret_cast<const f32x4*>(X + r1 * ldx) + lane;
+  const f32x4* w = reinterpret_cast<const f32x4*>(W) + lane;
+  const int K4 = K >> 2;
+  float acc[2][9];
+#pragma unroll
+  for (int n = 0; n < 9; ++n) acc[0][n] = acc[1][n] = 0.f;
+  f32x4 a0 = x0[0], a1 = x1[0], wv[9];
+#pragma unroll
+  for (int n = 0; n < 9; ++n) wv[n] = w[n * K4];
+  for (int i = 0; i < K4; i += 64) {
+    const f32x4 c0 = a0, c1 = a1;
+    f32x4 cw[9];
+#pragma unroll
+    for (int n = 0; n < 9; ++n) cw[n] = wv[n];
+    const int in = i + 64 < K4 ? i + 64 : i;              // (next step's loads, unconditional on a clamped index)
+    a0 = x0[in]; a1 = x1[in];
+#pragma unroll
+    for (int n = 0; n < 9; ++n) wv[n] = w[n * K4 + in];
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+      acc[0][n] += (c0.x * cw[n].x + c0.y * cw[n].y) + (c0.z * cw[n].z + c0.w * cw[n].w);
+      acc[1][n] += (c1.x * cw[n].x + c1.y * cw[n].y) + (c1.z * cw[n].z + c1.w * cw[n].w);
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+      acc[0][n] += __shfl_xor(acc[0][n], m, 64);
+      acc[1][n] += __shfl_xor(acc[1][n], m, 64);
+    }
+  if (lane < 2 && r0 + lane < F) {
+    const long f = r0 + lane;
+    float y[9];
+#pragma unroll
+    for (int n = 0; n < 9; ++n) y[n] = (lane == 0 ? acc[0][n] : acc[1][n]) + b[n];
+    if (y_out) {
+#pragma unroll
+      for (int n = 0; n < 9; ++n) y_out[f * 9 + n] = y[n];
+    }
+    const Rot6 r = rot6d_fwd(y, 1e-8f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      R[f * 9 + i * 3 + 0] = r.x[i]; R[f * 9 + i * 3 + 1] = r.y[i]; R[f * 9 + i * 3 + 2] = r.z[i];
+      t[f * 3 + i] = y[6 + i];
+    }
+  }
+}
+
 // loss[0] = sum |pred - target[:, map]| ; grad = scale * sign(pred - target) ; loss[1] = sum of the per-joint Euclidean
 // distances (the "accuracy" the reference logs per minibatch, Train_Upper.py:183-185: mean = loss[1] / (F * nsel)).
 //   pred [F, nsel, 3]; target [F, ntgt, 3]; map[nsel] selects target joints.  One thread per joint; single block with a
@@ -409,6 +470,15 @@ extern "C" int mmego_head_fk_backward(void* stream, int which, const float* y, c
 extern "C" int mmego_imu_head(void* stream, const float* y, long F, float* R, float* t) {
   MMEGO_REQUIRE(y && R && t && F > 0);
   hipLaunchKernelGGL(imu_head_kernel, dim3(cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, y, F, R, t);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_imu_fc2_head(void* stream, const float* X, long ldx, const float* W, const float* b, long F, int K, float* y_out,
+                                  float* R, float* t) {
+  MMEGO_REQUIRE(X && W && b && R && t && F > 0 && K > 0 && (K % 256) == 0 && ldx >= K && (ldx % 4) == 0);
+  MMEGO_REQUIRE((((uintptr_t)X | (uintptr_t)W) & 15) == 0);
+  hipLaunchKernelGGL(imu_fc2_head_kernel, dim3((unsigned)cdiv(F, 8)), dim3(256), 0, (hipStream_t)stream, X, ldx, W, b, F, K, y_out, R, t);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -687,9 +687,13 @@ class IMUNet(_NetBase):
             slow = blocks.lstm_steps_forward_bf16(ar, "slow", self.rnn_slow, pooled, B, T)
         else:
             slow = blocks.lstm_steps_forward(ar, "slow", self.rnn_slow, pooled, B, T)       # [B*T, 2H]
-        y = ar.get("y", (Bn, 9))
-        ops.linear(slow, self.fc2.weight, self.fc2.bias, y)
         R = torch.empty((B, T, 3, 3), dtype=torch.float32, device=dev)
         t = torch.empty((B, T, 3), dtype=torch.float32, device=dev)
-        hip.call("imu_head", y, Bn, R, t)
+        if slow.shape[1] % 256 == 0 and slow.stride(0) % 4 == 0 and slow.stride(1) == 1 and self.fc2.weight.is_contiguous():
+            # fc2 (2H -> 9) as row-wise dot products with the head behind them, one launch
+            hip.call("imu_fc2_head", slow, slow.stride(0), self.fc2.weight, self.fc2.bias, Bn, slow.shape[1], None, R, t)
+        else:
+            y = ar.get("y", (Bn, 9))
+            ops.linear(slow, self.fc2.weight, self.fc2.bias, y)
+            hip.call("imu_head", y, Bn, R, t)
         return R, t

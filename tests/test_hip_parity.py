@@ -685,6 +685,27 @@ def test_gcn_kernels_against_torch(dev):
             assert (dW.cpu().double() - 2 * Wg.grad).abs().max().item() < 2e-5 * scale + 2e-4
 
 
+def test_imu_fc2_head_kernel(dev):
+    """mmego_imu_fc2_head (IMU_Net.fc2 as row-wise dot products + the 6-D head in one launch) against torch in fp64 and against
+    mmego_imu_head on its own y (same bits); odd row count, row-strided input."""
+    from mmego_amd import hip
+    g = torch.Generator().manual_seed(31)
+    for F, K, ld in ((37, 512, 512), (512, 1024, 1028)):
+        xw = torch.randn(F, ld, generator=g).to(dev)
+        x = xw[:, :K]
+        W, b = (torch.randn(9, K, generator=g) / K ** 0.5).to(dev), torch.randn(9, generator=g).to(dev)
+        y, R, t = torch.empty(F, 9, device=dev), torch.empty(F, 3, 3, device=dev), torch.empty(F, 3, device=dev)
+        hip.call("imu_fc2_head", x, ld, W, b, F, K, y, R, t)
+        want = x.double() @ W.double().t() + b.double()
+        assert (y.double() - want).abs().max().item() < 1e-5
+        R2, t2 = torch.empty_like(R), torch.empty_like(t)
+        hip.call("imu_head", y, F, R2, t2)
+        assert torch.equal(R, R2) and torch.equal(t, t2)
+        R3, t3 = torch.empty_like(R), torch.empty_like(t)
+        hip.call("imu_fc2_head", x, ld, W, b, F, K, None, R3, t3)
+        assert torch.equal(R, R3) and torch.equal(t, t3)
+
+
 def test_fused_adam_matches_torch(dev):
     from mmego_amd import hip
     torch.manual_seed(5)
