@@ -246,7 +246,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // FULL: Bn is a multiple of the 64 rows of a workgroup -- no row predicates, so the prologue's loads (4 input projections, 4 cell
 // states per lane) and every chunk's operand loads are straight-line code.  Predicated row by row they were a chain of
 // "branch, load, wait for everything" blocks: four dependent memory round trips before the product even started.
-template <int SK, bool FULL>  // SK: k per staged chunk (128 / 64, or 32 when H is not a multiple of 64)
+// NK > 0 (= H / SK, whole row blocks): the loads of ALL NK chunks are issued before the first one is used (NK x 5 16-byte
+// registers per thread) and each chunk waits only for its own -- with one chunk prefetched at a time, under a condition, the
+// step was a chain of NK memory round trips (the prefetched values were waited for in front of the MFMAs they should have
+// overlapped): 10.0 us per launch at Bn = 64, H = 512.
+template <int SK, bool FULL, int NK = 0>  // SK: k per staged chunk (128 / 64, or 32 when H is not a multiple of 64)
 __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
   // two stages of A [64 rows][SK + 4] and B [16 gate columns][SK + 4] (dynamic LDS: 84.5 KB at SK = 128)
   extern __shared__ __attribute__((aligned(16))) float sm_small[];
@@ -308,24 +312,55 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
     _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                            \
       if (RPP <= 16 || lr < 16) *reinterpret_cast<f32x4*>(&Bs[((buf) * 16 + lr + b * RPP) * LDK + lk]) = rbv[b]; \
   } while (0)
-    SM_GLOAD(0);
-    SM_SSTORE(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) SM_GLOAD((kt + 1) * SK);
+#define SM_MFMA(buf)                                                                                          \
+  _Pragma("unroll") for (int kb = 0; kb < SK / 16; ++kb) {                                                    \
+    f32x4 a = *reinterpret_cast<const f32x4*>(&As[((buf) * 64 + wave * 16 + fr) * LDK + kb * 16 + 4 * fq]);  \
+    f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[((buf) * 16 + fr) * LDK + kb * 16 + 4 * fq]);              \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);                                    \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);                                    \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);                                    \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);                                    \
+  }
+    if (NK > 0) {
+      // every chunk's loads in flight at once; chunk kt is pinned (waited for) only when it is stored to LDS
+      constexpr int NKK = NK > 0 ? NK : 1;
+      f32x4 qa[NKK][NA], qb[NKK][NB];
 #pragma unroll
-      for (int kb = 0; kb < SK / 16; ++kb) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(&As[(buf * 64 + wave * 16 + fr) * LDK + kb * 16 + 4 * fq]);
-        f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[(buf * 16 + fr) * LDK + kb * 16 + 4 * fq]);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
+      for (int kt = 0; kt < NKK; ++kt) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) qa[kt][a] = *reinterpret_cast<const f32x4*>(ap + a * rsp + kt * SK);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) qb[kt][b] = *reinterpret_cast<const f32x4*>(wp[b] + kt * SK);
       }
-      if (kt + 1 < nk) SM_SSTORE(buf ^ 1);
+#pragma unroll
+      for (int kt = 0; kt < NKK; ++kt) {
+        const int buf = kt & 1;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          asm volatile("" : "+v"(qa[kt][a].x), "+v"(qa[kt][a].y), "+v"(qa[kt][a].z), "+v"(qa[kt][a].w));
+          *reinterpret_cast<f32x4*>(&As[(buf * 64 + lr + a * RPP) * LDK + lk]) = qa[kt][a];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          asm volatile("" : "+v"(qb[kt][b].x), "+v"(qb[kt][b].y), "+v"(qb[kt][b].z), "+v"(qb[kt][b].w));
+          if (RPP <= 16 || lr < 16) *reinterpret_cast<f32x4*>(&Bs[(buf * 16 + lr + b * RPP) * LDK + lk]) = qb[kt][b];
+        }
+        __syncthreads();                         // (two LDS stages: chunk kt+1 is stored while others may still read chunk kt-1's
+        SM_MFMA(buf)                             //  stage -- which the barrier of chunk kt has already retired)
+      }
+    } else {
+      SM_GLOAD(0);
+      SM_SSTORE(0);
       __syncthreads();
+      for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) SM_GLOAD((kt + 1) * SK);
+        SM_MFMA(buf)
+        if (kt + 1 < nk) SM_SSTORE(buf ^ 1);
+        __syncthreads();
+      }
     }
+#undef SM_MFMA
 #undef SM_GLOAD
 #undef SM_SSTORE
   }
@@ -418,6 +453,7 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
     const bool full = (Bn % 64) == 0;
     // (128-k chunks -- half as many dependent chunk round trips, 84.5 KB of LDS -- measured the same 9.9-10.0 us: kept for A/B runs)
     static const int small_sk = getenv("MMEGO_STEP_SMALL_SK") ? atoi(getenv("MMEGO_STEP_SMALL_SK")) : 64;
+    static const int small_all = getenv("MMEGO_STEP_SMALL_ALL") ? atoi(getenv("MMEGO_STEP_SMALL_ALL")) : 1;   // (0: one chunk ahead, for A/B runs)
 #define SMALL_LAUNCH(SK_, F_)                                                                                        \
   do {                                                                                                               \
     const size_t lds = (size_t)2 * (64 + 16) * (SK_ + 4) * sizeof(float);                                            \
@@ -431,6 +467,10 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
     hipLaunchKernelGGL((lstm_step_small_kernel<SK_, F_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);       \
   } while (0)
     if ((H % 128) == 0 && small_sk == 128) { if (full) SMALL_LAUNCH(128, true); else SMALL_LAUNCH(128, false); }
+    else if (H == 512 && full && small_all) {              // whole row blocks at IMU_Net's width: all eight chunks' loads up front
+      const size_t lds = (size_t)2 * (64 + 16) * (64 + 4) * sizeof(float);
+      hipLaunchKernelGGL((lstm_step_small_kernel<64, true, 8>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    }
     else if ((H % 64) == 0) { if (full) SMALL_LAUNCH(64, true); else SMALL_LAUNCH(64, false); }
     else { if (full) SMALL_LAUNCH(32, true); else SMALL_LAUNCH(32, false); }
 #undef SMALL_LAUNCH
