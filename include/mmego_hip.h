@@ -208,6 +208,15 @@ int mmego_lstm_cell_backward(void* stream, int ndir, int Bn, int H, const float*
  * gradients wrt R [F,3,3] and t [F,3] (scaled by `scale`). */
 int mmego_imu_loss(void* stream, const float* R, const float* t, const float* R_gt, const float* head_gt, long F,
                    float scale, float* loss, float* dR, float* dt);
+/* One step of a BiLSTM layer's backward recurrence, both directions: dh_rec = dgates_s [Bn][4H] (row stride dgs) . W_hh (given
+ * transposed, wT [H][4H]) with the cell backward of the next step of the backward pass applied on the product's tiles (same
+ * arithmetic as mmego_lstm_cell_backward: dh = dout + dh_rec; gst / cst / cprev: that step's forward stashes, cprev NULL at the
+ * sequence start; dc updated in place; dgo: that step's gate gradients, row stride dgs).  Replaces product + cell-backward
+ * launches of the reference's nn.LSTM autograd (Train_IMU.py:114-149).  Bn, H multiples of 32. */
+int mmego_lstm_bwd_step(void* stream, int Bn, int H, const float* dg0, const float* dg1, long dgs, const float* wT0,
+                        const float* wT1, const float* dout0, const float* dout1, long dos, const float* gst0,
+                        const float* gst1, const float* cst0, const float* cst1, const float* cprev0, const float* cprev1,
+                        float* dc0, float* dc1, float* dgo0, float* dgo1);
 /* Backward of mmego_imu_head: (dR [F,3,3], dt [F,3]) -> dy [F,9]. */
 int mmego_imu_head_backward(void* stream, const float* y, const float* dR, const float* dt, long F, float* dy);
 

@@ -30,6 +30,11 @@ struct GemmP {
   const float* cmul;  // optional elementwise multiplier in C's layout, applied last (a dropout mask on an input gradient)
   float* asum;        // optional: asum[b][m] (+)= sum_k A[b](m,k) -- the bias gradient beside a weight gradient dW = dY^T X
                       // (gemm32kq only; with split-K the slab sums go behind the product slabs and the reducer finishes them)
+  // optional LSTM cell-backward epilogue (gemm32kq, unsplit, batch = direction; mmego_lstm_bwd_step): the product is dh_rec of the
+  // step before, which only the cell backward of that step consumes -- it is applied to the tile's elements instead of storing C
+  const float* cb_dout[2]; long cb_dos;
+  const float* cb_gst[2]; const float* cb_cst[2]; const float* cb_cprev[2];
+  float* cb_dc[2]; float* cb_dg[2]; long cb_dgs;
 };
 
 #define LD64 68
@@ -261,6 +266,45 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
     } else {                                               // slab sums: [split][batch][M] behind the product slabs
       p.asum[((long)split * (gridDim.z / p.nsplit) + batch) * p.M + m0 + tid] = v;
     }
+  }
+  if (p.cb_dg[0]) {
+    // LSTM cell backward on the tile (the expressions of lstm_cell_bwd_kernel, imu_train.hip: same bits): whole tiles only (the
+    // launcher checks), N = H; every load of the thread's four elements before its first store
+    const int col = tid & 31, H = p.N, d = batch;
+    float dh[4], gi[4], gf[4], gg[4], go[4], cc[4], cp[4], dcin[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = (tid >> 5) + 8 * e;
+      const long r = m0 + row, j = n0 + col, i = r * H + j;
+      const float rec = ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+      const float* gs = p.cb_gst[d] + r * 4 * H + j;
+      dh[e] = p.cb_dout[d][r * p.cb_dos + j] + rec;
+      gi[e] = gs[0]; gf[e] = gs[H]; gg[e] = gs[2 * H]; go[e] = gs[3 * H];
+      cc[e] = p.cb_cst[d][i];
+      cp[e] = p.cb_cprev[d] ? p.cb_cprev[d][i] : 0.f;
+      dcin[e] = p.cb_dc[d][i];
+    }
+    float o0[4], o1[4], o2[4], o3[4], dco[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      asm volatile("" : "+v"(gi[e]), "+v"(gf[e]), "+v"(gg[e]), "+v"(go[e]), "+v"(cc[e]), "+v"(cp[e]), "+v"(dcin[e]), "+v"(dh[e]));
+      const float tc = tanhf(cc[e]);
+      const float dcv = dcin[e] + dh[e] * go[e] * (1.f - tc * tc);
+      o0[e] = dcv * gg[e] * gi[e] * (1.f - gi[e]);
+      o1[e] = dcv * cp[e] * gf[e] * (1.f - gf[e]);
+      o2[e] = dcv * gi[e] * (1.f - gg[e] * gg[e]);
+      o3[e] = dh[e] * tc * go[e] * (1.f - go[e]);
+      dco[e] = dcv * gf[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = (tid >> 5) + 8 * e;
+      const long r = m0 + row, j = n0 + col;
+      float* dg = p.cb_dg[d] + r * p.cb_dgs + j;
+      dg[0] = o0[e]; dg[H] = o1[e]; dg[2 * H] = o2[e]; dg[3 * H] = o3[e];
+      p.cb_dc[d][r * H + j] = dco[e];
+    }
+    return;
   }
   // (options' loads for all four elements first, from clamped addresses, then the stores: see gemm64_kernel's epilogue)
   float* C = p.C + (long)batch * p.sCb + (long)split * p.sCs;
@@ -505,6 +549,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   p.relu = relu; p.accumulate = accumulate;
   p.cmul = cmul;
   p.asum = asum;
+  p.cb_dg[0] = p.cb_dg[1] = nullptr;
   if (nsplit > 1) {
     MMEGO_REQUIRE(splitk_ws != nullptr);
     int kc = cdiv(K, nsplit);
@@ -545,5 +590,36 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
                        scm, scn, sCb, relu, accumulate, (const float*)p.asum, asum);
     MMEGO_LAUNCH_CHECK();
   }
+  return MMEGO_OK;
+}
+
+// One step of the backward recurrence of a BiLSTM layer (stage-1 training, reference autograd of nn.LSTM): for both directions
+// dh_rec = dgates_s . W_hh (A = dgates of step s, rows Bn, K = 4H; wT = W_hh transposed [H][4H]) and, on the product's tiles, the
+// cell backward of the step BEFORE in time order of the backward pass (dh = dout + dh_rec, gate / cell gradients from the forward
+// stashes) -- one launch instead of product + lstm_cell_backward, and dh_rec never reaches memory.  Bn, H multiples of 32.
+extern "C" int mmego_lstm_bwd_step(void* stream, int Bn, int H, const float* dg0, const float* dg1, long dgs, const float* wT0,
+                                   const float* wT1, const float* dout0, const float* dout1, long dos, const float* gst0,
+                                   const float* gst1, const float* cst0, const float* cst1, const float* cprev0,
+                                   const float* cprev1, float* dc0, float* dc1, float* dgo0, float* dgo1) {
+  MMEGO_REQUIRE(Bn > 0 && H > 0 && (Bn % 32) == 0 && (H % 32) == 0 && dg0 && dg1 && wT0 && wT1 && dout0 && dout1 && gst0 && gst1 &&
+                cst0 && cst1 && dc0 && dc1 && dgo0 && dgo1 && (cprev0 == nullptr) == (cprev1 == nullptr));
+  MMEGO_REQUIRE((dgs % 4) == 0 && ((((uintptr_t)dg0) | ((uintptr_t)dg1) | ((uintptr_t)wT0) | ((uintptr_t)wT1)) & 15) == 0);
+  GemmP p;
+  p.A = dg0; p.B = wT0; p.C = nullptr; p.bias = nullptr;
+  p.sam = dgs; p.sak = 1; p.sbk = 1; p.sbn = 4L * H;
+  p.sAb = dg1 - dg0; p.sBb = wT1 - wT0; p.sBiasb = 0;
+  p.scm = H; p.scn = 1; p.sCb = 0; p.sCs = 0;
+  p.M = Bn; p.N = H; p.K = 4 * H;
+  p.nsplit = 1; p.kchunk = cdiv(p.K, 16) * 16;
+  p.relu = 0; p.accumulate = 0;
+  p.cmul = nullptr; p.asum = nullptr;
+  p.avec = (p.sAb % 4) == 0; p.bvec = (p.sBb % 4) == 0;
+  p.cb_dout[0] = dout0; p.cb_dout[1] = dout1; p.cb_dos = dos;
+  p.cb_gst[0] = gst0; p.cb_gst[1] = gst1; p.cb_cst[0] = cst0; p.cb_cst[1] = cst1;
+  p.cb_cprev[0] = cprev0; p.cb_cprev[1] = cprev1;
+  p.cb_dc[0] = dc0; p.cb_dc[1] = dc1; p.cb_dg[0] = dgo0; p.cb_dg[1] = dgo1; p.cb_dgs = dgs;
+  dim3 grid(Bn / 32, H / 32, 2);
+  hipLaunchKernelGGL((gemm32kq_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -5,6 +5,8 @@ The recurrent products of the backward pass run as split-K mmego_gemm calls (one
 per-layer transposed W_hh); input and weight gradients of the projections run on the large-tile kernels in their
 natural operand orientation (dX = dY . W: NN, dW = dY^T . X: TN).
 """
+import os
+
 import torch
 
 from . import blocks, hip, ops
@@ -45,14 +47,24 @@ def lstm_steps_backward(ar, key, lstm, x, Bn, T, dout, G, need_dx):
             hip.call("transpose_batched", lstm.w("weight_hh", l, d), wT[d], 1, 4 * H, H)      # [4H,H] -> [H,4H]
         dg3 = dg.view(Bn, T, 8 * H)
         dcur3 = d_cur.view(Bn, T, 2 * H)
+        fused = Bn % 32 == 0 and H % 32 == 0 and os.environ.get("MMEGO_LSTM_BWD_FUSED", "1") != "0"
         for s in range(T - 1, -1, -1):
             t0, t1 = s, T - 1 - s
             last = s == T - 1
+            if fused and not last:
+                # the product dh_rec = dgates_{s+1} . W_hh of both directions with THIS step's cell backward on its tiles: one launch,
+                # dh_rec never leaves the CU (mmego_lstm_bwd_step; same arithmetic as the two launches below)
+                p0, p1 = s + 1, T - 1 - (s + 1)          # time indices of the step before in backward order
+                hip.call("lstm_bwd_step", Bn, H, dg3[:, p0, :4 * H], dg3[:, p1, 4 * H:], T * 8 * H, wT[0], wT[1],
+                         dcur3[:, t0, :H], dcur3[:, t1, H:], T * 2 * H, gst[0, t0], gst[1, t1], cst[0, t0], cst[1, t1],
+                         cst[0, t0 - 1] if s > 0 else None, cst[1, t1 + 1] if s > 0 else None, dc[0], dc[1],
+                         dg3[:, t0, :4 * H], dg3[:, t1, 4 * H:])
+                continue
             hip.call("lstm_cell_backward", 2, Bn, H, dcur3[:, t0, :H], dcur3[:, t1, H:], T * 2 * H,
                      None if last else dhrec[0], None if last else dhrec[1], gst[0, t0], gst[1, t1], cst[0, t0], cst[1, t1],
                      cst[0, t0 - 1] if s > 0 else None, cst[1, t1 + 1] if s > 0 else None, dc[0], dc[1],
                      dg3[:, t0, :4 * H], dg3[:, t1, 4 * H:], T * 8 * H)
-            if s > 0:
+            if s > 0 and not fused:
                 # dh_{t-1} = dgates_t . W_hh for BOTH directions in one batched launch (few tiles, K = 4H: the K-quartered
                 # small-GEMM kernel, in-workgroup K split, no separate reduce; measured 35 us against 42 us as a batched split-K
                 # tile product and 2 x 27 us as two split-K calls): this product sits on the serial backward chain.

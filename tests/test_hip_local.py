@@ -193,7 +193,7 @@ def test_imu_stage1_training(dev):
         assert (ph.grad.cpu() - go).abs().max().item() < 2e-4 * scale, k
 
 
-def test_imu_stage1_gradients_at_full_size(dev):
+def test_imu_stage1_gradients_at_full_size(dev, monkeypatch):
     """Stage-1 backward at the REAL size: IMUNet(15, 9, 512, 2) with 128 and 512 rnn_fast rows -- the
     dispatch the 8.9 ms/step figure runs on (persistent 128x128 tile products in NN / TN orientation with split-K, the batched
     K-quartered dh launch, lstm_step_dma2_kernel with gate and cell stashes) -- against the oracle's autograd: every gradient
@@ -223,6 +223,17 @@ def test_imu_stage1_gradients_at_full_size(dev):
             go = po[k].grad if po[k].grad is not None else torch.zeros_like(po[k])
             err = (ph.grad.cpu() - go).abs().max().item()
             assert err < 2e-4 * scale, (Bq, Tq, k, err, scale)
+        # the backward recurrence's fused launch (product + cell backward on its tiles, mmego_lstm_bwd_step) gives the bits of the
+        # two separate launches
+        fused = {k: ph.grad.clone() for k, ph in hb.named_parameters()}
+        monkeypatch.setenv("MMEGO_LSTM_BWD_FUSED", "0")
+        for ph in hb.parameters():
+            ph.grad = None
+        Rh2, th2 = hb(imu.to(dev))
+        ((Rh2 * wR.to(dev)).sum() + (th2 * wt.to(dev)).sum()).backward()
+        monkeypatch.delenv("MMEGO_LSTM_BWD_FUSED")
+        for k, ph in hb.named_parameters():
+            assert torch.equal(ph.grad, fused[k]), (Bq, Tq, k)
     # one optimiser step as Train_IMU.py:71-72 configures it (lr 1e-4 is the CLI's; weight_decay 1e-3)
     before = {k: v.clone() for k, v in o.state_dict().items()}
     opt_o = torch.optim.Adam(o.parameters(), lr=1e-4, weight_decay=0.001)
