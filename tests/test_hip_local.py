@@ -196,7 +196,7 @@ def test_imu_stage1_training(dev):
 def test_imu_stage1_gradients_at_full_size(dev, monkeypatch):
     """Stage-1 backward at the REAL size: IMUNet(15, 9, 512, 2) with 128 and 512 rnn_fast rows -- the
     dispatch the 8.9 ms/step figure runs on (persistent 128x128 tile products in NN / TN orientation with split-K, the batched
-    K-quartered dh launch, lstm_step_dma2_kernel with gate and cell stashes) -- against the oracle's autograd: every gradient
+    K-quartered dh launch with the cell backward on its tiles, lstm_step_dma_kernel with gate and cell stashes) -- against the oracle's autograd: every gradient
     element, 2e-4 of the largest gradient.  Then one Adam step with Train_IMU's weight decay: fc3 (never used in forward, Q7)
     must stay untouched, as under torch.optim.Adam (its .grad is None there), everything else must match torch's update."""
     from mmego_amd import nets
