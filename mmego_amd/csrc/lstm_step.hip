@@ -386,6 +386,50 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepP p) {
   }
 }
 
+// ---- the FIRST timestep of a sequence (h = c = 0): no product, gates = xproj + b_hh -- an elementwise pass ------------------
+// (Through the step kernels it cost their whole fixed part -- operand staging skipped, but workgroup set-up, the LDS output tile
+// and its barriers kept: 5.8-6.4 us per launch at Bn = 512; eight such launches per U+L step.)  Same expressions as the step
+// kernels' cell update with c_{t-1} = 0: same bits.  One thread per row and four hidden units.
+__global__ __launch_bounds__(256) void lstm_first_step_kernel(LstmStepP p) {
+  const int d = blockIdx.y, H = p.H, H4 = H >> 2;
+  const long n = (long)p.Bn * H4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / H4;
+    const int j = (int)(i - row * H4) * 4;
+    const float* xr = p.xproj[d] + row * p.xs + j;
+    f32x4 x[4], b[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) x[g] = *reinterpret_cast<const f32x4*>(xr + (long)g * H);
+    if (p.bhh[d]) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(p.bhh[d] + g * H + j);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 gi, gf, gg, go, cn, hn;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gi[u] = fast_sigmoid(x[0][u] + b[0][u]);
+      gf[u] = fast_sigmoid(x[1][u] + b[1][u]);
+      gg[u] = fast_tanh(x[2][u] + b[2][u]);
+      go[u] = fast_sigmoid(x[3][u] + b[3][u]);
+      cn[u] = gi[u] * gg[u];                     // (= gf * 0 + gi * gg of the step kernels)
+      hn[u] = go[u] * fast_tanh(cn[u]);
+    }
+    *reinterpret_cast<f32x4*>(p.c[d] + row * H + j) = cn;
+    *reinterpret_cast<f32x4*>(p.hout[d] + row * p.hos + j) = hn;
+    if (p.gst[d]) {
+      float* gs = p.gst[d] + row * 4 * H + j;
+      *reinterpret_cast<f32x4*>(gs) = gi;
+      *reinterpret_cast<f32x4*>(gs + H) = gf;
+      *reinterpret_cast<f32x4*>(gs + 2 * H) = gg;
+      *reinterpret_cast<f32x4*>(gs + 3 * H) = go;
+      *reinterpret_cast<f32x4*>(p.cst[d] + row * H + j) = cn;
+    }
+  }
+}
+
 #ifdef MMEGO_STAMP
 static int mmego_step_dbg = 0;
 #endif
@@ -415,7 +459,13 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
 #ifdef MMEGO_STAMP
   p.dbg = mmego_step_dbg;
 #endif
-  if (Bn >= 128) {
+  static const int first_ew = getenv("MMEGO_STEP_FIRST_ELEMENTWISE") ? atoi(getenv("MMEGO_STEP_FIRST_ELEMENTWISE")) : 1;
+  const uintptr_t al = (uintptr_t)bhh0 | (uintptr_t)bhh1 | (uintptr_t)gst0 | (uintptr_t)gst1 | (uintptr_t)cst0 | (uintptr_t)cst1 |
+                       (uintptr_t)c1 | (uintptr_t)hout1 | (uintptr_t)xproj1;
+  if (first && first_ew && (H % 4) == 0 && (al & 15) == 0) {
+    long b = ((long)Bn * (H / 4) + 255) / 256;
+    hipLaunchKernelGGL(lstm_first_step_kernel, dim3((unsigned)(b > 2048 ? 2048 : b), ndir), dim3(256), 0, (hipStream_t)stream, p);
+  } else if (Bn >= 128) {
     // HT = 32 by default; MMEGO_STEP_HT=16 selects the two-workgroups-per-CU variant for A/B runs (its product loop is
     // shorter, 37.9 k against 41.1 k cycles, but its prologue -- twice the workgroups fetching first chunks -- costs more)
     static const int force_ht = getenv("MMEGO_STEP_HT") ? atoi(getenv("MMEGO_STEP_HT")) : 0;
