@@ -319,7 +319,6 @@ class ConcurrentStages:
         self.use_graph = use_graph
         self.graph = None
         self.side = [torch.cuda.Stream() for _ in self.stages[1:]]
-        self._poses = {}
         # data parallel: the stages' gradients share one buffer, so one collective per step serves all of them
         self.bucket = None
         pgs = {id(st.pg) for st in self.stages}
@@ -356,11 +355,9 @@ class ConcurrentStages:
                     # later ones have another stage's tail beside them, which fills the same gaps (blocks.two_chains)
                     alone = i == len(stages) - 1 and os.environ.get("MMEGO_FIRST_IMU_TWO_CHAINS", "1") != "0"
                     with torch.no_grad(), blocks.two_chains(alone):
-                        R, t = st.imu(st.static["imu"])
-                        pose = self._pose_buf(i, R, t)
-                        ops.copy2d(R.view(-1, 9), pose[0].view(-1, 9))
-                        ops.copy2d(t.view(-1, 3), pose[1].view(-1, 3))
-                    st.pose = pose
+                        # (the forward's own output tensors serve as the stage's head pose: they stay referenced -- and, under
+                        # capture, reserved in the graph's pool -- until every branch has been enqueued; no copies)
+                        st.pose = st.imu(st.static["imu"])
                 if i > 0:
                     streams[i].wait_stream(main)
                     with torch.cuda.stream(streams[i]):
@@ -372,12 +369,6 @@ class ConcurrentStages:
                 st.imu, st.pose = imu, pose
         for side in self.side:
             main.wait_stream(side)
-
-    def _pose_buf(self, i, R, t):
-        buf = self._poses.get(i)
-        if buf is None or buf[0].shape != R.shape:
-            buf = self._poses[i] = (torch.empty_like(R), torch.empty_like(t))
-        return buf
 
     def prepare(self):
         """Warm-up (side-effect free) and graph capture, so that the first step() costs what every step costs."""
