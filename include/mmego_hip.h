@@ -222,8 +222,12 @@ int mmego_imu_head_backward(void* stream, const float* y, const float* dR, const
 
 /* ---- geometry, heads, loss, selection (geom.hip) --------------------------------------------------
  * In-place xyz <- R (xyz - t) per frame (Utils.py:284-292, quirk Q1: the caller's buffer is mutated).
- * src (may be NULL): xyz is read from src [F*P, 3] instead of pts (copy + transform, one launch). */
-int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t, const float* src);
+ * src (may be NULL): the points are read from src instead of pts (copy + transform, one launch); src_ld = 3: src holds xyz only,
+ * src_ld >= C: whole rows, the channels behind xyz are copied too.  keep (may be NULL, [F*P][C]) and feats (may be NULL: the first
+ * nfeat channels, row stride ldf) receive the transformed rows as well (Upper_Net.py:392-395 makes those copies right behind the
+ * transform).  C <= 8 when any row copy is asked for. */
+int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t, const float* src,
+                      long src_ld, float* keep, float* feats, long ldf, int nfeat);
 /* out = R^T in + t (transpose=1, add_t=1: Utils.py:274-281) or out = R in (its backward). */
 int mmego_rotate_points(void* stream, const float* in, float* out, long F, int P, const float* R, const float* t,
                         int transpose, int add_t);

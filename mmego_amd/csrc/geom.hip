@@ -14,20 +14,47 @@ __device__ __forceinline__ float dot3_nofma(float a0, float a1, float a2, float 
 }
 
 // pts[f, p, 0:3] <- R[f] . (pts[f, p, 0:3] - t[f])   IN PLACE (reference quirk Q1)
-// src (optional): read the points from src [npts, 3] instead (out of place: a copy + transform in one launch)
+// src (optional): read the points from src instead (out of place: a copy + transform in one launch).  src_ld = 3: src holds the
+// xyz only; src_ld >= C: whole rows, the channels behind xyz are copied as well (a training step's fresh minibatch).
+// keep (optional, [npts][C]) and feats (optional, the first nfeat channels, row stride ldf) receive the transformed rows too --
+// the copies Upper_Net's forward makes right behind the transform (the tensor stashed for backward, the xyz + intensity columns of
+// the concatenated feature buffer).
 __global__ __launch_bounds__(256) void transform2h_kernel(float* pts, int P, int C, const float* __restrict__ R,
-                                                          const float* __restrict__ t, long npts, const float* src) {
+                                                          const float* __restrict__ t, long npts, const float* src, long src_ld,
+                                                          float* __restrict__ keep, float* __restrict__ feats, long ldf, int nfeat) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npts) return;
   long f = i / P;
   const float* Rf = R + f * 9;
   const float* tf = t + f * 3;
   float* x = pts + i * C;
-  const float* xs = src ? src + i * 3 : x;
+  const float* xs = src ? src + i * src_ld : x;
   float d0 = __fsub_rn(xs[0], tf[0]), d1 = __fsub_rn(xs[1], tf[1]), d2 = __fsub_rn(xs[2], tf[2]);
-  x[0] = dot3_nofma(Rf[0], Rf[1], Rf[2], d0, d1, d2);
-  x[1] = dot3_nofma(Rf[3], Rf[4], Rf[5], d0, d1, d2);
-  x[2] = dot3_nofma(Rf[6], Rf[7], Rf[8], d0, d1, d2);
+  float v[8];
+  v[0] = dot3_nofma(Rf[0], Rf[1], Rf[2], d0, d1, d2);
+  v[1] = dot3_nofma(Rf[3], Rf[4], Rf[5], d0, d1, d2);
+  v[2] = dot3_nofma(Rf[6], Rf[7], Rf[8], d0, d1, d2);
+  const bool rest = (src && src_ld >= C) || keep || (feats && nfeat > 3);        // (uniform)
+  if (rest) {
+    const float* xo = (src && src_ld >= C) ? xs : x;
+#pragma unroll
+    for (int c = 3; c < 8; ++c) v[c] = c < C ? xo[c] : 0.f;
+  }
+  x[0] = v[0]; x[1] = v[1]; x[2] = v[2];
+  if (src && src_ld >= C) {
+#pragma unroll
+    for (int c = 3; c < 8; ++c) if (c < C) x[c] = v[c];
+  }
+  if (keep) {
+    float* k = keep + i * C;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < C) k[c] = v[c];
+  }
+  if (feats) {
+    float* q = feats + i * ldf;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < nfeat) q[c] = v[c];
+  }
 }
 
 // out[f, p, :] = R[f]^T . in[f, p, :] + t[f]     (transpose=1, Transform2R)
@@ -427,10 +454,15 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t, const float* src) {
+extern "C" int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t, const float* src,
+                                 long src_ld, float* keep, float* feats, long ldf, int nfeat) {
   MMEGO_REQUIRE(pts && R && t && F > 0 && P > 0 && C >= 3);
+  MMEGO_REQUIRE(!src || src_ld == 3 || src_ld >= C);
+  MMEGO_REQUIRE((!keep && !feats && !(src && src_ld >= C)) || C <= 8);
+  MMEGO_REQUIRE(!feats || (nfeat >= 1 && nfeat <= C && nfeat <= 8 && ldf >= nfeat));
   long n = F * P;
-  hipLaunchKernelGGL(transform2h_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, P, C, R, t, n, src);
+  hipLaunchKernelGGL(transform2h_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, P, C, R, t, n, src, src_ld, keep,
+                     feats, ldf, nfeat);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -189,25 +189,37 @@ class UpperNet(_NetBase):
         return self._forward_impl(*args, stash=False)
 
     # -- pipelines ---------------------------------------------------------------------------------
-    def _forward_impl(self, x, h0, c0, body, R, t, stash=True):
+    def _forward_impl(self, x, h0, c0, body, R, t, stash=True, x_src=None):
+        """x_src (optional, x's shape): the minibatch is read from there and x receives the transformed copy (one launch for a
+        trainer's 'fresh batch' copy and the transform)."""
         self.flat()
         training = self.training
         ar = self.arena("train" if stash else "eval")
         if not (x.dtype == torch.float32 and x.is_contiguous()):
             raise ValueError("UpperNet: x must be a contiguous fp32 tensor (it is transformed in place)")
+        if x_src is not None and not (x_src.dtype == torch.float32 and x_src.is_contiguous() and x_src.shape == x.shape):
+            raise ValueError("UpperNet: x_src must be a contiguous fp32 tensor of x's shape")
         B, T, N, Cx = x.shape
         F, rows = B * T, B * T * N
         R, t, body = _f32c(R), _f32c(t), _f32c(body)
         h0 = _f32c(h0) if h0 is not None else None
         c0 = _f32c(c0) if c0 is not None else None
-        ops.transform2h_(x, R, t)                                   # Q1: in place on the caller's tensor
-        pts = x.view(rows, Cx)
-        if stash:
-            keep = ar.get("pts", (rows, Cx))
-            ops.copy2d(pts, keep)
-            pts = keep
         feats = ar.get("feats", (rows, 28))
-        ops.copy2d(pts[:, :4], feats[:, :4])
+        keep = ar.get("pts", (rows, Cx)) if stash else None
+        if Cx <= 8:
+            # Q1: in place on the caller's tensor; the copy kept for backward and the xyz + intensity columns of the feature buffer
+            # leave from the same launch, and a trainer's fresh minibatch (x_src) enters through it
+            ops.transform2h_(x, R, t, src=x_src, keep=keep, feats=feats, nfeat=4)
+            pts = keep if stash else x.view(rows, Cx)
+        else:
+            if x_src is not None:
+                ops.copy2d(x_src.view(rows, Cx), x.view(rows, Cx))
+            ops.transform2h_(x, R, t)
+            pts = x.view(rows, Cx)
+            if stash:
+                ops.copy2d(pts, keep)
+                pts = keep
+            ops.copy2d(pts[:, :4], feats[:, :4])
         blocks.mlp3_forward(ar, "m0", self.module0, pts, feats[:, 4:28], training)
         g3 = ar.get("g3", (rows, 64))
         blocks.mlp3_forward(ar, "gp", self.module1.gpointnet, feats, g3, training)

@@ -364,19 +364,36 @@ def bn_backward_pair(dY, Ymask, X1, st1, dgamma1, dbeta1, dX1, X2, st2, dgamma2,
              X2, X2.stride(0), st2.mean, st2.invstd, st2.a, dgamma2, dbeta2, dX2, dX2.stride(0))
 
 
-def transform2h_(pts, R, t, src=None):
-    """In place on pts [F, P, C] (or any contiguous view of it); src [F, P, 3] (optional): the xyz are read from there."""
+def transform2h_(pts, R, t, src=None, keep=None, feats=None, nfeat=0):
+    """In place on pts [F, P, C] (or any contiguous view of it).  src (optional): the points are read from there -- [F, P, 3]
+    (xyz only) or a tensor of pts' shape (whole rows: the other channels are copied along).  keep (optional, pts' shape) and
+    feats (optional 2-D [F*P, >= nfeat] view with unit column stride: its first nfeat columns) receive the transformed rows too."""
     _chk(pts)
     if not pts.is_contiguous():
         raise ValueError("transform2h_ needs a contiguous point tensor")
-    if src is not None and not (src.is_contiguous() and src.dtype == torch.float32 and src.numel() * pts.shape[-1] == 3 * pts.numel()):
-        raise ValueError("transform2h_: src must be a contiguous fp32 [.., 3] tensor with one row per point")
     F = R.numel() // 9
     C = pts.shape[-1]
     P = pts.numel() // (F * C)
+    src_ld = 0
+    if src is not None:
+        if not (src.is_contiguous() and src.dtype == torch.float32):
+            raise ValueError("transform2h_: src must be a contiguous fp32 tensor")
+        if src.numel() * C == 3 * pts.numel():
+            src_ld = 3
+        elif src.numel() == pts.numel():
+            src_ld = C
+        else:
+            raise ValueError("transform2h_: src must hold one xyz row or one whole row per point")
+    if keep is not None and not (keep.is_contiguous() and keep.dtype == torch.float32 and keep.numel() == pts.numel()):
+        raise ValueError("transform2h_: keep must be a contiguous fp32 tensor of pts' size")
+    ldf = 0
+    if feats is not None:
+        if not (feats.dim() == 2 and feats.stride(1) == 1 and feats.shape[0] * C == pts.numel() and 1 <= nfeat <= min(C, feats.shape[1])):
+            raise ValueError("transform2h_: feats must be a [points, >= nfeat] view with unit column stride")
+        ldf = feats.stride(0)
     if not (R.is_contiguous() and t.is_contiguous() and t.numel() == 3 * F):
         raise ValueError("R/t must be contiguous [F,3,3]/[F,3]")
-    hip.call("transform2h", pts, F, P, C, R, t, src)
+    hip.call("transform2h", pts, F, P, C, R, t, src, src_ld, keep, feats, ldf, nfeat)
     return pts
 
 

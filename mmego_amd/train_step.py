@@ -129,7 +129,13 @@ class StageStep:
         """Fresh batch, head pose, forward of the trained net (and of the frozen Upper_Net in the Lower stage), loss."""
         s = self.static
         B, T = s["x"].shape[0], s["x"].shape[1]
-        ops.copy2d(s["x_src"].view(B * T, -1), s["x"].view(B * T, -1))        # fresh batch (x is transformed in place)
+        from .nets import UpperNet
+        first_net = self.net if self.stage == "upper" else self.upper_frozen
+        # fresh batch (x is transformed in place): Upper_Net's transform launch reads it from x_src; other nets get a copy first
+        via_transform = type(first_net) is UpperNet and s["x"].shape[-1] <= 8
+        if not via_transform:
+            ops.copy2d(s["x_src"].view(B * T, -1), s["x"].view(B * T, -1))
+        x_src = s["x_src"] if via_transform else None
         with torch.no_grad():
             if self.pose is not None:
                 R, t = self.pose
@@ -139,10 +145,18 @@ class StageStep:
                 R, t = s["R_gt"], s["t_gt"]
                 ops.copy2d(s["target"].view(B * T, 63)[:, 60:63], t.view(B * T, 3))
             if self.stage == "upper":
-                l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["body"], R, t, stash=True)[0]
+                if via_transform:
+                    l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["body"], R, t, stash=True, x_src=x_src)[0]
+                else:
+                    l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["body"], R, t, stash=True)[0]
                 nsel = 15
             else:
-                up = self.upper_frozen(s["x"], s["h0"], s["c0"], s["body"], R, t)[0]
+                if via_transform and not self.upper_frozen.training:
+                    up = self.upper_frozen._forward_impl(s["x"], s["h0"], s["c0"], s["body"], R, t, stash=False, x_src=x_src)[0]
+                else:
+                    if via_transform:
+                        ops.copy2d(s["x_src"].view(B * T, -1), s["x"].view(B * T, -1))
+                    up = self.upper_frozen(s["x"], s["h0"], s["c0"], s["body"], R, t)[0]
                 l = self.net._forward_impl(up, s["x"], s["body"], R, t, stash=True)[0]
                 nsel = 8
             hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss2, s["dl"])

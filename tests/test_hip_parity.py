@@ -279,6 +279,15 @@ def test_transform_bit_exact(dev, real16):
     p = T(g1["pts"]).to(dev)
     ops.transform2h_(p, T(g1["R"]).to(dev), T(g1["t"]).to(dev))
     assert torch.equal(p.cpu(), T(g1["mutated"]))
+    # the same launch fed from a source tensor (whole rows), with the two copies Upper_Net's forward takes behind the transform
+    src = x.to(dev)
+    dst = torch.full_like(src, float("nan"))
+    keep = torch.full_like(src, float("nan"))
+    feats = torch.full((src.numel() // src.shape[-1], 28), float("nan"), device=dev)
+    ops.transform2h_(dst, R.to(dev), t.to(dev), src=src, keep=keep, feats=feats, nfeat=4)
+    assert torch.equal(src.cpu(), x), "the source is left alone"
+    assert torch.equal(dst.cpu(), ref) and torch.equal(keep.cpu(), ref)
+    assert torch.equal(feats[:, :4].cpu(), ref.view(-1, ref.shape[-1])[:, :4]) and torch.isnan(feats[:, 4:]).all()
 
 
 def test_transforms_through_utils_surface(dev):
