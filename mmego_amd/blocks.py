@@ -351,8 +351,13 @@ def lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T, gst=None, cst=None):
     if _LSTM_TWO_CHAINS and T > 1 and Bn >= 128 and ops.capture_can_fork():
         cur = torch.cuda.current_stream()
         side = _side_stream(cur)
+        # the product-less first timestep of BOTH directions as one (elementwise) launch, in front of the fork
+        hip.call("lstm_step", 2, Bn, H, 1, None, None, os_, w0, w1, b0, b1, xp_p, xp_p + 4 * ((T - 1) * 8 * H + 4 * H), xs,
+                 out_p, out_p + 4 * ((T - 1) * 2 * H + H), os_, c[0], c[1],
+                 None if gst is None else gst[0, 0], None if gst is None else gst[1, T - 1],
+                 None if cst is None else cst[0, 0], None if cst is None else cst[1, T - 1])
         side.wait_stream(cur)
-        for s in range(T):
+        for s in range(1, T):
             t0, t1 = s, T - 1 - s
             hip.call("lstm_step", 1, Bn, H, int(s == 0), out_p + 4 * ((t0 - 1) * 2 * H) if s > 0 else None, None, os_, w0, None, b0, None,
                      xp_p + 4 * (t0 * 8 * H), None, xs, out_p + 4 * (t0 * 2 * H), None, os_, c[0], None,
