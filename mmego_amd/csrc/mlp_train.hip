@@ -145,11 +145,6 @@ __global__ __launch_bounds__(1024) void mlp_fwd_layer_kernel(MlpFwdP p) {
   __shared__ float Ws[64 * MT_S], Xs[MTF_NG][64 * MT_S], Bs[64], sm[4][64];
   __shared__ double red[16][2][64];
   const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = t >> 6;
-  for (int i = tid; i < 64 * 64; i += 1024) {
-    const int n = i >> 6, k = i & 63;
-    Ws[n * MT_S + k] = (n < p.Cout && k < p.Cin) ? p.W[n * p.Cin + k] : 0.f;
-  }
-  if (tid < 64) Bs[tid] = (tid < p.Cout && p.bias) ? p.bias[tid] : 0.f;
   const bool act = p.in_part != nullptr;
   const int K = (p.Cin + 1) & ~1;
   const int rt = wave & 1, ct = wave >> 1, col = ct * 32 + (lane & 31);
@@ -173,6 +168,28 @@ __global__ __launch_bounds__(1024) void mlp_fwd_layer_kernel(MlpFwdP p) {
   }
   const int xkc = xk < p.Cin ? xk : p.Cin - 1;
   if (rbeg < rend) { MTF_FETCH(rbeg + 64 * grp) }          // the first tile's loads fly while the statistics are finalized
+  // (behind the first tile's loads, so that both are in flight together)
+  // weights (zero padded) -> LDS: four elements per thread, every load unconditional from a clamped index and all in flight
+  // together, the padding applied to the values (written as `(n < Cout && k < Cin) ? W[..] : 0` each element was a branch around
+  // its load with a full wait: four consecutive memory round trips -- eight in the backward kernel -- before anything else)
+  {
+    float wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 1024 * u, n = i >> 6, k = i & 63;
+      wv[u] = p.W[min(n, p.Cout - 1) * p.Cin + min(k, p.Cin - 1)];
+    }
+    float bvv = 0.f;
+    if (p.bias) bvv = p.bias[min(tid & 63, p.Cout - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 1024 * u, n = i >> 6, k = i & 63;
+      asm volatile("" : "+v"(wv[u]));
+      Ws[n * MT_S + k] = (n < p.Cout && k < p.Cin) ? wv[u] : 0.f;
+    }
+    asm volatile("" : "+v"(bvv));
+    if (tid < 64) Bs[tid] = tid < p.Cout ? bvv : 0.f;
+  }
   if (act) mt_finalize_stats<16>(p.in_part, p.in_nblk, p.Cin, p.rows, p.in_gamma, p.in_beta, p.in_eps, p.in_rmean, p.in_rvar,
                                  p.in_momentum, p.in_state, sm, red);
   else __syncthreads();
@@ -296,22 +313,6 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
   float (*st)[64] = reinterpret_cast<float (*)[64]>(Wt + 64 * MT_S);      // [8][64]: this layer mean, invstd, a, b; below: mean, invstd, a, b
   float (*cc)[64] = st + 8;                  // [2][64]: c1 = sum g / N, c2 = sum g xhat / N
   double (*red)[2][64] = reinterpret_cast<double (*)[2][64]>(cc + 2);     // [8][2][64]
-  for (int i = tid; i < 64 * 64; i += 512) {
-    const int k = i >> 6, n = i & 63;        // k = cout, n = cin
-    Wt[n * MT_S + k] = (k < p.Cout && n < p.Cin) ? p.W[k * p.Cin + n] : 0.f;
-  }
-  if (tid < 64) {
-    const bool ok = tid < p.Cout;
-    st[0][tid] = ok ? p.state[tid] : 0.f;
-    st[1][tid] = ok ? p.state[p.Cout + tid] : 0.f;
-    st[2][tid] = ok ? p.state[2 * p.Cout + tid] : 0.f;
-    st[3][tid] = ok ? p.state[3 * p.Cout + tid] : 0.f;
-    const bool oki = p.in_state && tid < p.Cin;
-    st[4][tid] = oki ? p.in_state[tid] : 0.f;
-    st[5][tid] = oki ? p.in_state[p.Cin + tid] : 0.f;
-    st[6][tid] = oki ? p.in_state[2 * p.Cin + tid] : 1.f;
-    st[7][tid] = oki ? p.in_state[3 * p.Cin + tid] : 0.f;
-  }
   const long rbeg = (long)blockIdx.x * p.rows_per_wg, rend = min(p.rows, rbeg + p.rows_per_wg);
   const int xk = t & 63, xr = t >> 6;
   float gy[16], gz[16], gx[16];
@@ -331,6 +332,36 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
   }
   const int xko = xk < p.Cout ? xk : p.Cout - 1, xki = xk < p.Cin ? xk : p.Cin - 1;
   if (rbeg < rend) { MTB_FETCH(rbeg + 64 * grp) }          // the first tile's loads fly while the partial sums are gathered
+  {  // W^T and the two BatchNorm states -> LDS: unconditional loads from clamped indices, all in flight, padding applied to the values
+    float wv[8], sv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + 512 * u, k = i >> 6, n = i & 63;        // k = cout, n = cin
+      wv[u] = p.W[min(k, p.Cout - 1) * p.Cin + min(n, p.Cin - 1)];
+    }
+    const int co = min(tid & 63, p.Cout - 1), ci = min(tid & 63, p.Cin - 1);
+    const float* ins = p.in_state ? p.in_state : p.state;          // (a valid address either way; unused without in_state)
+    const int cis = p.in_state ? ci : co, Cs = p.in_state ? p.Cin : p.Cout;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sv[q] = p.state[q * p.Cout + co]; sv[4 + q] = ins[q * Cs + cis]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + 512 * u, k = i >> 6, n = i & 63;
+      asm volatile("" : "+v"(wv[u]));
+      Wt[n * MT_S + k] = (k < p.Cout && n < p.Cin) ? wv[u] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(sv[q]));
+    if (tid < 64) {
+      const bool ok = tid < p.Cout, oki = p.in_state && tid < p.Cin;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) st[q][tid] = ok ? sv[q] : 0.f;
+      st[4][tid] = oki ? sv[4] : 0.f;
+      st[5][tid] = oki ? sv[5] : 0.f;
+      st[6][tid] = oki ? sv[6] : 1.f;
+      st[7][tid] = oki ? sv[7] : 0.f;
+    }
+  }
   {  // finalize this layer's (sum g, sum g xhat): c1, c2; d(gamma), d(beta) by workgroup 0
     mt_gather_partials<8>(p.g_part, p.g_nblk, p.Cout, red);
     const int c = tid & 63;
