@@ -91,9 +91,19 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_lds_kernel(const float* __r
   const float* Xg = X + g * (long)P * C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int n4 = P * C / 4;
+  // the score weights ride with the tile's loads into LDS: read from global memory inside the dot-product loops they were one
+  // (cached, but waited-for) load per multiply-add
+  __shared__ float wsh[1024];
+  const bool wl = C <= 1024;
+  float wreg[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) wreg[u] = w[min(tid + 256 * u, C - 1)];
   tile_to_lds_any(Xg, Xs, n4, tid);        // all of the tile's loads in flight at once, then the LDS stores
   const float b = bptr ? bptr[0] : 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) if (tid + 256 * u < C && wl) wsh[tid + 256 * u] = wreg[u];
   __syncthreads();
+  const float* const wv = wl ? wsh : w;
   // scores: TPP threads per point, each over a contiguous slice of the channels, started at a point-dependent offset so that
   // neighbouring threads hit different LDS banks (the points' rows are C floats apart); partials summed in fixed order
   int TPP = 1;
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_lds_kernel(const float* __r
       for (int i = 0; i < len; ++i) {
         int c = i + p;
         c = c0 + (c >= len ? c % len : c);
-        s += Xs[p * C + c] * w[c];
+        s += Xs[p * C + c] * wv[c];
       }
       part[pt * P + p] = s;
     }
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_lds_kernel(const float* __r
   } else {
     for (int p = wave; p < P; p += nw) {
       float s = 0.f;
-      for (int c = lane; c < C; c += 64) s += Xs[p * C + c] * w[c];
+      for (int c = lane; c < C; c += 64) s += Xs[p * C + c] * wv[c];
       s = wave_sum(s);
       if (lane == 0) sc[p] = s + b;
     }
@@ -281,9 +291,18 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_lds_kernel(const float* __r
   const float* dv = dvec + g * C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int n4 = P * C / 4;
+  // (the group's d(vec) row into LDS with the tile: see attn_pool_fwd_lds_kernel)
+  __shared__ float dvs[1024];
+  const bool dl = C <= 1024;
+  float dreg[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) dreg[u] = dv[min(tid + 256 * u, C - 1)];
   tile_to_lds_any(Xg, Xs, n4, tid);        // tile <= 64 KB: all of its loads in flight at once, then the LDS stores
   for (int p = tid; p < P; p += blockDim.x) ags[p] = attn[g * P + p];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) if (tid + 256 * u < C && dl) dvs[tid + 256 * u] = dreg[u];
   __syncthreads();
+  const float* const dvv = dl ? dvs : dv;
   // da[p] = X[p, :] . dvec: TPP threads per row, each over a contiguous channel slice entered at a row-dependent offset
   // (bank-conflict free), partials summed in fixed order -- as in attn_pool_fwd_lds_kernel
   __shared__ float ps[1024];
@@ -297,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_lds_kernel(const float* __r
       for (int i = 0; i < len; ++i) {
         int c = i + p;
         c = c0 + (c >= len ? c % len : c);
-        s += Xs[p * C + c] * dv[c];
+        s += Xs[p * C + c] * dvv[c];
       }
       ps[pt * P + p] = s;
     }
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_lds_kernel(const float* __r
   } else {
     for (int p = wave; p < P; p += nw) {
       float s = 0.f;
-      for (int c = lane; c < C; c += 64) s += Xs[p * C + c] * dv[c];
+      for (int c = lane; c < C; c += 64) s += Xs[p * C + c] * dvv[c];
       s = wave_sum(s);
       if (lane == 0) sh[p] = s;
     }
