@@ -38,6 +38,24 @@ extern "C" {
 int mmego_gemm(void* stream, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
                long scm, long scn, const float* bias, int M, int N, int K, int nbatch, long sAb, long sBb, long sCb,
                int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb, const float* cmul, float* asum);
+/* Several INDEPENDENT products in one launch: each entry is one mmego_gemm argument set.  When all of them are small-tile products
+ * of one operand orientation (what mmego_gemm would hand to its K-quartered kernel, unsplit), they share a launch -- grid.z is cut
+ * into the products' ranges --; otherwise they run as n mmego_gemm calls in order.  Same results either way.  For the leaf
+ * products of a backward pass (weight gradients of a BiLSTM stack: the reference's autograd computes them per parameter, e.g.
+ * Net/Upper_Net.py:333), which otherwise sit one behind the other in a dependent chain of small kernels. */
+typedef struct MmegoGemmDesc {
+  const float* A; long sam, sak;
+  const float* B; long sbk, sbn;
+  float* C; long scm, scn;
+  const float* bias;
+  int M, N, K, nbatch;
+  long sAb, sBb, sCb;
+  int relu, accumulate;
+  float* splitk_ws; int nsplit;
+  long sBiasb;
+  const float* cmul; float* asum;
+} MmegoGemmDesc;
+int mmego_gemm_group(void* stream, int n, const MmegoGemmDesc* descs);
 
 /* ---- BatchNorm and row-wise helpers (bn.hip) ----------------------------------------------------
  * Train-mode statistics of X[rows, C] (+ running-stat update with torch semantics: momentum, unbiased

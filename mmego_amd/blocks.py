@@ -235,8 +235,12 @@ def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr, salt
 
 
 def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
+    """Backward of the three-layer BiLSTM(64).  The weight-gradient products of a layer are LEAVES (nothing in the backward pass
+    reads them) while the rest is one dependent chain of small kernels: the six of them are issued behind the last layer as ONE
+    grouped launch (hip.gemm_group / mmego_gemm_group) instead of sitting two by two between the chain's kernels."""
     L = lstm.num_layers
     d_cur = dout
+    leaves = []
     for l in range(L - 1, -1, -1):
         if l == 0:
             inp = x
@@ -255,18 +259,20 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
         # weight gradients of both directions per launch (batch dimension = direction)
         # the bias gradients (row sums of the gate gradients; bias_ih and bias_hh of a direction share them) ride on the two
         # batched weight-gradient products where the directions' bias tensors are neighbours in the flat buffer
-        bi = ops.stacked(G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_ih", l, 1)))
-        bh = ops.stacked(G(lstm.w("bias_hh", l, 0)), G(lstm.w("bias_hh", l, 1)))
-        got_i = ops.grad_weight_pair(dg, 256, inp, G(lstm.w("weight_ih", l, 0)), G(lstm.w("weight_ih", l, 1)), db=bi)
-        got_h = ops.grad_weight_pair(dg, 256, hprev[0], G(lstm.w("weight_hh", l, 0)), G(lstm.w("weight_hh", l, 1)), X1=hprev[1], db=bh)
-        if got_i and got_h:
-            pass
-        elif B * T <= 1024:     # the four bias gradients (bias_ih = bias_hh per direction) in one launch
-            hip.call("colsum_pair", dg, dg.stride(0), B * T, 256, G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_hh", l, 0)),
-                     G(lstm.w("bias_ih", l, 1)), G(lstm.w("bias_hh", l, 1)), 0)
-        else:
-            for d in range(2):
-                ops.colsum(dg[:, d * 256:(d + 1) * 256], G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
+        def weight_grads(l=l, dg=dg, inp=inp, hprev=hprev):
+            bi = ops.stacked(G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_ih", l, 1)))
+            bh = ops.stacked(G(lstm.w("bias_hh", l, 0)), G(lstm.w("bias_hh", l, 1)))
+            got_i = ops.grad_weight_pair(dg, 256, inp, G(lstm.w("weight_ih", l, 0)), G(lstm.w("weight_ih", l, 1)), db=bi)
+            got_h = ops.grad_weight_pair(dg, 256, hprev[0], G(lstm.w("weight_hh", l, 0)), G(lstm.w("weight_hh", l, 1)), X1=hprev[1], db=bh)
+            if got_i and got_h:
+                pass
+            elif B * T <= 1024:     # the four bias gradients (bias_ih = bias_hh per direction) in one launch
+                hip.call("colsum_pair", dg, dg.stride(0), B * T, 256, G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_hh", l, 0)),
+                         G(lstm.w("bias_ih", l, 1)), G(lstm.w("bias_hh", l, 1)), 0)
+            else:
+                for d in range(2):
+                    ops.colsum(dg[:, d * 256:(d + 1) * 256], G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
+        leaves.append(weight_grads)
         if l > 0 or need_dx:
             dinp = ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))
             # (the inter-layer dropout mask is applied by the last product's epilogue)
@@ -278,6 +284,9 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
                 ops.grad_input(dg[:, :256], lstm.w("weight_ih", l, 0), dinp)
                 ops.grad_input(dg[:, 256:], lstm.w("weight_ih", l, 1), dinp, accumulate=True, cmul=mask)
             d_cur = dinp
+    with hip.gemm_group():
+        for fn in leaves:
+            fn()
     return d_cur if need_dx else None
 
 

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "../../include/mmego_hip.h"       // MmegoGemmDesc (mmego_gemm_group)
 
 #include "gemm_tile.h"
 
@@ -183,12 +184,12 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmP p) {
 // k = k0 + 16 h + s at MFMA step s for BOTH operands (any k order is valid as long as A and B agree), which makes a
 // k-contiguous operand four 16-B loads per lane and an m-contiguous operand 16 loads that are contiguous across lanes.
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
+__device__ __forceinline__ void gemm32kq_body(const GemmP& p, const int bx, const int by, const int bz) {
   __shared__ float red[4][32][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int batch = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int batch = bz / p.nsplit, split = bz % p.nsplit;
+  const int m0 = bx * 32, n0 = by * 32;
   const float* A = p.A + (long)batch * p.sAb;
   const float* B = p.B + (long)batch * p.sBb;
   const int kbeg0 = split * p.kchunk;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
   } while (0)
 
   f32x16 acc = {0};
-  const bool want_asum = p.asum != nullptr && blockIdx.y == 0;
+  const bool want_asum = p.asum != nullptr && by == 0;
   float asum = 0.f;
   if (kbeg < kend) {
     KQ_LOAD(ra, rb, kbeg);
@@ -346,6 +347,27 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
     for (int e = 0; e < 4; ++e)
       if (m0 + (tid >> 5) + 8 * e < p.M && n0 + col < p.N) C[off[e]] = v[e];
   }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
+  gemm32kq_body<A_KC, B_KC>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several INDEPENDENT small products in one launch (mmego_gemm_group): grid.z is cut into the products' own z ranges, grid.x / y
+// cover the largest tile counts.  For leaves of a backward pass -- weight gradients nothing else reads -- that would otherwise sit
+// one behind the other between the kernels of a dependent chain.
+#define GEMM_GROUP_MAX 6
+struct GemmGroup { GemmP p[GEMM_GROUP_MAX]; int zend[GEMM_GROUP_MAX]; int n; };
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm32kq_group_kernel(GemmGroup g) {
+  int i = 0;
+  const int z = blockIdx.z;
+  while (i + 1 < g.n && z >= g.zend[i]) ++i;              // (uniform)
+  const int z0 = i ? g.zend[i - 1] : 0;
+  const GemmP& p = g.p[i];
+  if ((int)blockIdx.x * 32 >= p.M || (int)blockIdx.y * 32 >= p.N) return;
+  gemm32kq_body<A_KC, B_KC>(p, blockIdx.x, blockIdx.y, z - z0);
 }
 
 // ws: [nsplit][nbatch][M][N] contiguous partial products -> C (strided), + bias, relu, accumulate.
@@ -620,6 +642,63 @@ extern "C" int mmego_lstm_bwd_step(void* stream, int Bn, int H, const float* dg0
   p.cb_dc[0] = dc0; p.cb_dc[1] = dc1; p.cb_dg[0] = dgo0; p.cb_dg[1] = dgo1; p.cb_dgs = dgs;
   dim3 grid(Bn / 32, H / 32, 2);
   hipLaunchKernelGGL((gemm32kq_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// Several independent products in one launch where all of them are small-tile (K-quartered) products of one operand orientation;
+// otherwise one mmego_gemm call each, in order -- the results are the same either way.
+extern "C" int mmego_gemm_group(void* stream, int n, const MmegoGemmDesc* d) {
+  MMEGO_REQUIRE(n >= 1 && d);
+  static const long tile_min_other = getenv("MMEGO_GEMM_TILE_MIN") ? atol(getenv("MMEGO_GEMM_TILE_MIN")) : 256;
+  static const int kq_max = getenv("MMEGO_GEMM_KQ_MAX") ? atoi(getenv("MMEGO_GEMM_KQ_MAX")) : 512;
+  static const int group_on = getenv("MMEGO_GEMM_GROUP") ? atoi(getenv("MMEGO_GEMM_GROUP")) : 1;
+  bool ok = group_on && n >= 2 && n <= GEMM_GROUP_MAX;
+  const bool akc = d[0].sak == 1, bkc = d[0].sbk == 1;
+  GemmGroup g;
+  unsigned gx = 0, gy = 0;
+  int z = 0;
+  for (int i = 0; ok && i < n; ++i) {
+    const MmegoGemmDesc& a = d[i];
+    if (!(a.A && a.B && a.C && a.M > 0 && a.N > 0 && a.K > 0 && a.nbatch > 0)) return MMEGO_EBADARG;
+    const long units64 = (long)(a.M / 64) * (a.N / 64) * a.nbatch;
+    const long wgs64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64) * a.nbatch;
+    ok = a.nsplit == 1 && (a.sak == 1) == akc && (a.sbk == 1) == bkc && !(akc && bkc) && units64 < tile_min_other &&
+         wgs64 <= kq_max && a.K >= 64 && a.relu != 2 && cdiv(a.N, 32) <= 65535;
+    if (!ok) break;
+    GemmP& p = g.p[i];
+    p.A = a.A; p.B = a.B; p.bias = a.bias;
+    p.sam = a.sam; p.sak = a.sak; p.sbk = a.sbk; p.sbn = a.sbn;
+    p.sAb = a.sAb; p.sBb = a.sBb; p.sBiasb = a.sBiasb;
+    p.M = a.M; p.N = a.N; p.K = a.K;
+    p.nsplit = 1; p.kchunk = cdiv(a.K, 16) * 16;
+    p.relu = a.relu; p.accumulate = a.accumulate;
+    p.cmul = a.cmul; p.asum = a.asum;
+    p.cb_dg[0] = p.cb_dg[1] = nullptr;
+    p.C = a.C; p.scm = a.scm; p.scn = a.scn; p.sCb = a.sCb; p.sCs = 0;
+    p.avec = akc && (a.sam % 4) == 0 && (a.sAb % 4) == 0 && ((uintptr_t)a.A & 15) == 0;
+    p.bvec = bkc && (a.sbn % 4) == 0 && (a.sBb % 4) == 0 && ((uintptr_t)a.B & 15) == 0;
+    const unsigned tx = (unsigned)cdiv(a.M, 32), ty = (unsigned)cdiv(a.N, 32);
+    gx = tx > gx ? tx : gx; gy = ty > gy ? ty : gy;
+    z += a.nbatch;
+    g.zend[i] = z;
+  }
+  if (!ok || z > 65535) {
+    for (int i = 0; i < n; ++i) {
+      const MmegoGemmDesc& a = d[i];
+      int rc = mmego_gemm(stream, a.A, a.sam, a.sak, a.B, a.sbk, a.sbn, a.C, a.scm, a.scn, a.bias, a.M, a.N, a.K, a.nbatch, a.sAb, a.sBb,
+                          a.sCb, a.relu, a.accumulate, a.splitk_ws, a.nsplit, a.sBiasb, a.cmul, a.asum);
+      if (rc != MMEGO_OK) return rc;
+    }
+    return MMEGO_OK;
+  }
+  g.n = n;
+  for (int i = n; i < GEMM_GROUP_MAX; ++i) g.zend[i] = z;
+  dim3 grid(gx, gy, (unsigned)z);
+  hipStream_t st = (hipStream_t)stream;
+  if (akc) hipLaunchKernelGGL((gemm32kq_group_kernel<true, false>), grid, dim3(256), 0, st, g);
+  else if (bkc) hipLaunchKernelGGL((gemm32kq_group_kernel<false, true>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm32kq_group_kernel<false, false>), grid, dim3(256), 0, st, g);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

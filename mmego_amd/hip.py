@@ -63,8 +63,53 @@ def stream_handle():
     return torch.cuda.current_stream().cuda_stream
 
 
+class GemmDesc(ctypes.Structure):
+    """MmegoGemmDesc of include/mmego_hip.h: one mmego_gemm argument set (the stream aside)."""
+    _fields_ = [("A", ctypes.c_void_p), ("sam", ctypes.c_long), ("sak", ctypes.c_long),
+                ("B", ctypes.c_void_p), ("sbk", ctypes.c_long), ("sbn", ctypes.c_long),
+                ("C", ctypes.c_void_p), ("scm", ctypes.c_long), ("scn", ctypes.c_long),
+                ("bias", ctypes.c_void_p),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("nbatch", ctypes.c_int),
+                ("sAb", ctypes.c_long), ("sBb", ctypes.c_long), ("sCb", ctypes.c_long),
+                ("relu", ctypes.c_int), ("accumulate", ctypes.c_int),
+                ("splitk_ws", ctypes.c_void_p), ("nsplit", ctypes.c_int),
+                ("sBiasb", ctypes.c_long),
+                ("cmul", ctypes.c_void_p), ("asum", ctypes.c_void_p)]
+
+
+_gemm_rec = None
+
+
+class gemm_group:
+    """Context: the mmego_gemm calls made inside are collected and issued as ONE mmego_gemm_group launch at exit (independent
+    products only: nothing inside the context may read what another call inside it writes).  Other launches pass through."""
+
+    def __enter__(self):
+        global _gemm_rec
+        if _gemm_rec is not None:
+            raise RuntimeError("gemm_group contexts do not nest")
+        _gemm_rec = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _gemm_rec
+        rec, _gemm_rec = _gemm_rec, None
+        if et is None and rec:
+            for i in range(0, len(rec), 6):
+                part = rec[i:i + 6]
+                arr = (GemmDesc * len(part))()
+                for dsc, a in zip(arr, part):
+                    for (fname, _), v in zip(GemmDesc._fields_, a):
+                        setattr(dsc, fname, _conv(v))
+                call("gemm_group", len(part), ctypes.addressof(arr))
+        return False
+
+
 def call(name, *args):
     """Launch `mmego_<name>` on torch's current stream.  Tensors are passed as device pointers."""
+    if _gemm_rec is not None and name == "gemm":
+        _gemm_rec.append(args)
+        return
     fn = getattr(lib(), "mmego_" + name)
     rc = fn(stream_handle(), *[_conv(a) for a in args])
     if rc != 0:

@@ -694,6 +694,48 @@ def test_gcn_kernels_against_torch(dev):
             assert (dW.cpu().double() - 2 * Wg.grad).abs().max().item() < 2e-5 * scale + 2e-4
 
 
+def test_gemm_group_equals_separate_launches(dev):
+    """hip.gemm_group (mmego_gemm_group: several independent small products in one launch) gives the bits of the separate
+    mmego_gemm launches: weight-gradient shaped products (dY^T X, with the bias gradient as row sums of A) of different sizes,
+    batched and unbatched; a group the small-tile kernel cannot take falls back to separate launches."""
+    from mmego_amd import hip, ops
+    g = torch.Generator().manual_seed(41)
+    rows = 512
+    shapes = [(256, 128), (256, 64), (96, 200), (33, 17)]
+    dYs = [torch.randn(rows, m, generator=g).to(dev) for m, _ in shapes]
+    Xs = [torch.randn(rows, n, generator=g).to(dev) for _, n in shapes]
+
+    def run(grouped):
+        outs = [torch.full((m, n), float("nan"), device=dev) for m, n in shapes]
+        dbs = [torch.full((m,), float("nan"), device=dev) for m, _ in shapes]
+
+        def all_():
+            for dY, X, W, db in zip(dYs, Xs, outs, dbs):
+                ops.grad_weight(dY, X, W, db=db, prefer_fused=True)
+        if grouped:
+            with hip.gemm_group():
+                all_()
+        else:
+            all_()
+        torch.cuda.synchronize()
+        return outs, dbs
+    o1, b1 = run(False)
+    o2, b2 = run(True)
+    for a, b, dY, X in zip(o1, o2, dYs, Xs):
+        assert torch.equal(a, b)
+        assert (a.double() - dY.double().t() @ X.double()).abs().max().item() < 1e-3
+    for a, b, dY in zip(b1, b2, dYs):
+        assert torch.equal(a, b) and (a.double() - dY.double().sum(0)).abs().max().item() < 1e-3
+    # a group with a product the small-tile kernel does not take (k-contiguous operands: the tile kernels' shape) still works
+    A, Bm = torch.randn(128, 64, generator=g).to(dev), torch.randn(64, 64, generator=g).to(dev)
+    C1, C2 = torch.empty(128, 64, device=dev), torch.empty(128, 64, device=dev)
+    ops.mm(A, Bm, C1)
+    with hip.gemm_group():
+        ops.mm(A, Bm, C2)
+        ops.grad_weight(dYs[0], Xs[0], o2[0])
+    assert torch.equal(C1, C2)
+
+
 def test_imu_fc2_head_kernel(dev):
     """mmego_imu_fc2_head (IMU_Net.fc2 as row-wise dot products + the 6-D head in one launch) against torch in fp64 and against
     mmego_imu_head on its own y (same bits); odd row count, row-strided input."""
