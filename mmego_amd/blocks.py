@@ -181,12 +181,18 @@ def mlp3_backward(ar, key, mod, x, y3, dy3, G, need_dx):
 # ---------------------------------------------------------------------------------------------------
 # Linear (+ReLU) with backward
 # ---------------------------------------------------------------------------------------------------
-def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False, bias_grad=True, relu_input=False):
+def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False, bias_grad=True, relu_input=False, leaves=None):
     """Gradients of y = x W^T + b: writes G(W), G(b); fills dx if given.  bias_grad=False: the layer feeds a batch-statistics
     BatchNorm directly, so the bias gradient is identically zero and its slot in the gradient buffer stays 0.
     relu_input: x is the output of a ReLU whose backward is applied to dx right here (dx = 0 where x <= 0), in the epilogue of
-    the product that computes dx."""
-    ops.grad_weight(dy, x, G(lin.weight), db=G(lin.bias) if lin.bias is not None and bias_grad else None)
+    the product that computes dx.  leaves (optional list): the weight / bias gradient -- a leaf of the backward pass -- is not
+    computed here but appended as a closure, for the caller to run later (run_leaves; dy and x must stay untouched until then)."""
+    def weight_grad():
+        ops.grad_weight(dy, x, G(lin.weight), db=G(lin.bias) if lin.bias is not None and bias_grad else None)
+    if leaves is None:
+        weight_grad()
+    else:
+        leaves.append(weight_grad)
     if dx is not None:
         masked = relu_input and x.shape == dx.shape and x.stride() == dx.stride()
         ops.grad_input(dy, lin.weight, dx, accumulate=accumulate_dx, cmask=x if masked else None)
@@ -234,13 +240,24 @@ def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr, salt
     return out, hn, cn
 
 
-def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
+def run_leaves(leaves):
+    """Run deferred leaf closures (weight gradients): their small-tile products share launches (hip.gemm_group)."""
+    if leaves:
+        with hip.gemm_group():
+            for fn in leaves:
+                fn()
+        del leaves[:]
+
+
+def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx, leaves=None):
     """Backward of the three-layer BiLSTM(64).  The weight-gradient products of a layer are LEAVES (nothing in the backward pass
     reads them) while the rest is one dependent chain of small kernels: the six of them are issued behind the last layer as ONE
     grouped launch (hip.gemm_group / mmego_gemm_group) instead of sitting two by two between the chain's kernels."""
     L = lstm.num_layers
     d_cur = dout
-    leaves = []
+    own = leaves is None             # (a caller's list: the caller runs it, together with its other leaves)
+    if own:
+        leaves = []
     for l in range(L - 1, -1, -1):
         if l == 0:
             inp = x
@@ -284,9 +301,8 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx):
                 ops.grad_input(dg[:, :256], lstm.w("weight_ih", l, 0), dinp)
                 ops.grad_input(dg[:, 256:], lstm.w("weight_ih", l, 1), dinp, accumulate=True, cmul=mask)
             d_cur = dinp
-    with hip.gemm_group():
-        for fn in leaves:
-            fn()
+    if own:
+        run_leaves(leaves)
     return d_cur if need_dx else None
 
 

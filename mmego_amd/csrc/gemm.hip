@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void gemm32kq_kernel(GemmP p) {
 // Several INDEPENDENT small products in one launch (mmego_gemm_group): grid.z is cut into the products' own z ranges, grid.x / y
 // cover the largest tile counts.  For leaves of a backward pass -- weight gradients nothing else reads -- that would otherwise sit
 // one behind the other between the kernels of a dependent chain.
-#define GEMM_GROUP_MAX 6
+#define GEMM_GROUP_MAX 10
 struct GemmGroup { GemmP p[GEMM_GROUP_MAX]; int zend[GEMM_GROUP_MAX]; int n; };
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm32kq_group_kernel(GemmGroup g) {

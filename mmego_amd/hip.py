@@ -95,8 +95,8 @@ class gemm_group:
         global _gemm_rec
         rec, _gemm_rec = _gemm_rec, None
         if et is None and rec:
-            for i in range(0, len(rec), 6):
-                part = rec[i:i + 6]
+            for i in range(0, len(rec), 10):
+                part = rec[i:i + 10]
                 arr = (GemmDesc * len(part))()
                 for dsc, a in zip(arr, part):
                     for (fname, _), v in zip(GemmDesc._fields_, a):

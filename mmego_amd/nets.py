@@ -252,13 +252,15 @@ class UpperNet(_NetBase):
         dy = ar.get("dy", (F, 87))
         hip.call("head_fk_backward", 0, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
         dh1 = ar.get("dh1", (F, 128))
-        blocks.linear_backward(dy, h1, self.mlpHead.fc2, G, dh1, relu_input=True)
+        leaves = []          # weight gradients of the head and of the BiLSTM stack: leaves, issued together behind the stack
+        blocks.linear_backward(dy, h1, self.mlpHead.fc2, G, dh1, relu_input=True, leaves=leaves)
         seq = ar.get("grnn.out2", (F, 128))
         dseq = ar.get("dseq", (F, 128))
-        blocks.linear_backward(dh1, seq, self.mlpHead.fc1, G, dseq)
+        blocks.linear_backward(dh1, seq, self.mlpHead.fc1, G, dseq, leaves=leaves)
         lstm = self.module1.grnn
         vec = ar.get("vec", (F, 64))
-        dvec = blocks.lstm64_backward(ar, "grnn", lstm, vec, B, T, c0, dseq, G, self._drop_p(lstm), True)
+        dvec = blocks.lstm64_backward(ar, "grnn", lstm, vec, B, T, c0, dseq, G, self._drop_p(lstm), True, leaves=leaves)
+        blocks.run_leaves(leaves)
         g3 = ar.get("g3", (rows, 64))
         dg3 = ar.get("dg3", (rows, 64))
         blocks.attn_pool_backward(ar, "gpool", g3, self.module1.gpointnet.attn, attn, dvec, F, N, 64, dg3, G)
@@ -535,12 +537,14 @@ class LowerNet(_NetBase):
         dy = ar.get("dy", (F, 42))
         hip.call("head_fk_backward", 1, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
         df1, df0, dcat = ar.get("df1", (F, 64)), ar.get("df0", (F, 128)), ar.get("dcat", (F, 173))
-        blocks.linear_backward(dy, f1, fu.fc2, G, df1, relu_input=True)
-        blocks.linear_backward(df1, f0, fu.fc1, G, df0, relu_input=True)
-        blocks.linear_backward(df0, cat, fu.fc0, G, dcat)
+        leaves = []          # weight gradients of the fusion head and of the BiLSTM stack: leaves, issued together behind the stack
+        blocks.linear_backward(dy, f1, fu.fc2, G, df1, relu_input=True, leaves=leaves)
+        blocks.linear_backward(df1, f0, fu.fc1, G, df0, relu_input=True, leaves=leaves)
+        blocks.linear_backward(df0, cat, fu.fc0, G, dcat, leaves=leaves)
         lstm = fu.rnn_pk
         ak = ar.get("ak", (F, 192))
-        dak = blocks.lstm64_backward(ar, "rnn", lstm, ak, B, T, None, dcat[:, :128], G, self._drop_p(lstm), True)
+        dak = blocks.lstm64_backward(ar, "rnn", lstm, ak, B, T, None, dcat[:, :128], G, self._drop_p(lstm), True, leaves=leaves)
+        blocks.run_leaves(leaves)
         dboth = ar.get("dboth", (prow, 128))
         hip.call("group_bcast", dak, 192, F, LOWER_POINTS, 128, 1.0, dboth, 0)
         dk = ar.get("dk", (F * V, 64))
