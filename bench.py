@@ -155,8 +155,7 @@ def recurrence_graph(device, Bn=512, H=512, T=20, replays=20):
         st = torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
-            with torch.cuda.graph(g, stream=st):
-                ops.mark_capture_origin()
+            with ops.capture(g, stream=st):
                 body()
         torch.cuda.synchronize()
         for _ in range(3):
@@ -206,51 +205,119 @@ def pmc_traffic(kernel_label):
     return None, None
 
 
+NOISE_GRAD = r"(conv[123]\.bias|tcn\.2\.bias|residual\.0\.bias|attn\.bias|to_k\.bias|fusion\.attn\.weight)$"
+
+
+def _lstm_dropout_off(*modules):
+    """LSTM inter-layer dropout off (the two sides draw from different RNGs): nn.LSTM.dropout on the oracle's modules,
+    `lstm_dropout` on the HIP nets."""
+    for m in modules:
+        for mod in m.modules():
+            if hasattr(mod, "dropout") and isinstance(getattr(mod, "dropout"), float):
+                mod.dropout = 0.0
+        if hasattr(m, "lstm_dropout"):
+            m.lstm_dropout = 0.0
+
+
+def ul_step_parity(device, use_graph=True):
+    """The arrangement that is timed, checked against the CPU oracle AT THE TIMED SHAPE: freshly seeded nets on both sides
+    (identical weights, IMU_Net hidden 512), LSTM dropout off, the full synthetic minibatch (B=64, T=8, N=128: 512 rows through
+    rnn_fast, 65 536 points, 7 680 graph rows -- the dispatch branches of the timed step), ONE
+    `ConcurrentStages(use_graph=True).step()` (frozen IMU_Net forward in both bodies, frozen Upper_Net forward in the Lower body,
+    L1(sum) loss, backward, fused Adam) against one oracle Train_Upper + Train_Lower body (Processor/Train/Train_Upper.py:134-187,
+    Train_Lower.py:155-230).  Returns the figures and the per-parameter tensors the test asserts on."""
+    import re
+    from copy import deepcopy
+    from mmego_amd.train_step import ConcurrentStages, StageStep
+    from oracle import nets as on
+    from oracle import skeleton as sk
+    from oracle import train as ot
+    noise = re.compile(NOISE_GRAD)
+    torch.manual_seed(1234)
+    o_imu = on.IMUNet(15, 9, 512, 2, True, 0.1).eval()
+    o_up, o_lo = on.UpperNet().train(), on.LowerNet(64).train()
+    himu, hup, hlo, hfr = build_hip_models(device)                          # same seed -> the same initial weights
+    himu_l = clone_imu(himu, device)
+    for (ko, vo), (kh, vh) in zip(list(o_up.state_dict().items()) + list(o_lo.state_dict().items()),
+                                  list(hup.state_dict().items()) + list(hlo.state_dict().items())):
+        assert ko == kh and torch.equal(vo, vh.cpu()), "same seed -> same initial weights: " + ko
+    _lstm_dropout_off(o_up, o_lo, hup, hlo)
+    o_fr = deepcopy(o_up).eval()
+    x, imu_in, body, target = synth_batch(1234, "cpu")
+    # ---- HIP: one step of the timed engine
+    xd, imud, bodyd, targetd = [v.to(device) for v in (x, imu_in, body, target)]
+    su = StageStep("upper", hup, himu, lr=3e-5, use_graph=use_graph)
+    sl = StageStep("lower", hlo, himu_l, upper_frozen=hfr, lr=3e-5, use_graph=use_graph)
+    su.bind(xd, imud, bodyd, targetd)
+    sl.bind(xd, imud, bodyd, targetd)
+    both = ConcurrentStages([su, sl], use_graph=use_graph)
+    both.step()
+    torch.cuda.synchronize()
+    # ---- oracle: one Train_Upper body + one Train_Lower body
+    opt_u = torch.optim.Adam(o_up.parameters(), lr=3e-5)
+    opt_l = torch.optim.Adam(o_lo.parameters(), lr=3e-5)
+    loss_u, joints_u = ot.upper_train_step(o_up, o_imu, opt_u, x.clone(), imu_in, body, target)
+    loss_l, joints_l = ot.lower_train_step(o_lo, o_fr, o_imu, opt_l, x.clone(), imu_in, body, target)
+    res = {"what": "HIP vs CPU oracle at the timed shape: same seeded weights, LSTM dropout off, all %d sequences of the synthetic "
+                   "batch (%d rnn_fast rows), one ConcurrentStages(%s).step() vs one Train_Upper + Train_Lower body" %
+                   (B, B * T, "HIP graph" if use_graph else "eager"),
+           "tolerance_cm": 1e-3, "tensors": {}}
+    for tag, st, o_net, lo_, jo in (("upper", su, o_up, loss_u, joints_u), ("lower", sl, o_lo, loss_l, joints_l)):
+        res[tag + "_cm"] = (st.last_pred.detach().cpu().view_as(jo) - jo).norm(dim=-1).max().item() * 100.0
+        res["loss_rel_err_" + tag] = abs(st.loss.item() - lo_.item()) / abs(lo_.item())
+        po, ph = dict(o_net.named_parameters()), dict(st.net.named_parameters())
+        flat = st.net.flat()
+        scale = max(p.grad.abs().max().item() for p in po.values() if p.grad is not None)
+        worst_g = worst_p = 0.0
+        n_bad = n_all = 0
+        per = {}
+        for k in po:
+            go = po[k].grad if po[k].grad is not None else torch.zeros_like(po[k])
+            gh = flat.grad(ph[k]).detach().cpu()
+            eg = (gh - go).abs().max().item()
+            worst_g = max(worst_g, eg)
+            dp = (ph[k].detach().cpu() - po[k].detach()).abs()
+            per[k] = (eg, dp.max().item())
+            if not noise.search(k):
+                worst_p = max(worst_p, dp.max().item())
+                n_bad += int((dp > 2e-6).sum())
+                n_all += dp.numel()
+        res["grad_rel_err_" + tag] = worst_g / scale
+        res["param_max_abs_diff_" + tag] = worst_p
+        res["param_frac_moved_" + tag] = n_bad / max(1, n_all)
+        res["tensors"][tag] = {"scale": scale, "per_param": per}
+    res["max_joint_distance_cm"] = max(res["upper_cm"], res["lower_cm"])
+    return res
+
+
 def cpu_baseline(steps, warmup, device=None):
     """The CPU oracle (a port of the reference path, pinned to it by tests/golden) on the host cores.  While it is at hand it
-    also serves as the checker of the metric's "joint-err parity": freshly seeded nets on both sides (identical weights),
-    train-mode forward of IMU_Net -> Upper_Net -> Lower_Net on the first 8 sequences of the synthetic batch, largest joint
-    distance between the HIP path and the oracle."""
+    also serves as the checker of the metric's "joint-err parity" (`ul_step_parity`: one U+L step of the timed engine at the
+    timed shape against one oracle step -- joints, losses, gradients, post-Adam parameters)."""
+    import platform
     from oracle import nets as on
     from oracle import train as ot
     ncores = host_cores()
     torch.set_num_threads(ncores)
+    parity = None
+    if device is not None:
+        parity = ul_step_parity(device)
+        del parity["tensors"]
     torch.manual_seed(1234)
     imu = on.IMUNet(15, 9, 512, 2, True, 0.1)
     upper, lower = on.UpperNet(), on.LowerNet(64)
     x, imu_in, body, target = synth_batch(1234, "cpu")
-    parity = None
-    if device is not None:
-        himu, hupper, hlower, _ = build_hip_models(device)                 # same seed -> the same initial weights
-        nb = 8
-        for m in (upper, lower, hupper, hlower):
-            for mod in m.modules():
-                if hasattr(mod, "dropout") and isinstance(getattr(mod, "dropout"), float):
-                    mod.dropout = 0.0                                      # LSTM dropout off on both sides (different RNGs)
-            if hasattr(m, "lstm_dropout"):
-                m.lstm_dropout = 0.0
-        imu.eval(); upper.train(); lower.train()
-        with torch.no_grad():
-            h0, c0 = ot.zeros_state(nb)
-            xo = x[:nb].clone()
-            Ro, to_ = imu(imu_in[:nb])
-            upo = upper(xo, h0, c0, body[:nb], Ro, to_)[0]
-            loo = lower(upo.clone(), xo, h0, c0, h0, c0, body[:nb], Ro, to_)[0]
-            xh = x[:nb].clone().to(device)
-            hz = torch.zeros(6, nb, 64, device=device)
-            Rh, th = himu(imu_in[:nb].to(device))
-            uph = hupper(xh, hz, hz.clone(), body[:nb].to(device), Rh, th)[0]
-            loh = hlower(uph.clone(), xh, hz, hz, hz, hz, body[:nb].to(device), Rh, th)[0]
-        du = (uph.cpu() - upo).norm(dim=-1).max().item() * 100.0
-        dl = (loh.cpu() - loo).norm(dim=-1).max().item() * 100.0
-        parity = {"max_joint_distance_cm": max(du, dl), "upper_cm": du, "lower_cm": dl, "tolerance_cm": 1e-3,
-                  "what": "HIP vs CPU oracle, same seeded weights, train-mode forward (batch-stat BatchNorm, LSTM dropout off) of "
-                          "IMU_Net -> Upper_Net -> Lower_Net on 8 sequences of the synthetic batch"}
-        torch.manual_seed(1234)                                            # fresh oracle nets for the timed steps
-        imu = on.IMUNet(15, 9, 512, 2, True, 0.1)
-        upper, lower = on.UpperNet(), on.LowerNet(64)
     tu, tl = ot.time_ul_step(upper, lower, imu, x, imu_in, body, target, steps=steps, warmup=warmup)
+    model = platform.processor() or platform.machine()
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     out = {"value": B * T / (tu + tl), "unit": "frames/s", "cores": ncores, "kind": "port",
+           "cpu_model": model, "torch": torch.__version__,
            "sample": "%d U+L steps (after %d warm-up) of the same B=64,T=8,N=128 batch; t_upper %.1f ms, t_lower %.1f ms"
                      % (steps, warmup, tu * 1e3, tl * 1e3)}
     return out, parity

@@ -78,23 +78,34 @@ class GemmDesc(ctypes.Structure):
 
 
 _gemm_rec = None
+_gemm_rec_outs = None
 
 
 class gemm_group:
-    """Context: the mmego_gemm calls made inside are collected and issued as ONE mmego_gemm_group launch at exit (independent
-    products only: nothing inside the context may read what another call inside it writes).  Other launches pass through."""
+    """Context: the mmego_gemm calls made inside are collected and issued as ONE mmego_gemm_group launch at exit; every other
+    launch inside the context runs immediately.  Contract (checked):
+      * independent products only -- a product recorded here is not executed before the context ends, so nothing inside the
+        context may read OR write what a recorded product writes (its C and asum): a pass-through launch, or a later recorded
+        product, that takes one of those pointers raises;
+      * the group is issued on the stream that was current at entry: a stream switch inside the context raises at exit;
+      * split-K products share ops.scratch: the group entry point runs a group containing one as separate launches in recorded
+        order on that one stream (mmego_gemm_group's fallback), which keeps the scratch reuse stream-ordered."""
 
     def __enter__(self):
-        global _gemm_rec
+        global _gemm_rec, _gemm_rec_outs
         if _gemm_rec is not None:
             raise RuntimeError("gemm_group contexts do not nest")
-        _gemm_rec = []
+        _gemm_rec, _gemm_rec_outs = [], set()
+        self._stream = stream_handle()
         return self
 
     def __exit__(self, et, ev, tb):
-        global _gemm_rec
-        rec, _gemm_rec = _gemm_rec, None
+        global _gemm_rec, _gemm_rec_outs
+        rec, _gemm_rec, _gemm_rec_outs = _gemm_rec, None, None
         if et is None and rec:
+            if stream_handle() != self._stream:
+                raise RuntimeError("gemm_group: the current stream changed inside the context; the deferred products would be "
+                                   "issued on another stream than the launches around them")
             for i in range(0, len(rec), 10):
                 part = rec[i:i + 10]
                 arr = (GemmDesc * len(part))()
@@ -105,11 +116,20 @@ class gemm_group:
         return False
 
 
+_GEMM_OUT_ARGS = (6, 23)        # positions of C and asum in mmego_gemm's argument list (behind the stream)
+
+
 def call(name, *args):
     """Launch `mmego_<name>` on torch's current stream.  Tensors are passed as device pointers."""
-    if _gemm_rec is not None and name == "gemm":
-        _gemm_rec.append(args)
-        return
+    if _gemm_rec is not None and name != "gemm_group":
+        ptrs = {a.data_ptr() for a in args if isinstance(a, torch.Tensor)}
+        if ptrs & _gemm_rec_outs:
+            raise RuntimeError("gemm_group: mmego_%s takes the output of a product that is still deferred inside this context "
+                               "(only independent leaves may be grouped)" % name)
+        if name == "gemm":
+            _gemm_rec_outs.update(args[i].data_ptr() for i in _GEMM_OUT_ARGS if isinstance(args[i], torch.Tensor))
+            _gemm_rec.append(args)
+            return
     fn = getattr(lib(), "mmego_" + name)
     rc = fn(stream_handle(), *[_conv(a) for a in args])
     if rc != 0:

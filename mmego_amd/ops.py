@@ -60,16 +60,34 @@ _retired = []
 _capture_origin = {"stream": None}
 
 
-def mark_capture_origin():
-    """Called by whoever starts enqueuing a captured body: remembers the capture's ORIGIN stream.  On this ROCm a stream forked
-    from an already-forked capture stream crashes graph capture (minimal reproduction: scripts/repro_nested_capture_fork.py), so
-    code that wants a side stream under capture may only fork from the origin: see capture_can_fork()."""
-    _capture_origin["stream"] = torch.cuda.current_stream().cuda_stream if torch.cuda.is_current_stream_capturing() else None
+class capture:
+    """`with ops.capture(graph[, stream=...])`: torch.cuda.graph plus the bookkeeping of the capture's ORIGIN stream.
+
+    On this ROCm an event recorded on a stream that was itself forked from the capturing stream, and waited on by another
+    non-origin stream, aborts the process at capture (scripts/repro_nested_capture_fork.py), so code that wants a side stream
+    under capture may only fork from the origin (capture_can_fork()).  The origin is known exactly between the begin and the
+    end of THIS context -- set on entry, cleared on exit, never left behind for a later capture -- and the engines only read
+    it.  A capture started any other way (plain torch.cuda.graph) has no recorded origin: capture_can_fork() is False there
+    and every caller takes its single-chain form."""
+
+    def __init__(self, graph, **kw):
+        self._ctx = torch.cuda.graph(graph, **kw)
+
+    def __enter__(self):
+        if _capture_origin["stream"] is not None:
+            raise RuntimeError("ops.capture does not nest")
+        self._ctx.__enter__()
+        _capture_origin["stream"] = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _capture_origin["stream"] = None
+        return self._ctx.__exit__(et, ev, tb)
 
 
 def capture_can_fork():
     """True when a side stream may be forked from the current stream: always when running eagerly; under graph capture only on
-    the capture's origin stream."""
+    the origin stream of an ops.capture context."""
     if not torch.cuda.is_current_stream_capturing():
         return True
     return _capture_origin["stream"] is not None and torch.cuda.current_stream().cuda_stream == _capture_origin["stream"]

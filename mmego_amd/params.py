@@ -146,15 +146,53 @@ class FusedAdam:
     def zero_grad(self):
         pass  # every backward overwrites the flat gradient buffer
 
+    def layout(self):
+        """The fingerprint of the flat layout: (parameter name, offset, numel) in buffer order.  The order inside the flat buffers
+        is the net's own business (`flat_param_order`) and has changed between rounds, so a saved optimizer state carries it."""
+        f = self._ensure()
+        names = {id(p): n for n, p in f.module.named_parameters()}
+        return [(names[id(p)], int(off), int(p.numel())) for p, off in zip(f.params, f.offsets)]
+
     def state_dict(self):
-        """Moments and step counters (host copies) + hyper-parameters: everything a bit-exact resume needs."""
+        """Moments and step counters (host copies) + hyper-parameters + the layout the moments are stored in: everything a
+        bit-exact resume needs, also after the flat layout of the net has changed."""
         self._ensure()
         return {"m": self.m.cpu(), "v": self.v.cpu(), "state": self.state.cpu(), "lr": self.lr, "betas": tuple(self.betas),
-                "eps": self.eps, "weight_decay": self.weight_decay}
+                "eps": self.eps, "weight_decay": self.weight_decay, "layout": self.layout()}
 
     def load_state_dict(self, sd):
+        """Moments are matched to parameters BY NAME through the saved layout; a state saved under another flat order lands on
+        the right parameters.  A state without a layout (written before r03) is only accepted where no ambiguity exists: the net
+        has no layout of its own (registration order then and now).  Anything else is refused -- equal element counts say
+        nothing about where a parameter's moments are."""
         f = self._ensure()
-        if sd["m"].numel() != f.flat_p.numel():
-            raise ValueError("optimizer state has %d elements, the net's flat parameter buffer %d" % (sd["m"].numel(), f.flat_p.numel()))
-        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.state.copy_(sd["state"])
+        cur = self.layout()
+        saved = sd.get("layout")
+        if saved is None:
+            reg, off = [], 0
+            names = {id(p): n for n, p in f.module.named_parameters()}
+            for p in f.module.parameters():
+                reg.append((names[id(p)], off, p.numel()))
+                off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            if reg != cur or sd["m"].numel() != f.flat_p.numel():
+                raise ValueError("optimizer state carries no layout fingerprint and this net orders its flat buffer itself "
+                                 "(flat_param_order): the saved Adam moments cannot be matched to parameters; re-save the "
+                                 "training state with this build or resume from the model weights alone")
+            saved = cur
+        saved = [(str(n), int(o), int(k)) for n, o, k in saved]
+        if sorted((n, k) for n, _, k in saved) != sorted((n, k) for n, _, k in cur):
+            missing = sorted({n for n, _, _ in cur} ^ {n for n, _, _ in saved})
+            raise ValueError("optimizer state belongs to another net: parameters differ (%s%s)" %
+                             (", ".join(missing[:4]) or "shapes", " ..." if len(missing) > 4 else ""))
+        if saved == cur and sd["m"].numel() == f.flat_p.numel():
+            self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        else:
+            where = {n: o for n, o, _ in saved}
+            m_new, v_new = torch.zeros(f.flat_p.numel()), torch.zeros(f.flat_p.numel())
+            for n, o, k in cur:
+                so = where[n]
+                m_new[o:o + k] = sd["m"][so:so + k]
+                v_new[o:o + k] = sd["v"][so:so + k]
+            self.m.copy_(m_new); self.v.copy_(v_new)
+        self.state.copy_(sd["state"])
         self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]

@@ -119,9 +119,7 @@ class StageStep:
         self.loss = self.loss2[:1]
         self.last_pred = None
 
-    def _body(self, nested=False):
-        if not nested:
-            ops.mark_capture_origin()
+    def _body(self):
         self._body_forward()
         self._body_backward()
 
@@ -200,7 +198,7 @@ class StageStep:
         if self.use_graph and self.graph is None:
             self.warm_up()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with ops.capture(g):
                 self._body()
             self.graph = g
 
@@ -239,7 +237,6 @@ class ImuStep:
 
     def _body(self):
         from . import imu_train
-        ops.mark_capture_origin()
         s = self.static
         B, T = s["imu"].shape[0], s["imu"].shape[1]
         with torch.no_grad():
@@ -256,7 +253,7 @@ class ImuStep:
                 torch.cuda.synchronize()
                 self.net.seed_counter().copy_(keep)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with ops.capture(g):
                     self._body()
                 self.graph = g
             self.graph.replay()
@@ -283,12 +280,11 @@ class SharedImuStages:
         self.use_graph, self.graph = use_graph, None
 
     def _body(self):
-        ops.mark_capture_origin()
         with torch.no_grad():
             R, t = self.imu(self.imu_in)
             ops.copy2d(R.view(-1, 9), self.R.view(-1, 9))
             ops.copy2d(t.view(-1, 3), self.t.view(-1, 3))
-        self.pair._bodies(nested=True)
+        self.pair._bodies()
 
     def step(self):
         if self.use_graph:
@@ -302,7 +298,7 @@ class SharedImuStages:
                         t.copy_(k)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with ops.capture(g):
                     self._body()
                 self.graph = g
             self.graph.replay()
@@ -347,7 +343,7 @@ class ConcurrentStages:
             for st in self.stages:
                 allreduce_grads(st.net._flat, st.pg)
 
-    def _bodies(self, nested=False):
+    def _bodies(self):
         """Branch order: the LAST stage (longest tail: the Lower body also runs the frozen Upper_Net) gets its IMU_Net forward
         first, alone on the GPU, with its recurrences as two single-direction chains (blocks.two_chains); each earlier stage's
         IMU_Net forward follows on the launching stream when that one has finished, with the previous stage's small-kernel tail
@@ -355,8 +351,6 @@ class ConcurrentStages:
         buffer.  The IMU_Net forwards are compute-bound and gain nothing from running side by side, whereas the small-kernel
         tail of one stage overlaps with the IMU_Net forward of another (measured: 6.88 -> 6.54 ms per U+L step).  Other
         arrangements that were measured and dropped: DESIGN.md section 9."""
-        if not nested:
-            ops.mark_capture_origin()
         main = torch.cuda.current_stream()
         stages, streams = self.stages, [main] + self.side
         keep = [(st.imu, st.pose) for st in stages]
@@ -375,9 +369,9 @@ class ConcurrentStages:
                 if i > 0:
                     streams[i].wait_stream(main)
                     with torch.cuda.stream(streams[i]):
-                        st._body(nested=True)
+                        st._body()
                 else:
-                    st._body(nested=True)
+                    st._body()
         finally:
             for st, (imu, pose) in zip(stages, keep):
                 st.imu, st.pose = imu, pose
@@ -397,7 +391,7 @@ class ConcurrentStages:
                     t.copy_(k)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with ops.capture(g):
                 self._bodies()
             self.graph = g
 
@@ -466,7 +460,6 @@ class PipelinedStages:
         torch.cuda.synchronize()
 
     def _body(self):
-        ops.mark_capture_origin()
         main = torch.cuda.current_stream()
         for (Rc, tc), (Rn, tn) in zip(self.cur, self.nxt):
             ops.copy2d(Rn.view(-1, 9), Rc.view(-1, 9))
@@ -476,14 +469,14 @@ class PipelinedStages:
                 self.sides[k].wait_stream(main)
                 with torch.cuda.stream(self.sides[k]):
                     self._imu_forward(k)
-            self.pair._bodies(nested=True)
+            self.pair._bodies()
             for sd in self.sides:
                 main.wait_stream(sd)
             return
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             self._imu_forwards()
-        self.pair._bodies(nested=True)
+        self.pair._bodies()
         main.wait_stream(self.side)
 
     def prepare(self):
@@ -500,7 +493,7 @@ class PipelinedStages:
                 t.copy_(k)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with ops.capture(g):
                 self._body()
             self.graph = g
 

@@ -136,8 +136,7 @@ if "--pair" in sys.argv:
         st = torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
-            with torch.cuda.graph(g, stream=st):
-                ops.mark_capture_origin()
+            with ops.capture(g, stream=st):
                 run()
         torch.cuda.synchronize()
         for _ in range(3):

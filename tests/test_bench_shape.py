@@ -1,0 +1,113 @@
+"""GPU: parity AT THE SHAPE AND ARRANGEMENT THAT IS BENCHMARKED.
+
+The kernel-level and B=4 tests elsewhere run other dispatch branches than the timed step does (split-K thresholds, gemm64 vs
+gemm32kq, multi-round mlp_* workgroups, BatchNorm partial-block counts, tconv NG, the persistent projection GEMM and the
+LDS-DMA recurrent step at 512 rows).  Here the timed engine itself -- `ConcurrentStages(use_graph=True)` at B=64, T=8, N=128
+with IMU_Net(hidden 512) -- takes ONE step and is compared with one oracle Train_Upper + Train_Lower body
+(reference Processor/Train/Train_Upper.py:134-187, Train_Lower.py:155-230) on the same seeded weights and minibatch:
+losses 2e-5 rel., every element of both gradient buffers 2e-4 of the stage's largest gradient, joints 1e-3 cm, post-Adam
+parameters at the step-1 bar of test_hip_parity._compare_training.  bench.py prints the same figures in `parity`.
+"""
+import re
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from mmego_amd import hip
+    hip.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_ul_step_at_bench_shape_against_oracle(dev, use_graph):
+    import bench
+    torch.set_num_threads(bench.host_cores())
+    r = bench.ul_step_parity(dev, use_graph=use_graph)
+    noise = re.compile(bench.NOISE_GRAD)
+    for tag in ("upper", "lower"):
+        assert r["loss_rel_err_" + tag] < 2e-5, (tag, r["loss_rel_err_" + tag])
+        assert r[tag + "_cm"] < 1e-3, (tag, r[tag + "_cm"])                         # joints: the north-star bar, in cm
+        scale = r["tensors"][tag]["scale"]
+        for k, (eg, dp) in r["tensors"][tag]["per_param"].items():
+            assert eg < 2e-4 * scale, (tag, k, eg, scale)
+            if not noise.search(k):
+                assert dp <= 6e-5 + 2e-6, (tag, k, dp)                              # at most one +-lr flip of a ~0 gradient's sign
+        assert r["param_frac_moved_" + tag] < 0.05, (tag, r["param_frac_moved_" + tag])
+
+
+def _train_200(stage, p, dseed, dev):
+    """The HIP side of tests/golden/make_dropout_band.py: same fixed initial weights, `steps` StageStep.step()s (HIP graph) on
+    the 16 real sequences as one minibatch with the recorded head pose, then the eval-mode train-set joint error in cm."""
+    from conftest import golden, load_weights
+    from mmego_amd import nets
+    from mmego_amd.train_step import StageStep
+    from oracle import skeleton as sk
+    band, real = golden("g10_dropout_band.npz"), golden("real16.npz")
+    x0, target, body, R = [torch.tensor(real[k]).to(dev) for k in ("x", "target", "skl", "R")]
+    B, T = x0.shape[0], x0.shape[1]
+    torch.manual_seed(int(band["init_upper"] if stage == "upper" else band["init_lower"]))
+    net = (nets.UpperNet() if stage == "upper" else nets.LowerNet(64)).to(dev).train()
+    net.lstm_dropout = p
+    frozen = None
+    if stage == "lower":
+        frozen = load_weights(nets.UpperNet(), golden("w_upper_pretrained.npz")).to(dev).eval()
+    st = StageStep(stage, net, None, upper_frozen=frozen, lr=float(band["lr"]), use_graph=True)
+    st.bind(x0.clone(), torch.zeros(B, T, 20, 15, device=dev), body, target, R_gt=R)
+    net.seed_counter().fill_(dseed)
+    curve = []
+    for s in range(1, int(band["steps"]) + 1):
+        st.step()
+        if s % 50 == 0:
+            curve.append(st.loss.item())
+    net.eval()
+    t = target[:, :, 20].contiguous()
+    h0 = torch.zeros(6, B, 64, device=dev)
+    with torch.no_grad():
+        if stage == "upper":
+            pred = net(x0.clone(), h0, h0.clone(), body, R, t)[0]
+            tgt = target[:, :, list(sk.UPPER_MAP)]
+        else:
+            xl = x0.clone()
+            up = frozen(xl, h0, h0.clone(), body, R, t)[0]
+            pred = net(up.clone(), xl, None, None, None, None, body, R, t)[0]
+            tgt = target[:, :, list(sk.LOWER_MAP)]
+    return (pred - tgt).norm(dim=-1).mean().item() * 100.0, curve
+
+
+@pytest.mark.parametrize("stage", ["upper", "lower"])
+def test_dropout_active_training_lands_in_the_reference_band(dev, stage):
+    """VERDICT r02 item 1c.  The benchmarked configuration trains with nn.LSTM(dropout=0.1) live (reference
+    Net/Upper_Net.py:333, Net/Lower_Net.py:91-93); the two sides draw their masks from different RNGs, so parity there is
+    statistical.  tests/golden/g10_dropout_band.npz holds the REAL reference's final train-set joint error after 200 dropout-active
+    steps from fixed initial weights over 6 dropout seeds (the run-to-run band), the dropout-free deterministic run, and runs at
+    twice the rate (which leave the band upwards: the statistic separates a wrong rate from the band).  Here:
+      * dropout 0.1, three HIP dropout seeds: every run within the reference band widened by half its width on each side, their
+        mean inside the band itself;
+      * dropout 0: the HIP run's final error and 50/100/150/200-step losses against the reference's deterministic run.
+    What the statistic can and cannot see (the fixture's own numbers): for Upper_Net the dropout-free run (4.04 cm) and the runs at
+    rate 0.2 (4.37-4.47 cm) fall below / above the band [4.08, 4.33] cm; for Lower_Net they do not ([4.90, 5.12] cm against 5.12 and
+    4.90-5.25 cm), so the Lower half pins "trains equally well", not the rate."""
+    from conftest import golden
+    band = golden("g10_dropout_band.npz")
+    ref = band["ref.%s.p01.err_cm" % stage]
+    lo, hi = float(ref.min()), float(ref.max())
+    w = hi - lo
+    errs = [_train_200(stage, 0.1, 1000 + k, dev)[0] for k in range(3)]
+    for e in errs:
+        assert lo - 0.5 * w <= e <= hi + 0.5 * w, (stage, errs, (lo, hi))
+    assert lo <= sum(errs) / len(errs) <= hi, (stage, errs, (lo, hi))
+    e0, curve0 = _train_200(stage, 0.0, 0, dev)
+    ref0, refc = float(band["ref.%s.p00.err_cm" % stage][0]), band["ref.%s.p00.loss_curve" % stage][0]
+    # 200 Adam steps at lr 3e-4 amplify rounding differences: the oracle's own dropout-free run ends 0.017 cm (Upper) / 0.085 cm
+    # (Lower) from the reference's and its loss curve up to 3.6 % off at steps 100-200 (1e-4 .. 3e-3 at step 50) -- recorded in
+    # the fixture.  The HIP run is held to: half the dropout band's width on the final error, 1 % / 5 % on the curve.
+    assert abs(e0 - ref0) < 0.5 * w, (stage, e0, ref0, w)
+    for i, (a, b) in enumerate(zip(curve0, refc)):
+        assert abs(a - b) < (1e-2 if i == 0 else 5e-2) * abs(b), (stage, curve0, list(refc))
+    print("dropout band %s: reference [%.4f, %.4f] cm, HIP %s; dropout-free HIP %.4f vs reference %.4f" % (stage, lo, hi, ["%.4f" % e for e in errs], e0, ref0))

@@ -366,6 +366,7 @@ def test_stage_engines_with_two_chain_recurrence_in_graphs(dev):
         return su, sl, imu_u, imu_l
 
     def run(kind):
+        was = blocks._LSTM_TWO_CHAINS                 # (restored as found: MMEGO_LSTM_TWO_CHAINS=0 must survive this test)
         blocks._LSTM_TWO_CHAINS = kind != "reference"
         try:
             su, sl, imu_u, imu_l = build(kind != "pipelined", use_graph=kind == "stage_graphs")
@@ -391,7 +392,7 @@ def test_stage_engines_with_two_chain_recurrence_in_graphs(dev):
             torch.cuda.synchronize()
             return losses, su, sl
         finally:
-            blocks._LSTM_TWO_CHAINS = True
+            blocks._LSTM_TWO_CHAINS = was
     ref_losses, ru, rl = run("reference")
     for kind in ("stage_graphs", "concurrent", "pipelined"):
         losses, su, sl = run(kind)

@@ -463,7 +463,7 @@ def test_lstm_recurrence_two_chains_equal_one_launch_per_step(dev, monkeypatch):
                 torch.cuda.synchronize()
                 ops.fill(out, 0.0)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with ops.capture(g):
                     run()
                 g.replay()
             else:

@@ -84,3 +84,57 @@ def test_adjacency_matches_reference_golden():
     g = golden("g3_adjacency.npz")
     assert np.array_equal(gcn_adjacency("distance"), g["distance"])
     assert np.array_equal(gcn_adjacency("uniform"), g["uniform"])
+
+
+def test_optimizer_state_survives_a_flat_layout_change():
+    """FusedAdam.state_dict() carries the flat layout (name, offset, numel); load_state_dict() matches moments to parameters by
+    name.  Saved under registration order, loaded under a net-chosen order (and back): every parameter gets ITS moments; a state
+    without a fingerprint is refused where the net orders its buffer itself; a state of another net is refused."""
+    from mmego_amd.params import FlatParams, FusedAdam
+
+    class Net(torch.nn.Module):
+        def __init__(self, reorder):
+            super().__init__()
+            self.a = torch.nn.Linear(5, 3)           # 15 + 3 elements: offsets are padded to 4 floats
+            self.b = torch.nn.Linear(3, 7)
+            self.c = torch.nn.Parameter(torch.zeros(2))
+            self._reorder = reorder
+
+        def flat_param_order(self):
+            ps = list(self.parameters())
+            return [ps[3], ps[0], ps[4], ps[2], ps[1]] if self._reorder else ps
+
+    def fill(opt):
+        opt._ensure()
+        for k, (name, off, n) in enumerate(opt.layout()):
+            opt.m[off:off + n] = 10.0 * (["a.weight", "a.bias", "b.weight", "b.bias", "c"].index(name) + 1) + torch.arange(n) * 0.01
+            opt.v[off:off + n] = -opt.m[off:off + n]
+        opt.state.copy_(torch.tensor([7.0, 0.5, 0.25], dtype=torch.float64))
+
+    def by_name(opt):
+        return {name: (opt.m[off:off + n].clone(), opt.v[off:off + n].clone()) for name, off, n in opt.layout()}
+
+    for src_order, dst_order in ((False, True), (True, False), (True, True)):
+        src, dst = FusedAdam(FlatParams(Net(src_order))), FusedAdam(FlatParams(Net(dst_order)), lr=1.0)
+        fill(src)
+        sd = src.state_dict()
+        reg = [n for n, _ in Net(False).named_parameters()]
+        assert [n for n, _, _ in sd["layout"]] == (reg if not src_order else [reg[i] for i in (3, 0, 4, 2, 1)])
+        dst.load_state_dict(sd)
+        want, got = by_name(src), by_name(dst)
+        for name in want:
+            assert torch.equal(want[name][0], got[name][0]) and torch.equal(want[name][1], got[name][1]), (src_order, dst_order, name)
+        assert dst.state[0].item() == 7.0 and dst.lr == src.lr
+    # legacy state (no fingerprint): fine for a registration-order net, refused for a self-ordering one
+    src = FusedAdam(FlatParams(Net(False)))
+    fill(src)
+    legacy = {k: v for k, v in src.state_dict().items() if k != "layout"}
+    ok = FusedAdam(FlatParams(Net(False)))
+    ok.load_state_dict(legacy)
+    assert torch.equal(ok.m, src.m)
+    with pytest.raises(ValueError, match="layout fingerprint"):
+        FusedAdam(FlatParams(Net(True))).load_state_dict(legacy)
+    # another net's state
+    other = FusedAdam(FlatParams(torch.nn.Linear(4, 4)))
+    with pytest.raises(ValueError, match="another net"):
+        other.load_state_dict(src.state_dict())

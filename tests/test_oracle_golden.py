@@ -290,3 +290,40 @@ def test_oracle_fp32_gradients_close_to_fp64():
     scale = max(v.abs().max().item() for v in g64.values())
     for k in g64:
         assert (g32[k] - g64[k]).abs().max().item() < 1e-4 * scale, k
+
+
+def test_g10_oracle_trains_like_the_reference(real16):
+    """G10 (tests/golden/make_dropout_band.py): 200 dropout-FREE Upper_Net training steps of the oracle, live, against the REAL
+    reference's recorded deterministic run -- final train-set joint error and the loss at steps 50/100/150/200 -- and the
+    oracle's recorded dropout-active runs against the reference's band."""
+    band = golden("g10_dropout_band.npz")
+    x0, target, body, R = [torch.tensor(real16[k]) for k in ("x", "target", "skl", "R")]
+    t = target[:, :, 20].contiguous()
+    h0, c0 = ot.zeros_state(x0.shape[0])
+    tgt = target[:, :, list(sk.UPPER_MAP)]
+    torch.manual_seed(int(band["init_upper"]))
+    net = on.UpperNet().train()
+    set_lstm_dropout(net, 0.0)
+    opt = torch.optim.Adam(net.parameters(), lr=float(band["lr"]))
+    curve = []
+    for s in range(1, int(band["steps"]) + 1):
+        opt.zero_grad()
+        loss = ot.l1_sum(net(x0.clone(), h0, c0, body, R, t)[0], tgt)
+        loss.backward()
+        opt.step()
+        if s % 50 == 0:
+            curve.append(loss.item())
+    net.eval()
+    with torch.no_grad():
+        err = (net(x0.clone(), h0, c0, body, R, t)[0] - tgt).norm(dim=-1).mean().item() * 100.0
+    assert abs(err - float(band["ref.upper.p00.err_cm"][0])) < 0.05, (err, band["ref.upper.p00.err_cm"])
+    for i, (a, b) in enumerate(zip(curve, band["ref.upper.p00.loss_curve"][0])):      # (trajectories part ways slowly: 1e-4 at step 50)
+        assert abs(a - b) < (1e-2 if i == 0 else 5e-2) * abs(b), (curve, band["ref.upper.p00.loss_curve"][0])
+    # the recorded dropout-active oracle runs: trajectories of one seed part ways between the two sides (rounding differences,
+    # amplified by 200 Adam steps), so the comparison is of distributions -- the oracle's mean inside the reference's band, every
+    # oracle run inside the band widened by its width
+    for stage in ("upper", "lower"):
+        o, r = band["oracle.%s.p01.err_cm" % stage], band["ref.%s.p01.err_cm" % stage]
+        lo, hi = float(r.min()), float(r.max())
+        assert lo <= float(o.mean()) <= hi, (stage, o, r)
+        assert (o > lo - (hi - lo)).all() and (o < hi + (hi - lo)).all(), (stage, o, r)
