@@ -89,10 +89,12 @@ def test_dropout_active_training_lands_in_the_reference_band(dev, stage):
     twice the rate (which leave the band upwards: the statistic separates a wrong rate from the band).  Here:
       * dropout 0.1, three HIP dropout seeds: every run within the reference band widened by half its width on each side, their
         mean inside the band itself;
-      * dropout 0: the HIP run's final error and 50/100/150/200-step losses against the reference's deterministic run.
-    What the statistic can and cannot see (the fixture's own numbers): for Upper_Net the dropout-free run (4.04 cm) and the runs at
-    rate 0.2 (4.37-4.47 cm) fall below / above the band [4.08, 4.33] cm; for Lower_Net they do not ([4.90, 5.12] cm against 5.12 and
-    4.90-5.25 cm), so the Lower half pins "trains equally well", not the rate."""
+      * dropout 0: the HIP run's final error and 50/100/150/200-step losses inside the spread of the reference's dropout-free runs
+        from 1e-7-perturbed initial weights.
+    What the statistic can and cannot see (the fixture's own numbers): for Upper_Net the runs at rate 0.2 (4.37-4.47 cm) leave the
+    band [4.08, 4.33] cm upwards, the dropout-free runs ([3.97, 4.23] cm) overlap its lower half; for Lower_Net neither separates
+    ([4.90, 5.12] cm against 4.90-5.25 and [4.91, 5.31] cm).  It pins "trains as well as the reference, dropout live", and a
+    grossly wrong rate in Upper_Net; the mask rate itself is pinned by test_hip_parity.test_lstm64_fused_dropout_and_bias_pair."""
     from conftest import golden
     band = golden("g10_dropout_band.npz")
     ref = band["ref.%s.p01.err_cm" % stage]
@@ -102,12 +104,17 @@ def test_dropout_active_training_lands_in_the_reference_band(dev, stage):
     for e in errs:
         assert lo - 0.5 * w <= e <= hi + 0.5 * w, (stage, errs, (lo, hi))
     assert lo <= sum(errs) / len(errs) <= hi, (stage, errs, (lo, hi))
+    # Dropout-free: 200 Adam steps at lr 3e-4 amplify ROUNDING-sized differences -- the reference itself, started from weights
+    # perturbed by 1e-7 relative, ends anywhere in [3.97, 4.23] cm (Upper) / [4.91, 5.31] cm (Lower), and the CPU oracle's
+    # dropout-free run is not reproducible from process to process (multi-threaded reductions: 5.04 and 5.47 cm were both seen for
+    # Lower).  So a different-but-correct implementation is held to THAT band (widened by half its width), end point and curve.
     e0, curve0 = _train_200(stage, 0.0, 0, dev)
-    ref0, refc = float(band["ref.%s.p00.err_cm" % stage][0]), band["ref.%s.p00.loss_curve" % stage][0]
-    # 200 Adam steps at lr 3e-4 amplify rounding differences: the oracle's own dropout-free run ends 0.017 cm (Upper) / 0.085 cm
-    # (Lower) from the reference's and its loss curve up to 3.6 % off at steps 100-200 (1e-4 .. 3e-3 at step 50) -- recorded in
-    # the fixture.  The HIP run is held to: half the dropout band's width on the final error, 1 % / 5 % on the curve.
-    assert abs(e0 - ref0) < 0.5 * w, (stage, e0, ref0, w)
-    for i, (a, b) in enumerate(zip(curve0, refc)):
-        assert abs(a - b) < (1e-2 if i == 0 else 5e-2) * abs(b), (stage, curve0, list(refc))
-    print("dropout band %s: reference [%.4f, %.4f] cm, HIP %s; dropout-free HIP %.4f vs reference %.4f" % (stage, lo, hi, ["%.4f" % e for e in errs], e0, ref0))
+    pe = list(band["ref.%s.p00_perturbed.err_cm" % stage]) + list(band["ref.%s.p00.err_cm" % stage])
+    pc = list(band["ref.%s.p00_perturbed.loss_curve" % stage]) + list(band["ref.%s.p00.loss_curve" % stage])
+    plo, phi = float(min(pe)), float(max(pe))
+    assert plo - 0.5 * (phi - plo) <= e0 <= phi + 0.5 * (phi - plo), (stage, e0, pe)
+    for i, a in enumerate(curve0):
+        clo, chi = min(c[i] for c in pc), max(c[i] for c in pc)
+        assert clo - (chi - clo) - 1e-3 * clo <= a <= chi + (chi - clo) + 1e-3 * chi, (stage, i, curve0, [c[i] for c in pc])
+    print("dropout band %s: reference [%.4f, %.4f] cm, HIP %s; dropout-free: reference (perturbed 1e-7) [%.4f, %.4f] cm, HIP %.4f"
+          % (stage, lo, hi, ["%.4f" % e for e in errs], plo, phi, e0))
