@@ -193,15 +193,22 @@ def host_cores():
 
 
 def pmc_traffic(kernel_label):
-    """(HBM bytes per launch, source file) of a kernel from the COMMITTED rocprofv3 --pmc passes of this command (FETCH_SIZE and
-    WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950).  It is read from profiles/, not
-    measured in this run (counters need rocprofv3 around the process): the bench line says so in `traffic_source`."""
-    for name in ("r02_pmc_counters.json", "r01_pmc_counters.json"):
+    """(HBM bytes per launch, source) of a kernel from the COMMITTED rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950).  Read from profiles/, not measured in this run
+    (counters need rocprofv3 around the process); `traffic_source` says which passes the file holds: from r03 on they are taken
+    around THIS program (`bench.py --trace-only --no-graph`, scripts/collect_profiles.sh), the r02 / r01 files around the
+    micro-benchmarks scripts/bench_gemm_pair.py / bench_lstm_step.py."""
+    key = kernel_label.split(" ")[0]
+    for name, what in (("r03_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself"),
+                       ("r02_pmc_counters.json", "rocprofv3 --pmc passes of the micro-benchmarks scripts/bench_gemm_pair.py / bench_lstm_step.py"),
+                       ("r01_pmc_counters.json", "rocprofv3 --pmc passes of the micro-benchmarks")):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
-            v = json.load(open(path)).get(kernel_label.split(" ")[0].split("<")[0], {}).get("hbm_bytes_per_launch")
+            d = json.load(open(path))
+            e = d.get(key) or d.get(key + "<32>") or d.get(key.split("<")[0]) or {}
+            v = e.get("hbm_bytes_per_launch")
             if v is not None:
-                return v, "profiles/" + name + " (rocprofv3 --pmc passes of `bench.py --trace-only`, committed; not measured in this run)"
+                return v, "profiles/%s (%s; committed, not measured in this run)" % (name, what)
     return None, None
 
 
@@ -647,6 +654,9 @@ def main():
                                                                   "as concurrent branches of one HIP graph"),
                           "global_batch": world * B, "seq_len": T, "points": N, "parallelism": "dp%d" % world,
                           "hip_graph": not args.no_graph, "stages_concurrent": not args.sequential},
+               "value_is": ("B*T / ms_per_step of the arrangement named in config.workload (%s); SURVEY 8-d's formula "
+                            "B*T / (t_upper + t_lower) is `frames_per_s_sequential`" %
+                            ("stages one after the other" if args.sequential else "the two bodies as concurrent branches of one HIP graph")),
                "ms_per_step_imu_shared": dt_shared / args.steps * 1e3,
                "frames_per_s_imu_shared": world * B * T / (dt_shared / args.steps),
                "ms_per_step_sequential": t_u + t_l, "frames_per_s_sequential": world * B * T / ((t_u + t_l) * 1e-3),
@@ -705,12 +715,22 @@ def main():
             cands["gemm_tile_persistent_kernel (128x128 tiles; IMU_Net LSTM input projections, both directions per launch: 2 x 10240 x 2048 x {512,1024})"] = g128
         if g64:
             cands["gemm_tile_kernel<64,64> (smaller 64-aligned products)"] = g64
-        # dominant kernel = largest total time over the eager replay; no tie rule.  Every candidate is reported with its own
-        # fraction in `roofline_kernels`, so a near tie between the projection GEMM and the recurrent step shows as such.
-        # (per-launch entries of the recurrent step stay out of the contest when a whole-recurrence entry covers them)
-        totals = {k: sum(m for m, _ in v) for k, v in cands.items() if not k.startswith("lstm_step_dma_kernel<16>")}
-        best_k = max(totals, key=totals.get)
-        best = (best_k, cands[best_k])
+        # dominant kernel = largest CRITICAL-PATH time over the eager replay; no tie rule.  A family's critical-path time is the
+        # sum of its launch durations, except that the single-direction recurrent steps (<16>) run as two concurrent chains: two
+        # of their launches share one slot of the dependent chain, so they count half.  The rnn_fast recurrent steps enter the
+        # contest as ONE family (<32> launches + <16> launches).  Every candidate is also reported on its own in `roofline_kernels`.
+        crit = {k: sum(m for m, _ in v) * (0.5 if k.startswith("lstm_step_dma_kernel<16>") else 1.0) for k, v in cands.items()}
+        fam_step = [k for k in cands if k.startswith("lstm_step_dma_kernel")]
+        contest = {k: c for k, c in crit.items() if k not in fam_step}
+        if fam_step:
+            contest["lstm_step_dma_kernel (IMU_Net rnn_fast recurrent steps, 512 rows x 2048 gates x K=512 per direction; <32>: both "
+                    "directions per launch, <16>: one direction per launch as two concurrent chains, counted at half their duration)"] = \
+                sum(crit[k] for k in fam_step)
+        best_k = max(contest, key=contest.get)
+        if best_k in cands:
+            best = (best_k, cands[best_k])
+        else:       # the recurrent-step family: durations scaled to critical-path time, flops as launched
+            best = (best_k, [(m * (0.5 if k.startswith("lstm_step_dma_kernel<16>") else 1.0), f) for k in fam_step for m, f in cands[k]])
         tot_ms = sum(m for m, _ in best[1])
         tot_fl = sum(f for _, f in best[1])
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
@@ -720,7 +740,9 @@ def main():
                            "kernel": best[0],
                            "avg_launch_us": tot_ms / len(best[1]) * 1e3, "launches_per_step": len(best[1]) // iters,
                            "flop_per_launch_avg": tot_fl / len(best[1]),
-                           "share_of_step": (tot_ms / iters) / (t_u + t_l)}
+                           "share_of_step": (tot_ms / iters) / (t_u + t_l),
+                           "contest_ms_per_step": {k.split(" ")[0]: c / iters for k, c in contest.items()},
+                           "contest": "largest critical-path time per step over the eager replay (see roofline_kernels for every family)"}
         # the WHOLE step against the same roofline: algorithmic FLOPs of the literal U+L step / measured step time / peak
         step_flop = STEP_MFLOP_PER_FRAME * 1e6 * B * T
         out["roofline_step"] = {"bound": "mfma", "algorithmic_gflop_per_step": step_flop / 1e9,

@@ -8,11 +8,19 @@ import os
 import sys
 
 root = sys.argv[1]
-KERNELS = {"lstm_step_dma_kernel": "step", "gemm_tile_persistent_kernel": "gemm"}
+# kernel-name prefix -> counter-pass directory stem.  From r03 the passes wrap bench.py itself ("bench"); the r02 layout (passes around
+# the micro-benchmarks: "step" / "gemm") is still understood.
+KERNELS = {"lstm_step_dma_kernel<32>": ("bench", "step"), "lstm_step_dma_kernel<16>": ("bench",), "lstm_step_small_kernel": ("bench",),
+           "gemm_tile_persistent_kernel": ("bench", "gemm"), "lstm_step_dma_kernel": ("step",)}
 res = {}
-for kname, which in KERNELS.items():
+for kname, stems in KERNELS.items():
     by_grid = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(root, "pmc_%s_*" % which, "**", "*counter_collection.csv"), recursive=True):
+    files = []
+    for which in stems:
+        files = glob.glob(os.path.join(root, "pmc_%s_*" % which, "**", "*counter_collection.csv"), recursive=True)
+        if files:
+            break
+    for f in files:
         for r in csv.DictReader(open(f)):
             if kname in r["Kernel_Name"]:
                 by_grid["all"][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -35,7 +43,7 @@ for kname, which in KERNELS.items():
         entry["hbm_GBps"] = entry["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9
         entry["hbm_fraction_of_8TBps"] = entry["hbm_GBps"] / 8000.0
     res[kname] = entry
-res["note"] = ("separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group); FETCH doubled per MI355X_MICROARCH.md; "
-               "lstm_step: lstm_step_dma_kernel<32>, Bn=512,H=512,ndir=2 (scripts/bench_lstm_step.py 512 0); gemm: scripts/bench_gemm_pair.py, both "
-               "directions per launch, 2 x (10240 x 2048 x {512,1024}) averaged as in the U+L step")
+res["note"] = ("separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ group) around `bench.py --trace-only --no-graph` itself "
+               "(scripts/collect_profiles.sh); FETCH doubled per MI355X_MICROARCH.md; per-launch averages over all launches of the "
+               "kernel in that process (gemm_tile_persistent_kernel: the K = 512 and K = 1024 projection products of both IMU_Net forwards)")
 print(json.dumps(res, indent=1))
