@@ -280,6 +280,10 @@ int mmego_topk_rows(void* stream, const float* pts, long F, int N, int C, int ke
  * E[f,0:21] joint errors (m) of the assembled 21-joint skeleton, E[f,21:41] bone angles (deg),
  * E[f,41] mean upper-joint error, E[f,42] mean lower-joint error.  Means over frames via mmego_colsum. */
 int mmego_pose_errors(void* stream, const float* upper, const float* lower, const float* target, long F, float* E);
+/* Per-frame figures of the Upper stage's epoch evaluation (Processor/Train/Train_Upper.py:75-88 angle_loss, :228-240):
+ * U[f,0:15] error (m) of the 15 upper joints (upper_joint_map order), U[f,15:29] angles (deg) of the 14 upper-body bones,
+ * U[f,29] sum |upper - target[upper_joint_map]| of the frame (its share of L1Loss(sum)).  upper [F,15,3], target [F,21,3], U [F,30]. */
+int mmego_pose_errors_upper(void* stream, const float* upper, const float* target, long F, float* U);
 
 /* ---- anchor ("voxel") grouping of UpperNetwlocal (group.hip) -----------------------------------------
  * Per frame and per anchor of the 3x3x3 grid: indices (int64, exact, stable ties) of the 8 nearest points and

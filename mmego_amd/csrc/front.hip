@@ -1,0 +1,292 @@
+// Eval-mode front end of Upper_Net in ONE kernel: Transform2H -> PointNet (6-8-16-24) -> concat with the first four point
+// columns -> GlobalPointNet (28-32-48-64) -> softmax attention pooling over the frame's points.
+// Replaces, for the frozen / evaluated Upper_Net (reference Net/Upper_Net.py:242-266 PointNet, :270-301 GlobalPointNet incl. its
+// attention pooling, :381-393 UpperNet.forward up to the sequence model, Util/Universal_Util/Utils.py:284-292 Transform2H), the
+// chain transform2h -> mlp3_eval -> mlp3_eval -> attn_pool_forward, whose 28- and 64-channel per-point tensors went through HBM
+// between the launches.  Here a frame's points never leave the CU: per frame the kernel reads the radar tile (N x 6 floats), writes
+// the transformed points back (quirk Q1: the caller's tensor is transformed in place and Lower_Net reads it afterwards) and
+// emits 64 pooled floats + the N attention weights.
+//
+// Layout.  One workgroup (4 waves) walks frames; a wave owns 16-point SLABS of the frame (slab s of a frame goes to wave s & 3), and
+// a slab runs through all six stages inside its wave: the 16 x K activation tile of a stage is written by the wave that reads it
+// (D layout -> [row][k] in wave-private LDS -> A layout), so NO workgroup barrier separates the stages; the (BatchNorm-folded,
+// zero-padded) weights are staged once per workgroup and only read afterwards.  v_mfma_f32_16x16x4_f32, K padded to multiples of
+// 16, operands fetched with one ds_read_b128 per four MFMA steps through a k-permutation shared by both operands (lane (r, q)
+// holds k = 16 c + 4 q + s at step s of chunk c); row strides K + 4 floats keep those 16-byte reads conflict-free.
+// The pooling is an online softmax per wave (running max / sum / weighted column sums over its slabs), combined across the four
+// waves at the end of the frame in a fixed order: deterministic.
+#include "common.h"
+
+#define FR_SLAB 16
+// row strides (floats) of the [n][k] weight tiles and [row][k] activation tiles: Kpad + 4
+#define FR_S16 20
+#define FR_S32 36
+#define FR_S48 52
+
+struct FrontLayer { const float* W; const float* b; const float* gamma; const float* beta; const float* rmean; const float* rvar; };
+struct FrontP {
+  float* x; const float* x_src; const float* R; const float* t; long F; int N;
+  FrontLayer l[6];              // PointNet conv1..3, GlobalPointNet conv1..3 (gamma == NULL: no BatchNorm to fold)
+  const float* attn_w; const float* attn_b; float eps;
+  float* vec; float* attn;
+};
+
+// weights in LDS: [n][k] tiles with stride S; offsets in floats
+#define FR_W1 0                               // 16 x 16 (8 x 6 real)
+#define FR_W2 (FR_W1 + 16 * FR_S16)           // 16 x 16 (16 x 8)
+#define FR_W3 (FR_W2 + 16 * FR_S16)           // 32 x 16 (24 x 16)
+#define FR_G1 (FR_W3 + 32 * FR_S16)           // 32 x 32 (32 x 28)
+#define FR_G2 (FR_G1 + 32 * FR_S32)           // 48 x 32
+#define FR_G3 (FR_G2 + 48 * FR_S32)           // 64 x 48
+#define FR_WEND (FR_G3 + 64 * FR_S48)
+#define FR_B1 FR_WEND                         // biases: 16, 16, 32, 32, 48, 64; then the 64 score weights
+#define FR_B2 (FR_B1 + 16)
+#define FR_B3 (FR_B2 + 16)
+#define FR_C1 (FR_B3 + 32)
+#define FR_C2 (FR_C1 + 32)
+#define FR_C3 (FR_C2 + 48)
+#define FR_AW (FR_C3 + 64)
+#define FR_SHARED_END (FR_AW + 64)
+// wave-private activation tiles: P [16][20] | Q [16][20] (together also G1 [16][36]) | FZ [16][36] | G2 [16][52]
+#define FR_ACT_P 0
+#define FR_ACT_Q (16 * FR_S16)
+#define FR_ACT_FZ (2 * 16 * FR_S16)
+#define FR_ACT_G2 (FR_ACT_FZ + 16 * FR_S32)
+#define FR_ACT_WAVE (FR_ACT_G2 + 16 * FR_S48)
+#define FR_MAXN 1024
+
+__device__ __forceinline__ float fr_dot3_nofma(float a0, float a1, float a2, float b0, float b1, float b2) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b1)), __fmul_rn(a2, b2));
+}
+
+// one stage of a slab: D[16 rows][NCT*16 cols] = A[16][KCH*16] . W[NCT*16][KCH*16]^T, both operands in LDS ([row][k], [n][k])
+template <int NCT, int KCH, int SA, int SW>
+__device__ __forceinline__ void fr_stage(const float* A, const float* W, f32x4 (&acc)[NCT], int fr, int fq) {
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < KCH; ++c) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(A + fr * SA + 16 * c + 4 * fq);
+    f32x4 b[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) b[ct] = *reinterpret_cast<const f32x4*>(W + (ct * 16 + fr) * SW + 16 * c + 4 * fq);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[ct][s], acc[ct], 0, 0, 0);
+  }
+}
+
+// relu(D + bias) -> [row][col0 + ...] of the next stage's A tile (lane (fr, fq), register i: row 4 fq + i, column 16 ct + fr)
+template <int NCT, int SD>
+__device__ __forceinline__ void fr_store(const f32x4 (&acc)[NCT], const float* bias, float* D, int col0, int fr, int fq) {
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const float bv = bias[ct * 16 + fr];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) D[(4 * fq + i) * SD + col0 + ct * 16 + fr] = fmaxf(acc[ct][i] + bv, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
+  __shared__ __attribute__((aligned(16))) float sh[FR_SHARED_END];
+  __shared__ __attribute__((aligned(16))) float act[4 * FR_ACT_WAVE];
+  __shared__ float sc[FR_MAXN];                    // raw scores of the frame's points
+  __shared__ float comb[2][4][66];                 // per wave: running max, running sum, 64 weighted column sums (double buffered)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- weights -> LDS (BatchNorm folded: s = gamma / sqrt(var + eps); Wf = s W; bf = (b - mean) s + beta -- bn_fold_linear's
+  // expressions), zero padded.  All loads unconditional on clamped indices, selects afterwards (see mlp3.hip).
+  {
+    const int Cn[6] = {8, 16, 24, 32, 48, 64}, Kn[6] = {6, 8, 16, 28, 32, 48};
+    const int Cp[6] = {16, 16, 32, 32, 48, 64}, Kp[6] = {16, 16, 16, 32, 32, 48};
+    const int Sw[6] = {FR_S16, FR_S16, FR_S16, FR_S32, FR_S32, FR_S48};
+    const int Wo[6] = {FR_W1, FR_W2, FR_W3, FR_G1, FR_G2, FR_G3}, Bo[6] = {FR_B1, FR_B2, FR_B3, FR_C1, FR_C2, FR_C3};
+#pragma unroll
+    for (int L = 0; L < 6; ++L) {
+      const FrontLayer& q = p.l[L];
+      const bool fold = q.gamma != nullptr;
+      const int tot = Cp[L] * Kp[L];
+      for (int i = tid; i < tot; i += 256) {
+        const int n = i / Kp[L], k = i - n * Kp[L];
+        const int nc = min(n, Cn[L] - 1), kc = min(k, Kn[L] - 1);
+        float w = q.W[nc * Kn[L] + kc];
+        float s = 1.f;
+        if (fold) s = q.gamma[nc] / sqrtf(q.rvar[nc] + p.eps);
+        sh[Wo[L] + n * Sw[L] + k] = (n < Cn[L] && k < Kn[L]) ? s * w : 0.f;
+      }
+      if (tid < Cp[L]) {
+        const int nc = min(tid, Cn[L] - 1);
+        float b = q.b ? q.b[nc] : 0.f;
+        if (fold) {
+          const float s = q.gamma[nc] / sqrtf(q.rvar[nc] + p.eps);
+          b = (b - q.rmean[nc]) * s + q.beta[nc];
+        }
+        sh[Bo[L] + tid] = tid < Cn[L] ? b : 0.f;
+      }
+    }
+    if (tid < 64) sh[FR_AW + tid] = p.attn_w[tid];
+  }
+  const float attn_b = p.attn_b ? p.attn_b[0] : 0.f;
+  __syncthreads();
+
+  float* const A = act + wave * FR_ACT_WAVE;
+  const int N = p.N, nslab = N / FR_SLAB;
+  int par = 0;
+  for (long f = blockIdx.x; f < p.F; f += gridDim.x, par ^= 1) {
+    const float* Rf = p.R + f * 9;
+    const float* tf = p.t + f * 3;
+    float r[9], tt[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r[i] = Rf[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tt[i] = tf[i];
+    float* xf = p.x + f * (long)N * 6;
+    const float* xs = p.x_src ? p.x_src + f * (long)N * 6 : xf;
+    // running softmax state of this wave: max, sum, and this lane's share of the weighted column sums (column 16 ct + fr, rows of
+    // lane group fq; the four groups are added at the end)
+    float m_run = -INFINITY, s_run = 0.f;
+    float col[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = wave; s < nslab; s += 4) {
+      // ---- the slab's 16 points: lanes 0..15 load one row each (24 bytes), transform it, write it back and into the A tile
+      if (lane < FR_SLAB) {
+        const long row = (long)s * FR_SLAB + lane;
+        const float2 v01 = *reinterpret_cast<const float2*>(xs + row * 6);
+        const float2 v23 = *reinterpret_cast<const float2*>(xs + row * 6 + 2);
+        const float2 v45 = *reinterpret_cast<const float2*>(xs + row * 6 + 4);
+        const float d0 = __fsub_rn(v01.x, tt[0]), d1 = __fsub_rn(v01.y, tt[1]), d2 = __fsub_rn(v23.x, tt[2]);
+        const float h0 = fr_dot3_nofma(r[0], r[1], r[2], d0, d1, d2);
+        const float h1 = fr_dot3_nofma(r[3], r[4], r[5], d0, d1, d2);
+        const float h2 = fr_dot3_nofma(r[6], r[7], r[8], d0, d1, d2);
+        *reinterpret_cast<float2*>(xf + row * 6) = make_float2(h0, h1);
+        *reinterpret_cast<float2*>(xf + row * 6 + 2) = make_float2(h2, v23.y);
+        if (p.x_src) *reinterpret_cast<float2*>(xf + row * 6 + 4) = v45;
+        float* a0 = A + FR_ACT_P + lane * FR_S16;
+        *reinterpret_cast<f32x4*>(a0) = (f32x4){h0, h1, h2, v23.y};
+        *reinterpret_cast<f32x4*>(a0 + 4) = (f32x4){v45.x, v45.y, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(a0 + 8) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(a0 + 12) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float* fz = A + FR_ACT_FZ + lane * FR_S32;                         // concat: the first four point columns ...
+        *reinterpret_cast<f32x4*>(fz) = (f32x4){h0, h1, h2, v23.y};
+        *reinterpret_cast<f32x4*>(fz + 28) = (f32x4){0.f, 0.f, 0.f, 0.f};  // ... and the k padding behind the 24 features
+      }
+      // (wave-private LDS: the writes above are ordered before the reads below by the compiler's lgkmcnt waits)
+      f32x4 a1[1], a2[1], a3[2], g1[2], g2[3], g3[4];
+      fr_stage<1, 1, FR_S16, FR_S16>(A + FR_ACT_P, sh + FR_W1, a1, fr, fq);
+      fr_store<1, FR_S16>(a1, sh + FR_B1, A + FR_ACT_Q, 0, fr, fq);
+      fr_stage<1, 1, FR_S16, FR_S16>(A + FR_ACT_Q, sh + FR_W2, a2, fr, fq);
+      fr_store<1, FR_S16>(a2, sh + FR_B2, A + FR_ACT_P, 0, fr, fq);
+      fr_stage<2, 1, FR_S16, FR_S16>(A + FR_ACT_P, sh + FR_W3, a3, fr, fq);
+      // PointNet's 24 features land behind the four point columns: columns 4..27 of the concat tile (the padded outputs 24..31
+      // of the stage are zero and would land in columns 28..35: only columns < 28 are stored)
+      {
+        const float b0 = sh[FR_B3 + fr], b1 = sh[FR_B3 + 16 + fr];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float* d = A + FR_ACT_FZ + (4 * fq + i) * FR_S32 + 4;
+          d[fr] = fmaxf(a3[0][i] + b0, 0.f);
+          if (fr < 8) d[16 + fr] = fmaxf(a3[1][i] + b1, 0.f);
+        }
+      }
+      fr_stage<2, 2, FR_S32, FR_S32>(A + FR_ACT_FZ, sh + FR_G1, g1, fr, fq);
+      fr_store<2, FR_S32>(g1, sh + FR_C1, A + FR_ACT_P, 0, fr, fq);            // G1 tile [16][36] over P | Q
+      fr_stage<3, 2, FR_S32, FR_S32>(A + FR_ACT_P, sh + FR_G2, g2, fr, fq);
+      fr_store<3, FR_S48>(g2, sh + FR_C2, A + FR_ACT_G2, 0, fr, fq);
+      fr_stage<4, 3, FR_S48, FR_S48>(A + FR_ACT_G2, sh + FR_G3, g3, fr, fq);
+      // ---- scores and the online softmax update.  Lane (fr, fq), register i: point 4 fq + i of the slab, columns 16 ct + fr.
+      float y[4][4], part[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[i] = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float bv = sh[FR_C3 + ct * 16 + fr], wv = sh[FR_AW + ct * 16 + fr];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          y[ct][i] = fmaxf(g3[ct][i] + bv, 0.f);
+          part[i] += y[ct][i] * wv;
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[i] += __shfl_xor(part[i], o, 64);      // sum over the 16 lanes of a group: all columns
+      float smax = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { part[i] += attn_b; smax = fmaxf(smax, part[i]); }
+      if (fr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc[s * FR_SLAB + 4 * fq + i] = part[i];
+      }
+      smax = fmaxf(smax, __shfl_xor(smax, 16, 64));
+      smax = fmaxf(smax, __shfl_xor(smax, 32, 64));                              // max over the slab's 16 points
+      const float m_new = fmaxf(m_run, smax);
+      const float resc = __expf(m_run - m_new);                                  // (exp(-inf) = 0 on the first slab)
+      float e[4], esum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { e[i] = __expf(part[i] - m_new); esum += e[i]; }
+      esum += __shfl_xor(esum, 16, 64);
+      esum += __shfl_xor(esum, 32, 64);
+      s_run = s_run * resc + esum;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        float v = col[ct] * resc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v += e[i] * y[ct][i];
+        col[ct] = v;
+      }
+      m_run = m_new;
+    }
+    // ---- combine the four waves (fixed order) and emit the frame's outputs
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      col[ct] += __shfl_xor(col[ct], 16, 64);
+      col[ct] += __shfl_xor(col[ct], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) comb[par][wave][2 + ct * 16 + lane] = col[ct];
+      if (lane == 0) { comb[par][wave][0] = m_run; comb[par][wave][1] = s_run; }
+    }
+    __syncthreads();
+    float M = comb[par][0][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, comb[par][w][0]);
+    float S = 0.f, sw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { sw[w] = __expf(comb[par][w][0] - M); S += comb[par][w][1] * sw[w]; }
+    const float inv = 1.0f / S;
+    if (tid < 64) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += comb[par][w][2 + tid] * sw[w];
+      p.vec[f * 64 + tid] = v * inv;
+    }
+    for (int n = tid; n < N; n += 256) p.attn[f * (long)N + n] = __expf(sc[n] - M) * inv;
+    // (sc is rewritten by the next frame's slabs: every wave must be past the loop above first; comb is double buffered)
+    __syncthreads();
+  }
+}
+
+// w: host-side table of 38 device pointers: for PointNet conv1..3 then GlobalPointNet conv1..3: W, b, gamma, beta, running_mean,
+// running_var (gamma..running_var NULL for a layer without BatchNorm); then the attention Linear's weight [64] and bias [1].
+extern "C" int mmego_upper_front_eval(void* stream, float* x, const float* x_src, const float* R, const float* t, long F, int N,
+                                      const float* const* w, float eps, float* vec, float* attn) {
+  MMEGO_REQUIRE(x && R && t && w && vec && attn && F > 0);
+  MMEGO_REQUIRE(N >= FR_SLAB && N <= FR_MAXN && N % FR_SLAB == 0);
+  MMEGO_REQUIRE((((uintptr_t)x | (uintptr_t)x_src) & 7) == 0);
+  FrontP p;
+  p.x = x; p.x_src = x_src; p.R = R; p.t = t; p.F = F; p.N = N;
+  for (int L = 0; L < 6; ++L) {
+    MMEGO_REQUIRE(w[6 * L]);
+    const bool bn = w[6 * L + 2] != nullptr;
+    MMEGO_REQUIRE(!bn || (w[6 * L + 3] && w[6 * L + 4] && w[6 * L + 5]));
+    p.l[L] = {w[6 * L], w[6 * L + 1], w[6 * L + 2], w[6 * L + 3], w[6 * L + 4], w[6 * L + 5]};
+  }
+  MMEGO_REQUIRE(w[36]);
+  p.attn_w = w[36]; p.attn_b = w[37]; p.eps = eps; p.vec = vec; p.attn = attn;
+  const unsigned grid = (unsigned)(F < 512 ? F : 512);          // ~72 KB of LDS: two workgroups per CU, frames walked persistently
+  hipLaunchKernelGGL(upper_front_eval_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

@@ -589,6 +589,53 @@ __global__ __launch_bounds__(128) void pose_errors_kernel(const float* __restric
   e[42] = lo_sum / 8.f;
 }
 
+// Upper-body-only figures of Train_Upper.eval_model (Processor/Train/Train_Upper.py:75-88,228-240), per frame:
+// U[f, 0:15] Euclidean error of the 15 upper joints (upper_joint_map order), U[f, 15:29] angle (deg) between predicted and true
+// bone vectors of the 14 upper-body bones, U[f, 29] sum |pred - target| over the frame's 45 coordinates (the L1 loss share).
+__global__ __launch_bounds__(128) void pose_errors_upper_kernel(const float* __restrict__ upper, const float* __restrict__ target,
+                                                                long F, float* __restrict__ U) {
+  const int umap[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 20};
+  // skeleton_upper_body as positions in upper_joint_map: (20,3) (3,2) (2,1) (2,4) (2,8) (4,5) (5,6) (6,7) (8,9) (9,10) (10,11) (1,0) (0,12) (0,16)
+  const int bones[14][2] = {{14, 3}, {3, 2}, {2, 1}, {2, 4}, {2, 8}, {4, 5}, {5, 6}, {6, 7}, {8, 9}, {9, 10},
+                            {10, 11}, {1, 0}, {0, 12}, {0, 13}};
+  long f = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  float p[15][3], q[15][3];
+  const float* tg = target + f * 63;
+  float l1 = 0.f;
+  float* u = U + f * 30;
+  for (int s = 0; s < 15; ++s) {
+    float d2 = 0.f;
+    for (int i = 0; i < 3; ++i) {
+      const float v = upper[(f * 15 + s) * 3 + i], w = tg[umap[s] * 3 + i];
+      p[s][i] = v; q[s][i] = w;
+      const float d = v - w;
+      d2 += d * d;
+      l1 += fabsf(d);
+    }
+    u[s] = sqrtf(d2);
+  }
+  for (int b = 0; b < 14; ++b) {
+    const int r = bones[b][0], l = bones[b][1];
+    float dot = 0.f, n1 = 0.f, n2 = 0.f;
+    for (int i = 0; i < 3; ++i) {
+      const float a = p[l][i] - p[r][i], c = q[l][i] - q[r][i];
+      dot += a * c; n1 += a * a; n2 += c * c;
+    }
+    float cs = dot / (fmaxf(sqrtf(n1), 1e-8f) * fmaxf(sqrtf(n2), 1e-8f));
+    cs = fminf(fmaxf(cs, -1.0f), 1.0f);
+    u[15 + b] = fabsf(acosf(cs) / 3.14159265358f * 180.0f);
+  }
+  u[29] = l1;
+}
+
+extern "C" int mmego_pose_errors_upper(void* stream, const float* upper, const float* target, long F, float* U) {
+  MMEGO_REQUIRE(upper && target && U && F > 0);
+  hipLaunchKernelGGL(pose_errors_upper_kernel, dim3(cdiv(F, 128)), dim3(128), 0, (hipStream_t)stream, upper, target, F, U);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
 extern "C" int mmego_pose_errors(void* stream, const float* upper, const float* lower, const float* target, long F,
                                  float* E) {
   MMEGO_REQUIRE(upper && lower && target && E && F > 0);

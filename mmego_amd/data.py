@@ -254,6 +254,23 @@ def _gather_field_into(self, name, index, out):
 DeviceArrays.gather_field_into = _gather_field_into
 
 
+class ArraySplit:
+    """A data split given as arrays (what PosePC exposes to the trainers: `_items` in the reference loader's tuple order
+    data, target, skl, imu, ground, foot_contact, R_R0R, t_R0R -- Dataset_sample.py:264-277).  For callers that hold windows
+    already (tests, fixtures)."""
+
+    def __init__(self, data, target, skl, imu, R_R0R):
+        n = len(data)
+        z = np.zeros((n, 1), dtype=np.float32)
+        self._items = [np.asarray(data), np.asarray(target), np.asarray(skl), np.asarray(imu), z, z, np.asarray(R_R0R), z]
+
+    def __len__(self):
+        return len(self._items[0])
+
+    def __getitem__(self, i):
+        return tuple(a[i] for a in self._items)
+
+
 def batch_indices(n, batch_size, shuffle, rng=None):
     """The index sets `batches` iterates over (same RNG consumption), for on-device gathering."""
     order = (rng or np.random).permutation(n) if shuffle else np.arange(n)

@@ -16,7 +16,7 @@ import torch
 
 from . import hip, ops
 from .config import Config, ConfigDemo
-from .data import DeviceArrays, PosePC, batch_indices, batches
+from .data import DeviceArrays, PosePC, batch_indices
 from .nets import IMUNet, LowerNet, UpperNet
 from .train_step import PipelinedStages, StageStep, broadcast_flag, empty_step, shard_of, sync_replicas
 from .utils import EarlyStopping
@@ -24,10 +24,6 @@ from .utils import EarlyStopping
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # where report/, model/, lossAndacc/ go: the reference's Processor/Train (Train_Upper.py:22-50) unless MMEGO_TRAIN_DIR says otherwise
 _TRAIN_DIR = os.environ.get("MMEGO_TRAIN_DIR") or os.path.join(os.path.dirname(_HERE), "Processor", "Train")
-
-
-def _dev_tensor(a, device):
-    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(device)
 
 
 class _Base:
@@ -275,31 +271,15 @@ class UpperTrainer(_StageTrainer):
         return self._train_loop(report)
 
     def eval_model(self):
+        """Reference Processor/Train/Train_Upper.py:189-251, on the device end to end: the test split lives in HBM (DeviceArrays,
+        uploaded once), minibatches are gathered there, the per-frame figures come from one kernel (mmego_pose_errors_upper), their
+        per-minibatch sums land in a device-side log, and the host reads that log ONCE per epoch.  Returns the reference's tuple
+        (eval_loss, eval_loss_l, eval_accu, dis_l, accu_ll[15], angle_ll[14]): means over minibatches of per-minibatch means."""
         self.model.eval()
-        dev = self.device
-        umap = self.cfg.upper_joint_map
-        loss_l, accu_l, per_joint, angles, dis = [], [], [], [], []
-        bones = [(umap.index(p), umap.index(c)) for p, c in self.cfg.skeleton_upper_body.tolist()]
-        with torch.no_grad():
-            for data, target, skl, imu, _, _, R_R0R, _ in batches(self.test_data, self.batchsize, True, self._rng):
-                B, T = data.shape[0], data.shape[1]
-                x, tgt = _dev_tensor(data, dev), _dev_tensor(target, dev)
-                R, t = self.head_pose(self.model_IMU, _dev_tensor(imu, dev), _dev_tensor(R_R0R, dev), tgt)
-                h0 = torch.zeros((6, B, 64), device=dev)
-                up = self.model(x, h0, h0.clone(), _dev_tensor(skl, dev), R, t)[0]
-                tu = tgt[:, :, umap, :]
-                loss_l.append((up - tu).abs().sum().item() / B / T)
-                d = torch.sqrt(torch.sum(torch.square(up - tu), dim=-1))
-                accu_l.append(d.mean().item())
-                per_joint.append(d.mean(0).mean(0).cpu().numpy())
-                dis.append((up - tu).abs().mean().item())
-                pv = torch.stack([up[:, :, c] - up[:, :, p] for p, c in bones], 2)
-                tv = torch.stack([tu[:, :, c] - tu[:, :, p] for p, c in bones], 2)
-                cs = torch.nn.functional.cosine_similarity(pv, tv, dim=-1)
-                angles.append((torch.acos(cs.clamp(-1.0, 1.0)) / 3.14159265358 * 180.0).abs().mean(0).mean(0).cpu().numpy())
-        eval_loss = float(np.mean(loss_l))
-        return (eval_loss, np.asarray([eval_loss / self.cfg.joint_num_upper]), float(np.mean(accu_l)), float(np.mean(dis)),
-                np.mean(per_joint, axis=0), np.mean(angles, axis=0))
+        m = _epoch_eval(self, self.test_data, self.batchsize, True, self._rng, self.model_IMU, self.model, None)
+        eval_loss = float(np.mean(m[:, 29]))                                 # L1(sum) / B / T per minibatch
+        return (eval_loss, np.asarray([eval_loss / self.cfg.joint_num_upper]), float(np.mean(m[:, :15].mean(axis=1))),
+                float(np.mean(m[:, 29] / 45.0)), m[:, :15].mean(axis=0), m[:, 15:29].mean(axis=0))
 
 
 class LowerTrainer(_StageTrainer):
@@ -332,30 +312,60 @@ class LowerTrainer(_StageTrainer):
 
     def eval_model(self):
         self.model.eval()
-        return evaluate_full(self, self.model_IMU, self.Upper_net, self.model, batches(self.test_data, self.batchsize, True, self._rng))[0]
+        return evaluate_full(self, self.model_IMU, self.Upper_net, self.model, self.test_data, self.batchsize, True, self._rng)[0]
 
 
-def evaluate_full(base, imu_net, upper_net, lower_net, batch_iter):
-    """IMU -> Upper -> Lower over an iterator of minibatches; returns (reference-style tuple, summary dict)."""
+def _epoch_eval(base, dataset, batch_size, shuffle, rng, imu_net, upper_net, lower_net):
+    """One evaluation pass with ONE host synchronisation: -> float64 array [n_minibatches, W] of per-frame MEANS per minibatch.
+    lower_net None: W = 30, the columns of mmego_pose_errors_upper; else W = 45: the 43 columns of mmego_pose_errors, then the
+    Lower stage's L1(sum) loss per frame and its mean joint distance.  The split is uploaded once per dataset object
+    (DeviceArrays) and minibatches are gathered on the device in the order `data.batches` would produce (same RNG use)."""
     dev = base.device
-    cfg = base.cfg
-    loss_l, accu_l, accu_up, accu_lo, per_joint, angles = [], [], [], [], [], []
-    lmap = cfg.lower_joint_map
+    cache = base.__dict__.setdefault("_eval_dev", {})
+    arrays = cache.get(id(dataset))
+    if arrays is None:
+        arrays = cache[id(dataset)] = DeviceArrays(dataset, dev)
+    todo = list(batch_indices(len(dataset), batch_size, shuffle, rng))
+    W = 30 if lower_net is None else 45
+    log = torch.zeros((len(todo), W), dtype=torch.float32, device=dev)
+    frames = np.empty(len(todo), dtype=np.float64)
+    scratch = base.__dict__.setdefault("_eval_scratch", {})
+    lmap = scratch.get("lmap")
+    if lmap is None:
+        lmap = scratch["lmap"] = torch.tensor(list(base.cfg.lower_joint_map), dtype=torch.int32, device=dev)
     with torch.no_grad():
-        for batch in batch_iter:
-            data, target, skl, imu, R_R0R = batch[0], batch[1], batch[2], batch[3], batch[6]
-            B, T = data.shape[0], data.shape[1]
-            x, tgt = _dev_tensor(data, dev), _dev_tensor(target, dev)
-            R, t = base.head_pose(imu_net, _dev_tensor(imu, dev), _dev_tensor(R_R0R, dev), tgt)
-            h0 = torch.zeros((6, B, 64), device=dev)
-            body = _dev_tensor(skl, dev)
-            up = upper_net(x, h0, h0.clone(), body, R, t)[0]
-            lo, _ = lower_net(up.clone(), x, h0, h0, h0, h0, body, R, t)        # x already transformed once (Q1)
-            loss_l.append((lo - tgt[:, :, lmap, :]).abs().sum().item() / B / T)
-            a, u, l, pj, ang = base.pose_metrics(up, lo, tgt)
-            accu_l.append(a); accu_up.append(u); accu_lo.append(l); per_joint.append(pj); angles.append(ang)
-    eval_loss = float(np.mean(loss_l))
-    accu_ll, angle_ll = np.mean(per_joint, axis=0), np.mean(angles, axis=0)
+        for i, idx in enumerate(todo):
+            b = arrays.gather(idx)                          # fresh copies: the nets transform `data` in place (Q1)
+            B, T = b["data"].shape[0], b["data"].shape[1]
+            F = B * T
+            frames[i] = F
+            key = (B, T, W)
+            if key not in scratch:
+                scratch[key] = (torch.zeros((6, B, 64), device=dev), torch.zeros((6, B, 64), device=dev),
+                                torch.empty((F, 43 if lower_net is not None else 30), dtype=torch.float32, device=dev))
+            h0, c0, E = scratch[key]
+            tgt, body = b["target"], b["skl"]
+            R, t = base.head_pose(imu_net, b["imu"], b["R_R0R"], tgt)
+            up = upper_net(b["data"], h0, c0, body, R, t)[0]
+            if lower_net is None:
+                hip.call("pose_errors_upper", up.contiguous(), tgt, F, E)
+                ops.colsum(E, log[i])
+            else:
+                lo, _ = lower_net(up.clone(), b["data"], h0, h0, h0, h0, body, R, t)     # x already transformed once (Q1)
+                hip.call("pose_errors", up.contiguous(), lo.contiguous(), tgt, F, E)
+                ops.colsum(E, log[i, :43])
+                hip.call("l1_loss", lo.contiguous(), tgt, lmap, 8, 21, F, 1.0, log[i, 43:45], None)
+    return log.cpu().numpy().astype(np.float64) / frames[:, None]            # the epoch's one device -> host read
+
+
+def evaluate_full(base, imu_net, upper_net, lower_net, dataset, batch_size, shuffle, rng=None):
+    """IMU -> Upper -> Lower over a data split (reference Processor/Test/Demo_test.py:71-184, Train_Lower.py:232-332); returns
+    (reference-style tuple, summary dict).  Device-resident split, one host read per pass (_epoch_eval)."""
+    cfg = base.cfg
+    m = _epoch_eval(base, dataset, batch_size, shuffle, rng, imu_net, upper_net, lower_net)
+    eval_loss = float(np.mean(m[:, 43]))
+    accu_l, accu_up, accu_lo = m[:, :21].mean(axis=1), m[:, 41], m[:, 42]
+    accu_ll, angle_ll = m[:, :21].mean(axis=0), m[:, 21:41].mean(axis=0)
     summary = dict(all_cm=float(np.mean(accu_l)) * 100, upper_cm=float(np.mean(accu_up)) * 100, lower_cm=float(np.mean(accu_lo)) * 100,
                    rot_deg=float(sum(angle_ll) / len(angle_ll)), per_joint_cm=accu_ll * 100)
     return (eval_loss, np.asarray([eval_loss / cfg.joint_num_lower]), float(np.mean(accu_l)), float(np.mean(accu_lo)), accu_ll, angle_ll), summary
@@ -376,7 +386,7 @@ class Evaluator(_Base):
     def eval_model(self):
         self.model.load(self.cfg.model_lower_path)
         self.model.eval()
-        out, s = evaluate_full(self, self.model_IMU, self.Upper_net, self.model, batches(self.vis_data, 1, False))
+        out, s = evaluate_full(self, self.model_IMU, self.Upper_net, self.model, self.vis_data, 1, False)
         print("Average Joint Localization Error(cm): {}".format(s["all_cm"]))
         print("Average UpperBody Joint Localization Error(cm): {}".format(s["upper_cm"]))
         print("Average LowerBody Joint Localization Error(cm): {}".format(s["lower_cm"]))
@@ -412,13 +422,6 @@ class ImuTrainer(_Base):
         self._train_dev = None
         self._steps = {}
 
-    def _loss_and_grads(self, R, t, R_gt, head, want_grad):
-        F = R.shape[0] * R.shape[1]
-        dR = torch.empty_like(R) if want_grad else None
-        dt = torch.empty_like(t) if want_grad else None
-        hip.call("imu_loss", R.contiguous(), t.contiguous(), R_gt.contiguous(), head.contiguous(), F, 1.0, self._loss, dR, dt)
-        return dR, dt
-
     def train_imu_once(self):
         from .train_step import ImuStep
         self.model_IMU.train()
@@ -445,20 +448,31 @@ class ImuTrainer(_Base):
         return float(np.mean(losses))
 
     def eval_imu(self):
+        """Reference Processor/Train/Train_IMU.py:151-185.  Device-resident test split, per-minibatch figures kept in a device log
+        (total loss from mmego_imu_loss; the position part = sum of |t - head joint| from mmego_l1_loss's distance output), one
+        host read per epoch."""
         self.model_IMU.eval()
-        tot, parts = [], []
+        dev = self.device
+        if getattr(self, "_test_dev", None) is None:
+            self._test_dev = DeviceArrays(self.test_data, dev)
+            self._head_map = torch.tensor([20], dtype=torch.int32, device=dev)
+        todo = list(batch_indices(len(self.test_data), self.batchsize, True, self._rng))
+        log = torch.zeros((len(todo), 3), dtype=torch.float32, device=dev)
+        frames = np.empty(len(todo), dtype=np.float64)
         with torch.no_grad():
-            for data, target, skl, imu, _, _, R_R0R, _ in batches(self.test_data, self.batchsize, True, self._rng):
-                dev = self.device
-                B, T = imu.shape[0], imu.shape[1]
-                tgt, Rg = _dev_tensor(target, dev), _dev_tensor(R_R0R, dev)
-                R, t = self.model_IMU(_dev_tensor(imu, dev))
-                self._loss_and_grads(R, t, Rg, tgt[:, :, 20], False)
-                loss = self._loss.item()
-                pos = torch.sqrt(((t - tgt[:, :, 20]) ** 2).sum(-1)).sum().item()
-                tot.append(loss / B / T)
-                parts.append([(loss - 100 * pos) / B / T, pos / B / T])
-        return float(np.mean(tot)), np.mean(parts, axis=0)
+            for i, idx in enumerate(todo):
+                b = self._test_dev.gather(idx)
+                B, T = b["imu"].shape[0], b["imu"].shape[1]
+                F = B * T
+                frames[i] = F
+                head = torch.empty((B, T, 3), dtype=torch.float32, device=dev)
+                ops.copy2d(b["target"].view(F, 63)[:, 60:63], head.view(F, 3))
+                R, t = self.model_IMU(b["imu"])
+                hip.call("imu_loss", R.contiguous(), t.contiguous(), b["R_R0R"], head, F, 1.0, log[i, 0:1], None, None)
+                hip.call("l1_loss", t.contiguous(), b["target"], self._head_map, 1, 21, F, 1.0, log[i, 1:3], None)
+        m = log.cpu().numpy().astype(np.float64) / frames[:, None]          # the epoch's one device -> host read
+        tot, pos = m[:, 0], m[:, 2]
+        return float(np.mean(tot)), np.mean(np.stack((tot - 100.0 * pos, pos), axis=1), axis=0)
 
     def train_imu(self):
         early = EarlyStopping(patience=30)

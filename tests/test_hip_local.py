@@ -130,10 +130,9 @@ def test_infer_pipeline_on_real_sequences(dev, real16):
     base = processors._Base(ConfigDemo, make_dirs=False)
     up = load_weights(nets.UpperNet(), golden("w_upper_pretrained.npz")).to(dev).eval()
     lo = load_weights(nets.LowerNet(64), golden("w_lower_pretrained.npz")).to(dev).eval()
-    z = np.zeros((1, 1))
-    batch_iter = ((real16["x"][i:i + 1].copy(), real16["target"][i:i + 1], real16["skl"][i:i + 1], real16["imu"][i:i + 1], z, z,
-                   real16["R"][i:i + 1], z) for i in range(16))
-    _, s = processors.evaluate_full(base, None, up, lo, batch_iter)
+    from mmego_amd.data import ArraySplit
+    split = ArraySplit(real16["x"], real16["target"], real16["skl"], real16["imu"], real16["R"])
+    _, s = processors.evaluate_full(base, None, up, lo, split, 1, False)
     g9 = golden("g9_end2end.npz")
     assert abs(s["upper_cm"] - float(g9["upper_cm"])) < 1e-3, (s["upper_cm"], float(g9["upper_cm"]))
     assert abs(s["lower_cm"] - float(g9["lower_cm"])) < 0.05          # reference tie order at the top-64 cut differs
@@ -155,6 +154,52 @@ def test_infer_pipeline_on_real_sequences(dev, real16):
     for k in ("all_cm", "upper_cm", "lower_cm"):
         assert abs(s[k] - so[k]) < 1e-3, (k, s[k], so[k])
     assert abs(s["rot_deg"] - so["rot_deg"]) < 1e-2
+
+
+def test_upper_epoch_evaluation_on_device(dev, real16):
+    """SURVEY 8-f row f2, the Train_Upper half (reference Processor/Train/Train_Upper.py:189-251): UpperTrainer.eval_model -- device-
+    resident test split, per-frame figures from mmego_pose_errors_upper, one host read per epoch -- returns the reference's six
+    values (eval_loss, eval_loss_l, eval_accu, dis_l, accu_ll[15], angle_ll[14]) for minibatches of 5, 5, 5 and 1 sequences in
+    the shuffled order of the trainer's RNG; pinned against the oracle's forward + the reference's formulas written out in torch."""
+    from mmego_amd import nets, processors
+    from mmego_amd.config import Config
+    from mmego_amd.data import ArraySplit, batch_indices
+    Config.gt_head_pose = True
+    base = processors._Base(Config, make_dirs=False)
+    base.model = load_weights(nets.UpperNet(), golden("w_upper_pretrained.npz")).to(dev)
+    base.model_IMU, base.batchsize = None, 5
+    base.test_data = ArraySplit(real16["x"], real16["target"], real16["skl"], real16["imu"], real16["R"])
+    outs = []
+    for _ in range(2):                                     # second epoch: cached split / scratch buffers, another shuffle
+        base._rng = np.random.RandomState(77)
+        outs.append(processors.UpperTrainer.eval_model(base))
+    ou = load_weights(on.UpperNet(), golden("w_upper_pretrained.npz")).eval()
+    umap = list(sk.UPPER_MAP)
+    bones = [(umap.index(p), umap.index(c)) for p, c in sk.BONES_UPPER]
+    loss_l, accu_l, dis_l, pj, ang = [], [], [], [], []
+    with torch.no_grad():
+        for idx in batch_indices(16, 5, True, np.random.RandomState(77)):
+            x, tgt = T(real16["x"][idx]).clone(), T(real16["target"][idx])
+            skl, R = T(real16["skl"][idx]), T(real16["R"][idx])
+            B, Tn = x.shape[0], x.shape[1]
+            h0, c0 = ot.zeros_state(B)
+            up = ou(x, h0, c0, skl, R, tgt[:, :, 20].contiguous())[0]
+            tu = tgt[:, :, umap]
+            loss_l.append((up - tu).abs().sum().item() / B / Tn)
+            d = torch.sqrt(torch.sum(torch.square(up - tu), dim=-1))
+            accu_l.append(d.mean().item()); pj.append(d.mean(0).mean(0).numpy()); dis_l.append((up - tu).abs().mean().item())
+            pv = torch.stack([up[:, :, c] - up[:, :, p] for p, c in bones], 2)
+            tv = torch.stack([tu[:, :, c] - tu[:, :, p] for p, c in bones], 2)
+            cs = torch.nn.functional.cosine_similarity(pv, tv, dim=-1)
+            ang.append((torch.acos(cs.clamp(-1.0, 1.0)) / 3.14159265358 * 180.0).abs().mean(0).mean(0).numpy())
+    want = (float(np.mean(loss_l)), np.asarray([np.mean(loss_l) / 15]), float(np.mean(accu_l)), float(np.mean(dis_l)),
+            np.mean(pj, axis=0), np.mean(ang, axis=0))
+    for got in outs:
+        assert len(got) == 6 and got[4].shape == (15,) and got[5].shape == (14,)
+        assert abs(got[0] - want[0]) < 2e-5 * abs(want[0]) and abs(got[1][0] - want[1][0]) < 2e-5 * abs(want[1][0])
+        assert abs(got[2] - want[2]) * 100 < 1e-3 and abs(got[3] - want[3]) * 100 < 1e-3                 # cm
+        assert np.abs(got[4] - want[4]).max() * 100 < 1e-3, np.abs(got[4] - want[4]).max()
+        assert np.abs(got[5] - want[5]).max() < 1e-2, np.abs(got[5] - want[5]).max()                     # degrees
 
 
 def test_imu_stage1_training(dev):
