@@ -285,6 +285,16 @@ int mmego_pose_errors(void* stream, const float* upper, const float* lower, cons
  * U[f,29] sum |upper - target[upper_joint_map]| of the frame (its share of L1Loss(sum)).  upper [F,15,3], target [F,21,3], U [F,30]. */
 int mmego_pose_errors_upper(void* stream, const float* upper, const float* target, long F, float* U);
 
+/* ---- eval-mode front end of Upper_Net in one launch (front.hip) ---------------------------------------
+ * Per frame of N points (x [F,N,6], N a multiple of 16, <= 1024): Transform2H (Utils.py:284-292; bit-identical to mmego_transform2h,
+ * written back into x -- quirk Q1 -- from x_src when given), PointNet 6-8-16-24 (Net/Upper_Net.py:242-266), concat with the first
+ * four transformed columns, GlobalPointNet 28-32-48-64 and its softmax attention pooling (:270-301), all with eval-mode BatchNorm
+ * folded into the k=1 convs.  vec [F,64] pooled features, attn [F,N] attention weights.  w: HOST array of 38 device pointers --
+ * for PointNet conv1..3 then GlobalPointNet conv1..3: weight, bias, BatchNorm gamma, beta, running_mean, running_var; then the
+ * attention Linear's weight [64] and bias [1].  Replaces transform2h + 2 x mlp3_eval + attn_pool_forward and their HBM round trips. */
+int mmego_upper_front_eval(void* stream, float* x, const float* x_src, const float* R, const float* t, long F, int N,
+                           const float* const* w, float eps, float* vec, float* attn);
+
 /* ---- anchor ("voxel") grouping of UpperNetwlocal (group.hip) -----------------------------------------
  * Per frame and per anchor of the 3x3x3 grid: indices (int64, exact, stable ties) of the 8 nearest points and
  * the gathered rows cat(anchor, xyz-anchor, features) -- square_distance / point_ball_set / AnchorGrouping of

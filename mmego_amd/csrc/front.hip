@@ -26,7 +26,7 @@
 struct FrontLayer { const float* W; const float* b; const float* gamma; const float* beta; const float* rmean; const float* rvar; };
 struct FrontP {
   float* x; const float* x_src; const float* R; const float* t; long F; int N;
-  FrontLayer l[6];              // PointNet conv1..3, GlobalPointNet conv1..3 (gamma == NULL: no BatchNorm to fold)
+  FrontLayer l[6];              // PointNet conv1..3, GlobalPointNet conv1..3, each with its eval-mode BatchNorm
   const float* attn_w; const float* attn_b; float eps;
   float* vec; float* attn;
 };
@@ -97,37 +97,59 @@ __global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
   const int fr = lane & 15, fq = lane >> 4;
 
   // ---- weights -> LDS (BatchNorm folded: s = gamma / sqrt(var + eps); Wf = s W; bf = (b - mean) s + beta -- bn_fold_linear's
-  // expressions), zero padded.  All loads unconditional on clamped indices, selects afterwards (see mlp3.hip).
+  // expressions), zero padded.  Two phases, as in mlp3.hip: per-channel scales and folded biases (threads 0..63, all 30 loads in
+  // flight at once), then every thread's 26 weight elements -- every load unconditional on a clamped index and issued before the
+  // first LDS store (a rolled loop was one dependent round trip per iteration: ~26 of them in front of the first point).
+#define FR_PIN(v) asm volatile("" : "+v"(v))
   {
-    const int Cn[6] = {8, 16, 24, 32, 48, 64}, Kn[6] = {6, 8, 16, 28, 32, 48};
-    const int Cp[6] = {16, 16, 32, 32, 48, 64}, Kp[6] = {16, 16, 16, 32, 32, 48};
-    const int Sw[6] = {FR_S16, FR_S16, FR_S16, FR_S32, FR_S32, FR_S48};
-    const int Wo[6] = {FR_W1, FR_W2, FR_W3, FR_G1, FR_G2, FR_G3}, Bo[6] = {FR_B1, FR_B2, FR_B3, FR_C1, FR_C2, FR_C3};
+    constexpr int Cn[6] = {8, 16, 24, 32, 48, 64}, Kn[6] = {6, 8, 16, 28, 32, 48};
+    constexpr int Cp[6] = {16, 16, 32, 32, 48, 64}, Kp[6] = {16, 16, 16, 32, 32, 48};
+    constexpr int Sw[6] = {FR_S16, FR_S16, FR_S16, FR_S32, FR_S32, FR_S48};
+    constexpr int Wo[6] = {FR_W1, FR_W2, FR_W3, FR_G1, FR_G2, FR_G3}, Bo[6] = {FR_B1, FR_B2, FR_B3, FR_C1, FR_C2, FR_C3};
+    constexpr int So[6] = {0, 16, 32, 64, 96, 144};                    // per-channel scales, 208 floats at the head of `act`
+    float* const scale = act;
+    if (tid < 64) {
+      float g[6], v[6], m[6], e[6], c[6];
+#pragma unroll
+      for (int L = 0; L < 6; ++L) {
+        const FrontLayer& q = p.l[L];
+        const int nc = min(tid, Cn[L] - 1);
+        g[L] = q.gamma[nc]; v[L] = q.rvar[nc]; m[L] = q.rmean[nc]; e[L] = q.beta[nc]; c[L] = q.b[nc];
+      }
+#pragma unroll
+      for (int L = 0; L < 6; ++L) {
+        FR_PIN(g[L]); FR_PIN(v[L]); FR_PIN(m[L]); FR_PIN(e[L]); FR_PIN(c[L]);
+        const float sc_ = g[L] / sqrtf(v[L] + p.eps);
+        const float bf = (c[L] - m[L]) * sc_ + e[L];
+        if (tid < Cp[L]) { scale[So[L] + tid] = sc_; sh[Bo[L] + tid] = tid < Cn[L] ? bf : 0.f; }
+      }
+      sh[FR_AW + tid] = p.attn_w[tid];
+    }
+    __syncthreads();
+    float w[26];
+    int u0 = 0;
 #pragma unroll
     for (int L = 0; L < 6; ++L) {
-      const FrontLayer& q = p.l[L];
-      const bool fold = q.gamma != nullptr;
-      const int tot = Cp[L] * Kp[L];
-      for (int i = tid; i < tot; i += 256) {
-        const int n = i / Kp[L], k = i - n * Kp[L];
-        const int nc = min(n, Cn[L] - 1), kc = min(k, Kn[L] - 1);
-        float w = q.W[nc * Kn[L] + kc];
-        float s = 1.f;
-        if (fold) s = q.gamma[nc] / sqrtf(q.rvar[nc] + p.eps);
-        sh[Wo[L] + n * Sw[L] + k] = (n < Cn[L] && k < Kn[L]) ? s * w : 0.f;
+#pragma unroll
+      for (int u = 0; u < Cp[L] * Kp[L] / 256; ++u) {
+        const int i = tid + 256 * u, n = i / Kp[L], k = i - n * Kp[L];
+        w[u0 + u] = p.l[L].W[min(n, Cn[L] - 1) * Kn[L] + min(k, Kn[L] - 1)];
       }
-      if (tid < Cp[L]) {
-        const int nc = min(tid, Cn[L] - 1);
-        float b = q.b ? q.b[nc] : 0.f;
-        if (fold) {
-          const float s = q.gamma[nc] / sqrtf(q.rvar[nc] + p.eps);
-          b = (b - q.rmean[nc]) * s + q.beta[nc];
-        }
-        sh[Bo[L] + tid] = tid < Cn[L] ? b : 0.f;
-      }
+      u0 += Cp[L] * Kp[L] / 256;
     }
-    if (tid < 64) sh[FR_AW + tid] = p.attn_w[tid];
+    u0 = 0;
+#pragma unroll
+    for (int L = 0; L < 6; ++L) {
+#pragma unroll
+      for (int u = 0; u < Cp[L] * Kp[L] / 256; ++u) {
+        const int i = tid + 256 * u, n = i / Kp[L], k = i - n * Kp[L];
+        FR_PIN(w[u0 + u]);
+        sh[Wo[L] + n * Sw[L] + k] = (n < Cn[L] && k < Kn[L]) ? scale[So[L] + n] * w[u0 + u] : 0.f;
+      }
+      u0 += Cp[L] * Kp[L] / 256;
+    }
   }
+#undef FR_PIN
   const float attn_b = p.attn_b ? p.attn_b[0] : 0.f;
   __syncthreads();
 
@@ -148,13 +170,25 @@ __global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
     // lane group fq; the four groups are added at the end)
     float m_run = -INFINITY, s_run = 0.f;
     float col[4] = {0.f, 0.f, 0.f, 0.f};
+    // the slab's 16 points: every lane loads the row of point (lane & 15) (24 bytes; the four 16-lane groups load the same rows:
+    // no branch around the loads), and the NEXT slab's rows are requested before the current slab is computed
+    float2 c01, c23, c45;
+    {
+      const long row = (long)min(wave, nslab - 1) * FR_SLAB + fr;
+      c01 = *reinterpret_cast<const float2*>(xs + row * 6);
+      c23 = *reinterpret_cast<const float2*>(xs + row * 6 + 2);
+      c45 = *reinterpret_cast<const float2*>(xs + row * 6 + 4);
+    }
     for (int s = wave; s < nslab; s += 4) {
-      // ---- the slab's 16 points: lanes 0..15 load one row each (24 bytes), transform it, write it back and into the A tile
+      const float2 v01 = c01, v23 = c23, v45 = c45;
+      {
+        const long rown = (long)(s + 4 < nslab ? s + 4 : s) * FR_SLAB + fr;       // (past the last slab: this slab again)
+        c01 = *reinterpret_cast<const float2*>(xs + rown * 6);
+        c23 = *reinterpret_cast<const float2*>(xs + rown * 6 + 2);
+        c45 = *reinterpret_cast<const float2*>(xs + rown * 6 + 4);
+      }
       if (lane < FR_SLAB) {
         const long row = (long)s * FR_SLAB + lane;
-        const float2 v01 = *reinterpret_cast<const float2*>(xs + row * 6);
-        const float2 v23 = *reinterpret_cast<const float2*>(xs + row * 6 + 2);
-        const float2 v45 = *reinterpret_cast<const float2*>(xs + row * 6 + 4);
         const float d0 = __fsub_rn(v01.x, tt[0]), d1 = __fsub_rn(v01.y, tt[1]), d2 = __fsub_rn(v23.x, tt[2]);
         const float h0 = fr_dot3_nofma(r[0], r[1], r[2], d0, d1, d2);
         const float h1 = fr_dot3_nofma(r[3], r[4], r[5], d0, d1, d2);
@@ -171,7 +205,9 @@ __global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
         *reinterpret_cast<f32x4*>(fz) = (f32x4){h0, h1, h2, v23.y};
         *reinterpret_cast<f32x4*>(fz + 28) = (f32x4){0.f, 0.f, 0.f, 0.f};  // ... and the k padding behind the 24 features
       }
-      // (wave-private LDS: the writes above are ordered before the reads below by the compiler's lgkmcnt waits)
+      __builtin_amdgcn_wave_barrier();
+      // (wave-private LDS: a wave's LDS operations complete in issue order, so the tile written by some lanes is what the other
+      // lanes read; wave_barrier only keeps the compiler from moving code across the hand-over)
       f32x4 a1[1], a2[1], a3[2], g1[2], g2[3], g3[4];
       fr_stage<1, 1, FR_S16, FR_S16>(A + FR_ACT_P, sh + FR_W1, a1, fr, fq);
       fr_store<1, FR_S16>(a1, sh + FR_B1, A + FR_ACT_Q, 0, fr, fq);
@@ -269,7 +305,7 @@ __global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
 }
 
 // w: host-side table of 38 device pointers: for PointNet conv1..3 then GlobalPointNet conv1..3: W, b, gamma, beta, running_mean,
-// running_var (gamma..running_var NULL for a layer without BatchNorm); then the attention Linear's weight [64] and bias [1].
+// running_var of the layer's BatchNorm; then the attention Linear's weight [64] and bias [1].
 extern "C" int mmego_upper_front_eval(void* stream, float* x, const float* x_src, const float* R, const float* t, long F, int N,
                                       const float* const* w, float eps, float* vec, float* attn) {
   MMEGO_REQUIRE(x && R && t && w && vec && attn && F > 0);
@@ -278,9 +314,7 @@ extern "C" int mmego_upper_front_eval(void* stream, float* x, const float* x_src
   FrontP p;
   p.x = x; p.x_src = x_src; p.R = R; p.t = t; p.F = F; p.N = N;
   for (int L = 0; L < 6; ++L) {
-    MMEGO_REQUIRE(w[6 * L]);
-    const bool bn = w[6 * L + 2] != nullptr;
-    MMEGO_REQUIRE(!bn || (w[6 * L + 3] && w[6 * L + 4] && w[6 * L + 5]));
+    for (int j = 0; j < 6; ++j) MMEGO_REQUIRE(w[6 * L + j]);
     p.l[L] = {w[6 * L], w[6 * L + 1], w[6 * L + 2], w[6 * L + 3], w[6 * L + 4], w[6 * L + 5]};
   }
   MMEGO_REQUIRE(w[36]);

@@ -23,6 +23,9 @@ from .params import FlatParams
 from .skeleton import JOINTS_UPPER, LOWER_POINTS, gcn_adjacency
 
 
+_FUSED_FRONT = os.environ.get("MMEGO_FUSED_FRONT", "1") != "0"      # eval-mode Upper_Net front end as one launch (front.hip)
+
+
 def _require_gpu(t, who):
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise RuntimeError("%s runs on the MI355X HIP path only (got a %s tensor); there is no CPU fallback"
@@ -204,6 +207,13 @@ class UpperNet(_NetBase):
         R, t, body = _f32c(R), _f32c(t), _f32c(body)
         h0 = _f32c(h0) if h0 is not None else None
         c0 = _f32c(c0) if c0 is not None else None
+        vec = ar.get("vec", (F, 64))
+        attn = torch.empty((F, N, 1), dtype=torch.float32, device=x.device)
+        if not training and not stash and self._front_fusable(Cx, N):
+            # eval mode: transform, PointNet, concat, GlobalPointNet and the attention pooling as ONE launch (front.hip); the
+            # per-point 28- / 64-channel tensors never exist in memory
+            hip.call("upper_front_eval", x, x_src, R, t, F, N, self._front_table(), float(self.module0.cb1.eps), vec, attn)
+            return self._forward_tail(ar, vec, attn, B, T, N, h0, c0, body, R, t, stash, training)
         feats = ar.get("feats", (rows, 28))
         keep = ar.get("pts", (rows, Cx)) if stash else None
         if Cx <= 8:
@@ -223,9 +233,30 @@ class UpperNet(_NetBase):
         blocks.mlp3_forward(ar, "m0", self.module0, pts, feats[:, 4:28], training)
         g3 = ar.get("g3", (rows, 64))
         blocks.mlp3_forward(ar, "gp", self.module1.gpointnet, feats, g3, training)
-        vec = ar.get("vec", (F, 64))
-        attn = torch.empty((F, N, 1), dtype=torch.float32, device=x.device)
         blocks.attn_pool_forward(g3, self.module1.gpointnet.attn, F, N, 64, vec, attn)
+        return self._forward_tail(ar, vec, attn, B, T, N, h0, c0, body, R, t, stash, training)
+
+    def _front_fusable(self, Cx, N):
+        layers = blocks._mlp3_layers(self.module0) + blocks._mlp3_layers(self.module1.gpointnet)
+        dims = [tuple(conv.weight.shape[:2]) for conv, _ in layers]
+        return (_FUSED_FRONT and Cx == 6 and N % 16 == 0 and 16 <= N <= 1024 and len({float(bn.eps) for _, bn in layers}) == 1
+                and dims == [(8, 6), (16, 8), (24, 16), (32, 28), (48, 32), (64, 48)]
+                and all(conv.bias is not None for conv, _ in layers) and self.module1.gpointnet.attn.bias is not None)
+
+    def _front_table(self):
+        """Host-side pointer table of mmego_upper_front_eval (38 device pointers), rebuilt when a tensor moved."""
+        layers = blocks._mlp3_layers(self.module0) + blocks._mlp3_layers(self.module1.gpointnet)
+        ts = [v for conv, bn in layers for v in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+        ts += [self.module1.gpointnet.attn.weight, self.module1.gpointnet.attn.bias]
+        ptrs = tuple(v.data_ptr() for v in ts)
+        ent = self.__dict__.get("_front_tab")
+        if ent is None or ent[0] != ptrs:
+            ent = self.__dict__["_front_tab"] = (ptrs, torch.tensor(ptrs, dtype=torch.int64))
+        return ent[1]
+
+    def _forward_tail(self, ar, vec, attn, B, T, N, h0, c0, body, R, t, stash, training):
+        """Sequence model, head and kinematics behind the per-frame feature vector (Net/Upper_Net.py:333-364,393-404)."""
+        F = B * T
         lstm = self.module1.grnn
         seq, hn, cn = blocks.lstm64_forward(ar, "grnn", lstm, vec, B, T, h0, c0, stash, self._drop_p(lstm) if stash else 0.0,
                                             self.seed_counter())
@@ -233,9 +264,9 @@ class UpperNet(_NetBase):
         ops.linear(seq, self.mlpHead.fc1.weight, self.mlpHead.fc1.bias, h1, relu=True)
         y = ar.get("y", (F, 87))
         ops.linear(h1, self.mlpHead.fc2.weight, self.mlpHead.fc2.bias, y)
-        q = torch.empty((B, T, 14, 3, 3), dtype=torch.float32, device=x.device)
+        q = torch.empty((B, T, 14, 3, 3), dtype=torch.float32, device=vec.device)
         jh = ar.get("jh", (F, 15, 3))
-        l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=x.device)
+        l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=vec.device)
         tick = self._flat.tick_args(self.seed_counter()) if training else (None, 0, None)   # BatchNorm counters + dropout seed
         hip.call("head_fk_forward", 0, y, body, B, F, q, jh, R, t, l, *tick)       # kinematics + head-to-world transform, one launch
         if stash:

@@ -440,6 +440,71 @@ print("ok")
         assert r.returncode == 0 and "ok" in r.stdout, (bn, h, r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_upper_front_eval_fused_equals_chain(dev, monkeypatch):
+    """mmego_upper_front_eval (Transform2H + PointNet + concat + GlobalPointNet + attention pooling of an eval-mode Upper_Net in ONE
+    launch, front.hip) against the four-launch chain it replaces (transform2h, 2 x mlp3_eval, attn_pool_forward) and against fp64
+    torch: the in-place transformed points bit-identical (they are Lower_Net's sort keys), pooled features / attention weights /
+    joints to 1e-5; N = 128, 256 and a ragged-in-waves 48; with and without a separate source tensor; non-trivial BatchNorm
+    statistics."""
+    from mmego_amd import nets
+    g = torch.Generator().manual_seed(77)
+    torch.manual_seed(78)
+    net = nets.UpperNet()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.3)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.3)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+    net = net.to(dev).eval()
+    for B, Tn, N in ((3, 4, 128), (2, 3, 256), (5, 2, 48), (70, 8, 128)):
+        x0 = torch.randn(B, Tn, N, 6, generator=g)
+        x0[torch.rand(B, Tn, N, generator=g) < 0.3] = 0.0
+        R = torch.linalg.qr(torch.randn(B, Tn, 3, 3, generator=g))[0].contiguous()
+        t = torch.randn(B, Tn, 3, generator=g) * 0.2
+        body = torch.randn(B, 20, 3, generator=g) * 0.2
+        h0 = torch.zeros(6, B, 64, device=dev)
+        outs = {}
+        for fused in (False, True):
+            monkeypatch.setattr(nets, "_FUSED_FRONT", fused)
+            for with_src in (False, True):
+                x = x0.clone().to(dev)
+                with torch.no_grad():
+                    if with_src:
+                        xs = x0.clone().to(dev)
+                        x.fill_(float("nan"))
+                        res = net._forward_impl(x, h0, h0.clone(), body.to(dev), R.to(dev), t.to(dev), stash=False, x_src=xs)
+                        assert torch.equal(xs.cpu(), x0), "the source tensor is read only"
+                    else:
+                        res = net(x, h0, h0.clone(), body.to(dev), R.to(dev), t.to(dev))
+                torch.cuda.synchronize()
+                outs[(fused, with_src)] = (x.cpu(), res[0].cpu(), res[2].cpu(), net.arena("eval").get("vec", (B * Tn, 64)).cpu().clone())
+        ref = outs[(False, False)]
+        for key, got in outs.items():
+            assert torch.equal(got[0], ref[0]), ("transformed points must be bit-identical", key, N)
+            assert torch.allclose(got[1], ref[1], rtol=1e-5, atol=1e-5), (key, N, (got[1] - ref[1]).abs().max())
+            assert torch.allclose(got[2], ref[2], rtol=1e-4, atol=1e-7), (key, N, (got[2] - ref[2]).abs().max())
+            assert torch.allclose(got[3], ref[3], rtol=1e-5, atol=1e-5), (key, N, (got[3] - ref[3]).abs().max())
+        # fp64 torch restatement of the front end on the transformed points
+        xt = ref[0].double().view(B * Tn, N, 6)
+        sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+
+        def mlp(z, pre):
+            for i in (1, 2, 3):
+                z = z @ sd[pre + "conv%d.weight" % i][:, :, 0].t() + sd[pre + "conv%d.bias" % i]
+                z = (z - sd[pre + "cb%d.running_mean" % i]) / torch.sqrt(sd[pre + "cb%d.running_var" % i] + 1e-5) \
+                    * sd[pre + "cb%d.weight" % i] + sd[pre + "cb%d.bias" % i]
+                z = torch.relu(z)
+            return z
+        feats = torch.cat((xt[..., :4], mlp(xt, "module0.")), dim=-1)
+        g3 = mlp(feats, "module1.gpointnet.")
+        a = torch.softmax(g3 @ sd["module1.gpointnet.attn.weight"].t() + sd["module1.gpointnet.attn.bias"], dim=1)
+        want_vec = (g3 * a).sum(1)
+        got = outs[(True, False)]
+        assert (got[3].double() - want_vec).abs().max().item() < 2e-5 * max(1.0, want_vec.abs().max().item()), N
+        assert (got[2].double().view_as(a) - a).abs().max().item() < 1e-6, N
+
+
 def test_lstm_recurrence_two_chains_equal_one_launch_per_step(dev, monkeypatch):
     """blocks.lstm_recurrence: the two directions as two chains of single-direction launches on two streams (64 x 16 tiles, the
     default from 128 rows) give bit-identical h_t, final c and backward stashes to both directions in one launch per timestep
