@@ -26,4 +26,21 @@ for K in (512, 1024):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
-    print("pair 2 x (M%d N%d K%d): %.1f us, %.1f TFLOP/s" % (M, N, K, us, 4.0 * M * N * K / us / 1e6))
+    # the same launch ten times in a replayed HIP graph: no host launch cost in the figure (what the U+L step sees)
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(10):
+                ops.linear_pair(A, W[:N], W[N:], b[:N], b[N:], C, N)
+    torch.cuda.synchronize()
+    g.replay()
+    e0.record()
+    for _ in range(5):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    usg = e0.elapsed_time(e1) / 50 * 1e3
+    print("pair 2 x (M%d N%d K%d): %.1f us eager, %.1f us in a replayed graph = %.1f TFLOP/s (%.3f of 157.3)"
+          % (M, N, K, us, usg, 4.0 * M * N * K / usg / 1e6, 4.0 * M * N * K / usg / 1e6 / 157.3))

@@ -88,7 +88,8 @@ def test_linear_pair_and_batched_bias(dev):
     small kernel (ragged 200 x 96) and the non-contiguous fallback."""
     from mmego_amd import ops
     g = torch.Generator().manual_seed(5)
-    for rows, ncol, K in ((10240, 256, 128), (512, 2048, 256), (200, 96, 160), (64, 32, 24)):
+    # (10240 x 2048 per direction: 2560 tiles = five whole rounds of the persistent grid -> the phase-shifted walk, gemm_tile.hip)
+    for rows, ncol, K in ((10240, 256, 128), (10240, 2048, 128), (512, 2048, 256), (200, 96, 160), (64, 32, 24)):
         x = torch.randn(rows, K, generator=g).to(dev)
         Wb = (torch.randn(2 * ncol + 8, K, generator=g) * 0.1).to(dev)
         bb = torch.randn(2 * ncol + 8, generator=g).to(dev)
