@@ -674,10 +674,10 @@ def main():
         from mmego_amd import blocks as _blocks
 
         def eager():
-            # the same recurrence forms as the timed arrangement (train_step.ConcurrentStages): the Lower stage's IMU_Net forward
-            # runs first and alone -> two single-direction chains; the Upper stage's has the Lower tail beside it -> one launch
-            # per timestep for both directions.  --sequential: two chains in both.
-            with _blocks.two_chains(args.sequential):
+            # the same recurrence forms as the timed arrangement (train_step.ConcurrentStages): both IMU_Net forwards run their
+            # rnn_fast recurrences as two single-direction chains (MMEGO_ALL_IMU_TWO_CHAINS=0: the Upper stage's, which has the
+            # Lower tail beside it, as one launch per timestep for both directions).
+            with _blocks.two_chains(args.sequential or os.environ.get("MMEGO_ALL_IMU_TWO_CHAINS", "1") != "0"):
                 su_e._body()
             with _blocks.two_chains(True):
                 sl_e._body()

@@ -164,155 +164,6 @@ __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, i
   MMEGO_STAMP_AT(sid, 3, tid == 0);
 }
 
-// Software-pipelined body for the projection products (both operands k-contiguous, 32-k chunks, BM = 128): the arithmetic of
-// gemm_tile_body -- same fragments, same k order per output element: bit-identical results -- on a different schedule.
-//   * TWO LDS buffers (73.7 KB per 128x128 workgroup, two workgroups still fit a CU): chunk c+1 is written into the other buffer
-//     while chunk c is multiplied, so a chunk costs ONE barrier instead of two and no wave ever waits for its own stores;
-//   * the chunk's four 8-k blocks alternate between two fragment register sets: the ds_read_b128s of block b+1 are issued in front
-//     of block b's 16 MFMAs (1024 MFMA cycles of cover; the single-buffer loop issued them one MFMA ahead and stalled on them);
-//   * the barrier sits in front of the LAST block: by then a wave has issued all its reads of chunk c and its writes of chunk
-//     c+1, and behind it the first fragments of chunk c+1 are requested before block 3's MFMAs issue -- no LDS or global latency
-//     is exposed anywhere in the loop, only the arrival skew of the four waves at the one barrier;
-//   * the global loads of chunk c+2 are issued in block 2, after the staging registers were stored (blocks 0, 1).
-// (the barrier is raw `s_waitcnt lgkmcnt(0); s_barrier`: __syncthreads() would also wait for the global loads in flight)
-#define GT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-template <int BN>
-__device__ __forceinline__ void gemm_tile_body_pipe(const TileP& p, int m0, int n0, int sb, float* smem, int sid, int diag = 0) {
-  constexpr int BM = 128, KCH = 32, TLD = KCH + 4;
-  constexpr int WM = 64, WN = BN / 2, TM = 2, TN = WN / 32;
-  constexpr int AV = BM * KCH / 1024, BV = BN * KCH / 1024;       // f32x4 per thread per chunk: 4, 4 | 2
-  constexpr int BUF = (BM + BN) * TLD;                             // floats per LDS buffer
-  const int split = sb % p.nsplit, batch = sb / p.nsplit;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
-  const int kbeg = split * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
-  const int nk = (kend - kbeg) / KCH;
-  const int lk = (tid & 7) * 4, lr = tid >> 3;                     // staging: 8 lanes per 32-k row segment, rows lr + 32 i
-  const float* Ap = p.A + (long)batch * p.sAb + (long)(m0 + lr) * p.lda + kbeg + lk;
-  const float* Wp = p.W + (long)batch * p.sWb + (long)(n0 + lr) * p.ldw + kbeg + lk;
-  const long astep = 32 * p.lda, bstep = 32 * p.ldw;
-  const int r = lane & 31, h = lane >> 5;
-  // byte-free index arithmetic: this lane's staging slot and fragment rows inside a buffer
-  const int wofs = lr * TLD + lk;
-  const int aofs = (wm * WM + r) * TLD + 4 * h, bofs = BM * TLD + (wn * WN + r) * TLD + 4 * h;
-  f32x4 ra[AV], rb[BV];
-  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
-#define GT_LOAD(kt_)                                                                               \
-  do {                                                                                             \
-    const float* An_ = Ap + (long)(kt_) * KCH;                                                     \
-    const float* Wn_ = Wp + (long)(kt_) * KCH;                                                     \
-    _Pragma("unroll") for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(An_ + i * astep); \
-    _Pragma("unroll") for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wn_ + i * bstep); \
-  } while (0)
-#define GT_STORE_A(buf_, i0_, i1_)                                                                 \
-  do {                                                                                             \
-    _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i)                                          \
-      *reinterpret_cast<f32x4*>((buf_) + wofs + 32 * i * TLD) = ra[i];                             \
-  } while (0)
-#define GT_STORE_B(buf_, i0_, i1_)                                                                 \
-  do {                                                                                             \
-    _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i)                                          \
-      *reinterpret_cast<f32x4*>((buf_) + BM * TLD + wofs + 32 * i * TLD) = rb[i];                  \
-  } while (0)
-#define GT_READ(buf_, kb_, fa_, fb_)                                                               \
-  do {                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
-      fa_[i] = *reinterpret_cast<const f32x4*>((buf_) + aofs + i * 32 * TLD + (kb_) * 8);          \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
-      fb_[j] = *reinterpret_cast<const f32x4*>((buf_) + bofs + j * 32 * TLD + (kb_) * 8);          \
-  } while (0)
-#define GT_MMA(fa_, fb_)                                                                           \
-  do {                                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                               \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][s_], fb_[j][s_], acc[i][j], 0, 0, 0); \
-  } while (0)
-  MMEGO_STAMP_AT(sid, 0, tid == 0);
-  if (nk > 0) {
-    GT_LOAD(0);
-    // (a persistent workgroup comes here from the previous tile: its waves may still be reading that tile's last fragments)
-    GT_LDS_BARRIER();
-    GT_STORE_A(smem, 0, AV);
-    GT_STORE_B(smem, 0, BV);
-    GT_LOAD(min(1, nk - 1));
-    GT_LDS_BARRIER();
-    GT_READ(smem, 0, fa0, fb0);
-  }
-  MMEGO_STAMP_AT(sid, 1, tid == 0);
-  // (no condition anywhere in the loop: past the last chunk the stores / reads / loads run once more on the last chunk's data,
-  // which nobody uses -- a uniform branch around them made the compiler's LDS wait counts conservative: the MFMAs of a block
-  // then waited for the reads issued just in front of them)
-  for (int kt = 0; kt < nk; ++kt) {
-    float* cur = smem + (kt & 1) * BUF;
-    float* nxt = smem + ((kt + 1) & 1) * BUF;
-    // block 0
-    GT_READ(cur, 1, fa1, fb1);
-    GT_STORE_A(nxt, 0, AV);
-    __builtin_amdgcn_sched_barrier(0);
-    GT_MMA(fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    // block 1
-    GT_READ(cur, 2, fa0, fb0);
-    GT_STORE_B(nxt, 0, BV);
-    __builtin_amdgcn_sched_barrier(0);
-    GT_MMA(fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    // block 2
-    GT_READ(cur, 3, fa1, fb1);
-    if (!(diag & 4)) GT_LOAD((diag & 2) ? 0 : min(kt + 2, nk - 1));      // (diag: A/B probes of scripts/bench_gemm_pair.py, 0 in the product)
-    __builtin_amdgcn_sched_barrier(0);
-    GT_MMA(fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    // block 3: everything this wave reads of chunk kt and writes of chunk kt+1 has been issued
-    GT_LDS_BARRIER();
-    GT_READ(nxt, 0, fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    GT_MMA(fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#undef GT_LOAD
-#undef GT_STORE_A
-#undef GT_STORE_B
-#undef GT_READ
-#undef GT_MMA
-  MMEGO_STAMP_AT(sid, 2, tid == 0);
-
-  const bool slab = p.nsplit > 1;
-  float* C = slab ? p.ws + ((long)split * p.nbatch + batch) * p.M * p.N : p.C + (long)batch * p.sCb;
-  const long ldc = slab ? (long)p.N : p.ldc;
-  const bool relu = !slab && p.relu, accumulate = !slab && p.accumulate;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * WN + j * 32 + (lane & 31);
-    const float bv = (!slab && p.bias) ? p.bias[(long)batch * p.sBiasb + col] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float* cp = C + (long)(m0 + wm * WM + i * 32 + 4 * (lane >> 5)) * ldc + col;
-      float old[16];
-      if (accumulate) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) old[reg] = cp[(long)((reg & 3) + 8 * (reg >> 2)) * ldc];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) asm volatile("" : "+v"(old[reg]));
-      }
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        float v = acc[i][j][reg] + bv;
-        if (relu) v = fmaxf(v, 0.0f);
-        if (accumulate) v += old[reg];
-        cp[(long)((reg & 3) + 8 * (reg >> 2)) * ldc] = v;
-      }
-    }
-  }
-  MMEGO_STAMP_AT(sid, 3, tid == 0);
-}
-
 // XCD-aware tile order: blocks b and b+8 share an XCD; hand each XCD a contiguous run of tile ids
 __device__ __forceinline__ int xcd_order(int id, int n) { return (n & 7) == 0 ? (id & 7) * (n >> 3) + (id >> 3) : id; }
 
@@ -333,59 +184,27 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(TileP p) {
 // unit count leaves at most half a wave of workgroups over, those units are cut into two 128x64 halves, one per
 // workgroup: the tail costs half a tile time (2.5 tile times per workgroup for 1280 tiles, not 3).  Per output element
 // the arithmetic is the plain kernel's (bit-identical result).
-template <int BM, int BN, bool A_KC, bool B_KC, int KCH, bool PIPE>
-__device__ __forceinline__ void gemm_tile_unit(const TileP& p, int m0, int n0, int sb, float* smem, int sid, int diag) {
-  if constexpr (PIPE) gemm_tile_body_pipe<BN>(p, m0, n0, sb, smem, sid, diag);
-  else gemm_tile_body<BM, BN, 2, 2, A_KC, B_KC, KCH>(p, m0, n0, sb, smem, sid);
-}
-
-template <bool A_KC, bool B_KC, int KCH, bool PIPE = false>
+template <bool A_KC, bool B_KC, int KCH>
 __global__ __launch_bounds__(256) void gemm_tile_persistent_kernel(TileP p, int nfull, int nhalf, int stagger) {
-  static_assert(!PIPE || (A_KC && B_KC && KCH == 32), "the pipelined body takes k-contiguous operands in 32-k chunks");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ntn = p.N / 128, tiles = ntn * (p.M / 128), G = (int)gridDim.x;
   const int w = xcd_order(blockIdx.x, G);                  // each XCD walks a contiguous run of unit ids per round
   // The two workgroups of a CU (blocks b and b + G/2) start together and would reach their store epilogues together,
   // leaving the matrix pipe idle; the second one therefore runs its half tile FIRST, which keeps the pair out of phase.
-  const int diag = stagger >> 8;
-  if (stagger & 2) {
-    // PHASE-SHIFTED walk for unit counts that fill whole rounds (nhalf == G: the last G/2 units are cut into halves).  The two
-    // workgroups of a CU are blocks b and b + G/2; the second one ("B") runs  half | R-1 full tiles | half,  the first one R
-    // full tiles: equal work, but B's store epilogues and first-chunk prologues fall into the MIDDLE of A's tiles and vice versa.
-    // (Without it both start and finish every tile together, and ~19 us per round of epilogue + prologue lie bare on the matrix
-    // pipe: the K = 512 and K = 1024 projections cost the same ~97 us on top of their MFMA time.)
-    const int HB = G / 2, R = (nfull + HB) / G;
-    const bool btype = (int)blockIdx.x >= HB;
-    const int bid = (int)blockIdx.x - (btype ? HB : 0);
-    const int c = (bid & 7) * (HB >> 3) + (bid >> 3);         // this workgroup's number among its kind, XCD-contiguous
-    const int uh = nfull + c, idh = uh % tiles;
-    if (btype) gemm_tile_unit<128, 64, A_KC, B_KC, KCH, PIPE>(p, (idh / ntn) * 128, (idh % ntn) * 128, uh / tiles, smem, uh, diag);
-    for (int rr = 0; rr < R - 1; ++rr) {
-      const int u = rr * G + w, id = u % tiles;
-      gemm_tile_unit<128, 128, A_KC, B_KC, KCH, PIPE>(p, (id / ntn) * 128, (id % ntn) * 128, u / tiles, smem, u, diag);
-    }
-    if (!btype) {
-      const int u = (R - 1) * G + c, id = u % tiles;
-      gemm_tile_unit<128, 128, A_KC, B_KC, KCH, PIPE>(p, (id / ntn) * 128, (id % ntn) * 128, u / tiles, smem, u, diag);
-    } else {
-      gemm_tile_unit<128, 64, A_KC, B_KC, KCH, PIPE>(p, (idh / ntn) * 128, (idh % ntn) * 128 + 64, uh / tiles, smem, uh, diag);
-    }
-    return;
-  }
-  const bool halves_first = (int)blockIdx.x >= G / 2 && (stagger & 1);
+  const bool halves_first = (int)blockIdx.x >= G / 2 && stagger;
   if (halves_first)
     for (int q = w; q < nhalf; q += G) {
       const int u = nfull + (q >> 1), id = u % tiles;
-      gemm_tile_unit<128, 64, A_KC, B_KC, KCH, PIPE>(p, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, u / tiles, smem, nfull + q, diag);
+      gemm_tile_body<128, 64, 2, 2, A_KC, B_KC, KCH>(p, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, u / tiles, smem, nfull + q);
     }
   for (int u = w; u < nfull; u += G) {
     const int id = u % tiles;
-    gemm_tile_unit<128, 128, A_KC, B_KC, KCH, PIPE>(p, (id / ntn) * 128, (id % ntn) * 128, u / tiles, smem, u, diag);
+    gemm_tile_body<128, 128, 2, 2, A_KC, B_KC, KCH>(p, (id / ntn) * 128, (id % ntn) * 128, u / tiles, smem, u);
   }
   if (!halves_first)
     for (int q = w; q < nhalf; q += G) {
       const int u = nfull + (q >> 1), id = u % tiles;
-      gemm_tile_unit<128, 64, A_KC, B_KC, KCH, PIPE>(p, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, u / tiles, smem, nfull + q, diag);
+      gemm_tile_body<128, 64, 2, 2, A_KC, B_KC, KCH>(p, (id / ntn) * 128, (id % ntn) * 128 + (q & 1) * 64, u / tiles, smem, nfull + q);
     }
 }
 
@@ -431,42 +250,17 @@ static int launch_layout(hipStream_t st, const TileP& p) {
   const long units128 = (long)(p.M / 128) * (p.N / 128) * p.nsplit * p.nbatch;
   const bool big_ok = (p.M % 128) == 0 && (p.N % 128) == 0 && units128 >= 192;
   if (big_ok) {
-    // 2 workgroups per CU x 256 CUs.  MMEGO_GEMM_SLOTS=256 (A/B knob, scripts/bench_overlap.py): ONE workgroup per CU, its LDS
+    // 2 workgroups per CU x 256 CUs.  MMEGO_GEMM_SLOTS=256 (A/B knob of scripts/bench_overlap.py): ONE workgroup per CU, its LDS
     // request padded past half a CU's LDS so that the dispatcher cannot put two on one CU -- at 204 VGPRs a pair of these
     // workgroups leaves no registers for another kernel's waves, a single one leaves 300 per lane.
     static const int slots = getenv("MMEGO_GEMM_SLOTS") ? atoi(getenv("MMEGO_GEMM_SLOTS")) : 512;
     const int units = (int)units128;
     static const bool no_persist = getenv("MMEGO_GEMM_NO_PERSIST") != nullptr;
-    static const int stagger_env = (getenv("MMEGO_GEMM_NO_STAGGER") == nullptr ? 1 : 0) |
-                               ((getenv("MMEGO_GEMM_DIAG") ? atoi(getenv("MMEGO_GEMM_DIAG")) : 0) << 8);
+    static const int stagger = getenv("MMEGO_GEMM_NO_STAGGER") == nullptr;
     if (units > slots && !no_persist) {
       const int rest = units % slots;
       const bool halves = rest > 0 && rest <= slots / 2;
-      int nfull = halves ? units - rest : units, nhalf = halves ? 2 * rest : 0;
-      // whole rounds: phase-shift the two workgroups of a CU (see the kernel); MMEGO_GEMM_NO_STAGGER / MMEGO_GEMM_NO_PHASE: off
-      static const bool no_phase = getenv("MMEGO_GEMM_NO_PHASE") != nullptr;
-      int stagger = stagger_env;
-      if (rest == 0 && units >= 2 * slots && (slots % 16) == 0 && (stagger_env & 1) && !no_phase) {
-        nfull = units - slots / 2;
-        nhalf = slots;
-        stagger |= 2;
-      }
-      static const bool pipe = getenv("MMEGO_GEMM_PIPE") ? atoi(getenv("MMEGO_GEMM_PIPE")) != 0 : true;
-      if constexpr (A_KC && B_KC) {
-        if (pipe && chunk_k() == 32 && (p.kchunk % 32) == 0) {
-          static bool attr_pipe = false;
-          const size_t lds = (size_t)(2 * 256 * 36) * sizeof(float);       // two buffers: 73.7 KB, two workgroups per CU
-          if (!attr_pipe) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_persistent_kernel<true, true, 32, true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            attr_pipe = true;
-          }
-          hipLaunchKernelGGL((gemm_tile_persistent_kernel<true, true, 32, true>), dim3(slots), dim3(256), lds, st, p, nfull, nhalf, stagger);
-          hipError_t e = hipGetLastError();
-          return e == hipSuccess ? 0 : (int)e;
-        }
-      }
+      const int nfull = halves ? units - rest : units, nhalf = halves ? 2 * rest : 0;
       if (chunk_k() == 32 && (p.kchunk % 32) == 0) {
         size_t lds = (size_t)(256 * 36) * sizeof(float);
         if (slots <= 256) {

@@ -362,6 +362,10 @@ class ConcurrentStages:
                     # the FIRST forward (the last stage's) has the GPU to itself: its recurrences run as two chains; the
                     # later ones have another stage's tail beside them, which fills the same gaps (blocks.two_chains)
                     alone = i == len(stages) - 1 and os.environ.get("MMEGO_FIRST_IMU_TWO_CHAINS", "1") != "0"
+                    # r03: with the shorter tails the later forwards gain from the two-chain form as well (5.30 -> 5.24 ms per
+                    # U+L step); MMEGO_ALL_IMU_TWO_CHAINS=0 restores one launch per timestep beside a running tail
+                    if os.environ.get("MMEGO_ALL_IMU_TWO_CHAINS", "1") != "0" and os.environ.get("MMEGO_FIRST_IMU_TWO_CHAINS", "1") != "0":
+                        alone = True
                     with torch.no_grad(), blocks.two_chains(alone):
                         # (the forward's own output tensors serve as the stage's head pose: they stay referenced -- and, under
                         # capture, reserved in the graph's pool -- until every branch has been enqueued; no copies)
