@@ -26,6 +26,7 @@ struct LstmStepP {
   float* gst[2];   // optional stash for backward: post-activation gates [Bn][4H] and new cell state [Bn][H] of this step
   float* cst[2];
   int Bn, H, ndir, first;
+  int xcd_strided;
 #ifdef MMEGO_STAMP
   int dbg;         // diagnostic probe only (scripts/clock_probe.hip): 1 = loaders do not wait for DMAs, 2 = no DMAs, 4 = no ds_reads
 #endif
@@ -78,7 +79,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int wg = blockIdx.x;
     if ((npairs & 7) == 0) {                   // workgroups sharing a W_hh slice on one XCD: each L2 holds 1/8 of W_hh
       const int xcd = wg & 7, q = wg >> 3;
-      pair = xcd + 8 * (q / nrb);
+      // an XCD takes a CONTIGUOUS run of hidden blocks: at HT = 16 a (row, gate) segment of xproj / c / h is 64 bytes, half a
+      // cache line, and the neighbouring hidden block's workgroup reads the other half -- on the same XCD the pair shares one
+      // L2 fill (MMEGO_STEP_XCD_STRIDED=1: the r02 order, hidden blocks xcd, xcd + 8, ...)
+      pair = p.xcd_strided ? xcd + 8 * (q / nrb) : xcd * (npairs >> 3) + (q / nrb);
       rb = q % nrb;
     } else {
       pair = wg / nrb;
@@ -456,6 +460,8 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
   p.gst[0] = gst0; p.gst[1] = gst1; p.cst[0] = cst0; p.cst[1] = cst1;
   MMEGO_REQUIRE((gst0 == nullptr) == (cst0 == nullptr) && (gst1 == nullptr) == (cst1 == nullptr));
   p.Bn = Bn; p.H = H; p.ndir = ndir; p.first = first;
+  static const int xcd_strided = getenv("MMEGO_STEP_XCD_STRIDED") ? atoi(getenv("MMEGO_STEP_XCD_STRIDED")) : 0;
+  p.xcd_strided = xcd_strided;
 #ifdef MMEGO_STAMP
   p.dbg = mmego_step_dbg;
 #endif

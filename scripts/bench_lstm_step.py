@@ -81,7 +81,7 @@ if "--chains" in sys.argv:
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
             run()
-            with torch.cuda.graph(g, stream=st):
+            with ops.capture(g, stream=st):
                 run()
         torch.cuda.synchronize()
         for _ in range(3):
