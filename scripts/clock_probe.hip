@@ -91,12 +91,13 @@ int main(int argc, char** argv) {
     float *b0 = dev_random(4 * H, 0.04f, 8), *b1 = dev_random(4 * H, 0.04f, 9);
     float* c = dev_random((size_t)2 * Bn * H, 0.5f, 10);
     const long xs = (long)T * 8 * H, os = getenv("PROBE_DENSE_H") ? (long)2 * H : (long)T * 2 * H;   // dense: h rows 4 KB apart
+    const int ndir = getenv("PROBE_NDIR") ? atoi(getenv("PROBE_NDIR")) : 2;      // 1: single-direction launches (the two-chain form's)
     auto t0 = std::chrono::steady_clock::now();
     long n = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
       for (int i = 0; i < 200; ++i) {
         int s = 1 + (i % (T - 2)), t1 = T - 1 - s;
-        mmego_lstm_step(st, 2, Bn, H, 0, out + (long)(s - 1) * 2 * H, out + (long)(t1 + 1) * 2 * H + H, os, w0, w1, b0, b1,
+        mmego_lstm_step(st, ndir, Bn, H, 0, out + (long)(s - 1) * 2 * H, out + (long)(t1 + 1) * 2 * H + H, os, w0, w1, b0, b1,
                         xp + (long)s * 8 * H, xp + (long)t1 * 8 * H + 4 * H, xs, out + (long)s * 2 * H, out + (long)t1 * 2 * H + H, os,
                         c, c + (long)Bn * H, nullptr, nullptr, nullptr, nullptr);
       }
@@ -108,7 +109,8 @@ int main(int argc, char** argv) {
     {
       const int ht = getenv("MMEGO_STEP_HT") ? atoi(getenv("MMEGO_STEP_HT")) : 16;
       // ideal = MFMA issue cycles of the work that shares one SIMD's matrix pipe (two workgroups per CU at HT = 16)
-      report(ht == 16 ? "lstm_step_dma_kernel<16>" : "lstm_step_dma_kernel<32>", 2 * (H / ht) * (Bn / 64), 8.0 * 4 * 32 * 32);
+      report(ht == 16 ? "lstm_step_dma_kernel<16>" : "lstm_step_dma_kernel<32>", ndir * (H / ht) * (Bn / 64),
+             ndir == 2 ? 8.0 * 4 * 32 * 32 : 8.0 * 4 * 32 * 16);
     }
     hipFree(out); hipFree(xp); hipFree(w0); hipFree(w1); hipFree(b0); hipFree(b1); hipFree(c);
   }

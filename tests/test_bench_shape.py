@@ -118,3 +118,48 @@ def test_dropout_active_training_lands_in_the_reference_band(dev, stage):
         assert clo - (chi - clo) - 1e-3 * clo <= a <= chi + (chi - clo) + 1e-3 * chi, (stage, i, curve0, [c[i] for c in pc])
     print("dropout band %s: reference [%.4f, %.4f] cm, HIP %s; dropout-free: reference (perturbed 1e-7) [%.4f, %.4f] cm, HIP %.4f"
           % (stage, lo, hi, ["%.4f" % e for e in errs], plo, phi, e0))
+
+
+def test_engines_agree_bit_for_bit_at_bench_shape(dev):
+    """The arrangements bench.py reports beside `value` -- stages one after the other (per-stage HIP graphs), the IMU-shared engine
+    and the prefetch-pipelined engine -- against the timed one (`ConcurrentStages`, one graph) at B=64, T=8, N=128 with IMU_Net(512),
+    dropout live (same seeds): two steps each, losses / gradient buffers / parameters / BatchNorm buffers bit-identical.  (At B=16 the
+    same is checked in test_hip_local; here the 512-row recurrences, the persistent projection kernel and the large-grid tails run.)"""
+    import bench
+    from mmego_amd.train_step import ConcurrentStages, PipelinedStages, SharedImuStages, StageStep
+    x, imu_in, body, target = bench.synth_batch(1234, dev)
+
+    def run(kind):
+        himu, hup, hlo, hfr = bench.build_hip_models(dev)
+        himu_l = bench.clone_imu(himu, dev)
+        own = kind in ("concurrent", "sequential")
+        su = StageStep("upper", hup, himu if own else None, lr=3e-5, use_graph=kind == "sequential")
+        sl = StageStep("lower", hlo, himu_l if own else None, upper_frozen=hfr, lr=3e-5, use_graph=kind == "sequential")
+        if kind == "concurrent":
+            eng = ConcurrentStages([su, sl], use_graph=True)
+        elif kind == "shared":
+            eng = SharedImuStages(himu, [su, sl], imu_in, use_graph=True)
+        elif kind == "pipelined":
+            eng = PipelinedStages([su, sl], [himu, himu_l], imu_in, use_graph=True)
+        else:
+            eng = None
+        su.bind(x, imu_in, body, target)          # (the engines hand the stages their head-pose buffers: bind comes after)
+        sl.bind(x, imu_in, body, target)
+        if kind == "pipelined":
+            eng.prime()
+        for _ in range(2):
+            if eng is None:
+                su.step(); sl.step()
+            else:
+                eng.step()
+        torch.cuda.synchronize()
+        return su, sl
+    ref = run("concurrent")
+    for kind in ("sequential", "shared", "pipelined"):
+        got = run(kind)
+        for a, b in zip(got, ref):
+            assert a.loss.item() == b.loss.item(), (kind, a.stage, a.loss.item(), b.loss.item())
+            assert torch.equal(a.net.flat().flat_g, b.net.flat().flat_g), (kind, a.stage)
+            assert torch.equal(a.net.flat().flat_p, b.net.flat().flat_p), (kind, a.stage)
+            for ba, bb in zip(a.net.buffers(), b.net.buffers()):
+                assert torch.equal(ba, bb), (kind, a.stage)
