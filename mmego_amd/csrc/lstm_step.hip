@@ -62,13 +62,8 @@ __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __bui
 // still takes 35.7 k -- the matrix pipe drains at every chunk barrier (the in-order compute wave cannot issue past it).
 // With HT = 16 there are 512 WGs, two per CU with independent barriers: while one workgroup's compute wave sits at its
 // barrier the other one's owns the SIMD's matrix pipe.  HT = 32 remains for grids that fill the chip twice over anyway.
-// PAIR (r03): a ring of FOUR stages handed over two chunks at a time -- one barrier per 64 k instead of one per 32 k.  At HT = 16
-// a chunk is only 32 MFMAs per compute wave, and the barrier, the fragment-read issue and the loop control around it (260-450
-// cycles per chunk, in-kernel stamps) weigh twice what they do at HT = 32; the DMA look-ahead in time is unchanged (the pair
-// behind the one being multiplied is in flight).  Needs an even chunk count; 64 KB (HT = 16) / 96 KB (HT = 32) of LDS.
-template <int HT, bool PAIR = false>
+template <int HT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void lstm_step_dma_kernel(LstmStepP p) {
-  constexpr int NSTG = PAIR ? 4 : 3;
   constexpr int NA = HT / 16;                  // A fragments (16-row groups) per compute wave
   constexpr int WROWS = 4 * HT;                // W rows per stage
   constexpr int NWP = WROWS / 32;              // W DMA pieces-groups per loader wave and chunk (8 rows each)
@@ -98,7 +93,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int j0 = ht * HT, r0 = rb * 64;
   const bool first = p.first != 0;
   const int nk = first ? 0 : H / 32;
-  float* const OUT = smem + (nk % NSTG) * STAGE;  // new c tile [64][CLD], then new h tile [64][CLD]
+  float* const OUT = smem + (nk % 3) * STAGE;  // new c tile [64][CLD], then new h tile [64][CLD]
   MMEGO_STAMP_AT(blockIdx.x, 0, tid == 0);
 
   if (loader) {
@@ -119,30 +114,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define D2_CHUNK(kt)                                                                                        \
   do {                                                                                                      \
     if (D2_DBG(2)) break;                                                                                   \
-    float* st_ = smem + ((kt) % NSTG) * STAGE;                                                              \
+    float* st_ = smem + ((kt) % 3) * STAGE;                                                                 \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) GLDS16(ag[i] + (kt) * 32, st_ + 8 * (lw + 4 * i) * 32);   \
     _Pragma("unroll") for (int j = 0; j < NWP; ++j) GLDS16(wg_[j] + (kt) * 32, st_ + 2048 + 8 * (lw + 4 * j) * 32); \
   } while (0)
     constexpr int PC = 2 + NWP;                // DMAs per loader wave and chunk
-    if constexpr (PAIR) {
-      // pairs of chunks: pair pp = chunks 2pp, 2pp+1 in stages (2pp) % 4, (2pp+1) % 4; nk is even and >= 2 (launcher)
-      const int np = nk >> 1;
-      if (nk > 0) {
-        D2_CHUNK(0); D2_CHUNK(1);
-        if (np > 1) { D2_CHUNK(2); D2_CHUNK(3); }
-        if (D2_DBG(1)) { }
-        else if (np > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PC) & 15) | (((2 * PC) >> 4) << 14));
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();            // (1) pair 0 is in LDS
-      for (int pp = 0; pp + 1 < np; ++pp) {    // B_pp: pair pp+1 has landed; the two stages of pair pp may be refilled
-        if (!D2_DBG(1)) __builtin_amdgcn_s_waitcnt(0x0F70);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (pp + 2 < np) { D2_CHUNK(2 * pp + 4); D2_CHUNK(2 * pp + 5); }
-      }
-    } else {
     if (nk > 0) {
       D2_CHUNK(0);
       if (nk > 1) D2_CHUNK(1);
@@ -161,7 +137,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (kt + 3 < nk) D2_CHUNK(kt + 3);
-    }
     }
     __builtin_amdgcn_s_barrier();              // (E) new c / h tiles are in OUT
     {
@@ -229,34 +204,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // for with a full set of MFMAs queued.
     int so = 0;
     D2_RD(pa, pb, 0, sw0);
-    if constexpr (PAIR) {
-      const int np = nk >> 1;
-      for (int pp = 0; pp < np; ++pp) {
-        const int s1 = (so == 3 * STAGE) ? 0 : so + STAGE;       // second stage of the pair
-        D2_RD(qa, qb, so, sw1);                // chunk 2pp, second half
-        __builtin_amdgcn_sched_barrier(0);
-        D2_MM(pa, pb);
-        __builtin_amdgcn_sched_barrier(0);
-        D2_RD(pa, pb, s1, sw0);                // chunk 2pp+1, first half (the same hand-over: no barrier in between)
-        __builtin_amdgcn_sched_barrier(0);
-        D2_MM(qa, qb);
-        __builtin_amdgcn_sched_barrier(0);
-        D2_RD(qa, qb, s1, sw1);                // last reads of the pair
-        __builtin_amdgcn_sched_barrier(0);
-        D2_MM(pa, pb);
-        __builtin_amdgcn_sched_barrier(0);
-        if (pp + 1 < np) {
-          __builtin_amdgcn_s_waitcnt(0xC07F);  // this wave's reads of the pair are done (builtin: see the single-chunk loop)
-          asm volatile("" ::: "memory");
-          __builtin_amdgcn_s_barrier();        // B_pp: pair pp+1 has landed, pair pp's stages may be refilled
-          so = (s1 == 3 * STAGE) ? 0 : s1 + STAGE;
-          D2_RD(pa, pb, so, sw0);              // first reads of pair pp+1, under set q's MFMAs
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        D2_MM(qa, qb);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
     for (int kt = 0; kt < nk; ++kt) {
       D2_RD(qa, qb, so, sw1);                  // last reads of stage kt
       __builtin_amdgcn_sched_barrier(0);
@@ -274,7 +221,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
       D2_MM(qa, qb);
       __builtin_amdgcn_sched_barrier(0);
-    }
     }
   }
   MMEGO_STAMP_AT(blockIdx.x, 2, tid == 0);
@@ -540,29 +486,24 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
     // would fill at most HALF the chip with HT = 32 -- one direction of the pair, launched on its own stream -- takes HT = 16:
     // then each direction's grid covers every CU once and the two directions' workgroups share the CUs out of phase
     const bool ht16 = force_ht ? force_ht == 16 : 2 * grid32 <= ncu;
-    // PAIR: four-stage ring, one barrier per two chunks (needs an even chunk count).  MMEGO_STEP_PAIR: 0 = never, 1 = single-direction
-    // (HT = 16) launches only [default], 2 = both tile sizes
-    static const int pair_mode = getenv("MMEGO_STEP_PAIR") ? atoi(getenv("MMEGO_STEP_PAIR")) : 1;
-    const bool even = ((H / 32) % 2) == 0;
-    static bool attr32 = false, attr16 = false, attr32p = false, attr16p = false;
-#define STEP_LAUNCH(KERN_, FLAG_, LDS_, GRID_)                                                                       \
-  do {                                                                                                               \
-    const size_t lds = (LDS_);                                                                                       \
-    if (!FLAG_) {                                                                                                    \
-      hipError_t e = hipFuncSetAttribute((const void*)KERN_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-      if (e != hipSuccess) return (int)e;                                                                            \
-      FLAG_ = true;                                                                                                  \
-    }                                                                                                                \
-    hipLaunchKernelGGL(KERN_, dim3(GRID_), dim3(512), lds, (hipStream_t)stream, p);                                  \
-  } while (0)
+    static bool attr32 = false, attr16 = false;
     if (ht16) {
-      if (even && pair_mode >= 1) STEP_LAUNCH((lstm_step_dma_kernel<16, true>), attr16p, (size_t)4 * (64 + 64) * 32 * sizeof(float), 2 * grid32);
-      else STEP_LAUNCH((lstm_step_dma_kernel<16, false>), attr16, (size_t)3 * (64 + 64) * 32 * sizeof(float), 2 * grid32);
+      const size_t lds = (size_t)3 * (64 + 64) * 32 * sizeof(float);
+      if (!attr16) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_step_dma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr16 = true;
+      }
+      hipLaunchKernelGGL(lstm_step_dma_kernel<16>, dim3(2 * grid32), dim3(512), lds, (hipStream_t)stream, p);
     } else {
-      if (even && pair_mode >= 2) STEP_LAUNCH((lstm_step_dma_kernel<32, true>), attr32p, (size_t)4 * (64 + 128) * 32 * sizeof(float), grid32);
-      else STEP_LAUNCH((lstm_step_dma_kernel<32, false>), attr32, (size_t)3 * (64 + 128) * 32 * sizeof(float), grid32);
+      const size_t lds = (size_t)3 * (64 + 128) * 32 * sizeof(float);
+      if (!attr32) {
+        hipError_t e = hipFuncSetAttribute((const void*)lstm_step_dma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr32 = true;
+      }
+      hipLaunchKernelGGL(lstm_step_dma_kernel<32>, dim3(grid32), dim3(512), lds, (hipStream_t)stream, p);
     }
-#undef STEP_LAUNCH
   } else {
     int grid = ndir * (H / 4) * cdiv(Bn, 64);
     const bool full = (Bn % 64) == 0;
