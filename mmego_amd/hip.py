@@ -56,6 +56,8 @@ def lib():
 def _conv(v):
     if isinstance(v, torch.Tensor):
         return v.data_ptr()
+    if isinstance(v, ctypes.Array):          # a host-side descriptor table (gemm_group): kept alive by whoever holds the argument list
+        return ctypes.addressof(v)
     return v
 
 
@@ -112,15 +114,24 @@ class gemm_group:
                 for dsc, a in zip(arr, part):
                     for (fname, _), v in zip(GemmDesc._fields_, a):
                         setattr(dsc, fname, _conv(v))
-                call("gemm_group", len(part), ctypes.addressof(arr))
+                call("gemm_group", len(part), arr)          # (the array object, not its address: a recorded call keeps it alive)
         return False
 
 
 _GEMM_OUT_ARGS = (6, 23)        # positions of C and asum in mmego_gemm's argument list (behind the stream)
 
 
+def _launch(name, *args):
+    """The one place a kernel is launched: `mmego_<name>` on torch's current stream, tensors passed as device pointers.
+    (plan.StepPlan swaps this function for a recorder while it records a step.)"""
+    fn = getattr(lib(), "mmego_" + name)
+    rc = fn(stream_handle(), *[_conv(a) for a in args])
+    if rc != 0:
+        raise RuntimeError("mmego_%s failed: %s" % (name, "bad argument" if rc < 0 else "hipError %d" % rc))
+
+
 def call(name, *args):
-    """Launch `mmego_<name>` on torch's current stream.  Tensors are passed as device pointers."""
+    """Launch `mmego_<name>` on torch's current stream (inside a gemm_group context: defer the mmego_gemm calls)."""
     if _gemm_rec is not None and name != "gemm_group":
         ptrs = {a.data_ptr() for a in args if isinstance(a, torch.Tensor)}
         if ptrs & _gemm_rec_outs:
@@ -130,10 +141,7 @@ def call(name, *args):
             _gemm_rec_outs.update(args[i].data_ptr() for i in _GEMM_OUT_ARGS if isinstance(args[i], torch.Tensor))
             _gemm_rec.append(args)
             return
-    fn = getattr(lib(), "mmego_" + name)
-    rc = fn(stream_handle(), *[_conv(a) for a in args])
-    if rc != 0:
-        raise RuntimeError("mmego_%s failed: %s" % (name, "bad argument" if rc < 0 else "hipError %d" % rc))
+    _launch(name, *args)
 
 
 def graph_dA_nblk(G):

@@ -12,6 +12,25 @@ import torch
 
 from . import hip, ops
 from .params import FusedAdam
+from .plan import StepPlan
+
+# A step's HIP graphs: "0" (default) = the whole body as ONE graph whose parallel branches are the body's side streams; "1" = one
+# linear-chain graph per stream segment, replayed on the body's own streams with event waits in between (plan.StepPlan).  Measured
+# in r03: a graph with parallel branches dispatches TINY nodes in 5-6 us against 1.5-1.8 us for linear chains in separate graphs
+# (scripts/bench_launch_gap.py), but with the step's real kernels the ~15 graph boundaries cost more than that saves: 5.35 against
+# 5.25 ms per U+L step, 5.11 against 5.04 ms pipelined (bit-identical results; host enqueue time 0.6 against 2.1 ms per step).
+_MULTI_GRAPH = os.environ.get("MMEGO_MULTI_GRAPH", "0") == "1"
+
+
+def _capture_body(body):
+    """-> an object with .replay(): the body as HIP graphs (no state is changed: recording / capturing executes nothing)."""
+    if _MULTI_GRAPH:
+        return StepPlan().record(body).build()
+    g = torch.cuda.CUDAGraph()
+    with ops.capture(g):
+        body()
+    return g
+
 from .skeleton import LOWER_MAP, UPPER_MAP
 
 
@@ -197,10 +216,7 @@ class StageStep:
         every step costs)."""
         if self.use_graph and self.graph is None:
             self.warm_up()
-            g = torch.cuda.CUDAGraph()
-            with ops.capture(g):
-                self._body()
-            self.graph = g
+            self.graph = _capture_body(self._body)
 
     def step(self):
         if self.use_graph:
@@ -252,10 +268,7 @@ class ImuStep:
                 self._body()                                   # warm-up (side-effect free: IMU_Net has no BatchNorm)
                 torch.cuda.synchronize()
                 self.net.seed_counter().copy_(keep)
-                g = torch.cuda.CUDAGraph()
-                with ops.capture(g):
-                    self._body()
-                self.graph = g
+                self.graph = _capture_body(self._body)
             self.graph.replay()
         else:
             self._body()
@@ -297,10 +310,7 @@ class SharedImuStages:
                     for t, k in zip(st._mutable_state(), ks):
                         t.copy_(k)
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with ops.capture(g):
-                    self._body()
-                self.graph = g
+                self.graph = _capture_body(self._body)
             self.graph.replay()
         else:
             self._body()
@@ -394,10 +404,7 @@ class ConcurrentStages:
                 for t, k in zip(st._mutable_state(), ks):
                     t.copy_(k)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with ops.capture(g):
-                self._bodies()
-            self.graph = g
+            self.graph = _capture_body(self._bodies)
 
     def step(self):
         if self.use_graph:
@@ -496,10 +503,7 @@ class PipelinedStages:
             for t, k in zip([t for pr in (self.cur, self.nxt) for pose in pr for t in pose], keep_pose[0]):
                 t.copy_(k)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with ops.capture(g):
-                self._body()
-            self.graph = g
+            self.graph = _capture_body(self._body)
 
     def step(self):
         if self.use_graph:

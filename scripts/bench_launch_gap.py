@@ -100,3 +100,67 @@ def medium_and_tiny():
 
 
 timed(medium_and_tiny, 200, "the same with 200 tiny kernels on a second stream (per node of ONE chain)")
+
+# r03: the same two chains as TWO GRAPHS (each a plain linear chain) replayed on two streams, instead of two branches of one graph
+def capture(body):
+    body()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            body()
+    torch.cuda.synchronize()
+    return g
+
+
+ga, gb = capture(lambda: chain(N, bufs[0])), capture(lambda: chain(N, bufs[1]))
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+
+def replay_pair():
+    cur = torch.cuda.current_stream()
+    sa.wait_stream(cur); sb.wait_stream(cur)
+    with torch.cuda.stream(sa):
+        ga.replay()
+    with torch.cuda.stream(sb):
+        gb.replay()
+    cur.wait_stream(sa); cur.wait_stream(sb)
+
+
+for _ in range(3):
+    replay_pair()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    replay_pair()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 20 * 1e3
+print("two chains of %d as TWO graphs on two streams: %.1f us per pair of replays = %.2f us per node of ONE chain" % (N, us, us / N))
+# and the medium chain (256-workgroup kernels) beside the tiny chain, as two graphs
+gm, gt = capture(lambda: medium_chain(200)), capture(lambda: chain(200, bufs[1]))
+
+
+def replay_pair2():
+    cur = torch.cuda.current_stream()
+    sa.wait_stream(cur); sb.wait_stream(cur)
+    with torch.cuda.stream(sa):
+        gm.replay()
+    with torch.cuda.stream(sb):
+        gt.replay()
+    cur.wait_stream(sa); cur.wait_stream(sb)
+
+
+for _ in range(3):
+    replay_pair2()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(20):
+    replay_pair2()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 20 * 1e3
+print("200 4-MB fills and 200 tiny kernels as TWO graphs on two streams: %.1f us per pair = %.2f us per node of ONE chain" % (us, us / 200))

@@ -124,7 +124,8 @@ def test_engines_agree_bit_for_bit_at_bench_shape(dev):
     """The arrangements bench.py reports beside `value` -- stages one after the other (per-stage HIP graphs), the IMU-shared engine
     and the prefetch-pipelined engine -- against the timed one (`ConcurrentStages`, one graph) at B=64, T=8, N=128 with IMU_Net(512),
     dropout live (same seeds): two steps each, losses / gradient buffers / parameters / BatchNorm buffers bit-identical.  (At B=16 the
-    same is checked in test_hip_local; here the 512-row recurrences, the persistent projection kernel and the large-grid tails run.)"""
+    same is checked in test_hip_local; here the 512-row recurrences, the persistent projection kernel and the large-grid tails run.)
+    Also with the bodies captured through plan.StepPlan (MMEGO_MULTI_GRAPH=1: a graph per stream segment + event waits)."""
     import bench
     from mmego_amd.train_step import ConcurrentStages, PipelinedStages, SharedImuStages, StageStep
     x, imu_in, body, target = bench.synth_batch(1234, dev)
@@ -155,8 +156,17 @@ def test_engines_agree_bit_for_bit_at_bench_shape(dev):
         torch.cuda.synchronize()
         return su, sl
     ref = run("concurrent")
-    for kind in ("sequential", "shared", "pipelined"):
-        got = run(kind)
+    from mmego_amd import train_step
+    kinds = [("sequential", False), ("shared", False), ("pipelined", False), ("concurrent", True), ("pipelined", True), ("sequential", True)]
+    for kind, multi in kinds:
+        # multi: the body as one linear-chain HIP graph per stream segment (plan.StepPlan) instead of one graph with branches
+        was = train_step._MULTI_GRAPH
+        train_step._MULTI_GRAPH = multi
+        try:
+            got = run(kind)
+        finally:
+            train_step._MULTI_GRAPH = was
+        kind = kind + ("/plan" if multi else "")
         for a, b in zip(got, ref):
             assert a.loss.item() == b.loss.item(), (kind, a.stage, a.loss.item(), b.loss.item())
             assert torch.equal(a.net.flat().flat_g, b.net.flat().flat_g), (kind, a.stage)
