@@ -429,120 +429,6 @@ class ConcurrentStages:
         return [st.loss for st in self.stages]
 
 
-class OverlappedStages:
-    """The U+L step WITHOUT a join at its end: the first stage's small-kernel tail (the Upper body) of minibatch i runs on a stream
-    of its own, beside the last stage's IMU_Net forward of minibatch i+1.
-
-    Every dependency of the reference's two programs is kept as an event edge -- a body starts behind its own IMU_Net forward, a
-    stage's next body behind that stage's optimiser update, an IMU_Net forward's pose buffers are rewritten only behind the body
-    that read them -- and nothing else orders the work: the Lower stage's IMU_Net forward depends on nothing the Upper stage
-    writes (frozen weights, the minibatch's IMU samples), so it need not wait for the Upper tail, which in `ConcurrentStages` lies
-    bare at the end of every step (0.55 ms of 5.2).  No look-ahead into the next minibatch is needed (unlike `PipelinedStages`):
-    step i+1 simply starts when the host enqueues it.  The caller's minibatch buffers must not be rewritten while the tail of the
-    previous step may still read them: call `finish()` (the launching stream then waits for the tail stream) before touching
-    them, or double-buffer the inputs.
-    Three HIP graphs per step: P1 = the last stage's IMU_Net forward; P2 = the first stage's IMU_Net forward with the last stage's
-    body beside it (two branches); Q = the first stage's body.  Data parallel: the last stage's gradient all-reduce is issued behind
-    P2 on the launching stream and runs BESIDE Q; the first stage's follows Q on the tail stream.
-    Bit-identical to ConcurrentStages (tests/test_bench_shape.py)."""
-
-    def __init__(self, stages, use_graph=True):
-        self.stages = list(stages)
-        if len(self.stages) != 2 or any(st.imu is None or st.pose is not None for st in self.stages):
-            raise ValueError("OverlappedStages: two stages, each with its own IMU_Net")
-        nets_used = [id(m) for st in self.stages for m in (st.net, st.imu, st.upper_frozen) if m is not None]
-        if len(set(nets_used)) != len(nets_used):
-            raise ValueError("OverlappedStages: stages share a network instance")
-        self.first, self.last = self.stages[0], self.stages[1]
-        self.use_graph = use_graph
-        self.graphs = None
-        self.side = torch.cuda.Stream()          # the last stage's body inside P2
-        self.tail = torch.cuda.Stream()          # Q and the first stage's optimiser update
-        self.ev_p2, self.ev_q = torch.cuda.Event(), torch.cuda.Event()
-        self._imus = {id(st): st.imu for st in self.stages}
-        self._poses = {}
-
-    def _pose_bufs(self, st):
-        x = st.static["imu"]
-        B, T = x.shape[0], x.shape[1]
-        if id(st) not in self._poses:
-            self._poses[id(st)] = (torch.empty(B, T, 3, 3, device=x.device), torch.empty(B, T, 3, device=x.device))
-        return self._poses[id(st)]
-
-    def _imu_forward(self, st):
-        from . import blocks
-        Rb, tb = self._pose_bufs(st)
-        two = os.environ.get("MMEGO_OVERLAP_TWO_CHAINS", "11")       # (A/B knob: two-chain recurrences in P1 / P2)
-        with torch.no_grad(), blocks.two_chains(two[0 if st is self.last else 1] == "1"):
-            R, t = self._imus[id(st)](st.static["imu"])
-            ops.copy2d(R.view(-1, 9), Rb.view(-1, 9))
-            ops.copy2d(t.view(-1, 3), tb.view(-1, 3))
-
-    def _p1(self):
-        self._imu_forward(self.last)
-
-    def _p2(self):
-        main = torch.cuda.current_stream()
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            self._stage_body(self.last)
-        self._imu_forward(self.first)
-        main.wait_stream(self.side)
-
-    def _q(self):
-        self._stage_body(self.first)
-
-    def _stage_body(self, st):
-        keep = (st.imu, st.pose)
-        try:
-            st.imu, st.pose = None, self._pose_bufs(st)
-            st._body()
-        finally:
-            st.imu, st.pose = keep
-
-    def prepare(self):
-        if self.use_graph and self.graphs is None:
-            for st in self.stages:
-                st.warm_up()
-            keep = [[t.clone() for t in st._mutable_state()] for st in self.stages]
-            self._p1(); self._p2()                         # arenas / scratch of the streams these parts run on
-            torch.cuda.synchronize()
-            with torch.cuda.stream(self.tail):
-                self._q()
-            torch.cuda.synchronize()
-            for st, ks in zip(self.stages, keep):
-                for t, k in zip(st._mutable_state(), ks):
-                    t.copy_(k)
-            torch.cuda.synchronize()
-            # Q runs beside the next step's P1: it is captured under the tail stream, so that it owns its split-K scratch
-            self.graphs = [_capture_body(self._p1), _capture_body(self._p2), _capture_body(self._q, stream=self.tail)]
-
-    def step(self):
-        main = torch.cuda.current_stream()
-        if self.use_graph:
-            self.prepare()
-            run = [g.replay for g in self.graphs]
-        else:
-            run = [self._p1, self._p2, self._q]
-        run[0]()
-        main.wait_event(self.ev_q)               # the previous step's Q has read the first stage's pose buffers (recorded or not yet used)
-        run[1]()
-        self.ev_p2.record(main)
-        self.tail.wait_event(self.ev_p2)
-        with torch.cuda.stream(self.tail):
-            run[2]()
-            allreduce_grads(self.first.net._flat, self.first.pg)
-            self.first.opt.step()
-            self.ev_q.record(self.tail)
-        allreduce_grads(self.last.net._flat, self.last.pg)
-        self.last.opt.step()
-        return [st.loss for st in self.stages]
-
-    def finish(self):
-        """The launching stream behind everything enqueued so far (before reading the first stage's loss / parameters there)."""
-        torch.cuda.current_stream().wait_event(self.ev_q)
-
-
 class PipelinedStages:
     """ConcurrentStages with the frozen IMU_Net forwards moved one minibatch ahead (a prefetch pipeline).
 

@@ -60,32 +60,3 @@ print("  StepPlan (graph per chain): host %.3f ms, device %.1f us per layer = %.
 h, d = timeit(plan.run_eagerly)
 print("  same plan, eager launches : host %.3f ms, device %.1f us per layer = %.2f us per timestep" % (h, d * 1e3, d * 1e3 / T))
 
-# the U+L step: ConcurrentStages against OverlappedStages (no join at the end of a step), device time per step over 60 steps
-from mmego_amd.train_step import OverlappedStages  # noqa: E402
-
-
-def engine(cls):
-    imu, upper, lower, upper_frozen = bench.build_hip_models(dev)
-    imu_l = bench.clone_imu(imu, dev)
-    x, imu_in, body, target = bench.synth_batch(1234, dev)
-    su = StageStep("upper", upper, imu, lr=3e-5)
-    sl = StageStep("lower", lower, imu_l, upper_frozen=upper_frozen, lr=3e-5)
-    su.bind(x, imu_in, body, target); sl.bind(x, imu_in, body, target)
-    eng = cls([su, sl])
-    eng.prepare()
-    return eng
-
-
-for cls in (ConcurrentStages, OverlappedStages, ConcurrentStages, OverlappedStages):
-    eng = engine(cls)
-    for _ in range(5):
-        eng.step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(60):
-        eng.step()
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print("%s: host %.3f ms, %.3f ms per step" % (cls.__name__, (t1 - t0) / 60 * 1e3, (t2 - t0) / 60 * 1e3))
-    del eng

@@ -121,25 +121,23 @@ def test_dropout_active_training_lands_in_the_reference_band(dev, stage):
 
 
 def test_engines_agree_bit_for_bit_at_bench_shape(dev):
-    """The arrangements bench.py reports beside `value` -- stages one after the other (per-stage HIP graphs), the IMU-shared engine,
-    the prefetch-pipelined engine and the engine without a join at the end of a step (OverlappedStages) -- against the timed one (`ConcurrentStages`, one graph) at B=64, T=8, N=128 with IMU_Net(512),
+    """The arrangements bench.py reports beside `value` -- stages one after the other (per-stage HIP graphs), the IMU-shared engine
+    and the prefetch-pipelined engine -- against the timed one (`ConcurrentStages`, one graph) at B=64, T=8, N=128 with IMU_Net(512),
     dropout live (same seeds): three steps each, losses / gradient buffers / parameters / BatchNorm buffers bit-identical.  (At B=16 the
     same is checked in test_hip_local; here the 512-row recurrences, the persistent projection kernel and the large-grid tails run.)
     Also with the bodies captured through plan.StepPlan (MMEGO_MULTI_GRAPH=1: a graph per stream segment + event waits)."""
     import bench
-    from mmego_amd.train_step import ConcurrentStages, OverlappedStages, PipelinedStages, SharedImuStages, StageStep
+    from mmego_amd.train_step import ConcurrentStages, PipelinedStages, SharedImuStages, StageStep
     x, imu_in, body, target = bench.synth_batch(1234, dev)
 
     def run(kind):
         himu, hup, hlo, hfr = bench.build_hip_models(dev)
         himu_l = bench.clone_imu(himu, dev)
-        own = kind in ("concurrent", "sequential", "overlapped")
+        own = kind in ("concurrent", "sequential")
         su = StageStep("upper", hup, himu if own else None, lr=3e-5, use_graph=kind == "sequential")
         sl = StageStep("lower", hlo, himu_l if own else None, upper_frozen=hfr, lr=3e-5, use_graph=kind == "sequential")
         if kind == "concurrent":
             eng = ConcurrentStages([su, sl], use_graph=True)
-        elif kind == "overlapped":
-            eng = OverlappedStages([su, sl], use_graph=True)
         elif kind == "shared":
             eng = SharedImuStages(himu, [su, sl], imu_in, use_graph=True)
         elif kind == "pipelined":
@@ -150,7 +148,7 @@ def test_engines_agree_bit_for_bit_at_bench_shape(dev):
         sl.bind(x, imu_in, body, target)
         if kind == "pipelined":
             eng.prime()
-        for _ in range(3):                      # (three steps: the overlapped engine's tail runs beside a following forward twice)
+        for _ in range(3):
             if eng is None:
                 su.step(); sl.step()
             else:
@@ -159,8 +157,7 @@ def test_engines_agree_bit_for_bit_at_bench_shape(dev):
         return su, sl
     ref = run("concurrent")
     from mmego_amd import train_step
-    kinds = [("sequential", False), ("shared", False), ("pipelined", False), ("overlapped", False), ("concurrent", True),
-             ("pipelined", True), ("sequential", True), ("overlapped", True)]
+    kinds = [("sequential", False), ("shared", False), ("pipelined", False), ("concurrent", True), ("pipelined", True), ("sequential", True)]
     for kind, multi in kinds:
         # multi: the body as one linear-chain HIP graph per stream segment (plan.StepPlan) instead of one graph with branches
         was = train_step._MULTI_GRAPH
