@@ -87,8 +87,8 @@ def test_dropout_active_training_lands_in_the_reference_band(dev, stage):
     statistical.  tests/golden/g10_dropout_band.npz holds the REAL reference's final train-set joint error after 200 dropout-active
     steps from fixed initial weights over 6 dropout seeds (the run-to-run band), the dropout-free deterministic run, and runs at
     twice the rate (which leave the band upwards: the statistic separates a wrong rate from the band).  Here:
-      * dropout 0.1, three HIP dropout seeds: every run within the reference band widened by half its width on each side, their
-        mean inside the band itself;
+      * dropout 0.1, six HIP dropout seeds: their mean within three standard errors (two-sample) of the reference's mean, every
+        run within the reference band widened by its width on each side;
       * dropout 0: the HIP run's final error and 50/100/150/200-step losses inside the spread of the reference's dropout-free runs
         from 1e-7-perturbed initial weights.
     What the statistic can and cannot see (the fixture's own numbers): for Upper_Net the runs at rate 0.2 (4.37-4.47 cm) leave the
@@ -100,10 +100,15 @@ def test_dropout_active_training_lands_in_the_reference_band(dev, stage):
     ref = band["ref.%s.p01.err_cm" % stage]
     lo, hi = float(ref.min()), float(ref.max())
     w = hi - lo
-    errs = [_train_200(stage, 0.1, 1000 + k, dev)[0] for k in range(3)]
+    # six HIP dropout seeds against the reference's six: the means within three standard errors of each other (two-sample), every
+    # run within the reference band widened by its width (a future change of a kernel's rounding moves these end points around
+    # inside their spread -- the criterion is statistical on purpose)
+    errs = [_train_200(stage, 0.1, 1000 + k, dev)[0] for k in range(6)]
+    import numpy as np
+    se = float(np.sqrt(ref.var(ddof=1) / len(ref) + np.var(errs, ddof=1) / len(errs)))
+    assert abs(float(np.mean(errs)) - float(ref.mean())) < 3.0 * se + 0.02, (stage, errs, list(ref), se)
     for e in errs:
-        assert lo - 0.5 * w <= e <= hi + 0.5 * w, (stage, errs, (lo, hi))
-    assert lo <= sum(errs) / len(errs) <= hi, (stage, errs, (lo, hi))
+        assert lo - w <= e <= hi + w, (stage, errs, (lo, hi))
     # Dropout-free: 200 Adam steps at lr 3e-4 amplify ROUNDING-sized differences -- the reference itself, started from weights
     # perturbed by 1e-7 relative, ends anywhere in [3.97, 4.23] cm (Upper) / [4.91, 5.31] cm (Lower), and the CPU oracle's
     # dropout-free run is not reproducible from process to process (multi-threaded reductions: 5.04 and 5.47 cm were both seen for
