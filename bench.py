@@ -473,7 +473,7 @@ def main():
     ap.add_argument("--no-bf16-variant", action="store_true", help="skip the extra bf16-IMU figure")
     ap.add_argument("--no-pipelined-variant", action="store_true", help="skip the extra prefetch-pipelined figure")
     ap.add_argument("--no-config-extras", action="store_true", help="skip the config-2 / config-5 forward figures")
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=12, help="timed U+L steps of the CPU baseline (~0.85 s each on 16 cores: ~10 s)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
