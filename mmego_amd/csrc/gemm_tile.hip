@@ -164,160 +164,8 @@ __device__ __forceinline__ void gemm_tile_body(const TileP& p, int m0, int n0, i
   MMEGO_STAMP_AT(sid, 3, tid == 0);
 }
 
-// WIDE tiles (r03 experiment, MMEGO_GEMM_WIDE=1): 256 x 128 output tile per 512-thread workgroup (8 waves as 4 x 2 of 64 x 64), ONE
-// workgroup per CU; half the tiles of the 128 x 128 kernel (half the per-tile prologues / epilogues) and 0.75 of its operand bytes
-// per MFMA.  Both waves of a SIMD belong to the same workgroup and meet at the same barriers, so the loop is the software-pipelined
-// one: two LDS buffers (110.6 KB), one raw barrier per 32-k chunk in front of the chunk's last 8-k block, fragment sets alternating
-// per block, next chunk's stores and the loads of the one after it inside the MFMA blocks.  Same fragments and k order per output
-// element as gemm_tile_body: bit-identical results.
-#define GT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-__device__ __forceinline__ void gemm_tile_body_wide(const TileP& p, int m0, int n0, int sb, float* smem) {
-  constexpr int BN = 128; const int sid = 0; (void)sid;
-  constexpr int BM = 256, KCH = 32, TLD = KCH + 4;
-  constexpr int WM = 64, WN = 64, TM = 2, TN = 2;
-  constexpr int AV = BM * KCH / 2048, BV = BN * KCH / 2048;       // f32x4 per thread (512 threads) per chunk: 4, 2
-  constexpr int BUF = (BM + BN) * TLD;                             // floats per LDS buffer
-  const int split = sb % p.nsplit, batch = sb / p.nsplit;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 3, wn = wave >> 2;                          // 8 waves as 4 x 2 of 64 x 64
-  const int kbeg = split * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
-  const int nk = (kend - kbeg) / KCH;
-  const int lk = (tid & 7) * 4, lr = tid >> 3;                     // staging: 8 lanes per 32-k row segment, rows lr + 32 i
-  const float* Ap = p.A + (long)batch * p.sAb + (long)(m0 + lr) * p.lda + kbeg + lk;
-  const float* Wp = p.W + (long)batch * p.sWb + (long)(n0 + lr) * p.ldw + kbeg + lk;
-  const long astep = 64 * p.lda, bstep = 64 * p.ldw;               // staging rows lr + 64 i (lr = tid >> 3 < 64)
-  const int r = lane & 31, h = lane >> 5;
-  // byte-free index arithmetic: this lane's staging slot and fragment rows inside a buffer
-  const int wofs = lr * TLD + lk;
-  const int aofs = (wm * WM + r) * TLD + 4 * h, bofs = BM * TLD + (wn * WN + r) * TLD + 4 * h;
-  f32x4 ra[AV], rb[BV];
-  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
-#define GT_LOAD(kt_)                                                                               \
-  do {                                                                                             \
-    const float* An_ = Ap + (long)(kt_) * KCH;                                                     \
-    const float* Wn_ = Wp + (long)(kt_) * KCH;                                                     \
-    _Pragma("unroll") for (int i = 0; i < AV; ++i) ra[i] = *reinterpret_cast<const f32x4*>(An_ + i * astep); \
-    _Pragma("unroll") for (int i = 0; i < BV; ++i) rb[i] = *reinterpret_cast<const f32x4*>(Wn_ + i * bstep); \
-  } while (0)
-#define GT_STORE_A(buf_, i0_, i1_)                                                                 \
-  do {                                                                                             \
-    _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i)                                          \
-      *reinterpret_cast<f32x4*>((buf_) + wofs + 64 * i * TLD) = ra[i];                             \
-  } while (0)
-#define GT_STORE_B(buf_, i0_, i1_)                                                                 \
-  do {                                                                                             \
-    _Pragma("unroll") for (int i = (i0_); i < (i1_); ++i)                                          \
-      *reinterpret_cast<f32x4*>((buf_) + BM * TLD + wofs + 64 * i * TLD) = rb[i];                  \
-  } while (0)
-#define GT_READ(buf_, kb_, fa_, fb_)                                                               \
-  do {                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
-      fa_[i] = *reinterpret_cast<const f32x4*>((buf_) + aofs + i * 32 * TLD + (kb_) * 8);          \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
-      fb_[j] = *reinterpret_cast<const f32x4*>((buf_) + bofs + j * 32 * TLD + (kb_) * 8);          \
-  } while (0)
-#define GT_MMA(fa_, fb_)                                                                           \
-  do {                                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                               \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                               \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i][s_], fb_[j][s_], acc[i][j], 0, 0, 0); \
-  } while (0)
-  if (nk > 0) {
-    GT_LOAD(0);
-    // (a persistent workgroup comes here from the previous tile: its waves may still be reading that tile's last fragments)
-    GT_LDS_BARRIER();
-    GT_STORE_A(smem, 0, AV);
-    GT_STORE_B(smem, 0, BV);
-    GT_LOAD(min(1, nk - 1));
-    GT_LDS_BARRIER();
-    GT_READ(smem, 0, fa0, fb0);
-  }
-  // (no condition anywhere in the loop: past the last chunk the stores / reads / loads run once more on the last chunk's data,
-  // which nobody uses -- a uniform branch around them made the compiler's LDS wait counts conservative: the MFMAs of a block
-  // then waited for the reads issued just in front of them)
-  for (int kt = 0; kt < nk; ++kt) {
-    float* cur = smem + (kt & 1) * BUF;
-    float* nxt = smem + ((kt + 1) & 1) * BUF;
-    // block 0
-    GT_READ(cur, 1, fa1, fb1);
-    GT_STORE_A(nxt, 0, AV);
-    __builtin_amdgcn_sched_barrier(0);
-    GT_MMA(fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    // block 1
-    GT_READ(cur, 2, fa0, fb0);
-    GT_STORE_B(nxt, 0, BV);
-    __builtin_amdgcn_sched_barrier(0);
-    GT_MMA(fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    // block 2
-    GT_READ(cur, 3, fa1, fb1);
-    GT_LOAD(min(kt + 2, nk - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    GT_MMA(fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    // block 3: everything this wave reads of chunk kt and writes of chunk kt+1 has been issued
-    GT_LDS_BARRIER();
-    GT_READ(nxt, 0, fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    GT_MMA(fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#undef GT_LOAD
-#undef GT_STORE_A
-#undef GT_STORE_B
-#undef GT_READ
-#undef GT_MMA
-
-  if (p.relu == 99) return;            // EXPERIMENT: no epilogue
-  const bool slab = p.nsplit > 1;
-  float* C = slab ? p.ws + ((long)split * p.nbatch + batch) * p.M * p.N : p.C + (long)batch * p.sCb;
-  const long ldc = slab ? (long)p.N : p.ldc;
-  const bool relu = !slab && p.relu, accumulate = !slab && p.accumulate;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * WN + j * 32 + (lane & 31);
-    const float bv = (!slab && p.bias) ? p.bias[(long)batch * p.sBiasb + col] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      float* cp = C + (long)(m0 + wm * WM + i * 32 + 4 * (lane >> 5)) * ldc + col;
-      float old[16];
-      if (accumulate) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) old[reg] = cp[(long)((reg & 3) + 8 * (reg >> 2)) * ldc];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) asm volatile("" : "+v"(old[reg]));
-      }
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        float v = acc[i][j][reg] + bv;
-        if (relu) v = fmaxf(v, 0.0f);
-        if (accumulate) v += old[reg];
-        cp[(long)((reg & 3) + 8 * (reg >> 2)) * ldc] = v;
-      }
-    }
-  }
-}
-
 // XCD-aware tile order: blocks b and b+8 share an XCD; hand each XCD a contiguous run of tile ids
 __device__ __forceinline__ int xcd_order(int id, int n) { return (n & 7) == 0 ? (id & 7) * (n >> 3) + (id >> 3) : id; }
-
-__global__ __launch_bounds__(512) void gemm_tile_wide_kernel(TileP p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int ntn = p.N / 128, tiles = ntn * (p.M / 256), G = (int)gridDim.x;
-  const int units = tiles * p.nsplit * p.nbatch;
-  const int w = xcd_order(blockIdx.x, G);
-  for (int u = w; u < units; u += G) {
-    const int id = u % tiles;
-    gemm_tile_body_wide(p, (id / ntn) * 256, (id % ntn) * 128, u / tiles, smem);
-  }
-}
 
 // work unit u = (batch * nsplit + split) * tiles + tile
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int KCH>
@@ -401,25 +249,6 @@ static int launch_layout(hipStream_t st, const TileP& p) {
   // layout: 6 operand reads per 5 MFMAs), so it is not in the list.
   const long units128 = (long)(p.M / 128) * (p.N / 128) * p.nsplit * p.nbatch;
   const bool big_ok = (p.M % 128) == 0 && (p.N % 128) == 0 && units128 >= 192;
-  if constexpr (A_KC && B_KC) {
-    static const bool wide = getenv("MMEGO_GEMM_WIDE") && atoi(getenv("MMEGO_GEMM_WIDE")) != 0;
-    if (wide && (p.M % 256) == 0 && (p.N % 128) == 0 && (p.kchunk % 32) == 0 &&
-        (long)(p.M / 256) * (p.N / 128) * p.nsplit * p.nbatch >= 512) {
-      static bool attr_wide = false;
-      const size_t lds = (size_t)(2 * (256 + 128) * 36) * sizeof(float);
-      if (!attr_wide) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_wide = true;
-      }
-      TileP q = p;
-      static const bool nostore = getenv("MMEGO_GEMM_NOSTORE") != nullptr;      // EXPERIMENT
-      if (nostore) q.relu = 99;
-      hipLaunchKernelGGL(gemm_tile_wide_kernel, dim3(256), dim3(512), lds, st, q);
-      hipError_t e = hipGetLastError();
-      return e == hipSuccess ? 0 : (int)e;
-    }
-  }
   if (big_ok) {
     // 2 workgroups per CU x 256 CUs.  MMEGO_GEMM_SLOTS=256 (A/B knob of scripts/bench_overlap.py): ONE workgroup per CU, its LDS
     // request padded past half a CU's LDS so that the dispatcher cannot put two on one CU -- at 204 VGPRs a pair of these
