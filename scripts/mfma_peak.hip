@@ -22,6 +22,34 @@ __global__ __launch_bounds__(256) void spin(float* out, int iters) {
       }
     }
     out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+  } else if (KIND == 3) {
+    // fp32 32x32x2 in the GEMM's own pattern: 2 x 2 accumulator tiles, operands a0/a1 x b0/b1 from a set of registers holding
+    // RANDOM-looking floats (hashed bits in [0.5, 2)), a different set every k-step -- register-only, but with the operand toggling
+    // of real data (r03: is the nominal peak reachable on real operands at all?)
+    float ra[8], rb[8];
+    for (int e = 0; e < 8; ++e) {
+      unsigned x = (threadIdx.x * 2654435761u) ^ (e * 0x9E3779B9u) ^ (blockIdx.x * 40503u);
+      x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+      ra[e] = __builtin_bit_cast(float, 0x3f000000u | (x & 0x00ffffffu));
+      rb[e] = __builtin_bit_cast(float, 0x3f000000u | ((x * 2246822519u) & 0x00ffffffu));
+    }
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[u], rb[u], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[u], rb[u + 1], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[u + 1], rb[u], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[u + 1], rb[u + 1], c3, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[u], ra[u], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[u], ra[u + 1], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[u + 1], ra[u], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(rb[u + 1], ra[u + 1], c3, 0, 0, 0);
+      }
+      // keep the accumulators bounded (random products would overflow): one cheap rescale per 32 MFMAs
+      if ((i & 15) == 15) { c0 *= 1e-3f; c1 *= 1e-3f; c2 *= 1e-3f; c3 *= 1e-3f; }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
   } else if (KIND == 2) {
     // bf16 32x32x16 with realistic (non-constant) operand bits: the data pattern moves the power draw and with it the clock
     u32x4 ua, ub;
@@ -86,6 +114,9 @@ int main() {
   // short (like one GEMM launch, ~0.3 ms) and long (2 CU-resident WGs, ~30 ms) runs
   run<0>("32x32x2 short", 256, 2000, 2.0 * 32 * 32 * 2, 32);
   run<0>("32x32x2 long ", 512, 100000, 2.0 * 32 * 32 * 2, 32);
+  run<3>("32x32x2 random operands short", 256, 2000, 2.0 * 32 * 32 * 2, 32);
+  run<3>("32x32x2 random operands long ", 512, 100000, 2.0 * 32 * 32 * 2, 32);
+  run<3>("32x32x2 random operands, 2 WGs/CU x 4 waves, ~0.5 ms", 512, 2000, 2.0 * 32 * 32 * 2, 32);
   run<1>("16x16x4 short", 256, 2000, 2.0 * 16 * 16 * 4, 64);
   run<1>("16x16x4 long ", 512, 100000, 2.0 * 16 * 16 * 4, 64);
   run<2>("bf16 32x32x16 short", 256, 2000, 2.0 * 32 * 32 * 16, 32);
