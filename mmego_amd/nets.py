@@ -711,37 +711,22 @@ class IMUNet(_NetBase):
             from .imu_train import ImuBridge
             self.flat()
             return ImuBridge.apply(self, _f32c(imu), *self._flat.params)
-        return self.forward_slow(self.forward_fast(imu))
-
-    def forward_fast(self, imu):
-        """First half of the eval-mode forward: fc1 + the rnn_fast BiLSTM stack over the S IMU samples of every frame (the
-        compute-bound half).  Returns the state forward_slow() finishes from; train_step.ConcurrentStages runs the second half
-        (pooling, the 64-row rnn_slow stack, head: a chain of small latency-bound launches) on the stage's side stream, beside
-        the next stage's projection products."""
         self.flat()
         ar = self.arena("eval")
         imu = _f32c(imu)
         B, T, S, Cin = imu.shape
         H = self.hidden_n
         Bn = B * T
+        dev = imu.device
         h = ar.get("fc1", (Bn * S, H))
         ops.linear(imu.view(Bn * S, Cin), self.fc1.weight, self.fc1.bias, h, relu=True)
         if self.precision not in ("fp32", "bf16"):
             raise ValueError("IMUNet.precision must be 'fp32' or 'bf16', got %r" % (self.precision,))
-        if self.precision == "bf16":
+        bf16 = self.precision == "bf16"
+        if bf16:
             fast = blocks.lstm_steps_forward_bf16(ar, "fast", self.rnn_fast, h, Bn, S)
         else:
             fast = blocks.lstm_steps_forward(ar, "fast", self.rnn_fast, h, Bn, S)          # [Bn*S, 2H]
-        return fast, B, T, S
-
-    def forward_slow(self, state):
-        """Second half: attention pooling over the samples, rnn_slow over the T frames, fc2 + 6-D head."""
-        fast, B, T, S = state
-        ar = self.arena("eval")
-        H = self.hidden_n
-        Bn = B * T
-        dev = fast.device
-        bf16 = self.precision == "bf16"
         pooled = ar.get("pooled", (Bn, 2 * H))
         attn = ar.get("attn", (Bn, S))
         blocks.attn_pool_forward(fast, self.attn, Bn, S, 2 * H, pooled, attn)

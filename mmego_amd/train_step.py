@@ -387,23 +387,10 @@ class ConcurrentStages:
                     # U+L step); MMEGO_ALL_IMU_TWO_CHAINS=0 restores one launch per timestep beside a running tail
                     if os.environ.get("MMEGO_ALL_IMU_TWO_CHAINS", "1") != "0" and os.environ.get("MMEGO_FIRST_IMU_TWO_CHAINS", "1") != "0":
                         alone = True
-                    # MMEGO_SPLIT_IMU=1: only the compute-bound half of a side-stream stage's forward (fc1 + rnn_fast) stays on the
-                    # launching stream; its latency-bound second half (pooling, the 64-row rnn_slow chain, head) moves to the stage's
-                    # side stream in front of the body, so the next stage's projection products start that much earlier
-                    split = i > 0 and os.environ.get("MMEGO_SPLIT_IMU", "0") == "1" and not st.imu.training
                     with torch.no_grad(), blocks.two_chains(alone):
                         # (the forward's own output tensors serve as the stage's head pose: they stay referenced -- and, under
                         # capture, reserved in the graph's pool -- until every branch has been enqueued; no copies)
-                        if split:
-                            half = st.imu.forward_fast(st.static["imu"])
-                        else:
-                            st.pose = st.imu(st.static["imu"])
-                    if split:
-                        streams[i].wait_stream(main)
-                        with torch.cuda.stream(streams[i]), torch.no_grad():
-                            st.pose = st.imu.forward_slow(half)
-                            st._body()
-                        continue
+                        st.pose = st.imu(st.static["imu"])
                 if i > 0:
                     streams[i].wait_stream(main)
                     with torch.cuda.stream(streams[i]):
