@@ -96,7 +96,9 @@ def _emulate_bilstm(x, W, H, Bn, T):
 
 @pytest.mark.parametrize("Bn,T,H,In,fused", [(200, 5, 128, 64, False), (2100, 3, 64, 128, False), (64, 4, 512, 1024, False),
                                                (200, 3, 256, 64, False), (2050, 2, 256, 64, False),
-                                               (2100, 3, 64, 128, True), (2050, 2, 256, 64, True), (130, 4, 128, 192, True)])
+                                               (2100, 3, 64, 128, True), (2050, 2, 256, 64, True), (130, 4, 128, 192, True),
+                                               # multiples of 256 rows with H % 64 == 0: the 256 x 256-tile LDS-DMA form of the fused step
+                                               (512, 3, 64, 128, True), (256, 4, 128, 192, True), (768, 2, 256, 64, True)])
 def test_bilstm_bf16_forward_matches_emulation(Bn, T, H, In, fused, monkeypatch):
     """fused = the large-batch form (projection folded into the step kernel; default from 2049 rows), forced on or off here."""
     from mmego_amd import blocks, ops
