@@ -754,29 +754,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 / WR, 4 /
   }
 }
 
-// ---- 256 x 256 tile form of the fused step (r03; Bn % 256 == 0, H % 64 == 0) ----------------------------------------------
-// The 128-row kernel above stops at MFMA busy 0.44: at a 128 x 128 workgroup tile every MFMA needs 64 B/clk/CU through the
-// vector-memory path at the full matrix rate -- that path's limit -- and its LDS array carries the weight tile's writes and 1
-// ds_read_b128 per MFMA.  Here a workgroup owns 256 rows x 64 hidden units x 4 gates (256 x 256 outputs, half the operand bytes
-// per MFMA through memory AND through LDS), eight waves as 4 row groups x 2 unit groups, wave tile 64 rows x 32 units x 4 gates =
+// ---- 256 x 256 tile form of the fused step (r03; both directions, Bn % 256 == 0, H % 64 == 0, every K segment % 64 == 0) ------
+// A workgroup owns 256 rows x 64 hidden units x 4 gates (256 x 256 outputs: half the operand bytes per MFMA of the 128-row kernel
+// above, through memory and through LDS), eight waves as 4 row groups x 2 unit groups, wave tile 64 rows x 32 units x 4 gates =
 // 2 x 4 accumulator tiles (6 fragment reads per 8 MFMAs).  BOTH operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4):
 // they are fragment-major in memory, so a 1-KB piece (one MFMA operand of one 32-row block and one 16-k step) is one
 // wave-instruction, lands in LDS as it lies and is read back lane-linear (conflict-free, no padding, no VGPR staging, no
-// ds_write).  64-k chunks (64 pieces of 1 KB: 8 per wave) in a ring of NST stages of 64 KB; one barrier per chunk.
+// ds_write).  64-k chunks (64 pieces of 1 KB: 8 per wave) in a ring of two 64-KB stages; one barrier per chunk.
 // Piece q of a stage: q < 32: activation rows (q >> 2) of the workgroup's 8 row blocks, step q & 3; q >= 32: weight rows
 // [unit block (q - 32) >> 4][gate ((q - 32) >> 2) & 3], step q & 3.
+// The kernel is PERSISTENT (one 160-KB workgroup per CU walks its share of the tiles, XCD-contiguous): the c tile of a workgroup
+// travels by LDS-DMA into the ring stage that is free during the LAST chunk (64 KB: exactly one stage), the first operand chunk
+// of the NEXT tile is requested before the cell update starts, and the update's stores drain under that tile's product loop
+// (vmcnt counts in issue order: waiting for all but the youngest stores covers the requests issued before them); h_t in bf16
+// leaves as whole fragment pieces (16-byte stores) instead of two-byte stores.
+// Measured at Bn = 32768, H = 512 (scripts/bench_fused_step.py; the 128-row kernel in brackets): K = 1024 348-367 us (373-380),
+// K = 1536 464-482 us (501-505).  Where the time goes (diagnostic builds, in git history): the product loop takes 106-118 us per
+// 512 of K however the requests are issued (in one burst behind the barrier, one between every four MFMAs, 2 / 3 / 4 ring stages,
+// four waves x two workgroups per CU), 76 us without them -- the LDS-DMA path delivers ~20 B/clk/CU here -- and the cell update
+// costs 82 us per launch that do not hide under the product loops (60 us of stores at 5-6 TB/s, 18 us of cell arithmetic); PMC:
+// 536 MB fetched per launch against 857 MB for the 128-row kernel, MFMA busy 0.33 at 2.23 GHz against 0.43 at 1.82 GHz -- the
+// chip gives clock back as the loop gets denser, so the two kernels deliver nearly the same MFMA rate.
 #define GLDS16B(gptr, lptr)                                                                                 \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-// The kernel is PERSISTENT (one workgroup per CU walks its share of the tiles): with one 128-KB workgroup per CU and every tile
-// taking the same time, all CUs would otherwise run their HBM-bound cell updates (c in, c / h out: 0.47 GB per launch) at the
-// same moment, between two compute phases, instead of under them -- measured 143 us of a 363-us launch.  So the c tile of a
-// workgroup travels by LDS-DMA into the ring stage that is free during the LAST chunk (64 KB: exactly one stage), the first
-// operand chunk of the NEXT tile is requested before the cell update starts, and the update's stores drain under that tile's
-// product loop (vmcnt counts in issue order: waiting for all but the youngest stores covers the DMAs issued before them).
 template <bool HOUT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_bf16_fused256_kernel(FusedStepP p, int ntiles, int stagger, int dbg) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_bf16_fused256_kernel(FusedStepP p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   constexpr int STAGE = 64 * 1024;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -796,29 +800,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // this wave's 8 pieces of a chunk: waves 0..3 carry the activation pieces, waves 4..7 the weight pieces
   const int q0 = w * 8;
-  // a chunk's pieces are requested one at a time, BETWEEN the MFMAs of the chunk before (issue_piece): requested in one burst
-  // behind the barrier, the eight waves' 64 KB queue up in the CU's 64-B/clk vector-memory path and every wave sits in its
-  // issue slot for ~1000 cycles with the matrix pipe idle (measured: 118 us per 512 of K against 76 us without the requests)
-  const unsigned char* pg0 = nullptr;          // this lane's address of the wave's first piece of the chunk being requested
-  long pstride = 0;
-  unsigned char* pst = nullptr;
-  auto issue_setup = [&](int tile, int g, int stage) {
+  auto issue = [&](int tile, int g, int stage) {
     const int d = tile >= nb, rem = tile - d * nb, jb = rem % njb, rbw = rem / njb;
     int s0 = g * 4, seg = 0, S = S0;
     if (s0 >= S0) { s0 -= S0; seg = 1; S = S1; if (s0 >= S1) { s0 -= S1; seg = 2; S = S2; } }
     const unsigned char* ab = reinterpret_cast<const unsigned char*>(p.a[seg][d]);
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w[seg][d]);
+    unsigned char* st = smem256 + stage * STAGE;
     // piece q0 + i: consecutive pieces of a wave differ by one step (1 KB) inside a row block / gate, by S KB between them
     const long blk0 = q0 < 32 ? (long)(rbw * 8 + (q0 >> 2)) : (long)((jb * 2 + ((q0 - 32) >> 4)) * 4 + (((q0 - 32) >> 2) & 3));
-    pg0 = (q0 < 32 ? ab : wb) + ((blk0 * S + s0) << 10) + lane * 16;
-    pstride = (long)S << 10;
-    pst = smem256 + stage * STAGE + (q0 << 10);
-  };
-#define F256_PIECE(i) GLDS16B(pg0 + ((i) >> 2) * pstride + (((i) & 3) << 10), pst + ((i) << 10))
-  auto issue = [&](int tile, int g, int stage) {
-    issue_setup(tile, g, stage);
+    const unsigned char* g0 = (q0 < 32 ? ab : wb) + ((blk0 * S + s0) << 10) + lane * 16;
+    const long blk_stride = (long)S << 10;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) F256_PIECE(i);
+    for (int i = 0; i < 8; ++i) GLDS16B(g0 + (i >> 2) * blk_stride + ((i & 3) << 10), st + ((q0 + i) << 10));
   };
   // the c tile [256 rows][64 units] fp32 of a workgroup as 64 pieces of 4 rows (lane l: row 4 piece + l / 16, 16 B at column 4 (l % 16))
   auto issue_c = [&](int tile, int stage) {
@@ -845,12 +839,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][mi]),                       \
                                                              __builtin_bit_cast(bf16x8, fb[buf][n]), acc[mi][n], 0, 0, 0);  \
   } while (0)
-#define F256_MMH(buf, mi)                                                                                                   \
-  do {                                                                                                                      \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                           \
-      acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][mi]),                         \
-                                                           __builtin_bit_cast(bf16x8, fb[buf][n]), acc[mi][n], 0, 0, 0);    \
-  } while (0)
 #define F256_BARRIER()                       \
   do {                                       \
     asm volatile("" ::: "memory");           \
@@ -859,9 +847,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   } while (0)
 
   int stage = 0;                               // ring stage of the chunk about to be multiplied
-  // every tile takes the same time, so without this all CUs would sit in their (HBM-bound) cell updates at the same moment:
-  // four start phases spread them over a tile time
-  for (int i = ((blockIdx.x >> 3) & 3) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
   if (tile_of(0) < ntiles) issue(tile_of(0), 0, 0);
   for (int it = 0; it < niter; ++it) {
     const int tile = tile_of(it);
@@ -881,39 +866,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (c == 0 && it > 0) { if (HOUT) __builtin_amdgcn_s_waitcnt(0x0F70 | 15 | (3 << 14)); else __builtin_amdgcn_s_waitcnt(0x0F70 | 4 | (2 << 14)); }   // vmcnt(63) / vmcnt(36)
       else __builtin_amdgcn_s_waitcnt(0x0F70);                                        // vmcnt(0)
       F256_BARRIER();                          // everyone's pieces of chunk c are in LDS; everyone has finished the other stage
-      const bool more = c + 1 < NC && !(dbg & 16);
-      const bool paced = more && !(dbg & 128);
-      if (more) { if (paced) issue_setup(tile, c + 1, stage ^ 1); else issue(tile, (dbg & 64) ? 0 : c + 1, stage ^ 1); }
-      else if (c + 1 >= NC && !first) issue_c(tile, stage ^ 1);
+      if (c + 1 < NC) issue(tile, c + 1, stage ^ 1);
+      else if (!first) issue_c(tile, stage ^ 1);
       const unsigned char* st = smem256 + stage * STAGE;
       F256_RD(0, st, 0);
       F256_RD(1, st, 1);
       __builtin_amdgcn_sched_barrier(0);
-      F256_MMH(0, 0);
+      F256_MM(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (paced) F256_PIECE(0);
-      __builtin_amdgcn_sched_barrier(0);
-      F256_MMH(0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (paced) F256_PIECE(1);
       F256_RD(0, st, 2);
       __builtin_amdgcn_sched_barrier(0);
-      F256_MMH(1, 0);
+      F256_MM(1);
       __builtin_amdgcn_sched_barrier(0);
-      if (paced) { F256_PIECE(2); F256_PIECE(3); }
-      __builtin_amdgcn_sched_barrier(0);
-      F256_MMH(1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (paced) F256_PIECE(4);
       F256_RD(1, st, 3);
       __builtin_amdgcn_sched_barrier(0);
-      F256_MMH(0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (paced) { F256_PIECE(5); F256_PIECE(6); }
-      __builtin_amdgcn_sched_barrier(0);
-      F256_MMH(0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (paced) F256_PIECE(7);
+      F256_MM(0);
       __builtin_amdgcn_sched_barrier(0);
       F256_MM(1);
       __builtin_amdgcn_sched_barrier(0);
@@ -951,24 +918,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float cprev = first ? 0.f : cv[mi][i];
-        if (dbg & 1) { cn[i] = acc[mi][0][i] + acc[mi][1][i] + cprev; hn[i] = acc[mi][2][i] + acc[mi][3][i]; continue; }
         const float gi = bf_sigmoid(acc[mi][0][i] + bv[0]), gf = bf_sigmoid(acc[mi][1][i] + bv[1]);
         const float gg = bf_tanh(acc[mi][2][i] + bv[2]), go = bf_sigmoid(acc[mi][3][i] + bv[3]);
         cn[i] = gf * cprev + gi * gg;
         hn[i] = go * bf_tanh(cn[i]);
       }
-      if (dbg & 8) { if (cn[0] + hn[3] + cn[7] + hn[12] == 123.456f) p.o.c[d][0] = 1.f; continue; }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = rbw * 256 + lrow + 8 * (i >> 2) + (i & 3);
-        if (!(dbg & 4)) p.o.c[d][(long)row * H + j] = cn[i];
-        if (HOUT && !(dbg & 4)) p.o.hout[d][(long)row * p.o.hos + j] = hn[i];
+        p.o.c[d][(long)row * H + j] = cn[i];
+        if (HOUT) p.o.hout[d][(long)row * p.o.hos + j] = hn[i];
         // piece (mi, fr >> 4) of the wave's four; inside it [k half][row % 32][8 k]
         *reinterpret_cast<bf16_t*>(hst + ((((mi * 2 + (fr >> 4)) * 64 + ((fr >> 3) & 1) * 32 + 4 * fh + 8 * (i >> 2) + (i & 3)) * 8 + (fr & 7)) << 1)) =
             (bf16_t)f2bf_bits(hn[i]);
       }
     }
-    if (!(dbg & 2)) {
+    {
       bf16_t* hf = p.o.hfrag[d];
 #pragma unroll
       for (int pc = 0; pc < 4; ++pc) {                    // piece pc = (row block pc >> 1, 16-k group pc & 1) of this wave
@@ -982,180 +947,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 #undef F256_RD
 #undef F256_MM
-#undef F256_MMH
-#undef F256_PIECE
 #undef F256_BARRIER
-}
-
-// ---- generic LDS-DMA tile form: RG x CG waves, wave tile 64 rows x 32 units x 4 gates, KC-k chunks, NST-stage ring ---------
-// <2, 2, 32, 3>: 128 rows x 64 units per workgroup, four waves, 72 KB of LDS, <= 256 VGPRs: TWO workgroups per CU with
-// independent barriers and tiles -- one's cell update (VALU + memory bound: ~200 issue cycles per element) runs under the
-// other's product loop, which a single 8-wave workgroup per CU cannot do.
-template <int RG, int CG, int KC, int NST, bool HOUT, bool PACED = false>
-__global__ __launch_bounds__(64 * RG * CG) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_bf16_tile_kernel(FusedStepP p, int ntiles, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smemt[];
-  constexpr int NW = RG * CG, SPC = KC / 16;
-  constexpr int NA = 2 * RG * SPC, NP = (2 * RG + 4 * CG) * SPC, PPW = NP / NW;
-  constexpr int STAGE = NP * 1024;
-  static_assert(NP % NW == 0, "pieces per chunk must divide over the waves");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rg = w / CG, cg = w % CG;
-  const int H = p.o.H;
-  const int njb = H / (32 * CG), nb = ntiles >> 1;
-  const int id = bf_xcd_order(blockIdx.x, ntiles);
-  const int d = id >= nb, rem = id - d * nb, jb = rem % njb, rbw = rem / njb;
-  const int S0 = p.S[0], S1 = p.nseg > 1 ? p.S[1] : 0, S2 = p.nseg > 2 ? p.S[2] : 0;
-  const int NC = (S0 + S1 + S2) / SPC;
-  const bool first = p.o.first != 0;
-
-  const unsigned char* pg[PPW];
-  unsigned char* pst = nullptr;
-  auto issue_setup = [&](int g, int stage) {
-    int s0 = g * SPC, seg = 0, S = S0;
-    if (s0 >= S0) { s0 -= S0; seg = 1; S = S1; if (s0 >= S1) { s0 -= S1; seg = 2; S = S2; } }
-    const unsigned char* ab = reinterpret_cast<const unsigned char*>(p.a[seg][d]);
-    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w[seg][d]);
-    pst = smemt + stage * STAGE;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int q = w * PPW + i;
-      const unsigned char* g_;
-      if (q < NA) g_ = ab + ((((long)(rbw * 2 * RG + q / SPC)) * S + s0 + q % SPC) << 10);
-      else g_ = wb + ((((long)(jb * CG * 4 + (q - NA) / SPC)) * S + s0 + (q - NA) % SPC) << 10);
-      pg[i] = g_ + lane * 16;
-    }
-  };
-#define FT_PIECE(i) GLDS16B(pg[i], pst + ((w * PPW + (i)) << 10))
-  auto issue = [&](int g, int stage) {
-    issue_setup(g, stage);
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) FT_PIECE(i);
-  };
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mi][n][i] = 0.f;
-#pragma unroll
-  for (int g = 0; g < NST - 1; ++g)
-    if (g < NC) issue(g, g);
-  u32x4 fa[2][2], fb[2][4];
-#define FT_RD(buf, st, step)                                                                                                \
-  do {                                                                                                                      \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                                        \
-      fa[buf][mi] = *reinterpret_cast<const u32x4*>((st) + (((2 * rg + mi) * SPC + (step)) << 10) + lane * 16);             \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                           \
-      fb[buf][n] = *reinterpret_cast<const u32x4*>((st) + ((NA + (cg * 4 + n) * SPC + (step)) << 10) + lane * 16);          \
-  } while (0)
-#define FT_MM(buf)                                                                                                          \
-  do {                                                                                                                      \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                                        \
-      _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                         \
-        acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][mi]),                       \
-                                                             __builtin_bit_cast(bf16x8, fb[buf][n]), acc[mi][n], 0, 0, 0);  \
-  } while (0)
-#define FT_MMH(buf, mi)                                                                                                     \
-  do {                                                                                                                      \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                           \
-      acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][mi]),                         \
-                                                           __builtin_bit_cast(bf16x8, fb[buf][n]), acc[mi][n], 0, 0, 0);    \
-  } while (0)
-  int stage = 0;
-  for (int c = 0; c < NC; ++c) {
-    // this wave's pieces of chunk c have landed; up to NST - 2 younger chunks (PPW pieces each) may still be in flight
-    const int younger = NC - 1 - c < NST - 2 ? NC - 1 - c : NST - 2;
-    if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PPW) & 15) | (((2 * PPW) >> 4) << 14));
-    else if (younger == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (PPW & 15) | ((PPW >> 4) << 14));
-    else __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // everyone's pieces of chunk c are in LDS; everyone has finished chunk c-1's stage
-    asm volatile("" ::: "memory");
-    const bool more = c + NST - 1 < NC;
-    const unsigned char* st = smemt + stage * STAGE;
-    if (PACED) {
-      static_assert(!PACED || (SPC == 2 && PPW == 4), "paced form: two steps and four pieces per wave and chunk");
-      if (more) issue_setup(c + NST - 1, stage == 0 ? NST - 1 : stage - 1);
-      FT_RD(0, st, 0);
-      FT_RD(1, st, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      FT_MMH(0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) FT_PIECE(0);
-      __builtin_amdgcn_sched_barrier(0);
-      FT_MMH(0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) FT_PIECE(1);
-      __builtin_amdgcn_sched_barrier(0);
-      FT_MMH(1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) FT_PIECE(2);
-      __builtin_amdgcn_sched_barrier(0);
-      FT_MMH(1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) FT_PIECE(3);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-    if (more) issue(c + NST - 1, stage == 0 ? NST - 1 : stage - 1);
-    FT_RD(0, st, 0);
-#pragma unroll
-    for (int sl = 0; sl < SPC; ++sl) {
-      if (sl + 1 < SPC) FT_RD((sl + 1) & 1, st, sl + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (sl & 1) FT_MM(1); else FT_MM(0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    }
-    stage = stage + 1 == NST ? 0 : stage + 1;
-  }
-#undef FT_RD
-#undef FT_MM
-#undef FT_MMH
-#undef FT_PIECE
-
-  const int fr = lane & 31, fh = lane >> 5;
-  const int j = (jb * CG + cg) * 32 + fr;
-  if (dbg & 8) {
-    float sum = 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) sum += acc[mi][n][0] + acc[mi][n][7] + acc[mi][n][15];
-    if (sum == 123.456f) p.o.c[d][0] = 1.f;
-    return;
-  }
-  float bv[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) bv[n] = p.bias[(d * 4 + n) * H + j];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int rbase = rbw * 64 * RG + rg * 64 + mi * 32 + 4 * fh;
-    float cn[16], hn[16];
-    if (!first) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) cn[i] = p.o.c[d][(long)(rbase + 8 * (i >> 2) + (i & 3)) * H + j];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(cn[i]));
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float cprev = first ? 0.f : cn[i];
-      const float gi = bf_sigmoid(acc[mi][0][i] + bv[0]), gf = bf_sigmoid(acc[mi][1][i] + bv[1]);
-      const float gg = bf_tanh(acc[mi][2][i] + bv[2]), go = bf_sigmoid(acc[mi][3][i] + bv[3]);
-      cn[i] = gf * cprev + gi * gg;
-      hn[i] = go * bf_tanh(cn[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = rbase + 8 * (i >> 2) + (i & 3);
-      p.o.c[d][(long)row * H + j] = cn[i];
-      if (HOUT) p.o.hout[d][(long)row * p.o.hos + j] = hn[i];
-      p.o.hfrag[d][frag_off(row, j, H)] = (bf16_t)f2bf_bits(hn[i]);
-    }
-  }
 }
 
 extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H, int first, int nseg,
@@ -1193,40 +985,11 @@ extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H,
   // effect on that figure: the weight tile double-buffered in LDS (one barrier per chunk), L2 super-tiles of 8 x 2, 16 x 1, 2 x 8
   // (hidden x row blocks) instead of 4 x 4.
   static const int wr2 = getenv("MMEGO_BF16_FUSED_WR") ? atoi(getenv("MMEGO_BF16_FUSED_WR")) == 2 : 0;
-  // 256 x 256 tiles (LDS-DMA operands, eight waves) where the shape allows; MMEGO_BF16_FUSED_256=0 keeps the 128-row kernel,
-  // =3 takes the three-stage ring (192 KB: does not fit -- kept out), default 2 stages
-  static const int t256 = getenv("MMEGO_BF16_FUSED_256") ? atoi(getenv("MMEGO_BF16_FUSED_256")) : 2;
+  // 256 x 256 tiles (persistent, LDS-DMA operands, eight waves) where the shape allows; MMEGO_BF16_FUSED_256=0 keeps the 128-row kernel
+  static const int t256 = getenv("MMEGO_BF16_FUSED_256") ? atoi(getenv("MMEGO_BF16_FUSED_256")) : 1;
   bool k64 = true;
   for (int q = 0; q < p.nseg; ++q) k64 = k64 && p.S[q] % 4 == 0;
-  static const int dbgt = getenv("MMEGO_BF16_FUSED_DBG") ? atoi(getenv("MMEGO_BF16_FUSED_DBG")) : 0;
-  if ((t256 == 5 || t256 == 6 || t256 == 7) && ndir == 2 && Bn % 256 == 0 && H % 64 == 0) {
-    const int lds = (t256 == 6 ? 4 : 3) * 32 * 1024;
-    const int ntiles = 2 * (H / 64) * (Bn / 256);
-#define TL(NST_, P_)                                                                                                          \
-  do {                                                                                                                        \
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_step_bf16_tile_kernel<4, 2, 32, NST_, true, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-    if (e != hipSuccess) return (int)e;                                                                                       \
-    lstm_step_bf16_tile_kernel<4, 2, 32, NST_, true, P_><<<ntiles, 512, lds, (hipStream_t)stream>>>(p, ntiles, dbgt);           \
-  } while (0)
-    MMEGO_REQUIRE(hout0 && hout1);
-    if (t256 == 5) TL(3, true);
-    else if (t256 == 6) TL(4, true);
-    else TL(3, false);
-#undef TL
-  } else if (t256 == 4 && ndir == 2 && Bn % 128 == 0 && H % 64 == 0) {      // 128 x 256 tiles, four waves, two workgroups per CU
-    constexpr int lds = 3 * 24 * 1024;
-    static bool attr_set4 = false;
-    if (!attr_set4) {
-      hipError_t e = hipFuncSetAttribute((const void*)lstm_step_bf16_tile_kernel<2, 2, 32, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lstm_step_bf16_tile_kernel<2, 2, 32, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return (int)e;
-      attr_set4 = true;
-    }
-    MMEGO_REQUIRE((hout0 == nullptr) == (hout1 == nullptr));
-    const int ntiles = 2 * (H / 64) * (Bn / 128);
-    if (hout0) lstm_step_bf16_tile_kernel<2, 2, 32, 3, true><<<ntiles, 256, lds, (hipStream_t)stream>>>(p, ntiles, dbgt);
-    else lstm_step_bf16_tile_kernel<2, 2, 32, 3, false><<<ntiles, 256, lds, (hipStream_t)stream>>>(p, ntiles, dbgt);
-  } else if (t256 && ndir == 2 && Bn % 256 == 0 && H % 64 == 0 && k64) {
+  if (t256 && ndir == 2 && Bn % 256 == 0 && H % 64 == 0 && k64) {
     constexpr int lds = 2 * 64 * 1024 + 8 * 4096;      // two ring stages + 4 KB per wave for the h_t fragments
     static bool attr_set = false;
     if (!attr_set) {
@@ -1239,10 +1002,8 @@ extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H,
     const int ntiles = 2 * (H / 64) * (Bn / 256);
     static const int maxwg = getenv("MMEGO_BF16_FUSED_WGS") ? atoi(getenv("MMEGO_BF16_FUSED_WGS")) : 256;
     dim3 grid(ntiles < maxwg ? ntiles : maxwg, 1, 1);
-    static const int stagger = getenv("MMEGO_BF16_FUSED_STAGGER") ? atoi(getenv("MMEGO_BF16_FUSED_STAGGER")) : 0;
-    static const int dbg = getenv("MMEGO_BF16_FUSED_DBG") ? atoi(getenv("MMEGO_BF16_FUSED_DBG")) : 0;
-    if (hout0) lstm_step_bf16_fused256_kernel<true><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles, stagger, dbg);
-    else lstm_step_bf16_fused256_kernel<false><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles, stagger, dbg);
+    if (hout0) lstm_step_bf16_fused256_kernel<true><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles);
+    else lstm_step_bf16_fused256_kernel<false><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles);
   } else if (wr2) {
     dim3 grid(H / 32, cdiv(Bn, 256), ndir);
     lstm_step_bf16_fused_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(p);
