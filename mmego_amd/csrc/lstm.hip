@@ -11,8 +11,6 @@
 //                     Lower_Net (Upper_Net.py:333, Lower_Net.py:91): batch rows are independent through
 //                     the recurrence, so a workgroup keeps W_hh (64 KB) in LDS, 16 rows of h in LDS and c
 //                     in registers and walks all T steps with no inter-workgroup traffic.
-#include <stdlib.h>
-
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -201,159 +199,6 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
   }
 }
 
-// ---- eight-wave form of lstm64_fwd_kernel (r03) ---------------------------------------------------------------------------
-// A step of the four-wave kernel is a serial chain -- 64 MFMAs per wave (2048 cycles of matrix pipe), then the gate arithmetic of
-// four elements per lane -- on a workgroup that owns a whole CU.  Here the K = 64 reduction is cut in two: wave (ub, kh) multiplies
-// h[:, 32 kh .. 32 kh + 31] into the four gate tiles of units 16 ub .. 16 ub + 15 (32 MFMAs, 32 W_hh operand registers per lane),
-// the two k halves swap HALF of their partial tiles through LDS (each wave keeps two of a lane's four rows and gets the other
-// wave's partial sums of those) and every wave finishes two elements per lane instead of four: the cell update is halved as well.
-// Sum order of a gate pre-activation: (k half 0) + (k half 1), each half in ascending k steps -- fixed, the same on both waves.
-template <bool FULL, bool STASH, bool DROP>
-__global__ __launch_bounds__(512) void lstm64_fwd8_kernel(Lstm64P p) {
-  __shared__ __attribute__((aligned(16))) float hs[64 * 16];             // h_{t-1}: [64 k][16 rows]
-  __shared__ __attribute__((aligned(16))) float xch[8][4][2][64];        // [wave][gate][row pair slot][lane]: partial sums handed over
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ub = wave & 3, kh = wave >> 2;
-  const int d = blockIdx.y, r0 = blockIdx.x * 16;
-  const int B = p.B, T = p.T;
-  const float* W = p.whh[d];
-  const int fr = lane & 15, fq = lane >> 4;
-  const int j = ub * 16 + fr;          // hidden unit of this lane
-  const int rsel = 2 * kh;             // this wave finishes rows 4 fq + rsel, 4 fq + rsel + 1 of the tile
-  float creg[2], hreg[2], bh[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) bh[g] = p.bhh[d] ? p.bhh[d][g * 64 + j] : 0.f;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = r0 + fq * 4 + rsel + q;
-    const bool ok = row < B;
-    creg[q] = (ok && p.c0[d]) ? p.c0[d][row * 64 + j] : 0.f;
-    hreg[q] = (ok && p.h0[d]) ? p.h0[d][row * 64 + j] : 0.f;
-    hs[j * 16 + fq * 4 + rsel + q] = hreg[q];
-  }
-  __syncthreads();
-  // this lane's W_hh operands: at MFMA step s lane quad fq takes k = 32 kh + 8 fq + s (h and W_hh alike), so the eight values of a
-  // gate are two contiguous 16-B loads
-  float wreg[8][4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float* wrow = W + (g * 64 + j) * 64 + 32 * kh + 8 * fq;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(wrow + 4 * q);
-      wreg[4 * q + 0][g] = v.x; wreg[4 * q + 1][g] = v.y; wreg[4 * q + 2][g] = v.z; wreg[4 * q + 3][g] = v.w;
-    }
-  }
-  float xp[4][2], xpn[4][2];
-  constexpr bool stash = STASH, keep_h = STASH, drop = DROP;
-  const unsigned dkey = drop ? dropout_key(p.seed_ctr[0], p.salt) : 0u;
-  const float keep_scale = drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-  const int t_first = d == 0 ? 0 : T - 1;
-  const long dir = d == 0 ? 1 : -1;
-  l64_gcptr xq[2];
-  l64_gptr oq[2], hq[2], gq[2], cq[2];
-  bool live[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = r0 + fq * 4 + rsel + q;
-    live[q] = FULL || row < B;
-    const long rt = (long)(live[q] ? row : 0) * T + t_first;
-    xq[q] = (l64_gcptr)(p.xproj[d] + rt * p.xs + j);
-    oq[q] = (l64_gptr)(p.out + rt * p.os + d * 64 + j);
-    hq[q] = keep_h ? (l64_gptr)(p.hprev[d] + rt * 64 + j) : (l64_gptr)nullptr;
-    const long tr = (long)t_first * B + (live[q] ? row : 0);
-    gq[q] = stash ? (l64_gptr)(p.gates[d] + tr * 256 + 4 * j) : (l64_gptr)nullptr;
-    cq[q] = stash ? (l64_gptr)(p.cst[d] + tr * 64 + j) : (l64_gptr)nullptr;
-  }
-  const long xstep = dir * p.xs, ostep = dir * p.os, hstep = dir * 64, gstep = dir * (long)B * 256, cstep = dir * (long)B * 64;
-#define L64_LOAD_XP8(DST)                                                                          \
-  do {                                                                                             \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g) DST[g][q] = (FULL || live[q]) ? xq[q][g * 64] : 0.f; \
-      xq[q] += xstep;                                                                              \
-    }                                                                                              \
-  } while (0)
-  L64_LOAD_XP8(xp);
-  const int partner = wave ^ 4;
-  for (int s = 0; s < T; ++s) {
-    if (s + 1 >= T) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) xq[q] -= xstep;
-    }
-    L64_LOAD_XP8(xpn);
-    if (keep_h) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (FULL || live[q]) *hq[q] = hreg[q];
-        hq[q] += hstep;
-      }
-    }
-    f32x4 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float hk[8];
-#pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4) hk[k4] = hs[(32 * kh + 8 * fq + k4) * 16 + fr];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k4 = 0; k4 < 8; ++k4) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hk[k4], wreg[k4][g], acc[g], 0, 0, 0);
-    }
-    // hand the partner wave (same units, other k half) the partial sums of ITS two rows
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) xch[wave][g][q][lane] = acc[g][(rsel ^ 2) + q];
-    L64_LDS_BARRIER();  // partial sums are there; everyone has finished reading hs for this step
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float pre[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float mine = acc[g][rsel + q], theirs = xch[partner][g][q][lane];
-        pre[g] = (kh == 0 ? mine + theirs : theirs + mine) + (xp[g][q] + bh[g]);       // (k half 0) + (k half 1) on both waves
-      }
-      const float gi = l64_sigmoid(pre[0]), gf = l64_sigmoid(pre[1]), gg = l64_tanh(pre[2]), go = l64_sigmoid(pre[3]);
-      const float cn = gf * creg[q] + gi * gg;
-      const float hn = go * l64_tanh(cn);
-      creg[q] = cn;
-      hreg[q] = hn;
-      hs[j * 16 + fq * 4 + rsel + q] = hn;
-      if (FULL || live[q]) {
-        *oq[q] = hn;
-        if (drop) {
-          const long off = oq[q] - (l64_gptr)p.out;
-          const float mk = dropout_keep(dkey, (unsigned)off, p.drop_p) ? keep_scale : 0.f;
-          p.drop_mask[off] = mk;
-          p.drop_y[off] = hn * mk;
-        }
-        if (stash) {
-          *(l64_gptr4)gq[q] = (l64_f4){gi, gf, gg, go};
-          *cq[q] = cn;
-        }
-      }
-      oq[q] += ostep;
-      if (stash) { gq[q] += gstep; cq[q] += cstep; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) xp[g][q] = xpn[g][q];
-    L64_LDS_BARRIER();  // new h is in hs; the exchange slots may be written again
-  }
-#undef L64_LOAD_XP8
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = r0 + fq * 4 + rsel + q;
-    if (row < B) {
-      if (p.hn[d]) p.hn[d][row * 64 + j] = hreg[q];
-      if (p.cn[d]) p.cn[d][row * 64 + j] = creg[q];
-    }
-  }
-}
-
 extern "C" int mmego_lstm64_forward(void* stream, int B, int T, const float* xproj0, const float* xproj1, long xs,
                                     const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
                                     const float* h0_0, const float* h0_1, const float* c0_0, const float* c0_1, float* out,
@@ -391,25 +236,6 @@ extern "C" int mmego_lstm64_forward(void* stream, int B, int T, const float* xpr
     }                                                                                                                 \
     hipLaunchKernelGGL((lstm64_fwd_kernel<F_, S_, D_>), dim3(cdiv(B, 16), 2), dim3(256), lds, (hipStream_t)stream, p); \
   } while (0)
-  static const int waves8 = getenv("MMEGO_LSTM64_WAVES") ? atoi(getenv("MMEGO_LSTM64_WAVES")) == 8 : 1;
-#define L64_FWD8_LAUNCH(F_, S_, D_) \
-  hipLaunchKernelGGL((lstm64_fwd8_kernel<F_, S_, D_>), dim3(cdiv(B, 16), 2), dim3(512), 0, (hipStream_t)stream, p)
-  if (waves8) {
-    if (full) {
-      if (st_ && dr) L64_FWD8_LAUNCH(true, true, true);
-      else if (st_) L64_FWD8_LAUNCH(true, true, false);
-      else if (dr) L64_FWD8_LAUNCH(true, false, true);
-      else L64_FWD8_LAUNCH(true, false, false);
-    } else {
-      if (st_ && dr) L64_FWD8_LAUNCH(false, true, true);
-      else if (st_) L64_FWD8_LAUNCH(false, true, false);
-      else if (dr) L64_FWD8_LAUNCH(false, false, true);
-      else L64_FWD8_LAUNCH(false, false, false);
-    }
-    MMEGO_LAUNCH_CHECK();
-    return MMEGO_OK;
-  }
-#undef L64_FWD8_LAUNCH
   if (full) {
     if (st_ && dr) L64_FWD_LAUNCH(true, true, true);
     else if (st_) L64_FWD_LAUNCH(true, true, false);
