@@ -395,7 +395,7 @@ def config2_forward(device):
 def config5_forward(device):
     """BASELINE config 5: B=2048 T=16 N=256, IMU_Net -> Upper_Net -> Lower_Net eval forward with IMU_Net's BiLSTM products in
     bf16-operand / fp32-accumulate mode (everything else fp32).  Reports ms per forward, frames/s, and for the dominant kernel
-    (the fused projection + recurrence step, lstm_step_bf16_fused_kernel) its MFMA and HBM fractions from live event pairs:
+    (the fused projection + recurrence step, mmego_lstm_step_bf16_fused: lstm_step_bf16_fused256_kernel at this shape) its MFMA and HBM fractions from live event pairs:
       flop per launch   = 2 x ndir x Bn x 4H x (K_in + H)            (K_in + 0 on the first timestep)
       bytes per launch  = ndir x Bn x [2 K_in (x_t bf16) + 2 H (h_t-1 bf16) + 8 H (c read + write) + 2 H (h_t bf16)
                           + 4 H (h_t fp32, last layer only)] + the weights once (2 x 4H x (K_in + H) x 2 B)."""
@@ -444,7 +444,7 @@ def config5_forward(device):
     k = {}
     if rec:
         tf, gbps = tot_fl / (tot_ms * 1e-3) / 1e12, tot_by / (tot_ms * 1e-3) / 1e9
-        k = {"kernel": "lstm_step_bf16_fused_kernel (projection folded into the recurrent step)", "launches_per_forward": len(rec),
+        k = {"kernel": "lstm_step_bf16_fused256_kernel (projection folded into the recurrent step; persistent 256x256 tiles)", "launches_per_forward": len(rec),
              "avg_launch_us": tot_ms / len(rec) * 1e3, "share_of_forward": tot_ms / ms,
              "mfma": {"achieved": tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_MFMA_TFLOPS},
              "hbm": {"achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
