@@ -392,6 +392,33 @@ def config2_forward(device):
             "bound": "dependent-launch latency (t_roofline is below one kernel boundary)"}
 
 
+def stage1_step(device):
+    """SURVEY 8-f row 3, an extra figure: one stage-1 training step of IMU_Net (Processor/Train/Train_IMU.py:114-149 -- forward,
+    geodesic + 100 x position loss, backward through both BiLSTM(512) stacks, Adam with coupled weight decay) at B=64 T=8 as one
+    replayed HIP graph.  Algorithmic FLOPs: forward 222.48 MFLOP/frame, backward twice that."""
+    from mmego_amd import nets
+    from mmego_amd.train_step import ImuStep
+    torch.manual_seed(4)
+    net = nets.IMUNet(15, 9, 512, 2, True, 0).to(device).train()
+    st = ImuStep(net, lr=1e-4, weight_decay=0.001, use_graph=True)
+    g = torch.Generator().manual_seed(44)
+    imu = torch.randn(B, T, 20, 15, generator=g).to(device)
+    Rg = torch.linalg.qr(torch.randn(B, T, 3, 3, generator=g))[0].contiguous().to(device)
+    tgt = torch.randn(B, T, 21, 3, generator=g).to(device)
+    st.bind(imu, Rg, tgt)
+    for _ in range(3):
+        st.step()
+    ms = _time_events(st.step, 20, 2)
+    flop = 3.0 * 2.0 * 222.48e6 * B * T
+    res = {"workload": "stage-1 IMU_Net training step (forward, geodesic + position loss, backward, Adam with weight decay), "
+                       "B=64 T=8 S=20, fp32, one HIP graph per step", "ms_per_step": ms, "frames_per_s": B * T / (ms * 1e-3),
+           "algorithmic_tflops": flop / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+           "loss": float(st.loss.item())}
+    del net, st
+    torch.cuda.empty_cache()
+    return res
+
+
 def config5_forward(device):
     """BASELINE config 5: B=2048 T=16 N=256, IMU_Net -> Upper_Net -> Lower_Net eval forward with IMU_Net's BiLSTM products in
     bf16-operand / fp32-accumulate mode (everything else fp32).  Reports ms per forward, frames/s, and for the dominant kernel
@@ -768,6 +795,7 @@ def main():
         if world == 1 and not args.no_config_extras:
             out["config2"] = config2_forward(device)
             out["config5"] = config5_forward(device)
+            out["stage1"] = stage1_step(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_steps, 1, device)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

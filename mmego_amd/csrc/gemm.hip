@@ -615,6 +615,11 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   return MMEGO_OK;
 }
 
+int lstm_bwd_step_dma_try(void* stream, int Bn, int H, const float* dg0, const float* dg1, long dgs, const float* wT0,
+                                           const float* wT1, const float* dout0, const float* dout1, long dos, const float* gst0,
+                                           const float* gst1, const float* cst0, const float* cst1, const float* cprev0,
+                                           const float* cprev1, float* dc0, float* dc1, float* dgo0, float* dgo1);
+
 // One step of the backward recurrence of a BiLSTM layer (stage-1 training, reference autograd of nn.LSTM): for both directions
 // dh_rec = dgates_s . W_hh (A = dgates of step s, rows Bn, K = 4H; wT = W_hh transposed [H][4H]) and, on the product's tiles, the
 // cell backward of the step BEFORE in time order of the backward pass (dh = dout + dh_rec, gate / cell gradients from the forward
@@ -626,6 +631,11 @@ extern "C" int mmego_lstm_bwd_step(void* stream, int Bn, int H, const float* dg0
   MMEGO_REQUIRE(Bn > 0 && H > 0 && (Bn % 32) == 0 && (H % 32) == 0 && dg0 && dg1 && wT0 && wT1 && dout0 && dout1 && gst0 && gst1 &&
                 cst0 && cst1 && dc0 && dc1 && dgo0 && dgo1 && (cprev0 == nullptr) == (cprev1 == nullptr));
   MMEGO_REQUIRE((dgs % 4) == 0 && ((((uintptr_t)dg0) | ((uintptr_t)dg1) | ((uintptr_t)wT0) | ((uintptr_t)wT1)) & 15) == 0);
+  {   // 64-row multiples: the LDS-DMA step kernel (lstm_bwd_step.hip); anything else: the K-quartered small-tile product below
+    const int rc = lstm_bwd_step_dma_try(stream, Bn, H, dg0, dg1, dgs, wT0, wT1, dout0, dout1, dos, gst0, gst1, cst0, cst1,
+                                               cprev0, cprev1, dc0, dc1, dgo0, dgo1);
+    if (rc != -1) return rc;
+  }
   GemmP p;
   p.A = dg0; p.B = wT0; p.C = nullptr; p.bias = nullptr;
   p.sam = dgs; p.sak = 1; p.sbk = 1; p.sbn = 4L * H;

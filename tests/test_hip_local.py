@@ -268,17 +268,26 @@ def test_imu_stage1_gradients_at_full_size(dev, monkeypatch):
             go = po[k].grad if po[k].grad is not None else torch.zeros_like(po[k])
             err = (ph.grad.cpu() - go).abs().max().item()
             assert err < 2e-4 * scale, (Bq, Tq, k, err, scale)
-        # the backward recurrence's fused launch (product + cell backward on its tiles, mmego_lstm_bwd_step) gives the bits of the
-        # two separate launches
-        fused = {k: ph.grad.clone() for k, ph in hb.named_parameters()}
-        monkeypatch.setenv("MMEGO_LSTM_BWD_FUSED", "0")
-        for ph in hb.parameters():
-            ph.grad = None
-        Rh2, th2 = hb(imu.to(dev))
-        ((Rh2 * wR.to(dev)).sum() + (th2 * wt.to(dev)).sum()).backward()
-        monkeypatch.delenv("MMEGO_LSTM_BWD_FUSED")
-        for k, ph in hb.named_parameters():
-            assert torch.equal(ph.grad, fused[k]), (Bq, Tq, k)
+        # (these row counts run the LDS-DMA backward step, lstm_bwd_step.hip.)  The K-quartered small-tile form of the same launch
+        # (MMEGO_LSTM_BWD_DMA=0: other row counts) sums K in another order -- same gradients to rounding -- and gives the bits of
+        # the two separate launches (product, then cell backward: MMEGO_LSTM_BWD_FUSED=0)
+        def grads_with(**env):
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            for ph_ in hb.parameters():
+                ph_.grad = None
+            R2, t2 = hb(imu.to(dev))
+            ((R2 * wR.to(dev)).sum() + (t2 * wt.to(dev)).sum()).backward()
+            for k_ in env:
+                monkeypatch.delenv(k_)
+            return {k_: ph_.grad.clone() for k_, ph_ in hb.named_parameters()}
+        dma = {k: ph.grad.clone() for k, ph in hb.named_parameters()}
+        kq = grads_with(MMEGO_LSTM_BWD_DMA="0")
+        sep = grads_with(MMEGO_LSTM_BWD_DMA="0", MMEGO_LSTM_BWD_FUSED="0")
+        for k in dma:
+            assert torch.equal(kq[k], sep[k]), (Bq, Tq, k)
+            assert (dma[k] - kq[k]).abs().max().item() < 2e-5 * scale, (Bq, Tq, k, (dma[k] - kq[k]).abs().max().item(), scale)
+        assert any(not torch.equal(dma[k], kq[k]) for k in dma), "the two forms of the backward step should differ in summation order"
     # one optimiser step as Train_IMU.py:71-72 configures it (lr 1e-4 is the CLI's; weight_decay 1e-3)
     before = {k: v.clone() for k, v in o.state_dict().items()}
     opt_o = torch.optim.Adam(o.parameters(), lr=1e-4, weight_decay=0.001)
