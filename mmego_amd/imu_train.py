@@ -71,22 +71,29 @@ def lstm_steps_backward(ar, key, lstm, x, Bn, T, dout, G, need_dx):
                 # A batch = direction: rows of dg at time t0 (cols 0:4H) / t1 (cols 4H:8H); the batch stride may be negative.
                 hip.call("gemm", dg.data_ptr() + 4 * (t0 * 8 * H), T * 8 * H, 1, wT, 1, 4 * H, dhrec, H, 1, None,
                          Bn, H, 4 * H, 2, (t1 - t0) * 8 * H + 4 * H, H * 4 * H, Bn * H, 0, 0, None, 1, 0, None, None)
-        hp = ar.get("%s.hp" % key, (Bn * T, H))
+        # weight gradients: the two directions of a product kind as ONE batched launch (ops.grad_weight_pair); the h_{t-1} operands
+        # of both directions side by side in one buffer
+        hp = ar.get("%s.hp2" % key, (2, Bn * T, H))
+        ops.copy2d(out[:Bn * T - 1, :H], hp[0, 1:])                      # h_{t-1}: previous row of the same sequence; zero at t = 0
+        ops.copy2d(zeros, hp[0].view(Bn, T * H)[:, :H])
+        ops.copy2d(out[1:, H:], hp[1, :Bn * T - 1])                      # reverse direction: h fed into time t came from t+1; zero at T-1
+        ops.copy2d(zeros, hp[1].view(Bn, T * H)[:, (T - 1) * H:])
+        ops.grad_weight_pair(dg, 4 * H, inp, G(lstm.w("weight_ih", l, 0)), G(lstm.w("weight_ih", l, 1)))
+        ops.grad_weight_pair(dg, 4 * H, hp[0], G(lstm.w("weight_hh", l, 0)), G(lstm.w("weight_hh", l, 1)), X1=hp[1])
         for d in range(2):
             dgd = dg[:, d * 4 * H:(d + 1) * 4 * H]
-            ops.grad_weight(dgd, inp, G(lstm.w("weight_ih", l, d)))
-            if d == 0:      # h_{t-1}: previous row of the same sequence; zero at t = 0
-                ops.copy2d(out[:Bn * T - 1, :H], hp[1:])
-                ops.copy2d(zeros, hp.view(Bn, T * H)[:, :H])
-            else:           # reverse direction: h fed into time t came from time t+1; zero at t = T-1
-                ops.copy2d(out[1:, H:], hp[:Bn * T - 1])
-                ops.copy2d(zeros, hp.view(Bn, T * H)[:, (T - 1) * H:])
-            ops.grad_weight(dgd, hp, G(lstm.w("weight_hh", l, d)))
             ops.colsum(dgd, G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
         if l > 0 or need_dx:
             dinp = ar.get("%s.dx%d" % (key, l), (Bn * T, inp.shape[1]))
-            ops.grad_input(dg[:, :4 * H], lstm.w("weight_ih", l, 0), dinp)
-            ops.grad_input(dg[:, 4 * H:], lstm.w("weight_ih", l, 1), dinp, accumulate=True)
+            Wst = ops.stacked(lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1))
+            if Wst is not None:
+                # [W_ih ; W_ih_reverse] back to back in the flat buffer (flat_param_order): one product with K = 8H instead of a
+                # product and an accumulating one.  (Against the transposed stack, both operands K-contiguous, the 10 240-row
+                # products gain 2-8 % and the 512-row ones of rnn_slow lose 4x: measured, dropped.)
+                ops.grad_input(dg, Wst, dinp)
+            else:
+                ops.grad_input(dg[:, :4 * H], lstm.w("weight_ih", l, 0), dinp)
+                ops.grad_input(dg[:, 4 * H:], lstm.w("weight_ih", l, 1), dinp, accumulate=True)
             d_cur = dinp
     return d_cur if need_dx else None
 

@@ -689,6 +689,15 @@ class IMUNet(_NetBase):
         # (BASELINE config 5); everything else -- gates, cell state, pooling, heads -- stays fp32 in both modes.
         self.precision = os.environ.get("MMEGO_IMU_PRECISION", "fp32")
 
+    def _pulled_pairs(self):
+        """The two directions' input weights of every BiLSTM layer back to back: stage-1 training's input gradient of a layer is
+        then ONE product dgates [rows, 8H] . [W_ih ; W_ih_reverse] (imu_train.lstm_steps_backward)."""
+        pulled = super()._pulled_pairs()
+        for mname in ("rnn_fast", "rnn_slow"):
+            for l in range(getattr(self, mname).num_layers):
+                pulled["%s.weight_ih_l%d" % (mname, l)] = "%s.weight_ih_l%d_reverse" % (mname, l)
+        return pulled
+
     def never_trained(self):
         """Q7: fc3 is in the state_dict but not in forward, so its .grad stays None in the reference and torch's Adam never
         touches it (params.FusedAdam leaves these ranges alone, weight decay included)."""

@@ -197,6 +197,7 @@ def chain_split(M, N, K):
 
 
 _KQ_MAX = int(_os.environ.get("MMEGO_GEMM_KQ_MAX", "512"))
+_PAIR_SPLIT_WGS = int(_os.environ.get("MMEGO_PAIR_SPLIT_WGS", "512"))
 
 
 def asum_ok(M, N, K, nsplit, nbatch=1, over_tile=False):
@@ -232,8 +233,17 @@ def grad_weight_pair(dY, ncol, X, dW0, dW1, X1=None, db=None):
     W0, W1 = dW0.view(dW0.shape[0], -1), dW1.view(dW1.shape[0], -1)
     dist, xdist = W1.data_ptr() - W0.data_ptr(), Xb.data_ptr() - X.data_ptr()
     ok = (W0.shape == W1.shape == (ncol, K) and W0.is_contiguous() and W1.is_contiguous() and dY.stride(1) == 1 and X.stride(1) == 1
-          and Xb.shape == X.shape and Xb.stride() == X.stride() and dist % 16 == 0 and xdist % 16 == 0
-          and pick_split(ncol, K, rows) == 1)
+          and Xb.shape == X.shape and Xb.stride() == X.stride() and dist % 16 == 0 and xdist % 16 == 0)
+    if ok and pick_split(ncol, K, rows) > 1:
+        # long K (stage-1 IMU_Net: 10 240 rows): the two directions as one batched product keep twice the tiles in flight, so the
+        # K range is cut half as often as for one direction alone (or not at all) -- one launch + at most one slab reduce instead
+        # of two of each
+        tiles = ((ncol + 63) // 64) * ((K + 63) // 64) * 2
+        nsplit = int(max(1, min(_PAIR_SPLIT_WGS // tiles, rows // _SPLIT_K_MIN)))
+        ws = scratch(dY.device, nsplit * 2 * ncol * K) if nsplit > 1 else None
+        hip.call("gemm", dY, 1, dY.stride(0), X, X.stride(0), 1, W0, K, 1, None, ncol, K, rows, 2, ncol, xdist // 4, dist // 4, 0, 0, ws,
+                 nsplit, 0, None, None)
+        return False
     if not ok:
         grad_weight(dY[:, :ncol], X, dW0)
         grad_weight(dY[:, ncol:2 * ncol], Xb, dW1)
