@@ -305,6 +305,40 @@ def test_imu_stage1_gradients_at_full_size(dev, monkeypatch):
     assert n_bad < 0.02 * n_all, (n_bad, n_all)
 
 
+@pytest.mark.parametrize("H,Bq,Tq", [(32, 8, 8), (96, 16, 8), (64, 16, 4)])
+def test_lstm_bwd_step_kernel_forms_agree_at_small_sizes(dev, monkeypatch, H, Bq, Tq):
+    """The LDS-DMA backward step (lstm_bwd_step.hip) at the edges of its shape range -- K = 4H of two, four and six 64-k chunks
+    (the ring has three stages), one and two row blocks -- against the K-quartered small-tile form of the same launch
+    (MMEGO_LSTM_BWD_DMA=0) and against the oracle's autograd."""
+    from mmego_amd import nets
+    torch.manual_seed(40 + H)
+    o = on.IMUNet(15, 9, H, 2, True, 0).train()
+    hb = nets.IMUNet(15, 9, H, 2, True, 0)
+    hb.load_state_dict(o.state_dict())
+    hb = hb.to(dev).train()
+    gen = torch.Generator().manual_seed(H)
+    imu = torch.randn(Bq, Tq, 20, 15, generator=gen)
+    wR, wt = torch.randn(Bq, Tq, 3, 3, generator=gen), torch.randn(Bq, Tq, 3, generator=gen)
+    Ro, to_ = o(imu)
+    ((Ro * wR).sum() + (to_ * wt).sum()).backward()
+    po = dict(o.named_parameters())
+    scale = max(p_.grad.abs().max().item() for p_ in po.values() if p_.grad is not None)
+
+    def grads(dma):
+        monkeypatch.setenv("MMEGO_LSTM_BWD_DMA", dma)
+        for ph_ in hb.parameters():
+            ph_.grad = None
+        R2, t2 = hb(imu.to(dev))
+        ((R2 * wR.to(dev)).sum() + (t2 * wt.to(dev)).sum()).backward()
+        monkeypatch.delenv("MMEGO_LSTM_BWD_DMA")
+        return {k_: ph_.grad.clone() for k_, ph_ in hb.named_parameters()}
+    g_dma, g_kq = grads("1"), grads("0")
+    for k in g_dma:
+        go = po[k].grad if po[k].grad is not None else torch.zeros_like(po[k])
+        assert (g_dma[k].cpu() - go).abs().max().item() < 2e-4 * scale, ("oracle", k)
+        assert (g_dma[k] - g_kq[k]).abs().max().item() < 2e-5 * scale, ("forms", k)
+
+
 def test_fused_stage_step_equals_autograd_path(dev):
     """train_step.StageStep (fused L1 kernel, weight gradients on a second stream, HIP graph) produces the same
     gradients and the same Adam update as loss.backward() through the autograd bridge on one stream."""
