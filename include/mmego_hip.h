@@ -213,6 +213,11 @@ int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H, int first,
 /* rows (b*T + t) of X[., C] -> T fragment-major [Bp x C] bf16 matrices (timestep t at offset t*Bp*C): a layer-0 input of
  * mmego_lstm_step_bf16_fused.  C % 16 == 0, Bp % 32 == 0. */
 int mmego_cvt_bf16_frag_tm(void* stream, const float* X, long ldx, int Bn, int T, int C, unsigned short* Y, int Bp);
+/* Linear(Cin <= 16, H) (+ ReLU) straight into that layout: Y[t] = bf16(act(X[b*T + t] . W^T + bias)) for rows (b*T + t) of X[., Cin]
+ * (IMU_Net's fc1, Net/IMU_Net.py:53,73, as the layer-0 operand of the fused bf16 step: the fp32 activation is never stored).
+ * W [H][Cin] row-major, bias [H] or NULL; H % 16 == 0, Bp % 32 == 0; rows b >= Bn are written as zeros. */
+int mmego_fc_relu_bf16_frag_tm(void* stream, const float* X, long ldx, const float* W, const float* bias, int Bn, int T, int Cin,
+                               int H, unsigned short* Y, int Bp, int relu);
 
 /* ---- IMU_Net stage-1 training pieces (imu_train.hip): reference Processor/Train/Train_IMU.py:21-34,114-149 -------
  * Pointwise LSTM cell backward of one timestep, both directions: dh = dout + dh_rec (dh_rec may be NULL), reads the

@@ -487,15 +487,25 @@ def lstm_bf16_weights_fused(lstm):
 FUSED_MIN_ROWS = int(os.environ.get("MMEGO_BF16_FUSED_MIN", "2049"))
 
 
-def lstm_steps_forward_bf16_fused(ar, key, lstm, x, Bn, T):
+def fused_input_fragments(ar, key, Bn, T, In):
+    """The layer-0 operand buffer of lstm_steps_forward_bf16_fused: T fragment-major [Bp x In] bf16 matrices (a producer that writes
+    them itself -- IMU_Net's fc1, mmego_fc_relu_bf16_frag_tm -- passes the filled buffer as `xfrag`)."""
+    Bp = (Bn + 31) // 32 * 32
+    return ar.get("%s.xfrag" % key, (T, Bp * In), dtype=torch.bfloat16), Bp
+
+
+def lstm_steps_forward_bf16_fused(ar, key, lstm, x, Bn, T, xfrag=None):
     """Large-batch form of lstm_steps_forward_bf16: no projection tensor; every step multiplies [x_t | h_{t-1}] by [W_ih | W_hh]
-    (bf16.hip, lstm_step_bf16_fused_kernel).  Layer inputs and all h_t live fragment-major, one [Bp x K] matrix per timestep."""
+    (bf16.hip, lstm_step_bf16_fused_kernel).  Layer inputs and all h_t live fragment-major, one [Bp x K] matrix per timestep.
+    x [Bn*T, In] fp32 rows (b*T+t), or None with `xfrag` = the layer-0 operand already in that layout."""
     H = lstm.hidden_size
     W = lstm_bf16_weights_fused(lstm)
-    Bp = (Bn + 31) // 32 * 32
-    In = x.shape[1]
-    xf = ar.get("%s.xfrag" % key, (T, Bp * In), dtype=torch.bfloat16)
-    hip.call("cvt_bf16_frag_tm", x, x.stride(0), Bn, T, In, xf, Bp)
+    In = lstm.input_size
+    xf, Bp = fused_input_fragments(ar, key, Bn, T, In)
+    if xfrag is None:
+        hip.call("cvt_bf16_frag_tm", x, x.stride(0), Bn, T, In, xf, Bp)
+    elif xfrag.data_ptr() != xf.data_ptr():
+        raise ValueError("lstm_steps_forward_bf16_fused: xfrag must be the buffer of fused_input_fragments")
     out = None
     prev = None
     for l in range(lstm.num_layers):

@@ -592,6 +592,72 @@ extern "C" int mmego_cvt_bf16_frag_tm(void* stream, const float* X, long ldx, in
   return MMEGO_OK;
 }
 
+// IMU_Net's fc1 (Linear(15, H) + ReLU, Net/IMU_Net.py:53,73) straight into the fused step's layer-0 operand: Y[t] (fragment-major
+// [Bp x H] bf16) = bf16(relu(X[b*T + t] . W^T + bias)).  In the bf16 mode at large batch the fp32 activation (1.3 GB at config 5)
+// existed only to be converted: product 0.44 ms + conversion 0.89 ms there, this kernel writes the 0.67 GB of bf16 once.
+// One workgroup per (timestep, 32-row block); the K <= 16 input values of a row wait in registers, W (padded to 16 columns) in
+// LDS; a thread produces the 8 consecutive units of one lane of a 1-KB fragment piece, so a wave's store is one whole piece.
+__global__ __launch_bounds__(256) void fc_relu_bf16_frag_tm_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ W,
+                                                                    const float* __restrict__ bias, int Bn, int T, int Cin, int H,
+                                                                    bf16_t* __restrict__ Y, int Bp, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];      // [H][16] + bias [H]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < H * 16; i += 256) {
+    const int n = i >> 4, k = i & 15;
+    wsm[i] = k < Cin ? W[(long)n * Cin + k] : 0.f;
+  }
+  for (int i = tid; i < H; i += 256) wsm[H * 16 + i] = bias ? bias[i] : 0.f;
+  const int t = blockIdx.y, rb = blockIdx.x;
+  const int b = rb * 32 + (lane & 31), half = lane >> 5;
+  float x[16];
+  {
+    const float* xr = X + ((long)(b < Bn ? b : Bn - 1) * T + t) * ldx;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = xr[k < Cin ? k : Cin - 1];        // (clamped address; the padded weights are zero)
+  }
+  __syncthreads();
+  const bool live = b < Bn;
+  u32x4* dst = reinterpret_cast<u32x4*>(Y + (long)t * Bp * H) + (long)rb * (H >> 4) * 64 + lane;
+  for (int k16 = wave; k16 < (H >> 4); k16 += 4) {
+    const int n0 = k16 * 16 + half * 8;
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4* wr = reinterpret_cast<const f32x4*>(wsm + (n0 + j) * 16);
+      float a = wsm[H * 16 + n0 + j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w4 = wr[q];
+        a = fmaf(x[4 * q], w4[0], a); a = fmaf(x[4 * q + 1], w4[1], a); a = fmaf(x[4 * q + 2], w4[2], a); a = fmaf(x[4 * q + 3], w4[3], a);
+      }
+      y[j] = live ? (relu ? fmaxf(a, 0.f) : a) : 0.f;
+    }
+    u32x4 o;
+    o[0] = f2bf_bits(y[0]) | (f2bf_bits(y[1]) << 16);
+    o[1] = f2bf_bits(y[2]) | (f2bf_bits(y[3]) << 16);
+    o[2] = f2bf_bits(y[4]) | (f2bf_bits(y[5]) << 16);
+    o[3] = f2bf_bits(y[6]) | (f2bf_bits(y[7]) << 16);
+    dst[(long)k16 * 64] = o;
+  }
+}
+
+extern "C" int mmego_fc_relu_bf16_frag_tm(void* stream, const float* X, long ldx, const float* W, const float* bias, int Bn, int T,
+                                          int Cin, int H, unsigned short* Y, int Bp, int relu) {
+  MMEGO_REQUIRE(X && W && Y && Bn > 0 && T > 0 && Cin > 0 && Cin <= 16 && H > 0 && H % 16 == 0 && H <= 2048 && Bp >= Bn && Bp % 32 == 0);
+  MMEGO_REQUIRE(T <= 65535 && (((uintptr_t)Y) & 15) == 0);
+  const size_t lds = (size_t)(H * 16 + H) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)fc_relu_bf16_frag_tm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 17 * 4);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(Bp / 32, T);
+  fc_relu_bf16_frag_tm_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(X, ldx, W, bias, Bn, T, Cin, H, Y, Bp, relu);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
 struct FusedStepP {
   const bf16_t* a[3][2];     // operand segments [segment][direction], fragment-major [Bp x 16*S]; the last one is h_{t-1}
   const bf16_t* w[3][2];     // weight segments, fragment-major with rows [hidden block][gate][32 units]

@@ -727,15 +727,23 @@ class IMUNet(_NetBase):
         H = self.hidden_n
         Bn = B * T
         dev = imu.device
-        h = ar.get("fc1", (Bn * S, H))
-        ops.linear(imu.view(Bn * S, Cin), self.fc1.weight, self.fc1.bias, h, relu=True)
         if self.precision not in ("fp32", "bf16"):
             raise ValueError("IMUNet.precision must be 'fp32' or 'bf16', got %r" % (self.precision,))
         bf16 = self.precision == "bf16"
-        if bf16:
-            fast = blocks.lstm_steps_forward_bf16(ar, "fast", self.rnn_fast, h, Bn, S)
+        if (bf16 and Bn >= blocks.FUSED_MIN_ROWS and H % 64 == 0 and Cin <= 16 and imu.is_contiguous()
+                and self.fc1.weight.is_contiguous() and os.environ.get("MMEGO_BF16_FUSED_FC1", "1") != "0"):
+            # large batch in the bf16 mode: fc1 + ReLU written straight as the fused step's layer-0 operand (bf16, fragment-major);
+            # the fp32 activation [Bn*S, H] (1.3 GB at config 5) is never stored
+            xf, Bp = blocks.fused_input_fragments(ar, "fast", Bn, S, H)
+            hip.call("fc_relu_bf16_frag_tm", imu.view(Bn * S, Cin), Cin, self.fc1.weight, self.fc1.bias, Bn, S, Cin, H, xf, Bp, 1)
+            fast = blocks.lstm_steps_forward_bf16_fused(ar, "fast", self.rnn_fast, None, Bn, S, xfrag=xf)
         else:
-            fast = blocks.lstm_steps_forward(ar, "fast", self.rnn_fast, h, Bn, S)          # [Bn*S, 2H]
+            h = ar.get("fc1", (Bn * S, H))
+            ops.linear(imu.view(Bn * S, Cin), self.fc1.weight, self.fc1.bias, h, relu=True)
+            if bf16:
+                fast = blocks.lstm_steps_forward_bf16(ar, "fast", self.rnn_fast, h, Bn, S)
+            else:
+                fast = blocks.lstm_steps_forward(ar, "fast", self.rnn_fast, h, Bn, S)          # [Bn*S, 2H]
         pooled = ar.get("pooled", (Bn, 2 * H))
         attn = ar.get("attn", (Bn, S))
         blocks.attn_pool_forward(fast, self.attn, Bn, S, 2 * H, pooled, attn)

@@ -161,6 +161,48 @@ def test_large_batch_fused_and_unfused_forms_agree(monkeypatch):
     assert float(outs[True].abs().mean()) > 1e-2          # not trivially zero
 
 
+def test_fc_relu_bf16_fragments_and_the_imu_forward_that_uses_them(monkeypatch):
+    """mmego_fc_relu_bf16_frag_tm (IMU_Net's fc1 written straight as the fused step's layer-0 operand): every element is the bf16
+    rounding of relu(x . W^T + b) (fp32 sums in another order than the GEMM's: a value within half a bf16 ulp of a tie may round
+    the other way), at its fragment-major position, rows past Bn zero; and the IMU_Net forward that uses it agrees with the one
+    that stores the fp32 activation and converts it (MMEGO_BF16_FUSED_FC1=0) to the mode's bound."""
+    from mmego_amd import blocks, hip, nets
+    dev = _dev()
+    Bn, T, Cin, H = 70, 3, 15, 128
+    Bp = 96
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(Bn * T, Cin, generator=g)
+    W = torch.randn(H, Cin, generator=g) * 0.3
+    b = torch.randn(H, generator=g) * 0.1
+    Y = torch.full((T, Bp * H), 7.0, dtype=torch.bfloat16, device=dev)
+    hip.call("fc_relu_bf16_frag_tm", X.to(dev), Cin, W.to(dev), b.to(dev), Bn, T, Cin, H, Y, Bp, 1)
+    got = Y.cpu().float().view(T, Bp * H)
+    want = torch.relu(X.double() @ W.double().T + b.double()).view(Bn, T, H)
+    r = torch.arange(Bp).view(Bp, 1)
+    k = torch.arange(H).view(1, H)
+    off = (((r // 32) * (H // 16) + k // 16) * 64 + ((k // 8) % 2) * 32 + r % 32) * 8 + k % 8        # frag_off (bf16.hip)
+    for t in range(T):
+        m = got[t][off]                                         # [Bp, H] in matrix order
+        assert float(m[Bn:].abs().max()) == 0.0
+        ref = want[:, t]
+        err = (m[:Bn].double() - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6).all()), float(err.max())
+        exact = m[:Bn] == ref.float().to(torch.bfloat16).float()
+        assert float(exact.float().mean()) > 0.995
+    # the forward that uses it
+    torch.manual_seed(9)
+    net = nets.IMUNet(15, 9, 128, 2).to(dev).eval()
+    net.precision = "bf16"
+    monkeypatch.setattr(blocks, "FUSED_MIN_ROWS", 1)
+    imu = torch.randn(32, 8, 20, 15, generator=g).to(dev)         # 256 rows: the 256 x 256-tile fused step as well
+    with torch.no_grad():
+        R1, t1 = [v.clone() for v in net(imu)]
+        monkeypatch.setenv("MMEGO_BF16_FUSED_FC1", "0")
+        R0, t0 = [v.clone() for v in net(imu)]
+    assert float((R1 - R0).abs().max()) < 2e-2 and float((t1 - t0).abs().max()) < 2e-2
+    assert float((R1 - R0).abs().mean()) < 2e-3
+
+
 def test_config5_full_size_bf16_forward():
     """BASELINE config 5 at its FULL size (B = 2048 sequences, T = 16 frames -> 32 768 rows x 20 samples through rnn_fast, the
     fused projection + recurrence step; 2048 x 16 through rnn_slow): IMUNet.precision = "bf16".  The CPU emulation cannot run
