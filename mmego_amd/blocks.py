@@ -484,7 +484,7 @@ def lstm_bf16_weights_fused(lstm):
     return layers
 
 
-FUSED_MIN_ROWS = int(os.environ.get("MMEGO_BF16_FUSED_MIN", "2049"))
+FUSED_MIN_ROWS = int(os.environ.get("MMEGO_BF16_FUSED_MIN", "2048"))
 
 
 def fused_input_fragments(ar, key, Bn, T, In):

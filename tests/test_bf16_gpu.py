@@ -100,7 +100,7 @@ def _emulate_bilstm(x, W, H, Bn, T):
                                                # multiples of 256 rows with H % 64 == 0: the 256 x 256-tile LDS-DMA form of the fused step
                                                (512, 3, 64, 128, True), (256, 4, 128, 192, True), (768, 2, 256, 64, True)])
 def test_bilstm_bf16_forward_matches_emulation(Bn, T, H, In, fused, monkeypatch):
-    """fused = the large-batch form (projection folded into the step kernel; default from 2049 rows), forced on or off here."""
+    """fused = the large-batch form (projection folded into the step kernel; default from 2048 rows), forced on or off here."""
     from mmego_amd import blocks, ops
     monkeypatch.setattr(blocks, "FUSED_MIN_ROWS", 1 if fused else 10 ** 9)
     torch.manual_seed(Bn)
