@@ -1016,192 +1016,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef F256_BARRIER
 }
 
-// ---- 512 x 128 tile form: activations straight into registers, only the weights through LDS (experiment, MMEGO_BF16_FUSED_256=2) ---
-// The 256 x 256 kernel's product loop is bound by what the LDS-DMA path delivers (~20 B/clk/CU: 64 KB per 64-k chunk).  Here a
-// workgroup owns 512 rows x 32 units x 4 gates, eight waves stacked along the rows: a wave's activation fragments are its own (no
-// other wave reads them), fragment-major in memory -- one coalesced 1-KB plain load per fragment straight into the registers the
-// MFMAs read, a chunk ahead -- and only the 16-KB weight chunk, shared by all eight waves, goes through LDS-DMA (ring of four).
-template <bool HOUT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_bf16_fused512_kernel(FusedStepP p, int ntiles) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem512[];
-  constexpr int WST = 16 * 1024, NSTW = 4;
-  unsigned char* const creg = smem512 + NSTW * WST;              // c tile [512 rows][32 floats]
-  unsigned char* const hreg = creg + 64 * 1024;                  // h_t fragments: 4 KB per wave
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = p.o.H;
-  const int njb = H >> 5, nb = ntiles >> 1;
-  const int G = (int)gridDim.x;
-  const int S0 = p.S[0], S1 = p.nseg > 1 ? p.S[1] : 0, S2 = p.nseg > 2 ? p.S[2] : 0;
-  const int NC = (S0 + S1 + S2) >> 2;
-  const bool first = p.o.first != 0;
-  const bool xcd_walk = G == 256 && ntiles % 256 == 0;
-  const int niter = (ntiles + G - 1) / G;
-  auto tile_of = [&](int it) { return xcd_walk ? (int)(blockIdx.x & 7) * (ntiles >> 3) + it * 32 + (int)(blockIdx.x >> 3) : (int)blockIdx.x + it * G; };
-
-  // chunk g of a tile: segment, first step inside it, steps of the segment
-  auto seg_of = [&](int g, int& seg, int& s0, int& S) {
-    s0 = g * 4; seg = 0; S = S0;
-    if (s0 >= S0) { s0 -= S0; seg = 1; S = S1; if (s0 >= S1) { s0 -= S1; seg = 2; S = S2; } }
-  };
-  // the weight chunk: 16 pieces [gate][step], two per wave
-  auto issue_w = [&](int tile, int g, int stage) {
-    const int d = tile >= nb, rem = tile - d * nb, jb = rem % njb;
-    int seg, s0, S;
-    seg_of(g, seg, s0, S);
-    const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w[seg][d]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = w * 2 + i;                                   // gate q >> 2, step q & 3
-      GLDS16B(wb + ((((long)(jb * 4 + (q >> 2))) * S + s0 + (q & 3)) << 10) + lane * 16, smem512 + stage * WST + (q << 10));
-    }
-  };
-  auto issue_c = [&](int tile) {
-    const int d = tile >= nb, rem = tile - d * nb, jb = rem % njb, rbw = rem / njb;
-    const float* cb = p.o.c[d] + ((long)rbw * 512 + (lane >> 3)) * H + jb * 32 + (lane & 7) * 4;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) GLDS16B(cb + (long)(w * 8 + i) * 8 * H, creg + ((w * 8 + i) << 10));
-  };
-  u32x4 fa0[2][4], fa1[2][4], fb[2][4];
-#define F512_LOADA(DST, tile, g)                                                                                            \
-  do {                                                                                                                      \
-    const int d_ = (tile) >= nb, rem_ = (tile) - d_ * nb, rbw_ = rem_ / njb;                                                \
-    int seg_, s0_, S_;                                                                                                      \
-    seg_of((g), seg_, s0_, S_);                                                                                             \
-    const u32x4* ab_ = reinterpret_cast<const u32x4*>(p.a[seg_][d_]) + ((long)(rbw_ * 16 + w * 2) * S_ + s0_) * 64 + lane;  \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                                        \
-      _Pragma("unroll") for (int sl = 0; sl < 4; ++sl) DST[mi][sl] = ab_[((long)mi * S_ + sl) * 64];                        \
-  } while (0)
-#define F512_RDB(buf, st, step)                                                                                             \
-  do {                                                                                                                      \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                           \
-      fb[buf][n] = *reinterpret_cast<const u32x4*>((st) + (((n << 2) + (step)) << 10) + lane * 16);                         \
-  } while (0)
-#define F512_MM(A_, step, buf)                                                                                              \
-  do {                                                                                                                      \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                                        \
-      _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                         \
-        acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_[mi][step]),                      \
-                                                             __builtin_bit_cast(bf16x8, fb[buf][n]), acc[mi][n], 0, 0, 0);  \
-  } while (0)
-#define F512_BARRIER()                       \
-  do {                                       \
-    asm volatile("" ::: "memory");           \
-    __builtin_amdgcn_s_barrier();            \
-    asm volatile("" ::: "memory");           \
-  } while (0)
-  // one chunk: CUR holds its activation fragments, NXT receives the next chunk's (requested right behind the barrier, in front of
-  // the weight requests: all but the two youngest operations done = they and every older weight chunk have landed)
-#define F512_CHUNK(CUR, NXT, c)                                                                                             \
-  do {                                                                                                                      \
-    if ((c) == 0 && it > 0) { if (HOUT) __builtin_amdgcn_s_waitcnt(0x0F70 | 15 | (3 << 14)); else __builtin_amdgcn_s_waitcnt(0x0F70 | 4 | (2 << 14)); } \
-    else if ((c) + 2 < NC && (c) > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 2);                                               \
-    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                                \
-    F512_BARRIER();                                                                                                         \
-    if ((c) + 1 < NC) F512_LOADA(NXT, tile, (c) + 1);                                                                       \
-    if ((c) == 0 && !first) issue_c(tile);                                                                                  \
-    if ((c) + 3 < NC) issue_w(tile, (c) + 3, (stage + 3) & 3);                                                              \
-    const unsigned char* st = smem512 + stage * WST;                                                                        \
-    F512_RDB(0, st, 0);                                                                                                     \
-    F512_RDB(1, st, 1);                                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    F512_MM(CUR, 0, 0);                                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    F512_RDB(0, st, 2);                                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    F512_MM(CUR, 1, 1);                                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    F512_RDB(1, st, 3);                                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    F512_MM(CUR, 2, 0);                                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    F512_MM(CUR, 3, 1);                                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    stage = (stage + 1) & 3;                                                                                                \
-  } while (0)
-
-  const int fr = lane & 31, fh = lane >> 5;
-  int stage = 0;
-  if (tile_of(0) < ntiles) {
-    const int t0 = tile_of(0);
-    F512_LOADA(fa0, t0, 0);
-    for (int g = 0; g < 3 && g < NC; ++g) issue_w(t0, g, g);
-  }
-  for (int it = 0; it < niter; ++it) {
-    const int tile = tile_of(it);
-    if (tile >= ntiles) break;
-    const int tile_next = it + 1 < niter ? tile_of(it + 1) : ntiles;
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mi][n][i] = 0.f;
-    for (int c = 0; c < NC; c += 2) {
-      F512_CHUNK(fa0, fa1, c);
-      F512_CHUNK(fa1, fa0, c + 1);
-    }
-    // every wave has finished the last weight stage it read; c tile landed long ago.  The next tile's first chunks are requested
-    // before the cell update; its stores drain under that tile's product loop.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    F512_BARRIER();
-    if (tile_next < ntiles) {
-      F512_LOADA(fa0, tile_next, 0);
-      for (int g = 0; g < 3 && g < NC; ++g) issue_w(tile_next, g, (stage + g) & 3);
-    }
-    const int d = tile >= nb, rem = tile - d * nb, jb = rem % njb, rbw = rem / njb;
-    const int j = jb * 32 + fr;
-    float bv[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) bv[n] = p.bias[(d * 4 + n) * H + j];
-    const float* cs = reinterpret_cast<const float*>(creg);
-    unsigned char* hst = hreg + w * 4096;
-    float cv[2][16];
-    if (!first) {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) cv[mi][i] = cs[(w * 64 + mi * 32 + 4 * fh + 8 * (i >> 2) + (i & 3)) * 32 + fr];
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int lrow = w * 64 + mi * 32 + 4 * fh;
-      float cn[16], hn[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float cprev = first ? 0.f : cv[mi][i];
-        const float gi = bf_sigmoid(acc[mi][0][i] + bv[0]), gf = bf_sigmoid(acc[mi][1][i] + bv[1]);
-        const float gg = bf_tanh(acc[mi][2][i] + bv[2]), go = bf_sigmoid(acc[mi][3][i] + bv[3]);
-        cn[i] = gf * cprev + gi * gg;
-        hn[i] = go * bf_tanh(cn[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = rbw * 512 + lrow + 8 * (i >> 2) + (i & 3);
-        p.o.c[d][(long)row * H + j] = cn[i];
-        if (HOUT) p.o.hout[d][(long)row * p.o.hos + j] = hn[i];
-        *reinterpret_cast<bf16_t*>(hst + ((((mi * 2 + (fr >> 4)) * 64 + ((fr >> 3) & 1) * 32 + 4 * fh + 8 * (i >> 2) + (i & 3)) * 8 + (fr & 7)) << 1)) =
-            (bf16_t)f2bf_bits(hn[i]);
-      }
-    }
-    {
-      bf16_t* hf = p.o.hfrag[d];
-#pragma unroll
-      for (int pc = 0; pc < 4; ++pc) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(hst + ((pc * 64 + lane) << 4));
-        const long rb32 = (long)rbw * 16 + w * 2 + (pc >> 1), k16 = jb * 2 + (pc & 1);
-        *reinterpret_cast<u32x4*>(hf + ((rb32 * (H >> 4) + k16) * 64 + lane) * 8) = v;
-      }
-    }
-  }
-#undef F512_LOADA
-#undef F512_RDB
-#undef F512_MM
-#undef F512_BARRIER
-#undef F512_CHUNK
-}
-
 extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H, int first, int nseg,
                                           const unsigned short* a0_0, const unsigned short* a0_1, const unsigned short* w0_0,
                                           const unsigned short* w0_1, int K0, const unsigned short* a1_0,
@@ -1243,23 +1057,7 @@ extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H,
   for (int q = 0; q < p.nseg; ++q) k64 = k64 && p.S[q] % 4 == 0;
   // (also where the tiles do not fill the chip -- 2048 rows at H = 512: 128 tiles on 128 CUs: config 5 25.3 ms against 25.7 with the
   //  128-row kernel there)
-  int nchunks = 0;
-  for (int q = 0; q < p.nseg; ++q) nchunks += p.S[q] / 4;
-  if (t256 == 2 && ndir == 2 && Bn % 512 == 0 && H % 32 == 0 && k64 && nchunks % 2 == 0 && nchunks >= 4) {
-    constexpr int lds = 4 * 16 * 1024 + 64 * 1024 + 8 * 4096;
-    static bool attr_set5 = false;
-    if (!attr_set5) {
-      hipError_t e = hipFuncSetAttribute((const void*)lstm_step_bf16_fused512_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lstm_step_bf16_fused512_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return (int)e;
-      attr_set5 = true;
-    }
-    MMEGO_REQUIRE((hout0 == nullptr) == (hout1 == nullptr));
-    const int ntiles = 2 * (H / 32) * (Bn / 512);
-    dim3 grid(ntiles < 256 ? ntiles : 256, 1, 1);
-    if (hout0) lstm_step_bf16_fused512_kernel<true><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles);
-    else lstm_step_bf16_fused512_kernel<false><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles);
-  } else if (t256 && ndir == 2 && Bn % 256 == 0 && H % 64 == 0 && k64) {
+  if (t256 && ndir == 2 && Bn % 256 == 0 && H % 64 == 0 && k64) {
     constexpr int lds = 2 * 64 * 1024 + 8 * 4096;      // two ring stages + 4 KB per wave for the h_t fragments
     static bool attr_set = false;
     if (!attr_set) {
