@@ -515,8 +515,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    # MMEGO_FORCE_DIST=1: take the multi-rank code path (RCCL process group, barriers, MAX over ranks, warm-up collectives) with
+    # ONE rank as well -- the one-GPU box allows one rank per device, so this is how that path is rehearsed there
+    dist_on = world > 1 or os.environ.get("MMEGO_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("MMEGO_DIST_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=device)
@@ -543,14 +549,14 @@ def main():
         else:
             both.step()
 
-    if world > 1:       # bring the RCCL communicator (and its channels for these message sizes) up outside the timed region
+    if dist_on:       # bring the RCCL communicator (and its channels for these message sizes) up outside the timed region
         torch.distributed.all_reduce(torch.zeros(1, device=device))
         for net in (upper, lower):      # the gradient buffers are overwritten by every backward: reducing them here is harmless
             torch.distributed.all_reduce(net.flat().flat_g)
         torch.cuda.synchronize()
 
     def sync():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -566,7 +572,7 @@ def main():
         ul_step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
@@ -574,7 +580,7 @@ def main():
     if args.trace_only:
         if rank == 0:
             print(json.dumps({"trace_only": True, "ms_per_step": dt / args.steps * 1e3, "stages_concurrent": not args.sequential}))
-        if world > 1:
+        if dist_on:
             torch.distributed.destroy_process_group()
         return
 
@@ -603,7 +609,7 @@ def main():
         shared.step()
     sync()
     dt_shared = time.perf_counter() - t0s
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt_shared], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt_shared = tt.item()
@@ -628,7 +634,7 @@ def main():
                 both_b.step()
             sync()
             dt_b = time.perf_counter() - t0b
-            if world > 1:
+            if dist_on:
                 tt = torch.tensor([dt_b], dtype=torch.float64, device=device)
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
                 dt_b = tt.item()
@@ -800,7 +806,7 @@ def main():
             out["cpu_baseline"], out["parity"] = cpu_baseline(args.cpu_steps, 1, device)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

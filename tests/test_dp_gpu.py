@@ -135,3 +135,62 @@ def test_two_rank_ul_step_equals_sum_of_shard_gradients():
                 assert torch.equal(a, b.cpu()), ("rank's BatchNorm buffers are its own shard's", r, k)
             assert res[r]["loss"][k] == reps[r][k].loss.item()
     assert not torch.equal(res[0]["buffers"][0][0], res[1]["buffers"][0][0]), "the shards really differ"
+
+
+def _rccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # "nccl" IS RCCL on ROCm
+    try:
+        from mmego_amd import train_step
+        from mmego_amd.train_step import ConcurrentStages, broadcast_flag, sync_replicas
+        pg = dist.group.WORLD
+        real_ws = dist.get_world_size
+        # the one-GPU box allows one rank per device: make the trainers' "world > 1" tests true so that every collective the
+        # data-parallel path issues really goes through the (one-rank) RCCL communicator
+        dist.get_world_size = lambda group=None: 2
+        nets_ = _build(dev, seed=1000)
+        for net in nets_[:2]:
+            sync_replicas(net, pg)                                   # broadcasts
+        shard = _batch(dev)
+        su, sl = _stages(nets_, shard, pg, use_graph=True)
+        both = ConcurrentStages([su, sl], use_graph=True)
+        assert both.bucket is not None
+        for _ in range(2):
+            both.step()                                              # graph replay -> RCCL all-reduce of the bucket -> fused Adam
+        torch.cuda.synchronize()
+        assert broadcast_flag(True, dev, pg) is True
+        dist.get_world_size = real_ws
+        q.put(dict(g=[st.net.flat().flat_g.cpu().numpy().copy() for st in (su, sl)],
+                   p=[st.net.flat().flat_p.cpu().numpy().copy() for st in (su, sl)],
+                   backend=dist.get_backend(pg)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_rank_rccl_collectives_in_the_training_step():
+    """The collectives of the data-parallel step on the REAL backend (RCCL, `init_process_group("nccl", device_id=...)` as bench.py
+    and the trainers do), with one rank -- the one-GPU box refuses two ranks on a device: replica sync broadcasts, the gradient
+    bucket's all-reduce between the graph replay and the fused Adam, the early-stopping broadcast.  A sum over one rank must leave
+    the step's results exactly those of a run without a process group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert res["backend"] == "nccl"
+    dev = torch.device("cuda:0")
+    from mmego_amd.train_step import ConcurrentStages
+    nets_ = _build(dev, seed=1000)
+    su, sl = _stages(nets_, _batch(dev), None, use_graph=True)
+    both = ConcurrentStages([su, sl], use_graph=True)
+    for _ in range(2):
+        both.step()
+    torch.cuda.synchronize()
+    for k, st in enumerate((su, sl)):
+        assert np.array_equal(res["g"][k], st.net.flat().flat_g.cpu().numpy())
+        assert np.array_equal(res["p"][k], st.net.flat().flat_p.cpu().numpy())
