@@ -143,12 +143,15 @@ def test_imu_forward_bf16_mode_is_close_to_fp32_and_is_opt_in():
         net(imu)
 
 
-def test_large_batch_fused_and_unfused_forms_agree(monkeypatch):
+@pytest.mark.parametrize("Bn", [4096, 4352, 4128])
+def test_large_batch_fused_and_unfused_forms_agree(monkeypatch, Bn):
     """At a config-5-like size (4096 sequences, H = 512) the CPU emulation is too slow; instead the two device forms of the mode
     -- separate tile-major projection + step kernels, and the projection folded into the step -- must agree: same bf16 operand
-    roundings, fp32 accumulation in a different order (plus the occasional flipped bf16 ulp of h_t that follows from it)."""
+    roundings, fp32 accumulation in a different order (plus the occasional flipped bf16 ulp of h_t that follows from it).
+    4096 rows: the persistent 256 x 256-tile kernel on its XCD-contiguous walk (256 tiles); 4352 rows: 272 tiles, the plain walk
+    with a ragged last round; 4128 rows (not a multiple of 256): the 128-row kernel with a partial last row block."""
     from mmego_amd import blocks, ops
-    Bn, T, H, In = 4096, 3, 512, 512
+    T, H, In = 3, 512, 512
     torch.manual_seed(11)
     lstm = blocks.LstmParams(In, H, 2).to(_dev())
     x = torch.randn(Bn * T, In, generator=torch.Generator().manual_seed(12)).to(_dev())
