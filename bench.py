@@ -541,9 +541,6 @@ def main():
     su.bind(x, imu_in, body, target)
     sl.bind(x, imu_in, body, target)
     both = ConcurrentStages([su, sl], use_graph=not args.no_graph)
-    if os.environ.get("MMEGO_SPLIT_GRAPHS") == "1":        # experiment: the step as three graphs (train_step.SplitGraphStages)
-        from mmego_amd.train_step import SplitGraphStages
-        both = SplitGraphStages([su, sl])
 
     def ul_step():
         if args.sequential:

@@ -429,84 +429,6 @@ class ConcurrentStages:
         return [st.loss for st in self.stages]
 
 
-class SplitGraphStages:
-    """The two-stage U+L step of ConcurrentStages as THREE graphs instead of one graph with branches (experiment, r03):
-    A = the last stage's IMU_Net forward; B = that stage's body, replayed on a side stream behind an event; C = the first stage's
-    IMU_Net forward + body on the launching stream.  Same kernels, same data flow; what differs is who dispatches the nodes: a
-    graph with parallel branches hands out tiny nodes 3-4x slower than linear chains in separate graphs (scripts/bench_launch_gap.py),
-    and a full StepPlan (one graph per stream segment) pays ~15 graph boundaries per step."""
-
-    def __init__(self, stages):
-        self.stages = list(stages)
-        assert len(self.stages) == 2 and all(st.imu is not None for st in self.stages)
-        first, last = self.stages
-        dev = last.static["imu"].device
-        B, T = last.static["imu"].shape[0], last.static["imu"].shape[1]
-        self.R, self.t = torch.empty(B, T, 3, 3, device=dev), torch.empty(B, T, 3, device=dev)
-        self.imu_last = last.imu
-        self.side = torch.cuda.Stream()
-        self.side_a = torch.cuda.Stream()
-        self.ev = torch.cuda.Event()
-        self.graphs = None
-        self.bucket = None
-
-    def _body_a(self):
-        from . import blocks
-        last = self.stages[1]
-        with torch.no_grad(), blocks.two_chains(True):
-            R, t = self.imu_last(last.static["imu"])
-            ops.copy2d(R.view(-1, 9), self.R.view(-1, 9))
-            ops.copy2d(t.view(-1, 3), self.t.view(-1, 3))
-
-    def _body_b(self):
-        last = self.stages[1]
-        keep = (last.imu, last.pose)
-        try:
-            last.imu, last.pose = None, (self.R, self.t)
-            last._body()
-        finally:
-            last.imu, last.pose = keep
-
-    def _body_c(self):
-        from . import blocks
-        first = self.stages[0]
-        with blocks.two_chains(True):
-            first._body()
-
-    def prepare(self):
-        if self.graphs is None:
-            for st in self.stages:
-                st.warm_up()
-            keep = [[t.clone() for t in st._mutable_state()] for st in self.stages]
-            self._body_a(); self._body_c()
-            with torch.cuda.stream(self.side):
-                self.side.wait_stream(torch.cuda.current_stream())
-                self._body_b()
-            torch.cuda.synchronize()
-            for st, ks in zip(self.stages, keep):
-                for t, k in zip(st._mutable_state(), ks):
-                    t.copy_(k)
-            torch.cuda.synchronize()
-            self.graphs = (_capture_body(self._body_a, stream=self.side_a), _capture_body(self._body_b, stream=self.side),
-                           _capture_body(self._body_c))
-
-    def step(self):
-        self.prepare()
-        ga, gb, gc = self.graphs
-        main = torch.cuda.current_stream()
-        ga.replay()
-        self.ev.record(main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.ev)
-            gb.replay()
-        gc.replay()
-        main.wait_stream(self.side)
-        for st in self.stages:
-            allreduce_grads(st.net._flat, st.pg)
-            st.opt.step()
-        return [st.loss for st in self.stages]
-
-
 class PipelinedStages:
     """ConcurrentStages with the frozen IMU_Net forwards moved one minibatch ahead (a prefetch pipeline).
 
