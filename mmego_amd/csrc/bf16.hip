@@ -890,6 +890,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
 
   const int fr = lane & 31, fh = lane >> 5;
+  // vector-memory operations a lane issues in the cell update BEHIND the next tile's first operand requests: per accumulator row
+  // block (EPI_MI) 16 c stores (+ 16 fp32 h_t stores), then EPI_PIECES fragment stores.  The first chunk of the next tile waits
+  // with vmcnt(EPI_WAIT): everything older than the youngest EPI_WAIT operations -- the requests included -- has completed.
+  constexpr int EPI_MI = 2, EPI_PIECES = 4;
+  constexpr int EPI_YOUNGER = EPI_MI * 16 * (HOUT ? 2 : 1) + EPI_PIECES;
+  constexpr int EPI_WAIT = EPI_YOUNGER < 63 ? EPI_YOUNGER : 63;
   u32x4 fa[2][2], fb[2][4];
 #define F256_RD(buf, st, step)                                                                                              \
   do {                                                                                                                      \
@@ -928,8 +934,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int c = 0; c < NC; ++c) {
       // this wave's pieces of chunk c have landed.  They were issued BEFORE the previous tile's cell-update stores (if any):
       // all but the youngest 63 operations done covers them, and waits for no more of those stores than it must
-      // (younger than those pieces: 32 c stores, 32 h_t stores where the layer's fp32 output is wanted, 4 fragment stores)
-      if (c == 0 && it > 0) { if (HOUT) __builtin_amdgcn_s_waitcnt(0x0F70 | 15 | (3 << 14)); else __builtin_amdgcn_s_waitcnt(0x0F70 | 4 | (2 << 14)); }   // vmcnt(63) / vmcnt(36)
+      // (younger than those pieces: the cell update's stores, counted by the constants its loops run on -- EPI_YOUNGER above; the
+      // wait may leave at most that many operations outstanding, and the counter holds 63)
+      if (c == 0 && it > 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (EPI_WAIT & 15) | ((EPI_WAIT >> 4) << 14));
       else __builtin_amdgcn_s_waitcnt(0x0F70);                                        // vmcnt(0)
       F256_BARRIER();                          // everyone's pieces of chunk c are in LDS; everyone has finished the other stage
       if (c + 1 < NC) issue(tile, c + 1, stage ^ 1);
@@ -970,15 +977,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // no barrier) and leave as four 16-byte stores per lane -- element by element
     // they were 32 two-byte stores per lane scattered over eight 16-byte segments each (16 us of the launch)
     unsigned char* hst = smem256 + 2 * STAGE + w * 4096;
-    float cv[2][16];
+    float cv[EPI_MI][16];
     if (!first) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < EPI_MI; ++mi)
 #pragma unroll
         for (int i = 0; i < 16; ++i) cv[mi][i] = cs[(rg * 64 + mi * 32 + 4 * fh + 8 * (i >> 2) + (i & 3)) * 64 + cg * 32 + fr];
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < EPI_MI; ++mi) {
       const int lrow = rg * 64 + mi * 32 + 4 * fh;         // + 8 (i >> 2) + (i & 3)
       float cn[16], hn[16];
 #pragma unroll
@@ -1002,7 +1009,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       bf16_t* hf = p.o.hfrag[d];
 #pragma unroll
-      for (int pc = 0; pc < 4; ++pc) {                    // piece pc = (row block pc >> 1, 16-k group pc & 1) of this wave
+      for (int pc = 0; pc < EPI_PIECES; ++pc) {           // piece pc = (row block pc >> 1, 16-k group pc & 1) of this wave
         const u32x4 v = *reinterpret_cast<const u32x4*>(hst + ((pc * 64 + lane) << 4));
         const long rb32 = (long)rbw * 8 + rg * 2 + (pc >> 1), k16 = (jb * 2 + cg) * 2 + (pc & 1);
         *reinterpret_cast<u32x4*>(hf + ((rb32 * (H >> 4) + k16) * 64 + lane) * 8) = v;
