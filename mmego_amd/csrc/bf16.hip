@@ -849,7 +849,8 @@ template <bool HOUT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_bf16_fused256_kernel(FusedStepP p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   constexpr int STAGE = 64 * 1024;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the piece addresses below are scalar arithmetic
   const int rg = w >> 1, cg = w & 1;
   const int H = p.o.H;
   const int njb = H >> 6, nb = ntiles >> 1;               // tiles per direction
