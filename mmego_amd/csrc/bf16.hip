@@ -987,7 +987,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #pragma unroll
     for (int mi = 0; mi < EPI_MI; ++mi) {
-      const int lrow = rg * 64 + mi * 32 + 4 * fh;         // + 8 (i >> 2) + (i & 3)
       float cn[16], hn[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -997,14 +996,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         cn[i] = gf * cprev + gi * gg;
         hn[i] = go * bf_tanh(cn[i]);
       }
+      // addresses = a wave-uniform row base (scalar arithmetic) + one per-lane offset that does not depend on i
+      // addresses = a wave-uniform row base + one per-lane offset that does not depend on i
+      float* const cwave = p.o.c[d] + ((long)rbw * 256 + rg * 64 + mi * 32) * H;
+      float* const hwave = HOUT ? p.o.hout[d] + ((long)rbw * 256 + rg * 64 + mi * 32) * p.o.hos : nullptr;
+      const unsigned cl = (unsigned)(4 * fh) * (unsigned)H + (unsigned)j, hl = (unsigned)(4 * fh) * (unsigned)p.o.hos + (unsigned)j;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = rbw * 256 + lrow + 8 * (i >> 2) + (i & 3);
-        p.o.c[d][(long)row * H + j] = cn[i];
-        if (HOUT) p.o.hout[d][(long)row * p.o.hos + j] = hn[i];
+        cwave[(long)(8 * (i >> 2) + (i & 3)) * H + cl] = cn[i];
+        if (HOUT) hwave[(long)(8 * (i >> 2) + (i & 3)) * p.o.hos + hl] = hn[i];
         // piece (mi, fr >> 4) of the wave's four; inside it [k half][row % 32][8 k]
         *reinterpret_cast<bf16_t*>(hst + ((((mi * 2 + (fr >> 4)) * 64 + ((fr >> 3) & 1) * 32 + 4 * fh + 8 * (i >> 2) + (i & 3)) * 8 + (fr & 7)) << 1)) =
-            (bf16_t)f2bf_bits(hn[i]);
+            __builtin_bit_cast(bf16_t, (__bf16)hn[i]);      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN (f2bf_bits' branch per element gone)
       }
     }
     {
