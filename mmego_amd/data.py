@@ -223,6 +223,17 @@ class DeviceArrays:
             self.src[name] = torch.as_tensor(a.reshape(self.n, -1), dtype=torch.float32).to(device)
         self._out = {}
 
+    @staticmethod
+    def of(dataset, device):
+        """The device copy of ``dataset``, uploaded once per dataset OBJECT and shared by everybody who evaluates or trains on
+        it.  The copy hangs on the dataset itself (not in a table keyed by id(): an id can be reused after garbage collection), is
+        dropped with it, and is rebuilt when the dataset's length or its arrays' identity changed (a split mutated in place)."""
+        stamp = (str(device), len(dataset)) + tuple(id(dataset._items[i]) for _, i in DeviceArrays.FIELDS)
+        ent = dataset.__dict__.get("_device_arrays")
+        if ent is None or ent[0] != stamp:
+            ent = dataset.__dict__["_device_arrays"] = (stamp, DeviceArrays(dataset, device))
+        return ent[1]
+
     def gather(self, index):
         """index: int array of item numbers -> dict of device tensors [len(index), ...] (buffers reused per batch size)."""
         import torch

@@ -88,7 +88,8 @@ class gemm_group:
     launch inside the context runs immediately.  Contract (checked):
       * independent products only -- a product recorded here is not executed before the context ends, so nothing inside the
         context may read OR write what a recorded product writes (its C and asum): a pass-through launch, or a later recorded
-        product, that takes one of those pointers raises;
+        product, one of whose pointer arguments -- a tensor (any view) or a raw integer address -- falls inside the byte extent
+        of a deferred output raises;
       * the group is issued on the stream that was current at entry: a stream switch inside the context raises at exit;
       * split-K products share ops.scratch: the group entry point runs a group containing one as separate launches in recorded
         order on that one stream (mmego_gemm_group's fallback), which keeps the scratch reuse stream-ordered."""
@@ -97,7 +98,7 @@ class gemm_group:
         global _gemm_rec, _gemm_rec_outs
         if _gemm_rec is not None:
             raise RuntimeError("gemm_group contexts do not nest")
-        _gemm_rec, _gemm_rec_outs = [], set()
+        _gemm_rec, _gemm_rec_outs = [], []
         self._stream = stream_handle()
         return self
 
@@ -118,7 +119,7 @@ class gemm_group:
         return False
 
 
-_GEMM_OUT_ARGS = (6, 23)        # positions of C and asum in mmego_gemm's argument list (behind the stream)
+# (mmego_gemm's argument list behind the stream: C at 6 with strides at 7 / 8, M N K nbatch at 10..13, sCb at 16, asum at 23)
 
 
 def _launch(name, *args):
@@ -130,15 +131,40 @@ def _launch(name, *args):
         raise RuntimeError("mmego_%s failed: %s" % (name, "bad argument" if rc < 0 else "hipError %d" % rc))
 
 
+def _ptr_of(a):
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    if isinstance(a, int) and a >= (1 << 20):        # a raw device address (sizes, strides and flags are far below any mapping)
+        return a
+    return None
+
+
+def _gemm_out_extents(args):
+    """Byte ranges [lo, hi) a recorded mmego_gemm writes: C (M x N x nbatch through its strides) and asum (M floats per batch)."""
+    out = []
+    M, N, nb = int(args[10]), int(args[11]), max(1, int(args[13]))
+    c = _ptr_of(args[6])
+    if c is not None:
+        span = (M - 1) * abs(int(args[7])) + (N - 1) * abs(int(args[8])) + 1
+        for b in range(nb):              # (per batch: the batches of a pair product may lie apart, with other leaves' slots between)
+            lo = c + 4 * b * int(args[16])
+            out.append((lo, lo + 4 * span))
+    s = _ptr_of(args[23])
+    if s is not None:
+        out.append((s, s + 4 * M * nb))
+    return out
+
+
 def call(name, *args):
     """Launch `mmego_<name>` on torch's current stream (inside a gemm_group context: defer the mmego_gemm calls)."""
     if _gemm_rec is not None and name != "gemm_group":
-        ptrs = {a.data_ptr() for a in args if isinstance(a, torch.Tensor)}
-        if ptrs & _gemm_rec_outs:
-            raise RuntimeError("gemm_group: mmego_%s takes the output of a product that is still deferred inside this context "
-                               "(only independent leaves may be grouped)" % name)
+        for a in args:
+            p = _ptr_of(a)
+            if p is not None and any(lo <= p < hi for lo, hi in _gemm_rec_outs):
+                raise RuntimeError("gemm_group: mmego_%s takes the output of a product that is still deferred inside this context "
+                                   "(only independent leaves may be grouped)" % name)
         if name == "gemm":
-            _gemm_rec_outs.update(args[i].data_ptr() for i in _GEMM_OUT_ARGS if isinstance(args[i], torch.Tensor))
+            _gemm_rec_outs.extend(_gemm_out_extents(args))
             _gemm_rec.append(args)
             return
     _launch(name, *args)

@@ -70,12 +70,21 @@ class StepPlan:
 
     def record(self, body):
         """Run ``body`` with launches recorded instead of issued.  The body must be one whose every device operation goes through
-        hip.call (true of the stage bodies: DESIGN.md section 1); allocations it makes stay alive with the plan."""
+        hip.call (true of the stage bodies: DESIGN.md section 1); allocations it makes stay alive with the plan.  Stream.wait_event and
+        Event.record raise while recording (they would not be replayed); a torch compute op in the body cannot be intercepted
+        here -- tests compare run_eagerly() / replay() with the eager body to catch one.  Not thread-safe (class-wide patches)."""
         if self.built or self.segments:
             raise RuntimeError("a StepPlan records one body")
         plan = self
         self._main = torch.cuda.current_stream().cuda_stream
         orig_call, orig_wait = hip._launch, torch.cuda.Stream.wait_stream
+        orig_wait_event, orig_record = torch.cuda.Stream.wait_event, torch.cuda.Event.record
+
+        def refuse(what):
+            def raiser(*a, **k):
+                raise RuntimeError("StepPlan.record: the body called %s -- only hip.call launches and Stream.wait_stream are "
+                                   "recorded; anything else would run once now and be missing from every replay" % what)
+            return raiser
 
         def rec_call(name, *args):
             plan._segment_for(torch.cuda.current_stream()).calls.append((name, args))
@@ -86,17 +95,26 @@ class StepPlan:
                 return
             ev = plan._position_event(ko)
             plan._close(ks)                                   # what follows on the waiting stream is a new segment
-            if ev is not None:
-                plan._pending.setdefault(ks, []).append(ev)
+            mine = plan._pending.setdefault(ks, [])
+            if ev is not None and ev not in mine:
+                mine.append(ev)
+            # transitive order: waits the awaited stream has accepted but not yet launched behind (a join followed directly by a
+            # fork -- A.wait_stream(B); C.wait_stream(A) with no launch on A in between) bind the waiter too, as they do eagerly
+            # and under capture
+            for pe in plan._pending.get(ko, []):
+                if pe not in mine:
+                    mine.append(pe)
             if ks not in plan._streams:
                 plan._streams[ks] = None if ks == plan._main else self_stream
         hip._launch, torch.cuda.Stream.wait_stream = rec_call, rec_wait
+        torch.cuda.Stream.wait_event, torch.cuda.Event.record = refuse("Stream.wait_event"), refuse("Event.record")
         try:
             if hip._gemm_rec is not None:
                 raise RuntimeError("StepPlan.record inside a gemm_group context")
             body()                                            # (gemm_group contexts inside the body defer and group as always)
         finally:
             hip._launch, torch.cuda.Stream.wait_stream = orig_call, orig_wait
+            torch.cuda.Stream.wait_event, torch.cuda.Event.record = orig_wait_event, orig_record
         for k in list(self._open):
             self._close(k)
         # whatever the launching stream was told to wait for behind its last launch, and every other stream's tail: the replay ends

@@ -321,10 +321,7 @@ def _epoch_eval(base, dataset, batch_size, shuffle, rng, imu_net, upper_net, low
     Lower stage's L1(sum) loss per frame and its mean joint distance.  The split is uploaded once per dataset object
     (DeviceArrays) and minibatches are gathered on the device in the order `data.batches` would produce (same RNG use)."""
     dev = base.device
-    cache = base.__dict__.setdefault("_eval_dev", {})
-    arrays = cache.get(id(dataset))
-    if arrays is None:
-        arrays = cache[id(dataset)] = DeviceArrays(dataset, dev)
+    arrays = DeviceArrays.of(dataset, dev)                  # (one copy per split, shared with eval_imu; ADVICE r03)
     todo = list(batch_indices(len(dataset), batch_size, shuffle, rng))
     W = 30 if lower_net is None else 45
     log = torch.zeros((len(todo), W), dtype=torch.float32, device=dev)
@@ -453,8 +450,8 @@ class ImuTrainer(_Base):
         host read per epoch."""
         self.model_IMU.eval()
         dev = self.device
-        if getattr(self, "_test_dev", None) is None:
-            self._test_dev = DeviceArrays(self.test_data, dev)
+        self._test_dev = DeviceArrays.of(self.test_data, dev)
+        if getattr(self, "_head_map", None) is None:
             self._head_map = torch.tensor([20], dtype=torch.int32, device=dev)
         todo = list(batch_indices(len(self.test_data), self.batchsize, True, self._rng))
         log = torch.zeros((len(todo), 3), dtype=torch.float32, device=dev)

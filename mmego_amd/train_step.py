@@ -173,7 +173,10 @@ class StageStep:
                 R, t = s["R_gt"], s["t_gt"]
                 ops.copy2d(s["target"].view(B * T, 63)[:, 60:63], t.view(B * T, 3))
             if self.stage == "upper":
-                if via_transform:
+                from .nets_local import UpperNetwlocal
+                if isinstance(self.net, UpperNetwlocal):     # (Net/Upper_Net.py:406-432: a second state pair for the anchor branch)
+                    l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["h0"], s["c0"], s["body"], R, t, stash=True)[0]
+                elif via_transform:
                     l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["body"], R, t, stash=True, x_src=x_src)[0]
                 else:
                     l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["body"], R, t, stash=True)[0]

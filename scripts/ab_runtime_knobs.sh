@@ -14,5 +14,5 @@ run DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
 run GPU_STREAMOPS_CP_WAIT=0
 run GPU_STREAMOPS_CP_WAIT=1
 run DEBUG_HIP_DYNAMIC_QUEUES=0
-run DEBUG_HIP_DYNAMIC_QUEUES=1
+# (DEBUG_HIP_DYNAMIC_QUEUES=1 is NOT run: it aborts the process inside the HIP runtime at start-up -- r03)
 run X=0

@@ -76,3 +76,81 @@ def test_flat_gradient_allreduce_sum_and_sharding():
     assert all(r[5] for r in res), "GradBucket: both nets' gradients summed by one collective"
     assert all(r[6] is True for r in res), "broadcast_flag: rank 0's decision on every rank"
     assert res[0][3] == [0, 2, 4, 6, 8] and res[1][3] == [1, 3, 5, 7, 9]      # disjoint, exhaustive shards
+
+
+class _CpuAdam:
+    """Test stand-in for params.FusedAdam (the product optimiser is a HIP kernel): the same update rule in torch ops on the flat
+    buffers, so that the data-parallel CONTROL FLOW of a step can run on CPU ranks."""
+
+    def __init__(self, flat, lr=3e-5):
+        self.flat, self.lr, self.t = flat, lr, 0
+        self.m, self.v = torch.zeros_like(flat.flat_p), torch.zeros_like(flat.flat_p)
+
+    def step(self):
+        self.t += 1
+        g = self.flat.flat_g
+        self.m.mul_(0.9).add_(g, alpha=0.1)
+        self.v.mul_(0.999).addcmul_(g, g, value=0.001)
+        mh, vh = self.m / (1 - 0.9 ** self.t), self.v / (1 - 0.999 ** self.t)
+        self.flat.flat_p.sub_(self.lr * mh / (vh.sqrt() + 1e-8))
+
+
+def _worker_empty_shard(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmego_amd import nets, ops, train_step
+    from mmego_amd.params import FlatParams
+    ops.fill = lambda t, v: t.fill_(v)                     # (CPU stand-in for the device fill kernel: test-side only)
+    torch.manual_seed(5)
+    net = nets.UpperNet()
+    flat = net.flat()                                      # (the net's own flat buffers: what empty_step works on)
+    opt = _CpuAdam(flat)
+    gen = torch.Generator().manual_seed(77)
+    steps = []
+    for it in range(3):
+        g_full = torch.randn(flat.flat_g.shape, generator=gen)      # the same stream on both ranks
+        # a short last global minibatch: only rank 0 owns sequences in step 1 (rank 1's shard is empty); in steps 0 and 2 both
+        # ranks hold half of the gradient
+        if it == 1:
+            if rank == 0:
+                flat.flat_g.copy_(g_full)
+                train_step.allreduce_grads(flat, dist.group.WORLD)
+                opt.step()
+            else:
+                flat.flat_g.fill_(123.0)                   # stale content of the last backward: empty_step must zero it
+                train_step.empty_step(net, opt, dist.group.WORLD)
+        else:
+            flat.flat_g.copy_(g_full * (0.25 if rank == 0 else 0.75))
+            train_step.allreduce_grads(flat, dist.group.WORLD)
+            opt.step()
+        steps.append(flat.flat_p.clone())
+    # single-process reference: the full gradient every step
+    torch.manual_seed(5)
+    ref_net = nets.UpperNet()
+    ref_flat = FlatParams(ref_net).ensure()
+    ref_opt = _CpuAdam(ref_flat)
+    gen = torch.Generator().manual_seed(77)
+    for it in range(3):
+        g_full = torch.randn(ref_flat.flat_g.shape, generator=gen)
+        ref_flat.flat_g.copy_(g_full * 0.25 + g_full * 0.75 if it != 1 else g_full)
+        ref_opt.step()
+    q.put((rank, [s.numpy().tobytes() for s in steps], torch.equal(steps[-1], ref_flat.flat_p), opt.t))
+    dist.destroy_process_group()
+
+
+def test_rank_with_an_empty_last_shard_stays_bit_equal():
+    """train_step.empty_step (a rank whose shard of a short last global minibatch is empty): zero gradient into the SUM, the same
+    optimiser update -- both ranks' parameters stay bit-equal through and after that step, and equal a one-process run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_empty_shard, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1], "replicas parted ways around the empty-shard step"
+    assert res[0][2] and res[1][2], "data-parallel run != single-process run on the full gradient"
+    assert res[0][3] == res[1][3] == 3, "every rank took every optimiser step"
