@@ -417,7 +417,7 @@ def call_breakdown(body, iters=3):
     return dict(sorted(out.items(), key=lambda kv: -kv[1]["us"]))
 
 
-def wlocal_figures(device, cpu_steps=3, with_cpu=True):
+def wlocal_figures(device, cpu_steps=3, with_cpu=True, trace_only=False):
     """The UpperNetwlocal path (Net/Upper_Net.py:406-432: UpperNet plus the anchor / "voxel" branch -- grouping of the 8 nearest
     points around each of 27 anchors, per-group PointNet with softmax pooling, the 3x3x3 Conv3d extractor, a second BiLSTM), which
     no reference trainer constructs: reported separately from the headline.  One training step (forward, L1(sum)
@@ -431,11 +431,13 @@ def wlocal_figures(device, cpu_steps=3, with_cpu=True):
     x, imu_in, body, target = synth_batch(1234, device)
     g = torch.Generator().manual_seed(9)
     Rg = torch.linalg.qr(torch.randn(B, T, 3, 3, generator=g))[0].contiguous().to(device)
-    st = StageStep("upper", net, None, lr=3e-5, use_graph=True)
+    st = StageStep("upper", net, None, lr=3e-5, use_graph=os.environ.get("MMEGO_WLOCAL_EAGER") != "1")   # (eager: PMC passes)
     st.bind(x, imu_in, body, target, R_gt=Rg)
     st.prepare()
     ms_train = _time_events(st.step, 50, 5)
     loss = float(st.loss.item())
+    if trace_only:                       # (clean input for rocprofv3: graph replays of the training step only)
+        return {"trace_only": True, "train_ms_per_step": ms_train, "train_loss": loss}
     st_e = StageStep("upper", net, None, lr=3e-5, use_graph=False)
     st_e.bind(x, imu_in, body, target, R_gt=Rg)
     calls = call_breakdown(st_e._body)
@@ -643,7 +645,7 @@ def main():
     from mmego_amd.train_step import ConcurrentStages, StageStep
     hip.lib()
     if args.wlocal_only:
-        print(json.dumps({"wlocal": wlocal_figures(device, with_cpu=not args.no_cpu_baseline)}))
+        print(json.dumps({"wlocal": wlocal_figures(device, with_cpu=not args.no_cpu_baseline, trace_only=args.trace_only)}))
         return
     imu, upper, lower, upper_frozen = build_hip_models(device)
     imu_l = clone_imu(imu, device)

@@ -36,8 +36,13 @@ def build_library(force=False, verbose=True):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    newest_h = max([os.path.getmtime(h) for h in headers] + [os.path.getmtime(os.path.abspath(__file__))])
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_h):
+            return obj                  # (object newer than its source, every header and this recipe: keep it)
         cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -138,3 +138,28 @@ def test_optimizer_state_survives_a_flat_layout_change():
     other = FusedAdam(FlatParams(torch.nn.Linear(4, 4)))
     with pytest.raises(ValueError, match="another net"):
         other.load_state_dict(src.state_dict())
+
+
+def test_gemm_group_refuses_views_and_raw_addresses_of_deferred_outputs(monkeypatch):
+    """hip.gemm_group: a launch inside the context one of whose pointer arguments -- a raw integer address or any
+    view -- falls inside the byte extent of a deferred product's C / asum raises BEFORE anything is launched (no GPU needed)."""
+    from mmego_amd import hip
+    monkeypatch.setattr(hip, "stream_handle", lambda: 0)                  # (no GPU here: nothing below reaches a launch)
+    base = 0x7f0000000000
+    M, N, K = 64, 32, 128
+    gemm = lambda C, asum=None, nb=1, sCb=0: ("gemm", base, K, 1, base + (1 << 24), 1, K, C, N, 1, None, M, N, K, nb, 0, 0, sCb, 0, 0, None, 1, 0,
+                                            None, asum)
+    C = base + (2 << 24)
+    for bad in (C, C + 4 * (M * N - 1), C + 4 * 100):                     # first / last / an interior element of C
+        with pytest.raises(RuntimeError, match="still deferred"):
+            with hip.gemm_group():
+                hip.call(*gemm(C))
+                hip.call("fill", bad, 16, 0.0)
+    with pytest.raises(RuntimeError, match="still deferred"):             # a later product reading a deferred asum
+        with hip.gemm_group():
+            hip.call(*gemm(C, asum=base + (3 << 24)))
+            hip.call(*gemm(base + (4 << 24))[:1], base + (3 << 24) + 8, *gemm(base + (4 << 24))[2:])
+    # a pair product's two batches lie apart: what sits BETWEEN them is not part of its extent
+    ext = hip._gemm_out_extents(gemm(C, nb=2, sCb=4 * M * N)[1:])
+    assert ext == [(C, C + 4 * M * N), (C + 16 * M * N, C + 20 * M * N)]
+    assert hip._gemm_rec is None and hip._gemm_rec_outs is None           # the failed contexts left no recorder behind
