@@ -394,6 +394,75 @@ int mmego_mlp_bwd_layer(void* stream, const float* dY, long lddy, const float* Z
 int mmego_mlp_dw_reduce(void* stream, long rows, int nlayers, const float* part0, float* dW0, int Cout0, int Cin0,
                         const float* part1, float* dW1, int Cout1, int Cin1, const float* part2, float* dW2, int Cout2, int Cin2);
 
+/* ---- fused ST-GCN training step (gcn_fused.hip, gcn.hip): Net/GCN.py:67-147 st_gcn, :332-355 Model.extract_feature -----------------
+ * Train-mode BatchNorm statistics travel between these kernels as PARTIAL RECORDS: per producer workgroup j and channel c the float
+ * pair rec[j][c] = (mean_j, M2_j) over the rows the workgroup owns (rows_per_rec each, the last record ragged).  The consumer finalizes
+ * them in its prologue (every workgroup, fixed order); workgroup 0 writes state [4][C] = mean, invstd, a, b and updates the running
+ * statistics with torch's semantics.  Replaces the colstats / bn_finalize / affine_act launches between the products. */
+typedef struct MmegoBnRef {
+  const float* rec; int nrec; int rows_per_rec;
+  const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum; float eps;
+  float* state;
+} MmegoBnRef;
+/* One launch per st_gcn block front: [in_mode 1: x = relu(bn1(X1) + bn2(X2)), both BatchNorms from records | in_mode 0: x =
+ * data_bn(X1), X1 = the frame tensor [F][V*cin], statistics computed by the kernel itself (F <= 1024)] -> xact [F*V][cin] (kept for
+ * backward; may be NULL) -> zr = x W^T + bias, W [nout][cin] the stacked weight of the graph convolution's and the residual branch's
+ * 1x1 convs -> mix = 1: Z [F*V][(K+1) cout] = zr, Y [F*V][cout] = einsum('nkctv,kvw->nctw', z, A . importance), recY / recR
+ * [mmego_gcn_front_nrec(F)][cout]: records of Y and of the residual columns of Z (4 frames = 4 V rows per record); mix = 0: the
+ * closing 1x1 conv, stored transposed outT[b][nout][T*V] (GCN.py:351-353, the re-viewed layout).  cin in {<32 with in_mode 0, 32,
+ * 64, 128}; nout a multiple of 32 (<= 384 with cin <= 64). */
+typedef struct MmegoGcnFront {
+  const float* X1; long ld1; const float* X2; long ld2; int in_mode;
+  MmegoBnRef bn1, bn2;
+  float* xact;
+  const float* W; const float* bias; int cin, nout;
+  int mix, K, cout; const float* A; const float* importance;
+  float* Z; long ldz; float* Y; float* recY; float* recR;
+  float* outT; int T;
+  long F; int V;
+} MmegoGcnFront;
+int mmego_gcn_front_nrec(long F);
+int mmego_gcn_front(void* stream, const void* desc);
+/* mmego_tconv in the fused training step: in_bn = MmegoBnRef of the BatchNorm (+ReLU) in front, out_rec [ceil(rows/64)][Cout] =
+ * records of the output for the BatchNorm behind; mmego_tconv_bwd_stats = the input-gradient call (X = dY, gradient pack) whose
+ * epilogue leaves bw_rec [ceil(rows/64)][Cout] = (sum g, sum g xhat), g = dAct . [bn(ymix) > 0], for the BatchNorm + ReLU in front of
+ * the convolution's input (state [4][Cout]).  mmego_tconv_pack_multi: mode-2 packs of up to three weights in one launch. */
+int mmego_tconv_train(void* stream, const float* X, long ldx, const void* in_bn, const float* Wp, const float* bias, float* Y,
+                      long ldy, float* act, float* out_rec, int B, int T, int V, int Cin, int Cout, int taps);
+int mmego_tconv_bwd_stats(void* stream, const float* dY, long lddy, const float* Wp, float* dAct, long ldda, const float* ymix,
+                          long ldym, const float* state, float* bw_rec, int B, int T, int V, int Cin, int Cout, int taps);
+int mmego_tconv_pack_multi(void* stream, int n, const float* W0, float* Wp0, int Co0, int Ci0, const float* W1, float* Wp1,
+                           int Co1, int Ci1, const float* W2, float* Wp2, int Co2, int Ci2, int taps);
+/* Backward of a block's closing pair out = relu(BN(X1) + BN(X2)) (same dY, mask = out): reduce -> rec [ceil(rows/64)][2C] (sum g, sum
+ * g xhat), virtual channels [0, C) = first BatchNorm, [C, 2C) = second; apply: finalize in the prologue, dX = a (g - mean(g) - xhat
+ * mean(g xhat)) for both, d(gamma) / d(beta) by workgroup 0.  st1 / st2: state [4][C].  C % 4 == 0, C <= 128. */
+int mmego_gcn_bn_bwd_reduce(void* stream, const float* dY, long lddy, const float* mask, long ldm, const float* X1, long ld1,
+                            const float* st1, const float* X2, long ld2, const float* st2, long rows, int C, float* rec);
+int mmego_gcn_bn_bwd_apply(void* stream, const float* dY, long lddy, const float* mask, long ldm, const float* X1, long ld1,
+                           const float* st1, const float* X2, long ld2, const float* st2, long rows, int C, const float* rec,
+                           float* dgamma1, float* dbeta1, float* dX1, long lddx1, float* dgamma2, float* dbeta2, float* dX2,
+                           long lddx2);
+/* mmego_graph_dA with the backward of the BatchNorm + ReLU behind the einsum applied on load: dY0 = gradient of the activated rows,
+ * Ymix = the einsum output (pre-BatchNorm), st0 = that BatchNorm's state, rec [nrec][C] = mmego_tconv_bwd_stats' records; writes
+ * d(gamma), d(beta), the dA partials [mmego_graph_dA_fused_nblk(G)][K*V*V] and dZ. */
+int mmego_graph_dA_fused_nblk(long G);
+int mmego_graph_dA_fused(void* stream, const float* Z, long ldz, const float* dY0, const float* Ymix, const float* st0,
+                         const float* rec, int nrec, float* dgamma0, float* dbeta0, long G, int V, int K, int C,
+                         float* partial_ws, const float* A, const float* imp, float* dZ, long lddz);
+/* ONE launch for the deferred partial-product sums of a backward pass (fixed order).  kind 0: split-K slabs ws[nsplit][M*N] ->
+ * out[m*scm + n] (what mmego_gemm leaves with accumulate = 2; asum != NULL: the slab row sums ws[nsplit*M*N + k*M + m] -> asum[m]);
+ * kind 1: mmego_tconv_wgrad's slabs (accumulate = 2) ws[nsplit][taps][Co][Ci] -> out[co][ci][tap], M = taps*Co, N = Ci; kind 2:
+ * out[i] = scale[i] * sum_k ws[k][i], M = 1 (edge-importance gradient from mmego_graph_dA's partials).  n <= 24. */
+typedef struct MmegoSlab {
+  const float* ws; float* out; const float* scale; float* asum;
+  int kind, nsplit, M, N, taps; long scm;
+} MmegoSlab;
+int mmego_slab_reduce(void* stream, int n, const void* descs);
+/* d(gamma)[c] = sum_r dY[r][c] xhat[r][c], d(beta)[c] = sum_r dY[r][c] of a BatchNorm whose input gradient is not needed (data_bn,
+ * GCN.py:310: the skeleton input is detached, Train_Lower.py:196); state [4][C]. */
+int mmego_bn_param_grads(void* stream, const float* dY, long lddy, const float* X, long ldx, const float* state, long rows, int C,
+                         float* dgamma, float* dbeta);
+
 /* ---- optimiser (optim.hip) -------------------------------------------------------------------------
  * torch.optim.Adam step (coupled L2 weight decay) over one flat buffer; state = 3 doubles on the device
  * {step, lr/(1-b1^t), sqrt(1-b2^t)}, advanced by the call itself so a captured graph replays correctly

@@ -17,7 +17,7 @@
 //   tconv_wgrad  the weight gradient, implicit too: per tap a product over the row axis of dY and the shifted activated rows,
 //                row axis split over workgroups, partial tiles added in a fixed order.
 // 64 x 64 output tiles, v_mfma_f32_32x32x2_f32, operands in LDS, next chunk prefetched in registers.
-#include "common.h"
+#include "gcn_stats.h"
 
 #define GC_S 66          // even row stride: fragments are read as aligned float2 (lanes r = 0..31 hit 64 distinct banks)
 
@@ -90,6 +90,12 @@ struct TconvP {
   float* act;                        // optional [rows][Cin]: the activated input (kept for the backward pass), written from the
                                      // centre tap's tile loads by the workgroups of the first column tile
   long rows; int T, V, Cin, Cout, taps;
+  // fused training step (REC; gcn_fused.hip): the BatchNorm in front comes as partial records and is finalized in the prologue
+  // (in_state unused), and the output tile's own (mean, M2) per column leaves as out_rec[row tile][Cout]
+  BnRefD in_bn; float2* out_rec;
+  // backward statistics epilogue (input-gradient call, Y = d(act)): with g = Y . [bn(ym) > 0], xhat = (ym - mean) invstd of the
+  // BatchNorm whose state is bw_st [4][Cout], bw_rec[row tile][Cout] = (sum g, sum g xhat) over the tile's rows
+  const float* bw_ym; long ldym; const float* bw_st; float2* bw_rec;
 };
 
 // acc[32x32] += A[32 rows][K] . B[32 rows][K]^T (row-major LDS tiles, stride GC_S), K a multiple of 4 (zero padded).
@@ -103,10 +109,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // kernel waiting on 9-18 dependent memory round trips), NG = 1 when the grid alone fills the chip.
 // Tile loads: 16-byte loads from CLAMPED addresses, all eight of a step issued before the first is used, masks applied to the
 // values afterwards (a predicate on the load itself compiles to branch + load + wait: one memory round trip per load).
-template <int NG, bool ACT>
+template <int NG, bool ACT, bool REC = false>
 __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = t >> 6;
+  float* stl = smem + NG * 2 * 64 * GC_S;                  // REC: [4][Cin] mean, a, b, invstd of the BatchNorm in front
+  if (REC) bn_from_records<256 * NG>(p.in_bn, p.Cin, p.rows, reinterpret_cast<double*>(smem), stl, blockIdx.x == 0 && blockIdx.y == 0);
   float* As = smem + grp * 2 * 64 * GC_S;
   float* Bs = As + 64 * GC_S;
   const int rt = wave & 1, ct = wave >> 1;
@@ -141,7 +149,11 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
     const int d_ = tap_ - half;                                                                     \
     const int kk_ = k0_ + 4 * c4;                                                                   \
     const int kc_ = kk_ < p.Cin ? kk_ : 0;                                                          \
-    if (ACT) {                                                                                      \
+    if (ACT && REC) {                                                                               \
+      mu = *reinterpret_cast<const f32x4*>(stl + kc_);                                              \
+      sa = *reinterpret_cast<const f32x4*>(stl + p.Cin + kc_);                                      \
+      sb = *reinterpret_cast<const f32x4*>(stl + 2 * p.Cin + kc_);                                  \
+    } else if (ACT) {                                                                               \
       mu = *reinterpret_cast<const f32x4*>(p.in_state + kc_);                                       \
       sa = *reinterpret_cast<const f32x4*>(p.in_state + 2 * p.Cin + kc_);                           \
       sb = *reinterpret_cast<const f32x4*>(p.in_state + 3 * p.Cin + kc_);                           \
@@ -228,15 +240,16 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
         xch[((grp - 1) * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 64 + lcol] = acc[reg];
     }
     __syncthreads();
-    if (grp > 0) return;
+    if (grp == 0) {
 #pragma unroll
-    for (int g = 1; g < NG; ++g)
+      for (int g = 1; g < NG; ++g)
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg)
-        acc[reg] += xch[((g - 1) * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 64 + lcol];
+        for (int reg = 0; reg < 16; ++reg)
+          acc[reg] += xch[((g - 1) * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 64 + lcol];
+    }
   }
   const int col = n0 + lcol;
-  if (col < p.Cout) {
+  if (grp == 0 && col < p.Cout) {
     const float bb = p.bias ? p.bias[col] : 0.f;
     float* yp = p.Y + (r0 + rt * 32 + 4 * (lane >> 5)) * p.ldy + col;
 #pragma unroll
@@ -252,6 +265,58 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
         const long row = r0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
         if (row < p.rows) yp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldy] = acc[reg];
       }
+    }
+  }
+  if (p.out_rec || p.bw_rec) {
+    // statistics of the output tile for the BatchNorm behind it (forward) / of the BatchNorm + ReLU the gradient passes next
+    // (backward): the tile goes through LDS once, thread (column, row quarter) walks 16 rows, quarters added in a fixed order
+    __syncthreads();                                       // (the exchange tiles above have been read)
+    float* tl = smem;                                      // [64][65]
+    float* part = smem + 64 * 65;                          // [4][64][2]
+    if (grp == 0) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) tl[(rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 65 + lcol] = acc[reg];
+    }
+    __syncthreads();
+    const int cx = t & 63, rq = t >> 6;
+    const int nvr = (int)(p.rows - r0 < 64 ? p.rows - r0 : 64);
+    const int cg = n0 + cx < p.Cout ? n0 + cx : p.Cout - 1;
+    float s1 = 0.f, s2 = 0.f;
+    if (grp == 0) {
+      if (p.out_rec) {                                     // shifted sums: (mean, M2) of the column over the tile's valid rows
+        const float shift = tl[cx];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int row = rq * 16 + u;
+          const float d = row < nvr ? tl[row * 65 + cx] - shift : 0.f;
+          s1 += d; s2 = __builtin_fmaf(d, d, s2);
+        }
+      } else {
+        const float mu_ = p.bw_st[cg], is_ = p.bw_st[p.Cout + cg], a_ = p.bw_st[2 * p.Cout + cg], b_ = p.bw_st[3 * p.Cout + cg];
+        float ym[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const long row = r0 + rq * 16 + u;
+          ym[u] = p.bw_ym[(row < p.rows ? row : p.rows - 1) * p.ldym + cg];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          asm volatile("" : "+v"(ym[u]));
+          const int row = rq * 16 + u;
+          const float g = (row < nvr && __builtin_fmaf(ym[u] - mu_, a_, b_) > 0.f) ? tl[row * 65 + cx] : 0.f;
+          s1 += g;
+          s2 += g * ((ym[u] - mu_) * is_);
+        }
+      }
+      part[(rq * 64 + cx) * 2] = s1; part[(rq * 64 + cx) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (grp == 0 && rq == 0 && n0 + cx < p.Cout) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a += part[(j * 64 + cx) * 2]; b += part[(j * 64 + cx) * 2 + 1]; }
+      if (p.out_rec) p.out_rec[(long)blockIdx.x * p.Cout + n0 + cx] = rec_from_shifted(tl[cx], a, b, nvr);
+      else p.bw_rec[(long)blockIdx.x * p.Cout + n0 + cx] = float2{a, b};
     }
   }
 }
@@ -453,6 +518,35 @@ extern "C" int mmego_tconv_pack(void* stream, const float* W, int Co, int Ci, in
   return MMEGO_OK;
 }
 
+static int tconv_launch(hipStream_t st, TconvP& p, bool rec) {
+  dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.Cout + 63) / 64));
+  const size_t extra = rec ? (size_t)4 * p.Cin * sizeof(float) : 0;
+  const bool act = rec || p.in_state;
+  if ((long)grid.x * grid.y <= 512) {                      // small grid: four steps in flight per workgroup
+    const size_t lds = (size_t)4 * 2 * 64 * GC_S * sizeof(float) + extra;
+    static bool attr = false;
+    if (!attr) {
+      const int mx = (int)((size_t)4 * 2 * 64 * GC_S * sizeof(float) + 4 * 256 * sizeof(float));
+      hipError_t e = hipFuncSetAttribute((const void*)tconv_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tconv_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tconv_kernel<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+      if (e != hipSuccess) return (int)e;
+      attr = true;
+    }
+    if (rec) hipLaunchKernelGGL((tconv_kernel<4, true, true>), grid, dim3(1024), lds, st, p);
+    else if (act) hipLaunchKernelGGL((tconv_kernel<4, true>), grid, dim3(1024), lds, st, p);
+    else hipLaunchKernelGGL((tconv_kernel<4, false>), grid, dim3(1024), lds, st, p);
+  } else {
+    // (one step in flight: the prologue scratch of the record form needs 32 KB, the operand tiles are 33 KB)
+    const size_t lds = (size_t)2 * 64 * GC_S * sizeof(float) + extra;
+    if (rec) hipLaunchKernelGGL((tconv_kernel<1, true, true>), grid, dim3(256), lds, st, p);
+    else if (act) hipLaunchKernelGGL((tconv_kernel<1, true>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((tconv_kernel<1, false>), grid, dim3(256), lds, st, p);
+  }
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
 extern "C" int mmego_tconv(void* stream, const float* X, long ldx, const float* in_state, const float* Wp, const float* bias, float* Y,
                            long ldy, float* act, int B, int T, int V, int Cin, int Cout, int taps) {
   MMEGO_REQUIRE((long)B * T * V * ldx < (1L << 30) && (long)Cout * Cin < (1L << 30));   // (32-bit element offsets)
@@ -460,24 +554,72 @@ extern "C" int mmego_tconv(void* stream, const float* X, long ldx, const float* 
   MMEGO_REQUIRE((Cin % 4) == 0 && (ldx % 4) == 0 && (((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)in_state | (uintptr_t)act) & 15) == 0);
   MMEGO_REQUIRE(!act || in_state);
   TconvP p = {X, ldx, in_state, Wp, bias, Y, ldy, act, (long)B * T * V, T, V, Cin, Cout, taps};
-  dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((Cout + 63) / 64));
-  hipStream_t st = (hipStream_t)stream;
-  if ((long)grid.x * grid.y <= 512) {                      // small grid: four steps in flight per workgroup
-    const size_t lds = (size_t)4 * 2 * 64 * GC_S * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)tconv_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tconv_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      attr = true;
-    }
-    if (in_state) hipLaunchKernelGGL((tconv_kernel<4, true>), grid, dim3(1024), lds, st, p);
-    else hipLaunchKernelGGL((tconv_kernel<4, false>), grid, dim3(1024), lds, st, p);
-  } else {
-    const size_t lds = (size_t)2 * 64 * GC_S * sizeof(float);
-    if (in_state) hipLaunchKernelGGL((tconv_kernel<1, true>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((tconv_kernel<1, false>), grid, dim3(256), lds, st, p);
+  return tconv_launch((hipStream_t)stream, p, false);
+}
+
+// Training forward of the fused step: the BatchNorm (+ ReLU) in front is given by its partial records (finalized in the prologue by
+// every workgroup; workgroup 0 writes its state and updates the running statistics), the activated rows are kept in `act`, and the
+// (mean, M2) records of the OUTPUT's columns per 64-row tile go to out_rec[ceil(rows / 64)][Cout] for the BatchNorm behind.
+extern "C" int mmego_tconv_train(void* stream, const float* X, long ldx, const void* in_bn, const float* Wp, const float* bias, float* Y,
+                                 long ldy, float* act, float* out_rec, int B, int T, int V, int Cin, int Cout, int taps) {
+  const MmegoBnRefH* h = static_cast<const MmegoBnRefH*>(in_bn);
+  MMEGO_REQUIRE((long)B * T * V * ldx < (1L << 30) && (long)Cout * Cin < (1L << 30));
+  MMEGO_REQUIRE(X && h && Wp && Y && out_rec && B > 0 && T > 0 && V > 0 && Cin >= 4 && Cin <= 256 && Cout >= 1 && taps >= 1 && (taps & 1) &&
+                ldx >= Cin && ldy >= Cout);
+  MMEGO_REQUIRE((Cin % 4) == 0 && (ldx % 4) == 0 && (((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)act) & 15) == 0);
+  MMEGO_REQUIRE(h->rec && h->nrec >= 1 && h->rows_per_rec >= 1 && h->gamma && h->beta && (h->running_mean == nullptr) == (h->running_var == nullptr));
+  TconvP p = {X, ldx, nullptr, Wp, bias, Y, ldy, act, (long)B * T * V, T, V, Cin, Cout, taps};
+  p.in_bn = bnref_device(h);
+  p.out_rec = reinterpret_cast<float2*>(out_rec);
+  return tconv_launch((hipStream_t)stream, p, true);
+}
+
+// Input gradient of the temporal convolution (X = dY, Wp = the gradient pack, Y = d(act) [rows][Cout]) with the backward sums of the
+// BatchNorm + ReLU in front of the convolution's input taken in the epilogue: bw_rec[ceil(rows / 64)][Cout] = (sum g, sum g xhat) per
+// 64-row tile with g = Y . [bn(ymix) > 0], xhat = (ymix - mean) invstd, state = [4][Cout] mean, invstd, a, b of that BatchNorm.
+extern "C" int mmego_tconv_bwd_stats(void* stream, const float* dY, long lddy, const float* Wp, float* dAct, long ldda, const float* ymix,
+                                     long ldym, const float* state, float* bw_rec, int B, int T, int V, int Cin, int Cout, int taps) {
+  MMEGO_REQUIRE((long)B * T * V * lddy < (1L << 30) && (long)Cout * Cin < (1L << 30));
+  MMEGO_REQUIRE(dY && Wp && dAct && ymix && state && bw_rec && B > 0 && T > 0 && V > 0 && Cin >= 4 && Cout >= 1 && taps >= 1 && (taps & 1) &&
+                lddy >= Cin && ldda >= Cout && ldym >= Cout);
+  MMEGO_REQUIRE((Cin % 4) == 0 && (lddy % 4) == 0 && (((uintptr_t)dY | (uintptr_t)Wp) & 15) == 0);
+  TconvP p = {dY, lddy, nullptr, Wp, nullptr, dAct, ldda, nullptr, (long)B * T * V, T, V, Cin, Cout, taps};
+  p.bw_ym = ymix; p.ldym = ldym; p.bw_st = state; p.bw_rec = reinterpret_cast<float2*>(bw_rec);
+  return tconv_launch((hipStream_t)stream, p, false);
+}
+
+// Up to four temporal-conv weights packed by ONE launch (mode 2 of mmego_tconv_pack each: forward pack, gradient pack behind it)
+struct PackTab { const float* W[4]; float* Wp[4]; int Co[4], Ci[4], blk0[5]; int taps, n; };
+__global__ __launch_bounds__(256) void tconv_pack_multi_kernel(PackTab t) {
+  int k = 0;
+  while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
+  const int Co = t.Co[k], Ci = t.Ci[k], taps = t.taps;
+  const long total = (long)Co * Ci * taps;
+  const long i = (long)(blockIdx.x - t.blk0[k]) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int tap = (int)(i % taps);
+  const long q = i / taps;
+  const int ci = (int)(q % Ci), co = (int)(q / Ci);
+  const float w = t.W[k][i];
+  t.Wp[k][((long)tap * Co + co) * Ci + ci] = w;
+  t.Wp[k][total + ((long)(taps - 1 - tap) * Ci + ci) * Co + co] = w;
+}
+
+extern "C" int mmego_tconv_pack_multi(void* stream, int n, const float* W0, float* Wp0, int Co0, int Ci0, const float* W1, float* Wp1,
+                                      int Co1, int Ci1, const float* W2, float* Wp2, int Co2, int Ci2, int taps) {
+  MMEGO_REQUIRE(n >= 1 && n <= 3 && taps >= 1 && W0 && Wp0);
+  PackTab t;
+  const float* W[3] = {W0, W1, W2};
+  float* Wp[3] = {Wp0, Wp1, Wp2};
+  const int Co[3] = {Co0, Co1, Co2}, Ci[3] = {Ci0, Ci1, Ci2};
+  int blk = 0;
+  for (int k = 0; k < n; ++k) {
+    MMEGO_REQUIRE(W[k] && Wp[k] && Co[k] >= 1 && Ci[k] >= 1);
+    t.W[k] = W[k]; t.Wp[k] = Wp[k]; t.Co[k] = Co[k]; t.Ci[k] = Ci[k]; t.blk0[k] = blk;
+    blk += (int)(((long)Co[k] * Ci[k] * taps + 255) / 256);
   }
+  t.blk0[n] = blk; t.taps = taps; t.n = n;
+  hipLaunchKernelGGL(tconv_pack_multi_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, t);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
@@ -524,6 +666,7 @@ extern "C" int mmego_tconv_wgrad(void* stream, const float* dY, long lddy, const
   if (Cin <= 32 && Cout <= 32) hipLaunchKernelGGL(tconv_wgrad_kernel<true>, grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL(tconv_wgrad_kernel<false>, grid, dim3(256), lds, st, p);
   MMEGO_LAUNCH_CHECK();
+  if (accumulate == 2) return MMEGO_OK;                    // deferred: the slabs stay in ws for mmego_slab_reduce (kind 1)
   long b = ((long)taps * Cin * Cout + 255) / 256;
   hipLaunchKernelGGL(tconv_wgrad_reduce_kernel, dim3((int)(b > 1024 ? 1024 : b)), dim3(256), 0, st, ws, ns, taps, Cout, Cin, dW, accumulate);
   MMEGO_LAUNCH_CHECK();

@@ -1,0 +1,741 @@
+// Fused training-step kernels of the ST-GCN inside Lower_Net's KeyEncoder (reference Net/GCN.py:67-147 st_gcn, :55-64
+// ConvTemporalGraphical, :332-355 Model.extract_feature), channels-last rows (b, t, v).
+//
+// The reference's block is  1x1 conv -> einsum with A.importance -> BN -> ReLU -> 9x1 temporal conv -> BN, + residual(1x1 conv -> BN),
+// ReLU.  Train-mode BatchNorm needs every row of its input before anything behind it can run, so the block has TWO grid-wide
+// synchronisation points forward (behind the einsum, behind the temporal conv) and two backward -- those stay kernel boundaries.
+// Everything else that used to be a launch of its own between them is folded into the producer or the consumer:
+//   gcn_front      [finalize the previous block's two closing BatchNorms from partial records] -> relu(BN(tcn) + BN(residual)) applied
+//                  while the 4-frame input tile is loaded (the activated rows are kept for backward) -> the stacked 1x1 conv of the graph
+//                  convolution and the residual branch (one MFMA product) -> the einsum on 16x16x4 MFMAs straight from the product's
+//                  LDS tile -> z, the residual pre-activation and the einsum output leave together with their BatchNorm partial records.
+//                  Block 0 computes data_bn's batch statistics itself (the frame tensor is 92 KB); with mix = 0 the same kernel is the
+//                  closing 1x1 conv `fcn` with its transposed store (the re-viewed output layout, Q8).
+//                  Replaces per block: affine_act + product + graph_mix + colstats + 2 bn_finalize  (6 launches -> 1).
+//   (tconv, gcn.hip: statistics of the BatchNorm in front finalized in its prologue, its own output's records in the epilogue; in
+//   the backward pass the sums of the BatchNorm behind the einsum leave with the input gradient's epilogue)
+//   gcn_bn_bwd_reduce / gcn_bn_bwd_apply   the closing BatchNorm pair's backward: reduce to <= 128 records, then finalize-in-prologue +
+//                  apply in one launch (3 launches -> 2; d(gamma), d(beta) by workgroup 0)
+//   graph_dA_fused finalize + apply of the BatchNorm behind the einsum while the frame's rows are loaded, then both gradients of
+//                  the einsum (bn reduce + finalize + apply + graph_dA: 4 launches -> 1 with tconv's epilogue)
+//   slab_reduce    every split-K / split-row partial product of a backward pass summed by ONE launch at its end (fixed order)
+//   bn_param_grads data_bn's d(gamma), d(beta) alone (its input gradient is never used: the skeleton input is detached)
+// All reductions have a fixed order: results are bit-identical from run to run and between the graph / eager engines.
+#include "gcn_stats.h"
+
+#define GF_NT 512          // threads of gcn_front
+#define GF_FPB 4           // frames per workgroup: <= 128 records per BatchNorm at the training shape (512 frames)
+#define GF_ST 1024         // floats of statistics state in LDS: [2][4][128]
+
+struct GcnFrontD {
+  const float* X1; long ld1; const float* X2; long ld2;
+  int in_mode;             // 0: data_bn over the frame tensor X1 [F][V*cin], statistics computed here; 1: relu(bn1(X1) + bn2(X2))
+  BnRefD bn1, bn2;
+  float* xact;             // [rows][cin]: the activated input (the previous block's output / the normalised skeleton), or null
+  const float* W; const float* bias; int cin, nout;        // stacked weight [nout][cin]
+  int mix, Kk, cout; const float* A; const float* imp;
+  float* Z; long ldz;      // mix: [rows][(Kk + 1) cout] = (z | residual pre-activation)
+  float* Y;                // mix: einsum output [rows][cout]
+  float2* recY; float2* recR;
+  float* outT; int T;      // mix = 0: product stored transposed, outT[b][nout][T*V]
+  long F; int V;
+};
+
+// NCTW: 32-column tiles of the product per wave pair (4 wave pairs x 2 row halves); NK: 32-k chunks (0: scalar product, cin < 32)
+template <int NCTW, int NK>
+__global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = p.V, cin = p.cin, nout = p.nout, cout = p.cout;
+  const long f0 = (long)blockIdx.x * GF_FPB;
+  const int nf = (int)(p.F - f0 < GF_FPB ? p.F - f0 : GF_FPB);
+  const int nv = nf * V;                                 // valid rows of this tile (<= 60)
+  const long r0 = f0 * V, rows = p.F * V;
+  const int XS = (NK ? cin : 4) + 4, ZS = nout + 16, YS = cout + 4;
+  float* st = sm;                                        // [2][4][cin]: mean, a, b, invstd of bn1 | bn2 (bn_from_records)
+  float* zs = sm + GF_ST;                                // [64][ZS] product tile
+  float* xs = zs + 64 * ZS;                              // [64][XS] input tile; later ys [60][YS]
+  float* ys = xs;
+  double* red = reinterpret_cast<double*>(xs);
+  const bool first = blockIdx.x == 0;
+
+  // ---- the product's weight fragments: requested first, they fly under the statistics prologue.  Lane (r, h) of a 32x32x2 MFMA
+  // takes k = k0 + 16 h + s on BOTH operands (same permutation: the sum over k is unchanged), so a weight row's 16 values are
+  // four 16-byte loads straight into the operand registers -- no LDS staging of W.
+  const int r = lane & 31, h = lane >> 5, rt = wave & 1, wp = wave >> 1, NCT = nout / 32;
+  f32x4 wf[NCTW ? NCTW : 1][NK ? NK : 1][4];
+  if (NK) {
+#pragma unroll
+    for (int i = 0; i < NCTW; ++i) {
+      const int ct = wp + 4 * i < NCT ? wp + 4 * i : NCT - 1;
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          wf[i][kc][j] = *reinterpret_cast<const f32x4*>(p.W + (long)(ct * 32 + r) * cin + kc * 32 + 16 * h + 4 * j);
+    }
+  }
+  // A . importance as MFMA operand registers: ae[k][s] = (A.imp)[k][v = 4 s + lane/16][w = lane%16]
+  float ae[3][4];
+  if (p.mix) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int v = 4 * s + (lane >> 4), w = lane & 15;
+        const bool ok = k < p.Kk && v < V && w < V;
+        const int idx = ok ? (k * V + v) * V + w : 0;
+        const float a = p.A[idx], im = p.imp[idx];
+        ae[k][s] = ok ? a * im : 0.f;
+      }
+  }
+
+  // ---- statistics of the BatchNorm(s) in front
+  if (p.in_mode == 0) {
+    // data_bn: BatchNorm1d(V * cin) over the F frames -- every workgroup reads the whole frame tensor (F <= 1024 frames)
+    const int C = V * cin, c = tid & 63, q = tid >> 6;       // 8 row groups x 64 channel lanes
+    const int cc = c < C ? c : C - 1;
+    const float shift = p.X1[cc];
+    float s1 = 0.f, s2 = 0.f;
+    for (long fb = q; fb < p.F; fb += 8 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const long f = fb + 8 * u;
+        v[u] = p.X1[(f < p.F ? f : p.F - 1) * C + cc];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        asm volatile("" : "+v"(v[u]));
+        const float d = fb + 8 * u < p.F ? v[u] - shift : 0.f;
+        s1 += d; s2 += d * d;
+      }
+    }
+    red[(q * 2 + 0) * 64 + c] = (double)s1; red[(q * 2 + 1) * 64 + c] = (double)s2;
+    __syncthreads();
+    if (tid < C) {
+      double S1 = 0.0, S2 = 0.0;
+      for (int g = 0; g < 8; ++g) { S1 += red[(g * 2 + 0) * 64 + tid]; S2 += red[(g * 2 + 1) * 64 + tid]; }
+      const double N = (double)p.F, md = S1 / N;
+      const double mean = (double)shift + md;
+      double m2 = S2 - S1 * md;
+      m2 = m2 > 0.0 ? m2 : 0.0;
+      const double var = m2 / N;
+      const float invstd = (float)(1.0 / sqrt(var + (double)p.bn1.eps));
+      const float a = p.bn1.gamma[tid] * invstd, b = p.bn1.beta[tid];
+      st[tid] = (float)mean; st[C + tid] = a; st[2 * C + tid] = b;
+      if (first) {
+        if (p.bn1.state) { p.bn1.state[tid] = (float)mean; p.bn1.state[C + tid] = invstd; p.bn1.state[2 * C + tid] = a; p.bn1.state[3 * C + tid] = b; }
+        if (p.bn1.rmean) {
+          p.bn1.rmean[tid] = (1.f - p.bn1.momentum) * p.bn1.rmean[tid] + p.bn1.momentum * (float)mean;
+          const double unbiased = N > 1.0 ? m2 / (N - 1.0) : var;
+          p.bn1.rvar[tid] = (1.f - p.bn1.momentum) * p.bn1.rvar[tid] + p.bn1.momentum * (float)unbiased;
+        }
+      }
+    }
+    __syncthreads();
+    // input tile: x[(f, v)][c] = (X1[f][v cin + c] - mean) a + b
+    for (int i = tid; i < 64 * XS; i += GF_NT) xs[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < nv * cin; i += GF_NT) {
+      const int row = i / cin, ch = i - row * cin, fch = (row % V) * cin + ch;
+      const float x = __builtin_fmaf(p.X1[(f0 + row / V) * C + fch] - st[fch], st[C + fch], st[2 * C + fch]);
+      xs[row * XS + ch] = x;
+      if (p.xact) p.xact[(r0 + row) * cin + ch] = x;
+    }
+  } else {
+    // the tile's loads first (clamped rows), the two finalizations while they fly
+    const int c4n = cin / 4;                               // 16-byte pieces per row
+    f32x4 v1[4], v2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + GF_NT * u, row = i / c4n, c4 = i - row * c4n;
+      const int rc = row < nv ? row : nv - 1;
+      const bool in = i < 64 * c4n;
+      v1[u] = *reinterpret_cast<const f32x4*>(p.X1 + (r0 + rc) * p.ld1 + 4 * (in ? c4 : 0));
+      v2[u] = *reinterpret_cast<const f32x4*>(p.X2 + (r0 + rc) * p.ld2 + 4 * (in ? c4 : 0));
+    }
+    bn_from_records<GF_NT>(p.bn1, cin, rows, red, st, first);
+    bn_from_records<GF_NT>(p.bn2, cin, rows, red, st + 4 * cin, first);
+    const float *m1 = st, *a1 = st + cin, *b1 = st + 2 * cin, *m2 = st + 4 * cin, *a2 = st + 5 * cin, *b2 = st + 6 * cin;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + GF_NT * u, row = i / c4n, c4 = i - row * c4n;
+      asm volatile("" : "+v"(v1[u].x), "+v"(v1[u].y), "+v"(v1[u].z), "+v"(v1[u].w), "+v"(v2[u].x), "+v"(v2[u].y), "+v"(v2[u].z), "+v"(v2[u].w));
+      if (i < 64 * c4n) {
+        const int c = 4 * c4;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = __builtin_fmaf(v1[u][e] - m1[c + e], a1[c + e], b1[c + e]);
+          t += __builtin_fmaf(v2[u][e] - m2[c + e], a2[c + e], b2[c + e]);
+          o[e] = row < nv ? fmaxf(t, 0.f) : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(xs + row * XS + c) = o;
+        if (p.xact && row < nv) *reinterpret_cast<f32x4*>(p.xact + (r0 + row) * cin + c) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- the stacked 1x1 conv: zs[64][nout] = xs . W^T + bias
+  if (NK) {
+#pragma unroll
+    for (int i = 0; i < NCTW; ++i) {
+      const int ct = wp + 4 * i;
+      if (ct < NCT) {                                      // (uniform per wave)
+        f32x16 acc = {0};
+#pragma unroll
+        for (int kc = 0; kc < NK; ++kc) {
+          f32x4 af[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(xs + (rt * 32 + r) * XS + kc * 32 + 16 * h + 4 * j);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], wf[i][kc][j][e], acc, 0, 0, 0);
+        }
+        const int col = ct * 32 + r;
+        const float bb = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          const float v = acc[reg] + bb;
+          zs[row * ZS + col] = v;
+          if (p.mix && row < nv) p.Z[(r0 + row) * p.ldz + col] = v;
+        }
+      }
+    }
+  } else {
+    for (int i = tid; i < nv * nout; i += GF_NT) {
+      const int row = i / nout, col = i - row * nout;
+      float v = p.bias ? p.bias[col] : 0.f;
+      for (int c = 0; c < cin; ++c) v = __builtin_fmaf(xs[row * XS + c], p.W[col * cin + c], v);
+      zs[row * ZS + col] = v;
+      if (p.mix) p.Z[(r0 + row) * p.ldz + col] = v;
+    }
+  }
+  __syncthreads();
+
+  if (!p.mix) {
+    // closing 1x1 conv: transposed store outT[b][col][t V + v] (consecutive threads walk a column's rows: contiguous addresses)
+    const int TV = p.T * V;
+    for (int i = tid; i < nv * nout; i += GF_NT) {
+      const int col = i / nv, rr = i - col * nv;
+      const long f = f0 + rr / V;
+      const long b = f / p.T;
+      const int tv = (int)(f - b * p.T) * V + rr % V;
+      p.outT[(b * nout + col) * TV + tv] = zs[rr * ZS + col];
+    }
+    return;
+  }
+
+  // ---- einsum('nkctv,kvw->nctw'): y_f[w][c] = sum_k sum_v (A.imp)[k][v][w] z_f[v][k cout + c] on 16x16x4 MFMAs, one (frame, 16-channel
+  // chunk) pair per wave and round; B operand straight from the product's LDS tile
+  {
+    const int nch = cout / 16, npair = nf * nch;
+    const int vq = lane >> 4, cl = lane & 15;
+    for (int pi = wave; pi < npair; pi += GF_NT / 64) {
+      const int fi = pi / nch, n0 = (pi - fi * nch) * 16;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k < p.Kk) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int v = 4 * s + vq;
+            const float b = zs[(fi * V + (v < V ? v : V - 1)) * ZS + k * cout + n0 + cl];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[k][s], b, acc, 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int w = 4 * vq + reg;
+        if (w < V) {
+          p.Y[(r0 + fi * V + w) * cout + n0 + cl] = acc[reg];
+          ys[(fi * V + w) * YS + n0 + cl] = acc[reg];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- BatchNorm partial records of the einsum output and of the residual pre-activation over this tile's rows
+  if (tid < 2 * cout) {
+    const bool res = tid >= cout;
+    const int c = res ? tid - cout : tid;
+    const float* col = res ? zs + p.Kk * cout + c : ys + c;
+    const int S = res ? ZS : YS;
+    float s = 0.f;
+    for (int rr = 0; rr < nv; ++rr) s += col[rr * S];
+    const float mean = s / (float)nv;
+    float m2 = 0.f;
+    for (int rr = 0; rr < nv; ++rr) { const float d = col[rr * S] - mean; m2 = __builtin_fmaf(d, d, m2); }
+    (res ? p.recR : p.recY)[(long)blockIdx.x * cout + c] = float2{mean, m2};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Closing BatchNorm pair of a block, backward: out = relu(BN3(tz) + BNr(rz)); both BatchNorms see the same dY and mask.
+// reduce: rec[j][cv] = (sum g, sum g xhat) over rows [64 j, 64 j + 64), virtual channel cv in [0, 2C): [0, C) = BN3, [C, 2C) = BNr.
+struct GcnBnBwdD {
+  const float* dY; long lddy; const float* mask; long ldm;
+  const float* X1; long ld1; const float* st1;           // state [4][C]: mean, invstd, a, b
+  const float* X2; long ld2; const float* st2;
+  long rows; int C;
+  float2* rec; int nrec;
+  float* dg1; float* db1; float* dX1; long lddx1;
+  float* dg2; float* db2; float* dX2; long lddx2;
+};
+
+__global__ __launch_bounds__(256) void gcn_bn_bwd_reduce_kernel(GcnBnBwdD p) {
+  __shared__ float sh[4][64][2];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int cv = blockIdx.y * 64 + cx, C = p.C;
+  const bool second = cv >= C;
+  const int c = second ? cv - C : cv;
+  const bool live = cv < 2 * C;
+  const int cc = live ? c : 0;
+  const float* X = second ? p.X2 : p.X1;
+  const long ldx = second ? p.ld2 : p.ld1;
+  const float* stt = second ? p.st2 : p.st1;
+  const long rb = (long)blockIdx.x * 64;
+  const float mu = stt[cc], is = stt[C + cc];
+  float g[16], m[16], x[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const long rr = rb + ry + 4 * u;
+    const long rc = rr < p.rows ? rr : p.rows - 1;
+    g[u] = p.dY[rc * p.lddy + cc];
+    m[u] = p.mask[rc * p.ldm + cc];
+    x[u] = X[rc * ldx + cc];
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    asm volatile("" : "+v"(g[u]), "+v"(m[u]), "+v"(x[u]));
+    const float gg = (rb + ry + 4 * u < p.rows && m[u] > 0.f) ? g[u] : 0.f;
+    s1 += gg;
+    s2 += gg * ((x[u] - mu) * is);
+  }
+  sh[ry][cx][0] = s1; sh[ry][cx][1] = s2;
+  __syncthreads();
+  if (ry == 0 && live) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a += sh[j][cx][0]; b += sh[j][cx][1]; }
+    p.rec[(long)blockIdx.x * 2 * C + cv] = float2{a, b};
+  }
+}
+
+// sums of (s1, s2) records rec[nrec][CT] per channel, all NT threads taking part, fp64, fixed order -> c12 [2][CT] in LDS
+// (c1 = s1 / rows, c2 = s2 / rows); red: (NT / CP) * 2 * CP doubles.  The raw sums go to sums[2][CT] (LDS, float).
+template <int NT>
+__device__ __forceinline__ void bwd_sums_from_records(const float2* rec, int nrec, int CT, long rows, double* red, float* c12, float* sums) {
+  int CP = 32;
+  while (CP < CT) CP <<= 1;
+  const int Q = NT / CP;
+  const int tid = threadIdx.x, c = tid & (CP - 1), q = tid / CP;
+  const int cc = c < CT ? c : CT - 1;
+  double a = 0.0, b = 0.0;
+  for (int j0 = q; j0 < nrec; j0 += 8 * Q) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * Q;
+      v[u] = rec[(long)(j < nrec ? j : nrec - 1) * CT + cc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      asm volatile("" : "+v"(v[u].x), "+v"(v[u].y));
+      const bool ok = j0 + u * Q < nrec;
+      a += ok ? (double)v[u].x : 0.0;
+      b += ok ? (double)v[u].y : 0.0;
+    }
+  }
+  red[(q * 2 + 0) * CP + c] = a; red[(q * 2 + 1) * CP + c] = b;
+  __syncthreads();
+  if (tid < CT) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = 0; g < Q; ++g) { s1 += red[(g * 2 + 0) * CP + tid]; s2 += red[(g * 2 + 1) * CP + tid]; }
+    sums[tid] = (float)s1; sums[CT + tid] = (float)s2;
+    c12[tid] = (float)(s1 / (double)rows); c12[CT + tid] = (float)(s2 / (double)rows);
+  }
+  __syncthreads();
+}
+
+// dX = a (g - c1 - xhat c2) for both BatchNorms of the pair; c1, c2 finalized in the prologue from the reduce kernel's records
+#define GBA_NT 1024
+__global__ __launch_bounds__(GBA_NT) void gcn_bn_bwd_apply_kernel(GcnBnBwdD p, long rows_per_wg) {
+  __shared__ double red[GBA_NT / 32 * 2 * 32 > 4 * 2 * 256 ? GBA_NT / 32 * 2 * 32 : 4 * 2 * 256];
+  __shared__ float c12[2 * 256], sums[2 * 256], stl[2][3][128];
+  const int tid = threadIdx.x, C = p.C, CT = 2 * C;
+  const long rbeg = (long)blockIdx.x * rows_per_wg, rend = rbeg + rows_per_wg < p.rows ? rbeg + rows_per_wg : p.rows;
+  // first round of this workgroup's loads, then the prologue
+  const int c4n = C / 4;
+  const long npiece = (rend - rbeg) * c4n;
+  f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, m0 = g0, x10 = g0, x20 = g0;
+  {
+    const long i = tid < npiece ? tid : (npiece > 0 ? npiece - 1 : 0);
+    const long row = rbeg + i / c4n;
+    const int c = 4 * (int)(i % c4n);
+    if (npiece > 0) {
+      g0 = *reinterpret_cast<const f32x4*>(p.dY + row * p.lddy + c);
+      m0 = *reinterpret_cast<const f32x4*>(p.mask + row * p.ldm + c);
+      x10 = *reinterpret_cast<const f32x4*>(p.X1 + row * p.ld1 + c);
+      x20 = *reinterpret_cast<const f32x4*>(p.X2 + row * p.ld2 + c);
+    }
+  }
+  if (tid < C) {
+    stl[0][0][tid] = p.st1[tid]; stl[0][1][tid] = p.st1[C + tid]; stl[0][2][tid] = p.st1[2 * C + tid];
+    stl[1][0][tid] = p.st2[tid]; stl[1][1][tid] = p.st2[C + tid]; stl[1][2][tid] = p.st2[2 * C + tid];
+  }
+  bwd_sums_from_records<GBA_NT>(p.rec, p.nrec, CT, p.rows, red, c12, sums);
+  if (blockIdx.x == 0 && tid < CT) {                     // d(beta) = sum g, d(gamma) = sum g xhat
+    if (tid < C) { p.db1[tid] = sums[tid]; p.dg1[tid] = sums[CT + tid]; }
+    else { p.db2[tid - C] = sums[tid]; p.dg2[tid - C] = sums[CT + tid]; }
+  }
+  for (long i0 = 0; i0 < npiece; i0 += GBA_NT) {
+    const long i = i0 + tid;
+    f32x4 g = g0, m = m0, x1 = x10, x2 = x20;
+    if (i0 > 0 && i < npiece) {
+      const long row = rbeg + i / c4n;
+      const int c = 4 * (int)(i % c4n);
+      g = *reinterpret_cast<const f32x4*>(p.dY + row * p.lddy + c);
+      m = *reinterpret_cast<const f32x4*>(p.mask + row * p.ldm + c);
+      x1 = *reinterpret_cast<const f32x4*>(p.X1 + row * p.ld1 + c);
+      x2 = *reinterpret_cast<const f32x4*>(p.X2 + row * p.ld2 + c);
+    }
+    if (i < npiece) {
+      const long row = rbeg + i / c4n;
+      const int c = 4 * (int)(i % c4n);
+      f32x4 o1, o2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gg = m[e] > 0.f ? g[e] : 0.f;
+        const float xh1 = (x1[e] - stl[0][0][c + e]) * stl[0][1][c + e];
+        const float xh2 = (x2[e] - stl[1][0][c + e]) * stl[1][1][c + e];
+        o1[e] = stl[0][2][c + e] * (gg - c12[c + e] - xh1 * c12[CT + c + e]);
+        o2[e] = stl[1][2][c + e] * (gg - c12[C + c + e] - xh2 * c12[CT + C + c + e]);
+      }
+      *reinterpret_cast<f32x4*>(p.dX1 + row * p.lddx1 + c) = o1;
+      *reinterpret_cast<f32x4*>(p.dX2 + row * p.lddx2 + c) = o2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Both gradients of the einsum (pool.hip graph_dA_partial_kernel's arithmetic) with the backward of the BatchNorm + ReLU behind the
+// einsum applied while a frame's rows are loaded: dy[w][c] = a (g - c1 - xhat c2), g = dY0 . [bn(ymix) > 0], xhat from ymix; c1, c2
+// finalized in the prologue from the records tconv's input-gradient epilogue left (one per 64-row tile).
+#define GDF_FPB 2
+struct GraphDAFusedD {
+  const float* Z; long ldz; const float* dY0; const float* Ym; const float* st0;     // st0 [4][C]
+  const float2* rec; int nrec; float* dg0; float* db0;
+  long G; int V, Kk, C;
+  float* partial; const float* A; const float* imp; float* dZ; long lddz;
+};
+
+__global__ __launch_bounds__(512) void graph_dA_fused_kernel(GraphDAFusedD p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int V = p.V, Kk = p.Kk, C = p.C, KC = Kk * C;
+  float* zs = sm;                       // [V][KC + 1]
+  float* ys = zs + V * (KC + 1);        // [V][C + 1]
+  float* As = ys + V * (C + 1);         // [Kk][V][V]
+  float* c12 = As + Kk * V * V;         // [2][C]
+  float* sums = c12 + 2 * C;            // [2][C]
+  float* stl = sums + 2 * C;            // [3][C] mean, invstd, a ... b kept too: [4][C]
+  double* red = reinterpret_cast<double*>(sm + (((V * (KC + 1) + V * (C + 1) + Kk * V * V + 8 * C) + 1) & ~1));
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Kk * V * V; i += 512) As[i] = p.A[i] * p.imp[i];
+  for (int i = tid; i < 4 * C; i += 512) stl[i] = p.st0[i];
+  bwd_sums_from_records<512>(p.rec, p.nrec, C, p.G * V, red, c12, sums);
+  if (blockIdx.x == 0 && tid < C) { p.db0[tid] = sums[tid]; p.dg0[tid] = sums[C + tid]; }
+  const int nout = Kk * V * V;
+  const int e = tid;
+  const int w = e % V, v = (e / V) % V, k = e / (V * V);
+  float acc = 0.f;
+  const long g0 = (long)blockIdx.x * GDF_FPB;
+  for (long g = g0; g < g0 + GDF_FPB && g < p.G; ++g) {
+    __syncthreads();
+    for (int i = tid; i < V * KC; i += 512) zs[(i / KC) * (KC + 1) + (i % KC)] = p.Z[(g * V + i / KC) * p.ldz + (i % KC)];
+    for (int i = tid; i < V * C; i += 512) {
+      const int c = i % C;
+      const float ym = p.Ym[g * V * C + i], d0 = p.dY0[g * V * C + i];
+      const float gg = __builtin_fmaf(ym - stl[c], stl[2 * C + c], stl[3 * C + c]) > 0.f ? d0 : 0.f;
+      const float xh = (ym - stl[c]) * stl[C + c];
+      ys[(i / C) * (C + 1) + c] = stl[2 * C + c] * (gg - c12[c] - xh * c12[C + c]);
+    }
+    __syncthreads();
+    if (e < nout) {
+      const float* zr = zs + v * (KC + 1) + k * C;
+      const float* yr = ys + w * (C + 1);
+      float a = 0.f;
+      for (int c = 0; c < C; ++c) a += zr[c] * yr[c];
+      acc += a;
+    }
+    float* zf = p.dZ + g * V * p.lddz;
+    for (int i = tid; i < V * KC; i += 512) {
+      const int row = i / KC, col = i - row * KC;
+      const int kk = col / C, c = col - kk * C;
+      float a = 0.f;
+      for (int w2 = 0; w2 < V; ++w2) a += As[(kk * V + row) * V + w2] * ys[w2 * (C + 1) + c];
+      zf[(long)row * p.lddz + col] = a;
+    }
+  }
+  if (e < nout) p.partial[(long)blockIdx.x * nout + e] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// One launch for every deferred partial-product sum of a backward pass.  Entry kinds:
+//   0  split-K slabs ws[nsplit][M*N] -> C[m*scm + n] (the layout mmego_gemm leaves with accumulate = 2), optionally the slab row
+//      sums behind them ws[nsplit*M*N + k*M + m] -> asum[m]
+//   1  temporal-conv weight-gradient slabs ws[nsplit][tap][co][ci] -> dW[co][ci][tap]
+//   2  column sums of partial[nsplit][n] scaled per column: out[i] = scale[i] * sum_k partial[k][i]  (edge-importance gradient)
+struct SlabDesc { const float* ws; float* out; const float* scale; float* asum; int kind, nsplit, M, N, taps; long scm; int blk0; };
+#define SLAB_MAX 24
+struct SlabTable { SlabDesc d[SLAB_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(SlabTable t) {
+  __shared__ float sh[16][17];
+  int di = 0;
+#pragma unroll 1
+  while (di + 1 < t.n && (int)blockIdx.x >= t.d[di + 1].blk0) ++di;
+  const SlabDesc& d = t.d[di];
+  const int o = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const long total = (long)d.M * d.N;
+  const long cblocks = (total + 15) / 16;
+  const long blk = (long)blockIdx.x - d.blk0;
+  const bool is_asum = blk >= cblocks;                    // (uniform per block; kind 0 only)
+  const long i = (is_asum ? blk - cblocks : blk) * 16 + o;
+  const long cnt = is_asum ? d.M : total;
+  const float* src = is_asum ? d.ws + (long)d.nsplit * total : d.ws;
+  float s = 0.f;
+  if (i < cnt) {
+    int k = kg;
+#pragma unroll 1
+    for (; k + 7 * 16 < d.nsplit; k += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u * 16) * cnt + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < d.nsplit; k += 16) s += src[(long)k * cnt + i];
+  }
+  sh[kg][o] = s;
+  __syncthreads();
+  if (kg == 0 && i < cnt) {
+    s = sh[0][o];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) s += sh[g][o];
+    if (is_asum) { d.asum[i] = s; return; }
+    if (d.kind == 0) {
+      const long m = i / d.N;
+      d.out[m * d.scm + (i - m * d.N)] = s;
+    } else if (d.kind == 1) {                             // i = (tap * Co + co) * Ci + ci ;  M = taps * Co, N = Ci
+      const int ci = (int)(i % d.N);
+      const long q = i / d.N;
+      const int Co = d.M / d.taps;
+      const int co = (int)(q % Co), tap = (int)(q / Co);
+      d.out[((long)co * d.N + ci) * d.taps + tap] = s;
+    } else {
+      d.out[i] = d.scale ? s * d.scale[i] : s;
+    }
+  }
+}
+
+// d(gamma)[c] = sum_r dY[r][c] xhat[r][c], d(beta)[c] = sum_r dY[r][c] for a BatchNorm whose input gradient nobody needs
+// (rows <= 1024: one workgroup per 16 channels, 16 row lanes)
+__global__ __launch_bounds__(256) void bn_param_grads_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
+                                                             const float* __restrict__ st, long rows, int C, float* dgamma, float* dbeta) {
+  __shared__ double sh[16][16][2];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
+  const int cc = c < C ? c : C - 1;
+  const float mu = st[cc], is = st[C + cc];
+  double s1 = 0.0, s2 = 0.0;
+  for (long rb = ry; rb < rows; rb += 16 * 8) {
+    float g[8], x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long rr = rb + 16 * u;
+      const long rc = rr < rows ? rr : rows - 1;
+      g[u] = dY[rc * lddy + cc]; x[u] = X[rc * ldx + cc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      asm volatile("" : "+v"(g[u]), "+v"(x[u]));
+      const float gg = rb + 16 * u < rows ? g[u] : 0.f;
+      s1 += (double)gg;
+      s2 += (double)(gg * ((x[u] - mu) * is));
+    }
+  }
+  sh[ry][cx][0] = s1; sh[ry][cx][1] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < 16; ++j) { a += sh[j][cx][0]; b += sh[j][cx][1]; }
+    dbeta[c] = (float)a; dgamma[c] = (float)b;
+  }
+}
+
+// =============================================================================================================================
+// C ABI
+// =============================================================================================================================
+struct MmegoGcnFrontH {          // host-side mirror of include/mmego_hip.h's MmegoGcnFront (same field order)
+  const float* X1; long ld1; const float* X2; long ld2; int in_mode;
+  MmegoBnRefH bn1, bn2;
+  float* xact;
+  const float* W; const float* bias; int cin, nout;
+  int mix, K, cout; const float* A; const float* importance;
+  float* Z; long ldz; float* Y; float* recY; float* recR;
+  float* outT; int T;
+  long F; int V;
+};
+
+extern "C" int mmego_gcn_front_nrec(long F) { return cdiv(F, GF_FPB); }
+
+extern "C" int mmego_gcn_front(void* stream, const void* desc) {
+  const MmegoGcnFrontH* h = static_cast<const MmegoGcnFrontH*>(desc);
+  MMEGO_REQUIRE(h && h->X1 && h->W && h->F > 0 && h->V >= 1 && h->V <= 15 && h->cin >= 1 && h->nout >= 32 && (h->nout % 32) == 0);
+  MMEGO_REQUIRE(h->in_mode == 0 || h->in_mode == 1);
+  GcnFrontD p;
+  p.X1 = h->X1; p.ld1 = h->ld1; p.X2 = h->X2; p.ld2 = h->ld2; p.in_mode = h->in_mode;
+  p.bn1 = bnref_device(&h->bn1); p.bn2 = bnref_device(&h->bn2);
+  p.xact = h->xact; p.W = h->W; p.bias = h->bias; p.cin = h->cin; p.nout = h->nout;
+  p.mix = h->mix; p.Kk = h->K; p.cout = h->cout; p.A = h->A; p.imp = h->importance;
+  p.Z = h->Z; p.ldz = h->ldz; p.Y = h->Y; p.recY = reinterpret_cast<float2*>(h->recY); p.recR = reinterpret_cast<float2*>(h->recR);
+  p.outT = h->outT; p.T = h->T; p.F = h->F; p.V = h->V;
+  if (p.in_mode == 0) {
+    MMEGO_REQUIRE(p.V * p.cin <= 64 && p.F <= 1024 && p.bn1.gamma && p.bn1.beta);
+  } else {
+    MMEGO_REQUIRE(p.X2 && (p.cin % 32) == 0 && p.cin <= 128 && (p.ld1 % 4) == 0 && (p.ld2 % 4) == 0);
+    MMEGO_REQUIRE(p.bn1.rec && p.bn2.rec && p.bn1.nrec >= 1 && p.bn2.nrec >= 1 && p.bn1.rpr >= 1 && p.bn2.rpr >= 1 && p.bn1.gamma && p.bn2.gamma);
+    MMEGO_REQUIRE((((uintptr_t)p.X1 | (uintptr_t)p.X2 | (uintptr_t)p.xact | (uintptr_t)p.W) & 15) == 0);
+  }
+  if (p.mix) {
+    MMEGO_REQUIRE(p.Kk >= 1 && p.Kk <= 3 && p.cout >= 16 && (p.cout % 16) == 0 && p.cout <= 128 && p.nout == (p.Kk + 1) * p.cout);
+    MMEGO_REQUIRE(p.A && p.imp && p.Z && p.Y && p.recY && p.recR && p.ldz >= p.nout);
+  } else {
+    MMEGO_REQUIRE(p.outT && p.T >= 1 && (p.F % p.T) == 0);
+    p.cout = 4;                      // (unused; keeps the LDS carve-up small)
+  }
+  const bool scalar = p.cin < 32;
+  MMEGO_REQUIRE(scalar == (p.in_mode == 0) || !scalar);
+  const int NCT = p.nout / 32, nctw = (NCT + 3) / 4, nk = scalar ? 0 : p.cin / 32;
+  const int XS = (nk ? p.cin : 4) + 4, ZS = p.nout + 16, YS = p.cout + 4;
+  const int tail = 64 * XS > 60 * YS ? 64 * XS : 60 * YS;
+  const size_t lds = (size_t)(GF_ST + 64 * ZS + (tail > 8192 ? tail : 8192)) * sizeof(float);      // (>= 32 KB of prologue scratch)
+  MMEGO_REQUIRE(lds <= 160 * 1024 && 8 * p.cin <= GF_ST);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(p.F, GF_FPB));
+#define GF_LAUNCH(NCTW_, NK_)                                                                                         \
+  do {                                                                                                                \
+    static size_t attr = 0;                                                                                           \
+    if (lds > 64 * 1024 && lds > attr) {                                                                              \
+      hipError_t e = hipFuncSetAttribute((const void*)gcn_front_kernel<NCTW_, NK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                                             \
+      attr = lds;                                                                                                     \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((gcn_front_kernel<NCTW_, NK_>), grid, dim3(GF_NT), lds, st, p);                                \
+  } while (0)
+  if (nk == 0 && nctw == 1) GF_LAUNCH(1, 0);
+  else if (nk == 1 && nctw == 1) GF_LAUNCH(1, 1);
+  else if (nk == 1 && nctw == 2) GF_LAUNCH(2, 1);
+  else if (nk == 2 && nctw == 2) GF_LAUNCH(2, 2);
+  else if (nk == 2 && nctw == 3) GF_LAUNCH(3, 2);
+  else if (nk == 4 && nctw == 1) GF_LAUNCH(1, 4);
+  else if (nk == 2 && nctw == 1) GF_LAUNCH(1, 2);
+  else return MMEGO_EBADARG;
+#undef GF_LAUNCH
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+static int gcn_bn_bwd_fill(GcnBnBwdD& p, const float* dY, long lddy, const float* mask, long ldm, const float* X1, long ld1,
+                           const float* st1, const float* X2, long ld2, const float* st2, long rows, int C, float* rec) {
+  MMEGO_REQUIRE(dY && mask && X1 && st1 && X2 && st2 && rec && rows > 0 && C >= 4 && C <= 128 && (C % 4) == 0);
+  p.dY = dY; p.lddy = lddy; p.mask = mask; p.ldm = ldm; p.X1 = X1; p.ld1 = ld1; p.st1 = st1; p.X2 = X2; p.ld2 = ld2; p.st2 = st2;
+  p.rows = rows; p.C = C; p.rec = reinterpret_cast<float2*>(rec); p.nrec = cdiv(rows, 64);
+  p.dg1 = p.db1 = p.dX1 = p.dg2 = p.db2 = p.dX2 = nullptr; p.lddx1 = p.lddx2 = 0;
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_gcn_bn_bwd_reduce(void* stream, const float* dY, long lddy, const float* mask, long ldm, const float* X1, long ld1,
+                                       const float* st1, const float* X2, long ld2, const float* st2, long rows, int C, float* rec) {
+  GcnBnBwdD p;
+  int rc = gcn_bn_bwd_fill(p, dY, lddy, mask, ldm, X1, ld1, st1, X2, ld2, st2, rows, C, rec);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gcn_bn_bwd_reduce_kernel, dim3(p.nrec, cdiv(2 * C, 64)), dim3(256), 0, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_gcn_bn_bwd_apply(void* stream, const float* dY, long lddy, const float* mask, long ldm, const float* X1, long ld1,
+                                      const float* st1, const float* X2, long ld2, const float* st2, long rows, int C, const float* rec,
+                                      float* dgamma1, float* dbeta1, float* dX1, long lddx1, float* dgamma2, float* dbeta2, float* dX2,
+                                      long lddx2) {
+  GcnBnBwdD p;
+  int rc = gcn_bn_bwd_fill(p, dY, lddy, mask, ldm, X1, ld1, st1, X2, ld2, st2, rows, C, const_cast<float*>(rec));
+  if (rc) return rc;
+  MMEGO_REQUIRE(dgamma1 && dbeta1 && dX1 && dgamma2 && dbeta2 && dX2 && p.nrec <= 1024);
+  MMEGO_REQUIRE((lddy % 4) == 0 && (ldm % 4) == 0 && (ld1 % 4) == 0 && (ld2 % 4) == 0 && (lddx1 % 4) == 0 && (lddx2 % 4) == 0);
+  MMEGO_REQUIRE((((uintptr_t)dY | (uintptr_t)mask | (uintptr_t)X1 | (uintptr_t)X2 | (uintptr_t)dX1 | (uintptr_t)dX2) & 15) == 0);
+  p.dg1 = dgamma1; p.db1 = dbeta1; p.dX1 = dX1; p.lddx1 = lddx1; p.dg2 = dgamma2; p.db2 = dbeta2; p.dX2 = dX2; p.lddx2 = lddx2;
+  long nwg = cdiv(rows, 64);
+  if (nwg > 128) nwg = 128;
+  const long rpw = (rows + nwg - 1) / nwg;
+  hipLaunchKernelGGL(gcn_bn_bwd_apply_kernel, dim3((unsigned)cdiv(rows, rpw)), dim3(GBA_NT), 0, (hipStream_t)stream, p, rpw);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_graph_dA_fused_nblk(long G) { return cdiv(G, GDF_FPB); }
+
+extern "C" int mmego_graph_dA_fused(void* stream, const float* Z, long ldz, const float* dY0, const float* Ymix, const float* st0,
+                                    const float* rec, int nrec, float* dgamma0, float* dbeta0, long G, int V, int K, int C,
+                                    float* partial_ws, const float* A, const float* imp, float* dZ, long lddz) {
+  MMEGO_REQUIRE(Z && dY0 && Ymix && st0 && rec && nrec >= 1 && nrec <= 1024 && dgamma0 && dbeta0 && partial_ws && A && imp && dZ);
+  MMEGO_REQUIRE(G > 0 && V > 0 && K > 0 && C > 0 && C <= 256 && K * V * V <= 512 && ldz >= (long)K * C && lddz >= (long)K * C);
+  GraphDAFusedD p = {Z, ldz, dY0, Ymix, st0, reinterpret_cast<const float2*>(rec), nrec, dgamma0, dbeta0, G, V, K, C, partial_ws, A, imp, dZ, lddz};
+  int CP = 32;
+  while (CP < C) CP <<= 1;
+  const size_t fl = (size_t)V * (K * C + 1) + (size_t)V * (C + 1) + (size_t)K * V * V + 8 * (size_t)C + 2;
+  const size_t lds = fl * sizeof(float) + (size_t)(512 / CP) * 2 * CP * sizeof(double);
+  MMEGO_REQUIRE(lds <= 64 * 1024);
+  hipLaunchKernelGGL(graph_dA_fused_kernel, dim3((unsigned)cdiv(G, GDF_FPB)), dim3(512), lds, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+struct MmegoSlabH { const float* ws; float* out; const float* scale; float* asum; int kind, nsplit, M, N, taps; long scm; };
+
+extern "C" int mmego_slab_reduce(void* stream, int n, const void* descs) {
+  const MmegoSlabH* h = static_cast<const MmegoSlabH*>(descs);
+  MMEGO_REQUIRE(h && n >= 1 && n <= SLAB_MAX);
+  SlabTable t;
+  t.n = n;
+  int blk = 0;
+  for (int i = 0; i < n; ++i) {
+    MMEGO_REQUIRE(h[i].ws && h[i].out && h[i].nsplit >= 1 && h[i].M >= 1 && h[i].N >= 1 && h[i].kind >= 0 && h[i].kind <= 2);
+    MMEGO_REQUIRE(h[i].kind != 1 || (h[i].taps >= 1 && (h[i].M % h[i].taps) == 0));
+    MMEGO_REQUIRE(!h[i].asum || h[i].kind == 0);
+    t.d[i].ws = h[i].ws; t.d[i].out = h[i].out; t.d[i].scale = h[i].scale; t.d[i].asum = h[i].asum;
+    t.d[i].kind = h[i].kind; t.d[i].nsplit = h[i].nsplit; t.d[i].M = h[i].M; t.d[i].N = h[i].N; t.d[i].taps = h[i].taps;
+    t.d[i].scm = h[i].scm; t.d[i].blk0 = blk;
+    blk += (int)(((long)h[i].M * h[i].N + 15) / 16) + (h[i].asum ? (h[i].M + 15) / 16 : 0);
+  }
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, t);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_bn_param_grads(void* stream, const float* dY, long lddy, const float* X, long ldx, const float* state, long rows,
+                                    int C, float* dgamma, float* dbeta) {
+  MMEGO_REQUIRE(dY && X && state && dgamma && dbeta && rows > 0 && C > 0);
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, dY, lddy, X, ldx, state, rows, C,
+                     dgamma, dbeta);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

@@ -513,6 +513,10 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
                           long sBb, long sCb, int relu, int accumulate, float* splitk_ws, int nsplit, long sBiasb,
                           const float* cmul, float* asum) {
   MMEGO_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && nsplit >= 1);
+  // accumulate == 2: DEFERRED split-K -- the slabs (and the slab row sums behind them) stay in splitk_ws[nsplit][M*N] (+ [nsplit][M])
+  // and C is not touched; mmego_slab_reduce (kind 0) adds them later, together with a backward pass's other partial products
+  const bool defer = accumulate == 2;
+  MMEGO_REQUIRE(!defer || (nsplit > 1 && nbatch == 1 && !bias && !relu));
   MMEGO_REQUIRE(!cmul || nsplit == 1);
   MMEGO_REQUIRE(relu == 0 || relu == 1 || (relu == 2 && cmul));
   MMEGO_REQUIRE(sBiasb == 0 || nsplit == 1);          // (the split-K reducer applies one shared bias)
@@ -543,7 +547,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
       tp.nsplit = nsplit; tp.kchunk = kchunk_t; tp.ws = splitk_ws;
       tp.nbatch = nbatch; tp.sAb = sAb; tp.sWb = sBb; tp.sCb = sCb; tp.sBiasb = sBiasb;
       int rc = mmego_detail::gemm_tile_launch(st, tp, a_kc, b_kc);
-      if (rc == 0 && nsplit > 1) {
+      if (rc == 0 && nsplit > 1 && !defer) {
         long total = (long)nbatch * M * N;
         int blocks = (int)((total + SKR_OUT - 1) / SKR_OUT);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, splitk_ws, C, bias, nsplit, nbatch, M, N, scm, scn,
@@ -604,7 +608,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   else G64_LAUNCH(false, false);
 #undef G64_LAUNCH
   MMEGO_LAUNCH_CHECK();
-  if (nsplit > 1) {
+  if (nsplit > 1 && !defer) {
     long total = (long)nbatch * M * N;
     int blocks = (int)((total + SKR_OUT - 1) / SKR_OUT);
     if (asum) blocks += (int)(((long)nbatch * M + SKR_OUT - 1) / SKR_OUT);

@@ -56,9 +56,16 @@ def lib():
 def _conv(v):
     if isinstance(v, torch.Tensor):
         return v.data_ptr()
-    if isinstance(v, ctypes.Array):          # a host-side descriptor table (gemm_group): kept alive by whoever holds the argument list
+    if isinstance(v, (ctypes.Array, ctypes.Structure)):   # a host-side descriptor (table): kept alive by whoever holds the argument list
         return ctypes.addressof(v)
     return v
+
+
+def ptr(t):
+    """Device address of a tensor (or None / an integer address) for a descriptor field."""
+    if t is None:
+        return None
+    return t.data_ptr() if isinstance(t, torch.Tensor) else int(t)
 
 
 def stream_handle():
@@ -77,6 +84,35 @@ class GemmDesc(ctypes.Structure):
                 ("splitk_ws", ctypes.c_void_p), ("nsplit", ctypes.c_int),
                 ("sBiasb", ctypes.c_long),
                 ("cmul", ctypes.c_void_p), ("asum", ctypes.c_void_p)]
+
+
+class BnRef(ctypes.Structure):
+    """MmegoBnRef of include/mmego_hip.h: a BatchNorm whose batch statistics arrive as partial records."""
+    _fields_ = [("rec", ctypes.c_void_p), ("nrec", ctypes.c_int), ("rows_per_rec", ctypes.c_int),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
+                ("momentum", ctypes.c_float), ("eps", ctypes.c_float), ("state", ctypes.c_void_p)]
+
+    @staticmethod
+    def of(bn, state, rec=None, nrec=0, rows_per_rec=0):
+        return BnRef(ptr(rec), int(nrec), int(rows_per_rec), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                     float(bn.momentum), float(bn.eps), ptr(state))
+
+
+class GcnFront(ctypes.Structure):
+    """MmegoGcnFront of include/mmego_hip.h."""
+    _fields_ = [("X1", ctypes.c_void_p), ("ld1", ctypes.c_long), ("X2", ctypes.c_void_p), ("ld2", ctypes.c_long), ("in_mode", ctypes.c_int),
+                ("bn1", BnRef), ("bn2", BnRef), ("xact", ctypes.c_void_p),
+                ("W", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("cin", ctypes.c_int), ("nout", ctypes.c_int),
+                ("mix", ctypes.c_int), ("K", ctypes.c_int), ("cout", ctypes.c_int), ("A", ctypes.c_void_p), ("importance", ctypes.c_void_p),
+                ("Z", ctypes.c_void_p), ("ldz", ctypes.c_long), ("Y", ctypes.c_void_p), ("recY", ctypes.c_void_p), ("recR", ctypes.c_void_p),
+                ("outT", ctypes.c_void_p), ("T", ctypes.c_int), ("F", ctypes.c_long), ("V", ctypes.c_int)]
+
+
+class Slab(ctypes.Structure):
+    """MmegoSlab of include/mmego_hip.h: one deferred partial-product sum."""
+    _fields_ = [("ws", ctypes.c_void_p), ("out", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("asum", ctypes.c_void_p),
+                ("kind", ctypes.c_int), ("nsplit", ctypes.c_int), ("M", ctypes.c_int), ("N", ctypes.c_int), ("taps", ctypes.c_int),
+                ("scm", ctypes.c_long)]
 
 
 _gemm_rec = None

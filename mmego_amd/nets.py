@@ -24,6 +24,7 @@ from .skeleton import JOINTS_UPPER, LOWER_POINTS, gcn_adjacency
 
 
 _FUSED_FRONT = os.environ.get("MMEGO_FUSED_FRONT", "1") != "0"      # eval-mode Upper_Net front end as one launch (front.hip)
+_GCN_FUSED = os.environ.get("MMEGO_GCN_FUSED", "1") != "0"          # training: the ST-GCN's fused block kernels (gcn_fused.hip)
 
 
 def _require_gpu(t, who):
@@ -491,10 +492,78 @@ class LowerNet(_NetBase):
         return ent[1]
 
     # -- ST-GCN (Net/GCN.py:332-355) on channels-last rows (b,t,v) ------------------------------------
+    def _gcn_fusable(self, B, T):
+        """The fused training kernels' shape limits (gcn_fused.hip): <= 1024 frames (data_bn's statistics are taken by every
+        workgroup; <= 256 partial records per BatchNorm), the reference's channel ladder, K <= 3 partitions."""
+        gcn = self.keyEncoder.gcn
+        blks = gcn.gcn_networks
+        ok = _GCN_FUSED and B * T <= 1024 and len(blks) == 3 and gcn.A.shape[1] == JOINTS_UPPER and gcn.A.shape[0] <= 3
+        ok = ok and blks[0].cin * JOINTS_UPPER <= 64 and [b.cout for b in blks] == [32, 64, 128] and all(b.taps == 9 for b in blks)
+        ok = ok and gcn.fcn.weight.shape[0] == 64 and gcn.A.is_contiguous()
+        for blk in blks:
+            ok = ok and ops.stacked(blk.gcn.conv.weight.view(blk.K * blk.cout, blk.cin), blk.residual["0"].weight.view(blk.cout, blk.cin)) is not None
+            ok = ok and ops.stacked(blk.gcn.conv.bias, blk.residual["0"].bias) is not None
+        return bool(ok)
+
+    def _gcn_forward_fused(self, ar, up, B, T):
+        """Training forward of the ST-GCN in 8 launches (one weight pack, per block gcn_front + tconv_train, the closing conv):
+        BatchNorm statistics travel as partial records and are finalized in the consumers' prologues (gcn_fused.hip)."""
+        gcn = self.keyEncoder.gcn
+        V = JOINTS_UPPER
+        F, rows = B * T, B * T * V
+        nrf, nrt = hip.lib().mmego_gcn_front_nrec(F), (rows + 63) // 64
+        blks = gcn.gcn_networks
+        wps = [ar.get("gcn.b%d.wp" % i, (2, blk.tcn["2"].weight.numel())) for i, blk in enumerate(blks)]
+        hip.call("tconv_pack_multi", 3, *[v for blk, wp in zip(blks, wps) for v in (blk.tcn["2"].weight, wp, blk.cout, blk.cout)], blks[0].taps)
+        prev = None
+        for i, blk in enumerate(blks):
+            cin, cout, K = blk.cin, blk.cout, blk.K
+            key = "gcn.b%d" % i
+            zr = ar.get(key + ".zr", (rows, (K + 1) * cout))
+            ymix, tz, y0 = ar.get(key + ".ymix", (rows, cout)), ar.get(key + ".tz", (rows, cout)), ar.get(key + ".y0", (rows, cout))
+            recY, recR, rec3 = ar.get(key + ".recY", (nrf, cout, 2)), ar.get(key + ".recR", (nrf, cout, 2)), ar.get(key + ".rec3", (nrt, cout, 2))
+            d = hip.GcnFront()
+            if prev is None:
+                d.X1, d.ld1, d.in_mode = hip.ptr(up), V * cin, 0
+                d.bn1 = hip.BnRef.of(gcn.data_bn, ops.BnState(ar, "gcn.dbn", V * cin).all)
+                d.xact = hip.ptr(ar.get("gcn.x0", (F, V * cin)))
+            else:
+                ptz, pzr, prec3, precR, pblk, pkey = prev
+                pc = pblk.cout
+                d.X1, d.ld1, d.X2, d.ld2, d.in_mode = hip.ptr(ptz), pc, hip.ptr(pzr[:, pblk.K * pc:]), pzr.stride(0), 1
+                d.bn1 = hip.BnRef.of(pblk.tcn["3"], ops.BnState(ar, pkey + ".bn3", pc).all, prec3, nrt, 64)
+                d.bn2 = hip.BnRef.of(pblk.residual["1"], ops.BnState(ar, pkey + ".bnr", pc).all, precR, nrf, 4 * V)
+                d.xact = hip.ptr(ar.get(pkey + ".out", (rows, pc)))
+            Wc = ops.stacked(blk.gcn.conv.weight.view(K * cout, cin), blk.residual["0"].weight.view(cout, cin))
+            bc = ops.stacked(blk.gcn.conv.bias, blk.residual["0"].bias)
+            d.W, d.bias, d.cin, d.nout = hip.ptr(Wc), hip.ptr(bc), cin, (K + 1) * cout
+            d.mix, d.K, d.cout, d.A, d.importance = 1, K, cout, hip.ptr(gcn.A), hip.ptr(gcn.edge_importance[i])
+            d.Z, d.ldz, d.Y, d.recY, d.recR = hip.ptr(zr), zr.stride(0), hip.ptr(ymix), hip.ptr(recY), hip.ptr(recR)
+            d.F, d.V = F, V
+            hip.call("gcn_front", d)
+            bn0 = hip.BnRef.of(blk.tcn["0"], ops.BnState(ar, key + ".bn0", cout).all, recY, nrf, 4 * V)
+            hip.call("tconv_train", ymix, cout, bn0, wps[i][0], blk.tcn["2"].bias, tz, cout, y0, rec3, B, T, V, cout, cout, blk.taps)
+            prev = (tz, zr, rec3, recR, blk, key)
+        ptz, pzr, prec3, precR, pblk, pkey = prev
+        pc = pblk.cout
+        kv = ar.get("gcn.kv", (B, 64, T * V))
+        d = hip.GcnFront()
+        d.X1, d.ld1, d.X2, d.ld2, d.in_mode = hip.ptr(ptz), pc, hip.ptr(pzr[:, pblk.K * pc:]), pzr.stride(0), 1
+        d.bn1 = hip.BnRef.of(pblk.tcn["3"], ops.BnState(ar, pkey + ".bn3", pc).all, prec3, nrt, 64)
+        d.bn2 = hip.BnRef.of(pblk.residual["1"], ops.BnState(ar, pkey + ".bnr", pc).all, precR, nrf, 4 * V)
+        d.xact = hip.ptr(ar.get(pkey + ".out", (rows, pc)))
+        d.W, d.bias, d.cin, d.nout = hip.ptr(gcn.fcn.weight), hip.ptr(gcn.fcn.bias), pc, 64
+        d.mix, d.outT, d.T, d.F, d.V = 0, hip.ptr(kv), T, F, V
+        hip.call("gcn_front", d)
+        return kv.view(F * V, 64)
+
     def _gcn_forward(self, ar, up, B, T, training):
         gcn = self.keyEncoder.gcn
         V = JOINTS_UPPER
         F, rows = B * T, B * T * V
+        self._gcn_was_fused = bool(training and self._gcn_fusable(B, T))
+        if self._gcn_was_fused:
+            return self._gcn_forward_fused(ar, up, B, T)
         st = ops.bn_stats(ar, "gcn.dbn", up, gcn.data_bn, training)
         x0 = ar.get("gcn.x0", (F, V * 3))
         ops.affine_act(up, st, x0, relu=False)
@@ -589,18 +658,89 @@ class LowerNet(_NetBase):
         hip.call("cross_attn_backward", Qm, Km, Vm, Pm, dboth[:, 64:], 128, F, float(fu.scale), dQ, dK, dV, 128)
         p_vec = ar.get("both", (prow, 128))[:, :64]
         k_vec = ar.get("gcn.kv", (B, 64, T * V)).view(F * V, 64)
-        blocks.linear_backward(dQ, p_vec, fu.to_q, G, dp, accumulate_dx=True)
+        # split-K / split-row partial products of this backward pass are summed by ONE launch at its end (ops.SlabList)
+        slabs = ops.SlabList() if getattr(self, "_gcn_was_fused", False) else None
         Wkv = ops.stacked(fu.to_k.weight, fu.to_v.weight)
         gWkv, gbkv = ops.stacked(G(fu.to_k.weight), G(fu.to_v.weight)), ops.stacked(G(fu.to_k.bias), G(fu.to_v.bias))
+        if slabs is not None:
+            ops.grad_weight_deferred(dQ, p_vec, G(fu.to_q.weight), slabs, ar, "slab.to_q", db=G(fu.to_q.bias))
+            ops.grad_input(dQ, fu.to_q.weight, dp, accumulate=True)
+        else:
+            blocks.linear_backward(dQ, p_vec, fu.to_q, G, dp, accumulate_dx=True)
         if Wkv is not None and gWkv is not None and gbkv is not None:
-            ops.grad_weight(dKV, k_vec, gWkv, db=gbkv)          # both projections' gradients from the stacked products
+            if slabs is not None:
+                ops.grad_weight_deferred(dKV, k_vec, gWkv, slabs, ar, "slab.to_kv", db=gbkv)
+            else:
+                ops.grad_weight(dKV, k_vec, gWkv, db=gbkv)          # both projections' gradients from the stacked products
             ops.grad_input(dKV, Wkv, dk, accumulate=True)
         else:
             blocks.linear_backward(dK, k_vec, fu.to_k, G, dk, accumulate_dx=True)
             blocks.linear_backward(dV, k_vec, fu.to_v, G, dk, accumulate_dx=True)
         sel = ar.get("sel", (prow, 6))
         blocks.mlp3_backward(ar, "base", self.pointEncoder.module0, sel, p_vec[:, 3:64], dp[:, 3:64], G, False)
-        self._gcn_backward(ar, dk, B, T, G)
+        if slabs is not None:
+            self._gcn_backward_fused(ar, dk, B, T, G, slabs)
+            slabs.run()
+        else:
+            self._gcn_backward(ar, dk, B, T, G)
+
+    def _gcn_backward_fused(self, ar, dk, B, T, G, slabs):
+        """Backward of the fused ST-GCN step: per block reduce + apply of the closing BatchNorm pair, the temporal convolution's weight
+        and input gradient (the latter with the next BatchNorm's sums in its epilogue), both einsum gradients with that BatchNorm's
+        backward applied on load, the stacked 1x1 convs' weight gradient (slabs deferred) and input gradient: 7 launches (was 14)."""
+        gcn = self.keyEncoder.gcn
+        V = JOINTS_UPPER
+        F, rows = B * T, B * T * V
+        nrt = (rows + 63) // 64
+        dfz = ar.get("gcn.dfz", (rows, 64))
+        hip.call("transpose_batched", dk, dfz, B, 64, T * V)      # (B,64,T*V) -> (B,T*V,64)
+        cur = ar.get("gcn.b2.out", (rows, 128))
+        dcur = ar.get("gcn.d3", (rows, 128))
+        ops.grad_weight_deferred(dfz, cur, G(gcn.fcn.weight), slabs, ar, "slab.fcn", db=G(gcn.fcn.bias))
+        ops.grad_input(dfz, gcn.fcn.weight, dcur)
+        for i in (2, 1, 0):
+            blk = gcn.gcn_networks[i]
+            cin, cout, K = blk.cin, blk.cout, blk.K
+            key = "gcn.b%d" % i
+            inp = ar.get("gcn.b%d.out" % (i - 1), (rows, cin)) if i > 0 else ar.get("gcn.x0", (F, V * 3)).view(rows, 3)
+            out, tz = ar.get(key + ".out", (rows, cout)), ar.get(key + ".tz", (rows, cout))
+            zr = ar.get(key + ".zr", (rows, (K + 1) * cout))
+            z, res_z = zr[:, :K * cout], zr[:, K * cout:]
+            st3, st_r, st0 = ops.BnState(ar, key + ".bn3", cout), ops.BnState(ar, key + ".bnr", cout), ops.BnState(ar, key + ".bn0", cout)
+            dtz = ar.get(key + ".dtz", (rows, cout))
+            dzr = ar.get(key + ".dzr", (rows, (K + 1) * cout))
+            dz, drz = dzr[:, :K * cout], dzr[:, K * cout:]
+            brec = ar.get(key + ".brec", (nrt, 2 * cout, 2))
+            pair = (dcur, dcur.stride(0), out, out.stride(0), tz, tz.stride(0), st3.all, res_z, res_z.stride(0), st_r.all, rows, cout, brec)
+            hip.call("gcn_bn_bwd_reduce", *pair)
+            hip.call("gcn_bn_bwd_apply", *pair, G(blk.tcn["3"].weight), G(blk.tcn["3"].bias), dtz, dtz.stride(0),
+                     G(blk.residual["1"].weight), G(blk.residual["1"].bias), drz, drz.stride(0))
+            y0, ymix = ar.get(key + ".y0", (rows, cout)), ar.get(key + ".ymix", (rows, cout))
+            dy0 = ar.get(key + ".dy0", (rows, cout))
+            wp = ar.get(key + ".wp", (2, blk.tcn["2"].weight.numel()))
+            nsp = hip.lib().mmego_tconv_wgrad_nsplit(B, T, V, cout, cout, blk.taps)
+            wws = ar.get("slab." + key + ".tw", (nsp * blk.taps * cout * cout,))
+            hip.call("tconv_wgrad", dtz, cout, y0, cout, wws, G(blk.tcn["2"].weight), 2, B, T, V, cout, cout, blk.taps)
+            slabs.add(wws, G(blk.tcn["2"].weight), 1, nsp, blk.taps * cout, cout, taps=blk.taps)
+            bwrec = ar.get(key + ".bwrec", (nrt, cout, 2))
+            hip.call("tconv_bwd_stats", dtz, cout, wp[1], dy0, cout, ymix, cout, st0.all, bwrec, B, T, V, cout, cout, blk.taps)
+            nda = hip.lib().mmego_graph_dA_fused_nblk(F)
+            dAp = ar.get("slab." + key + ".dAp", (nda, K * V * V))
+            hip.call("graph_dA_fused", z, z.stride(0), dy0, ymix, st0.all, bwrec, nrt, G(blk.tcn["0"].weight), G(blk.tcn["0"].bias),
+                     F, V, K, cout, dAp, gcn.A, gcn.edge_importance[i], dz, dz.stride(0))
+            slabs.add(dAp, G(gcn.edge_importance[i]), 2, nda, 1, K * V * V, scale=gcn.A)
+            dinp = ar.get(key + ".dinp", (rows, cin))
+            Wc = ops.stacked(blk.gcn.conv.weight.view(K * cout, cin), blk.residual["0"].weight.view(cout, cin))
+            gWc = ops.stacked(G(blk.gcn.conv.weight).view(K * cout, cin), G(blk.residual["0"].weight).view(cout, cin))
+            gbc = ops.stacked(G(blk.gcn.conv.bias), G(blk.residual["0"].bias))
+            ops.grad_weight_deferred(dzr, inp, gWc, slabs, ar, "slab." + key + ".w", db=gbc)
+            ops.grad_input(dzr, Wc, dinp)
+            dcur = dinp
+        # data_bn: only its parameter gradients (its input, the predicted skeleton, is detached: Train_Lower.py:196)
+        dinp = dcur
+        up = ar.get("up", (F, V * 3))
+        st = ops.BnState(ar, "gcn.dbn", V * 3)
+        hip.call("bn_param_grads", dinp.view(F, V * 3), V * 3, up, V * 3, st.all, F, V * 3, G(gcn.data_bn.weight), G(gcn.data_bn.bias))
 
     def _gcn_backward(self, ar, dk, B, T, G):
         gcn = self.keyEncoder.gcn

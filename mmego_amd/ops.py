@@ -223,6 +223,50 @@ def grad_weight(dY, X, dW, db=None, prefer_fused=False):
     return dW
 
 
+class SlabList:
+    """The deferred partial-product sums of one backward pass: split-K weight gradients (grad_weight_deferred), the temporal
+    convolution's weight-gradient slabs and the edge-importance partials are left in buffers of their own (an Arena, not the shared
+    scratch, which the next product would overwrite) and added by ONE mmego_slab_reduce launch at the end of the pass -- every such
+    product used to be followed by a reduce launch of its own in the backward pass's dependent chain."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, ws, out, kind, nsplit, M, N, scm=0, taps=1, scale=None, asum=None):
+        self.items.append(hip.Slab(hip.ptr(ws), hip.ptr(out), hip.ptr(scale), hip.ptr(asum), int(kind), int(nsplit), int(M), int(N), int(taps),
+                                   int(scm)))
+
+    def run(self):
+        for i in range(0, len(self.items), 24):
+            part = self.items[i:i + 24]
+            arr = (hip.Slab * len(part))(*part)
+            hip.call("slab_reduce", len(part), arr)
+        self.items = []
+
+
+def grad_weight_deferred(dY, X, dW, slabs, arena, key, db=None):
+    """grad_weight whose split-K sum is left to ``slabs`` (a SlabList the caller runs at the end of its backward pass); db: the
+    bias gradient rides along as the product's slab row sums where the small-product kernel takes the shape."""
+    W2 = dW.view(dW.shape[0], -1)
+    M, N = W2.shape
+    K = X.shape[0]
+    nsplit = pick_split(M, N, K)
+    fused = db is not None and db.is_contiguous() and asum_ok(M, N, K, nsplit, over_tile=True)
+    if nsplit == 1:
+        mm(dY.t(), X, W2, asum=db if fused else None)
+    else:
+        _chk(dY, 2), _chk(X, 2)
+        if dY.shape[0] != K or dY.shape[1] != M or X.shape[1] != N or not W2.is_contiguous():
+            raise ValueError("grad_weight_deferred shape mismatch")
+        ws = arena.get(key, (nsplit * (M * N + (M if fused else 0)),))
+        hip.call("gemm", dY, dY.stride(1), dY.stride(0), X, X.stride(0), X.stride(1), W2, N, 1, None, M, N, K, 1, 0, 0, 0, 0, 2, ws, nsplit, 0,
+                 None, db if fused else None)
+        slabs.add(ws, W2, 0, nsplit, M, N, scm=N, asum=db if fused else None)
+    if db is not None and not fused:
+        colsum(dY, db)
+    return dW
+
+
 def grad_weight_pair(dY, ncol, X, dW0, dW1, X1=None, db=None):
     """dW0 = dY[:, :ncol]^T @ X and dW1 = dY[:, ncol:2 ncol]^T @ (X1 or X) as ONE batched product (the two directions' weight
     gradients of a BiLSTM layer; their slots in the flat gradient buffer are a fixed distance apart).  Falls back to two

@@ -841,3 +841,43 @@ def test_fused_adam_matches_torch(dev):
             hip.call("adam_step", p, grad.to(dev), m, v, n, state, 3e-5, 0.9, 0.999, 1e-8, wd, None, 0, ticket)
             assert torch.allclose(p.cpu(), ref_p.detach(), rtol=0, atol=2e-7), (wd, step)
         assert state[0].item() == 5.0 and ticket.item() == 0
+
+
+def test_gcn_fused_training_step_equals_the_launch_chain(dev):
+    """The fused ST-GCN training kernels (gcn_fused.hip: BatchNorm statistics as partial records finalized in the consumers'
+    prologues, einsum on MFMAs, deferred slab sums) against the per-operation launch chain they replace (MMEGO_GCN_FUSED=0), on the
+    same Lower_Net and minibatch: outputs, every gradient, BatchNorm running statistics -- and both against the CPU oracle through
+    the tests above.  Two shapes: ragged (frames not a multiple of the 4-frame tile) and the bench shape's row count."""
+    from mmego_amd import nets
+    for Bq, Tq in ((3, 5), (16, 8)):
+        g = torch.Generator().manual_seed(41 + Bq)
+        x = torch.randn(Bq, Tq, 128, 6, generator=g)
+        x[:, :, 90:] = 0.0
+        upper_l = torch.randn(Bq, Tq, 15, 3, generator=g) * 0.3
+        body = 0.2 * torch.randn(Bq, 20, 3, generator=g)
+        R = torch.linalg.qr(torch.randn(Bq, Tq, 3, 3, generator=g))[0].contiguous()
+        t = torch.randn(Bq, Tq, 3, generator=g) * 0.1
+        target = torch.randn(Bq, Tq, 8, 3, generator=g)
+        res = []
+        for fused in (False, True):
+            torch.manual_seed(77)
+            net = nets.LowerNet(64).to(dev).train()
+            net.lstm_dropout = 0.0
+            was = nets._GCN_FUSED
+            nets._GCN_FUSED = fused
+            try:
+                l = net(upper_l.to(dev), x.clone().to(dev), None, None, None, None, body.to(dev), R.to(dev), t.to(dev))[0]
+                (l - target.to(dev)).abs().sum().backward()
+                torch.cuda.synchronize()
+            finally:
+                nets._GCN_FUSED = was
+            assert net._gcn_was_fused == fused
+            res.append((l.detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()},
+                        {k: v.detach().cpu().clone() for k, v in net.named_buffers()}))
+        (l0, g0, b0), (l1, g1, b1) = res
+        assert (l0 - l1).abs().max().item() < 2e-5, (Bq, Tq)
+        scale = max(v.abs().max().item() for v in g0.values())
+        for k in g0:
+            assert (g0[k] - g1[k]).abs().max().item() < 2e-5 * scale, (k, (g0[k] - g1[k]).abs().max().item(), scale)
+        for k in b0:
+            assert (b0[k].double() - b1[k].double()).abs().max().item() < 1e-5 * max(1.0, b0[k].double().abs().max().item()), k
