@@ -426,13 +426,16 @@ int mmego_gcn_front(void* stream, const void* desc);
 /* mmego_tconv in the fused training step: in_bn = MmegoBnRef of the BatchNorm (+ReLU) in front, out_rec [ceil(rows/64)][Cout] =
  * records of the output for the BatchNorm behind; mmego_tconv_bwd_stats = the input-gradient call (X = dY, gradient pack) whose
  * epilogue leaves bw_rec [ceil(rows/64)][Cout] = (sum g, sum g xhat), g = dAct . [bn(ymix) > 0], for the BatchNorm + ReLU in front of
- * the convolution's input (state [4][Cout]).  mmego_tconv_pack_multi: mode-2 packs of up to three weights in one launch. */
+ * the convolution's input (state [4][Cout]).  mmego_pack_multi: every weight re-layout of a step in one launch, n <= 8 entries -- kind 0:
+ * mmego_tconv_pack mode 2 of W[Co][Ci][taps]; kind 1: a k=1 conv weight W[Co][Ci] (both multiples of 32) in the FRAGMENT-MAJOR order
+ * mmego_gcn_front reads with one coalesced 1-KB fetch per MFMA operand group (gcn.hip, pack_multi_kernel) -- MmegoGcnFront.W then
+ * points at that copy when cin >= 32. */
 int mmego_tconv_train(void* stream, const float* X, long ldx, const void* in_bn, const float* Wp, const float* bias, float* Y,
                       long ldy, float* act, float* out_rec, int B, int T, int V, int Cin, int Cout, int taps);
 int mmego_tconv_bwd_stats(void* stream, const float* dY, long lddy, const float* Wp, float* dAct, long ldda, const float* ymix,
                           long ldym, const float* state, float* bw_rec, int B, int T, int V, int Cin, int Cout, int taps);
-int mmego_tconv_pack_multi(void* stream, int n, const float* W0, float* Wp0, int Co0, int Ci0, const float* W1, float* Wp1,
-                           int Co1, int Ci1, const float* W2, float* Wp2, int Co2, int Ci2, int taps);
+typedef struct MmegoPack { const float* W; float* Wp; int Co, Ci, taps, kind; } MmegoPack;
+int mmego_pack_multi(void* stream, int n, const void* descs);
 /* Backward of a block's closing pair out = relu(BN(X1) + BN(X2)) (same dY, mask = out): reduce -> rec [ceil(rows/64)][2C] (sum g, sum
  * g xhat), virtual channels [0, C) = first BatchNorm, [C, 2C) = second; apply: finalize in the prologue, dX = a (g - mean(g) - xhat
  * mean(g xhat)) for both, d(gamma) / d(beta) by workgroup 0.  st1 / st2: state [4][C].  C % 4 == 0, C <= 128. */

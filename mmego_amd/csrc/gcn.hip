@@ -114,7 +114,6 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = t >> 6;
   float* stl = smem + NG * 2 * 64 * GC_S;                  // REC: [4][Cin] mean, a, b, invstd of the BatchNorm in front
-  if (REC) bn_from_records<256 * NG>(p.in_bn, p.Cin, p.rows, reinterpret_cast<double*>(smem), stl, blockIdx.x == 0 && blockIdx.y == 0);
   float* As = smem + grp * 2 * 64 * GC_S;
   float* Bs = As + 64 * GC_S;
   const int rt = wave & 1, ct = wave >> 1;
@@ -149,11 +148,7 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
     const int d_ = tap_ - half;                                                                     \
     const int kk_ = k0_ + 4 * c4;                                                                   \
     const int kc_ = kk_ < p.Cin ? kk_ : 0;                                                          \
-    if (ACT && REC) {                                                                               \
-      mu = *reinterpret_cast<const f32x4*>(stl + kc_);                                              \
-      sa = *reinterpret_cast<const f32x4*>(stl + p.Cin + kc_);                                      \
-      sb = *reinterpret_cast<const f32x4*>(stl + 2 * p.Cin + kc_);                                  \
-    } else if (ACT) {                                                                               \
+    if (ACT && !REC) {                                                                              \
       mu = *reinterpret_cast<const f32x4*>(p.in_state + kc_);                                       \
       sa = *reinterpret_cast<const f32x4*>(p.in_state + 2 * p.Cin + kc_);                           \
       sb = *reinterpret_cast<const f32x4*>(p.in_state + 3 * p.Cin + kc_);                           \
@@ -172,6 +167,12 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
     const int d_ = (ch) / nkc - half;                                                               \
     const bool kok_ = ((ch) % nkc) * 64 + 4 * c4 < p.Cin;                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) { TC_PIN4(av[j]); TC_PIN4(bv[j]); }               \
+    if (ACT && REC) {                      /* the state finalized in this kernel's prologue: from LDS, when the values are used */ \
+      const int kq_ = kok_ ? ((ch) % nkc) * 64 + 4 * c4 : 0;                                        \
+      mu = *reinterpret_cast<const f32x4*>(stl + kq_);                                              \
+      sa = *reinterpret_cast<const f32x4*>(stl + p.Cin + kq_);                                      \
+      sb = *reinterpret_cast<const f32x4*>(stl + 2 * p.Cin + kq_);                                  \
+    }                                                                                               \
     if (ACT) { TC_PIN4(mu); TC_PIN4(sa); TC_PIN4(sb); }                                             \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
       const int ts_ = tv[j] + d_;                                                                   \
@@ -190,6 +191,8 @@ __global__ __launch_bounds__(256 * NG) void tconv_kernel(TconvP p) {
   // (issued unconditionally, past the last step on a clamped index: a load under a condition would have its values copied -- and
   // waited for -- where the condition ends)
   TC_ISSUE(grp < nchunks ? grp : nchunks - 1);
+  // (REC: the first step's loads fly while the statistics of the BatchNorm in front are finalized from its partial records)
+  if (REC) bn_from_records<256 * NG>(p.in_bn, p.Cin, p.rows, reinterpret_cast<double*>(smem), stl, blockIdx.x == 0 && blockIdx.y == 0);
   f32x16 acc = {0};
   const bool live = n0 + ct * 32 < p.Cout && r0 + rt * 32 < p.rows;      // (a wave whose whole 32 x 32 part is padding skips the MFMAs)
   for (int ch0 = 0; ch0 < nchunks; ch0 += NG) {
@@ -588,38 +591,48 @@ extern "C" int mmego_tconv_bwd_stats(void* stream, const float* dY, long lddy, c
   return tconv_launch((hipStream_t)stream, p, false);
 }
 
-// Up to four temporal-conv weights packed by ONE launch (mode 2 of mmego_tconv_pack each: forward pack, gradient pack behind it)
-struct PackTab { const float* W[4]; float* Wp[4]; int Co[4], Ci[4], blk0[5]; int taps, n; };
-__global__ __launch_bounds__(256) void tconv_pack_multi_kernel(PackTab t) {
+// Every weight re-layout of a training step in ONE launch (host table of up to 8 entries):
+//   kind 0  temporal-conv weight W[co][ci][tap] -> mode 2 of mmego_tconv_pack (forward pack, gradient pack behind it)
+//   kind 1  a k=1 conv weight W[n][k] (n % 32 == 0, k % 32 == 0) -> FRAGMENT-MAJOR for gcn_front's 32x32x2 MFMAs:
+//           Wp[((((n/32) * (K/32) + k/32) * 4 + (k%16)/4) * 64 + (k%32)/16 * 32 + n%32) * 4 + k%4]: a wave's operand fetch is four
+//           coalesced 1-KB reads (fetched row by row, 32 rows 128-512 B apart per instruction, the same bytes took 5-6 us per kernel)
+struct PackTab { const float* W[8]; float* Wp[8]; int Co[8], Ci[8], taps[8], kind[8], blk0[9]; int n; };
+__global__ __launch_bounds__(256) void pack_multi_kernel(PackTab t) {
   int k = 0;
   while (k + 1 < t.n && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
-  const int Co = t.Co[k], Ci = t.Ci[k], taps = t.taps;
+  const int Co = t.Co[k], Ci = t.Ci[k], taps = t.taps[k];
   const long total = (long)Co * Ci * taps;
   const long i = (long)(blockIdx.x - t.blk0[k]) * 256 + threadIdx.x;
   if (i >= total) return;
-  const int tap = (int)(i % taps);
-  const long q = i / taps;
-  const int ci = (int)(q % Ci), co = (int)(q / Ci);
   const float w = t.W[k][i];
-  t.Wp[k][((long)tap * Co + co) * Ci + ci] = w;
-  t.Wp[k][total + ((long)(taps - 1 - tap) * Ci + ci) * Co + co] = w;
+  if (t.kind[k] == 0) {
+    const int tap = (int)(i % taps);
+    const long q = i / taps;
+    const int ci = (int)(q % Ci), co = (int)(q / Ci);
+    t.Wp[k][((long)tap * Co + co) * Ci + ci] = w;
+    t.Wp[k][total + ((long)(taps - 1 - tap) * Ci + ci) * Co + co] = w;
+  } else {
+    const int n = (int)(i / Ci), kk = (int)(i - (long)n * Ci);
+    const int ct = n >> 5, r = n & 31, kc = kk >> 5, k32 = kk & 31, h = k32 >> 4, j = (k32 & 15) >> 2, e = k32 & 3;
+    t.Wp[k][((((long)ct * (Ci >> 5) + kc) * 4 + j) * 64 + h * 32 + r) * 4 + e] = w;
+  }
 }
 
-extern "C" int mmego_tconv_pack_multi(void* stream, int n, const float* W0, float* Wp0, int Co0, int Ci0, const float* W1, float* Wp1,
-                                      int Co1, int Ci1, const float* W2, float* Wp2, int Co2, int Ci2, int taps) {
-  MMEGO_REQUIRE(n >= 1 && n <= 3 && taps >= 1 && W0 && Wp0);
+struct MmegoPackH { const float* W; float* Wp; int Co, Ci, taps, kind; };
+
+extern "C" int mmego_pack_multi(void* stream, int n, const void* descs) {
+  const MmegoPackH* h = static_cast<const MmegoPackH*>(descs);
+  MMEGO_REQUIRE(h && n >= 1 && n <= 8);
   PackTab t;
-  const float* W[3] = {W0, W1, W2};
-  float* Wp[3] = {Wp0, Wp1, Wp2};
-  const int Co[3] = {Co0, Co1, Co2}, Ci[3] = {Ci0, Ci1, Ci2};
   int blk = 0;
   for (int k = 0; k < n; ++k) {
-    MMEGO_REQUIRE(W[k] && Wp[k] && Co[k] >= 1 && Ci[k] >= 1);
-    t.W[k] = W[k]; t.Wp[k] = Wp[k]; t.Co[k] = Co[k]; t.Ci[k] = Ci[k]; t.blk0[k] = blk;
-    blk += (int)(((long)Co[k] * Ci[k] * taps + 255) / 256);
+    MMEGO_REQUIRE(h[k].W && h[k].Wp && h[k].Co >= 1 && h[k].Ci >= 1 && h[k].taps >= 1 && (h[k].kind == 0 || h[k].kind == 1));
+    MMEGO_REQUIRE(h[k].kind == 0 || (h[k].taps == 1 && (h[k].Co % 32) == 0 && (h[k].Ci % 32) == 0));
+    t.W[k] = h[k].W; t.Wp[k] = h[k].Wp; t.Co[k] = h[k].Co; t.Ci[k] = h[k].Ci; t.taps[k] = h[k].taps; t.kind[k] = h[k].kind; t.blk0[k] = blk;
+    blk += (int)(((long)h[k].Co * h[k].Ci * h[k].taps + 255) / 256);
   }
-  t.blk0[n] = blk; t.taps = taps; t.n = n;
-  hipLaunchKernelGGL(tconv_pack_multi_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, t);
+  t.blk0[n] = blk; t.n = n;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, t);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -21,6 +21,7 @@
 //   slab_reduce    every split-K / split-row partial product of a backward pass summed by ONE launch at its end (fixed order)
 //   bn_param_grads data_bn's d(gamma), d(beta) alone (its input gradient is never used: the skeleton input is detached)
 // All reductions have a fixed order: results are bit-identical from run to run and between the graph / eager engines.
+#include <stdlib.h>
 #include "gcn_stats.h"
 
 #define GF_NT 512          // threads of gcn_front
@@ -39,7 +40,30 @@ struct GcnFrontD {
   float2* recY; float2* recR;
   float* outT; int T;      // mix = 0: product stored transposed, outT[b][nout][T*V]
   long F; int V;
+  int dbg;                 // diagnostic mask (MMEGO_GCN_DBG; 0 in production): phases to skip, for timing by elimination
 };
+
+// Rows [0, nrows) x ncols floats of an LDS tile (row stride S, rows 16-byte aligned) -> global rows of stride ld: all GF_NT threads,
+// 16-byte pieces, a thread's LDS reads all ahead of its stores and no predicate on a store (indices past the end are clamped to the
+// last piece: those lanes write the same value again) -- a store under a predicate waits for the store before it.
+template <int NB>
+__device__ __forceinline__ void tile_out(const float* lds, int S, float* g, long ld, int nrows, int ncols, int tid) {
+  const int c4n = ncols >> 2, n4 = nrows * c4n;
+  for (int i0 = 0; i0 < n4; i0 += GF_NT * NB) {
+    f32x4 v[NB];
+    int off[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      int i = i0 + tid + GF_NT * u;
+      i = i < n4 ? i : n4 - 1;
+      const int row = i / c4n, c = (i - row * c4n) << 2;
+      v[u] = *reinterpret_cast<const f32x4*>(lds + row * S + c);
+      off[u] = row * 4096 + c;                           // (packed: row, column)
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) *reinterpret_cast<f32x4*>(g + (long)(off[u] >> 12) * ld + (off[u] & 4095)) = v[u];
+  }
+}
 
 // NCTW: 32-column tiles of the product per wave pair (4 wave pairs x 2 row halves); NK: 32-k chunks (0: scalar product, cin < 32)
 template <int NCTW, int NK>
@@ -51,7 +75,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
   const int nf = (int)(p.F - f0 < GF_FPB ? p.F - f0 : GF_FPB);
   const int nv = nf * V;                                 // valid rows of this tile (<= 60)
   const long r0 = f0 * V, rows = p.F * V;
-  const int XS = (NK ? cin : 4) + 4, ZS = nout + 16, YS = cout + 4;
+  const int XS = (NK ? cin : 4) + 4, ZS = p.mix ? nout + 16 : nout + 1, YS = cout + 4;
   float* st = sm;                                        // [2][4][cin]: mean, a, b, invstd of bn1 | bn2 (bn_from_records)
   float* zs = sm + GF_ST;                                // [64][ZS] product tile
   float* xs = zs + 64 * ZS;                              // [64][XS] input tile; later ys [60][YS]
@@ -60,8 +84,8 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
   const bool first = blockIdx.x == 0;
 
   // ---- the product's weight fragments: requested first, they fly under the statistics prologue.  Lane (r, h) of a 32x32x2 MFMA
-  // takes k = k0 + 16 h + s on BOTH operands (same permutation: the sum over k is unchanged), so a weight row's 16 values are
-  // four 16-byte loads straight into the operand registers -- no LDS staging of W.
+  // takes k = k0 + 16 h + s on BOTH operands (same permutation: the sum over k is unchanged); W comes FRAGMENT-MAJOR (mmego_pack_multi
+  // kind 1), so the four 16-byte loads of a (tile, chunk) are coalesced 1-KB reads straight into the operand registers.
   const int r = lane & 31, h = lane >> 5, rt = wave & 1, wp = wave >> 1, NCT = nout / 32;
   f32x4 wf[NCTW ? NCTW : 1][NK ? NK : 1][4];
   if (NK) {
@@ -72,7 +96,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
       for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          wf[i][kc][j] = *reinterpret_cast<const f32x4*>(p.W + (long)(ct * 32 + r) * cin + kc * 32 + 16 * h + 4 * j);
+          wf[i][kc][j] = *reinterpret_cast<const f32x4*>(p.W + ((((long)ct * NK + kc) * 4 + j) * 64 + lane) * 4);
     }
   }
   // A . importance as MFMA operand registers: ae[k][s] = (A.imp)[k][v = 4 s + lane/16][w = lane%16]
@@ -96,16 +120,21 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
     const int C = V * cin, c = tid & 63, q = tid >> 6;       // 8 row groups x 64 channel lanes
     const int cc = c < C ? c : C - 1;
     const float shift = p.X1[cc];
+    // this thread's element of the input tile and its piece of the (tiny) weight: requested now, used behind the statistics
+    const int xi = tid < nv * cin ? tid : 0, xrow = xi / cin, xch = xi - xrow * cin, xfch = (xrow % V) * cin + xch;
+    float xin = p.X1[(f0 + xrow / V) * C + xfch];
+    float wst = p.W[tid < nout * cin ? tid : 0], bst = p.bias ? p.bias[tid < nout ? tid : 0] : 0.f;
+    BnPre pre = bn_preload(p.bn1, C, 0, first);
     float s1 = 0.f, s2 = 0.f;
-    for (long fb = q; fb < p.F; fb += 8 * 16) {
-      float v[16];
+    for (long fb = q; fb < p.F; fb += 8 * 32) {
+      float v[32];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < 32; ++u) {
         const long f = fb + 8 * u;
         v[u] = p.X1[(f < p.F ? f : p.F - 1) * C + cc];
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < 32; ++u) {
         asm volatile("" : "+v"(v[u]));
         const float d = fb + 8 * u < p.F ? v[u] - shift : 0.f;
         s1 += d; s2 += d * d;
@@ -113,6 +142,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
     }
     red[(q * 2 + 0) * 64 + c] = (double)s1; red[(q * 2 + 1) * 64 + c] = (double)s2;
     __syncthreads();
+    asm volatile("" : "+v"(pre.g), "+v"(pre.b), "+v"(pre.rm), "+v"(pre.rv));
     if (tid < C) {
       double S1 = 0.0, S2 = 0.0;
       for (int g = 0; g < 8; ++g) { S1 += red[(g * 2 + 0) * 64 + tid]; S2 += red[(g * 2 + 1) * 64 + tid]; }
@@ -122,27 +152,27 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
       m2 = m2 > 0.0 ? m2 : 0.0;
       const double var = m2 / N;
       const float invstd = (float)(1.0 / sqrt(var + (double)p.bn1.eps));
-      const float a = p.bn1.gamma[tid] * invstd, b = p.bn1.beta[tid];
+      const float a = pre.g * invstd, b = pre.b;
       st[tid] = (float)mean; st[C + tid] = a; st[2 * C + tid] = b;
       if (first) {
         if (p.bn1.state) { p.bn1.state[tid] = (float)mean; p.bn1.state[C + tid] = invstd; p.bn1.state[2 * C + tid] = a; p.bn1.state[3 * C + tid] = b; }
         if (p.bn1.rmean) {
-          p.bn1.rmean[tid] = (1.f - p.bn1.momentum) * p.bn1.rmean[tid] + p.bn1.momentum * (float)mean;
+          p.bn1.rmean[tid] = (1.f - p.bn1.momentum) * pre.rm + p.bn1.momentum * (float)mean;
           const double unbiased = N > 1.0 ? m2 / (N - 1.0) : var;
-          p.bn1.rvar[tid] = (1.f - p.bn1.momentum) * p.bn1.rvar[tid] + p.bn1.momentum * (float)unbiased;
+          p.bn1.rvar[tid] = (1.f - p.bn1.momentum) * pre.rv + p.bn1.momentum * (float)unbiased;
         }
       }
     }
     __syncthreads();
-    // input tile: x[(f, v)][c] = (X1[f][v cin + c] - mean) a + b
-    for (int i = tid; i < 64 * XS; i += GF_NT) xs[i] = 0.f;
-    __syncthreads();
-    for (int i = tid; i < nv * cin; i += GF_NT) {
-      const int row = i / cin, ch = i - row * cin, fch = (row % V) * cin + ch;
-      const float x = __builtin_fmaf(p.X1[(f0 + row / V) * C + fch] - st[fch], st[C + fch], st[2 * C + fch]);
-      xs[row * XS + ch] = x;
-      if (p.xact) p.xact[(r0 + row) * cin + ch] = x;
+    // input tile: x[(f, v)][c] = (X1[f][v cin + c] - mean) a + b   (nv * cin <= 512: one element per thread)
+    asm volatile("" : "+v"(xin), "+v"(wst), "+v"(bst));
+    if (tid < nv * cin) {
+      const float x = __builtin_fmaf(xin - st[xfch], st[C + xfch], st[2 * C + xfch]);
+      xs[xrow * XS + xch] = x;
+      if (p.xact) p.xact[(r0 + xrow) * cin + xch] = x;
     }
+    if (tid < nout * cin) st[256 + tid] = wst;            // W [nout][cin] and bias behind the statistics (nout * cin <= 512)
+    if (tid < nout) st[768 + tid] = bst;
   } else {
     // the tile's loads first (clamped rows), the two finalizations while they fly
     const int c4n = cin / 4;                               // 16-byte pieces per row
@@ -155,8 +185,12 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
       v1[u] = *reinterpret_cast<const f32x4*>(p.X1 + (r0 + rc) * p.ld1 + 4 * (in ? c4 : 0));
       v2[u] = *reinterpret_cast<const f32x4*>(p.X2 + (r0 + rc) * p.ld2 + 4 * (in ? c4 : 0));
     }
-    bn_from_records<GF_NT>(p.bn1, cin, rows, red, st, first);
-    bn_from_records<GF_NT>(p.bn2, cin, rows, red, st + 4 * cin, first);
+    const BnPre pre1 = bn_preload(p.bn1, cin, 0, first), pre2 = bn_preload(p.bn2, cin, 256, first);
+    if (!(p.dbg & 1)) bn_gather2<GF_NT>(p.bn1, p.bn2, cin, rows, red, red + 2048);
+    __syncthreads();
+    bn_finish<GF_NT>(p.bn1, cin, red, st, first, 0, pre1);
+    bn_finish<GF_NT>(p.bn2, cin, red + 2048, st + 4 * cin, first, 256, pre2);
+    __syncthreads();
     const float *m1 = st, *a1 = st + cin, *b1 = st + 2 * cin, *m2 = st + 4 * cin, *a2 = st + 5 * cin, *b2 = st + 6 * cin;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -172,8 +206,11 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
           o[e] = row < nv ? fmaxf(t, 0.f) : 0.f;
         }
         *reinterpret_cast<f32x4*>(xs + row * XS + c) = o;
-        if (p.xact && row < nv) *reinterpret_cast<f32x4*>(p.xact + (r0 + row) * cin + c) = o;
       }
+    }
+    if (p.xact && !(p.dbg & 2)) {
+      __syncthreads();
+      tile_out<2>(xs, XS, p.xact + r0 * cin, cin, nv, cin, tid);
     }
   }
   __syncthreads();
@@ -183,7 +220,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
 #pragma unroll
     for (int i = 0; i < NCTW; ++i) {
       const int ct = wp + 4 * i;
-      if (ct < NCT) {                                      // (uniform per wave)
+      if (ct < NCT && !(p.dbg & 16)) {                     // (uniform per wave)
         f32x16 acc = {0};
 #pragma unroll
         for (int kc = 0; kc < NK; ++kc) {
@@ -202,30 +239,28 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
           const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
           const float v = acc[reg] + bb;
           zs[row * ZS + col] = v;
-          if (p.mix && row < nv) p.Z[(r0 + row) * p.ldz + col] = v;
         }
       }
     }
   } else {
-    for (int i = tid; i < nv * nout; i += GF_NT) {
-      const int row = i / nout, col = i - row * nout;
-      float v = p.bias ? p.bias[col] : 0.f;
-      for (int c = 0; c < cin; ++c) v = __builtin_fmaf(xs[row * XS + c], p.W[col * cin + c], v);
-      zs[row * ZS + col] = v;
-      if (p.mix) p.Z[(r0 + row) * p.ldz + col] = v;
-    }
+    for (int row = wave; row < nv; row += GF_NT / 64)
+      for (int col = lane; col < nout; col += 64) {
+        float v = st[768 + col];
+        for (int c = 0; c < cin; ++c) v = __builtin_fmaf(xs[row * XS + c], st[256 + col * cin + c], v);
+        zs[row * ZS + col] = v;
+      }
   }
   __syncthreads();
+  if (p.mix && !(p.dbg & 2)) tile_out<4>(zs, ZS, p.Z + r0 * p.ldz, p.ldz, nv, nout, tid);          // (z | residual pre-activation) leave together
 
   if (!p.mix) {
     // closing 1x1 conv: transposed store outT[b][col][t V + v] (consecutive threads walk a column's rows: contiguous addresses)
-    const int TV = p.T * V;
-    for (int i = tid; i < nv * nout; i += GF_NT) {
-      const int col = i / nv, rr = i - col * nv;
+    const int TV = p.T * V, rr = lane;                     // (a wave walks 64 consecutive rows of one column per round)
+    if (rr < nv) {
       const long f = f0 + rr / V;
       const long b = f / p.T;
-      const int tv = (int)(f - b * p.T) * V + rr % V;
-      p.outT[(b * nout + col) * TV + tv] = zs[rr * ZS + col];
+      float* dst = p.outT + b * nout * TV + (int)(f - b * p.T) * V + rr % V;
+      for (int col = wave; col < nout; col += GF_NT / 64) dst[(long)col * TV] = zs[rr * ZS + col];
     }
     return;
   }
@@ -235,7 +270,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
   {
     const int nch = cout / 16, npair = nf * nch;
     const int vq = lane >> 4, cl = lane & 15;
-    for (int pi = wave; pi < npair; pi += GF_NT / 64) {
+    for (int pi = wave; pi < ((p.dbg & 4) ? 0 : npair); pi += GF_NT / 64) {
       const int fi = pi / nch, n0 = (pi - fi * nch) * 16;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -250,28 +285,40 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
         }
       }
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int w = 4 * vq + reg;
-        if (w < V) {
-          p.Y[(r0 + fi * V + w) * cout + n0 + cl] = acc[reg];
-          ys[(fi * V + w) * YS + n0 + cl] = acc[reg];
-        }
-      }
+      for (int reg = 0; reg < 4; ++reg) ys[(fi * 16 + 4 * vq + reg) * YS + n0 + cl] = acc[reg];     // (16 rows per frame: row V is a dummy)
     }
   }
   __syncthreads();
-  // ---- BatchNorm partial records of the einsum output and of the residual pre-activation over this tile's rows
-  if (tid < 2 * cout) {
-    const bool res = tid >= cout;
-    const int c = res ? tid - cout : tid;
-    const float* col = res ? zs + p.Kk * cout + c : ys + c;
+  if (!(p.dbg & 2)) for (int fi = 0; fi < nf; ++fi) tile_out<1>(ys + fi * 16 * YS, YS, p.Y + (r0 + fi * V) * cout, cout, V, cout, tid);
+  // ---- BatchNorm partial records of the einsum output and of the residual pre-activation over this tile's rows: thread (column,
+  // row part) takes every P-th row (shifted sums, four loads in flight), the parts are added in a fixed order
+  if (!(p.dbg & 8)) {
+    const int ncol = 2 * cout, P = GF_NT / ncol;          // cout 32 / 64 / 128: 8 / 4 / 2 row parts
+    const int cid = tid % ncol, part = tid / ncol;
+    const bool res = cid >= cout;
+    const float* col = res ? zs + p.Kk * cout + (cid - cout) : ys + cid;
     const int S = res ? ZS : YS;
-    float s = 0.f;
-    for (int rr = 0; rr < nv; ++rr) s += col[rr * S];
-    const float mean = s / (float)nv;
-    float m2 = 0.f;
-    for (int rr = 0; rr < nv; ++rr) { const float d = col[rr * S] - mean; m2 = __builtin_fmaf(d, d, m2); }
-    (res ? p.recR : p.recY)[(long)blockIdx.x * cout + c] = float2{mean, m2};
+    const float shift = col[0];
+    float s1 = 0.f, s2 = 0.f;
+    if (part < P) {
+      for (int rr = part; rr < nv; rr += 4 * P) {
+        float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                      // (ys keeps 16 rows per frame, zs V)
+          const int q = rr + u * P < nv ? rr + u * P : 0;
+          d[u] = col[(res ? q : q + q / V) * S] - shift;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float dd = rr + u * P < nv ? d[u] : 0.f; s1 += dd; s2 = __builtin_fmaf(dd, dd, s2); }
+      }
+      st[(part * ncol + cid) * 2] = s1; st[(part * ncol + cid) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (tid < ncol) {
+      float a = 0.f, b = 0.f;
+      for (int j = 0; j < P; ++j) { a += st[(j * ncol + tid) * 2]; b += st[(j * ncol + tid) * 2 + 1]; }
+      (res ? p.recR : p.recY)[(long)blockIdx.x * cout + (res ? tid - cout : tid)] = rec_from_shifted(shift, a, b, nv);
+    }
   }
 }
 
@@ -331,22 +378,22 @@ __global__ __launch_bounds__(256) void gcn_bn_bwd_reduce_kernel(GcnBnBwdD p) {
 // sums of (s1, s2) records rec[nrec][CT] per channel, all NT threads taking part, fp64, fixed order -> c12 [2][CT] in LDS
 // (c1 = s1 / rows, c2 = s2 / rows); red: (NT / CP) * 2 * CP doubles.  The raw sums go to sums[2][CT] (LDS, float).
 template <int NT>
-__device__ __forceinline__ void bwd_sums_from_records(const float2* rec, int nrec, int CT, long rows, double* red, float* c12, float* sums) {
+__device__ __forceinline__ void bwd_gather(const float2* rec, int nrec, int CT, double* red) {
   int CP = 32;
   while (CP < CT) CP <<= 1;
   const int Q = NT / CP;
   const int tid = threadIdx.x, c = tid & (CP - 1), q = tid / CP;
   const int cc = c < CT ? c : CT - 1;
   double a = 0.0, b = 0.0;
-  for (int j0 = q; j0 < nrec; j0 += 8 * Q) {
-    float2 v[8];
+  for (int j0 = q; j0 < nrec; j0 += 16 * Q) {
+    float2 v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int j = j0 + u * Q;
       v[u] = rec[(long)(j < nrec ? j : nrec - 1) * CT + cc];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       asm volatile("" : "+v"(v[u].x), "+v"(v[u].y));
       const bool ok = j0 + u * Q < nrec;
       a += ok ? (double)v[u].x : 0.0;
@@ -354,21 +401,29 @@ __device__ __forceinline__ void bwd_sums_from_records(const float2* rec, int nre
     }
   }
   red[(q * 2 + 0) * CP + c] = a; red[(q * 2 + 1) * CP + c] = b;
-  __syncthreads();
+}
+// (behind a barrier) c12[2][CT] = the sums / rows; the raw sums are returned to threads < CT (d(beta), d(gamma))
+template <int NT>
+__device__ __forceinline__ float2 bwd_finish(int CT, long rows, const double* red, float* c12) {
+  int CP = 32;
+  while (CP < CT) CP <<= 1;
+  const int Q = NT / CP;
+  const int tid = threadIdx.x;
+  float2 out = {0.f, 0.f};
   if (tid < CT) {
     double s1 = 0.0, s2 = 0.0;
     for (int g = 0; g < Q; ++g) { s1 += red[(g * 2 + 0) * CP + tid]; s2 += red[(g * 2 + 1) * CP + tid]; }
-    sums[tid] = (float)s1; sums[CT + tid] = (float)s2;
+    out = float2{(float)s1, (float)s2};
     c12[tid] = (float)(s1 / (double)rows); c12[CT + tid] = (float)(s2 / (double)rows);
   }
-  __syncthreads();
+  return out;
 }
 
 // dX = a (g - c1 - xhat c2) for both BatchNorms of the pair; c1, c2 finalized in the prologue from the reduce kernel's records
 #define GBA_NT 1024
 __global__ __launch_bounds__(GBA_NT) void gcn_bn_bwd_apply_kernel(GcnBnBwdD p, long rows_per_wg) {
   __shared__ double red[GBA_NT / 32 * 2 * 32 > 4 * 2 * 256 ? GBA_NT / 32 * 2 * 32 : 4 * 2 * 256];
-  __shared__ float c12[2 * 256], sums[2 * 256], stl[2][3][128];
+  __shared__ float c12[2 * 256], stl[2][3][128];
   const int tid = threadIdx.x, C = p.C, CT = 2 * C;
   const long rbeg = (long)blockIdx.x * rows_per_wg, rend = rbeg + rows_per_wg < p.rows ? rbeg + rows_per_wg : p.rows;
   // first round of this workgroup's loads, then the prologue
@@ -386,15 +441,19 @@ __global__ __launch_bounds__(GBA_NT) void gcn_bn_bwd_apply_kernel(GcnBnBwdD p, l
       x20 = *reinterpret_cast<const f32x4*>(p.X2 + row * p.ld2 + c);
     }
   }
+  // (the BatchNorm states ride in the same memory round trip as the records: registers now, LDS behind the gather)
+  const int sc = tid < C ? tid : 0;
+  float sv[6] = {p.st1[sc], p.st1[C + sc], p.st1[2 * C + sc], p.st2[sc], p.st2[C + sc], p.st2[2 * C + sc]};
+  bwd_gather<GBA_NT>(p.rec, p.nrec, CT, red);
+#pragma unroll
+  for (int e = 0; e < 6; ++e) asm volatile("" : "+v"(sv[e]));
   if (tid < C) {
-    stl[0][0][tid] = p.st1[tid]; stl[0][1][tid] = p.st1[C + tid]; stl[0][2][tid] = p.st1[2 * C + tid];
-    stl[1][0][tid] = p.st2[tid]; stl[1][1][tid] = p.st2[C + tid]; stl[1][2][tid] = p.st2[2 * C + tid];
+    stl[0][0][tid] = sv[0]; stl[0][1][tid] = sv[1]; stl[0][2][tid] = sv[2];
+    stl[1][0][tid] = sv[3]; stl[1][1][tid] = sv[4]; stl[1][2][tid] = sv[5];
   }
-  bwd_sums_from_records<GBA_NT>(p.rec, p.nrec, CT, p.rows, red, c12, sums);
-  if (blockIdx.x == 0 && tid < CT) {                     // d(beta) = sum g, d(gamma) = sum g xhat
-    if (tid < C) { p.db1[tid] = sums[tid]; p.dg1[tid] = sums[CT + tid]; }
-    else { p.db2[tid - C] = sums[tid]; p.dg2[tid - C] = sums[CT + tid]; }
-  }
+  __syncthreads();
+  const float2 tot = bwd_finish<GBA_NT>(CT, p.rows, red, c12);
+  __syncthreads();
   for (long i0 = 0; i0 < npiece; i0 += GBA_NT) {
     const long i = i0 + tid;
     f32x4 g = g0, m = m0, x1 = x10, x2 = x20;
@@ -422,6 +481,10 @@ __global__ __launch_bounds__(GBA_NT) void gcn_bn_bwd_apply_kernel(GcnBnBwdD p, l
       *reinterpret_cast<f32x4*>(p.dX2 + row * p.lddx2 + c) = o2;
     }
   }
+  if (blockIdx.x == 0 && tid < CT) {                     // d(beta) = sum g, d(gamma) = sum g xhat (stored last: no load waits behind them)
+    if (tid < C) { p.db1[tid] = tot.x; p.dg1[tid] = tot.y; }
+    else { p.db2[tid - C] = tot.x; p.dg2[tid - C] = tot.y; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -436,54 +499,149 @@ struct GraphDAFusedD {
   float* partial; const float* A; const float* imp; float* dZ; long lddz;
 };
 
-__global__ __launch_bounds__(512) void graph_dA_fused_kernel(GraphDAFusedD p) {
+// 256 threads; a wave takes the (frame, partition k) pairs of the workgroup's GDF_FPB frames in turn.  Per pair, on 16x16x4 MFMAs:
+//   dz_k[v][c] = sum_w (A.imp)[k][v][w] dy[w][c]      A operand = (A.imp)_k (registers), B = the frame's dy rows (LDS)
+//   dA_k[v][w] += sum_c z_k[v][c] dy[w][c]            A = z_k rows, B = dy rows, both from LDS, the channel axis as k
+// dy is formed while the frame's rows are staged (the BatchNorm + ReLU backward); all of a frame's loads are in flight together and
+// the next frame's are requested before the current one is multiplied; dz leaves through LDS in 16-byte pieces.
+__global__ __launch_bounds__(256) void graph_dA_fused_kernel(GraphDAFusedD p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int V = p.V, Kk = p.Kk, C = p.C, KC = Kk * C;
-  float* zs = sm;                       // [V][KC + 1]
-  float* ys = zs + V * (KC + 1);        // [V][C + 1]
-  float* As = ys + V * (C + 1);         // [Kk][V][V]
-  float* c12 = As + Kk * V * V;         // [2][C]
-  float* sums = c12 + 2 * C;            // [2][C]
-  float* stl = sums + 2 * C;            // [3][C] mean, invstd, a ... b kept too: [4][C]
-  double* red = reinterpret_cast<double*>(sm + (((V * (KC + 1) + V * (C + 1) + Kk * V * V + 8 * C) + 1) & ~1));
-  const int tid = threadIdx.x;
-  for (int i = tid; i < Kk * V * V; i += 512) As[i] = p.A[i] * p.imp[i];
-  for (int i = tid; i < 4 * C; i += 512) stl[i] = p.st0[i];
-  bwd_sums_from_records<512>(p.rec, p.nrec, C, p.G * V, red, c12, sums);
-  if (blockIdx.x == 0 && tid < C) { p.db0[tid] = sums[tid]; p.dg0[tid] = sums[C + tid]; }
-  const int nout = Kk * V * V;
-  const int e = tid;
-  const int w = e % V, v = (e / V) % V, k = e / (V * V);
-  float acc = 0.f;
+  const int ZS = KC + 4, YS = C + 4;                     // row strides: 16-byte aligned rows, lanes 16 apart in k hit other banks
+  float* zs = sm;                                        // [16][ZS] z of the frame (row 15: zero), later dz
+  float* ys = zs + 16 * ZS;                              // [16][YS] dy
+  float* c12 = ys + 16 * YS;                             // [2][C]
+  float* stl = c12 + 2 * C;                              // [4][C]
+  float* dAs = stl + 4 * C;                              // [4 waves][256] partial dA tiles
+  double* red = reinterpret_cast<double*>(dAs + 1024);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 15, hi = lane >> 4;
+  // A . importance as the dz product's A operand: ae[k][s] = (A.imp)[k][v = lane%16][w = 4 s + lane/16]
+  float ae[3][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int v = lo, w = 4 * s + hi;
+      const bool ok = k < Kk && v < V && w < V;
+      const int idx = ok ? (k * V + v) * V + w : 0;
+      const float a = p.A[idx], im = p.imp[idx];
+      ae[k][s] = ok ? a * im : 0.f;
+    }
+  float sv[2] = {p.st0[tid < 4 * C ? tid : 0], p.st0[tid + 256 < 4 * C ? tid + 256 : 0]};
   const long g0 = (long)blockIdx.x * GDF_FPB;
-  for (long g = g0; g < g0 + GDF_FPB && g < p.G; ++g) {
-    __syncthreads();
-    for (int i = tid; i < V * KC; i += 512) zs[(i / KC) * (KC + 1) + (i % KC)] = p.Z[(g * V + i / KC) * p.ldz + (i % KC)];
-    for (int i = tid; i < V * C; i += 512) {
-      const int c = i % C;
-      const float ym = p.Ym[g * V * C + i], d0 = p.dY0[g * V * C + i];
-      const float gg = __builtin_fmaf(ym - stl[c], stl[2 * C + c], stl[3 * C + c]) > 0.f ? d0 : 0.f;
-      const float xh = (ym - stl[c]) * stl[C + c];
-      ys[(i / C) * (C + 1) + c] = stl[2 * C + c] * (gg - c12[c] - xh * c12[C + c]);
+  const int nfr = (int)(p.G - g0 < GDF_FPB ? p.G - g0 : GDF_FPB);
+  // frame loads: z [V][KC] in 16-byte pieces (<= 4 per thread), ym / dy0 [V][C] (<= 2 per thread each)
+  const int zc4 = KC / 4, yc4 = C / 4, nz4 = V * zc4, ny4 = V * yc4;
+  f32x4 zv[4], yv[2], dv[2];
+#define GDF_ISSUE(g_)                                                                                     \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                       \
+      const int i = tid + 256 * u < nz4 ? tid + 256 * u : nz4 - 1;                                        \
+      zv[u] = *reinterpret_cast<const f32x4*>(p.Z + ((g_) * V + i / zc4) * p.ldz + 4 * (i % zc4));        \
+    }                                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                       \
+      const int i = tid + 256 * u < ny4 ? tid + 256 * u : ny4 - 1;                                        \
+      yv[u] = *reinterpret_cast<const f32x4*>(p.Ym + (g_) * V * C + 4 * i);                               \
+      dv[u] = *reinterpret_cast<const f32x4*>(p.dY0 + (g_) * V * C + 4 * i);                              \
+    }                                                                                                     \
+  } while (0)
+  GDF_ISSUE(g0);
+  bwd_gather<256>(p.rec, p.nrec, C, red);
+  asm volatile("" : "+v"(sv[0]), "+v"(sv[1]));
+  if (tid < 4 * C) stl[tid] = sv[0];
+  if (tid + 256 < 4 * C) stl[tid + 256] = sv[1];
+  for (int i = tid; i < ZS; i += 256) zs[15 * ZS + i] = 0.f;
+  for (int i = tid; i < YS; i += 256) ys[15 * YS + i] = 0.f;
+  __syncthreads();
+  const float2 tot = bwd_finish<256>(C, p.G * V, red, c12);
+  __syncthreads();
+  f32x4 accA[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // this wave's dA_k tiles (k = wave, wave + 4, ...)
+  for (int fi = 0; fi < nfr; ++fi) {
+    const long g = g0 + fi;
+    // stage: z as it is, dy = a (g - c1 - xhat c2) with g = dY0 . [bn(ym) > 0]
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      asm volatile("" : "+v"(zv[u].x), "+v"(zv[u].y), "+v"(zv[u].z), "+v"(zv[u].w));
+      const int i = tid + 256 * u;
+      if (i < nz4) *reinterpret_cast<f32x4*>(zs + (i / zc4) * ZS + 4 * (i % zc4)) = zv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      asm volatile("" : "+v"(yv[u].x), "+v"(yv[u].y), "+v"(yv[u].z), "+v"(yv[u].w), "+v"(dv[u].x), "+v"(dv[u].y), "+v"(dv[u].z), "+v"(dv[u].w));
+      const int i = tid + 256 * u;
+      if (i < ny4) {
+        const int c = 4 * (i % yc4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ym = yv[u][e];
+          const float gg = __builtin_fmaf(ym - stl[c + e], stl[2 * C + c + e], stl[3 * C + c + e]) > 0.f ? dv[u][e] : 0.f;
+          const float xh = (ym - stl[c + e]) * stl[C + c + e];
+          o[e] = stl[2 * C + c + e] * (gg - c12[c + e] - xh * c12[C + c + e]);
+        }
+        *reinterpret_cast<f32x4*>(ys + (i / yc4) * YS + c) = o;
+      }
     }
     __syncthreads();
-    if (e < nout) {
-      const float* zr = zs + v * (KC + 1) + k * C;
-      const float* yr = ys + w * (C + 1);
-      float a = 0.f;
-      for (int c = 0; c < C; ++c) a += zr[c] * yr[c];
-      acc += a;
+    if (fi + 1 < nfr) GDF_ISSUE(g + 1);                  // the next frame's rows fly under this frame's products
+    // dA_k += z_k . dy^T over the channels (this wave's partitions), then dz_k = (A.imp)_k . dy
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      const int k = wave + 4 * kk;
+      if (k < Kk) {                                       // (uniform per wave)
+        for (int c0 = 0; c0 < C; c0 += 16) {
+          f32x4 a4 = *reinterpret_cast<const f32x4*>(zs + lo * ZS + k * C + c0 + 4 * hi);
+          f32x4 b4 = *reinterpret_cast<const f32x4*>(ys + lo * YS + c0 + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accA[kk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b4[e], accA[kk], 0, 0, 0);
+        }
+      }
     }
-    float* zf = p.dZ + g * V * p.lddz;
-    for (int i = tid; i < V * KC; i += 512) {
-      const int row = i / KC, col = i - row * KC;
-      const int kk = col / C, c = col - kk * C;
-      float a = 0.f;
-      for (int w2 = 0; w2 < V; ++w2) a += As[(kk * V + row) * V + w2] * ys[w2 * (C + 1) + c];
-      zf[(long)row * p.lddz + col] = a;
+    __syncthreads();                                      // (every wave has read z: the tile is overwritten with dz)
+    for (int pi = wave; pi < Kk * (C / 16); pi += 4) {
+      const int k = pi / (C / 16), n0 = (pi - k * (C / 16)) * 16;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float b = ys[(4 * s + hi) * YS + n0 + lo];
+        const float a = k == 0 ? ae[0][s] : (k == 1 ? ae[1][s] : ae[2][s]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) zs[(4 * hi + reg) * ZS + k * C + n0 + lo] = acc[reg];
+    }
+    __syncthreads();
+    {                                                     // dz rows out: 16-byte pieces, reads ahead of the stores
+      f32x4 o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = tid + 256 * u < nz4 ? tid + 256 * u : nz4 - 1;
+        o[u] = *reinterpret_cast<const f32x4*>(zs + (i / zc4) * ZS + 4 * (i % zc4));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = tid + 256 * u < nz4 ? tid + 256 * u : nz4 - 1;
+        *reinterpret_cast<f32x4*>(p.dZ + (g * V + i / zc4) * p.lddz + 4 * (i % zc4)) = o[u];
+      }
+    }
+    __syncthreads();                                      // (zs row 15 was overwritten with dz's dummy row: zero it again below)
+    for (int i = tid; i < ZS; i += 256) zs[15 * ZS + i] = 0.f;
+  }
+#undef GDF_ISSUE
+  // partial dA of this workgroup: D[i = v][j = w], lane (lo = w, hi): rows v = 4 hi + reg
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    const int k = wave + 4 * kk;
+    if (k < Kk) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int v = 4 * hi + reg, w = lo;
+        if (v < V && w < V) p.partial[(long)blockIdx.x * Kk * V * V + (k * V + v) * V + w] = accA[kk][reg];
+      }
     }
   }
-  if (e < nout) p.partial[(long)blockIdx.x * nout + e] = acc;
+  if (blockIdx.x == 0 && tid < C) { p.db0[tid] = tot.x; p.dg0[tid] = tot.y; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -607,6 +765,7 @@ extern "C" int mmego_gcn_front(void* stream, const void* desc) {
   p.mix = h->mix; p.Kk = h->K; p.cout = h->cout; p.A = h->A; p.imp = h->importance;
   p.Z = h->Z; p.ldz = h->ldz; p.Y = h->Y; p.recY = reinterpret_cast<float2*>(h->recY); p.recR = reinterpret_cast<float2*>(h->recR);
   p.outT = h->outT; p.T = h->T; p.F = h->F; p.V = h->V;
+  { const char* e = getenv("MMEGO_GCN_DBG"); p.dbg = e ? atoi(e) : 0; }
   if (p.in_mode == 0) {
     MMEGO_REQUIRE(p.V * p.cin <= 64 && p.F <= 1024 && p.bn1.gamma && p.bn1.beta);
   } else {
@@ -625,7 +784,7 @@ extern "C" int mmego_gcn_front(void* stream, const void* desc) {
   MMEGO_REQUIRE(scalar == (p.in_mode == 0) || !scalar);
   const int NCT = p.nout / 32, nctw = (NCT + 3) / 4, nk = scalar ? 0 : p.cin / 32;
   const int XS = (nk ? p.cin : 4) + 4, ZS = p.nout + 16, YS = p.cout + 4;
-  const int tail = 64 * XS > 60 * YS ? 64 * XS : 60 * YS;
+  const int tail = 64 * XS > 64 * YS ? 64 * XS : 64 * YS;
   const size_t lds = (size_t)(GF_ST + 64 * ZS + (tail > 8192 ? tail : 8192)) * sizeof(float);      // (>= 32 KB of prologue scratch)
   MMEGO_REQUIRE(lds <= 160 * 1024 && 8 * p.cin <= GF_ST);
   hipStream_t st = (hipStream_t)stream;
@@ -697,14 +856,16 @@ extern "C" int mmego_graph_dA_fused(void* stream, const float* Z, long ldz, cons
                                     const float* rec, int nrec, float* dgamma0, float* dbeta0, long G, int V, int K, int C,
                                     float* partial_ws, const float* A, const float* imp, float* dZ, long lddz) {
   MMEGO_REQUIRE(Z && dY0 && Ymix && st0 && rec && nrec >= 1 && nrec <= 1024 && dgamma0 && dbeta0 && partial_ws && A && imp && dZ);
-  MMEGO_REQUIRE(G > 0 && V > 0 && K > 0 && C > 0 && C <= 256 && K * V * V <= 512 && ldz >= (long)K * C && lddz >= (long)K * C);
+  MMEGO_REQUIRE(G > 0 && V > 0 && K > 0 && C > 0 && C <= 128 && K * V * V <= 512 && ldz >= (long)K * C && lddz >= (long)K * C);
   GraphDAFusedD p = {Z, ldz, dY0, Ymix, st0, reinterpret_cast<const float2*>(rec), nrec, dgamma0, dbeta0, G, V, K, C, partial_ws, A, imp, dZ, lddz};
+  MMEGO_REQUIRE(V <= 15 && K <= 3 && (C % 16) == 0 && V * K * C / 4 <= 1024 && V * C / 4 <= 512 && (ldz % 4) == 0 && (lddz % 4) == 0);
+  MMEGO_REQUIRE((((uintptr_t)Z | (uintptr_t)dY0 | (uintptr_t)Ymix | (uintptr_t)dZ) & 15) == 0);
   int CP = 32;
   while (CP < C) CP <<= 1;
-  const size_t fl = (size_t)V * (K * C + 1) + (size_t)V * (C + 1) + (size_t)K * V * V + 8 * (size_t)C + 2;
-  const size_t lds = fl * sizeof(float) + (size_t)(512 / CP) * 2 * CP * sizeof(double);
+  const size_t fl = (size_t)16 * (K * C + 4) + (size_t)16 * (C + 4) + 6 * (size_t)C + 1024;
+  const size_t lds = fl * sizeof(float) + (size_t)(256 / CP) * 2 * CP * sizeof(double);
   MMEGO_REQUIRE(lds <= 64 * 1024);
-  hipLaunchKernelGGL(graph_dA_fused_kernel, dim3((unsigned)cdiv(G, GDF_FPB)), dim3(512), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(graph_dA_fused_kernel, dim3((unsigned)cdiv(G, GDF_FPB)), dim3(256), lds, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

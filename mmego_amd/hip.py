@@ -108,6 +108,12 @@ class GcnFront(ctypes.Structure):
                 ("outT", ctypes.c_void_p), ("T", ctypes.c_int), ("F", ctypes.c_long), ("V", ctypes.c_int)]
 
 
+class Pack(ctypes.Structure):
+    """MmegoPack of include/mmego_hip.h: one weight re-layout of mmego_pack_multi."""
+    _fields_ = [("W", ctypes.c_void_p), ("Wp", ctypes.c_void_p), ("Co", ctypes.c_int), ("Ci", ctypes.c_int), ("taps", ctypes.c_int),
+                ("kind", ctypes.c_int)]
+
+
 class Slab(ctypes.Structure):
     """MmegoSlab of include/mmego_hip.h: one deferred partial-product sum."""
     _fields_ = [("ws", ctypes.c_void_p), ("out", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("asum", ctypes.c_void_p),

@@ -514,7 +514,18 @@ class LowerNet(_NetBase):
         nrf, nrt = hip.lib().mmego_gcn_front_nrec(F), (rows + 63) // 64
         blks = gcn.gcn_networks
         wps = [ar.get("gcn.b%d.wp" % i, (2, blk.tcn["2"].weight.numel())) for i, blk in enumerate(blks)]
-        hip.call("tconv_pack_multi", 3, *[v for blk, wp in zip(blks, wps) for v in (blk.tcn["2"].weight, wp, blk.cout, blk.cout)], blks[0].taps)
+        # every weight re-layout of the step in one launch: the temporal convs' tap-major packs (forward + gradient) and the
+        # fragment-major copies of the stacked 1x1 weights gcn_front multiplies with (blocks with cin >= 32, and fcn)
+        packs = [hip.Pack(hip.ptr(blk.tcn["2"].weight), hip.ptr(wp), blk.cout, blk.cout, blk.taps, 0) for blk, wp in zip(blks, wps)]
+        wfr = {}
+        for i, blk in enumerate(blks):
+            if blk.cin >= 32:
+                Wc = ops.stacked(blk.gcn.conv.weight.view(blk.K * blk.cout, blk.cin), blk.residual["0"].weight.view(blk.cout, blk.cin))
+                wfr[i] = ar.get("gcn.b%d.wfrag" % i, (Wc.numel(),))
+                packs.append(hip.Pack(hip.ptr(Wc), hip.ptr(wfr[i]), Wc.shape[0], blk.cin, 1, 1))
+        wfr["fcn"] = ar.get("gcn.fcn.wfrag", (gcn.fcn.weight.numel(),))
+        packs.append(hip.Pack(hip.ptr(gcn.fcn.weight), hip.ptr(wfr["fcn"]), 64, gcn.fcn.weight.shape[1], 1, 1))
+        hip.call("pack_multi", len(packs), (hip.Pack * len(packs))(*packs))
         prev = None
         for i, blk in enumerate(blks):
             cin, cout, K = blk.cin, blk.cout, blk.K
@@ -536,7 +547,7 @@ class LowerNet(_NetBase):
                 d.xact = hip.ptr(ar.get(pkey + ".out", (rows, pc)))
             Wc = ops.stacked(blk.gcn.conv.weight.view(K * cout, cin), blk.residual["0"].weight.view(cout, cin))
             bc = ops.stacked(blk.gcn.conv.bias, blk.residual["0"].bias)
-            d.W, d.bias, d.cin, d.nout = hip.ptr(Wc), hip.ptr(bc), cin, (K + 1) * cout
+            d.W, d.bias, d.cin, d.nout = hip.ptr(wfr.get(i, Wc)), hip.ptr(bc), cin, (K + 1) * cout
             d.mix, d.K, d.cout, d.A, d.importance = 1, K, cout, hip.ptr(gcn.A), hip.ptr(gcn.edge_importance[i])
             d.Z, d.ldz, d.Y, d.recY, d.recR = hip.ptr(zr), zr.stride(0), hip.ptr(ymix), hip.ptr(recY), hip.ptr(recR)
             d.F, d.V = F, V
@@ -552,7 +563,7 @@ class LowerNet(_NetBase):
         d.bn1 = hip.BnRef.of(pblk.tcn["3"], ops.BnState(ar, pkey + ".bn3", pc).all, prec3, nrt, 64)
         d.bn2 = hip.BnRef.of(pblk.residual["1"], ops.BnState(ar, pkey + ".bnr", pc).all, precR, nrf, 4 * V)
         d.xact = hip.ptr(ar.get(pkey + ".out", (rows, pc)))
-        d.W, d.bias, d.cin, d.nout = hip.ptr(gcn.fcn.weight), hip.ptr(gcn.fcn.bias), pc, 64
+        d.W, d.bias, d.cin, d.nout = hip.ptr(wfr["fcn"]), hip.ptr(gcn.fcn.bias), pc, 64
         d.mix, d.outT, d.T, d.F, d.V = 0, hip.ptr(kv), T, F, V
         hip.call("gcn_front", d)
         return kv.view(F * V, 64)
