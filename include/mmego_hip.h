@@ -311,6 +311,29 @@ int mmego_anchor_group(void* stream, const float* xf, long ldx, long F, int N, i
 int mmego_anchor_group_backward(void* stream, const float* dgrouped, const long long* idx, long F, int N, int D,
                                 float* dxf, long lddx);
 
+/* ---- the anchor ("voxel") branch of UpperNetwlocal, fused (local.hip): Net/Upper_Net.py:10-119,147-177,219-239 ---------------------
+ * mmego_local_group_l1: per frame the 27 x N squared distances (reference rounding, Q5), the 8 nearest points of every anchor (int64
+ * idx [F][27][8], stable ties) by wave-wide minimum rounds, the gathered rows cat(anchor, xyz - anchor, features) built in LDS and
+ * multiplied there with LocalPointNet's first k=1 conv: Z1 [F*216][C1] = gathered W1^T + b1, part1[min(nwg, F)][2][64] = per-workgroup
+ * (sum z, sum z^2) in fp64 (mmego_mlp_fwd_layer_n's in_part).  grouped (may be NULL) receives the gathered rows [F*216][6+D] (training:
+ * the layer's weight gradient reads them); W1 NULL: grouping only.  N in {64, 128, 256}; 6 + D <= 32; C1 <= 32, C1 % 4 == 0.
+ * mmego_pool8_bn_act: y = relu(BN(Z)) with the statistics finalized from mmego_mlp_fwd_layer's partials, attention score y.w + b,
+ * softmax over each group's 8 rows -> attn [rows], pooled vectors -> voxT [F][64][27] (Conv3d input order); rows = F*27*8, C = 64.
+ * mmego_pool8_backward: gradient of Z's activated rows dY from dvoxT [F][64][27] (y recomputed from Z and state [4][64]), gpart
+ * [mmego_pool8_nblk(rows)][2][64] = (sum g, sum g xhat) with g = dY.[y > 0] (mmego_mlp_bwd_layer's g_part), awpart [nblk][128] =
+ * per-workgroup partials of d(attention weight) [0:64] and d(bias) [64].
+ * mmego_anchor_scatter: dxf[f][p][0:3+D] += sum over slots with idx == p of dgrouped[slot][3:6+D], slot order (deterministic). */
+int mmego_local_group_l1(void* stream, const float* feats, long ldf, long F, int N, int D, const float* anchors, long long* idx,
+                         float* grouped, const float* W1, const float* b1, int C1, float* Z1, long ldz1, double* part1, int nwg,
+                         float* dist_out);
+int mmego_pool8_nblk(long rows);
+int mmego_pool8_bn_act(void* stream, const float* Z, long ldz, long rows, const double* part, const float* gamma, const float* beta,
+                       double eps, float* rmean, float* rvar, double momentum, float* state, const float* aw_w, const float* aw_b,
+                       float* voxT, float* attn);
+int mmego_pool8_backward(void* stream, const float* Z, long ldz, long rows, const float* state, const float* attn, const float* dvoxT,
+                         const float* aw_w, float* dY, long lddy, double* gpart, float* awpart);
+int mmego_anchor_scatter(void* stream, const float* dgrouped, const long long* idx, long F, int N, int D, float* dxf, long lddx);
+
 /* ---- pooling / attention / graph (pool.hip) -------------------------------------------------------
  * Softmax-attention pooling over the P points of each of G groups (Upper_Net.py:285-301,163-177,
  * IMU_Net.py:79-80). */
@@ -382,6 +405,10 @@ int mmego_mlp_train_nblk(long rows);
 int mmego_mlp_fwd_layer(void* stream, const float* X, long ldx, long rows, int Cin, const double* in_part, const float* in_gamma,
                         const float* in_beta, double in_eps, float* in_rmean, float* in_rvar, double in_momentum,
                         float* in_state, const float* W, const float* bias, int Cout, float* Z, long ldz, double* out_part);
+int mmego_mlp_fwd_layer_n(void* stream, const float* X, long ldx, long rows, int Cin, const double* in_part, int in_nblk,
+                          const float* in_gamma, const float* in_beta, double in_eps, float* in_rmean, float* in_rvar,
+                          double in_momentum, float* in_state, const float* W, const float* bias, int Cout, float* Z, long ldz,
+                          double* out_part);
 int mmego_mlp_bn_act(void* stream, const float* Z, long ldz, long rows, int C, const double* part, const float* gamma,
                      const float* beta, double eps, float* rmean, float* rvar, double momentum, float* state, float* Y,
                      long ldy);

@@ -81,9 +81,10 @@ def _mlp3_forward_fused(ar, key, mod, x, out_last):
     return out_last
 
 
-def _mlp3_backward_fused(ar, key, mod, x, dy3, G, need_dx):
+def _mlp3_backward_fused(ar, key, mod, x, dy3, G, need_dx, have_sums=False):
     """Backward of the three stages as 1 + 3 + 1 launches: per stage ONE pass computes dz, dX (the next stage's dy), the
-    per-workgroup dW partial and the BatchNorm sums of the stage below; a last launch sums the dW partials of all three."""
+    per-workgroup dW partial and the BatchNorm sums of the stage below; a last launch sums the dW partials of all three.
+    have_sums: the producer of dy3 has left the last stage's (sum g, sum g xhat) partials in "<key>.gp3" already (mmego_pool8_backward)."""
     rows = x.shape[0]
     nblk = hip.lib().mmego_mlp_train_nblk(rows)
     layers = _mlp3_layers(mod)
@@ -92,7 +93,8 @@ def _mlp3_backward_fused(ar, key, mod, x, dy3, G, need_dx):
     sts = [None] + [ops.BnState(ar, "%s.bn%d" % (key, i), dims[i]) for i in (1, 2, 3)]
     gp = [None] + [ar.get("%s.gp%d" % (key, i), (nblk * 2 * 64,), dtype=torch.float64) for i in (1, 2, 3)]
     dwp = [None] + [ar.get("%s.dwp%d" % (key, i), (nblk * 4096,)) for i in (1, 2, 3)]
-    hip.call("mlp_bn_bwd_reduce", dy3, dy3.stride(0), zs[3], zs[3].stride(0), rows, dims[3], sts[3].all, gp[3])
+    if not have_sums:
+        hip.call("mlp_bn_bwd_reduce", dy3, dy3.stride(0), zs[3], zs[3].stride(0), rows, dims[3], sts[3].all, gp[3])
     dy = dy3
     for i in (3, 2, 1):
         conv, bn = layers[i - 1]

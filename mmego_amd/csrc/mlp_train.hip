@@ -517,6 +517,26 @@ extern "C" int mmego_mlp_fwd_layer(void* stream, const float* X, long ldx, long 
   return MMEGO_OK;
 }
 
+// The same with the number of input partial records given (a producer other than mlp_fwd_layer -- mmego_local_group_l1 -- chooses
+// its own workgroup count).
+extern "C" int mmego_mlp_fwd_layer_n(void* stream, const float* X, long ldx, long rows, int Cin, const double* in_part, int in_nblk,
+                                     const float* in_gamma, const float* in_beta, double in_eps, float* in_rmean, float* in_rvar,
+                                     double in_momentum, float* in_state, const float* W, const float* bias, int Cout, float* Z,
+                                     long ldz, double* out_part) {
+  MMEGO_REQUIRE(X && W && Z && out_part && rows > 0 && Cin >= 1 && Cin <= 64 && Cout >= 1 && Cout <= 64 && ldx >= Cin && ldz >= Cout);
+  MMEGO_REQUIRE(in_part && in_gamma && in_beta && in_nblk >= 1 && in_nblk <= 1024);
+  MlpFwdP p;
+  int nblk;
+  mt_grid(rows, &nblk, &p.rows_per_wg);
+  p.X = X; p.ldx = ldx; p.rows = rows; p.Cin = Cin;
+  p.in_part = in_part; p.in_nblk = in_nblk; p.in_gamma = in_gamma; p.in_beta = in_beta; p.in_eps = (float)in_eps;
+  p.in_rmean = in_rmean; p.in_rvar = in_rvar; p.in_momentum = (float)in_momentum; p.in_state = in_state;
+  p.W = W; p.bias = bias; p.Cout = Cout; p.Z = Z; p.ldz = ldz; p.out_part = out_part;
+  hipLaunchKernelGGL(mlp_fwd_layer_kernel, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
 extern "C" int mmego_mlp_bn_act(void* stream, const float* Z, long ldz, long rows, int C, const double* part, const float* gamma,
                                 const float* beta, double eps, float* rmean, float* rvar, double momentum, float* state,
                                 float* Y, long ldy) {

@@ -4,6 +4,8 @@ Reference Net/Upper_Net.py:406-432 (defined there but constructed by no trainer;
 PointNet -> {GlobalModule, LocalModule (anchor grouping -> LocalPointNet -> LocalVoxelNet -> BiLSTM)} ->
 CombineModule -> FK -> Transform2R.  forward returns the reference's 8-tuple.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -12,6 +14,8 @@ from .blocks import LstmParams
 from .nets import GlobalModule, PointNet, _Bridge, _Mlp3, _NetBase, _f32c, _require_gpu
 
 N_ANCHOR, N_GROUP = 27, 8
+_LOCAL_FUSED = os.environ.get("MMEGO_LOCAL_FUSED", "1") != "0"      # the anchor branch on the fused kernels of local.hip
+_LOCAL_NWG = 256                                                     # workgroups of mmego_local_group_l1 (= BatchNorm partial records)
 
 
 def anchor_grid():
@@ -78,6 +82,25 @@ class UpperNetwlocal(_NetBase):
             self._anchors = self.module2.template_point.reshape(N_ANCHOR, 3).to(dev).contiguous()
         return self._anchors
 
+    def _local_fusable(self, N):
+        lp = self.module2.apointnet
+        dims = [tuple(c.weight.shape[:2]) for c in (lp.conv1, lp.conv2, lp.conv3)]
+        return bool(_LOCAL_FUSED and N in (64, 128, 256) and dims == [(32, 31), (48, 32), (64, 48)] and lp.attn.weight.shape == (1, 64))
+
+    def local_branch_bytes(self, F, N):
+        """HBM bytes per frame the anchor branch's activations move between launches in one training step (written once + read
+        once per consumer; parameters and the shared per-point features excluded): the fused path against the launch chain."""
+        g = N_ANCHOR * N_GROUP
+        fused = 4 * (g * 31 * 2                     # gathered rows: written by the grouping kernel, read by layer 1's weight gradient
+                     + g * (32 + 48 + 64) * 3       # z1..z3: written, read by the next stage, read by backward
+                     + g * (64 + 48 + 32 + 31) * 2  # dl3, dy2, dy1, dgrouped
+                     + N_ANCHOR * 64 * 4 + g * 2) + 8 * g
+        chain = fused + 4 * (g * 31 * 1             # gathered rows read by the separate first layer
+                             + g * 64 * 4           # l3 written, read by pooling, by its backward, by the BatchNorm backward
+                             + g * 64 * 2           # dl3 read by the separate BatchNorm reduce
+                             + N_ANCHOR * 64 * 4)   # vox / dvox through the transposes
+        return {"fused": fused, "launch_chain": chain, "gathered_rows": 4 * g * 31, "what": self.local_branch_bytes.__doc__.split(":")[0]}
+
     def forward(self, x, h0_g, c0_g, h0_a, c0_a, initial_body, R, t):
         _require_gpu(x, "UpperNetwlocal")
         args = (x, h0_g, c0_g, h0_a, c0_a, initial_body, R, t)
@@ -118,17 +141,44 @@ class UpperNetwlocal(_NetBase):
         ops.copy2d(seq_g, cat[:, :128])
         # local branch: grouping -> LocalPointNet (+attention pool over the 8 members) -> voxel net -> BiLSTM
         grows = F * N_ANCHOR * N_GROUP
-        grouped = ar.get("grouped", (grows, 31))
         gidx = ar.get("gidx", (F, N_ANCHOR, N_GROUP), dtype=torch.int64)
-        hip.call("anchor_group", feats, 28, F, N, 25, self.anchors(dev), gidx, grouped, None)
         self.last_group_idx = gidx
-        l3 = ar.get("l3", (grows, 64))
-        blocks.mlp3_forward(ar, "lp", self.module2.apointnet, grouped, l3, training)
-        vox = ar.get("vox", (F * N_ANCHOR, 64))
-        aw = torch.empty((F * N_ANCHOR, N_GROUP, 1), dtype=torch.float32, device=dev)
-        blocks.attn_pool_forward(l3, self.module2.apointnet.attn, F * N_ANCHOR, N_GROUP, 64, vox, aw)
+        lp = self.module2.apointnet
         voxT = ar.get("voxT", (F, 64 * N_ANCHOR))
-        hip.call("transpose_batched", vox, voxT, F, N_ANCHOR, 64)         # (F,27,64) -> (F,64,27): conv input order (cin,z,y,x)
+        aw = torch.empty((F * N_ANCHOR, N_GROUP, 1), dtype=torch.float32, device=dev)
+        fused = self._local_fusable(N)
+        self._local_was_fused = fused and training
+        if fused and training:
+            # grouping with LocalPointNet's first conv behind it in the same kernel (the gathered rows go from LDS into the product;
+            # they are also kept for the layer's weight gradient), two fused layer launches, then BatchNorm + ReLU + the 8-way
+            # softmax pooling in one kernel that writes the pooled vectors in the Conv3d input order: the activated 64-channel
+            # tensor, the pooling pass over it and the transpose launch do not exist (local.hip)
+            nblk = hip.lib().mmego_mlp_train_nblk(grows)
+            nwg = min(_LOCAL_NWG, F)
+            grouped = ar.get("grouped", (grows, 31))
+            z1, z2, z3 = ar.get("lp.z1", (grows, 32)), ar.get("lp.z2", (grows, 48)), ar.get("lp.z3", (grows, 64))
+            part1 = ar.get("lp.sp1g", (nwg * 2 * 64,), dtype=torch.float64)
+            part2, part3 = (ar.get("lp.sp%d" % i, (nblk * 2 * 64,), dtype=torch.float64) for i in (2, 3))
+            st1, st2, st3 = (ops.BnState(ar, "lp.bn%d" % i, c) for i, c in ((1, 32), (2, 48), (3, 64)))
+            hip.call("local_group_l1", feats, 28, F, N, 25, self.anchors(dev), gidx, grouped, lp.conv1.weight, lp.conv1.bias, 32, z1, 32,
+                     part1, nwg, None)
+            hip.call("mlp_fwd_layer_n", z1, 32, grows, 32, part1, nwg, lp.cb1.weight, lp.cb1.bias, float(lp.cb1.eps), lp.cb1.running_mean,
+                     lp.cb1.running_var, float(lp.cb1.momentum), st1.all, lp.conv2.weight, lp.conv2.bias, 48, z2, 48, part2)
+            hip.call("mlp_fwd_layer", z2, 48, grows, 48, part2, lp.cb2.weight, lp.cb2.bias, float(lp.cb2.eps), lp.cb2.running_mean,
+                     lp.cb2.running_var, float(lp.cb2.momentum), st2.all, lp.conv3.weight, lp.conv3.bias, 64, z3, 64, part3)
+            hip.call("pool8_bn_act", z3, 64, grows, part3, lp.cb3.weight, lp.cb3.bias, float(lp.cb3.eps), lp.cb3.running_mean,
+                     lp.cb3.running_var, float(lp.cb3.momentum), st3.all, lp.attn.weight, lp.attn.bias, voxT, aw)
+        else:
+            grouped = ar.get("grouped", (grows, 31))
+            if fused:           # (eval: the wave-parallel grouping alone, then the eval-mode PointNet kernel)
+                hip.call("local_group_l1", feats, 28, F, N, 25, self.anchors(dev), gidx, grouped, None, None, 0, None, 0, None, _LOCAL_NWG, None)
+            else:
+                hip.call("anchor_group", feats, 28, F, N, 25, self.anchors(dev), gidx, grouped, None)
+            l3 = ar.get("l3", (grows, 64))
+            blocks.mlp3_forward(ar, "lp", lp, grouped, l3, training)
+            vox = ar.get("vox", (F * N_ANCHOR, 64))
+            blocks.attn_pool_forward(l3, lp.attn, F * N_ANCHOR, N_GROUP, 64, vox, aw)
+            hip.call("transpose_batched", vox, voxT, F, N_ANCHOR, 64)     # (F,27,64) -> (F,64,27): conv input order (cin,z,y,x)
         vvec = ar.get("vvec", (F, 64))
         blocks.mlp3_forward(ar, "vx", self.module2.avoxel, voxT, vvec, training)
         p_a = self._drop_p(self.module2.arnn.rnn) if stash else 0.0
@@ -175,13 +225,31 @@ class UpperNetwlocal(_NetBase):
                                        self._drop_p(self.module2.arnn.rnn), True)
         voxT = ar.get("voxT", (F, 64 * N_ANCHOR))
         dvoxT = blocks.mlp3_backward(ar, "vx", self.module2.avoxel, voxT, vvec, dvvec, G, True)
-        dvox = ar.get("dvox", (F * N_ANCHOR, 64))
-        hip.call("transpose_batched", dvoxT, dvox, F, 64, N_ANCHOR)       # (F,64,27) -> (F,27,64)
-        l3, dl3 = ar.get("l3", (grows, 64)), ar.get("dl3", (grows, 64))
-        blocks.attn_pool_backward(ar, "lpool", l3, self.module2.apointnet.attn, aw, dvox, F * N_ANCHOR, N_GROUP, 64, dl3, G)
-        grouped = ar.get("grouped", (grows, 31))
-        dgrouped = blocks.mlp3_backward(ar, "lp", self.module2.apointnet, grouped, l3, dl3, G, True)
         gidx = ar.get("gidx", (F, N_ANCHOR, N_GROUP), dtype=torch.int64)
-        hip.call("anchor_group_backward", dgrouped, gidx, F, N, 25, dfeats, 28)
+        grouped = ar.get("grouped", (grows, 31))
+        lp = self.module2.apointnet
+        if getattr(self, "_local_was_fused", False):
+            # pooling backward with the activated rows recomputed, the last stage's BatchNorm sums and the attention parameter
+            # partials from the same kernel; the pooled gradient is read in the Conv3d order (no transpose launch)
+            nblk = hip.lib().mmego_pool8_nblk(grows)
+            z3, dl3 = ar.get("lp.z3", (grows, 64)), ar.get("dl3", (grows, 64))
+            gp3 = ar.get("lp.gp3", (nblk * 2 * 64,), dtype=torch.float64)
+            awp = ar.get("lpool.awp", (nblk, 128))
+            hip.call("pool8_backward", z3, 64, grows, ops.BnState(ar, "lp.bn3", 64).all, aw, dvoxT, lp.attn.weight, dl3, 64, gp3, awp)
+            gw, gb = G(lp.attn.weight).view(-1), G(lp.attn.bias)
+            if gb.data_ptr() == gw.data_ptr() + 4 * gw.numel():       # weight and bias gradient slots back to back: one column sum
+                ops.colsum(awp[:, :65], torch.as_strided(gw, (65,), (1,)))
+            else:
+                ops.colsum(awp[:, :64], gw)
+                ops.colsum(awp[:, 64:65], gb)
+            dgrouped = blocks._mlp3_backward_fused(ar, "lp", lp, grouped, dl3, G, True, have_sums=True)
+            hip.call("anchor_scatter", dgrouped, gidx, F, N, 25, dfeats, 28)
+        else:
+            dvox = ar.get("dvox", (F * N_ANCHOR, 64))
+            hip.call("transpose_batched", dvoxT, dvox, F, 64, N_ANCHOR)       # (F,64,27) -> (F,27,64)
+            l3, dl3 = ar.get("l3", (grows, 64)), ar.get("dl3", (grows, 64))
+            blocks.attn_pool_backward(ar, "lpool", l3, lp.attn, aw, dvox, F * N_ANCHOR, N_GROUP, 64, dl3, G)
+            dgrouped = blocks.mlp3_backward(ar, "lp", lp, grouped, l3, dl3, G, True)
+            hip.call("anchor_group_backward", dgrouped, gidx, F, N, 25, dfeats, 28)
         pts = ar.get("pts", (rows, 6))
         blocks.mlp3_backward(ar, "m0", self.module0, pts, feats[:, 4:28], dfeats[:, 4:28], G, False)

@@ -56,6 +56,110 @@ def test_anchor_grouping_bit_exact(dev):
     assert torch.allclose(dxf.cpu().view(Fn, N, 3 + D), xf_req.grad, atol=1e-5)
 
 
+def test_local_group_l1_bit_exact_and_against_the_launch_chain(dev):
+    """local.hip: the wave-parallel grouping kernel (mmego_local_group_l1) -- distances bit-identical to the reference's, int64 group
+    indices and gathered rows bit-identical to the oracle / to mmego_anchor_group (golden G2, incl. a frame with < 8 valid points and
+    exact-zero rows; a seeded N = 64 / 128 / 256 sweep with duplicated points = ties); its fused first layer + BatchNorm partial sums
+    against torch; mmego_anchor_scatter bit-identical to mmego_anchor_group_backward."""
+    from mmego_amd import hip
+    from mmego_amd.nets_local import anchor_grid
+    g = golden("g2_grouping.npz")
+    xyz, feats = T(g["xyz"]), T(g["feats"])
+    anchors = anchor_grid().to(dev)
+    cases = [(xyz, feats)]
+    gen = torch.Generator().manual_seed(5)
+    for N in (64, 128, 256):
+        x = torch.randn(5, N, 3, generator=gen) * 0.4 + torch.tensor([0.3, 0.0, 0.0])
+        x[:, N // 2:N // 2 + 9] = x[:, 0:9]                  # exact duplicates: ties
+        x[1, 5:] = 0.0                                        # a frame with 5 valid points (the rest at distance +inf)
+        x[2, ::3] = 0.0
+        cases.append((x, torch.randn(5, N, 25, generator=gen)))
+    for xyz_, feats_ in cases:
+        Fn, N, D = xyz_.shape[0], xyz_.shape[1], feats_.shape[2]
+        if N not in (64, 128, 256):
+            continue
+        xf = torch.cat((xyz_, feats_), dim=-1).contiguous().to(dev)
+        idx0, idx1 = (torch.empty((Fn, 27, 8), dtype=torch.int64, device=dev) for _ in range(2))
+        gr0, gr1 = (torch.empty((Fn * 216, 6 + D), device=dev) for _ in range(2))
+        d0, d1 = (torch.empty((Fn, 27, N), device=dev) for _ in range(2))
+        hip.call("anchor_group", xf, 3 + D, Fn, N, D, anchors, idx0, gr0, d0)
+        W1, b1 = torch.randn(32, 6 + D, generator=gen).to(dev) * 0.2, torch.randn(32, generator=gen).to(dev)
+        for nwg in (256, 3):                                 # one frame per workgroup / several frames per workgroup
+            z1 = torch.full((Fn * 216, 32), float("nan"), device=dev)
+            nw = min(nwg, Fn)
+            part = torch.empty(nw * 2 * 64, dtype=torch.float64, device=dev)
+            hip.call("local_group_l1", xf, 3 + D, Fn, N, D, anchors, idx1, gr1, W1, b1, 32, z1, 32, part, nwg, d1)
+            assert torch.equal(d0, d1) and torch.equal(idx0, idx1) and torch.equal(gr0, gr1), (N, nwg)
+            want = gr0.double() @ W1.double().t() + b1.double()
+            assert (z1.double() - want).abs().max().item() < 1e-4
+            ps = part.view(nw, 2, 64).sum(0)
+            assert (ps[0, :32] - want.sum(0)).abs().max().item() < 1e-3 and (ps[1, :32] - (want ** 2).sum(0)).abs().max().item() < 1e-2
+            assert float(ps[:, 32:].abs().max()) == 0.0
+        o_grouped, o_idx = geo.anchor_grouping(xyz_, feats_, 8)
+        assert torch.equal(idx1.cpu(), o_idx) and torch.equal(gr1.cpu().view(Fn, 27, 8, 6 + D), o_grouped)
+        if xyz_ is xyz:
+            assert torch.equal(d1.cpu(), T(g["dist"])), "distance matrix bit-identical to the reference's (golden G2)"
+            assert_indices_equal_modulo_ties(idx1.cpu(), T(g["idx"]), T(g["dist"]))
+        idx2 = torch.empty_like(idx1)
+        hip.call("local_group_l1", xf, 3 + D, Fn, N, D, anchors, idx2, None, None, None, 0, None, 0, None, 256, None)     # grouping only
+        assert torch.equal(idx2, idx1)
+        dg = torch.randn(Fn * 216, 6 + D, generator=gen).to(dev)
+        a0, a1 = (torch.ones((Fn * N, 3 + D), device=dev) for _ in range(2))
+        hip.call("anchor_group_backward", dg, idx1, Fn, N, D, a0, 3 + D)
+        hip.call("anchor_scatter", dg, idx1, Fn, N, D, a1, 3 + D)
+        assert torch.equal(a0, a1), "same summation order as the slot walk"
+
+
+def test_pool8_kernels_against_torch(dev):
+    """mmego_pool8_bn_act (BatchNorm + ReLU + score + 8-way softmax + weighted sum, pooled vectors in [frame][channel][anchor] order)
+    and mmego_pool8_backward (row gradients, BatchNorm sums through the ReLU mask, attention parameter partials) against autograd
+    in fp64, fed by mmego_mlp_fwd_layer's statistics partials."""
+    from mmego_amd import hip
+    gen = torch.Generator().manual_seed(9)
+    Fn = 7
+    rows = Fn * 216
+    x = torch.randn(rows, 48, generator=gen)
+    W, b = torch.randn(64, 48, generator=gen) * 0.2, torch.randn(64, generator=gen) * 0.1
+    gamma, beta = torch.rand(64, generator=gen) + 0.5, torch.randn(64, generator=gen) * 0.1
+    aw_w, aw_b = torch.randn(1, 64, generator=gen) * 0.3, torch.randn(1, generator=gen)
+    dv = torch.randn(Fn, 64, 27, generator=gen)
+    nblk = hip.lib().mmego_mlp_train_nblk(rows)
+    assert nblk == hip.lib().mmego_pool8_nblk(rows)
+    z = torch.empty(rows, 64, device=dev)
+    part = torch.empty(nblk * 2 * 64, dtype=torch.float64, device=dev)
+    d = lambda v: v.to(dev).contiguous()
+    hip.call("mlp_fwd_layer", d(x), 48, rows, 48, None, None, None, 0.0, None, None, 0.0, None, d(W), d(b), 64, z, 64, part)
+    rm, rv, state = torch.zeros(64, device=dev), torch.ones(64, device=dev), torch.empty(4, 64, device=dev)
+    voxT, attn = torch.empty(Fn, 64, 27, device=dev), torch.empty(rows, device=dev)
+    hip.call("pool8_bn_act", z, 64, rows, part, d(gamma), d(beta), 1e-5, rm, rv, 0.1, state, d(aw_w), d(aw_b), voxT, attn)
+    # fp64 reference
+    zd = (x.double() @ W.double().t() + b.double()).requires_grad_(True)
+    g64, b64, w64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True), aw_w.double().requires_grad_(True)
+    ab64 = aw_b.double().requires_grad_(True)
+    mean, var = zd.mean(0), zd.var(0, unbiased=False)
+    y = torch.relu((zd - mean) / torch.sqrt(var + 1e-5) * g64 + b64)
+    y.retain_grad()
+    sc = (y @ w64.t() + ab64).view(-1, 8)
+    at = torch.softmax(sc, dim=1)
+    vec = (at.unsqueeze(-1) * y.view(-1, 8, 64)).sum(1)                      # [F*27, 64]
+    assert (attn.double().cpu().view(-1, 8) - at).abs().max().item() < 1e-5
+    assert (voxT.double().cpu() - vec.view(Fn, 27, 64).transpose(1, 2)).abs().max().item() < 1e-4
+    assert (rm.double().cpu() - 0.1 * mean.detach()).abs().max().item() < 1e-5
+    (vec.view(Fn, 27, 64).transpose(1, 2) * dv.double()).sum().backward()
+    dY = torch.empty(rows, 64, device=dev)
+    gpart = torch.empty(nblk * 2 * 64, dtype=torch.float64, device=dev)
+    awp = torch.empty(nblk, 128, device=dev)
+    hip.call("pool8_backward", z, 64, rows, state, attn, d(dv), d(aw_w), dY, 64, gpart, awp)
+    assert (dY.double().cpu() - y.grad).abs().max().item() < 1e-4 * max(1.0, y.grad.abs().max().item())
+    gmask = y.grad * (y.detach() > 0)
+    xhat = ((zd - mean) / torch.sqrt(var + 1e-5)).detach()
+    gp = gpart.view(nblk, 2, 64).sum(0).cpu()
+    assert (gp[0] - gmask.sum(0)).abs().max().item() < 1e-3 and (gp[1] - (gmask * xhat).sum(0)).abs().max().item() < 1e-3
+    assert (awp[:, :64].double().sum(0).cpu() - w64.grad.view(-1)).abs().max().item() < 1e-3 * max(1.0, w64.grad.abs().max().item())
+    assert abs(float(awp[:, 64].double().sum()) - float(ab64.grad)) < 1e-3
+    assert float(awp[:, 65:].abs().max()) == 0.0
+
+
 def test_train_upper_wlocal(dev):
     from mmego_amd.nets_local import UpperNetwlocal
     g = golden("g6_train.npz")
