@@ -267,6 +267,13 @@ int mmego_head_fk_forward(void* stream, int which, const float* y, const float* 
                           unsigned long long* seed_ctr);
 int mmego_head_fk_backward(void* stream, int which, const float* y, const float* body, int B, long F, const float* dj,
                            float* dy, const float* Rw);
+/* mmego_head_fk_forward -> mmego_l1_loss (scale, loss[2], gradient = sign) -> mmego_head_fk_backward as ONE launch: F <= 512 frames, a
+ * single workgroup (the loss is a fixed-order sum).  map [nslots]: target joint of every predicted slot; dy [F, ny]: d loss / d y.
+ * Bit-identical to the three calls (Train_Upper.py:165-182, Train_Lower.py:199-224: forward tail, L1Loss(sum), start of backward). */
+int mmego_head_fk_loss(void* stream, int which, const float* y, const float* body, int B, long F, float* q, float* joints_h,
+                       const float* Rw, const float* tw, float* world, long long* counters, int ncount,
+                       unsigned long long* seed_ctr, const float* target, const int* map, int ntgt, double scale, float* loss,
+                       float* dy);
 /* y[F,9] -> R[F,3,3] (eps rule of IMU_Net.py:7-18), t[F,3]. */
 int mmego_imu_head(void* stream, const float* y, long F, float* R, float* t);
 /* IMU_Net.fc2 (Net/IMU_Net.py:84) and mmego_imu_head in one launch: y = X [F][K] . W[9][K]^T + b (row-wise dot products, fixed

@@ -296,6 +296,134 @@ __global__ __launch_bounds__(64) void head_fk_bwd_kernel(const float* __restrict
     for (int i = 0; i < 3; ++i) dyf[P::seed_off[s] + i] = g[P::seed_slot[s]][i];
 }
 
+// Forward kinematics + head-to-world transform + L1(sum) loss against the selected target joints + the loss gradient (its sign)
+// + the backward of the transform and of the kinematics, in ONE launch: F <= 512 frames, a single workgroup (a thread per frame, two
+// frames in turn above 256), so that the loss is a fixed-order sum (deterministic) without a second launch.  Same arithmetic, statement by statement, as
+// head_fk_fwd_kernel -> l1_loss_kernel -> head_fk_bwd_kernel (bit-identical results; tests/test_hip_parity.py).  Replaces three
+// dependent launches at the turning point of a training step (Train_Upper.py:165-182, Train_Lower.py:199-224).
+template <int WHICH>
+__global__ __launch_bounds__(256) void head_fk_loss_kernel(const float* __restrict__ y, const float* __restrict__ body, int B, long F,
+                                                           float* __restrict__ q, float* __restrict__ joints,
+                                                           const float* __restrict__ Rw, const float* __restrict__ tw,
+                                                           float* __restrict__ world, long long* counters, int ncount,
+                                                           unsigned long long* seed_ctr, const float* __restrict__ target,
+                                                           const int* __restrict__ map, int ntgt, float scale,
+                                                           float* __restrict__ loss, float* __restrict__ dy) {
+  using P = FkC<WHICH>;
+  __shared__ double sh[2][8];
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < ncount; ++i) counters[i] += 1;
+    if (seed_ctr) seed_ctr[0] = seed_ctr[0] * 6364136223846793005ULL + 1442695040888963407ULL;
+  }
+  double acc = 0.0, dist = 0.0;
+  // (256 threads = one wave per SIMD: the frame's ~400 live values fit the unified register file; a thread walks frames tid, tid + 256)
+#pragma unroll 1
+  for (long f = threadIdx.x; f < F; f += 256) {
+    float yv[P::ny];
+#pragma unroll
+    for (int i = 0; i < P::ny; ++i) yv[i] = y[f * P::ny + i];
+    float tg[P::nslots][3];
+#pragma unroll
+    for (int s_ = 0; s_ < P::nslots; ++s_) {
+      const float* tp = target + (f * ntgt + map[s_]) * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tg[s_][i] = tp[i];
+    }
+    const float* yf = yv;
+    const float* bf = body + (f % B) * 60;
+    float bd[P::nbones][3];
+#pragma unroll
+    for (int k = 0; k < P::nbones; ++k)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) bd[k][i] = bf[P::row[k] * 3 + i];
+    const float* Rf = Rw + f * 9;
+    float Rr[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rr[i] = Rf[i];
+    const float t0 = tw[f * 3], t1 = tw[f * 3 + 1], t2 = tw[f * 3 + 2];
+    float* qf = q + f * P::nrot * 9;
+    float l[P::nslots][3];
+    float g[P::nslots][3];
+    {
+      float R[P::nrot][9];
+#pragma unroll
+      for (int s_ = 0; s_ < P::nseed; ++s_)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) l[P::seed_slot[s_]][i] = yf[P::seed_off[s_] + i];
+#pragma unroll
+      for (int k = 0; k < P::nrot; ++k) {
+        Rot6 r = rot6d_fwd(yf + 6 * k, 1e-12f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { R[k][i * 3 + 0] = r.x[i]; R[k][i * 3 + 1] = r.y[i]; R[k][i * 3 + 2] = r.z[i]; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) qf[k * 9 + i] = R[k][i];
+      }
+#pragma unroll
+      for (int k = 0; k < P::nbones; ++k) {
+        const float b0 = bd[k][0], b1 = bd[k][1], b2 = bd[k][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          l[P::child[k]][i] = l[P::parent[k]][i] + (R[P::rot[k]][i * 3] * b0 + R[P::rot[k]][i * 3 + 1] * b1 + R[P::rot[k]][i * 3 + 2] * b2);
+      }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < P::nslots; ++s_) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) joints[(f * P::nslots + s_) * 3 + i] = l[s_][i];
+      float w[3];
+      w[0] = dot3_nofma(Rr[0], Rr[3], Rr[6], l[s_][0], l[s_][1], l[s_][2]) + t0;
+      w[1] = dot3_nofma(Rr[1], Rr[4], Rr[7], l[s_][0], l[s_][1], l[s_][2]) + t1;
+      w[2] = dot3_nofma(Rr[2], Rr[5], Rr[8], l[s_][0], l[s_][1], l[s_][2]) + t2;
+      float* wp = world + (f * P::nslots + s_) * 3;
+      wp[0] = w[0]; wp[1] = w[1]; wp[2] = w[2];
+      const float dx = w[0] - tg[s_][0], dyy = w[1] - tg[s_][1], dz = w[2] - tg[s_][2];
+      acc += ((double)fabsf(dx) + (double)fabsf(dyy)) + (double)fabsf(dz);
+      dist += (double)sqrtf(dx * dx + dyy * dyy + dz * dz);
+      const float v0 = dx > 0.f ? scale : (dx < 0.f ? -scale : 0.f);
+      const float v1 = dyy > 0.f ? scale : (dyy < 0.f ? -scale : 0.f);
+      const float v2 = dz > 0.f ? scale : (dz < 0.f ? -scale : 0.f);
+      g[s_][0] = dot3_nofma(Rr[0], Rr[1], Rr[2], v0, v1, v2);       // world -> head frame (head_fk_bwd_kernel's first step)
+      g[s_][1] = dot3_nofma(Rr[3], Rr[4], Rr[5], v0, v1, v2);
+      g[s_][2] = dot3_nofma(Rr[6], Rr[7], Rr[8], v0, v1, v2);
+    }
+    float gq[P::nrot][9];
+#pragma unroll
+    for (int k = 0; k < P::nrot; ++k)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gq[k][i] = 0.f;
+#pragma unroll
+    for (int k = P::nbones - 1; k >= 0; --k) {
+      const float b0 = bd[k][0], b1 = bd[k][1], b2 = bd[k][2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        g[P::parent[k]][i] += g[P::child[k]][i];
+        gq[P::rot[k]][i * 3 + 0] += g[P::child[k]][i] * b0;
+        gq[P::rot[k]][i * 3 + 1] += g[P::child[k]][i] * b1;
+        gq[P::rot[k]][i * 3 + 2] += g[P::child[k]][i] * b2;
+      }
+    }
+    float* dyf = dy + f * P::ny;
+#pragma unroll
+    for (int k = 0; k < P::nrot; ++k) rot6d_bwd(yf + 6 * k, 1e-12f, gq[k], dyf + 6 * k);
+#pragma unroll
+    for (int i = 6 * P::nrot; i < P::ny; ++i) dyf[i] = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < P::nseed; ++s_)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dyf[P::seed_off[s_] + i] = g[P::seed_slot[s_]][i];
+  }
+  acc = wave_sum_d(acc);
+  dist = wave_sum_d(dist);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = acc; sh[1][threadIdx.x >> 6] = dist; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { s0 += sh[0][w]; s1 += sh[1][w]; }
+    loss[0] = (float)s0;
+    loss[1] = (float)s1;
+  }
+}
+
 // IMU head: out[f, 0:9] -> R [f,3,3] (eps rule 1e-8), t [f,3]
 __global__ __launch_bounds__(128) void imu_head_kernel(const float* __restrict__ y, long F, float* __restrict__ R,
                                                        float* __restrict__ t) {
@@ -495,6 +623,21 @@ extern "C" int mmego_head_fk_backward(void* stream, int which, const float* y, c
   MMEGO_REQUIRE((which == 0 || which == 1) && y && body && dj && dy && B > 0 && F > 0);
   if (which == 0) hipLaunchKernelGGL(head_fk_bwd_kernel<0>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, dj, dy, Rw);
   else hipLaunchKernelGGL(head_fk_bwd_kernel<1>, dim3(cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, y, body, B, F, dj, dy, Rw);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// head_fk_forward + l1_loss + head_fk_backward as ONE launch (F <= 512 frames; map has the net's nslots entries: the target joint of
+// every predicted slot).  dy [F, ny]: gradient of the loss wrt the head output y.
+extern "C" int mmego_head_fk_loss(void* stream, int which, const float* y, const float* body, int B, long F, float* q, float* joints_h,
+                                  const float* Rw, const float* tw, float* world, long long* counters, int ncount,
+                                  unsigned long long* seed_ctr, const float* target, const int* map, int ntgt, double scale,
+                                  float* loss, float* dy) {
+  MMEGO_REQUIRE((which == 0 || which == 1) && y && body && q && joints_h && Rw && tw && world && target && map && loss && dy);
+  MMEGO_REQUIRE(B > 0 && F > 0 && F <= 512 && ntgt > 0 && ncount >= 0 && ncount <= 4096 && (ncount == 0 || counters));
+  const int nt = 256;
+  if (which == 0) hipLaunchKernelGGL(head_fk_loss_kernel<0>, dim3(1), dim3(nt), 0, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy);
+  else hipLaunchKernelGGL(head_fk_loss_kernel<1>, dim3(1), dim3(nt), 0, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -98,6 +98,23 @@ class _NetBase(nn.Module):
             self._seed = torch.tensor([0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=dev)
         return self._seed
 
+    # -- kinematics head, optionally with the trainer's loss and the start of backward in the same launch ----------------
+    loss_hook = None      # (target [B,T,21,3], joint map int32, loss buffer [2], scale): set by train_step.StageStep around a step
+
+    def _head_fk(self, ar, which, y, body, B, F, q, jh, R, t, l, tick, stash):
+        """mmego_head_fk_forward; with a loss hook (training step, <= 512 frames) mmego_head_fk_loss instead: kinematics, head-to-world
+        transform, L1(sum) loss, its gradient and the kinematics' backward in one launch -- dy lands in the arena and
+        _backward_impl skips its first launch (bit-identical to the three separate launches)."""
+        hook = self.loss_hook
+        self._dy_ready = False
+        if hook is not None and stash and F <= 512 and os.environ.get("MMEGO_FUSED_HEAD_LOSS", "1") != "0":
+            target, jmap, loss2, scale = hook
+            dy = ar.get("dy", (F, y.shape[1]))
+            hip.call("head_fk_loss", which, y, body, B, F, q, jh, R, t, l, *tick, target, jmap, target.shape[-2], float(scale), loss2, dy)
+            self._dy_ready = True
+        else:
+            hip.call("head_fk_forward", which, y, body, B, F, q, jh, R, t, l, *tick)
+
     def _drop_p(self, lstm):
         if not self.training:
             return 0.0
@@ -269,7 +286,7 @@ class UpperNet(_NetBase):
         jh = ar.get("jh", (F, 15, 3))
         l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=vec.device)
         tick = self._flat.tick_args(self.seed_counter()) if training else (None, 0, None)   # BatchNorm counters + dropout seed
-        hip.call("head_fk_forward", 0, y, body, B, F, q, jh, R, t, l, *tick)       # kinematics + head-to-world transform, one launch
+        self._head_fk(ar, 0, y, body, B, F, q, jh, R, t, l, tick, stash)    # kinematics + head-to-world transform (+ loss), one launch
         if stash:
             self._saved = (B, T, N, R, body, c0, attn)
         return l, q, attn, hn, cn
@@ -282,7 +299,8 @@ class UpperNet(_NetBase):
         dl = _f32c(dl)
         y, h1 = ar.get("y", (F, 87)), ar.get("h1", (F, 128))
         dy = ar.get("dy", (F, 87))
-        hip.call("head_fk_backward", 0, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
+        if not getattr(self, "_dy_ready", False):
+            hip.call("head_fk_backward", 0, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
         dh1 = ar.get("dh1", (F, 128))
         leaves = []          # weight gradients of the head and of the BiLSTM stack: leaves, issued together behind the stack
         blocks.linear_backward(dy, h1, self.mlpHead.fc2, G, dh1, relu_input=True, leaves=leaves)
@@ -474,7 +492,7 @@ class LowerNet(_NetBase):
         jh = ar.get("jh", (F, 8, 3))
         l = torch.empty((B, T, 8, 3), dtype=torch.float32, device=dev)
         tick = self._flat.tick_args(self.seed_counter()) if training else (None, 0, None)   # BatchNorm counters + dropout seed
-        hip.call("head_fk_forward", 1, y, body, B, F, q, jh, R, t, l, *tick)       # kinematics + head-to-world transform, one launch
+        self._head_fk(ar, 1, y, body, B, F, q, jh, R, t, l, tick, stash)    # kinematics + head-to-world transform (+ loss), one launch
         if stash:
             self._saved = (B, T, N, R, body)
         return l, q
@@ -646,7 +664,8 @@ class LowerNet(_NetBase):
         dl = _f32c(dl)
         y, f1, f0, cat = ar.get("y", (F, 42)), ar.get("f1", (F, 64)), ar.get("f0", (F, 128)), ar.get("cat", (F, 173))
         dy = ar.get("dy", (F, 42))
-        hip.call("head_fk_backward", 1, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
+        if not getattr(self, "_dy_ready", False):
+            hip.call("head_fk_backward", 1, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
         df1, df0, dcat = ar.get("df1", (F, 64)), ar.get("df0", (F, 128)), ar.get("dcat", (F, 173))
         leaves = []          # weight gradients of the fusion head and of the BiLSTM stack: leaves, issued together behind the stack
         blocks.linear_backward(dy, f1, fu.fc2, G, df1, relu_input=True, leaves=leaves)

@@ -193,7 +193,7 @@ class UpperNetwlocal(_NetBase):
         jh = ar.get("jh", (F, 15, 3))
         l = torch.empty((B, T, 15, 3), dtype=torch.float32, device=dev)
         tick = self._flat.tick_args(self.seed_counter()) if training else (None, 0, None)   # BatchNorm counters + dropout seed
-        hip.call("head_fk_forward", 0, y, body, B, F, q, jh, R, t, l, *tick)       # kinematics + head-to-world transform, one launch
+        self._head_fk(ar, 0, y, body, B, F, q, jh, R, t, l, tick, stash)    # kinematics + head-to-world transform (+ loss), one launch
         if stash:
             self._saved = (B, T, N, R, body, c0g, c0a, gw, aw)
         return l, q, gw, aw, hn_g, cn_g, hn_a, cn_a
@@ -207,7 +207,8 @@ class UpperNetwlocal(_NetBase):
         dl = _f32c(dl)
         y, h1, cat = ar.get("y", (F, 87)), ar.get("h1", (F, 128)), ar.get("cat", (F, 256))
         dy = ar.get("dy", (F, 87))
-        hip.call("head_fk_backward", 0, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
+        if not getattr(self, "_dy_ready", False):
+            hip.call("head_fk_backward", 0, y, body, B, F, dl, dy, R)           # (world -> head frame inside the kernel)
         dh1 = ar.get("dh1", (F, 128))
         blocks.linear_backward(dy, h1, self.module3.fc2, G, dh1, relu_input=True)
         dcat = ar.get("dcat", (F, 256))

@@ -161,6 +161,15 @@ class StageStep:
         first_net = self.net if self.stage == "upper" else self.upper_frozen
         # fresh batch (x is transformed in place): Upper_Net's transform launch reads it from x_src; other nets get a copy first
         via_transform = type(first_net) is UpperNet and s["x"].shape[-1] <= 8
+        # the trained net's kinematics launch takes the loss, its gradient and the first backward step along (nets._head_fk)
+        self.net.loss_hook = (s["target"], self.jmap, self.loss2, 1.0)
+        try:
+            self._body_forward_inner(s, B, T, first_net, via_transform)
+        finally:
+            self.net.loss_hook = None
+
+    def _body_forward_inner(self, s, B, T, first_net, via_transform):
+        from .nets import UpperNet
         if not via_transform:
             ops.copy2d(s["x_src"].view(B * T, -1), s["x"].view(B * T, -1))
         x_src = s["x_src"] if via_transform else None
@@ -190,7 +199,8 @@ class StageStep:
                     up = self.upper_frozen(s["x"], s["h0"], s["c0"], s["body"], R, t)[0]
                 l = self.net._forward_impl(up, s["x"], s["body"], R, t, stash=True)[0]
                 nsel = 8
-            hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss2, s["dl"])
+            if not getattr(self.net, "_dy_ready", False):
+                hip.call("l1_loss", l, s["target"], self.jmap, nsel, 21, B * T, 1.0, self.loss2, s["dl"])
         self.last_pred = l
 
     def _body_backward(self):

@@ -178,3 +178,43 @@ def test_engines_agree_bit_for_bit_at_bench_shape(dev):
             assert torch.equal(a.net.flat().flat_p, b.net.flat().flat_p), (kind, a.stage)
             for ba, bb in zip(a.net.buffers(), b.net.buffers()):
                 assert torch.equal(ba, bb), (kind, a.stage)
+
+
+@pytest.mark.gpu
+def test_fused_head_loss_launch_is_bit_identical_to_the_three_launches():
+    """mmego_head_fk_loss (kinematics + transform + L1(sum) loss + its gradient + kinematics backward in one launch, what StageStep
+    uses) against head_fk_forward -> l1_loss -> head_fk_backward (MMEGO_FUSED_HEAD_LOSS=0): predictions, both loss figures and every
+    gradient bit for bit, Upper_Net, Lower_Net and UpperNetwlocal, B = 64 (512 frames: two frames per thread) and B = 5."""
+    import os
+    from mmego_amd import nets, nets_local
+    from mmego_amd.train_step import StageStep
+    dev = torch.device("cuda:0")
+    for Bq in (5, 64):
+        g = torch.Generator().manual_seed(3 + Bq)
+        x = torch.randn(Bq, 8, 128, 6, generator=g).to(dev)
+        imu = torch.randn(Bq, 8, 20, 15, generator=g).to(dev)
+        body = (0.2 * torch.randn(Bq, 20, 3, generator=g)).to(dev)
+        target = torch.randn(Bq, 8, 21, 3, generator=g).to(dev)
+        Rg = torch.linalg.qr(torch.randn(Bq, 8, 3, 3, generator=g))[0].contiguous().to(dev)
+        for kind in ("upper", "lower", "wlocal"):
+            res = []
+            for fused in ("1", "0"):
+                os.environ["MMEGO_FUSED_HEAD_LOSS"] = fused
+                try:
+                    torch.manual_seed(9)
+                    if kind == "lower":
+                        net, fr = nets.LowerNet(64).to(dev).train(), nets.UpperNet().to(dev).eval()
+                        st = StageStep("lower", net, None, upper_frozen=fr, use_graph=False)
+                    else:
+                        net = (nets.UpperNet() if kind == "upper" else nets_local.UpperNetwlocal()).to(dev).train()
+                        st = StageStep("upper", net, None, use_graph=False)
+                    net.lstm_dropout = 0.0
+                    st.bind(x, imu, body, target, R_gt=Rg)
+                    st._body()
+                    torch.cuda.synchronize()
+                    assert getattr(net, "_dy_ready", False) == (fused == "1")
+                    res.append((st.last_pred.clone(), st.loss2.clone(), net.flat().flat_g.clone()))
+                finally:
+                    os.environ.pop("MMEGO_FUSED_HEAD_LOSS", None)
+            for a, b in zip(*res):
+                assert torch.equal(a, b), (kind, Bq)
