@@ -65,6 +65,34 @@ __device__ __forceinline__ void tile_out(const float* lds, int S, float* g, long
   }
 }
 
+// (mean, M2) records of `ncol` columns (a power of two <= 256) of an LDS tile over its nv valid rows: thread (column, row part) takes
+// every P-th row (shifted sums, four loads in flight), the parts are added in a fixed order through `scr` (GF_NT * 2 floats).
+// rows16: the tile keeps 16 rows per frame of V (row V a dummy).  Ends with the records stored (no trailing barrier).
+__device__ __forceinline__ void tile_records(const float* base, int S, int ncol, int nv, int V, bool rows16, float* scr, float2* rec) {
+  const int tid = threadIdx.x, P = GF_NT / ncol;
+  const int cid = tid & (ncol - 1), part = tid / ncol;
+  const float* col = base + cid;
+  const float shift = col[0];
+  float s1 = 0.f, s2 = 0.f;
+  for (int rr = part; rr < nv; rr += 4 * P) {
+    float d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = rr + u * P < nv ? rr + u * P : 0;
+      d[u] = col[(rows16 ? q + q / V : q) * S] - shift;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const float dd = rr + u * P < nv ? d[u] : 0.f; s1 += dd; s2 = __builtin_fmaf(dd, dd, s2); }
+  }
+  scr[(part * ncol + cid) * 2] = s1; scr[(part * ncol + cid) * 2 + 1] = s2;
+  __syncthreads();
+  if (tid < ncol) {
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < P; ++j) { a += scr[(j * ncol + tid) * 2]; b += scr[(j * ncol + tid) * 2 + 1]; }
+    rec[tid] = rec_from_shifted(shift, a, b, nv);
+  }
+}
+
 // NCTW: 32-column tiles of the product per wave pair (4 wave pairs x 2 row halves); NK: 32-k chunks (0: scalar product, cin < 32)
 template <int NCTW, int NK>
 __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
@@ -75,7 +103,8 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
   const int nf = (int)(p.F - f0 < GF_FPB ? p.F - f0 : GF_FPB);
   const int nv = nf * V;                                 // valid rows of this tile (<= 60)
   const long r0 = f0 * V, rows = p.F * V;
-  const int XS = (NK ? cin : 4) + 4, ZS = p.mix ? nout + 16 : nout + 1, YS = cout + 4;
+  const bool phased = NK > 0 && p.mix;                   // blocks with cin >= 32: the product in parts of cout columns (LDS <= 75 KB)
+  const int XS = (NK ? cin : 4) + 4, ZS = phased ? cout + 16 : (p.mix ? nout + 16 : nout + 1), YS = cout + 4;
   float* st = sm;                                        // [2][4][cin]: mean, a, b, invstd of bn1 | bn2 (bn_from_records)
   float* zs = sm + GF_ST;                                // [64][ZS] product tile
   float* xs = zs + 64 * ZS;                              // [64][XS] input tile; later ys [60][YS]
@@ -87,11 +116,14 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
   // takes k = k0 + 16 h + s on BOTH operands (same permutation: the sum over k is unchanged); W comes FRAGMENT-MAJOR (mmego_pack_multi
   // kind 1), so the four 16-byte loads of a (tile, chunk) are coalesced 1-KB reads straight into the operand registers.
   const int r = lane & 31, h = lane >> 5, rt = wave & 1, wp = wave >> 1, NCT = nout / 32;
+  // (phased: part i = partition k (i < Kk) or the residual branch (i = Kk), this wave's tile = columns i cout + 32 wp ..; else tile
+  // wp + 4 i of the whole product)
   f32x4 wf[NCTW ? NCTW : 1][NK ? NK : 1][4];
   if (NK) {
 #pragma unroll
     for (int i = 0; i < NCTW; ++i) {
-      const int ct = wp + 4 * i < NCT ? wp + 4 * i : NCT - 1;
+      int ct = phased ? i * (cout / 32) + (wp < cout / 32 ? wp : 0) : wp + 4 * i;
+      ct = ct < NCT ? ct : NCT - 1;
 #pragma unroll
       for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
@@ -214,6 +246,74 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
     }
   }
   __syncthreads();
+
+  if (phased) {
+    // ---- blocks with cin >= 32: the stacked product one part of cout columns at a time (partition 0 .. Kk-1, then the residual
+    // branch); a part's tile leaves for Z, and a partition's goes straight into the einsum (accumulated in registers over the
+    // partitions) -- the whole (Kk + 1) cout wide tile never sits in LDS, so a recurrent-step workgroup of the other stage's IMU_Net
+    // still fits on the CU beside this one
+    const int nch = cout / 16, npair = nf * nch;
+    const int vq = lane >> 4, cl = lane & 15;
+    f32x4 accm[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int q = 0; q < NCTW; ++q) {
+      if (q <= p.Kk) {                                     // (uniform)
+        if (wp < cout / 32 && !(p.dbg & 16)) {
+          f32x16 acc = {0};
+#pragma unroll
+          for (int kc = 0; kc < NK; ++kc) {
+            f32x4 af[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(xs + (rt * 32 + r) * XS + kc * 32 + 16 * h + 4 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], wf[q][kc][j][e], acc, 0, 0, 0);
+          }
+          const int col = wp * 32 + r;
+          const float bb = p.bias ? p.bias[q * cout + col] : 0.f;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) zs[(rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * ZS + col] = acc[reg] + bb;
+        }
+        __syncthreads();
+        if (!(p.dbg & 2)) tile_out<2>(zs, ZS, p.Z + r0 * p.ldz + q * cout, p.ldz, nv, cout, tid);
+        if (q < p.Kk) {
+          if (!(p.dbg & 4)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int pi = wave + (GF_NT / 64) * i;
+              if (pi < npair) {
+                const int fi = pi / nch, n0 = (pi - fi * nch) * 16;
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                  const int v = 4 * s_ + vq;
+                  const float b = zs[(fi * V + (v < V ? v : V - 1)) * ZS + n0 + cl];
+                  const float a = q == 0 ? ae[0][s_] : (q == 1 ? ae[1][s_] : ae[2][s_]);
+                  accm[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, accm[i], 0, 0, 0);
+                }
+              }
+            }
+          }
+        } else if (!(p.dbg & 8)) {
+          tile_records(zs, ZS, cout, nv, V, false, st, p.recR + (long)blockIdx.x * cout);
+        }
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pi = wave + (GF_NT / 64) * i;
+      if (pi < npair) {
+        const int fi = pi / nch, n0 = (pi - fi * nch) * 16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) ys[(fi * 16 + 4 * vq + reg) * YS + n0 + cl] = accm[i][reg];
+      }
+    }
+    __syncthreads();
+    if (!(p.dbg & 2)) for (int fi = 0; fi < nf; ++fi) tile_out<1>(ys + fi * 16 * YS, YS, p.Y + (r0 + fi * V) * cout, cout, V, cout, tid);
+    if (!(p.dbg & 8)) tile_records(ys, YS, cout, nv, V, true, st, p.recY + (long)blockIdx.x * cout);
+    return;
+  }
 
   // ---- the stacked 1x1 conv: zs[64][nout] = xs . W^T + bias
   if (NK) {
@@ -782,8 +882,9 @@ extern "C" int mmego_gcn_front(void* stream, const void* desc) {
   }
   const bool scalar = p.cin < 32;
   MMEGO_REQUIRE(scalar == (p.in_mode == 0) || !scalar);
-  const int NCT = p.nout / 32, nctw = (NCT + 3) / 4, nk = scalar ? 0 : p.cin / 32;
-  const int XS = (nk ? p.cin : 4) + 4, ZS = p.nout + 16, YS = p.cout + 4;
+  const bool phased = !scalar && p.mix;
+  const int NCT = p.nout / 32, nctw = phased ? p.Kk + 1 : (NCT + 3) / 4, nk = scalar ? 0 : p.cin / 32;
+  const int XS = (nk ? p.cin : 4) + 4, ZS = phased ? p.cout + 16 : (p.mix ? p.nout + 16 : p.nout + 1), YS = p.cout + 4;
   const int tail = 64 * XS > 64 * YS ? 64 * XS : 64 * YS;
   const size_t lds = (size_t)(GF_ST + 64 * ZS + (tail > 8192 ? tail : 8192)) * sizeof(float);      // (>= 32 KB of prologue scratch)
   MMEGO_REQUIRE(lds <= 160 * 1024 && 8 * p.cin <= GF_ST);
@@ -800,12 +901,14 @@ extern "C" int mmego_gcn_front(void* stream, const void* desc) {
     hipLaunchKernelGGL((gcn_front_kernel<NCTW_, NK_>), grid, dim3(GF_NT), lds, st, p);                                \
   } while (0)
   if (nk == 0 && nctw == 1) GF_LAUNCH(1, 0);
-  else if (nk == 1 && nctw == 1) GF_LAUNCH(1, 1);
-  else if (nk == 1 && nctw == 2) GF_LAUNCH(2, 1);
-  else if (nk == 2 && nctw == 2) GF_LAUNCH(2, 2);
+  else if (nk == 1 && nctw == 3) GF_LAUNCH(3, 1);
   else if (nk == 2 && nctw == 3) GF_LAUNCH(3, 2);
   else if (nk == 4 && nctw == 1) GF_LAUNCH(1, 4);
   else if (nk == 2 && nctw == 1) GF_LAUNCH(1, 2);
+  else if (nk == 1 && nctw == 2) GF_LAUNCH(2, 1);
+  else if (nk == 2 && nctw == 2) GF_LAUNCH(2, 2);
+  else if (nk == 1 && nctw == 4) GF_LAUNCH(4, 1);
+  else if (nk == 2 && nctw == 4) GF_LAUNCH(4, 2);
   else return MMEGO_EBADARG;
 #undef GF_LAUNCH
   MMEGO_LAUNCH_CHECK();
