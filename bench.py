@@ -678,6 +678,10 @@ def main():
         su.prepare(); sl.prepare()
     else:
         both.prepare()
+    # clock ramp: a GPU that has just been idle (process start-up, graph capture on the host) runs its first ~0.2 s of steps several
+    # per cent slower -- untimed burn-in in front of the W warm-up steps, so that a short --steps block measures the steady state
+    for _ in range(0 if args.trace_only else 40):
+        ul_step()
     for _ in range(args.warmup):
         ul_step()
     sync()

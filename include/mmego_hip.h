@@ -468,6 +468,15 @@ int mmego_tconv_train(void* stream, const float* X, long ldx, const void* in_bn,
                       long ldy, float* act, float* out_rec, int B, int T, int V, int Cin, int Cout, int taps);
 int mmego_tconv_bwd_stats(void* stream, const float* dY, long lddy, const float* Wp, float* dAct, long ldda, const float* ymix,
                           long ldym, const float* state, float* bw_rec, int B, int T, int V, int Cin, int Cout, int taps);
+/* Sequence-tiled forms of the two calls above for T*V <= 128 rows per sequence and Cin in {32, 64, 128} (mmego_tconv_seq_ok): one
+ * workgroup per (sequence, 32 output columns), the sequence's rows staged in LDS once for all taps, weights Wf fragment-major per tap
+ * (mmego_pack_multi kind 2: 2 * taps * Co * Ci floats, the forward image then the input-gradient image); out_rec / bw_rec are per
+ * SEQUENCE: [B][Cout], T*V rows per record. */
+int mmego_tconv_seq_ok(int T, int V, int Cin, int Cout);
+int mmego_tconv_seq_train(void* stream, const float* X, long ldx, const void* in_bn, const float* Wf, const float* bias, float* Y,
+                          long ldy, float* act, float* out_rec, int B, int T, int V, int Cin, int Cout, int taps);
+int mmego_tconv_seq_bwd(void* stream, const float* dY, long lddy, const float* Wf, float* dAct, long ldda, const float* ymix,
+                        long ldym, const float* state, float* bw_rec, int B, int T, int V, int Cin, int Cout, int taps);
 typedef struct MmegoPack { const float* W; float* Wp; int Co, Ci, taps, kind; } MmegoPack;
 int mmego_pack_multi(void* stream, int n, const void* descs);
 /* Backward of a block's closing pair out = relu(BN(X1) + BN(X2)) (same dY, mask = out): reduce -> rec [ceil(rows/64)][2C] (sum g, sum

@@ -17,6 +17,7 @@
 //   tconv_wgrad  the weight gradient, implicit too: per tap a product over the row axis of dY and the shifted activated rows,
 //                row axis split over workgroups, partial tiles added in a fixed order.
 // 64 x 64 output tiles, v_mfma_f32_32x32x2_f32, operands in LDS, next chunk prefetched in registers.
+#include <stdlib.h>
 #include "gcn_stats.h"
 
 #define GC_S 66          // even row stride: fragments are read as aligned float2 (lanes r = 0..31 hit 64 distinct banks)
@@ -591,6 +592,258 @@ extern "C" int mmego_tconv_bwd_stats(void* stream, const float* dY, long lddy, c
   return tconv_launch((hipStream_t)stream, p, false);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Temporal convolution, SEQUENCE-TILED (training shape: T V <= 128 rows per sequence).  The 9 taps of a (t, v) row reach only rows
+// of the same sequence, so a workgroup takes ONE sequence and a 32-column slice of the output: the sequence's (activated) input
+// rows go to LDS once -- not once per tap -- and every tap is the same tile read 15 d rows further down, rows outside the sequence
+// masked to zero.  The weights come fragment-major per tap (mmego_pack_multi kind 2): a wave fetches its B operand straight into
+// registers with coalesced 1-KB reads, the next tap's while the current one is multiplied; no LDS for W, no barrier in the tap loop.
+// 4 waves = 4 row tiles of 32; K = taps x Cin per wave.  LDS: 128 x (Cin + 4) floats (68 KB at Cin = 128).
+//   REC   forward of a training step: BatchNorm (+ReLU) in front from partial records (prologue), `act` kept, out_rec[b][Cout] =
+//         (mean, M2) of the output over the sequence's rows
+//   else  input gradient with the backward sums of the BatchNorm + ReLU in front of the convolution's input: bw_rec[b][Cout]
+// The old tile kernel took 21 / 26 / 40 us at 32 / 64 / 128 channels and 7 680 rows: 9 x Cin / 64 steps of (barrier, tile loads
+// from L2, LDS store, barrier, MFMA) with 120 workgroups -- overhead-bound below 128 channels.
+struct TconvSeqP {
+  const float* X; long ldx;
+  const float* Wf;                  // fragment-major [taps][Cout/32][Cin/32][4][64][4]
+  const float* bias; float* Y; long ldy; float* act;
+  int B, TV, V, Cin, Cout, taps;
+  BnRefD in_bn; float2* out_rec;
+  const float* bw_ym; long ldym; const float* bw_st; float2* bw_rec;
+};
+
+template <int NK, bool REC>
+__global__ __launch_bounds__(256) void tconv_seq_kernel(TconvSeqP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Cin = p.Cin, XS = Cin + 4, TV = p.TV;
+  float* xs = sm;                                          // [128][XS] the sequence's rows; later the output tile [128][36]
+  float* stl = sm + 128 * XS;                              // [4][Cin] (REC)
+  float* scr = sm + (128 * XS + 4 * Cin > 2 * 128 * 36 ? 128 * XS + 4 * Cin : 2 * 128 * 36);      // [512] partial sums (behind both output-phase tiles)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const long b = blockIdx.x;
+  const int ct = blockIdx.y, n0 = ct * 32;
+  const long r0 = b * TV;
+  // ---- the first tap's weight fragments and the sequence's rows: requested first
+  f32x4 wf[2][NK][4];
+  const float* wbase = p.Wf + ((long)ct * NK * 4) * 256 + lane * 4;
+#define TS_WLOAD(buf, tap)                                                                           \
+  _Pragma("unroll") for (int kc = 0; kc < NK; ++kc)                                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+      wf[buf][kc][j] = *reinterpret_cast<const f32x4*>(wbase + (long)(tap) * p.Cout * Cin + (kc * 4 + j) * 256)
+  TS_WLOAD(0, 0);
+  const int c4n = Cin / 4, n4 = TV * c4n;
+  constexpr int NP = NK * 4;                               // 16-byte pieces per thread: 128 rows x Cin / 4 / 256 threads
+  f32x4 xv[NP];
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const int i = tid + 256 * u < n4 ? tid + 256 * u : n4 - 1;
+    xv[u] = *reinterpret_cast<const f32x4*>(p.X + (r0 + i / c4n) * p.ldx + 4 * (i % c4n));
+  }
+  f32x4 ymv[4];                                            // backward statistics: this sequence's ymix columns n0 .. n0 + 31
+  if (!REC && p.bw_rec) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u < TV * 8 ? tid + 256 * u : TV * 8 - 1;
+      ymv[u] = *reinterpret_cast<const f32x4*>(p.bw_ym + (r0 + (i >> 3)) * p.ldym + n0 + 4 * (i & 7));
+    }
+  }
+  if (REC) bn_from_records<256>(p.in_bn, Cin, (long)p.B * TV, reinterpret_cast<double*>(sm), stl, blockIdx.x == 0 && blockIdx.y == 0);
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    asm volatile("" : "+v"(xv[u].x), "+v"(xv[u].y), "+v"(xv[u].z), "+v"(xv[u].w));
+    const int i = tid + 256 * u;
+    const int row = i / c4n, c = 4 * (i % c4n);
+    if (i < 128 * c4n) {
+      f32x4 v = xv[u];
+      if (REC) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(__builtin_fmaf(v[e] - stl[c + e], stl[Cin + c + e], stl[2 * Cin + c + e]), 0.f);
+      }
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(xs + row * XS + c) = row < TV ? v : z4;
+    }
+  }
+  __syncthreads();
+  if (REC && p.act && ct == 0) {                           // the activated rows, kept for backward: 16-byte pieces, reads ahead of stores
+    f32x4 o[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int i = tid + 256 * u < n4 ? tid + 256 * u : n4 - 1;
+      o[u] = *reinterpret_cast<const f32x4*>(xs + (i / c4n) * XS + 4 * (i % c4n));
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int i = tid + 256 * u < n4 ? tid + 256 * u : n4 - 1;
+      *reinterpret_cast<f32x4*>(p.act + (r0 + i / c4n) * Cin + 4 * (i % c4n)) = o[u];
+    }
+  }
+  // ---- taps: acc[32 rows of this wave][32 columns] += shift(xs, 15 d) . W_tap^T.  A lane whose shifted row leaves the sequence
+  // reads the tile's zero row 127 instead (T V < 128): no select in the loop; the next chunk's A fragments are requested before the
+  // current chunk's 16 MFMAs (one wave per SIMD: nothing else hides the LDS latency), the next tap's weights a whole tap ahead.
+  f32x16 acc = {0};
+  constexpr int TAPS = 9, half = TAPS / 2;                 // (straight-line tap loop: across a loop's back edge the compiler waits for
+                                                           // EVERY outstanding load, i.e. for the weights it has just requested)
+  const int rowl = wave * 32 + r;
+#define TS_AROW(tp_) (xs + ((rowl < TV && (unsigned)(rowl + ((tp_) - half) * p.V) < (unsigned)TV) ? rowl + ((tp_) - half) * p.V : 127) * XS + 16 * h)
+#define TS_ALOAD(buf, ptr, kc_)                                                                       \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) af[buf][j] = *reinterpret_cast<const f32x4*>((ptr) + (kc_) * 32 + 4 * j)
+  f32x4 af[2][4];
+  const float* ap = TS_AROW(0);
+  TS_ALOAD(0, ap, 0);
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp) {
+    const int sub = tp & 1;
+    const int tn = tp + 1 < TAPS ? tp + 1 : tp;
+    if (tp + 1 < TAPS) { if (sub == 0) TS_WLOAD(1, tn); else TS_WLOAD(0, tn); }
+    const float* apn = TS_AROW(tn);
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) {
+      const int cur = (tp * NK + kc) & 1;
+      if (kc + 1 < NK) { if (cur) TS_ALOAD(0, ap, kc + 1); else TS_ALOAD(1, ap, kc + 1); }
+      else if (tp + 1 < TAPS) { if (cur) TS_ALOAD(0, apn, 0); else TS_ALOAD(1, apn, 0); }
+      __builtin_amdgcn_sched_barrier(0);                   // (the next chunk's reads stay AHEAD of this chunk's MFMAs)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][j][e], wf[sub][kc][j][e], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ap = apn;
+  }
+#undef TS_AROW
+#undef TS_ALOAD
+#undef TS_WLOAD
+  __syncthreads();                                         // (every wave has read the input tile: it becomes the output tile)
+  float* os = sm;                                          // [128][36]
+  {
+    const float bb = p.bias ? p.bias[n0 + r] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) os[(wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * 36 + r] = acc[reg] + bb;
+  }
+  __syncthreads();
+  {                                                        // output rows: 16-byte pieces, reads ahead of the stores
+    f32x4 o[4];
+    const int n8 = TV * 8;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u < n8 ? tid + 256 * u : n8 - 1;
+      o[u] = *reinterpret_cast<const f32x4*>(os + (i >> 3) * 36 + 4 * (i & 7));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + 256 * u < n8 ? tid + 256 * u : n8 - 1;
+      *reinterpret_cast<f32x4*>(p.Y + (r0 + (i >> 3)) * p.ldy + n0 + 4 * (i & 7)) = o[u];
+    }
+  }
+  // ---- statistics over the sequence's TV rows for this workgroup's 32 columns: thread (column, row part of 8)
+  const int cx = tid & 31, part = tid >> 5;
+  if (REC) {
+    if (p.out_rec) {
+      const float shift = os[cx];
+      float s1 = 0.f, s2 = 0.f;
+      for (int rr = part; rr < TV; rr += 8) { const float d = os[rr * 36 + cx] - shift; s1 += d; s2 = __builtin_fmaf(d, d, s2); }
+      scr[(part * 32 + cx) * 2] = s1; scr[(part * 32 + cx) * 2 + 1] = s2;
+      __syncthreads();
+      if (tid < 32) {
+        float a = 0.f, c = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a += scr[(j * 32 + tid) * 2]; c += scr[(j * 32 + tid) * 2 + 1]; }
+        p.out_rec[b * p.Cout + n0 + tid] = rec_from_shifted(shift, a, c, TV);
+      }
+    }
+  } else if (p.bw_rec) {
+    // g = dAct . [bn(ym) > 0], xhat = (ym - mean) invstd: the prefetched ymix pieces go through LDS to the (column, part) threads
+    float* yt = sm + 128 * 36;                             // [128][36]
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      asm volatile("" : "+v"(ymv[u].x), "+v"(ymv[u].y), "+v"(ymv[u].z), "+v"(ymv[u].w));
+      const int i = tid + 256 * u;
+      if (i < TV * 8) *reinterpret_cast<f32x4*>(yt + (i >> 3) * 36 + 4 * (i & 7)) = ymv[u];
+    }
+    const int cg = n0 + cx;
+    const float mu_ = p.bw_st[cg], is_ = p.bw_st[p.Cout + cg], a_ = p.bw_st[2 * p.Cout + cg], b_ = p.bw_st[3 * p.Cout + cg];
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    for (int rr = part; rr < TV; rr += 8) {
+      const float ym = yt[rr * 36 + cx];
+      const float g = __builtin_fmaf(ym - mu_, a_, b_) > 0.f ? os[rr * 36 + cx] : 0.f;
+      s1 += g;
+      s2 += g * ((ym - mu_) * is_);
+    }
+    scr[(part * 32 + cx) * 2] = s1; scr[(part * 32 + cx) * 2 + 1] = s2;
+    __syncthreads();
+    if (tid < 32) {
+      float a = 0.f, c = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a += scr[(j * 32 + tid) * 2]; c += scr[(j * 32 + tid) * 2 + 1]; }
+      p.bw_rec[b * p.Cout + n0 + tid] = float2{a, c};
+    }
+  }
+}
+
+static int tconv_seq_launch(hipStream_t st, TconvSeqP& p, bool rec) {
+  const int nk = p.Cin / 32;
+  size_t fl = (size_t)128 * (p.Cin + 4) + 4 * p.Cin;
+  if (fl < 2 * 128 * 36) fl = 2 * 128 * 36;
+  size_t lds = (fl + 512) * sizeof(float);
+  dim3 grid((unsigned)p.B, (unsigned)(p.Cout / 32));
+  // a grid of at most one workgroup per CU whose workgroups are matrix-pipe bound (128 channels: 576 MFMAs per wave): ask for more
+  // than half a CU's LDS so that the dispatcher cannot put two of them on one CU while another CU stays empty
+  static const bool spread = getenv("MMEGO_TCONV_SEQ_NOSPREAD") == nullptr;
+  if (spread && nk >= 4 && (long)grid.x * grid.y <= 256 && lds < 84 * 1024) lds = 84 * 1024;
+#define TS_LAUNCH(NK_, REC_)                                                                                          \
+  do {                                                                                                                \
+    static size_t attr = 0;                                                                                           \
+    if (lds > 64 * 1024 && lds > attr) {                                                                              \
+      hipError_t e = hipFuncSetAttribute((const void*)tconv_seq_kernel<NK_, REC_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                                             \
+      attr = lds;                                                                                                     \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((tconv_seq_kernel<NK_, REC_>), grid, dim3(256), lds, st, p);                                   \
+  } while (0)
+  if (rec) {
+    if (nk == 1) TS_LAUNCH(1, true); else if (nk == 2) TS_LAUNCH(2, true); else if (nk == 4) TS_LAUNCH(4, true); else return MMEGO_EBADARG;
+  } else {
+    if (nk == 1) TS_LAUNCH(1, false); else if (nk == 2) TS_LAUNCH(2, false); else if (nk == 4) TS_LAUNCH(4, false); else return MMEGO_EBADARG;
+  }
+#undef TS_LAUNCH
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// 1 when the sequence-tiled kernel takes the shape (else mmego_tconv_train / mmego_tconv_bwd_stats run the tile kernel)
+extern "C" int mmego_tconv_seq_ok(int T, int V, int Cin, int Cout) {
+  return T * V < 128 && (Cin == 32 || Cin == 64 || Cin == 128) && (Cout % 32) == 0 && Cout <= 256 ? 1 : 0;      // (and 9 taps)
+}
+
+// mmego_tconv_train / mmego_tconv_bwd_stats on the sequence-tiled kernel: Wf = the fragment-major pack (mmego_pack_multi kind 2; its
+// second half for the input gradient); records per SEQUENCE: out_rec / bw_rec [B][Cout], T V rows per record.
+extern "C" int mmego_tconv_seq_train(void* stream, const float* X, long ldx, const void* in_bn, const float* Wf, const float* bias, float* Y,
+                                     long ldy, float* act, float* out_rec, int B, int T, int V, int Cin, int Cout, int taps) {
+  const MmegoBnRefH* h = static_cast<const MmegoBnRefH*>(in_bn);
+  MMEGO_REQUIRE(X && h && Wf && Y && out_rec && B > 0 && taps == 9 && mmego_tconv_seq_ok(T, V, Cin, Cout) && ldx >= Cin && ldy >= Cout);
+  MMEGO_REQUIRE((ldx % 4) == 0 && (ldy % 4) == 0 && (((uintptr_t)X | (uintptr_t)Wf | (uintptr_t)Y | (uintptr_t)act) & 15) == 0);
+  MMEGO_REQUIRE(h->rec && h->nrec >= 1 && h->rows_per_rec >= 1 && h->gamma && h->beta && (h->running_mean == nullptr) == (h->running_var == nullptr));
+  TconvSeqP p = {X, ldx, Wf, bias, Y, ldy, act, B, T * V, V, Cin, Cout, taps};
+  p.in_bn = bnref_device(h);
+  p.out_rec = reinterpret_cast<float2*>(out_rec);
+  p.bw_ym = nullptr; p.ldym = 0; p.bw_st = nullptr; p.bw_rec = nullptr;
+  return tconv_seq_launch((hipStream_t)stream, p, true);
+}
+
+extern "C" int mmego_tconv_seq_bwd(void* stream, const float* dY, long lddy, const float* Wf, float* dAct, long ldda, const float* ymix,
+                                   long ldym, const float* state, float* bw_rec, int B, int T, int V, int Cin, int Cout, int taps) {
+  MMEGO_REQUIRE(dY && Wf && dAct && ymix && state && bw_rec && B > 0 && taps == 9 && mmego_tconv_seq_ok(T, V, Cin, Cout));
+  MMEGO_REQUIRE(lddy >= Cin && ldda >= Cout && ldym >= Cout && (lddy % 4) == 0 && (ldda % 4) == 0 && (ldym % 4) == 0);
+  MMEGO_REQUIRE((((uintptr_t)dY | (uintptr_t)Wf | (uintptr_t)dAct | (uintptr_t)ymix) & 15) == 0);
+  TconvSeqP p = {dY, lddy, Wf, nullptr, dAct, ldda, nullptr, B, T * V, V, Cin, Cout, taps};
+  p.in_bn = BnRefD{}; p.out_rec = nullptr;
+  p.bw_ym = ymix; p.ldym = ldym; p.bw_st = state; p.bw_rec = reinterpret_cast<float2*>(bw_rec);
+  return tconv_seq_launch((hipStream_t)stream, p, false);
+}
+
 // Every weight re-layout of a training step in ONE launch (host table of up to 8 entries):
 //   kind 0  temporal-conv weight W[co][ci][tap] -> mode 2 of mmego_tconv_pack (forward pack, gradient pack behind it)
 //   kind 1  a k=1 conv weight W[n][k] (n % 32 == 0, k % 32 == 0) -> FRAGMENT-MAJOR for gcn_front's 32x32x2 MFMAs:
@@ -611,10 +864,24 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(PackTab t) {
     const int ci = (int)(q % Ci), co = (int)(q / Ci);
     t.Wp[k][((long)tap * Co + co) * Ci + ci] = w;
     t.Wp[k][total + ((long)(taps - 1 - tap) * Ci + ci) * Co + co] = w;
-  } else {
+  } else if (t.kind[k] == 1) {
     const int n = (int)(i / Ci), kk = (int)(i - (long)n * Ci);
     const int ct = n >> 5, r = n & 31, kc = kk >> 5, k32 = kk & 31, h = k32 >> 4, j = (k32 & 15) >> 2, e = k32 & 3;
     t.Wp[k][((((long)ct * (Ci >> 5) + kc) * 4 + j) * 64 + h * 32 + r) * 4 + e] = w;
+  } else {
+    // kind 2: W[co][ci][tap] -> per tap the fragment-major image of the forward product's B operand (rows n = co, k = ci), and behind
+    // all taps the same for the input gradient (taps reversed, rows n = ci, k = co): tconv_seq_kernel's operand fetches
+    const int tap = (int)(i % taps);
+    const long q = i / taps;
+    const int ci = (int)(q % Ci), co = (int)(q / Ci);
+    {
+      const int ct = co >> 5, r = co & 31, kc = ci >> 5, k32 = ci & 31, h = k32 >> 4, j = (k32 & 15) >> 2, e = k32 & 3;
+      t.Wp[k][(long)tap * Co * Ci + ((((long)ct * (Ci >> 5) + kc) * 4 + j) * 64 + h * 32 + r) * 4 + e] = w;
+    }
+    {
+      const int ct = ci >> 5, r = ci & 31, kc = co >> 5, k32 = co & 31, h = k32 >> 4, j = (k32 & 15) >> 2, e = k32 & 3;
+      t.Wp[k][total + (long)(taps - 1 - tap) * Co * Ci + ((((long)ct * (Co >> 5) + kc) * 4 + j) * 64 + h * 32 + r) * 4 + e] = w;
+    }
   }
 }
 
@@ -626,8 +893,9 @@ extern "C" int mmego_pack_multi(void* stream, int n, const void* descs) {
   PackTab t;
   int blk = 0;
   for (int k = 0; k < n; ++k) {
-    MMEGO_REQUIRE(h[k].W && h[k].Wp && h[k].Co >= 1 && h[k].Ci >= 1 && h[k].taps >= 1 && (h[k].kind == 0 || h[k].kind == 1));
-    MMEGO_REQUIRE(h[k].kind == 0 || (h[k].taps == 1 && (h[k].Co % 32) == 0 && (h[k].Ci % 32) == 0));
+    MMEGO_REQUIRE(h[k].W && h[k].Wp && h[k].Co >= 1 && h[k].Ci >= 1 && h[k].taps >= 1 && h[k].kind >= 0 && h[k].kind <= 2);
+    MMEGO_REQUIRE(h[k].kind == 0 || ((h[k].Co % 32) == 0 && (h[k].Ci % 32) == 0));
+    MMEGO_REQUIRE(h[k].kind != 1 || h[k].taps == 1);
     t.W[k] = h[k].W; t.Wp[k] = h[k].Wp; t.Co[k] = h[k].Co; t.Ci[k] = h[k].Ci; t.taps[k] = h[k].taps; t.kind[k] = h[k].kind; t.blk0[k] = blk;
     blk += (int)(((long)h[k].Co * h[k].Ci * h[k].taps + 255) / 256);
   }

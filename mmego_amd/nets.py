@@ -534,7 +534,10 @@ class LowerNet(_NetBase):
         wps = [ar.get("gcn.b%d.wp" % i, (2, blk.tcn["2"].weight.numel())) for i, blk in enumerate(blks)]
         # every weight re-layout of the step in one launch: the temporal convs' tap-major packs (forward + gradient) and the
         # fragment-major copies of the stacked 1x1 weights gcn_front multiplies with (blocks with cin >= 32, and fcn)
-        packs = [hip.Pack(hip.ptr(blk.tcn["2"].weight), hip.ptr(wp), blk.cout, blk.cout, blk.taps, 0) for blk, wp in zip(blks, wps)]
+        seq = [blk.taps == 9 and bool(hip.lib().mmego_tconv_seq_ok(T, V, blk.cout, blk.cout)) for blk in blks]      # sequence-tiled temporal conv (gcn.hip)
+        self._tconv_seq = seq
+        packs = [hip.Pack(hip.ptr(blk.tcn["2"].weight), hip.ptr(wp), blk.cout, blk.cout, blk.taps, 2 if sq else 0)
+                 for blk, wp, sq in zip(blks, wps, seq)]
         wfr = {}
         for i, blk in enumerate(blks):
             if blk.cin >= 32:
@@ -550,17 +553,18 @@ class LowerNet(_NetBase):
             key = "gcn.b%d" % i
             zr = ar.get(key + ".zr", (rows, (K + 1) * cout))
             ymix, tz, y0 = ar.get(key + ".ymix", (rows, cout)), ar.get(key + ".tz", (rows, cout)), ar.get(key + ".y0", (rows, cout))
-            recY, recR, rec3 = ar.get(key + ".recY", (nrf, cout, 2)), ar.get(key + ".recR", (nrf, cout, 2)), ar.get(key + ".rec3", (nrt, cout, 2))
+            n3, r3 = (B, T * V) if seq[i] else (nrt, 64)                  # records of the temporal conv's output: per sequence / per 64-row tile
+            recY, recR, rec3 = ar.get(key + ".recY", (nrf, cout, 2)), ar.get(key + ".recR", (nrf, cout, 2)), ar.get(key + ".rec3", (n3, cout, 2))
             d = hip.GcnFront()
             if prev is None:
                 d.X1, d.ld1, d.in_mode = hip.ptr(up), V * cin, 0
                 d.bn1 = hip.BnRef.of(gcn.data_bn, ops.BnState(ar, "gcn.dbn", V * cin).all)
                 d.xact = hip.ptr(ar.get("gcn.x0", (F, V * cin)))
             else:
-                ptz, pzr, prec3, precR, pblk, pkey = prev
+                ptz, pzr, prec3, precR, pblk, pkey, pn3, pr3 = prev
                 pc = pblk.cout
                 d.X1, d.ld1, d.X2, d.ld2, d.in_mode = hip.ptr(ptz), pc, hip.ptr(pzr[:, pblk.K * pc:]), pzr.stride(0), 1
-                d.bn1 = hip.BnRef.of(pblk.tcn["3"], ops.BnState(ar, pkey + ".bn3", pc).all, prec3, nrt, 64)
+                d.bn1 = hip.BnRef.of(pblk.tcn["3"], ops.BnState(ar, pkey + ".bn3", pc).all, prec3, pn3, pr3)
                 d.bn2 = hip.BnRef.of(pblk.residual["1"], ops.BnState(ar, pkey + ".bnr", pc).all, precR, nrf, 4 * V)
                 d.xact = hip.ptr(ar.get(pkey + ".out", (rows, pc)))
             Wc = ops.stacked(blk.gcn.conv.weight.view(K * cout, cin), blk.residual["0"].weight.view(cout, cin))
@@ -571,14 +575,15 @@ class LowerNet(_NetBase):
             d.F, d.V = F, V
             hip.call("gcn_front", d)
             bn0 = hip.BnRef.of(blk.tcn["0"], ops.BnState(ar, key + ".bn0", cout).all, recY, nrf, 4 * V)
-            hip.call("tconv_train", ymix, cout, bn0, wps[i][0], blk.tcn["2"].bias, tz, cout, y0, rec3, B, T, V, cout, cout, blk.taps)
-            prev = (tz, zr, rec3, recR, blk, key)
-        ptz, pzr, prec3, precR, pblk, pkey = prev
+            hip.call("tconv_seq_train" if seq[i] else "tconv_train", ymix, cout, bn0, wps[i][0], blk.tcn["2"].bias, tz, cout, y0, rec3,
+                     B, T, V, cout, cout, blk.taps)
+            prev = (tz, zr, rec3, recR, blk, key, n3, r3)
+        ptz, pzr, prec3, precR, pblk, pkey, pn3, pr3 = prev
         pc = pblk.cout
         kv = ar.get("gcn.kv", (B, 64, T * V))
         d = hip.GcnFront()
         d.X1, d.ld1, d.X2, d.ld2, d.in_mode = hip.ptr(ptz), pc, hip.ptr(pzr[:, pblk.K * pc:]), pzr.stride(0), 1
-        d.bn1 = hip.BnRef.of(pblk.tcn["3"], ops.BnState(ar, pkey + ".bn3", pc).all, prec3, nrt, 64)
+        d.bn1 = hip.BnRef.of(pblk.tcn["3"], ops.BnState(ar, pkey + ".bn3", pc).all, prec3, pn3, pr3)
         d.bn2 = hip.BnRef.of(pblk.residual["1"], ops.BnState(ar, pkey + ".bnr", pc).all, precR, nrf, 4 * V)
         d.xact = hip.ptr(ar.get(pkey + ".out", (rows, pc)))
         d.W, d.bias, d.cin, d.nout = hip.ptr(wfr["fcn"]), hip.ptr(gcn.fcn.bias), pc, 64
@@ -752,11 +757,14 @@ class LowerNet(_NetBase):
             wws = ar.get("slab." + key + ".tw", (nsp * blk.taps * cout * cout,))
             hip.call("tconv_wgrad", dtz, cout, y0, cout, wws, G(blk.tcn["2"].weight), 2, B, T, V, cout, cout, blk.taps)
             slabs.add(wws, G(blk.tcn["2"].weight), 1, nsp, blk.taps * cout, cout, taps=blk.taps)
-            bwrec = ar.get(key + ".bwrec", (nrt, cout, 2))
-            hip.call("tconv_bwd_stats", dtz, cout, wp[1], dy0, cout, ymix, cout, st0.all, bwrec, B, T, V, cout, cout, blk.taps)
+            sq = getattr(self, "_tconv_seq", [False] * 3)[i]
+            nbw = B if sq else nrt
+            bwrec = ar.get(key + ".bwrec", (nbw, cout, 2))
+            hip.call("tconv_seq_bwd" if sq else "tconv_bwd_stats", dtz, cout, wp[1], dy0, cout, ymix, cout, st0.all, bwrec, B, T, V, cout, cout,
+                     blk.taps)
             nda = hip.lib().mmego_graph_dA_fused_nblk(F)
             dAp = ar.get("slab." + key + ".dAp", (nda, K * V * V))
-            hip.call("graph_dA_fused", z, z.stride(0), dy0, ymix, st0.all, bwrec, nrt, G(blk.tcn["0"].weight), G(blk.tcn["0"].bias),
+            hip.call("graph_dA_fused", z, z.stride(0), dy0, ymix, st0.all, bwrec, nbw, G(blk.tcn["0"].weight), G(blk.tcn["0"].bias),
                      F, V, K, cout, dAp, gcn.A, gcn.edge_importance[i], dz, dz.stride(0))
             slabs.add(dAp, G(gcn.edge_importance[i]), 2, nda, 1, K * V * V, scale=gcn.A)
             dinp = ar.get(key + ".dinp", (rows, cin))
