@@ -333,6 +333,11 @@ int mmego_anchor_group_backward(void* stream, const float* dgrouped, const long 
 int mmego_local_group_l1(void* stream, const float* feats, long ldf, long F, int N, int D, const float* anchors, long long* idx,
                          float* grouped, const float* W1, const float* b1, int C1, float* Z1, long ldz1, double* part1, int nwg,
                          float* dist_out);
+/* The eval-mode branch up to the pooled vectors in ONE launch: grouping, LocalPointNet's three conv + BatchNorm (running statistics,
+ * folded) + ReLU stages, attention score, softmax over the 8 members, weighted sum; tab = HOST array of 20 device pointers: per layer
+ * {W, b, gamma, beta, running_mean, running_var}, then the attention weight and bias.  Writes idx, attn [F*216], voxT [F][64][27]. */
+int mmego_local_front_eval(void* stream, const float* feats, long ldf, long F, int N, int D, const float* anchors, long long* idx,
+                           const float* const* tab, double eps, float* voxT, float* attn);
 int mmego_pool8_nblk(long rows);
 int mmego_pool8_bn_act(void* stream, const float* Z, long ldz, long rows, const double* part, const float* gamma, const float* beta,
                        double eps, float* rmean, float* rvar, double momentum, float* state, const float* aw_w, const float* aw_b,

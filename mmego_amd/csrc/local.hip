@@ -62,6 +62,81 @@ struct LocalGroupP {
   long F;
 };
 
+// One frame: rows -> LDS, the 27 x N squared distances, the 8 nearest points per anchor (sidx), the int64 indices stored, and the
+// gathered rows cat(anchor, xyz - anchor, features) built in the LDS tile gs [224][LG_GS] (zero padded).  Ends with a barrier.
+template <int NKEY>
+__device__ __forceinline__ void lg_group_frame(const float* __restrict__ feats, long ldf, int N, int D, long f, float* fs, float* dist,
+                                               float* gs, const float* an, int* sidx, long long* __restrict__ idxo,
+                                               float* __restrict__ dist_out) {
+  const int W = 6 + D, FS = 3 + D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- the frame's rows -> LDS (every load in flight before the first LDS store)
+  {
+    const float* src = feats + f * (long)N * ldf;
+    const int total = N * FS;
+    for (int i0 = 0; i0 < total; i0 += LG_NT * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + tid + LG_NT * u < total ? i0 + tid + LG_NT * u : total - 1;
+        v[u] = src[(long)(i / FS) * ldf + i % FS];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + tid + LG_NT * u;
+        if (i < total) fs[i] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- squared distances, the reference's rounding: dot = fma(az, z, fma(ay, y, ax x)); d = (-2 dot + |a|^2) + |p|^2; +inf for xyz == 0
+  for (int i = tid; i < NA * N; i += LG_NT) {
+    const int a = i / N, q = i - a * N;
+    const float x = fs[q * FS], y = fs[q * FS + 1], z = fs[q * FS + 2];
+    const float dot = __fmaf_rn(an[a * 4 + 2], z, __fmaf_rn(an[a * 4 + 1], y, __fmul_rn(an[a * 4], x)));
+    float d = __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), an[a * 4 + 3]), sq3_nofma(x, y, z));
+    if (x == 0.f && y == 0.f && z == 0.f) d = INFINITY;
+    dist[i] = d;
+    if (dist_out) dist_out[f * (long)NA * N + i] = d;
+  }
+  __syncthreads();
+  // ---- the 8 nearest points of each anchor (ascending, ties: lowest index first): a wave per anchor
+  for (int a = wave; a < NA; a += LG_NT / 64) {
+    unsigned u[NKEY];
+#pragma unroll
+    for (int j = 0; j < NKEY; ++j) u[j] = key_code(dist[a * N + j * 64 + lane]);
+    for (int rnd = 0; rnd < NS; ++rnd) {
+      unsigned m = u[0];
+#pragma unroll
+      for (int j = 1; j < NKEY; ++j) m = u[j] < m ? u[j] : m;
+      const unsigned wm = wave_min_u32(m);
+      int sel = -1;
+#pragma unroll
+      for (int j = 0; j < NKEY; ++j) {
+        const unsigned long long b = __ballot(u[j] == wm);
+        if (sel < 0 && b) sel = j * 64 + (int)__ffsll((long long)b) - 1;
+      }
+#pragma unroll
+      for (int j = 0; j < NKEY; ++j)
+        if (sel == j * 64 + lane) u[j] = 0xffffffffu;
+      if (lane == 0) sidx[a * NS + rnd] = sel;
+    }
+  }
+  __syncthreads();
+  if (tid < NSLOT) idxo[f * NSLOT + tid] = (long long)sidx[tid];
+  // ---- gathered rows cat(anchor, xyz - anchor, features) -> LDS tile (columns >= 6 + D and rows >= 216: zero)
+  for (int i = tid; i < 224 * 32; i += LG_NT) {
+    const int row = i >> 5, col = i & 31;
+    float v = 0.f;
+    if (row < NSLOT && col < W) {
+      const int a = row >> 3, q = sidx[row];
+      v = col < 3 ? an[a * 4 + col] : (col < 6 ? fs[q * FS + col - 3] - an[a * 4 + col - 3] : fs[q * FS + col - 3]);
+    }
+    gs[row * LG_GS + col] = v;
+  }
+  __syncthreads();
+}
+
 // NKEY = N / 64 keys per lane
 template <int NKEY>
 __global__ __launch_bounds__(LG_NT) void local_group_l1_kernel(LocalGroupP p) {
@@ -92,71 +167,7 @@ __global__ __launch_bounds__(LG_NT) void local_group_l1_kernel(LocalGroupP p) {
   double s1 = 0.0, s2 = 0.0;                             // this lane's column sums of z1 over the workgroup's frames
   for (long f = blockIdx.x; f < p.F; f += gridDim.x) {
     __syncthreads();
-    // ---- the frame's rows -> LDS (every load in flight before the first LDS store)
-    {
-      const float* src = p.feats + f * (long)N * p.ldf;
-      const int total = N * FS;
-      for (int i0 = 0; i0 < total; i0 += LG_NT * 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + tid + LG_NT * u < total ? i0 + tid + LG_NT * u : total - 1;
-          v[u] = src[(long)(i / FS) * p.ldf + i % FS];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + tid + LG_NT * u;
-          if (i < total) fs[i] = v[u];
-        }
-      }
-    }
-    __syncthreads();
-    // ---- squared distances, the reference's rounding: dot = fma(az, z, fma(ay, y, ax x)); d = (-2 dot + |a|^2) + |p|^2; +inf for xyz == 0
-    for (int i = tid; i < NA * N; i += LG_NT) {
-      const int a = i / N, q = i - a * N;
-      const float x = fs[q * FS], y = fs[q * FS + 1], z = fs[q * FS + 2];
-      const float dot = __fmaf_rn(an[a * 4 + 2], z, __fmaf_rn(an[a * 4 + 1], y, __fmul_rn(an[a * 4], x)));
-      float d = __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), an[a * 4 + 3]), sq3_nofma(x, y, z));
-      if (x == 0.f && y == 0.f && z == 0.f) d = INFINITY;
-      dist[i] = d;
-      if (p.dist_out) p.dist_out[f * (long)NA * N + i] = d;
-    }
-    __syncthreads();
-    // ---- the 8 nearest points of each anchor (ascending, ties: lowest index first): a wave per anchor
-    for (int a = wave; a < NA; a += LG_NT / 64) {
-      unsigned u[NKEY];
-#pragma unroll
-      for (int j = 0; j < NKEY; ++j) u[j] = key_code(dist[a * N + j * 64 + lane]);
-      for (int rnd = 0; rnd < NS; ++rnd) {
-        unsigned m = u[0];
-#pragma unroll
-        for (int j = 1; j < NKEY; ++j) m = u[j] < m ? u[j] : m;
-        const unsigned wm = wave_min_u32(m);
-        int sel = -1;
-#pragma unroll
-        for (int j = 0; j < NKEY; ++j) {
-          const unsigned long long b = __ballot(u[j] == wm);
-          if (sel < 0 && b) sel = j * 64 + (int)__ffsll((long long)b) - 1;
-        }
-#pragma unroll
-        for (int j = 0; j < NKEY; ++j)
-          if (sel == j * 64 + lane) u[j] = 0xffffffffu;
-        if (lane == 0) sidx[a * NS + rnd] = sel;
-      }
-    }
-    __syncthreads();
-    if (tid < NSLOT) p.idx[f * NSLOT + tid] = (long long)sidx[tid];
-    // ---- gathered rows cat(anchor, xyz - anchor, features) -> LDS tile (columns >= 6 + D and rows >= 216: zero)
-    for (int i = tid; i < 224 * 32; i += LG_NT) {
-      const int row = i >> 5, col = i & 31;
-      float v = 0.f;
-      if (row < NSLOT && col < W) {
-        const int a = row >> 3, q = sidx[row];
-        v = col < 3 ? an[a * 4 + col] : (col < 6 ? fs[q * FS + col - 3] - an[a * 4 + col - 3] : fs[q * FS + col - 3]);
-      }
-      gs[row * LG_GS + col] = v;
-    }
-    __syncthreads();
+    lg_group_frame<NKEY>(p.feats, p.ldf, N, D, f, fs, dist, gs, an, sidx, p.idx, p.dist_out);
     if (p.grouped) {
       float* g = p.grouped + f * (long)NSLOT * W;
       for (int i = tid; i < NSLOT * W; i += LG_NT) g[i] = gs[(i / W) * LG_GS + i % W];
@@ -342,6 +353,166 @@ __global__ __launch_bounds__(P8_NT) void pool8_bn_act_kernel(Pool8P p) {
       if (gi * 8 < rend) {
         const long f = gi / NA;
         p.voxT[(f * 64 + lane) * NA + (gi - f * NA)] = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Eval-mode anchor branch up to the pooled vectors in ONE launch (the frozen / --infer path): grouping as above, then LocalPointNet's
+// three k=1 conv + BatchNorm (running statistics, folded into the weights while they are staged) + ReLU stages on MFMAs with the
+// intermediates in LDS, the attention score, the softmax over each group's 8 members and the weighted sum -- the gathered rows
+// (26.8 kB per frame), the per-member 32 / 48 / 64-channel activations and the pooling input never reach HBM.
+// Outputs: idx [F][27][8], attn [F*216], voxT [F][64][27].  C1 = 32, C2 = 48, C3 = 64 (LocalPointNet), 6 + D <= 32.
+struct LocalEvalP {
+  const float* feats; long ldf; int N, D; const float* anchors; long long* idx;
+  const float* W[3]; const float* b[3]; const float* gamma[3]; const float* beta[3]; const float* rmean[3]; const float* rvar[3];
+  float eps;
+  const float* aw_w; const float* aw_b;
+  float* voxT; float* attn; long F;
+};
+#define LE_TS 68                 // row stride of the activation tile (64 columns)
+
+// acc[32x32] = A[32 rows][K] . B[32 rows][K]^T, K a multiple of 32; lane (r, h) takes k = 32 c + 16 h + 4 j + e on both operands
+__device__ __forceinline__ f32x16 le_tile(const float* A, int SA, const float* B, int SB, int K, int r, int h) {
+  f32x16 acc = {0};
+  for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + r * SA + k0 + 16 * h + 4 * j);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(B + r * SB + k0 + 16 * h + 4 * j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+template <int NKEY>
+__global__ __launch_bounds__(LG_NT) void local_front_eval_kernel(LocalEvalP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = p.N, D = p.D, W = 6 + D, FS = 3 + D;
+  // the activation tile t2 [224][LE_TS] shares its LDS with the frame rows and the distance matrix (dead once the rows are gathered)
+  float* t2 = sm;
+  float* fs = sm;
+  float* dist = fs + ((N * FS + 3) & ~3);
+  const int region = 224 * LE_TS > ((N * FS + 3) & ~3) + NA * N ? 224 * LE_TS : ((N * FS + 3) & ~3) + NA * N;
+  float* gs = sm + region;                               // [224][LG_GS]
+  float* w1 = gs + 224 * LG_GS;                          // [32][36]
+  float* w2 = w1 + 32 * LG_GS;                           // [64][36]  (48 rows used)
+  float* w3 = w2 + 64 * LG_GS;                           // [64][68]  (48 columns used)
+  float* bsv = w3 + 64 * LE_TS;                          // [3][64] folded biases, then [64] attention weight, [1] bias
+  float* an = bsv + 4 * 64 + 4;
+  int* sidx = reinterpret_cast<int*>(an + NA * 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  if (tid < NA) {
+    const float ax = p.anchors[tid * 3], ay = p.anchors[tid * 3 + 1], az = p.anchors[tid * 3 + 2];
+    an[tid * 4] = ax; an[tid * 4 + 1] = ay; an[tid * 4 + 2] = az; an[tid * 4 + 3] = sq3_nofma(ax, ay, az);
+  }
+  {  // weights with the BatchNorm folded: W' = s W, b' = (b - mean) s + beta, s = gamma / sqrt(var + eps)
+    const int C[4] = {W, 32, 48, 64};
+    float* wd[3] = {w1, w2, w3};
+    const int SW[3] = {LG_GS, LG_GS, LE_TS}, KP[3] = {32, 32, 64}, NP[3] = {32, 64, 64};
+    if (tid < 64) {
+#pragma unroll
+      for (int l = 0; l < 3; ++l) {
+        const int n = tid < C[l + 1] ? tid : C[l + 1] - 1;
+        const float sc = p.gamma[l][n] / sqrtf(p.rvar[l][n] + p.eps);
+        bsv[l * 64 + tid] = tid < C[l + 1] ? (p.b[l][n] - p.rmean[l][n]) * sc + p.beta[l][n] : 0.f;
+      }
+      bsv[3 * 64 + tid] = p.aw_w[tid];
+      if (tid == 0) bsv[4 * 64] = p.aw_b[0];
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      for (int i = tid; i < NP[l] * KP[l]; i += LG_NT) {
+        const int n = i / KP[l], k = i - n * KP[l];
+        const int nc = n < C[l + 1] ? n : C[l + 1] - 1, kc = k < C[l] ? k : C[l] - 1;
+        const float sc = p.gamma[l][nc] / sqrtf(p.rvar[l][nc] + p.eps);
+        const float w = p.W[l][nc * C[l] + kc];
+        wd[l][n * SW[l] + k] = (n < C[l + 1] && k < C[l]) ? sc * w : 0.f;
+      }
+    }
+  }
+  for (long f = blockIdx.x; f < p.F; f += gridDim.x) {
+    __syncthreads();
+    lg_group_frame<NKEY>(p.feats, p.ldf, N, D, f, fs, dist, gs, an, sidx, p.idx, nullptr);
+    // ---- stage 1: gathered [224][32] -> t2 columns 0..31 (K = 32)
+    for (int t = wave; t < 7; t += 4) {
+      const f32x16 acc = le_tile(gs + t * 32 * LG_GS, LG_GS, w1, LG_GS, 32, r, h);
+      const float bb = bsv[r];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) t2[(t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * LE_TS + r] = fmaxf(acc[reg] + bb, 0.f);
+    }
+    __syncthreads();
+    // ---- stage 2: t2[:, 0:32] -> gs-free: 48 columns written to t2 columns 0..47 AFTER every wave has read its A rows: the 14 tiles
+    // (7 row x 2 column) are computed first, a barrier, then stored
+    {
+      f32x16 acc2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tl = wave + 4 * i;                       // tile = (row tile tl >> 1, column tile tl & 1)
+        if (tl < 14) acc2[i] = le_tile(t2 + (tl >> 1) * 32 * LE_TS, LE_TS, w2 + (tl & 1) * 32 * LG_GS, LG_GS, 32, r, h);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tl = wave + 4 * i;
+        if (tl < 14) {
+          const int col = (tl & 1) * 32 + r;
+          const float bb = bsv[64 + col];
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            t2[((tl >> 1) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * LE_TS + col] = col < 48 ? fmaxf(acc2[i][reg] + bb, 0.f) : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- stage 3: t2[:, 0:64] (columns 48..63 zero) -> 64 columns, same two-phase form
+    {
+      f32x16 acc3[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tl = wave + 4 * i;
+        if (tl < 14) acc3[i] = le_tile(t2 + (tl >> 1) * 32 * LE_TS, LE_TS, w3 + (tl & 1) * 32 * LE_TS, LE_TS, 64, r, h);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tl = wave + 4 * i;
+        if (tl < 14) {
+          const int col = (tl & 1) * 32 + r;
+          const float bb = bsv[128 + col];
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            t2[((tl >> 1) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * LE_TS + col] = fmaxf(acc3[i][reg] + bb, 0.f);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- pooling: a wave per 64-row block (8 groups): lane = row: score; softmax over the group's 8 lanes; lane = channel: weighted sum
+    {
+      const int r0 = wave * 64, row = r0 + lane;
+      float sc = bsv[4 * 64];
+#pragma unroll
+      for (int c = 0; c < 64; c += 4) {
+        const f32x4 y4 = *reinterpret_cast<const f32x4*>(t2 + row * LE_TS + c);
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(bsv + 3 * 64 + c);
+        sc = __builtin_fmaf(y4.x, w4.x, sc); sc = __builtin_fmaf(y4.y, w4.y, sc); sc = __builtin_fmaf(y4.z, w4.z, sc); sc = __builtin_fmaf(y4.w, w4.w, sc);
+      }
+      const float mx = grp8_max(sc);
+      const float ex = expf(sc - mx);
+      const float at = ex / grp8_sum(ex);
+      if (row < NSLOT) p.attn[f * NSLOT + row] = at;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int a = (r0 >> 3) + g;                       // anchor
+        if (a < NA) {                                      // (uniform)
+          float o = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o = __builtin_fmaf(lane_of(at, g * 8 + j), t2[(a * 8 + j) * LE_TS + lane], o);
+          p.voxT[(f * 64 + lane) * NA + a] = o;
+        }
       }
     }
   }
@@ -541,6 +712,46 @@ extern "C" int mmego_local_group_l1(void* stream, const float* feats, long ldf, 
   else if (N == 128) LG_LAUNCH(2);
   else LG_LAUNCH(4);
 #undef LG_LAUNCH
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_local_front_eval(void* stream, const float* feats, long ldf, long F, int N, int D, const float* anchors,
+                                      long long* idx, const float* const* tab, double eps, float* voxT, float* attn) {
+  // tab: HOST array of 20 device pointers: per layer l = 0..2 {W, b, gamma, beta, running_mean, running_var} (18), then the attention
+  // weight [64] and bias [1]
+  MMEGO_REQUIRE(feats && anchors && idx && tab && voxT && attn && F > 0 && D >= 0 && 6 + D <= 32 && ldf >= 3 + D);
+  MMEGO_REQUIRE(N == 64 || N == 128 || N == 256);
+  for (int i = 0; i < 20; ++i) MMEGO_REQUIRE(tab[i] != nullptr);
+  LocalEvalP p;
+  p.feats = feats; p.ldf = ldf; p.N = N; p.D = D; p.anchors = anchors; p.idx = idx;
+  for (int l = 0; l < 3; ++l) {
+    p.W[l] = tab[6 * l]; p.b[l] = tab[6 * l + 1]; p.gamma[l] = tab[6 * l + 2]; p.beta[l] = tab[6 * l + 3];
+    p.rmean[l] = tab[6 * l + 4]; p.rvar[l] = tab[6 * l + 5];
+  }
+  p.eps = (float)eps; p.aw_w = tab[18]; p.aw_b = tab[19]; p.voxT = voxT; p.attn = attn; p.F = F;
+  const int FS = 3 + D;
+  const size_t head = (size_t)((N * FS + 3) & ~3) + (size_t)NA * N;
+  const size_t region = head > (size_t)224 * LE_TS ? head : (size_t)224 * LE_TS;
+  const size_t fl = region + 224 * LG_GS + 32 * LG_GS + 64 * LG_GS + 64 * LE_TS + 4 * 64 + 4 + NA * 4 + NSLOT;
+  const size_t lds = fl * sizeof(float);
+  MMEGO_REQUIRE(lds <= 160 * 1024);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(F < 512 ? F : 512));
+#define LE_LAUNCH(NK_)                                                                                                  \
+  do {                                                                                                                  \
+    static size_t attr = 0;                                                                                             \
+    if (lds > 64 * 1024 && lds > attr) {                                                                                \
+      hipError_t e = hipFuncSetAttribute((const void*)local_front_eval_kernel<NK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                                               \
+      attr = lds;                                                                                                       \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((local_front_eval_kernel<NK_>), grid, dim3(LG_NT), lds, st, p);                                  \
+  } while (0)
+  if (N == 64) LE_LAUNCH(1);
+  else if (N == 128) LE_LAUNCH(2);
+  else LE_LAUNCH(4);
+#undef LE_LAUNCH
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

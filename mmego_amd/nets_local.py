@@ -87,6 +87,17 @@ class UpperNetwlocal(_NetBase):
         dims = [tuple(c.weight.shape[:2]) for c in (lp.conv1, lp.conv2, lp.conv3)]
         return bool(_LOCAL_FUSED and N in (64, 128, 256) and dims == [(32, 31), (48, 32), (64, 48)] and lp.attn.weight.shape == (1, 64))
 
+    def _local_table(self):
+        """Host-side pointer table of mmego_local_front_eval (20 device pointers), rebuilt when a tensor moved."""
+        lp = self.module2.apointnet
+        ts = [v for conv, bn in ((lp.conv1, lp.cb1), (lp.conv2, lp.cb2), (lp.conv3, lp.cb3))
+              for v in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)] + [lp.attn.weight, lp.attn.bias]
+        ptrs = tuple(v.data_ptr() for v in ts)
+        ent = self.__dict__.get("_local_tab")
+        if ent is None or ent[0] != ptrs:
+            ent = self.__dict__["_local_tab"] = (ptrs, torch.tensor(ptrs, dtype=torch.int64))
+        return ent[1]
+
     def local_branch_bytes(self, F, N):
         """HBM bytes per frame the anchor branch's activations move between launches in one training step (written once + read
         once per consumer; parameters and the shared per-point features excluded): the fused path against the launch chain."""
@@ -168,9 +179,13 @@ class UpperNetwlocal(_NetBase):
                      lp.cb2.running_var, float(lp.cb2.momentum), st2.all, lp.conv3.weight, lp.conv3.bias, 64, z3, 64, part3)
             hip.call("pool8_bn_act", z3, 64, grows, part3, lp.cb3.weight, lp.cb3.bias, float(lp.cb3.eps), lp.cb3.running_mean,
                      lp.cb3.running_var, float(lp.cb3.momentum), st3.all, lp.attn.weight, lp.attn.bias, voxT, aw)
+        elif fused and not training and len({float(bn.eps) for bn in (lp.cb1, lp.cb2, lp.cb3)}) == 1:
+            # eval: grouping, the three conv + BatchNorm(running statistics, folded) + ReLU stages and the pooling in ONE launch; neither
+            # the gathered rows nor any per-member activation reaches HBM
+            hip.call("local_front_eval", feats, 28, F, N, 25, self.anchors(dev), gidx, self._local_table(), float(lp.cb1.eps), voxT, aw)
         else:
             grouped = ar.get("grouped", (grows, 31))
-            if fused:           # (eval: the wave-parallel grouping alone, then the eval-mode PointNet kernel)
+            if fused:           # (training-mode forward without a backward pass: the wave-parallel grouping alone)
                 hip.call("local_group_l1", feats, 28, F, N, 25, self.anchors(dev), gidx, grouped, None, None, 0, None, 0, None, _LOCAL_NWG, None)
             else:
                 hip.call("anchor_group", feats, 28, F, N, 25, self.anchors(dev), gidx, grouped, None)

@@ -160,6 +160,49 @@ def test_pool8_kernels_against_torch(dev):
     assert float(awp[:, 65:].abs().max()) == 0.0
 
 
+def test_upper_wlocal_eval_forward_fused_against_oracle_and_chain(dev):
+    """Eval-mode UpperNetwlocal with the anchor branch as ONE launch (mmego_local_front_eval: grouping + folded conv/BatchNorm/ReLU x3
+    + 8-way softmax pooling) against the CPU oracle (all eight outputs) and against the launch chain (MMEGO_LOCAL_FUSED=0): group
+    indices bit-identical, everything else at the eval-forward bar."""
+    from mmego_amd import nets_local
+    g = torch.Generator().manual_seed(21)
+    Bq, Tq, N = 3, 5, 128
+    x = torch.randn(Bq, Tq, N, 6, generator=g) * 0.4
+    x[:, :, 100:] = 0.0
+    x[1, 2, 4:] = 0.0                                         # a frame with 4 valid points
+    body = 0.2 * torch.randn(Bq, 20, 3, generator=g)
+    R = torch.linalg.qr(torch.randn(Bq, Tq, 3, 3, generator=g))[0].contiguous()
+    t = torch.randn(Bq, Tq, 3, generator=g) * 0.1
+    h0, c0 = ot.zeros_state(Bq)
+    torch.manual_seed(31)
+    o = on.UpperNetwlocal()
+    for m in o.modules():                                     # non-trivial running statistics
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
+            m.running_mean.normal_(0.0, 0.2, generator=g)
+            m.running_var.uniform_(0.5, 1.5, generator=g)
+    o.eval()
+    hnet = nets_local.UpperNetwlocal()
+    hnet.load_state_dict(o.state_dict())
+    hnet = hnet.to(dev).eval()
+    d = lambda v: v.to(dev)
+    with torch.no_grad():
+        want = o(x.clone(), h0, c0, h0, c0, body, R, t)
+        outs = {}
+        for fused in (True, False):
+            was = nets_local._LOCAL_FUSED
+            nets_local._LOCAL_FUSED = fused
+            try:
+                outs[fused] = [v.cpu() for v in hnet(d(x.clone()), d(h0), d(c0), d(h0), d(c0), d(body), d(R), d(t))]
+                idx = hnet.last_group_idx.cpu().clone()
+            finally:
+                nets_local._LOCAL_FUSED = was
+            outs[(fused, "idx")] = idx
+    assert torch.equal(outs[(True, "idx")], outs[(False, "idx")])
+    for k, (a, b, w) in enumerate(zip(outs[True], outs[False], want)):
+        assert (a - b).abs().max().item() < 2e-5, ("fused vs chain, output", k)
+        assert (a - w.view_as(a)).abs().max().item() < 5e-5, ("fused vs oracle, output", k)
+
+
 def test_train_upper_wlocal(dev):
     from mmego_amd.nets_local import UpperNetwlocal
     g = golden("g6_train.npz")
