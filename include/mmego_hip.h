@@ -430,6 +430,13 @@ int mmego_mlp_bwd_layer(void* stream, const float* dY, long lddy, const float* Z
                         const float* state, const double* g_part, float* dgamma, float* dbeta, const float* Xin, long ldxin,
                         int Cin, const float* in_state, const float* W, float* dX, long lddx, double* gprev_part,
                         float* dW_part);
+/* mmego_mlp_bwd_layer for the first stage of LocalPointNet with its input rows GATHERED on the fly through the group indices (row r =
+ * cat(anchors[(r % 216) / 8], xyz - anchor, features) of point gidx[r] of frame r / 216; feats [F*N][ldf] = xyz | D features): the
+ * gathered tensor of mmego_local_group_l1 need not be kept for the layer's weight gradient. */
+int mmego_mlp_bwd_layer_gather(void* stream, const float* dY, long lddy, const float* Z, long ldz, long rows, int Cout,
+                               const float* state, const double* g_part, float* dgamma, float* dbeta, const long long* gidx,
+                               const float* feats, long ldf, const float* anchors, int N, int D, const float* W, float* dX,
+                               long lddx, float* dW_part);
 int mmego_mlp_dw_reduce(void* stream, long rows, int nlayers, const float* part0, float* dW0, int Cout0, int Cin0,
                         const float* part1, float* dW1, int Cout1, int Cin1, const float* part2, float* dW2, int Cout2, int Cin2);
 

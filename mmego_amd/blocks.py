@@ -81,11 +81,12 @@ def _mlp3_forward_fused(ar, key, mod, x, out_last):
     return out_last
 
 
-def _mlp3_backward_fused(ar, key, mod, x, dy3, G, need_dx, have_sums=False):
+def _mlp3_backward_fused(ar, key, mod, x, dy3, G, need_dx, have_sums=False, gather=None):
     """Backward of the three stages as 1 + 3 + 1 launches: per stage ONE pass computes dz, dX (the next stage's dy), the
     per-workgroup dW partial and the BatchNorm sums of the stage below; a last launch sums the dW partials of all three.
-    have_sums: the producer of dy3 has left the last stage's (sum g, sum g xhat) partials in "<key>.gp3" already (mmego_pool8_backward)."""
-    rows = x.shape[0]
+    have_sums: the producer of dy3 has left the last stage's (sum g, sum g xhat) partials in "<key>.gp3" already (mmego_pool8_backward).
+    gather = (rows, gidx, feats, ldf, anchors, N, D): the first stage's input is not in memory (x is None) but gathered on the fly."""
+    rows = x.shape[0] if gather is None else gather[0]
     nblk = hip.lib().mmego_mlp_train_nblk(rows)
     layers = _mlp3_layers(mod)
     dims = [layers[0][0].weight.numel() // layers[0][0].weight.shape[0]] + [c.weight.shape[0] for c, _ in layers]
@@ -101,9 +102,14 @@ def _mlp3_backward_fused(ar, key, mod, x, dy3, G, need_dx, have_sums=False):
         xin = zs[i - 1] if i > 1 else x
         want_dx = i > 1 or need_dx
         dprev = ar.get("%s.dy%d" % (key, i - 1), (rows, dims[i - 1])) if want_dx else None
-        hip.call("mlp_bwd_layer", dy, dy.stride(0), zs[i], zs[i].stride(0), rows, dims[i], sts[i].all, gp[i], G(bn.weight), G(bn.bias),
-                 xin, xin.stride(0), dims[i - 1], sts[i - 1].all if i > 1 else None, conv.weight, dprev,
-                 dprev.stride(0) if want_dx else 0, gp[i - 1] if i > 1 else None, dwp[i])
+        if i == 1 and gather is not None:
+            _, gidx, feats, ldf, anchors, Npts, D = gather
+            hip.call("mlp_bwd_layer_gather", dy, dy.stride(0), zs[i], zs[i].stride(0), rows, dims[i], sts[i].all, gp[i], G(bn.weight), G(bn.bias),
+                     gidx, feats, ldf, anchors, Npts, D, conv.weight, dprev, dprev.stride(0) if want_dx else 0, dwp[i])
+        else:
+            hip.call("mlp_bwd_layer", dy, dy.stride(0), zs[i], zs[i].stride(0), rows, dims[i], sts[i].all, gp[i], G(bn.weight), G(bn.bias),
+                     xin, xin.stride(0), dims[i - 1], sts[i - 1].all if i > 1 else None, conv.weight, dprev,
+                     dprev.stride(0) if want_dx else 0, gp[i - 1] if i > 1 else None, dwp[i])
         dy = dprev
     hip.call("mlp_dw_reduce", rows, 3, dwp[1], G(layers[0][0].weight), dims[1], dims[0], dwp[2], G(layers[1][0].weight), dims[2],
              dims[1], dwp[3], G(layers[2][0].weight), dims[3], dims[2])

@@ -299,10 +299,14 @@ struct MlpBwdP {
   double* gprev_part;                 // partials of the layer below (needs dX and in_state)
   float* dW_part;                     // [gridDim.x][64 * 64]
   long rows_per_wg;
+  // gather form of Xin (LocalPointNet's first layer, Upper_Net.py:100-119): row (f, slot) = cat(anchor, xyz - anchor, features) of point
+  // gidx[row] of frame f, read from the per-point feature rows -- the gathered tensor is not kept in memory
+  const long long* gidx; const float* gfeats; long gldf; const float* ganch; int gN;
 };
 
 // 512 threads = 2 groups of 4 waves, each group one 64-row tile of a 128-row round (three tiles of LDS per group)
 #define MTB_NG 2
+template <bool GATHER>
 __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = t >> 6;
@@ -317,6 +321,24 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
   const int xk = t & 63, xr = t >> 6;
   float gy[16], gz[16], gx[16];
 #define MTB_FETCH(r0_)                                                                              \
+  if (GATHER) {                                        /* the layer input gathered through the group indices */ \
+    long long gq_[16];                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                \
+      const long rr_ = (r0_) + xr + 4 * j;                                                          \
+      const long rc_ = rr_ < rend ? rr_ : rend - 1;                                                 \
+      gq_[j] = p.gidx[rc_];                                                                         \
+      gy[j] = p.dY[rc_ * p.lddy + xko]; gz[j] = p.Z[rc_ * p.ldz + xko];                             \
+    }                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                \
+      const long rr_ = (r0_) + xr + 4 * j;                                                          \
+      const long rc_ = rr_ < rend ? rr_ : rend - 1;                                                 \
+      const long fr_ = rc_ / 216;                                                                   \
+      const int an_ = (int)(rc_ - fr_ * 216) >> 3;                                                  \
+      const float pv_ = p.gfeats[(fr_ * p.gN + gq_[j]) * p.gldf + (xki >= 3 ? xki - 3 : 0)];        \
+      const float av_ = p.ganch[an_ * 3 + (xki < 3 ? xki : (xki < 6 ? xki - 3 : 0))];               \
+      gx[j] = xki < 3 ? av_ : (xki < 6 ? pv_ - av_ : pv_);                                          \
+    }                                                                                               \
+  } else                                                                                            \
   _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
     const long rr_ = (r0_) + xr + 4 * j;                                                            \
     const long rc_ = rr_ < rend ? rr_ : rend - 1;      /* clamped row / columns: unconditional loads (see MTF_FETCH) */ \
@@ -563,6 +585,24 @@ extern "C" int mmego_mlp_bn_bwd_reduce(void* stream, const float* dY, long lddy,
   return MMEGO_OK;
 }
 
+static int mlp_bwd_layer_launch(hipStream_t st, MlpBwdP& p) {
+  int nblk;
+  mt_grid(p.rows, &nblk, &p.rows_per_wg);
+  p.g_nblk = nblk;
+  const size_t lds = (size_t)((MTB_NG * 3 + 1) * 64 * MT_S + 10 * 64) * sizeof(float) + sizeof(double) * 8 * 2 * 64;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_bwd_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  if (p.gidx) hipLaunchKernelGGL(mlp_bwd_layer_kernel<true>, dim3(nblk), dim3(512), lds, st, p);
+  else hipLaunchKernelGGL(mlp_bwd_layer_kernel<false>, dim3(nblk), dim3(512), lds, st, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
 extern "C" int mmego_mlp_bwd_layer(void* stream, const float* dY, long lddy, const float* Z, long ldz, long rows, int Cout,
                                    const float* state, const double* g_part, float* dgamma, float* dbeta, const float* Xin,
                                    long ldxin, int Cin, const float* in_state, const float* W, float* dX, long lddx,
@@ -572,22 +612,31 @@ extern "C" int mmego_mlp_bwd_layer(void* stream, const float* dY, long lddy, con
   MMEGO_REQUIRE(!dX || lddx >= Cin);
   MMEGO_REQUIRE(!gprev_part || (dX && in_state));
   MlpBwdP p;
-  int nblk;
-  mt_grid(rows, &nblk, &p.rows_per_wg);
   p.dY = dY; p.lddy = lddy; p.Z = Z; p.ldz = ldz; p.rows = rows; p.Cout = Cout; p.state = state;
-  p.g_part = g_part; p.g_nblk = nblk; p.dgamma = dgamma; p.dbeta = dbeta;
+  p.g_part = g_part; p.dgamma = dgamma; p.dbeta = dbeta;
   p.Xin = Xin; p.ldxin = ldxin; p.Cin = Cin; p.in_state = in_state; p.W = W; p.dX = dX; p.lddx = lddx;
   p.gprev_part = gprev_part; p.dW_part = dW_part;
-  const size_t lds = (size_t)((MTB_NG * 3 + 1) * 64 * MT_S + 10 * 64) * sizeof(float) + sizeof(double) * 8 * 2 * 64;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  hipLaunchKernelGGL(mlp_bwd_layer_kernel, dim3(nblk), dim3(512), lds, (hipStream_t)stream, p);
-  MMEGO_LAUNCH_CHECK();
-  return MMEGO_OK;
+  p.gidx = nullptr; p.gfeats = nullptr; p.gldf = 0; p.ganch = nullptr; p.gN = 0;
+  return mlp_bwd_layer_launch((hipStream_t)stream, p);
+}
+
+// mmego_mlp_bwd_layer for the FIRST stage of LocalPointNet with its input gathered on the fly: row r = (frame r / 216, slot r % 216) is
+// cat(anchors[slot / 8], xyz - anchor, features) of point gidx[r] of that frame, feats [F*N][ldf] = (xyz | D features); Cin = 6 + D.
+extern "C" int mmego_mlp_bwd_layer_gather(void* stream, const float* dY, long lddy, const float* Z, long ldz, long rows, int Cout,
+                                          const float* state, const double* g_part, float* dgamma, float* dbeta,
+                                          const long long* gidx, const float* feats, long ldf, const float* anchors, int N, int D,
+                                          const float* W, float* dX, long lddx, float* dW_part) {
+  MMEGO_REQUIRE(dY && Z && state && g_part && dgamma && dbeta && gidx && feats && anchors && W && dW_part && rows > 0 && (rows % 216) == 0);
+  const int Cin = 6 + D;
+  MMEGO_REQUIRE(D >= 0 && Cin <= 64 && Cout >= 1 && Cout <= 64 && lddy >= Cout && ldz >= Cout && ldf >= 3 + D && N > 0);
+  MMEGO_REQUIRE(!dX || lddx >= Cin);
+  MlpBwdP p;
+  p.dY = dY; p.lddy = lddy; p.Z = Z; p.ldz = ldz; p.rows = rows; p.Cout = Cout; p.state = state;
+  p.g_part = g_part; p.dgamma = dgamma; p.dbeta = dbeta;
+  p.Xin = feats; p.ldxin = 0; p.Cin = Cin; p.in_state = nullptr; p.W = W; p.dX = dX; p.lddx = lddx;
+  p.gprev_part = nullptr; p.dW_part = dW_part;
+  p.gidx = gidx; p.gfeats = feats; p.gldf = ldf; p.ganch = anchors; p.gN = N;
+  return mlp_bwd_layer_launch((hipStream_t)stream, p);
 }
 
 extern "C" int mmego_mlp_dw_reduce(void* stream, long rows, int nlayers, const float* part0, float* dW0, int Cout0, int Cin0,

@@ -102,11 +102,11 @@ class UpperNetwlocal(_NetBase):
         """HBM bytes per frame the anchor branch's activations move between launches in one training step (written once + read
         once per consumer; parameters and the shared per-point features excluded): the fused path against the launch chain."""
         g = N_ANCHOR * N_GROUP
-        fused = 4 * (g * 31 * 2                     # gathered rows: written by the grouping kernel, read by layer 1's weight gradient
-                     + g * (32 + 48 + 64) * 3       # z1..z3: written, read by the next stage, read by backward
+        fused = 4 * (g * (32 + 48 + 64) * 3         # z1..z3: written, read by the next stage, read by backward (the gathered rows
+                                                    # themselves never reach memory: LDS forward, re-gathered backward)
                      + g * (64 + 48 + 32 + 31) * 2  # dl3, dy2, dy1, dgrouped
                      + N_ANCHOR * 64 * 4 + g * 2) + 8 * g
-        chain = fused + 4 * (g * 31 * 1             # gathered rows read by the separate first layer
+        chain = fused + 4 * (g * 31 * 3             # gathered rows written, read by the first layer and by its weight gradient
                              + g * 64 * 4           # l3 written, read by pooling, by its backward, by the BatchNorm backward
                              + g * 64 * 2           # dl3 read by the separate BatchNorm reduce
                              + N_ANCHOR * 64 * 4)   # vox / dvox through the transposes
@@ -160,13 +160,13 @@ class UpperNetwlocal(_NetBase):
         fused = self._local_fusable(N)
         self._local_was_fused = fused and training
         if fused and training:
-            # grouping with LocalPointNet's first conv behind it in the same kernel (the gathered rows go from LDS into the product;
-            # they are also kept for the layer's weight gradient), two fused layer launches, then BatchNorm + ReLU + the 8-way
+            # grouping with LocalPointNet's first conv behind it in the same kernel (the gathered rows go from LDS into the product and
+            # are never stored: the layer's backward gathers them again through the indices), two fused layer launches, then BatchNorm + ReLU + the 8-way
             # softmax pooling in one kernel that writes the pooled vectors in the Conv3d input order: the activated 64-channel
             # tensor, the pooling pass over it and the transpose launch do not exist (local.hip)
             nblk = hip.lib().mmego_mlp_train_nblk(grows)
             nwg = min(_LOCAL_NWG, F)
-            grouped = ar.get("grouped", (grows, 31))
+            grouped = None           # (not kept: the first layer's weight gradient gathers its input again through the indices)
             z1, z2, z3 = ar.get("lp.z1", (grows, 32)), ar.get("lp.z2", (grows, 48)), ar.get("lp.z3", (grows, 64))
             part1 = ar.get("lp.sp1g", (nwg * 2 * 64,), dtype=torch.float64)
             part2, part3 = (ar.get("lp.sp%d" % i, (nblk * 2 * 64,), dtype=torch.float64) for i in (2, 3))
@@ -242,7 +242,6 @@ class UpperNetwlocal(_NetBase):
         voxT = ar.get("voxT", (F, 64 * N_ANCHOR))
         dvoxT = blocks.mlp3_backward(ar, "vx", self.module2.avoxel, voxT, vvec, dvvec, G, True)
         gidx = ar.get("gidx", (F, N_ANCHOR, N_GROUP), dtype=torch.int64)
-        grouped = ar.get("grouped", (grows, 31))
         lp = self.module2.apointnet
         if getattr(self, "_local_was_fused", False):
             # pooling backward with the activated rows recomputed, the last stage's BatchNorm sums and the attention parameter
@@ -258,9 +257,11 @@ class UpperNetwlocal(_NetBase):
             else:
                 ops.colsum(awp[:, :64], gw)
                 ops.colsum(awp[:, 64:65], gb)
-            dgrouped = blocks._mlp3_backward_fused(ar, "lp", lp, grouped, dl3, G, True, have_sums=True)
+            dgrouped = blocks._mlp3_backward_fused(ar, "lp", lp, None, dl3, G, True, have_sums=True,
+                                                   gather=(grows, gidx, feats, 28, self.anchors(feats.device), N, 25))
             hip.call("anchor_scatter", dgrouped, gidx, F, N, 25, dfeats, 28)
         else:
+            grouped = ar.get("grouped", (grows, 31))
             dvox = ar.get("dvox", (F * N_ANCHOR, 64))
             hip.call("transpose_batched", dvoxT, dvox, F, 64, N_ANCHOR)       # (F,64,27) -> (F,27,64)
             l3, dl3 = ar.get("l3", (grows, 64)), ar.get("dl3", (grows, 64))
