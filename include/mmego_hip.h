@@ -267,13 +267,15 @@ int mmego_head_fk_forward(void* stream, int which, const float* y, const float* 
                           unsigned long long* seed_ctr);
 int mmego_head_fk_backward(void* stream, int which, const float* y, const float* body, int B, long F, const float* dj,
                            float* dy, const float* Rw);
-/* mmego_head_fk_forward -> mmego_l1_loss (scale, loss[2], gradient = sign) -> mmego_head_fk_backward as ONE launch: F <= 512 frames, a
- * single workgroup (the loss is a fixed-order sum).  map [nslots]: target joint of every predicted slot; dy [F, ny]: d loss / d y.
- * Bit-identical to the three calls (Train_Upper.py:165-182, Train_Lower.py:199-224: forward tail, L1Loss(sum), start of backward). */
+/* mmego_head_fk_forward -> mmego_l1_loss (scale, loss[2], gradient = sign) -> mmego_head_fk_backward as ONE launch.  The loss is a
+ * fixed-order sum: per-workgroup partial pairs in scratch (2 * ceil(F/64) + 1 doubles; the last double's storage is a ticket that must
+ * be 0 before the first call and is left 0), added in index order by the workgroup that finishes last.  map [nslots]: target joint of
+ * every predicted slot; dy [F, ny]: d loss / d y.  Predictions and gradients bit-identical to the three calls; the two loss figures
+ * agree to fp64 rounding of a different (but fixed) summation order (Train_Upper.py:165-182, Train_Lower.py:199-224). */
 int mmego_head_fk_loss(void* stream, int which, const float* y, const float* body, int B, long F, float* q, float* joints_h,
                        const float* Rw, const float* tw, float* world, long long* counters, int ncount,
                        unsigned long long* seed_ctr, const float* target, const int* map, int ntgt, double scale, float* loss,
-                       float* dy);
+                       float* dy, double* scratch);
 /* y[F,9] -> R[F,3,3] (eps rule of IMU_Net.py:7-18), t[F,3]. */
 int mmego_imu_head(void* stream, const float* y, long F, float* R, float* t);
 /* IMU_Net.fc2 (Net/IMU_Net.py:84) and mmego_imu_head in one launch: y = X [F][K] . W[9][K]^T + b (row-wise dot products, fixed
@@ -515,6 +517,16 @@ typedef struct MmegoSlab {
   const float* ws; float* out; const float* scale; float* asum;
   int kind, nsplit, M, N, taps; long scm;
 } MmegoSlab;
+/* Launch-count helpers of the Lower_Net tail: two group sums / two group broadcasts / two 2-D copies per launch, and mmego_topk_rows
+ * with the kept rows' first n2 columns written to a second buffer as well (same arithmetic as the single forms). */
+int mmego_group_sum2(void* stream, long G, const float* X1, int P1, int C1, float scale1, float* Y1, long ldy1, const float* X2, int P2,
+                     int C2, float scale2, float* Y2, long ldy2);
+int mmego_group_bcast2(void* stream, long G, const float* dY1, long lddy1, int P1, int C1, float scale1, float* dX1, const float* dY2,
+                       long lddy2, int P2, int C2, float scale2, float* dX2);
+int mmego_copy2d_pair(void* stream, const float* X1, long ldx1, float* Y1, long ldy1, long rows1, int C1, const float* X2, long ldx2,
+                      float* Y2, long ldy2, long rows2, int C2);
+int mmego_topk_rows2(void* stream, const float* pts, long F, int N, int C, int keep, float* out, long long* idx, float* out2, long ld2,
+                     int n2);
 int mmego_slab_reduce(void* stream, int n, const void* descs);
 /* d(gamma)[c] = sum_r dY[r][c] xhat[r][c], d(beta)[c] = sum_r dY[r][c] of a BatchNorm whose input gradient is not needed (data_bn,
  * GCN.py:310: the skeleton input is detached, Train_Lower.py:196); state [4][C]. */

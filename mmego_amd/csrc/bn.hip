@@ -186,6 +186,23 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ X
   }
 }
 
+// two 2-D copies in one launch (concatenation of two sources into one buffer): blocks [0, nb1) copy the first
+__global__ __launch_bounds__(256) void copy2d_pair_kernel(const float* __restrict__ X1, long ldx1, float* __restrict__ Y1, long ldy1,
+                                                          long rows1, int C1, const float* __restrict__ X2, long ldx2,
+                                                          float* __restrict__ Y2, long ldy2, long rows2, int C2, int nb1) {
+  const bool second = (int)blockIdx.x >= nb1;
+  const float* X = second ? X2 : X1;
+  float* Y = second ? Y2 : Y1;
+  const long ldx = second ? ldx2 : ldx1, ldy = second ? ldy2 : ldy1, total = second ? rows2 * C2 : rows1 * C1;
+  const int C = second ? C2 : C1;
+  const long nb = second ? (long)gridDim.x - nb1 : nb1;
+  for (long i = (long)(blockIdx.x - (second ? nb1 : 0)) * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    Y[r * ldy + c] = X[r * ldx + c];
+  }
+}
+
 // dZ = dY * [Ymask > 0];  partial[c][blk] = (sum dZ, sum dZ*xhat)   with xhat = (X-mean)*invstd
 // A second BatchNorm that shares dY and the mask (st_gcn: relu(BN(tcn) + BN(residual)), GCN.py:140-147) rides along as the
 // virtual channels [C, 2C): Bn2 holds its X / mean / invstd (pair.X == nullptr: single).
@@ -479,6 +496,16 @@ extern "C" int mmego_copy2d(void* stream, const float* X, long ldx, float* Y, lo
   MMEGO_REQUIRE(X && Y && rows > 0 && C > 0);
   hipLaunchKernelGGL(copy2d_kernel, dim3(ew_blocks(rows * C)), dim3(256), 0, (hipStream_t)stream, X, ldx, Y, ldy, rows,
                      C, accumulate);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_copy2d_pair(void* stream, const float* X1, long ldx1, float* Y1, long ldy1, long rows1, int C1, const float* X2,
+                                 long ldx2, float* Y2, long ldy2, long rows2, int C2) {
+  MMEGO_REQUIRE(X1 && Y1 && X2 && Y2 && rows1 > 0 && C1 > 0 && rows2 > 0 && C2 > 0);
+  const int nb1 = ew_blocks(rows1 * C1), nb2 = ew_blocks(rows2 * C2);
+  hipLaunchKernelGGL(copy2d_pair_kernel, dim3(nb1 + nb2), dim3(256), 0, (hipStream_t)stream, X1, ldx1, Y1, ldy1, rows1, C1, X2, ldx2, Y2,
+                     ldy2, rows2, C2, nb1);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -297,28 +297,29 @@ __global__ __launch_bounds__(64) void head_fk_bwd_kernel(const float* __restrict
 }
 
 // Forward kinematics + head-to-world transform + L1(sum) loss against the selected target joints + the loss gradient (its sign)
-// + the backward of the transform and of the kinematics, in ONE launch: F <= 512 frames, a single workgroup (a thread per frame, two
-// frames in turn above 256), so that the loss is a fixed-order sum (deterministic) without a second launch.  Same arithmetic, statement by statement, as
+// + the backward of the transform and of the kinematics, in ONE launch: one thread per frame in 64-thread workgroups (one wave per
+// workgroup: the frame's ~400 live values fit the unified register file).  The loss is a fixed-order sum: every workgroup publishes its
+// partial pair (agent-scope stores), takes a ticket, and the workgroup that draws the last one adds the partials IN INDEX ORDER -- the
+// same value whichever workgroup is last -- and resets the ticket for the next launch (graph replays).  Same arithmetic, statement by statement, as
 // head_fk_fwd_kernel -> l1_loss_kernel -> head_fk_bwd_kernel (bit-identical results; tests/test_hip_parity.py).  Replaces three
 // dependent launches at the turning point of a training step (Train_Upper.py:165-182, Train_Lower.py:199-224).
 template <int WHICH>
-__global__ __launch_bounds__(256) void head_fk_loss_kernel(const float* __restrict__ y, const float* __restrict__ body, int B, long F,
-                                                           float* __restrict__ q, float* __restrict__ joints,
-                                                           const float* __restrict__ Rw, const float* __restrict__ tw,
-                                                           float* __restrict__ world, long long* counters, int ncount,
-                                                           unsigned long long* seed_ctr, const float* __restrict__ target,
-                                                           const int* __restrict__ map, int ntgt, float scale,
-                                                           float* __restrict__ loss, float* __restrict__ dy) {
+__global__ __launch_bounds__(64) void head_fk_loss_kernel(const float* __restrict__ y, const float* __restrict__ body, int B, long F,
+                                                          float* __restrict__ q, float* __restrict__ joints,
+                                                          const float* __restrict__ Rw, const float* __restrict__ tw,
+                                                          float* __restrict__ world, long long* counters, int ncount,
+                                                          unsigned long long* seed_ctr, const float* __restrict__ target,
+                                                          const int* __restrict__ map, int ntgt, float scale,
+                                                          float* __restrict__ loss, float* __restrict__ dy, double* part,
+                                                          unsigned* ticket) {
   using P = FkC<WHICH>;
-  __shared__ double sh[2][8];
-  if (threadIdx.x == 0) {
+  const long f = (long)blockIdx.x * 64 + threadIdx.x;
+  if (f == 0) {
     for (int i = 0; i < ncount; ++i) counters[i] += 1;
     if (seed_ctr) seed_ctr[0] = seed_ctr[0] * 6364136223846793005ULL + 1442695040888963407ULL;
   }
   double acc = 0.0, dist = 0.0;
-  // (256 threads = one wave per SIMD: the frame's ~400 live values fit the unified register file; a thread walks frames tid, tid + 256)
-#pragma unroll 1
-  for (long f = threadIdx.x; f < F; f += 256) {
+  if (f < F) {
     float yv[P::ny];
 #pragma unroll
     for (int i = 0; i < P::ny; ++i) yv[i] = y[f * P::ny + i];
@@ -414,13 +415,21 @@ __global__ __launch_bounds__(256) void head_fk_loss_kernel(const float* __restri
   }
   acc = wave_sum_d(acc);
   dist = wave_sum_d(dist);
-  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = acc; sh[1][threadIdx.x >> 6] = dist; }
-  __syncthreads();
   if (threadIdx.x == 0) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { s0 += sh[0][w]; s1 += sh[1][w]; }
-    loss[0] = (float)s0;
-    loss[1] = (float)s1;
+    __hip_atomic_store(&part[2 * blockIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&part[2 * blockIdx.x + 1], dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);                         // the partial pair has been acknowledged before the ticket is drawn
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {                              // last workgroup: the partials in index order (agent-scope loads: not a stale L2 line)
+      double s0 = 0.0, s1 = 0.0;
+      for (unsigned w = 0; w < gridDim.x; ++w) {
+        s0 += __hip_atomic_load(&part[2 * w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s1 += __hip_atomic_load(&part[2 * w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      loss[0] = (float)s0;
+      loss[1] = (float)s1;
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -559,8 +568,11 @@ __global__ __launch_bounds__(1024) void l1_loss_kernel(const float* __restrict__
 
 // Keep the `keep` rows with the largest key (column 0), descending, ties lowest-index-first (stable);
 // out [F, keep, C], idx int64 [F, keep].  Reference Lower_Net.py:216-227 (torch.sort, tie order unspecified).
+// out2 (optional): the first n2 columns of every kept row go there too (row stride ld2) -- Lower_Net's cat(xyz, features) buffer gets
+// its xyz part from this launch instead of a copy launch behind it.
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ pts, int N, int C, int keep,
-                                                        float* __restrict__ out, long long* __restrict__ idx) {
+                                                        float* __restrict__ out, long long* __restrict__ idx,
+                                                        float* __restrict__ out2, long ld2, int n2) {
   extern __shared__ float keys[];
   const long f = blockIdx.x;
   const float* pf = pts + f * N * C;
@@ -577,6 +589,8 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
       idx[f * keep + rank] = i;
       float* o = out + (f * keep + rank) * C;
       for (int c = 0; c < C; ++c) o[c] = pf[i * C + c];
+      if (out2)
+        for (int c = 0; c < n2; ++c) out2[(f * keep + rank) * ld2 + c] = pf[i * C + c];
     }
   }
 }
@@ -632,12 +646,15 @@ extern "C" int mmego_head_fk_backward(void* stream, int which, const float* y, c
 extern "C" int mmego_head_fk_loss(void* stream, int which, const float* y, const float* body, int B, long F, float* q, float* joints_h,
                                   const float* Rw, const float* tw, float* world, long long* counters, int ncount,
                                   unsigned long long* seed_ctr, const float* target, const int* map, int ntgt, double scale,
-                                  float* loss, float* dy) {
-  MMEGO_REQUIRE((which == 0 || which == 1) && y && body && q && joints_h && Rw && tw && world && target && map && loss && dy);
-  MMEGO_REQUIRE(B > 0 && F > 0 && F <= 512 && ntgt > 0 && ncount >= 0 && ncount <= 4096 && (ncount == 0 || counters));
-  const int nt = 256;
-  if (which == 0) hipLaunchKernelGGL(head_fk_loss_kernel<0>, dim3(1), dim3(nt), 0, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy);
-  else hipLaunchKernelGGL(head_fk_loss_kernel<1>, dim3(1), dim3(nt), 0, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy);
+                                  float* loss, float* dy, double* scratch) {
+  // scratch: 2 * ceil(F / 64) + 1 doubles -- the workgroups' partial pairs, then (in the last double's storage) the ticket, which must
+  // be 0 before the first call and is left 0 by every call
+  MMEGO_REQUIRE((which == 0 || which == 1) && y && body && q && joints_h && Rw && tw && world && target && map && loss && dy && scratch);
+  MMEGO_REQUIRE(B > 0 && F > 0 && F <= 65536 && ntgt > 0 && ncount >= 0 && ncount <= 4096 && (ncount == 0 || counters));
+  const int nb = cdiv(F, 64);
+  unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 2 * nb);
+  if (which == 0) hipLaunchKernelGGL(head_fk_loss_kernel<0>, dim3(nb), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy, scratch, ticket);
+  else hipLaunchKernelGGL(head_fk_loss_kernel<1>, dim3(nb), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy, scratch, ticket);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
@@ -671,7 +688,17 @@ extern "C" int mmego_topk_rows(void* stream, const float* pts, long F, int N, in
                                long long* idx) {
   MMEGO_REQUIRE(pts && out && idx && F > 0 && N > 0 && C > 0 && keep > 0 && keep <= N && N <= 4096);
   hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)F), dim3(N < 256 ? ((N + 63) / 64) * 64 : 256),
-                     (size_t)N * sizeof(float), (hipStream_t)stream, pts, N, C, keep, out, idx);
+                     (size_t)N * sizeof(float), (hipStream_t)stream, pts, N, C, keep, out, idx, (float*)nullptr, 0L, 0);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// mmego_topk_rows whose kept rows' first n2 columns are also written to out2 (row stride ld2): one launch instead of two
+extern "C" int mmego_topk_rows2(void* stream, const float* pts, long F, int N, int C, int keep, float* out, long long* idx, float* out2,
+                                long ld2, int n2) {
+  MMEGO_REQUIRE(pts && out && idx && out2 && F > 0 && N > 0 && C > 0 && keep > 0 && keep <= N && N <= 4096 && n2 >= 1 && n2 <= C && ld2 >= n2);
+  hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)F), dim3(N < 256 ? ((N + 63) / 64) * 64 : 256),
+                     (size_t)N * sizeof(float), (hipStream_t)stream, pts, N, C, keep, out, idx, out2, ld2, n2);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -399,6 +399,41 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict_
   Y[g * ldy + c] = s * scale;
 }
 
+// Two group sums / two group broadcasts in one launch (Lower_Net's fusion module reduces the point features and the joint features
+// of a frame side by side, Lower_Net.py:112-115): blocks [0, nb1) take the first problem, the rest the second.
+struct GroupSeg { const float* X; float* Y; long ld; int P, C; float scale; };
+__global__ __launch_bounds__(256) void group_sum2_kernel(GroupSeg a, GroupSeg b, long G, int nb1) {
+  const bool second = (int)blockIdx.x >= nb1;
+  const GroupSeg& s_ = second ? b : a;
+  const long i = (long)(blockIdx.x - (second ? nb1 : 0)) * blockDim.x + threadIdx.x;
+  if (i >= G * s_.C) return;
+  const long g = i / s_.C;
+  const int c = (int)(i - g * s_.C);
+  const float* x = s_.X + g * (long)s_.P * s_.C + c;
+  float s = 0.f;
+  for (int p0 = 0; p0 < s_.P; p0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p0 + u < s_.P ? x[(long)(p0 + u) * s_.C] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (p0 + u < s_.P) s += v[u];
+  }
+  s_.Y[g * s_.ld + c] = s * s_.scale;
+}
+// dX[g, p, c] = scale * dY[g, c] for two problems (X = dY with row stride ld, Y = dX contiguous)
+__global__ __launch_bounds__(256) void group_bcast2_kernel(GroupSeg a, GroupSeg b, long G, int nb1) {
+  const bool second = (int)blockIdx.x >= nb1;
+  const GroupSeg& s_ = second ? b : a;
+  const long total = G * s_.P * s_.C;
+  const long nb = second ? (long)gridDim.x - nb1 : nb1;
+  for (long i = (long)(blockIdx.x - (second ? nb1 : 0)) * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
+    const int c = (int)(i % s_.C);
+    const long g = i / ((long)s_.P * s_.C);
+    s_.Y[i] = s_.scale * s_.X[g * s_.ld + c];
+  }
+}
+
 // dX[g, p, c] (+)= scale * dY[g, c]
 __global__ __launch_bounds__(256) void group_bcast_kernel(const float* __restrict__ dY, long lddy, int P, int C,
                                                           float scale, float* __restrict__ dX, long G,
@@ -641,6 +676,26 @@ extern "C" int mmego_attn_pool_backward(void* stream, const float* X, const floa
 extern "C" int mmego_group_sum(void* stream, const float* X, long G, int P, int C, float scale, float* Y, long ldy) {
   MMEGO_REQUIRE(X && Y && G > 0 && P > 0 && C > 0);
   hipLaunchKernelGGL(group_sum_kernel, dim3(cdiv(G * C, 256)), dim3(256), 0, (hipStream_t)stream, X, P, C, scale, Y, ldy, G);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_group_sum2(void* stream, long G, const float* X1, int P1, int C1, float scale1, float* Y1, long ldy1, const float* X2,
+                                int P2, int C2, float scale2, float* Y2, long ldy2) {
+  MMEGO_REQUIRE(X1 && Y1 && X2 && Y2 && G > 0 && P1 > 0 && C1 > 0 && P2 > 0 && C2 > 0);
+  GroupSeg a = {X1, Y1, ldy1, P1, C1, scale1}, b = {X2, Y2, ldy2, P2, C2, scale2};
+  const int nb1 = cdiv(G * C1, 256), nb2 = cdiv(G * C2, 256);
+  hipLaunchKernelGGL(group_sum2_kernel, dim3(nb1 + nb2), dim3(256), 0, (hipStream_t)stream, a, b, G, nb1);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_group_bcast2(void* stream, long G, const float* dY1, long lddy1, int P1, int C1, float scale1, float* dX1,
+                                  const float* dY2, long lddy2, int P2, int C2, float scale2, float* dX2) {
+  MMEGO_REQUIRE(dY1 && dX1 && dY2 && dX2 && G > 0 && P1 > 0 && C1 > 0 && P2 > 0 && C2 > 0);
+  GroupSeg a = {dY1, dX1, lddy1, P1, C1, scale1}, b = {dY2, dX2, lddy2, P2, C2, scale2};
+  const int nb1 = ew_blocks(G * P1 * C1), nb2 = ew_blocks(G * P2 * C2);
+  hipLaunchKernelGGL(group_bcast2_kernel, dim3(nb1 + nb2), dim3(256), 0, (hipStream_t)stream, a, b, G, nb1);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -107,10 +107,15 @@ class _NetBase(nn.Module):
         _backward_impl skips its first launch (bit-identical to the three separate launches)."""
         hook = self.loss_hook
         self._dy_ready = False
-        if hook is not None and stash and F <= 512 and os.environ.get("MMEGO_FUSED_HEAD_LOSS", "1") != "0":
+        if hook is not None and stash and os.environ.get("MMEGO_FUSED_HEAD_LOSS", "1") != "0":
             target, jmap, loss2, scale = hook
             dy = ar.get("dy", (F, y.shape[1]))
-            hip.call("head_fk_loss", which, y, body, B, F, q, jh, R, t, l, *tick, target, jmap, target.shape[-2], float(scale), loss2, dy)
+            nb = (F + 63) // 64
+            fresh = not ar.has("fkloss.scratch%d" % nb)
+            scr = ar.get("fkloss.scratch%d" % nb, (2 * nb + 1,), dtype=torch.float64)
+            if fresh:
+                scr.zero_()          # (the ticket starts at 0; every launch leaves it 0.  One-time, outside any captured graph: warm-up)
+            hip.call("head_fk_loss", which, y, body, B, F, q, jh, R, t, l, *tick, target, jmap, target.shape[-2], float(scale), loss2, dy, scr)
             self._dy_ready = True
         else:
             hip.call("head_fk_forward", which, y, body, B, F, q, jh, R, t, l, *tick)
@@ -445,8 +450,11 @@ class LowerNet(_NetBase):
         ops.transform2h_(up.view(F, V, 3), R, t, src=_f32c(upper_l).view(F, V, 3))     # (copy + transform, one launch)
         sel = ar.get("sel", (F * LOWER_POINTS, Cx))
         idx = ar.get("sel_idx", (F, LOWER_POINTS), dtype=torch.int64)
+        prow = F * LOWER_POINTS
+        both = ar.get("both", (prow, 128))                      # [p_vec | cross-attention output]: p_vec is written in place
+        p_vec = both[:, :64]
         if pin_select_idx is None:
-            hip.call("topk_rows", x, F, N, Cx, LOWER_POINTS, sel, idx)
+            hip.call("topk_rows2", x, F, N, Cx, LOWER_POINTS, sel, idx, p_vec, both.stride(0), 3)      # (xyz part of p_vec from the same launch)
         else:                                                         # replay a recorded selection (see forward)
             pin = pin_select_idx.to(device=dev, dtype=torch.int64).reshape(F, LOWER_POINTS)
             if int(pin.min()) < 0 or int(pin.max()) >= N:
@@ -454,11 +462,8 @@ class LowerNet(_NetBase):
             idx.copy_(pin)
             flat_idx = (pin + torch.arange(F, device=dev, dtype=torch.int64).view(F, 1) * N).reshape(-1).contiguous()
             ops.gather_rows(x.view(F * N, Cx), flat_idx, sel)
+            ops.copy2d(sel[:, :3], p_vec[:, :3])
         self.last_select_idx = idx
-        prow = F * LOWER_POINTS
-        both = ar.get("both", (prow, 128))                      # [p_vec | cross-attention output]: p_vec is written in place
-        p_vec = both[:, :64]
-        ops.copy2d(sel[:, :3], p_vec[:, :3])
         blocks.mlp3_forward(ar, "base", self.pointEncoder.module0, sel, p_vec[:, 3:64], training)
 
         k_vec = self._gcn_forward(ar, up, B, T, training)            # [F*15, 64] in the re-viewed layout (Q8)
@@ -476,14 +481,13 @@ class LowerNet(_NetBase):
         Pm = ar.get("Pm", (F, LOWER_POINTS, V))
         hip.call("cross_attn_forward", Qm, Km, Vm, F, float(fu.scale), both[:, 64:], 128, Pm, 128)
         ak = ar.get("ak", (F, 192))
-        hip.call("group_sum", both, F, LOWER_POINTS, 128, 1.0, ak, 192)            # Q6: gate == 1 -> plain sum
-        hip.call("group_sum", k_vec, F, V, 64, 1.0 / V, ak[:, 128:], 192)
+        # Q6: gate == 1 -> plain sum over the points; mean over the joints: one launch for both
+        hip.call("group_sum2", F, both, LOWER_POINTS, 128, 1.0, ak, 192, k_vec, V, 64, 1.0 / V, ak[:, 128:], 192)
         lstm = fu.rnn_pk
         seq, _, _ = blocks.lstm64_forward(ar, "rnn", lstm, ak, B, T, None, None, stash, self._drop_p(lstm) if stash else 0.0,
                                           self.seed_counter())
         cat = ar.get("cat", (F, 173))
-        ops.copy2d(seq, cat[:, :128])
-        ops.copy2d(up, cat[:, 128:173])
+        hip.call("copy2d_pair", seq, seq.stride(0), cat, cat.stride(0), F, 128, up, up.stride(0), cat[:, 128:173], cat.stride(0), F, 45)
         f0, f1, y = ar.get("f0", (F, 128)), ar.get("f1", (F, 64)), ar.get("y", (F, 42))
         ops.linear(cat, fu.fc0.weight, fu.fc0.bias, f0, relu=True)
         ops.linear(f0, fu.fc1.weight, fu.fc1.bias, f1, relu=True)
@@ -681,9 +685,8 @@ class LowerNet(_NetBase):
         dak = blocks.lstm64_backward(ar, "rnn", lstm, ak, B, T, None, dcat[:, :128], G, self._drop_p(lstm), True, leaves=leaves)
         blocks.run_leaves(leaves)
         dboth = ar.get("dboth", (prow, 128))
-        hip.call("group_bcast", dak, 192, F, LOWER_POINTS, 128, 1.0, dboth, 0)
         dk = ar.get("dk", (F * V, 64))
-        hip.call("group_bcast", dak[:, 128:], 192, F, V, 64, 1.0 / V, dk, 0)
+        hip.call("group_bcast2", F, dak, 192, LOWER_POINTS, 128, 1.0, dboth, dak[:, 128:], 192, V, 64, 1.0 / V, dk)
         dp = dboth[:, :64]           # (accumulated into in place: the attention's input gradient reads the other half)
         Qm, KVm = ar.get("Qm", (prow, 64)), ar.get("KVm", (F * V, 128))
         Km, Vm = KVm[:, :64], KVm[:, 64:]
