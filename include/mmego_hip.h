@@ -519,6 +519,10 @@ typedef struct MmegoSlab {
 } MmegoSlab;
 /* Launch-count helpers of the Lower_Net tail: two group sums / two group broadcasts / two 2-D copies per launch, and mmego_topk_rows
  * with the kept rows' first n2 columns written to a second buffer as well (same arithmetic as the single forms). */
+int mmego_transform2h_pair(void* stream, float* pts, long F, int P, int C, const float* R, const float* t, float* pts2, int P2,
+                           const float* src2);
+int mmego_colsum2(void* stream, const float* X1, long ld1, long rows1, int C1, float* out1, const float* X2, long ld2, long rows2,
+                  int C2, float* out2);
 int mmego_group_sum2(void* stream, long G, const float* X1, int P1, int C1, float scale1, float* Y1, long ldy1, const float* X2, int P2,
                      int C2, float scale2, float* Y2, long ldy2);
 int mmego_group_bcast2(void* stream, long G, const float* dY1, long lddy1, int P1, int C1, float scale1, float* dX1, const float* dY2,

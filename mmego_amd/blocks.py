@@ -325,8 +325,11 @@ def attn_pool_backward(ar, key, X, lin, attn, dvec, G_, P, C, dX, G):
     pdw = ar.get("%s.pdw" % key, (G_, C))
     pdb = ar.get("%s.pdb" % key, (G_, 1))
     hip.call("attn_pool_backward", X, lin.weight, attn, dvec, G_, P, C, dX, pdw, pdb)
-    ops.colsum(pdw, G(lin.weight).view(-1))
-    ops.colsum(pdb, G(lin.bias))
+    if G_ <= 1024:          # both parameter gradients' column sums in one launch
+        hip.call("colsum2", pdw, C, G_, C, G(lin.weight).view(-1), pdb, 1, G_, 1, G(lin.bias))
+    else:
+        ops.colsum(pdw, G(lin.weight).view(-1))
+        ops.colsum(pdb, G(lin.bias))
 
 
 # ---------------------------------------------------------------------------------------------------

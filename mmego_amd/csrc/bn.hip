@@ -579,6 +579,46 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
   return MMEGO_OK;
 }
 
+// two short column sums (<= 1024 rows each) in one launch: blocks [0, nb1) take the first tensor
+__global__ __launch_bounds__(256) void colsum_small2_kernel(const float* __restrict__ X1, long ld1, long rows1, int C1, float* out1,
+                                                            const float* __restrict__ X2, long ld2, long rows2, int C2, float* out2,
+                                                            int nb1) {
+  __shared__ double sh[256];
+  const bool second = (int)blockIdx.x >= nb1;
+  const float* X = second ? X2 : X1;
+  const long ldx = second ? ld2 : ld1, rows = second ? rows2 : rows1;
+  const int C = second ? C2 : C1;
+  float* out = second ? out2 : out1;
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = (blockIdx.x - (second ? nb1 : 0)) * 16 + cx;
+  double s = 0.0;
+  if (c < C) {
+    long r = ry;
+    for (; r + 3L * 16 < rows; r += 4L * 16) {
+      float v0 = X[r * ldx + c], v1 = X[(r + 16) * ldx + c], v2 = X[(r + 32) * ldx + c], v3 = X[(r + 48) * ldx + c];
+      s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; r < rows; r += 16) s += (double)X[r * ldx + c];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    double a = 0.0;
+    for (int j = 0; j < 16; ++j) a += sh[j * 16 + cx];
+    out[c] = (float)a;
+  }
+}
+
+extern "C" int mmego_colsum2(void* stream, const float* X1, long ld1, long rows1, int C1, float* out1, const float* X2, long ld2,
+                             long rows2, int C2, float* out2) {
+  MMEGO_REQUIRE(X1 && out1 && X2 && out2 && rows1 > 0 && rows1 <= 1024 && rows2 > 0 && rows2 <= 1024 && C1 > 0 && C2 > 0);
+  const int nb1 = cdiv(C1, 16), nb2 = cdiv(C2, 16);
+  hipLaunchKernelGGL(colsum_small2_kernel, dim3(nb1 + nb2), dim3(256), 0, (hipStream_t)stream, X1, ld1, rows1, C1, out1, X2, ld2, rows2, C2,
+                     out2, nb1);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
 extern "C" int mmego_colsum_pair(void* stream, const float* X, long ldx, long rows, int C, float* outA, float* outA2, float* outB,
                                  float* outB2, int accumulate) {
   MMEGO_REQUIRE(X && rows > 0 && rows <= 1024 && C >= 16 && (C % 16) == 0 && outA && outB);

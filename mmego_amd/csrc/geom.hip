@@ -19,11 +19,9 @@ __device__ __forceinline__ float dot3_nofma(float a0, float a1, float a2, float 
 // keep (optional, [npts][C]) and feats (optional, the first nfeat channels, row stride ldf) receive the transformed rows too --
 // the copies Upper_Net's forward makes right behind the transform (the tensor stashed for backward, the xyz + intensity columns of
 // the concatenated feature buffer).
-__global__ __launch_bounds__(256) void transform2h_kernel(float* pts, int P, int C, const float* __restrict__ R,
-                                                          const float* __restrict__ t, long npts, const float* src, long src_ld,
-                                                          float* __restrict__ keep, float* __restrict__ feats, long ldf, int nfeat) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npts) return;
+__device__ __forceinline__ void t2h_point(long i, float* pts, int P, int C, const float* __restrict__ R, const float* __restrict__ t,
+                                          const float* src, long src_ld, float* __restrict__ keep, float* __restrict__ feats, long ldf,
+                                          int nfeat) {
   long f = i / P;
   const float* Rf = R + f * 9;
   const float* tf = t + f * 3;
@@ -55,6 +53,24 @@ __global__ __launch_bounds__(256) void transform2h_kernel(float* pts, int P, int
 #pragma unroll
     for (int c = 0; c < 8; ++c) if (c < nfeat) q[c] = v[c];
   }
+}
+
+__global__ __launch_bounds__(256) void transform2h_kernel(float* pts, int P, int C, const float* __restrict__ R,
+                                                          const float* __restrict__ t, long npts, const float* src, long src_ld,
+                                                          float* __restrict__ keep, float* __restrict__ feats, long ldf, int nfeat) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npts) return;
+  t2h_point(i, pts, P, C, R, t, src, src_ld, keep, feats, ldf, nfeat);
+}
+
+// Two point sets of the same frames in one launch: pts [F][P][C] in place, and pts2 [F][P2][3] <- transform of src2 [F][P2][3]
+// (Lower_Net.py:191-192,205: the radar points and the predicted upper-body joints go to the head frame side by side)
+__global__ __launch_bounds__(256) void transform2h_pair_kernel(float* pts, int P, int C, const float* __restrict__ R,
+                                                               const float* __restrict__ t, long npts, float* pts2, int P2,
+                                                               const float* src2, long npts2) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npts) t2h_point(i, pts, P, C, R, t, nullptr, 0, nullptr, nullptr, 0, 0);
+  else if (i - npts < npts2) t2h_point(i - npts, pts2, P2, 3, R, t, src2, 3, nullptr, nullptr, 0, 0);
 }
 
 // out[f, p, :] = R[f]^T . in[f, p, :] + t[f]     (transpose=1, Transform2R)
@@ -605,6 +621,15 @@ extern "C" int mmego_transform2h(void* stream, float* pts, long F, int P, int C,
   long n = F * P;
   hipLaunchKernelGGL(transform2h_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pts, P, C, R, t, n, src, src_ld, keep,
                      feats, ldf, nfeat);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_transform2h_pair(void* stream, float* pts, long F, int P, int C, const float* R, const float* t, float* pts2, int P2,
+                                      const float* src2) {
+  MMEGO_REQUIRE(pts && R && t && pts2 && src2 && F > 0 && P > 0 && C >= 3 && P2 > 0);
+  const long n = F * P, n2 = F * P2;
+  hipLaunchKernelGGL(transform2h_pair_kernel, dim3(cdiv(n + n2, 256)), dim3(256), 0, (hipStream_t)stream, pts, P, C, R, t, n, pts2, P2, src2, n2);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -445,9 +445,9 @@ class LowerNet(_NetBase):
         V = JOINTS_UPPER
         dev = x.device
         R, t, body = _f32c(R), _f32c(t), _f32c(body)
-        ops.transform2h_(x, R, t)                                     # Q1 (second transform after UpperNet)
         up = ar.get("up", (F, V * 3))
-        ops.transform2h_(up.view(F, V, 3), R, t, src=_f32c(upper_l).view(F, V, 3))     # (copy + transform, one launch)
+        # Q1 (second transform after UpperNet) and the predicted joints' copy + transform: one launch
+        hip.call("transform2h_pair", x, F, N, Cx, R, t, up, V, _f32c(upper_l))
         sel = ar.get("sel", (F * LOWER_POINTS, Cx))
         idx = ar.get("sel_idx", (F, LOWER_POINTS), dtype=torch.int64)
         prow = F * LOWER_POINTS
