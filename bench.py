@@ -199,7 +199,8 @@ def pmc_traffic(kernel_label):
     around THIS program (`bench.py --trace-only --no-graph`, scripts/collect_profiles.sh), the r02 / r01 files around the
     micro-benchmarks scripts/bench_gemm_pair.py / bench_lstm_step.py."""
     key = kernel_label.split(" ")[0]
-    for name, what in (("r03_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself"),
+    for name, what in (("r04_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself (scripts/collect_r04.sh)"),
+                       ("r03_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself"),
                        ("r02_pmc_counters.json", "rocprofv3 --pmc passes of the micro-benchmarks scripts/bench_gemm_pair.py / bench_lstm_step.py"),
                        ("r01_pmc_counters.json", "rocprofv3 --pmc passes of the micro-benchmarks")):
         path = os.path.join(ROOT, "profiles", name)

@@ -446,7 +446,7 @@ int mmego_mlp_dw_reduce(void* stream, long rows, int nlayers, const float* part0
  * Train-mode BatchNorm statistics travel between these kernels as PARTIAL RECORDS: per producer workgroup j and channel c the float
  * pair rec[j][c] = (mean_j, M2_j) over the rows the workgroup owns (rows_per_rec each, the last record ragged).  The consumer finalizes
  * them in its prologue (every workgroup, fixed order); workgroup 0 writes state [4][C] = mean, invstd, a, b and updates the running
- * statistics with torch's semantics.  Replaces the colstats / bn_finalize / affine_act launches between the products. */
+ * statistics with torch semantics.  Replaces the colstats / bn_finalize / affine_act launches between the products. */
 typedef struct MmegoBnRef {
   const float* rec; int nrec; int rows_per_rec;
   const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum; float eps;
