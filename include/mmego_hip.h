@@ -347,6 +347,16 @@ int mmego_pool8_bn_act(void* stream, const float* Z, long ldz, long rows, const 
 int mmego_pool8_backward(void* stream, const float* Z, long ldz, long rows, const float* state, const float* attn, const float* dvoxT,
                          const float* aw_w, float* dY, long lddy, double* gpart, float* awpart);
 int mmego_anchor_scatter(void* stream, const float* dgrouped, const long long* idx, long F, int N, int D, float* dxf, long lddx);
+/* GlobalPointNet's softmax pooling over the 128 points of a frame (Upper_Net.py:285-301) fused the same way: forward = BatchNorm (from
+ * mmego_mlp_fwd_layer's partials) + ReLU + score + softmax + weighted sum -> vec [F][64], attn [F*128] (the activated tensor is never
+ * stored); backward = row gradients dY with y recomputed, gpart [rows/256][2][64] and awpart [rows/256][128] as mmego_pool8_backward.
+ * rows = F * 128 with mmego_pool128_ok(rows) (two frames per workgroup = mlp_train's 256-row partition, rows <= 65 536). */
+int mmego_pool128_ok(long rows);
+int mmego_pool128_bn_act(void* stream, const float* Z, long ldz, long rows, const double* part, const float* gamma, const float* beta,
+                         double eps, float* rmean, float* rvar, double momentum, float* state, const float* aw_w, const float* aw_b,
+                         float* vec, float* attn);
+int mmego_pool128_backward(void* stream, const float* Z, long ldz, long rows, const float* state, const float* attn, const float* vec,
+                           const float* dvec, const float* aw_w, float* dY, long lddy, double* gpart, float* awpart);
 
 /* ---- pooling / attention / graph (pool.hip) -------------------------------------------------------
  * Softmax-attention pooling over the P points of each of G groups (Upper_Net.py:285-301,163-177,

@@ -56,7 +56,7 @@ def _mlp3_fused_train(mod, x):
     return _FUSED_TRAIN_MLP and max(dims) <= 64 and x.stride(1) == 1
 
 
-def _mlp3_forward_fused(ar, key, mod, x, out_last):
+def _mlp3_forward_fused(ar, key, mod, x, out_last, pool=None):
     """Training forward of the three stages as 3 + 1 launches (mlp_train.hip): each product applies the PREVIOUS stage's
     BatchNorm + ReLU while loading its operand and leaves its own column statistics as per-workgroup partials; only the
     pre-BN tensors z1, z2, z3 and the last stage's output exist in memory."""
@@ -76,6 +76,13 @@ def _mlp3_forward_fused(ar, key, mod, x, out_last):
                      bn_prev.running_mean, bn_prev.running_var, float(bn_prev.momentum), st_prev.all,
                      conv.weight, conv.bias, C, z, z.stride(0), part_i)
         cur, part, bn_prev, st_prev = z, part_i, bn, ops.BnState(ar, "%s.bn%d" % (key, i), C)
+    if pool is not None:
+        # the last stage's BatchNorm + ReLU inside the frame-wise softmax pooling behind it (local.hip pool128_bn_act): the activated
+        # tensor is not stored
+        lin, vec, attn = pool
+        hip.call("pool128_bn_act", cur, cur.stride(0), rows, part, bn_prev.weight, bn_prev.bias, float(bn_prev.eps), bn_prev.running_mean,
+                 bn_prev.running_var, float(bn_prev.momentum), st_prev.all, lin.weight, lin.bias, vec, attn)
+        return None
     hip.call("mlp_bn_act", cur, cur.stride(0), rows, cur.shape[1], part, bn_prev.weight, bn_prev.bias, float(bn_prev.eps),
              bn_prev.running_mean, bn_prev.running_var, float(bn_prev.momentum), st_prev.all, out_last, out_last.stride(0))
     return out_last
@@ -116,11 +123,25 @@ def _mlp3_backward_fused(ar, key, mod, x, dy3, G, need_dx, have_sums=False, gath
     return dy if need_dx else None
 
 
-def mlp3_forward(ar, key, mod, x, out_last, training):
+_POOL_FUSED = os.environ.get("MMEGO_POOL_FUSED", "1") != "0"
+
+
+def pool128_fusable(mod, x, P, training):
+    """GlobalPointNet's pooling fused into the train-mode chain's last stage (and its backward): 128 points per frame, 64 channels,
+    the fused PointNet kernels in use, and a row count mlp_train's partition cuts into whole frame pairs."""
+    return bool(_POOL_FUSED and training and P == 128 and mod.conv3.weight.shape[0] == 64 and _mlp3_fused_train(mod, x)
+                and hip.lib().mmego_pool128_ok(x.shape[0]))
+
+
+def mlp3_forward(ar, key, mod, x, out_last, training, pool=None):
+    """pool = (attention Linear, vec, attn) with pool128_fusable(...): the softmax pooling behind the chain runs inside its last launch
+    (out_last is not written); returns None then."""
     rows = x.shape[0]
     cur = x
     if training and _mlp3_fused_train(mod, x) and out_last.stride(1) == 1:
-        return _mlp3_forward_fused(ar, key, mod, x, out_last)
+        return _mlp3_forward_fused(ar, key, mod, x, out_last, pool=pool)
+    if pool is not None:
+        raise ValueError("mlp3_forward: pool needs the fused train-mode chain (check pool128_fusable)")
     if not training:
         # eval: BatchNorm folded into the convs (bn_fold_linear), then the three stages in ONE kernel whose intermediates
         # stay in LDS (mlp3.hip) -- no pre-BN tensors, no per-point 32/48/64-channel activations in HBM
@@ -319,6 +340,22 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx, leaves
 # ---------------------------------------------------------------------------------------------------
 def attn_pool_forward(X, lin, G_, P, C, vec, attn):
     hip.call("attn_pool_forward", X, lin.weight, lin.bias, G_, P, C, vec, attn)
+
+
+def pool128_backward_fused(ar, key, mod, lin, attn, vec, dvec, rows, dY, G):
+    """Backward of the fused pooling (pool128_bn_act): row gradients with the activated rows recomputed from "<key>.z3", the stage's
+    BatchNorm sums into "<key>.gp3" (what _mlp3_backward_fused(have_sums=True) expects) and the attention parameter gradients."""
+    nblk = hip.lib().mmego_mlp_train_nblk(rows)
+    z3 = ar.get("%s.z3" % key, (rows, 64))
+    gp3 = ar.get("%s.gp3" % key, (nblk * 2 * 64,), dtype=torch.float64)
+    awp = ar.get("%s.awp" % key, (nblk, 128))
+    hip.call("pool128_backward", z3, 64, rows, ops.BnState(ar, "%s.bn3" % key, 64).all, attn, vec, dvec, lin.weight, dY, dY.stride(0), gp3, awp)
+    gw, gb = G(lin.weight).view(-1), G(lin.bias)
+    if gb.data_ptr() == gw.data_ptr() + 4 * gw.numel():       # weight and bias gradient slots back to back: one column sum
+        ops.colsum(awp[:, :65], torch.as_strided(gw, (65,), (1,)))
+    else:
+        ops.colsum(awp[:, :64], gw)
+        ops.colsum(awp[:, 64:65], gb)
 
 
 def attn_pool_backward(ar, key, X, lin, attn, dvec, G_, P, C, dX, G):

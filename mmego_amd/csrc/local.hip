@@ -640,6 +640,161 @@ __global__ __launch_bounds__(P8_NT) void pool8_bwd_kernel(Pool8BwdP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The same two fusions for GlobalPointNet's pooling over the 128 points of a frame (Upper_Net.py:285-301): a workgroup of 8 waves
+// takes the 2 frames (256 rows) mlp_train.hip's partition gives it, 4 waves per frame.
+//   pool128_bn_act   y = relu(BN(z3)) (statistics finalized in the prologue), score, softmax over the frame's 128 rows, pooled
+//                    vector: replaces mlp_bn_act + attn_pool_forward (the activated 64-channel tensor, 16.8 MB at the bench shape,
+//                    is neither written nor read)
+//   pool128_bwd      row gradients with y recomputed, the stage's BatchNorm sums, attention parameter partials: replaces
+//                    attn_pool_backward + 2 column sums + mlp_bn_bwd_reduce
+#define P128_TS 65
+struct Pool128P {
+  const float* Z; long ldz; long rows;
+  const double* part; int nblk; const float* gamma; const float* beta; float eps; float* rmean; float* rvar; float momentum; float* state;
+  const float* aw_w; const float* aw_b;
+  float* vec;                                            // [F][64]
+  float* attn;                                           // [rows]
+};
+
+__global__ __launch_bounds__(P8_NT) void pool128_bn_act_kernel(Pool128P p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float (*sm)[64] = reinterpret_cast<float (*)[64]>(smem);                        // [4][64]
+  double (*red)[2][64] = reinterpret_cast<double (*)[2][64]>(smem + 256);         // [8][2][64]
+  float* tiles = smem + 256 + 2 * 8 * 2 * 64;                                     // [2 frames][128][P128_TS]
+  float* aux = tiles + 2 * 128 * P128_TS;                                         // per frame: at [128], red4 [4][64], mx[2], sx[2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = wave >> 2, w4 = wave & 3;
+  float* T = tiles + fr * 128 * P128_TS;
+  float* at_s = aux + fr * (128 + 256 + 8);
+  float* vred = at_s + 128;
+  float* mred = vred + 256;
+  const long f = (long)blockIdx.x * 2 + fr;
+  const long F = p.rows / 128;
+  const float wv = p.aw_w[lane], bsc = p.aw_b[0];
+  // the frame's rows: requested before the statistics prologue (wave w4 takes rows 32 w4 .. 32 w4 + 31)
+  float z[32];
+  const long r0 = (f < F ? f : F - 1) * 128 + 32 * w4;
+#pragma unroll
+  for (int u = 0; u < 32; ++u) z[u] = p.Z[(r0 + u) * p.ldz + lane];
+  p8_finalize<P8_NT / 64>(p.part, p.nblk, p.rows, p.gamma, p.beta, p.eps, p.rmean, p.rvar, p.momentum, p.state, sm, red);
+  const float mu = sm[0][lane], aa = sm[1][lane], bb = sm[2][lane];
+#pragma unroll
+  for (int u = 0; u < 32; ++u) T[(32 * w4 + u) * P128_TS + lane] = fmaxf(__builtin_fmaf(z[u] - mu, aa, bb), 0.f);
+  __syncthreads();
+  // scores: waves 0 / 1 of the frame take rows 0..63 / 64..127 (lane = row)
+  float sc = 0.f;
+  if (w4 < 2) {
+    sc = bsc;
+    const float* tr = T + (64 * w4 + lane) * P128_TS;
+#pragma unroll 16
+    for (int c = 0; c < 64; ++c) sc = __builtin_fmaf(tr[c], lane_of(wv, c), sc);
+    const float m = wave_max(sc);
+    if (lane == 0) mred[w4] = m;
+  }
+  __syncthreads();
+  if (w4 < 2) {
+    const float mx = fmaxf(mred[0], mred[1]);
+    const float ex = expf(sc - mx);
+    at_s[64 * w4 + lane] = ex;
+    const float sx = wave_sum(ex);
+    if (lane == 0) mred[2 + w4] = sx;
+  }
+  __syncthreads();
+  const float inv = 1.0f / (mred[2] + mred[3]);
+  if (w4 < 2 && f < F) p.attn[f * 128 + 64 * w4 + lane] = at_s[64 * w4 + lane] * inv;
+  // pooled vector: lane = channel, wave w4 sums its 32 rows; the four partial sums are added in wave order
+  float o = 0.f;
+#pragma unroll 8
+  for (int u = 0; u < 32; ++u) o = __builtin_fmaf(at_s[32 * w4 + u] * inv, T[(32 * w4 + u) * P128_TS + lane], o);
+  vred[w4 * 64 + lane] = o;
+  __syncthreads();
+  if (w4 == 0 && f < F) p.vec[f * 64 + lane] = ((vred[lane] + vred[64 + lane]) + vred[128 + lane]) + vred[192 + lane];
+}
+
+struct Pool128BwdP {
+  const float* Z; long ldz; long rows; const float* state; const float* attn; const float* vec; const float* dvec; const float* aw_w;
+  float* dY; long lddy; double* gpart; float* awpart;
+};
+
+__global__ __launch_bounds__(P8_NT) void pool128_bwd_kernel(Pool128BwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  double (*red)[2][64] = reinterpret_cast<double (*)[2][64]>(smem);               // [8][2][64]
+  float* dwred = smem + 2 * 8 * 2 * 64;                                           // [8][65]
+  float* tiles = dwred + 8 * 65 + 3;                                              // [2][128][P128_TS]
+  float* aux = tiles + 2 * 128 * P128_TS;                                         // per frame: at [128], ds [128], dv [64], tv [4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = wave >> 2, w4 = wave & 3;
+  float* T = tiles + fr * 128 * P128_TS;
+  float* at_s = aux + fr * (128 + 128 + 64 + 4);
+  float* ds_s = at_s + 128;
+  float* dv_s = ds_s + 128;
+  float* tv_s = dv_s + 64;
+  const long F = p.rows / 128;
+  const long f = (long)blockIdx.x * 2 + fr;
+  const bool in = f < F;
+  const long fc = in ? f : F - 1;
+  const float mu = p.state[lane], is = p.state[64 + lane], aa = p.state[128 + lane], bb = p.state[192 + lane], wv = p.aw_w[lane];
+  float z[32];
+  const long r0 = fc * 128 + 32 * w4;
+#pragma unroll
+  for (int u = 0; u < 32; ++u) z[u] = p.Z[(r0 + u) * p.ldz + lane];
+  const float dv = p.dvec[fc * 64 + lane], vc = p.vec[fc * 64 + lane];
+  if (w4 < 2) at_s[64 * w4 + lane] = p.attn[fc * 128 + 64 * w4 + lane];
+  if (w4 == 2) dv_s[lane] = dv;
+  const float tvv = wave_sum(dv * vc);                   // dvec . vec (every wave of the frame computes the same value)
+#pragma unroll
+  for (int u = 0; u < 32; ++u) T[(32 * w4 + u) * P128_TS + lane] = fmaxf(__builtin_fmaf(z[u] - mu, aa, bb), 0.f);
+  __syncthreads();
+  float dbacc = 0.f;
+  if (w4 < 2) {                                          // lane = row: t_j = dvec . y_j;  ds_j = a_j (t_j - tv)
+    const float* tr = T + (64 * w4 + lane) * P128_TS;
+    float tj = 0.f;
+#pragma unroll 16
+    for (int c = 0; c < 64; ++c) tj = __builtin_fmaf(tr[c], dv_s[c], tj);
+    const float ds = in ? at_s[64 * w4 + lane] * (tj - tvv) : 0.f;
+    ds_s[64 * w4 + lane] = ds;
+    dbacc = ds;
+  }
+  __syncthreads();
+  // lane = channel, this wave's 32 rows: dy = a_j dvec[c] + ds_j w[c]; BatchNorm sums through the ReLU mask; attention weight gradient
+  float s1f = 0.f, s2f = 0.f, dwacc = 0.f;
+  float dy[32];
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const int j = 32 * w4 + u;
+    const float aj = in ? at_s[j] : 0.f, dsj = ds_s[j];
+    dy[u] = __builtin_fmaf(aj, dv, dsj * wv);
+    const float y = T[j * P128_TS + lane];
+    dwacc = __builtin_fmaf(dsj, y, dwacc);
+    const float gq = y > 0.f ? dy[u] : 0.f;
+    s1f += gq;
+    s2f = __builtin_fmaf(gq, (z[u] - mu) * is, s2f);
+  }
+  if (in) {
+#pragma unroll
+    for (int u = 0; u < 32; ++u) p.dY[(r0 + u) * p.lddy + lane] = dy[u];
+  }
+  const float dbw = wave_sum(dbacc);
+  red[wave][0][lane] = (double)s1f; red[wave][1][lane] = (double)s2f;
+  dwred[wave * 65 + lane] = dwacc;
+  if (lane == 0) dwred[wave * 65 + 64] = dbw;
+  __syncthreads();
+  if (tid < 128) {
+    const int c = tid & 63, k = tid >> 6;
+    double s = red[0][k][c];
+#pragma unroll
+    for (int q = 1; q < P8_NT / 64; ++q) s += red[q][k][c];
+    p.gpart[((long)blockIdx.x * 2 + k) * 64 + c] = s;
+  } else if (tid < 128 + 65) {
+    const int c = tid - 128;
+    float s = dwred[c];
+#pragma unroll
+    for (int q = 1; q < P8_NT / 64; ++q) s += dwred[q * 65 + c];
+    p.awpart[(long)blockIdx.x * 128 + c] = s;
+  } else if (tid < 256) {
+    p.awpart[(long)blockIdx.x * 128 + (tid - 128)] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // dfeats[f][p][0:3+D] += sum over the slots with idx == p of dgrouped[slot][3:6+D]  (slot order: deterministic)
 __global__ __launch_bounds__(256) void anchor_scatter_kernel(const float* __restrict__ dgrouped, const long long* __restrict__ idx,
                                                              int N, int D, float* __restrict__ dxf, long lddx, long F) {
@@ -804,6 +959,53 @@ extern "C" int mmego_pool8_backward(void* stream, const float* Z, long ldz, long
     attr = true;
   }
   hipLaunchKernelGGL(pool8_bwd_kernel, dim3(nblk), dim3(P8_NT), lds, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// GlobalPointNet's pooling fused with the last stage's BatchNorm + ReLU (forward) / with the stage's BatchNorm sums and the attention
+// parameter partials (backward): rows = F * 128, two frames per workgroup = mlp_train.hip's partition of 256-row rounds (requires
+// mmego_mlp_train_nblk(rows) == rows / 256, i.e. rows <= 65 536: larger batches take the separate launches).
+extern "C" int mmego_pool128_ok(long rows) {
+  int nblk; long rpw;
+  p8_grid(rows > 0 ? rows : 1, &nblk, &rpw);
+  return rows > 0 && (rows % 256) == 0 && rpw == 256 ? 1 : 0;
+}
+
+extern "C" int mmego_pool128_bn_act(void* stream, const float* Z, long ldz, long rows, const double* part, const float* gamma,
+                                    const float* beta, double eps, float* rmean, float* rvar, double momentum, float* state,
+                                    const float* aw_w, const float* aw_b, float* vec, float* attn) {
+  MMEGO_REQUIRE(Z && part && gamma && beta && aw_w && aw_b && vec && attn && mmego_pool128_ok(rows) && ldz >= 64);
+  int nblk; long rpw;
+  p8_grid(rows, &nblk, &rpw);
+  Pool128P p = {Z, ldz, rows, part, nblk, gamma, beta, (float)eps, rmean, rvar, (float)momentum, state, aw_w, aw_b, vec, attn};
+  const size_t lds = (size_t)(256 + 2 * 8 * 2 * 64 + 2 * 128 * P128_TS + 2 * (128 + 256 + 8)) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)pool128_bn_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(pool128_bn_act_kernel, dim3(nblk), dim3(P8_NT), lds, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_pool128_backward(void* stream, const float* Z, long ldz, long rows, const float* state, const float* attn,
+                                      const float* vec, const float* dvec, const float* aw_w, float* dY, long lddy, double* gpart,
+                                      float* awpart) {
+  MMEGO_REQUIRE(Z && state && attn && vec && dvec && aw_w && dY && gpart && awpart && mmego_pool128_ok(rows) && ldz >= 64 && lddy >= 64);
+  int nblk; long rpw;
+  p8_grid(rows, &nblk, &rpw);
+  Pool128BwdP p = {Z, ldz, rows, state, attn, vec, dvec, aw_w, dY, lddy, gpart, awpart};
+  const size_t lds = (size_t)(2 * 8 * 2 * 64 + 8 * 65 + 3 + 2 * 128 * P128_TS + 2 * (128 + 128 + 64 + 4)) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)pool128_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(pool128_bwd_kernel, dim3(nblk), dim3(P8_NT), lds, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -255,8 +255,13 @@ class UpperNet(_NetBase):
             ops.copy2d(pts[:, :4], feats[:, :4])
         blocks.mlp3_forward(ar, "m0", self.module0, pts, feats[:, 4:28], training)
         g3 = ar.get("g3", (rows, 64))
-        blocks.mlp3_forward(ar, "gp", self.module1.gpointnet, feats, g3, training)
-        blocks.attn_pool_forward(g3, self.module1.gpointnet.attn, F, N, 64, vec, attn)
+        gpn = self.module1.gpointnet
+        self._gpool_fused = bool(stash and blocks.pool128_fusable(gpn, feats, N, training))
+        if self._gpool_fused:       # the pooling inside the chain's last launch: g3 (the activated rows) is never stored
+            blocks.mlp3_forward(ar, "gp", gpn, feats, g3, training, pool=(gpn.attn, vec, attn))
+        else:
+            blocks.mlp3_forward(ar, "gp", gpn, feats, g3, training)
+            blocks.attn_pool_forward(g3, gpn.attn, F, N, 64, vec, attn)
         return self._forward_tail(ar, vec, attn, B, T, N, h0, c0, body, R, t, stash, training)
 
     def _front_fusable(self, Cx, N):
@@ -318,9 +323,14 @@ class UpperNet(_NetBase):
         blocks.run_leaves(leaves)
         g3 = ar.get("g3", (rows, 64))
         dg3 = ar.get("dg3", (rows, 64))
-        blocks.attn_pool_backward(ar, "gpool", g3, self.module1.gpointnet.attn, attn, dvec, F, N, 64, dg3, G)
         feats = ar.get("feats", (rows, 28))
-        dfeats = blocks.mlp3_backward(ar, "gp", self.module1.gpointnet, feats, g3, dg3, G, True)
+        gpn = self.module1.gpointnet
+        if getattr(self, "_gpool_fused", False):
+            blocks.pool128_backward_fused(ar, "gp", gpn, gpn.attn, attn, vec, dvec, rows, dg3, G)
+            dfeats = blocks._mlp3_backward_fused(ar, "gp", gpn, feats, dg3, G, True, have_sums=True)
+        else:
+            blocks.attn_pool_backward(ar, "gpool", g3, gpn.attn, attn, dvec, F, N, 64, dg3, G)
+            dfeats = blocks.mlp3_backward(ar, "gp", gpn, feats, g3, dg3, G, True)
         pts = ar.get("pts", (rows, 6))
         blocks.mlp3_backward(ar, "m0", self.module0, pts, feats[:, 4:28], dfeats[:, 4:28], G, False)
 

@@ -142,10 +142,15 @@ class UpperNetwlocal(_NetBase):
         blocks.mlp3_forward(ar, "m0", self.module0, pts, feats[:, 4:28], training)
         # global branch
         g3 = ar.get("g3", (rows, 64))
-        blocks.mlp3_forward(ar, "gp", self.module1.gpointnet, feats, g3, training)
         vec = ar.get("vec", (F, 64))
         gw = torch.empty((F, N, 1), dtype=torch.float32, device=dev)
-        blocks.attn_pool_forward(g3, self.module1.gpointnet.attn, F, N, 64, vec, gw)
+        gpn = self.module1.gpointnet
+        self._gpool_fused = bool(stash and blocks.pool128_fusable(gpn, feats, N, training))
+        if self._gpool_fused:       # the pooling inside the chain's last launch: g3 (the activated rows) is never stored
+            blocks.mlp3_forward(ar, "gp", gpn, feats, g3, training, pool=(gpn.attn, vec, gw))
+        else:
+            blocks.mlp3_forward(ar, "gp", gpn, feats, g3, training)
+            blocks.attn_pool_forward(g3, gpn.attn, F, N, 64, vec, gw)
         p_g = self._drop_p(self.module1.grnn) if stash else 0.0
         cat = ar.get("cat", (F, 256))
         seq_g, hn_g, cn_g = blocks.lstm64_forward(ar, "grnn", self.module1.grnn, vec, B, T, h0g, c0g, stash, p_g, self.seed_counter())
@@ -232,9 +237,14 @@ class UpperNetwlocal(_NetBase):
         vec = ar.get("vec", (F, 64))
         dvec = blocks.lstm64_backward(ar, "grnn", self.module1.grnn, vec, B, T, c0g, dcat[:, :128], G, self._drop_p(self.module1.grnn), True)
         g3, dg3 = ar.get("g3", (rows, 64)), ar.get("dg3", (rows, 64))
-        blocks.attn_pool_backward(ar, "gpool", g3, self.module1.gpointnet.attn, gw, dvec, F, N, 64, dg3, G)
         feats = ar.get("feats", (rows, 28))
-        dfeats = blocks.mlp3_backward(ar, "gp", self.module1.gpointnet, feats, g3, dg3, G, True)
+        gpn = self.module1.gpointnet
+        if getattr(self, "_gpool_fused", False):
+            blocks.pool128_backward_fused(ar, "gp", gpn, gpn.attn, gw, vec, dvec, rows, dg3, G)
+            dfeats = blocks._mlp3_backward_fused(ar, "gp", gpn, feats, dg3, G, True, have_sums=True)
+        else:
+            blocks.attn_pool_backward(ar, "gpool", g3, gpn.attn, gw, dvec, F, N, 64, dg3, G)
+            dfeats = blocks.mlp3_backward(ar, "gp", gpn, feats, g3, dg3, G, True)
         # local branch
         vvec = ar.get("vvec", (F, 64))
         dvvec = blocks.lstm64_backward(ar, "arnn", self.module2.arnn.rnn, vvec, B, T, c0a, dcat[:, 128:], G,

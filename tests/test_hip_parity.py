@@ -881,3 +881,42 @@ def test_gcn_fused_training_step_equals_the_launch_chain(dev):
             assert (g0[k] - g1[k]).abs().max().item() < 2e-5 * scale, (k, (g0[k] - g1[k]).abs().max().item(), scale)
         for k in b0:
             assert (b0[k].double() - b1[k].double()).abs().max().item() < 1e-5 * max(1.0, b0[k].double().abs().max().item()), k
+
+
+def test_fused_pooling_in_the_pointnet_chain_equals_the_separate_launches(dev):
+    """pool128_bn_act / pool128_backward (GlobalPointNet's last BatchNorm + ReLU inside the softmax pooling, and the pooling's backward
+    with the stage's BatchNorm sums and the attention partials) against mlp_bn_act + attn_pool_forward / attn_pool_backward + column
+    sums + mlp_bn_bwd_reduce (MMEGO_POOL_FUSED=0) on the same Upper_Net: outputs, attention weights, every gradient, running statistics."""
+    from mmego_amd import blocks, nets
+    g = torch.Generator().manual_seed(13)
+    Bq, Tq = 4, 6
+    x = torch.randn(Bq, Tq, 128, 6, generator=g) * 0.5
+    x[:, :, 80:] = 0.0
+    body = 0.2 * torch.randn(Bq, 20, 3, generator=g)
+    R = torch.linalg.qr(torch.randn(Bq, Tq, 3, 3, generator=g))[0].contiguous()
+    t = torch.randn(Bq, Tq, 3, generator=g) * 0.1
+    target = torch.randn(Bq, Tq, 15, 3, generator=g)
+    h0 = torch.zeros(6, Bq, 64)
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(5)
+        net = nets.UpperNet().to(dev).train()
+        net.lstm_dropout = 0.0
+        was = blocks._POOL_FUSED
+        blocks._POOL_FUSED = fused
+        try:
+            out = net(x.clone().to(dev), h0.to(dev), h0.to(dev), body.to(dev), R.to(dev), t.to(dev))
+            (out[0] - target.to(dev)).abs().sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            blocks._POOL_FUSED = was
+        assert net._gpool_fused == fused
+        res.append((out[0].detach().cpu(), out[2].detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()},
+                    {k: v.detach().cpu().clone() for k, v in net.named_buffers()}))
+    (l1, a1, g1, b1), (l0, a0, g0, b0) = res
+    assert (l1 - l0).abs().max().item() < 2e-5 and (a1 - a0).abs().max().item() < 1e-6
+    scale = max(v.abs().max().item() for v in g0.values())
+    for k in g0:
+        assert (g1[k] - g0[k]).abs().max().item() < 2e-5 * scale, (k, (g1[k] - g0[k]).abs().max().item(), scale)
+    for k in b0:
+        assert (b1[k].double() - b0[k].double()).abs().max().item() < 1e-5 * max(1.0, b0[k].double().abs().max().item()), k
