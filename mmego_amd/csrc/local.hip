@@ -64,11 +64,15 @@ struct LocalGroupP {
 
 // One frame: rows -> LDS, the 27 x N squared distances, the 8 nearest points per anchor (sidx), the int64 indices stored, and the
 // gathered rows cat(anchor, xyz - anchor, features) built in the LDS tile gs [224][LG_GS] (zero padded).  Ends with a barrier.
-template <int NKEY>
-__device__ __forceinline__ void lg_group_frame(const float* __restrict__ feats, long ldf, int N, int D, long f, float* fs, float* dist,
+// DD >= 0: the feature count as a compile-time constant (with N = 64 NKEY every index division becomes a multiplication)
+template <int NKEY, int DD>
+__device__ __forceinline__ void lg_group_frame(const float* __restrict__ feats, long ldf, int N_, int D_, long f, float* fs, float* dist,
                                                float* gs, const float* an, int* sidx, long long* __restrict__ idxo,
                                                float* __restrict__ dist_out) {
+  constexpr int N = 64 * NKEY;
+  const int D = DD >= 0 ? DD : D_;
   const int W = 6 + D, FS = 3 + D;
+  (void)N_;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- the frame's rows -> LDS (every load in flight before the first LDS store)
   {
@@ -138,10 +142,11 @@ __device__ __forceinline__ void lg_group_frame(const float* __restrict__ feats, 
 }
 
 // NKEY = N / 64 keys per lane
-template <int NKEY>
+template <int NKEY, int DD>
 __global__ __launch_bounds__(LG_NT) void local_group_l1_kernel(LocalGroupP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int N = p.N, D = p.D, W = 6 + D, FS = 3 + D;     // FS: floats per point row kept in LDS (xyz + features)
+  constexpr int N = 64 * NKEY;
+  const int D = DD >= 0 ? DD : p.D, W = 6 + D, FS = 3 + D;     // FS: floats per point row kept in LDS (xyz + features)
   float* fs = sm;                                        // [N][FS] the frame's rows
   float* dist = fs + ((N * FS + 3) & ~3);                // [27][N]
   float* gs = dist + NA * N;                             // [224][LG_GS] gathered rows, later the z1 tile
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(LG_NT) void local_group_l1_kernel(LocalGroupP p) {
   double s1 = 0.0, s2 = 0.0;                             // this lane's column sums of z1 over the workgroup's frames
   for (long f = blockIdx.x; f < p.F; f += gridDim.x) {
     __syncthreads();
-    lg_group_frame<NKEY>(p.feats, p.ldf, N, D, f, fs, dist, gs, an, sidx, p.idx, p.dist_out);
+    lg_group_frame<NKEY, DD>(p.feats, p.ldf, N, D, f, fs, dist, gs, an, sidx, p.idx, p.dist_out);
     if (p.grouped) {
       float* g = p.grouped + f * (long)NSLOT * W;
       for (int i = tid; i < NSLOT * W; i += LG_NT) g[i] = gs[(i / W) * LG_GS + i % W];
@@ -388,10 +393,11 @@ __device__ __forceinline__ f32x16 le_tile(const float* A, int SA, const float* B
   return acc;
 }
 
-template <int NKEY>
+template <int NKEY, int DD>
 __global__ __launch_bounds__(LG_NT) void local_front_eval_kernel(LocalEvalP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int N = p.N, D = p.D, W = 6 + D, FS = 3 + D;
+  constexpr int N = 64 * NKEY;
+  const int D = DD >= 0 ? DD : p.D, W = 6 + D, FS = 3 + D;
   // the activation tile t2 [224][LE_TS] shares its LDS with the frame rows and the distance matrix (dead once the rows are gathered)
   float* t2 = sm;
   float* fs = sm;
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(LG_NT) void local_front_eval_kernel(LocalEvalP p) {
   }
   for (long f = blockIdx.x; f < p.F; f += gridDim.x) {
     __syncthreads();
-    lg_group_frame<NKEY>(p.feats, p.ldf, N, D, f, fs, dist, gs, an, sidx, p.idx, nullptr);
+    lg_group_frame<NKEY, DD>(p.feats, p.ldf, N, D, f, fs, dist, gs, an, sidx, p.idx, nullptr);
     // ---- stage 1: gathered [224][32] -> t2 columns 0..31 (K = 32)
     for (int t = wave; t < 7; t += 4) {
       const f32x16 acc = le_tile(gs + t * 32 * LG_GS, LG_GS, w1, LG_GS, 32, r, h);
@@ -857,15 +863,14 @@ extern "C" int mmego_local_group_l1(void* stream, const float* feats, long ldf, 
   do {                                                                                                                  \
     static size_t attr = 0;                                                                                             \
     if (lds > 64 * 1024 && lds > attr) {                                                                                \
-      hipError_t e = hipFuncSetAttribute((const void*)local_group_l1_kernel<NK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipError_t e = hipFuncSetAttribute((const void*)local_group_l1_kernel<NK_, DD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                                               \
       attr = lds;                                                                                                       \
     }                                                                                                                   \
-    hipLaunchKernelGGL((local_group_l1_kernel<NK_>), grid, dim3(LG_NT), lds, st, p);                                    \
+    hipLaunchKernelGGL((local_group_l1_kernel<NK_, DD_>), grid, dim3(LG_NT), lds, st, p);                               \
   } while (0)
-  if (N == 64) LG_LAUNCH(1);
-  else if (N == 128) LG_LAUNCH(2);
-  else LG_LAUNCH(4);
+  if (N == 128 && D == 25) { constexpr int DD_ = 25; LG_LAUNCH(2); }       // (the reference's shape: constants folded)
+  else { constexpr int DD_ = -1; if (N == 64) LG_LAUNCH(1); else if (N == 128) LG_LAUNCH(2); else LG_LAUNCH(4); }
 #undef LG_LAUNCH
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
@@ -897,15 +902,14 @@ extern "C" int mmego_local_front_eval(void* stream, const float* feats, long ldf
   do {                                                                                                                  \
     static size_t attr = 0;                                                                                             \
     if (lds > 64 * 1024 && lds > attr) {                                                                                \
-      hipError_t e = hipFuncSetAttribute((const void*)local_front_eval_kernel<NK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipError_t e = hipFuncSetAttribute((const void*)local_front_eval_kernel<NK_, DD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return (int)e;                                                                               \
       attr = lds;                                                                                                       \
     }                                                                                                                   \
-    hipLaunchKernelGGL((local_front_eval_kernel<NK_>), grid, dim3(LG_NT), lds, st, p);                                  \
+    hipLaunchKernelGGL((local_front_eval_kernel<NK_, DD_>), grid, dim3(LG_NT), lds, st, p);                             \
   } while (0)
-  if (N == 64) LE_LAUNCH(1);
-  else if (N == 128) LE_LAUNCH(2);
-  else LE_LAUNCH(4);
+  if (N == 128 && D == 25) { constexpr int DD_ = 25; LE_LAUNCH(2); }
+  else { constexpr int DD_ = -1; if (N == 64) LE_LAUNCH(1); else if (N == 128) LE_LAUNCH(2); else LE_LAUNCH(4); }
 #undef LE_LAUNCH
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
