@@ -541,6 +541,7 @@ def config5_forward(device):
     imu_net = nets.IMUNet(15, 9, H, 2, True, 0.1).to(device).eval()
     imu_net.precision = "bf16"
     up, lo = nets.UpperNet().to(device).eval(), nets.LowerNet(64).to(device).eval()
+    up.precision = lo.precision = "bf16"
     x0, _, _, body, imu_in = [v.to(device) for v in _synth_points(Bq, Tq, Nq, 55)]
     h0 = torch.zeros(6, Bq, 64, device=device)
 
@@ -588,8 +589,9 @@ def config5_forward(device):
     # algorithmic FLOPs of the forward (SURVEY 8-d per-frame figures: IMU 444.96, Upper 2.15, Lower 9.26 MFLOP at N=128; the
     # per-point part of Upper/Lower doubles at N=256 and stays < 3 % of the total)
     fl = (444.96e6 + 2.15e6 + 9.26e6) * Bq * Tq
-    res = {"workload": "IMU_Net -> Upper_Net -> Lower_Net eval forward, B=2048 T=16 N=256, IMU BiLSTM products bf16 operands / "
-                       "fp32 accumulation, everything else fp32", "ms_per_forward": ms, "frames_per_s": Bq * Tq / (ms * 1e-3),
+    res = {"workload": "IMU_Net -> Upper_Net -> Lower_Net eval forward, B=2048 T=16 N=256, precision = 'bf16' on all three nets: "
+                       "IMU_Net's BiLSTM products and Lower_Net's ST-GCN products (1x1 and temporal convs) on bf16 operands with fp32 "
+                       "accumulation, everything else fp32", "ms_per_forward": ms, "frames_per_s": Bq * Tq / (ms * 1e-3),
            "algorithmic_tflops": fl / (ms * 1e-3) / 1e12, "frac_of_bf16_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
            "outputs_finite": finite, "dominant_kernel": k}
     del imu_net, up, lo, x0, imu_in

@@ -501,6 +501,27 @@ int mmego_tconv_seq_train(void* stream, const float* X, long ldx, const void* in
                           long ldy, float* act, float* out_rec, int B, int T, int V, int Cin, int Cout, int taps);
 int mmego_tconv_seq_bwd(void* stream, const float* dY, long lddy, const float* Wf, float* dAct, long ldda, const float* ymix,
                         long ldym, const float* state, float* bw_rec, int B, int T, int V, int Cin, int Cout, int taps);
+/* Eval-mode ST-GCN block with bf16 operands and fp32 accumulation (opt-in precision mode; csrc/gcn_bf16.hip; reference
+ * Net/GCN.py:55-64,67-147 with the BatchNorms frozen).  A block = mmego_gcn_mix_eval_bf16 + mmego_tconv_eval_bf16:
+ *   gcn_mix: Yact = bf16(relu(bn0(einsum(conv1x1(X), A . importance)))), Rn = bn_r(residual conv1x1(X)) in fp32; the einsum is applied
+ *     to X in fp32 in front of the product (exact in real arithmetic), the product's k axis is [A_0^T X | A_1^T X | A_2^T X | X].
+ *     Wy / Wr: the two weights in bf16, fragment-major [Cout / 32][k steps][64 lanes][8] with lane (n, hf) of step ks holding
+ *     W[32 ct + n][16 ks + 8 hf .. + 8] over the k axis above (Wy: rows of the graph conv, zero over X's columns, steps [0, ksy);
+ *     Wr: the residual conv, zero elsewhere, steps [kr0, kr0 + ksr); ksy = ceil(K Cin / 16), kr0 = floor(K Cin / 16), kr0 + ksr =
+ *     ceil((K + 1) Cin / 16)); biasy [V][Cout] = sum_k
+ *     colsum_v((A . importance)[k])[w] b_k[c]; in_state: [4][V Cin] state of data_bn applied while loading (first block) or NULL;
+ *     st0 / st_r: [4][Cout] mean, invstd, a, b.
+ *   tconv: Y = relu?(bn?(bias + temporal conv of X (bf16, activated)) + res); Wp from mmego_tconv_pack_bf16 (taps * Cout * Cin bf16);
+ *     one workgroup per sequence, (T + taps - 1) V rows of LDS (mmego_tconv_eval_bf16_ok). */
+int mmego_gcn_mix_eval_bf16_ok(int V, int Cin, int Cout, int K);
+int mmego_gcn_mix_eval_bf16(void* stream, const float* X, const float* in_state, const float* A, const float* importance,
+                            const unsigned short* Wy, const unsigned short* Wr, const float* biasy, const float* biasr,
+                            const float* st0, const float* st_r, unsigned short* Yact, float* Rn, long F, int V, int Cin, int Cout,
+                            int K);
+int mmego_tconv_eval_bf16_ok(int T, int V, int Cin, int Cout, int taps);
+int mmego_tconv_eval_bf16(void* stream, const unsigned short* X, const unsigned short* Wp, const float* bias, const float* post,
+                          const float* res, long ldr, float* Y, long ldy, int relu, int B, int T, int V, int Cin, int Cout, int taps);
+int mmego_tconv_pack_bf16(void* stream, const float* W, int Cout, int Cin, int taps, unsigned short* Wp);
 typedef struct MmegoPack { const float* W; float* Wp; int Co, Ci, taps, kind; } MmegoPack;
 int mmego_pack_multi(void* stream, int n, const void* descs);
 /* Backward of a block's closing pair out = relu(BN(X1) + BN(X2)) (same dY, mask = out): reduce -> rec [ceil(rows/64)][2C] (sum g, sum

@@ -47,6 +47,14 @@ class _NetBase(nn.Module):
         self._arenas = {}
         self._seed = None
         self.lstm_dropout = None      # None -> use the LstmParams.dropout value in training mode
+        # "fp32" (default, the parity path) or "bf16": EVAL forwards run their dense products with bf16 operands and fp32
+        # accumulation where a kernel for it exists (BASELINE config 5; training always runs fp32)
+        self.precision = os.environ.get("MMEGO_EVAL_PRECISION", "fp32")
+
+    def _bf16_eval(self, training):
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError("%s.precision must be 'fp32' or 'bf16', got %r" % (type(self).__name__, self.precision))
+        return self.precision == "bf16" and not training
 
     # -- storage -------------------------------------------------------------------------------
     def flat(self):
@@ -605,6 +613,79 @@ class LowerNet(_NetBase):
         hip.call("gcn_front", d)
         return kv.view(F * V, 64)
 
+    # -- eval-mode ST-GCN with bf16 operands (gcn_bf16.hip) ------------------------------------------
+    def _gcn_bf16_ok(self, B, T):
+        gcn = self.keyEncoder.gcn
+        V, lib = JOINTS_UPPER, hip.lib()
+        ok = gcn.A.is_contiguous() and gcn.A.shape[1] == V
+        for blk in gcn.gcn_networks:
+            ok = ok and bool(lib.mmego_gcn_mix_eval_bf16_ok(V, blk.cin, blk.cout, blk.K))
+            ok = ok and bool(lib.mmego_tconv_eval_bf16_ok(T, V, blk.cout, blk.cout, blk.taps))
+        return bool(ok)
+
+    def _gcn_pack_bf16(self):
+        """Everything the bf16 eval blocks read besides activations, built once per weight version: the 1x1 weights as bf16
+        fragment-major matrices over the k axis [A_0^T X | A_1^T X | A_2^T X | X] (include/mmego_hip.h), the einsum's bias table,
+        the temporal weights in their chunk order, the frozen BatchNorms as [4][C] states (mean, invstd, a, b)."""
+        gcn = self.keyEncoder.gcn
+        src = list(gcn.parameters()) + list(gcn.buffers())
+        ver = tuple((t._version, t.data_ptr()) for t in src)
+        ent = self.__dict__.get("_gcn_bf16_pack")
+        if ent is not None and ent[0] == ver:
+            return ent[1]
+        dev = gcn.A.device
+
+        def state(bn):
+            C = bn.weight.numel()
+            st = torch.empty((4, C), dtype=torch.float32, device=dev)
+            hip.call("bn_eval_affine", C, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), st[0], st[1], st[2], st[3])
+            return st
+
+        def frag(Wm):                                          # [cout][16 ns] fp32 -> bf16 [cout / 32][ns][lane half][32][8]
+            co, kd = Wm.shape
+            return Wm.to(torch.bfloat16).view(co // 32, 32, kd // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+        with torch.no_grad():
+            pk = {"dbn": state(gcn.data_bn), "blocks": []}
+            for i, blk in enumerate(gcn.gcn_networks):
+                cin, cout, K = blk.cin, blk.cout, blk.K
+                kd = ((K + 1) * cin + 15) // 16 * 16
+                ksy, kr0 = (K * cin + 15) // 16, (K * cin) // 16
+                Wcat = torch.zeros((cout, kd), dtype=torch.float32, device=dev)
+                Wcat[:, :K * cin] = blk.gcn.conv.weight.view(K, cout, cin).permute(1, 0, 2).reshape(cout, K * cin)
+                Wy = Wcat[:, :ksy * 16].clone()
+                Wcat.zero_()
+                Wcat[:, K * cin:(K + 1) * cin] = blk.residual["0"].weight.view(cout, cin)
+                Wr = Wcat[:, kr0 * 16:].clone()
+                AI = gcn.A * gcn.edge_importance[i]
+                biasy = torch.einsum("kw,kc->wc", AI.sum(dim=1), blk.gcn.conv.bias.view(K, cout)).contiguous()
+                wt = blk.tcn["2"].weight
+                Wt = torch.empty(wt.numel(), dtype=torch.bfloat16, device=dev)
+                hip.call("tconv_pack_bf16", wt.contiguous(), cout, cout, blk.taps, Wt)
+                pk["blocks"].append({"Wy": frag(Wy), "Wr": frag(Wr), "biasy": biasy, "biasr": blk.residual["0"].bias.detach().clone(),
+                                     "st0": state(blk.tcn["0"]), "st3": state(blk.tcn["3"]), "st_r": state(blk.residual["1"]),
+                                     "Wt": Wt, "bt": blk.tcn["2"].bias.detach().clone()})
+        self.__dict__["_gcn_bf16_pack"] = (ver, pk)
+        return pk
+
+    def _gcn_forward_bf16(self, ar, up, B, T):
+        """Eval forward of the three ST-GCN blocks in six launches, dense products on bf16 operands (gcn_bf16.hip)."""
+        gcn = self.keyEncoder.gcn
+        V = JOINTS_UPPER
+        F, rows = B * T, B * T * V
+        pk = self._gcn_pack_bf16()
+        cur, in_state = _f32c(up).view(F, -1), pk["dbn"]
+        for i, blk in enumerate(gcn.gcn_networks):
+            cin, cout, K = blk.cin, blk.cout, blk.K
+            key, bk = "gcn.b%d" % i, pk["blocks"][i]
+            yact = ar.get(key + ".yact16", (rows, cout), dtype=torch.bfloat16)
+            rn, out = ar.get(key + ".rn", (rows, cout)), ar.get(key + ".out", (rows, cout))
+            hip.call("gcn_mix_eval_bf16", cur, in_state, gcn.A, gcn.edge_importance[i], bk["Wy"], bk["Wr"], bk["biasy"], bk["biasr"],
+                     bk["st0"], bk["st_r"], yact, rn, F, V, cin, cout, K)
+            hip.call("tconv_eval_bf16", yact, bk["Wt"], bk["bt"], bk["st3"], rn, cout, out, cout, 1, B, T, V, cout, cout, blk.taps)
+            cur, in_state = out, None
+        return cur
+
     def _gcn_forward(self, ar, up, B, T, training):
         gcn = self.keyEncoder.gcn
         V = JOINTS_UPPER
@@ -612,6 +693,9 @@ class LowerNet(_NetBase):
         self._gcn_was_fused = bool(training and self._gcn_fusable(B, T))
         if self._gcn_was_fused:
             return self._gcn_forward_fused(ar, up, B, T)
+        if self._bf16_eval(training) and self._gcn_bf16_ok(B, T):
+            cur = self._gcn_forward_bf16(ar, up, B, T)
+            return self._gcn_fcn(ar, cur, B, T)
         st = ops.bn_stats(ar, "gcn.dbn", up, gcn.data_bn, training)
         x0 = ar.get("gcn.x0", (F, V * 3))
         ops.affine_act(up, st, x0, relu=False)
@@ -661,6 +745,12 @@ class LowerNet(_NetBase):
             out = ar.get(key + ".out", (rows, cout))
             ops.affine_act(tz, st3, out, relu=True, X2=res_z, st2=st_r)
             cur = out
+        return self._gcn_fcn(ar, cur, B, T)
+
+    def _gcn_fcn(self, ar, cur, B, T):
+        gcn = self.keyEncoder.gcn
+        V = JOINTS_UPPER
+        F, rows = B * T, B * T * V
         kv = ar.get("gcn.kv", (B, 64, T * V))
         if rows <= 16384:
             # fcn as one product per sequence b with a TRANSPOSED store: (B,T*V,128) -> (B,64,T*V), then re-viewed (Q8); no

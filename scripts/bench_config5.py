@@ -155,7 +155,7 @@ def config5(imu_net):
     # Upper/Lower doubles at N=256 and is < 3 % of the total either way)
     flops = imu_flops(B, T) + B * T * 2.0 * (1.075e6 + 4.632e6)
     for prec in (("bf16",) if trace else ("fp32", "bf16")):
-        imu_net.precision = prec
+        imu_net.precision = upper.precision = lower.precision = prec
 
         def fwd():
             with torch.no_grad():

@@ -240,3 +240,162 @@ def test_config5_full_size_bf16_forward():
     assert float((Rb - R32).abs().max()) < 2e-2 and float((tb - t32).abs().max()) < 2e-2, \
         (float((Rb - R32).abs().max()), float((tb - t32).abs().max()))
     assert float((Rb - R32).abs().mean()) < 2e-3
+
+
+# ---- eval-mode ST-GCN block on bf16 operands (mmego_amd/csrc/gcn_bf16.hip) --------------------------------------------------------
+@pytest.mark.parametrize("B,T,V,C", [(3, 16, 15, 128), (5, 8, 15, 64), (2, 16, 15, 32), (2, 20, 15, 64), (1, 3, 15, 128), (2, 40, 13, 32)])
+def test_tconv_eval_bf16_matches_emulation(B, T, V, C):
+    """mmego_tconv_eval_bf16 against the same arithmetic on the CPU: the (already bf16) input and the bf16-rounded weights
+    multiplied and summed in float64, then bias -> BatchNorm affine -> + residual -> ReLU.  The kernel accumulates 9 C products per
+    output in fp32 in another order: 2e-5 of the output scale at worst.  (2, 20, 15, 64) and (2, 40, 13, 32): T V > 256 rows, two
+    and three row passes per sequence; (1, 3, 15, 128): a sequence shorter than the kernel's reach of 4 frames each way."""
+    from mmego_amd import hip
+    dev, taps = _dev(), 9
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + C)
+    rows = B * T * V
+    x = torch.relu(torch.randn(rows, C, generator=g)).to(torch.bfloat16)
+    w = torch.randn(C, C, taps, 1, generator=g) / (taps * C) ** 0.5
+    bias, res = torch.randn(C, generator=g) * 0.1, torch.randn(rows, C + 4, generator=g)
+    post = torch.stack([torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5, torch.rand(C, generator=g) + 0.5,
+                        torch.randn(C, generator=g) * 0.1])
+    assert hip.lib().mmego_tconv_eval_bf16_ok(T, V, C, C, taps)
+    wp = torch.empty(w.numel(), dtype=torch.bfloat16, device=dev)
+    hip.call("tconv_pack_bf16", w.to(dev), C, C, taps, wp)
+    resd = res.to(dev)
+    outs = {}
+    for name, (pb, pp, pr, relu) in {"full": (bias, post, resd, 1), "plain": (None, None, None, 0)}.items():
+        y = torch.full((rows, C + 8), 7.0, device=dev)
+        hip.call("tconv_eval_bf16", x.to(dev), wp, None if pb is None else pb.to(dev), None if pp is None else pp.to(dev).contiguous(),
+                 None if pr is None else pr[:, 2:], resd.stride(0), y[:, 4:4 + C], y.stride(0), relu, B, T, V, C, C, taps)
+        torch.cuda.synchronize()
+        assert torch.all(y[:, :4] == 7.0) and torch.all(y[:, 4 + C:] == 7.0)           # nothing outside the output columns
+        outs[name] = y[:, 4:4 + C].cpu().double()
+    xe = x.double().view(B, T, V, C).permute(0, 3, 1, 2)
+    conv = torch.nn.functional.conv2d(xe, _bf(w), None, padding=(taps // 2, 0)).permute(0, 2, 3, 1).reshape(rows, C)
+    scale = float(conv.abs().max())
+    err = float((outs["plain"] - conv).abs().max())
+    assert err < 2e-5 * scale, (err, scale)
+    full = torch.relu((conv + bias.double() - post[0].double()) * post[2].double() + post[3].double() + res[:, 2:2 + C].double())
+    err = float((outs["full"] - full).abs().max())
+    assert err < 2e-5 * max(scale, float(full.abs().max())), err
+
+
+def _emulate_mix(x, in_state, AI, Wg, bg, Wres, bres, st0, st_r, F, V, cin, cout, K):
+    """gcn_mix_eval_bf16 in float64 with the kernel's roundings: X (after data_bn's affine, fp32) is mixed with A . importance, the
+    mixed copies and X itself are rounded to bf16, the weights are rounded to bf16, everything else is exact."""
+    xf = x.view(F, V, cin).float()
+    if in_state is not None:
+        m, a, b = (in_state[i].view(V, cin) for i in (0, 2, 3))
+        xf = (xf - m) * a + b
+    xd = xf.double()
+    y = torch.zeros(F, V, cout, dtype=torch.float64)
+    for k in range(K):
+        xk = torch.einsum("vw,fvc->fwc", AI[k].double(), xd).float()                 # (fp32 like the kernel, up to summation order)
+        y += _bf(xk) @ _bf(Wg[k]).t()
+    y += torch.einsum("kw,kc->wc", AI.double().sum(dim=1), bg.double().view(K, cout))
+    yact = torch.relu((y - st0[0].double()) * st0[2].double() + st0[3].double())
+    r = _bf(xf) @ _bf(Wres).t() + bres.double()
+    rn = (r - st_r[0].double()) * st_r[2].double() + st_r[3].double()
+    return yact.view(F * V, cout), rn.view(F * V, cout)
+
+
+@pytest.mark.parametrize("cin,cout,F,K", [(3, 32, 19, 3), (32, 64, 64, 3), (64, 128, 37, 3), (64, 128, 8, 2), (3, 32, 2100, 2), (32, 64, 21, 2),
+                                          (64, 128, 9, 1)])
+def test_gcn_mix_eval_bf16_matches_emulation(cin, cout, F, K):
+    """mmego_gcn_mix_eval_bf16 against _emulate_mix.  Differences: fp32 summation order, and -- rarely -- one bf16 ulp (2^-8
+    relative) of a mixed operand whose fp32 sum lands on the other side of a rounding boundary, which moves an output by
+    ~4e-3 x |w| x |x|: 3e-3 of the output scale at worst, 3e-5 on average; the bf16 einsum output within one bf16 ulp.
+    F = 19 / 37: ragged last tile of 8 frames; 2100 frames: more tiles than workgroups (the persistent loop); K = 2 is the skeleton graph's
+    partition count, K = 3 the reference's general case."""
+    from mmego_amd import hip
+    dev, V = _dev(), 15
+    g = torch.Generator().manual_seed(cin * 100 + F)
+    x = torch.randn(F * V, cin, generator=g)
+    A = torch.rand(K, V, V, generator=g) * (torch.rand(K, V, V, generator=g) < 0.3).float()
+    imp = torch.rand(K, V, V, generator=g) + 0.5
+    Wg = torch.randn(K, cout, cin, generator=g) / (K * cin) ** 0.5
+    bg = torch.randn(K * cout, generator=g) * 0.1
+    Wres, bres = torch.randn(cout, cin, generator=g) / cin ** 0.5, torch.randn(cout, generator=g) * 0.1
+
+    def state(C):
+        return torch.stack([torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5, torch.rand(C, generator=g) + 0.5,
+                            torch.randn(C, generator=g) * 0.1]).contiguous()
+    st0, st_r = state(cout), state(cout)
+    in_state = state(V * cin) if cin == 3 else None
+    assert hip.lib().mmego_gcn_mix_eval_bf16_ok(V, cin, cout, K)
+    kd = ((K + 1) * cin + 15) // 16 * 16
+    ksy, kr0 = (K * cin + 15) // 16, (K * cin) // 16
+    Wcat = torch.zeros(cout, kd)
+    Wcat[:, :K * cin] = Wg.permute(1, 0, 2).reshape(cout, K * cin)
+    Wy = Wcat[:, :ksy * 16].clone()
+    Wcat.zero_()
+    Wcat[:, K * cin:(K + 1) * cin] = Wres
+    Wr = Wcat[:, kr0 * 16:].clone()
+
+    def frag(Wm):
+        co, n = Wm.shape
+        return Wm.to(torch.bfloat16).view(co // 32, 32, n // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().to(dev)
+    AI = A * imp
+    biasy = torch.einsum("kw,kc->wc", AI.sum(dim=1), bg.view(K, cout)).contiguous()
+    yact = torch.zeros(F * V + 3, cout, dtype=torch.bfloat16, device=dev)
+    rn = torch.full((F * V + 3, cout), 7.0, device=dev)
+    hip.call("gcn_mix_eval_bf16", x.to(dev), None if in_state is None else in_state.to(dev), A.to(dev), imp.to(dev), frag(Wy), frag(Wr),
+             biasy.to(dev), bres.to(dev), st0.to(dev), st_r.to(dev), yact, rn, F, V, cin, cout, K)
+    torch.cuda.synchronize()
+    assert torch.all(rn[F * V:] == 7.0) and torch.all(yact[F * V:].float() == 0.0)      # nothing behind the last frame
+    want_y, want_r = _emulate_mix(x, in_state, AI, Wg, bg, Wres, bres, st0, st_r, F, V, cin, cout, K)
+    got_y, got_r = yact[:F * V].cpu().double(), rn[:F * V].cpu().double()
+    sr = float(want_r.abs().max())
+    er = (got_r - want_r).abs()
+    if in_state is None:
+        assert float(er.max()) < 2e-5 * sr, (float(er.max()), sr)      # the residual product's operands are exact roundings of x
+    else:       # x passes data_bn's affine in fp32 first (one fused multiply-add in the kernel): rarely the other side of a bf16 boundary
+        assert float(er.max()) < 3e-3 * sr and float(er.mean()) < 2e-5 * sr, (float(er.max()), float(er.mean()), sr)
+    sy = float(want_y.abs().max())
+    ey = (got_y - _bf(want_y.float())).abs()
+    assert float(ey.max()) < 3e-3 * sy + 2.0 ** -7 * sy, (float(ey.max()), sy)
+    assert float(ey.mean()) < 2e-4 * sy, (float(ey.mean()), sy)
+    # and within bf16 resolution of the emulation for nearly every element
+    close = (got_y - want_y).abs() <= 2.0 ** -8 * want_y.abs() + 1e-4 * sy
+    assert float(close.double().mean()) > 0.999
+
+
+def test_lower_eval_bf16_mode_is_close_to_fp32_and_is_opt_in():
+    """LowerNet.precision = "bf16": the eval forward's ST-GCN runs on gcn_bf16.hip; joints move by well under a millimetre per
+    metre of skeleton, the mode is deterministic, switching back restores the fp32 path bit for bit, training ignores it."""
+    from mmego_amd import nets
+    dev = _dev()
+    torch.manual_seed(21)
+    lo = nets.LowerNet(64).to(dev).eval()
+    assert lo.precision == "fp32"
+    with torch.no_grad():
+        for m in lo.modules():                                       # running statistics away from (0, 1): the folded affines matter
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.6, 1.4)
+    g = torch.Generator().manual_seed(22)
+    B, T, N = 6, 16, 128
+    x = torch.randn(B, T, N, 6, generator=g).to(dev)
+    up = (torch.randn(B, T, 15, 3, generator=g) * 0.3).to(dev)
+    body = (torch.randn(B, 20, 3, generator=g) * 0.2).to(dev)
+    R = torch.linalg.qr(torch.randn(B, T, 3, 3, generator=g))[0].contiguous().to(dev)
+    t = (torch.randn(B, T, 3, generator=g) * 0.1).to(dev)
+
+    def fwd():
+        with torch.no_grad():
+            l, q = lo(up.clone(), x.clone(), None, None, None, None, body, R, t)[:2]
+        return l.clone(), q.clone()
+    l32, q32 = fwd()
+    lo.precision = "bf16"
+    lb, qb = fwd()
+    lb2, qb2 = fwd()
+    assert torch.equal(lb, lb2) and torch.equal(qb, qb2)
+    assert not torch.equal(l32, lb)
+    assert float((l32 - lb).abs().max()) < 2e-2, float((l32 - lb).abs().max())
+    assert float((q32 - qb).abs().max()) < 5e-2
+    lo.precision = "fp32"
+    l32b, q32b = fwd()
+    assert torch.equal(l32, l32b) and torch.equal(q32, q32b)
+    lo.precision = "fp16"
+    with pytest.raises(ValueError):
+        fwd()
