@@ -308,6 +308,10 @@ int mmego_pose_errors_upper(void* stream, const float* upper, const float* targe
  * attention Linear's weight [64] and bias [1].  Replaces transform2h + 2 x mlp3_eval + attn_pool_forward and their HBM round trips. */
 int mmego_upper_front_eval(void* stream, float* x, const float* x_src, const float* R, const float* t, long F, int N,
                            const float* const* w, float eps, float* vec, float* attn);
+/* The same launch with the six stages' operands (folded weights, activation tiles) rounded to bf16 and fp32 accumulation
+ * (front_bf16.hip; opt-in precision mode of eval forwards).  Transform2H and its write-back stay fp32 and bit-identical. */
+int mmego_upper_front_eval_bf16(void* stream, float* x, const float* x_src, const float* R, const float* t, long F, int N,
+                                const float* const* w, float eps, float* vec, float* attn);
 
 /* ---- anchor ("voxel") grouping of UpperNetwlocal (group.hip) -----------------------------------------
  * Per frame and per anchor of the 3x3x3 grid: indices (int64, exact, stable ties) of the 8 nearest points and

@@ -243,7 +243,8 @@ class UpperNet(_NetBase):
         if not training and not stash and self._front_fusable(Cx, N):
             # eval mode: transform, PointNet, concat, GlobalPointNet and the attention pooling as ONE launch (front.hip); the
             # per-point 28- / 64-channel tensors never exist in memory
-            hip.call("upper_front_eval", x, x_src, R, t, F, N, self._front_table(), float(self.module0.cb1.eps), vec, attn)
+            hip.call("upper_front_eval_bf16" if self._bf16_eval(training) else "upper_front_eval", x, x_src, R, t, F, N, self._front_table(),
+                     float(self.module0.cb1.eps), vec, attn)
             return self._forward_tail(ar, vec, attn, B, T, N, h0, c0, body, R, t, stash, training)
         feats = ar.get("feats", (rows, 28))
         keep = ar.get("pts", (rows, Cx)) if stash else None

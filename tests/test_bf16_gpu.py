@@ -399,3 +399,70 @@ def test_lower_eval_bf16_mode_is_close_to_fp32_and_is_opt_in():
     lo.precision = "fp16"
     with pytest.raises(ValueError):
         fwd()
+
+
+def test_upper_front_eval_bf16_against_emulation_and_fp32():
+    """mmego_upper_front_eval_bf16 (front_bf16.hip) against the six stages written out in float64 with the kernel's roundings (folded
+    weights and every stage's input rounded to bf16), and UpperNet.precision = "bf16" end to end: the transformed points written back
+    into x are bit-identical to the fp32 launch, pooled features within bf16 resolution of the emulation, opt-in and reversible."""
+    from mmego_amd import nets
+    dev = _dev()
+    torch.manual_seed(31)
+    up = nets.UpperNet().to(dev).eval()
+    with torch.no_grad():
+        for m in up.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.6, 1.4)
+                m.weight.uniform_(0.7, 1.3)
+                m.bias.uniform_(-0.1, 0.1)
+    g = torch.Generator().manual_seed(32)
+    B, T, N = 3, 5, 128
+    x0 = torch.randn(B, T, N, 6, generator=g)
+    body = torch.randn(B, 20, 3, generator=g) * 0.2
+    R = torch.linalg.qr(torch.randn(B, T, 3, 3, generator=g))[0].contiguous()
+    t = torch.randn(B, T, 3, generator=g) * 0.1
+    h0 = torch.zeros(6, B, 64)
+
+    def fwd():
+        x = x0.clone().to(dev)
+        with torch.no_grad():
+            out = up(x, h0.to(dev), h0.clone().to(dev), body.to(dev), R.to(dev), t.to(dev))
+        return x.cpu(), out[0].cpu(), up.arena("eval").get("vec", (B * T, 64)).cpu().clone()
+    x32, l32, v32 = fwd()
+    up.precision = "bf16"
+    xb, lb, vb = fwd()
+    xb2, lb2, vb2 = fwd()
+    assert torch.equal(lb, lb2) and torch.equal(vb, vb2)
+    assert torch.equal(x32, xb)                                       # Transform2H and its write-back: untouched by the mode
+    assert not torch.equal(v32, vb)
+    up.precision = "fp32"
+    x32b, l32b, v32b = fwd()
+    assert torch.equal(l32, l32b) and torch.equal(v32, v32b)
+    # emulation of the pooled features from the transformed points
+    pts = x32.view(B * T, N, 6).double()
+    cur = _bf(pts.float())
+    feats4 = cur[..., :4]
+
+    def layer(a, conv, bn):
+        s = bn.weight.detach().cpu() / torch.sqrt(bn.running_var.cpu() + bn.eps)
+        Wf = (s[:, None] * conv.weight.detach().cpu().view(conv.weight.shape[0], -1)).float()
+        bf = ((conv.bias.detach().cpu() - bn.running_mean.cpu()) * s + bn.bias.detach().cpu()).float()
+        return torch.relu(a @ _bf(Wf).t() + bf.double())
+    m0, m1 = up.module0, up.module1.gpointnet
+    a = layer(cur, m0.conv1, m0.cb1)
+    a = layer(_bf(a.float()), m0.conv2, m0.cb2)
+    a = layer(_bf(a.float()), m0.conv3, m0.cb3)
+    z = torch.cat([feats4, _bf(a.float())], dim=-1)
+    gq = layer(z, m1.conv1, m1.cb1)
+    gq = layer(_bf(gq.float()), m1.conv2, m1.cb2)
+    gq = layer(_bf(gq.float()), m1.conv3, m1.cb3)                     # [F, N, 64] fp32 features (not rounded: pooled in fp32)
+    sc = gq @ m1.attn.weight.detach().cpu().double().view(-1) + m1.attn.bias.detach().cpu().double()
+    w = torch.softmax(sc, dim=1)
+    want = (w.unsqueeze(-1) * gq).sum(dim=1)
+    err = (vb.double() - want).abs()
+    scale = float(want.abs().max())
+    # an activation that lands on the other side of a bf16 boundary (fp32 vs float64 sums) moves a feature by 2^-8 of one term
+    assert float(err.max()) < 5e-3 * scale and float(err.mean()) < 2e-4 * scale, (float(err.max()), float(err.mean()), scale)
+    assert float((v32 - vb).abs().max()) < 5e-2 * scale
+    assert float((l32 - lb).abs().max()) < 2e-2
