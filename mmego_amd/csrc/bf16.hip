@@ -641,6 +641,77 @@ __global__ __launch_bounds__(256) void fc_relu_bf16_frag_tm_kernel(const float* 
   }
 }
 
+// The same product on the matrix pipe for H a multiple of 128 (IMU_Net: 512).  The VALU form above reads every weight from LDS
+// once per 32 rows (a broadcast ds_read_b128 per four multiply-adds: 412 us at config 5, bound by the LDS reads); here one workgroup
+// owns a 32-row block for ALL timesteps with its share of W^T as v_mfma_f32_32x32x2_f32 operand registers (fp32 operands: the
+// result is the fp32 product rounded to bf16, as before), x_t's eight values per lane requested one timestep ahead, and the 32 x 32
+// accumulator tile turned into fragment pieces (a lane's 8 consecutive units) through a wave-private LDS tile.
+template <int NCTW>
+__global__ __launch_bounds__(256) void fc_relu_bf16_frag_tm_mfma_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ W,
+                                                                         const float* __restrict__ bias, int Bn, int T, int Cin, int H,
+                                                                         bf16_t* __restrict__ Y, int Bp, int relu) {
+  __shared__ float tile[4][32 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int rb = blockIdx.x;
+  float wf[NCTW][8], bs[NCTW];
+#pragma unroll
+  for (int j = 0; j < NCTW; ++j) {
+    const int n = (wave * NCTW + j) * 32 + r;
+    bs[j] = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = 2 * s + h;
+      const float w = W[(long)n * Cin + (k < Cin ? k : Cin - 1)];
+      wf[j][s] = k < Cin ? w : 0.f;
+    }
+  }
+  const int b = rb * 32 + r;
+  const float* xr = X + (long)(b < Bn ? b : Bn - 1) * T * ldx;
+  float xn[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) xn[s] = xr[2 * s + h < Cin ? 2 * s + h : Cin - 1];
+  float* tl = tile[wave];
+  const int prow = lane & 31, pc8 = lane >> 5;          // this lane's row and 8-column half inside a 16-column piece
+  const bool live = rb * 32 + prow < Bn;
+  for (int t = 0; t < T; ++t) {
+    float xa[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) xa[s] = xn[s];
+    {
+      const float* xq = xr + (long)(t + 1 < T ? t + 1 : t) * ldx;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) xn[s] = xq[2 * s + h < Cin ? 2 * s + h : Cin - 1];
+    }
+    u32x4* dst = reinterpret_cast<u32x4*>(Y + (long)t * Bp * H) + (long)rb * (H >> 4) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < NCTW; ++j) {
+      f32x16 acc = {0};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], wf[j][s], acc, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc[e] + bs[j];
+        tl[((e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = relu ? fmaxf(v, 0.f) : v;
+      }
+      __builtin_amdgcn_wave_barrier();                  // (wave-private tile: LDS operations of a wave complete in issue order)
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        float y[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) y[q] = live ? tl[prow * 33 + pc * 16 + pc8 * 8 + q] : 0.f;
+        u32x4 o;
+        o[0] = f2bf_bits(y[0]) | (f2bf_bits(y[1]) << 16);
+        o[1] = f2bf_bits(y[2]) | (f2bf_bits(y[3]) << 16);
+        o[2] = f2bf_bits(y[4]) | (f2bf_bits(y[5]) << 16);
+        o[3] = f2bf_bits(y[6]) | (f2bf_bits(y[7]) << 16);
+        dst[(long)(((wave * NCTW + j) * 2 + pc)) * 64] = o;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 extern "C" int mmego_fc_relu_bf16_frag_tm(void* stream, const float* X, long ldx, const float* W, const float* bias, int Bn, int T,
                                           int Cin, int H, unsigned short* Y, int Bp, int relu) {
   MMEGO_REQUIRE(X && W && Y && Bn > 0 && T > 0 && Cin > 0 && Cin <= 16 && H > 0 && H % 16 == 0 && H <= 2048 && Bp >= Bn && Bp % 32 == 0);
@@ -651,6 +722,18 @@ extern "C" int mmego_fc_relu_bf16_frag_tm(void* stream, const float* X, long ldx
     hipError_t e = hipFuncSetAttribute((const void*)fc_relu_bf16_frag_tm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 17 * 4);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
+  }
+  if (H % 128 == 0 && H <= 512) {
+    const dim3 g(Bp / 32);
+    hipStream_t st = (hipStream_t)stream;
+    switch (H / 128) {
+      case 1: fc_relu_bf16_frag_tm_mfma_kernel<1><<<g, 256, 0, st>>>(X, ldx, W, bias, Bn, T, Cin, H, Y, Bp, relu); break;
+      case 2: fc_relu_bf16_frag_tm_mfma_kernel<2><<<g, 256, 0, st>>>(X, ldx, W, bias, Bn, T, Cin, H, Y, Bp, relu); break;
+      case 3: fc_relu_bf16_frag_tm_mfma_kernel<3><<<g, 256, 0, st>>>(X, ldx, W, bias, Bn, T, Cin, H, Y, Bp, relu); break;
+      default: fc_relu_bf16_frag_tm_mfma_kernel<4><<<g, 256, 0, st>>>(X, ldx, W, bias, Bn, T, Cin, H, Y, Bp, relu); break;
+    }
+    MMEGO_LAUNCH_CHECK();
+    return MMEGO_OK;
   }
   dim3 grid(Bp / 32, T);
   fc_relu_bf16_frag_tm_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(X, ldx, W, bias, Bn, T, Cin, H, Y, Bp, relu);

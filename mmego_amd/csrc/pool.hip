@@ -594,16 +594,31 @@ __global__ __launch_bounds__(512) void graph_dA_partial_kernel(const float* __re
   if (e < nout) partial[(long)blockIdx.x * nout + e] = acc;
 }
 
-// out[b][c][r] = in[b][r][c]
+// out[b][c][r] = in[b][r][c]: 64 x 64 tiles through LDS (both the read and the write of a tile walk contiguous addresses; the
+// one-element-per-thread form read with a stride of C floats: 268 us for 126 MB at config 5)
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                 long Bn, int R, int C) {
-  const long total = Bn * R * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int r = (int)(i % R);
-    long q = i / R;
-    int c = (int)(q % C);
-    long b = q / C;
-    out[i] = in[(b * R + r) * (long)C + c];
+  __shared__ float tile[64][65];
+  const int tr = (R + 63) / 64, tc = (C + 63) / 64;
+  const long ntile = Bn * tr * tc;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (long tI = blockIdx.x; tI < ntile; tI += gridDim.x) {
+    const long b = tI / (tr * tc);
+    const int q = (int)(tI - b * tr * tc), r0 = (q / tc) * 64, c0 = (q % tc) * 64;
+    const float* src = in + b * (long)R * C;
+    float* dst = out + b * (long)R * C;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = r0 + ty + 4 * i, c = c0 + tx;
+      tile[ty + 4 * i][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = c0 + ty + 4 * i, r = r0 + tx;
+      if (r < R && c < C) dst[(long)c * R + r] = tile[tx][ty + 4 * i];
+    }
+    __syncthreads();
   }
 }
 
@@ -744,7 +759,8 @@ extern "C" int mmego_graph_dA(void* stream, const float* Z, const float* dY, lon
 
 extern "C" int mmego_transpose_batched(void* stream, const float* in, float* out, long Bn, int R, int C) {
   MMEGO_REQUIRE(in && out && Bn > 0 && R > 0 && C > 0);
-  hipLaunchKernelGGL(transpose_batched_kernel, dim3(ew_blocks(Bn * R * C)), dim3(256), 0, (hipStream_t)stream, in, out,
+  const long ntile = Bn * ((R + 63) / 64) * ((C + 63) / 64);
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)(ntile < 8192 ? ntile : 8192)), dim3(256), 0, (hipStream_t)stream, in, out,
                      Bn, R, C);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;

@@ -920,3 +920,16 @@ def test_fused_pooling_in_the_pointnet_chain_equals_the_separate_launches(dev):
         assert (g1[k] - g0[k]).abs().max().item() < 2e-5 * scale, (k, (g1[k] - g0[k]).abs().max().item(), scale)
     for k in b0:
         assert (b1[k].double() - b0[k].double()).abs().max().item() < 1e-5 * max(1.0, b0[k].double().abs().max().item()), k
+
+
+@pytest.mark.parametrize("Bn,R,C", [(5, 240, 64), (7, 27, 64), (3, 64, 27), (1, 2048, 512), (2, 130, 70), (9000, 3, 5)])
+def test_transpose_batched_bit_exact(dev, Bn, R, C):
+    """mmego_transpose_batched (64 x 64 tiles through LDS): out[b][c][r] = in[b][r][c], every shape the nets use and ragged ones."""
+    from mmego_amd import hip
+    g = torch.Generator().manual_seed(Bn + R + C)
+    x = torch.randn(Bn, R, C, generator=g).to(dev)
+    out = torch.full((Bn * R * C + 8,), 7.0, device=dev)
+    hip.call("transpose_batched", x, out, Bn, R, C)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:Bn * R * C].view(Bn, C, R), x.transpose(1, 2).contiguous())
+    assert torch.all(out[Bn * R * C:] == 7.0)
