@@ -164,7 +164,7 @@ def config5(imu_net):
                 up = upper(x, h0, h0.clone(), body, R, t)[0]
                 return lower(up, x, None, None, None, None, body, R, t)[0]
         ms = timeit(fwd, n=2 if trace else 3, warm=1)
-        print("config 5 forward, IMU products in %s: %.1f ms, %.0f frames/s, %.0f TFLOP/s algorithmic (%.3f of the %s MFMA peak)"
+        print("config 5 forward, precision %s on all three nets: %.1f ms, %.0f frames/s, %.0f TFLOP/s algorithmic (%.3f of the %s MFMA peak)"
               % (prec, ms, B * T / ms * 1e3, flops / ms / 1e9, flops / ms / 1e9 / (PEAK_BF16 if prec == "bf16" else PEAK_F32),
                  prec))
         torch.cuda.synchronize()
