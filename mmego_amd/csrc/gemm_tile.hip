@@ -257,7 +257,11 @@ static int launch_layout(hipStream_t st, const TileP& p) {
     const int units = (int)units128;
     static const bool no_persist = getenv("MMEGO_GEMM_NO_PERSIST") != nullptr;
     static const int stagger = getenv("MMEGO_GEMM_NO_STAGGER") == nullptr;
-    if (units > slots && !no_persist) {
+    // (K <= 128: two chunks per tile -- the tile is its 64-KB store; the static walk's two tiles per workgroup then run one after
+    // the other, load latency and store each exposed: 59 us for the 32768 x 512 x 64 BiLSTM(64) projections of config 5.  The plain
+    // grid keeps four workgroups per CU in flight.)
+    static const int persist_min_k = getenv("MMEGO_GEMM_PERSIST_MIN_K") ? atoi(getenv("MMEGO_GEMM_PERSIST_MIN_K")) : 129;
+    if (units > slots && !no_persist && p.K >= persist_min_k) {
       const int rest = units % slots;
       const bool halves = rest > 0 && rest <= slots / 2;
       const int nfull = halves ? units - rest : units, nhalf = halves ? 2 * rest : 0;
