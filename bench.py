@@ -959,6 +959,11 @@ def main():
                 "launches_per_step": len(fam_launch) // iters, "kernel_ms_per_step": fam_ms / iters,
                 "traffic": tr_f, "traffic_source": tr_src,
                 "kernel_ms_per_step_by_family": {k.split(" ")[0]: v / iters for k, v in by_time.items()}}
+        # the persistent rnn_slow launches (lstm_seq.hip) bound their spins: a launch that could not make progress flags it
+        from mmego_amd import blocks as _blocks
+        out["persistent_launch_errors"] = _blocks.seq_xcd_errors()
+        if out["persistent_launch_errors"]:
+            raise RuntimeError("mmego_lstm_seq_xcd: %d launch(es) ran out of their bounded spin -- results invalid" % out["persistent_launch_errors"])
         sys.stderr.write("[bench] gpu part done: %.1f frames/s; timing the CPU oracle on %d threads\n" % (out["value"], host_cores()))
         sys.stderr.flush()
         if world == 1 and not args.no_config_extras:

@@ -397,6 +397,33 @@ class two_chains:
         return False
 
 
+_LSTM_SEQ_XCD = os.environ.get("MMEGO_LSTM_SEQ_XCD", "1") != "0"
+
+
+def seq_xcd_sync(ar, key):
+    """The 10 synchronisation words of mmego_lstm_seq_xcd for one BiLSTM stack of one net (its arena): zero when created, left
+    zero by every launch; word 9 is the kernel's sticky error flag (seq_xcd_errors)."""
+    name = "%s.seqsync" % key
+    fresh = not ar.has(name)
+    t = ar.get(name, (16,), dtype=torch.int32)
+    if fresh:
+        t.zero_()
+        _seq_sync_bufs.append(t)
+    return t
+
+
+_seq_sync_bufs = []
+
+
+def seq_xcd_errors(ar=None):
+    """Sum of the error words of the mmego_lstm_seq_xcd sync buffers of arena `ar` (None: of every buffer handed out in this process);
+    0 = every launch so far made progress.  One host read per buffer: for tests, the smoke check and the end of a benchmark, not
+    for the step loop."""
+    if ar is None:
+        return sum(int(t[9].item()) for t in _seq_sync_bufs)
+    return sum(int(t[9].item()) for (name, _, _), t in ar.bufs.items() if name.endswith(".seqsync"))
+
+
 def _side_stream(cur):
     """One extra stream per launching stream (the second direction's chain of a BiLSTM layer's recurrence)."""
     st = _side_streams.get(cur.cuda_stream)
@@ -416,9 +443,15 @@ def lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T, gst=None, cst=None):
     23.4 us with both directions in one launch (Bn = H = 512, scripts/bench_lstm_step.py --chains).  Same arithmetic in the
     same order: results are bit-identical (tests/test_hip_parity.py)."""
     H = lstm.hidden_size
-    c = ar.get("%s.c" % key, (2, Bn, H))
     w0, w1 = lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1)
     b0, b1 = lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1)
+    if (_LSTM_SEQ_XCD and gst is None and cst is None and T > 1 and w0.is_contiguous() and w1.is_contiguous()
+            and hip.lib().mmego_lstm_seq_xcd_ok(Bn, H, T)):
+        # <= 64 rows (IMU_Net's rnn_slow): the layer's whole recurrence as ONE persistent launch with stationary weights
+        # (lstm_seq.hip): 2 launches per forward instead of 2 T
+        hip.call("lstm_seq_xcd", xp, xp.stride(0), w0, w1, b0, b1, out, out.stride(0), seq_xcd_sync(ar, key), Bn, H, T)
+        return
+    c = ar.get("%s.c" % key, (2, Bn, H))
     xp_p, out_p = xp.data_ptr(), out.data_ptr()
     xs, os_ = T * 8 * H, T * 2 * H       # row strides between consecutive batch rows b
     if _LSTM_TWO_CHAINS and T > 1 and Bn >= 128 and ops.capture_can_fork():

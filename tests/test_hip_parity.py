@@ -933,3 +933,35 @@ def test_transpose_batched_bit_exact(dev, Bn, R, C):
     torch.cuda.synchronize()
     assert torch.equal(out[:Bn * R * C].view(Bn, C, R), x.transpose(1, 2).contiguous())
     assert torch.all(out[Bn * R * C:] == 7.0)
+
+
+@pytest.mark.parametrize("Bn,T", [(64, 8), (37, 5), (16, 2), (5, 16), (64, 1)])
+def test_rnn_slow_persistent_recurrence_against_the_step_launches(dev, Bn, T, monkeypatch):
+    """mmego_lstm_seq_xcd (lstm_seq.hip: a BiLSTM(512) layer's whole recurrence for <= 64 rows as one persistent launch, weights
+    stationary) against the launch-per-timestep form on the same projections: same expressions, the products summed in another
+    order -> 2e-6 absolute on |h| < 1 after up to 16 steps and two layers; no bounded spin ran out; the synchronisation words are
+    back at zero; a second run gives the same bits (fixed summation order); T = 1 takes the step path."""
+    from mmego_amd import blocks, ops
+    torch.manual_seed(Bn * 100 + T)
+    H, In = 512, 1024
+    lstm = blocks.LstmParams(In, H, 2, bidirectional=True).to(dev)
+    x = torch.randn(Bn * T, In, generator=torch.Generator().manual_seed(3)).to(dev)
+    outs = {}
+    for on in (False, True, True):
+        monkeypatch.setattr(blocks, "_LSTM_SEQ_XCD", on)
+        ar = ops.Arena(dev)
+        o = blocks.lstm_steps_forward(ar, "slow", lstm, x, Bn, T).clone()
+        torch.cuda.synchronize()
+        if on:
+            assert ar.has("slow.seqsync") == (T > 1)
+            assert blocks.seq_xcd_errors(ar) == 0
+            if T > 1:
+                assert int(ar.get("slow.seqsync", (16,), dtype=torch.int32).abs().sum().item()) == 0
+            if True in outs:
+                assert torch.equal(outs[True], o)
+        outs[on] = o
+    err = float((outs[True] - outs[False]).abs().max())
+    assert torch.isfinite(outs[True]).all()
+    assert err < 2e-6, err
+    if T == 1:
+        assert torch.equal(outs[True], outs[False])
