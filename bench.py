@@ -721,14 +721,20 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    # per-stage split, stages one after the other (device time, events on the launch stream; median of 5)
-    tu_s, tl_s = [], []
-    for i in range(6):
+    # per-stage split, stages one after the other (device time, events on the launch stream).  The steps run BACK TO BACK -- events
+    # recorded around every stage, one host synchronisation behind the last -- and the medians are reported: with a host
+    # synchronisation behind every step (r03: median of 5 isolated steps) the same code measured 5.67 and 5.84 ms in two runs on one
+    # box (the GPU idles between isolated steps and its clock follows)
+    su.step(); sl.step()                                 # (the first pass captures the per-stage graphs)
+    torch.cuda.synchronize()
+    evs = []
+    for i in range(44):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record(); su.step(); ev[1].record(); sl.step(); ev[2].record()
-        torch.cuda.synchronize()
-        if i:                                            # the first pass captures the per-stage graphs
-            tu_s.append(ev[0].elapsed_time(ev[1])); tl_s.append(ev[1].elapsed_time(ev[2]))
+        evs.append(ev)
+    torch.cuda.synchronize()
+    tu_s = [ev[0].elapsed_time(ev[1]) for ev in evs[4:]]
+    tl_s = [ev[1].elapsed_time(ev[2]) for ev in evs[4:]]
     t_u, t_l = sorted(tu_s)[len(tu_s) // 2], sorted(tl_s)[len(tl_s) // 2]
 
     # "IMU-shared" variant: one IMU_Net forward per minibatch feeds both bodies.  Extra figure, not `value`.

@@ -401,15 +401,17 @@ _LSTM_SEQ_XCD = os.environ.get("MMEGO_LSTM_SEQ_XCD", "1") != "0"
 
 
 def seq_xcd_sync(ar, key):
-    """The 10 synchronisation words of mmego_lstm_seq_xcd for one BiLSTM stack of one net (its arena): zero when created, left
-    zero by every launch; word 9 is the kernel's sticky error flag (seq_xcd_errors)."""
+    """The synchronisation words and the exchange buffer of mmego_lstm_seq_xcd for one BiLSTM stack of one net (its arena): zero when
+    created; word 9 of the first is the kernel's sticky error flag (seq_xcd_errors), word 10 its launch generation."""
     name = "%s.seqsync" % key
     fresh = not ar.has(name)
     t = ar.get(name, (16,), dtype=torch.int32)
+    x = ar.get("%s.seqxbuf" % key, (2, 8, 16, 512), dtype=torch.int64)
     if fresh:
         t.zero_()
+        x.zero_()
         _seq_sync_bufs.append(t)
-    return t
+    return t, x
 
 
 _seq_sync_bufs = []
@@ -449,7 +451,8 @@ def lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T, gst=None, cst=None):
             and hip.lib().mmego_lstm_seq_xcd_ok(Bn, H, T)):
         # <= 64 rows (IMU_Net's rnn_slow): the layer's whole recurrence as ONE persistent launch with stationary weights
         # (lstm_seq.hip): 2 launches per forward instead of 2 T
-        hip.call("lstm_seq_xcd", xp, xp.stride(0), w0, w1, b0, b1, out, out.stride(0), seq_xcd_sync(ar, key), Bn, H, T)
+        sync, xbuf = seq_xcd_sync(ar, key)
+        hip.call("lstm_seq_xcd", xp, xp.stride(0), w0, w1, b0, b1, out, out.stride(0), sync, xbuf, Bn, H, T)
         return
     c = ar.get("%s.c" % key, (2, Bn, H))
     xp_p, out_p = xp.data_ptr(), out.data_ptr()

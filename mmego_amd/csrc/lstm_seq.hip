@@ -10,10 +10,13 @@
 //   * inside a group, workgroup c owns hidden units [16 c, 16 c + 16): its four waves hold the 4 gates' W_hh rows for those units
 //     as v_mfma_f32_16x16x4_f32 B-operand REGISTERS (128 per lane, loaded once, under the product-less first timestep), the cell
 //     state of its 16 x 16 (row, unit) elements lives in one register per thread.
-//   * per timestep a workgroup waits for its group's arrival counter (32 per step), copies the group's h_{t-1} (16 rows x 512: the
-//     layer's OUTPUT tensor is the exchange medium) into LDS, multiplies (128 MFMA steps per wave over four accumulation chains),
-//     swaps the four gate tiles through LDS, updates its cells, stores its 16 x 16 slice of h_t with agent-scope stores and
-//     arrives.  Measured exchange round trip inside a group: 3.5-4.0 us (scripts/bench_handoff.hip, variant C).
+//   * the exchange is IN-BAND: a workgroup stores its 16 x 16 slice of h_t as 8-byte (value, tag) words -- tag = launch generation and
+//     timestep, one atomic store each -- into a two-stage exchange buffer and goes on; nobody waits for a store to be acknowledged
+//     and there is no arrival counter (store -> ack -> atomic -> poll -> load were four dependent trips to the memory side: 3.5-4.0
+//     us per step in scripts/bench_handoff.hip, variant C; 6.2 us per step for the kernel built that way).  A consumer polls ONE
+//     word per producer (32 per step, one wave), then fetches the group's 16 x 512 words once and checks every tag (a straggler is
+//     fetched again), copies the values into LDS, multiplies (128 MFMA steps per wave over four accumulation chains), swaps the
+//     four gate tiles through LDS and updates its cells.  The plain h_t goes to the layer's output tensor beside it.
 // Every spin is bounded: a grid that cannot make progress (three such launches side by side would wait for each other's CUs) sets
 // an error word and runs to its end with wrong results instead of hanging the GPU; the host checks the word (blocks.seq_xcd_check).
 // The last workgroup to finish resets the counters, so a launch leaves them as it found them (graph replays need no memset node).
@@ -31,7 +34,8 @@ struct LstmSeqP {
   const float* xproj; long xs;           // input projections [Bn*T rows (b*T + t)][8H]: direction d at column offset d * 4H; xs = row stride
   const float* whh[2]; const float* bhh[2];
   float* out; long os;                   // [Bn*T][2H] (os = row stride): h_t of direction d at column offset d * H
-  unsigned* sync;                        // [8 arrival counters | done counter | error word], zero before the first launch
+  unsigned* sync;                        // [8 unused | done counter | error word | launch generation], zero before the first launch
+  unsigned long long* xbuf;              // [2 stages][8 groups][16 rows][512] (value bits | tag << 32), zero before the first launch
   int Bn, T;
 };
 
@@ -47,9 +51,11 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_xcd_kernel(LstmSeqP p) {
   const int d = g >> 2, r0 = (g & 3) * 16;
   const int fr = lane & 15, fq = lane >> 4;
   const int T = p.T, H = LQ_H;
-  unsigned* cnt = p.sync + g;
   unsigned* done = p.sync + 8;
   unsigned* err = p.sync + 9;
+  // (stream order: the launch before this one -- whose last workgroup bumped the generation -- has completed)
+  const unsigned gen = __hip_atomic_load(p.sync + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long* xg = p.xbuf + (long)g * 16 * LQ_H;
 
   // ---- this wave's gate (= wave) of the workgroup's 16 units: W_hh[gate H + 16 c + fr][128 fq .. + 128) -> 128 registers.
   // Lane group fq owns k in [128 fq, 128 fq + 128) for BOTH operands (any k order is valid as long as they agree).
@@ -84,26 +90,50 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_xcd_kernel(LstmSeqP p) {
     for (int q = 0; q < 4; ++q) xpn[q] = xq[(xrow + tn) * p.xs + q * H];
     float pre[4] = {0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      // ---- wait for the group's h_{t-1}, fetch it (agent-scope loads: they bypass this CU's L1), multiply
-      if (tid == 0) {
-        const unsigned want = 32u * (unsigned)s;
+      // ---- the group's h_{t-1}: poll one word per producer, fetch all 16 x 512 once, check every tag
+      const unsigned tag = gen * 4096u + (unsigned)s;             // written by the producers at step s - 1
+      const unsigned long long* xs_ = xg + (long)((s - 1) & 1) * 8 * 16 * LQ_H;
+      if (wave == 0) {
+        const unsigned long long* f = xs_ + (lane & 31) * 16;     // row 0, first unit of producer lane & 31
         int spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-          if (++spins > LQ_SPIN_MAX) { atomicOr(err, 1u); break; }
+        while (true) {
+          const unsigned long long w = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all((unsigned)(w >> 32) == tag)) break;
+          if (++spins > LQ_SPIN_MAX) { if (lane == 0) atomicOr(err, 1u); break; }
         }
       }
       __syncthreads();
       {
-        const int tp = d == 0 ? t - 1 : t + 1;
-        // element (row u / 2, k = 256 (u % 2) + tid) in round u: an instruction reads 1 KB of one row
-        float v[32];
+        // element (row u / 2, k = 256 (u % 2) + tid) in round u: an instruction reads 2 KB of one row; two batches of 16 rounds
+        // (the weights hold 128 of the 256 registers)
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-          const int hb = r0 + (u >> 1) < p.Bn ? r0 + (u >> 1) : p.Bn - 1;
-          v[u] = __hip_atomic_load(p.out + ((long)hb * T + tp) * p.os + d * H + (u & 1) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int hb = 0; hb < 2; ++hb) {
+          unsigned long long v[16];
+          bool ok = true;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int uu = 16 * hb + u;
+            v[u] = __hip_atomic_load(xs_ + (uu >> 1) * LQ_H + (uu & 1) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) ok = ok && (unsigned)(v[u] >> 32) == tag;
+          int spins = 0;
+          while (!__all(ok)) {                                    // (rare: a producer's stores have not all landed yet)
+            ok = true;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int uu = 16 * hb + u;
+              v[u] = __hip_atomic_load(xs_ + (uu >> 1) * LQ_H + (uu & 1) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = ok && (unsigned)(v[u] >> 32) == tag;
+            }
+            if (++spins > LQ_SPIN_MAX) { if (lane == 0) atomicOr(err, 1u); break; }
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int uu = 16 * hb + u;
+            hs[(uu >> 1) * LQ_RS + (uu & 1) * 256 + tid] = __uint_as_float((unsigned)v[u]);
+          }
         }
-#pragma unroll
-        for (int u = 0; u < 32; ++u) hs[(u >> 1) * LQ_RS + (u & 1) * 256 + tid] = v[u];
       }
       __syncthreads();
       f32x4 acc[4];
@@ -132,40 +162,42 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_xcd_kernel(LstmSeqP p) {
     const float go = lq_sigmoid(pre[3] + (xp[3] + bh[3]));
     creg = gf * creg + gi * gg;
     const float hval = go * lq_tanh(creg);
-    if (live) __hip_atomic_store(oq + (xrow + t) * p.os, hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (live) oq[(xrow + t) * p.os] = hval;
+    if (s + 1 < T) {
+      // (value, tag) in one 8-byte store; stage s & 1 was last read at step s - 1, which every workgroup of the group has left:
+      // it produced h_{s-1}... the words of step s - 2 are dead once anybody can be here
+      const unsigned long long w = (unsigned long long)__float_as_uint(hval) | ((unsigned long long)(gen * 4096u + (unsigned)(s + 1)) << 32);
+      __hip_atomic_store(xg + (long)(s & 1) * 8 * 16 * LQ_H + crow * LQ_H + unit, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) xp[q] = xpn[q];
-    if (s + 1 < T) {
-      __builtin_amdgcn_s_waitcnt(0);                              // this thread's store has been acknowledged
-      __syncthreads();                                            // (also: gs and hs may be rewritten)
-      if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __syncthreads();                                              // (gs and hs may be rewritten)
   }
-  // ---- the last workgroup of the launch puts the counters back to zero (nobody waits on them any more)
-  __syncthreads();
+  // ---- the last workgroup of the launch advances the generation (tags of this launch can never match again)
   if (tid == 0) {
     const unsigned n = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n == gridDim.x - 1) {
-      for (int i = 0; i < 8; ++i) __hip_atomic_store(p.sync + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.sync + 10, (gen + 1u) & 0xFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
 // 1 when mmego_lstm_seq_xcd takes the shape
-extern "C" int mmego_lstm_seq_xcd_ok(int Bn, int H, int T) { return Bn >= 1 && Bn <= 64 && H == LQ_H && T >= 1 && T <= 4096; }
+extern "C" int mmego_lstm_seq_xcd_ok(int Bn, int H, int T) { return Bn >= 1 && Bn <= 64 && H == LQ_H && T >= 1 && T <= 4095; }
 
 // One BiLSTM layer's recurrence, both directions, all T timesteps in one launch.  xproj [Bn*T][xs >= 8H] rows (b*T + t): W_ih x + b_ih of
 // direction d at columns [4H d, 4H d + 4H); out [Bn*T][os >= 2H]: h_t of direction d at columns [H d, H d + H); h_0 = c_0 = 0.
-// sync: 10 unsigned words, zero before the first launch (a launch leaves the counters zero; word 9 is the sticky error flag: non-zero
-// after a launch whose workgroups could not all become resident -- results are then invalid).
+// sync: 16 unsigned words and xbuf: 2 * 8 * 16 * 512 8-byte words, both zero before the first launch and private to one stream of
+// launches (word 8: done counter, left zero; word 9: sticky error flag, non-zero after a launch whose workgroups could not all
+// become resident -- its results are invalid; word 10: launch generation).
 extern "C" int mmego_lstm_seq_xcd(void* stream, const float* xproj, long xs, const float* whh0, const float* whh1, const float* bhh0,
-                                  const float* bhh1, float* out, long os, unsigned* sync, int Bn, int H, int T) {
-  MMEGO_REQUIRE(xproj && whh0 && whh1 && out && sync && mmego_lstm_seq_xcd_ok(Bn, H, T) && xs >= 8 * H && os >= 2 * H);
+                                  const float* bhh1, float* out, long os, unsigned* sync, unsigned long long* xbuf, int Bn, int H, int T) {
+  MMEGO_REQUIRE(xproj && whh0 && whh1 && out && sync && xbuf && mmego_lstm_seq_xcd_ok(Bn, H, T) && xs >= 8 * H && os >= 2 * H);
   MMEGO_REQUIRE((((uintptr_t)whh0 | (uintptr_t)whh1) & 15) == 0);
   LstmSeqP p;
   p.xproj = xproj; p.xs = xs; p.whh[0] = whh0; p.whh[1] = whh1; p.bhh[0] = bhh0; p.bhh[1] = bhh1;
-  p.out = out; p.os = os; p.sync = sync; p.Bn = Bn; p.T = T;
+  p.out = out; p.os = os; p.sync = sync; p.xbuf = xbuf; p.Bn = Bn; p.T = T;
   hipLaunchKernelGGL(lstm_seq_xcd_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
