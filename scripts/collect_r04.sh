@@ -28,7 +28,7 @@ python3 "$root/scripts/pmc_summary.py" "$out" > "$out/pmc_counters.json"
 python3 - "$out" <<'PY'
 import glob, os, re, shutil, sys
 out = sys.argv[1]
-pat = re.compile("gemm_tile_persistent|lstm_step_dma_kernel|lstm_step_small|tconv_seq|gcn_front|tconv_wgrad|graph_dA_fused|mlp_bwd_layer|local_group_l1|pool8")
+pat = re.compile("gemm_tile_persistent|lstm_step_dma_kernel|lstm_step_small|lstm_seq_xcd|tconv_seq|gcn_front|tconv_wgrad|graph_dA_fused|mlp_bwd_layer|local_group_l1|pool8")
 for d in sorted(glob.glob(os.path.join(out, "pmc_bench_*")) + glob.glob(os.path.join(out, "pmc_wlocal_*"))):
     if not os.path.isdir(d):
         continue

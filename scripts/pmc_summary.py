@@ -15,7 +15,9 @@ KERNELS = {"lstm_step_dma_kernel<32>": ("bench", "step"), "lstm_step_dma_kernel<
            # r04: the fused ST-GCN step's kernels and the train-mode PointNet backward layer (the dominant kernel of the UpperNetwlocal step)
            "tconv_seq_kernel": ("bench",), "gcn_front_kernel": ("bench",), "tconv_wgrad_kernel": ("bench",), "graph_dA_fused_kernel": ("bench",),
            "mlp_bwd_layer_kernel": ("bench", "wlocal"), "local_group_l1_kernel": ("wlocal",), "pool8_bwd_kernel": ("wlocal",),
-           "pool8_bn_act_kernel": ("wlocal",)}
+           "pool8_bn_act_kernel": ("wlocal",),
+           # r04, late: rnn_slow's recurrence as one persistent launch per layer (lstm_seq.hip)
+           "lstm_seq_xcd_kernel": ("bench",)}
 res = {}
 for kname, stems in KERNELS.items():
     by_grid = collections.defaultdict(lambda: collections.defaultdict(list))
