@@ -308,15 +308,14 @@ int mmego_pose_errors_upper(void* stream, const float* upper, const float* targe
  * attention Linear's weight [64] and bias [1].  Replaces transform2h + 2 x mlp3_eval + attn_pool_forward and their HBM round trips. */
 int mmego_upper_front_eval(void* stream, float* x, const float* x_src, const float* R, const float* t, long F, int N,
                            const float* const* w, float eps, float* vec, float* attn);
-/* A whole BiLSTM layer's recurrence for Bn <= 512 rows and H = 512 as ONE persistent launch with stationary weights (lstm_seq.hip;
- * IMU_Net's rnn_slow and rnn_fast, Net/IMU_Net.py:58-62,77,82): xproj [Bn*T][xs >= 8H] rows (b*T + t) = W_ih x + b_ih of direction d at columns [4H d,
+/* A whole BiLSTM layer's recurrence for Bn <= 64 rows and H = 512 as ONE persistent launch with stationary weights (lstm_seq.hip;
+ * IMU_Net's rnn_slow, Net/IMU_Net.py:61-62,82): xproj [Bn*T][xs >= 8H] rows (b*T + t) = W_ih x + b_ih of direction d at columns [4H d,
  * 4H d + 4H); out [Bn*T][os >= 2H]: h_t of direction d at columns [H d, H d + H); h_0 = c_0 = 0.  256 workgroups in 8 independent
- * groups (direction x 16 * mmego_lstm_seq_xcd_tiles(Bn) rows) that exchange h_t as (value, tag) words through xbuf.  sync: 80 unsigned
- * words, xbuf: 2 * 8 * 16 * 512 * mmego_lstm_seq_xcd_tiles(Bn) 8-byte words, both zero before the first launch and private to one stream of launches; sync[9] is a sticky error flag (non-zero: a
+ * groups (direction x 16 rows) that exchange h_t as (value, tag) words through xbuf.  sync: 16 unsigned words, xbuf: 2 * 8 * 16 * 512
+ * 8-byte words, both zero before the first launch and private to one stream of launches; sync[9] is a sticky error flag (non-zero: a
  * bounded spin ran out -- the launch's workgroups could not all be resident -- and the results are invalid), sync[10] the launch
  * generation. */
 int mmego_lstm_seq_xcd_ok(int Bn, int H, int T);
-int mmego_lstm_seq_xcd_tiles(int Bn);
 int mmego_lstm_seq_xcd(void* stream, const float* xproj, long xs, const float* whh0, const float* whh1, const float* bhh0,
                        const float* bhh1, float* out, long os, unsigned* sync, unsigned long long* xbuf, int Bn, int H, int T);
 /* The same launch with the six stages' operands (folded weights, activation tiles) rounded to bf16 and fp32 accumulation

@@ -400,20 +400,17 @@ class two_chains:
 _LSTM_SEQ_XCD = os.environ.get("MMEGO_LSTM_SEQ_XCD", "1") != "0"
 
 
-def seq_xcd_sync(ar, key, tiles=1):
+def seq_xcd_sync(ar, key):
     """The synchronisation words and the exchange buffer of mmego_lstm_seq_xcd for one BiLSTM stack of one net (its arena): zero when
     created; word 9 of the first is the kernel's sticky error flag (seq_xcd_errors), word 10 its launch generation."""
     name = "%s.seqsync" % key
     fresh = not ar.has(name)
-    t = ar.get(name, (128,), dtype=torch.int32)
-    xname = "%s.seqxbuf%d" % (key, tiles)
-    xfresh = not ar.has(xname)
-    x = ar.get(xname, (2, 8, 16 * tiles, 512), dtype=torch.int64)
+    t = ar.get(name, (16,), dtype=torch.int32)
+    x = ar.get("%s.seqxbuf" % key, (2, 8, 16, 512), dtype=torch.int64)
     if fresh:
         t.zero_()
-        _seq_sync_bufs.append(t)
-    if xfresh:
         x.zero_()
+        _seq_sync_bufs.append(t)
     return t, x
 
 
@@ -452,9 +449,9 @@ def lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T, gst=None, cst=None):
     b0, b1 = lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1)
     if (_LSTM_SEQ_XCD and gst is None and cst is None and T > 1 and w0.is_contiguous() and w1.is_contiguous()
             and hip.lib().mmego_lstm_seq_xcd_ok(Bn, H, T)):
-        # <= 512 rows and H = 512 (IMU_Net's rnn_slow and rnn_fast in frozen / eval forwards): the layer's whole recurrence as ONE
-        # persistent launch with stationary weights (lstm_seq.hip): 2 launches per BiLSTM stack instead of 2 T (or 4 T - 2)
-        sync, xbuf = seq_xcd_sync(ar, key, int(hip.lib().mmego_lstm_seq_xcd_tiles(Bn)))
+        # <= 64 rows (IMU_Net's rnn_slow): the layer's whole recurrence as ONE persistent launch with stationary weights
+        # (lstm_seq.hip): 2 launches per forward instead of 2 T
+        sync, xbuf = seq_xcd_sync(ar, key)
         hip.call("lstm_seq_xcd", xp, xp.stride(0), w0, w1, b0, b1, out, out.stride(0), sync, xbuf, Bn, H, T)
         return
     c = ar.get("%s.c" % key, (2, Bn, H))

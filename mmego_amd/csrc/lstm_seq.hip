@@ -37,7 +37,6 @@ struct LstmSeqP {
   unsigned* sync;                        // [8 unused | done counter | error word | launch generation], zero before the first launch
   unsigned long long* xbuf;              // [2 stages][8 groups][16 rows][512] (value bits | tag << 32), zero before the first launch
   int Bn, T;
-  int dbg;                               // diagnostic mask (MMEGO_LQ_DBG; 0 in production): phases to skip, for timing by elimination
 };
 
 // (the step kernels' forms: lstm_step.hip)
@@ -184,187 +183,12 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_xcd_kernel(LstmSeqP p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// The same for up to 512 rows (IMU_Net's rnn_fast: 512 rows x 20 samples): a group owns RT row tiles of 16 rows and walks them inside
-// every timestep with its weights still in registers -- 128 MFMA steps per wave and tile, the matrix pipe of every SIMD busy.  A tile's
-// h_{t-1} was produced RT tiles ago, so its exchange is off the critical path and uses plain values + one arrival counter per (group,
-// tile): a workgroup signals a tile one tile late (by then its stores have long been acknowledged: no wait), a consumer reads the
-// counter two tiles ahead of use (the answer is there when it is needed) and then has the tile's 16 x 512 floats copied global -> LDS
-// by LDS-DMA (agent scope) under the MFMAs of the tile before: no registers, no VALU work.  One barrier per tile hands over the gate
-// tiles and the next operand stage.  Cell states live in LDS (RT x 256 floats).  (A first version moved (value, tag) words through
-// registers in four batches per tile, each requested one MFMA group -- 0.4 us -- ahead of its use: 50 us per timestep, every batch
-// waited for.)  Per timestep a workgroup multiplies 8.4 MFLOP = 13.7 us of its CU's fp32 MFMA rate at RT = 8, against 18.7 us per
-// timestep of a layer for the two chains of step launches (lstm_step_dma_kernel<16>).
-// One lane reads the counter, the wave shares the value: an atomic load issued by all 64 lanes is 64 atomic operations on ONE address,
-// which the L2 channel takes one after the other (1024 waves polling every tile: 3.6 us per tile, more than the tile's MFMAs).
-__device__ __forceinline__ unsigned lq_poll(const unsigned* p, int lane) {
-  unsigned v = 0u;
-  if (lane == 0) v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return __builtin_amdgcn_readfirstlane(v);
-}
-
-#define LQ_GLDS16(gptr, lptr)                                                                               \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 16)   /* aux 16: sc1 = agent scope */
-
-template <int RT>
-__global__ __launch_bounds__(256, 2) void lstm_seq_rows_kernel(LstmSeqP p) {
-  extern __shared__ __attribute__((aligned(16))) float lq_sm[];
-  float* hs = lq_sm;                                   // [2][16 * LQ_RS]
-  float* gsm = hs + 2 * 16 * LQ_RS;                    // [2][4][16][17]
-  float* cs = gsm + 2 * 4 * 16 * 17;                   // [RT][256]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = blockIdx.x, g = wg & 7, c = wg >> 3;
-  const int d = g >> 2, r0 = (g & 3) * 16 * RT;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int T = p.T, H = LQ_H;
-  unsigned* done = p.sync + 8;
-  unsigned* err = p.sync + 9;
-  unsigned* cnt = p.sync + 16 + g * 8;                 // arrivals per row tile of this group (32 per timestep)
-  constexpr long STAGE = 8L * RT * 16 * LQ_H;          // floats per exchange stage
-  float* xg = reinterpret_cast<float*>(p.xbuf) + (long)g * RT * 16 * LQ_H;
-
-  f32x4 wreg[32];
-  {
-    const float* wrow = p.whh[d] + ((long)wave * H + 16 * c + fr) * H + 128 * fq;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) wreg[j] = *reinterpret_cast<const f32x4*>(wrow + 4 * j);
-  }
-  const int crow = tid >> 4, cu = tid & 15;
-  const int unit = 16 * c + cu;
-  float bh[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) bh[q] = p.bhh[d] ? p.bhh[d][q * H + unit] : 0.f;
-  const float* xq = p.xproj + d * 4 * H + unit;
-  float* oq = p.out + d * H + unit;
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) cs[rt * 256 + tid] = 0.f;
-  const int ntile = T * RT;
-#define LQ_TIME(s_) (d == 0 ? (s_) : T - 1 - (s_))
-  float xp[4], xpn[4];
-  {
-    const int b0 = r0 + crow < p.Bn ? r0 + crow : p.Bn - 1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) xp[q] = xq[((long)b0 * T + LQ_TIME(0)) * p.xs + q * H];
-  }
-  unsigned pollv = 0u, polln = 0u;                     // arrival counts read ahead: for tile q + 1 / for tile q + 2
-#pragma unroll 1
-  for (int q = 0; q < ntile; ++q) {
-    const int s = q / RT, rt = q - s * RT;
-    const int t = LQ_TIME(s);
-    const int brow = r0 + rt * 16 + crow;
-    const bool live = brow < p.Bn;
-    const long xrow = (long)(live ? brow : p.Bn - 1) * T;
-    // ---- (1) the operand of tile q + 1 (h of its timestep - 1): arrived?  then LDS-DMA into the other stage, under this tile's MFMAs
-    if (q + 1 < ntile && q + 1 >= RT) {
-      const int sn = (q + 1) / RT, rn = (q + 1) - sn * RT;
-      const unsigned want = (p.dbg & 16) ? 0u : 32u * (unsigned)sn;
-      int spins = 0;
-      while (pollv < want) {
-        pollv = lq_poll(cnt + rn, lane);
-        if (++spins > LQ_SPIN_MAX) { if (lane == 0) atomicOr(err, 1u); break; }
-      }
-      const float* src = xg + (long)((sn - 1) & 1) * STAGE + (long)rn * 16 * LQ_H;
-      float* dst = hs + ((q + 1) & 1) * 16 * LQ_RS;
-      if (!(p.dbg & 2)) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {                              // wave w: rows 4 w .. 4 w + 3, two 256-float halves each
-          const int row = 4 * wave + (u >> 1), hf = u & 1;
-          LQ_GLDS16(src + row * LQ_H + hf * 256 + lane * 4, dst + row * LQ_RS + hf * 256);
-        }
-      }
-    }
-    // ---- (2) the arrival count of tile q + 2, requested now, looked at in the next pass
-    if (q + 2 < ntile && q + 2 >= RT && !(p.dbg & 16)) {
-      const int rn2 = (q + 2) % RT;
-      polln = lq_poll(cnt + rn2, lane);
-    }
-    {
-      const int qn = q + 1 < ntile ? q + 1 : q, sn = qn / RT, rn = qn - sn * RT;
-      const int bn = r0 + rn * 16 + crow < p.Bn ? r0 + rn * 16 + crow : p.Bn - 1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xpn[k] = xq[((long)bn * T + LQ_TIME(sn)) * p.xs + k * H];
-    }
-    // ---- (3) the product
-    float* gw = gsm + (q & 1) * 4 * 16 * 17;
-    if (s > 0 && !(p.dbg & 1)) {
-      f32x4 acc[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const float* ha = hs + (q & 1) * 16 * LQ_RS + fr * LQ_RS + 128 * fq;
-#pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(ha + 4 * j);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wreg[j].x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wreg[j].y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wreg[j].z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wreg[j].w, acc[3], 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) gw[(wave * 16 + 4 * fq + i) * 17 + fr] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
-    }
-    // ---- (4) hand-over: the DMA of (1) has landed, the stores of the tile before have been acknowledged -> signal that tile
-    if (!(p.dbg & 8)) __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tid == 0 && q >= 1 && (q - 1) / RT + 1 < T && !(p.dbg & 32)) __hip_atomic_fetch_add(cnt + (q - 1) % RT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- (5) cell update of (tile row crow, unit)
-    float pre[4] = {0.f, 0.f, 0.f, 0.f};
-    if (s > 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) pre[k] = gw[(k * 16 + crow) * 17 + cu];
-    }
-    const float gi = lq_sigmoid(pre[0] + (xp[0] + bh[0]));
-    const float gf = lq_sigmoid(pre[1] + (xp[1] + bh[1]));
-    const float gg = lq_tanh(pre[2] + (xp[2] + bh[2]));
-    const float go = lq_sigmoid(pre[3] + (xp[3] + bh[3]));
-    const float cn = gf * cs[rt * 256 + tid] + gi * gg;
-    cs[rt * 256 + tid] = cn;
-    const float hval = go * lq_tanh(cn);
-    if (live) oq[(xrow + t) * p.os] = hval;
-    if (s + 1 < T && !(p.dbg & 4)) __hip_atomic_store(xg + (long)(s & 1) * STAGE + (long)(rt * 16 + crow) * LQ_H + unit, hval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) xp[k] = xpn[k];
-    pollv = polln;
-  }
-#undef LQ_TIME
-  // ---- the last workgroup of the launch puts the arrival counters back to zero (nobody reads them any more)
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned n = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n == gridDim.x - 1) {
-      for (int i = 0; i < 64; ++i) __hip_atomic_store(p.sync + 16 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned gen = __hip_atomic_load(p.sync + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p.sync + 10, (gen + 1u) & 0xFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-template <int RT>
-static int lstm_seq_rows_launch(hipStream_t st, const LstmSeqP& p) {
-  constexpr size_t lds = (size_t)(2 * 16 * LQ_RS + 2 * 4 * 16 * 17 + RT * 256) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_seq_rows_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  hipLaunchKernelGGL(lstm_seq_rows_kernel<RT>, dim3(256), dim3(256), lds, st, p);
-  MMEGO_LAUNCH_CHECK();
-  return MMEGO_OK;
-}
-
-// row tiles of 16 per group that mmego_lstm_seq_xcd uses for Bn rows (1: the 64-row kernel; 4 / 8); xbuf needs 2 * 8 * 16 * 512 * that
-// many 8-byte words
-// (a tile is signalled one tile late and looked for RT - 1 tiles after it was produced: RT >= 4 in the row-tiled kernel)
-extern "C" int mmego_lstm_seq_xcd_tiles(int Bn) { return Bn <= 64 ? 1 : (Bn <= 256 ? 4 : 8); }
-
 // 1 when mmego_lstm_seq_xcd takes the shape
-extern "C" int mmego_lstm_seq_xcd_ok(int Bn, int H, int T) { return Bn >= 1 && Bn <= 512 && H == LQ_H && T >= 1 && T <= 4095; }
+extern "C" int mmego_lstm_seq_xcd_ok(int Bn, int H, int T) { return Bn >= 1 && Bn <= 64 && H == LQ_H && T >= 1 && T <= 4095; }
 
 // One BiLSTM layer's recurrence, both directions, all T timesteps in one launch.  xproj [Bn*T][xs >= 8H] rows (b*T + t): W_ih x + b_ih of
 // direction d at columns [4H d, 4H d + 4H); out [Bn*T][os >= 2H]: h_t of direction d at columns [H d, H d + H); h_0 = c_0 = 0.
-// sync: 80 unsigned words and xbuf: 2 * 8 * 16 * 512 * mmego_lstm_seq_xcd_tiles(Bn) 8-byte words, both zero before the first launch and private to one stream of
+// sync: 16 unsigned words and xbuf: 2 * 8 * 16 * 512 8-byte words, both zero before the first launch and private to one stream of
 // launches (word 8: done counter, left zero; word 9: sticky error flag, non-zero after a launch whose workgroups could not all
 // become resident -- its results are invalid; word 10: launch generation).
 extern "C" int mmego_lstm_seq_xcd(void* stream, const float* xproj, long xs, const float* whh0, const float* whh1, const float* bhh0,
@@ -374,13 +198,6 @@ extern "C" int mmego_lstm_seq_xcd(void* stream, const float* xproj, long xs, con
   LstmSeqP p;
   p.xproj = xproj; p.xs = xs; p.whh[0] = whh0; p.whh[1] = whh1; p.bhh[0] = bhh0; p.bhh[1] = bhh1;
   p.out = out; p.os = os; p.sync = sync; p.xbuf = xbuf; p.Bn = Bn; p.T = T;
-  {
-    const char* e = getenv("MMEGO_LQ_DBG");            // (read per call: scripts/bench_lstm_seq.py switches it)
-    p.dbg = e ? atoi(e) : 0;
-  }
-  const int rt = mmego_lstm_seq_xcd_tiles(Bn);
-  if (rt == 4) return lstm_seq_rows_launch<4>((hipStream_t)stream, p);
-  if (rt == 8) return lstm_seq_rows_launch<8>((hipStream_t)stream, p);
   hipLaunchKernelGGL(lstm_seq_xcd_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;

@@ -935,13 +935,12 @@ def test_transpose_batched_bit_exact(dev, Bn, R, C):
     assert torch.all(out[Bn * R * C:] == 7.0)
 
 
-@pytest.mark.parametrize("Bn,T", [(64, 8), (37, 5), (16, 2), (5, 16), (64, 1), (512, 20), (100, 3), (200, 4), (300, 2), (65, 7)])
+@pytest.mark.parametrize("Bn,T", [(64, 8), (37, 5), (16, 2), (5, 16), (64, 1), (65, 3)])
 def test_rnn_slow_persistent_recurrence_against_the_step_launches(dev, Bn, T, monkeypatch):
     """mmego_lstm_seq_xcd (lstm_seq.hip: a BiLSTM(512) layer's whole recurrence for <= 64 rows as one persistent launch, weights
     stationary) against the launch-per-timestep form on the same projections: same expressions, the products summed in another
     order -> 2e-6 absolute on |h| < 1 after up to 20 steps and two layers; no bounded spin ran out; the synchronisation words are
-    back at zero; a second run gives the same bits (fixed summation order); T = 1 takes the step path.  More than 64 rows (rnn_fast's
-    512 x 20): the row-tiled kernel with 4 / 8 tiles per group, ragged row counts included."""
+    back at zero; a second run gives the same bits (fixed summation order); T = 1 and more than 64 rows take the step path."""
     from mmego_amd import blocks, ops
     torch.manual_seed(Bn * 100 + T)
     H, In = 512, 1024
@@ -954,17 +953,16 @@ def test_rnn_slow_persistent_recurrence_against_the_step_launches(dev, Bn, T, mo
         o = blocks.lstm_steps_forward(ar, "slow", lstm, x, Bn, T).clone()
         torch.cuda.synchronize()
         if on:
-            assert ar.has("slow.seqsync") == (T > 1)
+            assert ar.has("slow.seqsync") == (T > 1 and Bn <= 64)
             assert blocks.seq_xcd_errors(ar) == 0
-            if T > 1:
-                words = ar.get("slow.seqsync", (128,), dtype=torch.int32).cpu()
+            if T > 1 and Bn <= 64:
+                words = ar.get("slow.seqsync", (16,), dtype=torch.int32).cpu()
                 assert int(words[8]) == 0 and int(words[9]) == 0 and int(words[10]) == 2        # two layers = two launches
-                assert int(words[16:80].abs().sum()) == 0                                      # arrival counters back at zero
             if True in outs:
                 assert torch.equal(outs[True], o)
         outs[on] = o
     err = float((outs[True] - outs[False]).abs().max())
     assert torch.isfinite(outs[True]).all()
     assert err < 2e-6, err
-    if T == 1:
+    if T == 1 or Bn > 64:
         assert torch.equal(outs[True], outs[False])
