@@ -13,10 +13,11 @@
 //   * the exchange is IN-BAND: a workgroup stores its 16 x 16 slice of h_t as 8-byte (value, tag) words -- tag = launch generation and
 //     timestep, one atomic store each -- into a two-stage exchange buffer and goes on; nobody waits for a store to be acknowledged
 //     and there is no arrival counter (store -> ack -> atomic -> poll -> load were four dependent trips to the memory side: 3.5-4.0
-//     us per step in scripts/bench_handoff.hip, variant C; 6.2 us per step for the kernel built that way).  A consumer polls ONE
-//     word per producer (32 per step, one wave), then fetches the group's 16 x 512 words once and checks every tag (a straggler is
-//     fetched again), copies the values into LDS, multiplies (128 MFMA steps per wave over four accumulation chains), swaps the
-//     four gate tiles through LDS and updates its cells.  The plain h_t goes to the layer's output tensor beside it.
+//     us per step in scripts/bench_handoff.hip, variant C; 6.2 us per step for the kernel built that way).  A consumer fetches the
+//     group's 16 x 512 words in two batches and checks every tag (a batch with a word still missing is fetched again: agent-scope
+//     loads are served at L2 speed, a retry is cheap -- polling one word per producer first was 2 us per layer slower), copies the
+//     values into LDS, multiplies (128 MFMA steps per wave over four accumulation chains), swaps the four gate tiles through LDS and
+//     updates its cells.  The plain h_t goes to the layer's output tensor beside it.
 // Every spin is bounded: a grid that cannot make progress (three such launches side by side would wait for each other's CUs) sets
 // an error word and runs to its end with wrong results instead of hanging the GPU; the host checks the word (blocks.seq_xcd_check).
 // The last workgroup to finish resets the counters, so a launch leaves them as it found them (graph replays need no memset node).
@@ -90,19 +91,9 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_xcd_kernel(LstmSeqP p) {
     for (int q = 0; q < 4; ++q) xpn[q] = xq[(xrow + tn) * p.xs + q * H];
     float pre[4] = {0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-      // ---- the group's h_{t-1}: poll one word per producer, fetch all 16 x 512 once, check every tag
+      // ---- the group's h_{t-1}: fetch all 16 x 512 words, check every tag, fetch a batch again while a word is missing
       const unsigned tag = gen * 4096u + (unsigned)s;             // written by the producers at step s - 1
       const unsigned long long* xs_ = xg + (long)((s - 1) & 1) * 8 * 16 * LQ_H;
-      if (wave == 0) {
-        const unsigned long long* f = xs_ + (lane & 31) * 16;     // row 0, first unit of producer lane & 31
-        int spins = 0;
-        while (true) {
-          const unsigned long long w = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (__all((unsigned)(w >> 32) == tag)) break;
-          if (++spins > LQ_SPIN_MAX) { if (lane == 0) atomicOr(err, 1u); break; }
-        }
-      }
-      __syncthreads();
       {
         // element (row u / 2, k = 256 (u % 2) + tid) in round u: an instruction reads 2 KB of one row; two batches of 16 rounds
         // (the weights hold 128 of the 256 registers)
