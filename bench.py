@@ -861,7 +861,7 @@ def main():
                 sl_e._body()
         eager()
         torch.cuda.synchronize()
-        rec, iters = profile_kernels(eager, ("lstm_step", "gemm"))
+        rec, iters = profile_kernels(eager, ("lstm_step", "gemm", "lstm_seq_xcd"))
         # lstm_step: args = (ndir, Bn, H, first, ...).  Algorithmic flops per launch = 2 * ndir * Bn * 4H * H (0 for the
         # first timestep of a sequence, whose h_{t-1} = 0 product is skipped).  ALL launches of the kernel family are
         # averaged, so avg_launch_us is directly comparable with rocprofv3's per-kernel AverageNs.
@@ -889,6 +889,11 @@ def main():
                   "step: see recurrence_graph)"] = big16
         if small:
             cands["lstm_step_small_kernel (IMU_Net rnn_slow recurrent steps: 2 dirs x 64 rows x 2048 gates x K=512)"] = small
+        # rnn_slow's recurrence as one persistent launch per layer (lstm_seq.hip): args = (..., Bn, H, T) at 10..12; T - 1 product steps
+        seqx = [(ms_, 2.0 * 2 * a[10] * 4 * a[11] * a[11] * (a[12] - 1)) for ms_, a in rec.get("lstm_seq_xcd", [])]
+        if seqx:
+            cands["lstm_seq_xcd_kernel (IMU_Net rnn_slow: a layer's whole recurrence per launch, 2 dirs x 64 rows x 2048 gates x K=512 x "
+                  "(T-1) steps, weights stationary)"] = seqx
         if g128:
             cands["gemm_tile_persistent_kernel (128x128 tiles; IMU_Net LSTM input projections, both directions per launch: 2 x 10240 x 2048 x {512,1024})"] = g128
         if g64:
