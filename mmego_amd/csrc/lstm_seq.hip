@@ -175,7 +175,21 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_xcd_kernel(LstmSeqP p) {
 }
 
 // 1 when mmego_lstm_seq_xcd takes the shape
-extern "C" int mmego_lstm_seq_xcd_ok(int Bn, int H, int T) { return Bn >= 1 && Bn <= 64 && H == LQ_H && T >= 1 && T <= 4095; }
+// (the 256 workgroups of a launch wait for each other: they must all be resident -- two fit on a CU, so at least 128 CUs; on a smaller
+// device or partition the caller keeps the launch-per-timestep form)
+static int lq_device_fits() {
+  static int fits = -1;
+  if (fits < 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    fits = cus >= 128 ? 1 : 0;
+  }
+  return fits;
+}
+
+extern "C" int mmego_lstm_seq_xcd_ok(int Bn, int H, int T) {
+  return Bn >= 1 && Bn <= 64 && H == LQ_H && T >= 1 && T <= 4095 && lq_device_fits();
+}
 
 // One BiLSTM layer's recurrence, both directions, all T timesteps in one launch.  xproj [Bn*T][xs >= 8H] rows (b*T + t): W_ih x + b_ih of
 // direction d at columns [4H d, 4H d + 4H); out [Bn*T][os >= 2H]: h_t of direction d at columns [H d, H d + H); h_0 = c_0 = 0.
