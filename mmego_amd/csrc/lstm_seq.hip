@@ -29,7 +29,7 @@
 
 #define LQ_H 512
 #define LQ_RS (LQ_H + 4)                  // LDS row stride of the h tile (floats): 16-byte aligned, rows on distinct bank groups
-#define LQ_SPIN_MAX (1 << 22)
+#define LQ_SPIN_MAX (1 << 20)        // ~1 s of retries: far beyond any wait for co-resident workgroups, short enough that a stuck grid ends
 
 struct LstmSeqP {
   const float* xproj; long xs;           // input projections [Bn*T rows (b*T + t)][8H]: direction d at column offset d * 4H; xs = row stride
