@@ -966,3 +966,32 @@ def test_rnn_slow_persistent_recurrence_against_the_step_launches(dev, Bn, T, mo
     assert err < 2e-6, err
     if T == 1 or Bn > 64:
         assert torch.equal(outs[True], outs[False])
+
+
+def test_two_persistent_recurrences_side_by_side(dev):
+    """Two mmego_lstm_seq_xcd launch chains on two streams at once (what PipelinedStages does with the two frozen IMU_Net forwards):
+    each launch's 256 workgroups wait for each other, so both grids must be resident together (two workgroups per CU).  Results equal
+    the one-at-a-time runs bit for bit, no bounded spin runs out."""
+    from mmego_amd import blocks, ops
+    H, In, Bn, T = 512, 1024, 64, 8
+    nets_ = []
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        lstm = blocks.LstmParams(In, H, 2).to(dev)
+        x = torch.randn(Bn * T, In, generator=torch.Generator().manual_seed(10 + seed)).to(dev)
+        nets_.append((lstm, x, ops.Arena(dev)))
+    alone = [blocks.lstm_steps_forward(ar, "slow", lstm, x, Bn, T).clone() for lstm, x, ar in nets_]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None, None]
+    for it in range(20):
+        for i, (lstm, x, ar) in enumerate(nets_):
+            streams[i].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[i]):
+                outs[i] = blocks.lstm_steps_forward(ar, "slow", lstm, x, Bn, T)
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    assert blocks.seq_xcd_errors() == 0
+    for a, o in zip(alone, outs):
+        assert torch.equal(a, o)
