@@ -466,6 +466,12 @@ int mmego_mlp_bwd_layer_gather(void* stream, const float* dY, long lddy, const f
                                long lddx, float* dW_part);
 int mmego_mlp_dw_reduce(void* stream, long rows, int nlayers, const float* part0, float* dW0, int Cout0, int Cin0,
                         const float* part1, float* dW1, int Cout1, int Cin1, const float* part2, float* dW2, int Cout2, int Cin2);
+/* mmego_mlp_dw_reduce for up to 9 layers of several chains in ONE launch (descs: n MmegoDwRed; a layer's partials are
+ * mmego_mlp_train_nblk(rows) x 4096 floats).  nblk > 0 / stride > 0 describe other per-workgroup partial records summed the same way:
+ * nblk records `stride` floats apart, element (m, n) of a record at m * 64 + n (e.g. the pooling kernels' attention-parameter partials:
+ * Cout = 1, Cin = 64, stride 128). */
+typedef struct MmegoDwRed { const float* part; float* dW; int Cout, Cin; long rows; int nblk; long stride; } MmegoDwRed;
+int mmego_mlp_dw_reduce_multi(void* stream, int n, const void* descs);
 
 /* ---- fused ST-GCN training step (gcn_fused.hip, gcn.hip): Net/GCN.py:67-147 st_gcn, :332-355 Model.extract_feature -----------------
  * Train-mode BatchNorm statistics travel between these kernels as PARTIAL RECORDS: per producer workgroup j and channel c the float

@@ -118,9 +118,43 @@ def _mlp3_backward_fused(ar, key, mod, x, dy3, G, need_dx, have_sums=False, gath
                      xin, xin.stride(0), dims[i - 1], sts[i - 1].all if i > 1 else None, conv.weight, dprev,
                      dprev.stride(0) if want_dx else 0, gp[i - 1] if i > 1 else None, dwp[i])
         dy = dprev
-    hip.call("mlp_dw_reduce", rows, 3, dwp[1], G(layers[0][0].weight), dims[1], dims[0], dwp[2], G(layers[1][0].weight), dims[2],
-             dims[1], dwp[3], G(layers[2][0].weight), dims[3], dims[2])
+    descs = [hip.DwRed(hip.ptr(dwp[i]), hip.ptr(G(layers[i - 1][0].weight)), dims[i], dims[i - 1], rows, 0, 0) for i in (1, 2, 3)]
+    if _dw_group is not None:
+        _dw_group.extend(descs)                              # summed by ONE launch at the end of the backward pass (dw_reduce_group)
+        _dw_keep.extend(dwp[1:])
+    else:
+        hip.call("mlp_dw_reduce", rows, 3, dwp[1], G(layers[0][0].weight), dims[1], dims[0], dwp[2], G(layers[1][0].weight), dims[2],
+                 dims[1], dwp[3], G(layers[2][0].weight), dims[3], dims[2])
     return dy if need_dx else None
+
+
+_dw_group = None
+_dw_keep = []
+
+
+class dw_reduce_group:
+    """Context around a backward pass with several fused pointwise-MLP chains (Upper_Net: GlobalPointNet + PointNet; UpperNetwlocal: three):
+    their weight-gradient partials are summed by ONE mmego_mlp_dw_reduce_multi launch when the context ends instead of one launch per
+    chain (same sums, same order: the kernel works layer by layer)."""
+
+    def __enter__(self):
+        global _dw_group
+        if _dw_group is not None:
+            raise RuntimeError("dw_reduce_group contexts do not nest")
+        _dw_group = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _dw_group
+        descs, _dw_group = _dw_group, None
+        try:
+            if et is None:
+                for i in range(0, len(descs), 9):
+                    part = descs[i:i + 9]
+                    hip.call("mlp_dw_reduce_multi", len(part), (hip.DwRed * len(part))(*part))
+        finally:
+            del _dw_keep[:]
+        return False
 
 
 _POOL_FUSED = os.environ.get("MMEGO_POOL_FUSED", "1") != "0"
@@ -351,7 +385,12 @@ def pool128_backward_fused(ar, key, mod, lin, attn, vec, dvec, rows, dY, G):
     awp = ar.get("%s.awp" % key, (nblk, 128))
     hip.call("pool128_backward", z3, 64, rows, ops.BnState(ar, "%s.bn3" % key, 64).all, attn, vec, dvec, lin.weight, dY, dY.stride(0), gp3, awp)
     gw, gb = G(lin.weight).view(-1), G(lin.bias)
-    if gb.data_ptr() == gw.data_ptr() + 4 * gw.numel():       # weight and bias gradient slots back to back: one column sum
+    if _dw_group is not None:
+        # the attention parameters' per-workgroup partials join the pass's one reduce launch (dw_reduce_group)
+        _dw_group.append(hip.DwRed(hip.ptr(awp), hip.ptr(gw), 1, 64, 0, nblk, 128))
+        _dw_group.append(hip.DwRed(hip.ptr(awp[:, 64:]), hip.ptr(gb), 1, 1, 0, nblk, 128))
+        _dw_keep.append(awp)
+    elif gb.data_ptr() == gw.data_ptr() + 4 * gw.numel():     # weight and bias gradient slots back to back: one column sum
         ops.colsum(awp[:, :65], torch.as_strided(gw, (65,), (1,)))
     else:
         ops.colsum(awp[:, :64], gw)

@@ -465,8 +465,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
   if (want_prev) mt_store_partials<8>(s1, s2, col, grp * 4 + rt * 2 + (lane >> 5), p.gprev_part, red);
 }
 
-// dW[l][cout][cin] = sum over the workgroups' partials, fixed order, fp64 accumulation; up to 3 layers per launch
-struct MlpDwP { const float* part[3]; float* dW[3]; int Cout[3], Cin[3], nblk[3]; int nlayers; };
+// dW[l][cout][cin] = sum over the workgroups' partials, fixed order, fp64 accumulation; up to 9 layers (three chains) per launch
+#define MT_DW_MAX 9
+struct MlpDwP { const float* part[MT_DW_MAX]; float* dW[MT_DW_MAX]; int Cout[MT_DW_MAX], Cin[MT_DW_MAX], nblk[MT_DW_MAX]; long stride[MT_DW_MAX]; int nlayers; };
 
 __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(MlpDwP p) {
   // 16 elements per workgroup, 16 lanes per element: lane s sums partials s, s + 16, ... (all loads in flight), then the 16
@@ -475,6 +476,7 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(MlpDwP p) {
   const int l = blockIdx.y;
   if (l >= p.nlayers) return;
   const int Cout = p.Cout[l], Cin = p.Cin[l], nblk = p.nblk[l];
+  const long pstride = p.stride[l];                       // floats between two workgroups' partials (64 x 64 for a dW tile)
   const int e = threadIdx.x >> 4, s_ = threadIdx.x & 15;
   for (int i0 = blockIdx.x * 16; i0 < Cout * Cin; i0 += gridDim.x * 16) {
     const int i = i0 + e;
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(MlpDwP p) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int b = s_ + 16 * u;
-        const float vl = src[(long)(b < nblk ? b : nblk - 1) * 64 * 64];      // (clamped: load, then select)
+        const float vl = src[(long)(b < nblk ? b : nblk - 1) * pstride];      // (clamped: load, then select)
         v[u] = b < nblk ? vl : 0.f;
       }
 #pragma unroll
@@ -647,16 +649,38 @@ extern "C" int mmego_mlp_dw_reduce(void* stream, long rows, int nlayers, const f
   MMEGO_REQUIRE(nlayers < 3 || (part2 && dW2));
   int nblk; long rpw;
   mt_grid(rows, &nblk, &rpw);
-  MlpDwP p;
+  MlpDwP p = {};
   p.part[0] = part0; p.dW[0] = dW0; p.Cout[0] = Cout0; p.Cin[0] = Cin0;
   p.part[1] = part1; p.dW[1] = dW1; p.Cout[1] = Cout1; p.Cin[1] = Cin1;
   p.part[2] = part2; p.dW[2] = dW2; p.Cout[2] = Cout2; p.Cin[2] = Cin2;
   for (int l = 0; l < 3; ++l) {
     p.nblk[l] = nblk;
+    p.stride[l] = 64 * 64;
     if (l < nlayers) MMEGO_REQUIRE(p.Cout[l] >= 1 && p.Cout[l] <= 64 && p.Cin[l] >= 1 && p.Cin[l] <= 64);
   }
   p.nlayers = nlayers;
   hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(256, nlayers), dim3(256), 0, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// The same sum for up to 9 layers of SEVERAL chains in one launch (a net with two or three pointwise-MLP chains had one reduce launch
+// per chain at the end of each: the partials stay where they are until the pass ends, one node instead of two or three).
+struct MmegoDwRedH { const float* part; float* dW; int Cout, Cin; long rows; int nblk; long stride; };   // host mirror of include/mmego_hip.h's MmegoDwRed
+extern "C" int mmego_mlp_dw_reduce_multi(void* stream, int n, const void* descs) {
+  MMEGO_REQUIRE(n >= 1 && n <= MT_DW_MAX && descs);
+  const MmegoDwRedH* d = static_cast<const MmegoDwRedH*>(descs);
+  MlpDwP p = {};
+  for (int l = 0; l < n; ++l) {
+    MMEGO_REQUIRE(d[l].part && d[l].dW && (d[l].rows > 0 || d[l].nblk > 0) && d[l].Cout >= 1 && d[l].Cout <= 64 && d[l].Cin >= 1 && d[l].Cin <= 64);
+    int nblk = d[l].nblk; long rpw;
+    if (nblk <= 0) mt_grid(d[l].rows, &nblk, &rpw);
+    MMEGO_REQUIRE(nblk <= 256 && d[l].stride >= 0);
+    p.part[l] = d[l].part; p.dW[l] = d[l].dW; p.Cout[l] = d[l].Cout; p.Cin[l] = d[l].Cin; p.nblk[l] = nblk;
+    p.stride[l] = d[l].stride > 0 ? d[l].stride : 64 * 64;
+  }
+  p.nlayers = n;
+  hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -114,6 +114,12 @@ class Pack(ctypes.Structure):
                 ("kind", ctypes.c_int)]
 
 
+class DwRed(ctypes.Structure):
+    """MmegoDwRed of include/mmego_hip.h: one layer's weight-gradient partials to be summed by mmego_mlp_dw_reduce_multi."""
+    _fields_ = [("part", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("Cout", ctypes.c_int), ("Cin", ctypes.c_int), ("rows", ctypes.c_long),
+                ("nblk", ctypes.c_int), ("stride", ctypes.c_long)]
+
+
 class Slab(ctypes.Structure):
     """MmegoSlab of include/mmego_hip.h: one deferred partial-product sum."""
     _fields_ = [("ws", ctypes.c_void_p), ("out", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("asum", ctypes.c_void_p),

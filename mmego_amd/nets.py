@@ -334,14 +334,15 @@ class UpperNet(_NetBase):
         dg3 = ar.get("dg3", (rows, 64))
         feats = ar.get("feats", (rows, 28))
         gpn = self.module1.gpointnet
-        if getattr(self, "_gpool_fused", False):
-            blocks.pool128_backward_fused(ar, "gp", gpn, gpn.attn, attn, vec, dvec, rows, dg3, G)
-            dfeats = blocks._mlp3_backward_fused(ar, "gp", gpn, feats, dg3, G, True, have_sums=True)
-        else:
-            blocks.attn_pool_backward(ar, "gpool", g3, gpn.attn, attn, dvec, F, N, 64, dg3, G)
-            dfeats = blocks.mlp3_backward(ar, "gp", gpn, feats, g3, dg3, G, True)
-        pts = ar.get("pts", (rows, 6))
-        blocks.mlp3_backward(ar, "m0", self.module0, pts, feats[:, 4:28], dfeats[:, 4:28], G, False)
+        with blocks.dw_reduce_group():                         # the two chains' weight-gradient partials: one reduce launch
+            if getattr(self, "_gpool_fused", False):
+                blocks.pool128_backward_fused(ar, "gp", gpn, gpn.attn, attn, vec, dvec, rows, dg3, G)
+                dfeats = blocks._mlp3_backward_fused(ar, "gp", gpn, feats, dg3, G, True, have_sums=True)
+            else:
+                blocks.attn_pool_backward(ar, "gpool", g3, gpn.attn, attn, dvec, F, N, 64, dg3, G)
+                dfeats = blocks.mlp3_backward(ar, "gp", gpn, feats, g3, dg3, G, True)
+            pts = ar.get("pts", (rows, 6))
+            blocks.mlp3_backward(ar, "m0", self.module0, pts, feats[:, 4:28], dfeats[:, 4:28], G, False)
 
 
 # =====================================================================================================

@@ -233,50 +233,54 @@ class UpperNetwlocal(_NetBase):
         blocks.linear_backward(dy, h1, self.module3.fc2, G, dh1, relu_input=True)
         dcat = ar.get("dcat", (F, 256))
         blocks.linear_backward(dh1, cat, self.module3.fc1, G, dcat)
-        # global branch
-        vec = ar.get("vec", (F, 64))
-        dvec = blocks.lstm64_backward(ar, "grnn", self.module1.grnn, vec, B, T, c0g, dcat[:, :128], G, self._drop_p(self.module1.grnn), True)
-        g3, dg3 = ar.get("g3", (rows, 64)), ar.get("dg3", (rows, 64))
-        feats = ar.get("feats", (rows, 28))
-        gpn = self.module1.gpointnet
-        if getattr(self, "_gpool_fused", False):
-            blocks.pool128_backward_fused(ar, "gp", gpn, gpn.attn, gw, vec, dvec, rows, dg3, G)
-            dfeats = blocks._mlp3_backward_fused(ar, "gp", gpn, feats, dg3, G, True, have_sums=True)
-        else:
-            blocks.attn_pool_backward(ar, "gpool", g3, gpn.attn, gw, dvec, F, N, 64, dg3, G)
-            dfeats = blocks.mlp3_backward(ar, "gp", gpn, feats, g3, dg3, G, True)
-        # local branch
-        vvec = ar.get("vvec", (F, 64))
-        dvvec = blocks.lstm64_backward(ar, "arnn", self.module2.arnn.rnn, vvec, B, T, c0a, dcat[:, 128:], G,
-                                       self._drop_p(self.module2.arnn.rnn), True)
-        voxT = ar.get("voxT", (F, 64 * N_ANCHOR))
-        dvoxT = blocks.mlp3_backward(ar, "vx", self.module2.avoxel, voxT, vvec, dvvec, G, True)
-        gidx = ar.get("gidx", (F, N_ANCHOR, N_GROUP), dtype=torch.int64)
-        lp = self.module2.apointnet
-        if getattr(self, "_local_was_fused", False):
-            # pooling backward with the activated rows recomputed, the last stage's BatchNorm sums and the attention parameter
-            # partials from the same kernel; the pooled gradient is read in the Conv3d order (no transpose launch)
-            nblk = hip.lib().mmego_pool8_nblk(grows)
-            z3, dl3 = ar.get("lp.z3", (grows, 64)), ar.get("dl3", (grows, 64))
-            gp3 = ar.get("lp.gp3", (nblk * 2 * 64,), dtype=torch.float64)
-            awp = ar.get("lpool.awp", (nblk, 128))
-            hip.call("pool8_backward", z3, 64, grows, ops.BnState(ar, "lp.bn3", 64).all, aw, dvoxT, lp.attn.weight, dl3, 64, gp3, awp)
-            gw, gb = G(lp.attn.weight).view(-1), G(lp.attn.bias)
-            if gb.data_ptr() == gw.data_ptr() + 4 * gw.numel():       # weight and bias gradient slots back to back: one column sum
-                ops.colsum(awp[:, :65], torch.as_strided(gw, (65,), (1,)))
+        with blocks.dw_reduce_group():                         # the three chains' weight-gradient partials: one reduce launch
+            # global branch
+            vec = ar.get("vec", (F, 64))
+            dvec = blocks.lstm64_backward(ar, "grnn", self.module1.grnn, vec, B, T, c0g, dcat[:, :128], G, self._drop_p(self.module1.grnn), True)
+            g3, dg3 = ar.get("g3", (rows, 64)), ar.get("dg3", (rows, 64))
+            feats = ar.get("feats", (rows, 28))
+            gpn = self.module1.gpointnet
+            if getattr(self, "_gpool_fused", False):
+                blocks.pool128_backward_fused(ar, "gp", gpn, gpn.attn, gw, vec, dvec, rows, dg3, G)
+                dfeats = blocks._mlp3_backward_fused(ar, "gp", gpn, feats, dg3, G, True, have_sums=True)
             else:
-                ops.colsum(awp[:, :64], gw)
-                ops.colsum(awp[:, 64:65], gb)
-            dgrouped = blocks._mlp3_backward_fused(ar, "lp", lp, None, dl3, G, True, have_sums=True,
-                                                   gather=(grows, gidx, feats, 28, self.anchors(feats.device), N, 25))
-            hip.call("anchor_scatter", dgrouped, gidx, F, N, 25, dfeats, 28)
-        else:
-            grouped = ar.get("grouped", (grows, 31))
-            dvox = ar.get("dvox", (F * N_ANCHOR, 64))
-            hip.call("transpose_batched", dvoxT, dvox, F, 64, N_ANCHOR)       # (F,64,27) -> (F,27,64)
-            l3, dl3 = ar.get("l3", (grows, 64)), ar.get("dl3", (grows, 64))
-            blocks.attn_pool_backward(ar, "lpool", l3, lp.attn, aw, dvox, F * N_ANCHOR, N_GROUP, 64, dl3, G)
-            dgrouped = blocks.mlp3_backward(ar, "lp", lp, grouped, l3, dl3, G, True)
-            hip.call("anchor_group_backward", dgrouped, gidx, F, N, 25, dfeats, 28)
-        pts = ar.get("pts", (rows, 6))
-        blocks.mlp3_backward(ar, "m0", self.module0, pts, feats[:, 4:28], dfeats[:, 4:28], G, False)
+                blocks.attn_pool_backward(ar, "gpool", g3, gpn.attn, gw, dvec, F, N, 64, dg3, G)
+                dfeats = blocks.mlp3_backward(ar, "gp", gpn, feats, g3, dg3, G, True)
+            # local branch
+            vvec = ar.get("vvec", (F, 64))
+            dvvec = blocks.lstm64_backward(ar, "arnn", self.module2.arnn.rnn, vvec, B, T, c0a, dcat[:, 128:], G,
+                                           self._drop_p(self.module2.arnn.rnn), True)
+            voxT = ar.get("voxT", (F, 64 * N_ANCHOR))
+            dvoxT = blocks.mlp3_backward(ar, "vx", self.module2.avoxel, voxT, vvec, dvvec, G, True)
+            gidx = ar.get("gidx", (F, N_ANCHOR, N_GROUP), dtype=torch.int64)
+            lp = self.module2.apointnet
+            if getattr(self, "_local_was_fused", False):
+                # pooling backward with the activated rows recomputed, the last stage's BatchNorm sums and the attention parameter
+                # partials from the same kernel; the pooled gradient is read in the Conv3d order (no transpose launch)
+                nblk = hip.lib().mmego_pool8_nblk(grows)
+                z3, dl3 = ar.get("lp.z3", (grows, 64)), ar.get("dl3", (grows, 64))
+                gp3 = ar.get("lp.gp3", (nblk * 2 * 64,), dtype=torch.float64)
+                awp = ar.get("lpool.awp", (nblk, 128))
+                hip.call("pool8_backward", z3, 64, grows, ops.BnState(ar, "lp.bn3", 64).all, aw, dvoxT, lp.attn.weight, dl3, 64, gp3, awp)
+                gw, gb = G(lp.attn.weight).view(-1), G(lp.attn.bias)
+                if nblk <= 256 and blocks._dw_group is not None:          # with the pass's other partial sums (blocks.dw_reduce_group)
+                    blocks._dw_group.append(hip.DwRed(hip.ptr(awp), hip.ptr(gw), 1, 64, 0, nblk, 128))
+                    blocks._dw_group.append(hip.DwRed(hip.ptr(awp[:, 64:]), hip.ptr(gb), 1, 1, 0, nblk, 128))
+                elif gb.data_ptr() == gw.data_ptr() + 4 * gw.numel():     # weight and bias gradient slots back to back: one column sum
+                    ops.colsum(awp[:, :65], torch.as_strided(gw, (65,), (1,)))
+                else:
+                    ops.colsum(awp[:, :64], gw)
+                    ops.colsum(awp[:, 64:65], gb)
+                dgrouped = blocks._mlp3_backward_fused(ar, "lp", lp, None, dl3, G, True, have_sums=True,
+                                                       gather=(grows, gidx, feats, 28, self.anchors(feats.device), N, 25))
+                hip.call("anchor_scatter", dgrouped, gidx, F, N, 25, dfeats, 28)
+            else:
+                grouped = ar.get("grouped", (grows, 31))
+                dvox = ar.get("dvox", (F * N_ANCHOR, 64))
+                hip.call("transpose_batched", dvoxT, dvox, F, 64, N_ANCHOR)       # (F,64,27) -> (F,27,64)
+                l3, dl3 = ar.get("l3", (grows, 64)), ar.get("dl3", (grows, 64))
+                blocks.attn_pool_backward(ar, "lpool", l3, lp.attn, aw, dvox, F * N_ANCHOR, N_GROUP, 64, dl3, G)
+                dgrouped = blocks.mlp3_backward(ar, "lp", lp, grouped, l3, dl3, G, True)
+                hip.call("anchor_group_backward", dgrouped, gidx, F, N, 25, dfeats, 28)
+            pts = ar.get("pts", (rows, 6))
+            blocks.mlp3_backward(ar, "m0", self.module0, pts, feats[:, 4:28], dfeats[:, 4:28], G, False)
