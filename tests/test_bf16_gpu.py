@@ -466,3 +466,48 @@ def test_upper_front_eval_bf16_against_emulation_and_fp32():
     assert float(err.max()) < 5e-3 * scale and float(err.mean()) < 2e-4 * scale, (float(err.max()), float(err.mean()), scale)
     assert float((v32 - vb).abs().max()) < 5e-2 * scale
     assert float((l32 - lb).abs().max()) < 2e-2
+
+
+def test_config5_full_size_upper_lower_bf16_forward():
+    """The Upper_Net / Lower_Net half of BASELINE config 5 at its FULL size (B = 2048, T = 16, N = 256: 32 768 frames, 491 520 skeleton
+    rows through the ST-GCN) with precision = "bf16", head pose given.  Size-independent properties: (i) outputs finite; (ii) sequences are
+    independent in eval mode, so the first 3 sequences of the big batch equal the same 3 run alone up to what the fp32 products around
+    the bf16 kernels do differently at another batch size (other tile shapes, other summation order; and a bf16 operand that lands on
+    the other side of a rounding boundary because of it): 2e-3; (iii) against the fp32 path on the same inputs the joints move by
+    < 3e-2 (5e-3 on average)."""
+    from mmego_amd import nets
+    dev = _dev()
+    torch.manual_seed(41)
+    up, lo = nets.UpperNet().to(dev).eval(), nets.LowerNet(64).to(dev).eval()
+    with torch.no_grad():
+        for m in list(up.modules()) + list(lo.modules()):
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.6, 1.4)
+    B, T, N = 2048, 16, 256
+    g = torch.Generator().manual_seed(42)
+    x0 = (torch.randn(B, T, N, 6, generator=g) * 0.4).to(dev)
+    # ONE skeleton for every sequence: the reference indexes the bone table by FRAME index modulo B (quirk Q2), so with different
+    # skeletons per sequence a sub-batch would not see the bones the big batch gives the same frames
+    body = (torch.randn(1, 20, 3, generator=g) * 0.2).expand(B, 20, 3).contiguous().to(dev)
+    R = torch.linalg.qr(torch.randn(B, T, 3, 3, generator=g))[0].contiguous().to(dev)
+    t = (torch.randn(B, T, 3, generator=g) * 0.1).to(dev)
+
+    def fwd(n):
+        h0 = torch.zeros(6, n, 64, device=dev)
+        with torch.no_grad():
+            x = x0[:n].clone()
+            u = up(x, h0, h0.clone(), body[:n].contiguous(), R[:n].contiguous(), t[:n].contiguous())[0]
+            l = lo(u, x, None, None, None, None, body[:n].contiguous(), R[:n].contiguous(), t[:n].contiguous())[0]
+        return u.clone(), l.clone()
+    up.precision = lo.precision = "bf16"
+    ub, lb = fwd(B)
+    us, ls = fwd(3)
+    up.precision = lo.precision = "fp32"
+    u32, l32 = fwd(B)
+    assert bool(torch.isfinite(ub).all()) and bool(torch.isfinite(lb).all())
+    assert float((ub[:3] - us).abs().max()) < 2e-3 and float((lb[:3] - ls).abs().max()) < 2e-3, \
+        (float((ub[:3] - us).abs().max()), float((lb[:3] - ls).abs().max()))
+    du, dl = (ub - u32).abs(), (lb - l32).abs()
+    assert float(du.max()) < 3e-2 and float(dl.max()) < 3e-2, (float(du.max()), float(dl.max()))
+    assert float(du.mean()) < 5e-3 and float(dl.mean()) < 5e-3, (float(du.mean()), float(dl.mean()))
