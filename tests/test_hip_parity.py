@@ -995,3 +995,31 @@ def test_two_persistent_recurrences_side_by_side(dev):
     assert blocks.seq_xcd_errors() == 0
     for a, o in zip(alone, outs):
         assert torch.equal(a, o)
+
+
+def test_mlp_dw_reduce_multi_against_torch(dev):
+    """mmego_mlp_dw_reduce_multi: several layers' per-workgroup partial records summed by one launch (fp64, fixed order) -- dW tiles
+    (records 4096 floats apart, element (m, n) at m * 64 + n) of two row counts, and the pooling kernels' attention-parameter partials
+    (records 128 floats apart: weight [64], bias at column 64) -- against float64 sums; neighbouring memory untouched."""
+    from mmego_amd import hip
+    g = torch.Generator().manual_seed(9)
+    descs, want, outs, keep = [], [], [], []
+    for rows, Cout, Cin in ((65536, 64, 28), (65536, 8, 6), (3000, 32, 31)):
+        nblk = int(hip.lib().mmego_mlp_train_nblk(rows))
+        part = torch.randn(nblk, 64, 64, generator=g).to(dev)
+        out = torch.full((Cout * Cin + 4,), 7.0, device=dev)
+        descs.append(hip.DwRed(hip.ptr(part), hip.ptr(out), Cout, Cin, rows, 0, 0))
+        want.append(part[:, :Cout, :Cin].double().sum(0).reshape(-1))
+        outs.append(out); keep.append(part)
+    awp = torch.randn(200, 128, generator=g).to(dev)
+    ow, ob = torch.full((68,), 7.0, device=dev), torch.full((5,), 7.0, device=dev)
+    descs.append(hip.DwRed(hip.ptr(awp), hip.ptr(ow), 1, 64, 0, 200, 128))
+    descs.append(hip.DwRed(hip.ptr(awp[:, 64:]), hip.ptr(ob), 1, 1, 0, 200, 128))
+    want += [awp[:, :64].double().sum(0), awp[:, 64:65].double().sum(0)]
+    outs += [ow, ob]
+    hip.call("mlp_dw_reduce_multi", len(descs), (hip.DwRed * len(descs))(*descs))
+    torch.cuda.synchronize()
+    for o, w in zip(outs, want):
+        n = w.numel()
+        assert torch.equal(o[:n].cpu(), w.float().cpu())          # fp64 sums rounded once: the fp32 nearest to the exact sum
+        assert torch.all(o[n:] == 7.0)
