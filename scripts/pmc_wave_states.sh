@@ -32,7 +32,7 @@ for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
             dur[k].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
 tot = {k: sum(dur[k]) for k in acc}
 with open(root + "/summary.txt", "w") as fo:
-    for k in sorted(acc, key=lambda k_: -tot.get(k_, 0))[:8]:
+    for k in sorted(acc, key=lambda k_: -tot.get(k_, 0))[:12]:
         m = {n: sum(v) / len(v) for n, v in acc[k].items()}
         wc = m.get("SQ_WAVE_CYCLES", 0.0)
         line = ["%s  (%d launches, %.1f us avg in the counter pass)" % (k, len(acc[k].get("SQ_WAVE_CYCLES", [])), sum(dur[k]) / max(len(dur[k]), 1))]
