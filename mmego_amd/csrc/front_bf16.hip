@@ -11,14 +11,16 @@
 typedef unsigned short bf16_t;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned int frb_bf(float x) {
-  const unsigned int u = __float_as_uint(x);
-  const unsigned int rne = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;  // round to nearest even
-  const unsigned int nan = (u >> 16) | 0x40u;
-  return (u & 0x7fffffffu) > 0x7f800000u ? nan : rne;
+// (a float -> __bf16 conversion is v_cvt_pk_bf16_f32 on gfx950: round to nearest even, NaN stays NaN -- one instruction for two
+// values where the integer form took five per value)
+typedef float lo_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 lo_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int frb_bf(float x) { return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ unsigned int frb_bf2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector((lo_f32x2){lo, hi}, lo_bf16x2));
 }
 __device__ __forceinline__ uint2 frb_pack4(float a, float b, float c, float d) {
-  return make_uint2(frb_bf(a) | (frb_bf(b) << 16), frb_bf(c) | (frb_bf(d) << 16));
+  return make_uint2(frb_bf2(a, b), frb_bf2(c, d));
 }
 
 #define FR_SLAB 16

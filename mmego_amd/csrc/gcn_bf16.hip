@@ -25,11 +25,13 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef unsigned short bf16_t;   // raw bf16 bits (the C ABI carries them as unsigned short)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned int f2bf(float x) {
-  const unsigned int u = __float_as_uint(x);
-  const unsigned int rne = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;  // round to nearest even
-  const unsigned int nan = (u >> 16) | 0x40u;                         // NaN stays NaN
-  return (u & 0x7fffffffu) > 0x7f800000u ? nan : rne;                 // (a select, not a branch: dozens of these per thread)
+// (a float -> __bf16 conversion is v_cvt_pk_bf16_f32 on gfx950: round to nearest even, NaN stays NaN -- one instruction for two
+// values where the integer form took five per value)
+typedef float lo_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 lo_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int f2bf(float x) { return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ unsigned int f2bf2(float lo, float hi) {
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector((lo_f32x2){lo, hi}, lo_bf16x2));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -395,8 +397,8 @@ __global__ __launch_bounds__(GM_NT, CIN >= 64 ? 1 : 2) void gcn_mix_eval_bf16_ke
           bf16_t* d = xk + (tfl * 16 + twg * WPT + w) * XS + k * CIN + c0;
           if (NC == 4) {
             uint2 o;
-            o.x = f2bf(s[w][0]) | (f2bf(s[w][1]) << 16);
-            o.y = f2bf(s[w][2]) | (f2bf(s[w][3]) << 16);
+            o.x = f2bf2(s[w][0], s[w][1]);
+            o.y = f2bf2(s[w][2], s[w][3]);
             *reinterpret_cast<uint2*>(d) = o;
           } else {
 #pragma unroll
@@ -418,8 +420,8 @@ __global__ __launch_bounds__(GM_NT, CIN >= 64 ? 1 : 2) void gcn_mix_eval_bf16_ke
         }
         if (NC == 4) {
           uint2 o;
-          o.x = f2bf(__uint_as_float(xb[0])) | (f2bf(__uint_as_float(xb[1])) << 16);
-          o.y = f2bf(__uint_as_float(xb[2])) | (f2bf(__uint_as_float(xb[3])) << 16);
+          o.x = f2bf2(__uint_as_float(xb[0]), __uint_as_float(xb[1]));
+          o.y = f2bf2(__uint_as_float(xb[2]), __uint_as_float(xb[3]));
           *reinterpret_cast<uint2*>(d) = o;
         } else {
 #pragma unroll
