@@ -17,11 +17,9 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef unsigned short bf16_t;   // raw bf16 bits (the C ABI carries them as unsigned short)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned int f2bf_bits(float x) {
-  unsigned int u = __float_as_uint(x);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;                     // round to nearest even
-}
+// round to nearest even, NaN stays NaN: v_cvt_pk_bf16_f32 on gfx950 (the integer form -- add 0x7fff + lsb, shift, a branch for NaN --
+// was five VALU instructions and a branch per value)
+__device__ __forceinline__ unsigned int f2bf_bits(float x) { return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)x); }
 
 // ---- fp32 -> bf16 ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ X, long ldx, long rows, long cols4,
