@@ -681,9 +681,11 @@ def main():
         su.prepare(); sl.prepare()
     else:
         both.prepare()
-    # clock ramp: a GPU that has just been idle (process start-up, graph capture on the host) runs its first ~0.2 s of steps several
-    # per cent slower -- untimed burn-in in front of the W warm-up steps, so that a short --steps block measures the steady state
-    for _ in range(0 if args.trace_only else 40):
+    # clock ramp: a GPU that has just been idle (process start-up, graph capture on the host) runs its first steps several per cent
+    # slower -- untimed burn-in in front of the W warm-up steps, so that a short --steps block measures the steady state.  (40 steps
+    # = 0.2 s were not always enough: in about one run in four the first timed block still came out 3 % above the ten blocks behind
+    # it -- 5.16 against 5.01-5.03 ms; 1 s of burn-in.)
+    for _ in range(0 if args.trace_only else 200):
         ul_step()
     for _ in range(args.warmup):
         ul_step()
