@@ -167,7 +167,7 @@ def pool128_fusable(mod, x, P, training):
                 and hip.lib().mmego_pool128_ok(x.shape[0]))
 
 
-def mlp3_forward(ar, key, mod, x, out_last, training, pool=None):
+def mlp3_forward(ar, key, mod, x, out_last, training, pool=None, bf16=False):
     """pool = (attention Linear, vec, attn) with pool128_fusable(...): the softmax pooling behind the chain runs inside its last launch
     (out_last is not written); returns None then."""
     rows = x.shape[0]
@@ -188,7 +188,8 @@ def mlp3_forward(ar, key, mod, x, out_last, training, pool=None):
             bnp = torch.tensor([t.data_ptr() for _, bn in layers for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)],
                                dtype=torch.int64)
             wb = [v for (conv, _), C in zip(layers, dims) for v in (conv.weight, conv.bias, C)]
-            hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *wb, out_last, out_last.stride(0), bnp, float(layers[0][1].eps))
+            hip.call("mlp3_eval_bf16" if bf16 else "mlp3_eval", x, x.stride(0), rows, Cin, *wb, out_last, out_last.stride(0), bnp,
+                     float(layers[0][1].eps))
             return out_last
         folded = []
         for i, (conv, bn) in enumerate(layers, 1):

@@ -484,7 +484,7 @@ class LowerNet(_NetBase):
             ops.gather_rows(x.view(F * N, Cx), flat_idx, sel)
             ops.copy2d(sel[:, :3], p_vec[:, :3])
         self.last_select_idx = idx
-        blocks.mlp3_forward(ar, "base", self.pointEncoder.module0, sel, p_vec[:, 3:64], training)
+        blocks.mlp3_forward(ar, "base", self.pointEncoder.module0, sel, p_vec[:, 3:64], training, bf16=self._bf16_eval(training))
 
         k_vec = self._gcn_forward(ar, up, B, T, training)            # [F*15, 64] in the re-viewed layout (Q8)
 

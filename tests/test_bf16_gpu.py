@@ -511,3 +511,41 @@ def test_config5_full_size_upper_lower_bf16_forward():
     du, dl = (ub - u32).abs(), (lb - l32).abs()
     assert float(du.max()) < 3e-2 and float(dl.max()) < 3e-2, (float(du.max()), float(dl.max()))
     assert float(du.mean()) < 5e-3 and float(dl.mean()) < 5e-3, (float(du.mean()), float(dl.mean()))
+
+
+@pytest.mark.parametrize("rows,dims", [(1000, (6, 16, 32, 61)), (64, (28, 32, 48, 64)), (4099, (6, 8, 16, 24))])
+def test_mlp3_eval_bf16_matches_emulation(rows, dims):
+    """mmego_mlp3_eval_bf16 (mlp3_bf16.hip) against the three stages in float64 with the kernel's roundings (folded weights and every
+    stage's input rounded to bf16; biases, ReLU, output fp32): 5e-3 of the output scale at worst (an activation on the other side of a
+    bf16 boundary), 2e-4 on average.  Row counts with a ragged last 64-row tile, BasePointNet's / GlobalPointNet's / PointNet's widths."""
+    from mmego_amd import hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, dims[0] + 2, generator=g)
+    Ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(3)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(3)]
+    bn = [(torch.rand(dims[i + 1], generator=g) + 0.5, torch.randn(dims[i + 1], generator=g) * 0.1, torch.randn(dims[i + 1], generator=g) * 0.2,
+           torch.rand(dims[i + 1], generator=g) + 0.5) for i in range(3)]
+    eps = 1e-5
+    xd = x.to(dev)
+    y = torch.full((rows, dims[3] + 3), 7.0, device=dev)
+    devt = [[t.to(dev) for t in b] for b in bn]
+    bnp = torch.tensor([t.data_ptr() for b in devt for t in b], dtype=torch.int64)
+    Wd, bd = [w.to(dev) for w in Ws], [b.to(dev) for b in bs]
+    hip.call("mlp3_eval_bf16", xd[:, 1:], xd.stride(0), rows, dims[0], Wd[0], bd[0], dims[1], Wd[1], bd[1], dims[2], Wd[2], bd[2], dims[3],
+             y[:, 2:], y.stride(0), bnp, eps)
+    torch.cuda.synchronize()
+    assert torch.all(y[:, :2] == 7.0) and torch.all(y[:, 2 + dims[3]:] == 7.0)
+    a = _bf(x[:, 1:1 + dims[0]])
+    for i in range(3):
+        gam, bet, mean, var = bn[i]
+        sc = (gam / torch.sqrt(var + eps)).float()
+        Wf = (sc[:, None] * Ws[i]).float()
+        bf = ((bs[i] - mean) * sc + bet).float()
+        a = torch.relu(a @ _bf(Wf).t() + bf.double())
+        if i < 2:
+            a = _bf(a.float())
+    got = y[:, 2:2 + dims[3]].cpu().double()
+    err = (got - a).abs()
+    scale = float(a.abs().max())
+    assert float(err.max()) < 5e-3 * scale and float(err.mean()) < 2e-4 * scale, (float(err.max()), float(err.mean()), scale)
