@@ -590,8 +590,8 @@ def config5_forward(device):
     # per-point part of Upper/Lower doubles at N=256 and stays < 3 % of the total)
     fl = (444.96e6 + 2.15e6 + 9.26e6) * Bq * Tq
     res = {"workload": "IMU_Net -> Upper_Net -> Lower_Net eval forward, B=2048 T=16 N=256, precision = 'bf16' on all three nets: "
-                       "IMU_Net's BiLSTM products, Upper_Net's PointNet / GlobalPointNet stages and Lower_Net's ST-GCN products (1x1 and "
-                       "temporal convs) on bf16 operands with fp32 accumulation, everything else fp32", "ms_per_forward": ms, "frames_per_s": Bq * Tq / (ms * 1e-3),
+                       "IMU_Net's BiLSTM products, Upper_Net's PointNet / GlobalPointNet stages, Lower_Net's BasePointNet stages and ST-GCN products "
+                       "(1x1 and temporal convs) on bf16 operands with fp32 accumulation, everything else fp32", "ms_per_forward": ms, "frames_per_s": Bq * Tq / (ms * 1e-3),
            "algorithmic_tflops": fl / (ms * 1e-3) / 1e12, "frac_of_bf16_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
            "outputs_finite": finite, "dominant_kernel": k}
     del imu_net, up, lo, x0, imu_in
