@@ -320,7 +320,11 @@ int mmego_upper_front_eval(void* stream, float* x, const float* x_src, const flo
  * 8-byte words, both zero before the first launch and private to one stream of launches; sync[9] is a sticky error flag (non-zero: a
  * bounded spin ran out -- the launch's workgroups could not all be resident -- and the results are invalid), sync[10] the launch
  * generation. */
-/* (mmego_lstm_seq_xcd_ok is also 0 on a device or partition with fewer than 128 CUs: the 256 workgroups of a launch must be co-resident) */
+/* mmego_lstm_seq_xcd_slots: how many such launches the current device holds at once (the 256 workgroups of a launch must be
+ * co-resident): the kernel's occupancy (hipOccupancyMaxActiveBlocksPerMultiprocessor) x CU count / 256, per device -- 2 on a whole
+ * MI355X, 0 on a device / partition too small for one launch.  mmego_lstm_seq_xcd_ok is 0 there too.  A caller that may have k such
+ * launches in flight on different streams at once (two frozen IMU_Net forwards side by side) needs slots >= k. */
+int mmego_lstm_seq_xcd_slots(void);
 int mmego_lstm_seq_xcd_ok(int Bn, int H, int T);
 int mmego_lstm_seq_xcd(void* stream, const float* xproj, long xs, const float* whh0, const float* whh1, const float* bhh0,
                        const float* bhh1, float* out, long os, unsigned* sync, unsigned long long* xbuf, int Bn, int H, int T);

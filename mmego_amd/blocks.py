@@ -440,6 +440,26 @@ class two_chains:
 _LSTM_SEQ_XCD = os.environ.get("MMEGO_LSTM_SEQ_XCD", "1") != "0"
 
 
+class seq_xcd:
+    """Context: allow (True) or forbid (False) the persistent rnn_slow launch (mmego_lstm_seq_xcd) for the forwards issued inside.
+    A launch's 256 workgroups wait for each other, so every launch that may be in flight at once needs its own co-resident set:
+    an engine that runs k forwards side by side (train_step.PipelinedStages) allows it for the first
+    `mmego_lstm_seq_xcd_slots()` of them only; the others take the launch-per-timestep form (same results to fp32 rounding)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        global _LSTM_SEQ_XCD
+        self.was, _LSTM_SEQ_XCD = _LSTM_SEQ_XCD, bool(self.on) and _LSTM_SEQ_XCD
+        return self
+
+    def __exit__(self, *exc):
+        global _LSTM_SEQ_XCD
+        _LSTM_SEQ_XCD = self.was
+        return False
+
+
 def seq_xcd_sync(ar, key):
     """The synchronisation words and the exchange buffer of mmego_lstm_seq_xcd for one BiLSTM stack of one net (its arena): zero when
     created; word 9 of the first is the kernel's sticky error flag (seq_xcd_errors), word 10 its launch generation."""
@@ -464,6 +484,16 @@ def seq_xcd_errors(ar=None):
     if ar is None:
         return sum(int(t[9].item()) for t in _seq_sync_bufs)
     return sum(int(t[9].item()) for (name, _, _), t in ar.bufs.items() if name.endswith(".seqsync"))
+
+
+def seq_xcd_raise():
+    """Raise if any persistent rnn_slow launch of this process reported that its workgroups were not co-resident (results invalid).
+    The trainers call it once per epoch and every evaluation pass once at its end (processors.py); one host read per buffer."""
+    n = seq_xcd_errors()
+    if n:
+        raise RuntimeError("mmego_lstm_seq_xcd: %d persistent recurrence buffer(s) report a launch whose workgroups could not all be "
+                           "resident (shared / partitioned device?) -- the head poses computed since the last check are invalid. "
+                           "Set MMEGO_LSTM_SEQ_XCD=0 to use one launch per timestep." % n)
 
 
 def _side_stream(cur):

@@ -40,7 +40,6 @@ struct GcnFrontD {
   float2* recY; float2* recR;
   float* outT; int T;      // mix = 0: product stored transposed, outT[b][nout][T*V]
   long F; int V;
-  int dbg;                 // diagnostic mask (MMEGO_GCN_DBG; 0 in production): phases to skip, for timing by elimination
 };
 
 // Rows [0, nrows) x ncols floats of an LDS tile (row stride S, rows 16-byte aligned) -> global rows of stride ld: all GF_NT threads,
@@ -218,7 +217,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
       v2[u] = *reinterpret_cast<const f32x4*>(p.X2 + (r0 + rc) * p.ld2 + 4 * (in ? c4 : 0));
     }
     const BnPre pre1 = bn_preload(p.bn1, cin, 0, first), pre2 = bn_preload(p.bn2, cin, 256, first);
-    if (!(p.dbg & 1)) bn_gather2<GF_NT>(p.bn1, p.bn2, cin, rows, red, red + 2048);
+    bn_gather2<GF_NT>(p.bn1, p.bn2, cin, rows, red, red + 2048);
     __syncthreads();
     bn_finish<GF_NT>(p.bn1, cin, red, st, first, 0, pre1);
     bn_finish<GF_NT>(p.bn2, cin, red + 2048, st + 4 * cin, first, 256, pre2);
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
         *reinterpret_cast<f32x4*>(xs + row * XS + c) = o;
       }
     }
-    if (p.xact && !(p.dbg & 2)) {
+    if (p.xact) {
       __syncthreads();
       tile_out<2>(xs, XS, p.xact + r0 * cin, cin, nv, cin, tid);
     }
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
 #pragma unroll
     for (int q = 0; q < NCTW; ++q) {
       if (q <= p.Kk) {                                     // (uniform)
-        if (wp < cout / 32 && !(p.dbg & 16)) {
+        if (wp < cout / 32) {
           f32x16 acc = {0};
 #pragma unroll
           for (int kc = 0; kc < NK; ++kc) {
@@ -276,9 +275,9 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
           for (int reg = 0; reg < 16; ++reg) zs[(rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * ZS + col] = acc[reg] + bb;
         }
         __syncthreads();
-        if (!(p.dbg & 2)) tile_out<2>(zs, ZS, p.Z + r0 * p.ldz + q * cout, p.ldz, nv, cout, tid);
+        tile_out<2>(zs, ZS, p.Z + r0 * p.ldz + q * cout, p.ldz, nv, cout, tid);
         if (q < p.Kk) {
-          if (!(p.dbg & 4)) {
+          {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int pi = wave + (GF_NT / 64) * i;
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
               }
             }
           }
-        } else if (!(p.dbg & 8)) {
+        } else {
           tile_records(zs, ZS, cout, nv, V, false, st, p.recR + (long)blockIdx.x * cout);
         }
         __syncthreads();
@@ -310,8 +309,8 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
       }
     }
     __syncthreads();
-    if (!(p.dbg & 2)) for (int fi = 0; fi < nf; ++fi) tile_out<1>(ys + fi * 16 * YS, YS, p.Y + (r0 + fi * V) * cout, cout, V, cout, tid);
-    if (!(p.dbg & 8)) tile_records(ys, YS, cout, nv, V, true, st, p.recY + (long)blockIdx.x * cout);
+    for (int fi = 0; fi < nf; ++fi) tile_out<1>(ys + fi * 16 * YS, YS, p.Y + (r0 + fi * V) * cout, cout, V, cout, tid);
+    tile_records(ys, YS, cout, nv, V, true, st, p.recY + (long)blockIdx.x * cout);
     return;
   }
 
@@ -320,7 +319,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
 #pragma unroll
     for (int i = 0; i < NCTW; ++i) {
       const int ct = wp + 4 * i;
-      if (ct < NCT && !(p.dbg & 16)) {                     // (uniform per wave)
+      if (ct < NCT) {                     // (uniform per wave)
         f32x16 acc = {0};
 #pragma unroll
         for (int kc = 0; kc < NK; ++kc) {
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
       }
   }
   __syncthreads();
-  if (p.mix && !(p.dbg & 2)) tile_out<4>(zs, ZS, p.Z + r0 * p.ldz, p.ldz, nv, nout, tid);          // (z | residual pre-activation) leave together
+  if (p.mix) tile_out<4>(zs, ZS, p.Z + r0 * p.ldz, p.ldz, nv, nout, tid);          // (z | residual pre-activation) leave together
 
   if (!p.mix) {
     // closing 1x1 conv: transposed store outT[b][col][t V + v] (consecutive threads walk a column's rows: contiguous addresses)
@@ -370,7 +369,7 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
   {
     const int nch = cout / 16, npair = nf * nch;
     const int vq = lane >> 4, cl = lane & 15;
-    for (int pi = wave; pi < ((p.dbg & 4) ? 0 : npair); pi += GF_NT / 64) {
+    for (int pi = wave; pi < npair; pi += GF_NT / 64) {
       const int fi = pi / nch, n0 = (pi - fi * nch) * 16;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -389,10 +388,10 @@ __global__ __launch_bounds__(GF_NT) void gcn_front_kernel(GcnFrontD p) {
     }
   }
   __syncthreads();
-  if (!(p.dbg & 2)) for (int fi = 0; fi < nf; ++fi) tile_out<1>(ys + fi * 16 * YS, YS, p.Y + (r0 + fi * V) * cout, cout, V, cout, tid);
+  for (int fi = 0; fi < nf; ++fi) tile_out<1>(ys + fi * 16 * YS, YS, p.Y + (r0 + fi * V) * cout, cout, V, cout, tid);
   // ---- BatchNorm partial records of the einsum output and of the residual pre-activation over this tile's rows: thread (column,
   // row part) takes every P-th row (shifted sums, four loads in flight), the parts are added in a fixed order
-  if (!(p.dbg & 8)) {
+  {
     const int ncol = 2 * cout, P = GF_NT / ncol;          // cout 32 / 64 / 128: 8 / 4 / 2 row parts
     const int cid = tid % ncol, part = tid / ncol;
     const bool res = cid >= cout;
@@ -865,7 +864,6 @@ extern "C" int mmego_gcn_front(void* stream, const void* desc) {
   p.mix = h->mix; p.Kk = h->K; p.cout = h->cout; p.A = h->A; p.imp = h->importance;
   p.Z = h->Z; p.ldz = h->ldz; p.Y = h->Y; p.recY = reinterpret_cast<float2*>(h->recY); p.recR = reinterpret_cast<float2*>(h->recR);
   p.outT = h->outT; p.T = h->T; p.F = h->F; p.V = h->V;
-  { const char* e = getenv("MMEGO_GCN_DBG"); p.dbg = e ? atoi(e) : 0; }
   if (p.in_mode == 0) {
     MMEGO_REQUIRE(p.V * p.cin <= 64 && p.F <= 1024 && p.bn1.gamma && p.bn1.beta);
   } else {

@@ -434,9 +434,17 @@ __global__ __launch_bounds__(64) void head_fk_loss_kernel(const float* __restric
   if (threadIdx.x == 0) {
     __hip_atomic_store(&part[2 * blockIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&part[2 * blockIdx.x + 1], dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);                         // the partial pair has been acknowledged before the ticket is drawn
+    // The pair above must be visible before the ticket is drawn, and the last workgroup must read the pairs after its ticket.
+    // Hardware side: agent-scope atomic (write-through, sc1) stores, drained by vmcnt(0), then an agent-scope atomic add; the reader's
+    // loads are agent-scope atomics too (never a stale L1 / L2 line) -- the "8-byte agent atomics on both sides" form of the hand-off
+    // rules.  Compiler side: relaxed atomics on different addresses may legally be moved across a waitcnt BUILTIN, so the
+    // drain is a volatile asm with a memory clobber (no memory access crosses it), and a second one opens the reading branch.  A
+    // release / acquire pair in the memory model would say the same at the price of an L2 write-back + invalidate (~1.7 us each)
+    // per launch on the critical path of both stage tails.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == gridDim.x - 1) {                              // last workgroup: the partials in index order (agent-scope loads: not a stale L2 line)
+      asm volatile("" ::: "memory");
       double s0 = 0.0, s1 = 0.0;
       for (unsigned w = 0; w < gridDim.x; ++w) {
         s0 += __hip_atomic_load(&part[2 * w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

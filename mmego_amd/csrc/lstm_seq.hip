@@ -19,7 +19,11 @@
 //     values into LDS, multiplies (128 MFMA steps per wave over four accumulation chains), swaps the four gate tiles through LDS and
 //     updates its cells.  The plain h_t goes to the layer's output tensor beside it.
 // Every spin is bounded: a grid that cannot make progress (three such launches side by side would wait for each other's CUs) sets
-// an error word and runs to its end with wrong results instead of hanging the GPU; the host checks the word (blocks.seq_xcd_check).
+// an error word and runs to its end with wrong results instead of hanging the GPU; the host checks the word (blocks.seq_xcd_errors:
+// the trainers and evaluation passes of processors.py read it once per epoch / pass and raise).  A wave that has timed out once -- or, while
+// spinning, finds the error word set by another wave (looked at every LQ_SPIN_CHECK retries, nothing on the normal path) -- skips every
+// later wait, so a stuck launch ends ~one spin bound after it got stuck whatever T is, not after one bound per wait; workgroups that
+// only become resident after that (their tags are long overwritten) leave after LQ_SPIN_CHECK retries.
 // The last workgroup to finish resets the counters, so a launch leaves them as it found them (graph replays need no memset node).
 // Arithmetic: the products accumulate in another order than the step kernels' (k split over lane groups and four chains), so results
 // agree with them to fp32 rounding, not bit for bit; gate non-linearities and the cell update are the step kernels' expressions.
@@ -30,6 +34,7 @@
 #define LQ_H 512
 #define LQ_RS (LQ_H + 4)                  // LDS row stride of the h tile (floats): 16-byte aligned, rows on distinct bank groups
 #define LQ_SPIN_MAX (1 << 20)        // ~1 s of retries: far beyond any wait for co-resident workgroups, short enough that a stuck grid ends
+#define LQ_SPIN_CHECK (1 << 10)      // a spinning wave looks at the error word every ~1 ms: once any wave has given up, all do
 
 struct LstmSeqP {
   const float* xproj; long xs;           // input projections [Bn*T rows (b*T + t)][8H]: direction d at column offset d * 4H; xs = row stride
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_xcd_kernel(LstmSeqP p) {
   float* oq = p.out + d * H + unit;
   float creg = 0.f;
   float xp[4], xpn[4];
+  bool dead = false;                       // wave-uniform: this launch has failed (here or elsewhere); no more waiting
   {
     const int t = d == 0 ? 0 : T - 1;
 #pragma unroll
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_xcd_kernel(LstmSeqP p) {
 #pragma unroll
           for (int u = 0; u < 16; ++u) ok = ok && (unsigned)(v[u] >> 32) == tag;
           int spins = 0;
-          while (!__all(ok)) {                                    // (rare: a producer's stores have not all landed yet)
+          while (!dead && !__all(ok)) {                           // (rare: a producer's stores have not all landed yet)
             ok = true;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -117,7 +123,14 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_xcd_kernel(LstmSeqP p) {
               v[u] = __hip_atomic_load(xs_ + (uu >> 1) * LQ_H + (uu & 1) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               ok = ok && (unsigned)(v[u] >> 32) == tag;
             }
-            if (++spins > LQ_SPIN_MAX) { if (lane == 0) atomicOr(err, 1u); break; }
+            ++spins;
+            if (spins > LQ_SPIN_MAX) { if (lane == 0) atomicOr(err, 1u); dead = true; }
+            else if ((spins & (LQ_SPIN_CHECK - 1)) == 0) {
+              // somebody else has given up already (ONE lane asks: an atomic load by 64 lanes is 64 operations on one address)
+              unsigned e = 0u;
+              if (lane == 0) e = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (__builtin_amdgcn_readfirstlane(e) != 0u) dead = true;
+            }
           }
 #pragma unroll
           for (int u = 0; u < 16; ++u) {
@@ -174,21 +187,28 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_xcd_kernel(LstmSeqP p) {
   }
 }
 
-// 1 when mmego_lstm_seq_xcd takes the shape
-// (the 256 workgroups of a launch wait for each other: they must all be resident -- two fit on a CU, so at least 128 CUs; on a smaller
-// device or partition the caller keeps the launch-per-timestep form)
-static int lq_device_fits() {
-  static int fits = -1;
-  if (fits < 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-    fits = cus >= 128 ? 1 : 0;
+// How many mmego_lstm_seq_xcd launches the CURRENT device can hold at once (the 256 workgroups of a launch wait for each other: they
+// must all be resident).  From the kernel's real occupancy -- hipOccupancyMaxActiveBlocksPerMultiprocessor x CU count, queried per
+// device -- not from an assumed two workgroups per CU; 0 on a device or partition that cannot hold one launch (the caller then keeps
+// the launch-per-timestep form), 2 on a whole MI355X (256 CUs x 2).
+extern "C" int mmego_lstm_seq_xcd_slots(void) {
+  static int slots[64];
+  static bool have[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (!have[dev]) {
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_xcd_kernel, 256, 0) != hipSuccess) per_cu = 0;
+    slots[dev] = (int)(((long)cus * per_cu) / 256);
+    have[dev] = true;
   }
-  return fits;
+  return slots[dev];
 }
 
+// 1 when mmego_lstm_seq_xcd takes the shape on the current device
 extern "C" int mmego_lstm_seq_xcd_ok(int Bn, int H, int T) {
-  return Bn >= 1 && Bn <= 64 && H == LQ_H && T >= 1 && T <= 4095 && lq_device_fits();
+  return Bn >= 1 && Bn <= 64 && H == LQ_H && T >= 1 && T <= 4095 && mmego_lstm_seq_xcd_slots() >= 1;
 }
 
 // One BiLSTM layer's recurrence, both directions, all T timesteps in one launch.  xproj [Bn*T][xs >= 8H] rows (b*T + t): W_ih x + b_ih of

@@ -51,6 +51,22 @@ class _NetBase(nn.Module):
         # accumulation where a kernel for it exists (BASELINE config 5; training always runs fp32)
         self.precision = os.environ.get("MMEGO_EVAL_PRECISION", "fp32")
 
+    # -- derived weight copies ----------------------------------------------------------------------
+    # Re-laid-out / folded copies of parameters and BatchNorm statistics (eval-mode packs: _tconv_packed, _gcn_bf16_pack, the bf16
+    # LSTM weights of IMUNet) are keyed on (tensor._version, data_ptr) -- but the fused Adam and the train-mode BatchNorm kernels
+    # write through raw pointers, which never bumps _version.  So the copies are dropped whenever the weights MAY
+    # change: on .train() and on every params.FusedAdam.step() of this net; the next eval forward packs again.
+    _derived = ("_tconv_packed", "_gcn_bf16_pack")
+
+    def weights_changed(self):
+        for name in self._derived:
+            self.__dict__.pop(name, None)
+
+    def train(self, mode=True):
+        if mode:
+            self.weights_changed()
+        return super().train(mode)
+
     def _bf16_eval(self, training):
         if self.precision not in ("fp32", "bf16"):
             raise ValueError("%s.precision must be 'fp32' or 'bf16', got %r" % (type(self).__name__, self.precision))
@@ -986,11 +1002,10 @@ class IMUNet(_NetBase):
         touches it (params.FusedAdam leaves these ranges alone, weight decay included)."""
         return (self.fc3.weight, self.fc3.bias)
 
-    def train(self, mode=True):
-        if mode:                                   # weights may change: drop the bf16 copies of the LSTM weights
-            for m in (self.rnn_fast, self.rnn_slow):
-                m._bf16_cache = m._bf16_fused_cache = None
-        return super().train(mode)
+    def weights_changed(self):
+        super().weights_changed()                  # weights may change: drop the bf16 copies of the LSTM weights
+        for m in (self.rnn_fast, self.rnn_slow):
+            m._bf16_cache = m._bf16_fused_cache = None
 
     def forward(self, imu, h0_i=None):
         _require_gpu(imu, "IMUNet")

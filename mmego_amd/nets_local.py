@@ -163,7 +163,7 @@ class UpperNetwlocal(_NetBase):
         voxT = ar.get("voxT", (F, 64 * N_ANCHOR))
         aw = torch.empty((F * N_ANCHOR, N_GROUP, 1), dtype=torch.float32, device=dev)
         fused = self._local_fusable(N)
-        self._local_was_fused = fused and training
+        self._local_was_fused = bool(fused and training and stash)      # (read by backward only: as _gpool_fused)
         if fused and training:
             # grouping with LocalPointNet's first conv behind it in the same kernel (the gathered rows go from LDS into the product and
             # are never stored: the layer's backward gathers them again through the indices), two fused layer launches, then BatchNorm + ReLU + the 8-way
@@ -190,7 +190,7 @@ class UpperNetwlocal(_NetBase):
             hip.call("local_front_eval", feats, 28, F, N, 25, self.anchors(dev), gidx, self._local_table(), float(lp.cb1.eps), voxT, aw)
         else:
             grouped = ar.get("grouped", (grows, 31))
-            if fused:           # (training-mode forward without a backward pass: the wave-parallel grouping alone)
+            if fused:           # (eval mode with BatchNorms of unequal eps -- local_front_eval folds with ONE eps: the wave-parallel grouping alone)
                 hip.call("local_group_l1", feats, 28, F, N, 25, self.anchors(dev), gidx, grouped, None, None, 0, None, 0, None, _LOCAL_NWG, None)
             else:
                 hip.call("anchor_group", feats, 28, F, N, 25, self.anchors(dev), gidx, grouped, None)

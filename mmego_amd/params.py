@@ -142,6 +142,10 @@ class FusedAdam:
         hip.call("adam_step", f.flat_p, f.flat_g, self.m, self.v, f.flat_p.numel(), self.state, float(self.lr),
                  float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                  skip if skip is not False else None, skip.numel() // 2 if skip is not False else 0, self._ticket)
+        # the update went through raw pointers (no tensor._version bump): tell the net to drop derived copies of its weights
+        changed = getattr(f.module, "weights_changed", None)
+        if changed is not None:
+            changed()
 
     def zero_grad(self):
         pass  # every backward overwrites the flat gradient buffer

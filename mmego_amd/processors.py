@@ -14,7 +14,7 @@ import os
 import numpy as np
 import torch
 
-from . import hip, ops
+from . import blocks, hip, ops
 from .config import Config, ConfigDemo
 from .data import DeviceArrays, PosePC, batch_indices
 from .nets import IMUNet, LowerNet, UpperNet
@@ -224,6 +224,9 @@ class _StageTrainer(_Base):
         for epoch in range(self.start_epoch, self.num_epochs):
             print("epoch: {}".format(epoch + 1))
             self.train_once()
+            # a persistent rnn_slow launch of the frozen IMU_Net whose workgroups were not co-resident reports it only through a
+            # sticky word: read once per epoch (train_once has just synchronised for its log) -- never train on silently
+            blocks.seq_xcd_raise()
             sync_replicas(self.model, self.pg, params=False)       # BatchNorm running statistics: rank 0's, on every rank
             out = self.eval_model()
             eval_loss, eval_loss_l, eval_accu, second, accu_ll, angle_ll = out
@@ -352,7 +355,9 @@ def _epoch_eval(base, dataset, batch_size, shuffle, rng, imu_net, upper_net, low
                 hip.call("pose_errors", up.contiguous(), lo.contiguous(), tgt, F, E)
                 ops.colsum(E, log[i, :43])
                 hip.call("l1_loss", lo.contiguous(), tgt, lmap, 8, 21, F, 1.0, log[i, 43:45], None)
-    return log.cpu().numpy().astype(np.float64) / frames[:, None]            # the epoch's one device -> host read
+    out = log.cpu().numpy().astype(np.float64) / frames[:, None]             # the epoch's one device -> host read
+    blocks.seq_xcd_raise()          # (the frozen IMU_Net's persistent launches: invalid head poses must not become a reported metric)
+    return out
 
 
 def evaluate_full(base, imu_net, upper_net, lower_net, dataset, batch_size, shuffle, rng=None):
@@ -468,6 +473,7 @@ class ImuTrainer(_Base):
                 hip.call("imu_loss", R.contiguous(), t.contiguous(), b["R_R0R"], head, F, 1.0, log[i, 0:1], None, None)
                 hip.call("l1_loss", t.contiguous(), b["target"], self._head_map, 1, 21, F, 1.0, log[i, 1:3], None)
         m = log.cpu().numpy().astype(np.float64) / frames[:, None]          # the epoch's one device -> host read
+        blocks.seq_xcd_raise()
         tot, pos = m[:, 0], m[:, 2]
         return float(np.mean(tot)), np.mean(np.stack((tot - 100.0 * pos, pos), axis=1), axis=0)
 

@@ -477,10 +477,11 @@ class PipelinedStages:
         self.side_by_side = os.environ.get("MMEGO_PIPE_IMU_SIDE_BY_SIDE", "1") != "0"
         self.use_graph, self.graph = use_graph, None
 
-    def _imu_forward(self, k):
+    def _imu_forward(self, k, persistent=True):
         from . import blocks
         net, (Rn, tn) = self.imus[k], self.nxt[k]
-        with torch.no_grad(), blocks.two_chains(False):       # (the stage bodies run beside these forwards: see blocks.two_chains)
+        # (the stage bodies run beside these forwards: see blocks.two_chains; `persistent`: blocks.seq_xcd)
+        with torch.no_grad(), blocks.two_chains(False), blocks.seq_xcd(persistent):
             R, t = net(self.imu_next)
             ops.copy2d(R.view(-1, 9), Rn.view(-1, 9))
             ops.copy2d(t.view(-1, 3), tn.view(-1, 3))
@@ -500,10 +501,13 @@ class PipelinedStages:
             ops.copy2d(Rn.view(-1, 9), Rc.view(-1, 9))
             ops.copy2d(tn.view(-1, 3), tc.view(-1, 3))
         if self.side_by_side:
-            for k in reversed(range(len(self.imus))):
+            # every forward that runs at once needs its own co-resident set of 256 workgroups for the persistent rnn_slow launch:
+            # the device holds `slots` of them (2 on a whole MI355X); the others take the launch-per-timestep form
+            slots = hip.lib().mmego_lstm_seq_xcd_slots()
+            for n, k in enumerate(reversed(range(len(self.imus)))):
                 self.sides[k].wait_stream(main)
                 with torch.cuda.stream(self.sides[k]):
-                    self._imu_forward(k)
+                    self._imu_forward(k, persistent=n < slots)
             self.pair._bodies()
             for sd in self.sides:
                 main.wait_stream(sd)

@@ -1,7 +1,6 @@
 """The fused ST-GCN training kernels alone (Lower_Net's KeyEncoder at the bench shape B=64 T=8): GPU time per entry point of one
 forward + backward of the GCN part (event pairs around every launch, eager), for the fused path and -- MMEGO_GCN_FUSED=0 -- the
-launch chain.  MMEGO_GCN_DBG=<mask> skips phases of gcn_front for timing by elimination (1 prologue gathers, 2 copy-outs, 4 einsum,
-8 records, 16 product; results are wrong then)."""
+launch chain.  (The MMEGO_GCN_DBG phase mask of r04 -- timing by elimination -- was removed from the kernel in r05: git history.)"""
 import os
 import sys
 
@@ -90,5 +89,5 @@ for _ in range(50):
     g.replay()
 e1.record()
 torch.cuda.synchronize()
-print("fused=%s dbg=%s: sum of launches %.1f us; replayed graph %.1f us per forward+backward" %
-      (net._gcn_was_fused, os.environ.get("MMEGO_GCN_DBG", "0"), tot, e0.elapsed_time(e1) / 50 * 1e3))
+print("fused=%s: sum of launches %.1f us; replayed graph %.1f us per forward+backward" %
+      (net._gcn_was_fused, tot, e0.elapsed_time(e1) / 50 * 1e3))

@@ -401,6 +401,57 @@ def test_lower_eval_bf16_mode_is_close_to_fp32_and_is_opt_in():
         fwd()
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_eval_packs_follow_the_weights_through_a_training_step(precision):
+    """LowerNet's eval-mode packs (the bf16 ST-GCN pack `_gcn_bf16_pack`: weight fragments, folded BatchNorm states, bias
+    tables; the fp32 path's re-packed temporal-conv weights `_tconv_packed`) were keyed on tensor._version, which the fused Adam and
+    the train-mode BatchNorm kernels never bump (they write through raw pointers): the first evaluation froze them.  Eval -> one
+    training step (forward, backward, Adam at a large lr) -> eval must CHANGE the output, and the second eval must equal a freshly
+    constructed net that holds the same state (so nothing stale is left)."""
+    from mmego_amd import nets
+    from mmego_amd.params import FusedAdam
+    dev = _dev()
+    torch.manual_seed(41)
+    lo = nets.LowerNet(64).to(dev)
+    lo.precision = precision
+    g = torch.Generator().manual_seed(42)
+    B, T, N = 4, 8, 128
+    x = torch.randn(B, T, N, 6, generator=g).to(dev)
+    up = (torch.randn(B, T, 15, 3, generator=g) * 0.3).to(dev)
+    body = (torch.randn(B, 20, 3, generator=g) * 0.2).to(dev)
+    R = torch.linalg.qr(torch.randn(B, T, 3, 3, generator=g))[0].contiguous().to(dev)
+    t = (torch.randn(B, T, 3, generator=g) * 0.1).to(dev)
+    target = torch.randn(B, T, 8, 3, generator=g).to(dev)
+
+    def ev(net):
+        net.eval()
+        with torch.no_grad():
+            l, q = net(up.clone(), x.clone(), None, None, None, None, body, R, t)[:2]
+        return l.clone(), q.clone()
+    l0, q0 = ev(lo)
+    lo.train()
+    lo.lstm_dropout = 0.0
+    l = lo(up.clone(), x.clone(), None, None, None, None, body, R, t)[0]
+    (l - target).abs().sum().backward()
+    FusedAdam(lo.flat(), lr=1e-2).step()
+    torch.cuda.synchronize()
+    l1, q1 = ev(lo)
+    assert not torch.equal(l0, l1), "the evaluation after a training step still ran the old weights"
+    fresh = nets.LowerNet(64).to(dev)
+    fresh.precision = precision
+    fresh.load_state_dict(lo.state_dict())
+    l2, q2 = ev(fresh)
+    assert torch.equal(l1, l2) and torch.equal(q1, q2), float((l1 - l2).abs().max())
+    # ... and a step taken while the net is ALREADY in eval mode (no .train() call in between) is seen too
+    lo.flat().flat_g.fill_(1e-3)
+    FusedAdam(lo.flat(), lr=1e-2).step()
+    torch.cuda.synchronize()
+    l3, _ = ev(lo)
+    fresh.load_state_dict(lo.state_dict())
+    l4, _ = ev(fresh)
+    assert not torch.equal(l1, l3) and torch.equal(l3, l4)
+
+
 def test_upper_front_eval_bf16_against_emulation_and_fp32():
     """mmego_upper_front_eval_bf16 (front_bf16.hip) against the six stages written out in float64 with the kernel's roundings (folded
     weights and every stage's input rounded to bf16), and UpperNet.precision = "bf16" end to end: the transformed points written back

@@ -1,23 +1,20 @@
 """CPU, world_size 2 over gloo: the data-parallel plumbing (flat gradient buffer, SUM all-reduce, sharding)."""
 import os
-import socket
 
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _init(rank, world, store):
+    """Rendezvous through a file:// store in the test's tmp_path: no TCP port is picked and handed over, so there is no
+    bind-close-reuse race between choosing a port and the ranks' store (a lost race ends in init_process_group's own timeout)."""
+    dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world)
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, store, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    _init(rank, world, store)
     from mmego_amd import nets
     from mmego_amd.params import FlatParams
     from mmego_amd.train_step import allreduce_grads, shard_of
@@ -60,11 +57,11 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_flat_gradient_allreduce_sum_and_sharding():
+def test_flat_gradient_allreduce_sum_and_sharding(tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    store = str(tmp_path / "rendezvous")
+    procs = [ctx.Process(target=_worker, args=(r, 2, store, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
@@ -95,9 +92,9 @@ class _CpuAdam:
         self.flat.flat_p.sub_(self.lr * mh / (vh.sqrt() + 1e-8))
 
 
-def _worker_empty_shard(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker_empty_shard(rank, world, store, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    _init(rank, world, store)
     from mmego_amd import nets, ops, train_step
     from mmego_amd.params import FlatParams
     ops.fill = lambda t, v: t.fill_(v)                     # (CPU stand-in for the device fill kernel: test-side only)
@@ -138,13 +135,13 @@ def _worker_empty_shard(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_rank_with_an_empty_last_shard_stays_bit_equal():
+def test_rank_with_an_empty_last_shard_stays_bit_equal(tmp_path):
     """train_step.empty_step (a rank whose shard of a short last global minibatch is empty): zero gradient into the SUM, the same
     optimiser update -- both ranks' parameters stay bit-equal through and after that step, and equal a one-process run."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_empty_shard, args=(r, 2, port, q)) for r in range(2)]
+    store = str(tmp_path / "rendezvous")
+    procs = [ctx.Process(target=_worker_empty_shard, args=(r, 2, store, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)

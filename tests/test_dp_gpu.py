@@ -7,7 +7,6 @@ with one all-reduce (GradBucket) and applies Adam.  Checked against a single pro
 other: the all-reduced gradient must equal g(shard 0) + g(shard 1) bit for bit, the parameters after Adam must be bit-equal on
 both ranks and equal to the single-process result, and each rank's BatchNorm running statistics must be its own shard's."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -17,14 +16,6 @@ import torch.multiprocessing as mp
 from conftest import golden
 
 pytestmark = pytest.mark.gpu
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _batch(dev):
@@ -57,10 +48,11 @@ def _stages(nets_, shard, pg, use_graph):
     return su, sl
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, store, q):
+    # rendezvous through a file:// store in tmp_path (no port picked by bind-close and handed over: no reuse race)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world)
     try:
         from mmego_amd.train_step import ConcurrentStages, shard_of, sync_replicas
         dev = torch.device("cuda:0")
@@ -88,11 +80,11 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_ul_step_equals_sum_of_shard_gradients():
+def test_two_rank_ul_step_equals_sum_of_shard_gradients(tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    store = str(tmp_path / "rendezvous")
+    procs = [ctx.Process(target=_worker, args=(r, 2, store, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in procs)
@@ -137,12 +129,12 @@ def test_two_rank_ul_step_equals_sum_of_shard_gradients():
     assert not torch.equal(res[0]["buffers"][0][0], res[1]["buffers"][0][0]), "the shards really differ"
 
 
-def _rccl_worker(port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+def _rccl_worker(store, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1")
     import torch.distributed as dist
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # "nccl" IS RCCL on ROCm
+    dist.init_process_group("nccl", init_method="file://" + store, rank=0, world_size=1, device_id=dev)   # "nccl" IS RCCL on ROCm
     try:
         from mmego_amd import train_step
         from mmego_amd.train_step import ConcurrentStages, broadcast_flag, sync_replicas
@@ -170,14 +162,14 @@ def _rccl_worker(port, q):
         dist.destroy_process_group()
 
 
-def test_single_rank_rccl_collectives_in_the_training_step():
+def test_single_rank_rccl_collectives_in_the_training_step(tmp_path):
     """The collectives of the data-parallel step on the REAL backend (RCCL, `init_process_group("nccl", device_id=...)` as bench.py
     and the trainers do), with one rank -- the one-GPU box refuses two ranks on a device: replica sync broadcasts, the gradient
     bucket's all-reduce between the graph replay and the fused Adam, the early-stopping broadcast.  A sum over one rank must leave
     the step's results exactly those of a run without a process group."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_rccl_worker, args=(str(tmp_path / "rendezvous"), q))
     p.start()
     res = q.get(timeout=600)
     p.join(timeout=120)

@@ -349,6 +349,65 @@ def test_upper_epoch_evaluation_on_device(dev, real16):
         assert np.abs(got[5] - want[5]).max() < 1e-2, np.abs(got[5] - want[5]).max()                     # degrees
 
 
+def test_trainers_and_eval_passes_raise_on_a_failed_persistent_launch(dev, real16):
+    """VERDICT r04 item 2 / ADVICE r04: mmego_lstm_seq_xcd (the frozen IMU_Net's rnn_slow recurrence as one persistent launch) reports
+    "my workgroups were not co-resident, results invalid" only through the sticky word 9 of its sync buffer.  The product path must
+    read it: every evaluation pass (processors._epoch_eval: UpperTrainer / LowerTrainer.eval_model, Evaluator.eval_model via
+    evaluate_full) at its end and the trainers' epoch loop once per epoch (reference loop: Processor/Train/Train_Upper.py:90-132).
+    The word is set BY HAND here (a real failure needs a partitioned / shared device) and reset afterwards."""
+    from mmego_amd import blocks, hip, nets, processors
+    from mmego_amd.config import Config
+    from mmego_amd.data import ArraySplit
+    if not blocks._LSTM_SEQ_XCD or hip.lib().mmego_lstm_seq_xcd_slots() < 1:
+        pytest.skip("persistent rnn_slow launch not in use on this device")
+    was = Config.gt_head_pose
+    Config.gt_head_pose = False
+    try:
+        base = processors._Base(Config, make_dirs=False)
+    finally:
+        Config.gt_head_pose = was
+    base.model = load_weights(nets.UpperNet(), golden("w_upper_pretrained.npz")).to(dev)
+    torch.manual_seed(3)
+    base.model_IMU = nets.IMUNet(15, 9, 512, 2, True, 0.1).to(dev).eval()
+    base.batchsize = 8
+    base.test_data = ArraySplit(real16["x"], real16["target"], real16["skl"], real16["imu"], real16["R"])
+    base._rng = np.random.RandomState(5)
+    n0 = len(blocks._seq_sync_bufs)
+    out = processors.UpperTrainer.eval_model(base)                   # head pose from IMU_Net: persistent launches, word stays 0
+    assert len(out) == 6 and np.isfinite(out[0])
+    bufs = blocks._seq_sync_bufs[n0:]
+    assert bufs, "the IMU_Net forward of the evaluation pass did not take the persistent launch"
+    assert blocks.seq_xcd_errors() == 0
+    try:
+        bufs[0][9] = 1
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="mmego_lstm_seq_xcd"):
+            processors.UpperTrainer.eval_model(base)
+        # the trainers' epoch loop: the check sits directly behind train_once
+        class _Loop(processors._StageTrainer):
+            def __init__(self):
+                pass
+        tr = _Loop()
+        tr.cfg, tr.start_epoch, tr.num_epochs, tr.pg, tr.rank = Config, 0, 1, None, 0
+        ran = []
+        tr.train_once = lambda: ran.append(1)
+        tr.eval_model = lambda: pytest.fail("the epoch went on after a failed persistent launch")
+        tr.model = base.model
+        rp = getattr(Config, "resume_path", None)
+        Config.resume_path = None
+        try:
+            with pytest.raises(RuntimeError, match="mmego_lstm_seq_xcd"):
+                tr._train_loop(lambda *a: None)
+        finally:
+            Config.resume_path = rp
+        assert ran == [1]
+    finally:
+        bufs[0][9] = 0
+        torch.cuda.synchronize()
+    assert blocks.seq_xcd_errors() == 0
+    processors.UpperTrainer.eval_model(base)                         # and the path works again once the word is clear
+
+
 def test_imu_stage1_training(dev):
     """IMU_Net forward + backward (BiLSTM backward through time, attention pool, geodesic + position loss) vs the
     reference's gradients (golden g7, hidden 32) and vs the oracle at hidden 64 with the benchmark's T/S."""
