@@ -227,7 +227,7 @@ def _lstm_dropout_off(*modules):
             m.lstm_dropout = 0.0
 
 
-def ul_step_parity(device, use_graph=True):
+def ul_step_parity(device, use_graph=True, imu_precision="fp32"):
     """The arrangement that is timed, checked against the CPU oracle AT THE TIMED SHAPE: freshly seeded nets on both sides
     (identical weights, IMU_Net hidden 512), LSTM dropout off, the full synthetic minibatch (B=64, T=8, N=128: 512 rows through
     rnn_fast, 65 536 points, 7 680 graph rows -- the dispatch branches of the timed step), ONE
@@ -246,6 +246,7 @@ def ul_step_parity(device, use_graph=True):
     o_up, o_lo = on.UpperNet().train(), on.LowerNet(64).train()
     himu, hup, hlo, hfr = build_hip_models(device)                          # same seed -> the same initial weights
     himu_l = clone_imu(himu, device)
+    himu.precision = himu_l.precision = imu_precision          # ("split3": the fp32-accurate bf16-pipe mode, same bars)
     for (ko, vo), (kh, vh) in zip(list(o_up.state_dict().items()) + list(o_lo.state_dict().items()),
                                   list(hup.state_dict().items()) + list(hlo.state_dict().items())):
         assert ko == kh and torch.equal(vo, vh.cpu()), "same seed -> same initial weights: " + ko

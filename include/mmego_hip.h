@@ -333,6 +333,25 @@ int mmego_lstm_seq_xcd(void* stream, const float* xproj, long xs, const float* w
 int mmego_upper_front_eval_bf16(void* stream, float* x, const float* x_src, const float* R, const float* t, long F, int N,
                                 const float* const* w, float eps, float* vec, float* attn);
 
+/* ---- fp32-accurate products on the bf16 matrix pipe ("split3", split3.hip) ------------------------------------
+ * Opt-in mode of the frozen IMU_Net forward (Net/IMU_Net.py:58-62,76-83; IMUNet.precision = "split3"): every fp32 operand of the
+ * BiLSTM products is split EXACTLY into three bf16 pieces a = a1 + a2 + a3 (round to nearest even, residuals exact) and a product
+ * is the fp32-accumulated sum of the six piece products a1b1, a1b2, a2b1, a2b2, a1b3, a3b1 (nprod = 6; dropped terms <= 2^-24
+ * relative) or of all nine (nprod = 9) on v_mfma_f32_32x32x16_bf16.
+ * Operand layout "sfrag": block (rb, s, p) -- 32 rows x 16 k of piece p as the MFMA lanes read it, lane l = row 32 rb + l % 32,
+ * k = 16 s + 8 (l / 32) .. + 8 -- is 1 KB at ((rb * K / 16 + s) * 3 + p) KB.  Activation rows are time-major (t * Bp + b). */
+int mmego_split3_cvt(void* stream, const float* X, long ldx, long rows_in, int K, int tm, int Bn, int T, int Bp, long Rp,
+                     unsigned short* Y);
+int mmego_split3_join(void* stream, const unsigned short* Y, long Rp, int K, float* X, long ldx);
+int mmego_split3_fc_relu(void* stream, const float* X, long ldx, const float* W, const float* bias, int Bn, int T, int Cin,
+                         int H, unsigned short* Y, int Bp, int relu);
+int mmego_split3_gemm(void* stream, const unsigned short* A, const unsigned short* W, float* Cf, float* C, long ldc,
+                      const float* bias, int Mrb, int Nrb, int K, int M, int nprod, int wm);
+int mmego_split3_step(void* stream, int ndir, int Bn, int H, int first, const unsigned short* hprev0, const unsigned short* hprev1,
+                      long hrb, const unsigned short* whh0, const unsigned short* whh1, const float* xpf, long mt0_0, long mt0_1,
+                      float* hout0, float* hout1, long hos, unsigned short* hnext0, unsigned short* hnext1, long hnrb,
+                      float* c0, float* c1, int nprod, int dbase);
+
 /* ---- anchor ("voxel") grouping of UpperNetwlocal (group.hip) -----------------------------------------
  * Per frame and per anchor of the 3x3x3 grid: indices (int64, exact, stable ties) of the 8 nearest points and
  * the gathered rows cat(anchor, xyz-anchor, features) -- square_distance / point_ball_set / AnchorGrouping of

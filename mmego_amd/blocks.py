@@ -722,3 +722,109 @@ def lstm_steps_forward_bf16(ar, key, lstm, x, Bn, T):
                      nxt[0], nxt[1], c[0], c[1])
         cur = outb
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp32-ACCURATE BiLSTM forward on the bf16 matrix pipe (opt-in mode "split3" of the frozen IMU_Net, split3.hip): every
+# fp32 operand as three bf16 pieces (exact), six piece products per product, fp32 accumulation
+# ---------------------------------------------------------------------------------------------------
+SPLIT3_NPROD = int(os.environ.get("MMEGO_SPLIT3_NPROD", "6"))       # 6: dropped terms <= 2^-24 relative; 9: all piece products
+SPLIT3_WM = int(os.environ.get("MMEGO_SPLIT3_WM", "0"))             # projection tile rows / 64 (0: the library's choice)
+
+
+def split3_buffer(ar, name, Rp, K):
+    """A "sfrag" operand buffer (include/mmego_hip.h): Rp x K values as three bf16 pieces, [Rp / 32][K / 16][3][64][8]."""
+    return ar.get(name, (Rp // 32, K // 16, 3, 64, 8), dtype=torch.bfloat16)
+
+
+def split3_cvt(x, out=None, Rp=None, tm=None):
+    """fp32 [rows, K] (unit column stride) -> sfrag pieces.  tm = (Bn, T, Bp): rows b*T + t in, rows t*Bp + b out."""
+    rows, K = x.shape
+    if x.stride(1) != 1 or x.dtype != torch.float32 or K % 16:
+        raise ValueError("split3_cvt needs fp32 rows with unit column stride and K % 16 == 0")
+    if tm is not None:
+        Bn, T, Bp = tm
+        Rp = T * Bp
+    else:
+        Bn = T = Bp = 0
+        Rp = (rows + 31) // 32 * 32 if Rp is None else Rp
+    if out is None:
+        out = torch.empty((Rp // 32, K // 16, 3, 64, 8), dtype=torch.bfloat16, device=x.device)
+    hip.call("split3_cvt", x, x.stride(0), rows, K, int(tm is not None), Bn, T, Bp, Rp, out)
+    return out
+
+
+def split3_join(y, rows, K):
+    """sfrag pieces -> fp32 [Rp, K] (a1 + a2 + a3): the inverse of split3_cvt for values in the exact range."""
+    Rp = y.shape[0] * 32
+    x = torch.empty((Rp, K), dtype=torch.float32, device=y.device)
+    hip.call("split3_join", y, Rp, K, x, K)
+    return x[:rows]
+
+
+def lstm_split3_weights(lstm):
+    """Per layer: (W_ih of both directions stacked [8H, In] as pieces, b_ih + b_hh stacked [8H] fp32, W_hh pieces per direction with
+    rows reordered [hidden block][gate][32 units]).  Built once per weight version (dropped by weights_changed())."""
+    cache = getattr(lstm, "_split3_cache", None)
+    if cache is not None:
+        return cache
+    H = lstm.hidden_size
+    layers = []
+    with torch.no_grad():
+        for l in range(lstm.num_layers):
+            w0 = lstm.w("weight_ih", l, 0)
+            dev = w0.device
+            wih = torch.cat((w0.detach(), lstm.w("weight_ih", l, 1).detach()), 0).contiguous()
+            bias = torch.empty((8 * H,), dtype=torch.float32, device=dev)
+            whh = []
+            for d in range(2):
+                hip.call("add", lstm.w("bias_ih", l, d).detach(), lstm.w("bias_hh", l, d).detach(), bias[4 * H * d:], 4 * H)
+                wr = lstm.w("weight_hh", l, d).detach().view(4, H // 32, 32, H).permute(1, 0, 2, 3).reshape(4 * H, H).contiguous()
+                whh.append(split3_cvt(wr))
+            layers.append((split3_cvt(wih), bias, whh[0], whh[1]))
+    lstm._split3_cache = layers
+    return layers
+
+
+def lstm_steps_forward_split3(ar, key, lstm, x, Bn, T, xfrag=None, nprod=None):
+    """lstm_steps_forward with every product on split operands: x [Bn*T, In] fp32 rows (b*T + t) -- or None with `xfrag` = the
+    layer-0 operand already as pieces in time-major rows (split3_buffer(ar, key + ".x", T*Bp, In), e.g. written by
+    mmego_split3_fc_relu) -> out [Bn*T, 2H] fp32 of the last layer, rows (b*T + t).  Projections tile-major fp32; a layer's h_t of
+    all timesteps and both directions live as pieces in ONE buffer [T*Bp/32][2H/16][3] KB that is the next step's operand (a
+    window) and the next layer's projection operand (whole)."""
+    H = lstm.hidden_size
+    In = lstm.input_size
+    nprod = SPLIT3_NPROD if nprod is None else nprod
+    W = lstm_split3_weights(lstm)
+    Bp = (Bn + 31) // 32 * 32
+    cur = split3_buffer(ar, "%s.x" % key, T * Bp, In)
+    if xfrag is None:
+        split3_cvt(x, out=cur, tm=(Bn, T, Bp))
+    elif xfrag.data_ptr() != cur.data_ptr():
+        raise ValueError("lstm_steps_forward_split3: xfrag must be split3_buffer(ar, key + '.x', T * Bp, In)")
+    K = In
+    out = None
+    nrb = Bp // 32
+    S2 = 2 * H // 16                                   # 16-k steps of a layer-output row
+    hrb = S2 * 3                                       # 1-KB blocks between row blocks of the layer output
+    for l in range(lstm.num_layers):
+        wih, bias, whh0, whh1 = W[l]
+        last = l == lstm.num_layers - 1
+        xpf = ar.get("%s.s3xpf%d" % (key, l), (T * Bp * 8 * H,))
+        hip.call("split3_gemm", cur, wih, xpf, None, 0, bias, T * nrb, 8 * H // 32, K, 0, nprod, SPLIT3_WM)
+        O = split3_buffer(ar, "%s.s3h%d" % (key, l), T * Bp, 2 * H)
+        if last:
+            out = ar.get("%s.out%d" % (key, l), (Bn * T, 2 * H))
+        c = ar.get("%s.c" % key, (2, Bn, H))
+        o_p = O.data_ptr()
+        out_p = out.data_ptr() if last else 0
+        os_ = T * 2 * H
+        win = lambda t, d: o_p + 2 * ((t * nrb * S2 + d * (H // 16)) * 3 * 512)       # bytes: 1 KB = 512 bf16
+        for s in range(T):
+            t0, t1 = s, T - 1 - s
+            hip.call("split3_step", 2, Bn, H, int(s == 0), win(t0 - 1, 0) if s > 0 else None, win(t1 + 1, 1) if s > 0 else None, hrb,
+                     whh0, whh1, xpf, t0 * nrb, t1 * nrb,
+                     out_p + 4 * (t0 * 2 * H) if last else None, out_p + 4 * (t1 * 2 * H + H) if last else None, os_,
+                     win(t0, 0), win(t1, 1), hrb, c[0], c[1], nprod, 0)
+        cur, K = O, 2 * H
+    return out

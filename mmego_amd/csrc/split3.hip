@@ -1,0 +1,595 @@
+// fp32-ACCURATE dense products on the bf16 matrix pipe ("split3"), for the frozen IMU_Net forward (reference Net/IMU_Net.py:58-62,
+// 76-83: fc1 -> rnn_fast BiLSTM(512) over the 20 samples -> attention pooling -> rnn_slow BiLSTM(512) over T -> fc2).
+//
+// On gfx950 v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMAs.  An fp32 value is EXACTLY the sum of three bf16
+// values: a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2) (round to nearest even; each residual is exact in fp32 and the
+// third one fits bf16's 8 significant bits).  A product a.b is then the sum of nine exact piece products, of which
+//     a1 b1,   a1 b2, a2 b1,   a2 b2, a1 b3, a3 b1          (relative size 1, 2^-8, 2^-8, 2^-16, 2^-16, 2^-16)
+// are kept (NPROD = 6) and a2 b3, a3 b2 (2^-24), a3 b3 (2^-32) are dropped -- below the rounding of ONE fp32 product; NPROD = 9
+// keeps them, to measure what they are worth.  All piece products are exact in fp32 and accumulate in fp32 inside the MFMA, so a
+// 6-product sum over K has the error profile of an fp32 dot product at 6/16 of its matrix time.
+// Outside the exact range: a value that rounds to +-inf in bf16 (|a| > 3.39e38) or is inf / NaN has a1 = that, a2 = a3 = 0
+// (and inf x a zero piece is NaN where fp32 would say inf); below 2^-110 the third piece underflows bf16's subnormals (absolute
+// error <= 2^-134 per operand).  Neither range occurs in the net's weights or activations; the mode is opt-in
+// (IMUNet.precision = "split3") and the native fp32 engine stays the default.
+//
+// OPERAND LAYOUT ("sfrag": split, fragment-major).  The MFMA wants, per 16-k step s and 32-row block rb, 16 B per lane: lane l
+// holds row 32 rb + l % 32, k = 16 s + 8 (l / 32) .. + 8.  Both operands of every product are stored that way, piece by piece:
+//     block (rb, s, p) = 1 KB = 64 lanes x 8 bf16, at ((rb * SK + s) * 3 + p) KB,      SK = K / 16, p = piece 0..2,
+// so a wave's operand fetch is one coalesced 1-KB read, an LDS image of a tile is a straight copy (lane-linear ds_read_b128, no
+// padding, no conflicts), and the producers (fc1, the recurrent step's epilogue, the one-time weight re-layout) write whole
+// blocks.  Activation rows are TIME-MAJOR (m = t * Bp + b, Bp = Bn rounded up to 32): a 32-row block is 32 sequences at one
+// timestep, so the layer output buffer [T Bp / 32][2H / 16][3] KB is at once the next step's h_{t-1} operand (a strided window:
+// one timestep, one direction's H columns) and the next layer's projection operand.
+// The projection result is stored TILE-MAJOR fp32 (every 32 x 32 accumulator tile as it sits in registers; bf16.hip has the
+// element formula) and the step kernel loads it back the same way.
+//
+//   s3_cvt_kernel        fp32 row-major -> sfrag pieces (weights once; small activations)
+//   s3_fc_relu_kernel    IMU_Net's fc1 + ReLU (K <= 16) straight into the layer-0 operand
+//   s3_gemm_kernel       C = A . W^T + bias on 6 (9) piece products, (64 WM) x 128 tiles
+//   s3_step_kernel       one BiLSTM timestep, both directions: gates = xproj + h_{t-1} . W_hh^T, cell update, h_t as pieces
+#include "common.h"
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 s3_bf16x8;
+typedef unsigned short s3_bf16_t;
+typedef unsigned int s3_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned s3_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }   // RNE: v_cvt_pk_bf16_f32
+__device__ __forceinline__ float s3_up(unsigned b) { return __uint_as_float(b << 16); }
+
+// a -> (a1, a2, a3) as bf16 bit patterns; a1 + a2 + a3 == a exactly for every finite a with 2^-110 <= |a| <= 3.38e38 and for 0
+__device__ __forceinline__ void s3_split(float a, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = s3_bits(a);
+  const bool fin = (p1 & 0x7f80u) != 0x7f80u;           // a1 neither inf nor NaN
+  const float r1 = fin ? a - s3_up(p1) : 0.f;
+  p2 = s3_bits(r1);
+  const float r2 = r1 - s3_up(p2);
+  p3 = s3_bits(r2);
+}
+
+// 8 values -> the three 16-byte pieces of one lane
+__device__ __forceinline__ void s3_split8(const float (&y)[8], s3_u32x4& o1, s3_u32x4& o2, s3_u32x4& o3) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned a1, a2, a3, b1, b2, b3;
+    s3_split(y[2 * q], a1, a2, a3);
+    s3_split(y[2 * q + 1], b1, b2, b3);
+    o1[q] = a1 | (b1 << 16);
+    o2[q] = a2 | (b2 << 16);
+    o3[q] = a3 | (b3 << 16);
+  }
+}
+
+// ---- fp32 row-major -> sfrag ------------------------------------------------------------------------------------------------
+// Output row r (of Rp, a multiple of 32) takes input row r (tm == 0; rows >= rows_in are zero) or, time-major (tm != 0: r = t Bp + b),
+// input row b T + t (b < Bn, else zero).
+__global__ __launch_bounds__(256) void s3_cvt_kernel(const float* __restrict__ X, long ldx, int rows_in, int SK, int tm, int Bn, int T,
+                                                      int Bp, s3_u32x4* __restrict__ Y, long nblk) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = (int)(idx & 63);
+  const long blk = idx >> 6;
+  if (blk >= nblk) return;
+  const long rb = blk / SK;
+  const int s = (int)(blk - rb * SK);
+  const long r = rb * 32 + (lane & 31);
+  long src;
+  bool live;
+  if (tm) {
+    const long t = r / Bp, b = r - t * Bp;
+    live = b < Bn && t < T;
+    src = b * T + t;
+  } else {
+    live = r < rows_in;
+    src = r;
+  }
+  float y[8];
+  const float* xr = X + (live ? src : 0) * ldx + 16 * s + 8 * (lane >> 5);
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr), v1 = *reinterpret_cast<const f32x4*>(xr + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    y[e] = live ? v0[e] : 0.f;
+    y[4 + e] = live ? v1[e] : 0.f;
+  }
+  s3_u32x4 o1, o2, o3;
+  s3_split8(y, o1, o2, o3);
+  s3_u32x4* dst = Y + blk * 192 + lane;
+  dst[0] = o1;
+  dst[64] = o2;
+  dst[128] = o3;
+}
+
+// X [rows_in][K] fp32 (row stride ldx, 16-byte aligned rows) -> Y sfrag [Rp / 32][K / 16][3][64][8] bf16.  tm = 0: Rp >= rows_in
+// rows in order (zero padded); tm = 1: Rp = T * Bp rows t * Bp + b from input rows b * T + t (b < Bn).
+extern "C" int mmego_split3_cvt(void* stream, const float* X, long ldx, long rows_in, int K, int tm, int Bn, int T, int Bp, long Rp,
+                                unsigned short* Y) {
+  MMEGO_REQUIRE(X && Y && rows_in > 0 && K > 0 && K % 16 == 0 && ldx % 4 == 0 && Rp > 0 && Rp % 32 == 0 && rows_in < (1L << 31));
+  MMEGO_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Y) & 15) == 0);
+  if (tm) MMEGO_REQUIRE(Bn > 0 && T > 0 && Bp >= Bn && Bp % 32 == 0 && Rp == (long)T * Bp && rows_in == (long)Bn * T);
+  else MMEGO_REQUIRE(Rp >= rows_in);
+  const long nblk = (Rp / 32) * (K / 16);
+  const long nthr = nblk * 64;
+  MMEGO_REQUIRE(nthr / 256 + 1 < (1L << 31));
+  s3_cvt_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, (hipStream_t)stream>>>(X, ldx, (int)rows_in, K / 16, tm, Bn, T, Bp,
+                                                                                  reinterpret_cast<s3_u32x4*>(Y), nblk);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// sfrag -> fp32 row-major (a1 + a2 + a3 in that order of addition: exact for a split of an fp32 value).  Test / debug aid.
+__global__ __launch_bounds__(256) void s3_join_kernel(const s3_u32x4* __restrict__ Y, int SK, long nblk, float* __restrict__ X, long ldx) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = (int)(idx & 63);
+  const long blk = idx >> 6;
+  if (blk >= nblk) return;
+  const long rb = blk / SK;
+  const int s = (int)(blk - rb * SK);
+  const s3_u32x4* src = Y + blk * 192 + lane;
+  const s3_u32x4 o1 = src[0], o2 = src[64], o3 = src[128];
+  float* xr = X + (rb * 32 + (lane & 31)) * ldx + 16 * s + 8 * (lane >> 5);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    xr[2 * q] = (s3_up(o1[q] & 0xffffu) + s3_up(o2[q] & 0xffffu)) + s3_up(o3[q] & 0xffffu);
+    xr[2 * q + 1] = (s3_up(o1[q] >> 16) + s3_up(o2[q] >> 16)) + s3_up(o3[q] >> 16);
+  }
+}
+
+extern "C" int mmego_split3_join(void* stream, const unsigned short* Y, long Rp, int K, float* X, long ldx) {
+  MMEGO_REQUIRE(X && Y && Rp > 0 && Rp % 32 == 0 && K > 0 && K % 16 == 0 && ldx >= K);
+  const long nblk = (Rp / 32) * (K / 16);
+  s3_join_kernel<<<(unsigned)((nblk * 64 + 255) / 256), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const s3_u32x4*>(Y), K / 16, nblk, X, ldx);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// ---- IMU_Net's fc1 + ReLU (Linear(15, H), Net/IMU_Net.py:53,73) straight into the layer-0 operand ---------------------------------
+// Y (sfrag, rows t * Bp + b, K = H) = split(relu(X[b * T + t] . W^T + bias)).  One workgroup per (32-row block, timestep); W (padded to
+// 16 columns) and the bias wait in LDS, a row's <= 16 inputs in registers; a thread produces the 8 consecutive units of one lane of
+// a block, so a wave stores three whole 1-KB blocks per 16 units.  fp32 FMAs in k order (the fp32 path's fc1 is a product kernel with
+// another summation order: same result to fp32 rounding).
+__global__ __launch_bounds__(256) void s3_fc_relu_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, int Bn, int T, int Cin, int H,
+                                                          s3_u32x4* __restrict__ Y, int Bp, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float s3_wsm[];      // [H][16] + bias [H]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < H * 16; i += 256) {
+    const int n = i >> 4, k = i & 15;
+    s3_wsm[i] = k < Cin ? W[(long)n * Cin + k] : 0.f;
+  }
+  for (int i = tid; i < H; i += 256) s3_wsm[H * 16 + i] = bias ? bias[i] : 0.f;
+  const int t = blockIdx.y, rb = blockIdx.x;
+  const int b = rb * 32 + (lane & 31), half = lane >> 5;
+  float x[16];
+  {
+    const float* xr = X + ((long)(b < Bn ? b : Bn - 1) * T + t) * ldx;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = xr[k < Cin ? k : Cin - 1];        // (clamped address; the padded weights are zero)
+  }
+  __syncthreads();
+  const bool live = b < Bn;
+  const int SK = H >> 4;
+  s3_u32x4* dst = Y + ((long)t * (Bp >> 5) + rb) * SK * 192 + lane;
+  for (int k16 = wave; k16 < SK; k16 += 4) {
+    const int n0 = k16 * 16 + half * 8;
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4* wr = reinterpret_cast<const f32x4*>(s3_wsm + (n0 + j) * 16);
+      float a = s3_wsm[H * 16 + n0 + j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 w4 = wr[q];
+        a = fmaf(x[4 * q], w4[0], a); a = fmaf(x[4 * q + 1], w4[1], a); a = fmaf(x[4 * q + 2], w4[2], a); a = fmaf(x[4 * q + 3], w4[3], a);
+      }
+      y[j] = live ? (relu ? fmaxf(a, 0.f) : a) : 0.f;
+    }
+    s3_u32x4 o1, o2, o3;
+    s3_split8(y, o1, o2, o3);
+    dst[(long)k16 * 192] = o1;
+    dst[(long)k16 * 192 + 64] = o2;
+    dst[(long)k16 * 192 + 128] = o3;
+  }
+}
+
+extern "C" int mmego_split3_fc_relu(void* stream, const float* X, long ldx, const float* W, const float* bias, int Bn, int T, int Cin,
+                                    int H, unsigned short* Y, int Bp, int relu) {
+  MMEGO_REQUIRE(X && W && Y && Bn > 0 && T > 0 && Cin > 0 && Cin <= 16 && H > 0 && H % 16 == 0 && H <= 2048 && Bp >= Bn && Bp % 32 == 0);
+  MMEGO_REQUIRE(T <= 65535 && (((uintptr_t)Y) & 15) == 0);
+  const size_t lds = (size_t)(H * 16 + H) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)s3_fc_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * 17 * 4);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(Bp / 32, T);
+  s3_fc_relu_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(X, ldx, W, bias, Bn, T, Cin, H, reinterpret_cast<s3_u32x4*>(Y), Bp, relu);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// ---- the piece products of one (A tile, B tile) pair at one 16-k step --------------------------------------------------------
+// small terms first, a1 b1 last (the accumulator is fp32 either way; this order keeps the partial sums' rounding smallest)
+template <int NPROD>
+__device__ __forceinline__ f32x16 s3_mma(const s3_u32x4 (&a)[3], const s3_u32x4 (&b)[3], f32x16 acc) {
+#define S3_MM(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s3_bf16x8, a[i]), __builtin_bit_cast(s3_bf16x8, b[j]), acc, 0, 0, 0)
+  if (NPROD == 9) {
+    S3_MM(2, 2);
+    S3_MM(1, 2);
+    S3_MM(2, 1);
+  }
+  S3_MM(0, 2);
+  S3_MM(2, 0);
+  S3_MM(1, 1);
+  S3_MM(0, 1);
+  S3_MM(1, 0);
+  S3_MM(0, 0);
+#undef S3_MM
+  return acc;
+}
+
+// XCD-aware tile order: blocks b and b + 8 share an XCD; hand each XCD a contiguous run of tile ids.
+__device__ __forceinline__ int s3_xcd_order(int id, int n) { return (n & 7) == 0 ? (id & 7) * (n >> 3) + (id >> 3) : id; }
+
+// ---- C = A . W^T + bias -----------------------------------------------------------------------------------------------------------
+struct S3GemmP {
+  const s3_u32x4* A;       // sfrag [Mrb][SK][3][64]
+  const s3_u32x4* W;       // sfrag [Nrb][SK][3][64]
+  float* Cf;               // tile-major fp32 [Mrb][Nrb][1024] or null
+  float* C; long ldc;      // row-major fp32 or null
+  const float* bias;       // [32 Nrb] or null
+  int Mrb, Nrb, SK, M;     // M: rows really stored to C (row-major output only)
+  int tiles_m, tiles_n;
+};
+
+// Workgroup tile (64 WM) x 128, WM x 2 waves, wave tile 64 x 64 = 2 x 2 MFMA tiles.  32-k chunks (2 16-k steps): the chunk's blocks
+// of a row block are 6 consecutive KB in memory, copied as they lie into an LDS image [row block][step][piece][lane] through
+// registers (the next chunk's loads are in flight while this one is multiplied); per 16-k step a wave reads 12 fragments
+// (lane-linear ds_read_b128) for 24 (36) MFMAs.  LDS: (2 WM + 4) x 6 KB = 48 KB (WM = 2: two workgroups per CU) / 72 KB (WM = 4).
+template <int WM, int NPROD>
+__global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
+  constexpr int NT = WM * 128;                 // threads
+  constexpr int RBA = WM * 2;                  // A row blocks per tile
+  constexpr int NLA = RBA * 384 / NT;          // 16-byte loads per thread and chunk: A (6), W (6 / 3)
+  constexpr int NLW = 4 * 384 / NT;
+  __shared__ s3_u32x4 As[RBA * 384];
+  __shared__ s3_u32x4 Bs[4 * 384];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  // tile order: runs of 16 row panels sweep the N tiles, so a W panel is shared by 16 consecutive workgroups and the 16 A panels
+  // stay in L2 for the whole sweep
+  const int id = s3_xcd_order(blockIdx.x, (int)gridDim.x);
+  const int GM = 16;
+  const int per_group = GM * p.tiles_n;
+  const int group = id / per_group, in_group = id - group * per_group;
+  const int gm = min(GM, p.tiles_m - group * GM);
+  const int tm = group * GM + in_group % gm, tn = in_group / gm;
+  const int rbA0 = tm * RBA, rbW0 = tn * 4;
+  const int SK = p.SK;
+
+  // piece i = j NT + tid of an operand's image: row block i / 384, offset i % 384 inside its 6-KB run
+  int ga[NLA], gw[NLW];
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+    const int i = j * NT + tid;
+    ga[j] = min(rbA0 + i / 384, p.Mrb - 1) * SK * 192 + i % 384;
+  }
+#pragma unroll
+  for (int j = 0; j < NLW; ++j) {
+    const int i = j * NT + tid;
+    gw[j] = min(rbW0 + i / 384, p.Nrb - 1) * SK * 192 + i % 384;
+  }
+  s3_u32x4 ra[NLA], rw[NLW];
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) ra[j] = p.A[ga[j]];
+#pragma unroll
+  for (int j = 0; j < NLW; ++j) rw[j] = p.W[gw[j]];
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+  const int nchunk = SK >> 1;
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();                            // the previous chunk's fragments have been read
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) As[j * NT + tid] = ra[j];
+#pragma unroll
+    for (int j = 0; j < NLW; ++j) Bs[j * NT + tid] = rw[j];
+    __syncthreads();
+    {
+      const int cn = min(c + 1, nchunk - 1) * 384;      // (unconditional prefetch; past the end: the last chunk again)
+#pragma unroll
+      for (int j = 0; j < NLA; ++j) ra[j] = p.A[ga[j] + cn];
+#pragma unroll
+      for (int j = 0; j < NLW; ++j) rw[j] = p.W[gw[j] + cn];
+    }
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      s3_u32x4 a[2][3], b[2][3];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[mi][q] = As[(((wm * 2 + mi) * 2 + kc) * 3 + q) * 64 + lane];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[ni][q] = Bs[(((wn * 2 + ni) * 2 + kc) * 3 + q) * 64 + lane];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = s3_mma<NPROD>(a[mi], b[ni], acc[mi][ni]);
+    }
+  }
+  // accumulator layout of the 32 x 32 MFMA: register i of lane l is (row = 8 (i / 4) + 4 (l / 32) + i % 4, col = l % 32)
+  const int fr = lane & 31;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int cb = rbW0 + wn * 2 + ni;                 // column block
+    if (cb >= p.Nrb) continue;
+    const float bv = p.bias ? p.bias[cb * 32 + fr] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int rbm = rbA0 + wm * 2 + mi;
+      if (rbm >= p.Mrb) continue;
+      if (p.Cf) {                                        // an accumulator tile IS a tile of the tile-major layout: four 1-KB stores
+        float* t = p.Cf + ((long)rbm * p.Nrb + cb) * 1024 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r] + bv;
+          *reinterpret_cast<f32x4*>(t + q * 256) = v;
+        }
+      }
+      if (p.C) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = rbm * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+          if (row < p.M) p.C[(long)row * p.ldc + cb * 32 + fr] = acc[mi][ni][i] + bv;
+        }
+      }
+    }
+  }
+}
+
+// C[m][n] = sum_k A[m][k] W[n][k] + bias[n] on 6 (nprod = 6) or 9 piece products; A sfrag [Mrb][K / 16][3] KB, W sfrag [Nrb][K / 16][3] KB
+// (mmego_split3_cvt).  Cf: tile-major fp32 [Mrb][Nrb][1024] and / or C: row-major (rows < M stored, row stride ldc).  K % 32 == 0.
+// wm = 2: 128 x 128 tiles on 256-thread workgroups, wm = 4: 256 x 128 tiles on 512-thread workgroups (0: the default choice).
+extern "C" int mmego_split3_gemm(void* stream, const unsigned short* A, const unsigned short* W, float* Cf, float* C, long ldc,
+                                 const float* bias, int Mrb, int Nrb, int K, int M, int nprod, int wm) {
+  MMEGO_REQUIRE(A && W && (Cf || C) && Mrb > 0 && Nrb > 0 && K > 0 && K % 32 == 0 && (nprod == 6 || nprod == 9));
+  MMEGO_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (!Cf || (((uintptr_t)Cf) & 15) == 0));
+  MMEGO_REQUIRE(!C || (M > 0 && M <= Mrb * 32 && ldc >= Nrb * 32));
+  MMEGO_REQUIRE((long)Mrb * (K / 16) * 192 < (1L << 31) && (long)Nrb * (K / 16) * 192 < (1L << 31));
+  if (wm == 0) wm = Mrb >= 8 * 256 / 32 ? 4 : 2;
+  MMEGO_REQUIRE(wm == 2 || wm == 4);
+  S3GemmP p;
+  p.A = reinterpret_cast<const s3_u32x4*>(A); p.W = reinterpret_cast<const s3_u32x4*>(W);
+  p.Cf = Cf; p.C = C; p.ldc = ldc; p.bias = bias; p.Mrb = Mrb; p.Nrb = Nrb; p.SK = K / 16; p.M = M;
+  p.tiles_m = cdiv(Mrb, 2 * wm); p.tiles_n = cdiv(Nrb, 4);
+  const long tiles = (long)p.tiles_m * p.tiles_n;
+  MMEGO_REQUIRE(tiles < (1L << 30));
+  hipStream_t st = (hipStream_t)stream;
+  if (wm == 2 && nprod == 6) s3_gemm_kernel<2, 6><<<(int)tiles, 256, 0, st>>>(p);
+  else if (wm == 2) s3_gemm_kernel<2, 9><<<(int)tiles, 256, 0, st>>>(p);
+  else if (nprod == 6) s3_gemm_kernel<4, 6><<<(int)tiles, 512, 0, st>>>(p);
+  else s3_gemm_kernel<4, 9><<<(int)tiles, 512, 0, st>>>(p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// ---- one BiLSTM timestep -------------------------------------------------------------------------------------------------------------
+struct S3StepP {
+  const s3_u32x4* hprev[2]; long hrb;   // h_{t-1} pieces: block (rb, s, p) at hprev[d] + (rb * hrb + s * 3 + p) * 64; hrb = blocks between row blocks
+  const s3_u32x4* whh[2];               // W_hh pieces, sfrag with rows [hidden block jb][gate][32 units], SK = H / 16
+  const float* xpf; long mt0[2];        // x . W_ih^T + b_ih + b_hh, tile-major; mt0[d] = first row tile of direction d's timestep
+  float* hout[2]; long hos;             // h_t fp32 row-major (may be null)
+  s3_u32x4* hnext[2]; long hnrb;        // h_t pieces, addressed like hprev
+  float* c[2];
+  int Bn, H, first, dbase;             // dbase: direction of slot 0 (a single-direction launch of the reverse direction: 1)
+};
+
+__device__ __forceinline__ float s3_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float s3_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+// The small-batch step of the bf16 mode (lstm_step_bf16_direct_kernel, bf16.hip) on piece products.  Workgroup = 64 rows x 32 hidden
+// units x 4 gates of one direction (Bn = H = 512: 8 x 16 x 2 = 256 workgroups, one per CU); wave w takes k quarter w of the whole tile,
+// so no fragment is fetched twice, and streams its SQ 16-k steps through a ring of three fragment sets (18 coalesced 1-KB reads per
+// step, requested two steps = 96 MFMAs ahead); the four partial tiles meet in LDS (fixed order) and all four waves run the cell
+// update of 16 rows each.  h_t leaves as 12 whole 1-KB blocks per workgroup (pieces put together in LDS), and optionally as fp32 rows.
+template <int SQ, int NPROD, bool FIRST>
+__global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
+  extern __shared__ __attribute__((aligned(16))) float s3_red[];      // [4 waves][2 mi][4 n][16 i][64 lanes] = 128 KB
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int d = blockIdx.z, H = p.H, S = H >> 4;
+  const int nrb = gridDim.y, nb = gridDim.x * nrb;
+  const int id = s3_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, nb);
+  const int jb = id / nrb, j0 = jb * 32, r0 = (id % nrb) * 64;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int j = j0 + fr;
+  const int own_mi = w >> 1, own_i0 = 8 * (w & 1);     // this wave finishes rows 32 own_mi + 16 (w & 1) .. + 16:
+  const int own_r0 = own_mi * 32 + 16 * (w & 1);       // accumulator registers own_i0 .. own_i0 + 8 of row block own_mi
+  const int last_rb = (p.Bn - 1) >> 5;
+  const int hb = H >> 5;
+
+  // operand pointers and the first two steps' fragment requests go out BEFORE the cell update's own operands (xproj tile, c_{t-1}):
+  // one memory round trip for all of them (asked for first, the compiler parked the xproj values in AGPRs behind a vmcnt(0) and
+  // only then issued the first fragment load)
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][n][i] = 0.f;
+  const s3_u32x4* ap[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) ap[mi] = p.hprev[d] + ((long)min((r0 >> 5) + mi, last_rb) * p.hrb + (long)w * SQ * 3) * 64 + lane;
+  const s3_u32x4* wp = p.whh[d] + ((long)jb * 4 * S + w * SQ) * 192 + lane;
+  const int gstride = S * 192;                        // between the gates' row blocks
+  s3_u32x4 a[3][2][3], b[3][4][3];
+#define S3_LOAD(slot, s)                                                                    \
+    {                                                                                       \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                      \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) a[slot][mi][q] = ap[mi][((s) * 3 + q) * 64];      \
+      _Pragma("unroll") for (int n = 0; n < 4; ++n)                                         \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) b[slot][n][q] = wp[n * gstride + ((s) * 3 + q) * 64]; \
+    }
+  if (!FIRST) {                                         // (compile time: the step loop below is straight-line code)
+    S3_LOAD(0, 0)
+    S3_LOAD(1, 1 < SQ ? 1 : 0)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 xp[4][2];
+  float cprev[8];
+  {
+    const int rb = min((r0 >> 5) + own_mi, last_rb);
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+        xp[n][qq] = (reinterpret_cast<const f32x4*>(p.xpf + ((p.mt0[d] + rb) * (long)(8 * hb) + ((p.dbase + d) * 4 + n) * hb + jb) * 1024) + lane)[(2 * (w & 1) + qq) * 64];
+  }
+#pragma unroll
+  for (int ii = 0; ii < 8; ++ii) {                      // (FIRST: dead code, c_0 = 0)
+    const int row = min(r0 + own_r0 + 8 * (ii >> 2) + 4 * fh + (ii & 3), p.Bn - 1);
+    cprev[ii] = p.c[d][(long)row * H + j];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  float pre[4][8];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) pre[n][ii] = 0.f;
+
+  if (!FIRST) {
+#pragma unroll
+    for (int s = 0; s < SQ; ++s) {
+      if (s + 2 < SQ) {
+        if ((s + 2) % 3 == 0) S3_LOAD(0, s + 2)
+        else if ((s + 2) % 3 == 1) S3_LOAD(1, s + 2)
+        else S3_LOAD(2, s + 2)
+      }
+      __builtin_amdgcn_sched_barrier(0);                // (requests of step s + 2 out before the MFMAs of step s)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[mi][n] = s3_mma<NPROD>(a[s % 3][mi], b[s % 3][n], acc[mi][n]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef S3_LOAD
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s3_red[(((w * 2 + mi) * 4 + n) * 16 + i) * 64 + lane] = acc[mi][n][i];
+    __syncthreads();
+#pragma unroll
+    for (int src = 0; src < 4; ++src)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) pre[n][ii] += s3_red[(((src * 2 + own_mi) * 4 + n) * 16 + own_i0 + ii) * 64 + lane];
+    __syncthreads();                                    // (the reduction buffer becomes the piece image below)
+  }
+  // cell update of this lane's 8 (row, unit j) elements; PyTorch gate order i, f, g, o
+  s3_bf16_t* img = reinterpret_cast<s3_bf16_t*>(s3_red);            // [2 rb][2 s][3 p][64 lanes][8] bf16 = 12 KB
+#pragma unroll
+  for (int ii = 0; ii < 8; ++ii) {
+    const int rl = own_r0 + 8 * (ii >> 2) + 4 * fh + (ii & 3);      // row inside the workgroup's 64
+    const int row = r0 + rl;
+    const float gi = s3_sigmoid(pre[0][ii] + xp[0][ii >> 2][ii & 3]);
+    const float gf = s3_sigmoid(pre[1][ii] + xp[1][ii >> 2][ii & 3]);
+    const float gg = s3_tanh(pre[2][ii] + xp[2][ii >> 2][ii & 3]);
+    const float go = s3_sigmoid(pre[3][ii] + xp[3][ii >> 2][ii & 3]);
+    const float cn = gf * (FIRST ? 0.f : cprev[ii]) + gi * gg;
+    const float hn = row < p.Bn ? go * s3_tanh(cn) : 0.f;
+    if (row < p.Bn) {
+      p.c[d][(long)row * H + j] = cn;
+      if (p.hout[d]) p.hout[d][(long)row * p.hos + j] = hn;
+    }
+    unsigned q1, q2, q3;
+    s3_split(hn, q1, q2, q3);
+    // element (row rl, k = fr of the workgroup's 32 units): block (rl / 32, fr / 16), lane (rl % 32) + 32 ((fr / 8) & 1), e = fr % 8
+    const int o = ((((rl >> 5) * 2 + (fr >> 4)) * 3) * 64 + (rl & 31) + 32 * ((fr >> 3) & 1)) * 8 + (fr & 7);
+    img[o] = (s3_bf16_t)q1;
+    img[o + 512] = (s3_bf16_t)q2;
+    img[o + 1024] = (s3_bf16_t)q3;
+  }
+  __syncthreads();
+  {
+    // 768 16-byte pieces: image index i = ((rb_l * 2 + s_l) * 3 + p) * 64 + lane
+    const s3_u32x4* im4 = reinterpret_cast<const s3_u32x4*>(img);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = u * 256 + tid;
+      const int blk = i >> 6, ln = i & 63;
+      const int rbl = blk / 6, rest = blk - rbl * 6;               // rest = s_l * 3 + p
+      const int rb = (r0 >> 5) + rbl;
+      if (rb <= last_rb) p.hnext[d][((long)rb * p.hnrb + (long)(j0 >> 4) * 3 + rest) * 64 + ln] = im4[i];
+    }
+  }
+}
+
+// One timestep of both (ndir = 2) or one direction of a BiLSTM layer on piece products.  hprev / hnext: h_{t-1} / h_t as sfrag pieces
+// inside a buffer whose row blocks are hrb / hnrb 1-KB blocks apart (a [Bp x H] window of the layer output [T Bp / 32][2H / 16][3] KB:
+// pointer = buffer + ((t Bp / 32) (2H / 16) + d H / 16) 3 KB, hrb = (2H / 16) 3); whh: mmego_split3_cvt of W_hh with rows reordered
+// [hidden block][gate][32 units]; xpf: tile-major projections (mmego_split3_gemm's Cf), mt0_d = t_d Bp / 32; hout (optional): fp32
+// rows with stride hos; c [Bn][H]; dbase: the direction slot 0 stands for (ndir = 1 launches
+// of the reverse direction pass 1: it selects the projection's columns).  Bn <= 2048 rows, H = 256 / 512 / 1024.
+extern "C" int mmego_split3_step(void* stream, int ndir, int Bn, int H, int first, const unsigned short* hprev0, const unsigned short* hprev1,
+                                 long hrb, const unsigned short* whh0, const unsigned short* whh1, const float* xpf, long mt0_0, long mt0_1,
+                                 float* hout0, float* hout1, long hos, unsigned short* hnext0, unsigned short* hnext1, long hnrb,
+                                 float* c0, float* c1, int nprod, int dbase) {
+  MMEGO_REQUIRE(dbase >= 0 && dbase + ndir <= 2);
+  MMEGO_REQUIRE((ndir == 1 || ndir == 2) && Bn > 0 && Bn <= 2048 && (H == 256 || H == 512 || H == 1024) && (nprod == 6 || nprod == 9));
+  MMEGO_REQUIRE(first || (hprev0 && (ndir == 1 || hprev1) && ((((uintptr_t)hprev0) | ((uintptr_t)hprev1)) & 15) == 0));
+  MMEGO_REQUIRE(whh0 && (ndir == 1 || whh1) && ((((uintptr_t)whh0) | ((uintptr_t)whh1)) & 15) == 0);
+  MMEGO_REQUIRE(hnext0 && (ndir == 1 || hnext1) && ((((uintptr_t)hnext0) | ((uintptr_t)hnext1)) & 15) == 0 && hnext0 != hprev0);
+  MMEGO_REQUIRE(xpf && (((uintptr_t)xpf) & 15) == 0 && mt0_0 >= 0 && mt0_1 >= 0 && c0 && (ndir == 1 || c1) && hrb > 0 && hnrb > 0);
+  S3StepP p;
+  p.hprev[0] = reinterpret_cast<const s3_u32x4*>(hprev0); p.hprev[1] = reinterpret_cast<const s3_u32x4*>(hprev1); p.hrb = hrb;
+  p.whh[0] = reinterpret_cast<const s3_u32x4*>(whh0); p.whh[1] = reinterpret_cast<const s3_u32x4*>(whh1);
+  p.xpf = xpf; p.mt0[0] = mt0_0; p.mt0[1] = mt0_1;
+  p.hout[0] = hout0; p.hout[1] = hout1; p.hos = hos;
+  p.hnext[0] = reinterpret_cast<s3_u32x4*>(hnext0); p.hnext[1] = reinterpret_cast<s3_u32x4*>(hnext1); p.hnrb = hnrb;
+  p.c[0] = c0; p.c[1] = c1;
+  p.Bn = Bn; p.H = H; p.first = first; p.dbase = dbase;
+  const int lds = 4 * 2 * 4 * 16 * 64 * (int)sizeof(float);
+  dim3 grid(H / 32, cdiv(Bn, 64), ndir);
+  hipStream_t st = (hipStream_t)stream;
+  const int sq = H / 64;
+#define S3_STEP_LAUNCH(SQ_, NP_, F_)                                                                                        \
+  {                                                                                                                         \
+    static bool attr_set = false;                                                                                           \
+    if (!attr_set) {                                                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void*)s3_step_kernel<SQ_, NP_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      if (e != hipSuccess) return (int)e;                                                                                   \
+      attr_set = true;                                                                                                      \
+    }                                                                                                                       \
+    s3_step_kernel<SQ_, NP_, F_><<<grid, 256, lds, st>>>(p);                                                               \
+  }
+#define S3_STEP_NP(SQ_, F_)                 \
+  {                                         \
+    if (nprod == 6) S3_STEP_LAUNCH(SQ_, 6, F_) \
+    else S3_STEP_LAUNCH(SQ_, 9, F_)         \
+  }
+#define S3_STEP_F(SQ_)              \
+  {                                 \
+    if (first) S3_STEP_NP(SQ_, true) \
+    else S3_STEP_NP(SQ_, false)     \
+  }
+  if (sq == 8) S3_STEP_F(8)
+  else if (sq == 4) S3_STEP_F(4)
+  else S3_STEP_F(16)
+#undef S3_STEP_F
+#undef S3_STEP_NP
+#undef S3_STEP_LAUNCH
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

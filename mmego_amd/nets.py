@@ -1005,7 +1005,34 @@ class IMUNet(_NetBase):
     def weights_changed(self):
         super().weights_changed()                  # weights may change: drop the bf16 copies of the LSTM weights
         for m in (self.rnn_fast, self.rnn_slow):
-            m._bf16_cache = m._bf16_fused_cache = None
+            m._bf16_cache = m._bf16_fused_cache = m._split3_cache = None
+
+    def _forward_split3(self, ar, imu, B, T, S, Cin, H):
+        """precision = "split3" (split3.hip): the fp32 forward with rnn_fast's products -- input projections and recurrent steps,
+        94 % of the model's FLOPs -- on exactly split bf16 operands (a = a1 + a2 + a3, six piece products, fp32 accumulation:
+        fp32-accurate at 6/16 of the fp32 matrix time).  fc1 writes the layer-0 operand itself; attention pooling, rnn_slow (64
+        rows: its persistent fp32 recurrence is latency-bound, not matrix-bound), fc2 and the head are the fp32 path's kernels."""
+        Bn = B * T
+        dev = imu.device
+        if not (H in (256, 512, 1024) and Cin <= 16 and Bn <= 2048 and self.fc1.weight.is_contiguous()):
+            raise ValueError("IMUNet.precision = 'split3' needs hidden_n in (256, 512, 1024), input_n <= 16 and B*T <= 2048")
+        Bp = (Bn + 31) // 32 * 32
+        xf = blocks.split3_buffer(ar, "fast.x", S * Bp, H)
+        hip.call("split3_fc_relu", imu.view(Bn * S, Cin), Cin, self.fc1.weight, self.fc1.bias, Bn, S, Cin, H, xf, Bp, 1)
+        fast = blocks.lstm_steps_forward_split3(ar, "fast", self.rnn_fast, None, Bn, S, xfrag=xf)
+        pooled = ar.get("pooled", (Bn, 2 * H))
+        attn = ar.get("attn", (Bn, S))
+        blocks.attn_pool_forward(fast, self.attn, Bn, S, 2 * H, pooled, attn)
+        slow = blocks.lstm_steps_forward(ar, "slow", self.rnn_slow, pooled, B, T)
+        R = torch.empty((B, T, 3, 3), dtype=torch.float32, device=dev)
+        t = torch.empty((B, T, 3), dtype=torch.float32, device=dev)
+        if slow.shape[1] % 256 == 0 and slow.stride(0) % 4 == 0 and slow.stride(1) == 1 and self.fc2.weight.is_contiguous():
+            hip.call("imu_fc2_head", slow, slow.stride(0), self.fc2.weight, self.fc2.bias, Bn, slow.shape[1], None, R, t)
+        else:
+            y = ar.get("y", (Bn, 9))
+            ops.linear(slow, self.fc2.weight, self.fc2.bias, y)
+            hip.call("imu_head", y, Bn, R, t)
+        return R, t
 
     def forward(self, imu, h0_i=None):
         _require_gpu(imu, "IMUNet")
@@ -1025,9 +1052,11 @@ class IMUNet(_NetBase):
         H = self.hidden_n
         Bn = B * T
         dev = imu.device
-        if self.precision not in ("fp32", "bf16"):
-            raise ValueError("IMUNet.precision must be 'fp32' or 'bf16', got %r" % (self.precision,))
+        if self.precision not in ("fp32", "bf16", "split3"):
+            raise ValueError("IMUNet.precision must be 'fp32', 'bf16' or 'split3', got %r" % (self.precision,))
         bf16 = self.precision == "bf16"
+        if self.precision == "split3":
+            return self._forward_split3(ar, imu, B, T, S, Cin, H)
         if (bf16 and Bn >= blocks.FUSED_MIN_ROWS and H % 64 == 0 and Cin <= 16 and imu.is_contiguous()
                 and self.fc1.weight.is_contiguous() and os.environ.get("MMEGO_BF16_FUSED_FC1", "1") != "0"):
             # large batch in the bf16 mode: fc1 + ReLU written straight as the fused step's layer-0 operand (bf16, fragment-major);

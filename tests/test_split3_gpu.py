@@ -1,0 +1,208 @@
+"""GPU: the "split3" mode of the frozen IMU_Net forward (mmego_amd/csrc/split3.hip; reference Net/IMU_Net.py:58-62,76-83) -- fp32
+products on the bf16 matrix pipe: every fp32 operand split EXACTLY into three bf16 pieces, six piece products per product, fp32
+accumulation.  Unlike the lossy bf16 mode this one is held to the fp32 path's own bars:
+
+* the split itself, bit for bit, against a CPU restatement in torch (bf16 casts = round to nearest even), incl. zeros, subnormals,
+  inf, NaN and values that overflow bf16; split -> join returns the input bit for bit in the exact range;
+* the product kernel against float64 (its error must be of the native fp32 product's order) and against the 6-piece-product sum
+  written out in float64;
+* a whole BiLSTM(512) stack against the fp32 step-kernel path of this repository at fp32 rounding;
+* IMU_Net's forward against the reference golden G7 and the CPU oracle at test_imu_forward's tolerances (R, t within 2e-5);
+* one U+L training step at the benchmarked shape against the oracle at test_bench_shape's bars (joints <= 1e-3 cm).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, load_weights
+from oracle import nets as on
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from mmego_amd import hip
+    hip.lib()
+    return torch.device("cuda:0")
+
+
+def _split_cpu(x):
+    """The split of split3.hip in torch on the CPU: a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2); a1 inf / NaN -> no residual."""
+    a1 = x.to(torch.bfloat16)
+    f1 = a1.float()
+    fin = torch.isfinite(f1)
+    r1 = torch.where(fin, x - f1, torch.zeros_like(x))
+    a2 = r1.to(torch.bfloat16)
+    r2 = r1 - a2.float()
+    a3 = r2.to(torch.bfloat16)
+    return a1, a2, a3
+
+
+def _pieces_from_sfrag(y, rows, K):
+    """sfrag [Rp/32][K/16][3][64][8] -> three [rows, K] bf16 matrices (lane l = row l % 32, k half l / 32)."""
+    nrb, SK = y.shape[0], y.shape[1]
+    v = y.view(nrb, SK, 3, 2, 32, 8).permute(2, 0, 4, 1, 3, 5).reshape(3, nrb * 32, SK * 16)
+    return v[0, :rows, :K], v[1, :rows, :K], v[2, :rows, :K]
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int16) if t.dtype == torch.bfloat16 else t.contiguous().view(torch.int32)
+
+
+def test_split_and_join_are_exact(dev):
+    from mmego_amd import blocks
+    g = torch.Generator().manual_seed(1)
+    rows, K = 70, 64                                            # 70 rows: a ragged third row block (zero padded)
+    x = torch.randn(rows, K, generator=g) * torch.exp(torch.randn(rows, K, generator=g) * 8.0)       # ~ 1e-10 .. 1e10
+    special = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 3.3895e38, 3.4e38, -3.4e38, float("inf"), float("-inf"),
+                            float("nan"), 1.1754944e-38, -1.1754944e-38, 1e-39, -1e-39, 1.4e-45, 2.0 ** -100, 2.0 ** -109,
+                            2.0 ** -120, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 255.99998, 256.0, 0.1, 1.0 / 3.0, 65504.0,
+                            1.00390625, 1.0039062, 1.0078125 - 2.0 ** -23, 3.1415927, -2.7182817], dtype=torch.float32)
+    x.view(-1)[:special.numel()] = special
+    y = blocks.split3_cvt(x.to(dev))
+    got = [p.cpu() for p in _pieces_from_sfrag(y, rows, K)]
+    want = _split_cpu(x)
+    for gp, wp, name in zip(got, want, ("a1", "a2", "a3")):
+        gb, wb = _bits(gp), _bits(wp)
+        nan = torch.isnan(wp.float())
+        assert torch.equal(gb[~nan], wb[~nan]), name
+        assert torch.isnan(gp.float()[nan]).all(), name + ": NaN stays NaN"
+    # padding rows of the last row block are zero pieces
+    full = y.view(y.shape[0], y.shape[1], 3, 2, 32, 8)
+    assert (full[2, :, :, :, rows - 64:, :].float() == 0).all()
+    # split -> join: bit-exact wherever the three pieces can hold the value (|a| >= 2^-110, no overflow of bf16), and for +-0
+    back = blocks.split3_join(y, rows, K).cpu()
+    ax = x.abs()
+    exact = torch.isfinite(x) & (ax >= 2.0 ** -110) & (ax <= 3.38e38)
+    assert torch.equal(_bits(back)[exact], _bits(x)[exact])
+    assert (back[x == 0] == 0).all()                            # (-0 comes back as +0: (-0) + (+0) = +0; the pieces of -0 are -0, +0, +0)
+    assert torch.equal(back[torch.isinf(x)], x[torch.isinf(x)]) and torch.isnan(back[torch.isnan(x)]).all()
+    tiny = torch.isfinite(x) & (ax < 2.0 ** -110) & (x != 0)
+    assert tiny.any() and float((back[tiny].double() - x[tiny].double()).abs().max()) <= 2.0 ** -133
+    # the CPU statement of the same claim on a large random sample: a1 + a2 + a3 == a
+    z = torch.randn(1 << 20, generator=g) * torch.exp(torch.randn(1 << 20, generator=g) * 4.0)
+    z1, z2, z3 = _split_cpu(z)
+    assert torch.equal((z1.float() + z2.float()) + z3.float(), z)
+    # time-major form: rows b*T + t in, rows t*Bp + b out
+    Bn, T, Bp = 5, 3, 32
+    xt = torch.randn(Bn * T, 32, generator=g)
+    yt = blocks.split3_cvt(xt.to(dev), tm=(Bn, T, Bp))
+    bt = blocks.split3_join(yt, T * Bp, 32).cpu().view(T, Bp, 32)
+    assert torch.equal(bt[:, :Bn], xt.view(Bn, T, 32).permute(1, 0, 2)) and (bt[:, Bn:] == 0).all()
+
+
+@pytest.mark.parametrize("M,N,K,wm", [(256, 256, 512, 2), (512, 384, 1024, 4), (160, 128, 64, 2), (288, 160, 96, 4)])
+def test_split3_gemm_against_float64(dev, M, N, K, wm):
+    """C = A . W^T + bias: 6 piece products are fp32-accurate (error against float64 of the order of the native fp32 MFMA product's),
+    9 are at least as good; both agree with the piece-product sums written out in float64; tile-major and row-major outputs agree."""
+    from mmego_amd import blocks, hip, ops
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t() + bias.double()
+    scale = (A.double().abs() @ W.double().abs().t()).max().item()
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    Ap, Wp = blocks.split3_cvt(Ad), blocks.split3_cvt(Wd)
+    Mrb, Nrb = Ap.shape[0], Wp.shape[0]
+    native = torch.empty(M, N, device=dev)
+    ops.linear(Ad, Wd, bd, native)
+    e_native = (native.cpu().double() - ref).abs().max().item()
+    a1, a2, a3 = [p.double() for p in _split_cpu(A)]
+    w1, w2, w3 = [p.double() for p in _split_cpu(W)]
+    six = a1 @ w1.t() + a1 @ w2.t() + a2 @ w1.t() + a2 @ w2.t() + a1 @ w3.t() + a3 @ w1.t() + bias.double()
+    errs = {}
+    for nprod in (6, 9):
+        C = torch.zeros(M, N, device=dev)
+        Cf = torch.zeros(Mrb * Nrb * 1024, device=dev)
+        hip.call("split3_gemm", Ap, Wp, Cf, C, N, bd, Mrb, Nrb, K, M, nprod, wm)
+        torch.cuda.synchronize()
+        Cc = C.cpu().double()
+        errs[nprod] = (Cc - ref).abs().max().item()
+        # tile-major element (m, n): ((m/32) Nrb + n/32) 1024 + ((m%32)/8) 256 + (n%32 + 32 (((m%32)/4)&1)) 4 + m%4
+        t = Cf.cpu().view(Mrb, Nrb, 4, 2, 32, 4)                  # [rb][cb][q][half][col][r]: row = 8 q + 4 half + r
+        Ct = t.permute(0, 2, 3, 5, 1, 4).reshape(Mrb * 32, Nrb * 32)[:M, :N]
+        assert torch.equal(Ct, C.cpu()), "tile-major and row-major outputs hold the same values"
+        if nprod == 6:
+            assert (Cc - six).abs().max().item() < 3e-7 * scale, ((Cc - six).abs().max().item(), scale)
+    assert errs[6] < max(2.0 * e_native, 2e-7 * scale), (errs, e_native, scale)
+    assert errs[9] < max(2.0 * e_native, 2e-7 * scale), (errs, e_native, scale)
+
+
+@pytest.mark.parametrize("Bn,T,H", [(512, 20, 512), (100, 5, 512), (64, 3, 256)])
+def test_split3_bilstm_stack_against_the_fp32_step_kernels(dev, Bn, T, H):
+    """blocks.lstm_steps_forward_split3 (projection GEMMs + recurrent steps on split operands) against blocks.lstm_steps_forward (the
+    fp32 path: gemm_tile / lstm_step kernels) on the same two-layer BiLSTM: outputs of the last layer at fp32 rounding -- the bench
+    shape (512 rows x 20 samples, every workgroup full), a ragged row count and H = 256."""
+    from mmego_amd import blocks, ops
+    torch.manual_seed(17)
+    lstm = blocks.LstmParams(H, H, 2, dropout=0.0, bidirectional=True).to(dev)
+    x = torch.randn(Bn * T, H, device=dev).relu_()
+    ar32, ar3 = ops.Arena(dev), ops.Arena(dev)
+    with torch.no_grad():
+        want = blocks.lstm_steps_forward(ar32, "t", lstm, x, Bn, T).clone()
+        got6 = blocks.lstm_steps_forward_split3(ar3, "t", lstm, x, Bn, T, nprod=6).clone()
+        got9 = blocks.lstm_steps_forward_split3(ar3, "t", lstm, x, Bn, T, nprod=9).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(got6).all()
+    e6, e9 = (got6 - want).abs().max().item(), (got9 - want).abs().max().item()
+    assert e6 < 4e-6 and e9 < 4e-6, (e6, e9)                       # |h| <= 1: fp32 rounding through T steps and two layers
+    assert blocks.seq_xcd_errors() == 0
+
+
+def test_imu_forward_split3_at_the_fp32_bars(dev):
+    """tests/test_hip_parity.py::test_imu_forward with IMUNet.precision = "split3": the reference's golden G7 (seeded IMUNet(15, 9, 512,
+    2), R and t within 2e-5) and the CPU oracle at 64, 128 and 200 rnn_fast rows; switching back restores the fp32 path bit for bit."""
+    from mmego_amd import nets
+    g = golden("g7_imu.npz")
+    T_ = lambda a: torch.tensor(np.asarray(a))
+    imu = T_(g["imu"])
+    torch.manual_seed(703)
+    big = nets.IMUNet(15, 9, 512, 2, True, 0.1).to(dev).eval()
+    with torch.no_grad():
+        R32, t32 = big(imu.to(dev))
+    big.precision = "split3"
+    with torch.no_grad():
+        R, t = big(imu.to(dev))
+    assert torch.allclose(R.cpu(), T_(g["big.R"]), atol=2e-5) and torch.allclose(t.cpu(), T_(g["big.t"]), atol=2e-5)
+    assert float((R - R32).abs().max()) < 2e-5 and float((t - t32).abs().max()) < 2e-5
+    ob = on.IMUNet(15, 9, 512, 2, True, 0.1).eval()
+    ob.load_state_dict({k: v.cpu() for k, v in big.state_dict().items()})
+    torch.manual_seed(9)
+    worst = 0.0
+    for Bq, Tq in ((8, 8), (25, 8), (16, 8), (64, 8)):
+        imu3 = torch.randn(Bq, Tq, 20, 15)
+        with torch.no_grad():
+            Ro, to_ = ob(imu3)
+            Rh, th = big(imu3.to(dev))
+        worst = max(worst, float((Rh.cpu() - Ro).abs().max()), float((th.cpu() - to_).abs().max()))
+        assert torch.allclose(Rh.cpu(), Ro, atol=2e-5) and torch.allclose(th.cpu(), to_, atol=2e-5), (Bq, Tq, worst)
+    big.precision = "fp32"
+    with torch.no_grad():
+        R32b, t32b = big(imu.to(dev))
+    assert torch.equal(R32, R32b) and torch.equal(t32, t32b)
+    big.precision = "split2"
+    with pytest.raises(ValueError):
+        big(imu.to(dev))
+
+
+def test_ul_step_at_bench_shape_with_split3_imu(dev):
+    """tests/test_bench_shape.py::test_ul_step_at_bench_shape_against_oracle with both frozen IMU_Net forwards in the split3 mode: the
+    SAME bars (losses 2e-5 rel., joints 1e-3 cm, every gradient 2e-4 of the largest, post-Adam parameters)."""
+    import re
+
+    import bench
+    torch.set_num_threads(bench.host_cores())
+    r = bench.ul_step_parity(dev, use_graph=True, imu_precision="split3")
+    noise = re.compile(bench.NOISE_GRAD)
+    for tag in ("upper", "lower"):
+        assert r["loss_rel_err_" + tag] < 2e-5, (tag, r["loss_rel_err_" + tag])
+        assert r[tag + "_cm"] < 1e-3, (tag, r[tag + "_cm"])
+        scale = r["tensors"][tag]["scale"]
+        for k, (eg, dp) in r["tensors"][tag]["per_param"].items():
+            assert eg < 2e-4 * scale, (tag, k, eg, scale)
+            if not noise.search(k):
+                assert dp <= 6e-5 + 2e-6, (tag, k, dp)
+        assert r["param_frac_moved_" + tag] < 0.05, (tag, r["param_frac_moved_" + tag])
