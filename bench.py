@@ -294,7 +294,9 @@ def ul_step_parity(device, use_graph=True, imu_precision="fp32"):
         res["grad_rel_err_" + tag] = worst_g / scale
         res["param_max_abs_diff_" + tag] = worst_p
         res["param_frac_moved_" + tag] = n_bad / max(1, n_all)
-        res["tensors"][tag] = {"scale": scale, "per_param": per}
+        res["tensors"][tag] = {"scale": scale, "per_param": per,
+                               "grads": {k: (flat.grad(ph[k]).detach().cpu().clone(), None if po[k].grad is None else po[k].grad.detach().clone())
+                                         for k in po}}
     res["max_joint_distance_cm"] = max(res["upper_cm"], res["lower_cm"])
     return res
 
@@ -600,6 +602,75 @@ def config5_forward(device):
     return res
 
 
+def split3_figures(device, imu, imu_in, out, with_parity=True):
+    """The split3 mode's own block of the detail line: the IMU_Net forward in both modes (replayed graphs, one launch per timestep),
+    the two kernel families' rooflines from event pairs around an eager forward -- `achieved` = bf16 MFMA flops actually issued
+    (6 x the algorithmic product flops) / time against the 2.5 PF dense bf16 peak, `fp32_equivalent_tflops` = algorithmic flops / time
+    against nothing (the fp32 pipe's peak is 157.3) -- and the parity of one U+L step at the timed shape with the mode on, at the
+    fp32 path's bars (bench.ul_step_parity)."""
+    from mmego_amd import blocks
+    res = {"what": "IMUNet.precision = 'split3': rnn_fast's products (input projections + recurrent steps, 94 %% of the step's FLOPs) "
+                   "on exactly split bf16 operands a = a1 + a2 + a3, %d piece products each, fp32 accumulation (csrc/split3.hip); "
+                   "everything else is the fp32 path" % blocks.SPLIT3_NPROD, "nprod": blocks.SPLIT3_NPROD}
+    fwd_ms = {}
+    was = imu.precision
+    try:
+        for prec in ("fp32", "split3"):
+            imu.precision = prec
+
+            def fwd():
+                with torch.no_grad(), blocks.two_chains(False):
+                    return imu(imu_in)
+            fwd()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(4):
+                    fwd()
+            fwd_ms[prec] = _time_events(g.replay, 10, 3) / 4
+        res["imu_forward_ms"] = {"fp32_one_launch_per_timestep": fwd_ms["fp32"], "split3": fwd_ms["split3"]}
+        imu.precision = "split3"
+
+        def eager():
+            with torch.no_grad(), blocks.two_chains(False):
+                imu(imu_in)
+        eager()
+        torch.cuda.synchronize()
+        rec, iters = profile_kernels(eager, ("split3_gemm", "split3_step"))
+    finally:
+        imu.precision = was
+    npr = blocks.SPLIT3_NPROD
+    gem = [(ms_, 2.0 * 32 * a[6] * 32 * a[7] * a[8]) for ms_, a in rec["split3_gemm"]]            # args: A, W, Cf, C, ldc, bias, Mrb, Nrb, K
+    stp = [(ms_, 0.0 if a[3] else 2.0 * a[0] * a[1] * 4 * a[2] * a[2]) for ms_, a in rec["split3_step"]]   # args: ndir, Bn, H, first
+    fam = {}
+    for name, v in (("s3_gemm_kernel (rnn_fast input projections, both directions: 10240 x 4096 x {512, 1024})", gem),
+                    ("s3_step_kernel (rnn_fast recurrent steps, both directions per launch: 2 x 512 x 2048 x 512)", stp)):
+        if not v:
+            continue
+        tot_ms, tot_fl = sum(m for m, _ in v), sum(f for _, f in v)
+        fam[name] = {"avg_launch_us": tot_ms / len(v) * 1e3, "launches_per_forward": len(v) // iters, "ms_per_forward": tot_ms / iters,
+                     "achieved": npr * tot_fl / (tot_ms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "bound": "mfma",
+                     "frac": npr * tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                     "fp32_equivalent_tflops": tot_fl / (tot_ms * 1e-3) / 1e12}
+    res["kernels"] = fam
+    if fam:
+        k0 = max(fam, key=lambda k: fam[k]["ms_per_forward"])
+        res["roofline"] = dict(fam[k0], kernel=k0.split(" ")[0],
+                               achieved_is="%d x algorithmic product flops (the bf16 MFMAs issued) / event-pair time" % npr)
+    if with_parity:
+        par = ul_step_parity(device, use_graph=True, imu_precision="split3")
+        del par["tensors"]
+        res["parity"] = par
+    res["summary"] = {"ms_per_step": round(out["ms_per_step_split3"], 4), "ms_sequential": round(out["ms_per_step_split3_sequential"], 4),
+                      "imu_fwd_ms": [round(fwd_ms["fp32"], 4), round(fwd_ms["split3"], 4)]}
+    if "roofline" in res:
+        res["summary"]["roofline"] = {"kernel": res["roofline"]["kernel"], "frac_of_2.5PF": round(res["roofline"]["frac"], 3),
+                                      "fp32_equiv_TF": round(res["roofline"]["fp32_equivalent_tflops"], 1)}
+    if "parity" in res:
+        res["summary"]["parity_cm"] = [float("%.3g" % res["parity"]["upper_cm"]), float("%.3g" % res["parity"]["lower_cm"])]
+    return res
+
+
 def emit(out):
     """Everything measured goes out as ONE comment line (`# detail: {...}`, also written to gpurun_out/bench_detail.json when that
     directory can be written), THEN the contract's JSON line -- kept under 2 KB, so that a reader who only has the tail of stdout
@@ -678,6 +749,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-variant", action="store_true", help="skip the extra bf16-IMU figure")
     ap.add_argument("--no-pipelined-variant", action="store_true", help="skip the extra prefetch-pipelined figure")
+    ap.add_argument("--no-split3-variant", action="store_true", help="skip the split3 (fp32-accurate bf16-pipe IMU_Net) figures")
     ap.add_argument("--no-config-extras", action="store_true", help="skip the config-2 / config-5 forward figures")
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed U+L steps of the CPU baseline (~0.85 s each on 16 cores: ~10 s)")
     args = ap.parse_args()
@@ -853,6 +925,43 @@ def main():
         finally:
             imu.precision = imu_l.precision = "fp32"
 
+    # split3 variant (IMUNet.precision = "split3", csrc/split3.hip): the SAME fp32 step with rnn_fast's products of both frozen
+    # IMU_Net forwards on exactly split bf16 operands (six piece products, fp32 accumulation): fp32-accurate -- it passes the fp32
+    # path's parity bars (`split3.parity` below, tests/test_split3_gpu.py) -- but NOT `value` this round.
+    split3_extra = {}
+    if not args.no_split3_variant and world == 1:
+        try:
+            imu.precision = imu_l.precision = "split3"
+            su_3 = StageStep("upper", upper, imu, lr=3e-5, process_group=pg, use_graph=not args.no_graph)
+            sl_3 = StageStep("lower", lower, imu_l, upper_frozen=upper_frozen, lr=3e-5, process_group=pg, use_graph=not args.no_graph)
+            su_3.bind(x, imu_in, body, target)
+            sl_3.bind(x, imu_in, body, target)
+            both_3 = ConcurrentStages([su_3, sl_3], use_graph=not args.no_graph)
+            both_3.prepare()
+            for _ in range(20):
+                both_3.step()
+            sync()
+            t03 = time.perf_counter()
+            for _ in range(args.steps):
+                both_3.step()
+            sync()
+            dt_3 = time.perf_counter() - t03
+            su_3.step(); sl_3.step()
+            torch.cuda.synchronize()
+            ev3 = []
+            for i in range(24):
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record(); su_3.step(); ev[1].record(); sl_3.step(); ev[2].record()
+                ev3.append(ev)
+            torch.cuda.synchronize()
+            tu3 = sorted(ev[0].elapsed_time(ev[1]) for ev in ev3[4:])
+            tl3 = sorted(ev[1].elapsed_time(ev[2]) for ev in ev3[4:])
+            split3_extra = {"ms_per_step_split3": dt_3 / args.steps * 1e3, "frames_per_s_split3": world * B * T / (dt_3 / args.steps),
+                            "ms_per_step_split3_sequential": tu3[len(tu3) // 2] + tl3[len(tl3) // 2],
+                            "t_upper_ms_split3": tu3[len(tu3) // 2], "t_lower_ms_split3": tl3[len(tl3) // 2]}
+        finally:
+            imu.precision = imu_l.precision = "fp32"
+
     # Prefetch-pipelined variant (train_step.PipelinedStages): the frozen IMU_Net forwards of minibatch i+1 overlap the trainable
     # bodies of minibatch i; two DIFFERENT synthetic minibatches alternate and are copied into the static buffers inside the timed
     # loop.  Same work per step, bit-identical results (tests/test_hip_local.py); extra figure, never `value`.
@@ -907,6 +1016,7 @@ def main():
                "ms_per_step_sequential": t_u + t_l, "frames_per_s_sequential": world * B * T / ((t_u + t_l) * 1e-3),
                "t_upper_ms": t_u, "t_lower_ms": t_l, "loss_upper": loss_u, "loss_lower": loss_l}
         out.update(bf16_extra)
+        out.update(split3_extra)
         out.update(pipe_extra)
 
     # ---- roofline of the dominant kernel: eager replay with event pairs around every launch ----------------
@@ -1044,6 +1154,8 @@ def main():
             raise RuntimeError("mmego_lstm_seq_xcd: %d launch(es) ran out of their bounded spin -- results invalid" % out["persistent_launch_errors"])
         sys.stderr.write("[bench] gpu part done: %.1f frames/s; timing the CPU oracle on %d threads\n" % (out["value"], host_cores()))
         sys.stderr.flush()
+        if world == 1 and split3_extra:
+            out["split3"] = split3_figures(device, imu, imu_in, out, with_parity=not args.no_cpu_baseline)
         if world == 1 and not args.no_config_extras:
             out["config2"] = config2_forward(device)
             out["config5"] = config5_forward(device)

@@ -351,6 +351,12 @@ int mmego_split3_step(void* stream, int ndir, int Bn, int H, int first, const un
                       long hrb, const unsigned short* whh0, const unsigned short* whh1, const float* xpf, long mt0_0, long mt0_1,
                       float* hout0, float* hout1, long hos, unsigned short* hnext0, unsigned short* hnext1, long hnrb,
                       float* c0, float* c1, int nprod, int dbase);
+/* the same timestep on 16-unit workgroups (two per CU: single-direction launches of a layer's two directions run as two chains);
+ * W_hh rows -- and the projection's columns -- ordered [16-unit block][gate][16 units] */
+int mmego_split3_step16(void* stream, int ndir, int Bn, int H, int first, const unsigned short* hprev0, const unsigned short* hprev1,
+                        long hrb, const unsigned short* whh0, const unsigned short* whh1, const float* xpf, long mt0_0, long mt0_1,
+                        float* hout0, float* hout1, long hos, unsigned short* hnext0, unsigned short* hnext1, long hnrb,
+                        float* c0, float* c1, int nprod, int dbase);
 
 /* ---- anchor ("voxel") grouping of UpperNetwlocal (group.hip) -----------------------------------------
  * Per frame and per anchor of the 3x3x3 grid: indices (int64, exact, stable ties) of the 8 nearest points and

@@ -730,6 +730,13 @@ def lstm_steps_forward_bf16(ar, key, lstm, x, Bn, T):
 # ---------------------------------------------------------------------------------------------------
 SPLIT3_NPROD = int(os.environ.get("MMEGO_SPLIT3_NPROD", "6"))       # 6: dropped terms <= 2^-24 relative; 9: all piece products
 SPLIT3_WM = int(os.environ.get("MMEGO_SPLIT3_WM", "0"))             # projection tile rows / 64 (0: the library's choice)
+# 1: a layer's recurrence as two chains of single-direction launches on 16-unit workgroups (mmego_split3_step16).  OFF by default:
+# that kernel is correct and 4 % faster per forward when the forward runs alone, but a workgroup of it that shares a CU with
+# head_fk_loss_kernel<1> (geom.hip; the Lower stage's turning point, which runs beside the Upper stage's IMU_Net forward in
+# train_step.ConcurrentStages) changes that kernel's dy in a 16-lane group of a wave in ~5 % of the runs -- reproduced on every box
+# with two plain streams and no graph (scripts/coexec_head_fk.py; NOTES.md, r05).  The 32-unit kernel (444 registers, 128 KB of
+# LDS: alone on its CU) and the projection kernel have run beside it 200+ times without a difference.
+SPLIT3_TWO_CHAINS = os.environ.get("MMEGO_SPLIT3_TWO_CHAINS", "0") == "1"
 
 
 def split3_buffer(ar, name, Rp, K):
@@ -762,27 +769,33 @@ def split3_join(y, rows, K):
     return x[:rows]
 
 
-def lstm_split3_weights(lstm):
-    """Per layer: (W_ih of both directions stacked [8H, In] as pieces, b_ih + b_hh stacked [8H] fp32, W_hh pieces per direction with
-    rows reordered [hidden block][gate][32 units]).  Built once per weight version (dropped by weights_changed())."""
+def lstm_split3_weights(lstm, nu=32):
+    """Per layer: (W_ih of both directions stacked [8H, In] as pieces, b_ih + b_hh stacked [8H] fp32, W_hh pieces per direction,
+    b_ih stacked).  nu = 32: W_hh rows reordered [32-unit block][gate][32 units] (mmego_split3_step), the projection's columns in
+    PyTorch's order; nu = 16: W_hh rows AND the projection's columns (W_ih rows, biases) per direction reordered [16-unit block][gate]
+    [16 units] (mmego_split3_step16).  Built once per weight version and layout (dropped by weights_changed())."""
     cache = getattr(lstm, "_split3_cache", None)
-    if cache is not None:
-        return cache
+    if cache is None:
+        cache = lstm._split3_cache = {}
+    if nu in cache:
+        return cache[nu]
     H = lstm.hidden_size
+    blocked = lambda m: m.view(4, H // nu, nu, -1).permute(1, 0, 2, 3).reshape(4 * H, -1).contiguous()       # rows [block][gate][unit]
     layers = []
     with torch.no_grad():
         for l in range(lstm.num_layers):
-            w0 = lstm.w("weight_ih", l, 0)
-            dev = w0.device
-            wih = torch.cat((w0.detach(), lstm.w("weight_ih", l, 1).detach()), 0).contiguous()
-            bias = torch.empty((8 * H,), dtype=torch.float32, device=dev)
-            whh = []
+            wih, bias, bias_ih, whh = [], [], [], []
             for d in range(2):
-                hip.call("add", lstm.w("bias_ih", l, d).detach(), lstm.w("bias_hh", l, d).detach(), bias[4 * H * d:], 4 * H)
-                wr = lstm.w("weight_hh", l, d).detach().view(4, H // 32, 32, H).permute(1, 0, 2, 3).reshape(4 * H, H).contiguous()
-                whh.append(split3_cvt(wr))
-            layers.append((split3_cvt(wih), bias, whh[0], whh[1]))
-    lstm._split3_cache = layers
+                wi, bi, bh = lstm.w("weight_ih", l, d).detach(), lstm.w("bias_ih", l, d).detach(), lstm.w("bias_hh", l, d).detach()
+                if nu == 16:                                   # the projection's columns follow the step kernel's gate-pair blocks
+                    wi, bi, bh = blocked(wi), blocked(bi.view(-1, 1)).view(-1), blocked(bh.view(-1, 1)).view(-1)
+                wih.append(wi)
+                bias.append(bi + bh)
+                bias_ih.append(bi)
+                whh.append(split3_cvt(blocked(lstm.w("weight_hh", l, d).detach())))
+            layers.append((split3_cvt(torch.cat(wih, 0).contiguous()), torch.cat(bias).contiguous(), whh[0], whh[1],
+                           torch.cat(bias_ih).contiguous()))
+    cache[nu] = layers
     return layers
 
 
@@ -791,11 +804,15 @@ def lstm_steps_forward_split3(ar, key, lstm, x, Bn, T, xfrag=None, nprod=None):
     layer-0 operand already as pieces in time-major rows (split3_buffer(ar, key + ".x", T*Bp, In), e.g. written by
     mmego_split3_fc_relu) -> out [Bn*T, 2H] fp32 of the last layer, rows (b*T + t).  Projections tile-major fp32; a layer's h_t of
     all timesteps and both directions live as pieces in ONE buffer [T*Bp/32][2H/16][3] KB that is the next step's operand (a
-    window) and the next layer's projection operand (whole)."""
+    window) and the next layer's projection operand (whole).
+    The recurrence of a layer runs as TWO CHAINS of single-direction launches on 16-unit workgroups (mmego_split3_step16; two streams =
+    two parallel branches under graph capture) wherever blocks.lstm_recurrence would do so for the fp32 kernels (>= 128 rows, forking
+    allowed), else as one both-direction launch per timestep on 32-unit workgroups (mmego_split3_step)."""
     H = lstm.hidden_size
     In = lstm.input_size
     nprod = SPLIT3_NPROD if nprod is None else nprod
-    W = lstm_split3_weights(lstm)
+    chains = _LSTM_TWO_CHAINS and T > 1 and Bn >= 128 and ops.capture_can_fork() and SPLIT3_TWO_CHAINS
+    W = lstm_split3_weights(lstm, 16 if chains else 32)
     Bp = (Bn + 31) // 32 * 32
     cur = split3_buffer(ar, "%s.x" % key, T * Bp, In)
     if xfrag is None:
@@ -808,7 +825,7 @@ def lstm_steps_forward_split3(ar, key, lstm, x, Bn, T, xfrag=None, nprod=None):
     S2 = 2 * H // 16                                   # 16-k steps of a layer-output row
     hrb = S2 * 3                                       # 1-KB blocks between row blocks of the layer output
     for l in range(lstm.num_layers):
-        wih, bias, whh0, whh1 = W[l]
+        wih, bias, whh0, whh1, _ = W[l]
         last = l == lstm.num_layers - 1
         xpf = ar.get("%s.s3xpf%d" % (key, l), (T * Bp * 8 * H,))
         hip.call("split3_gemm", cur, wih, xpf, None, 0, bias, T * nrb, 8 * H // 32, K, 0, nprod, SPLIT3_WM)
@@ -820,11 +837,51 @@ def lstm_steps_forward_split3(ar, key, lstm, x, Bn, T, xfrag=None, nprod=None):
         out_p = out.data_ptr() if last else 0
         os_ = T * 2 * H
         win = lambda t, d: o_p + 2 * ((t * nrb * S2 + d * (H // 16)) * 3 * 512)       # bytes: 1 KB = 512 bf16
-        for s in range(T):
-            t0, t1 = s, T - 1 - s
-            hip.call("split3_step", 2, Bn, H, int(s == 0), win(t0 - 1, 0) if s > 0 else None, win(t1 + 1, 1) if s > 0 else None, hrb,
-                     whh0, whh1, xpf, t0 * nrb, t1 * nrb,
-                     out_p + 4 * (t0 * 2 * H) if last else None, out_p + 4 * (t1 * 2 * H + H) if last else None, os_,
-                     win(t0, 0), win(t1, 1), hrb, c[0], c[1], nprod, 0)
+        ho = lambda t, d: out_p + 4 * (t * 2 * H + d * H) if last else None
+        if chains:
+            cur_s = torch.cuda.current_stream()
+            side = _side_stream(cur_s)
+            # the product-less first timestep of both directions as one launch, in front of the fork
+            hip.call("split3_step16", 2, Bn, H, 1, None, None, hrb, whh0, whh1, xpf, 0, (T - 1) * nrb, ho(0, 0), ho(T - 1, 1), os_,
+                     win(0, 0), win(T - 1, 1), hrb, c[0], c[1], nprod, 0)
+            side.wait_stream(cur_s)
+            for s in range(1, T):
+                t0, t1 = s, T - 1 - s
+                hip.call("split3_step16", 1, Bn, H, 0, win(t0 - 1, 0), None, hrb, whh0, None, xpf, t0 * nrb, 0, ho(t0, 0), None, os_,
+                         win(t0, 0), None, hrb, c[0], None, nprod, 0)
+                with torch.cuda.stream(side):
+                    hip.call("split3_step16", 1, Bn, H, 0, win(t1 + 1, 1), None, hrb, whh1, None, xpf, t1 * nrb, 0, ho(t1, 1), None, os_,
+                             win(t1, 1), None, hrb, c[1], None, nprod, 1)
+            cur_s.wait_stream(side)
+        else:
+            for s in range(T):
+                t0, t1 = s, T - 1 - s
+                hip.call("split3_step", 2, Bn, H, int(s == 0), win(t0 - 1, 0) if s > 0 else None, win(t1 + 1, 1) if s > 0 else None, hrb,
+                         whh0, whh1, xpf, t0 * nrb, t1 * nrb, ho(t0, 0), ho(t1, 1), os_,
+                         win(t0, 0), win(t1, 1), hrb, c[0], c[1], nprod, 0)
         cur, K = O, 2 * H
+    return out
+
+
+def lstm_steps_forward_split3_proj(ar, key, lstm, x, Bn, T, nprod=None):
+    """lstm_steps_forward for a BiLSTM whose recurrence stays on the fp32 kernels (IMU_Net's rnn_slow: 64 rows, a persistent
+    weight-stationary launch per layer that is latency-bound, not matrix-bound) with only the INPUT PROJECTIONS on split operands:
+    per layer one conversion of the layer input to pieces, one split3 product with a row-major fp32 result (rows b*T + t, W_ih x +
+    b_ih of both directions), then blocks.lstm_recurrence as in the fp32 path."""
+    H = lstm.hidden_size
+    nprod = SPLIT3_NPROD if nprod is None else nprod
+    W = lstm_split3_weights(lstm)
+    rows = Bn * T
+    Rp = (rows + 31) // 32 * 32
+    cur = x
+    out = None
+    for l in range(lstm.num_layers):
+        K = cur.shape[1]
+        xs = split3_buffer(ar, "%s.s3in%d" % (key, l), Rp, K)
+        split3_cvt(cur, out=xs, Rp=Rp)
+        xp = ar.get("%s.xp%d" % (key, l), (rows, 8 * H))
+        hip.call("split3_gemm", xs, W[l][0], None, xp, xp.stride(0), W[l][4], Rp // 32, 8 * H // 32, K, rows, nprod, 0)
+        out = ar.get("%s.out%d" % (key, l), (rows, 2 * H))
+        lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T)
+        cur = out
     return out

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmmego_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"] + os.environ.get("MMEGO_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():

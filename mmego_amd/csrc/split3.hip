@@ -26,9 +26,17 @@
 //
 //   s3_cvt_kernel        fp32 row-major -> sfrag pieces (weights once; small activations)
 //   s3_fc_relu_kernel    IMU_Net's fc1 + ReLU (K <= 16) straight into the layer-0 operand
-//   s3_gemm_kernel       C = A . W^T + bias on 6 (9) piece products, (64 WM) x 128 tiles
+//   s3_gemm_kernel       C = A . W^T + bias on 6 (9) piece products, 64 / 128 / 256 x 128 tiles
 //   s3_step_kernel       one BiLSTM timestep, both directions: gates = xproj + h_{t-1} . W_hh^T, cell update, h_t as pieces
 #include "common.h"
+
+// Compile-time experiment mask (scripts/s3_experiments.py builds variant libraries with -DS3_EXP=<mask> to take a kernel's time apart
+// by elimination; 0 -- nothing of it exists -- in the product build).  1: piece products replaced by an XOR of the fragments,
+// 2: every chunk / step reads the FIRST one's addresses (operands cache-resident), 4: step kernel without reduction and cell update,
+// 8: GEMM without its C stores.
+#ifndef S3_EXP
+#define S3_EXP 0
+#endif
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 s3_bf16x8;
 typedef unsigned short s3_bf16_t;
@@ -151,9 +159,20 @@ __global__ __launch_bounds__(256) void s3_fc_relu_kernel(const float* __restrict
                                                           s3_u32x4* __restrict__ Y, int Bp, int relu) {
   extern __shared__ __attribute__((aligned(16))) float s3_wsm[];      // [H][16] + bias [H]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < H * 16; i += 256) {
-    const int n = i >> 4, k = i & 15;
-    s3_wsm[i] = k < Cin ? W[(long)n * Cin + k] : 0.f;
+  // (W padded to 16 columns; loads unconditional on clamped addresses, 16 in flight: under `k < Cin ? W[..] : 0` every load was a round
+  //  trip of its own -- 32 of them in a row were most of this kernel's 30 us)
+  for (int i0 = 0; i0 < H * 16; i0 += 16 * 256) {
+    float wv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = min(i0 + u * 256 + tid, H * 16 - 1);
+      wv[u] = W[(long)(i >> 4) * Cin + min(i & 15, Cin - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u * 256 + tid;
+      if (i < H * 16) s3_wsm[i] = (i & 15) < Cin ? wv[u] : 0.f;
+    }
   }
   for (int i = tid; i < H; i += 256) s3_wsm[H * 16 + i] = bias ? bias[i] : 0.f;
   const int t = blockIdx.y, rb = blockIdx.x;
@@ -211,6 +230,14 @@ extern "C" int mmego_split3_fc_relu(void* stream, const float* X, long ldx, cons
 // small terms first, a1 b1 last (the accumulator is fp32 either way; this order keeps the partial sums' rounding smallest)
 template <int NPROD>
 __device__ __forceinline__ f32x16 s3_mma(const s3_u32x4 (&a)[3], const s3_u32x4 (&b)[3], f32x16 acc) {
+  if (S3_EXP & 1) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const s3_u32x4 v = a[q] ^ b[q];
+      acc[q] = __uint_as_float(__float_as_uint(acc[q]) ^ v[0] ^ v[1] ^ v[2] ^ v[3]);
+    }
+    return acc;
+  }
 #define S3_MM(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s3_bf16x8, a[i]), __builtin_bit_cast(s3_bf16x8, b[j]), acc, 0, 0, 0)
   if (NPROD == 9) {
     S3_MM(2, 2);
@@ -241,16 +268,18 @@ struct S3GemmP {
   int tiles_m, tiles_n;
 };
 
-// Workgroup tile (64 WM) x 128, WM x 2 waves, wave tile 64 x 64 = 2 x 2 MFMA tiles.  32-k chunks (2 16-k steps): the chunk's blocks
-// of a row block are 6 consecutive KB in memory, copied as they lie into an LDS image [row block][step][piece][lane] through
-// registers (the next chunk's loads are in flight while this one is multiplied); per 16-k step a wave reads 12 fragments
-// (lane-linear ds_read_b128) for 24 (36) MFMAs.  LDS: (2 WM + 4) x 6 KB = 48 KB (WM = 2: two workgroups per CU) / 72 KB (WM = 4).
-template <int WM, int NPROD>
+// Workgroup tile (32 MI WM) x 128, WM x 2 waves, wave tile (32 MI) x 64 = MI x 2 MFMA tiles.  32-k chunks (2 16-k steps): the chunk's
+// blocks of a row block are 6 consecutive KB in memory, copied as they lie into an LDS image [row block][step][piece][lane] through
+// registers (the next chunk's loads are in flight while this one is multiplied); per 16-k step a wave reads 3 (MI + 2) fragments
+// (lane-linear ds_read_b128) for 6 MI 2 (9 MI 2) MFMAs.  LDS: (WM MI + 4) x 6 KB = 48 KB (WM = MI = 2: 128 x 128 tiles, two or three
+// workgroups per CU) / 72 KB (WM = 4: 256 x 128) / 36 KB (WM = 2, MI = 1: 64 x 128, for products with few rows).
+template <int WM, int MI, int NPROD>
 __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
   constexpr int NT = WM * 128;                 // threads
-  constexpr int RBA = WM * 2;                  // A row blocks per tile
-  constexpr int NLA = RBA * 384 / NT;          // 16-byte loads per thread and chunk: A (6), W (6 / 3)
+  constexpr int RBA = WM * MI;                 // A row blocks per tile
+  constexpr int NLA = RBA * 384 / NT;          // 16-byte loads per thread and chunk
   constexpr int NLW = 4 * 384 / NT;
+  static_assert(RBA * 384 % NT == 0 && 4 * 384 % NT == 0, "tile images must divide over the threads");
   __shared__ s3_u32x4 As[RBA * 384];
   __shared__ s3_u32x4 Bs[4 * 384];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -284,9 +313,9 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
 #pragma unroll
   for (int j = 0; j < NLW; ++j) rw[j] = p.W[gw[j]];
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -301,7 +330,7 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
     for (int j = 0; j < NLW; ++j) Bs[j * NT + tid] = rw[j];
     __syncthreads();
     {
-      const int cn = min(c + 1, nchunk - 1) * 384;      // (unconditional prefetch; past the end: the last chunk again)
+      const int cn = (S3_EXP & 2) ? 0 : min(c + 1, nchunk - 1) * 384;      // (unconditional prefetch; past the end: the last chunk again)
 #pragma unroll
       for (int j = 0; j < NLA; ++j) ra[j] = p.A[ga[j] + cn];
 #pragma unroll
@@ -309,48 +338,54 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
     }
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
-      s3_u32x4 a[2][3], b[2][3];
+      s3_u32x4 a[MI][3], b[2][3];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a[mi][q] = As[(((wm * 2 + mi) * 2 + kc) * 3 + q) * 64 + lane];
+        for (int q = 0; q < 3; ++q) a[mi][q] = As[(((wm * MI + mi) * 2 + kc) * 3 + q) * 64 + lane];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int q = 0; q < 3; ++q) b[ni][q] = Bs[(((wn * 2 + ni) * 2 + kc) * 3 + q) * 64 + lane];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = s3_mma<NPROD>(a[mi], b[ni], acc[mi][ni]);
     }
   }
-  // accumulator layout of the 32 x 32 MFMA: register i of lane l is (row = 8 (i / 4) + 4 (l / 32) + i % 4, col = l % 32)
+  // accumulator layout of the 32 x 32 MFMA: register i of lane l is (row = 8 (i / 4) + 4 (l / 32) + i % 4, col = l % 32).
+  // The bias goes into the accumulators in place and the stores read them where they are: a temporary per store would be one register
+  // rewritten 16 times, each rewrite waiting for the store before it.
   const int fr = lane & 31;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int cb = min(rbW0 + wn * 2 + ni, p.Nrb - 1);
+    const float bv = p.bias ? p.bias[cb * 32 + fr] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] += bv;
+  }
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int cb = rbW0 + wn * 2 + ni;                 // column block
     if (cb >= p.Nrb) continue;
-    const float bv = p.bias ? p.bias[cb * 32 + fr] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int rbm = rbA0 + wm * 2 + mi;
+    for (int mi = 0; mi < MI; ++mi) {
+      const int rbm = rbA0 + wm * MI + mi;
       if (rbm >= p.Mrb) continue;
-      if (p.Cf) {                                        // an accumulator tile IS a tile of the tile-major layout: four 1-KB stores
+      if (p.Cf && !((S3_EXP & 8) && acc[mi][ni][0] != 12345.f)) {     // an accumulator tile IS a tile of the tile-major layout: four 1-KB stores
         float* t = p.Cf + ((long)rbm * p.Nrb + cb) * 1024 + lane * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][4 * q + r] + bv;
-          *reinterpret_cast<f32x4*>(t + q * 256) = v;
-        }
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(t + q * 256) = (f32x4){acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
       }
       if (p.C) {
+        float* cp = p.C + (long)(rbm * 32 + 4 * (lane >> 5)) * p.ldc + cb * 32 + fr;
+        const int rows_left = p.M - (rbm * 32 + 4 * (lane >> 5));         // rows 8 (i / 4) + i % 4 below this lane's first
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = rbm * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
-          if (row < p.M) p.C[(long)row * p.ldc + cb * 32 + fr] = acc[mi][ni][i] + bv;
-        }
+        for (int i = 0; i < 16; ++i)
+          if (8 * (i >> 2) + (i & 3) < rows_left) cp[(long)(8 * (i >> 2) + (i & 3)) * p.ldc] = acc[mi][ni][i];
       }
     }
   }
@@ -358,15 +393,19 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
 
 // C[m][n] = sum_k A[m][k] W[n][k] + bias[n] on 6 (nprod = 6) or 9 piece products; A sfrag [Mrb][K / 16][3] KB, W sfrag [Nrb][K / 16][3] KB
 // (mmego_split3_cvt).  Cf: tile-major fp32 [Mrb][Nrb][1024] and / or C: row-major (rows < M stored, row stride ldc).  K % 32 == 0.
-// wm = 2: 128 x 128 tiles on 256-thread workgroups, wm = 4: 256 x 128 tiles on 512-thread workgroups (0: the default choice).
+// wm: tile rows / 64 -- 1: 64 x 128 tiles (256-thread workgroups of four 32 x 64 wave tiles: products with few rows), 2: 128 x 128
+// tiles (256 threads), 4: 256 x 128 tiles (512 threads); 0: the library's choice.
 extern "C" int mmego_split3_gemm(void* stream, const unsigned short* A, const unsigned short* W, float* Cf, float* C, long ldc,
                                  const float* bias, int Mrb, int Nrb, int K, int M, int nprod, int wm) {
   MMEGO_REQUIRE(A && W && (Cf || C) && Mrb > 0 && Nrb > 0 && K > 0 && K % 32 == 0 && (nprod == 6 || nprod == 9));
   MMEGO_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (!Cf || (((uintptr_t)Cf) & 15) == 0));
   MMEGO_REQUIRE(!C || (M > 0 && M <= Mrb * 32 && ldc >= Nrb * 32));
   MMEGO_REQUIRE((long)Mrb * (K / 16) * 192 < (1L << 31) && (long)Nrb * (K / 16) * 192 < (1L << 31));
-  if (wm == 0) wm = Mrb >= 8 * 256 / 32 ? 4 : 2;
-  MMEGO_REQUIRE(wm == 2 || wm == 4);
+  if (wm == 0) {
+    const long t128 = (long)cdiv(Mrb, 4) * cdiv(Nrb, 4);        // 128 x 128 tiles
+    wm = t128 < 256 ? 1 : (Mrb >= 64 ? 4 : 2);                   // fewer tiles than CUs: 64-row tiles
+  }
+  MMEGO_REQUIRE(wm == 1 || wm == 2 || wm == 4);
   S3GemmP p;
   p.A = reinterpret_cast<const s3_u32x4*>(A); p.W = reinterpret_cast<const s3_u32x4*>(W);
   p.Cf = Cf; p.C = C; p.ldc = ldc; p.bias = bias; p.Mrb = Mrb; p.Nrb = Nrb; p.SK = K / 16; p.M = M;
@@ -374,10 +413,16 @@ extern "C" int mmego_split3_gemm(void* stream, const unsigned short* A, const un
   const long tiles = (long)p.tiles_m * p.tiles_n;
   MMEGO_REQUIRE(tiles < (1L << 30));
   hipStream_t st = (hipStream_t)stream;
-  if (wm == 2 && nprod == 6) s3_gemm_kernel<2, 6><<<(int)tiles, 256, 0, st>>>(p);
-  else if (wm == 2) s3_gemm_kernel<2, 9><<<(int)tiles, 256, 0, st>>>(p);
-  else if (nprod == 6) s3_gemm_kernel<4, 6><<<(int)tiles, 512, 0, st>>>(p);
-  else s3_gemm_kernel<4, 9><<<(int)tiles, 512, 0, st>>>(p);
+  if (wm == 1) {
+    if (nprod == 6) s3_gemm_kernel<2, 1, 6><<<(int)tiles, 256, 0, st>>>(p);
+    else s3_gemm_kernel<2, 1, 9><<<(int)tiles, 256, 0, st>>>(p);
+  } else if (wm == 2) {
+    if (nprod == 6) s3_gemm_kernel<2, 2, 6><<<(int)tiles, 256, 0, st>>>(p);
+    else s3_gemm_kernel<2, 2, 9><<<(int)tiles, 256, 0, st>>>(p);
+  } else {
+    if (nprod == 6) s3_gemm_kernel<4, 2, 6><<<(int)tiles, 512, 0, st>>>(p);
+    else s3_gemm_kernel<4, 2, 9><<<(int)tiles, 512, 0, st>>>(p);
+  }
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
@@ -398,8 +443,8 @@ __device__ __forceinline__ float s3_tanh(float x) { return 1.0f - 2.0f * __built
 
 // The small-batch step of the bf16 mode (lstm_step_bf16_direct_kernel, bf16.hip) on piece products.  Workgroup = 64 rows x 32 hidden
 // units x 4 gates of one direction (Bn = H = 512: 8 x 16 x 2 = 256 workgroups, one per CU); wave w takes k quarter w of the whole tile,
-// so no fragment is fetched twice, and streams its SQ 16-k steps through a ring of three fragment sets (18 coalesced 1-KB reads per
-// step, requested two steps = 96 MFMAs ahead); the four partial tiles meet in LDS (fixed order) and all four waves run the cell
+// so no fragment is fetched twice, and streams its SQ 16-k steps through a ring of four fragment sets (18 coalesced 1-KB reads per
+// step, requested three steps = 144 MFMAs ahead: with two, every step still waited for memory -- product and fetch added up); the four partial tiles meet in LDS (fixed order) and all four waves run the cell
 // update of 16 rows each.  h_t leaves as 12 whole 1-KB blocks per workgroup (pieces put together in LDS), and optionally as fp32 rows.
 template <int SQ, int NPROD, bool FIRST>
 __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
@@ -415,6 +460,8 @@ __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
   const int own_r0 = own_mi * 32 + 16 * (w & 1);       // accumulator registers own_i0 .. own_i0 + 8 of row block own_mi
   const int last_rb = (p.Bn - 1) >> 5;
   const int hb = H >> 5;
+  const int s3_stamp_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  MMEGO_STAMP_AT(s3_stamp_id, 0, tid == 0);
 
   // operand pointers and the first two steps' fragment requests go out BEFORE the cell update's own operands (xproj tile, c_{t-1}):
   // one memory round trip for all of them (asked for first, the compiler parked the xproj values in AGPRs behind a vmcnt(0) and
@@ -431,35 +478,36 @@ __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
   for (int mi = 0; mi < 2; ++mi) ap[mi] = p.hprev[d] + ((long)min((r0 >> 5) + mi, last_rb) * p.hrb + (long)w * SQ * 3) * 64 + lane;
   const s3_u32x4* wp = p.whh[d] + ((long)jb * 4 * S + w * SQ) * 192 + lane;
   const int gstride = S * 192;                        // between the gates' row blocks
-  s3_u32x4 a[3][2][3], b[3][4][3];
+  constexpr int NR = SQ >= 4 ? 4 : SQ;                // ring of fragment sets: requests run NR - 1 steps (48 (NR - 1) MFMAs) ahead
+  s3_u32x4 a[NR][2][3], b[NR][4][3];
 #define S3_LOAD(slot, s)                                                                    \
     {                                                                                       \
-      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                      \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) a[slot][mi][q] = ap[mi][((s) * 3 + q) * 64];      \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) a[slot][0][q] = ap[0][((S3_EXP & 2 ? 0 : (s)) * 3 + q) * 64];        \
       _Pragma("unroll") for (int n = 0; n < 4; ++n)                                         \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) b[slot][n][q] = wp[n * gstride + ((s) * 3 + q) * 64]; \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) b[slot][n][q] = wp[n * gstride + ((S3_EXP & 2 ? 0 : (s)) * 3 + q) * 64]; \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) a[slot][1][q] = ap[1][((S3_EXP & 2 ? 0 : (s)) * 3 + q) * 64];        \
     }
   if (!FIRST) {                                         // (compile time: the step loop below is straight-line code)
-    S3_LOAD(0, 0)
-    S3_LOAD(1, 1 < SQ ? 1 : 0)
+#pragma unroll
+    for (int s = 0; s < NR - 1; ++s) S3_LOAD(s, s)
   }
   __builtin_amdgcn_sched_barrier(0);
+  // the cell update's own operands (this wave's part of the projection tile, c_{t-1}): requested two steps before the end of the
+  // product loop, not in front of it (16 more requests on top of the ring's 54 would run into the 63 a wave may have outstanding)
   f32x4 xp[4][2];
   float cprev[8];
-  {
-    const int rb = min((r0 >> 5) + own_mi, last_rb);
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq)
-        xp[n][qq] = (reinterpret_cast<const f32x4*>(p.xpf + ((p.mt0[d] + rb) * (long)(8 * hb) + ((p.dbase + d) * 4 + n) * hb + jb) * 1024) + lane)[(2 * (w & 1) + qq) * 64];
+#define S3_CELL_OPERANDS()                                                                                                       \
+  {                                                                                                                              \
+    const int rbx = min((r0 >> 5) + own_mi, last_rb);                                                                            \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                                \
+      _Pragma("unroll") for (int qq = 0; qq < 2; ++qq)                                                                           \
+        xp[n][qq] = (reinterpret_cast<const f32x4*>(p.xpf + ((p.mt0[d] + rbx) * (long)(8 * hb) + ((p.dbase + d) * 4 + n) * hb + jb) * 1024) + lane)[(2 * (w & 1) + qq) * 64]; \
+    _Pragma("unroll") for (int ii = 0; ii < 8; ++ii) {                                                                           \
+      const int row = min(r0 + own_r0 + 8 * (ii >> 2) + 4 * fh + (ii & 3), p.Bn - 1);                                            \
+      cprev[ii] = FIRST ? 0.f : p.c[d][(long)row * H + j];                                                                       \
+    }                                                                                                                            \
   }
-#pragma unroll
-  for (int ii = 0; ii < 8; ++ii) {                      // (FIRST: dead code, c_0 = 0)
-    const int row = min(r0 + own_r0 + 8 * (ii >> 2) + 4 * fh + (ii & 3), p.Bn - 1);
-    cprev[ii] = p.c[d][(long)row * H + j];
-  }
-  __builtin_amdgcn_sched_barrier(0);
+  if (FIRST) S3_CELL_OPERANDS()
   float pre[4][8];
 #pragma unroll
   for (int n = 0; n < 4; ++n)
@@ -467,35 +515,56 @@ __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
     for (int ii = 0; ii < 8; ++ii) pre[n][ii] = 0.f;
 
   if (!FIRST) {
+    MMEGO_STAMP_AT(s3_stamp_id, 1, tid == 0);
 #pragma unroll
     for (int s = 0; s < SQ; ++s) {
-      if (s + 2 < SQ) {
-        if ((s + 2) % 3 == 0) S3_LOAD(0, s + 2)
-        else if ((s + 2) % 3 == 1) S3_LOAD(1, s + 2)
-        else S3_LOAD(2, s + 2)
+      // The requests of step s + NR - 1 go out BETWEEN this step's MFMA groups, three per group: a wave is alone on its SIMD, so
+      // while it issues a burst of 18 loads (all four waves at once, the CU's load path takes them at ~1 KB per 16 cycles) it issues
+      // no MFMA -- with the burst in front of the step, product time and fetch time ADDED UP (timing by elimination,
+      // scripts/s3_experiments.py: 19.5 us per timestep, 15.4 with cache-resident operands, 14.7 without the MFMAs, 11.5 with neither).
+      constexpr bool more = true;
+      const int sn = s + NR - 1, slot = (s + NR - 1) % NR;
+      if (s == (SQ >= 2 ? SQ - 2 : 0)) S3_CELL_OPERANDS()
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int mi = g >> 2, n = g & 3;
+        acc[mi][n] = s3_mma<NPROD>(a[s % NR][mi], b[s % NR][n], acc[mi][n]);
+        if (more && sn < SQ && g < 6) {
+          // order of need in step sn: a[0], b[0..3], a[1]
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            if (g == 0) a[slot][0][q] = ap[0][((S3_EXP & 2 ? 0 : sn) * 3 + q) * 64];
+            else if (g == 5) a[slot][1][q] = ap[1][((S3_EXP & 2 ? 0 : sn) * 3 + q) * 64];
+            else b[slot][g - 1][q] = wp[(g - 1) * gstride + ((S3_EXP & 2 ? 0 : sn) * 3 + q) * 64];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);                // (requests of step s + 2 out before the MFMAs of step s)
+    }
+#undef S3_LOAD
+#undef S3_CELL_OPERANDS
+    MMEGO_STAMP_AT(s3_stamp_id, 2, tid == 0);
+    if (S3_EXP & 4) {                                   // (experiment: no reduction -- every wave keeps its own partial sums)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) pre[n][ii] = acc[own_mi][n][own_i0 + ii] + acc[1 - own_mi][n][own_i0 + ii];
+    } else {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[mi][n] = s3_mma<NPROD>(a[s % 3][mi], b[s % 3][n], acc[mi][n]);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s3_red[(((w * 2 + mi) * 4 + n) * 16 + i) * 64 + lane] = acc[mi][n][i];
+      __syncthreads();
+#pragma unroll
+      for (int src = 0; src < 4; ++src)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int ii = 0; ii < 8; ++ii) pre[n][ii] += s3_red[(((src * 2 + own_mi) * 4 + n) * 16 + own_i0 + ii) * 64 + lane];
+      __syncthreads();                                  // (the reduction buffer becomes the piece image below)
     }
-#undef S3_LOAD
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s3_red[(((w * 2 + mi) * 4 + n) * 16 + i) * 64 + lane] = acc[mi][n][i];
-    __syncthreads();
-#pragma unroll
-    for (int src = 0; src < 4; ++src)
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int ii = 0; ii < 8; ++ii) pre[n][ii] += s3_red[(((src * 2 + own_mi) * 4 + n) * 16 + own_i0 + ii) * 64 + lane];
-    __syncthreads();                                    // (the reduction buffer becomes the piece image below)
   }
   // cell update of this lane's 8 (row, unit j) elements; PyTorch gate order i, f, g, o
   s3_bf16_t* img = reinterpret_cast<s3_bf16_t*>(s3_red);            // [2 rb][2 s][3 p][64 lanes][8] bf16 = 12 KB
@@ -532,6 +601,173 @@ __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
       const int rbl = blk / 6, rest = blk - rbl * 6;               // rest = s_l * 3 + p
       const int rb = (r0 >> 5) + rbl;
       if (rb <= last_rb) p.hnext[d][((long)rb * p.hnrb + (long)(j0 >> 4) * 3 + rest) * 64 + ln] = im4[i];
+    }
+  }
+  MMEGO_STAMP_AT(s3_stamp_id, 3, tid == 0);
+}
+
+// The same step on HALF the hidden units per workgroup (64 rows x 16 units x 4 gates: 64 x 64 outputs), for the two-chain form of a
+// layer's recurrence (blocks.lstm_steps_forward_split3: one launch per direction and timestep on two streams).  In-kernel stamps of the
+// 32-unit kernel (scripts/s3_probe.hip, 2.02 GHz): prologue 5.6 k cycles (first fragments from cold L2s), product loop 15.6 k (12.3 k of
+// MFMA issue), reduction + cell update + stores 7.6 k, ~2.7 us between launches -- more than half of a step is NOT the product loop,
+// and with 128 KB of LDS and 444 registers per lane a CU holds one such workgroup, so nothing runs beside those phases.  This kernel
+// needs half of everything (64 accumulators, a three-deep ring of 12 fragments, 64 KB of LDS: two workgroups per CU), and the two
+// directions' launches -- independent dependency chains -- put one workgroup of each on a CU: one direction's launch gap, prologue
+// and cell update run beside the other's product loop.  (Both directions in one 512-workgroup launch would run the pairs in lockstep.)
+// NOT THE DEFAULT (blocks.SPLIT3_TWO_CHAINS): correct by itself and against the fp32 kernels, but while a workgroup of it shares a CU with
+// head_fk_loss_kernel<1> of geom.hip that kernel's dy comes out different in one 16-lane group in ~5 % of the runs (scripts/
+// coexec_head_fk.py: two plain streams; not with the MFMAs compiled out, not with the 32-unit kernel, the projection kernel or the
+// fp32 step kernels beside it; LDS contents, SGPR / VGPR allocation padding, stray stores and ds_bpermute were ruled out one by one).
+// W_hh rows [16-unit block][gate][16 units]: a 32-column block holds a gate PAIR -- block 0: i | f, block 1: g | o -- of 16 units, so
+// the four gates of a (row, unit) sit in lanes l and l ^ 16 of the two accumulator tiles; one exchange (the pre-activations of the
+// rows the partner finishes) and every lane updates 4 cells.  The projection's columns are permuted the same way (weight
+// preparation), so its tiles load straight into the accumulator layout as before.
+template <int SQ, int NPROD, bool FIRST>
+__global__ __launch_bounds__(256, 2) void s3_step16_kernel(S3StepP p) {
+  extern __shared__ __attribute__((aligned(16))) float s3_red16[];    // [4 waves][2 mi][2 n][16 i][64 lanes] = 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int d = blockIdx.z, H = p.H, S = H >> 4;
+  const int nrb = gridDim.y, nb = gridDim.x * nrb;
+  const int id = s3_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, nb);
+  const int jb = id / nrb, j0 = jb * 16, r0 = (id % nrb) * 64;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int ju = fr & 15, gsel = fr >> 4;              // unit inside the block; which gate of a pair this lane's column is
+  const int own_mi = w >> 1, own_i0 = 8 * (w & 1);
+  const int own_r0 = own_mi * 32 + 16 * (w & 1);
+  const int last_rb = (p.Bn - 1) >> 5;
+  const int hb = H >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][n][i] = 0.f;
+  const s3_u32x4* ap[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) ap[mi] = p.hprev[d] + ((long)min((r0 >> 5) + mi, last_rb) * p.hrb + (long)w * SQ * 3) * 64 + lane;
+  const s3_u32x4* wp = p.whh[d] + ((long)jb * 2 * S + w * SQ) * 192 + lane;
+  const int gstride = S * 192;
+  constexpr int NR = SQ >= 3 ? 3 : SQ;
+  s3_u32x4 a[NR][2][3], b[NR][2][3];
+#define S3_LOAD16(slot, s)                                                                  \
+    {                                                                                       \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) a[slot][0][q] = ap[0][((s) * 3 + q) * 64];              \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n)                                         \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) b[slot][n][q] = wp[n * gstride + ((s) * 3 + q) * 64]; \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) a[slot][1][q] = ap[1][((s) * 3 + q) * 64];              \
+    }
+  if (!FIRST) {
+#pragma unroll
+    for (int s = 0; s < NR - 1; ++s) S3_LOAD16(s, s)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 xp[2][2];
+  float cprev[4];
+#define S3_CELL_OPERANDS16()                                                                                                     \
+  {                                                                                                                              \
+    const int rbx = min((r0 >> 5) + own_mi, last_rb);                                                                            \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                                \
+      _Pragma("unroll") for (int qq = 0; qq < 2; ++qq)                                                                           \
+        xp[n][qq] = (reinterpret_cast<const f32x4*>(p.xpf + ((p.mt0[d] + rbx) * (long)(8 * hb) + (p.dbase + d) * 4 * hb + jb * 2 + n) * 1024) + lane)[(2 * (w & 1) + qq) * 64]; \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                              \
+      const int row = min(r0 + own_r0 + 8 * gsel + 4 * fh + r, p.Bn - 1);                                                        \
+      cprev[r] = FIRST ? 0.f : p.c[d][(long)row * H + j0 + ju];                                                                  \
+    }                                                                                                                            \
+  }
+  if (FIRST) S3_CELL_OPERANDS16()
+  float pre[2][8];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) pre[n][ii] = 0.f;
+
+  if (!FIRST) {
+#pragma unroll
+    for (int s = 0; s < SQ; ++s) {
+      const int sn = s + NR - 1, slot = (s + NR - 1) % NR;
+      if (s == (SQ >= 2 ? SQ - 2 : 0)) S3_CELL_OPERANDS16()
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                     // (three requests of step s + NR - 1 behind each MFMA group, in the order of need)
+        const int mi = g >> 1, n = g & 1;
+        acc[mi][n] = s3_mma<NPROD>(a[s % NR][mi], b[s % NR][n], acc[mi][n]);
+        if (sn < SQ) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            if (g == 0) a[slot][0][q] = ap[0][(sn * 3 + q) * 64];
+            else if (g == 3) a[slot][1][q] = ap[1][(sn * 3 + q) * 64];
+            else b[slot][g - 1][q] = wp[(g - 1) * gstride + (sn * 3 + q) * 64];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#undef S3_LOAD16
+#undef S3_CELL_OPERANDS16
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s3_red16[(((w * 2 + mi) * 2 + n) * 16 + i) * 64 + lane] = acc[mi][n][i];
+    __syncthreads();
+#pragma unroll
+    for (int src = 0; src < 4; ++src)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) pre[n][ii] += s3_red16[(((src * 2 + own_mi) * 2 + n) * 16 + own_i0 + ii) * 64 + lane];
+    __syncthreads();                                    // (the reduction buffer becomes the piece image below)
+  }
+  // gate pre-activations of this lane's column (gate 2 n + gsel of unit ju) for its wave's 16 rows; this lane finishes rows ii = 4 gsel + r
+  // and needs the partner column's (lane ^ 16) two gates for them: it hands over its own values for the rows the partner finishes
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) pre[n][ii] += xp[n][ii >> 2][ii & 3];
+  float mine[2][4], theirs[2][4];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      mine[n][r] = gsel ? pre[n][4 + r] : pre[n][r];
+      theirs[n][r] = __shfl_xor(gsel ? pre[n][r] : pre[n][4 + r], 16, 64);
+    }
+  s3_bf16_t* img = reinterpret_cast<s3_bf16_t*>(s3_red16);          // [2 rb][3 p][64 lanes][8] bf16 = 6 KB
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rl = own_r0 + 8 * gsel + 4 * fh + r;
+    const int row = r0 + rl;
+    // PyTorch gate order i, f, g, o = columns (n, gsel) = (0, 0), (0, 1), (1, 0), (1, 1)
+    const float gi = s3_sigmoid(gsel ? theirs[0][r] : mine[0][r]);
+    const float gf = s3_sigmoid(gsel ? mine[0][r] : theirs[0][r]);
+    const float gg = s3_tanh(gsel ? theirs[1][r] : mine[1][r]);
+    const float go = s3_sigmoid(gsel ? mine[1][r] : theirs[1][r]);
+    const float cn = gf * (FIRST ? 0.f : cprev[r]) + gi * gg;
+    const float hn = row < p.Bn ? go * s3_tanh(cn) : 0.f;
+    if (row < p.Bn) {
+      p.c[d][(long)row * H + j0 + ju] = cn;
+      if (p.hout[d]) p.hout[d][(long)row * p.hos + j0 + ju] = hn;
+    }
+    unsigned q1, q2, q3;
+    s3_split(hn, q1, q2, q3);
+    const int o = (((rl >> 5) * 3) * 64 + (rl & 31) + 32 * ((ju >> 3) & 1)) * 8 + (ju & 7);
+    img[o] = (s3_bf16_t)q1;
+    img[o + 512] = (s3_bf16_t)q2;
+    img[o + 1024] = (s3_bf16_t)q3;
+  }
+  __syncthreads();
+  {
+    // 384 16-byte pieces: image index i = (rb_l * 3 + p) * 64 + lane
+    const s3_u32x4* im4 = reinterpret_cast<const s3_u32x4*>(img);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = u * 256 + tid;
+      const int blk = i >> 6, ln = i & 63;
+      const int rbl = blk / 3, pc = blk - rbl * 3;
+      const int rb = (r0 >> 5) + rbl;
+      if (i < 384 && rb <= last_rb) p.hnext[d][((long)rb * p.hnrb + (long)jb * 3 + pc) * 64 + ln] = im4[i];
     }
   }
 }
@@ -573,6 +809,60 @@ extern "C" int mmego_split3_step(void* stream, int ndir, int Bn, int H, int firs
       attr_set = true;                                                                                                      \
     }                                                                                                                       \
     s3_step_kernel<SQ_, NP_, F_><<<grid, 256, lds, st>>>(p);                                                               \
+  }
+#define S3_STEP_NP(SQ_, F_)                 \
+  {                                         \
+    if (nprod == 6) S3_STEP_LAUNCH(SQ_, 6, F_) \
+    else S3_STEP_LAUNCH(SQ_, 9, F_)         \
+  }
+#define S3_STEP_F(SQ_)              \
+  {                                 \
+    if (first) S3_STEP_NP(SQ_, true) \
+    else S3_STEP_NP(SQ_, false)     \
+  }
+  if (sq == 8) S3_STEP_F(8)
+  else if (sq == 4) S3_STEP_F(4)
+  else S3_STEP_F(16)
+#undef S3_STEP_F
+#undef S3_STEP_NP
+#undef S3_STEP_LAUNCH
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// The same timestep on 16-unit workgroups (s3_step16_kernel): for single-direction launches that run as two chains.  Same arguments;
+// whh: W_hh rows reordered [16-unit block][gate][16 units], and the projection's columns (W_ih rows, bias) in that order too.
+extern "C" int mmego_split3_step16(void* stream, int ndir, int Bn, int H, int first, const unsigned short* hprev0, const unsigned short* hprev1,
+                                   long hrb, const unsigned short* whh0, const unsigned short* whh1, const float* xpf, long mt0_0, long mt0_1,
+                                   float* hout0, float* hout1, long hos, unsigned short* hnext0, unsigned short* hnext1, long hnrb,
+                                   float* c0, float* c1, int nprod, int dbase) {
+  MMEGO_REQUIRE(dbase >= 0 && dbase + ndir <= 2);
+  MMEGO_REQUIRE((ndir == 1 || ndir == 2) && Bn > 0 && Bn <= 2048 && (H == 256 || H == 512 || H == 1024) && (nprod == 6 || nprod == 9));
+  MMEGO_REQUIRE(first || (hprev0 && (ndir == 1 || hprev1) && ((((uintptr_t)hprev0) | ((uintptr_t)hprev1)) & 15) == 0));
+  MMEGO_REQUIRE(whh0 && (ndir == 1 || whh1) && ((((uintptr_t)whh0) | ((uintptr_t)whh1)) & 15) == 0);
+  MMEGO_REQUIRE(hnext0 && (ndir == 1 || hnext1) && ((((uintptr_t)hnext0) | ((uintptr_t)hnext1)) & 15) == 0 && hnext0 != hprev0);
+  MMEGO_REQUIRE(xpf && (((uintptr_t)xpf) & 15) == 0 && mt0_0 >= 0 && mt0_1 >= 0 && c0 && (ndir == 1 || c1) && hrb > 0 && hnrb > 0);
+  S3StepP p;
+  p.hprev[0] = reinterpret_cast<const s3_u32x4*>(hprev0); p.hprev[1] = reinterpret_cast<const s3_u32x4*>(hprev1); p.hrb = hrb;
+  p.whh[0] = reinterpret_cast<const s3_u32x4*>(whh0); p.whh[1] = reinterpret_cast<const s3_u32x4*>(whh1);
+  p.xpf = xpf; p.mt0[0] = mt0_0; p.mt0[1] = mt0_1;
+  p.hout[0] = hout0; p.hout[1] = hout1; p.hos = hos;
+  p.hnext[0] = reinterpret_cast<s3_u32x4*>(hnext0); p.hnext[1] = reinterpret_cast<s3_u32x4*>(hnext1); p.hnrb = hnrb;
+  p.c[0] = c0; p.c[1] = c1;
+  p.Bn = Bn; p.H = H; p.first = first; p.dbase = dbase;
+  const int lds = 4 * 2 * 2 * 16 * 64 * (int)sizeof(float);
+  dim3 grid(H / 16, cdiv(Bn, 64), ndir);
+  hipStream_t st = (hipStream_t)stream;
+  const int sq = H / 64;
+#define S3_STEP_LAUNCH(SQ_, NP_, F_)                                                                                        \
+  {                                                                                                                         \
+    static bool attr_set = false;                                                                                           \
+    if (!attr_set) {                                                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void*)s3_step16_kernel<SQ_, NP_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      if (e != hipSuccess) return (int)e;                                                                                   \
+      attr_set = true;                                                                                                      \
+    }                                                                                                                       \
+    s3_step16_kernel<SQ_, NP_, F_><<<grid, 256, lds, st>>>(p);                                                             \
   }
 #define S3_STEP_NP(SQ_, F_)                 \
   {                                         \

@@ -1010,8 +1010,9 @@ class IMUNet(_NetBase):
     def _forward_split3(self, ar, imu, B, T, S, Cin, H):
         """precision = "split3" (split3.hip): the fp32 forward with rnn_fast's products -- input projections and recurrent steps,
         94 % of the model's FLOPs -- on exactly split bf16 operands (a = a1 + a2 + a3, six piece products, fp32 accumulation:
-        fp32-accurate at 6/16 of the fp32 matrix time).  fc1 writes the layer-0 operand itself; attention pooling, rnn_slow (64
-        rows: its persistent fp32 recurrence is latency-bound, not matrix-bound), fc2 and the head are the fp32 path's kernels."""
+        fp32-accurate at 6/16 of the fp32 matrix time).  fc1 writes the layer-0 operand itself; rnn_slow's input projections run on split operands too, its
+        recurrence (64 rows: a persistent fp32 launch per layer, latency-bound, not matrix-bound), attention pooling, fc2 and the
+        head are the fp32 path's kernels."""
         Bn = B * T
         dev = imu.device
         if not (H in (256, 512, 1024) and Cin <= 16 and Bn <= 2048 and self.fc1.weight.is_contiguous()):
@@ -1023,7 +1024,7 @@ class IMUNet(_NetBase):
         pooled = ar.get("pooled", (Bn, 2 * H))
         attn = ar.get("attn", (Bn, S))
         blocks.attn_pool_forward(fast, self.attn, Bn, S, 2 * H, pooled, attn)
-        slow = blocks.lstm_steps_forward(ar, "slow", self.rnn_slow, pooled, B, T)
+        slow = blocks.lstm_steps_forward_split3_proj(ar, "slow", self.rnn_slow, pooled, B, T)
         R = torch.empty((B, T, 3, 3), dtype=torch.float32, device=dev)
         t = torch.empty((B, T, 3), dtype=torch.float32, device=dev)
         if slow.shape[1] % 256 == 0 and slow.stride(0) % 4 == 0 and slow.stride(1) == 1 and self.fc2.weight.is_contiguous():

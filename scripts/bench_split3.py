@@ -14,12 +14,12 @@ dev = torch.device("cuda:0")
 hip.lib()
 
 
-def timeit(fn, n=20, warm=3):
+def timeit(fn, n=20, warm=3, fork=False):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with (ops.capture(g) if fork else torch.cuda.graph(g)):          # (ops.capture: side streams may be forked -- two-chain recurrences)
         for _ in range(n):
             fn()
     g.replay()
@@ -97,10 +97,12 @@ imu = nets.IMUNet(15, 9, 512, 2, True, 0.1).to(dev).eval()
 inp = torch.randn(64, 8, 20, 15, device=dev)
 for prec in ("fp32", "split3", "bf16"):
     imu.precision = prec
-    with torch.no_grad():
-        def fwd():
-            with blocks.two_chains(False):
-                return imu(inp)
-        us = timeit(fwd, n=4)
-    print("IMU_Net forward B=64 T=8, precision=%-6s (one launch per timestep, graph replay): %8.1f us" % (prec, us))
+    for chains in (False, True):
+        with torch.no_grad():
+            def fwd():
+                with blocks.two_chains(chains):
+                    return imu(inp)
+            us = timeit(fwd, n=4, fork=chains)
+        print("IMU_Net forward B=64 T=8, precision=%-6s (%s, graph replay): %8.1f us"
+              % (prec, "two chains per recurrence" if chains else "one launch per timestep ", us))
 assert blocks.seq_xcd_errors() == 0

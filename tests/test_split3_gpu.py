@@ -93,7 +93,8 @@ def test_split_and_join_are_exact(dev):
     assert torch.equal(bt[:, :Bn], xt.view(Bn, T, 32).permute(1, 0, 2)) and (bt[:, Bn:] == 0).all()
 
 
-@pytest.mark.parametrize("M,N,K,wm", [(256, 256, 512, 2), (512, 384, 1024, 4), (160, 128, 64, 2), (288, 160, 96, 4)])
+@pytest.mark.parametrize("M,N,K,wm", [(256, 256, 512, 2), (512, 384, 1024, 4), (160, 128, 64, 2), (288, 160, 96, 4), (200, 256, 1024, 1),
+                                      (512, 4096, 1024, 0)])
 def test_split3_gemm_against_float64(dev, M, N, K, wm):
     """C = A . W^T + bias: 6 piece products are fp32-accurate (error against float64 of the order of the native fp32 MFMA product's),
     9 are at least as good; both agree with the piece-product sums written out in float64; tile-major and row-major outputs agree."""
@@ -127,16 +128,23 @@ def test_split3_gemm_against_float64(dev, M, N, K, wm):
         assert torch.equal(Ct, C.cpu()), "tile-major and row-major outputs hold the same values"
         if nprod == 6:
             assert (Cc - six).abs().max().item() < 3e-7 * scale, ((Cc - six).abs().max().item(), scale)
-    assert errs[6] < max(2.0 * e_native, 2e-7 * scale), (errs, e_native, scale)
-    assert errs[9] < max(2.0 * e_native, 2e-7 * scale), (errs, e_native, scale)
+    # measured: 0.9-2.4 x the native product's error (K = 1024: one fp32 accumulator takes 384 MFMA results per output where the
+    # native kernel's takes 512 and splits them over chunks); 6 and 9 products agree to the last digit -- the error is the fp32
+    # accumulation's, not the dropped 2^-24 terms'
+    assert errs[6] < max(3.0 * e_native, 3e-7 * scale), (errs, e_native, scale)
+    assert errs[9] < max(3.0 * e_native, 3e-7 * scale), (errs, e_native, scale)
 
 
-@pytest.mark.parametrize("Bn,T,H", [(512, 20, 512), (100, 5, 512), (64, 3, 256)])
-def test_split3_bilstm_stack_against_the_fp32_step_kernels(dev, Bn, T, H):
+@pytest.mark.parametrize("Bn,T,H,chains", [(512, 20, 512, True), (512, 20, 512, False), (200, 5, 512, True), (100, 5, 512, False),
+                                           (64, 3, 256, False), (160, 4, 256, True)])
+def test_split3_bilstm_stack_against_the_fp32_step_kernels(dev, monkeypatch, Bn, T, H, chains):
     """blocks.lstm_steps_forward_split3 (projection GEMMs + recurrent steps on split operands) against blocks.lstm_steps_forward (the
     fp32 path: gemm_tile / lstm_step kernels) on the same two-layer BiLSTM: outputs of the last layer at fp32 rounding -- the bench
-    shape (512 rows x 20 samples, every workgroup full), a ragged row count and H = 256."""
+    shape (512 rows x 20 samples, every workgroup full), ragged row counts and H = 256; both forms of the recurrence: two chains of
+    single-direction launches on 16-unit workgroups (mmego_split3_step16, from 128 rows) and one both-direction launch per timestep
+    on 32-unit workgroups (mmego_split3_step)."""
     from mmego_amd import blocks, ops
+    monkeypatch.setattr(blocks, "SPLIT3_TWO_CHAINS", chains)
     torch.manual_seed(17)
     lstm = blocks.LstmParams(H, H, 2, dropout=0.0, bidirectional=True).to(dev)
     x = torch.randn(Bn * T, H, device=dev).relu_()
@@ -197,6 +205,7 @@ def test_ul_step_at_bench_shape_with_split3_imu(dev):
     torch.set_num_threads(bench.host_cores())
     r = bench.ul_step_parity(dev, use_graph=True, imu_precision="split3")
     noise = re.compile(bench.NOISE_GRAD)
+
     for tag in ("upper", "lower"):
         assert r["loss_rel_err_" + tag] < 2e-5, (tag, r["loss_rel_err_" + tag])
         assert r[tag + "_cm"] < 1e-3, (tag, r[tag + "_cm"])
@@ -206,3 +215,35 @@ def test_ul_step_at_bench_shape_with_split3_imu(dev):
             if not noise.search(k):
                 assert dp <= 6e-5 + 2e-6, (tag, k, dp)
         assert r["param_frac_moved_" + tag] < 0.05, (tag, r["param_frac_moved_" + tag])
+
+
+def test_concurrent_step_with_split3_imu_is_reproducible_bit_for_bit(dev):
+    """Six U+L steps of the timed engine (ConcurrentStages, HIP graph: the Lower tail runs beside the Upper stage's IMU_Net forward) from
+    the same seeded state with both IMU_Net forwards in the split3 mode: both stages' gradient buffers bit-equal every time.  r05: with
+    the 16-unit two-chain step kernel beside the Lower tail, head_fk_loss's dy -- and with it every Lower gradient -- changed in ~10 %
+    of such runs (scripts/coexec_head_fk.py; that form is off by default, blocks.SPLIT3_TWO_CHAINS)."""
+    import bench
+    from mmego_amd import blocks
+    from mmego_amd.train_step import ConcurrentStages, StageStep
+    assert blocks.SPLIT3_TWO_CHAINS is False
+    x, imu_in, body, target = [v.to(dev) for v in bench.synth_batch(1234, "cpu")]
+    ref = None
+    for it in range(6):
+        himu, hup, hlo, hfr = bench.build_hip_models(dev)
+        himu_l = bench.clone_imu(himu, dev)
+        himu.precision = himu_l.precision = "split3"
+        bench._lstm_dropout_off(hup, hlo)
+        su = StageStep("upper", hup, himu, lr=3e-5, use_graph=True)
+        sl = StageStep("lower", hlo, himu_l, upper_frozen=hfr, lr=3e-5, use_graph=True)
+        su.bind(x, imu_in, body, target)
+        sl.bind(x, imu_in, body, target)
+        ConcurrentStages([su, sl], use_graph=True).step()
+        torch.cuda.synchronize()
+        g = [st.net.flat().flat_g.detach().clone() for st in (su, sl)]
+        if ref is None:
+            ref = g
+        for a, b, tag in zip(g, ref, ("upper", "lower")):
+            assert torch.equal(a, b), (it, tag, float((a - b).abs().max()))
+        junk = torch.full((16 << 20,), float("nan"), device=dev)           # (the next nets land on used memory, as in a long session)
+        del junk
+    assert blocks.seq_xcd_errors() == 0
