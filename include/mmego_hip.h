@@ -351,6 +351,10 @@ int mmego_split3_step(void* stream, int ndir, int Bn, int H, int first, const un
                       long hrb, const unsigned short* whh0, const unsigned short* whh1, const float* xpf, long mt0_0, long mt0_1,
                       float* hout0, float* hout1, long hos, unsigned short* hnext0, unsigned short* hnext1, long hnrb,
                       float* c0, float* c1, int nprod, int dbase);
+/* projection for few rows (M <= 2048): C[m][d 4H + n] = A[m][:] . W_d[n][:] + bias[d 4H + n], both directions; W_d rows reordered
+ * [32-unit block][gate][32 units]; K = 256 / 512 / 1024; C row-major (IMU_Net's rnn_slow: Net/IMU_Net.py:61-62,82) */
+int mmego_split3_proj(void* stream, const unsigned short* A, const unsigned short* W0, const unsigned short* W1, const float* bias,
+                      float* C, long ldc, int M, int H, int K, int nprod);
 /* the same timestep on 16-unit workgroups (two per CU: single-direction launches of a layer's two directions run as two chains);
  * W_hh rows -- and the projection's columns -- ordered [16-unit block][gate][16 units] */
 int mmego_split3_step16(void* stream, int ndir, int Bn, int H, int first, const unsigned short* hprev0, const unsigned short* hprev1,

@@ -770,8 +770,8 @@ def split3_join(y, rows, K):
 
 
 def lstm_split3_weights(lstm, nu=32):
-    """Per layer: (W_ih of both directions stacked [8H, In] as pieces, b_ih + b_hh stacked [8H] fp32, W_hh pieces per direction,
-    b_ih stacked).  nu = 32: W_hh rows reordered [32-unit block][gate][32 units] (mmego_split3_step), the projection's columns in
+    """Per layer: (W_ih of both directions stacked [8H, In] as pieces, b_ih + b_hh stacked [8H] fp32, W_hh pieces per direction).
+    nu = 32: W_hh rows reordered [32-unit block][gate][32 units] (mmego_split3_step), the projection's columns in
     PyTorch's order; nu = 16: W_hh rows AND the projection's columns (W_ih rows, biases) per direction reordered [16-unit block][gate]
     [16 units] (mmego_split3_step16).  Built once per weight version and layout (dropped by weights_changed())."""
     cache = getattr(lstm, "_split3_cache", None)
@@ -784,17 +784,15 @@ def lstm_split3_weights(lstm, nu=32):
     layers = []
     with torch.no_grad():
         for l in range(lstm.num_layers):
-            wih, bias, bias_ih, whh = [], [], [], []
+            wih, bias, whh = [], [], []
             for d in range(2):
                 wi, bi, bh = lstm.w("weight_ih", l, d).detach(), lstm.w("bias_ih", l, d).detach(), lstm.w("bias_hh", l, d).detach()
                 if nu == 16:                                   # the projection's columns follow the step kernel's gate-pair blocks
                     wi, bi, bh = blocked(wi), blocked(bi.view(-1, 1)).view(-1), blocked(bh.view(-1, 1)).view(-1)
                 wih.append(wi)
                 bias.append(bi + bh)
-                bias_ih.append(bi)
                 whh.append(split3_cvt(blocked(lstm.w("weight_hh", l, d).detach())))
-            layers.append((split3_cvt(torch.cat(wih, 0).contiguous()), torch.cat(bias).contiguous(), whh[0], whh[1],
-                           torch.cat(bias_ih).contiguous()))
+            layers.append((split3_cvt(torch.cat(wih, 0).contiguous()), torch.cat(bias).contiguous(), whh[0], whh[1]))
     cache[nu] = layers
     return layers
 
@@ -825,7 +823,7 @@ def lstm_steps_forward_split3(ar, key, lstm, x, Bn, T, xfrag=None, nprod=None):
     S2 = 2 * H // 16                                   # 16-k steps of a layer-output row
     hrb = S2 * 3                                       # 1-KB blocks between row blocks of the layer output
     for l in range(lstm.num_layers):
-        wih, bias, whh0, whh1, _ = W[l]
+        wih, bias, whh0, whh1 = W[l]
         last = l == lstm.num_layers - 1
         xpf = ar.get("%s.s3xpf%d" % (key, l), (T * Bp * 8 * H,))
         hip.call("split3_gemm", cur, wih, xpf, None, 0, bias, T * nrb, 8 * H // 32, K, 0, nprod, SPLIT3_WM)
@@ -863,14 +861,33 @@ def lstm_steps_forward_split3(ar, key, lstm, x, Bn, T, xfrag=None, nprod=None):
     return out
 
 
+def lstm_split3_proj_weights(lstm):
+    """Per layer and direction: W_ih as pieces with rows reordered [32-unit block][gate][32 units] (mmego_split3_proj), and b_ih of both
+    directions stacked [8H]."""
+    cache = getattr(lstm, "_split3_cache", None)
+    if cache is None:
+        cache = lstm._split3_cache = {}
+    if "proj" in cache:
+        return cache["proj"]
+    H = lstm.hidden_size
+    blocked = lambda m: m.view(4, H // 32, 32, -1).permute(1, 0, 2, 3).reshape(4 * H, -1).contiguous()
+    layers = []
+    with torch.no_grad():
+        for l in range(lstm.num_layers):
+            w = [split3_cvt(blocked(lstm.w("weight_ih", l, d).detach())) for d in range(2)]
+            layers.append((w[0], w[1], torch.cat((lstm.w("bias_ih", l, 0).detach(), lstm.w("bias_ih", l, 1).detach())).contiguous()))
+    cache["proj"] = layers
+    return layers
+
+
 def lstm_steps_forward_split3_proj(ar, key, lstm, x, Bn, T, nprod=None):
     """lstm_steps_forward for a BiLSTM whose recurrence stays on the fp32 kernels (IMU_Net's rnn_slow: 64 rows, a persistent
     weight-stationary launch per layer that is latency-bound, not matrix-bound) with only the INPUT PROJECTIONS on split operands:
-    per layer one conversion of the layer input to pieces, one split3 product with a row-major fp32 result (rows b*T + t, W_ih x +
+    per layer one conversion of the layer input to pieces, one mmego_split3_proj launch (row-major fp32 result, rows b*T + t, W_ih x +
     b_ih of both directions), then blocks.lstm_recurrence as in the fp32 path."""
     H = lstm.hidden_size
     nprod = SPLIT3_NPROD if nprod is None else nprod
-    W = lstm_split3_weights(lstm)
+    W = lstm_split3_proj_weights(lstm)
     rows = Bn * T
     Rp = (rows + 31) // 32 * 32
     cur = x
@@ -880,7 +897,7 @@ def lstm_steps_forward_split3_proj(ar, key, lstm, x, Bn, T, nprod=None):
         xs = split3_buffer(ar, "%s.s3in%d" % (key, l), Rp, K)
         split3_cvt(cur, out=xs, Rp=Rp)
         xp = ar.get("%s.xp%d" % (key, l), (rows, 8 * H))
-        hip.call("split3_gemm", xs, W[l][0], None, xp, xp.stride(0), W[l][4], Rp // 32, 8 * H // 32, K, rows, nprod, 0)
+        hip.call("split3_proj", xs, W[l][0], W[l][1], W[l][2], xp, xp.stride(0), rows, H, K, nprod)
         out = ar.get("%s.out%d" % (key, l), (rows, 2 * H))
         lstm_recurrence(ar, key, lstm, l, xp, out, Bn, T)
         cur = out

@@ -436,6 +436,7 @@ struct S3StepP {
   s3_u32x4* hnext[2]; long hnrb;        // h_t pieces, addressed like hprev
   float* c[2];
   int Bn, H, first, dbase;             // dbase: direction of slot 0 (a single-direction launch of the reverse direction: 1)
+  int S;                               // 16-k steps of the product: H / 16 for a timestep, K / 16 for mmego_split3_proj
 };
 
 __device__ __forceinline__ float s3_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -446,11 +447,16 @@ __device__ __forceinline__ float s3_tanh(float x) { return 1.0f - 2.0f * __built
 // so no fragment is fetched twice, and streams its SQ 16-k steps through a ring of four fragment sets (18 coalesced 1-KB reads per
 // step, requested three steps = 144 MFMAs ahead: with two, every step still waited for memory -- product and fetch added up); the four partial tiles meet in LDS (fixed order) and all four waves run the cell
 // update of 16 rows each.  h_t leaves as 12 whole 1-KB blocks per workgroup (pieces put together in LDS), and optionally as fp32 rows.
-template <int SQ, int NPROD, bool FIRST>
+// MODE 0: a timestep with its product; 1: the product-less first timestep; 2: the product alone, as a projection for few rows (IMU_Net's
+// rnn_slow: 512 rows) -- out[row][gate H + j] = A[row][:] . W[gate H + j][:] + bias, row-major, K = 16 p.S: the chunked kernel above
+// is latency-bound there (64 x 128 tiles, one workgroup per CU, a memory round trip per 32-k chunk: 55 us against gemm_tile's 50),
+// this one keeps three steps of requests in flight per wave (mmego_split3_proj).
+template <int SQ, int NPROD, int MODE>
 __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
+  constexpr bool FIRST = MODE == 1, PROJ = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) float s3_red[];      // [4 waves][2 mi][4 n][16 i][64 lanes] = 128 KB
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int d = blockIdx.z, H = p.H, S = H >> 4;
+  const int d = blockIdx.z, H = p.H, S = p.S;
   const int nrb = gridDim.y, nb = gridDim.x * nrb;
   const int id = s3_xcd_order(blockIdx.y * gridDim.x + blockIdx.x, nb);
   const int jb = id / nrb, j0 = jb * 32, r0 = (id % nrb) * 64;
@@ -508,6 +514,11 @@ __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
     }                                                                                                                            \
   }
   if (FIRST) S3_CELL_OPERANDS()
+  float bproj[4] = {0.f, 0.f, 0.f, 0.f};
+  if (PROJ && p.xpf) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bproj[n] = p.xpf[(long)(p.dbase + d) * 4 * H + n * H + j];       // (MODE 2: xpf = the bias vector [2][4H])
+  }
   float pre[4][8];
 #pragma unroll
   for (int n = 0; n < 4; ++n)
@@ -524,7 +535,7 @@ __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
       // scripts/s3_experiments.py: 19.5 us per timestep, 15.4 with cache-resident operands, 14.7 without the MFMAs, 11.5 with neither).
       constexpr bool more = true;
       const int sn = s + NR - 1, slot = (s + NR - 1) % NR;
-      if (s == (SQ >= 2 ? SQ - 2 : 0)) S3_CELL_OPERANDS()
+      if (!PROJ && s == (SQ >= 2 ? SQ - 2 : 0)) S3_CELL_OPERANDS()
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int mi = g >> 2, n = g & 3;
@@ -565,6 +576,17 @@ __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
           for (int ii = 0; ii < 8; ++ii) pre[n][ii] += s3_red[(((src * 2 + own_mi) * 4 + n) * 16 + own_i0 + ii) * 64 + lane];
       __syncthreads();                                  // (the reduction buffer becomes the piece image below)
     }
+  }
+  if (PROJ) {                                           // the product alone: 8 rows x 4 gate columns per lane, row-major
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) {
+      const int row = r0 + own_r0 + 8 * (ii >> 2) + 4 * fh + (ii & 3);
+      if (row < p.Bn) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) p.hout[d][(long)row * p.hos + n * H + j] = pre[n][ii] + bproj[n];
+      }
+    }
+    return;
   }
   // cell update of this lane's 8 (row, unit j) elements; PyTorch gate order i, f, g, o
   s3_bf16_t* img = reinterpret_cast<s3_bf16_t*>(s3_red);            // [2 rb][2 s][3 p][64 lanes][8] bf16 = 12 KB
@@ -795,7 +817,7 @@ extern "C" int mmego_split3_step(void* stream, int ndir, int Bn, int H, int firs
   p.hout[0] = hout0; p.hout[1] = hout1; p.hos = hos;
   p.hnext[0] = reinterpret_cast<s3_u32x4*>(hnext0); p.hnext[1] = reinterpret_cast<s3_u32x4*>(hnext1); p.hnrb = hnrb;
   p.c[0] = c0; p.c[1] = c1;
-  p.Bn = Bn; p.H = H; p.first = first; p.dbase = dbase;
+  p.Bn = Bn; p.H = H; p.first = first; p.dbase = dbase; p.S = H / 16;
   const int lds = 4 * 2 * 4 * 16 * 64 * (int)sizeof(float);
   dim3 grid(H / 32, cdiv(Bn, 64), ndir);
   hipStream_t st = (hipStream_t)stream;
@@ -817,8 +839,8 @@ extern "C" int mmego_split3_step(void* stream, int ndir, int Bn, int H, int firs
   }
 #define S3_STEP_F(SQ_)              \
   {                                 \
-    if (first) S3_STEP_NP(SQ_, true) \
-    else S3_STEP_NP(SQ_, false)     \
+    if (first) S3_STEP_NP(SQ_, 1) \
+    else S3_STEP_NP(SQ_, 0)     \
   }
   if (sq == 8) S3_STEP_F(8)
   else if (sq == 4) S3_STEP_F(4)
@@ -826,6 +848,42 @@ extern "C" int mmego_split3_step(void* stream, int ndir, int Bn, int H, int firs
 #undef S3_STEP_F
 #undef S3_STEP_NP
 #undef S3_STEP_LAUNCH
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// Projection for few rows: C[m][d 4H + n] = sum_k A[m][k] W_d[n][k] + bias[d 4H + n] for both directions d (grid z), m < M <= 2048, n < 4H,
+// K = 256 / 512 / 1024 (the k quarters of a workgroup's four waves are 4 / 8 / 16 steps).  A: sfrag pieces [ceil(M/32)][K/16][3] KB (rows
+// in order); W0 / W1: mmego_split3_cvt of each direction's weight [4H][K] with rows reordered [32-unit block][gate][32 units]; C row-major,
+// row stride ldc >= 8H.  (s3_step_kernel<.., 2>: 64 x 128 outputs per workgroup, K split over its waves, three steps of requests in flight.)
+extern "C" int mmego_split3_proj(void* stream, const unsigned short* A, const unsigned short* W0, const unsigned short* W1, const float* bias,
+                                 float* C, long ldc, int M, int H, int K, int nprod) {
+  MMEGO_REQUIRE(A && W0 && W1 && C && M > 0 && M <= 2048 && H > 0 && H % 32 == 0 && (K == 256 || K == 512 || K == 1024) && ldc >= 8 * H);
+  MMEGO_REQUIRE((nprod == 6 || nprod == 9) && ((((uintptr_t)A) | ((uintptr_t)W0) | ((uintptr_t)W1)) & 15) == 0);
+  S3StepP p = {};
+  p.hprev[0] = p.hprev[1] = reinterpret_cast<const s3_u32x4*>(A); p.hrb = (long)(K / 16) * 3;
+  p.whh[0] = reinterpret_cast<const s3_u32x4*>(W0); p.whh[1] = reinterpret_cast<const s3_u32x4*>(W1);
+  p.xpf = bias;
+  p.hout[0] = C; p.hout[1] = C + 4 * H; p.hos = ldc;
+  p.Bn = M; p.H = H; p.first = 0; p.dbase = 0; p.S = K / 16;
+  const int lds = 4 * 2 * 4 * 16 * 64 * (int)sizeof(float);
+  dim3 grid(H / 32, cdiv(M, 64), 2);
+  hipStream_t st = (hipStream_t)stream;
+  const int sq = K / 64;
+#define S3_PROJ_LAUNCH(SQ_, NP_)                                                                                            \
+  {                                                                                                                         \
+    static bool attr_set = false;                                                                                           \
+    if (!attr_set) {                                                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void*)s3_step_kernel<SQ_, NP_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      if (e != hipSuccess) return (int)e;                                                                                   \
+      attr_set = true;                                                                                                      \
+    }                                                                                                                       \
+    s3_step_kernel<SQ_, NP_, 2><<<grid, 256, lds, st>>>(p);                                                                 \
+  }
+  if (sq == 16) { if (nprod == 6) S3_PROJ_LAUNCH(16, 6) else S3_PROJ_LAUNCH(16, 9) }
+  else if (sq == 8) { if (nprod == 6) S3_PROJ_LAUNCH(8, 6) else S3_PROJ_LAUNCH(8, 9) }
+  else { if (nprod == 6) S3_PROJ_LAUNCH(4, 6) else S3_PROJ_LAUNCH(4, 9) }
+#undef S3_PROJ_LAUNCH
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
@@ -849,7 +907,7 @@ extern "C" int mmego_split3_step16(void* stream, int ndir, int Bn, int H, int fi
   p.hout[0] = hout0; p.hout[1] = hout1; p.hos = hos;
   p.hnext[0] = reinterpret_cast<s3_u32x4*>(hnext0); p.hnext[1] = reinterpret_cast<s3_u32x4*>(hnext1); p.hnrb = hnrb;
   p.c[0] = c0; p.c[1] = c1;
-  p.Bn = Bn; p.H = H; p.first = first; p.dbase = dbase;
+  p.Bn = Bn; p.H = H; p.first = first; p.dbase = dbase; p.S = H / 16;
   const int lds = 4 * 2 * 2 * 16 * 64 * (int)sizeof(float);
   dim3 grid(H / 16, cdiv(Bn, 64), ndir);
   hipStream_t st = (hipStream_t)stream;

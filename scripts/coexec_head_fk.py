@@ -40,7 +40,7 @@ def step16_stack():
     nrb, S2 = d["nrb"], d["S2"]
     cur, K = d["x"], H
     for layer in range(2):
-        wih, bias, whh0, whh1, _ = d["W"][layer]
+        wih, bias, whh0, whh1 = d["W"][layer]
         hip.call("split3_gemm", cur, wih, d["xpf"], None, 0, bias, S * nrb, 8 * H // 32, K, 0, 6, 0)
         o_p, out_p = d["O"][layer].data_ptr(), d["out"].data_ptr()
         win = lambda tt, dd: o_p + 2 * ((tt * nrb * S2 + dd * (H // 16)) * 3 * 512)

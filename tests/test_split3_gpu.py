@@ -135,6 +135,32 @@ def test_split3_gemm_against_float64(dev, M, N, K, wm):
     assert errs[9] < max(3.0 * e_native, 3e-7 * scale), (errs, e_native, scale)
 
 
+@pytest.mark.parametrize("M,H,K", [(512, 512, 1024), (200, 512, 512), (64, 256, 256)])
+def test_split3_projection_for_few_rows(dev, M, H, K):
+    """mmego_split3_proj (the step kernel's product alone: IMU_Net's rnn_slow input projections, 512 rows x 4096 columns x K = 1024) against
+    float64 and the native fp32 product; both directions, ragged row counts."""
+    from mmego_amd import blocks, hip, ops
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(2, 4 * H, K, generator=g) * 0.04
+    bias = torch.randn(8 * H, generator=g)
+    ref = torch.cat((A.double() @ W[0].double().t(), A.double() @ W[1].double().t()), 1) + bias.double()
+    scale = (A.double().abs() @ W[0].double().abs().t()).max().item()
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    native = torch.empty(M, 8 * H, device=dev)
+    ops.linear_pair(Ad, Wd[0], Wd[1], bd[:4 * H], bd[4 * H:], native, 4 * H)
+    e_native = (native.cpu().double() - ref).abs().max().item()
+    blocked = lambda m: m.view(4, H // 32, 32, -1).permute(1, 0, 2, 3).reshape(4 * H, -1).contiguous()
+    Ap = blocks.split3_cvt(Ad)
+    Wp = [blocks.split3_cvt(blocked(Wd[d])) for d in range(2)]
+    for nprod in (6, 9):
+        C = torch.full((M, 8 * H), float("nan"), device=dev)
+        hip.call("split3_proj", Ap, Wp[0], Wp[1], bd, C, C.stride(0), M, H, K, nprod)
+        torch.cuda.synchronize()
+        err = (C.cpu().double() - ref).abs().max().item()
+        assert err < max(3.0 * e_native, 3e-7 * scale), (nprod, err, e_native, scale)
+
+
 @pytest.mark.parametrize("Bn,T,H,chains", [(512, 20, 512, True), (512, 20, 512, False), (200, 5, 512, True), (100, 5, 512, False),
                                            (64, 3, 256, False), (160, 4, 256, True)])
 def test_split3_bilstm_stack_against_the_fp32_step_kernels(dev, monkeypatch, Bn, T, H, chains):
