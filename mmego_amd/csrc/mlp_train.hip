@@ -23,6 +23,9 @@
 #define MT_MAXBLK 256           // workgroups (= partial records) per layer launch: one per CU
 
 __device__ __forceinline__ float mt_bn(float z, float mean, float a, float b) { return __builtin_fmaf(z - mean, a, b); }
+// element at a 32-bit BYTE offset from a uniform base pointer: one SGPR pair + one offset register per access
+__device__ __forceinline__ float mt_ld(const float* base, unsigned boff) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff); }
+__device__ __forceinline__ void mt_st(float* base, unsigned boff, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v; }
 
 // acc[32x32] = A[32 rows][K] . B[32 rows][K]^T, both row-major with stride MT_S; K even
 __device__ __forceinline__ f32x16 mt_tile_nt(const float* A, const float* B, int K, int lane) {
@@ -140,7 +143,9 @@ struct MlpFwdP {
 
 // 1024 threads = 4 groups of 4 waves; every group owns one 64-row tile of a 256-row round, so a workgroup keeps four tiles'
 // loads in flight (one tile at a time left the kernel waiting on one memory round trip per tile).
+// FULL: see mlp_bwd_layer_kernel -- complete workgroups, uniform base pointers + 32-bit byte offsets, no row tests
 #define MTF_NG 4
+template <bool FULL>
 __global__ __launch_bounds__(1024) void mlp_fwd_layer_kernel(MlpFwdP p) {
   __shared__ float Ws[64 * MT_S], Xs[MTF_NG][64 * MT_S], Bs[64], sm[4][64];
   __shared__ double red[16][2][64];
@@ -157,6 +162,10 @@ __global__ __launch_bounds__(1024) void mlp_fwd_layer_kernel(MlpFwdP p) {
 // dependent round trips per tile; MT_PIN keeps the loaded value live outside the select so the load stays unconditional)
 #define MT_PIN(v) asm volatile("" : "+v"(v))
 #define MTF_FETCH(r0_)                                                                              \
+  if (FULL) {                                                                                       \
+    const unsigned lr_ = (unsigned)((r0_) - rbeg) + xr;                                             \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) xv[j] = mt_ld(Xb, box + (lr_ + 4 * j) * sx);     \
+  } else                                                                                            \
   _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
     const long rr_ = (r0_) + xr + 4 * j;                                                            \
     xv[j] = p.X[(rr_ < rend ? rr_ : rend - 1) * p.ldx + xkc];                                       \
@@ -164,9 +173,12 @@ __global__ __launch_bounds__(1024) void mlp_fwd_layer_kernel(MlpFwdP p) {
   _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
     const long rr_ = (r0_) + xr + 4 * j;                                                            \
     MT_PIN(xv[j]);                                                                                  \
-    xv[j] = (rr_ < rend && xk < p.Cin) ? xv[j] : 0.f;                                               \
+    xv[j] = ((FULL || rr_ < rend) && xk < p.Cin) ? xv[j] : 0.f;                                     \
   }
   const int xkc = xk < p.Cin ? xk : p.Cin - 1;
+  const float* __restrict__ Xb = p.X + rbeg * p.ldx;
+  float* __restrict__ Zb = p.Z + rbeg * p.ldz;
+  const unsigned sx = 4u * (unsigned)p.ldx, box = 4u * (unsigned)xkc, sz = 4u * (unsigned)p.ldz;
   if (rbeg < rend) { MTF_FETCH(rbeg + 64 * grp) }          // the first tile's loads fly while the statistics are finalized
   // (behind the first tile's loads, so that both are in flight together)
   // weights (zero padded) -> LDS: four elements per thread, every load unconditional from a clamped index and all in flight
@@ -203,13 +215,27 @@ __global__ __launch_bounds__(1024) void mlp_fwd_layer_kernel(MlpFwdP p) {
     for (int j = 0; j < 16; ++j) {
       const long rr = r0 + xr + 4 * j;
       float v = xv[j];
-      if (act) v = (rr < rend && xk < p.Cin) ? fmaxf(mt_bn(v, mu, aa, bb), 0.f) : 0.f;
+      if (act) v = ((FULL || rr < rend) && xk < p.Cin) ? fmaxf(mt_bn(v, mu, aa, bb), 0.f) : 0.f;
       Xg[(xr + 4 * j) * MT_S + xk] = v;
     }
     __syncthreads();
     if (rr0 + 64 * MTF_NG < rend) { MTF_FETCH(r0 + 64 * MTF_NG) }
     if (ct * 32 < p.Cout && r0 < rend) {                  // (a wave whose 32 output channels are all padding has nothing to do)
-      const f32x16 acc = mt_tile_nt(Xg + rt * 32 * MT_S, Ws + ct * 32 * MT_S, K, lane);
+      f32x16 acc = mt_tile_nt(Xg + rt * 32 * MT_S, Ws + ct * 32 * MT_S, K, lane);
+      if (FULL) {
+        if (col < p.Cout) {
+          const unsigned ob = 4u * (unsigned)col + (unsigned)((int)(r0 - rbeg) + rt * 32 + 4 * (lane >> 5)) * sz;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) acc[reg] += bv;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) mt_st(Zb, ob + (unsigned)((reg & 3) + 8 * (reg >> 2)) * sz, acc[reg]);
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            s1 += (double)acc[reg];
+            s2 += (double)acc[reg] * (double)acc[reg];
+          }
+        }
+      } else {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const long row = r0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -219,6 +245,7 @@ __global__ __launch_bounds__(1024) void mlp_fwd_layer_kernel(MlpFwdP p) {
           s1 += (double)z;
           s2 += (double)z * (double)z;
         }
+      }
       }
     }
   }
@@ -305,8 +332,14 @@ struct MlpBwdP {
 };
 
 // 512 threads = 2 groups of 4 waves, each group one 64-row tile of a 128-row round (three tiles of LDS per group)
+// FULL: every workgroup of the launch owns rows_per_wg complete rows (rows % rows_per_wg == 0: every shape of the training step).  In-kernel
+// stamps (scripts/mlp_bwd_probe.hip) put the two 128-row rounds of a workgroup at ~15 k cycles EACH whatever the channel count -- 8 or
+// 64 -- with ~1400 instructions per wave and round, a third of them 64-bit row x stride address arithmetic, row clamps and per-element
+// predicates: the kernel is bound by instruction issue (two waves per SIMD), not by memory or the matrix pipe (regrouping its loads,
+// the gather rounds or the LDS operand reads changed nothing).  The FULL form addresses everything through uniform base pointers + 32-bit
+// byte offsets and drops every row test.
 #define MTB_NG 2
-template <bool GATHER>
+template <bool GATHER, bool FULL>
 __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = t >> 6;
@@ -338,6 +371,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
       const float av_ = p.ganch[an_ * 3 + (xki < 3 ? xki : (xki < 6 ? xki - 3 : 0))];               \
       gx[j] = xki < 3 ? av_ : (xki < 6 ? pv_ - av_ : pv_);                                          \
     }                                                                                               \
+  } else if (FULL) {                                                                                \
+    const unsigned lr_ = (unsigned)((r0_) - rbeg) + xr;                                             \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                \
+      gy[j] = mt_ld(dYb, boy + (lr_ + 4 * j) * sy); gz[j] = mt_ld(Zb, boz + (lr_ + 4 * j) * sz); gx[j] = mt_ld(Xb, box + (lr_ + 4 * j) * sx); \
+    }                                                                                               \
   } else                                                                                            \
   _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
     const long rr_ = (r0_) + xr + 4 * j;                                                            \
@@ -346,13 +384,21 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
   }                                                                                                 \
   _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                                  \
     const long rr_ = (r0_) + xr + 4 * j;                                                            \
-    const bool oko_ = rr_ < rend && xk < p.Cout;                                                    \
+    const bool oko_ = (FULL || rr_ < rend) && xk < p.Cout;                                          \
     MT_PIN(gy[j]); MT_PIN(gz[j]); MT_PIN(gx[j]);                                                    \
     gy[j] = oko_ ? gy[j] : 0.f;                                                                     \
     gz[j] = oko_ ? gz[j] : 0.f;                                                                     \
-    gx[j] = (rr_ < rend && xk < p.Cin) ? gx[j] : 0.f;                                               \
+    gx[j] = ((FULL || rr_ < rend) && xk < p.Cin) ? gx[j] : 0.f;                                     \
   }
   const int xko = xk < p.Cout ? xk : p.Cout - 1, xki = xk < p.Cin ? xk : p.Cin - 1;
+  // FULL: uniform bases at the workgroup's first row, 32-bit byte offsets (column part + row x stride)
+  const float* __restrict__ dYb = p.dY + rbeg * p.lddy;
+  const float* __restrict__ Zb = p.Z + rbeg * p.ldz;
+  const float* __restrict__ Xb = GATHER ? p.Z : p.Xin + rbeg * p.ldxin;
+  float* __restrict__ dXb = p.dX ? p.dX + rbeg * p.lddx : nullptr;
+  const unsigned sy = 4u * (unsigned)p.lddy, sz = 4u * (unsigned)p.ldz, sx = 4u * (unsigned)p.ldxin, sdx = 4u * (unsigned)p.lddx;
+  const unsigned boy = 4u * (unsigned)xko, boz = boy, box = 4u * (unsigned)xki;
+  MMEGO_STAMP_AT(blockIdx.x, 0, tid == 0);
   if (rbeg < rend) { MTB_FETCH(rbeg + 64 * grp) }          // the first tile's loads fly while the partial sums are gathered
   {  // W^T and the two BatchNorm states -> LDS: unconditional loads from clamped indices, all in flight, padding applied to the values
     float wv[8], sv[8];
@@ -401,6 +447,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
   const bool want_dx = p.dX != nullptr, want_prev = p.gprev_part != nullptr;
   f32x16 accw = {0};
   double s1 = 0.0, s2 = 0.0;
+  MMEGO_STAMP_AT(blockIdx.x, 1, tid == 0);
   for (long rr0 = rbeg; rr0 < rend; rr0 += 64 * MTB_NG) {
     const long r0 = rr0 + 64 * grp;
     __syncthreads();
@@ -410,7 +457,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const long rr = r0 + xr + 4 * j;
-        const bool oko = rr < rend && xk < p.Cout, oki = rr < rend && xk < p.Cin;
+        const bool oko = (FULL || rr < rend) && xk < p.Cout, oki = (FULL || rr < rend) && xk < p.Cin;
         const float z = gz[j];
         const float g = mt_bn(z, mu, a, b) > 0.f ? gy[j] : 0.f;
         DZs[(xr + 4 * j) * MT_S + xk] = oko ? a * (g - c1 - ((z - mu) * is) * c2) : 0.f;
@@ -425,6 +472,28 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
     if (want_dx && ct * 32 < p.Cin) {                     // dX tile: rows rt, input channels ct
       const f32x16 acc = mt_tile_nt(DZs + rt * 32 * MT_S, Wt + ct * 32 * MT_S, Ko, lane);
       const float mui = st[4][col], isi = st[5][col];
+      if (FULL) {
+        if (col < p.Cin) {                                // (one test per wave half; the stores read the accumulator registers as they are)
+          const unsigned ob = 4u * (unsigned)col + (unsigned)((int)(r0 - rbeg) + rt * 32 + 4 * (lane >> 5)) * sdx;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) mt_st(dXb, ob + (unsigned)((reg & 3) + 8 * (reg >> 2)) * sdx, acc[reg]);
+          if (want_prev) {
+            float xa[16], za[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int lr = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+              xa[reg] = Xs[lr * MT_S + col];
+              za[reg] = Zp[lr * MT_S + col];
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const float g = xa[reg] > 0.f ? acc[reg] : 0.f;
+              s1 += (double)g;
+              s2 += (double)g * (double)((za[reg] - mui) * isi);
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int lr = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
@@ -439,12 +508,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
           }
         }
       }
+      }
     }
     // dW[cout tile rt][cin tile ct] += dz^T . act(x) over the tile's 64 rows
     if (rt * 32 < p.Cout && ct * 32 < p.Cin) accw = mt_tile_tn(DZs + rt * 32, Xs + ct * 32, accw, lane);
   }
   // the two groups' dW accumulators, added in a fixed order (group 1's go through LDS)
   __syncthreads();
+  MMEGO_STAMP_AT(blockIdx.x, 2, tid == 0);
   float* const xch = smem;                   // [64][64] exchange area (the tiles are no longer needed)
   if (grp == 1) {
 #pragma unroll
@@ -463,6 +534,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_layer_kernel(MlpBwdP p) {
     }
   }
   if (want_prev) mt_store_partials<8>(s1, s2, col, grp * 4 + rt * 2 + (lane >> 5), p.gprev_part, red);
+  MMEGO_STAMP_AT(blockIdx.x, 3, tid == 0);
 }
 
 // dW[l][cout][cin] = sum over the workgroups' partials, fixed order, fp64 accumulation; up to 9 layers (three chains) per launch
@@ -536,7 +608,10 @@ extern "C" int mmego_mlp_fwd_layer(void* stream, const float* X, long ldx, long 
   p.in_part = in_part; p.in_nblk = nblk; p.in_gamma = in_gamma; p.in_beta = in_beta; p.in_eps = (float)in_eps;
   p.in_rmean = in_rmean; p.in_rvar = in_rvar; p.in_momentum = (float)in_momentum; p.in_state = in_state;
   p.W = W; p.bias = bias; p.Cout = Cout; p.Z = Z; p.ldz = ldz; p.out_part = out_part;
-  hipLaunchKernelGGL(mlp_fwd_layer_kernel, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, p);
+  if (p.rows % p.rows_per_wg == 0 && p.rows_per_wg * 4 * (p.ldx > p.ldz ? p.ldx : p.ldz) < (1L << 31))
+    hipLaunchKernelGGL(mlp_fwd_layer_kernel<true>, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(mlp_fwd_layer_kernel<false>, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
@@ -556,7 +631,10 @@ extern "C" int mmego_mlp_fwd_layer_n(void* stream, const float* X, long ldx, lon
   p.in_part = in_part; p.in_nblk = in_nblk; p.in_gamma = in_gamma; p.in_beta = in_beta; p.in_eps = (float)in_eps;
   p.in_rmean = in_rmean; p.in_rvar = in_rvar; p.in_momentum = (float)in_momentum; p.in_state = in_state;
   p.W = W; p.bias = bias; p.Cout = Cout; p.Z = Z; p.ldz = ldz; p.out_part = out_part;
-  hipLaunchKernelGGL(mlp_fwd_layer_kernel, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, p);
+  if (p.rows % p.rows_per_wg == 0 && p.rows_per_wg * 4 * (p.ldx > p.ldz ? p.ldx : p.ldz) < (1L << 31))
+    hipLaunchKernelGGL(mlp_fwd_layer_kernel<true>, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(mlp_fwd_layer_kernel<false>, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
@@ -594,13 +672,18 @@ static int mlp_bwd_layer_launch(hipStream_t st, MlpBwdP& p) {
   const size_t lds = (size_t)((MTB_NG * 3 + 1) * 64 * MT_S + 10 * 64) * sizeof(float) + sizeof(double) * 8 * 2 * 64;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_bwd_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_layer_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_bwd_layer_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mlp_bwd_layer_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  if (p.gidx) hipLaunchKernelGGL(mlp_bwd_layer_kernel<true>, dim3(nblk), dim3(512), lds, st, p);
-  else hipLaunchKernelGGL(mlp_bwd_layer_kernel<false>, dim3(nblk), dim3(512), lds, st, p);
+  // the fast form: complete workgroups only, 32-bit byte offsets inside a workgroup's rows
+  const long ldmax = p.lddy > p.ldz ? (p.lddy > p.ldxin ? p.lddy : p.ldxin) : (p.ldz > p.ldxin ? p.ldz : p.ldxin);
+  const bool full = !p.gidx && p.rows % p.rows_per_wg == 0 && p.rows_per_wg * 4 * (ldmax > p.lddx ? ldmax : p.lddx) < (1L << 31);
+  if (p.gidx) hipLaunchKernelGGL((mlp_bwd_layer_kernel<true, false>), dim3(nblk), dim3(512), lds, st, p);
+  else if (full) hipLaunchKernelGGL((mlp_bwd_layer_kernel<false, true>), dim3(nblk), dim3(512), lds, st, p);
+  else hipLaunchKernelGGL((mlp_bwd_layer_kernel<false, false>), dim3(nblk), dim3(512), lds, st, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
