@@ -259,26 +259,27 @@ struct MlpActP {
   float* Y; long ldy;
 };
 
-__global__ __launch_bounds__(1024) void mlp_bn_act_kernel(MlpActP p) {
+// lane = column, 16 row groups per workgroup, rows_per_wg rows per workgroup (the layer kernels' partition); 32-bit byte offsets from
+// the workgroup's first row.  (r04 form: a flat element index with a 64-bit division per element -- ~100 instructions each.)
+__global__ __launch_bounds__(1024) void mlp_bn_act_kernel(MlpActP p, long rows_per_wg) {
   __shared__ float sm[4][64];
   __shared__ double red[16][2][64];
   mt_finalize_stats<16>(p.part, p.nblk, p.C, p.rows, p.gamma, p.beta, p.eps, p.rmean, p.rvar, p.momentum, p.state, sm, red);
-  const long total = p.rows * p.C, stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += 8 * stride) {
-    float zv[8];
-    long rr[8];
-    int cc_[8];
+  const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
+  const long rbeg = (long)blockIdx.x * rows_per_wg, rend = min(p.rows, rbeg + rows_per_wg);
+  if (c >= p.C || rbeg >= rend) return;
+  const float mu = sm[0][c], a = sm[1][c], b = sm[2][c];
+  const int n = (int)(rend - rbeg);
+  const float* __restrict__ Zb = p.Z + rbeg * p.ldz;
+  float* __restrict__ Yb = p.Y + rbeg * p.ldy;
+  const unsigned sz = 4u * (unsigned)p.ldz, sy = 4u * (unsigned)p.ldy, bo = 4u * (unsigned)c;
+  for (int r = q; r < n; r += 16 * 16) {                  // 16 rows per thread and round, all loads in flight
+    float zv[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long ii = i + u * stride;
-      const long iic = ii < total ? ii : total - 1;
-      rr[u] = iic / p.C;
-      cc_[u] = (int)(iic - rr[u] * p.C);
-      zv[u] = p.Z[rr[u] * p.ldz + cc_[u]];                 // (clamped index: unconditional load; the store below is predicated)
-    }
+    for (int u = 0; u < 16; ++u) zv[u] = mt_ld(Zb, bo + (unsigned)min(r + 16 * u, n - 1) * sz);
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (i + u * stride < total) p.Y[rr[u] * p.ldy + cc_[u]] = fmaxf(mt_bn(zv[u], sm[0][cc_[u]], sm[1][cc_[u]], sm[2][cc_[u]]), 0.f);
+    for (int u = 0; u < 16; ++u)
+      if (r + 16 * u < n) mt_st(Yb, bo + (unsigned)(r + 16 * u) * sy, fmaxf(mt_bn(zv[u], mu, a, b), 0.f));
   }
 }
 
@@ -292,17 +293,20 @@ __global__ __launch_bounds__(1024) void mlp_bn_bwd_reduce_kernel(MlpRedP p) {
   const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
   const long rbeg = (long)blockIdx.x * p.rows_per_wg, rend = min(p.rows, rbeg + p.rows_per_wg);
   double s1 = 0.0, s2 = 0.0;
-  if (c < p.C) {
+  if (c < p.C && rbeg < rend) {
     const float mu = p.state[c], is = p.state[p.C + c], a = p.state[2 * p.C + c], b = p.state[3 * p.C + c];
-    for (long r = rbeg + q; r < rend; r += 128) {         // 8 rows per round: 16 loads in flight per thread
+    const int n = (int)(rend - rbeg);
+    const float* __restrict__ Zb = p.Z + rbeg * p.ldz;
+    const float* __restrict__ Gb = p.dY + rbeg * p.lddy;
+    const unsigned sz = 4u * (unsigned)p.ldz, sg = 4u * (unsigned)p.lddy, bo = 4u * (unsigned)c;
+    for (int r = q; r < n; r += 128) {                    // 8 rows per round: 16 loads in flight per thread; 32-bit byte offsets
       float zz[8], gg[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const long rr = r + 16 * u;
-        const long rc = rr < rend ? rr : rend - 1;         // (clamped: unconditional loads, then select)
-        const float zl = p.Z[rc * p.ldz + c], gl = p.dY[rc * p.lddy + c];
-        zz[u] = rr < rend ? zl : 0.f;
-        gg[u] = rr < rend ? gl : 0.f;
+        const int rc = min(r + 16 * u, n - 1);             // (clamped: unconditional loads, then select)
+        const float zl = mt_ld(Zb, bo + (unsigned)rc * sz), gl = mt_ld(Gb, bo + (unsigned)rc * sg);
+        zz[u] = r + 16 * u < n ? zl : 0.f;
+        gg[u] = r + 16 * u < n ? gl : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -646,9 +650,8 @@ extern "C" int mmego_mlp_bn_act(void* stream, const float* Z, long ldz, long row
   int nblk; long rpw;
   mt_grid(rows, &nblk, &rpw);
   MlpActP p = {Z, ldz, rows, C, part, nblk, gamma, beta, (float)eps, rmean, rvar, (float)momentum, state, Y, ldy};
-  long b = (rows * C + 8191) / 8192;
-  const int grid = (int)(b > MT_MAXBLK ? MT_MAXBLK : (b < 1 ? 1 : b));       // (every workgroup re-reads the partials: keep them few)
-  hipLaunchKernelGGL(mlp_bn_act_kernel, dim3(grid), dim3(1024), 0, (hipStream_t)stream, p);
+  MMEGO_REQUIRE(rpw * 4 * (ldz > ldy ? ldz : ldy) < (1L << 31));
+  hipLaunchKernelGGL(mlp_bn_act_kernel, dim3(nblk), dim3(1024), 0, (hipStream_t)stream, p, rpw);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
