@@ -169,6 +169,28 @@ int mmego_lstm64_backward(void* stream, int B, int T, const float* dout, long do
                           const float* c0_1, const float* whh0, const float* whh1, float* dgates0, float* dgates1,
                           long dgs);
 
+/* The two calls above for n <= 4 INDEPENDENT stacks' layers in ONE launch (grid z = stack; descs: n host structs whose fields are the
+ * argument lists above, in order).  All stacks share B and T and the options (stashes for all or none, dropout for all or none).
+ * UpperNetwlocal's global and anchor BiLSTM(64) stacks (Net/Upper_Net.py:333-339 and :208-216: same shape, no data in common) run
+ * layer by layer side by side this way. */
+typedef struct MmegoLstm64Fwd {
+  const float* xproj[2]; long xs;
+  const float* whh[2]; const float* bhh[2]; const float* h0[2]; const float* c0[2];
+  float* out; long os;
+  float* hn[2]; float* cn[2];
+  float* gates[2]; float* cst[2]; float* hprev[2];
+  int B, T;
+  float* drop_y; float* drop_mask; float drop_p; const unsigned long long* seed_ctr; unsigned salt;
+} MmegoLstm64Fwd;
+typedef struct MmegoLstm64Bwd {
+  const float* dout; long dos;
+  const float* gates[2]; const float* cst[2]; const float* c0[2]; const float* whh[2];
+  float* dgates[2]; long dgs;
+  int B, T;
+} MmegoLstm64Bwd;
+int mmego_lstm64_forward_multi(void* stream, int n, const void* descs);
+int mmego_lstm64_backward_multi(void* stream, int n, const void* descs);
+
 /* ---- bf16-operand / fp32-accumulate forward of the frozen IMU_Net (bf16.hip; BASELINE config 5) -------------------
  * Opt-in precision mode, never the parity path.  bf16 values cross the ABI as raw bits in unsigned short.
  * Y[r, 0:cols] = bf16(X[r, 0:cols]) (round to nearest even); cols, ldx, ldy multiples of 4. */

@@ -272,36 +272,59 @@ def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr, salt
     """x [B*T, In] rows (b*T+t) -> out [B*T,128] (arena), hn, cn [2L,B,64] (fresh tensors).  With ``stash`` and p_drop > 0 the
     inter-layer dropout is applied by the layer kernel itself while it stores its outputs (mask from seed_ctr, which the net's
     once-per-forward tick advances: FlatParams.tick_args; ``salt`` separates the LSTM stacks of one net)."""
-    L = lstm.num_layers
-    dev = x.device
-    hn = torch.empty((2 * L, B, 64), dtype=torch.float32, device=dev)
-    cn = torch.empty((2 * L, B, 64), dtype=torch.float32, device=dev)
-    cur = x
-    out = None
+    return lstm64_forward_multi(ar, [(key, lstm, x, h0, c0, p_drop, seed_ctr, salt)], B, T, stash)[0]
+
+
+def lstm64_forward_multi(ar, stacks, B, T, stash, last_out=None):
+    """lstm64_forward for several INDEPENDENT stacks of the same depth and (B, T) -- stacks: (key, lstm, x, h0, c0, p_drop, seed_ctr, salt)
+    each -- with ONE sequence-kernel launch per layer for all of them (mmego_lstm64_forward_multi: grid z = stack).  -> [(out, hn, cn)].
+    last_out: per stack a [B*T, 128] view (any row stride) the LAST layer writes instead of its arena slot (the callers' concatenation)."""
+    L = stacks[0][1].num_layers
+    if any(st[1].num_layers != L for st in stacks):
+        raise ValueError("lstm64_forward_multi: stacks of different depth")
+    dev = stacks[0][2].device
+    hns = [torch.empty((2 * L, B, 64), dtype=torch.float32, device=dev) for _ in stacks]
+    cns = [torch.empty((2 * L, B, 64), dtype=torch.float32, device=dev) for _ in stacks]
+    curs = [st[2] for st in stacks]
+    outs = [None] * len(stacks)
     for l in range(L):
-        xp = ar.get("%s.xp%d" % (key, l), (B * T, 512))
-        ops.linear_pair(cur, lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1), lstm.w("bias_ih", l, 0), lstm.w("bias_ih", l, 1), xp, 256)
-        out = ar.get("%s.out%d" % (key, l), (B * T, 128))
-        if stash:
-            gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
-            cst = ar.get("%s.c%d" % (key, l), (2, T, B, 64))
-            hprev = ar.get("%s.hp%d" % (key, l), (2, B * T, 64))
-            st = (gates[0], gates[1], cst[0], cst[1], hprev[0], hprev[1])
+        calls = []
+        for i, (key, lstm, _, h0, c0, p_drop, seed_ctr, salt) in enumerate(stacks):
+            hn, cn = hns[i], cns[i]
+            xp = ar.get("%s.xp%d" % (key, l), (B * T, 512))
+            ops.linear_pair(curs[i], lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1), lstm.w("bias_ih", l, 0), lstm.w("bias_ih", l, 1), xp, 256)
+            out = last_out[i] if (last_out is not None and l == L - 1) else ar.get("%s.out%d" % (key, l), (B * T, 128))
+            if stash:
+                gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
+                cst = ar.get("%s.c%d" % (key, l), (2, T, B, 64))
+                hprev = ar.get("%s.hp%d" % (key, l), (2, B * T, 64))
+                st = (gates[0], gates[1], cst[0], cst[1], hprev[0], hprev[1])
+            else:
+                st = (None,) * 6
+            h00 = h0[2 * l] if h0 is not None else None
+            h01 = h0[2 * l + 1] if h0 is not None else None
+            c00 = c0[2 * l] if c0 is not None else None
+            c01 = c0[2 * l + 1] if c0 is not None else None
+            outs[i] = curs[i] = out
+            drop = (None, None, 0.0, None, 0)
+            if stash and p_drop > 0.0 and l < L - 1:
+                curs[i] = ar.get("%s.do%d" % (key, l), (B * T, 128))
+                drop = (curs[i], ar.get("%s.mk%d" % (key, l), (B * T, 128)), float(p_drop), seed_ctr, 8 * salt + l)
+            calls.append((B, T, xp, xp[:, 256:], 512, lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1),
+                          lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1), h00, h01, c00, c01, out, out.stride(0), hn[2 * l], hn[2 * l + 1],
+                          cn[2 * l], cn[2 * l + 1], *st, *drop))
+        # one launch for all the stacks when their options agree (the kernel's instantiation is per launch)
+        if len(calls) > 1 and len({(c[25] is None) for c in calls}) == 1:
+            P = hip.pair2
+            descs = (hip.Lstm64Fwd * len(calls))(*[
+                hip.Lstm64Fwd(P(c[2], c[3]), c[4], P(c[5], c[6]), P(c[7], c[8]), P(c[9], c[10]), P(c[11], c[12]), hip.ptr(c[13]), c[14],
+                              P(c[15], c[16]), P(c[17], c[18]), P(c[19], c[20]), P(c[21], c[22]), P(c[23], c[24]), B, T,
+                              hip.ptr(c[25]), hip.ptr(c[26]), c[27], hip.ptr(c[28]), c[29]) for c in calls])
+            hip.call("lstm64_forward_multi", len(calls), descs)
         else:
-            st = (None,) * 6
-        h00 = h0[2 * l] if h0 is not None else None
-        h01 = h0[2 * l + 1] if h0 is not None else None
-        c00 = c0[2 * l] if c0 is not None else None
-        c01 = c0[2 * l + 1] if c0 is not None else None
-        cur = out
-        drop = (None, None, 0.0, None, 0)
-        if stash and p_drop > 0.0 and l < L - 1:
-            cur = ar.get("%s.do%d" % (key, l), (B * T, 128))
-            drop = (cur, ar.get("%s.mk%d" % (key, l), (B * T, 128)), float(p_drop), seed_ctr, 8 * salt + l)
-        hip.call("lstm64_forward", B, T, xp, xp[:, 256:], 512, lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1),
-                 lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1), h00, h01, c00, c01, out, 128, hn[2 * l], hn[2 * l + 1], cn[2 * l], cn[2 * l + 1],
-                 *st, *drop)
-    return out, hn, cn
+            for c in calls:
+                hip.call("lstm64_forward", *c)
+    return [(outs[i], hns[i], cns[i]) for i in range(len(stacks))]
 
 
 def run_leaves(leaves):
@@ -317,57 +340,80 @@ def lstm64_backward(ar, key, lstm, x, B, T, c0, dout, G, p_drop, need_dx, leaves
     """Backward of the three-layer BiLSTM(64).  The weight-gradient products of a layer are LEAVES (nothing in the backward pass
     reads them) while the rest is one dependent chain of small kernels: the six of them are issued behind the last layer as ONE
     grouped launch (hip.gemm_group / mmego_gemm_group) instead of sitting two by two between the chain's kernels."""
-    L = lstm.num_layers
-    d_cur = dout
+    return lstm64_backward_multi(ar, [(key, lstm, x, c0, dout, p_drop)], B, T, G, need_dx, leaves)[0]
+
+
+def lstm64_backward_multi(ar, stacks, B, T, G, need_dx, leaves=None):
+    """lstm64_backward for several independent stacks -- (key, lstm, x, c0, dout, p_drop) each -- one backward-through-time launch per
+    layer for all of them (mmego_lstm64_backward_multi), every stack's weight-gradient leaves in one grouped launch.  -> [dx or None]."""
+    L = stacks[0][1].num_layers
+    if any(st[1].num_layers != L for st in stacks):
+        raise ValueError("lstm64_backward_multi: stacks of different depth")
+    d_curs = [st[4] for st in stacks]
     own = leaves is None             # (a caller's list: the caller runs it, together with its other leaves)
     if own:
         leaves = []
     for l in range(L - 1, -1, -1):
-        if l == 0:
-            inp = x
-        elif p_drop > 0.0:
-            inp = ar.get("%s.do%d" % (key, l - 1), (B * T, 128))
+        calls, after = [], []
+        for i, (key, lstm, x, c0, _, p_drop) in enumerate(stacks):
+            if l == 0:
+                inp = x
+            elif p_drop > 0.0:
+                inp = ar.get("%s.do%d" % (key, l - 1), (B * T, 128))
+            else:
+                inp = ar.get("%s.out%d" % (key, l - 1), (B * T, 128))
+            gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
+            cst = ar.get("%s.c%d" % (key, l), (2, T, B, 64))
+            hprev = ar.get("%s.hp%d" % (key, l), (2, B * T, 64))
+            dg = ar.get("%s.dg%d" % (key, l), (B * T, 512))
+            c00 = c0[2 * l] if c0 is not None else None
+            c01 = c0[2 * l + 1] if c0 is not None else None
+            d_cur = d_curs[i]
+            calls.append((B, T, d_cur, d_cur.stride(0), gates[0], gates[1], cst[0], cst[1], c00, c01,
+                          lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1), dg, dg[:, 256:], 512))
+            # weight gradients of both directions per launch (batch dimension = direction)
+            # the bias gradients (row sums of the gate gradients; bias_ih and bias_hh of a direction share them) ride on the two
+            # batched weight-gradient products where the directions' bias tensors are neighbours in the flat buffer
+            def weight_grads(l=l, dg=dg, inp=inp, hprev=hprev, lstm=lstm):
+                bi = ops.stacked(G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_ih", l, 1)))
+                bh = ops.stacked(G(lstm.w("bias_hh", l, 0)), G(lstm.w("bias_hh", l, 1)))
+                got_i = ops.grad_weight_pair(dg, 256, inp, G(lstm.w("weight_ih", l, 0)), G(lstm.w("weight_ih", l, 1)), db=bi)
+                got_h = ops.grad_weight_pair(dg, 256, hprev[0], G(lstm.w("weight_hh", l, 0)), G(lstm.w("weight_hh", l, 1)), X1=hprev[1], db=bh)
+                if got_i and got_h:
+                    pass
+                elif B * T <= 1024:     # the four bias gradients (bias_ih = bias_hh per direction) in one launch
+                    hip.call("colsum_pair", dg, dg.stride(0), B * T, 256, G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_hh", l, 0)),
+                             G(lstm.w("bias_ih", l, 1)), G(lstm.w("bias_hh", l, 1)), 0)
+                else:
+                    for d in range(2):
+                        ops.colsum(dg[:, d * 256:(d + 1) * 256], G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
+            leaves.append(weight_grads)
+            if l > 0 or need_dx:
+                def input_grad(i=i, key=key, lstm=lstm, inp=inp, dg=dg, p_drop=p_drop, l=l):
+                    dinp = ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))
+                    # (the inter-layer dropout mask is applied by the last product's epilogue)
+                    mask = ar.get("%s.mk%d" % (key, l - 1), (B * T, 128)) if l > 0 and p_drop > 0.0 else None
+                    Wc = ops.stacked(lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1))
+                    if Wc is not None:      # both directions' input weights back to back (the net's flat_param_order): one product
+                        ops.grad_input(dg, Wc, dinp, cmul=mask)
+                    else:
+                        ops.grad_input(dg[:, :256], lstm.w("weight_ih", l, 0), dinp)
+                        ops.grad_input(dg[:, 256:], lstm.w("weight_ih", l, 1), dinp, accumulate=True, cmul=mask)
+                    d_curs[i] = dinp
+                after.append(input_grad)
+        if len(calls) > 1:
+            P = hip.pair2
+            descs = (hip.Lstm64Bwd * len(calls))(*[
+                hip.Lstm64Bwd(hip.ptr(c[2]), c[3], P(c[4], c[5]), P(c[6], c[7]), P(c[8], c[9]), P(c[10], c[11]), P(c[12], c[13]), c[14], B, T)
+                for c in calls])
+            hip.call("lstm64_backward_multi", len(calls), descs)
         else:
-            inp = ar.get("%s.out%d" % (key, l - 1), (B * T, 128))
-        gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
-        cst = ar.get("%s.c%d" % (key, l), (2, T, B, 64))
-        hprev = ar.get("%s.hp%d" % (key, l), (2, B * T, 64))
-        dg = ar.get("%s.dg%d" % (key, l), (B * T, 512))
-        c00 = c0[2 * l] if c0 is not None else None
-        c01 = c0[2 * l + 1] if c0 is not None else None
-        hip.call("lstm64_backward", B, T, d_cur, d_cur.stride(0), gates[0], gates[1], cst[0], cst[1], c00, c01,
-                 lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1), dg, dg[:, 256:], 512)
-        # weight gradients of both directions per launch (batch dimension = direction)
-        # the bias gradients (row sums of the gate gradients; bias_ih and bias_hh of a direction share them) ride on the two
-        # batched weight-gradient products where the directions' bias tensors are neighbours in the flat buffer
-        def weight_grads(l=l, dg=dg, inp=inp, hprev=hprev):
-            bi = ops.stacked(G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_ih", l, 1)))
-            bh = ops.stacked(G(lstm.w("bias_hh", l, 0)), G(lstm.w("bias_hh", l, 1)))
-            got_i = ops.grad_weight_pair(dg, 256, inp, G(lstm.w("weight_ih", l, 0)), G(lstm.w("weight_ih", l, 1)), db=bi)
-            got_h = ops.grad_weight_pair(dg, 256, hprev[0], G(lstm.w("weight_hh", l, 0)), G(lstm.w("weight_hh", l, 1)), X1=hprev[1], db=bh)
-            if got_i and got_h:
-                pass
-            elif B * T <= 1024:     # the four bias gradients (bias_ih = bias_hh per direction) in one launch
-                hip.call("colsum_pair", dg, dg.stride(0), B * T, 256, G(lstm.w("bias_ih", l, 0)), G(lstm.w("bias_hh", l, 0)),
-                         G(lstm.w("bias_ih", l, 1)), G(lstm.w("bias_hh", l, 1)), 0)
-            else:
-                for d in range(2):
-                    ops.colsum(dg[:, d * 256:(d + 1) * 256], G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
-        leaves.append(weight_grads)
-        if l > 0 or need_dx:
-            dinp = ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))
-            # (the inter-layer dropout mask is applied by the last product's epilogue)
-            mask = ar.get("%s.mk%d" % (key, l - 1), (B * T, 128)) if l > 0 and p_drop > 0.0 else None
-            Wc = ops.stacked(lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1))
-            if Wc is not None:      # both directions' input weights back to back (the net's flat_param_order): one product
-                ops.grad_input(dg, Wc, dinp, cmul=mask)
-            else:
-                ops.grad_input(dg[:, :256], lstm.w("weight_ih", l, 0), dinp)
-                ops.grad_input(dg[:, 256:], lstm.w("weight_ih", l, 1), dinp, accumulate=True, cmul=mask)
-            d_cur = dinp
+            hip.call("lstm64_backward", *calls[0])
+        for fn in after:
+            fn()
     if own:
         run_leaves(leaves)
-    return d_cur if need_dx else None
+    return [d if need_dx else None for d in d_curs]
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -12,6 +12,8 @@
 //                     the recurrence, so a workgroup keeps W_hh (64 KB) in LDS, 16 rows of h in LDS and c
 //                     in registers and walks all T steps with no inter-workgroup traffic.
 #include "common.h"
+#include <stddef.h>
+#include "../../include/mmego_hip.h"       // MmegoLstm64Fwd / MmegoLstm64Bwd (the _multi entry points)
 
 // ---------------------------------------------------------------------------------------------
 // H = 64 persistent sequence kernels
@@ -57,7 +59,7 @@ typedef const l64_f4 __attribute__((address_space(1)))* l64_gcptr4;
 // the loop and put ONE s_waitcnt vmcnt(0) into every step -- which waits for the previous step's ~28 stores per lane to be
 // acknowledged, not only for the prefetched inputs (2.26 us per step; 1.96 us now).
 template <bool FULL, bool STASH, bool DROP>
-__global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
+__device__ __forceinline__ void lstm64_fwd_body(const Lstm64P& p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* hs = smem;              // [64 k][16 rows]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -199,6 +201,19 @@ __global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) {
   }
 }
 
+template <bool FULL, bool STASH, bool DROP>
+__global__ __launch_bounds__(256) void lstm64_fwd_kernel(Lstm64P p) { lstm64_fwd_body<FULL, STASH, DROP>(p); }
+
+// Several INDEPENDENT stacks' layers in one launch (grid z = stack): UpperNetwlocal's global and anchor BiLSTM(64) stacks have the same
+// shape and no data in common (Net/Upper_Net.py:333-339 and :208-216) -- one after the other each layer was 8 workgroups on a 256-CU
+// chip, twice.
+#define L64_MAX_MULTI 4
+static_assert(sizeof(Lstm64P) == sizeof(MmegoLstm64Fwd) && offsetof(Lstm64P, seed_ctr) == offsetof(MmegoLstm64Fwd, seed_ctr) &&
+              offsetof(Lstm64P, B) == offsetof(MmegoLstm64Fwd, B), "MmegoLstm64Fwd is Lstm64P");
+struct Lstm64Multi { Lstm64P p[L64_MAX_MULTI]; };
+template <bool FULL, bool STASH, bool DROP>
+__global__ __launch_bounds__(256) void lstm64_fwd_multi_kernel(Lstm64Multi m) { lstm64_fwd_body<FULL, STASH, DROP>(m.p[blockIdx.z]); }
+
 extern "C" int mmego_lstm64_forward(void* stream, int B, int T, const float* xproj0, const float* xproj1, long xs,
                                     const float* whh0, const float* whh1, const float* bhh0, const float* bhh1,
                                     const float* h0_0, const float* h0_1, const float* c0_0, const float* c0_1, float* out,
@@ -264,7 +279,7 @@ struct Lstm64BwdP {
 // FULL as in lstm64_fwd_kernel: straight-line step loop (no row predicates, the prefetch unconditional, loads from explicit
 // global pointers), so the compiler counts its waits instead of draining the memory pipe every step.
 template <bool FULL>
-__global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
+__device__ __forceinline__ void lstm64_bwd_body(const Lstm64BwdP& p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dgs = smem;              // [256 n][16 rows]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -378,6 +393,13 @@ __global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) {
 #undef L64_LOAD_BWD
 }
 
+template <bool FULL>
+__global__ __launch_bounds__(256) void lstm64_bwd_kernel(Lstm64BwdP p) { lstm64_bwd_body<FULL>(p); }
+static_assert(sizeof(Lstm64BwdP) == sizeof(MmegoLstm64Bwd) && offsetof(Lstm64BwdP, dgs) == offsetof(MmegoLstm64Bwd, dgs), "MmegoLstm64Bwd is Lstm64BwdP");
+struct Lstm64BwdMulti { Lstm64BwdP p[L64_MAX_MULTI]; };
+template <bool FULL>
+__global__ __launch_bounds__(256) void lstm64_bwd_multi_kernel(Lstm64BwdMulti m) { lstm64_bwd_body<FULL>(m.p[blockIdx.z]); }
+
 extern "C" int mmego_lstm64_backward(void* stream, int B, int T, const float* dout, long dos, const float* gates0,
                                      const float* gates1, const float* cst0, const float* cst1, const float* c0_0,
                                      const float* c0_1, const float* whh0, const float* whh1, float* dgates0,
@@ -394,6 +416,65 @@ extern "C" int mmego_lstm64_backward(void* stream, int B, int T, const float* do
   const size_t lds = (size_t)(256 * 16) * sizeof(float);
   if (B % 16 == 0) hipLaunchKernelGGL(lstm64_bwd_kernel<true>, dim3(cdiv(B, 16), 2), dim3(256), lds, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(lstm64_bwd_kernel<false>, dim3(cdiv(B, 16), 2), dim3(256), lds, (hipStream_t)stream, p);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// n <= 4 independent stacks' layers per launch.  descs: n host structs MmegoLstm64Fwd / MmegoLstm64Bwd (include/mmego_hip.h: the argument
+// lists of mmego_lstm64_forward / _backward as structs); every stack must have the same B and T and the same options (stashes for all or
+// none, dropout for all or none).
+extern "C" int mmego_lstm64_forward_multi(void* stream, int n, const void* descs) {
+  MMEGO_REQUIRE(descs && n >= 1 && n <= L64_MAX_MULTI);
+  const Lstm64P* h = static_cast<const Lstm64P*>(descs);
+  Lstm64Multi m;
+  const int B = h[0].B, T = h[0].T;
+  const bool st_ = h[0].gates[0] != nullptr, dr = h[0].drop_mask != nullptr;
+  for (int i = 0; i < n; ++i) {
+    const Lstm64P& p = h[i];
+    MMEGO_REQUIRE(p.B == B && p.T == T && B > 0 && T > 0 && p.xproj[0] && p.xproj[1] && p.whh[0] && p.whh[1] && p.out);
+    MMEGO_REQUIRE((((uintptr_t)p.whh[0] | (uintptr_t)p.whh[1]) & 15) == 0);
+    MMEGO_REQUIRE((p.drop_mask == nullptr) == (p.drop_y == nullptr) && (p.drop_mask != nullptr) == dr);
+    MMEGO_REQUIRE(!p.drop_mask || (p.seed_ctr && p.drop_p > 0.f && p.drop_p < 1.f && (long)B * T * p.os < (1L << 32)));
+    MMEGO_REQUIRE((p.gates[0] != nullptr) == st_ && (p.gates[1] != nullptr) == st_ && (p.cst[0] != nullptr) == st_ && (p.cst[1] != nullptr) == st_ &&
+                  (p.hprev[0] != nullptr) == st_ && (p.hprev[1] != nullptr) == st_);
+    m.p[i] = p;
+  }
+  for (int i = n; i < L64_MAX_MULTI; ++i) m.p[i] = h[0];
+  const size_t lds = (size_t)(64 * 16) * sizeof(float);
+  const bool full = B % 16 == 0;
+#define L64_FWDM_LAUNCH(F_, S_, D_) hipLaunchKernelGGL((lstm64_fwd_multi_kernel<F_, S_, D_>), dim3(cdiv(B, 16), 2, n), dim3(256), lds, (hipStream_t)stream, m)
+  if (full) {
+    if (st_ && dr) L64_FWDM_LAUNCH(true, true, true);
+    else if (st_) L64_FWDM_LAUNCH(true, true, false);
+    else if (dr) L64_FWDM_LAUNCH(true, false, true);
+    else L64_FWDM_LAUNCH(true, false, false);
+  } else {
+    if (st_ && dr) L64_FWDM_LAUNCH(false, true, true);
+    else if (st_) L64_FWDM_LAUNCH(false, true, false);
+    else if (dr) L64_FWDM_LAUNCH(false, false, true);
+    else L64_FWDM_LAUNCH(false, false, false);
+  }
+#undef L64_FWDM_LAUNCH
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_lstm64_backward_multi(void* stream, int n, const void* descs) {
+  MMEGO_REQUIRE(descs && n >= 1 && n <= L64_MAX_MULTI);
+  const Lstm64BwdP* h = static_cast<const Lstm64BwdP*>(descs);
+  Lstm64BwdMulti m;
+  const int B = h[0].B, T = h[0].T;
+  for (int i = 0; i < n; ++i) {
+    const Lstm64BwdP& p = h[i];
+    MMEGO_REQUIRE(p.B == B && p.T == T && B > 0 && T > 0 && p.dout && p.gates[0] && p.gates[1] && p.cst[0] && p.cst[1] && p.whh[0] && p.whh[1] &&
+                  p.dgates[0] && p.dgates[1]);
+    MMEGO_REQUIRE((((uintptr_t)p.whh[0] | (uintptr_t)p.whh[1]) & 15) == 0);
+    m.p[i] = p;
+  }
+  for (int i = n; i < L64_MAX_MULTI; ++i) m.p[i] = h[0];
+  const size_t lds = (size_t)(256 * 16) * sizeof(float);
+  if (B % 16 == 0) hipLaunchKernelGGL(lstm64_bwd_multi_kernel<true>, dim3(cdiv(B, 16), 2, n), dim3(256), lds, (hipStream_t)stream, m);
+  else hipLaunchKernelGGL(lstm64_bwd_multi_kernel<false>, dim3(cdiv(B, 16), 2, n), dim3(256), lds, (hipStream_t)stream, m);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

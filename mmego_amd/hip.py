@@ -120,6 +120,27 @@ class DwRed(ctypes.Structure):
                 ("nblk", ctypes.c_int), ("stride", ctypes.c_long)]
 
 
+class Lstm64Fwd(ctypes.Structure):
+    """MmegoLstm64Fwd of include/mmego_hip.h: one stack's layer for mmego_lstm64_forward_multi."""
+    _P2 = ctypes.c_void_p * 2
+    _fields_ = [("xproj", _P2), ("xs", ctypes.c_long), ("whh", _P2), ("bhh", _P2), ("h0", _P2), ("c0", _P2),
+                ("out", ctypes.c_void_p), ("os", ctypes.c_long), ("hn", _P2), ("cn", _P2), ("gates", _P2), ("cst", _P2), ("hprev", _P2),
+                ("B", ctypes.c_int), ("T", ctypes.c_int), ("drop_y", ctypes.c_void_p), ("drop_mask", ctypes.c_void_p),
+                ("drop_p", ctypes.c_float), ("seed_ctr", ctypes.c_void_p), ("salt", ctypes.c_uint)]
+
+
+class Lstm64Bwd(ctypes.Structure):
+    """MmegoLstm64Bwd of include/mmego_hip.h."""
+    _P2 = ctypes.c_void_p * 2
+    _fields_ = [("dout", ctypes.c_void_p), ("dos", ctypes.c_long), ("gates", _P2), ("cst", _P2), ("c0", _P2), ("whh", _P2),
+                ("dgates", _P2), ("dgs", ctypes.c_long), ("B", ctypes.c_int), ("T", ctypes.c_int)]
+
+
+def pair2(a, b):
+    """Two device addresses as a descriptor's pointer pair."""
+    return (ctypes.c_void_p * 2)(ptr(a), ptr(b))
+
+
 class Slab(ctypes.Structure):
     """MmegoSlab of include/mmego_hip.h: one deferred partial-product sum."""
     _fields_ = [("ws", ctypes.c_void_p), ("out", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("asum", ctypes.c_void_p),

@@ -153,8 +153,6 @@ class UpperNetwlocal(_NetBase):
             blocks.attn_pool_forward(g3, gpn.attn, F, N, 64, vec, gw)
         p_g = self._drop_p(self.module1.grnn) if stash else 0.0
         cat = ar.get("cat", (F, 256))
-        seq_g, hn_g, cn_g = blocks.lstm64_forward(ar, "grnn", self.module1.grnn, vec, B, T, h0g, c0g, stash, p_g, self.seed_counter())
-        ops.copy2d(seq_g, cat[:, :128])
         # local branch: grouping -> LocalPointNet (+attention pool over the 8 members) -> voxel net -> BiLSTM
         grows = F * N_ANCHOR * N_GROUP
         gidx = ar.get("gidx", (F, N_ANCHOR, N_GROUP), dtype=torch.int64)
@@ -202,8 +200,12 @@ class UpperNetwlocal(_NetBase):
         vvec = ar.get("vvec", (F, 64))
         blocks.mlp3_forward(ar, "vx", self.module2.avoxel, voxT, vvec, training)
         p_a = self._drop_p(self.module2.arnn.rnn) if stash else 0.0
-        seq_a, hn_a, cn_a = blocks.lstm64_forward(ar, "arnn", self.module2.arnn.rnn, vvec, B, T, h0a, c0a, stash, p_a, self.seed_counter(), salt=1)
-        ops.copy2d(seq_a, cat[:, 128:])
+        # the global and the anchor BiLSTM(64) stacks (Net/Upper_Net.py:333-339, :208-216: same shape, nothing in common) layer by layer side
+        # by side: one sequence-kernel launch per layer for both (blocks.lstm64_forward_multi)
+        (seq_g, hn_g, cn_g), (seq_a, hn_a, cn_a) = blocks.lstm64_forward_multi(
+            ar, [("grnn", self.module1.grnn, vec, h0g, c0g, p_g, self.seed_counter(), 0),
+                 ("arnn", self.module2.arnn.rnn, vvec, h0a, c0a, p_a, self.seed_counter(), 1)], B, T, stash,
+            last_out=(cat[:, :128], cat[:, 128:]))          # (the last layers write the two halves of the concatenation themselves)
         # combine head
         h1 = ar.get("h1", (F, 128))
         ops.linear(cat, self.module3.fc1.weight, self.module3.fc1.bias, h1, relu=True)
@@ -236,7 +238,10 @@ class UpperNetwlocal(_NetBase):
         with blocks.dw_reduce_group():                         # the three chains' weight-gradient partials: one reduce launch
             # global branch
             vec = ar.get("vec", (F, 64))
-            dvec = blocks.lstm64_backward(ar, "grnn", self.module1.grnn, vec, B, T, c0g, dcat[:, :128], G, self._drop_p(self.module1.grnn), True)
+            vvec = ar.get("vvec", (F, 64))
+            dvec, dvvec = blocks.lstm64_backward_multi(
+                ar, [("grnn", self.module1.grnn, vec, c0g, dcat[:, :128], self._drop_p(self.module1.grnn)),
+                     ("arnn", self.module2.arnn.rnn, vvec, c0a, dcat[:, 128:], self._drop_p(self.module2.arnn.rnn))], B, T, G, True)
             g3, dg3 = ar.get("g3", (rows, 64)), ar.get("dg3", (rows, 64))
             feats = ar.get("feats", (rows, 28))
             gpn = self.module1.gpointnet
@@ -247,9 +252,6 @@ class UpperNetwlocal(_NetBase):
                 blocks.attn_pool_backward(ar, "gpool", g3, gpn.attn, gw, dvec, F, N, 64, dg3, G)
                 dfeats = blocks.mlp3_backward(ar, "gp", gpn, feats, g3, dg3, G, True)
             # local branch
-            vvec = ar.get("vvec", (F, 64))
-            dvvec = blocks.lstm64_backward(ar, "arnn", self.module2.arnn.rnn, vvec, B, T, c0a, dcat[:, 128:], G,
-                                           self._drop_p(self.module2.arnn.rnn), True)
             voxT = ar.get("voxT", (F, 64 * N_ANCHOR))
             dvoxT = blocks.mlp3_backward(ar, "vx", self.module2.avoxel, voxT, vvec, dvvec, G, True)
             gidx = ar.get("gidx", (F, N_ANCHOR, N_GROUP), dtype=torch.int64)

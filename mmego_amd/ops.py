@@ -164,7 +164,8 @@ def stacked(a, b):
     """One [na + nb, ...] view over ``a`` and ``b`` when ``b`` sits directly behind ``a`` in memory (two tensors laid out back to
     back in a flat parameter / gradient buffer: params.FlatParams, a module's flat_param_order), else None."""
     if (a.dtype != b.dtype or tuple(a.shape[1:]) != tuple(b.shape[1:]) or not a.is_contiguous() or not b.is_contiguous()
-            or b.data_ptr() != a.data_ptr() + a.numel() * a.element_size()):
+            or b.data_ptr() != a.data_ptr() + a.numel() * a.element_size()
+            or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()):     # (neighbours by chance in the allocator are not one buffer)
         return None
     return torch.as_strided(a.detach(), (a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), a.stride())
 

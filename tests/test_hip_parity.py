@@ -250,6 +250,55 @@ def test_lstm64_fused_dropout_and_bias_pair(dev):
     assert torch.equal(dx, dx2 * masks[0])
 
 
+@pytest.mark.parametrize("B,T,p", [(64, 8, 0.1), (13, 5, 0.0), (16, 3, 0.1)])
+def test_lstm64_stacks_side_by_side_are_the_separate_launches(dev, B, T, p):
+    """mmego_lstm64_forward_multi / _backward_multi (UpperNetwlocal's global and anchor stacks in one launch per layer, grid z = stack):
+    every output, stash, dropout mask, input gradient and weight gradient bit-identical to the stacks run one after the other; the
+    last layers may write the halves of a wider tensor (the nets' concatenation)."""
+    from mmego_amd import blocks, ops
+    torch.manual_seed(11)
+    lstms = [blocks.LstmParams(64, 64, 3, dropout=0.1).to(dev) for _ in range(2)]
+    xs = [torch.randn(B * T, 64, device=dev) for _ in range(2)]
+    h0 = [torch.randn(6, B, 64, device=dev) * 0.3 for _ in range(2)]
+    c0 = [torch.randn(6, B, 64, device=dev) * 0.3 for _ in range(2)]
+    seed = torch.tensor([777], dtype=torch.int64, device=dev)
+    douts = [torch.randn(B * T, 128, device=dev) for _ in range(2)]
+
+    def grads():
+        store = {}
+        def G(t):
+            return store.setdefault(t.data_ptr(), torch.zeros_like(t))
+        return store, G
+
+    ar1, ar2 = ops.Arena(dev), ops.Arena(dev)
+    sep = [blocks.lstm64_forward(ar1, "s%d" % i, lstms[i], xs[i], B, T, h0[i], c0[i], True, p, seed, salt=i) for i in range(2)]
+    cat = torch.zeros(B * T, 256, device=dev)
+    both = blocks.lstm64_forward_multi(ar2, [("s%d" % i, lstms[i], xs[i], h0[i], c0[i], p, seed, i) for i in range(2)], B, T, True,
+                                       last_out=(cat[:, :128], cat[:, 128:]))
+    for i in range(2):
+        assert torch.equal(cat[:, 128 * i:128 * i + 128], sep[i][0])
+        assert torch.equal(both[i][1], sep[i][1]) and torch.equal(both[i][2], sep[i][2])
+        for l in range(3):
+            for n, shape in (("g", (2, T, B, 256)), ("c", (2, T, B, 64)), ("hp", (2, B * T, 64))) + ((("mk", (B * T, 128)),) if p > 0 and l < 2 else ()):
+                key = "s%d.%s%d" % (i, n, l)
+                assert torch.equal(ar1.get(key, shape), ar2.get(key, shape)), key
+    st1, G1 = grads()
+    st2, G2 = grads()
+    dx_sep = [blocks.lstm64_backward(ar1, "s%d" % i, lstms[i], xs[i], B, T, c0[i], douts[i], G1, p, True) for i in range(2)]
+    dx_both = blocks.lstm64_backward_multi(ar2, [("s%d" % i, lstms[i], xs[i], c0[i], douts[i], p) for i in range(2)], B, T, G2, True)
+    for i in range(2):
+        assert torch.equal(dx_sep[i], dx_both[i])
+    assert st1.keys() == st2.keys() and len(st1) == 2 * 3 * 2 * 4
+    for k in st1:
+        assert torch.equal(st1[k], st2[k])
+    # eval form (no stashes, no dropout)
+    ar3 = ops.Arena(dev)
+    ev = blocks.lstm64_forward_multi(ar3, [("s%d" % i, lstms[i], xs[i], None, None, 0.0, None, i) for i in range(2)], B, T, False)
+    for i in range(2):
+        ref = blocks.lstm64_forward(ops.Arena(dev), "e", lstms[i], xs[i], B, T, None, None, False, 0.0, None)
+        assert torch.equal(ev[i][0], ref[0]) and torch.equal(ev[i][1], ref[1])
+
+
 def _seq(real16, i, device=None):
     x = T(real16["x"][i:i + 1]).clone()
     tgt = T(real16["target"][i:i + 1])
