@@ -1030,9 +1030,8 @@ def main():
 
         def eager():
             # the same recurrence forms as the timed arrangement (train_step.ConcurrentStages): both IMU_Net forwards run their
-            # rnn_fast recurrences as two single-direction chains (MMEGO_ALL_IMU_TWO_CHAINS=0: the Upper stage's, which has the
-            # Lower tail beside it, as one launch per timestep for both directions).
-            with _blocks.two_chains(args.sequential or os.environ.get("MMEGO_ALL_IMU_TWO_CHAINS", "1") != "0"):
+            # rnn_fast recurrences as two single-direction chains.
+            with _blocks.two_chains(True):
                 su_e._body()
             with _blocks.two_chains(True):
                 sl_e._body()

@@ -41,19 +41,13 @@ class LstmParams(nn.Module):
 # ---------------------------------------------------------------------------------------------------
 # three (k=1 conv, BatchNorm, ReLU) stages over rows
 # ---------------------------------------------------------------------------------------------------
-_FUSED_EVAL_MLP = os.environ.get("MMEGO_FUSED_EVAL_MLP", "1") != "0"
-
-
 def _mlp3_layers(mod):
     return ((mod.conv1, mod.cb1), (mod.conv2, mod.cb2), (mod.conv3, mod.cb3))
 
 
-_FUSED_TRAIN_MLP = os.environ.get("MMEGO_FUSED_TRAIN_MLP", "1") != "0"
-
-
 def _mlp3_fused_train(mod, x):
     dims = [mod.conv1.weight.numel() // mod.conv1.weight.shape[0]] + [c.weight.shape[0] for c in (mod.conv1, mod.conv2, mod.conv3)]
-    return _FUSED_TRAIN_MLP and max(dims) <= 64 and x.stride(1) == 1
+    return max(dims) <= 64 and x.stride(1) == 1
 
 
 def _mlp3_forward_fused(ar, key, mod, x, out_last, pool=None):
@@ -157,7 +151,7 @@ class dw_reduce_group:
         return False
 
 
-_POOL_FUSED = os.environ.get("MMEGO_POOL_FUSED", "1") != "0"
+_POOL_FUSED = True        # (False: the pooling as its own launches -- what other shapes take; tests compare the two)
 
 
 def pool128_fusable(mod, x, P, training):
@@ -182,7 +176,7 @@ def mlp3_forward(ar, key, mod, x, out_last, training, pool=None, bf16=False):
         layers = _mlp3_layers(mod)
         dims = [conv.weight.shape[0] for conv, _ in layers]
         Cin = layers[0][0].weight.numel() // dims[0]
-        if (_FUSED_EVAL_MLP and Cin <= 32 and dims[0] <= 32 and dims[1] <= 64 and dims[2] <= 64 and x.stride(1) == 1
+        if (Cin <= 32 and dims[0] <= 32 and dims[1] <= 64 and dims[2] <= 64 and x.stride(1) == 1
                 and out_last.stride(1) == 1 and len({bn.eps for _, bn in layers}) == 1):
             # BatchNorm folded by the kernel itself while it stages the weights: no fold launches
             bnp = torch.tensor([t.data_ptr() for _, bn in layers for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)],
@@ -458,8 +452,7 @@ def attn_pool_backward(ar, key, X, lin, attn, dvec, G_, P, C, dX, G):
 # ---------------------------------------------------------------------------------------------------
 # generic-H step-kernel LSTM stack (forward only): IMU_Net's rnn_fast / rnn_slow
 # ---------------------------------------------------------------------------------------------------
-_LSTM_TWO_CHAINS_DEFAULT = os.environ.get("MMEGO_LSTM_TWO_CHAINS", "1") != "0"
-_LSTM_TWO_CHAINS = _LSTM_TWO_CHAINS_DEFAULT
+_LSTM_TWO_CHAINS = True
 _side_streams = {}
 
 
@@ -474,7 +467,7 @@ class two_chains:
 
     def __enter__(self):
         global _LSTM_TWO_CHAINS
-        self.was, _LSTM_TWO_CHAINS = _LSTM_TWO_CHAINS, bool(self.on) and _LSTM_TWO_CHAINS_DEFAULT
+        self.was, _LSTM_TWO_CHAINS = _LSTM_TWO_CHAINS, bool(self.on)
         return self
 
     def __exit__(self, *exc):
@@ -483,7 +476,7 @@ class two_chains:
         return False
 
 
-_LSTM_SEQ_XCD = os.environ.get("MMEGO_LSTM_SEQ_XCD", "1") != "0"
+_LSTM_SEQ_XCD = True
 
 
 class seq_xcd:
@@ -539,7 +532,7 @@ def seq_xcd_raise():
     if n:
         raise RuntimeError("mmego_lstm_seq_xcd: %d persistent recurrence buffer(s) report a launch whose workgroups could not all be "
                            "resident (shared / partitioned device?) -- the head poses computed since the last check are invalid. "
-                           "Set MMEGO_LSTM_SEQ_XCD=0 to use one launch per timestep." % n)
+                           "blocks.seq_xcd(False) runs the recurrence as one launch per timestep." % n)
 
 
 def _side_stream(cur):
@@ -684,7 +677,7 @@ def lstm_bf16_weights_fused(lstm):
     return layers
 
 
-FUSED_MIN_ROWS = int(os.environ.get("MMEGO_BF16_FUSED_MIN", "2048"))
+FUSED_MIN_ROWS = 2048
 
 
 def fused_input_fragments(ar, key, Bn, T, In):
@@ -775,7 +768,7 @@ def lstm_steps_forward_bf16(ar, key, lstm, x, Bn, T):
 # fp32 operand as three bf16 pieces (exact), six piece products per product, fp32 accumulation
 # ---------------------------------------------------------------------------------------------------
 SPLIT3_NPROD = int(os.environ.get("MMEGO_SPLIT3_NPROD", "6"))       # 6: dropped terms <= 2^-24 relative; 9: all piece products
-SPLIT3_WM = int(os.environ.get("MMEGO_SPLIT3_WM", "0"))             # projection tile rows / 64 (0: the library's choice)
+SPLIT3_WM = 0             # projection tile rows / 64 (0: the library's choice)
 # 1: a layer's recurrence as two chains of single-direction launches on 16-unit workgroups (mmego_split3_step16).  OFF by default:
 # that kernel is correct and 4 % faster per forward when the forward runs alone, but a workgroup of it that shares a CU with
 # head_fk_loss_kernel<1> (geom.hip; the Lower stage's turning point, which runs beside the Upper stage's IMU_Net forward in

@@ -1138,18 +1138,16 @@ extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H,
   p.o.hfrag[0] = hfrag0; p.o.hfrag[1] = hfrag1;
   p.o.c[0] = c0; p.o.c[1] = c1;
   p.o.Bn = Bn; p.o.H = H; p.o.first = first;
-  // WR = 1 (128 rows per WG, 128 VGPRs, four WGs per CU) by default; MMEGO_BF16_FUSED_WR=2 (256 rows, two WGs per CU, half the
-  // weight-tile reads per MFMA) for A/B runs: 20.3 - 20.5 ms per config-5 IMU_Net forward either way.  Also measured without
+  // WR = 1 (128 rows per WG, 128 VGPRs, four WGs per CU); WR = 2 (256 rows, two WGs per CU, half the weight-tile reads per MFMA)
+  // measured 20.3 - 20.5 ms per config-5 IMU_Net forward either way and went with its knob in r05.  Also measured without
   // effect on that figure: the weight tile double-buffered in LDS (one barrier per chunk), L2 super-tiles of 8 x 2, 16 x 1, 2 x 8
   // (hidden x row blocks) instead of 4 x 4.
-  static const int wr2 = getenv("MMEGO_BF16_FUSED_WR") ? atoi(getenv("MMEGO_BF16_FUSED_WR")) == 2 : 0;
-  // 256 x 256 tiles (persistent, LDS-DMA operands, eight waves) where the shape allows; MMEGO_BF16_FUSED_256=0 keeps the 128-row kernel
-  static const int t256 = getenv("MMEGO_BF16_FUSED_256") ? atoi(getenv("MMEGO_BF16_FUSED_256")) : 1;
+  // 256 x 256 tiles (persistent, LDS-DMA operands, eight waves) where the shape allows, else the 128-row kernel
   bool k64 = true;
   for (int q = 0; q < p.nseg; ++q) k64 = k64 && p.S[q] % 4 == 0;
   // (also where the tiles do not fill the chip -- 2048 rows at H = 512: 128 tiles on 128 CUs: config 5 25.3 ms against 25.7 with the
   //  128-row kernel there)
-  if (t256 && ndir == 2 && Bn % 256 == 0 && H % 64 == 0 && k64) {
+  if (ndir == 2 && Bn % 256 == 0 && H % 64 == 0 && k64) {
     constexpr int lds = 2 * 64 * 1024 + 8 * 4096;      // two ring stages + 4 KB per wave for the h_t fragments
     static bool attr_set = false;
     if (!attr_set) {
@@ -1160,13 +1158,10 @@ extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H,
     }
     MMEGO_REQUIRE((hout0 == nullptr) == (hout1 == nullptr));
     const int ntiles = 2 * (H / 64) * (Bn / 256);
-    static const int maxwg = getenv("MMEGO_BF16_FUSED_WGS") ? atoi(getenv("MMEGO_BF16_FUSED_WGS")) : 256;
+    constexpr int maxwg = 256;
     dim3 grid(ntiles < maxwg ? ntiles : maxwg, 1, 1);
     if (hout0) lstm_step_bf16_fused256_kernel<true><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles);
     else lstm_step_bf16_fused256_kernel<false><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles);
-  } else if (wr2) {
-    dim3 grid(H / 32, cdiv(Bn, 256), ndir);
-    lstm_step_bf16_fused_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(p);
   } else {
     dim3 grid(H / 32, cdiv(Bn, 128), ndir);
     lstm_step_bf16_fused_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(p);

@@ -791,8 +791,7 @@ static int tconv_seq_launch(hipStream_t st, TconvSeqP& p, bool rec) {
   dim3 grid((unsigned)p.B, (unsigned)(p.Cout / 32));
   // a grid of at most one workgroup per CU whose workgroups are matrix-pipe bound (128 channels: 576 MFMAs per wave): ask for more
   // than half a CU's LDS so that the dispatcher cannot put two of them on one CU while another CU stays empty
-  static const bool spread = getenv("MMEGO_TCONV_SEQ_NOSPREAD") == nullptr;
-  if (spread && nk >= 4 && (long)grid.x * grid.y <= 256 && lds < 84 * 1024) lds = 84 * 1024;
+  if (nk >= 4 && (long)grid.x * grid.y <= 256 && lds < 84 * 1024) lds = 84 * 1024;
 #define TS_LAUNCH(NK_, REC_)                                                                                          \
   do {                                                                                                                \
     static size_t attr = 0;                                                                                           \

@@ -39,6 +39,10 @@ struct GemmP {
 };
 
 #define LD64 68
+// kernel choice (ops.py mirrors both): the other operand orientations take the tile kernels from this many 64x64 work units; up to
+// GEMM_KQ_MAX 64x64 workgroups a product runs on K-quartered 32x32 tiles
+constexpr long GEMM_TILE_MIN_OTHER = 256;
+constexpr int GEMM_KQ_MAX = 512;
 
 // 64x64xBK tiles, BK = 64 (16 when the K range of a workgroup is shorter than 64).  These products are small
 // (<= 1 GFLOP) and their k-loop is bound by the global-load latency of each step, not by the matrix cores (BK = 16:
@@ -530,12 +534,11 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
     const int kchunk_t = nsplit > 1 ? cdiv(cdiv(K, nsplit), 64) * 64 : K;
     // k-contiguous x k-contiguous products take the tile kernels at any size (measured better than the K-quartered kernel
     // even for 32 tiles); the other orientations only when there are enough 64x64 work units to fill the chip.
-    static const long tile_min_other = getenv("MMEGO_GEMM_TILE_MIN") ? atol(getenv("MMEGO_GEMM_TILE_MIN")) : 256;
+    constexpr long tile_min_other = GEMM_TILE_MIN_OTHER;
     // (a long-K product with few tiles is a serial chain of load-latency-bound chunks: the K-quartered kernel is better)
     const long tile_min_units = (a_kc && b_kc && nsplit == 1) ? (K <= 1024 ? 1 : 200) : tile_min_other;
     const long units64 = (long)(M / 64) * (N / 64) * nsplit * nbatch;
-    static const bool nt_only = getenv("MMEGO_GEMM_TILE_NT_ONLY") != nullptr;
-    const bool ok = !cmul && !asum && !(nt_only && !(a_kc && b_kc && nsplit == 1 && !accumulate)) && scn == 1 && (nbatch == 1 || ((sAb % 4) == 0 && (sBb % 4) == 0)) && (a_kc || a_mc) && (b_kc || b_mc) && (lda % 4) == 0 && (ldw % 4) == 0 &&
+    const bool ok = !cmul && !asum && scn == 1 && (nbatch == 1 || ((sAb % 4) == 0 && (sBb % 4) == 0)) && (a_kc || a_mc) && (b_kc || b_mc) && (lda % 4) == 0 && (ldw % 4) == 0 &&
                     (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (M % 64) == 0 && (N % 64) == 0 &&
                     (K % 64) == 0 && units64 >= tile_min_units && (nsplit == 1 || (long)(nsplit - 1) * kchunk_t < K);
     if (ok) {
@@ -588,7 +591,7 @@ extern "C" int mmego_gemm(void* stream, const float* A, long sam, long sak, cons
   }
   MMEGO_REQUIRE(cdiv(N, 32) <= 65535 && (long)nbatch * nsplit <= 65535);
   const long wgs64 = (long)cdiv(M, 64) * cdiv(N, 64) * nbatch * nsplit;
-  static const int kq_max = getenv("MMEGO_GEMM_KQ_MAX") ? atoi(getenv("MMEGO_GEMM_KQ_MAX")) : 512;
+  constexpr int kq_max = GEMM_KQ_MAX;
   const bool kq = wgs64 <= kq_max && p.kchunk >= 64;     // few tiles and a k-chain worth cutting: K-quartered 32x32 tiles
   MMEGO_REQUIRE(!asum || kq);                            // (row sums of A: the K-quartered kernel only; callers check with ops)
   dim3 grid(cdiv(M, kq ? 32 : 64), cdiv(N, kq ? 32 : 64), nbatch * nsplit);
@@ -664,10 +667,9 @@ extern "C" int mmego_lstm_bwd_step(void* stream, int Bn, int H, const float* dg0
 // otherwise one mmego_gemm call each, in order -- the results are the same either way.
 extern "C" int mmego_gemm_group(void* stream, int n, const MmegoGemmDesc* d) {
   MMEGO_REQUIRE(n >= 1 && d);
-  static const long tile_min_other = getenv("MMEGO_GEMM_TILE_MIN") ? atol(getenv("MMEGO_GEMM_TILE_MIN")) : 256;
-  static const int kq_max = getenv("MMEGO_GEMM_KQ_MAX") ? atoi(getenv("MMEGO_GEMM_KQ_MAX")) : 512;
-  static const int group_on = getenv("MMEGO_GEMM_GROUP") ? atoi(getenv("MMEGO_GEMM_GROUP")) : 1;
-  bool ok = group_on && n >= 2 && n <= GEMM_GROUP_MAX;
+  constexpr long tile_min_other = GEMM_TILE_MIN_OTHER;
+  constexpr int kq_max = GEMM_KQ_MAX;
+  bool ok = n >= 2 && n <= GEMM_GROUP_MAX;
   const bool akc = d[0].sak == 1, bkc = d[0].sbk == 1;
   GemmGroup g;
   unsigned gx = 0, gy = 0;

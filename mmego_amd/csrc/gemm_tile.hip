@@ -210,13 +210,10 @@ __global__ __launch_bounds__(256) void gemm_tile_persistent_kernel(TileP p, int 
 
 namespace mmego_detail {
 
-// k per staged chunk: 32 by default (measured at least as fast as 64 for the persistent kernel -- 207.8 / 348.9 us against
-// 210.5 / 353.1 us on the 10240 x 2048 x {512, 1024} projections -- and it halves the LDS footprint: 36.9 KB per 128x128
-// workgroup, so a 72-KB recurrent-step workgroup of another branch fits beside the two GEMM workgroups of a CU).
-static int chunk_k() {
-  static const int kch = getenv("MMEGO_GEMM_KC") ? atoi(getenv("MMEGO_GEMM_KC")) : 32;
-  return kch == 64 ? 64 : 32;
-}
+// k per staged chunk: 32 (measured at least as fast as 64 for the persistent kernel -- 207.8 / 348.9 us against 210.5 / 353.1 us on the
+// 10240 x 2048 x {512, 1024} projections -- and it halves the LDS footprint: 36.9 KB per 128x128 workgroup, so a 72-KB recurrent-step
+// workgroup of another branch fits beside the two GEMM workgroups of a CU).  The 64-k instantiations went with their knob in r05.
+constexpr int GT_KCH = 32;
 
 template <int BM, int BN, bool A_KC, bool B_KC, int KCH>
 static int launch_plain_k(hipStream_t st, const TileP& p) {
@@ -235,11 +232,7 @@ static int launch_plain_k(hipStream_t st, const TileP& p) {
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC>
-static int launch_plain(hipStream_t st, const TileP& p) {
-  static const int plain_kc = getenv("MMEGO_GEMM_PLAIN_KC") ? atoi(getenv("MMEGO_GEMM_PLAIN_KC")) : chunk_k();
-  if (plain_kc == 32 && (p.kchunk % 32) == 0) return launch_plain_k<BM, BN, A_KC, B_KC, 32>(st, p);
-  return launch_plain_k<BM, BN, A_KC, B_KC, 64>(st, p);
-}
+static int launch_plain(hipStream_t st, const TileP& p) { return launch_plain_k<BM, BN, A_KC, B_KC, GT_KCH>(st, p); }
 
 template <bool A_KC, bool B_KC>
 static int launch_layout(hipStream_t st, const TileP& p) {
@@ -255,40 +248,26 @@ static int launch_layout(hipStream_t st, const TileP& p) {
     // workgroups leaves no registers for another kernel's waves, a single one leaves 300 per lane.
     static const int slots = getenv("MMEGO_GEMM_SLOTS") ? atoi(getenv("MMEGO_GEMM_SLOTS")) : 512;
     const int units = (int)units128;
-    static const bool no_persist = getenv("MMEGO_GEMM_NO_PERSIST") != nullptr;
-    static const int stagger = getenv("MMEGO_GEMM_NO_STAGGER") == nullptr;
     // (K <= 128: two chunks per tile -- the tile is its 64-KB store; the static walk's two tiles per workgroup then run one after
     // the other, load latency and store each exposed: 59 us for the 32768 x 512 x 64 BiLSTM(64) projections of config 5.  The plain
     // grid keeps four workgroups per CU in flight.)
-    static const int persist_min_k = getenv("MMEGO_GEMM_PERSIST_MIN_K") ? atoi(getenv("MMEGO_GEMM_PERSIST_MIN_K")) : 129;
-    if (units > slots && !no_persist && p.K >= persist_min_k) {
+    if (units > slots && p.K > 128) {
       const int rest = units % slots;
       const bool halves = rest > 0 && rest <= slots / 2;
       const int nfull = halves ? units - rest : units, nhalf = halves ? 2 * rest : 0;
-      if (chunk_k() == 32 && (p.kchunk % 32) == 0) {
-        size_t lds = (size_t)(256 * 36) * sizeof(float);
-        if (slots <= 256) {
-          static bool attr32 = false;
-          lds = 84 * 1024;
-          if (!attr32) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_persistent_kernel<A_KC, B_KC, 32>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            attr32 = true;
-          }
-        }
-        hipLaunchKernelGGL((gemm_tile_persistent_kernel<A_KC, B_KC, 32>), dim3(slots), dim3(256), lds, st, p, nfull, nhalf, stagger);
-      } else {
-        static bool attr_set = false;
-        const size_t lds = (size_t)(256 * TLD_MAX) * sizeof(float);
-        if (!attr_set) {
-          hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_persistent_kernel<A_KC, B_KC, 64>,
+      size_t lds = (size_t)(256 * (GT_KCH + 4)) * sizeof(float);
+      if (slots <= 256) {
+        static bool attr32 = false;
+        lds = 84 * 1024;
+        if (!attr32) {
+          hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_persistent_kernel<A_KC, B_KC, GT_KCH>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           if (e != hipSuccess) return (int)e;
-          attr_set = true;
+          attr32 = true;
         }
-        hipLaunchKernelGGL((gemm_tile_persistent_kernel<A_KC, B_KC, 64>), dim3(slots), dim3(256), lds, st, p, nfull, nhalf, stagger);
       }
+      // (second half of the grid starts with its half tiles: the walk's tail is staggered)
+      hipLaunchKernelGGL((gemm_tile_persistent_kernel<A_KC, B_KC, GT_KCH>), dim3(slots), dim3(256), lds, st, p, nfull, nhalf, 1);
       hipError_t e = hipGetLastError();
       return e == hipSuccess ? 0 : (int)e;
     }

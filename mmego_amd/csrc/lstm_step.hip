@@ -26,7 +26,6 @@ struct LstmStepP {
   float* gst[2];   // optional stash for backward: post-activation gates [Bn][4H] and new cell state [Bn][H] of this step
   float* cst[2];
   int Bn, H, ndir, first;
-  int xcd_strided;
 #ifdef MMEGO_STAMP
   int dbg;         // diagnostic probe only (scripts/clock_probe.hip): 1 = loaders do not wait for DMAs, 2 = no DMAs, 4 = no ds_reads
 #endif
@@ -81,8 +80,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int xcd = wg & 7, q = wg >> 3;
       // an XCD takes a CONTIGUOUS run of hidden blocks: at HT = 16 a (row, gate) segment of xproj / c / h is 64 bytes, half a
       // cache line, and the neighbouring hidden block's workgroup reads the other half -- on the same XCD the pair shares one
-      // L2 fill (MMEGO_STEP_XCD_STRIDED=1: the r02 order, hidden blocks xcd, xcd + 8, ...)
-      pair = p.xcd_strided ? xcd + 8 * (q / nrb) : xcd * (npairs >> 3) + (q / nrb);
+      // L2 fill (the r02 order was strided: hidden blocks xcd, xcd + 8, ...)
+      pair = xcd * (npairs >> 3) + (q / nrb);
       rb = q % nrb;
     } else {
       pair = wg / nrb;
@@ -460,21 +459,17 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
   p.gst[0] = gst0; p.gst[1] = gst1; p.cst[0] = cst0; p.cst[1] = cst1;
   MMEGO_REQUIRE((gst0 == nullptr) == (cst0 == nullptr) && (gst1 == nullptr) == (cst1 == nullptr));
   p.Bn = Bn; p.H = H; p.ndir = ndir; p.first = first;
-  static const int xcd_strided = getenv("MMEGO_STEP_XCD_STRIDED") ? atoi(getenv("MMEGO_STEP_XCD_STRIDED")) : 0;
-  p.xcd_strided = xcd_strided;
 #ifdef MMEGO_STAMP
   p.dbg = mmego_step_dbg;
 #endif
-  static const int first_ew = getenv("MMEGO_STEP_FIRST_ELEMENTWISE") ? atoi(getenv("MMEGO_STEP_FIRST_ELEMENTWISE")) : 1;
   const uintptr_t al = (uintptr_t)bhh0 | (uintptr_t)bhh1 | (uintptr_t)gst0 | (uintptr_t)gst1 | (uintptr_t)cst0 | (uintptr_t)cst1 |
                        (uintptr_t)c1 | (uintptr_t)hout1 | (uintptr_t)xproj1;
-  if (first && first_ew && (H % 4) == 0 && (al & 15) == 0) {
+  if (first && (H % 4) == 0 && (al & 15) == 0) {
     long b = ((long)Bn * (H / 4) + 255) / 256;
     hipLaunchKernelGGL(lstm_first_step_kernel, dim3((unsigned)(b > 2048 ? 2048 : b), ndir), dim3(256), 0, (hipStream_t)stream, p);
   } else if (Bn >= 128) {
-    // HT = 32 by default; MMEGO_STEP_HT=16 selects the two-workgroups-per-CU variant for A/B runs (its product loop is
-    // shorter, 37.9 k against 41.1 k cycles, but its prologue -- twice the workgroups fetching first chunks -- costs more)
-    static const int force_ht = getenv("MMEGO_STEP_HT") ? atoi(getenv("MMEGO_STEP_HT")) : 0;
+    // HT = 32 by default (the HT = 16 two-workgroups-per-CU variant: shorter product loop, 37.9 k against 41.1 k cycles, but its
+    // prologue -- twice the workgroups fetching first chunks -- costs more)
     static int ncu = 0;
     if (!ncu) {
       int dev = 0;
@@ -485,7 +480,7 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
     // (both directions in one launch, Bn = H = 512: 26.7 us with HT 16 against 24.3 us with HT 32 per step.)  A launch that
     // would fill at most HALF the chip with HT = 32 -- one direction of the pair, launched on its own stream -- takes HT = 16:
     // then each direction's grid covers every CU once and the two directions' workgroups share the CUs out of phase
-    const bool ht16 = force_ht ? force_ht == 16 : 2 * grid32 <= ncu;
+    const bool ht16 = 2 * grid32 <= ncu;
     static bool attr32 = false, attr16 = false;
     if (ht16) {
       const size_t lds = (size_t)3 * (64 + 64) * 32 * sizeof(float);
@@ -507,9 +502,7 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
   } else {
     int grid = ndir * (H / 4) * cdiv(Bn, 64);
     const bool full = (Bn % 64) == 0;
-    // (128-k chunks -- half as many dependent chunk round trips, 84.5 KB of LDS -- measured the same 9.9-10.0 us: kept for A/B runs)
-    static const int small_sk = getenv("MMEGO_STEP_SMALL_SK") ? atoi(getenv("MMEGO_STEP_SMALL_SK")) : 64;
-    static const int small_all = getenv("MMEGO_STEP_SMALL_ALL") ? atoi(getenv("MMEGO_STEP_SMALL_ALL")) : 1;   // (0: one chunk ahead, for A/B runs)
+    // (128-k chunks -- half as many dependent chunk round trips, 84.5 KB of LDS -- measured the same 9.9-10.0 us: not kept)
 #define SMALL_LAUNCH(SK_, F_)                                                                                        \
   do {                                                                                                               \
     const size_t lds = (size_t)2 * (64 + 16) * (SK_ + 4) * sizeof(float);                                            \
@@ -522,8 +515,7 @@ extern "C" int mmego_lstm_step(void* stream, int ndir, int Bn, int H, int first,
     }                                                                                                                \
     hipLaunchKernelGGL((lstm_step_small_kernel<SK_, F_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);       \
   } while (0)
-    if ((H % 128) == 0 && small_sk == 128) { if (full) SMALL_LAUNCH(128, true); else SMALL_LAUNCH(128, false); }
-    else if (H == 512 && full && small_all) {              // whole row blocks at IMU_Net's width: all eight chunks' loads up front
+    if (H == 512 && full) {              // whole row blocks at IMU_Net's width: all eight chunks' loads up front
       const size_t lds = (size_t)2 * (64 + 16) * (64 + 4) * sizeof(float);
       hipLaunchKernelGGL((lstm_step_small_kernel<64, true, 8>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     }

@@ -23,8 +23,12 @@ from .params import FlatParams
 from .skeleton import JOINTS_UPPER, LOWER_POINTS, gcn_adjacency
 
 
-_FUSED_FRONT = os.environ.get("MMEGO_FUSED_FRONT", "1") != "0"      # eval-mode Upper_Net front end as one launch (front.hip)
-_GCN_FUSED = os.environ.get("MMEGO_GCN_FUSED", "1") != "0"          # training: the ST-GCN's fused block kernels (gcn_fused.hip)
+_FUSED_FRONT = True      # eval-mode Upper_Net front end as one launch (front.hip)
+_GCN_FUSED = True          # training: the ST-GCN's fused block kernels (gcn_fused.hip)
+_FUSED_HEAD_LOSS = True    # training: kinematics + loss + its backward as one launch (mmego_head_fk_loss)
+_BF16_FUSED_FC1 = True     # bf16 mode: fc1 written straight as the fused step's fragment-major operand
+# (the four flags above are not user settings: the forms they switch off are what shapes outside the fused kernels' ranges run, and the
+#  tests flip them to hold the fused kernels to those forms bit for bit)
 
 
 def _require_gpu(t, who):
@@ -131,7 +135,7 @@ class _NetBase(nn.Module):
         _backward_impl skips its first launch (bit-identical to the three separate launches)."""
         hook = self.loss_hook
         self._dy_ready = False
-        if hook is not None and stash and os.environ.get("MMEGO_FUSED_HEAD_LOSS", "1") != "0":
+        if hook is not None and stash and _FUSED_HEAD_LOSS:
             target, jmap, loss2, scale = hook
             dy = ar.get("dy", (F, y.shape[1]))
             nb = (F + 63) // 64
@@ -1059,7 +1063,7 @@ class IMUNet(_NetBase):
         if self.precision == "split3":
             return self._forward_split3(ar, imu, B, T, S, Cin, H)
         if (bf16 and Bn >= blocks.FUSED_MIN_ROWS and H % 64 == 0 and Cin <= 16 and imu.is_contiguous()
-                and self.fc1.weight.is_contiguous() and os.environ.get("MMEGO_BF16_FUSED_FC1", "1") != "0"):
+                and self.fc1.weight.is_contiguous() and _BF16_FUSED_FC1):
             # large batch in the bf16 mode: fc1 + ReLU written straight as the fused step's layer-0 operand (bf16, fragment-major);
             # the fp32 activation [Bn*S, H] (1.3 GB at config 5) is never stored
             xf, Bp = blocks.fused_input_fragments(ar, "fast", Bn, S, H)

@@ -14,7 +14,7 @@ from .blocks import LstmParams
 from .nets import GlobalModule, PointNet, _Bridge, _Mlp3, _NetBase, _f32c, _require_gpu
 
 N_ANCHOR, N_GROUP = 27, 8
-_LOCAL_FUSED = os.environ.get("MMEGO_LOCAL_FUSED", "1") != "0"      # the anchor branch on the fused kernels of local.hip
+_LOCAL_FUSED = True      # the anchor branch on the fused kernels of local.hip
 _LOCAL_NWG = 256                                                     # workgroups of mmego_local_group_l1 (= BatchNorm partial records)
 
 

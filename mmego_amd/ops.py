@@ -175,8 +175,8 @@ def linear(x, W, b, out, relu=False):
     return mm(x, W.view(W.shape[0], -1).t(), out, bias=b, relu=relu)
 
 
-_SPLIT_K_MIN = int(_os.environ.get("MMEGO_SPLIT_K_MIN", "128"))
-_SPLIT_K_FROM = int(_os.environ.get("MMEGO_SPLIT_K_FROM", "1024"))
+_SPLIT_K_MIN = 128          # k per slab at least
+_SPLIT_K_FROM = 1024        # split from this K on
 
 
 def pick_split(M, N, K):
@@ -197,8 +197,8 @@ def chain_split(M, N, K):
     return int(max(1, min(512 // max(tiles, 1), K // 512)))
 
 
-_KQ_MAX = int(_os.environ.get("MMEGO_GEMM_KQ_MAX", "512"))
-_PAIR_SPLIT_WGS = int(_os.environ.get("MMEGO_PAIR_SPLIT_WGS", "512"))
+_KQ_MAX = 512               # gemm.hip GEMM_KQ_MAX
+_PAIR_SPLIT_WGS = 512
 
 
 def asum_ok(M, N, K, nsplit, nbatch=1, over_tile=False):

@@ -14,12 +14,12 @@ from . import hip, ops
 from .params import FusedAdam
 from .plan import StepPlan
 
-# A step's HIP graphs: "0" (default) = the whole body as ONE graph whose parallel branches are the body's side streams; "1" = one
+# A step's HIP graphs: False (the product) = the whole body as ONE graph whose parallel branches are the body's side streams; True (tests flip it) = one
 # linear-chain graph per stream segment, replayed on the body's own streams with event waits in between (plan.StepPlan).  Measured
 # in r03: a graph with parallel branches dispatches TINY nodes in 5-6 us against 1.5-1.8 us for linear chains in separate graphs
 # (scripts/bench_launch_gap.py), but with the step's real kernels the ~15 graph boundaries cost more than that saves: 5.35 against
 # 5.25 ms per U+L step, 5.11 against 5.04 ms pipelined (bit-identical results; host enqueue time 0.6 against 2.1 ms per step).
-_MULTI_GRAPH = os.environ.get("MMEGO_MULTI_GRAPH", "0") == "1"
+_MULTI_GRAPH = False
 
 
 def _capture_body(body, stream=None):
@@ -395,12 +395,9 @@ class ConcurrentStages:
                     from . import blocks
                     # the FIRST forward (the last stage's) has the GPU to itself: its recurrences run as two chains; the
                     # later ones have another stage's tail beside them, which fills the same gaps (blocks.two_chains)
-                    alone = i == len(stages) - 1 and os.environ.get("MMEGO_FIRST_IMU_TWO_CHAINS", "1") != "0"
                     # r03: with the shorter tails the later forwards gain from the two-chain form as well (5.30 -> 5.24 ms per
-                    # U+L step); MMEGO_ALL_IMU_TWO_CHAINS=0 restores one launch per timestep beside a running tail
-                    if os.environ.get("MMEGO_ALL_IMU_TWO_CHAINS", "1") != "0" and os.environ.get("MMEGO_FIRST_IMU_TWO_CHAINS", "1") != "0":
-                        alone = True
-                    with torch.no_grad(), blocks.two_chains(alone):
+                    # U+L step), so all of them take it
+                    with torch.no_grad(), blocks.two_chains(True):
                         # (the forward's own output tensors serve as the stage's head pose: they stay referenced -- and, under
                         # capture, reserved in the graph's pool -- until every branch has been enqueued; no copies)
                         st.pose = st.imu(st.static["imu"])
@@ -452,7 +449,7 @@ class PipelinedStages:
     forwards run SIDE BY SIDE (each on a stream of its own, forked from the capture's origin), so that one net's recurrent step
     fills the launch gap / prologue / cell update of the other's -- 19.3 us per timestep and net instead of 23.4 (bench.py
     `recurrence_graph`), 5.18 ms per U+L step instead of 5.48 with the two forwards one after the other in ONE branch
-    (MMEGO_PIPE_IMU_SIDE_BY_SIDE=0).  Within one minibatch the same pairing loses (both tails then start together, DESIGN.md
+    (side_by_side = False).  Within one minibatch the same pairing loses (both tails then start together, DESIGN.md
     section 9); across minibatches nothing waits for the forwards.
     Every step still runs both IMU_Net forwards in full; results are bit-identical to ConcurrentStages on the same sequence of
     minibatches (tests/test_hip_local.py).  `imu_next` is the static buffer the caller fills with minibatch i+1's IMU samples
@@ -474,7 +471,7 @@ class PipelinedStages:
         self.pair = ConcurrentStages(self.stages, use_graph=False)
         self.side = torch.cuda.Stream()
         self.sides = [self.side] + [torch.cuda.Stream() for _ in self.imus[1:]]
-        self.side_by_side = os.environ.get("MMEGO_PIPE_IMU_SIDE_BY_SIDE", "1") != "0"
+        self.side_by_side = True
         self.use_graph, self.graph = use_graph, None
 
     def _imu_forward(self, k, persistent=True):

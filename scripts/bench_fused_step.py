@@ -1,6 +1,6 @@
 """The fused projection + recurrence step of the bf16 mode (bf16.hip, mmego_lstm_step_bf16_fused) alone, at the config-5 shape
 (Bn = 32768 rows, H = 512): layer 0 (K = 512 + 512) and layer 1 (K = 1024 + 512), both directions per launch.
-usage: python scripts/bench_fused_step.py [Bn]        (MMEGO_BF16_FUSED_256=0: the 128-row kernel)"""
+usage: python scripts/bench_fused_step.py [Bn]"""
 import os
 import sys
 

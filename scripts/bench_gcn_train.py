@@ -1,5 +1,5 @@
 """The fused ST-GCN training kernels alone (Lower_Net's KeyEncoder at the bench shape B=64 T=8): GPU time per entry point of one
-forward + backward of the GCN part (event pairs around every launch, eager), for the fused path and -- MMEGO_GCN_FUSED=0 -- the
+forward + backward of the GCN part (event pairs around every launch, eager), for the fused path and -- nets._GCN_FUSED = False -- the
 launch chain.  (The MMEGO_GCN_DBG phase mask of r04 -- timing by elimination -- was removed from the kernel in r05: git history.)"""
 import os
 import sys

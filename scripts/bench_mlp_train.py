@@ -1,5 +1,5 @@
 """Train-mode three-stage pointwise MLP (conv k=1 -> BatchNorm -> ReLU x 3), forward + backward: the per-layer fused kernels of
-mlp_train.hip against the unfused chain (MMEGO_FUSED_TRAIN_MLP=0 path), in a replayed HIP graph; plus per-kernel event times."""
+mlp_train.hip against the generic launch chain (what wider layers take), in a replayed HIP graph; plus per-kernel event times."""
 import collections
 import os
 import sys
@@ -11,6 +11,7 @@ from mmego_amd import blocks, hip, nets, ops  # noqa: E402
 from mmego_amd.params import FlatParams  # noqa: E402
 
 dev = torch.device("cuda:0")
+_was = blocks._mlp3_fused_train
 hip.lib()
 for name, mod, rows in (("PointNet 6-8-16-24", nets.PointNet(), 65536), ("GlobalPointNet 28-32-48-64", nets.GlobalPointNet(), 65536),
                         ("BasePointNet 6-16-32-61", nets.BasePointNet(64), 32768)):
@@ -21,7 +22,7 @@ for name, mod, rows in (("PointNet 6-8-16-24", nets.PointNet(), 65536), ("Global
     x = torch.randn(rows, cin, device=dev)
     dy = torch.randn(rows, cout, device=dev)
     for fused in (False, True):
-        blocks._FUSED_TRAIN_MLP = fused
+        blocks._mlp3_fused_train = _was if fused else (lambda mod, x: False)
         ar = ops.Arena(dev)
         y = ar.get("y3", (rows, cout))
 

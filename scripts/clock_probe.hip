@@ -79,10 +79,10 @@ int main(int argc, char** argv) {
     double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("gemm_tile 10240x2048x%d: %ld launches, %.1f us each (stamped build)\n", K, n, el / n * 1e6);
     // 2 workgroups share a CU: a wave owns its SIMD's matrix pipe half of the time at best -> ideal = 2 x MFMA cycles
-    report("gemm_tile", getenv("MMEGO_GEMM_NO_PERSIST") ? 1280 : 1536, 2.0 * (K / 64) * 8 * 16 * 64);
+    report("gemm_tile", 1536, 2.0 * (K / 64) * 8 * 16 * 64);
     hipFree(A); hipFree(W); hipFree(C); hipFree(bias);
   }
-  {  // recurrent step of rnn_fast: Bn=512, H=512, both directions; lstm_step_dma_kernel<HT> (MMEGO_STEP_HT=16|32)
+  {  // recurrent step of rnn_fast: Bn=512, H=512, both directions; lstm_step_dma_kernel<32> (both directions in one launch)
     const int Bn = 512, H = 512, T = 20;
     mmego_step_dbg = getenv("PROBE_STEP_DBG") ? atoi(getenv("PROBE_STEP_DBG")) : 0;
     float* out = dev_random((size_t)Bn * T * 2 * H, 0.5f, 4);
@@ -107,7 +107,7 @@ int main(int argc, char** argv) {
     double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     printf("lstm_step Bn=512: %ld launches, %.1f us each (stamped build)\n", n, el / n * 1e6);
     {
-      const int ht = getenv("MMEGO_STEP_HT") ? atoi(getenv("MMEGO_STEP_HT")) : 16;
+      const int ht = 32;
       // ideal = MFMA issue cycles of the work that shares one SIMD's matrix pipe (two workgroups per CU at HT = 16)
       report(ht == 16 ? "lstm_step_dma_kernel<16>" : "lstm_step_dma_kernel<32>", ndir * (H / ht) * (Bn / 64),
              ndir == 2 ? 8.0 * 4 * 32 * 32 : 8.0 * 4 * 32 * 16);

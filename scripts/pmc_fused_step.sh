@@ -1,6 +1,6 @@
 #!/bin/bash
-# PMC passes (HBM fetch / write bytes, MFMA busy) around scripts/bench_fused_step.py for one setting of MMEGO_BF16_FUSED_256.
-# usage (through gpurun): bash scripts/pmc_fused_step.sh <tag> ; env MMEGO_BF16_FUSED_256 is inherited by the benchmarked process
+# PMC passes (HBM fetch / write bytes, MFMA busy) around scripts/bench_fused_step.py.
+# usage (through gpurun): bash scripts/pmc_fused_step.sh <tag>
 set -e -o pipefail
 tag=${1:-x}
 root=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -130,7 +130,7 @@ def test_engines_agree_bit_for_bit_at_bench_shape(dev):
     and the prefetch-pipelined engine -- against the timed one (`ConcurrentStages`, one graph) at B=64, T=8, N=128 with IMU_Net(512),
     dropout live (same seeds): three steps each, losses / gradient buffers / parameters / BatchNorm buffers bit-identical.  (At B=16 the
     same is checked in test_hip_local; here the 512-row recurrences, the persistent projection kernel and the large-grid tails run.)
-    Also with the bodies captured through plan.StepPlan (MMEGO_MULTI_GRAPH=1: a graph per stream segment + event waits)."""
+    Also with the bodies captured through plan.StepPlan (train_step._MULTI_GRAPH: a graph per stream segment + event waits)."""
     import bench
     from mmego_amd.train_step import ConcurrentStages, PipelinedStages, SharedImuStages, StageStep
     x, imu_in, body, target = bench.synth_batch(1234, dev)
@@ -183,7 +183,7 @@ def test_engines_agree_bit_for_bit_at_bench_shape(dev):
 @pytest.mark.gpu
 def test_fused_head_loss_launch_is_bit_identical_to_the_three_launches():
     """mmego_head_fk_loss (kinematics + transform + L1(sum) loss + its gradient + kinematics backward in one launch, what StageStep
-    uses) against head_fk_forward -> l1_loss -> head_fk_backward (MMEGO_FUSED_HEAD_LOSS=0): predictions, both loss figures and every
+    uses) against head_fk_forward -> l1_loss -> head_fk_backward (nets._FUSED_HEAD_LOSS = False): predictions, both loss figures and every
     gradient bit for bit (the loss figures to an fp32 ulp: fixed but different summation order), Upper_Net, Lower_Net and UpperNetwlocal,
     B = 64 (8 workgroups, ticketed fixed-order sum) and B = 5; replayed twice more to check the ticket resets."""
     import os
@@ -199,8 +199,8 @@ def test_fused_head_loss_launch_is_bit_identical_to_the_three_launches():
         Rg = torch.linalg.qr(torch.randn(Bq, 8, 3, 3, generator=g))[0].contiguous().to(dev)
         for kind in ("upper", "lower", "wlocal"):
             res = []
-            for fused in ("1", "0"):
-                os.environ["MMEGO_FUSED_HEAD_LOSS"] = fused
+            for fused in (True, False):
+                nets._FUSED_HEAD_LOSS = fused
                 try:
                     torch.manual_seed(9)
                     if kind == "lower":
@@ -214,10 +214,10 @@ def test_fused_head_loss_launch_is_bit_identical_to_the_three_launches():
                     for _ in range(3):                       # (the ticket of the fused launch must come back to 0 every time)
                         st._body()
                     torch.cuda.synchronize()
-                    assert getattr(net, "_dy_ready", False) == (fused == "1")
+                    assert getattr(net, "_dy_ready", False) == fused
                     res.append((st.last_pred.clone(), st.loss2.clone(), net.flat().flat_g.clone()))
                 finally:
-                    os.environ.pop("MMEGO_FUSED_HEAD_LOSS", None)
+                    nets._FUSED_HEAD_LOSS = True
             (p1, l1, g1), (p0, l0, g0) = res
             assert torch.equal(p1, p0) and torch.equal(g1, g0), (kind, Bq)
             # (the two loss figures: fp64 sums in a different, fixed order -- equal after rounding to fp32 up to one ulp)

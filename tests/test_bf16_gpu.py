@@ -168,7 +168,7 @@ def test_fc_relu_bf16_fragments_and_the_imu_forward_that_uses_them(monkeypatch):
     """mmego_fc_relu_bf16_frag_tm (IMU_Net's fc1 written straight as the fused step's layer-0 operand): every element is the bf16
     rounding of relu(x . W^T + b) (fp32 sums in another order than the GEMM's: a value within half a bf16 ulp of a tie may round
     the other way), at its fragment-major position, rows past Bn zero; and the IMU_Net forward that uses it agrees with the one
-    that stores the fp32 activation and converts it (MMEGO_BF16_FUSED_FC1=0) to the mode's bound."""
+    that stores the fp32 activation and converts it (nets._BF16_FUSED_FC1 = False) to the mode's bound."""
     from mmego_amd import blocks, hip, nets
     dev = _dev()
     Bn, T, Cin, H = 70, 3, 15, 128
@@ -200,7 +200,7 @@ def test_fc_relu_bf16_fragments_and_the_imu_forward_that_uses_them(monkeypatch):
     imu = torch.randn(32, 8, 20, 15, generator=g).to(dev)         # 256 rows: the 256 x 256-tile fused step as well
     with torch.no_grad():
         R1, t1 = [v.clone() for v in net(imu)]
-        monkeypatch.setenv("MMEGO_BF16_FUSED_FC1", "0")
+        monkeypatch.setattr(nets, "_BF16_FUSED_FC1", False)
         R0, t0 = [v.clone() for v in net(imu)]
     assert float((R1 - R0).abs().max()) < 2e-2 and float((t1 - t0).abs().max()) < 2e-2
     assert float((R1 - R0).abs().mean()) < 2e-3

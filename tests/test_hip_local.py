@@ -162,7 +162,7 @@ def test_pool8_kernels_against_torch(dev):
 
 def test_upper_wlocal_eval_forward_fused_against_oracle_and_chain(dev):
     """Eval-mode UpperNetwlocal with the anchor branch as ONE launch (mmego_local_front_eval: grouping + folded conv/BatchNorm/ReLU x3
-    + 8-way softmax pooling) against the CPU oracle (all eight outputs) and against the launch chain (MMEGO_LOCAL_FUSED=0): group
+    + 8-way softmax pooling) against the CPU oracle (all eight outputs) and against the launch chain (nets_local._LOCAL_FUSED = False): group
     indices bit-identical, everything else at the eval-forward bar."""
     from mmego_amd import nets_local
     g = torch.Generator().manual_seed(21)
@@ -660,7 +660,7 @@ def test_stage_engines_with_two_chain_recurrence_in_graphs(dev):
         return su, sl, imu_u, imu_l
 
     def run(kind):
-        was = blocks._LSTM_TWO_CHAINS                 # (restored as found: MMEGO_LSTM_TWO_CHAINS=0 must survive this test)
+        was = blocks._LSTM_TWO_CHAINS                 # (restored as found)
         blocks._LSTM_TWO_CHAINS = kind != "reference"
         try:
             su, sl, imu_u, imu_l = build(kind != "pipelined", use_graph=kind == "stage_graphs")

@@ -894,7 +894,7 @@ def test_fused_adam_matches_torch(dev):
 
 def test_gcn_fused_training_step_equals_the_launch_chain(dev):
     """The fused ST-GCN training kernels (gcn_fused.hip: BatchNorm statistics as partial records finalized in the consumers'
-    prologues, einsum on MFMAs, deferred slab sums) against the per-operation launch chain they replace (MMEGO_GCN_FUSED=0), on the
+    prologues, einsum on MFMAs, deferred slab sums) against the per-operation launch chain they replace (nets._GCN_FUSED = False), on the
     same Lower_Net and minibatch: outputs, every gradient, BatchNorm running statistics -- and both against the CPU oracle through
     the tests above.  Two shapes: ragged (frames not a multiple of the 4-frame tile) and the bench shape's row count."""
     from mmego_amd import nets
@@ -935,7 +935,7 @@ def test_gcn_fused_training_step_equals_the_launch_chain(dev):
 def test_fused_pooling_in_the_pointnet_chain_equals_the_separate_launches(dev):
     """pool128_bn_act / pool128_backward (GlobalPointNet's last BatchNorm + ReLU inside the softmax pooling, and the pooling's backward
     with the stage's BatchNorm sums and the attention partials) against mlp_bn_act + attn_pool_forward / attn_pool_backward + column
-    sums + mlp_bn_bwd_reduce (MMEGO_POOL_FUSED=0) on the same Upper_Net: outputs, attention weights, every gradient, running statistics."""
+    sums + mlp_bn_bwd_reduce (blocks._POOL_FUSED = False) on the same Upper_Net: outputs, attention weights, every gradient, running statistics."""
     from mmego_amd import blocks, nets
     g = torch.Generator().manual_seed(13)
     Bq, Tq = 4, 6

@@ -1,4 +1,4 @@
-"""plan.StepPlan (MMEGO_MULTI_GRAPH=1's engine) on the MI355X: recorded stream topology == eager topology."""
+"""plan.StepPlan (train_step._MULTI_GRAPH's engine) on the MI355X: recorded stream topology == eager topology."""
 import pytest
 import torch
 
