@@ -533,6 +533,38 @@ int mmego_mlp_dw_reduce(void* stream, long rows, int nlayers, const float* part0
 typedef struct MmegoDwRed { const float* part; float* dW; int Cout, Cin; long rows; int nblk; long stride; } MmegoDwRed;
 int mmego_mlp_dw_reduce_multi(void* stream, int n, const void* descs);
 
+/* ---- LocalVoxelNet training step (vox.hip): Net/Upper_Net.py:180-205 -------------------------------------------------------------
+ * Conv3d(64, 96, k=3) over the whole 3x3x3 anchor grid (= a 1728 -> 96 map per frame), two 1x1x1 convs 96 -> 128 -> 64, a train-mode
+ * BatchNorm3d + ReLU behind each, over rows = B*T frames: 4 forward + 5 backward launches, one wherever a BatchNorm needs every row's
+ * statistics (mmego_vox_ok: the widths these kernels are built for, K = 1728, 2 <= rows <= 4096; other shapes take the generic
+ * launches).  Forward statistics travel as (mean, M2) records [ceil(rows/16)][C] float pairs (rec*), finalized in the consumer's
+ * prologue; workgroup 0 writes bn->state [4][C] = mean, invstd, a, b and the running statistics (bn: an MmegoBnRef whose rec / nrec /
+ * rows_per_rec fields are ignored).  Backward sums travel as (sum g, sum g xhat) pairs per 16-row tile (prt*).
+ *   vox_l1_fwd    Z[rows][C] = X[rows][K] W[C][K]^T + bias, rec
+ *   vox_mid_fwd   Yin = relu(bn(Zin)) [rows][Cin] (stored for backward), Zout = Yin W[Cout][Cin]^T + bias, rec_out; (Cin, Cout) = (96, 128), (128, 64)
+ *   vox_out_fwd   Y[rows][C] (row stride ldy) = relu(bn(Z))
+ *   vox_bwd_sums  G = dY . [Y > 0] [rows][C], prt from Z and the forward state
+ *   vox_mid_bwd   dZ = BatchNorm backward of G (sums prt, state; dgamma / dbeta assigned), Gp = (dZ W[Cout][Cin]) . [Yp > 0], prtp from Zp / statep;
+ *                 (Cout, Cin) = (64, 128), (128, 96)
+ *   vox_l1_bwd    dZ as above for the first layer (C = 96), dX[rows][K] = dZ W[C][K]
+ *   vox_dw        dW1[C1][K] = dZ1^T X, dW2[C2][C1] = dZ2^T Y1, dW3[C3][C2] = dZ3^T Y2 (assigned)
+ * The conv biases get no gradient (exactly zero in front of a batch-statistics BatchNorm). */
+int mmego_vox_ok(long rows, int K, int C1, int C2, int C3);
+int mmego_vox_l1_fwd(void* stream, const float* X, long ldx, long rows, int K, const float* W, const float* bias, int C, float* Z,
+                     float* rec);
+int mmego_vox_mid_fwd(void* stream, const float* Zin, const float* rec_in, const void* bn, long rows, int Cin, float* Yin,
+                      const float* W, const float* bias, int Cout, float* Zout, float* rec_out);
+int mmego_vox_out_fwd(void* stream, const float* Z, const float* rec, const void* bn, long rows, int C, float* Y, long ldy);
+int mmego_vox_bwd_sums(void* stream, const float* dY, long lddy, const float* Y, long ldy, const float* Z, const float* state,
+                       long rows, int C, float* G, float* prt);
+int mmego_vox_mid_bwd(void* stream, const float* G, const float* Z, const float* state, const float* prt, long rows, int Cout,
+                      float* dZ, float* dgamma, float* dbeta, const float* W, int Cin, const float* Yp, const float* Zp,
+                      const float* statep, float* Gp, float* prtp);
+int mmego_vox_l1_bwd(void* stream, const float* G, const float* Z, const float* state, const float* prt, long rows, int C, float* dZ,
+                     float* dgamma, float* dbeta, const float* W, int K, float* dX, long lddx);
+int mmego_vox_dw(void* stream, long rows, const float* dZ1, const float* X, long ldx, float* dW1, int C1, int K, const float* dZ2,
+                 const float* Y1, float* dW2, int C2, const float* dZ3, const float* Y2, float* dW3, int C3);
+
 /* ---- fused ST-GCN training step (gcn_fused.hip, gcn.hip): Net/GCN.py:67-147 st_gcn, :332-355 Model.extract_feature -----------------
  * Train-mode BatchNorm statistics travel between these kernels as PARTIAL RECORDS: per producer workgroup j and channel c the float
  * pair rec[j][c] = (mean_j, M2_j) over the rows the workgroup owns (rows_per_rec each, the last record ragged).  The consumer finalizes

@@ -260,6 +260,66 @@ def linear_backward(dy, x, lin, G, dx=None, accumulate_dx=False, bias_grad=True,
 
 
 # ---------------------------------------------------------------------------------------------------
+# LocalVoxelNet's training step on its own kernels (vox.hip)
+# ---------------------------------------------------------------------------------------------------
+def vox_fusable(mod, x):
+    """Conv3d(64, 96, k = 3 over the whole 3x3x3 grid) -> 1x1x1 convs 96 -> 128 -> 64 with train-mode BatchNorm + ReLU (Net/Upper_Net.py:
+    180-205) over x [rows, 1728]: the shapes mmego_vox_* are built for."""
+    layers = _mlp3_layers(mod)
+    C = [conv.weight.shape[0] for conv, _ in layers]
+    K = layers[0][0].weight.numel() // C[0]
+    ok = (x.dim() == 2 and x.shape[1] == K and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+          and layers[1][0].weight.numel() == C[1] * C[0] and layers[2][0].weight.numel() == C[2] * C[1]
+          and all(conv.weight.is_contiguous() and conv.bias is not None for conv, _ in layers))
+    return bool(ok and hip.lib().mmego_vox_ok(x.shape[0], K, C[0], C[1], C[2]))
+
+
+def _vox_buffers(ar, key, mod, rows):
+    layers = _mlp3_layers(mod)
+    C = [conv.weight.shape[0] for conv, _ in layers]
+    nrt = (rows + 15) // 16
+    z = [ar.get("%s.z%d" % (key, i + 1), (rows, C[i])) for i in range(3)]
+    y = [ar.get("%s.y%d" % (key, i + 1), (rows, C[i])) for i in range(2)]
+    rec = [ar.get("%s.rec%d" % (key, i + 1), (nrt, C[i], 2)) for i in range(3)]
+    st = [ops.BnState(ar, "%s.bn%d" % (key, i + 1), C[i]) for i in range(3)]
+    return layers, C, z, y, rec, st
+
+
+def voxel_forward(ar, key, mod, x, out):
+    """Train-mode LocalVoxelNet forward, x [rows, 1728] -> out [rows, 64]: 4 launches (a launch boundary only where a BatchNorm needs
+    every row's statistics; vox.hip).  Keeps z1..z3, y1, y2 and the BatchNorm states for voxel_backward."""
+    rows, K = x.shape
+    layers, C, z, y, rec, st = _vox_buffers(ar, key, mod, rows)
+    (c1, b1), (c2, b2), (c3, b3) = layers
+    hip.call("vox_l1_fwd", x, x.stride(0), rows, K, c1.weight, c1.bias, C[0], z[0], rec[0])
+    hip.call("vox_mid_fwd", z[0], rec[0], hip.BnRef.of(b1, st[0].all), rows, C[0], y[0], c2.weight, c2.bias, C[1], z[1], rec[1])
+    hip.call("vox_mid_fwd", z[1], rec[1], hip.BnRef.of(b2, st[1].all), rows, C[1], y[1], c3.weight, c3.bias, C[2], z[2], rec[2])
+    hip.call("vox_out_fwd", z[2], rec[2], hip.BnRef.of(b3, st[2].all), rows, C[2], out, out.stride(0))
+    return out
+
+
+def voxel_backward(ar, key, mod, x, out, dout, G):
+    """Backward of voxel_forward: 5 launches; -> dx [rows, 1728].  Weight and BatchNorm parameter gradients are assigned; the conv biases
+    get none (exactly zero in front of a batch-statistics BatchNorm, as in mlp3_backward)."""
+    rows, K = x.shape
+    layers, C, z, y, rec, st = _vox_buffers(ar, key, mod, rows)
+    (c1, b1), (c2, b2), (c3, b3) = layers
+    nrt = (rows + 15) // 16
+    g = [ar.get("%s.g%d" % (key, i + 1), (rows, C[i])) for i in range(3)]
+    dz = [ar.get("%s.dz%d" % (key, i + 1), (rows, C[i])) for i in range(3)]
+    prt = [ar.get("%s.prt%d" % (key, i + 1), (nrt, C[i], 2)) for i in range(3)]
+    dx = ar.get("%s.dx" % key, (rows, K))
+    hip.call("vox_bwd_sums", dout, dout.stride(0), out, out.stride(0), z[2], st[2].all, rows, C[2], g[2], prt[2])
+    hip.call("vox_mid_bwd", g[2], z[2], st[2].all, prt[2], rows, C[2], dz[2], G(b3.weight), G(b3.bias), c3.weight, C[1], y[1], z[1],
+             st[1].all, g[1], prt[1])
+    hip.call("vox_mid_bwd", g[1], z[1], st[1].all, prt[1], rows, C[1], dz[1], G(b2.weight), G(b2.bias), c2.weight, C[0], y[0], z[0],
+             st[0].all, g[0], prt[0])
+    hip.call("vox_l1_bwd", g[0], z[0], st[0].all, prt[0], rows, C[0], dz[0], G(b1.weight), G(b1.bias), c1.weight, K, dx, K)
+    hip.call("vox_dw", rows, dz[0], x, x.stride(0), G(c1.weight), C[0], K, dz[1], y[0], G(c2.weight), C[1], dz[2], y[1], G(c3.weight), C[2])
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------------
 # 3-layer bidirectional LSTM, H = 64 (persistent sequence kernels)
 # ---------------------------------------------------------------------------------------------------
 def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr, salt=0):

@@ -4,6 +4,8 @@
 //
 // References: Util/Universal_Util/Utils.py:274-292 (Transform2H/2R), Net/Upper_Net.py:122-144,343-364,
 // Net/Lower_Net.py:12-37,125-136,216-227, Net/IMU_Net.py:7-47, Processor/Train/Train_Upper.py:53,179.
+#include <stdlib.h>
+
 #include "common.h"
 
 // r = (a0*b0 + a1*b1) + a2*b2 with every product and sum rounded separately (no fma contraction): this
@@ -686,8 +688,26 @@ extern "C" int mmego_head_fk_loss(void* stream, int which, const float* y, const
   MMEGO_REQUIRE(B > 0 && F > 0 && F <= 65536 && ntgt > 0 && ncount >= 0 && ncount <= 4096 && (ncount == 0 || counters));
   const int nb = cdiv(F, 64);
   unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 2 * nb);
-  if (which == 0) hipLaunchKernelGGL(head_fk_loss_kernel<0>, dim3(nb), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy, scratch, ticket);
-  else hipLaunchKernelGGL(head_fk_loss_kernel<1>, dim3(nb), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy, scratch, ticket);
+  // The launch asks for 144 KB of LDS it never touches, so that no LDS-using workgroup -- every MFMA kernel of this library -- shares a
+  // CU with one of its (at most 8) workgroups.  r05 finding (scripts/coexec_head_fk.py): with a bf16-MFMA recurrence kernel
+  // (mmego_split3_step16, two 64-KB workgroups per CU) resident on the same CU, dy came back different in 12 of 200 rounds of 20
+  // launches -- always one 16-lane group of the wave, values close to the right ones -- and in 0 of 200 with this request; never beside
+  // fp32-MFMA kernels.  Not explained (its LDS, stores, cross-lane traffic and register allocation were ruled out one by one); the
+  // request costs nothing measurable.
+#ifdef MMEGO_HEAD_FK_NO_LDS_PAD                          // (a build for the reproducer: MMEGO_EXTRA_HIPCC_FLAGS=-DMMEGO_HEAD_FK_NO_LDS_PAD)
+  constexpr int lds_pad = 0;
+#else
+  constexpr int lds_pad = 144 * 1024;
+#endif
+  static bool attr_set = false;
+  if (lds_pad && !attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)head_fk_loss_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_fk_loss_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  if (which == 0) hipLaunchKernelGGL(head_fk_loss_kernel<0>, dim3(nb), dim3(64), lds_pad, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy, scratch, ticket);
+  else hipLaunchKernelGGL(head_fk_loss_kernel<1>, dim3(nb), dim3(64), lds_pad, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy, scratch, ticket);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

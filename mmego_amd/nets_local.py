@@ -15,6 +15,7 @@ from .nets import GlobalModule, PointNet, _Bridge, _Mlp3, _NetBase, _f32c, _requ
 
 N_ANCHOR, N_GROUP = 27, 8
 _LOCAL_FUSED = True      # the anchor branch on the fused kernels of local.hip
+_VOX_FUSED = True        # LocalVoxelNet's training step on the kernels of vox.hip (tests flip it: the generic launches)
 _LOCAL_NWG = 256                                                     # workgroups of mmego_local_group_l1 (= BatchNorm partial records)
 
 
@@ -120,7 +121,7 @@ class UpperNetwlocal(_NetBase):
             return _Bridge.apply(self, 1, args, *self._flat.params)
         return self._forward_impl(*args, stash=False)
 
-    def _forward_impl(self, x, h0g, c0g, h0a, c0a, body, R, t, stash=True):
+    def _forward_impl(self, x, h0g, c0g, h0a, c0a, body, R, t, stash=True, x_src=None):
         self.flat()
         training = self.training
         ar = self.arena("train" if stash else "eval")
@@ -131,14 +132,22 @@ class UpperNetwlocal(_NetBase):
         dev = x.device
         R, t, body = _f32c(R), _f32c(t), _f32c(body)
         h0g, c0g, h0a, c0a = [_f32c(v) if v is not None else None for v in (h0g, c0g, h0a, c0a)]
-        ops.transform2h_(x, R, t)
-        pts = x.view(rows, Cx)
-        if stash:
-            keep = ar.get("pts", (rows, Cx))
-            ops.copy2d(pts, keep)
-            pts = keep
         feats = ar.get("feats", (rows, 28))
-        ops.copy2d(pts[:, :4], feats[:, :4])
+        keep = ar.get("pts", (rows, Cx)) if stash else None
+        if Cx <= 8:
+            # Q1: in place on the caller's tensor; the copy kept for backward and the xyz + intensity columns of the feature buffer leave
+            # from the same launch, and a trainer's fresh minibatch (x_src) enters through it (as in nets.UpperNet)
+            ops.transform2h_(x, R, t, src=x_src, keep=keep, feats=feats, nfeat=4)
+            pts = keep if stash else x.view(rows, Cx)
+        else:
+            if x_src is not None:
+                ops.copy2d(x_src.view(rows, Cx), x.view(rows, Cx))
+            ops.transform2h_(x, R, t)
+            pts = x.view(rows, Cx)
+            if stash:
+                ops.copy2d(pts, keep)
+                pts = keep
+            ops.copy2d(pts[:, :4], feats[:, :4])
         blocks.mlp3_forward(ar, "m0", self.module0, pts, feats[:, 4:28], training)
         # global branch
         g3 = ar.get("g3", (rows, 64))
@@ -198,7 +207,11 @@ class UpperNetwlocal(_NetBase):
             blocks.attn_pool_forward(l3, lp.attn, F * N_ANCHOR, N_GROUP, 64, vox, aw)
             hip.call("transpose_batched", vox, voxT, F, N_ANCHOR, 64)     # (F,27,64) -> (F,64,27): conv input order (cin,z,y,x)
         vvec = ar.get("vvec", (F, 64))
-        blocks.mlp3_forward(ar, "vx", self.module2.avoxel, voxT, vvec, training)
+        self._vox_fused = bool(_VOX_FUSED and stash and training and blocks.vox_fusable(self.module2.avoxel, voxT))
+        if self._vox_fused:         # LocalVoxelNet's 512-row chain on its own kernels: 4 launches instead of 12 (vox.hip)
+            blocks.voxel_forward(ar, "vx", self.module2.avoxel, voxT, vvec)
+        else:
+            blocks.mlp3_forward(ar, "vx", self.module2.avoxel, voxT, vvec, training)
         p_a = self._drop_p(self.module2.arnn.rnn) if stash else 0.0
         # the global and the anchor BiLSTM(64) stacks (Net/Upper_Net.py:333-339, :208-216: same shape, nothing in common) layer by layer side
         # by side: one sequence-kernel launch per layer for both (blocks.lstm64_forward_multi)
@@ -253,7 +266,10 @@ class UpperNetwlocal(_NetBase):
                 dfeats = blocks.mlp3_backward(ar, "gp", gpn, feats, g3, dg3, G, True)
             # local branch
             voxT = ar.get("voxT", (F, 64 * N_ANCHOR))
-            dvoxT = blocks.mlp3_backward(ar, "vx", self.module2.avoxel, voxT, vvec, dvvec, G, True)
+            if getattr(self, "_vox_fused", False):
+                dvoxT = blocks.voxel_backward(ar, "vx", self.module2.avoxel, voxT, vvec, dvvec, G)
+            else:
+                dvoxT = blocks.mlp3_backward(ar, "vx", self.module2.avoxel, voxT, vvec, dvvec, G, True)
             gidx = ar.get("gidx", (F, N_ANCHOR, N_GROUP), dtype=torch.int64)
             lp = self.module2.apointnet
             if getattr(self, "_local_was_fused", False):

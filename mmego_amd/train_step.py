@@ -160,7 +160,8 @@ class StageStep:
         from .nets import UpperNet
         first_net = self.net if self.stage == "upper" else self.upper_frozen
         # fresh batch (x is transformed in place): Upper_Net's transform launch reads it from x_src; other nets get a copy first
-        via_transform = type(first_net) is UpperNet and s["x"].shape[-1] <= 8
+        from .nets_local import UpperNetwlocal
+        via_transform = (type(first_net) is UpperNet or (self.stage == "upper" and type(first_net) is UpperNetwlocal)) and s["x"].shape[-1] <= 8
         # the trained net's kinematics launch takes the loss, its gradient and the first backward step along (nets._head_fk)
         self.net.loss_hook = (s["target"], self.jmap, self.loss2, 1.0)
         try:
@@ -184,7 +185,7 @@ class StageStep:
             if self.stage == "upper":
                 from .nets_local import UpperNetwlocal
                 if isinstance(self.net, UpperNetwlocal):     # (Net/Upper_Net.py:406-432: a second state pair for the anchor branch)
-                    l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["h0"], s["c0"], s["body"], R, t, stash=True)[0]
+                    l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["h0"], s["c0"], s["body"], R, t, stash=True, x_src=x_src)[0]
                 elif via_transform:
                     l = self.net._forward_impl(s["x"], s["h0"], s["c0"], s["body"], R, t, stash=True, x_src=x_src)[0]
                 else:

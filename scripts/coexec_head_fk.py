@@ -5,7 +5,10 @@ loss) must not depend on what runs beside it.  Measured on MI355X (several boxes
 rounds of 20 launches -- always a 16-lane group of one wave, a few columns, values close to the right ones -- and never beside the
 others; q, joints and the loss never differ.  Ruled out by variants of the 16-unit kernel: its LDS contents (LDS poison in front of
 every launch of a whole Lower step changes nothing: scripts/find_lds_uninit.py), its global stores, ds_bpermute, padding its VGPR /
-SGPR allocation; with its MFMAs compiled out nothing differs.  blocks.SPLIT3_TWO_CHAINS is therefore off by default."""
+SGPR allocation; with its MFMAs compiled out nothing differs.  What does remove it: keeping every LDS-using workgroup off the victim's
+CU -- the victim asking for 144 KB of LDS it never touches: 12 of 200 rounds differ without, 0 of 200 with the request, same box, same
+run (gpurun_out r05_coexec_a/b).  mmego_head_fk_loss has made that request since; to see the effect again build the library with
+MMEGO_EXTRA_HIPCC_FLAGS=-DMMEGO_HEAD_FK_NO_LDS_PAD.  blocks.SPLIT3_TWO_CHAINS stays off by default (the unexplained part)."""
 import os
 import sys
 

@@ -203,6 +203,96 @@ def test_upper_wlocal_eval_forward_fused_against_oracle_and_chain(dev):
         assert (a - w.view_as(a)).abs().max().item() < 5e-5, ("fused vs oracle, output", k)
 
 
+@pytest.mark.parametrize("rows", [512, 40, 37, 17])
+def test_local_voxel_net_kernels_against_fp64_and_the_generic_launches(dev, rows):
+    """LocalVoxelNet's training step on its own kernels (vox.hip: 4 forward + 5 backward launches, BatchNorm statistics as partial
+    records between them) against a float64 torch autograd reference of Net/Upper_Net.py:180-205 on the same inputs (output, input
+    gradient, every parameter gradient, running statistics) and against the generic launch chain it replaces; whole and ragged 16-row
+    tiles, down to a last tile of one row.  (Two-row batches are not held to fp64: xhat = +-1 there and the fp32 chain itself is 1e-3 off.)"""
+    import torch.nn.functional as Fn
+    from mmego_amd import blocks, nets_local, ops
+    g = torch.Generator().manual_seed(100 + rows)
+    mod = nets_local.LocalVoxelNet()
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.weight.data.uniform_(0.5, 1.5, generator=g)
+            m.bias.data.normal_(0.0, 0.2, generator=g)
+            m.running_mean.normal_(0.0, 0.2, generator=g)
+            m.running_var.uniform_(0.5, 1.5, generator=g)
+    mod = mod.to(dev).train()
+    x = (torch.randn(rows, 1728, generator=g) * 0.7).to(dev)
+    dout = torch.randn(rows, 64, generator=g).to(dev)
+    layers = blocks._mlp3_layers(mod)
+    rstats0 = [(bn.running_mean.clone(), bn.running_var.clone()) for _, bn in layers]
+
+    # float64 reference
+    xd = x.double().requires_grad_(True)
+    ps, cur, rstats_ref = [], xd, []
+    for (conv, bn), (rm, rv) in zip(layers, rstats0):
+        W = conv.weight.detach().double().view(conv.weight.shape[0], -1).requires_grad_(True)
+        b = conv.bias.detach().double().requires_grad_(True)
+        ga, be = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+        rm, rv = rm.double().clone(), rv.double().clone()
+        cur = torch.relu(Fn.batch_norm(cur @ W.t() + b, rm, rv, ga, be, True, bn.momentum, bn.eps))
+        ps.append((W, ga, be))
+        rstats_ref.append((rm, rv))
+    cur.backward(dout.double())
+
+    def grads():
+        store = {}
+        def G(t):
+            return store.setdefault(t.data_ptr(), torch.full_like(t, 7.0))      # (assigned, not accumulated)
+        return store, G
+
+    def restore():
+        for (_, bn), (rm, rv) in zip(layers, rstats0):
+            bn.running_mean.copy_(rm)
+            bn.running_var.copy_(rv)
+
+    res = {}
+    for fused in (True, False):
+        restore()
+        ar = ops.Arena(dev)
+        out = torch.empty(rows, 64, device=dev)
+        store, G = grads()
+        if fused:
+            assert blocks.vox_fusable(mod, x)
+            blocks.voxel_forward(ar, "vx", mod, x, out)
+            dx = blocks.voxel_backward(ar, "vx", mod, x, out, dout, G)
+        else:
+            blocks.mlp3_forward(ar, "vx", mod, x, out, True)
+            dx = blocks.mlp3_backward(ar, "vx", mod, x, out, dout, G, True)
+        torch.cuda.synchronize()
+        res[fused] = (out.clone(), dx.clone(), {k: v.clone() for k, v in store.items()},
+                      [(bn.running_mean.clone(), bn.running_var.clone()) for _, bn in layers])
+
+    def close(a, ref, tol, what):
+        scale = max(1.0, float(ref.abs().max()))
+        err = float((a.double() - ref.double()).abs().max())
+        assert err < tol * scale, (what, rows, err, scale)
+
+    out_f, dx_f, gr_f, rs_f = res[True]
+    close(out_f, cur.detach(), 2e-5, "output")
+    close(dx_f, xd.grad, 2e-4, "input gradient")
+    for i, ((conv, bn), (W, ga, be)) in enumerate(zip(layers, ps)):
+        tol = 2e-4
+        close(gr_f[conv.weight.data_ptr()].view(W.shape), W.grad, tol, "dW%d" % (i + 1))
+        close(gr_f[bn.weight.data_ptr()], ga.grad, tol, "dgamma%d" % (i + 1))
+        close(gr_f[bn.bias.data_ptr()], be.grad, tol, "dbeta%d" % (i + 1))
+        assert conv.bias.data_ptr() not in gr_f                                  # no bias gradient is written
+        close(rs_f[i][0], rstats_ref[i][0], 1e-5, "running_mean%d" % (i + 1))
+        close(rs_f[i][1], rstats_ref[i][1], 1e-5, "running_var%d" % (i + 1))
+    out_c, dx_c, gr_c, rs_c = res[False]
+    close(out_f, out_c, 2e-5, "output vs chain")
+    close(dx_f, dx_c, 2e-4, "input gradient vs chain")
+    for k in gr_c:
+        if k in gr_f:
+            close(gr_f[k], gr_c[k], 2e-4, "gradient vs chain")
+    for (m1, v1), (m2, v2) in zip(rs_f, rs_c):
+        close(m1, m2, 1e-5, "running_mean vs chain")
+        close(v1, v2, 1e-5, "running_var vs chain")
+
+
 def test_train_upper_wlocal(dev):
     from mmego_amd.nets_local import UpperNetwlocal
     g = golden("g6_train.npz")
@@ -247,7 +337,20 @@ def test_train_upper_wlocal_from_synced_states(dev):
     d = lambda v: v.to(dev)
     fwd_h = lambda m: m(d(x0.clone()), d(h0), d(c0), d(h0), d(c0), d(body), d(R), d(t))[0]
     fwd_o = lambda m: m(x0.clone(), h0, c0, h0, c0, body, R, t)[0]
-    _compare_training("wlocal", o, h, fwd_o, fwd_h, target[:, :, list(sk.UPPER_MAP)], g, dev, resync=True)
+
+    def near_tie(m):
+        # LocalVoxelNet's stages are 32 rows x 64..128 channels here.  On this trajectory step 2 has bn3(z3) = -1.9e-6 at one element
+        # (values of order 3: fp32 rounding): the generic product lands below zero, vox.hip's summation order above it, and that one
+        # mask element moves the gradients by 2.4e-3 of the largest one -- while both forms are 3e-7 from a float64 run of the oracle
+        # at steps 1 and 3 and the fp32 oracle itself is 1e-4 from it (tests/probe_vox_tie.py prints all of this).
+        ar = m.arena("train")
+        F = 4 * 8
+        worst = float("inf")
+        for i, C in ((1, 96), (2, 128), (3, 64)):
+            z, st = ar.get("vx.z%d" % i, (F, C)), ar.get("vx.bn%d" % i, (4, C))
+            worst = min(worst, float(((z - st[0]) * st[2] + st[3]).abs().min()))
+        return worst < 1e-5
+    _compare_training("wlocal", o, h, fwd_o, fwd_h, target[:, :, list(sk.UPPER_MAP)], g, dev, resync=True, near_tie=near_tie)
     o.eval(); h.eval()
     with torch.no_grad():
         out_o = o(x0.clone(), h0, c0, h0, c0, body, R, t)
