@@ -329,6 +329,23 @@ def lstm64_forward(ar, key, lstm, x, B, T, h0, c0, stash, p_drop, seed_ctr, salt
     return lstm64_forward_multi(ar, [(key, lstm, x, h0, c0, p_drop, seed_ctr, salt)], B, T, stash)[0]
 
 
+def _l64_bufs(ar, keys, name, l, shape):
+    """One arena buffer per stack -- for TWO stacks the halves of one buffer, so that a pair of tensors of the two stacks is always the
+    same distance apart (ops.mm_two: the stacks' products of a layer as one batched launch, masks included)."""
+    if len(keys) == 2:
+        t = ar.get("%s+%s.%s%d" % (keys[0], keys[1], name, l), (2,) + tuple(shape))
+        return [t[0], t[1]]
+    return [ar.get("%s.%s%d" % (k, name, l), shape) for k in keys]
+
+
+def _l64_wih(lstm, l):
+    """(W_ih of both directions as one [512, In] matrix, their biases as one [512] vector) where they are neighbours in memory (the
+    nets' flat parameter order), else None."""
+    W = ops.stacked(lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1))
+    b = ops.stacked(lstm.w("bias_ih", l, 0), lstm.w("bias_ih", l, 1))
+    return (W, b) if W is not None and b is not None else None
+
+
 def lstm64_forward_multi(ar, stacks, B, T, stash, last_out=None):
     """lstm64_forward for several INDEPENDENT stacks of the same depth and (B, T) -- stacks: (key, lstm, x, h0, c0, p_drop, seed_ctr, salt)
     each -- with ONE sequence-kernel launch per layer for all of them (mmego_lstm64_forward_multi: grid z = stack).  -> [(out, hn, cn)].
@@ -341,13 +358,25 @@ def lstm64_forward_multi(ar, stacks, B, T, stash, last_out=None):
     cns = [torch.empty((2 * L, B, 64), dtype=torch.float32, device=dev) for _ in stacks]
     curs = [st[2] for st in stacks]
     outs = [None] * len(stacks)
+    keys = [st[0] for st in stacks]
     for l in range(L):
         calls = []
+        xps = _l64_bufs(ar, keys, "xp", l, (B * T, 512))
+        outl = _l64_bufs(ar, keys, "out", l, (B * T, 128))
+        dol = _l64_bufs(ar, keys, "do", l, (B * T, 128)) if stash and l < L - 1 else None
+        mkl = _l64_bufs(ar, keys, "mk", l, (B * T, 128)) if stash and l < L - 1 else None
+        wih = [_l64_wih(st[1], l) for st in stacks]
+        if len(stacks) == 2 and all(w is not None for w in wih):
+            # both stacks' input projections (both directions each: N = 512) as one batched product
+            ops.mm_two(curs[0], wih[0][0].t(), xps[0], curs[1], wih[1][0].t(), xps[1], bias0=wih[0][1], bias1=wih[1][1])
+        else:
+            for i, (key, lstm, _, h0, c0, p_drop, seed_ctr, salt) in enumerate(stacks):
+                ops.linear_pair(curs[i], lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1), lstm.w("bias_ih", l, 0), lstm.w("bias_ih", l, 1),
+                                xps[i], 256)
         for i, (key, lstm, _, h0, c0, p_drop, seed_ctr, salt) in enumerate(stacks):
             hn, cn = hns[i], cns[i]
-            xp = ar.get("%s.xp%d" % (key, l), (B * T, 512))
-            ops.linear_pair(curs[i], lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1), lstm.w("bias_ih", l, 0), lstm.w("bias_ih", l, 1), xp, 256)
-            out = last_out[i] if (last_out is not None and l == L - 1) else ar.get("%s.out%d" % (key, l), (B * T, 128))
+            xp = xps[i]
+            out = last_out[i] if (last_out is not None and l == L - 1) else outl[i]
             if stash:
                 gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
                 cst = ar.get("%s.c%d" % (key, l), (2, T, B, 64))
@@ -362,8 +391,8 @@ def lstm64_forward_multi(ar, stacks, B, T, stash, last_out=None):
             outs[i] = curs[i] = out
             drop = (None, None, 0.0, None, 0)
             if stash and p_drop > 0.0 and l < L - 1:
-                curs[i] = ar.get("%s.do%d" % (key, l), (B * T, 128))
-                drop = (curs[i], ar.get("%s.mk%d" % (key, l), (B * T, 128)), float(p_drop), seed_ctr, 8 * salt + l)
+                curs[i] = dol[i]
+                drop = (curs[i], mkl[i], float(p_drop), seed_ctr, 8 * salt + l)
             calls.append((B, T, xp, xp[:, 256:], 512, lstm.w("weight_hh", l, 0), lstm.w("weight_hh", l, 1),
                           lstm.w("bias_hh", l, 0), lstm.w("bias_hh", l, 1), h00, h01, c00, c01, out, out.stride(0), hn[2 * l], hn[2 * l + 1],
                           cn[2 * l], cn[2 * l + 1], *st, *drop))
@@ -407,19 +436,24 @@ def lstm64_backward_multi(ar, stacks, B, T, G, need_dx, leaves=None):
     own = leaves is None             # (a caller's list: the caller runs it, together with its other leaves)
     if own:
         leaves = []
+    keys = [st[0] for st in stacks]
     for l in range(L - 1, -1, -1):
         calls, after = [], []
+        dgl = _l64_bufs(ar, keys, "dg", l, (B * T, 512))
+        inps, masks = [], []
         for i, (key, lstm, x, c0, _, p_drop) in enumerate(stacks):
             if l == 0:
-                inp = x
-            elif p_drop > 0.0:
-                inp = ar.get("%s.do%d" % (key, l - 1), (B * T, 128))
+                inps.append(x)
             else:
-                inp = ar.get("%s.out%d" % (key, l - 1), (B * T, 128))
+                inps.append(_l64_bufs(ar, keys, "do" if p_drop > 0.0 else "out", l - 1, (B * T, 128))[i])
+            masks.append(_l64_bufs(ar, keys, "mk", l - 1, (B * T, 128))[i] if l > 0 and p_drop > 0.0 else None)
+        dxl = _l64_bufs(ar, keys, "dx", l, (B * T, inps[0].shape[1])) if (l > 0 or need_dx) and len({t.shape[1] for t in inps}) == 1 else None
+        for i, (key, lstm, x, c0, _, p_drop) in enumerate(stacks):
+            inp = inps[i]
             gates = ar.get("%s.g%d" % (key, l), (2, T, B, 256))
             cst = ar.get("%s.c%d" % (key, l), (2, T, B, 64))
             hprev = ar.get("%s.hp%d" % (key, l), (2, B * T, 64))
-            dg = ar.get("%s.dg%d" % (key, l), (B * T, 512))
+            dg = dgl[i]
             c00 = c0[2 * l] if c0 is not None else None
             c01 = c0[2 * l + 1] if c0 is not None else None
             d_cur = d_curs[i]
@@ -443,10 +477,10 @@ def lstm64_backward_multi(ar, stacks, B, T, G, need_dx, leaves=None):
                         ops.colsum(dg[:, d * 256:(d + 1) * 256], G(lstm.w("bias_ih", l, d)), out2=G(lstm.w("bias_hh", l, d)))
             leaves.append(weight_grads)
             if l > 0 or need_dx:
-                def input_grad(i=i, key=key, lstm=lstm, inp=inp, dg=dg, p_drop=p_drop, l=l):
-                    dinp = ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))
+                def input_grad(i=i, key=key, lstm=lstm, inp=inp, dg=dg, l=l):
+                    dinp = dxl[i] if dxl is not None else ar.get("%s.dx%d" % (key, l), (B * T, inp.shape[1]))
                     # (the inter-layer dropout mask is applied by the last product's epilogue)
-                    mask = ar.get("%s.mk%d" % (key, l - 1), (B * T, 128)) if l > 0 and p_drop > 0.0 else None
+                    mask = masks[i]
                     Wc = ops.stacked(lstm.w("weight_ih", l, 0), lstm.w("weight_ih", l, 1))
                     if Wc is not None:      # both directions' input weights back to back (the net's flat_param_order): one product
                         ops.grad_input(dg, Wc, dinp, cmul=mask)
@@ -463,8 +497,14 @@ def lstm64_backward_multi(ar, stacks, B, T, G, need_dx, leaves=None):
             hip.call("lstm64_backward_multi", len(calls), descs)
         else:
             hip.call("lstm64_backward", *calls[0])
-        for fn in after:
-            fn()
+        wih = [_l64_wih(st[1], l) for st in stacks]
+        if len(after) == 2 and dxl is not None and all(w is not None for w in wih):
+            # both stacks' input gradients (dropout masks in the epilogue) as one batched product
+            ops.mm_two(dgl[0], wih[0][0], dxl[0], dgl[1], wih[1][0], dxl[1], cmul0=masks[0], cmul1=masks[1])
+            d_curs[0], d_curs[1] = dxl[0], dxl[1]
+        else:
+            for fn in after:
+                fn()
     if own:
         run_leaves(leaves)
     return [d if need_dx else None for d in d_curs]

@@ -144,6 +144,33 @@ def bmm(A, B, C, accumulate=False, bias=None):
     return C
 
 
+def mm_two(A0, B0, C0, A1, B1, C1, bias0=None, bias1=None, cmul0=None, cmul1=None):
+    """C0 = A0 @ B0 (+ bias0)(* cmul0) and C1 = A1 @ B1 (+ bias1)(* cmul1) -- two INDEPENDENT products of one shape -- as ONE batched
+    launch: the batch strides are the distances between the operands (any two fp32 tensors are a whole number of elements apart).  The
+    multipliers must lie as far apart as the outputs (two halves of one buffer).  Falls back to two launches when the layouts differ."""
+    same = (A0.shape == A1.shape and B0.shape == B1.shape and C0.shape == C1.shape and A0.stride() == A1.stride() and B0.stride() == B1.stride()
+            and C0.stride() == C1.stride() and (bias0 is None) == (bias1 is None) and (cmul0 is None) == (cmul1 is None))
+    dA, dB, dC = A1.data_ptr() - A0.data_ptr(), B1.data_ptr() - B0.data_ptr(), C1.data_ptr() - C0.data_ptr()
+    if same and cmul0 is not None:
+        same = (cmul0.shape == C0.shape and cmul1.shape == C0.shape and cmul0.stride() == C0.stride() and cmul1.stride() == C0.stride()
+                and cmul1.data_ptr() - cmul0.data_ptr() == dC)
+    if same and bias0 is not None:
+        same = bias0.is_contiguous() and bias1.is_contiguous() and bias0.numel() == B0.shape[1] == bias1.numel()
+    if not same or dA % 16 or dB % 16 or dC % 16:
+        mm(A0, B0, C0, bias=bias0, cmul=cmul0)
+        mm(A1, B1, C1, bias=bias1, cmul=cmul1)
+        return False
+    _chk(A0, 2), _chk(B0, 2), _chk(C0, 2), _chk(A1, 2), _chk(B1, 2), _chk(C1, 2)
+    M, K = A0.shape
+    K2, N = B0.shape
+    if K2 != K or tuple(C0.shape) != (M, N):
+        raise ValueError("mm_two shape mismatch")
+    dbias = (bias1.data_ptr() - bias0.data_ptr()) // 4 if bias0 is not None else 0
+    hip.call("gemm", A0, A0.stride(0), A0.stride(1), B0, B0.stride(0), B0.stride(1), C0, C0.stride(0), C0.stride(1), bias0,
+             M, N, K, 2, dA // 4, dB // 4, dC // 4, 0, 0, None, 1, dbias, cmul0, None)
+    return True
+
+
 def linear_pair(x, W0, W1, b0, b1, out, ncol):
     """out[:, :ncol] = x W0^T + b0 and out[:, ncol:2 ncol] = x W1^T + b1 as ONE batched product (the two directions' input
     projections of a BiLSTM layer: 2 x 1280 tiles = exactly five rounds of the persistent GEMM grid instead of 2 x 2.5)."""
