@@ -17,7 +17,13 @@ KERNELS = {"lstm_step_dma_kernel<32>": ("bench", "step"), "lstm_step_dma_kernel<
            "mlp_bwd_layer_kernel": ("bench", "wlocal"), "local_group_l1_kernel": ("wlocal",), "pool8_bwd_kernel": ("wlocal",),
            "pool8_bn_act_kernel": ("wlocal",),
            # r04, late: rnn_slow's recurrence as one persistent launch per layer (lstm_seq.hip)
-           "lstm_seq_xcd_kernel": ("bench",)}
+           "lstm_seq_xcd_kernel": ("bench",),
+           # r05: the split3 mode's kernels (passes with MMEGO_IMU_PRECISION=split3: "split3"), the PointNet forward layer, LocalVoxelNet's
+           # kernels, the paired BiLSTM(64) launches
+           "s3_gemm_kernel": ("split3",), "s3_step_kernel": ("split3",), "s3_cvt_kernel": ("split3",), "s3_fc_relu_kernel": ("split3",),
+           "mlp_fwd_layer_kernel": ("bench", "wlocal"), "vox_l1_fwd_kernel": ("wlocal",), "vox_l1_bwd_kernel": ("wlocal",),
+           "vox_dw_kernel": ("wlocal",), "vox_mid_fwd_kernel": ("wlocal",), "vox_mid_bwd_kernel": ("wlocal",),
+           "lstm64_fwd_multi_kernel": ("wlocal",), "lstm64_bwd_multi_kernel": ("wlocal",)}
 res = {}
 for kname, stems in KERNELS.items():
     by_grid = collections.defaultdict(lambda: collections.defaultdict(list))
