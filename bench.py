@@ -199,7 +199,8 @@ def pmc_traffic(kernel_label):
     around THIS program (`bench.py --trace-only --no-graph`, scripts/collect_profiles.sh), the r02 / r01 files around the
     micro-benchmarks scripts/bench_gemm_pair.py / bench_lstm_step.py."""
     key = kernel_label.split(" ")[0]
-    for name, what in (("r04_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself (scripts/collect_r04.sh)"),
+    for name, what in (("r05_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself (scripts/collect_r05.sh)"),
+                       ("r04_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself (scripts/collect_r04.sh)"),
                        ("r03_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself"),
                        ("r02_pmc_counters.json", "rocprofv3 --pmc passes of the micro-benchmarks scripts/bench_gemm_pair.py / bench_lstm_step.py"),
                        ("r01_pmc_counters.json", "rocprofv3 --pmc passes of the micro-benchmarks")):
@@ -654,6 +655,8 @@ def split3_figures(device, imu, imu_in, out, with_parity=True):
                      "achieved": npr * tot_fl / (tot_ms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "bound": "mfma",
                      "frac": npr * tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                      "fp32_equivalent_tflops": tot_fl / (tot_ms * 1e-3) / 1e12}
+        tr, src = pmc_traffic(name)
+        fam[name]["traffic"], fam[name]["traffic_source"] = tr, src
     res["kernels"] = fam
     if fam:
         k0 = max(fam, key=lambda k: fam[k]["ms_per_forward"])

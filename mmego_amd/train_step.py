@@ -385,7 +385,7 @@ class ConcurrentStages:
         beside it; each stage's remaining body forks off right after its own forward and takes the head pose from a per-stage
         buffer.  The IMU_Net forwards are compute-bound and gain nothing from running side by side, whereas the small-kernel
         tail of one stage overlaps with the IMU_Net forward of another (measured: 6.88 -> 6.54 ms per U+L step).  Other
-        arrangements that were measured and dropped: DESIGN.md section 9."""
+        arrangements that were measured and dropped: NOTES.md."""
         main = torch.cuda.current_stream()
         stages, streams = self.stages, [main] + self.side
         keep = [(st.imu, st.pose) for st in stages]
@@ -450,8 +450,7 @@ class PipelinedStages:
     forwards run SIDE BY SIDE (each on a stream of its own, forked from the capture's origin), so that one net's recurrent step
     fills the launch gap / prologue / cell update of the other's -- 19.3 us per timestep and net instead of 23.4 (bench.py
     `recurrence_graph`), 5.18 ms per U+L step instead of 5.48 with the two forwards one after the other in ONE branch
-    (side_by_side = False).  Within one minibatch the same pairing loses (both tails then start together, DESIGN.md
-    section 9); across minibatches nothing waits for the forwards.
+    (side_by_side = False).  Within one minibatch the same pairing loses (both tails then start together, NOTES.md); across minibatches nothing waits for the forwards.
     Every step still runs both IMU_Net forwards in full; results are bit-identical to ConcurrentStages on the same sequence of
     minibatches (tests/test_hip_local.py).  `imu_next` is the static buffer the caller fills with minibatch i+1's IMU samples
     before step i; `prime()` runs the forwards for the first minibatch."""

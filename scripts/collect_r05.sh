@@ -15,7 +15,8 @@ for prec in fp32 split3; do
     rocprofv3 --kernel-trace --stats -d "$out/trace_${prec}_$mode" -o bench -- python3 "$root/bench.py" --steps 20 --warmup 3 --trace-only $flag > "$out/trace_${prec}_$mode.log" 2>&1
     db=$(find "$out/trace_${prec}_$mode" -name "*.db" | head -1)
     python3 "$root/scripts/prof_summary.py" "$db" --grids > "$out/kernel_stats_${prec}_$mode.csv"
-    [ $mode == sequential ] && python3 "$root/scripts/trace_timeline.py" "$db" > "$out/timeline_${prec}_sequential.txt"
+    # (a sequential U+L step ends with its second Adam launch)
+    [ $mode == sequential ] && (python3 "$root/scripts/trace_timeline.py" "$db" --marker adam_kernel --per-step 2 > "$out/timeline_${prec}_sequential.txt" || true)
     rm -rf "$out/trace_${prec}_$mode"
     echo "trace $prec $mode done"
   done
