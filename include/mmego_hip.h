@@ -237,6 +237,13 @@ int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H, int first,
                                const unsigned short* whh0, const unsigned short* whh1, const float* bias,
                                float* hout0, float* hout1, long hos, unsigned short* hfrag0, unsigned short* hfrag1,
                                float* c0, float* c1);
+/* Attention pooling over the T timesteps of a layer run by mmego_lstm_step_bf16_fused (IMU_Net.py:77-81: softmax over t of
+ * w . h_t + b, weighted sum), read from the steps' own fragment-major bf16 h_t: hf = [T][2 directions][Bp x H] (the hfrag outputs,
+ * direction 0 then 1 per timestep).  The layer's step launches then need no fp32 output (hout NULL).  vec [Bn][2H] fp32 row-major,
+ * attn [Bn][T] or NULL; H in {128, 256, 512} (mmego_attn_pool_frag_bf16_ok), Bp % 32 == 0. */
+int mmego_attn_pool_frag_bf16_ok(int H);
+int mmego_attn_pool_frag_bf16(void* stream, const unsigned short* hf, int T, int Bp, int Bn, int H, const float* w, const float* b,
+                              float* vec, float* attn);
 /* rows (b*T + t) of X[., C] -> T fragment-major [Bp x C] bf16 matrices (timestep t at offset t*Bp*C): a layer-0 input of
  * mmego_lstm_step_bf16_fused.  C % 16 == 0, Bp % 32 == 0. */
 int mmego_cvt_bf16_frag_tm(void* stream, const float* X, long ldx, int Bn, int T, int C, unsigned short* Y, int Bp);

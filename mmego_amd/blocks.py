@@ -787,10 +787,12 @@ def fused_input_fragments(ar, key, Bn, T, In):
     return ar.get("%s.xfrag" % key, (T, Bp * In), dtype=torch.bfloat16), Bp
 
 
-def lstm_steps_forward_bf16_fused(ar, key, lstm, x, Bn, T, xfrag=None):
+def lstm_steps_forward_bf16_fused(ar, key, lstm, x, Bn, T, xfrag=None, pool=None):
     """Large-batch form of lstm_steps_forward_bf16: no projection tensor; every step multiplies [x_t | h_{t-1}] by [W_ih | W_hh]
     (bf16.hip, lstm_step_bf16_fused_kernel).  Layer inputs and all h_t live fragment-major, one [Bp x K] matrix per timestep.
-    x [Bn*T, In] fp32 rows (b*T+t), or None with `xfrag` = the layer-0 operand already in that layout."""
+    x [Bn*T, In] fp32 rows (b*T+t), or None with `xfrag` = the layer-0 operand already in that layout.
+    pool = (attention Linear, vec [Bn, 2H], attn [Bn, T]): the softmax pooling over the T timesteps behind the stack reads the last
+    layer's bf16 fragments (mmego_attn_pool_frag_bf16) -- no fp32 output is written at all; returns None then."""
     H = lstm.hidden_size
     W = lstm_bf16_weights_fused(lstm)
     In = lstm.input_size
@@ -803,7 +805,8 @@ def lstm_steps_forward_bf16_fused(ar, key, lstm, x, Bn, T, xfrag=None):
     prev = None
     for l in range(lstm.num_layers):
         segs, whh, bias = W[l]
-        last = l == lstm.num_layers - 1
+        pooled = pool is not None and bool(hip.lib().mmego_attn_pool_frag_bf16_ok(H))
+        last = l == lstm.num_layers - 1 and not pooled           # (the layer that writes the fp32 output)
         hf = ar.get("%s.hfall%d" % (key, l), (T, 2, Bp * H), dtype=torch.bfloat16)      # h_t of every timestep, fragment-major
         c = ar.get("%s.c" % key, (2, Bn, H))
         if last:
@@ -823,6 +826,13 @@ def lstm_steps_forward_bf16_fused(ar, key, lstm, x, Bn, T, xfrag=None):
                      out_p + 4 * (t0 * 2 * H) if last else None, out_p + 4 * (t1 * 2 * H + H) if last else None, os_,
                      hf[t0, 0], hf[t1, 1], c[0], c[1])
         prev = hf
+    if pool is not None:
+        lin, vec, attn = pool
+        if out is None:
+            hip.call("attn_pool_frag_bf16", prev, T, Bp, Bn, H, lin.weight, lin.bias, vec, attn)
+            return None
+        attn_pool_forward(out, lin, Bn, T, 2 * H, vec, attn)
+        return None
     return out
 
 

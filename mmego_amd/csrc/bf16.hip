@@ -1169,3 +1169,103 @@ extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H,
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
+
+// ---- attention pooling over the timesteps of a BiLSTM layer whose h_t live fragment-major in bf16 (r05) ---------------------------
+// IMU_Net.py:77-81 (softmax over the 20 samples of a frame of w . h + b, weighted sum) on the fused step's own h_t fragments
+// (hf [T][2 directions][Bp x H], fragment-major bf16): the layer's last step launches then write NO fp32 output (the HOUT form of the
+// 256 x 256-tile step costs 73 us per launch more: 134 MB of fp32 stores per timestep at config 5) and the pooling reads 2 instead of
+// 4 bytes per element.  One workgroup per 32-frame row block, eight waves = 2 directions x 4 column quarters, lane = (frame, 8-k
+// half): per timestep a wave fetches its NPW pieces (one coalesced 1-KB read each), the partial scores meet in LDS (one barrier per
+// timestep, double-buffered), and the weighted sum is kept ONLINE (running maximum and denominator: one pass over the data); the next
+// timestep's pieces are in flight while this one is reduced.  vec [Bn][2H] fp32 row-major; attn [Bn][T] (optional).
+template <int NPW>
+__global__ __launch_bounds__(512) void attn_pool_frag_bf16_kernel(const bf16_t* __restrict__ hf, int T, int Bp, int Bn,
+                                                                  const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  float* __restrict__ vec, float* __restrict__ attn) {
+  constexpr int H = NPW * 64;
+  __shared__ float red[2][8][32];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, d = wv >> 2, q = wv & 3;
+  const int rb = blockIdx.x, fr = lane & 31, kh = lane >> 5;
+  const int frame = rb * 32 + fr;
+  const int col0 = d * H + q * (H / 4) + 8 * kh;               // this lane's columns: col0 + 16 p + e
+  float wl[NPW][8];
+#pragma unroll
+  for (int p = 0; p < NPW; ++p)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wl[p][e] = w[col0 + 16 * p + e];
+  const float b0 = bias[0];
+  // piece (row block rb, 16-k group q NPW + p) of direction d at timestep s
+  const long step_stride = 2L * Bp * H;
+  const u32x4* base = reinterpret_cast<const u32x4*>(hf + (long)d * Bp * H) + ((long)rb * (H >> 4) + q * NPW) * 64 + lane;
+  u32x4 cur[NPW], nxt[NPW];
+#pragma unroll
+  for (int p = 0; p < NPW; ++p) cur[p] = base[p * 64];
+  float acc[NPW][8];
+#pragma unroll
+  for (int p = 0; p < NPW; ++p)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  for (int s = 0; s < T; ++s) {
+    const int sn = min(s + 1, T - 1);                          // (clamped, unconditional: a predicated load drains the memory pipe)
+    const u32x4* nb = reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(base) + sn * step_stride);
+#pragma unroll
+    for (int p = 0; p < NPW; ++p) nxt[p] = nb[p * 64];
+    float hv[NPW][8];
+    float ps = 0.f;
+#pragma unroll
+    for (int p = 0; p < NPW; ++p)
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const unsigned u = cur[p][e2];
+        hv[p][2 * e2] = __uint_as_float(u << 16);
+        hv[p][2 * e2 + 1] = __uint_as_float(u & 0xffff0000u);
+        ps += wl[p][2 * e2] * hv[p][2 * e2] + wl[p][2 * e2 + 1] * hv[p][2 * e2 + 1];
+      }
+    ps += __shfl_xor(ps, 32);
+    if (lane < 32) red[s & 1][wv][fr] = ps;
+    __syncthreads();
+    float sc = b0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sc += red[s & 1][k][fr];
+    const float mn = fmaxf(m, sc);
+    const float scale = __expf(m - mn), pe = __expf(sc - mn);
+    l = l * scale + pe;
+    m = mn;
+#pragma unroll
+    for (int p = 0; p < NPW; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[p][e] = acc[p][e] * scale + pe * hv[p][e];
+    if (attn && wv == 0 && lane < 32 && frame < Bn) attn[(long)frame * T + s] = sc;      // (raw scores; normalized below)
+#pragma unroll
+    for (int p = 0; p < NPW; ++p) cur[p] = nxt[p];
+  }
+  if (frame < Bn) {
+    const float inv = 1.0f / l;
+    float* o = vec + (long)frame * (2 * H) + col0;
+#pragma unroll
+    for (int p = 0; p < NPW; ++p) {
+      *reinterpret_cast<f32x4*>(o + 16 * p) = f32x4{acc[p][0] * inv, acc[p][1] * inv, acc[p][2] * inv, acc[p][3] * inv};
+      *reinterpret_cast<f32x4*>(o + 16 * p + 4) = f32x4{acc[p][4] * inv, acc[p][5] * inv, acc[p][6] * inv, acc[p][7] * inv};
+    }
+    if (attn && wv == 0 && lane < 32)
+      for (int s = 0; s < T; ++s) attn[(long)frame * T + s] = __expf(attn[(long)frame * T + s] - m) * inv;
+  }
+}
+
+extern "C" int mmego_attn_pool_frag_bf16_ok(int H) { return H == 128 || H == 256 || H == 512; }
+
+// hf: [T][2][Bp x H] fragment-major bf16 (the hfrag outputs of mmego_lstm_step_bf16_fused for every timestep, direction 0 then 1);
+// w [2H], b [1]: the attention Linear; vec [Bn][2H]; attn [Bn][T] or NULL.  Bp % 32 == 0, Bn <= Bp, H in {128, 256, 512}.
+extern "C" int mmego_attn_pool_frag_bf16(void* stream, const unsigned short* hf, int T, int Bp, int Bn, int H, const float* w, const float* b,
+                                         float* vec, float* attn) {
+  MMEGO_REQUIRE(hf && w && b && vec && T > 0 && Bp > 0 && Bp % 32 == 0 && Bn > 0 && Bn <= Bp && mmego_attn_pool_frag_bf16_ok(H));
+  MMEGO_REQUIRE((((uintptr_t)hf | (uintptr_t)vec) & 15) == 0);
+  const dim3 grid(Bp / 32);
+  const bf16_t* h = reinterpret_cast<const bf16_t*>(hf);
+  if (H == 512) attn_pool_frag_bf16_kernel<8><<<grid, 512, 0, (hipStream_t)stream>>>(h, T, Bp, Bn, w, b, vec, attn);
+  else if (H == 256) attn_pool_frag_bf16_kernel<4><<<grid, 512, 0, (hipStream_t)stream>>>(h, T, Bp, Bn, w, b, vec, attn);
+  else attn_pool_frag_bf16_kernel<2><<<grid, 512, 0, (hipStream_t)stream>>>(h, T, Bp, Bn, w, b, vec, attn);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}

@@ -28,6 +28,8 @@
 //   s3_fc_relu_kernel    IMU_Net's fc1 + ReLU (K <= 16) straight into the layer-0 operand
 //   s3_gemm_kernel       C = A . W^T + bias on 6 (9) piece products, 64 / 128 / 256 x 128 tiles
 //   s3_step_kernel       one BiLSTM timestep, both directions: gates = xproj + h_{t-1} . W_hh^T, cell update, h_t as pieces
+#include <stdlib.h>
+
 #include "common.h"
 
 // Compile-time experiment mask (scripts/s3_experiments.py builds variant libraries with -DS3_EXP=<mask> to take a kernel's time apart
@@ -266,6 +268,7 @@ struct S3GemmP {
   const float* bias;       // [32 Nrb] or null
   int Mrb, Nrb, SK, M;     // M: rows really stored to C (row-major output only)
   int tiles_m, tiles_n;
+  int gm;                  // row panels per sweep group (tile order)
 };
 
 // Workgroup tile (32 MI WM) x 128, WM x 2 waves, wave tile (32 MI) x 64 = MI x 2 MFMA tiles.  32-k chunks (2 16-k steps): the chunk's
@@ -284,10 +287,10 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
   __shared__ s3_u32x4 Bs[4 * 384];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;
-  // tile order: runs of 16 row panels sweep the N tiles, so a W panel is shared by 16 consecutive workgroups and the 16 A panels
-  // stay in L2 for the whole sweep
+  // tile order: runs of p.gm row panels sweep the N tiles, so that the workgroups resident on an XCD at one time share few A and few W
+  // panels (64 resident 256 x 128 tiles as 4 row panels x 16 column tiles)
   const int id = s3_xcd_order(blockIdx.x, (int)gridDim.x);
-  const int GM = 16;
+  const int GM = p.gm;
   const int per_group = GM * p.tiles_n;
   const int group = id / per_group, in_group = id - group * per_group;
   const int gm = min(GM, p.tiles_m - group * GM);
@@ -410,6 +413,7 @@ extern "C" int mmego_split3_gemm(void* stream, const unsigned short* A, const un
   p.A = reinterpret_cast<const s3_u32x4*>(A); p.W = reinterpret_cast<const s3_u32x4*>(W);
   p.Cf = Cf; p.C = C; p.ldc = ldc; p.bias = bias; p.Mrb = Mrb; p.Nrb = Nrb; p.SK = K / 16; p.M = M;
   p.tiles_m = cdiv(Mrb, 2 * wm); p.tiles_n = cdiv(Nrb, 4);
+  p.gm = 4;         // (r05: 4 / 8 / 16 / 32 row panels per sweep group measured 194 / 193 / 197 / 205 us at K = 512, 369 / 373 / 377 / 387 at 1024)
   const long tiles = (long)p.tiles_m * p.tiles_n;
   MMEGO_REQUIRE(tiles < (1L << 30));
   hipStream_t st = (hipStream_t)stream;

@@ -1068,7 +1068,10 @@ class IMUNet(_NetBase):
             # the fp32 activation [Bn*S, H] (1.3 GB at config 5) is never stored
             xf, Bp = blocks.fused_input_fragments(ar, "fast", Bn, S, H)
             hip.call("fc_relu_bf16_frag_tm", imu.view(Bn * S, Cin), Cin, self.fc1.weight, self.fc1.bias, Bn, S, Cin, H, xf, Bp, 1)
-            fast = blocks.lstm_steps_forward_bf16_fused(ar, "fast", self.rnn_fast, None, Bn, S, xfrag=xf)
+            # (the attention pooling behind rnn_fast reads the last layer's bf16 fragments: no fp32 h_t is stored either)
+            pooled = ar.get("pooled", (Bn, 2 * H))
+            attn = ar.get("attn", (Bn, S))
+            fast = blocks.lstm_steps_forward_bf16_fused(ar, "fast", self.rnn_fast, None, Bn, S, xfrag=xf, pool=(self.attn, pooled, attn))
         else:
             h = ar.get("fc1", (Bn * S, H))
             ops.linear(imu.view(Bn * S, Cin), self.fc1.weight, self.fc1.bias, h, relu=True)
@@ -1076,9 +1079,10 @@ class IMUNet(_NetBase):
                 fast = blocks.lstm_steps_forward_bf16(ar, "fast", self.rnn_fast, h, Bn, S)
             else:
                 fast = blocks.lstm_steps_forward(ar, "fast", self.rnn_fast, h, Bn, S)          # [Bn*S, 2H]
-        pooled = ar.get("pooled", (Bn, 2 * H))
-        attn = ar.get("attn", (Bn, S))
-        blocks.attn_pool_forward(fast, self.attn, Bn, S, 2 * H, pooled, attn)
+        if fast is not None:
+            pooled = ar.get("pooled", (Bn, 2 * H))
+            attn = ar.get("attn", (Bn, S))
+            blocks.attn_pool_forward(fast, self.attn, Bn, S, 2 * H, pooled, attn)
         if bf16:
             slow = blocks.lstm_steps_forward_bf16(ar, "slow", self.rnn_slow, pooled, B, T)
         else:

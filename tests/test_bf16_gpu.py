@@ -206,6 +206,38 @@ def test_fc_relu_bf16_fragments_and_the_imu_forward_that_uses_them(monkeypatch):
     assert float((R1 - R0).abs().mean()) < 2e-3
 
 
+@pytest.mark.parametrize("T,Bn,H", [(20, 70, 128), (5, 32, 512), (20, 64, 256), (1, 33, 128)])
+def test_attention_pooling_from_bf16_fragments(T, Bn, H):
+    """mmego_attn_pool_frag_bf16 (IMU_Net's pooling over the 20 samples read from the fused step's own bf16 h_t fragments, online
+    softmax) against the fp32 pooling kernel on the same bf16-rounded values: pooled vectors and attention weights at fp32 rounding;
+    ragged row counts (rows past Bn are padding), one timestep."""
+    from mmego_amd import blocks, hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(T * 1000 + Bn + H)
+    Bp = (Bn + 31) // 32 * 32
+    h = (torch.randn(T, 2, Bp, H, generator=g) * 1.5).to(torch.bfloat16)
+    r, k = torch.arange(Bp)[:, None], torch.arange(H)[None, :]
+    off = ((((r >> 5) * (H >> 4) + (k >> 4)) * 64) + ((k >> 3) & 1) * 32 + (r & 31)) * 8 + (k & 7)      # frag_off of bf16.hip
+    hf = torch.empty(T, 2, Bp * H, dtype=torch.bfloat16)
+    for t in range(T):
+        for d in range(2):
+            hf[t, d][off.flatten()] = h[t, d].flatten()
+    lin = torch.nn.Linear(2 * H, 1)
+    lin.weight.data.normal_(0.0, 0.2, generator=g)
+    lin = lin.to(dev)
+    # the fp32 kernel's input: rows (b * T + t), columns [direction 0 | direction 1]
+    fast = torch.cat([h[:, 0], h[:, 1]], dim=2)[:, :Bn].float().permute(1, 0, 2).reshape(Bn * T, 2 * H).contiguous().to(dev)
+    vec_ref, attn_ref = torch.empty(Bn, 2 * H, device=dev), torch.empty(Bn, T, device=dev)
+    blocks.attn_pool_forward(fast, lin, Bn, T, 2 * H, vec_ref, attn_ref)
+    vec, attn = torch.full((Bn, 2 * H), 7.0, device=dev), torch.full((Bn, T), 7.0, device=dev)
+    assert hip.lib().mmego_attn_pool_frag_bf16_ok(H)
+    hip.call("attn_pool_frag_bf16", hf.to(dev), T, Bp, Bn, H, lin.weight, lin.bias, vec, attn)
+    torch.cuda.synchronize()
+    assert float((attn - attn_ref).abs().max()) < 2e-6
+    assert float((vec - vec_ref).abs().max()) < 2e-5 * max(1.0, float(vec_ref.abs().max()))
+    assert abs(float(attn.sum(1).mean()) - 1.0) < 1e-5
+
+
 def test_config5_full_size_bf16_forward():
     """BASELINE config 5 at its FULL size (B = 2048 sequences, T = 16 frames -> 32 768 rows x 20 samples through rnn_fast, the
     fused projection + recurrence step; 2048 x 16 through rnn_slow): IMUNet.precision = "bf16".  The CPU emulation cannot run
