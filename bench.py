@@ -524,11 +524,28 @@ def stage1_step(device):
     for _ in range(3):
         st.step()
     ms = _time_events(st.step, 20, 2)
+    # the same step with rnn_fast's input-projection and input-gradient products as fp32-accurate piece products on the bf16 matrix
+    # pipe (IMUNet.train_precision = "split3", opt-in; test_imu_stage1_gradients_at_full_size holds it to the same bars)
+    ms_s3 = None
+    try:
+        torch.manual_seed(4)
+        net3 = nets.IMUNet(15, 9, 512, 2, True, 0).to(device).train()
+        net3.train_precision = "split3"
+        st3 = ImuStep(net3, lr=1e-4, weight_decay=0.001, use_graph=True)
+        st3.bind(imu, Rg, tgt)
+        for _ in range(3):
+            st3.step()
+        ms_s3 = _time_events(st3.step, 20, 2)
+        loss_s3 = float(st3.loss.item())
+        del net3, st3
+    except Exception as e:                                  # (reported, never fatal for the headline)
+        ms_s3, loss_s3 = None, repr(e)
     flop = 3.0 * 2.0 * 222.48e6 * B * T
     res = {"workload": "stage-1 IMU_Net training step (forward, geodesic + position loss, backward, Adam with weight decay), "
                        "B=64 T=8 S=20, fp32, one HIP graph per step", "ms_per_step": ms, "frames_per_s": B * T / (ms * 1e-3),
            "algorithmic_tflops": flop / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-           "loss": float(st.loss.item())}
+           "loss": float(st.loss.item()),
+           "ms_per_step_split3_products": ms_s3, "loss_split3_products": loss_s3}
     del net, st
     torch.cuda.empty_cache()
     return res
@@ -722,7 +739,7 @@ def emit(out):
     if "parity" in out and isinstance(out["parity"], dict):
         ex["parity_cm"] = {k[:-3]: float("%.3g" % out["parity"][k]) for k in ("upper_cm", "lower_cm", "tolerance_cm") if k in out["parity"]}
     for k, sub in (("config2_ms", ("config2", "ms_per_forward")), ("config5_ms", ("config5", "ms_per_forward")),
-                   ("stage1_ms", ("stage1", "ms_per_step")), ("wlocal_train_ms", ("wlocal", "train_ms_per_step")),
+                   ("stage1_ms", ("stage1", "ms_per_step")), ("stage1_split3_ms", ("stage1", "ms_per_step_split3_products")), ("wlocal_train_ms", ("wlocal", "train_ms_per_step")),
                    ("wlocal_eval_ms", ("wlocal", "eval_ms_per_forward"))):
         v = out.get(sub[0])
         if isinstance(v, dict) and sub[1] in v:

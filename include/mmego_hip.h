@@ -371,6 +371,16 @@ int mmego_upper_front_eval_bf16(void* stream, float* x, const float* x_src, cons
  * k = 16 s + 8 (l / 32) .. + 8 -- is 1 KB at ((rb * K / 16 + s) * 3 + p) KB.  Activation rows are time-major (t * Bp + b). */
 int mmego_split3_cvt(void* stream, const float* X, long ldx, long rows_in, int K, int tm, int Bn, int T, int Bp, long Rp,
                      unsigned short* Y);
+/* mmego_split3_gemm cut into nsplit slabs of K (a long contraction with few output tiles): slab y leaves its partial product row-major
+ * at ws + y * (32 Mrb) * (32 Nrb) floats -- the format mmego_slab_reduce kind 0 sums. */
+int mmego_split3_gemm_slabs(void* stream, const unsigned short* A, const unsigned short* W, float* ws, int Mrb, int Nrb, int K,
+                            int nprod, int wm, int nsplit);
+/* out[i] = sum over y < nsplit of ws[y * n + i] (slab order): the K slabs of mmego_split3_gemm_slabs as one streaming sum.  n % 4 == 0. */
+int mmego_split3_slab_sum(void* stream, const float* ws, int nsplit, long n, float* out);
+/* The pieces of X^T for X [R][C] row-major (weight-gradient operands: both are read along the row axis): Y = sfrag of the [Cp x R]
+ * matrix, Cp % 32 == 0 >= C, R % 16 == 0.  T > 0: column r of X^T is row r + shift of X where that row lies in the same T-row sequence
+ * (rows b T + t), zero otherwise -- h_{t-1} / h_{t+1} of a layer's outputs without a shifted copy; T = 0, shift = 0: plain. */
+int mmego_split3_cvt_t(void* stream, const float* X, long ldx, long R, int C, long Cp, unsigned short* Y, int shift, int T);
 int mmego_split3_join(void* stream, const unsigned short* Y, long Rp, int K, float* X, long ldx);
 int mmego_split3_fc_relu(void* stream, const float* X, long ldx, const float* W, const float* bias, int Bn, int T, int Cin,
                          int H, unsigned short* Y, int Bp, int relu);

@@ -910,6 +910,19 @@ def split3_cvt(x, out=None, Rp=None, tm=None):
     return out
 
 
+def split3_cvt_t(x, out=None, shift=0, T=0):
+    """fp32 [R, C] (unit column stride, R % 16 == 0) -> the sfrag pieces of x^T ([C rounded up to 32] rows, K = R).
+    T > 0: column r of x^T is row r + shift of x inside r's T-row sequence, zero outside (h_{t-1} / h_{t+1} without a copy)."""
+    R, C = x.shape
+    if x.stride(1) != 1 or x.dtype != torch.float32 or R % 16:
+        raise ValueError("split3_cvt_t needs fp32 rows with unit column stride and R % 16 == 0")
+    Cp = (C + 31) // 32 * 32
+    if out is None:
+        out = torch.empty((Cp // 32, R // 16, 3, 64, 8), dtype=torch.bfloat16, device=x.device)
+    hip.call("split3_cvt_t", x, x.stride(0), R, C, Cp, out, int(shift), int(T))
+    return out
+
+
 def split3_join(y, rows, K):
     """sfrag pieces -> fp32 [Rp, K] (a1 + a2 + a3): the inverse of split3_cvt for values in the exact range."""
     Rp = y.shape[0] * 32

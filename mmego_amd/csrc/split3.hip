@@ -125,6 +125,57 @@ extern "C" int mmego_split3_cvt(void* stream, const float* X, long ldx, long row
   return MMEGO_OK;
 }
 
+// The pieces of X^T: X [R][C] fp32 row-major (row stride ldx) -> sfrag of the [Cp x R] matrix whose row c is X's column c (Cp = C rounded
+// up to 32, zero rows behind C; R % 16 == 0).  Lane l of block (rb, s) holds row 32 rb + l % 32 of X^T = COLUMN 32 rb + l % 32 of X and
+// k = 16 s + 8 (l / 32) + e = ROW of X: for a fixed e the 32 lanes of a half wave read 32 consecutive floats of one row of X (128 B).
+// For the weight-gradient products of stage-1 training (dW = dY^T X: both operands are read along the row axis).
+// shift / T (T > 0): the k axis reads row r + shift of X where that row belongs to the same T-row sequence as r (rows b T + t), zero
+// otherwise: h_{t-1} (shift -1) or h_{t+1} (shift +1, the reverse direction) of a BiLSTM layer's outputs without a shifted copy.
+__global__ __launch_bounds__(256) void s3_cvt_t_kernel(const float* __restrict__ X, long ldx, int C, int SK, s3_u32x4* __restrict__ Y, long nblk,
+                                                        int shift, int T) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int lane = (int)(idx & 63);
+  const long blk = idx >> 6;
+  if (blk >= nblk) return;
+  const long rb = blk / SK;
+  const int s = (int)(blk - rb * SK);
+  const int c = (int)rb * 32 + (lane & 31);
+  const bool live = c < C;
+  const int r0 = 16 * s + 8 * (lane >> 5);
+  const float* xc = X + (live ? c : 0);
+  float y[8];
+  bool ok[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int r = r0 + e;
+    int t = 0;
+    if (T > 0) t = r % T + shift;
+    ok[e] = live && t >= 0 && (T <= 0 || t < T);
+    y[e] = xc[(long)(ok[e] ? r + (T > 0 ? shift : 0) : r) * ldx];          // (clamped to a valid row, never predicated)
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) y[e] = ok[e] ? y[e] : 0.f;
+  s3_u32x4 o1, o2, o3;
+  s3_split8(y, o1, o2, o3);
+  s3_u32x4* dst = Y + blk * 192 + lane;
+  dst[0] = o1;
+  dst[64] = o2;
+  dst[128] = o3;
+}
+
+// X [R][C] fp32 (row stride ldx) -> Y = sfrag pieces of X^T: [Cp / 32][R / 16][3][64][8] bf16, Cp % 32 == 0, Cp >= C, R % 16 == 0.
+extern "C" int mmego_split3_cvt_t(void* stream, const float* X, long ldx, long R, int C, long Cp, unsigned short* Y, int shift, int T) {
+  MMEGO_REQUIRE(X && Y && R > 0 && R % 16 == 0 && R < (1L << 30) && C > 0 && Cp >= C && Cp % 32 == 0 && ldx >= C);
+  MMEGO_REQUIRE(T >= 0 && (T == 0 ? shift == 0 : (R % T == 0 && shift > -T && shift < T)));
+  MMEGO_REQUIRE((((uintptr_t)Y) & 15) == 0);
+  const long nblk = (Cp / 32) * (R / 16);
+  const long nthr = nblk * 64;
+  MMEGO_REQUIRE(nthr / 256 + 1 < (1L << 31));
+  s3_cvt_t_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, (hipStream_t)stream>>>(X, ldx, C, (int)(R / 16), reinterpret_cast<s3_u32x4*>(Y), nblk, shift, T);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
 // sfrag -> fp32 row-major (a1 + a2 + a3 in that order of addition: exact for a split of an fp32 value).  Test / debug aid.
 __global__ __launch_bounds__(256) void s3_join_kernel(const s3_u32x4* __restrict__ Y, int SK, long nblk, float* __restrict__ X, long ldx) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -269,6 +320,8 @@ struct S3GemmP {
   int Mrb, Nrb, SK, M;     // M: rows really stored to C (row-major output only)
   int tiles_m, tiles_n;
   int gm;                  // row panels per sweep group (tile order)
+  int cps;                 // split-K (grid.y = number of K slabs): 32-k chunks per slab; slab y writes its partial product behind the
+  long slab;               // others' (C + y * slab floats; Cf likewise); bias only in slab 0
 };
 
 // Workgroup tile (32 MI WM) x 128, WM x 2 waves, wave tile (32 MI) x 64 = MI x 2 MFMA tiles.  32-k chunks (2 16-k steps): the chunk's
@@ -310,11 +363,12 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
     const int i = j * NT + tid;
     gw[j] = min(rbW0 + i / 384, p.Nrb - 1) * SK * 192 + i % 384;
   }
+  const int c0 = (int)blockIdx.y * p.cps;
   s3_u32x4 ra[NLA], rw[NLW];
 #pragma unroll
-  for (int j = 0; j < NLA; ++j) ra[j] = p.A[ga[j]];
+  for (int j = 0; j < NLA; ++j) ra[j] = p.A[ga[j] + c0 * 384];
 #pragma unroll
-  for (int j = 0; j < NLW; ++j) rw[j] = p.W[gw[j]];
+  for (int j = 0; j < NLW; ++j) rw[j] = p.W[gw[j] + c0 * 384];
 
   f32x16 acc[MI][2];
 #pragma unroll
@@ -324,8 +378,8 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-  const int nchunk = SK >> 1;
-  for (int c = 0; c < nchunk; ++c) {
+  const int nchunk = min(SK >> 1, c0 + p.cps);          // (this K slab: chunks [c0, nchunk))
+  for (int c = c0; c < nchunk; ++c) {
     __syncthreads();                            // the previous chunk's fragments have been read
 #pragma unroll
     for (int j = 0; j < NLA; ++j) As[j * NT + tid] = ra[j];
@@ -363,7 +417,7 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int cb = min(rbW0 + wn * 2 + ni, p.Nrb - 1);
-    const float bv = p.bias ? p.bias[cb * 32 + fr] : 0.f;
+    const float bv = (p.bias && blockIdx.y == 0) ? p.bias[cb * 32 + fr] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -378,13 +432,13 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
       const int rbm = rbA0 + wm * MI + mi;
       if (rbm >= p.Mrb) continue;
       if (p.Cf && !((S3_EXP & 8) && acc[mi][ni][0] != 12345.f)) {     // an accumulator tile IS a tile of the tile-major layout: four 1-KB stores
-        float* t = p.Cf + ((long)rbm * p.Nrb + cb) * 1024 + lane * 4;
+        float* t = p.Cf + (long)blockIdx.y * p.slab + ((long)rbm * p.Nrb + cb) * 1024 + lane * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *reinterpret_cast<f32x4*>(t + q * 256) = (f32x4){acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
       }
       if (p.C) {
-        float* cp = p.C + (long)(rbm * 32 + 4 * (lane >> 5)) * p.ldc + cb * 32 + fr;
+        float* cp = p.C + (long)blockIdx.y * p.slab + (long)(rbm * 32 + 4 * (lane >> 5)) * p.ldc + cb * 32 + fr;
         const int rows_left = p.M - (rbm * 32 + 4 * (lane >> 5));         // rows 8 (i / 4) + i % 4 below this lane's first
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -398,15 +452,16 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
 // (mmego_split3_cvt).  Cf: tile-major fp32 [Mrb][Nrb][1024] and / or C: row-major (rows < M stored, row stride ldc).  K % 32 == 0.
 // wm: tile rows / 64 -- 1: 64 x 128 tiles (256-thread workgroups of four 32 x 64 wave tiles: products with few rows), 2: 128 x 128
 // tiles (256 threads), 4: 256 x 128 tiles (512 threads); 0: the library's choice.
-extern "C" int mmego_split3_gemm(void* stream, const unsigned short* A, const unsigned short* W, float* Cf, float* C, long ldc,
-                                 const float* bias, int Mrb, int Nrb, int K, int M, int nprod, int wm) {
+static int s3_gemm_launch(void* stream, const unsigned short* A, const unsigned short* W, float* Cf, float* C, long ldc, const float* bias,
+                          int Mrb, int Nrb, int K, int M, int nprod, int wm, int nsplit, long slab) {
   MMEGO_REQUIRE(A && W && (Cf || C) && Mrb > 0 && Nrb > 0 && K > 0 && K % 32 == 0 && (nprod == 6 || nprod == 9));
   MMEGO_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)W) & 15) == 0 && (!Cf || (((uintptr_t)Cf) & 15) == 0));
   MMEGO_REQUIRE(!C || (M > 0 && M <= Mrb * 32 && ldc >= Nrb * 32));
   MMEGO_REQUIRE((long)Mrb * (K / 16) * 192 < (1L << 31) && (long)Nrb * (K / 16) * 192 < (1L << 31));
+  MMEGO_REQUIRE(nsplit >= 1 && nsplit <= 64 && (nsplit == 1 || slab > 0));
   if (wm == 0) {
-    const long t128 = (long)cdiv(Mrb, 4) * cdiv(Nrb, 4);        // 128 x 128 tiles
-    wm = t128 < 256 ? 1 : (Mrb >= 64 ? 4 : 2);                   // fewer tiles than CUs: 64-row tiles
+    const long t128 = (long)cdiv(Mrb, 4) * cdiv(Nrb, 4) * nsplit;        // 128 x 128 tiles
+    wm = t128 < 256 ? 1 : (Mrb >= 64 && (long)cdiv(Mrb, 8) * cdiv(Nrb, 4) * nsplit >= 256 ? 4 : 2);     // fewer tiles than CUs: smaller tiles
   }
   MMEGO_REQUIRE(wm == 1 || wm == 2 || wm == 4);
   S3GemmP p;
@@ -414,19 +469,61 @@ extern "C" int mmego_split3_gemm(void* stream, const unsigned short* A, const un
   p.Cf = Cf; p.C = C; p.ldc = ldc; p.bias = bias; p.Mrb = Mrb; p.Nrb = Nrb; p.SK = K / 16; p.M = M;
   p.tiles_m = cdiv(Mrb, 2 * wm); p.tiles_n = cdiv(Nrb, 4);
   p.gm = 4;         // (r05: 4 / 8 / 16 / 32 row panels per sweep group measured 194 / 193 / 197 / 205 us at K = 512, 369 / 373 / 377 / 387 at 1024)
+  p.cps = cdiv(K / 32, nsplit); p.slab = slab;
+  MMEGO_REQUIRE((long)(nsplit - 1) * p.cps < K / 32);          // (no empty slab: its first loads would lie behind the operands)
   const long tiles = (long)p.tiles_m * p.tiles_n;
   MMEGO_REQUIRE(tiles < (1L << 30));
   hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)tiles, (unsigned)nsplit);
   if (wm == 1) {
-    if (nprod == 6) s3_gemm_kernel<2, 1, 6><<<(int)tiles, 256, 0, st>>>(p);
-    else s3_gemm_kernel<2, 1, 9><<<(int)tiles, 256, 0, st>>>(p);
+    if (nprod == 6) s3_gemm_kernel<2, 1, 6><<<grid, 256, 0, st>>>(p);
+    else s3_gemm_kernel<2, 1, 9><<<grid, 256, 0, st>>>(p);
   } else if (wm == 2) {
-    if (nprod == 6) s3_gemm_kernel<2, 2, 6><<<(int)tiles, 256, 0, st>>>(p);
-    else s3_gemm_kernel<2, 2, 9><<<(int)tiles, 256, 0, st>>>(p);
+    if (nprod == 6) s3_gemm_kernel<2, 2, 6><<<grid, 256, 0, st>>>(p);
+    else s3_gemm_kernel<2, 2, 9><<<grid, 256, 0, st>>>(p);
   } else {
-    if (nprod == 6) s3_gemm_kernel<4, 2, 6><<<(int)tiles, 512, 0, st>>>(p);
-    else s3_gemm_kernel<4, 2, 9><<<(int)tiles, 512, 0, st>>>(p);
+    if (nprod == 6) s3_gemm_kernel<4, 2, 6><<<grid, 512, 0, st>>>(p);
+    else s3_gemm_kernel<4, 2, 9><<<grid, 512, 0, st>>>(p);
   }
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+extern "C" int mmego_split3_gemm(void* stream, const unsigned short* A, const unsigned short* W, float* Cf, float* C, long ldc,
+                                 const float* bias, int Mrb, int Nrb, int K, int M, int nprod, int wm) {
+  return s3_gemm_launch(stream, A, W, Cf, C, ldc, bias, Mrb, Nrb, K, M, nprod, wm, 1, 0);
+}
+
+// The same product cut into nsplit slabs of K (long contractions with few output tiles: the weight gradients of stage-1 training,
+// K = the 10 240 rows): slab y leaves its partial product row-major at ws + y * (32 Mrb) * (32 Nrb) floats (the format of mmego_gemm's
+// accumulate = 2, summed by mmego_slab_reduce kind 0).
+extern "C" int mmego_split3_gemm_slabs(void* stream, const unsigned short* A, const unsigned short* W, float* ws, int Mrb, int Nrb, int K,
+                                       int nprod, int wm, int nsplit) {
+  return s3_gemm_launch(stream, A, W, nullptr, ws, (long)Nrb * 32, nullptr, Mrb, Nrb, K, Mrb * 32, nprod, wm, nsplit,
+                        (long)Mrb * 32 * Nrb * 32);
+}
+
+// out[i] = sum over the nsplit slabs of ws[y][i], i < n (n % 4 == 0): the K slabs of mmego_split3_gemm_slabs, added in slab order.  A plain
+// streaming sum (16-byte loads, every slab's request in flight before the first add): the weight gradients' slabs are 8-67 MB each,
+// for which mmego_slab_reduce's 16-outputs-per-workgroup form ran at 0.7 TB/s.
+__global__ __launch_bounds__(256) void s3_slab_sum_kernel(const f32x4* __restrict__ ws, int nsplit, long n4, f32x4* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 acc = ws[i];
+  int y = 1;
+  for (; y + 3 < nsplit; y += 4) {
+    const f32x4 a = ws[(long)y * n4 + i], b = ws[(long)(y + 1) * n4 + i], c = ws[(long)(y + 2) * n4 + i], d = ws[(long)(y + 3) * n4 + i];
+    acc += a; acc += b; acc += c; acc += d;
+  }
+  for (; y < nsplit; ++y) acc += ws[(long)y * n4 + i];
+  out[i] = acc;
+}
+
+extern "C" int mmego_split3_slab_sum(void* stream, const float* ws, int nsplit, long n, float* out) {
+  MMEGO_REQUIRE(ws && out && nsplit >= 1 && n > 0 && n % 4 == 0 && n / 4 / 256 + 1 < (1L << 31));
+  MMEGO_REQUIRE((((uintptr_t)ws | (uintptr_t)out) & 15) == 0);
+  s3_slab_sum_kernel<<<(unsigned)((n / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const f32x4*>(ws), nsplit, n / 4,
+                                                                                    reinterpret_cast<f32x4*>(out));
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -547,7 +547,8 @@ def test_imu_stage1_training(dev):
         assert (ph.grad.cpu() - go).abs().max().item() < 2e-4 * scale, k
 
 
-def test_imu_stage1_gradients_at_full_size(dev, monkeypatch):
+@pytest.mark.parametrize("train_precision", ["fp32", "split3"])
+def test_imu_stage1_gradients_at_full_size(dev, monkeypatch, train_precision):
     """Stage-1 backward at the REAL size: IMUNet(15, 9, 512, 2) with 128 and 512 rnn_fast rows -- the
     dispatch the 8.9 ms/step figure runs on (persistent 128x128 tile products in NN / TN orientation with split-K, the batched
     K-quartered dh launch with the cell backward on its tiles, lstm_step_dma_kernel with gate and cell stashes) -- against the oracle's autograd: every gradient
@@ -560,6 +561,9 @@ def test_imu_stage1_gradients_at_full_size(dev, monkeypatch):
     hb = nets.IMUNet(15, 9, 512, 2, True, 0)
     hb.load_state_dict(o.state_dict())
     hb = hb.to(dev).train()
+    # "split3" (r05, opt-in): rnn_fast's input-projection and input-gradient products as fp32-accurate piece products on the bf16
+    # matrix pipe (imu_train._s3_worth: the 10 240-row products of the B = 64 case; at B = 16 every product stays on the fp32 kernels)
+    hb.train_precision = train_precision
     for Bq, Tq in ((16, 8), (64, 8)):
         gen = torch.Generator().manual_seed(100 + Bq)
         imu = torch.randn(Bq, Tq, 20, 15, generator=gen)

@@ -135,6 +135,48 @@ def test_split3_gemm_against_float64(dev, M, N, K, wm):
     assert errs[9] < max(3.0 * e_native, 3e-7 * scale), (errs, e_native, scale)
 
 
+@pytest.mark.parametrize("R,Co,Ci,ns", [(10240, 4096, 512, 8), (10240, 2048, 512, 10), (512, 64, 96, 2), (1024, 100, 33, 3)])
+def test_split3_weight_gradient_product_in_k_slabs(dev, R, Co, Ci, ns):
+    """dW = dY^T X on piece products (stage-1 training with IMUNet.train_precision = "split3"): mmego_split3_cvt_t's pieces of a
+    transpose are bit-identical to mmego_split3_cvt of the explicit transpose; the K-slab product (mmego_split3_gemm_slabs) + the
+    streaming slab sum against float64 -- no worse than the native fp32 product (at K = 10 240 it is 5 x closer) --, ragged widths."""
+    from mmego_amd import blocks, hip
+    g = torch.Generator().manual_seed(R + Co + Ci)
+    dg, x = torch.randn(R, Co, generator=g).to(dev), torch.randn(R, Ci, generator=g).to(dev)
+    Cop, Cip = (Co + 31) // 32 * 32, (Ci + 31) // 32 * 32
+    a, b = blocks.split3_cvt_t(dg), blocks.split3_cvt_t(x)
+    assert torch.equal(a.view(torch.int16), blocks.split3_cvt(dg.t().contiguous()).view(torch.int16))
+    ws = torch.empty(ns * Cop * Cip, device=dev)
+    hip.call("split3_gemm_slabs", a, b, ws, Cop // 32, Cip // 32, R, 6, 0, ns)
+    out = torch.empty(Cop, Cip, device=dev)
+    hip.call("split3_slab_sum", ws, ns, Cop * Cip, out)
+    assert torch.equal(out, ws.view(ns, Cop, Cip).sum(0)) or float((out - ws.view(ns, Cop, Cip).sum(0)).abs().max()) < 1e-3     # (slab order vs torch's tree)
+    ref = dg.double().t() @ x.double()
+    e3 = float((out[:Co, :Ci].double() - ref).abs().max())
+    en = float(((dg.t() @ x).double() - ref).abs().max())
+    assert e3 <= max(1.5 * en, 3e-7 * float(ref.abs().max())), (e3, en)
+    assert float(out[Co:].abs().max()) == 0.0 if Cop > Co else True
+
+
+def test_split3_transposed_pieces_of_shifted_rows(dev):
+    """mmego_split3_cvt_t with (shift, T): column r of the transpose is row r + shift of the same T-row sequence, zero outside it -- the
+    h_{t-1} (shift -1) and h_{t+1} (shift +1) operands of the recurrent weight gradients read from a layer's outputs in place."""
+    from mmego_amd import blocks
+    g = torch.Generator().manual_seed(5)
+    Bn, T, H = 24, 20, 96
+    out = torch.randn(Bn * T, 2 * H, generator=g).to(dev)
+    for d, shift in ((0, -1), (1, 1)):
+        src = out[:, d * H:(d + 1) * H]
+        ref = torch.zeros(Bn, T, H, device=dev)
+        if shift < 0:
+            ref[:, 1:] = src.view(Bn, T, H)[:, :-1]
+        else:
+            ref[:, :-1] = src.view(Bn, T, H)[:, 1:]
+        got = blocks.split3_cvt_t(src, shift=shift, T=T)
+        want = blocks.split3_cvt(ref.view(Bn * T, H).t().contiguous())
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (d, shift)
+
+
 @pytest.mark.parametrize("M,H,K", [(512, 512, 1024), (200, 512, 512), (64, 256, 256)])
 def test_split3_projection_for_few_rows(dev, M, H, K):
     """mmego_split3_proj (the step kernel's product alone: IMU_Net's rnn_slow input projections, 512 rows x 4096 columns x K = 1024) against
