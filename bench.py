@@ -729,7 +729,7 @@ def emit(out):
           "t_upper_ms": r5(out["t_upper_ms"]), "t_lower_ms": r5(out["t_lower_ms"]),
           "ms_imu_shared": r5(out["ms_per_step_imu_shared"]), "roofline_step_frac": r5(out["roofline_step"]["frac"])}
     for k_out, k_in in (("ms_pipelined", "ms_per_step_pipelined"), ("ms_bf16_imu", "ms_per_step_bf16_imu"),
-                        ("ms_split3", "ms_per_step_split3")):
+                        ("ms_split3", "ms_per_step_split3"), ("ms_pipelined_split3", "ms_per_step_pipelined_split3")):
         if k_in in out:
             ex[k_out] = r5(out[k_in])
     if "roofline_by_kernel_time" in out:
@@ -1014,6 +1014,32 @@ def main():
         sync()
         dt_p = time.perf_counter() - t0p
         pipe_extra = {"ms_per_step_pipelined": dt_p / args.steps * 1e3, "frames_per_s_pipelined": world * B * T / (dt_p / args.steps)}
+        if not args.no_split3_variant:
+            # the same engine with both frozen forwards in the split3 mode (`main.py --train --imu_precision split3`)
+            try:
+                imu.precision = imu_l.precision = "split3"
+                pipe3 = PipelinedStages([su_p, sl_p], [imu, imu_l], inext, use_graph=not args.no_graph)
+                su_p.bind(xb, imu_in, body, tb)
+                sl_p.bind(xb, imu_in, body, tb)
+                pipe3.prime()
+                pipe3.prepare()
+
+                def pipe3_step(i):
+                    xs_, ts_, _ = sets[i % 2]
+                    xb.copy_(xs_); tb.copy_(ts_); inext.copy_(sets[(i + 1) % 2][2])
+                    pipe3.step()
+                for i in range(4):
+                    pipe3_step(i)
+                sync()
+                t0p = time.perf_counter()
+                for i in range(args.steps):
+                    pipe3_step(i)
+                sync()
+                dt_p3 = time.perf_counter() - t0p
+                pipe_extra["ms_per_step_pipelined_split3"] = dt_p3 / args.steps * 1e3
+                pipe_extra["frames_per_s_pipelined_split3"] = world * B * T / (dt_p3 / args.steps)
+            finally:
+                imu.precision = imu_l.precision = "fp32"
 
     out = None
     if rank == 0:

@@ -36,9 +36,13 @@ def build_parser():
     p.add_argument("--gt_head_pose", action="store_true", help="head pose from the recording instead of IMU_Net")
     p.add_argument("--data_root", type=str, help="Sample_data directory")
     p.add_argument("--seed", type=int, help="seed torch (net initialisation) and numpy (point-cloud padding) -- the reference does not seed")
-    p.add_argument("--imu_precision", type=str, choices=["fp32", "bf16"],
-                   help="eval-mode IMU_Net forwards (stages 2/3, --infer): fp32 (default, parity path) or bf16 product operands "
-                        "with fp32 accumulation (DESIGN.md 7a)")
+    p.add_argument("--imu_precision", type=str, choices=["fp32", "split3", "bf16"],
+                   help="eval-mode IMU_Net forwards (stages 2/3, --infer): fp32 (default), split3 (fp32-accurate piece products on the "
+                        "bf16 matrix pipe, inside the parity bars: DESIGN.md 7c) or bf16 product operands with fp32 accumulation "
+                        "(DESIGN.md 7a, outside them)")
+    p.add_argument("--imu_train_precision", type=str, choices=["fp32", "split3"],
+                   help="stage-1 IMU_Net training: fp32 (default) or split3 (rnn_fast's projection / input-gradient / weight-gradient "
+                        "products as piece products: DESIGN.md 7c)")
     p.add_argument("--resume", type=str, help="continue --train from a checkpoint written by this framework (the model .pth "
                                                "or its .train_state.pth: weights, Adam state, epoch, RNGs)")
     return p
@@ -68,6 +72,8 @@ def apply_overrides(args):
     Config.resume_path = args.resume
     if args.imu_precision is not None:
         os.environ["MMEGO_IMU_PRECISION"] = args.imu_precision      # read by IMUNet.__init__
+    if args.imu_train_precision is not None:
+        os.environ["MMEGO_IMU_TRAIN_PRECISION"] = args.imu_train_precision
 
 
 def main(argv=None):

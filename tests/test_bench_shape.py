@@ -181,6 +181,49 @@ def test_engines_agree_bit_for_bit_at_bench_shape(dev):
 
 
 @pytest.mark.gpu
+def test_engines_agree_bit_for_bit_with_split3_imu(dev):
+    """The same with both frozen IMU_Net forwards in the split3 mode (fp32-accurate piece products): stages one after the other and the
+    prefetch-pipelined engine -- what `main.py --train --imu_precision split3` runs -- against ConcurrentStages, three steps each, bit
+    for bit."""
+    import bench
+    from mmego_amd.train_step import ConcurrentStages, PipelinedStages, StageStep
+    x, imu_in, body, target = bench.synth_batch(1234, dev)
+
+    def run(kind):
+        himu, hup, hlo, hfr = bench.build_hip_models(dev)
+        himu_l = bench.clone_imu(himu, dev)
+        himu.precision = himu_l.precision = "split3"
+        own = kind != "pipelined"
+        su = StageStep("upper", hup, himu if own else None, lr=3e-5, use_graph=kind == "sequential")
+        sl = StageStep("lower", hlo, himu_l if own else None, upper_frozen=hfr, lr=3e-5, use_graph=kind == "sequential")
+        eng = None
+        if kind == "concurrent":
+            eng = ConcurrentStages([su, sl], use_graph=True)
+        elif kind == "pipelined":
+            eng = PipelinedStages([su, sl], [himu, himu_l], imu_in, use_graph=True)
+        su.bind(x, imu_in, body, target)
+        sl.bind(x, imu_in, body, target)
+        if kind == "pipelined":
+            eng.prime()
+        for _ in range(3):
+            if eng is None:
+                su.step(); sl.step()
+            else:
+                eng.step()
+        torch.cuda.synchronize()
+        return su, sl
+    ref = run("concurrent")
+    for kind in ("sequential", "pipelined"):
+        got = run(kind)
+        for a, b in zip(got, ref):
+            assert a.loss.item() == b.loss.item(), (kind, a.stage, a.loss.item(), b.loss.item())
+            assert torch.equal(a.net.flat().flat_g, b.net.flat().flat_g), (kind, a.stage)
+            assert torch.equal(a.net.flat().flat_p, b.net.flat().flat_p), (kind, a.stage)
+    from mmego_amd import blocks
+    assert blocks.seq_xcd_errors() == 0
+
+
+@pytest.mark.gpu
 def test_fused_head_loss_launch_is_bit_identical_to_the_three_launches():
     """mmego_head_fk_loss (kinematics + transform + L1(sum) loss + its gradient + kinematics backward in one launch, what StageStep
     uses) against head_fk_forward -> l1_loss -> head_fk_backward (nets._FUSED_HEAD_LOSS = False): predictions, both loss figures and every
