@@ -135,3 +135,35 @@ def test_training_with_imu_net_pipelined_equals_unpipelined(tmp_path):
     assert sd["pipelined"].keys() == sd["plain"].keys()
     for k in sd["plain"]:
         assert torch.equal(sd["pipelined"][k], sd["plain"][k]), k
+
+
+def test_training_with_the_frozen_imu_net_in_split3_mode(tmp_path):
+    """`main.py --train --network Upper_Net --imu_precision split3`: the frozen IMU_Net's forwards on fp32-accurate piece products
+    (DESIGN.md 7c), pipelined and unpipelined: identical checkpoints, and within fp32 rounding's reach of the default run's after two
+    epochs (the head poses differ in the last bits, the trained weights follow)."""
+    import glob
+    import torch
+    from mmego_amd import nets
+    data = str(tmp_path / "Sample_data")
+    _make_dataset(data, np.random.default_rng(2))
+    torch.manual_seed(1)
+    imu_ck = str(tmp_path / "imu.pth")
+    torch.save(nets.IMUNet(15, 9, 512, 2, True, 0.1).state_dict(), imu_ck)
+    out_dir = str(tmp_path / "train_out")
+    model_dir = os.path.join(out_dir, "model")
+    sd = {}
+    for tag, idx, args, extra in (("split3", "9131", ["--imu_precision", "split3"], {}),
+                                  ("split3_plain", "9132", ["--imu_precision", "split3"], {"MMEGO_PIPELINE_IMU": "0"}),
+                                  ("fp32", "9133", [], {})):
+        env = dict(os.environ, PYTHONPATH=ROOT, MMEGO_TRAIN_DIR=out_dir, **extra)
+        env.pop("MMEGO_IMU_PRECISION", None)
+        out = _run(["--train", "--network", "Upper_Net", "--load_IMU_path", imu_ck, "--data_root", data, "--epochs", "2",
+                    "--batch_size", "3", "--device", "cuda:0", "--seed", "3", "--log_dir", idx] + args, env)
+        assert "epoch: 2" in out
+        files = [f for f in sorted(glob.glob(os.path.join(model_dir, idx, "epoch*_batch3frame*.pth"))) if not f.endswith(".train_state.pth")]
+        assert files, os.listdir(os.path.join(model_dir, idx))
+        sd[tag] = torch.load(files[-1], map_location="cpu")
+    for k in sd["fp32"]:
+        assert torch.equal(sd["split3"][k], sd["split3_plain"][k]), k
+        if sd["fp32"][k].is_floating_point():
+            assert torch.allclose(sd["split3"][k], sd["fp32"][k], rtol=1e-3, atol=2e-4), (k, float((sd["split3"][k] - sd["fp32"][k]).abs().max()))
