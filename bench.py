@@ -622,6 +622,45 @@ def config5_forward(device):
     return res
 
 
+def mode_joint_errors(device):
+    """A joint-error statement for the precision MODES (config 5's numbers carried none beyond "< 2e-2"): the eval forward
+    IMU_Net -> Upper_Net -> Lower_Net at B=64, T=8, N=128 on the HIP path in each mode against the CPU oracle's fp32 forward on the same
+    seeded weights and batch: largest joint distance in cm, upper and lower body.  "bf16" = all three nets in the bf16 mode (what
+    config 5 times), "split3" = IMU_Net's products as fp32-accurate piece products, "fp32" = the native path (the parity path)."""
+    from oracle import nets as on
+    from oracle import train as ot
+    torch.manual_seed(1234)
+    o_imu = on.IMUNet(15, 9, 512, 2, True, 0.1).eval()
+    o_up, o_lo = on.UpperNet().eval(), on.LowerNet(64).eval()
+    himu, hup, hlo, _ = build_hip_models(device)
+    hup.eval(); hlo.eval()
+    x, imu_in, body, _ = synth_batch(1234, "cpu")
+    h0, c0 = ot.zeros_state(B)
+    with torch.no_grad():
+        R, t = o_imu(imu_in)
+        xo = x.clone()
+        up_o = o_up(xo, h0, c0, body, R, t)[0]
+        lo_o = o_lo(up_o.clone(), xo, h0, c0, h0, c0, body, R, t)[0]
+    res = {"what": "eval forward IMU_Net -> Upper_Net -> Lower_Net, B=64 T=8 N=128, HIP path in each precision mode vs the CPU oracle (fp32), "
+                   "same seeded weights: max joint distance in cm (upper body, lower body)"}
+    d = lambda v: v.to(device)
+    hz = torch.zeros(6, B, 64, device=device)
+    for mode in ("fp32", "split3", "bf16"):
+        himu.precision = "fp32" if mode == "fp32" else mode
+        hup.precision = hlo.precision = "bf16" if mode == "bf16" else "fp32"
+        with torch.no_grad():
+            xh = d(x.clone())
+            Rh, th = himu(d(imu_in))
+            up_h = hup(xh, hz, hz, d(body), Rh, th)[0]
+            lo_h = hlo(up_h.clone(), xh, None, None, None, None, d(body), Rh, th)[0]
+        torch.cuda.synchronize()
+        res[mode] = {"upper_cm": (up_h.cpu().view_as(up_o) - up_o).norm(dim=-1).max().item() * 100.0,
+                     "lower_cm": (lo_h.cpu().view_as(lo_o) - lo_o).norm(dim=-1).max().item() * 100.0}
+    del himu, hup, hlo
+    torch.cuda.empty_cache()
+    return res
+
+
 def split3_figures(device, imu, imu_in, out, with_parity=True):
     """The split3 mode's own block of the detail line: the IMU_Net forward in both modes (replayed graphs, one launch per timestep),
     the two kernel families' rooflines from event pairs around an eager forward -- `achieved` = bf16 MFMA flops actually issued
@@ -1206,6 +1245,8 @@ def main():
         if world == 1 and not args.no_config_extras:
             out["config2"] = config2_forward(device)
             out["config5"] = config5_forward(device)
+            if not args.no_cpu_baseline:           # (uses the oracle as the checker, like `parity`)
+                out["config5"]["joint_error_vs_oracle"] = mode_joint_errors(device)
             out["stage1"] = stage1_step(device)
         if world == 1 and not args.no_wlocal:
             out["wlocal"] = wlocal_figures(device, with_cpu=not args.no_cpu_baseline)

@@ -265,3 +265,17 @@ def test_fused_head_loss_launch_is_bit_identical_to_the_three_launches():
             assert torch.equal(p1, p0) and torch.equal(g1, g0), (kind, Bq)
             # (the two loss figures: fp64 sums in a different, fixed order -- equal after rounding to fp32 up to one ulp)
             assert torch.allclose(l1, l0, rtol=2e-7, atol=0.0), (kind, Bq, l1, l0)
+
+
+@pytest.mark.gpu
+def test_precision_modes_joint_error_against_the_oracle(dev):
+    """bench.mode_joint_errors (`config5.joint_error_vs_oracle` in the bench detail): the eval forward IMU_Net -> Upper_Net ->
+    Lower_Net at the bench shape in each precision mode against the CPU oracle's fp32 forward.  The native path and the split3 mode
+    are inside the parity bar (1e-3 cm); the bf16 mode (what config 5 times, opt-in, outside the bar) is held to 0.3 cm -- measured
+    0.03 cm upper / 0.10 cm lower body on these random-init nets."""
+    import bench
+    r = bench.mode_joint_errors(dev)
+    for mode in ("fp32", "split3"):
+        assert r[mode]["upper_cm"] < 1e-3 and r[mode]["lower_cm"] < 1e-3, (mode, r[mode])
+    assert r["bf16"]["upper_cm"] < 0.3 and r["bf16"]["lower_cm"] < 0.3, r["bf16"]
+    assert r["bf16"]["lower_cm"] > r["split3"]["lower_cm"]          # (the modes are really different arithmetic)
