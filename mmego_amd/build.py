@@ -13,7 +13,15 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmmego_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"] + os.environ.get("MMEGO_EXTRA_HIPCC_FLAGS", "").split()
+# No packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) in any kernel: the target feature is switched
+# off for the device compilation.  r06 finding: a wave that executes them while a bf16-MFMA workgroup of ANOTHER
+# kernel is resident on its CU gets wrong VCC-dependent selects in lanes 48-63 (silently wrong gradients in 22-59 of 60 step engines
+# with the instructions, 0 of 120 without); tests/test_host_cpu.py holds the built library to zero such instructions.  No measurable
+# cost (U+L step 4.98-4.99 ms with, 5.00 ms without; config 5, wlocal and stage-1 figures unchanged).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32 + os.environ.get("MMEGO_EXTRA_HIPCC_FLAGS", "").split()
+# (the host pass of the same command line does not know the amdgcn feature and says so once per file)
+_HOST_NOISE = ("'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)", "1 warning generated when compiling for host.")
 
 
 def sources():
@@ -28,12 +36,15 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True):
-    if not force and not stale():
+def build_library(force=False, verbose=True, variant=None, extra_flags=()):
+    """variant (measurement builds only, scripts/): a second library lib/variants/libmmego_hip_<variant>.so with `extra_flags` appended,
+    objects in build_<variant>/; the product library is variant None."""
+    lib = LIB if variant is None else os.path.join(LIBDIR, "variants", "libmmego_hip_%s.so" % variant)
+    if variant is None and not force and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(HERE, "build")
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    objdir = os.path.join(HERE, "build" if variant is None else "build_" + variant)
     os.makedirs(objdir, exist_ok=True)
 
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -43,22 +54,23 @@ def build_library(force=False, verbose=True):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_h):
             return obj                  # (object newer than its source, every header and this recipe: keep it)
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
-        if verbose and r.stderr.strip():
-            sys.stderr.write(r.stderr)
+        err = "\n".join(l for l in r.stderr.splitlines() if l.strip() and not any(n in l for n in _HOST_NOISE))
+        if verbose and err.strip():
+            sys.stderr.write(err + "\n")
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, sources()))
-    r = subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+    r = subprocess.run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
     if verbose:
-        print("built", LIB)
-    return LIB
+        print("built", lib)
+    return lib
 
 
 if __name__ == "__main__":

@@ -127,6 +127,18 @@ __device__ __forceinline__ Rot6 rot6d_fwd(const float* six, float eps) {
 }
 
 // gR: gradient wrt the 3x3 matrix whose COLUMNS are x,y,z (row-major 9 floats) -> gradient wrt the 6 inputs
+// MMEGO_HFK_VARIANT (probe builds of scripts/coexec_variants.py only; 0 = the product code): bit 0 = the two eps tests as selects of
+// the projection factor instead of branches; bit 1 = this function's divisions as multiplications by v_rcp_f32.
+#ifndef MMEGO_HFK_VARIANT
+#define MMEGO_HFK_VARIANT 0
+#endif
+__device__ __forceinline__ float hfk_div(float a, float b) {
+#if MMEGO_HFK_VARIANT & 2
+  return a * __builtin_amdgcn_rcpf(b);
+#else
+  return a / b;
+#endif
+}
 __device__ __forceinline__ void rot6d_bwd(const float* six, float eps, const float* gR, float* gsix) {
   Rot6 r = rot6d_fwd(six, eps);
   const float* b = six + 3;
@@ -145,24 +157,40 @@ __device__ __forceinline__ void rot6d_bwd(const float* six, float eps, const flo
     w2 = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   }
   float gw[3];
+#if MMEGO_HFK_VARIANT & 1
+  {
+    float dz = r.z[0] * gz[0] + r.z[1] * gz[1] + r.z[2] * gz[2];
+    dz = w2 > eps ? dz : 0.f;
+    for (int i = 0; i < 3; ++i) gw[i] = hfk_div(gz[i] - r.z[i] * dz, r.nw);
+  }
+#else
   if (w2 > eps) {
     float dz = r.z[0] * gz[0] + r.z[1] * gz[1] + r.z[2] * gz[2];
-    for (int i = 0; i < 3; ++i) gw[i] = (gz[i] - r.z[i] * dz) / r.nw;
+    for (int i = 0; i < 3; ++i) gw[i] = hfk_div(gz[i] - r.z[i] * dz, r.nw);
   } else {
-    for (int i = 0; i < 3; ++i) gw[i] = gz[i] / r.nw;
+    for (int i = 0; i < 3; ++i) gw[i] = hfk_div(gz[i], r.nw);
   }
+#endif
   // w = x cross b
   cross3(b, gw, tmp);
   for (int i = 0; i < 3; ++i) gx[i] += tmp[i];
   cross3(gw, r.x, gsix + 3);
   // x = a / max(|a|, eps)
   float a2 = sqrtf(six[0] * six[0] + six[1] * six[1] + six[2] * six[2]);
+#if MMEGO_HFK_VARIANT & 1
+  {
+    float dx = r.x[0] * gx[0] + r.x[1] * gx[1] + r.x[2] * gx[2];
+    dx = a2 > eps ? dx : 0.f;
+    for (int i = 0; i < 3; ++i) gsix[i] = hfk_div(gx[i] - r.x[i] * dx, r.na);
+  }
+#else
   if (a2 > eps) {
     float dx = r.x[0] * gx[0] + r.x[1] * gx[1] + r.x[2] * gx[2];
-    for (int i = 0; i < 3; ++i) gsix[i] = (gx[i] - r.x[i] * dx) / r.na;
+    for (int i = 0; i < 3; ++i) gsix[i] = hfk_div(gx[i] - r.x[i] * dx, r.na);
   } else {
-    for (int i = 0; i < 3; ++i) gsix[i] = gx[i] / r.na;
+    for (int i = 0; i < 3; ++i) gsix[i] = hfk_div(gx[i], r.na);
   }
+#endif
 }
 
 // Forward-kinematics plans, compile-time: bone k writes slot child[k] = slot parent[k] + Rot[rot[k]] . body[row[k]].
@@ -688,26 +716,10 @@ extern "C" int mmego_head_fk_loss(void* stream, int which, const float* y, const
   MMEGO_REQUIRE(B > 0 && F > 0 && F <= 65536 && ntgt > 0 && ncount >= 0 && ncount <= 4096 && (ncount == 0 || counters));
   const int nb = cdiv(F, 64);
   unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 2 * nb);
-  // The launch asks for 144 KB of LDS it never touches, so that no LDS-using workgroup -- every MFMA kernel of this library -- shares a
-  // CU with one of its (at most 8) workgroups.  r05 finding (scripts/coexec_head_fk.py): with a bf16-MFMA recurrence kernel
-  // (mmego_split3_step16, two 64-KB workgroups per CU) resident on the same CU, dy came back different in 12 of 200 rounds of 20
-  // launches -- always one 16-lane group of the wave, values close to the right ones -- and in 0 of 200 with this request; never beside
-  // fp32-MFMA kernels.  Not explained (its LDS, stores, cross-lane traffic and register allocation were ruled out one by one); the
-  // request costs nothing measurable.
-#ifdef MMEGO_HEAD_FK_NO_LDS_PAD                          // (a build for the reproducer: MMEGO_EXTRA_HIPCC_FLAGS=-DMMEGO_HEAD_FK_NO_LDS_PAD)
-  constexpr int lds_pad = 0;
-#else
-  constexpr int lds_pad = 144 * 1024;
-#endif
-  static bool attr_set = false;
-  if (lds_pad && !attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)head_fk_loss_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_fk_loss_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  if (which == 0) hipLaunchKernelGGL(head_fk_loss_kernel<0>, dim3(nb), dim3(64), lds_pad, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy, scratch, ticket);
-  else hipLaunchKernelGGL(head_fk_loss_kernel<1>, dim3(nb), dim3(64), lds_pad, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy, scratch, ticket);
+  // (r05 asked for 144 KB of untouched LDS here to keep MFMA workgroups off this kernel's CUs; r06 found the cause class -- packed-fp32
+  //  instructions beside a bf16-MFMA workgroup, DESIGN.md section 7d -- and the library is built without them: the request is gone.)
+  if (which == 0) hipLaunchKernelGGL(head_fk_loss_kernel<0>, dim3(nb), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy, scratch, ticket);
+  else hipLaunchKernelGGL(head_fk_loss_kernel<1>, dim3(nb), dim3(64), 0, (hipStream_t)stream, y, body, B, F, q, joints_h, Rw, tw, world, counters, ncount, seed_ctr, target, map, ntgt, (float)scale, loss, dy, scratch, ticket);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

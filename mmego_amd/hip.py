@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "mmego_hip.h")
-LIBPATH = os.path.join(_HERE, "lib", "libmmego_hip.so")
+LIBPATH = os.environ.get("MMEGO_HIP_LIB") or os.path.join(_HERE, "lib", "libmmego_hip.so")    # (MMEGO_HIP_LIB: A/B builds of scripts/)
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
 

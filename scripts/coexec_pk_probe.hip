@@ -1,0 +1,353 @@
+// r06, the co-residency finding: which dependency pattern around the packed-fp32 instructions miscomputes beside
+// a bf16-MFMA workgroup on the same CU?  scripts/coexec_variants.py named the class (head_fk_loss<1> built with -fno-slp-vectorize: 0 of
+// 600 rounds differ; with its v_pk_* instructions: 22-279 of 600, always lanes 48-63).  These kernels isolate the patterns that occur
+// in that kernel's differing region, each as explicit-register inline assembly (so the compiler neither reorders nor pads them):
+//   mode 0  v_mov_b32 (writes the HIGH register of a pair)   -> v_pk_mul_f32 reading the pair, back to back
+//   mode 1  v_mov_b32 (writes the LOW register of a pair)    -> v_pk_mul_f32 reading the pair, back to back
+//   mode 2  the same as 0 with s_nop 1 between the two (two wait states)
+//   mode 3  v_pk_mul_f32 -> v_add_f32 reading its HIGH result register, back to back
+//   mode 4  v_pk_mul_f32 / v_pk_add_f32 with every operand at least 8 instructions old (no short dependency)
+//   mode 5  control: v_mov_b32 -> v_mul_f32 back to back (no packed instruction)
+//   mode 6  v_cmp (vcc) -> s_nop 1 -> v_cndmask_b32 (HIGH register) -> v_pk_mul_f32, back to back (the sign-select pattern)
+//   mode 7  v_pk_mov_b32 op_sel:[1,0] fed by a fresh v_mov_b32 -> v_pk_add_f32
+//   modes 8-15: the VALU-writes-VCC -> VALU-reads-VCC distance (LLVM's gfx940 rule: 2 wait states, one per VALU instruction or
+//   s_nop cycle in between) with DIFFERENT fillers between v_cmp and v_cndmask; VCC holds the opposite outcome beforehand:
+//     8  v_pk_add_f32, v_mov_b32        9  v_mov_b32, v_mov_b32 (control)     10  v_pk_add_f32, v_pk_mul_f32     11  v_pk_mul_f32 op_sel:[0,1], v_mov_b32
+//    12  v_pk_add_f32 alone (one state: NOT a sequence the compiler emits)     13  v_mov_b32 alone (one state, control for 12)
+//    14  s_nop 1 (control)             15  v_mov_b32, v_pk_mul_f32
+//    16  v_pk_mul_f32, s_nop 3, v_mov_b32    17  v_mul_f32, s_nop 3, v_mov_b32 (control)    18  s_nop 3, v_pk_mul_f32, v_mov_b32
+//    19  the v_pk_mul_f32 in FRONT of the v_cmp, then s_nop 3, v_mov_b32           20  pk, s_nop 3, cmp, s_nop 3, pk, s_nop 3, mov
+//   (dense: plain v_add_f32 fillers instead of s_nop around the tested sequence, so that another wave's MFMAs interleave with it)
+// Every lane carries its own data; the result of a launch on an idle GPU is the reference.
+#include <hip/hip_runtime.h>
+
+#define REP4(X) X X X X
+#define REP16(X) REP4(REP4(X))
+
+template <int MODE>
+__global__ __launch_bounds__(64) void pk_probe_kernel(float* out, int iters, int pad_regs) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  float a = 1.0f + 1e-3f * (float)((t * 131) % 977), b = 0.5f + 1e-3f * (float)((t * 71) % 991);
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  // fixed registers: v[100:101] operand pair, v[102:103] result pair, v[104:105] constant pair, v106 / v107 moving scalars
+  for (int it = 0; it < iters; ++it) {
+    a = a * 0.999f + 0.001f;                                                           // (changes every round; stays in [0.5, 2])
+    b = b * 0.998f + 0.0015f;
+    if (MODE == 0) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_mov_b32 v101, v106\n\t"
+              "v_pk_mul_f32 v[102:103], v[100:101], v[104:105]\n\t"
+              "s_nop 4\n\t"
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t"
+              "s_nop 4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+    }
+    if (MODE == 2) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_mov_b32 v101, v106\n\t"
+              "s_nop 1\n\t"
+              "v_pk_mul_f32 v[102:103], v[100:101], v[104:105]\n\t"
+              "s_nop 4\n\t"
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t"
+              "s_nop 4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+    }
+    if (MODE == 1) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v101, %4\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_mov_b32 v100, v106\n\t"
+              "v_pk_mul_f32 v[102:103], v[100:101], v[104:105]\n\t"
+              "s_nop 4\n\t"
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t"
+              "s_nop 4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+    }
+    if (MODE == 3) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v101, %5\n\ts_nop 4\n\t" REP16(
+              "v_pk_mul_f32 v[102:103], v[100:101], v[104:105]\n\t"
+              "v_add_f32 %1, %1, v103\n\t"
+              "v_add_f32 %0, %0, v102\n\t"
+              "v_fma_f32 v101, v101, 0.5, %4\n\t"
+              "s_nop 4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+    }
+    if (MODE == 4) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v101, %5\n\ts_nop 7\n\t" REP16(
+              "v_pk_mul_f32 v[102:103], v[100:101], v[104:105]\n\t"
+              "s_nop 7\n\t"
+              "v_pk_add_f32 v[106:107], v[102:103], v[104:105]\n\t"
+              "s_nop 7\n\t"
+              "v_add_f32 %0, %0, v106\n\tv_add_f32 %1, %1, v107\n\t"
+              "v_fma_f32 v101, v101, 0.5, %4\n\t"
+              "s_nop 7\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+    }
+    if (MODE == 5) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_mov_b32 v101, v106\n\t"
+              "v_mul_f32 v103, v101, v105\n\t"
+              "v_mul_f32 v102, v100, v104\n\t"
+              "s_nop 4\n\t"
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t"
+              "s_nop 4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+    }
+    if (MODE == 6) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\ts_nop 4\n\t" REP16(
+              "v_cmp_lt_f32 vcc, 1.0, v106\n\t"
+              "s_nop 1\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_pk_mul_f32 v[102:103], v[100:101], v[104:105]\n\t"
+              "s_nop 4\n\t"
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t"
+              "s_nop 4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "vcc");
+    }
+    if (MODE == 7) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_mov_b32 v107, %4\n\ts_nop 4\n\t" REP16(
+              "v_mov_b32 v101, v106\n\t"
+              "v_pk_mov_b32 v[102:103], v[100:101], v[106:107] op_sel:[1,0]\n\t"
+              "v_pk_add_f32 v[102:103], v[102:103], v[104:105]\n\t"
+              "s_nop 4\n\t"
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t"
+              "s_nop 4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107");
+    }
+    if (MODE == 8) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t"
+              "v_pk_add_f32 v[108:109], v[104:105], v[104:105]\n\t" "v_mov_b32 v110, v105\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 9) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t"
+              "v_mov_b32 v108, v104\n\t" "v_mov_b32 v110, v105\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 10) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t"
+              "v_pk_add_f32 v[108:109], v[104:105], v[104:105]\n\t" "v_pk_mul_f32 v[110:111], v[104:105], v[104:105]\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 11) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t"
+              "v_pk_mul_f32 v[110:111], v[104:105], v[112:113] op_sel:[0,1]\n\t" "v_mov_b32 v108, v104\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 12) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t"
+              "v_pk_add_f32 v[108:109], v[104:105], v[104:105]\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 13) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t"
+              "v_mov_b32 v108, v104\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 14) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t"
+              "s_nop 1\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 15) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t"
+              "v_mov_b32 v108, v104\n\t" "v_pk_mul_f32 v[110:111], v[104:105], v[104:105]\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 16) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t" "v_pk_mul_f32 v[110:111], v[104:105], v[112:113] op_sel:[0,1]\n\t" "s_nop 3\n\t" "v_mov_b32 v108, v104\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 17) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t" "v_mul_f32 v110, v104, v112\n\t" "s_nop 3\n\t" "v_mov_b32 v108, v104\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 18) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_cmp_lt_f32 vcc, 2.0, v106\n\t" "s_nop 3\n\t" "v_pk_mul_f32 v[110:111], v[104:105], v[112:113] op_sel:[0,1]\n\t" "v_mov_b32 v108, v104\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 19) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_pk_mul_f32 v[110:111], v[104:105], v[112:113] op_sel:[0,1]\n\t" "v_cmp_lt_f32 vcc, 2.0, v106\n\t" "s_nop 3\n\t" "v_mov_b32 v108, v104\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 20) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v106, %5\n\tv_sub_f32 v107, 0, %4\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v110, 0\n\ts_nop 4\n\t" REP16(
+              "v_cmp_ge_f32 vcc, 2.0, v106\n\t"
+              "v_add_f32 v112, v104, v105\n\t" "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" "v_add_f32 v112, v104, v105\n\t" 
+              "v_pk_mul_f32 v[110:111], v[104:105], v[112:113] op_sel:[0,1]\n\t" "s_nop 3\n\t" "v_cmp_lt_f32 vcc, 2.0, v106\n\t" "s_nop 3\n\t" "v_pk_mul_f32 v[110:111], v[104:105], v[112:113] op_sel:[0,1]\n\t" "s_nop 3\n\t" "v_mov_b32 v108, v104\n\t"
+              "v_cndmask_b32 v101, v107, v106, vcc\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %1, %1, v101\n\tv_add_f32 %0, %0, v108\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    acc0 *= 0.25f;                                                                     // (keeps the sums finite over many rounds)
+    acc1 *= 0.25f;
+  }
+  out[(long)t * 4 + 0] = acc0;
+  out[(long)t * 4 + 1] = acc1;
+  out[(long)t * 4 + 2] = acc2 + a;
+  out[(long)t * 4 + 3] = acc3 + b;
+}
+
+// every kernel reserves v100-v115, i.e. >= 116 VGPRs: four waves per SIMD at most
+extern "C" int pk_probe_launch(void* stream, int mode, float* out, int nblk, int iters) {
+  hipStream_t st = (hipStream_t)stream;
+#define L(M) case M: pk_probe_kernel<M><<<nblk, 64, 0, st>>>(out, iters, 0); break
+  switch (mode) {
+    L(0); L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); L(9); L(10); L(11); L(12); L(13); L(14); L(15); L(16); L(17); L(18); L(19); L(20);
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}

@@ -20,6 +20,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(autouse=True)
+def _stall_probe(request):
+    """MMEGO_STALL_PROBE=<seconds>[:<logfile>]: native backtraces of every thread when a test runs longer (tests/stall_probe.py)."""
+    from stall_probe import arm
+    w = arm(request.node.nodeid)
+    yield
+    if w is not None:
+        w.stop()
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
