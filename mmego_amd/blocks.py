@@ -879,13 +879,29 @@ def lstm_steps_forward_bf16(ar, key, lstm, x, Bn, T):
 # ---------------------------------------------------------------------------------------------------
 SPLIT3_NPROD = int(os.environ.get("MMEGO_SPLIT3_NPROD", "6"))       # 6: dropped terms <= 2^-24 relative; 9: all piece products
 SPLIT3_WM = 0             # projection tile rows / 64 (0: the library's choice)
-# 1: a layer's recurrence as two chains of single-direction launches on 16-unit workgroups (mmego_split3_step16).  OFF by default:
-# that kernel is correct and 4 % faster per forward when the forward runs alone, but a workgroup of it that shares a CU with
-# head_fk_loss_kernel<1> (geom.hip; the Lower stage's turning point, which runs beside the Upper stage's IMU_Net forward in
-# train_step.ConcurrentStages) changes that kernel's dy in a 16-lane group of a wave in ~5 % of the runs -- reproduced on every box
-# with two plain streams and no graph (scripts/coexec_head_fk.py; NOTES.md, r05).  The 32-unit kernel (444 registers, 128 KB of
-# LDS: alone on its CU) and the projection kernel have run beside it 200+ times without a difference.
-SPLIT3_TWO_CHAINS = os.environ.get("MMEGO_SPLIT3_TWO_CHAINS", "0") == "1"
+# True: a layer's recurrence as two chains of single-direction launches on 16-unit workgroups (mmego_split3_step16).  Off: 4 % faster
+# per forward when the forward runs alone, no faster inside a step.  It is the form in which the co-residency corruption of r05 showed
+# most often (a kernel WITH packed-fp32 instructions on a CU that also holds one of its workgroups: DESIGN.md section 7d).
+SPLIT3_TWO_CHAINS = False        # (a measurement / test hook, see split3_two_chains(); no environment variable since r06)
+
+
+class split3_two_chains:
+    """`with blocks.split3_two_chains(True)`: rnn_fast's split3 recurrences as two chains of the 16-unit step kernel (two bf16-MFMA
+    workgroups per CU) where forking is allowed.  The form in which the co-residency corruption of r05 showed most often; kept for
+    its reproducers and regression tests, not a user setting."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global SPLIT3_TWO_CHAINS
+        self.was, SPLIT3_TWO_CHAINS = SPLIT3_TWO_CHAINS, self.on
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global SPLIT3_TWO_CHAINS
+        SPLIT3_TWO_CHAINS = self.was
+        return False
 
 
 def split3_buffer(ar, name, Rp, K):

@@ -737,10 +737,11 @@ __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
 // needs half of everything (64 accumulators, a three-deep ring of 12 fragments, 64 KB of LDS: two workgroups per CU), and the two
 // directions' launches -- independent dependency chains -- put one workgroup of each on a CU: one direction's launch gap, prologue
 // and cell update run beside the other's product loop.  (Both directions in one 512-workgroup launch would run the pairs in lockstep.)
-// NOT THE DEFAULT (blocks.SPLIT3_TWO_CHAINS): correct by itself and against the fp32 kernels, but while a workgroup of it shares a CU with
-// head_fk_loss_kernel<1> of geom.hip that kernel's dy comes out different in one 16-lane group in ~5 % of the runs (scripts/
-// coexec_head_fk.py: two plain streams; not with the MFMAs compiled out, not with the 32-unit kernel, the projection kernel or the
-// fp32 step kernels beside it; LDS contents, SGPR / VGPR allocation padding, stray stores and ds_bpermute were ruled out one by one).
+// NOT THE DEFAULT (blocks.split3_two_chains, a test hook): no faster inside a step.  r05 saw head_fk_loss_kernel<1> of geom.hip come out
+// different in a 16-lane group of a wave in ~5 % of the runs while a workgroup of THIS kernel shared its CU; r06 found what the victim
+// needs for that -- packed-fp32 instructions (v_pk_*_f32): VCC-dependent selects read 0 in lanes 48-63 -- and that the 32-unit kernel
+// does it as well (22 of 60 step engines); the library is compiled without those instructions and a step with bf16-MFMA kernels runs as
+// one chain (scripts/coexec_variants.py, coexec_asm_patch.py, coexec_fullstep.py).
 // W_hh rows [16-unit block][gate][16 units]: a 32-column block holds a gate PAIR -- block 0: i | f, block 1: g | o -- of 16 units, so
 // the four gates of a (row, unit) sit in lanes l and l ^ 16 of the two accumulator tiles; one exchange (the pre-activations of the
 // rows the partner finishes) and every lane updates 4 cells.  The projection's columns are permuted the same way (weight

@@ -68,6 +68,13 @@ def ptr(t):
     return t.data_ptr() if isinstance(t, torch.Tensor) else int(t)
 
 
+def is_bf16_mfma_entry(name):
+    """True for the entry points (name without the mmego_ prefix) whose kernels run bf16 MFMAs or belong to their chains: everything
+    exported by csrc/split3.hip, bf16.hip and *_bf16.hip (tests/test_host_cpu.py checks that no other file contains a bf16 MFMA and
+    that every entry point of those files matches).  What the exclusivity check of plan.unordered_with() calls an aggressor."""
+    return name.startswith("split3_") or "bf16" in name
+
+
 def stream_handle():
     return torch.cuda.current_stream().cuda_stream
 

@@ -85,9 +85,29 @@ class capture:
         return self._ctx.__exit__(et, ev, tb)
 
 
+_no_fork = [0]
+
+
+class no_fork:
+    """`with ops.no_fork()`: every fork site of the package (blocks.lstm_recurrence's two chains, the engines' stage branches) takes
+    its single-chain form -- whatever is launched inside runs as ONE dependency chain on the current stream.  The engines of
+    train_step.py open it whenever a net of theirs runs bf16-MFMA kernels (precision "split3" / "bf16"): no other kernel is
+    then ever resident on a CU beside a bf16-MFMA workgroup."""
+
+    def __enter__(self):
+        _no_fork[0] += 1
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _no_fork[0] -= 1
+        return False
+
+
 def capture_can_fork():
     """True when a side stream may be forked from the current stream: always when running eagerly; under graph capture only on
-    the origin stream of an ops.capture context."""
+    the origin stream of an ops.capture context; never inside ops.no_fork()."""
+    if _no_fork[0]:
+        return False
     if not torch.cuda.is_current_stream_capturing():
         return True
     return _capture_origin["stream"] is not None and torch.cuda.current_stream().cuda_stream == _capture_origin["stream"]

@@ -181,6 +181,44 @@ class StepPlan:
         for ev in self.final_waits:
             main.wait_event(ev)
 
+    # -- structure ---------------------------------------------------------------------------------------
+    def unordered_with(self, pred):
+        """The launches that MAY RUN AT THE SAME TIME as a launch whose entry-point name satisfies ``pred``: pairs
+        (name of the pred launch, name of the other launch) for every two launches of different segments with no
+        happens-before path between their segments (stream order + the recorded event waits) either way.  Empty = every launch
+        of the recorded body is ordered against every `pred` launch: no kernel can be resident beside one of them.  Structural:
+        read off the recorded dependency graph, nothing is launched (tests/test_split3_gpu.py holds the engines to it with
+        pred = hip.is_bf16_mfma_entry)."""
+        segs = self.segments
+        by_signal = {id(sg.signal): i for i, sg in enumerate(segs) if sg.signal is not None}
+        n = len(segs)
+        before = [set() for _ in range(n)]                    # before[i]: segments that finish before segment i starts
+        last_on = {}
+        for i, sg in enumerate(segs):
+            preds = set()
+            if sg.stream in last_on:
+                preds.add(last_on[sg.stream])
+            for ev in sg.deps:
+                j = by_signal.get(id(ev))
+                if j is not None:
+                    preds.add(j)
+            for j in preds:
+                before[i].add(j)
+                before[i] |= before[j]
+            last_on[sg.stream] = i
+        pairs = set()
+        for i, a in enumerate(segs):
+            hot = {name for name, _ in a.calls if pred(name)}
+            if not hot:
+                continue
+            for j, b in enumerate(segs):
+                if i == j or j in before[i] or i in before[j]:
+                    continue
+                for h in hot:
+                    for name, _ in b.calls:
+                        pairs.add((h, name))
+        return sorted(pairs)
+
     def describe(self):
         return "%d segments on %d streams, %d launches" % (len(self.segments), len({s.stream for s in self.segments}),
                                                           sum(len(s.calls) for s in self.segments))

@@ -6,6 +6,7 @@ frozen IMU_Net forward (eval) -> [frozen Upper_Net forward (eval)] -> trained ne
 device (no .item() sync per step), gradients live in one flat buffer (one all-reduce for data parallel,
 one fused Adam launch).  Each body is capturable into a HIP graph.
 """
+import contextlib
 import os
 
 import torch
@@ -125,6 +126,14 @@ def broadcast_flag(value, device, process_group, src=0):
     t = torch.tensor([1.0 if value else 0.0], device=device)
     torch.distributed.broadcast(t, src=src, group=process_group)
     return bool(t.item() != 0.0)
+
+
+def needs_exclusive(nets):
+    """True when one of the nets runs bf16-MFMA kernels (IMUNet.precision / train_precision, UpperNet / LowerNet.precision other than
+    "fp32").  r06: a kernel that shares a CU with a bf16-MFMA workgroup of another kernel can compute wrong
+    results; the cause class found there (packed-fp32 instructions) is compiled out of the library, and INDEPENDENTLY of that the engines
+    keep such a step one dependency chain: nothing is resident beside a bf16-MFMA workgroup but its own kernel."""
+    return any(getattr(m, a, "fp32") != "fp32" for m in nets if m is not None for a in ("precision", "train_precision"))
 
 
 class StageStep:
@@ -315,10 +324,11 @@ class SharedImuStages:
         for st in self.stages:
             st.pose = (self.R, self.t)
         self.pair = ConcurrentStages(self.stages, use_graph=False)
+        self.pair.extra_nets = [self.imu]
         self.use_graph, self.graph = use_graph, None
 
     def _body(self):
-        with torch.no_grad():
+        with torch.no_grad(), (ops.no_fork() if self.pair.exclusive() else contextlib.nullcontext()):
             R, t = self.imu(self.imu_in)
             ops.copy2d(R.view(-1, 9), self.R.view(-1, 9))
             ops.copy2d(t.view(-1, 3), self.t.view(-1, 3))
@@ -355,14 +365,18 @@ class ConcurrentStages:
     nets keep their activations in per-instance arenas).  Results are bit-identical to running the stages one after
     the other (every reduction in the kernels has a fixed order)."""
 
-    def __init__(self, stages, use_graph=True):
+    def __init__(self, stages, use_graph=True, unguarded=False):
         self.stages = list(stages)
+        # unguarded: keep the concurrent branches even when a net runs bf16-MFMA kernels (bench.py's comparison figure and the
+        # reproducers of scripts/ only; see needs_exclusive)
+        self.unguarded = unguarded
         nets_used = [id(m) for st in self.stages for m in (st.net, st.imu, st.upper_frozen) if m is not None]
         if len(set(nets_used)) != len(nets_used):
             raise ValueError("ConcurrentStages: stages share a network instance (each stage needs its own IMU_Net / "
                              "frozen Upper_Net copy: their activation arenas would be written concurrently)")
         self.use_graph = use_graph
         self.graph = None
+        self.extra_nets = []                                  # nets that run beside the stages without being theirs (the owner's IMU_Nets)
         self.side = [torch.cuda.Stream() for _ in self.stages[1:]]
         # data parallel: the stages' gradients share one buffer, so one collective per step serves all of them
         self.bucket = None
@@ -378,7 +392,19 @@ class ConcurrentStages:
             for st in self.stages:
                 allreduce_grads(st.net._flat, st.pg)
 
+    def exclusive(self):
+        """One chain instead of branches: a net of a stage (or one handed in by PipelinedStages / SharedImuStages) runs bf16 MFMAs."""
+        return not self.unguarded and needs_exclusive([m for st in self.stages for m in (st.net, st.imu, st.upper_frozen)] + list(self.extra_nets))
+
     def _bodies(self):
+        if self.exclusive():
+            with ops.no_fork():
+                for st in reversed(self.stages):              # (the order of the branch form; the results do not depend on it)
+                    st._body()
+            return
+        self._bodies_concurrent()
+
+    def _bodies_concurrent(self):
         """Branch order: the LAST stage (longest tail: the Lower body also runs the frozen Upper_Net) gets its IMU_Net forward
         first, alone on the GPU, with its recurrences as two single-direction chains (blocks.two_chains); each earlier stage's
         IMU_Net forward follows on the launching stream when that one has finished, with the previous stage's small-kernel tail
@@ -455,7 +481,7 @@ class PipelinedStages:
     minibatches (tests/test_hip_local.py).  `imu_next` is the static buffer the caller fills with minibatch i+1's IMU samples
     before step i; `prime()` runs the forwards for the first minibatch."""
 
-    def __init__(self, stages, imu_nets, imu_next, use_graph=True):
+    def __init__(self, stages, imu_nets, imu_next, use_graph=True, unguarded=False):
         self.stages, self.imus, self.imu_next = list(stages), list(imu_nets), imu_next
         if len(self.stages) != len(self.imus) or any(st.imu is not None for st in self.stages):
             raise ValueError("PipelinedStages: one IMU_Net per stage, and the stages themselves must be built with imu_net=None")
@@ -468,7 +494,8 @@ class PipelinedStages:
         self.nxt = [mk() for _ in self.stages]
         for st, pose in zip(self.stages, self.cur):
             st.pose = pose
-        self.pair = ConcurrentStages(self.stages, use_graph=False)
+        self.pair = ConcurrentStages(self.stages, use_graph=False, unguarded=unguarded)
+        self.pair.extra_nets = self.imus
         self.side = torch.cuda.Stream()
         self.sides = [self.side] + [torch.cuda.Stream() for _ in self.imus[1:]]
         self.side_by_side = True
@@ -497,6 +524,12 @@ class PipelinedStages:
         for (Rc, tc), (Rn, tn) in zip(self.cur, self.nxt):
             ops.copy2d(Rn.view(-1, 9), Rc.view(-1, 9))
             ops.copy2d(tn.view(-1, 3), tc.view(-1, 3))
+        if self.pair.exclusive():
+            # a net runs bf16 MFMAs: the prefetched forwards and the bodies as ONE chain (needs_exclusive)
+            with ops.no_fork():
+                self._imu_forwards()
+                self.pair._bodies()
+            return
         if self.side_by_side:
             # every forward that runs at once needs its own co-resident set of 256 workgroups for the persistent rnn_slow launch:
             # the device holds `slots` of them (2 on a whole MI355X); the others take the launch-per-timestep form

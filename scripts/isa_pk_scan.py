@@ -10,6 +10,7 @@ import tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 PK = re.compile(r"\b(v_pk_fma_f32|v_pk_mul_f32|v_pk_add_f32|v_pk_mov_b32)\b")
+BF16_MFMA = re.compile(r"\bv_(s?mfma)_\w*bf16\w*\b")
 
 
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
@@ -37,8 +38,9 @@ def device_code_objects(lib):
     return out
 
 
-def scan(lib):
-    """-> (Counter kernel -> packed-fp32 instruction count, number of kernel symbols seen)."""
+def scan(lib, pattern=None):
+    """-> (Counter kernel -> count of instructions matching `pattern` (default: the packed-fp32 ones), number of kernel symbols)."""
+    pattern = pattern or PK
     per, nk = collections.Counter(), 0
     for co in device_code_objects(lib):
         with tempfile.NamedTemporaryFile(suffix=".co") as fh:
@@ -52,7 +54,7 @@ def scan(lib):
                 cur = m.group(1)
                 nk += 1
                 continue
-            if cur and PK.search(line):
+            if cur and pattern.search(line):
                 per[cur] += 1
     return per, nk
 

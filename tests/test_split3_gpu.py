@@ -285,11 +285,136 @@ def test_ul_step_at_bench_shape_with_split3_imu(dev):
         assert r["param_frac_moved_" + tag] < 0.05, (tag, r["param_frac_moved_" + tag])
 
 
+def _ul_engine(dev, kind, precision, unguarded=False, graph=True):
+    """A U+L engine of train_step.py at the benchmarked shape with both frozen IMU_Net forwards (and, for "bf16", the frozen Upper_Net
+    of the Lower stage) in the given precision mode.  -> (engine, its body, su, sl)"""
+    import bench
+    from mmego_amd.train_step import ConcurrentStages, PipelinedStages, SharedImuStages, StageStep
+    x, imu_in, body, target = [v.to(dev) for v in bench.synth_batch(1234, "cpu")]
+    himu, hup, hlo, hfr = bench.build_hip_models(dev)
+    himu_l = bench.clone_imu(himu, dev)
+    himu.precision = himu_l.precision = precision
+    if precision == "bf16":
+        hfr.precision = "bf16"
+    bench._lstm_dropout_off(hup, hlo)
+    own = kind == "concurrent"
+    su = StageStep("upper", hup, himu if own else None, lr=3e-5, use_graph=False)
+    sl = StageStep("lower", hlo, himu_l if own else None, upper_frozen=hfr, lr=3e-5, use_graph=False)
+    kw = {"unguarded": True} if unguarded else {}
+    if kind == "concurrent":
+        eng = ConcurrentStages([su, sl], use_graph=graph, **kw)
+        run = eng._bodies
+    elif kind == "shared":
+        eng = SharedImuStages(himu, [su, sl], imu_in, use_graph=graph)
+        eng.pair.unguarded = unguarded
+        run = eng._body
+    else:
+        eng = PipelinedStages([su, sl], [himu, himu_l], imu_in, use_graph=graph, **kw)
+        run = eng._body
+    su.bind(x, imu_in, body, target)
+    sl.bind(x, imu_in, body, target)
+    if kind == "pipelined":
+        eng.prime()
+    return eng, run, su, sl
+
+
+def test_no_kernel_can_run_beside_a_bf16_mfma_kernel(dev):
+    """STRUCTURAL guard of the r06 co-residency finding (VERDICT r05 item 1 c / d): with a net in "split3" or
+    "bf16" precision every engine of train_step.py (the timed two-stage engine, the IMU-shared one, the prefetch-pipelined one that
+    main.py --train runs) must issue its step as ONE dependency chain -- read off the recorded launch / wait graph of the engine's own
+    body (plan.StepPlan.record: nothing is launched): no launch of any segment may be unordered against a launch of a bf16-MFMA entry
+    point (hip.is_bf16_mfma_entry: everything exported by split3.hip, bf16.hip, *_bf16.hip).  Controls: the same engines in fp32
+    precision DO have parallel segments (and no bf16-MFMA launch), and `unguarded=True` (bench.py's comparison figure) is seen by the
+    check -- so an engine that forgot the guard would fail here every time, not in 5 % of runs."""
+    from mmego_amd import hip
+    from mmego_amd.plan import StepPlan
+    for kind in ("concurrent", "shared", "pipelined"):
+        for precision in ("split3", "bf16"):
+            eng, run, su, sl = _ul_engine(dev, kind, precision, graph=False)
+            eng.step()                                       # (sizes the arenas: recording must not allocate what a launch reads)
+            torch.cuda.synchronize()
+            plan = StepPlan().record(run)
+            names = [n for sg in plan.segments for n, _ in sg.calls]
+            hot = [n for n in names if hip.is_bf16_mfma_entry(n)]
+            assert len(hot) >= 20, (kind, precision, len(hot))                       # the forwards really run on the bf16 pipe
+            assert plan.unordered_with(hip.is_bf16_mfma_entry) == [], (kind, precision)
+            assert len({sg.stream for sg in plan.segments}) == 1, (kind, precision)  # one chain on the launching stream
+            del eng, run, su, sl
+        # control 1: fp32 -- branches exist, no bf16-MFMA launch
+        eng, run, su, sl = _ul_engine(dev, kind, "fp32", graph=False)
+        eng.step()
+        torch.cuda.synchronize()
+        plan = StepPlan().record(run)
+        assert len({sg.stream for sg in plan.segments}) > 1, kind
+        assert not any(hip.is_bf16_mfma_entry(n) for sg in plan.segments for n, _ in sg.calls), kind
+        assert plan.unordered_with(lambda n: n == "lstm_step"), kind                # (the check sees the fp32 branches)
+        del eng, run, su, sl
+        # control 2: the guard switched off -- the check must report the pairs
+        eng, run, su, sl = _ul_engine(dev, kind, "split3", unguarded=True, graph=False)
+        eng.step()
+        torch.cuda.synchronize()
+        pairs = StepPlan().record(run).unordered_with(hip.is_bf16_mfma_entry)
+        assert any(a in ("split3_step", "split3_gemm") and not hip.is_bf16_mfma_entry(b) for a, b in pairs), (kind, pairs[:5])
+        del eng, run, su, sl
+
+
+def test_stage1_training_on_split_products_is_one_chain_too(dev):
+    """The same structural check for the stage-1 trainer with train_precision = "split3" (imu_train.py: piece products beside the
+    fp32 recurrent steps of the same step)."""
+    import bench
+    from mmego_amd import hip
+    from mmego_amd.plan import StepPlan
+    from mmego_amd.train_step import ImuStep
+    himu = bench.build_hip_models(dev)[0]
+    himu.train()
+    himu.train_precision = "split3"
+    g = torch.Generator().manual_seed(5)
+    B, T = 64, 8
+    imu_in = torch.randn(B, T, 20, 15, generator=g).to(dev)
+    R = torch.linalg.qr(torch.randn(B, T, 3, 3, generator=g))[0].contiguous().to(dev)
+    target = torch.randn(B, T, 21, 3, generator=g).to(dev)
+    st = ImuStep(himu, use_graph=False)
+    st.bind(imu_in, R, target)
+    st.step()
+    torch.cuda.synchronize()
+    plan = StepPlan().record(st._body)
+    assert sum(hip.is_bf16_mfma_entry(n) for sg in plan.segments for n, _ in sg.calls) >= 8
+    assert plan.unordered_with(hip.is_bf16_mfma_entry) == []
+
+
+def test_unguarded_concurrent_split3_steps_are_reproducible_bit_for_bit(dev):
+    """The r05 / r06 reproducer as a regression test of the BUILD (no packed-fp32 instruction in any kernel):
+    the arrangement that corrupted the Lower stage's gradients -- both IMU_Net forwards in split3 mode as concurrent graph branches
+    beside the other stage's tail (`unguarded=True`), in the 32-unit form AND in the 16-unit two-chain form -- 10 fresh engines x 3
+    steps each, both stages' gradient buffers bit-equal to the first engine's.  With the packed instructions in the library 22 of 60
+    (32-unit) and 59 of 60 (two chains) such engines differed (profiles/r06_coexec/r06_fullstep_b.log): this test would then fail
+    with probability > 0.99; without them 0 of 120."""
+    import bench
+    from mmego_amd import blocks
+    for two in (True, False):
+        ref = None
+        with blocks.split3_two_chains(two):
+            for it in range(10):
+                eng, run, su, sl = _ul_engine(dev, "concurrent", "split3", unguarded=True)
+                gs = []
+                for _ in range(3):
+                    eng.step()
+                    torch.cuda.synchronize()
+                    gs.append([st.net.flat().flat_g.detach().clone() for st in (su, sl)])
+                if ref is None:
+                    ref = gs
+                for s_, (ga, gb) in enumerate(zip(gs, ref)):
+                    for a, b, tag in zip(ga, gb, ("upper", "lower")):
+                        assert torch.equal(a, b), (two, it, s_, tag, float((a - b).abs().max()))
+                del eng, run, su, sl
+    assert blocks.seq_xcd_errors() == 0
+
+
 def test_concurrent_step_with_split3_imu_is_reproducible_bit_for_bit(dev):
-    """Six U+L steps of the timed engine (ConcurrentStages, HIP graph: the Lower tail runs beside the Upper stage's IMU_Net forward) from
-    the same seeded state with both IMU_Net forwards in the split3 mode: both stages' gradient buffers bit-equal every time.  r05: with
-    the 16-unit two-chain step kernel beside the Lower tail, head_fk_loss's dy -- and with it every Lower gradient -- changed in ~10 %
-    of such runs (scripts/coexec_head_fk.py; that form is off by default, blocks.SPLIT3_TWO_CHAINS)."""
+    """Six U+L steps of the timed engine (ConcurrentStages, HIP graph) from the same seeded state with both IMU_Net forwards in the
+    split3 mode: both stages' gradient buffers bit-equal every time.  (r05: with its stage branches side by side this differed in
+    ~10 % of runs, the co-residency finding; since r06 the engine runs such a step as one chain -- see the two tests above -- and the
+    library holds no packed-fp32 instruction.)"""
     import bench
     from mmego_amd import blocks
     from mmego_amd.train_step import ConcurrentStages, StageStep
