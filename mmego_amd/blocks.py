@@ -947,14 +947,23 @@ def split3_join(y, rows, K):
     return x[:rows]
 
 
+def _split3_cache_of(lstm):
+    """The per-layout cache of an LSTM's weight pieces for the CURRENT parameter version (an empty one after any change)."""
+    ver = tuple(p._version for p in lstm.parameters()) + tuple(p.data_ptr() for p in lstm.parameters())
+    cache = getattr(lstm, "_split3_cache", None)
+    if cache is None or cache.get("ver") != ver:
+        cache = lstm._split3_cache = {"ver": ver}
+    return cache
+
+
 def lstm_split3_weights(lstm, nu=32):
     """Per layer: (W_ih of both directions stacked [8H, In] as pieces, b_ih + b_hh stacked [8H] fp32, W_hh pieces per direction).
     nu = 32: W_hh rows reordered [32-unit block][gate][32 units] (mmego_split3_step), the projection's columns in
     PyTorch's order; nu = 16: W_hh rows AND the projection's columns (W_ih rows, biases) per direction reordered [16-unit block][gate]
-    [16 units] (mmego_split3_step16).  Built once per weight version and layout (dropped by weights_changed())."""
-    cache = getattr(lstm, "_split3_cache", None)
-    if cache is None:
-        cache = lstm._split3_cache = {}
+    [16 units] (mmego_split3_step16).  Built once per weight version and layout: keyed like the bf16 copies on every parameter's
+    (_version, data_ptr) -- load_state_dict / copy_ in eval mode drop it -- and dropped by weights_changed() for the
+    writers that do not bump _version (fused Adam)."""
+    cache = _split3_cache_of(lstm)
     if nu in cache:
         return cache[nu]
     H = lstm.hidden_size
@@ -1042,9 +1051,7 @@ def lstm_steps_forward_split3(ar, key, lstm, x, Bn, T, xfrag=None, nprod=None):
 def lstm_split3_proj_weights(lstm):
     """Per layer and direction: W_ih as pieces with rows reordered [32-unit block][gate][32 units] (mmego_split3_proj), and b_ih of both
     directions stacked [8H]."""
-    cache = getattr(lstm, "_split3_cache", None)
-    if cache is None:
-        cache = lstm._split3_cache = {}
+    cache = _split3_cache_of(lstm)
     if "proj" in cache:
         return cache["proj"]
     H = lstm.hidden_size

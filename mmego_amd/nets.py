@@ -991,8 +991,8 @@ class IMUNet(_NetBase):
         # "fp32" (default, the parity path) or "bf16": eval-mode BiLSTM products with bf16 operands and fp32 accumulation
         # (BASELINE config 5); everything else -- gates, cell state, pooling, heads -- stays fp32 in both modes.
         self.precision = os.environ.get("MMEGO_IMU_PRECISION", "fp32")
-        # stage-1 TRAINING (imu_train.py): "split3" runs rnn_fast's input-projection and input-gradient products as fp32-accurate
-        # piece products on the bf16 matrix pipe (opt-in; the recurrent steps and the weight gradients stay on the fp32 kernels)
+        # stage-1 TRAINING (imu_train.py): "split3" runs rnn_fast's input-projection, input-gradient AND weight-gradient products as
+        # fp32-accurate piece products on the bf16 matrix pipe (opt-in; the recurrent steps stay on the fp32 kernels)
         self.train_precision = os.environ.get("MMEGO_IMU_TRAIN_PRECISION", "fp32")
 
     def _pulled_pairs(self):

@@ -264,6 +264,41 @@ def test_imu_forward_split3_at_the_fp32_bars(dev):
         big(imu.to(dev))
 
 
+def test_split3_and_bf16_weight_pieces_follow_load_state_dict_in_eval_mode(dev):
+    """the cached weight pieces of the split3 mode were keyed by layout only and dropped by weights_changed() alone, so
+    load_state_dict() / an in-place copy AFTER an eval-mode split3 forward kept the old pieces.  Now keyed on every parameter's
+    (_version, data_ptr) like the bf16 copies: forward -> load other weights (still in eval mode) -> forward must equal a FRESH net that
+    was given those weights from the start, bit for bit, in both modes."""
+    from mmego_amd import nets
+    imu = torch.randn(16, 8, 20, 15, generator=torch.Generator().manual_seed(2)).to(dev)
+    torch.manual_seed(41)
+    a = nets.IMUNet(15, 9, 512, 2, True, 0.1).to(dev).eval()
+    torch.manual_seed(42)
+    other = {k: v.clone() for k, v in nets.IMUNet(15, 9, 512, 2, True, 0.1).state_dict().items()}
+    for mode in ("split3", "bf16"):
+        a.precision = mode
+        with torch.no_grad():
+            R0, t0 = [v.clone() for v in a(imu)]
+        a.load_state_dict({k: v.to(dev) for k, v in other.items()})
+        with torch.no_grad():
+            R1, t1 = [v.clone() for v in a(imu)]
+        fresh = nets.IMUNet(15, 9, 512, 2, True, 0.1).to(dev).eval()
+        fresh.load_state_dict({k: v.to(dev) for k, v in other.items()})
+        fresh.precision = mode
+        with torch.no_grad():
+            R2, t2 = fresh(imu)
+        assert not torch.equal(R0, R1), mode
+        assert torch.equal(R1, R2) and torch.equal(t1, t2), (mode, float((R1 - R2).abs().max()))
+        with torch.no_grad():                                  # an in-place change of one weight tensor
+            a.rnn_fast.w("weight_hh", 0, 0).mul_(0.5)
+            fresh.rnn_fast.w("weight_hh", 0, 0).mul_(0.5)
+            fresh.weights_changed()
+            R3, R4 = a(imu)[0].clone(), fresh(imu)[0]
+        assert torch.equal(R3, R4), mode
+        torch.manual_seed(41)
+        a.load_state_dict({k: v.to(dev) for k, v in nets.IMUNet(15, 9, 512, 2, True, 0.1).state_dict().items()})
+
+
 def test_ul_step_at_bench_shape_with_split3_imu(dev):
     """tests/test_bench_shape.py::test_ul_step_at_bench_shape_against_oracle with both frozen IMU_Net forwards in the split3 mode: the
     SAME bars (losses 2e-5 rel., joints 1e-3 cm, every gradient 2e-4 of the largest, post-Adam parameters)."""
