@@ -1,14 +1,9 @@
-"""r05 finding, standalone reproducer: mmego_head_fk_loss (which = 1: the Lower stage's kinematics + L1 loss + first backward step,
-geom.hip) launched on one stream while a BiLSTM(512) stack runs on another -- as the fp32 step kernels, as the split3 32-unit step
-kernel, and as the split3 16-unit step kernel in its two-chain form (mmego_split3_step16).  Its outputs (q, joints, world joints, dy,
-loss) must not depend on what runs beside it.  Measured on MI355X (several boxes): beside the 16-unit kernel dy differs in 4-8 of 100
-rounds of 20 launches -- always a 16-lane group of one wave, a few columns, values close to the right ones -- and never beside the
-others; q, joints and the loss never differ.  Ruled out by variants of the 16-unit kernel: its LDS contents (LDS poison in front of
-every launch of a whole Lower step changes nothing: scripts/find_lds_uninit.py), its global stores, ds_bpermute, padding its VGPR /
-SGPR allocation; with its MFMAs compiled out nothing differs.  What does remove it: keeping every LDS-using workgroup off the victim's
-CU -- the victim asking for 144 KB of LDS it never touches: 12 of 200 rounds differ without, 0 of 200 with the request, same box, same
-run (gpurun_out r05_coexec_a/b).  mmego_head_fk_loss has made that request since; to see the effect again build the library with
-MMEGO_EXTRA_HIPCC_FLAGS=-DMMEGO_HEAD_FK_NO_LDS_PAD.  blocks.SPLIT3_TWO_CHAINS stays off by default (the unexplained part)."""
+"""r05's standalone reproducer of the co-residency finding (kept as written; r06's tools supersede it: scripts/coexec_variants.py --
+victim variants --, coexec_asm_patch.py -- the real kernel's assembly patched --, coexec_fullstep.py -- the whole step --).
+mmego_head_fk_loss (which = 1) launched on one stream while a BiLSTM(512) stack runs on another -- as the fp32 step kernels, as the split3
+32-unit step kernel, and as the split3 16-unit step kernel in its two-chain form.  With the PRODUCT library it reports 0 differing rounds
+everywhere since r06 (no packed-fp32 instruction in the victim); r05's statement below the table "never beside the others" was wrong for
+the whole step (22 of 60 engines in the 32-unit arrangement)."""
 import os
 import sys
 

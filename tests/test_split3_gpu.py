@@ -389,7 +389,10 @@ def test_no_kernel_can_run_beside_a_bf16_mfma_kernel(dev):
         eng.step()
         torch.cuda.synchronize()
         pairs = StepPlan().record(run).unordered_with(hip.is_bf16_mfma_entry)
-        assert any(a in ("split3_step", "split3_gemm") and not hip.is_bf16_mfma_entry(b) for a, b in pairs), (kind, pairs[:5])
+        if kind == "shared":
+            assert pairs == [], kind           # (its one IMU_Net forward precedes the fork of the two bodies: nothing beside it either way)
+        else:
+            assert any(a in ("split3_step", "split3_gemm") and not hip.is_bf16_mfma_entry(b) for a, b in pairs), (kind, pairs[:5])
         del eng, run, su, sl
 
 
