@@ -397,12 +397,37 @@ class ConcurrentStages:
         return not self.unguarded and needs_exclusive([m for st in self.stages for m in (st.net, st.imu, st.upper_frozen)] + list(self.extra_nets))
 
     def _bodies(self):
-        if self.exclusive():
-            with ops.no_fork():
-                for st in reversed(self.stages):              # (the order of the branch form; the results do not depend on it)
-                    st._body()
-            return
-        self._bodies_concurrent()
+        if not self.exclusive():
+            return self._bodies_concurrent()
+        # A net runs bf16 MFMAs (needs_exclusive): everything that may launch such a kernel goes onto ONE chain -- the frozen IMU_Net
+        # forwards first, one after the other, every fork site inside them closed (ops.no_fork) -- and only bodies whose own nets are
+        # all fp32 fork off behind it (one stage's tail beside the other's: neither holds a bf16-MFMA kernel).  Bodies with such a net
+        # (a frozen Upper_Net in bf16 precision) stay on the chain as well.  The structural test reads exactly this off the recorded
+        # launch graph (tests/test_split3_gpu.py::test_no_kernel_can_run_beside_a_bf16_mfma_kernel).
+        main = torch.cuda.current_stream()
+        stages = self.stages
+        keep = [(st.imu, st.pose) for st in stages]
+        try:
+            with ops.no_fork(), torch.no_grad():
+                for st in reversed(stages):
+                    if st.imu is not None and st.pose is None:
+                        st.pose = st.imu(st.static["imu"])
+            hot_bodies = needs_exclusive([m for st in stages for m in (st.net, st.upper_frozen)])
+            if hot_bodies or len(stages) == 1 or not ops.capture_can_fork():
+                with ops.no_fork():
+                    for st in reversed(stages):               # (the order of the branch form; the results do not depend on it)
+                        st._body()
+            else:
+                for i in range(len(stages) - 1, 0, -1):
+                    self.side[i - 1].wait_stream(main)
+                    with torch.cuda.stream(self.side[i - 1]):
+                        stages[i]._body()
+                stages[0]._body()
+                for side in self.side:
+                    main.wait_stream(side)
+        finally:
+            for st, (imu, pose) in zip(stages, keep):
+                st.imu, st.pose = imu, pose
 
     def _bodies_concurrent(self):
         """Branch order: the LAST stage (longest tail: the Lower body also runs the frozen Upper_Net) gets its IMU_Net forward
@@ -528,7 +553,7 @@ class PipelinedStages:
             # a net runs bf16 MFMAs: the prefetched forwards and the bodies as ONE chain (needs_exclusive)
             with ops.no_fork():
                 self._imu_forwards()
-                self.pair._bodies()
+            self.pair._bodies()                               # (forks only all-fp32 bodies, behind the forwards)
             return
         if self.side_by_side:
             # every forward that runs at once needs its own co-resident set of 256 workgroups for the persistent rnn_slow launch:
