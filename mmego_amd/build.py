@@ -14,10 +14,12 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmmego_hip.so")
 ARCH = "gfx950"
 # No packed-fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) in any kernel: the target feature is switched
-# off for the device compilation.  r06 finding: a wave that executes them while a bf16-MFMA workgroup of ANOTHER
-# kernel is resident on its CU gets wrong VCC-dependent selects in lanes 48-63 (silently wrong gradients in 22-59 of 60 step engines
-# with the instructions, 0 of 120 without); tests/test_host_cpu.py holds the built library to zero such instructions.  No measurable
-# cost (U+L step 4.98-4.99 ms with, 5.00 ms without; config 5, wlocal and stage-1 figures unchanged).
+# off for the device compilation.  r06 finding: such an instruction whose op_sel takes the HIGH register of its
+# second source pair for the LOW result can receive 0.0 for that operand in lanes 48-63 while s3_gemm_kernel's workgroups are resident
+# on the same CU (standalone: scripts/coexec_pk_probe.hip, 45-92 of 1000 rounds; the whole step: silently wrong gradients in 22-59 of 60
+# engines with the instructions, 0 of 120 without).  Which packed instruction gets that op_sel is the register allocator's choice, so the
+# class goes; tests/test_host_cpu.py holds the built library to zero of them.  No measurable cost (U+L step 4.98-4.99 ms with, 5.00 ms
+# without; config 5, wlocal and stage-1 figures unchanged).
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32 + os.environ.get("MMEGO_EXTRA_HIPCC_FLAGS", "").split()
 # (the host pass of the same command line does not know the amdgcn feature and says so once per file)

@@ -17,6 +17,11 @@
 //    14  s_nop 1 (control)             15  v_mov_b32, v_pk_mul_f32
 //    16  v_pk_mul_f32, s_nop 3, v_mov_b32    17  v_mul_f32, s_nop 3, v_mov_b32 (control)    18  s_nop 3, v_pk_mul_f32, v_mov_b32
 //    19  the v_pk_mul_f32 in FRONT of the v_cmp, then s_nop 3, v_mov_b32           20  pk, s_nop 3, cmp, s_nop 3, pk, s_nop 3, mov
+//   modes 21-27 (r06, after scripts/coexec_asm_patch.py's probe caught the failing instruction of the real kernel -- a packed add whose
+//   op_sel takes the HIGH register of a source pair for the LOW result: that operand arrived as 0.0 in lanes 48-63): one packed
+//   instruction per repetition on fresh operands, BOTH result halves summed.  21 v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]   22 v_pk_mul_f32
+//   op_sel:[0,1]   23 v_pk_mul_f32 op_sel_hi:[1,0]   24 v_pk_add_f32 without op_sel (control)   25 v_pk_fma_f32 op_sel:[0,1,0]
+//   26 v_pk_mov_b32 op_sel:[1,0]   27 v_pk_add_f32 op_sel:[1,0]
 //   (dense: plain v_add_f32 fillers instead of s_nop around the tested sequence, so that another wave's MFMAs interleave with it)
 // Every lane carries its own data; the result of a launch on an idle GPU is the reference.
 #include <hip/hip_runtime.h>
@@ -332,6 +337,104 @@ __global__ __launch_bounds__(64) void pk_probe_kernel(float* out, int iters, int
           : "v"(a), "v"(b)
           : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
     }
+    if (MODE == 21) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v101, %5\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_fma_f32 v100, v106, 0.5, %4\n\t"
+              "v_fma_f32 v101, v106, 2.0, %5\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_pk_add_f32 v[102:103], v[104:105], v[100:101] op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 22) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v101, %5\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_fma_f32 v100, v106, 0.5, %4\n\t"
+              "v_fma_f32 v101, v106, 2.0, %5\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_pk_mul_f32 v[102:103], v[104:105], v[100:101] op_sel:[0,1]\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 23) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v101, %5\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_fma_f32 v100, v106, 0.5, %4\n\t"
+              "v_fma_f32 v101, v106, 2.0, %5\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_pk_mul_f32 v[102:103], v[104:105], v[100:101] op_sel_hi:[1,0]\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 24) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v101, %5\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_fma_f32 v100, v106, 0.5, %4\n\t"
+              "v_fma_f32 v101, v106, 2.0, %5\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_pk_add_f32 v[102:103], v[104:105], v[100:101]\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 25) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v101, %5\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_fma_f32 v100, v106, 0.5, %4\n\t"
+              "v_fma_f32 v101, v106, 2.0, %5\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_pk_fma_f32 v[102:103], v[104:105], v[100:101], v[104:105] op_sel:[0,1,0]\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 26) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v101, %5\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_fma_f32 v100, v106, 0.5, %4\n\t"
+              "v_fma_f32 v101, v106, 2.0, %5\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_pk_mov_b32 v[102:103], v[100:101], v[104:105] op_sel:[1,0]\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
+    if (MODE == 27) {
+      asm volatile(
+          "v_mov_b32 v104, %5\n\tv_mov_b32 v105, %4\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v101, %5\n\tv_mov_b32 v106, %5\n\ts_nop 4\n\t" REP16(
+              "v_fma_f32 v100, v106, 0.5, %4\n\t"
+              "v_fma_f32 v101, v106, 2.0, %5\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_pk_add_f32 v[102:103], v[104:105], v[100:101] op_sel:[1,0]\n\t"
+              "v_add_f32 v113, v104, v105\n\t" "v_add_f32 v114, v104, v105\n\t" "v_add_f32 v115, v104, v105\n\t" 
+              "v_add_f32 %0, %0, v102\n\tv_add_f32 %1, %1, v103\n\t"
+              "v_fma_f32 v106, v106, 0.5, %4\n\t")
+          : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+          : "v"(a), "v"(b)
+          : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "vcc");
+    }
     acc0 *= 0.25f;                                                                     // (keeps the sums finite over many rounds)
     acc1 *= 0.25f;
   }
@@ -346,7 +449,7 @@ extern "C" int pk_probe_launch(void* stream, int mode, float* out, int nblk, int
   hipStream_t st = (hipStream_t)stream;
 #define L(M) case M: pk_probe_kernel<M><<<nblk, 64, 0, st>>>(out, iters, 0); break
   switch (mode) {
-    L(0); L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); L(9); L(10); L(11); L(12); L(13); L(14); L(15); L(16); L(17); L(18); L(19); L(20);
+    L(0); L(1); L(2); L(3); L(4); L(5); L(6); L(7); L(8); L(9); L(10); L(11); L(12); L(13); L(14); L(15); L(16); L(17); L(18); L(19); L(20); L(21); L(22); L(23); L(24); L(25); L(26); L(27);
     default: return -1;
   }
   return (int)hipGetLastError();
