@@ -448,6 +448,145 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
   }
 }
 
+// ---- the same product on 320 x 256 tiles, operands by LDS-DMA (r06) ---------------------------------------------------------------
+// Why: the kernel above is bound by what a CU can pull from L2, not by the matrix pipe.  A 256 x 128 tile needs (256 + 128) x 32 k x 6 B =
+// 74 KB per 32-k chunk for 6144 cycles of MFMA issue on its SIMDs (two workgroups per CU): 24 B / clk / CU, against the ~20 B / clk / CU
+// this chip delivers from L2 on any path (NOTES.md) -- PMC: MFMA busy 0.63, 3.0 TB/s of L2 misses, 3.9 x the algorithmic bytes.  Arithmetic
+// intensity is M N / (M + N) per tile: 85 for 256 x 128, **142 for 320 x 256** (14 B / clk / CU), and 10 240 x 4096 is exactly 32 x 16 = 512
+// such tiles = TWO full rounds of the 256 CUs (1280 tiles on 512 slots were 2.5).
+//   Workgroup = one tile, 512 threads, ONE per CU (256 VGPRs per wave): waves 2 (M) x 4 (N), wave tile 160 x 64 = 5 x 2 MFMA tiles
+//   (160 accumulator registers); per 16-k step a wave reads 2 x 3 W fragments once and 5 x 3 A fragments (lane-linear ds_read_b128)
+//   for 60 (90) MFMAs.
+//   Operands: a 16-k step of the tile is (10 + 8) row blocks x 3 KB = 54 KB, as it lies in memory; it goes global -> LDS by LDS-DMA
+//   (global_load_lds_dwordx4: 54 1-KB transfers per step, 7 per wave, no VGPRs -- the register-staged copy of the kernel above would need
+//   56 more), into a ring of TWO 54-KB stages; one barrier per step, placed INSIDE the step (see the schedule in the kernel).
+//   Tile order: an XCD's 64 tiles are two rounds of 4 row panels x 8 column tiles over the SAME 4 row panels (A panels stay in its L2).
+template <int NPROD>
+__global__ __launch_bounds__(512, 1) void s3_gemm_big_kernel(S3GemmP p) {
+  constexpr int TRB = 10, TCB = 8, NBLK = (TRB + TCB) * 3;       // 1-KB blocks per step and stage
+  extern __shared__ __attribute__((aligned(16))) s3_u32x4 s3_big[];   // [2 stages][NBLK][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // (wave-uniform by construction: addresses below stay scalar)
+  const int wm = w >> 2, wn = w & 3;
+  int tm, tn;
+  {
+    const int n = (int)gridDim.x;
+    if ((n & 63) == 0 && (p.tiles_m & 3) == 0 && (p.tiles_n & 7) == 0) {
+      const int x = blockIdx.x & 7, l = blockIdx.x >> 3;          // XCD (round-robin dispatch), index inside the XCD's run
+      const int per_x = n >> 3, rounds = per_x >> 5;             // 32 tiles = 4 x 8 per round
+      const int blk = x * rounds + (l >> 5), within = l & 31;     // block of 4 row panels x 8 column tiles
+      const int bn_count = p.tiles_n >> 3;
+      tm = (blk / bn_count) * 4 + (within & 3);
+      tn = (blk % bn_count) * 8 + (within >> 2);
+    } else {
+      tm = blockIdx.x % p.tiles_m;
+      tn = blockIdx.x / p.tiles_m;
+    }
+  }
+  const int rbA0 = tm * TRB, rbW0 = tn * TCB;
+  const int SK = p.SK;
+  // this wave's transfers: blocks i = w + 8 j of a stage (i < NBLK); block i < 30: A row block i / 3, piece i % 3; else W.
+  // Source = a wave-uniform block address (scalar registers) + 16 lane.
+  const s3_u32x4* gp[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int i = min(w + 8 * j, NBLK - 1);
+    const int isw = i >= TRB * 3, ii = isw ? i - TRB * 3 : i;
+    const int rb = (isw ? rbW0 : rbA0) + ii / 3;
+    gp[j] = (isw ? p.W : p.A) + ((long)rb * SK * 3 + ii % 3) * 64;
+  }
+#define S3_BIG_DMA(s, stage)                                                                                          \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 7; ++j)                                                                     \
+      if (w + 8 * j < NBLK && !(S3_EXP & 16))                                                                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[j] + (long)((S3_EXP & 2) ? 0 : (s)) * 192 + lane), \
+                                         (__attribute__((address_space(3))) void*)(s3_big + ((stage) * NBLK + w + 8 * j) * 64), 16, 0, 0); \
+  }
+  f32x16 acc[5][2];
+#pragma unroll
+  for (int mi = 0; mi < 5; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+  // Schedule (steps in pairs, so that every register index below is a compile-time constant).  At the top of step s its stage holds
+  // its data and its W fragments + first A fragments are requested.  Inside the step: row block mi + 1's fragments are requested in
+  // front of row block mi's 12 (18) MFMAs; in front of row block 3's -- the last read of this stage is out -- the wave waits for its
+  // reads and for its transfers of step s + 1, meets the others at THE step's one barrier, and requests step s + 2 into the stage it has
+  // just finished with; in front of row block 4's MFMAs it requests the first fragments of step s + 1.  So no barrier sits between two
+  // steps, and a transfer has a whole step (3840 cycles of MFMA issue per SIMD) to land.
+  s3_u32x4 b[2][2][3], a[2][3];
+#define S3_BIG_RD_B(slot, stage)                                                                                      \
+  if (!(S3_EXP & 32)) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                \
+    _Pragma("unroll") for (int q = 0; q < 3; ++q) b[slot][ni][q] = s3_big[((stage) * NBLK + TRB * 3 + (wn * 2 + ni) * 3 + q) * 64 + lane];
+#define S3_BIG_RD_A(slot, stage, mi)                                                                                  \
+  if (!(S3_EXP & 32)) _Pragma("unroll") for (int q = 0; q < 3; ++q) a[slot][q] = s3_big[((stage) * NBLK + (wm * 5 + (mi)) * 3 + q) * 64 + lane];
+#define S3_BIG_STEP(s, par)                                                                                           \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < 5; ++mi) {                                                                \
+      if (mi < 4) { S3_BIG_RD_A(((par) + mi + 1) & 1, par, mi + 1) }                                                  \
+      if (mi == 3) {                                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                   \
+        __builtin_amdgcn_s_barrier();                                                                                 \
+        if (wm == 0 && (s) + 2 < SK) S3_BIG_DMA((s) + 2, par)                                                         \
+      }                                                                                                               \
+      if (mi == 4 && (s) + 1 < SK) {                                                                                  \
+        S3_BIG_RD_B((par) ^ 1, (par) ^ 1)                                                                             \
+        S3_BIG_RD_A(((par) ^ 1), (par) ^ 1, 0)                                                                        \
+      }                                                                                                               \
+      /* the two waves of a SIMD (w and w + 4) issue their transfers at DIFFERENT points: a 1-KB LDS-DMA costs its wave 60-185   \
+         cycles of issue (MI355X_MICROARCH.md), seven of them a fifth of a step -- while one wave of the SIMD issues them the     \
+         other one issues MFMAs */                                                                                    \
+      if (mi == 4 && wm == 1 && (s) + 2 < SK) S3_BIG_DMA((s) + 2, par)                                                 \
+      /* (no scheduling barrier here: pinning the requests in front of the group's MFMAs measured 1.5 % SLOWER than the      \
+         scheduler's own placement, same box, three alternations) */                                                 \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = s3_mma<NPROD>(a[((par) + mi) & 1], b[par][ni], acc[mi][ni]); \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }                                                                                                                 \
+  }
+  // (A-fragment slots: step parity par starts with slot par -- row block mi sits in slot (par + mi) & 1 -- so that the first
+  //  fragments of the NEXT step, requested in front of row block 4's MFMAs (slot par), go to slot par ^ 1.)
+  S3_BIG_DMA(0, 0)
+  if (SK > 1) S3_BIG_DMA(1, 1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  S3_BIG_RD_B(0, 0)
+  S3_BIG_RD_A(0, 0, 0)
+  for (int s = 0; s < SK; s += 2) {
+    S3_BIG_STEP(s, 0)
+    if (s + 1 < SK) S3_BIG_STEP(s + 1, 1)
+  }
+#undef S3_BIG_STEP
+#undef S3_BIG_RD_A
+#undef S3_BIG_RD_B
+#undef S3_BIG_DMA
+  const int fr = lane & 31;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int cb = rbW0 + wn * 2 + ni;
+    const float bv = p.bias ? p.bias[cb * 32 + fr] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 5; ++mi) {
+      const int rbm = rbA0 + wm * 5 + mi;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mi][ni][i] += bv;
+      if (p.Cf) {
+        float* t = p.Cf + ((long)rbm * p.Nrb + cb) * 1024 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(t + q * 256) = (f32x4){acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+      }
+      if (p.C) {
+        float* cp = p.C + (long)(rbm * 32 + 4 * (lane >> 5)) * p.ldc + cb * 32 + fr;
+        const int rows_left = p.M - (rbm * 32 + 4 * (lane >> 5));
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (8 * (i >> 2) + (i & 3) < rows_left) cp[(long)(8 * (i >> 2) + (i & 3)) * p.ldc] = acc[mi][ni][i];
+      }
+    }
+  }
+}
+
 // C[m][n] = sum_k A[m][k] W[n][k] + bias[n] on 6 (nprod = 6) or 9 piece products; A sfrag [Mrb][K / 16][3] KB, W sfrag [Nrb][K / 16][3] KB
 // (mmego_split3_cvt).  Cf: tile-major fp32 [Mrb][Nrb][1024] and / or C: row-major (rows < M stored, row stride ldc).  K % 32 == 0.
 // wm: tile rows / 64 -- 1: 64 x 128 tiles (256-thread workgroups of four 32 x 64 wave tiles: products with few rows), 2: 128 x 128
@@ -459,6 +598,30 @@ static int s3_gemm_launch(void* stream, const unsigned short* A, const unsigned 
   MMEGO_REQUIRE(!C || (M > 0 && M <= Mrb * 32 && ldc >= Nrb * 32));
   MMEGO_REQUIRE((long)Mrb * (K / 16) * 192 < (1L << 31) && (long)Nrb * (K / 16) * 192 < (1L << 31));
   MMEGO_REQUIRE(nsplit >= 1 && nsplit <= 64 && (nsplit == 1 || slab > 0));
+  // wm = 0 (the library's choice) or 10: 320 x 256 tiles where they divide the product and fill the chip (the projections of rnn_fast:
+  // 10 240 x 4096 = 512 tiles)
+  if ((wm == 0 || wm == 10) && nsplit == 1 && Mrb % 10 == 0 && Nrb % 8 == 0 && (long)(Mrb / 10) * (Nrb / 8) >= (wm == 10 ? 1 : 256)) {
+    S3GemmP p;
+    p.A = reinterpret_cast<const s3_u32x4*>(A); p.W = reinterpret_cast<const s3_u32x4*>(W);
+    p.Cf = Cf; p.C = C; p.ldc = ldc; p.bias = bias; p.Mrb = Mrb; p.Nrb = Nrb; p.SK = K / 16; p.M = M;
+    p.tiles_m = Mrb / 10; p.tiles_n = Nrb / 8; p.gm = 4; p.cps = K / 32; p.slab = 0;
+    constexpr int lds = 2 * 54 * 1024;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MMEGO_EBADARG;
+    if (!attr_set[dev]) {
+      hipError_t e = hipFuncSetAttribute((const void*)s3_gemm_big_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s3_gemm_big_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      attr_set[dev] = true;
+    }
+    const unsigned tiles = (unsigned)(p.tiles_m * p.tiles_n);
+    if (nprod == 6) s3_gemm_big_kernel<6><<<tiles, 512, lds, (hipStream_t)stream>>>(p);
+    else s3_gemm_big_kernel<9><<<tiles, 512, lds, (hipStream_t)stream>>>(p);
+    MMEGO_LAUNCH_CHECK();
+    return MMEGO_OK;
+  }
+  if (wm == 10) return MMEGO_EBADARG;
   if (wm == 0) {
     const long t128 = (long)cdiv(Mrb, 4) * cdiv(Nrb, 4) * nsplit;        // 128 x 128 tiles
     wm = t128 < 256 ? 1 : (Mrb >= 64 && (long)cdiv(Mrb, 8) * cdiv(Nrb, 4) * nsplit >= 256 ? 4 : 2);     // fewer tiles than CUs: smaller tiles
@@ -738,10 +901,10 @@ __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
 // directions' launches -- independent dependency chains -- put one workgroup of each on a CU: one direction's launch gap, prologue
 // and cell update run beside the other's product loop.  (Both directions in one 512-workgroup launch would run the pairs in lockstep.)
 // NOT THE DEFAULT (blocks.split3_two_chains, a test hook): no faster inside a step.  r05 saw head_fk_loss_kernel<1> of geom.hip come out
-// different in a 16-lane group of a wave in ~5 % of the runs while a workgroup of THIS kernel shared its CU; r06 found what the victim
-// needs for that -- packed-fp32 instructions (v_pk_*_f32): VCC-dependent selects read 0 in lanes 48-63 -- and that the 32-unit kernel
-// does it as well (22 of 60 step engines); the library is compiled without those instructions and a step with bf16-MFMA kernels runs as
-// one chain (scripts/coexec_variants.py, coexec_asm_patch.py, coexec_fullstep.py).
+// different in a 16-lane group of a wave in ~5 % of the runs while this stack ran beside it; r06 found the instruction -- a packed-fp32
+// add / mul / fma whose op_sel takes the HIGH register of its second source pair for the LOW result receives 0.0 for it in lanes 48-63 --
+// and the neighbour that does it: s3_gemm_kernel above, not this kernel (scripts/coexec_pk_probe.hip is the
+// standalone reproducer).  The library is compiled without packed-fp32 instructions, and a step with bf16-MFMA kernels runs them on one chain.
 // W_hh rows [16-unit block][gate][16 units]: a 32-column block holds a gate PAIR -- block 0: i | f, block 1: g | o -- of 16 units, so
 // the four gates of a (row, unit) sit in lanes l and l ^ 16 of the two accumulator tiles; one exchange (the pre-activations of the
 // rows the partner finishes) and every lane updates 4 cells.  The projection's columns are permuted the same way (weight
