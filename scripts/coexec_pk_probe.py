@@ -17,7 +17,7 @@ nblk = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 # what runs on the second stream (argv[5], comma-separated; default the 16-unit split3 stack): none | step16 (s3_gemm + 16-unit steps,
 # two workgroups per CU) | step32 (the product's split3 stack: s3_gemm + 32-unit steps) | s3gemm (the projection products alone) |
-# s3steps (the 16-unit steps alone) | fp32 (the fp32 stack: gemm_tile + LDS-DMA steps) | bf16 (the bf16-mode stack of section 7a)
+# s3gemm4 / s3gemm10 (the same with the 256 x 128 register-staged / the 320 x 256 LDS-DMA kernel forced) | s3steps (the 16-unit steps alone) | fp32 (the fp32 stack: gemm_tile + LDS-DMA steps) | bf16 (the bf16-mode stack of section 7a)
 aggressors = sys.argv[5].split(",") if len(sys.argv) > 5 else ["step16"]
 from mmego_amd import ops  # noqa: E402
 ar = ops.Arena(dev)
@@ -30,7 +30,7 @@ sB = torch.cuda.Stream()
 _s16 = {}
 
 
-def step16_stack(gemm=True, steps=True):
+def step16_stack(gemm=True, steps=True, wm=0):
     if not _s16:
         nrb, S2 = Bn // 32, 2 * H // 16
         _s16.update(W=blocks.lstm_split3_weights(lstm, 16), x=blocks.split3_cvt(xs, tm=(Bn, S, Bn)), xpf=torch.empty(S * Bn * 8 * H, device=dev),
@@ -42,7 +42,7 @@ def step16_stack(gemm=True, steps=True):
     for layer in range(2):
         wih, bias, whh0, whh1 = d["W"][layer]
         if gemm:
-            hip.call("split3_gemm", cur, wih, d["xpf"], None, 0, bias, S * nrb, 8 * H // 32, K, 0, 6, 0)
+            hip.call("split3_gemm", cur, wih, d["xpf"], None, 0, bias, S * nrb, 8 * H // 32, K, 0, 6, wm)
         o_p, out_p = d["O"][layer].data_ptr(), d["out"].data_ptr()
         win = lambda tt, dd: o_p + 2 * ((tt * nrb * S2 + dd * (H // 16)) * 3 * 512)
         ho = lambda tt, dd: out_p + 4 * (tt * 2 * H + dd * H) if layer == 1 else None
@@ -58,9 +58,9 @@ def aggressor(kind):
     with torch.no_grad(), blocks.two_chains(False):
         if kind == "step16":
             step16_stack()
-        elif kind == "s3gemm":
+        elif kind in ("s3gemm", "s3gemm4", "s3gemm10"):      # the library's choice (r06: the 320 x 256 LDS-DMA kernel) / 256 x 128 / 320 x 256
             for _ in range(3):
-                step16_stack(steps=False)
+                step16_stack(steps=False, wm={"s3gemm": 0, "s3gemm4": 4, "s3gemm10": 10}[kind])
         elif kind == "s3steps":
             step16_stack(gemm=False)
         elif kind == "step32":

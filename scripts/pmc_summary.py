@@ -20,7 +20,7 @@ KERNELS = {"lstm_step_dma_kernel<32>": ("bench", "step"), "lstm_step_dma_kernel<
            "lstm_seq_xcd_kernel": ("bench",),
            # r05: the split3 mode's kernels (passes with MMEGO_IMU_PRECISION=split3: "split3"), the PointNet forward layer, LocalVoxelNet's
            # kernels, the paired BiLSTM(64) launches
-           "s3_gemm_kernel": ("split3",), "s3_step_kernel": ("split3",), "s3_cvt_kernel": ("split3",), "s3_fc_relu_kernel": ("split3",),
+           "s3_gemm_kernel": ("split3",), "s3_gemm_big_kernel": ("split3",), "s3_step_kernel": ("split3",), "s3_cvt_kernel": ("split3",), "s3_fc_relu_kernel": ("split3",),
            "mlp_fwd_layer_kernel": ("bench", "wlocal"), "vox_l1_fwd_kernel": ("wlocal",), "vox_l1_bwd_kernel": ("wlocal",),
            "vox_dw_kernel": ("wlocal",), "vox_mid_fwd_kernel": ("wlocal",), "vox_mid_bwd_kernel": ("wlocal",),
            "lstm64_fwd_multi_kernel": ("wlocal",), "lstm64_bwd_multi_kernel": ("wlocal",)}
