@@ -199,7 +199,8 @@ def pmc_traffic(kernel_label):
     around THIS program (`bench.py --trace-only --no-graph`, scripts/collect_profiles.sh), the r02 / r01 files around the
     micro-benchmarks scripts/bench_gemm_pair.py / bench_lstm_step.py."""
     key = kernel_label.split(" ")[0]
-    for name, what in (("r05_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself (scripts/collect_r05.sh)"),
+    for name, what in (("r06_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself (scripts/collect_r06.sh)"),
+                       ("r05_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself (scripts/collect_r05.sh)"),
                        ("r04_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself (scripts/collect_r04.sh)"),
                        ("r03_pmc_counters.json", "rocprofv3 --pmc passes of `bench.py --trace-only --no-graph` itself"),
                        ("r02_pmc_counters.json", "rocprofv3 --pmc passes of the micro-benchmarks scripts/bench_gemm_pair.py / bench_lstm_step.py"),
@@ -702,7 +703,7 @@ def split3_figures(device, imu, imu_in, out, with_parity=True):
     gem = [(ms_, 2.0 * 32 * a[6] * 32 * a[7] * a[8]) for ms_, a in rec["split3_gemm"]]            # args: A, W, Cf, C, ldc, bias, Mrb, Nrb, K
     stp = [(ms_, 0.0 if a[3] else 2.0 * a[0] * a[1] * 4 * a[2] * a[2]) for ms_, a in rec["split3_step"]]   # args: ndir, Bn, H, first
     fam = {}
-    for name, v in (("s3_gemm_kernel (rnn_fast input projections, both directions: 10240 x 4096 x {512, 1024})", gem),
+    for name, v in (("s3_gemm_big_kernel (rnn_fast input projections, both directions: 10240 x 4096 x {512, 1024}; 320 x 256 tiles, LDS-DMA)", gem),
                     ("s3_step_kernel (rnn_fast recurrent steps, both directions per launch: 2 x 512 x 2048 x 512)", stp)):
         if not v:
             continue
