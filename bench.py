@@ -1169,7 +1169,14 @@ def main():
         if seqx:
             cands["lstm_seq_xcd_kernel (IMU_Net rnn_slow: a layer's whole recurrence per launch, 2 dirs x 64 rows x 2048 gates x K=512 x "
                   "(T-1) steps, weights stationary)"] = seqx
-        if g128:
+        def is_tile_big(a):      # gemm_tile.hip's dispatch: whole rounds of 320 x 256 tiles (r06); MMEGO_GEMM_BIG=0 keeps the 128 x 128 walk
+            return (os.environ.get("MMEGO_GEMM_BIG", "1") != "0" and is_nt_aligned(a) and a[10] % 320 == 0 and a[11] % 256 == 0
+                    and ((a[10] // 320) * (a[11] // 256) * a[13]) % 256 == 0 and not a[17])
+        gbig = [(ms_, fl) for (ms_, fl), (_, a) in zip(g128, [r_ for r_ in rec["gemm"] if is_tile128(r_[1])]) if is_tile_big(a)]
+        if gbig and len(gbig) == len(g128):
+            cands["gemm_tile_big_kernel (320x256 tiles, operands by LDS-DMA, one workgroup per CU; IMU_Net LSTM input projections, both directions per launch: "
+                  "2 x 10240 x 2048 x {512,1024} = 512 tiles = two rounds)"] = g128
+        elif g128:
             cands["gemm_tile_persistent_kernel (128x128 tiles; IMU_Net LSTM input projections, both directions per launch: 2 x 10240 x 2048 x {512,1024})"] = g128
         if g64:
             cands["gemm_tile_kernel<64,64> (smaller 64-aligned products)"] = g64

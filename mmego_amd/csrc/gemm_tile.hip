@@ -208,6 +208,127 @@ __global__ __launch_bounds__(256) void gemm_tile_persistent_kernel(TileP p, int 
     }
 }
 
+// ---- 320 x 256 tiles, operands by LDS-DMA (r06) --------------------------------------------------------------------------------------
+// For the products whose output is exactly a whole number of rounds of such tiles on the 256 CUs -- the BiLSTM(512) input projections
+// of IMU_Net, both directions batched: 10 240 x 2048 x {512, 1024} x 2 = 32 x 8 x 2 = 512 tiles = TWO rounds (the 128 x 128 walk above
+// needs five rounds of 512 workgroups, and what it loses against the matrix pipe is not its main loop -- 0.94-0.96 of MFMA issue -- but
+// the prologue / epilogue / unequal finish of every tile: ~120 us per launch whatever K).  One 512-thread workgroup per CU, waves 2 (M) x
+// 4 (N), wave tile 160 x 64 = 5 x 2 tiles of v_mfma_f32_32x32x2_f32 (160 accumulator registers: a wave has 256).
+//   Operands (NT form only: A[m][k], W[n][k], both k-contiguous): a 32-k chunk of the tile is (320 + 256) rows x 128 B = 72 KB; it goes
+//   global -> LDS by LDS-DMA (global_load_lds_dwordx4, 72 1-KB transfers per chunk, 9 per wave, no staging registers) into a ring of TWO
+//   stages (144 KB).  LDS rows are the UNPADDED 128-byte rows of the chunk; 16-byte piece q of row r sits at piece q ^ ((r >> 1) & 7), so
+//   that the 16 lanes of every ds_read_b128 phase of the MFMA's operand fetch (lane l: row l % 32, k pieces 2 kb + l / 32) hit 16 distinct
+//   bank quads -- the swizzle of lstm_step.hip, applied by the transfer's per-lane SOURCE address (a transfer writes lane l's 16 bytes
+//   to LDS base + 16 l: rows r0 .. r0 + 7, piece position l % 8).  Same k permutation as the kernel above (lane half h supplies
+//   k = 8 kb + 4 h + s at MFMA step s, both operands alike).
+//   Schedule: ONE barrier per 32-k chunk (20 480 cycles of MFMA issue per SIMD), placed behind the chunk's last fragment read; the wave
+//   then requests chunk kt + 2 into the stage it has just finished with and goes on with the last k block's MFMAs.
+//   Epilogue: bias added in the accumulators, row-major stores of 128 contiguous bytes per half wave.
+struct TileBigArgs {
+  int tiles_m, tiles_n;       // 320-row panels, 256-column tiles per batch entry
+};
+
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void gemm_tile_big_kernel(TileP p, TileBigArgs g) {
+  constexpr int BM = 320, BN = 256, KCH = 32, ROWS = BM + BN, NDMA = ROWS / 8, STAGE = ROWS * KCH;   // floats per stage
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  int tm, tn, batch;
+  {
+    const int per_batch = g.tiles_m * g.tiles_n, n = (int)gridDim.x;
+    if ((n & 63) == 0 && (g.tiles_m & 3) == 0 && (g.tiles_n & 7) == 0) {
+      // XCD x (blocks x, x + 8, ...) walks blocks of 4 row panels x 8 column tiles: its A panels stay in its L2 for a round
+      const int x = blockIdx.x & 7, l = blockIdx.x >> 3, rounds = (n >> 3) >> 5;
+      const int blk = x * rounds + (l >> 5), within = l & 31;
+      const int nb_n = g.tiles_n >> 3, nb = (g.tiles_m >> 2) * nb_n;
+      batch = blk / nb;
+      const int rem = blk - batch * nb;
+      tm = (rem / nb_n) * 4 + (within & 3);
+      tn = (rem % nb_n) * 8 + (within >> 2);
+    } else {
+      batch = blockIdx.x / per_batch;
+      const int id = blockIdx.x - batch * per_batch;
+      tm = id / g.tiles_n;
+      tn = id - tm * g.tiles_n;
+    }
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const float* Ab = p.A + (long)batch * p.sAb + (long)m0 * p.lda;
+  const float* Wb = p.W + (long)batch * p.sWb + (long)n0 * p.ldw;
+  // this wave's transfers: row groups i = w + 8 j (8 rows each) of a stage, j < 9; group i < 40: A rows 8 i .. 8 i + 7, else W rows.
+  // lane l: row 8 i + l / 8, LDS piece position l % 8 <- source piece (l % 8) ^ ((row >> 1) & 7)
+  const float* gp[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int i = w + 8 * j;
+    const bool isw = i >= BM / 8;
+    const int row = (isw ? i - BM / 8 : i) * 8 + (lane >> 3);
+    const int piece = (lane & 7) ^ ((row >> 1) & 7);
+    gp[j] = (isw ? Wb + (long)row * p.ldw : Ab + (long)row * p.lda) + 4 * piece;
+  }
+#define GTB_DMA(kt, stage)                                                                                                  \
+  {                                                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 9; ++j)                                                                           \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[j] + (long)(kt) * KCH),            \
+                                       (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + (w + 8 * j) * 8 * KCH), 16, 0, 0); \
+  }
+  const int nk = p.K / KCH;
+  const int r = lane & 31, h = lane >> 5, key = (r >> 1) & 7;
+  // fragment addresses: row (base + r) of the stage, piece (2 kb + h) ^ key -- the row bases are multiples of 32, so the key is the lane's
+  int off[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) off[kb] = r * KCH + 4 * ((2 * kb + h) ^ key);
+  f32x16 acc[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+  GTB_DMA(0, 0)
+  if (nk > 1) GTB_DMA(1, 1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* As = smem + (kt & 1) * STAGE + wm * 160 * KCH;
+    const float* Bs = smem + (kt & 1) * STAGE + (BM + wn * 64) * KCH;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      f32x4 a[5], b[2];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * KCH + off[kb]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * KCH + off[kb]);
+      if (kb == 3) {
+        // the stage's last fragments are requested: wait for them and for this wave's transfers of chunk kt + 1, meet the others, and
+        // hand the stage back (chunk kt + 2)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) GTB_DMA(kt + 2, kt & 1)
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][c], b[j][c], acc[i][j], 0, 0, 0);
+    }
+  }
+#undef GTB_DMA
+  float* C = p.C + (long)batch * p.sCb;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + r;
+    const float bv = p.bias ? p.bias[(long)batch * p.sBiasb + col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      float* cp = C + (long)(m0 + wm * 160 + i * 32 + 4 * h) * p.ldc + col;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) cp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldc] = acc[i][j][reg] + bv;
+    }
+  }
+}
+
 namespace mmego_detail {
 
 // k per staged chunk: 32 (measured at least as fast as 64 for the persistent kernel -- 207.8 / 348.9 us against 210.5 / 353.1 us on the
@@ -240,6 +361,28 @@ static int launch_layout(hipStream_t st, const TileP& p) {
   // projections at 93-109 TFLOP/s, 64x64 at 88-97), else 64x64 (e.g. M = 512: 23.6 us vs 84 us with 64 big tiles).
   // A 160x128 tile (1024 tiles = exactly 2 waves of 512 for those projections) was measured 3-4 % SLOWER (1x4 wave
   // layout: 6 operand reads per 5 MFMAs), so it is not in the list.
+  if (A_KC && B_KC) {
+    // 320 x 256 tiles by LDS-DMA where the output is whole rounds of them (MMEGO_GEMM_BIG=0: the 128 x 128 walk, for A/B runs)
+    static const bool big = !(getenv("MMEGO_GEMM_BIG") && atoi(getenv("MMEGO_GEMM_BIG")) == 0);
+    const long tiles = (long)(p.M / 320) * (p.N / 256) * p.nbatch;
+    if (big && (p.M % 320) == 0 && (p.N % 256) == 0 && (p.K % 32) == 0 && p.K >= 64 && p.nsplit == 1 && !p.relu && !p.accumulate &&
+        tiles >= 256 && (tiles % 256) == 0 && tiles < (1L << 30) && (p.lda % 4) == 0 && (p.ldw % 4) == 0 && (p.sAb % 4) == 0 && (p.sWb % 4) == 0 &&
+        ((((uintptr_t)p.A) | ((uintptr_t)p.W)) & 15) == 0) {
+      constexpr int lds = 2 * (320 + 256) * 32 * (int)sizeof(float);        // 144 KB
+      static bool attr_set[64] = {};
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+      if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+      }
+      TileBigArgs g = {p.M / 320, p.N / 256};
+      hipLaunchKernelGGL((gemm_tile_big_kernel<0>), dim3((unsigned)tiles), dim3(512), lds, st, p, g);
+      hipError_t e = hipGetLastError();
+      return e == hipSuccess ? 0 : (int)e;
+    }
+  }
   const long units128 = (long)(p.M / 128) * (p.N / 128) * p.nsplit * p.nbatch;
   const bool big_ok = (p.M % 128) == 0 && (p.N % 128) == 0 && units128 >= 192;
   if (big_ok) {

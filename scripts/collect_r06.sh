@@ -38,7 +38,7 @@ python3 "$root/scripts/pmc_summary.py" "$out" > "$out/pmc_counters.json"
 python3 - "$out" <<'PY'
 import glob, os, re, shutil, sys
 out = sys.argv[1]
-pat = re.compile("gemm_tile_persistent|lstm_step_dma_kernel|lstm_seq_xcd|tconv_seq|gcn_front|graph_dA_fused|mlp_bwd_layer|mlp_fwd_layer|local_group_l1|pool8|s3_gemm|s3_gemm_big|s3_step|s3_cvt|vox_")
+pat = re.compile("gemm_tile_big|gemm_tile_persistent|lstm_step_dma_kernel|lstm_seq_xcd|tconv_seq|gcn_front|graph_dA_fused|mlp_bwd_layer|mlp_fwd_layer|local_group_l1|pool8|s3_gemm|s3_gemm_big|s3_step|s3_cvt|vox_")
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
         continue

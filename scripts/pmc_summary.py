@@ -10,7 +10,7 @@ import sys
 root = sys.argv[1]
 # kernel-name prefix -> counter-pass directory stem.  From r03 the passes wrap bench.py itself ("bench"); the r02 layout (passes around
 # the micro-benchmarks: "step" / "gemm") is still understood.
-KERNELS = {"lstm_step_dma_kernel<32>": ("bench", "step"), "lstm_step_dma_kernel<16>": ("bench",), "lstm_step_small_kernel": ("bench",),
+KERNELS = {"gemm_tile_big_kernel": ("bench",), "lstm_step_dma_kernel<32>": ("bench", "step"), "lstm_step_dma_kernel<16>": ("bench",), "lstm_step_small_kernel": ("bench",),
            "gemm_tile_persistent_kernel": ("bench", "gemm"), "lstm_step_dma_kernel": ("step",),
            # r04: the fused ST-GCN step's kernels and the train-mode PointNet backward layer (the dominant kernel of the UpperNetwlocal step)
            "tconv_seq_kernel": ("bench",), "gcn_front_kernel": ("bench",), "tconv_wgrad_kernel": ("bench",), "graph_dA_fused_kernel": ("bench",),
