@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 rocpd database (--kernel-trace) of bench.py: per-kernel and per-(kernel, grid) time per step.
-usage: python scripts/prof_summary.py <results.db> [steps_divisor]   (default: launches of the persistent GEMM / 8)"""
+usage: python scripts/prof_summary.py <results.db> [steps_divisor]   (default: launches of the projection product / 4)"""
 import collections
 import re
 import sqlite3
@@ -8,7 +8,8 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, grid_x, grid_y, grid_z, workgroup_x, end-start from kernels order by start"))
 short = lambda n: re.sub(r"\(.*", "", n).replace("void ", "")
-nper = sum(1 for r in rows if "gemm_tile_persistent_kernel<true, true" in r[0]) / 4.0   # 4 batched input projections per U+L step
+# 4 batched input projections per U+L step, whichever kernel runs them (r06: gemm_tile_big / s3_gemm_big)
+nper = sum(1 for r in rows if any(t in r[0] for t in ("gemm_tile_persistent_kernel<true, true", "gemm_tile_big_kernel", "s3_gemm_big_kernel"))) / 4.0
 pos = [a for a in sys.argv[2:] if not a.startswith("--")]
 steps = float(pos[0]) if pos else (nper or 1.0)
 tot = sum(r[5] for r in rows)
