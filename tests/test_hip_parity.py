@@ -699,6 +699,29 @@ def _compare_training(tag, o, h, fwd_o, fwd_h, target, g, dev, later_grad_tol=2e
             assert torch.allclose(bh.cpu().float(), bo.float(), rtol=1e-3, atol=1e-4 * step), (tag, step, ko)
 
 
+def test_projection_product_on_320x256_tiles_is_the_128x128_walk_bit_for_bit(dev):
+    """gemm_tile_big_kernel (gemm_tile.hip, r06: 320 x 256 tiles, operands by LDS-DMA into a swizzled unpadded LDS image; what
+    mmego_gemm picks for IMU_Net's batched BiLSTM input projections, Net/IMU_Net.py:58-62) against the 128 x 128 persistent walk:
+    the same product with 128 extra rows (10 368 is not a multiple of 320, so the dispatch falls back) must give the first 10 240
+    rows BIT FOR BIT -- same k permutation, same accumulation order -- for both layers' K, and both agree with float64."""
+    from mmego_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, N = 10240, 2048
+    for K in (512, 1024):
+        A = torch.randn(M + 128, K, generator=g).to(dev)
+        W = (torch.randn(2 * N, K, generator=g) * 0.05).to(dev)
+        b = torch.randn(2 * N, generator=g).to(dev)
+        c_big = torch.full((M, 2 * N), float("nan"), device=dev)
+        c_walk = torch.full((M + 128, 2 * N), float("nan"), device=dev)
+        ops.linear_pair(A[:M], W[:N], W[N:], b[:N], b[N:], c_big, N)
+        ops.linear_pair(A, W[:N], W[N:], b[:N], b[N:], c_walk, N)
+        assert torch.isfinite(c_big).all()
+        assert torch.equal(c_big, c_walk[:M]), (K, float((c_big - c_walk[:M]).abs().max()))
+        rows = torch.tensor([0, 31, 32, 159, 160, 319, 320, 5119, 5120, 10239], device=dev)
+        ref = A[rows].double() @ W.double().t() + b.double()
+        assert float((c_big[rows].double() - ref).abs().max()) < 2e-5 * (K / 512) ** 0.5, K
+
+
 def test_train_upper(dev):
     from mmego_amd import nets
     g = golden("g6_train.npz")

@@ -228,6 +228,29 @@ def test_split3_bilstm_stack_against_the_fp32_step_kernels(dev, monkeypatch, Bn,
     assert blocks.seq_xcd_errors() == 0
 
 
+def test_split3_projection_on_320x256_tiles_is_the_256x128_kernel_bit_for_bit(dev):
+    """s3_gemm_big_kernel (split3.hip, r06: 320 x 256 tiles, LDS-DMA operands; mmego_split3_gemm's choice for rnn_fast's projections)
+    against s3_gemm_kernel<4, 2> (wm = 4) on the same pieces: tile-major and row-major outputs bit for bit, both K; a shape the
+    big tiles do not divide takes the old kernel either way."""
+    from mmego_amd import blocks, hip
+    g = torch.Generator().manual_seed(12)
+    for M, N, K in ((10240, 4096, 512), (10240, 4096, 1024), (640, 512, 256)):
+        A = torch.randn(M, K, generator=g).to(dev)
+        W = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        Ap, Wp = blocks.split3_cvt(A), blocks.split3_cvt(W)
+        out = {}
+        for wm in (4, 10, 0):
+            Cf, C = torch.full((M * N,), float("nan"), device=dev), torch.full((M, N), float("nan"), device=dev)
+            hip.call("split3_gemm", Ap, Wp, Cf, C, N, bias, M // 32, N // 32, K, M, 6, wm)
+            out[wm] = (Cf, C)
+        assert torch.isfinite(out[10][1]).all()
+        for wm in (10, 0):
+            assert torch.equal(out[wm][0], out[4][0]) and torch.equal(out[wm][1], out[4][1]), (M, N, K, wm)
+        ref = A[:64].double() @ W.double().t() + bias.double()
+        assert float((out[10][1][:64].double() - ref).abs().max()) < 3e-5 * (K / 512) ** 0.5
+
+
 def test_imu_forward_split3_at_the_fp32_bars(dev):
     """tests/test_hip_parity.py::test_imu_forward with IMUNet.precision = "split3": the reference's golden G7 (seeded IMUNet(15, 9, 512,
     2), R and t within 2e-5) and the CPU oracle at 64, 128 and 200 rnn_fast rows; switching back restores the fp32 path bit for bit."""
