@@ -268,8 +268,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tile_big_kernel(TileP p, TileBigA
     const int piece = (lane & 7) ^ ((row >> 1) & 7);
     gp[j] = (isw ? Wb + (long)row * p.ldw : Ab + (long)row * p.lda) + 4 * piece;
   }
+#ifndef GTB_EXP
+#define GTB_EXP 0            // probe builds (scripts/bench_gemm_big.py): 1 = no transfers behind the first two chunks, 2 = no LDS reads, 4 = no C stores
+#endif
 #define GTB_DMA(kt, stage)                                                                                                  \
-  {                                                                                                                         \
+  if (!((GTB_EXP & 1) && (kt) > 1)) {                                                                                       \
     _Pragma("unroll") for (int j = 0; j < 9; ++j)                                                                           \
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[j] + (long)(kt) * KCH),            \
                                        (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + (w + 8 * j) * 8 * KCH), 16, 0, 0); \
@@ -289,16 +292,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tile_big_kernel(TileP p, TileBigA
   if (nk > 1) GTB_DMA(1, 1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  f32x4 a[5], b[2];
   for (int kt = 0; kt < nk; ++kt) {
     const float* As = smem + (kt & 1) * STAGE + wm * 160 * KCH;
     const float* Bs = smem + (kt & 1) * STAGE + (BM + wn * 64) * KCH;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      f32x4 a[5], b[2];
+      if (!(GTB_EXP & 2) || (kt == 0 && kb == 0)) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * KCH + off[kb]);
+        for (int i = 0; i < 5; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * KCH + off[kb]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * KCH + off[kb]);
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * KCH + off[kb]);
+      }
       if (kb == 3) {
         // the stage's last fragments are requested: wait for them and for this wave's transfers of chunk kt + 1, meet the others, and
         // hand the stage back (chunk kt + 2)
@@ -324,7 +329,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tile_big_kernel(TileP p, TileBigA
     for (int i = 0; i < 5; ++i) {
       float* cp = C + (long)(m0 + wm * 160 + i * 32 + 4 * h) * p.ldc + col;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) cp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldc] = acc[i][j][reg] + bv;
+      for (int reg = 0; reg < 16; ++reg)
+        if (!(GTB_EXP & 4) || acc[i][j][reg] == 12345.f) cp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldc] = acc[i][j][reg] + bv;
     }
   }
 }
@@ -368,10 +374,10 @@ static int launch_layout(hipStream_t st, const TileP& p) {
     if (big && (p.M % 320) == 0 && (p.N % 256) == 0 && (p.K % 32) == 0 && p.K >= 64 && p.nsplit == 1 && !p.relu && !p.accumulate &&
         tiles >= 256 && (tiles % 256) == 0 && tiles < (1L << 30) && (p.lda % 4) == 0 && (p.ldw % 4) == 0 && (p.sAb % 4) == 0 && (p.sWb % 4) == 0 &&
         ((((uintptr_t)p.A) | ((uintptr_t)p.W)) & 15) == 0) {
-      constexpr int lds = 2 * (320 + 256) * 32 * (int)sizeof(float);        // 144 KB
-      static bool attr_set[64] = {};
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+      constexpr int lds = 2 * (320 + 256) * 32 * (int)sizeof(float);        // 144 KB
+      static bool attr_set[64] = {};
       if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
