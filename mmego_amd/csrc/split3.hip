@@ -449,11 +449,12 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
 }
 
 // ---- the same product on 320 x 256 tiles, operands by LDS-DMA (r06) ---------------------------------------------------------------
-// Why: the kernel above is bound by what a CU can pull from L2, not by the matrix pipe.  A 256 x 128 tile needs (256 + 128) x 32 k x 6 B =
-// 74 KB per 32-k chunk for 6144 cycles of MFMA issue on its SIMDs (two workgroups per CU): 24 B / clk / CU, against the ~20 B / clk / CU
-// this chip delivers from L2 on any path (NOTES.md) -- PMC: MFMA busy 0.63, 3.0 TB/s of L2 misses, 3.9 x the algorithmic bytes.  Arithmetic
-// intensity is M N / (M + N) per tile: 85 for 256 x 128, **142 for 320 x 256** (14 B / clk / CU), and 10 240 x 4096 is exactly 32 x 16 = 512
-// such tiles = TWO full rounds of the 256 CUs (1280 tiles on 512 slots were 2.5).
+// Why: the kernel above needs (256 + 128) x 32 k x 6 B = 74 KB per 32-k chunk for 6144 cycles of MFMA issue on its SIMDs (two workgroups per
+// CU) = 24 B / clk / CU of operand traffic through two barriers per chunk and a register-staged copy -- PMC: MFMA busy 0.63, 3.0 TB/s of L2
+// misses, 3.9 x the algorithmic bytes.  (r05 read that as "bound by what a CU can pull from L2"; profiles/r06_l2_delivery.txt measures 52-93
+// B / clk / CU for a pure stream, so it was the kernel's structure, not the path.)  Arithmetic intensity is M N / (M + N) per tile: 85 for
+// 256 x 128, **142 for 320 x 256** (14 B / clk / CU), and 10 240 x 4096 is exactly 32 x 16 = 512 such tiles = TWO full rounds of the 256 CUs
+// (1280 tiles on 512 slots were 2.5).
 //   Workgroup = one tile, 512 threads, ONE per CU (256 VGPRs per wave): waves 2 (M) x 4 (N), wave tile 160 x 64 = 5 x 2 MFMA tiles
 //   (160 accumulator registers); per 16-k step a wave reads 2 x 3 W fragments once and 5 x 3 A fragments (lane-linear ds_read_b128)
 //   for 60 (90) MFMAs.
