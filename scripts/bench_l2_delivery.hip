@@ -13,10 +13,12 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int PATH>
-__global__ __launch_bounds__(1024) void stream_kernel(const f4* __restrict__ buf, long nvec, int reps, float* sink, unsigned long long* stamps) {
+__global__ __launch_bounds__(1024) void stream_kernel(const f4* __restrict__ buf, long nvec, int reps, float* sink, unsigned long long* stamps, int priv) {
   extern __shared__ __attribute__((aligned(16))) f4 lds[];
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, w = tid >> 6;
-  const f4* region = buf + (long)(blockIdx.x & 7) * nvec;
+  // priv = 0: the 32 workgroups of an XCD stream the SAME region (operand sharing, as the tiles of a product do); 1: every workgroup its
+  // own region (distinct lines per CU: what the L2 can deliver to 32 CUs at once)
+  const f4* region = buf + (long)(priv ? blockIdx.x : (blockIdx.x & 7)) * nvec;
   unsigned long long t0 = 0, r0 = 0;
   if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -55,17 +57,18 @@ int main() {
   if (hipMalloc(&buf, max_bytes) != hipSuccess || hipMalloc(&sink, 256 * 1024 * 4) != hipSuccess || hipMalloc(&stamps, 512 * 8) != hipSuccess) return 1;
   hipMemset(buf, 0x3c, max_bytes);
   hipFuncSetAttribute((const void*)stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  printf("path                      waves/CU  region/XCD   GB/s per CU   shader clock   B/clk/CU   aggregate TB/s\n");
+  printf("region   path                      waves/CU  region size  GB/s per CU   shader clock   B/clk/CU   aggregate TB/s\n");
+  for (int priv = 0; priv < 2; ++priv)
   for (int path = 0; path < 2; ++path)
-    for (long kb : {2048L, 65536L})
+    for (long kb : (priv ? std::vector<long>{128L, 2048L} : std::vector<long>{2048L, 65536L}))
       for (int waves : {4, 8, 16}) {
         const int nthr = waves * 64;
         const long nvec = kb * 1024 / 16;
-        const int reps = kb == 2048 ? 40 : 2;
+        const int reps = kb == 128 ? 600 : (kb == 2048 ? 40 : 2);
         const size_t lds = path ? (size_t)waves * 8 * 1024 : 0;
         for (int it = 0; it < 2; ++it) {                 // (first pass warms the L2s)
-          if (path == 0) stream_kernel<0><<<256, nthr, 0, 0>>>(buf, nvec, reps, sink, stamps);
-          else stream_kernel<1><<<256, nthr, lds, 0>>>(buf, nvec, reps, sink, stamps);
+          if (path == 0) stream_kernel<0><<<256, nthr, 0, 0>>>(buf, nvec, reps, sink, stamps, priv);
+          else stream_kernel<1><<<256, nthr, lds, 0>>>(buf, nvec, reps, sink, stamps, priv);
           if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 2; }
         }
         std::vector<unsigned long long> h(512);
@@ -76,7 +79,7 @@ int main() {
         const long per_round = (long)nthr * 8;
         const double bytes = (double)reps * (double)(nvec / per_round * per_round) * 16.0;
         const double sec = rt / 1e8, ghz = cyc / rt / 10.0;
-        printf("%-25s %5d     %6ld KB   %9.1f     %6.2f GHz   %7.1f    %8.2f\n", path ? "global_load_lds_dwordx4" : "global_load_dwordx4", waves, kb,
+        printf("%-8s %-25s %5d     %6ld KB   %9.1f     %6.2f GHz   %7.1f    %8.2f\n", priv ? "own" : "shared", path ? "global_load_lds_dwordx4" : "global_load_dwordx4", waves, kb,
                bytes / sec / 1e9, ghz, bytes / cyc, bytes * 256 / sec / 1e12);
       }
   return 0;
