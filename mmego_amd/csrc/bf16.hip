@@ -922,24 +922,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 / WR, 4 /
 // costs 82 us per launch that do not hide under the product loops (60 us of stores at 5-6 TB/s, 18 us of cell arithmetic); PMC:
 // 536 MB fetched per launch against 857 MB for the 128-row kernel, MFMA busy 0.33 at 2.23 GHz against 0.43 at 1.82 GHz -- the
 // chip gives clock back as the loop gets denser, so the two kernels deliver nearly the same MFMA rate.
+// r06 probes of this kernel (git d15b147, logs in profiles/r06_fused256_probes/; none kept): tile walks that leave an XCD 1 / 2 / 4 unit
+// blocks so that its weights stay L2-resident -- 344-361 / 453-478 us against 347-349 / 456 (nothing); every tile reading the SAME
+// activation rows (all L2 hits) -- 316 / 410 us (-10 %: what misses cost); a four-wave form with 128 x 128 wave tiles (8 instead of 12
+// fragment reads per 16 MFMAs, one wave per SIMD, requests fired between the last MFMAs of a chunk; bit-identical) -- the SAME 100 us per
+// 512 of K and 30 us more per launch in the cell update: the loop is not bound by LDS traffic either; every second workgroup started
+// 7-27 us late so that store bursts meet product loops -- slower by about a third of the delay.  What the numbers say together: the loop
+// runs at ~0.7 of the MFMA rate the clock under this load allows, and 130 us of a 335-us launch are the eight cell updates.
 #define GLDS16B(gptr, lptr)                                                                                 \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-// probe (MMEGO_F256_SKEW = n > 0): every second workgroup of an XCD starts n x 3.4 us late, so that the cell updates (store bursts at the
-// HBM write rate) of one half of the CUs fall into the product loops of the other half
-#define F256_SKEW(n)                                                       \
-  do {                                                                     \
-    if ((blockIdx.x >> 3) & 1)                                             \
-      for (int sk = 0; sk < (n); ++sk) __builtin_amdgcn_s_sleep(127);      \
-  } while (0)
-
 template <bool HOUT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_bf16_fused256_kernel(FusedStepP p, int ntiles, int skew) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_bf16_fused256_kernel(FusedStepP p, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
   constexpr int STAGE = 64 * 1024;
   const int tid = threadIdx.x, lane = tid & 63;
-  F256_SKEW(skew);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the piece addresses below are scalar arithmetic
   const int rg = w >> 1, cg = w & 1;
   const int H = p.o.H;
@@ -953,20 +951,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // at the same pace: an activation chunk is fetched into that L2 once for its 8 readers, a weight chunk once for 4)
   const bool xcd_walk = G == 256 && ntiles % 256 == 0;
   const int niter = (ntiles + G - 1) / G;
-#ifndef MMEGO_F256_WALK
-#define MMEGO_F256_WALK 8
-#endif
-  auto tile_of = [&](int it) {
-    if (!xcd_walk) return (int)blockIdx.x + it * G;
-    const int x = (int)(blockIdx.x & 7), i = (int)(blockIdx.x >> 3);
-    if (MMEGO_F256_WALK == 8 || njb != 8) return x * (ntiles >> 3) + it * 32 + i;
-    const int nrb = nb / njb;                   // row blocks of 256 (a multiple of 16 here)
-    int d, jb, rbw;
-    if (MMEGO_F256_WALK == 4) { d = x >> 2; jb = ((x >> 1) & 1) * 4 + (i & 3); rbw = (x & 1) * (nrb >> 1) + it * 8 + (i >> 2); }
-    else if (MMEGO_F256_WALK == 2) { d = x >> 2; jb = (x & 3) * 2 + (i & 1); rbw = it * 16 + (i >> 1); }
-    else { jb = x; d = i & 1; rbw = it * 16 + (i >> 1); }
-    return d * nb + rbw * njb + jb;
-  };
+  auto tile_of = [&](int it) { return xcd_walk ? (int)(blockIdx.x & 7) * (ntiles >> 3) + it * 32 + (int)(blockIdx.x >> 3) : (int)blockIdx.x + it * G; };
 
   // this wave's 8 pieces of a chunk: waves 0..3 carry the activation pieces, waves 4..7 the weight pieces
   const int q0 = w * 8;
@@ -978,11 +963,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w[seg][d]);
     unsigned char* st = smem256 + stage * STAGE;
     // piece q0 + i: consecutive pieces of a wave differ by one step (1 KB) inside a row block / gate, by S KB between them
-#ifdef MMEGO_F256_EXP_SAMEROWS     // probe builds only: every tile reads row block 0's activations (all L2 hits)
-    const long blk0 = q0 < 32 ? (long)(0 * 8 + (q0 >> 2)) : (long)((jb * 2 + ((q0 - 32) >> 4)) * 4 + (((q0 - 32) >> 2) & 3));
-#else
     const long blk0 = q0 < 32 ? (long)(rbw * 8 + (q0 >> 2)) : (long)((jb * 2 + ((q0 - 32) >> 4)) * 4 + (((q0 - 32) >> 2) & 3));
-#endif
     const unsigned char* g0 = (q0 < 32 ? ab : wb) + ((blk0 * S + s0) << 10) + lane * 16;
     const long blk_stride = (long)S << 10;
 #pragma unroll
@@ -1134,232 +1115,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef F256_BARRIER
 }
 
-// ---- the same 256 x 256 tile on FOUR waves (r06): wave tile 128 rows x 32 units x 4 gates = 4 x 4 accumulator tiles ---------------
-// Why: the eight-wave kernel above reads 6 fragments (6 KB) from LDS per 8 MFMAs and wave; with the LDS-DMA writes of the next chunk
-// that is 256 KB of LDS traffic per 64-k chunk against 2048 cycles of MFMA issue -- 125 B / clk of the array's 128: the loop was bound by
-// the LDS array, not by what arrives from memory (probe: every tile reading the SAME activation rows, all of them L2 hits, still took
-// 316 / 410 us against 349 / 456; tile walks that keep the weights of an XCD resident changed nothing).  A 128 x 128 wave tile reads
-// 8 fragments per 16 MFMAs: 192 KB per chunk, 94 B / clk.  The price is one wave per SIMD (256 accumulator registers, in AGPRs), so
-// nothing hides a wave's own LDS latency but its own schedule: the hand-over to the next chunk (wait for its pieces, barrier, request
-// the chunk after it, read its first fragments) sits BEFORE the last MFMA group of the current chunk instead of after it.
-template <bool HOUT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_step_bf16_fused256w4_kernel(FusedStepP p, int ntiles, int skew) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem256[];
-  constexpr int STAGE = 64 * 1024;
-  const int tid = threadIdx.x, lane = tid & 63;
-  F256_SKEW(skew);
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rg = w >> 1, cg = w & 1;                      // 2 row groups of 128 rows x 2 unit groups of 32 units
-  const int H = p.o.H;
-  const int njb = H >> 6, nb = ntiles >> 1;
-  const int G = (int)gridDim.x;
-  const int S0 = p.S[0], S1 = p.nseg > 1 ? p.S[1] : 0, S2 = p.nseg > 2 ? p.S[2] : 0;
-  const int NC = (S0 + S1 + S2) >> 2;
-  const bool first = p.o.first != 0;
-  const bool xcd_walk = G == 256 && ntiles % 256 == 0;
-  const int niter = (ntiles + G - 1) / G;
-  auto tile_of = [&](int it) { return xcd_walk ? (int)(blockIdx.x & 7) * (ntiles >> 3) + it * 32 + (int)(blockIdx.x >> 3) : (int)blockIdx.x + it * G; };
-
-  // this wave's 16 pieces of an item: of an operand chunk waves 0, 1 carry the activation pieces (q < 32), waves 2, 3 the weight
-  // pieces; of a c tile [256 rows][64 units] fp32 every wave 16 pieces of 4 rows (lane l: row 4 piece + l / 16, 16 B at column
-  // 4 (l % 16)).  A request is prepared (its addresses: scalar work with kernel-argument loads) while MFMAs run and fired later:
-  // transfer i reads base + (i >> 2) * sa + (i & 3) * sb and lands at piece q0 + i of the stage.
-  const int q0 = w * 16;
-  struct Req { const unsigned char* base; long sa, sb; };
-  // this wave's operand of every segment and direction (activations for waves 0, 1, weights for waves 2, 3), read from the kernel
-  // arguments ONCE: a dynamically indexed p.a[seg][d] inside the loop is a scalar load and a wait that nothing hides at one wave per SIMD
-#define W4_OB(sg, dd) reinterpret_cast<const unsigned char*>(q0 < 32 ? (const void*)p.a[sg][dd] : (const void*)p.w[sg][dd])
-  const unsigned char *const ob00 = W4_OB(0, 0), *const ob01 = W4_OB(0, 1), *const ob10 = W4_OB(1, 0), *const ob11 = W4_OB(1, 1),
-                      *const ob20 = W4_OB(2, 0), *const ob21 = W4_OB(2, 1);
-#undef W4_OB
-  const Req idle{reinterpret_cast<const unsigned char*>(p.w[0][0]) + lane * 16, 0, 0};
-  // a tile's decode (one integer division) and its segment bases are computed once per tile; per chunk only a select and an add remain
-  struct TileAt { const unsigned char* sb0; const unsigned char* sb1; const unsigned char* sb2; const unsigned char* cb; };
-  auto tile_at = [&](int tile) {
-    const int d = tile >= nb, rem = tile - d * nb, jb = rem % njb, rbw = rem / njb;
-    const long blk0 = q0 < 32 ? (long)(rbw * 8 + (q0 >> 2)) : (long)((jb * 2 + ((q0 - 32) >> 4)) * 4 + (((q0 - 32) >> 2) & 3));
-    const float* cb = p.o.c[d] + ((long)rbw * 256 + (lane >> 4) + q0 * 4) * H + jb * 64 + (lane & 15) * 4;
-    return TileAt{(d ? ob01 : ob00) + ((blk0 * S0) << 10), (d ? ob11 : ob10) + ((blk0 * S1) << 10), (d ? ob21 : ob20) + ((blk0 * S2) << 10),
-                  reinterpret_cast<const unsigned char*>(cb)};
-  };
-  auto prep = [&](const TileAt& t, int g) {
-    const int s0 = g * 4;
-    if (s0 < S0) return Req{t.sb0 + ((long)s0 << 10) + lane * 16, (long)S0 << 10, 1024};
-    if (s0 < S0 + S1) return Req{t.sb1 + ((long)(s0 - S0) << 10) + lane * 16, (long)S1 << 10, 1024};
-    return Req{t.sb2 + ((long)(s0 - S0 - S1) << 10) + lane * 16, (long)S2 << 10, 1024};
-  };
-  auto prep_c = [&](const TileAt& t) { return Req{t.cb, (long)H * 64, (long)H * 16}; };
-#define W4_FIRE1(r, stage, i) GLDS16B((r).base + ((i) >> 2) * (r).sa + ((i) & 3) * (r).sb, smem256 + (stage) * STAGE + ((q0 + (i)) << 10))
-  auto fire = [&](const Req& r, int stage) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) W4_FIRE1(r, stage, i);
-  };
-
-  const int fr = lane & 31, fh = lane >> 5;
-  constexpr int EPI_MI = 4, EPI_PIECES = 8;
-  constexpr int EPI_YOUNGER = EPI_MI * 16 * (HOUT ? 2 : 1) + EPI_PIECES;
-  constexpr int EPI_WAIT = EPI_YOUNGER < 63 ? EPI_YOUNGER : 63;
-  u32x4 fa[2][4], fb[2][4];
-#define W4_RD(buf, st, step)                                                                                                \
-  do {                                                                                                                      \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                        \
-      fa[buf][mi] = *reinterpret_cast<const u32x4*>((st) + ((((4 * rg + mi) << 2) + (step)) << 10) + lane * 16);            \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                           \
-      fb[buf][n] = *reinterpret_cast<const u32x4*>((st) + ((32 + ((cg * 4 + n) << 2) + (step)) << 10) + lane * 16);         \
-  } while (0)
-#define W4_MM(buf)                                                                                                          \
-  do {                                                                                                                      \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                        \
-      _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                         \
-        acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][mi]),                       \
-                                                             __builtin_bit_cast(bf16x8, fb[buf][n]), acc[mi][n], 0, 0, 0);  \
-  } while (0)
-#define W4_MM_ROWS(buf, m0, m1)                                                                                             \
-  do {                                                                                                                      \
-    _Pragma("unroll") for (int mi = m0; mi < m1; ++mi)                                                                      \
-      _Pragma("unroll") for (int n = 0; n < 4; ++n)                                                                         \
-        acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][mi]),                       \
-                                                             __builtin_bit_cast(bf16x8, fb[buf][n]), acc[mi][n], 0, 0, 0);  \
-  } while (0)
-#define W4_BARRIER()                         \
-  do {                                       \
-    asm volatile("" ::: "memory");           \
-    __builtin_amdgcn_s_barrier();            \
-    asm volatile("" ::: "memory");           \
-  } while (0)
-#define W4_SB() __builtin_amdgcn_sched_barrier(0)
-#define W4_USE(buf)                                                                                                         \
-  asm volatile("" ::"v"(fa[buf][0]), "v"(fa[buf][1]), "v"(fa[buf][2]), "v"(fa[buf][3]), "v"(fb[buf][0]), "v"(fb[buf][1]),  \
-               "v"(fb[buf][2]), "v"(fb[buf][3]))
-
-  // the ring: items follow one another in the two stages alternately -- chunk 0 .. NC - 1 of a tile, its c tile, chunk 0 of the next
-  // tile ...  Invariant at the top of a chunk: its step-0 fragments are in fa[0] / fb[0], and the item after it has been requested.
-  int stage = 0;
-  if (tile_of(0) >= ntiles) return;
-  TileAt tn = tile_at(tile_of(0));             // the tile whose chunks are being requested next
-  fire(prep(tn, 0), 0);
-  fire(NC > 1 ? prep(tn, 1) : first ? idle : prep_c(tn), 1);
-  __builtin_amdgcn_s_waitcnt(0x0F70);          // (once per launch: both requests)
-  W4_BARRIER();
-  W4_RD(0, smem256, 0);
-  for (int it = 0; it < niter; ++it) {
-    const int tile = tile_of(it);
-    if (tile >= ntiles) break;
-    const int tile_next = it + 1 < niter ? tile_of(it + 1) : ntiles;
-    const TileAt tc = tn;
-    if (tile_next < ntiles) tn = tile_at(tile_next);
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mi][n][i] = 0.f;
-    for (int c = 0; c < NC; ++c) {
-      const unsigned char* st = smem256 + stage * STAGE;
-      // W4_USE(b): an empty asm that reads fragment set b -- the compiler puts its wait for those ds_reads THERE (it waits with
-      // lgkmcnt(0) wherever it waits in this loop, so the wait has to come before the next set is requested, not after)
-      W4_USE(0);
-      W4_SB();
-      W4_RD(1, st, 1);
-      W4_SB();
-      W4_MM_ROWS(0, 0, 2);
-      W4_SB();
-      // the item two places on in the ring: chunk c + 2, else the c tile, else chunk 0 of the next tile (scalar work in the shadow
-      // of the MFMAs just issued)
-      const Req nxt = c + 2 < NC ? prep(tc, c + 2) : c + 2 == NC ? (first ? idle : prep_c(tc)) : tile_next < ntiles ? prep(tn, 0) : idle;
-      W4_SB();
-      W4_MM_ROWS(0, 2, 4);
-      W4_SB();
-      W4_USE(1);
-      W4_SB();
-      W4_RD(0, st, 2);
-      W4_SB();
-      W4_MM(1);
-      W4_SB();
-      W4_USE(0);
-      W4_SB();
-      W4_RD(1, st, 3);
-      W4_SB();
-      W4_MM(0);
-      W4_SB();
-      W4_USE(1);
-      W4_SB();
-      // hand-over: every fragment of this chunk is in registers, this wave's pieces of the next item have landed
-      // (vmcnt(0): they were requested a whole chunk ago; older than them only stores of the previous tile's cell update)
-      __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) expcnt(7) lgkmcnt(0)
-      W4_BARRIER();                              // the next item is complete in LDS; this chunk's stage is free
-      if (c + 1 < NC) W4_RD(0, smem256 + (stage ^ 1) * STAGE, 0);
-      W4_SB();
-      // the 16 requests go out between the 16 MFMAs of the last group (where the ring has no next item -- no c tile at the first
-      // timestep, no tile after the last -- the request re-reads this wave's first weight piece into the free stage: one code path)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          acc[mi][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[1][mi]), __builtin_bit_cast(bf16x8, fb[1][n]), acc[mi][n], 0, 0, 0);
-          W4_FIRE1(nxt, stage, mi * 4 + n);
-        }
-      W4_SB();
-      stage ^= 1;
-    }
-    // `stage` holds the c tile; the other one is receiving chunk 0 of the next tile
-    const float* cs = reinterpret_cast<const float*>(smem256 + stage * STAGE);
-    const int d = tile >= nb, rem = tile - d * nb, jb = rem % njb, rbw = rem / njb;
-    const int j = (jb * 2 + cg) * 32 + fr;
-    float bv[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) bv[n] = p.bias[(d * 4 + n) * H + j];
-    unsigned char* hst = smem256 + 2 * STAGE + w * 8192;   // 8 KB per wave: its 128 rows x 32 units of h_t as eight 1-KB fragment pieces
-#pragma unroll
-    for (int mi = 0; mi < EPI_MI; ++mi) {
-      float cn[16], hn[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float cprev = first ? 0.f : cs[(rg * 128 + mi * 32 + 4 * fh + 8 * (i >> 2) + (i & 3)) * 64 + cg * 32 + fr];
-        const float gi = bf_sigmoid(acc[mi][0][i] + bv[0]), gf = bf_sigmoid(acc[mi][1][i] + bv[1]);
-        const float gg = bf_tanh(acc[mi][2][i] + bv[2]), go = bf_sigmoid(acc[mi][3][i] + bv[3]);
-        cn[i] = gf * cprev + gi * gg;
-        hn[i] = go * bf_tanh(cn[i]);
-      }
-      float* const cwave = p.o.c[d] + ((long)rbw * 256 + rg * 128 + mi * 32) * H;
-      float* const hwave = HOUT ? p.o.hout[d] + ((long)rbw * 256 + rg * 128 + mi * 32) * p.o.hos : nullptr;
-      const unsigned cl = (unsigned)(4 * fh) * (unsigned)H + (unsigned)j, hl = (unsigned)(4 * fh) * (unsigned)p.o.hos + (unsigned)j;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        cwave[(long)(8 * (i >> 2) + (i & 3)) * H + cl] = cn[i];
-        if (HOUT) hwave[(long)(8 * (i >> 2) + (i & 3)) * p.o.hos + hl] = hn[i];
-        *reinterpret_cast<bf16_t*>(hst + ((((mi * 2 + (fr >> 4)) * 64 + ((fr >> 3) & 1) * 32 + 4 * fh + 8 * (i >> 2) + (i & 3)) * 8 + (fr & 7)) << 1)) =
-            __builtin_bit_cast(bf16_t, (__bf16)hn[i]);
-      }
-    }
-    {
-      bf16_t* hf = p.o.hfrag[d];
-#pragma unroll
-      for (int pc = 0; pc < EPI_PIECES; ++pc) {           // piece pc = (row block pc >> 1, 16-k group pc & 1) of this wave
-        const u32x4 v = *reinterpret_cast<const u32x4*>(hst + ((pc * 64 + lane) << 4));
-        const long rb32 = (long)rbw * 8 + rg * 4 + (pc >> 1), k16 = (jb * 2 + cg) * 2 + (pc & 1);
-        *reinterpret_cast<u32x4*>(hf + ((rb32 * (H >> 4) + k16) * 64 + lane) * 8) = v;
-      }
-    }
-    if (tile_next >= ntiles) break;
-    // chunk 0 of the next tile was requested BEFORE the stores above: all but the youngest EPI_WAIT operations done covers it;
-    // lgkmcnt(0): this wave has read its part of the c tile, whose stage the barrier hands to the next tile's second item
-    __builtin_amdgcn_s_waitcnt(0x0070 | (EPI_WAIT & 15) | ((EPI_WAIT >> 4) << 14));
-    W4_BARRIER();
-    stage ^= 1;
-    fire(NC > 1 ? prep(tn, 1) : first ? idle : prep_c(tn), stage ^ 1);
-    W4_RD(0, smem256 + stage * STAGE, 0);
-  }
-#undef W4_RD
-#undef W4_MM
-#undef W4_BARRIER
-#undef W4_SB
-#undef W4_USE
-#undef W4_FIRE1
-#undef W4_MM_ROWS
-}
-
 extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H, int first, int nseg,
                                           const unsigned short* a0_0, const unsigned short* a0_1, const unsigned short* w0_0,
                                           const unsigned short* w0_1, int K0, const unsigned short* a1_0,
@@ -1412,23 +1167,8 @@ extern "C" int mmego_lstm_step_bf16_fused(void* stream, int ndir, int Bn, int H,
     const int ntiles = 2 * (H / 64) * (Bn / 256);
     constexpr int maxwg = 256;
     dim3 grid(ntiles < maxwg ? ntiles : maxwg, 1, 1);
-    // the four-wave form of the tile (MMEGO_F256_W4=0: the eight-wave kernel, for A/B runs and the test that holds them equal)
-    const int skew = getenv("MMEGO_F256_SKEW") ? atoi(getenv("MMEGO_F256_SKEW")) : 0;
-    const bool w4 = !(getenv("MMEGO_F256_W4") && atoi(getenv("MMEGO_F256_W4")) == 0);
-    if (w4) {
-      static bool attr4_set[64] = {};
-      int devid = 0;
-      if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return (int)hipErrorInvalidDevice;
-      if (!attr4_set[devid]) {
-        hipError_t e = hipFuncSetAttribute((const void*)lstm_step_bf16_fused256w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lstm_step_bf16_fused256w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr4_set[devid] = true;
-      }
-      if (hout0) lstm_step_bf16_fused256w4_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(p, ntiles, skew);
-      else lstm_step_bf16_fused256w4_kernel<false><<<grid, 256, lds, (hipStream_t)stream>>>(p, ntiles, skew);
-    } else if (hout0) lstm_step_bf16_fused256_kernel<true><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles, skew);
-    else lstm_step_bf16_fused256_kernel<false><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles, skew);
+    if (hout0) lstm_step_bf16_fused256_kernel<true><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles);
+    else lstm_step_bf16_fused256_kernel<false><<<grid, 512, lds, (hipStream_t)stream>>>(p, ntiles);
   } else {
     dim3 grid(H / 32, cdiv(Bn, 128), ndir);
     lstm_step_bf16_fused_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(p);

@@ -164,25 +164,6 @@ def test_large_batch_fused_and_unfused_forms_agree(monkeypatch, Bn):
     assert float(outs[True].abs().mean()) > 1e-2          # not trivially zero
 
 
-@pytest.mark.parametrize("Bn,T,H,In", [(4096, 3, 512, 512), (512, 3, 64, 128), (768, 2, 256, 64), (4352, 2, 512, 512)])
-def test_fused_step_on_four_waves_is_the_eight_wave_kernel_bit_for_bit(monkeypatch, Bn, T, H, In):
-    """r06: lstm_step_bf16_fused256w4_kernel (128 x 128 wave tiles, one wave per SIMD) against lstm_step_bf16_fused256_kernel
-    (MMEGO_F256_W4=0): the same tile, the same k order per accumulator, the same cell update -- every output bit equal.  4096 rows:
-    the XCD walk over 8 tiles per workgroup (ring hand-over from tile to tile); 512 / 768 rows: fewer tiles than CUs, K segments of
-    128 / 64 (two chunks / ONE chunk per segment: the c tile follows chunk 0 at once); 4352 rows: a ragged last round."""
-    from mmego_amd import blocks, ops
-    monkeypatch.setattr(blocks, "FUSED_MIN_ROWS", 1)
-    torch.manual_seed(5)
-    lstm = blocks.LstmParams(In, H, 2).to(_dev())
-    x = torch.randn(Bn * T, In, generator=torch.Generator().manual_seed(6)).to(_dev())
-    outs = {}
-    for w4 in ("0", "1"):
-        monkeypatch.setenv("MMEGO_F256_W4", w4)
-        outs[w4] = blocks.lstm_steps_forward_bf16(ops.Arena(_dev()), "t", lstm, x, Bn, T).clone()
-    assert torch.equal(outs["0"], outs["1"])
-    assert float(outs["1"].abs().mean()) > 1e-2
-
-
 def test_fc_relu_bf16_fragments_and_the_imu_forward_that_uses_them(monkeypatch):
     """mmego_fc_relu_bf16_frag_tm (IMU_Net's fc1 written straight as the fused step's layer-0 operand): every element is the bf16
     rounding of relu(x . W^T + b) (fp32 sums in another order than the GEMM's: a value within half a bf16 ulp of a tie may round
