@@ -545,6 +545,42 @@ __global__ __launch_bounds__(512, 1) void s3_gemm_big_kernel(S3GemmP p) {
       __builtin_amdgcn_sched_barrier(0);                                                                              \
     }                                                                                                                 \
   }
+#ifndef S3_BIG_SCHED
+#define S3_BIG_SCHED 1
+#endif
+#if S3_BIG_SCHED == 1
+  // r06, second schedule.  The compiler waits with lgkmcnt(0) wherever it waits in a loop that also holds LDS-DMA requests, so a fragment
+  // read requested just in front of the MFMAs that use the PREVIOUS read is waited for too (the first schedule: "3 ds_read, 2 MFMAs,
+  // s_waitcnt lgkmcnt(0), 10 MFMAs" per row block).  Here an empty asm that READS row block mi's fragments stands in front of the request
+  // for row block mi + 1: the wait lands there, where only reads requested a whole MFMA group ago are outstanding.  The step's barrier
+  // moves behind row block 3's MFMAs (row block 4's fragments, the stage's last read, are then in registers without a wait of their own).
+#undef S3_BIG_STEP
+#define S3_USE3(x) asm volatile("" ::"v"((x)[0]), "v"((x)[1]), "v"((x)[2]))
+#define S3_BIG_STEP(s, par)                                                                                           \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < 5; ++mi) {                                                                \
+      if (!(S3_EXP & 32)) {                                                                                           \
+        S3_USE3(a[((par) + mi) & 1]);                                                                                 \
+        if (mi == 0) { S3_USE3(b[par][0]); S3_USE3(b[par][1]); }                                                      \
+      }                                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+      if (mi < 4) { S3_BIG_RD_A(((par) + mi + 1) & 1, par, mi + 1) }                                                  \
+      if (mi == 4) {                                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+        __builtin_amdgcn_s_barrier();                                                                                 \
+        if (wm == 0 && (s) + 2 < SK) S3_BIG_DMA((s) + 2, par)                                                         \
+        if ((s) + 1 < SK) {                                                                                           \
+          S3_BIG_RD_B((par) ^ 1, (par) ^ 1)                                                                           \
+          S3_BIG_RD_A(((par) ^ 1), (par) ^ 1, 0)                                                                      \
+        }                                                                                                             \
+      }                                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = s3_mma<NPROD>(a[((par) + mi) & 1], b[par][ni], acc[mi][ni]); \
+      __builtin_amdgcn_sched_barrier(0);                                                                              \
+      if (mi == 4 && wm == 1 && (s) + 2 < SK) S3_BIG_DMA((s) + 2, par)                                                 \
+    }                                                                                                                 \
+  }
+#endif
   // (A-fragment slots: step parity par starts with slot par -- row block mi sits in slot (par + mi) & 1 -- so that the first
   //  fragments of the NEXT step, requested in front of row block 4's MFMAs (slot par), go to slot par ^ 1.)
   S3_BIG_DMA(0, 0)
@@ -558,6 +594,7 @@ __global__ __launch_bounds__(512, 1) void s3_gemm_big_kernel(S3GemmP p) {
     if (s + 1 < SK) S3_BIG_STEP(s + 1, 1)
   }
 #undef S3_BIG_STEP
+#undef S3_USE3
 #undef S3_BIG_RD_A
 #undef S3_BIG_RD_B
 #undef S3_BIG_DMA
