@@ -292,6 +292,66 @@ __global__ __launch_bounds__(512, 1) void gemm_tile_big_kernel(TileP p, TileBigA
   if (nk > 1) GTB_DMA(1, 1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifndef GTB_SCHED
+#define GTB_SCHED 1
+#endif
+#if GTB_SCHED == 1
+  // r06, second schedule: the MFMAs of a k block go row block by row block (per accumulator the same k order: bit-identical), so row
+  // block i's fragment registers are free after its 8 MFMAs and receive the next fragments two row blocks later -- every fragment is
+  // requested 24 MFMAs before its use with no second register set (only the two W fragments are double-buffered).  An empty asm that reads
+  // the fragments about to be used pins the compiler's wait (lgkmcnt(0) in this loop, whatever it waits for) in front of the new request.
+  // The chunk's barrier sits in front of row block 2 of the last k block: every read of the stage is at least 8 MFMAs old there.
+#define GTB_USE(x) asm volatile("" ::"v"(x))
+#define GTB_SB() __builtin_amdgcn_sched_barrier(0)
+  f32x4 a[5], b[2][2];
+  {
+    const float* As = smem + wm * 160 * KCH;
+    const float* Bs = smem + (BM + wn * 64) * KCH;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * KCH + off[0]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * KCH + off[0]);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      // slot i (in front of row block i's MFMAs) requests: i = 0, 1: row blocks 3, 4 of THIS k block (their registers were read last by
+      // the previous k block's MFMAs); i = 2, 3, 4: row blocks 0, 1, 2 (and, at i = 2, the W fragments) of the NEXT k block -- from this
+      // stage, or (last k block of the chunk) from the other one, behind the barrier at slot 2.  Every request is 24 MFMAs ahead of its use
+      // and 8 MFMAs behind the previous one, so the wait in front of it finds nothing young outstanding.
+      const float* Ac = smem + (kt & 1) * STAGE + wm * 160 * KCH + off[kb];
+      const int nst = kb < 3 ? (kt & 1) : ((kt + 1) & 1);
+      const float* An = smem + nst * STAGE + wm * 160 * KCH + off[(kb + 1) & 3];
+      const float* Bn = smem + nst * STAGE + (BM + wn * 64) * KCH + off[(kb + 1) & 3];
+      const bool more = kb < 3 || kt + 1 < nk;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        GTB_USE(a[i]);
+        if (i == 0) { GTB_USE(b[kb & 1][0]); GTB_USE(b[kb & 1][1]); }
+        GTB_SB();
+        if (i == 2 && kb == 3) {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (kt + 2 < nk) GTB_DMA(kt + 2, kt & 1)
+        }
+        if (i < 2) a[i + 3] = *reinterpret_cast<const f32x4*>(Ac + (i + 3) * 32 * KCH);
+        else if (more) a[i - 2] = *reinterpret_cast<const f32x4*>(An + (i - 2) * 32 * KCH);
+        if (i == 2 && more) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b[(kb + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bn + j * 32 * KCH);
+        }
+        GTB_SB();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][c], b[kb & 1][j][c], acc[i][j], 0, 0, 0);
+        GTB_SB();
+      }
+    }
+  }
+#undef GTB_USE
+#undef GTB_SB
+#else
   f32x4 a[5], b[2];
   for (int kt = 0; kt < nk; ++kt) {
     const float* As = smem + (kt & 1) * STAGE + wm * 160 * KCH;
@@ -319,6 +379,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tile_big_kernel(TileP p, TileBigA
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][c], b[j][c], acc[i][j], 0, 0, 0);
     }
   }
+#endif
 #undef GTB_DMA
   float* C = p.C + (long)batch * p.sCb;
 #pragma unroll
