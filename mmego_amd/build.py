@@ -22,6 +22,12 @@ ARCH = "gfx950"
 # without; config 5, wlocal and stage-1 figures unchanged).
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=on", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32 + os.environ.get("MMEGO_EXTRA_HIPCC_FLAGS", "").split()
+# Per-file additions.  front_bf16.hip: its 16 x 16 MFMA chains hand every accumulator straight to VALU code (ReLU, bf16 rounding, the next
+# MFMA's operand); with the accumulators in AGPRs -- the compiler's default choice -- each of the 52 values per slab costs a
+# v_accvgpr_read_b32 first (r06: 342 -> 290 instructions per slab and wave).
+# -fno-honor-nans there: relu(x) is one v_max_f32 instead of two (the first canonicalises a possible signalling NaN); the file holds one
+# eval-mode kernel whose inputs are finite activations.
+FILE_FLAGS = {"front_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
 # (the host pass of the same command line does not know the amdgcn feature and says so once per file)
 _HOST_NOISE = ("'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)", "1 warning generated when compiling for host.")
 
@@ -56,7 +62,7 @@ def build_library(force=False, verbose=True, variant=None, extra_flags=()):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_h):
             return obj                  # (object newer than its source, every header and this recipe: keep it)
-        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + list(extra_flags) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr))
