@@ -491,6 +491,74 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
   }
 }
 
+// The same forward on the fp32 matrix pipe (r06; v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation), no LDS at all.
+// The scalar kernel above does 480 broadcast LDS reads and 480 FMAs per lane and frame row (402 us for 32 768 frames at config 5, the
+// LDS queue full); here a wave owns 16 queries of the frame and computes both products TRANSPOSED, so that every operand is a plain
+// contiguous read and no value changes lanes between the two products:
+//   S^T[key][query] = K Q^T: lane (m, g) supplies K[key m][16 g + kk] and Q[query m][16 g + kk] at step kk = 0..15 -- each lane reads 16
+//     contiguous channels of its key / query row (four 16-byte loads each); result lane (query c, g), register i: key 4 g + i;
+//   softmax over a query's 15 keys = over 4 registers and the 4 lane groups g (two shuffles per reduction); key 15 is padding (-inf);
+//   O^T[channel][query] = V^T P^T: the B operand at step kk is register kk of the softmax result as it stands (key 4 g + kk), the A
+//     operand V[key 4 g + kk][16 ct + m]; result lane (query c, g), register i: channel 16 ct + 4 g + i -- one 16-byte store per tile.
+// Requires 16-byte aligned Q, K, V, O and ldkv, ldo multiples of 4 (the launcher falls back to the scalar kernel otherwise).
+__global__ __launch_bounds__(256) void cross_attn_fwd_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                  const float* __restrict__ V, float scale,
+                                                                  float* __restrict__ O, long ldo, float* __restrict__ Pout,
+                                                                  long ldkv) {
+  const long f = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const long qrow = f * NQ + 16 * wave + c;
+  const float* qp = Q + qrow * DH + 16 * g;
+  const float* kp = K + (f * NK + min(c, NK - 1)) * ldkv + 16 * g;          // (lane group row 15: key 14 again; masked below)
+  f32x4 qv[4], kv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    qv[j] = *reinterpret_cast<const f32x4*>(qp + 4 * j);
+    kv[j] = *reinterpret_cast<const f32x4*>(kp + 4 * j);
+  }
+  // V^T fragments: lane (m = c, g): V[key 4 g + kk][16 ct + c]
+  float vv[4][4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const float* vp = V + (f * NK + min(4 * g + kk, NK - 1)) * ldkv + c;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) vv[ct][kk] = vp[16 * ct];
+  }
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[j][e], qv[j][e], s, 0, 0, 0);
+  float sv[4], m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sv[i] = (4 * g + i < NK) ? s[i] * scale : -INFINITY;
+    m = fmaxf(m, sv[i]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { sv[i] = expf(sv[i] - m); sum += sv[i]; }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sv[i] *= inv;
+    if (4 * g + i < NK) Pout[qrow * NK + 4 * g + i] = sv[i];
+  }
+  float* op = O + qrow * ldo + 4 * g;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[ct][kk], sv[kk], o, 0, 0, 0);
+    *reinterpret_cast<f32x4*>(op + 16 * ct) = o;
+  }
+}
+
 // dO read at lddo; -> dQ [F,64,64], dK, dV [F,15,64]
 __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                              const float* __restrict__ V, const float* __restrict__ Pm,
@@ -727,7 +795,9 @@ extern "C" int mmego_group_bcast(void* stream, const float* dY, long lddy, long 
 extern "C" int mmego_cross_attn_forward(void* stream, const float* Q, const float* K, const float* V, long F, float scale,
                                         float* O, long ldo, float* P, long ldkv) {
   MMEGO_REQUIRE(Q && K && V && O && P && F > 0 && ldkv >= DH);
-  hipLaunchKernelGGL(cross_attn_fwd_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P, ldkv);
+  const bool aligned = (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0 && (ldkv & 3) == 0 && (ldo & 3) == 0;
+  if (aligned) hipLaunchKernelGGL(cross_attn_fwd_mfma_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P, ldkv);
+  else hipLaunchKernelGGL(cross_attn_fwd_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P, ldkv);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -722,6 +722,37 @@ def test_projection_product_on_320x256_tiles_is_the_128x128_walk_bit_for_bit(dev
         assert float((c_big[rows].double() - ref).abs().max()) < 2e-5 * (K / 512) ** 0.5, K
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("F,aligned", [(1, True), (37, True), (512, True), (37, False)])
+def test_cross_attention_forward_against_float64(dev, F, aligned):
+    """mmego_cross_attn_forward (Lower_Net.py:95-136's FusionModule: softmax(Q K^T scale) V over 64 queries x 15 keys x 64 channels per
+    frame) against float64: the fp32 matrix-pipe kernel (r06; 16-byte aligned operands) and the scalar kernel it falls back to (here:
+    K / V / O shifted by one float).  Both keep fp32 accuracy: 2e-6 of the largest output; the probabilities sum to one."""
+    from mmego_amd import hip
+    g = torch.Generator().manual_seed(F)
+    Q = torch.randn(F * 64, 64, generator=g).to(dev)
+    off = 0 if aligned else 1
+    KV = torch.randn(F * 15 * 128 + 4, generator=g).to(dev)
+    Kv, Vv = KV[off:], KV[off + 64:]
+    Obuf = torch.full((F * 64 * 128 + 4,), float("nan"), device=dev)
+    O = Obuf[off + 64:]
+    P = torch.zeros(F * 64, 15, device=dev)
+    scale = 0.125
+    hip.call("cross_attn_forward", Q, Kv, Vv, F, scale, O, 128, P, 128)
+    torch.cuda.synchronize()
+    Kd = KV[off:off + F * 15 * 128].view(F, 15, 128)[:, :, :64].double().cpu()
+    Vd = KV[off:off + F * 15 * 128].view(F, 15, 128)[:, :, 64:].double().cpu()
+    Qd = Q.view(F, 64, 64).double().cpu()
+    Pw = torch.softmax(Qd @ Kd.transpose(1, 2) * scale, dim=-1)
+    Ow = Pw @ Vd
+    Og = Obuf[off:off + F * 64 * 128].view(F, 64, 128)[:, :, 64:].double().cpu()
+    assert float((P.view(F, 64, 15).double().cpu() - Pw).abs().max()) < 2e-6
+    assert float((Og - Ow).abs().max()) < 2e-6 * max(1.0, float(Ow.abs().max()))
+    assert float((P.sum(dim=1) - 1).abs().max()) < 1e-5
+    # nothing outside the 64 output columns of a row is written
+    assert bool(torch.isnan(Obuf[off:off + F * 64 * 128].view(F, 64, 128)[:, :, :64]).all())
+
+
 def test_train_upper(dev):
     from mmego_amd import nets
     g = golden("g6_train.npz")
