@@ -91,15 +91,17 @@ int mmego_bn_fold_linear(void* stream, const float* W, const float* b, int N, in
  * bn == NULL: W, b are BN-folded already (mmego_bn_fold_linear).  Otherwise bn is a HOST array of 12 device pointers
  * {gamma, beta, running_mean, running_var} x 3 layers and W, b are the raw conv parameters (b may be NULL): the kernel folds
  * BatchNorm(eps) into them while staging the weights, with mmego_bn_fold_linear's arithmetic (same bits).
- * Cin, C1 <= 32; C2, C3 <= 64.  X, Y may be column slices (row strides ldx, ldy). */
+ * Cin, C1 <= 32; C2, C3 <= 64.  X, Y may be column slices (row strides ldx, ldy).
+ * pre (0..4, <= Cin): the first `pre` input columns of every row are also written in FRONT of the row's outputs, Y[row * ldy - pre + c]
+ * (Lower_Net.py:229-233's cat(xyz, features) written row by row in one launch); 0: nothing outside Y's columns is written. */
 int mmego_mlp3_eval(void* stream, const float* X, long ldx, long rows, int Cin, const float* W1, const float* b1, int C1,
                     const float* W2, const float* b2, int C2, const float* W3, const float* b3, int C3, float* Y, long ldy,
-                    const float* const* bn, float eps);
+                    const float* const* bn, float eps, int pre);
 /* The same with the three stages' operands (folded weights, stage inputs) rounded to bf16 and fp32 accumulation (mlp3_bf16.hip; opt-in
  * precision mode of eval forwards).  Biases, ReLU and Y stay fp32. */
 int mmego_mlp3_eval_bf16(void* stream, const float* X, long ldx, long rows, int Cin, const float* W1, const float* b1, int C1,
                          const float* W2, const float* b2, int C2, const float* W3, const float* b3, int C3, float* Y, long ldy,
-                         const float* const* bn, float eps);
+                         const float* const* bn, float eps, int pre);
 /* Y = act((X1-m1)*a1+b1 [+ (X2-m2)*a2+b2]) -- BN apply + ReLU, and the st_gcn "tcn(x)+residual" join
  * (GCN.py:140-147). */
 int mmego_affine_act(void* stream, const float* X1, long ld1, const float* m1, const float* a1, const float* b1,

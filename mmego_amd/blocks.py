@@ -161,12 +161,20 @@ def pool128_fusable(mod, x, P, training):
                 and hip.lib().mmego_pool128_ok(x.shape[0]))
 
 
-def mlp3_forward(ar, key, mod, x, out_last, training, pool=None, bf16=False):
+def mlp3_forward(ar, key, mod, x, out_last, training, pool=None, bf16=False, front=None):
     """pool = (attention Linear, vec, attn) with pool128_fusable(...): the softmax pooling behind the chain runs inside its last launch
-    (out_last is not written); returns None then."""
+    (out_last is not written); returns None then.
+    front (optional; [rows, n <= 4] columns that end where out_last's begin, same row stride): receives x[:, :n] -- Lower_Net's
+    cat(xyz, features) rows.  The one-kernel eval path writes them in the same launch as the features (whole lines for the L2 instead
+    of 12 bytes per 512-byte row from another launch); the other paths copy."""
     rows = x.shape[0]
     cur = x
+
+    def copy_front():
+        if front is not None:
+            ops.copy2d(x[:, :front.shape[1]], front)
     if training and _mlp3_fused_train(mod, x) and out_last.stride(1) == 1:
+        copy_front()
         return _mlp3_forward_fused(ar, key, mod, x, out_last, pool=pool)
     if pool is not None:
         raise ValueError("mlp3_forward: pool needs the fused train-mode chain (check pool128_fusable)")
@@ -182,9 +190,16 @@ def mlp3_forward(ar, key, mod, x, out_last, training, pool=None, bf16=False):
             bnp = torch.tensor([t.data_ptr() for _, bn in layers for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)],
                                dtype=torch.int64)
             wb = [v for (conv, _), C in zip(layers, dims) for v in (conv.weight, conv.bias, C)]
+            pre = 0
+            if front is not None:
+                pre = front.shape[1]
+                if not (front.stride(0) == out_last.stride(0) and front.stride(1) == 1 and pre <= min(4, Cin)
+                        and front.data_ptr() + 4 * pre == out_last.data_ptr()):
+                    raise ValueError("mlp3_forward: front must be the columns right in front of out_last")
             hip.call("mlp3_eval_bf16" if bf16 else "mlp3_eval", x, x.stride(0), rows, Cin, *wb, out_last, out_last.stride(0), bnp,
-                     float(layers[0][1].eps))
+                     float(layers[0][1].eps), pre)
             return out_last
+        copy_front()
         folded = []
         for i, (conv, bn) in enumerate(layers, 1):
             C = conv.weight.shape[0]
@@ -199,6 +214,7 @@ def mlp3_forward(ar, key, mod, x, out_last, training, pool=None, bf16=False):
             ops.linear(cur, wf, bf, y, relu=True)
             cur = y
         return cur
+    copy_front()
     for i, (conv, bn) in enumerate(_mlp3_layers(mod), 1):
         C = conv.weight.shape[0]
         z = ar.get("%s.z%d" % (key, i), (rows, C))

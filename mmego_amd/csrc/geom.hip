@@ -649,6 +649,142 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
 }
 
+// The same selection by an in-register bitonic sort (r06): ONE WAVE per frame, NR = ceil(N / 64) elements per lane (element e = 64 r +
+// lane, padded with key -inf / index e), sorted descending by (key, then index ascending) -- a total order, so the network's result is
+// THE order the rank kernel above computes, bit for bit (float compares: -0 == +0 ties go by index there and here).  Compare-exchange
+// partners 64 r apart are registers of the same lane; partners < 64 apart are lanes (DPP / permlane moves, no LDS).  36 steps x 4
+// elements for N = 256 against 256 LDS reads and compares per element.  Small launches (F <= 1024) keep the rank kernel: four waves
+// per frame finish a frame sooner than one, and that is what counts when the frames do not fill the chip.
+// the value of lane (l ^ J), J = 1 .. 32, without the LDS crossbar (ds_bpermute: the sort was bound by it -- 264 of them per frame):
+// DPP quad permutes (1, 2), two bank-masked row shifts (4), a row rotate (8), v_permlane16_swap / v_permlane32_swap (16, 32)
+typedef unsigned tk_u32x2 __attribute__((ext_vector_type(2)));
+template <int J>
+__device__ __forceinline__ int tk_xor_lane(int x, int lane) {
+  if constexpr (J == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);           // quad_perm [1, 0, 3, 2]
+  else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
+  else if constexpr (J == 4) {
+    const int r = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0x5, false);                      // row_shl:4 into banks 0, 2
+    return __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);                             // row_shr:4 into banks 1, 3
+  } else if constexpr (J == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true);   // row_ror:8
+  else if constexpr (J == 16) {
+    const tk_u32x2 r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+    return (lane & 16) ? (int)r[0] : (int)r[1];
+  } else {
+    const tk_u32x2 r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return (lane & 32) ? (int)r[0] : (int)r[1];
+  }
+}
+
+// one compare-exchange step between lanes J apart, all NR elements of the lane (KK: the bitonic stage, for the direction)
+template <int NR, int KK, int J>
+__device__ __forceinline__ void tk_lane_step(float (&k)[NR], int (&id)[NR], int lane) {
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const float ko = __builtin_bit_cast(float, tk_xor_lane<J>(__builtin_bit_cast(int, k[r]), lane));
+    const int io = tk_xor_lane<J>(id[r], lane);
+    const int p = 64 * r + lane;
+    const bool desc = (p & KK) == 0;
+    const bool lower = (lane & J) == 0;                 // this lane holds the lower position of the pair
+    const bool mine_first = (k[r] > ko) | ((k[r] == ko) & (id[r] < io));           // (| and &: no branches around the compares)
+    // the lower position keeps the element that comes first in a descending pair, second in an ascending one
+    const bool keep_mine = mine_first == (lower == desc);
+    k[r] = keep_mine ? k[r] : ko;
+    id[r] = keep_mine ? id[r] : io;
+  }
+}
+
+template <int NR, int KK>
+__device__ __forceinline__ void tk_lane_steps(float (&k)[NR], int (&id)[NR], int lane) {
+  if constexpr (KK >= 64) tk_lane_step<NR, KK, 32>(k, id, lane);
+  if constexpr (KK >= 32) tk_lane_step<NR, KK, 16>(k, id, lane);
+  if constexpr (KK >= 16) tk_lane_step<NR, KK, 8>(k, id, lane);
+  if constexpr (KK >= 8) tk_lane_step<NR, KK, 4>(k, id, lane);
+  if constexpr (KK >= 4) tk_lane_step<NR, KK, 2>(k, id, lane);
+  tk_lane_step<NR, KK, 1>(k, id, lane);
+}
+
+// the stage's steps between registers (partners 64 jr apart), largest distance first
+template <int NR, int KK>
+__device__ __forceinline__ void tk_reg_steps(float (&k)[NR], int (&id)[NR]) {
+#pragma unroll
+  for (int j = KK >> 1; j >= 64; j >>= 1) {
+    const int jr = j >> 6;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      if ((r & jr) == 0) {                              // r < partner r ^ jr: position p = 64 r + lane, direction from p & KK
+        const int rp = r ^ jr;
+        const bool desc = ((64 * r) & KK) == 0;         // (KK >= 128 here: a bit of r)
+        const bool first = (k[r] > k[rp]) | ((k[r] == k[rp]) & (id[r] < id[rp]));   // element r comes before element rp
+        const bool swap = first != desc;
+        const float k0 = swap ? k[rp] : k[r], k1 = swap ? k[r] : k[rp];
+        const int i0 = swap ? id[rp] : id[r], i1 = swap ? id[r] : id[rp];
+        k[r] = k0; k[rp] = k1; id[r] = i0; id[rp] = i1;
+      }
+    }
+  }
+}
+
+template <int NR, int KK>
+__device__ __forceinline__ void tk_stage(float (&k)[NR], int (&id)[NR], int lane) {
+  if constexpr (KK <= 64 * NR) {
+    tk_reg_steps<NR, KK>(k, id);
+    tk_lane_steps<NR, KK>(k, id, lane);
+  }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void topk_rows_sort_kernel(const float* __restrict__ pts, long F, int N, int C, int keep,
+                                                             float* __restrict__ out, long long* __restrict__ idx,
+                                                             float* __restrict__ out2, long ld2, int n2) {
+  const int lane = threadIdx.x & 63;
+  const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= F) return;                                     // (whole waves; no barrier in this kernel)
+  const float* pf = pts + f * N * C;
+  float k[NR];
+  int id[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int e = 64 * r + lane;
+    id[r] = e;
+    k[r] = e < N ? pf[(long)e * C] : -INFINITY;
+  }
+  tk_stage<NR, 2>(k, id, lane);
+  tk_stage<NR, 4>(k, id, lane);
+  tk_stage<NR, 8>(k, id, lane);
+  tk_stage<NR, 16>(k, id, lane);
+  tk_stage<NR, 32>(k, id, lane);
+  tk_stage<NR, 64>(k, id, lane);
+  tk_stage<NR, 128>(k, id, lane);
+  tk_stage<NR, 256>(k, id, lane);
+  tk_stage<NR, 512>(k, id, lane);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int rank = 64 * r + lane;
+    if (rank < keep) {
+      const int i = id[r];
+      idx[f * keep + rank] = i;
+      float* o = out + (f * keep + rank) * C;
+      for (int c = 0; c < C; ++c) o[c] = pf[(long)i * C + c];
+      if (out2)
+        for (int c = 0; c < n2; ++c) out2[(f * keep + rank) * ld2 + c] = pf[(long)i * C + c];
+    }
+  }
+}
+
+static void topk_launch(hipStream_t st, const float* pts, long F, int N, int C, int keep, float* out, long long* idx, float* out2, long ld2,
+                        int n2) {
+  const unsigned grid4 = (unsigned)((F + 3) / 4);
+  if (F <= 1024 && N <= 4096)
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)F), dim3(N < 256 ? ((N + 63) / 64) * 64 : 256), (size_t)N * sizeof(float), st, pts, N, C,
+                       keep, out, idx, out2, ld2, n2);
+  else if (N <= 64) hipLaunchKernelGGL(topk_rows_sort_kernel<1>, dim3(grid4), dim3(256), 0, st, pts, F, N, C, keep, out, idx, out2, ld2, n2);
+  else if (N <= 128) hipLaunchKernelGGL(topk_rows_sort_kernel<2>, dim3(grid4), dim3(256), 0, st, pts, F, N, C, keep, out, idx, out2, ld2, n2);
+  else if (N <= 256) hipLaunchKernelGGL(topk_rows_sort_kernel<4>, dim3(grid4), dim3(256), 0, st, pts, F, N, C, keep, out, idx, out2, ld2, n2);
+  else if (N <= 512) hipLaunchKernelGGL(topk_rows_sort_kernel<8>, dim3(grid4), dim3(256), 0, st, pts, F, N, C, keep, out, idx, out2, ld2, n2);
+  else
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)F), dim3(256), (size_t)N * sizeof(float), st, pts, N, C, keep, out, idx, out2, ld2, n2);
+}
+
 // ------------------------------------------------------------------------------------------------
 extern "C" int mmego_transform2h(void* stream, float* pts, long F, int P, int C, const float* R, const float* t, const float* src,
                                  long src_ld, float* keep, float* feats, long ldf, int nfeat) {
@@ -752,8 +888,7 @@ extern "C" int mmego_l1_loss(void* stream, const float* pred, const float* targe
 extern "C" int mmego_topk_rows(void* stream, const float* pts, long F, int N, int C, int keep, float* out,
                                long long* idx) {
   MMEGO_REQUIRE(pts && out && idx && F > 0 && N > 0 && C > 0 && keep > 0 && keep <= N && N <= 4096);
-  hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)F), dim3(N < 256 ? ((N + 63) / 64) * 64 : 256),
-                     (size_t)N * sizeof(float), (hipStream_t)stream, pts, N, C, keep, out, idx, (float*)nullptr, 0L, 0);
+  topk_launch((hipStream_t)stream, pts, F, N, C, keep, out, idx, nullptr, 0L, 0);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }
@@ -762,8 +897,7 @@ extern "C" int mmego_topk_rows(void* stream, const float* pts, long F, int N, in
 extern "C" int mmego_topk_rows2(void* stream, const float* pts, long F, int N, int C, int keep, float* out, long long* idx, float* out2,
                                 long ld2, int n2) {
   MMEGO_REQUIRE(pts && out && idx && out2 && F > 0 && N > 0 && C > 0 && keep > 0 && keep <= N && N <= 4096 && n2 >= 1 && n2 <= C && ld2 >= n2);
-  hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)F), dim3(N < 256 ? ((N + 63) / 64) * 64 : 256),
-                     (size_t)N * sizeof(float), (hipStream_t)stream, pts, N, C, keep, out, idx, out2, ld2, n2);
+  topk_launch((hipStream_t)stream, pts, F, N, C, keep, out, idx, out2, ld2, n2);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -21,6 +21,7 @@ struct Mlp3P {
   const float* W3; const float* b3; int C3;
   float* Y; long ldy;
   Mlp3Bn bn[3]; float eps;
+  int pre;                 // the first `pre` input columns of every row are also written in FRONT of the row's outputs: Y[row * ldy - pre + c]
 };
 
 // BatchNorm folding: s = gamma / sqrt(var + eps); Wf = s W; bf = (b - mean) s + beta -- the expressions of bn_fold_linear_kernel
@@ -130,6 +131,13 @@ __global__ __launch_bounds__(256) void mlp3_eval_kernel(Mlp3P p) {
   M3_FETCH((long)blockIdx.x < ntiles ? (long)blockIdx.x : ntiles - 1);
   for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const long r0 = t * M3_ROWS;
+    // (r06) Lower_Net's cat(xyz, features) rows: the xyz columns come from THIS launch, next to the features of the same rows, so that
+    // the L2 sees whole lines -- written by the selection kernel they were 12 bytes into every 512-byte row of a 1-GB buffer at config
+    // 5: 150 us of isolated partial-line writes
+    if (p.pre > 0 && tid < M3_ROWS * p.pre) {
+      const int row = tid / p.pre, c = tid - row * p.pre;
+      if (r0 + row < p.rows) p.Y[(r0 + row) * p.ldy - p.pre + c] = p.X[(r0 + row) * p.ldx + c];
+    }
     __syncthreads();                                      // previous iteration's readers of Xs / Y1s / Y2s are done
 #pragma unroll
     for (int j = 0; j < 8; ++j) Xs[(xr + 8 * j) * M3_S32 + xk] = xv[j];
@@ -182,11 +190,12 @@ __global__ __launch_bounds__(256) void mlp3_eval_kernel(Mlp3P p) {
 
 extern "C" int mmego_mlp3_eval(void* stream, const float* X, long ldx, long rows, int Cin, const float* W1, const float* b1, int C1,
                                const float* W2, const float* b2, int C2, const float* W3, const float* b3, int C3, float* Y,
-                               long ldy, const float* const* bn, float eps) {
+                               long ldy, const float* const* bn, float eps, int pre) {
   MMEGO_REQUIRE(X && Y && W1 && W2 && W3 && rows > 0);
   MMEGO_REQUIRE(bn || (b1 && b2 && b3));
   MMEGO_REQUIRE(Cin >= 1 && Cin <= 32 && C1 >= 1 && C1 <= 32 && C2 >= 1 && C2 <= 64 && C3 >= 1 && C3 <= 64);
-  Mlp3P p = {X, ldx, rows, Cin, W1, b1, C1, W2, b2, C2, W3, b3, C3, Y, ldy, {}, eps};
+  MMEGO_REQUIRE(pre >= 0 && pre <= 4 && pre <= Cin);
+  Mlp3P p = {X, ldx, rows, Cin, W1, b1, C1, W2, b2, C2, W3, b3, C3, Y, ldy, {}, eps, pre};
   for (int i = 0; i < 3; ++i) {
     if (bn) {
       MMEGO_REQUIRE(bn[4 * i] && bn[4 * i + 1] && bn[4 * i + 2] && bn[4 * i + 3]);

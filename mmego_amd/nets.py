@@ -493,8 +493,15 @@ class LowerNet(_NetBase):
         prow = F * LOWER_POINTS
         both = ar.get("both", (prow, 128))                      # [p_vec | cross-attention output]: p_vec is written in place
         p_vec = both[:, :64]
+        # the xyz part of p_vec: in training from the selection launch itself (one launch less in a latency-bound chain); in eval mode
+        # from BasePointNet's launch, next to the features of the same rows (r06: at config 5 the selection's 12 bytes into every
+        # 512-byte row of a 1-GB buffer cost 150 us of isolated partial-line writes)
+        front = None if training else p_vec[:, :3]
         if pin_select_idx is None:
-            hip.call("topk_rows2", x, F, N, Cx, LOWER_POINTS, sel, idx, p_vec, both.stride(0), 3)      # (xyz part of p_vec from the same launch)
+            if training:
+                hip.call("topk_rows2", x, F, N, Cx, LOWER_POINTS, sel, idx, p_vec, both.stride(0), 3)
+            else:
+                hip.call("topk_rows", x, F, N, Cx, LOWER_POINTS, sel, idx)
         else:                                                         # replay a recorded selection (see forward)
             pin = pin_select_idx.to(device=dev, dtype=torch.int64).reshape(F, LOWER_POINTS)
             if int(pin.min()) < 0 or int(pin.max()) >= N:
@@ -502,9 +509,10 @@ class LowerNet(_NetBase):
             idx.copy_(pin)
             flat_idx = (pin + torch.arange(F, device=dev, dtype=torch.int64).view(F, 1) * N).reshape(-1).contiguous()
             ops.gather_rows(x.view(F * N, Cx), flat_idx, sel)
-            ops.copy2d(sel[:, :3], p_vec[:, :3])
+            if training:
+                ops.copy2d(sel[:, :3], p_vec[:, :3])
         self.last_select_idx = idx
-        blocks.mlp3_forward(ar, "base", self.pointEncoder.module0, sel, p_vec[:, 3:64], training, bf16=self._bf16_eval(training))
+        blocks.mlp3_forward(ar, "base", self.pointEncoder.module0, sel, p_vec[:, 3:64], training, bf16=self._bf16_eval(training), front=front)
 
         k_vec = self._gcn_forward(ar, up, B, T, training)            # [F*15, 64] in the re-viewed layout (Q8)
 

@@ -616,9 +616,10 @@ def test_mlp3_eval_bf16_matches_emulation(rows, dims):
     bnp = torch.tensor([t.data_ptr() for b in devt for t in b], dtype=torch.int64)
     Wd, bd = [w.to(dev) for w in Ws], [b.to(dev) for b in bs]
     hip.call("mlp3_eval_bf16", xd[:, 1:], xd.stride(0), rows, dims[0], Wd[0], bd[0], dims[1], Wd[1], bd[1], dims[2], Wd[2], bd[2], dims[3],
-             y[:, 2:], y.stride(0), bnp, eps)
+             y[:, 2:], y.stride(0), bnp, eps, 1)
     torch.cuda.synchronize()
-    assert torch.all(y[:, :2] == 7.0) and torch.all(y[:, 2 + dims[3]:] == 7.0)
+    # pre = 1: the first input column, in fp32, right in front of every row's outputs; nothing else outside them
+    assert torch.all(y[:, 0] == 7.0) and torch.equal(y[:, 1], xd[:, 1]) and torch.all(y[:, 2 + dims[3]:] == 7.0)
     a = _bf(x[:, 1:1 + dims[0]])
     for i in range(3):
         gam, bet, mean, var = bn[i]

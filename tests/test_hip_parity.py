@@ -138,7 +138,7 @@ def test_fused_eval_mlp_and_bn_fold(dev):
             folded += [wf, bf, C]
             raw += [dv[0], dv[1], C]
             bn += dv[2:]
-        hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *folded, y, y.stride(0), None, 0.0)
+        hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *folded, y, y.stride(0), None, 0.0, 0)
         torch.cuda.synchronize()
         err = (y.double().cpu() - cur).abs().max().item()
         assert err < 2e-5 * max(1.0, cur.abs().max().item()), (rows, dims, err)
@@ -146,8 +146,15 @@ def test_fused_eval_mlp_and_bn_fold(dev):
         # the kernel folding BatchNorm itself (raw conv parameters + a host array of the 12 BatchNorm vectors): same bits
         y2 = torch.empty(rows, dims[3], device=dev)
         hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *raw, y2, y2.stride(0),
-                 torch.tensor([t.data_ptr() for t in bn], dtype=torch.int64), 1e-5)
+                 torch.tensor([t.data_ptr() for t in bn], dtype=torch.int64), 1e-5, 0)
         assert torch.equal(y2, y)
+        # pre = 2: the first two input columns land in front of every row's outputs (r06), nothing else moves
+        if Cin >= 2:
+            y3 = torch.full((rows, dims[3] + 5), 7.0, device=dev)
+            hip.call("mlp3_eval", x, x.stride(0), rows, Cin, *raw, y3[:, 3:], y3.stride(0),
+                     torch.tensor([t.data_ptr() for t in bn], dtype=torch.int64), 1e-5, 2)
+            assert torch.equal(y3[:, 3:3 + dims[3]], y) and torch.equal(y3[:, 1:3], x[:, :2])
+            assert (y3[:, 0] == 7.0).all() and (y3[:, 3 + dims[3]:] == 7.0).all()
 
 
 def test_bn_backward_pair_equals_two_calls(dev):
@@ -751,6 +758,37 @@ def test_cross_attention_forward_against_float64(dev, F, aligned):
     assert float((P.sum(dim=1) - 1).abs().max()) < 1e-5
     # nothing outside the 64 output columns of a row is written
     assert bool(torch.isnan(Obuf[off:off + F * 64 * 128].view(F, 64, 128)[:, :, :64]).all())
+
+
+@pytest.mark.parametrize("F,N,keep", [(5, 64, 64), (7, 100, 64), (33, 256, 64), (3, 256, 200), (2, 600, 64),            # the rank kernel
+                                      (1025, 64, 64), (1027, 100, 64), (1030, 128, 64), (1026, 200, 64), (1100, 256, 64),
+                                      (1025, 256, 200), (1029, 300, 64), (1025, 512, 64), (1025, 600, 64)])
+def test_topk_rows_is_the_stable_descending_sort(dev, F, N, keep):
+    """mmego_topk_rows / mmego_topk_rows2 (Lower_Net.py:216-227: the 64 points with the largest x; r06: an in-register bitonic sort per
+    wave for more than 1024 frames of up to 512 points, the rank kernel otherwise) against torch's STABLE descending sort -- ties by index, -0 == +0 -- with many ties in the
+    keys: indices, gathered rows and the second output, all bit for bit; rows / columns outside the outputs untouched."""
+    from mmego_amd import hip
+    g = torch.Generator().manual_seed(N * 10 + F)
+    C = 6
+    x = torch.randn(F, N, C, generator=g)
+    x[:, :, 0] = torch.randint(-6, 7, (F, N), generator=g).float() * 0.5          # 13 distinct keys: ties everywhere
+    x[0, ::3, 0] = -0.0
+    x[0, 1::3, 0] = 0.0
+    xd = x.to(dev)
+    out = torch.full((F * keep, C), float("nan"), device=dev)
+    idx = torch.full((F, keep), -1, dtype=torch.int64, device=dev)
+    out2 = torch.full((F * keep, 8), float("nan"), device=dev)
+    hip.call("topk_rows2", xd, F, N, C, keep, out, idx, out2, 8, 3)
+    out_b = torch.full((F * keep, C), float("nan"), device=dev)
+    idx_b = torch.full((F, keep), -1, dtype=torch.int64, device=dev)
+    hip.call("topk_rows", xd, F, N, C, keep, out_b, idx_b)
+    torch.cuda.synchronize()
+    want = torch.sort(x[:, :, 0], dim=1, descending=True, stable=True)[1][:, :keep]
+    assert torch.equal(idx.cpu(), want) and torch.equal(idx_b.cpu(), want)
+    rows = torch.gather(x, 1, want.unsqueeze(-1).expand(F, keep, C)).reshape(F * keep, C)
+    assert torch.equal(out.cpu().view(torch.int32), rows.view(torch.int32)) and torch.equal(out_b.cpu().view(torch.int32), rows.view(torch.int32))
+    assert torch.equal(out2.cpu()[:, :3].view(torch.int32), rows[:, :3].contiguous().view(torch.int32))
+    assert bool(torch.isnan(out2[:, 3:]).all())
 
 
 def test_train_upper(dev):
