@@ -15,6 +15,11 @@
 // holds k = 16 c + 4 q + s at step s of chunk c); row strides K + 4 floats keep those 16-byte reads conflict-free.
 // The pooling is an online softmax per wave (running max / sum / weighted column sums over its slabs), combined across the four
 // waves at the end of the frame in a fixed order: deterministic.
+// r06: the stages are computed TRANSPOSED, as in front_bf16.hip -- D^T[feature][point] = W . X^T with the weight tile as the A operand:
+// the result (lane (point, q), register i: feature 16 ct + 4 q + i) is what the next stage's MFMA step s wants as its B value (k = 16 c
+// + 4 q + s), so ReLU happens in registers, the folded bias is the first MFMA's addend and the activation tiles in LDS are gone; the
+// concat keeps PointNet's 24 features at k 0..23 and puts the four point columns behind them (weight columns permuted while staged);
+// the pooling sums per lane (its point, its 16 features) and is reduced over the points once per frame.
 #include "common.h"
 
 #define FR_SLAB 16
@@ -47,50 +52,42 @@ struct FrontP {
 #define FR_C3 (FR_C2 + 48)
 #define FR_AW (FR_C3 + 64)
 #define FR_SHARED_END (FR_AW + 64)
-// wave-private activation tiles: P [16][20] | Q [16][20] (together also G1 [16][36]) | FZ [16][36] | G2 [16][52]
-#define FR_ACT_P 0
-#define FR_ACT_Q (16 * FR_S16)
-#define FR_ACT_FZ (2 * 16 * FR_S16)
-#define FR_ACT_G2 (FR_ACT_FZ + 16 * FR_S32)
-#define FR_ACT_WAVE (FR_ACT_G2 + 16 * FR_S48)
 #define FR_MAXN 1024
 
 __device__ __forceinline__ float fr_dot3_nofma(float a0, float a1, float a2, float b0, float b1, float b2) {
   return __fadd_rn(__fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b1)), __fmul_rn(a2, b2));
 }
 
-// one stage of a slab: D[16 rows][NCT*16 cols] = A[16][KCH*16] . W[NCT*16][KCH*16]^T, both operands in LDS ([row][k], [n][k])
-template <int NCT, int KCH, int SA, int SW>
-__device__ __forceinline__ void fr_stage(const float* A, const float* W, f32x4 (&acc)[NCT], int fr, int fq) {
+// one stage of a slab, transposed: D^T[NCT*16 features][16 points] = bias + W[NCT*16][KCH*16] . X^T; W in LDS ([n][k], stride SW) as the
+// A operand (one ds_read_b128 per four MFMA steps: lane (n, q) holds k = 16 c + 4 q + s at step s), the activations' k blocks in registers
+// as the B operand (lane (point, q), component s: k = 16 c + 4 q + s -- the accumulator layout of the stage before)
+template <int NCT, int KCH, int SW>
+__device__ __forceinline__ void fr_stage_t(const float* W, const f32x4* x, const float* bias4, f32x4 (&acc)[NCT], int fr, int fq) {
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ct = 0; ct < NCT; ++ct) acc[ct] = *reinterpret_cast<const f32x4*>(bias4 + ct * 16);
 #pragma unroll
   for (int c = 0; c < KCH; ++c) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(A + fr * SA + 16 * c + 4 * fq);
-    f32x4 b[NCT];
+    f32x4 w[NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) b[ct] = *reinterpret_cast<const f32x4*>(W + (ct * 16 + fr) * SW + 16 * c + 4 * fq);
+    for (int ct = 0; ct < NCT; ++ct) w[ct] = *reinterpret_cast<const f32x4*>(W + (ct * 16 + fr) * SW + 16 * c + 4 * fq);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[ct][s], acc[ct], 0, 0, 0);
+      for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ct][s], x[c][s], acc[ct], 0, 0, 0);
   }
 }
 
-// relu(D + bias) -> [row][col0 + ...] of the next stage's A tile (lane (fr, fq), register i: row 4 fq + i, column 16 ct + fr)
-template <int NCT, int SD>
-__device__ __forceinline__ void fr_store(const f32x4 (&acc)[NCT], const float* bias, float* D, int col0, int fr, int fq) {
+template <int NCT>
+__device__ __forceinline__ void fr_relu_t(const f32x4 (&acc)[NCT], f32x4 (&out)[NCT]) {
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) {
-    const float bv = bias[ct * 16 + fr];
+  for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) D[(4 * fq + i) * SD + col0 + ct * 16 + fr] = fmaxf(acc[ct][i] + bv, 0.f);
-  }
+    for (int i = 0; i < 4; ++i) out[ct][i] = fmaxf(acc[ct][i], 0.f);
 }
 
 __global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
   __shared__ __attribute__((aligned(16))) float sh[FR_SHARED_END];
-  __shared__ __attribute__((aligned(16))) float act[4 * FR_ACT_WAVE];
+  __shared__ float scale_s[208];                   // per-channel BatchNorm scales while the weights are folded
   __shared__ float sc[FR_MAXN];                    // raw scores of the frame's points
   __shared__ float comb[2][4][66];                 // per wave: running max, running sum, 64 weighted column sums (double buffered)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,8 +103,8 @@ __global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
     constexpr int Cp[6] = {16, 16, 32, 32, 48, 64}, Kp[6] = {16, 16, 16, 32, 32, 48};
     constexpr int Sw[6] = {FR_S16, FR_S16, FR_S16, FR_S32, FR_S32, FR_S48};
     constexpr int Wo[6] = {FR_W1, FR_W2, FR_W3, FR_G1, FR_G2, FR_G3}, Bo[6] = {FR_B1, FR_B2, FR_B3, FR_C1, FR_C2, FR_C3};
-    constexpr int So[6] = {0, 16, 32, 64, 96, 144};                    // per-channel scales, 208 floats at the head of `act`
-    float* const scale = act;
+    constexpr int So[6] = {0, 16, 32, 64, 96, 144};                    // per-channel scales
+    float* const scale = scale_s;
     if (tid < 64) {
       float g[6], v[6], m[6], e[6], c[6];
 #pragma unroll
@@ -133,7 +130,9 @@ __global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
 #pragma unroll
       for (int u = 0; u < Cp[L] * Kp[L] / 256; ++u) {
         const int i = tid + 256 * u, n = i / Kp[L], k = i - n * Kp[L];
-        w[u0 + u] = p.l[L].W[min(n, Cn[L] - 1) * Kn[L] + min(k, Kn[L] - 1)];
+        // GlobalPointNet conv1 (L = 3): tile column k < 24 holds input column 4 + k (PointNet feature k), 24..27 the point columns 0..3
+        const int ks = L == 3 ? (k < 24 ? k + 4 : (k < 28 ? k - 24 : Kn[L] - 1)) : min(k, Kn[L] - 1);
+        w[u0 + u] = p.l[L].W[min(n, Cn[L] - 1) * Kn[L] + ks];
       }
       u0 += Cp[L] * Kp[L] / 256;
     }
@@ -153,7 +152,6 @@ __global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
   const float attn_b = p.attn_b ? p.attn_b[0] : 0.f;
   __syncthreads();
 
-  float* const A = act + wave * FR_ACT_WAVE;
   const int N = p.N, nslab = N / FR_SLAB;
   int par = 0;
   for (long f = blockIdx.x; f < p.F; f += gridDim.x, par ^= 1) {
@@ -166,10 +164,14 @@ __global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
     for (int i = 0; i < 3; ++i) tt[i] = tf[i];
     float* xf = p.x + f * (long)N * 6;
     const float* xs = p.x_src ? p.x_src + f * (long)N * 6 : xf;
-    // running softmax state of this wave: max, sum, and this lane's share of the weighted column sums (column 16 ct + fr, rows of
-    // lane group fq; the four groups are added at the end)
-    float m_run = -INFINITY, s_run = 0.f;
-    float col[4] = {0.f, 0.f, 0.f, 0.f};
+    // running softmax state of this wave: the maximum (wave-uniform) and, per lane, its point's share of the denominator and of the
+    // 16 weighted feature sums it holds (features 16 ct + 4 fq + i); the lanes are added once per frame
+    float m_run = -INFINITY, s_part = 0.f;
+    float col[4][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) col[ct][i] = 0.f;
     // the slab's 16 points: every lane loads the row of point (lane & 15) (24 bytes; the four 16-lane groups load the same rows:
     // no branch around the loads), and the NEXT slab's rows are requested before the current slab is computed
     float2 c01, c23, c45;
@@ -187,102 +189,91 @@ __global__ __launch_bounds__(256) void upper_front_eval_kernel(FrontP p) {
         c23 = *reinterpret_cast<const float2*>(xs + rown * 6 + 2);
         c45 = *reinterpret_cast<const float2*>(xs + rown * 6 + 4);
       }
+      const float d0 = __fsub_rn(v01.x, tt[0]), d1 = __fsub_rn(v01.y, tt[1]), d2 = __fsub_rn(v23.x, tt[2]);
+      const float h0 = fr_dot3_nofma(r[0], r[1], r[2], d0, d1, d2);
+      const float h1 = fr_dot3_nofma(r[3], r[4], r[5], d0, d1, d2);
+      const float h2 = fr_dot3_nofma(r[6], r[7], r[8], d0, d1, d2);
       if (lane < FR_SLAB) {
         const long row = (long)s * FR_SLAB + lane;
-        const float d0 = __fsub_rn(v01.x, tt[0]), d1 = __fsub_rn(v01.y, tt[1]), d2 = __fsub_rn(v23.x, tt[2]);
-        const float h0 = fr_dot3_nofma(r[0], r[1], r[2], d0, d1, d2);
-        const float h1 = fr_dot3_nofma(r[3], r[4], r[5], d0, d1, d2);
-        const float h2 = fr_dot3_nofma(r[6], r[7], r[8], d0, d1, d2);
         *reinterpret_cast<float2*>(xf + row * 6) = make_float2(h0, h1);
         *reinterpret_cast<float2*>(xf + row * 6 + 2) = make_float2(h2, v23.y);
         if (p.x_src) *reinterpret_cast<float2*>(xf + row * 6 + 4) = v45;
-        float* a0 = A + FR_ACT_P + lane * FR_S16;
-        *reinterpret_cast<f32x4*>(a0) = (f32x4){h0, h1, h2, v23.y};
-        *reinterpret_cast<f32x4*>(a0 + 4) = (f32x4){v45.x, v45.y, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(a0 + 8) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(a0 + 12) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float* fz = A + FR_ACT_FZ + lane * FR_S32;                         // concat: the first four point columns ...
-        *reinterpret_cast<f32x4*>(fz) = (f32x4){h0, h1, h2, v23.y};
-        *reinterpret_cast<f32x4*>(fz + 28) = (f32x4){0.f, 0.f, 0.f, 0.f};  // ... and the k padding behind the 24 features
       }
-      __builtin_amdgcn_wave_barrier();
-      // (wave-private LDS: a wave's LDS operations complete in issue order, so the tile written by some lanes is what the other
-      // lanes read; wave_barrier only keeps the compiler from moving code across the hand-over)
+      // the point's six columns as the first stage's B operand (k = 4 fq + s): group 0: h0 h1 h2 x3, group 1: x4 x5 0 0, groups 2, 3: 0
+      const f32x4 xcols = {h0, h1, h2, v23.y};
+      const f32x4 x45 = {v45.x, v45.y, 0.f, 0.f};
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 bx = fq == 0 ? xcols : fq == 1 ? x45 : zero4;
       f32x4 a1[1], a2[1], a3[2], g1[2], g2[3], g3[4];
-      fr_stage<1, 1, FR_S16, FR_S16>(A + FR_ACT_P, sh + FR_W1, a1, fr, fq);
-      fr_store<1, FR_S16>(a1, sh + FR_B1, A + FR_ACT_Q, 0, fr, fq);
-      fr_stage<1, 1, FR_S16, FR_S16>(A + FR_ACT_Q, sh + FR_W2, a2, fr, fq);
-      fr_store<1, FR_S16>(a2, sh + FR_B2, A + FR_ACT_P, 0, fr, fq);
-      fr_stage<2, 1, FR_S16, FR_S16>(A + FR_ACT_P, sh + FR_W3, a3, fr, fq);
-      // PointNet's 24 features land behind the four point columns: columns 4..27 of the concat tile (the padded outputs 24..31
-      // of the stage are zero and would land in columns 28..35: only columns < 28 are stored)
-      {
-        const float b0 = sh[FR_B3 + fr], b1 = sh[FR_B3 + 16 + fr];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float* d = A + FR_ACT_FZ + (4 * fq + i) * FR_S32 + 4;
-          d[fr] = fmaxf(a3[0][i] + b0, 0.f);
-          if (fr < 8) d[16 + fr] = fmaxf(a3[1][i] + b1, 0.f);
-        }
-      }
-      fr_stage<2, 2, FR_S32, FR_S32>(A + FR_ACT_FZ, sh + FR_G1, g1, fr, fq);
-      fr_store<2, FR_S32>(g1, sh + FR_C1, A + FR_ACT_P, 0, fr, fq);            // G1 tile [16][36] over P | Q
-      fr_stage<3, 2, FR_S32, FR_S32>(A + FR_ACT_P, sh + FR_G2, g2, fr, fq);
-      fr_store<3, FR_S48>(g2, sh + FR_C2, A + FR_ACT_G2, 0, fr, fq);
-      fr_stage<4, 3, FR_S48, FR_S48>(A + FR_ACT_G2, sh + FR_G3, g3, fr, fq);
-      // ---- scores and the online softmax update.  Lane (fr, fq), register i: point 4 fq + i of the slab, columns 16 ct + fr.
-      float y[4][4], part[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) part[i] = 0.f;
+      f32x4 p1[1], p2[1], f01[2], q01[2], r012[3];
+      // (the biases and score weights are read from LDS in every slab: the offset is opaque to the compiler, which would otherwise keep
+      //  all 17 float4 of them in registers across the loop)
+      int bo = 4 * fq;
+      asm volatile("" : "+v"(bo));
+      const float* const b4 = sh + bo;
+      fr_stage_t<1, 1, FR_S16>(sh + FR_W1, &bx, b4 + FR_B1, a1, fr, fq);
+      fr_relu_t<1>(a1, p1);
+      fr_stage_t<1, 1, FR_S16>(sh + FR_W2, p1, b4 + FR_B2, a2, fr, fq);
+      fr_relu_t<1>(a2, p2);
+      fr_stage_t<2, 1, FR_S16>(sh + FR_W3, p2, b4 + FR_B3, a3, fr, fq);
+      fr_relu_t<2>(a3, f01);
+      // concat: features 0..15 | features 16..23, the four point columns, padding (the stage's padded outputs 24..31 are zero)
+      if (fq == 2) f01[1] = xcols;
+      fr_stage_t<2, 2, FR_S32>(sh + FR_G1, f01, b4 + FR_C1, g1, fr, fq);
+      fr_relu_t<2>(g1, q01);
+      fr_stage_t<3, 2, FR_S32>(sh + FR_G2, q01, b4 + FR_C2, g2, fr, fq);
+      fr_relu_t<3>(g2, r012);
+      fr_stage_t<4, 3, FR_S48>(sh + FR_G3, r012, b4 + FR_C3, g3, fr, fq);
+      // ---- scores and the online softmax update.  Lane (fr, fq), register i of tile ct: feature 16 ct + 4 fq + i of point fr.
+      float y[4][4], part = 0.f;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        const float bv = sh[FR_C3 + ct * 16 + fr], wv = sh[FR_AW + ct * 16 + fr];
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(b4 + FR_AW + ct * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          y[ct][i] = fmaxf(g3[ct][i] + bv, 0.f);
-          part[i] += y[ct][i] * wv;
+          y[ct][i] = fmaxf(g3[ct][i], 0.f);
+          part += y[ct][i] * wv[i];
         }
       }
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);                                          // sum over the four feature groups: the point's score
+      part += attn_b;
+      if (fq == 0) sc[s * FR_SLAB + fr] = part;
+      float smax = part;
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) part[i] += __shfl_xor(part[i], o, 64);      // sum over the 16 lanes of a group: all columns
-      float smax = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { part[i] += attn_b; smax = fmaxf(smax, part[i]); }
-      if (fr == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sc[s * FR_SLAB + 4 * fq + i] = part[i];
-      }
-      smax = fmaxf(smax, __shfl_xor(smax, 16, 64));
-      smax = fmaxf(smax, __shfl_xor(smax, 32, 64));                              // max over the slab's 16 points
+      for (int o = 1; o < 16; o <<= 1) smax = fmaxf(smax, __shfl_xor(smax, o, 64));   // max over the slab's 16 points
       const float m_new = fmaxf(m_run, smax);
-      const float resc = __expf(m_run - m_new);                                  // (exp(-inf) = 0 on the first slab)
-      float e[4], esum = 0.f;
+      if (m_new != m_run) {                                                      // wave-uniform; rare after a frame's first slabs
+        const float resc = __expf(m_run - m_new);                                // (exp(-inf) = 0 on the first slab)
+        s_part *= resc;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { e[i] = __expf(part[i] - m_new); esum += e[i]; }
-      esum += __shfl_xor(esum, 16, 64);
-      esum += __shfl_xor(esum, 32, 64);
-      s_run = s_run * resc + esum;
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        float v = col[ct] * resc;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v += e[i] * y[ct][i];
-        col[ct] = v;
+          for (int i = 0; i < 4; ++i) col[ct][i] *= resc;
+        m_run = m_new;
       }
-      m_run = m_new;
-    }
-    // ---- combine the four waves (fixed order) and emit the frame's outputs
+      const float e = __expf(part - m_run);
+      s_part += e;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      col[ct] += __shfl_xor(col[ct], 16, 64);
-      col[ct] += __shfl_xor(col[ct], 32, 64);
-    }
-    if (lane < 16) {
+      for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) comb[par][wave][2 + ct * 16 + lane] = col[ct];
-      if (lane == 0) { comb[par][wave][0] = m_run; comb[par][wave][1] = s_run; }
+        for (int i = 0; i < 4; ++i) col[ct][i] += e * y[ct][i];
+    }
+    // ---- add the 16 points' lanes (once per frame), then combine the four waves (fixed order) and emit the frame's outputs
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      s_part += __shfl_xor(s_part, o, 64);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) col[ct][i] += __shfl_xor(col[ct][i], o, 64);
+    }
+    if (fr == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) comb[par][wave][2 + ct * 16 + 4 * fq + i] = col[ct][i];
+      if (lane == 0) { comb[par][wave][0] = m_run; comb[par][wave][1] = s_part; }
     }
     __syncthreads();
     float M = comb[par][0][0];
@@ -319,7 +310,7 @@ extern "C" int mmego_upper_front_eval(void* stream, float* x, const float* x_src
   }
   MMEGO_REQUIRE(w[36]);
   p.attn_w = w[36]; p.attn_b = w[37]; p.eps = eps; p.vec = vec; p.attn = attn;
-  const unsigned grid = (unsigned)(F < 512 ? F : 512);          // ~72 KB of LDS: two workgroups per CU, frames walked persistently
+  const unsigned grid = (unsigned)(F < 1024 ? F : 1024);        // ~34 KB of LDS: four workgroups per CU, frames walked persistently
   hipLaunchKernelGGL(upper_front_eval_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
