@@ -230,7 +230,7 @@ struct TileBigArgs {
 
 template <int DUMMY>
 __global__ __launch_bounds__(512, 1) void gemm_tile_big_kernel(TileP p, TileBigArgs g) {
-  constexpr int BM = 320, BN = 256, KCH = 32, ROWS = BM + BN, NDMA = ROWS / 8, STAGE = ROWS * KCH;   // floats per stage
+  constexpr int BM = 320, BN = 256, KCH = 32, ROWS = BM + BN, STAGE = ROWS * KCH;   // floats per stage (72 8-row transfers)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

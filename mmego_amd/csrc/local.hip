@@ -731,8 +731,7 @@ __global__ __launch_bounds__(P8_NT) void pool128_bwd_kernel(Pool128BwdP p) {
   float* T = tiles + fr * 128 * P128_TS;
   float* at_s = aux + fr * (128 + 128 + 64 + 4);
   float* ds_s = at_s + 128;
-  float* dv_s = ds_s + 128;
-  float* tv_s = dv_s + 64;
+  float* dv_s = ds_s + 128;                 // (the last 4 floats of the frame's aux block, at dv_s + 64, are spare)
   const long F = p.rows / 128;
   const long f = (long)blockIdx.x * 2 + fr;
   const bool in = f < F;

@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256, 1) void s3_step_kernel(S3StepP p) {
   const int own_r0 = own_mi * 32 + 16 * (w & 1);       // accumulator registers own_i0 .. own_i0 + 8 of row block own_mi
   const int last_rb = (p.Bn - 1) >> 5;
   const int hb = H >> 5;
-  const int s3_stamp_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  [[maybe_unused]] const int s3_stamp_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   MMEGO_STAMP_AT(s3_stamp_id, 0, tid == 0);
 
   // operand pointers and the first two steps' fragment requests go out BEFORE the cell update's own operands (xproj tile, c_{t-1}):
