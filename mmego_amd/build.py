@@ -27,8 +27,10 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-ffp-contract=
 # v_accvgpr_read_b32 first (r06: 342 -> 290 instructions per slab and wave).
 # -fno-honor-nans there: relu(x) is one v_max_f32 instead of two (the first canonicalises a possible signalling NaN); the file holds one
 # eval-mode kernel whose inputs are finite activations.
-_FRONT = ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]
-FILE_FLAGS = {"front_bf16.hip": _FRONT, "front.hip": _FRONT}        # (front.hip: the fp32 form of the same kernel, same reasons)
+_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+# (front.hip, the fp32 form of the same kernel: accumulators in VGPRs too, but NaNs stay honoured there -- a NaN in the input of the
+#  default path has to come out as a NaN, as it does from the reference)
+FILE_FLAGS = {"front_bf16.hip": _VGPR_FORM + ["-fno-honor-nans"], "front.hip": _VGPR_FORM}
 # (the host pass of the same command line does not know the amdgcn feature and says so once per file)
 _HOST_NOISE = ("'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)", "1 warning generated when compiling for host.")
 
