@@ -462,9 +462,12 @@ __global__ __launch_bounds__(WM * 128, 2) void s3_gemm_kernel(S3GemmP p) {
 //   (global_load_lds_dwordx4: 54 1-KB transfers per step, 7 per wave, no VGPRs -- the register-staged copy of the kernel above would need
 //   56 more), into a ring of TWO 54-KB stages; one barrier per step, placed INSIDE the step (see the schedule in the kernel).
 //   Tile order: an XCD's 64 tiles are two rounds of 4 row panels x 8 column tiles over the SAME 4 row panels (A panels stay in its L2).
-template <int NPROD>
+//   TRB = 10 (320-row tiles: the projections) or 8 (256-row tiles, wave tile 128 x 64: products whose row count is a multiple of 256 but
+//   not of 320 -- the weight gradients of stage-1 training, 2048 / 4096 rows over K = 10 240).  grid.y = K slabs (p.cps 32-k chunks each):
+//   slab y leaves its partial product at C + y * p.slab (mmego_split3_gemm_slabs), bias in slab 0 only.
+template <int NPROD, int TRB>
 __global__ __launch_bounds__(512, 1) void s3_gemm_big_kernel(S3GemmP p) {
-  constexpr int TRB = 10, TCB = 8, NBLK = (TRB + TCB) * 3;       // 1-KB blocks per step and stage
+  constexpr int TCB = 8, NBLK = (TRB + TCB) * 3, MI = TRB / 2;   // 1-KB blocks per step and stage; accumulator row blocks per wave
   extern __shared__ __attribute__((aligned(16))) s3_u32x4 s3_big[];   // [2 stages][NBLK][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // (wave-uniform by construction: addresses below stay scalar)
@@ -485,8 +488,10 @@ __global__ __launch_bounds__(512, 1) void s3_gemm_big_kernel(S3GemmP p) {
     }
   }
   const int rbA0 = tm * TRB, rbW0 = tn * TCB;
-  const int SK = p.SK;
-  // this wave's transfers: blocks i = w + 8 j of a stage (i < NBLK); block i < 30: A row block i / 3, piece i % 3; else W.
+  const int SKall = p.SK;
+  const int s_first = (int)blockIdx.y * 2 * p.cps;               // this slab's 16-k steps: [s_first, s_first + SK)
+  const int SK = min(SKall - s_first, 2 * p.cps);
+  // this wave's transfers: blocks i = w + 8 j of a stage (i < NBLK); block i < 3 TRB: A row block i / 3, piece i % 3; else W.
   // Source = a wave-uniform block address (scalar registers) + 16 lane.
   const s3_u32x4* gp[7];
 #pragma unroll
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(512, 1) void s3_gemm_big_kernel(S3GemmP p) {
     const int i = min(w + 8 * j, NBLK - 1);
     const int isw = i >= TRB * 3, ii = isw ? i - TRB * 3 : i;
     const int rb = (isw ? rbW0 : rbA0) + ii / 3;
-    gp[j] = (isw ? p.W : p.A) + ((long)rb * SK * 3 + ii % 3) * 64;
+    gp[j] = (isw ? p.W : p.A) + (((long)rb * SKall + s_first) * 3 + ii % 3) * 64;
   }
 #define S3_BIG_DMA(s, stage)                                                                                          \
   {                                                                                                                   \
@@ -503,119 +508,93 @@ __global__ __launch_bounds__(512, 1) void s3_gemm_big_kernel(S3GemmP p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[j] + (long)((S3_EXP & 2) ? 0 : (s)) * 192 + lane), \
                                          (__attribute__((address_space(3))) void*)(s3_big + ((stage) * NBLK + w + 8 * j) * 64), 16, 0, 0); \
   }
-  f32x16 acc[5][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int mi = 0; mi < 5; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
   // Schedule (steps in pairs, so that every register index below is a compile-time constant).  At the top of step s its stage holds
-  // its data and its W fragments + first A fragments are requested.  Inside the step: row block mi + 1's fragments are requested in
-  // front of row block mi's 12 (18) MFMAs; in front of row block 3's -- the last read of this stage is out -- the wave waits for its
-  // reads and for its transfers of step s + 1, meets the others at THE step's one barrier, and requests step s + 2 into the stage it has
-  // just finished with; in front of row block 4's MFMAs it requests the first fragments of step s + 1.  So no barrier sits between two
-  // steps, and a transfer has a whole step (3840 cycles of MFMA issue per SIMD) to land.
+  // its data and its W fragments + first A fragments are requested.  Inside the step: in front of row block mi's 12 (18) MFMAs an empty
+  // asm READS that row block's fragments -- the compiler waits with lgkmcnt(0) wherever it waits in a loop that also holds LDS-DMA
+  // requests, so the wait has to land where only reads requested a whole MFMA group ago are outstanding -- then row block mi + 1's
+  // fragments are requested.  In front of the LAST row block's MFMAs (all of the stage's fragments are in registers) the wave waits for
+  // its transfers of step s + 1, meets the others at THE step's one barrier, requests step s + 2 into the stage it has just finished
+  // with (waves 0-3 here, waves 4-7 behind the MFMAs: a 1-KB LDS-DMA costs its wave 60-185 cycles of issue, and while one wave of a
+  // SIMD issues them the other one issues MFMAs) and the first fragments of step s + 1.  No barrier sits between two steps, and a
+  // transfer has a whole step to land.  (r06's first schedule -- requests in front of the previous group's MFMAs without the pinned
+  // wait, barrier in front of row block 3 -- was 1.5-2.5 % slower; git history.)
+  // A-fragment slots: row block mi of a step of parity par sits in slot (par + mi) & 1 for odd MI, mi & 1 for even MI -- either way the
+  // next step's first fragments, requested in front of the last row block's MFMAs, go to the slot those MFMAs do not read.
   s3_u32x4 b[2][2][3], a[2][3];
+#define S3_SLOT(par, mi) ((MI & 1) ? (((par) + (mi)) & 1) : ((mi) & 1))
 #define S3_BIG_RD_B(slot, stage)                                                                                      \
   if (!(S3_EXP & 32)) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                \
     _Pragma("unroll") for (int q = 0; q < 3; ++q) b[slot][ni][q] = s3_big[((stage) * NBLK + TRB * 3 + (wn * 2 + ni) * 3 + q) * 64 + lane];
 #define S3_BIG_RD_A(slot, stage, mi)                                                                                  \
-  if (!(S3_EXP & 32)) _Pragma("unroll") for (int q = 0; q < 3; ++q) a[slot][q] = s3_big[((stage) * NBLK + (wm * 5 + (mi)) * 3 + q) * 64 + lane];
-#define S3_BIG_STEP(s, par)                                                                                           \
-  {                                                                                                                   \
-    _Pragma("unroll") for (int mi = 0; mi < 5; ++mi) {                                                                \
-      if (mi < 4) { S3_BIG_RD_A(((par) + mi + 1) & 1, par, mi + 1) }                                                  \
-      if (mi == 3) {                                                                                                  \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                   \
-        __builtin_amdgcn_s_barrier();                                                                                 \
-        if (wm == 0 && (s) + 2 < SK) S3_BIG_DMA((s) + 2, par)                                                         \
-      }                                                                                                               \
-      if (mi == 4 && (s) + 1 < SK) {                                                                                  \
-        S3_BIG_RD_B((par) ^ 1, (par) ^ 1)                                                                             \
-        S3_BIG_RD_A(((par) ^ 1), (par) ^ 1, 0)                                                                        \
-      }                                                                                                               \
-      /* the two waves of a SIMD (w and w + 4) issue their transfers at DIFFERENT points: a 1-KB LDS-DMA costs its wave 60-185   \
-         cycles of issue (MI355X_MICROARCH.md), seven of them a fifth of a step -- while one wave of the SIMD issues them the     \
-         other one issues MFMAs */                                                                                    \
-      if (mi == 4 && wm == 1 && (s) + 2 < SK) S3_BIG_DMA((s) + 2, par)                                                 \
-      /* (no scheduling barrier here: pinning the requests in front of the group's MFMAs measured 1.5 % SLOWER than the      \
-         scheduler's own placement, same box, three alternations) */                                                 \
-      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = s3_mma<NPROD>(a[((par) + mi) & 1], b[par][ni], acc[mi][ni]); \
-      __builtin_amdgcn_sched_barrier(0);                                                                              \
-    }                                                                                                                 \
-  }
-#ifndef S3_BIG_SCHED
-#define S3_BIG_SCHED 1
-#endif
-#if S3_BIG_SCHED == 1
-  // r06, second schedule.  The compiler waits with lgkmcnt(0) wherever it waits in a loop that also holds LDS-DMA requests, so a fragment
-  // read requested just in front of the MFMAs that use the PREVIOUS read is waited for too (the first schedule: "3 ds_read, 2 MFMAs,
-  // s_waitcnt lgkmcnt(0), 10 MFMAs" per row block).  Here an empty asm that READS row block mi's fragments stands in front of the request
-  // for row block mi + 1: the wait lands there, where only reads requested a whole MFMA group ago are outstanding.  The step's barrier
-  // moves behind row block 3's MFMAs (row block 4's fragments, the stage's last read, are then in registers without a wait of their own).
-#undef S3_BIG_STEP
+  if (!(S3_EXP & 32)) _Pragma("unroll") for (int q = 0; q < 3; ++q) a[slot][q] = s3_big[((stage) * NBLK + (wm * MI + (mi)) * 3 + q) * 64 + lane];
 #define S3_USE3(x) asm volatile("" ::"v"((x)[0]), "v"((x)[1]), "v"((x)[2]))
 #define S3_BIG_STEP(s, par)                                                                                           \
   {                                                                                                                   \
-    _Pragma("unroll") for (int mi = 0; mi < 5; ++mi) {                                                                \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                               \
       if (!(S3_EXP & 32)) {                                                                                           \
-        S3_USE3(a[((par) + mi) & 1]);                                                                                 \
+        S3_USE3(a[S3_SLOT(par, mi)]);                                                                                 \
         if (mi == 0) { S3_USE3(b[par][0]); S3_USE3(b[par][1]); }                                                      \
       }                                                                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                                              \
-      if (mi < 4) { S3_BIG_RD_A(((par) + mi + 1) & 1, par, mi + 1) }                                                  \
-      if (mi == 4) {                                                                                                  \
+      if (mi < MI - 1) { S3_BIG_RD_A(S3_SLOT(par, mi + 1), par, mi + 1) }                                             \
+      if (mi == MI - 1) {                                                                                             \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
         __builtin_amdgcn_s_barrier();                                                                                 \
         if (wm == 0 && (s) + 2 < SK) S3_BIG_DMA((s) + 2, par)                                                         \
         if ((s) + 1 < SK) {                                                                                           \
           S3_BIG_RD_B((par) ^ 1, (par) ^ 1)                                                                           \
-          S3_BIG_RD_A(((par) ^ 1), (par) ^ 1, 0)                                                                      \
+          S3_BIG_RD_A(S3_SLOT((par) ^ 1, 0), (par) ^ 1, 0)                                                            \
         }                                                                                                             \
       }                                                                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                                              \
-      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = s3_mma<NPROD>(a[((par) + mi) & 1], b[par][ni], acc[mi][ni]); \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = s3_mma<NPROD>(a[S3_SLOT(par, mi)], b[par][ni], acc[mi][ni]); \
       __builtin_amdgcn_sched_barrier(0);                                                                              \
-      if (mi == 4 && wm == 1 && (s) + 2 < SK) S3_BIG_DMA((s) + 2, par)                                                 \
+      if (mi == MI - 1 && wm == 1 && (s) + 2 < SK) S3_BIG_DMA((s) + 2, par)                                            \
     }                                                                                                                 \
   }
-#endif
-  // (A-fragment slots: step parity par starts with slot par -- row block mi sits in slot (par + mi) & 1 -- so that the first
-  //  fragments of the NEXT step, requested in front of row block 4's MFMAs (slot par), go to slot par ^ 1.)
   S3_BIG_DMA(0, 0)
   if (SK > 1) S3_BIG_DMA(1, 1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   S3_BIG_RD_B(0, 0)
-  S3_BIG_RD_A(0, 0, 0)
+  S3_BIG_RD_A(S3_SLOT(0, 0), 0, 0)
   for (int s = 0; s < SK; s += 2) {
     S3_BIG_STEP(s, 0)
     if (s + 1 < SK) S3_BIG_STEP(s + 1, 1)
   }
 #undef S3_BIG_STEP
 #undef S3_USE3
+#undef S3_SLOT
 #undef S3_BIG_RD_A
 #undef S3_BIG_RD_B
 #undef S3_BIG_DMA
   const int fr = lane & 31;
+  float* const Cs = p.C ? p.C + (long)blockIdx.y * p.slab : nullptr;
+  float* const Cfs = p.Cf ? p.Cf + (long)blockIdx.y * p.slab : nullptr;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int cb = rbW0 + wn * 2 + ni;
-    const float bv = p.bias ? p.bias[cb * 32 + fr] : 0.f;
+    const float bv = (p.bias && blockIdx.y == 0) ? p.bias[cb * 32 + fr] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 5; ++mi) {
-      const int rbm = rbA0 + wm * 5 + mi;
+    for (int mi = 0; mi < MI; ++mi) {
+      const int rbm = rbA0 + wm * MI + mi;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mi][ni][i] += bv;
-      if (p.Cf) {
-        float* t = p.Cf + ((long)rbm * p.Nrb + cb) * 1024 + lane * 4;
+      if (Cfs) {
+        float* t = Cfs + ((long)rbm * p.Nrb + cb) * 1024 + lane * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *reinterpret_cast<f32x4*>(t + q * 256) = (f32x4){acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
       }
-      if (p.C) {
-        float* cp = p.C + (long)(rbm * 32 + 4 * (lane >> 5)) * p.ldc + cb * 32 + fr;
+      if (Cs) {
+        float* cp = Cs + (long)(rbm * 32 + 4 * (lane >> 5)) * p.ldc + cb * 32 + fr;
         const int rows_left = p.M - (rbm * 32 + 4 * (lane >> 5));
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -636,30 +615,50 @@ static int s3_gemm_launch(void* stream, const unsigned short* A, const unsigned 
   MMEGO_REQUIRE(!C || (M > 0 && M <= Mrb * 32 && ldc >= Nrb * 32));
   MMEGO_REQUIRE((long)Mrb * (K / 16) * 192 < (1L << 31) && (long)Nrb * (K / 16) * 192 < (1L << 31));
   MMEGO_REQUIRE(nsplit >= 1 && nsplit <= 64 && (nsplit == 1 || slab > 0));
-  // wm = 0 (the library's choice) or 10: 320 x 256 tiles where they divide the product and fill the chip (the projections of rnn_fast:
-  // 10 240 x 4096 = 512 tiles)
-  if ((wm == 0 || wm == 10) && nsplit == 1 && Mrb % 10 == 0 && Nrb % 8 == 0 && (long)(Mrb / 10) * (Nrb / 8) >= (wm == 10 ? 1 : 256)) {
-    S3GemmP p;
-    p.A = reinterpret_cast<const s3_u32x4*>(A); p.W = reinterpret_cast<const s3_u32x4*>(W);
-    p.Cf = Cf; p.C = C; p.ldc = ldc; p.bias = bias; p.Mrb = Mrb; p.Nrb = Nrb; p.SK = K / 16; p.M = M;
-    p.tiles_m = Mrb / 10; p.tiles_n = Nrb / 8; p.gm = 4; p.cps = K / 32; p.slab = 0;
-    constexpr int lds = 2 * 54 * 1024;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MMEGO_EBADARG;
-    if (!attr_set[dev]) {
-      hipError_t e = hipFuncSetAttribute((const void*)s3_gemm_big_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s3_gemm_big_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return (int)e;
-      attr_set[dev] = true;
+  // wm = 0 (the library's choice), 10 or 8: 320 x 256 / 256 x 256 tiles where they divide the product and (with the K slabs) fill the
+  // chip -- the projections of rnn_fast (10 240 x 4096 = 512 tiles of 320 x 256), the weight gradients of stage-1 training (2048 / 4096
+  // rows: 256 x 256 tiles x K slabs)
+  {
+    const int cps = cdiv(K / 32, nsplit);
+    const bool fits10 = Mrb % 10 == 0 && Nrb % 8 == 0, fits8 = Mrb % 8 == 0 && Nrb % 8 == 0;
+    const long t10 = fits10 ? (long)(Mrb / 10) * (Nrb / 8) * nsplit : 0, t8 = fits8 ? (long)(Mrb / 8) * (Nrb / 8) * nsplit : 0;
+    int trb = 0;
+    if (wm == 10 && fits10) trb = 10;
+    else if (wm == 8 && fits8) trb = 8;
+    else if (wm == 0 && t10 >= 256) trb = 10;
+    else if (wm == 0 && t8 >= 256 && (nsplit == 1 || 2 * cps >= 16)) trb = 8;        // (slabs of at least 256 k)
+    if (trb) {
+      MMEGO_REQUIRE((long)(nsplit - 1) * cps < K / 32);          // (no empty slab)
+      S3GemmP p;
+      p.A = reinterpret_cast<const s3_u32x4*>(A); p.W = reinterpret_cast<const s3_u32x4*>(W);
+      p.Cf = Cf; p.C = C; p.ldc = ldc; p.bias = bias; p.Mrb = Mrb; p.Nrb = Nrb; p.SK = K / 16; p.M = M;
+      p.tiles_m = Mrb / trb; p.tiles_n = Nrb / 8; p.gm = 4; p.cps = cps; p.slab = slab;
+      constexpr int lds = 2 * 54 * 1024;
+      static bool attr_set[64] = {};
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MMEGO_EBADARG;
+      if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)s3_gemm_big_kernel<6, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s3_gemm_big_kernel<9, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s3_gemm_big_kernel<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)s3_gemm_big_kernel<9, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+      }
+      const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)nsplit);
+      hipStream_t st = (hipStream_t)stream;
+      if (trb == 10) {
+        if (nprod == 6) s3_gemm_big_kernel<6, 10><<<grid, 512, lds, st>>>(p);
+        else s3_gemm_big_kernel<9, 10><<<grid, 512, lds, st>>>(p);
+      } else {
+        if (nprod == 6) s3_gemm_big_kernel<6, 8><<<grid, 512, lds, st>>>(p);
+        else s3_gemm_big_kernel<9, 8><<<grid, 512, lds, st>>>(p);
+      }
+      MMEGO_LAUNCH_CHECK();
+      return MMEGO_OK;
     }
-    const unsigned tiles = (unsigned)(p.tiles_m * p.tiles_n);
-    if (nprod == 6) s3_gemm_big_kernel<6><<<tiles, 512, lds, (hipStream_t)stream>>>(p);
-    else s3_gemm_big_kernel<9><<<tiles, 512, lds, (hipStream_t)stream>>>(p);
-    MMEGO_LAUNCH_CHECK();
-    return MMEGO_OK;
   }
-  if (wm == 10) return MMEGO_EBADARG;
+  if (wm == 10 || wm == 8) return MMEGO_EBADARG;
   if (wm == 0) {
     const long t128 = (long)cdiv(Mrb, 4) * cdiv(Nrb, 4) * nsplit;        // 128 x 128 tiles
     wm = t128 < 256 ? 1 : (Mrb >= 64 && (long)cdiv(Mrb, 8) * cdiv(Nrb, 4) * nsplit >= 256 ? 4 : 2);     // fewer tiles than CUs: smaller tiles

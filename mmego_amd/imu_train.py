@@ -19,13 +19,29 @@ def _s3_worth(rows, N, K):
 
 
 def _s3_nsplit(M, N, K):
-    """K slabs of a split3 weight-gradient product: enough 256 x 128 (or 128 x 128) tiles x slabs to cover the chip twice, slabs of at
-    least 1024 k."""
-    tiles = ((M + 255) // 256) * ((N + 127) // 128)
-    ns = int(max(1, min(512 // max(tiles, 1), K // 1024, 64)))
+    """K slabs of a split3 weight-gradient product: 256 x 256 tiles (s3_gemm_big_kernel<., 8>, one workgroup per CU) x slabs cover the chip
+    once, slabs of at least 512 k (r06; before: 256 x 128 tiles x slabs twice over the chip, slabs of at least 1024 k)."""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    ns = int(max(1, min(256 // max(tiles, 1), K // 512, 64)))
     chunks = K // 32
     cps = (chunks + ns - 1) // ns
     return (chunks + cps - 1) // cps          # (no empty slab)
+
+
+def _s3_slabs_320(M, N, K):
+    """K slabs that bring a product of M x N outputs (M % 320 == 0, N % 256 == 0) to the 256 tiles of 320 x 256 that s3_gemm_big_kernel
+    wants (one per CU), slabs of at least 512 k; 1: no slabs (the product has the tiles by itself, or does not fit)."""
+    if M % 320 or N % 256:
+        return 1
+    tiles = (M // 320) * (N // 256)
+    if tiles >= 256:
+        return 1
+    ns = int(min(256 // tiles, K // 512, 64))
+    if ns < 2 or tiles * ns < 256:
+        return 1
+    chunks = K // 32
+    cps = (chunks + ns - 1) // ns
+    return (chunks + cps - 1) // cps
 
 
 def _s3_pieces(ar, name, x):
@@ -154,7 +170,17 @@ def lstm_steps_backward(ar, key, lstm, x, Bn, T, dout, G, need_dx, split3=False)
                 WT = ar.get("%s.s3wT%d" % (key, l), (In, 8 * H))
                 hip.call("transpose_batched", Wst, WT, 1, 8 * H, In)
                 wtp = _s3_pieces(ar, "%s.s3wTp%d" % (key, l), WT)
-                hip.call("split3_gemm", dgp, wtp, None, dinp, dinp.stride(0), None, Bn * T // 32, In // 32, 8 * H, Bn * T, 6, 0)
+                rows = Bn * T
+                ns = _s3_slabs_320(rows, In, 8 * H)
+                if ns > 1 and dinp.is_contiguous():
+                    # 10 240 x {512, 1024} outputs are 64 / 128 tiles of 320 x 256: with K cut into 4 / 2 slabs the product runs on
+                    # s3_gemm_big_kernel (one workgroup per CU, 0.55 instead of 0.34 of the bf16 peak) and a streaming sum adds the
+                    # slabs in order
+                    ws = ar.get("%s.s3ws_dx%d" % (key, l), (ns * rows * In,))
+                    hip.call("split3_gemm_slabs", dgp, wtp, ws, rows // 32, In // 32, 8 * H, 6, 0, ns)
+                    hip.call("split3_slab_sum", ws, ns, rows * In, dinp)
+                else:
+                    hip.call("split3_gemm", dgp, wtp, None, dinp, dinp.stride(0), None, rows // 32, In // 32, 8 * H, rows, 6, 0)
             elif Wst is not None:
                 # [W_ih ; W_ih_reverse] back to back in the flat buffer (flat_param_order): one product with K = 8H instead of a
                 # product and an accumulating one.  (Against the transposed stack, both operands K-contiguous, the 10 240-row

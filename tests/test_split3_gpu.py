@@ -135,7 +135,10 @@ def test_split3_gemm_against_float64(dev, M, N, K, wm):
     assert errs[9] < max(3.0 * e_native, 3e-7 * scale), (errs, e_native, scale)
 
 
-@pytest.mark.parametrize("R,Co,Ci,ns", [(10240, 4096, 512, 8), (10240, 2048, 512, 10), (512, 64, 96, 2), (1024, 100, 33, 3)])
+# (r06: the first, fifth and sixth shape take 256 x 256 tiles x slabs on s3_gemm_big_kernel<., 8> -- stage-1 training's weight gradients;
+#  the others the 256 x 128 / 64 x 128 kernel)
+@pytest.mark.parametrize("R,Co,Ci,ns", [(10240, 4096, 512, 8), (10240, 2048, 512, 10), (512, 64, 96, 2), (1024, 100, 33, 3),
+                                        (10240, 2048, 512, 16), (10240, 4096, 1024, 4)])
 def test_split3_weight_gradient_product_in_k_slabs(dev, R, Co, Ci, ns):
     """dW = dY^T X on piece products (stage-1 training with IMUNet.train_precision = "split3"): mmego_split3_cvt_t's pieces of a
     transpose are bit-identical to mmego_split3_cvt of the explicit transpose; the K-slab product (mmego_split3_gemm_slabs) + the
