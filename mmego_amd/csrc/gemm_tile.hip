@@ -226,6 +226,9 @@ __global__ __launch_bounds__(256) void gemm_tile_persistent_kernel(TileP p, int 
 //   Epilogue: bias added in the accumulators, row-major stores of 128 contiguous bytes per half wave.
 struct TileBigArgs {
   int tiles_m, tiles_n;       // 320-row panels, 256-column tiles per batch entry
+  // (grid.y = p.nsplit K slabs: slab y covers k in [y * p.kchunk, min(K, (y + 1) * p.kchunk)) and leaves its partial product at
+  //  p.ws + y * M * N, row stride N -- the deferred split-K format of mmego_gemm (accumulate = 2): products with fewer than 256 tiles,
+  //  e.g. the input-gradient products of stage-1 training, 10 240 x {512, 1024} outputs over K = 4096)
 };
 
 template <int DUMMY>
@@ -255,8 +258,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tile_big_kernel(TileP p, TileBigA
     }
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  const float* Ab = p.A + (long)batch * p.sAb + (long)m0 * p.lda;
-  const float* Wb = p.W + (long)batch * p.sWb + (long)n0 * p.ldw;
+  const int kbeg = p.nsplit > 1 ? (int)blockIdx.y * p.kchunk : 0;
+  const int kend = p.nsplit > 1 ? min(p.K, kbeg + p.kchunk) : p.K;
+  const float* Ab = p.A + (long)batch * p.sAb + (long)m0 * p.lda + kbeg;
+  const float* Wb = p.W + (long)batch * p.sWb + (long)n0 * p.ldw + kbeg;
   // this wave's transfers: row groups i = w + 8 j (8 rows each) of a stage, j < 9; group i < 40: A rows 8 i .. 8 i + 7, else W rows.
   // lane l: row 8 i + l / 8, LDS piece position l % 8 <- source piece (l % 8) ^ ((row >> 1) & 7)
   const float* gp[9];
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tile_big_kernel(TileP p, TileBigA
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp[j] + (long)(kt) * KCH),            \
                                        (__attribute__((address_space(3))) void*)(smem + (stage) * STAGE + (w + 8 * j) * 8 * KCH), 16, 0, 0); \
   }
-  const int nk = p.K / KCH;
+  const int nk = (kend - kbeg) / KCH;
   const int r = lane & 31, h = lane >> 5, key = (r >> 1) & 7;
   // fragment addresses: row (base + r) of the stage, piece (2 kb + h) ^ key -- the row bases are multiples of 32, so the key is the lane's
   int off[4];
@@ -381,17 +386,19 @@ __global__ __launch_bounds__(512, 1) void gemm_tile_big_kernel(TileP p, TileBigA
   }
 #endif
 #undef GTB_DMA
-  float* C = p.C + (long)batch * p.sCb;
+  const bool slabs = p.nsplit > 1;
+  float* C = slabs ? p.ws + (long)blockIdx.y * p.M * p.N : p.C + (long)batch * p.sCb;
+  const long ldc = slabs ? (long)p.N : p.ldc;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn * 64 + j * 32 + r;
-    const float bv = p.bias ? p.bias[(long)batch * p.sBiasb + col] : 0.0f;
+    const float bv = (p.bias && !slabs) ? p.bias[(long)batch * p.sBiasb + col] : 0.0f;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      float* cp = C + (long)(m0 + wm * 160 + i * 32 + 4 * h) * p.ldc + col;
+      float* cp = C + (long)(m0 + wm * 160 + i * 32 + 4 * h) * ldc + col;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
-        if (!(GTB_EXP & 4) || acc[i][j][reg] == 12345.f) cp[(long)((reg & 3) + 8 * (reg >> 2)) * p.ldc] = acc[i][j][reg] + bv;
+        if (!(GTB_EXP & 4) || acc[i][j][reg] == 12345.f) cp[(long)((reg & 3) + 8 * (reg >> 2)) * ldc] = acc[i][j][reg] + bv;
     }
   }
 }
@@ -432,8 +439,14 @@ static int launch_layout(hipStream_t st, const TileP& p) {
     // 320 x 256 tiles by LDS-DMA where the output is whole rounds of them (MMEGO_GEMM_BIG=0: the 128 x 128 walk, for A/B runs)
     static const bool big = !(getenv("MMEGO_GEMM_BIG") && atoi(getenv("MMEGO_GEMM_BIG")) == 0);
     const long tiles = (long)(p.M / 320) * (p.N / 256) * p.nbatch;
-    if (big && (p.M % 320) == 0 && (p.N % 256) == 0 && (p.K % 32) == 0 && p.K >= 64 && p.nsplit == 1 && !p.relu && !p.accumulate &&
-        tiles >= 256 && (tiles % 256) == 0 && tiles < (1L << 30) && (p.lda % 4) == 0 && (p.ldw % 4) == 0 && (p.sAb % 4) == 0 && (p.sWb % 4) == 0 &&
+    // (K slabs: only the deferred form -- accumulate = 2, one batch entry, the caller sums the slabs -- and only where tiles x slabs is
+    //  whole rounds of the chip)
+    const bool slab_ok = p.nsplit == 1 ? !p.accumulate
+                                       : (p.accumulate == 2 && p.nbatch == 1 && p.ws && !p.bias && (p.kchunk % 32) == 0 && p.kchunk >= 64 &&
+                                          (long)(p.nsplit - 1) * p.kchunk < p.K && (p.K - (long)(p.nsplit - 1) * p.kchunk) >= 64);
+    const long units = tiles * p.nsplit;
+    if (big && (p.M % 320) == 0 && (p.N % 256) == 0 && (p.K % 32) == 0 && p.K >= 64 && slab_ok && !p.relu &&
+        units >= 256 && (units % 256) == 0 && tiles < (1L << 30) && (p.lda % 4) == 0 && (p.ldw % 4) == 0 && (p.sAb % 4) == 0 && (p.sWb % 4) == 0 &&
         ((((uintptr_t)p.A) | ((uintptr_t)p.W)) & 15) == 0) {
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
@@ -445,7 +458,7 @@ static int launch_layout(hipStream_t st, const TileP& p) {
         attr_set[dev] = true;
       }
       TileBigArgs g = {p.M / 320, p.N / 256};
-      hipLaunchKernelGGL((gemm_tile_big_kernel<0>), dim3((unsigned)tiles), dim3(512), lds, st, p, g);
+      hipLaunchKernelGGL((gemm_tile_big_kernel<0>), dim3((unsigned)tiles, (unsigned)p.nsplit), dim3(512), lds, st, p, g);
       hipError_t e = hipGetLastError();
       return e == hipSuccess ? 0 : (int)e;
     }

@@ -185,7 +185,8 @@ def lstm_steps_backward(ar, key, lstm, x, Bn, T, dout, G, need_dx, split3=False)
                 # [W_ih ; W_ih_reverse] back to back in the flat buffer (flat_param_order): one product with K = 8H instead of a
                 # product and an accumulating one.  (Against the transposed stack, both operands K-contiguous, the 10 240-row
                 # products gain 2-8 % and the 512-row ones of rnn_slow lose 4x: measured, dropped.)
-                ops.grad_input(dg, Wst, dinp)
+                if not ops.grad_input_slabs(ar, "%s.dxs%d" % (key, l), dg, Wst, dinp):
+                    ops.grad_input(dg, Wst, dinp)
             else:
                 ops.grad_input(dg[:, :4 * H], lstm.w("weight_ih", l, 0), dinp)
                 ops.grad_input(dg[:, 4 * H:], lstm.w("weight_ih", l, 1), dinp, accumulate=True)

@@ -351,6 +351,32 @@ def grad_input(dY, W, dX, accumulate=False, cmul=None, cmask=None):
     return mm(dY, W.view(W.shape[0], -1), dX, accumulate=accumulate, cmul=cmul, cmask=cmask)
 
 
+def grad_input_slabs(arena, key, dY, W, dX):
+    """dX[rows, In] = dY[rows, K] @ W[K, In] for outputs that are FEWER than 256 tiles of 320 x 256 (stage-1 IMU_Net training: 10 240 x
+    {512, 1024} over K = 4096): against W^T both operands are k-contiguous, and with K cut into 256 / tiles slabs the product runs on
+    gemm_tile_big_kernel, one workgroup per CU (r06: 0.85 instead of 0.52-0.63 of the fp32 peak on the 128 x 128 walk); the slabs are
+    added in order by a streaming sum.  -> False (nothing done) where the shape does not fit."""
+    rows, K = dY.shape
+    W2 = W.view(W.shape[0], -1)
+    In = W2.shape[1]
+    if (rows % 320 or In % 256 or K % 64 or W2.shape[0] != K or dY.stride(1) != 1 or not W2.is_contiguous() or not dX.is_contiguous()
+            or tuple(dX.shape) != (rows, In)):
+        return False
+    tiles = (rows // 320) * (In // 256)
+    ns = 256 // tiles if tiles < 256 else 0
+    if ns < 2 or tiles * ns != 256 or K // ns < 512:
+        return False
+    kchunk = -(-(-(-K // ns)) // 64) * 64
+    if (ns - 1) * kchunk >= K or K - (ns - 1) * kchunk < 64:
+        return False
+    WT = arena.get("%s.wT" % key, (In, K))
+    hip.call("transpose_batched", W2, WT, 1, K, In)
+    ws = arena.get("%s.ws" % key, (ns * rows * In,))
+    hip.call("gemm", dY, dY.stride(0), 1, WT, 1, K, dX, In, 1, None, rows, In, K, 1, 0, 0, 0, 0, 2, ws, ns, 0, None, None)
+    hip.call("split3_slab_sum", ws, ns, rows * In, dX)
+    return True
+
+
 def colsum(X, out, accumulate=False, out2=None, scale=None):
     """out[c] (+)= sum_r X[r, c] (* scale[c], for up to 1024 rows); out2 (optional) gets a copy of the result."""
     X = _rows(X)
