@@ -791,6 +791,33 @@ def test_topk_rows_is_the_stable_descending_sort(dev, F, N, keep):
     assert bool(torch.isnan(out2[:, 3:]).all())
 
 
+@pytest.mark.parametrize("rows,In,K", [(10240, 512, 4096), (10240, 1024, 4096), (5120, 1024, 2048), (640, 512, 4096)])
+def test_input_gradient_product_in_k_slabs_on_320x256_tiles(dev, rows, In, K):
+    """ops.grad_input_slabs (r06; stage-1 IMU_Net training's dX = dgates . W_ih in fp32): W^T + gemm_tile_big_kernel with K cut into
+    256 / tiles slabs (grid.y; the deferred split-K format) + the streaming slab sum, against float64 -- no worse than the plain product
+    of ops.grad_input; the last shape (4 tiles: 64 slabs of 64 k would be too short) must decline and leave dX alone."""
+    from mmego_amd import ops
+    g = torch.Generator().manual_seed(rows + In)
+    dY = (torch.randn(rows, K, generator=g) * 0.1).to(dev)
+    W = (torch.randn(K, In, generator=g) * 0.05).to(dev)
+    dX = torch.full((rows, In), 7.0, device=dev)
+    ar = ops.Arena(dev)
+    took = ops.grad_input_slabs(ar, "t", dY, W, dX)
+    torch.cuda.synchronize()
+    if rows == 640:
+        assert not took and bool((dX == 7.0).all())
+        return
+    assert took
+    sel = torch.tensor([0, 1, 159, 160, 319, 320, rows // 2, rows - 1], device=dev)
+    ref = dY[sel].double() @ W.double()
+    plain = torch.empty(rows, In, device=dev)
+    ops.grad_input(dY, W, plain)
+    e_slabs = float((dX[sel].double() - ref).abs().max())
+    e_plain = float((plain[sel].double() - ref).abs().max())
+    assert e_slabs <= max(1.5 * e_plain, 3e-7 * float(ref.abs().max())), (e_slabs, e_plain)
+    assert float((dX - plain).abs().max()) < 1e-4 * float(plain.abs().max())
+
+
 def test_train_upper(dev):
     from mmego_amd import nets
     g = golden("g6_train.npz")
