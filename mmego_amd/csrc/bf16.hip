@@ -1218,16 +1218,16 @@ __global__ __launch_bounds__(512) void attn_pool_frag_bf16_kernel(const bf16_t* 
     const u32x4* nb = reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(base) + sn * step_stride);
 #pragma unroll
     for (int p = 0; p < NPW; ++p) nxt[p] = nb[p * 64];
-    float hv[NPW][8];
+    // (the 64 unpacked values are NOT kept for the weighted sum below: they are unpacked again from `cur` there -- 64 more shifts / ands
+    //  per step against 64 registers; without packed-fp32 instructions (r06) the kernel had 17 spilled registers in this loop and went
+    //  from 281 to 387 us)
     float ps = 0.f;
 #pragma unroll
     for (int p = 0; p < NPW; ++p)
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
         const unsigned u = cur[p][e2];
-        hv[p][2 * e2] = __uint_as_float(u << 16);
-        hv[p][2 * e2 + 1] = __uint_as_float(u & 0xffff0000u);
-        ps += wl[p][2 * e2] * hv[p][2 * e2] + wl[p][2 * e2 + 1] * hv[p][2 * e2 + 1];
+        ps += wl[p][2 * e2] * __uint_as_float(u << 16) + wl[p][2 * e2 + 1] * __uint_as_float(u & 0xffff0000u);
       }
     ps += __shfl_xor(ps, 32);
     if (lane < 32) red[s & 1][wv][fr] = ps;
@@ -1242,7 +1242,11 @@ __global__ __launch_bounds__(512) void attn_pool_frag_bf16_kernel(const bf16_t* 
 #pragma unroll
     for (int p = 0; p < NPW; ++p)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[p][e] = acc[p][e] * scale + pe * hv[p][e];
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const unsigned u = cur[p][e2];
+        acc[p][2 * e2] = acc[p][2 * e2] * scale + pe * __uint_as_float(u << 16);
+        acc[p][2 * e2 + 1] = acc[p][2 * e2 + 1] * scale + pe * __uint_as_float(u & 0xffff0000u);
+      }
     if (attn && wv == 0 && lane < 32 && frame < Bn) attn[(long)frame * T + s] = sc;      // (raw scores; normalized below)
 #pragma unroll
     for (int p = 0; p < NPW; ++p) cur[p] = nxt[p];
