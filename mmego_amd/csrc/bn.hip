@@ -314,6 +314,36 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
 }
 
+// Long, wide tensors (r06; the gate gradients of stage-1 IMU_Net training: 10 240 rows x 2048 columns per direction -- the 16-row blocks
+// of the kernel above are 20 480 workgroups with four scalar loads per thread there: 45 us for 84 MB): 128 rows x 64 columns per
+// workgroup, a thread takes 4 consecutive columns (16-byte loads) of every 16th row, all 8 loads in flight at once.
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ X, long ldx, long rows, int C,
+                                                              float* __restrict__ partial) {
+  __shared__ f32x4 sh4[256];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = (blockIdx.y * 16 + cx) * 4;
+  const long r0 = (long)blockIdx.x * 128;
+  f32x4 v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long r = r0 + ry + 16 * u;
+    const long rc = r < rows ? r : rows - 1;                              // (clamped address: load, then select)
+    v[u] = c < C ? *reinterpret_cast<const f32x4*>(X + rc * ldx + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r >= rows) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 s4 = v[0];
+#pragma unroll
+  for (int u = 1; u < 8; ++u) s4 += v[u];
+  sh4[threadIdx.x] = s4;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    f32x4 a = sh4[cx];
+    for (int j = 1; j < 16; ++j) a += sh4[j * 16 + cx];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) partial[(long)(c + e) * gridDim.x + blockIdx.x] = a[e];       // [channel][block]
+  }
+}
+
 // Short tensors (<= 1024 rows): one block per column tile sums all rows -- one launch instead of two (a kernel boundary
 // costs more than these reductions themselves).  Same fixed summation structure on every run (deterministic).
 // seg > 0: columns [seg, C) go to outB / out2B (index c - seg): the gate gradients of both directions of a BiLSTM layer in one launch.
@@ -571,8 +601,13 @@ extern "C" int mmego_colsum(void* stream, const float* X, long ldx, long rows, i
   const long RPB = rows_per_block(rows);
   int nblk = cdiv(rows, RPB);
   MMEGO_REQUIRE(nblk <= 1024);
-  const int TC = col_tile(C);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC);
+  if (rows >= 4096 && C >= 256 && (C % 4) == 0 && (ldx % 4) == 0 && (((uintptr_t)X) & 15) == 0 && cdiv(rows, 128) <= nblk) {
+    nblk = cdiv(rows, 128);                 // (fewer blocks than the workspace was sized for)
+    hipLaunchKernelGGL(colsum_partial4_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, X, ldx, rows, C, partial_ws);
+  } else {
+    const int TC = col_tile(C);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, TC)), dim3(256), 0, st, X, ldx, rows, C, partial_ws, RPB, TC);
+  }
   MMEGO_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(64), 0, st, partial_ws, nblk, C, out, out2, accumulate);
   MMEGO_LAUNCH_CHECK();

@@ -818,6 +818,24 @@ def test_input_gradient_product_in_k_slabs_on_320x256_tiles(dev, rows, In, K):
     assert float((dX - plain).abs().max()) < 1e-4 * float(plain.abs().max())
 
 
+@pytest.mark.parametrize("rows,C,ld,off", [(10240, 2048, 4096, 2048), (4100, 260, 264, 0), (10240, 2048, 4097, 0), (5000, 200, 200, 0)])
+def test_colsum_of_long_wide_tensors(dev, rows, C, ld, off):
+    """ops.colsum on > 1024 rows: the 128 x 64 16-byte-load partial kernel (r06; aligned tensors of >= 4096 rows and >= 256 columns: the
+    first two shapes -- the second with ragged last row block and column tile) and the 16-row-block kernel (unaligned row stride; narrow)
+    against float64, with the copy in out2 and accumulation."""
+    from mmego_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    buf = torch.randn(rows, ld, generator=g).to(dev)
+    X = buf[:, off:off + C]
+    out, out2 = torch.full((C,), 3.0, device=dev), torch.zeros(C, device=dev)
+    ops.colsum(X, out, out2=out2)
+    ref = X.double().sum(0)
+    tol = 2e-6 * float(X.abs().double().sum(0).max())
+    assert float((out.double() - ref).abs().max()) < tol and torch.equal(out, out2)
+    ops.colsum(X, out, accumulate=True)
+    assert float((out.double() - 2 * ref).abs().max()) < 2 * tol
+
+
 def test_train_upper(dev):
     from mmego_amd import nets
     g = golden("g6_train.npz")
