@@ -467,6 +467,11 @@ int mmego_group_bcast(void* stream, const float* dY, long lddy, long G, int P, i
  * (and of dK, dV) in floats -- K and V may be the column halves of one [rows, 128] buffer (to_k and to_v as one stacked product). */
 int mmego_cross_attn_forward(void* stream, const float* Q, const float* K, const float* V, long F, float scale, float* O,
                              long ldo, float* P, long ldkv);
+/* The eval-mode form (r06): osum[f][0..63] (row stride ldos) = the sum over frame f's 64 queries of the attention output -- what
+ * Lower_Net.py:131-133 does with it next (gate == 1) -- added in ascending query order (the bits of mmego_group_sum2 over O); neither
+ * O nor P is stored.  Q, K, V 16-byte aligned, ldkv % 4 == 0. */
+int mmego_cross_attn_forward_pooled(void* stream, const float* Q, const float* K, const float* V, long F, float scale, float* osum,
+                                    long ldos, long ldkv);
 int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, const float* V, const float* P,
                               const float* dO, long lddo, long F, float scale, float* dQ, float* dK, float* dV, long ldkv);
 /* Gradient of einsum('nkctv,kvw->nctw') wrt A (GCN.py:62).  Writes per-block partial sums

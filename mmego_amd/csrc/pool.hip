@@ -501,10 +501,16 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
 //   O^T[channel][query] = V^T P^T: the B operand at step kk is register kk of the softmax result as it stands (key 4 g + kk), the A
 //     operand V[key 4 g + kk][16 ct + m]; result lane (query c, g), register i: channel 16 ct + 4 g + i -- one 16-byte store per tile.
 // Requires 16-byte aligned Q, K, V, O and ldkv, ldo multiples of 4 (the launcher falls back to the scalar kernel otherwise).
+// POOLED (eval forwards: nothing reads O or P but the sum over the frame's 64 queries that follows, Lower_Net.py:131-133 with gate == 1):
+// the O tiles meet in LDS and channel ch's thread adds the 64 queries in ascending order -- the order of group_sum2, so the pooled
+// vector has the bits of the two-launch form -- and only [64] floats per frame are written (O + P: 0.66 of this kernel's 1.45 GB at
+// config 5, and group_sum2 read the O half back).
+template <bool POOLED>
 __global__ __launch_bounds__(256) void cross_attn_fwd_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                                   const float* __restrict__ V, float scale,
                                                                   float* __restrict__ O, long ldo, float* __restrict__ Pout,
                                                                   long ldkv) {
+  __shared__ __attribute__((aligned(16))) float osh[POOLED ? NQ * 68 : 4];
   const long f = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -547,15 +553,29 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_mfma_kernel(const float* _
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     sv[i] *= inv;
-    if (4 * g + i < NK) Pout[qrow * NK + 4 * g + i] = sv[i];
+    if (!POOLED && 4 * g + i < NK) Pout[qrow * NK + 4 * g + i] = sv[i];
   }
-  float* op = O + qrow * ldo + 4 * g;
+  float* op = POOLED ? osh + (16 * wave + c) * 68 + 4 * g : O + qrow * ldo + 4 * g;
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[ct][kk], sv[kk], o, 0, 0, 0);
     *reinterpret_cast<f32x4*>(op + 16 * ct) = o;
+  }
+  if (POOLED) {
+    __syncthreads();
+    if (threadIdx.x < DH) {
+      float sum_o = 0.f;
+      for (int p0 = 0; p0 < NQ; p0 += 8) {             // (group_sum2_kernel's loop: 8 values fetched, added one by one in order)
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = osh[(p0 + u) * 68 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum_o += v8[u];
+      }
+      O[f * ldo + threadIdx.x] = sum_o * 1.0f;
+    }
   }
 }
 
@@ -796,8 +816,20 @@ extern "C" int mmego_cross_attn_forward(void* stream, const float* Q, const floa
                                         float* O, long ldo, float* P, long ldkv) {
   MMEGO_REQUIRE(Q && K && V && O && P && F > 0 && ldkv >= DH);
   const bool aligned = (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0 && (ldkv & 3) == 0 && (ldo & 3) == 0;
-  if (aligned) hipLaunchKernelGGL(cross_attn_fwd_mfma_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P, ldkv);
+  if (aligned) hipLaunchKernelGGL(cross_attn_fwd_mfma_kernel<false>, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P, ldkv);
   else hipLaunchKernelGGL(cross_attn_fwd_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P, ldkv);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// The eval-mode form: osum[f][0..63] (row stride ldos) = sum over frame f's 64 queries of softmax(Q K^T scale) V; neither the per-query
+// outputs nor the probabilities are stored (only backward reads them).  Needs 16-byte aligned Q, K, V and ldkv % 4 == 0.
+extern "C" int mmego_cross_attn_forward_pooled(void* stream, const float* Q, const float* K, const float* V, long F, float scale,
+                                               float* osum, long ldos, long ldkv) {
+  MMEGO_REQUIRE(Q && K && V && osum && F > 0 && ldkv >= DH && ldos >= DH);
+  MMEGO_REQUIRE((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 && (ldkv & 3) == 0);
+  hipLaunchKernelGGL(cross_attn_fwd_mfma_kernel<true>, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, osum, ldos,
+                     (float*)nullptr, ldkv);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

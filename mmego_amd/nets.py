@@ -491,8 +491,10 @@ class LowerNet(_NetBase):
         sel = ar.get("sel", (F * LOWER_POINTS, Cx))
         idx = ar.get("sel_idx", (F, LOWER_POINTS), dtype=torch.int64)
         prow = F * LOWER_POINTS
-        both = ar.get("both", (prow, 128))                      # [p_vec | cross-attention output]: p_vec is written in place
-        p_vec = both[:, :64]
+        # training: [p_vec | cross-attention output] in one buffer (p_vec is written in place; backward reads both halves).  Eval (r06):
+        # p_vec alone, contiguous -- the attention output is pooled over the points inside its own launch and never stored
+        both = ar.get("both", (prow, 128)) if training else None
+        p_vec = both[:, :64] if training else ar.get("p_vec", (prow, 64))
         # the xyz part of p_vec: in training from the selection launch itself (one launch less in a latency-bound chain); in eval mode
         # from BasePointNet's launch, next to the features of the same rows (r06: at config 5 the selection's 12 bytes into every
         # 512-byte row of a 1-GB buffer cost 150 us of isolated partial-line writes)
@@ -526,11 +528,17 @@ class LowerNet(_NetBase):
         else:
             ops.linear(k_vec, fu.to_k.weight, fu.to_k.bias, Km)
             ops.linear(k_vec, fu.to_v.weight, fu.to_v.bias, Vm)
-        Pm = ar.get("Pm", (F, LOWER_POINTS, V))
-        hip.call("cross_attn_forward", Qm, Km, Vm, F, float(fu.scale), both[:, 64:], 128, Pm, 128)
         ak = ar.get("ak", (F, 192))
-        # Q6: gate == 1 -> plain sum over the points; mean over the joints: one launch for both
-        hip.call("group_sum2", F, both, LOWER_POINTS, 128, 1.0, ak, 192, k_vec, V, 64, 1.0 / V, ak[:, 128:], 192)
+        if training:
+            Pm = ar.get("Pm", (F, LOWER_POINTS, V))
+            hip.call("cross_attn_forward", Qm, Km, Vm, F, float(fu.scale), both[:, 64:], 128, Pm, 128)
+            # Q6: gate == 1 -> plain sum over the points; mean over the joints: one launch for both
+            hip.call("group_sum2", F, both, LOWER_POINTS, 128, 1.0, ak, 192, k_vec, V, 64, 1.0 / V, ak[:, 128:], 192)
+        else:
+            # the attention output summed over the points by the attention launch (same order of addition as group_sum2: same bits),
+            # straight into its columns of ak; the p_vec half and the joints' mean as before
+            hip.call("cross_attn_forward_pooled", Qm, Km, Vm, F, float(fu.scale), ak[:, 64:], 192, 128)
+            hip.call("group_sum2", F, p_vec, LOWER_POINTS, 64, 1.0, ak, 192, k_vec, V, 64, 1.0 / V, ak[:, 128:], 192)
         lstm = fu.rnn_pk
         seq, _, _ = blocks.lstm64_forward(ar, "rnn", lstm, ak, B, T, None, None, stash, self._drop_p(lstm) if stash else 0.0,
                                           self.seed_counter())

@@ -836,6 +836,28 @@ def test_colsum_of_long_wide_tensors(dev, rows, C, ld, off):
     assert float((out.double() - 2 * ref).abs().max()) < 2 * tol
 
 
+@pytest.mark.parametrize("F", [1, 37, 1024])
+def test_pooled_cross_attention_is_the_two_launch_form_bit_for_bit(dev, F):
+    """mmego_cross_attn_forward_pooled (r06, eval forwards of Lower_Net: the attention output summed over the frame's 64 points inside
+    the attention launch, O and P never stored) against mmego_cross_attn_forward + mmego_group_sum2 over its output: the same products
+    and the same order of addition -- every bit equal; columns of the output row outside the 64 sums untouched."""
+    from mmego_amd import hip
+    g = torch.Generator().manual_seed(100 + F)
+    Q = torch.randn(F * 64, 64, generator=g).to(dev)
+    KV = torch.randn(F * 15, 128, generator=g).to(dev)
+    both = torch.zeros(F * 64, 128, device=dev)
+    P = torch.zeros(F * 64, 15, device=dev)
+    hip.call("cross_attn_forward", Q, KV, KV[:, 64:], F, 0.125, both[:, 64:], 128, P, 128)
+    ak = torch.full((F, 192), 7.0, device=dev)
+    kv = torch.zeros(F * 15, 64, device=dev)
+    hip.call("group_sum2", F, both, 64, 128, 1.0, ak, 192, kv, 15, 64, 1.0, ak[:, 128:], 192)
+    ak2 = torch.full((F, 192), 7.0, device=dev)
+    hip.call("cross_attn_forward_pooled", Q, KV, KV[:, 64:], F, 0.125, ak2[:, 64:], 192, 128)
+    torch.cuda.synchronize()
+    assert torch.equal(ak2[:, 64:128].view(torch.int32), ak[:, 64:128].view(torch.int32))
+    assert bool((ak2[:, :64] == 7.0).all()) and bool((ak2[:, 128:] == 7.0).all())
+
+
 def test_train_upper(dev):
     from mmego_amd import nets
     g = golden("g6_train.npz")
