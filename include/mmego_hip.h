@@ -472,6 +472,10 @@ int mmego_cross_attn_forward(void* stream, const float* Q, const float* K, const
  * O nor P is stored.  Q, K, V 16-byte aligned, ldkv % 4 == 0. */
 int mmego_cross_attn_forward_pooled(void* stream, const float* Q, const float* K, const float* V, long F, float scale, float* osum,
                                     long ldos, long ldkv);
+/* ... with the query projection of Lower_Net.py:100 inside: Q = X Wq^T + bq from the point features X [F * 64][ldx] (Wq [64][64], bq
+ * [64]) is computed per frame on the matrix pipe and never stored.  X, Wq, bq, K, V 16-byte aligned, ldx % 4 == 0, ldkv % 4 == 0. */
+int mmego_cross_attn_forward_pooled_q(void* stream, const float* X, long ldx, const float* Wq, const float* bq, const float* K,
+                                      const float* V, long F, float scale, float* osum, long ldos, long ldkv);
 int mmego_cross_attn_backward(void* stream, const float* Q, const float* K, const float* V, const float* P,
                               const float* dO, long lddo, long F, float scale, float* dQ, float* dK, float* dV, long ldkv);
 /* Gradient of einsum('nkctv,kvw->nctw') wrt A (GCN.py:62).  Writes per-block partial sums

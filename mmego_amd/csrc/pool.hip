@@ -505,23 +505,59 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
 // the O tiles meet in LDS and channel ch's thread adds the 64 queries in ascending order -- the order of group_sum2, so the pooled
 // vector has the bits of the two-launch form -- and only [64] floats per frame are written (O + P: 0.66 of this kernel's 1.45 GB at
 // config 5, and group_sum2 read the O half back).
-template <bool POOLED>
+// FUSEQ (with POOLED; eval forwards): the queries are computed here -- Q = X Wq^T + bq (Lower_Net.py:100: to_q on the 64-channel point
+// features, a 64 x 64 weight) -- instead of being written by a product launch and read back (2 x 537 MB at config 5): Wq sits in LDS,
+// Q^T[channel][query] = Wq X^T is one more transposed product (bias as its addend), and its result layout -- lane (query, g), tile ct,
+// register i: channel 16 ct + 4 g + i -- is used as it stands: the K operand of S^T = K Q^T simply reads the same channels (four 16-byte
+// loads 64 bytes apart instead of one 64-byte run).  Q is then `ldq` floats per row of X.
+template <bool POOLED, bool FUSEQ>
 __global__ __launch_bounds__(256) void cross_attn_fwd_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                                   const float* __restrict__ V, float scale,
                                                                   float* __restrict__ O, long ldo, float* __restrict__ Pout,
-                                                                  long ldkv) {
+                                                                  long ldkv, const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                                  long ldq, long nframes) {
   __shared__ __attribute__((aligned(16))) float osh[POOLED ? NQ * 68 : 4];
-  const long f = blockIdx.x;
+  __shared__ __attribute__((aligned(16))) float wsh[FUSEQ ? DH * 68 : 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const long qrow = f * NQ + 16 * wave + c;
-  const float* qp = Q + qrow * DH + 16 * g;
-  const float* kp = K + (f * NK + min(c, NK - 1)) * ldkv + 16 * g;          // (lane group row 15: key 14 again; masked below)
-  f32x4 qv[4], kv[4];
+  if (FUSEQ) {                                              // Wq [64][64] -> LDS rows of 68 floats, once per workgroup: 16 floats per thread
+    const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 16;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    qv[j] = *reinterpret_cast<const f32x4*>(qp + 4 * j);
-    kv[j] = *reinterpret_cast<const f32x4*>(kp + 4 * j);
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(wsh + r * 68 + c0 + 4 * j) = *reinterpret_cast<const f32x4*>(Wq + r * DH + c0 + 4 * j);
+    __syncthreads();
+  }
+  // (the FUSEQ launch is persistent -- a workgroup walks frames blockIdx.x, + gridDim.x, ... with its copy of Wq; the others have one
+  //  frame per workgroup)
+  for (long f = blockIdx.x; f < nframes; f += gridDim.x) {
+  const long qrow = f * NQ + 16 * wave + c;
+  f32x4 qv[4], kv[4];
+  if (FUSEQ) {
+    const float* xp = Q + qrow * ldq + 16 * g;              // (Q = X here: the point features)
+    f32x4 xv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xp + 4 * j);
+    const float* kp = K + (f * NK + min(c, NK - 1)) * ldkv + 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) kv[ct] = *reinterpret_cast<const f32x4*>(kp + 16 * ct);       // channels 16 ct + 4 g + i
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      f32x4 acc = *reinterpret_cast<const f32x4*>(bq + 16 * ct + 4 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wsh + (16 * ct + c) * 68 + 16 * g + 4 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[e], xv[j][e], acc, 0, 0, 0);
+      }
+      qv[ct] = acc;
+    }
+  } else {
+    const float* qp = Q + qrow * DH + 16 * g;
+    const float* kp = K + (f * NK + min(c, NK - 1)) * ldkv + 16 * g;          // (lane group row 15: key 14 again; masked below)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      qv[j] = *reinterpret_cast<const f32x4*>(qp + 4 * j);
+      kv[j] = *reinterpret_cast<const f32x4*>(kp + 4 * j);
+    }
   }
   // V^T fragments: lane (m = c, g): V[key 4 g + kk][16 ct + c]
   float vv[4][4];
@@ -576,6 +612,8 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_mfma_kernel(const float* _
       }
       O[f * ldo + threadIdx.x] = sum_o * 1.0f;
     }
+    __syncthreads();                                   // (osh is the next frame's)
+  }
   }
 }
 
@@ -816,7 +854,7 @@ extern "C" int mmego_cross_attn_forward(void* stream, const float* Q, const floa
                                         float* O, long ldo, float* P, long ldkv) {
   MMEGO_REQUIRE(Q && K && V && O && P && F > 0 && ldkv >= DH);
   const bool aligned = (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0 && (ldkv & 3) == 0 && (ldo & 3) == 0;
-  if (aligned) hipLaunchKernelGGL(cross_attn_fwd_mfma_kernel<false>, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P, ldkv);
+  if (aligned) hipLaunchKernelGGL((cross_attn_fwd_mfma_kernel<false, false>), dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P, ldkv, (const float*)nullptr, (const float*)nullptr, 0L, F);
   else hipLaunchKernelGGL(cross_attn_fwd_kernel, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, O, ldo, P, ldkv);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
@@ -828,8 +866,20 @@ extern "C" int mmego_cross_attn_forward_pooled(void* stream, const float* Q, con
                                                float* osum, long ldos, long ldkv) {
   MMEGO_REQUIRE(Q && K && V && osum && F > 0 && ldkv >= DH && ldos >= DH);
   MMEGO_REQUIRE((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 && (ldkv & 3) == 0);
-  hipLaunchKernelGGL(cross_attn_fwd_mfma_kernel<true>, dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, osum, ldos,
-                     (float*)nullptr, ldkv);
+  hipLaunchKernelGGL((cross_attn_fwd_mfma_kernel<true, false>), dim3((unsigned)F), dim3(256), 0, (hipStream_t)stream, Q, K, V, scale, osum, ldos,
+                     (float*)nullptr, ldkv, (const float*)nullptr, (const float*)nullptr, 0L, F);
+  MMEGO_LAUNCH_CHECK();
+  return MMEGO_OK;
+}
+
+// ... with the query projection inside: X [F * 64][ldx >= 64] point features, Wq [64][64], bq [64]; Q = X Wq^T + bq is never stored.
+extern "C" int mmego_cross_attn_forward_pooled_q(void* stream, const float* X, long ldx, const float* Wq, const float* bq, const float* K,
+                                                 const float* V, long F, float scale, float* osum, long ldos, long ldkv) {
+  MMEGO_REQUIRE(X && Wq && bq && K && V && osum && F > 0 && ldkv >= DH && ldos >= DH && ldx >= DH);
+  MMEGO_REQUIRE((((uintptr_t)X | (uintptr_t)Wq | (uintptr_t)bq | (uintptr_t)K | (uintptr_t)V) & 15) == 0 && (ldkv & 3) == 0 && (ldx & 3) == 0);
+  const unsigned grid = (unsigned)(F < 2048 ? F : 2048);        // 35 KB of LDS: four workgroups per CU, two rounds of them
+  hipLaunchKernelGGL((cross_attn_fwd_mfma_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, K, V, scale, osum, ldos,
+                     (float*)nullptr, ldkv, Wq, bq, ldx, F);
   MMEGO_LAUNCH_CHECK();
   return MMEGO_OK;
 }

@@ -519,9 +519,13 @@ class LowerNet(_NetBase):
         k_vec = self._gcn_forward(ar, up, B, T, training)            # [F*15, 64] in the re-viewed layout (Q8)
 
         fu = self.fusion
-        Qm, KVm = ar.get("Qm", (prow, 64)), ar.get("KVm", (F * V, 128))
+        KVm = ar.get("KVm", (F * V, 128))
         Km, Vm = KVm[:, :64], KVm[:, 64:]
-        ops.linear(p_vec, fu.to_q.weight, fu.to_q.bias, Qm)
+        Wq = fu.to_q.weight.view(64, -1)
+        fuse_q = (not training) and Wq.shape == (64, 64) and Wq.is_contiguous() and fu.to_q.bias is not None      # (eval: inside the attention launch)
+        if not fuse_q:
+            Qm = ar.get("Qm", (prow, 64))
+            ops.linear(p_vec, fu.to_q.weight, fu.to_q.bias, Qm)
         Wkv, bkv = ops.stacked(fu.to_k.weight, fu.to_v.weight), ops.stacked(fu.to_k.bias, fu.to_v.bias)
         if Wkv is not None and bkv is not None:                 # keys and values: one stacked product (flat_param_order)
             ops.linear(k_vec, Wkv, bkv, KVm)
@@ -537,7 +541,10 @@ class LowerNet(_NetBase):
         else:
             # the attention output summed over the points by the attention launch (same order of addition as group_sum2: same bits),
             # straight into its columns of ak; the p_vec half and the joints' mean as before
-            hip.call("cross_attn_forward_pooled", Qm, Km, Vm, F, float(fu.scale), ak[:, 64:], 192, 128)
+            if fuse_q:                  # ... and the queries computed there too: Q is never stored
+                hip.call("cross_attn_forward_pooled_q", p_vec, p_vec.stride(0), Wq, fu.to_q.bias, Km, Vm, F, float(fu.scale), ak[:, 64:], 192, 128)
+            else:
+                hip.call("cross_attn_forward_pooled", Qm, Km, Vm, F, float(fu.scale), ak[:, 64:], 192, 128)
             hip.call("group_sum2", F, p_vec, LOWER_POINTS, 64, 1.0, ak, 192, k_vec, V, 64, 1.0 / V, ak[:, 128:], 192)
         lstm = fu.rnn_pk
         seq, _, _ = blocks.lstm64_forward(ar, "rnn", lstm, ak, B, T, None, None, stash, self._drop_p(lstm) if stash else 0.0,

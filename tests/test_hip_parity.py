@@ -856,6 +856,18 @@ def test_pooled_cross_attention_is_the_two_launch_form_bit_for_bit(dev, F):
     torch.cuda.synchronize()
     assert torch.equal(ak2[:, 64:128].view(torch.int32), ak[:, 64:128].view(torch.int32))
     assert bool((ak2[:, :64] == 7.0).all()) and bool((ak2[:, 128:] == 7.0).all())
+    # ... and with the query projection inside (mmego_cross_attn_forward_pooled_q): Q = X Wq^T + bq never stored; against float64 and
+    # against the stored-Q form (other summation orders in two products: 2e-6 of the largest sum)
+    X = torch.randn(F * 64, 64, generator=g).to(dev)
+    Wq, bq = (torch.randn(64, 64, generator=g) * 0.2).to(dev), (torch.randn(64, generator=g) * 0.1).to(dev)
+    ak3 = torch.full((F, 192), 7.0, device=dev)
+    hip.call("cross_attn_forward_pooled_q", X, 64, Wq, bq, KV, KV[:, 64:], F, 0.125, ak3[:, 64:], 192, 128)
+    Qd = X.double().cpu() @ Wq.double().cpu().t() + bq.double().cpu()
+    Kd, Vd = KV[:, :64].double().cpu().view(F, 15, 64), KV[:, 64:].double().cpu().view(F, 15, 64)
+    want = (torch.softmax(Qd.view(F, 64, 64) @ Kd.transpose(1, 2) * 0.125, dim=-1) @ Vd).sum(dim=1)
+    torch.cuda.synchronize()
+    assert float((ak3[:, 64:128].double().cpu() - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max())) * 8
+    assert bool((ak3[:, :64] == 7.0).all()) and bool((ak3[:, 128:] == 7.0).all())
 
 
 def test_train_upper(dev):
